@@ -1,0 +1,440 @@
+"""CPU ORACLE for the IAF posterior hot path -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+A NumPy restatement (dtype-following; fp64 by default) of the reference's algorithm for
+the down_iaf2_nl / up_iaf2_nl masked-autoregressive transform and its log-det-Jacobian
+accumulation.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+import this package; the product (iaf_amd/) never does and fails loudly without its HIP
+library.
+
+Parity pinning: the reference cannot be installed here (TensorFlow/Theano absent), but its
+own Python for this path IS executed, unmodified, on a NumPy stand-in for the TF leaf ops
+(tests/golden/tf_shim.py + make_golden.py).  tests/test_oracle_golden.py checks every
+function below against those reference outputs and against the reference's known-answer
+tests (tf_utils/distributions_test.py:7-38).  The Theano-variant functions at the bottom
+have NO such pin (Python-2-only source, cuDNN-only convs): "parity unpinned" for those.
+
+Every function cites the reference file:line (relative to /root/reference) it follows.
+"""
+import math
+
+import numpy as np
+
+
+# --------------------------------------------------------------------------------------
+# a1 / a2  MADE masks
+# --------------------------------------------------------------------------------------
+def get_linear_ar_mask(n_in, n_out, zerodiagonal=False):
+    """tf_utils/layers.py:115-131 (Python-2 integer division at 120,126)."""
+    assert n_in % n_out == 0 or n_out % n_in == 0, "%d - %d" % (n_in, n_out)
+    mask = np.ones([n_in, n_out], dtype=np.float32)
+    if n_out >= n_in:
+        k = n_out // n_in
+        for i in range(n_in):
+            mask[i + 1:, i * k:(i + 1) * k] = 0
+            if zerodiagonal:
+                mask[i:i + 1, i * k:(i + 1) * k] = 0
+    else:
+        k = n_in // n_out
+        for i in range(n_out):
+            mask[(i + 1) * k:, i:i + 1] = 0
+            if zerodiagonal:
+                mask[i * k:(i + 1) * k, i:i + 1] = 0
+    return mask
+
+
+def get_conv_ar_mask(h, w, n_in, n_out, zerodiagonal=False):
+    """tf_utils/layers.py:134-141.  HWIO; rows above centre dead, centre row left of centre dead,
+    centre tap = linear MADE mask."""
+    l = (h - 1) // 2
+    m = (w - 1) // 2
+    mask = np.ones([h, w, n_in, n_out], dtype=np.float32)
+    mask[:l, :, :, :] = 0
+    mask[l, :m, :, :] = 0
+    mask[l, m, :, :] = get_linear_ar_mask(n_in, n_out, zerodiagonal)
+    return mask
+
+
+# --------------------------------------------------------------------------------------
+# a3  weight-normed (optionally masked) convolution
+# --------------------------------------------------------------------------------------
+def l2_normalize(v, axes, epsilon=1e-12):
+    """tf.nn.l2_normalize as used at layers.py:45,60: v * rsqrt(max(sum v^2, eps))."""
+    ss = np.sum(np.square(v), axis=axes, keepdims=True)
+    return v / np.sqrt(np.maximum(ss, epsilon))
+
+
+def weightnorm_weights(V, g, mask=None):
+    """layers.py:56-60: v = mask*V; w = exp(g)[o] * l2_normalize(v, [0,1,2])."""
+    v = V if mask is None else mask * V
+    return np.exp(g).reshape([1, 1, 1, -1]) * l2_normalize(v, (0, 1, 2))
+
+
+def _same_pad(n, k, s):
+    out = -(-n // s)
+    tot = max((out - 1) * s + k - n, 0)
+    return out, tot // 2, tot - tot // 2
+
+
+def conv2d_same_nchw(x, w, stride=(1, 1)):
+    """tf.nn.conv2d(x, w, [1,1,sh,sw], "SAME", data_format="NCHW") (layers.py:46,64):
+    cross-correlation, w HWIO, zero padding."""
+    n, c, hh, ww = x.shape
+    kh, kw, ci, co = w.shape
+    assert ci == c
+    sh, sw = stride
+    oh, pt, pb = _same_pad(hh, kh, sh)
+    ow, pl, pr = _same_pad(ww, kw, sw)
+    xp = np.zeros((n, c, hh + pt + pb, ww + pl + pr), dtype=np.result_type(x, w))
+    xp[:, :, pt:pt + hh, pl:pl + ww] = x
+    y = np.zeros((n, co, oh, ow), dtype=xp.dtype)
+    for a in range(kh):
+        for b in range(kw):
+            patch = xp[:, :, a:a + (oh - 1) * sh + 1:sh, b:b + (ow - 1) * sw + 1:sw]
+            # tensordot over channels: [n,c,h,w] x [c,o] -> [n,h,w,o]
+            y += np.moveaxis(np.tensordot(patch, w[a, b], axes=([1], [0])), 3, 1)
+    return y
+
+
+def conv2d(x, V, g, b, stride=(1, 1), mask=None):
+    """layers.py:52-64 (non-init branch)."""
+    w = weightnorm_weights(V, g, mask)
+    return conv2d_same_nchw(x, w, stride) + b.reshape([1, -1, 1, 1])
+
+
+def conv2d_init(x, V0, stride=(1, 1), init_scale=0.1, mask=None):
+    """layers.py:38-51 (data-dependent init branch).  Returns (y, g, b)."""
+    v = V0 if mask is None else mask * V0
+    v_norm = l2_normalize(v, (0, 1, 2))
+    x_init = conv2d_same_nchw(x, v_norm, stride)
+    m_init = x_init.mean(axis=(0, 2, 3))
+    v_init = x_init.var(axis=(0, 2, 3))
+    scale_init = init_scale / np.sqrt(v_init + 1e-10)
+    g = np.log(scale_init) / 3.0                   # layers.py:49 (sic: applied later as exp(g))
+    b = -m_init * scale_init
+    y = scale_init.reshape([1, -1, 1, 1]) * (x_init - m_init.reshape([1, -1, 1, 1]))
+    return y, g, b
+
+
+def elu(x):
+    """tf.nn.elu (layers.py:159 default nl)."""
+    return np.where(x > 0, x, np.expm1(np.minimum(x, 0)))
+
+
+# --------------------------------------------------------------------------------------
+# a4 / a5  masked AR conv stack
+# --------------------------------------------------------------------------------------
+def ar_conv2d(x, V, g, b, zerodiagonal=True):
+    """layers.py:144-154: 3x3 (filter shape taken from V), stride 1, SAME, mask = a2."""
+    kh, kw, n_in, n_out = V.shape
+    mask = get_conv_ar_mask(kh, kw, n_in, n_out, zerodiagonal)
+    return conv2d(x, V, g, b, mask=mask)
+
+
+def ar_conv2d_init(x, V0, init_scale=1.0, zerodiagonal=True):
+    """ar_conv2d under arg_scope(init=True): layers.py:152-154 -> 38-51 (init_scale default 1.)."""
+    kh, kw, n_in, n_out = V0.shape
+    mask = get_conv_ar_mask(kh, kw, n_in, n_out, zerodiagonal)
+    return conv2d_init(x, V0, init_scale=init_scale, mask=mask)
+
+
+def ar_multiconv2d(x, context, params, n_h, n_out, nl=elu):
+    """layers.py:158-166.  params: {"layer_%d/V|g|b", "layer_out_%d/V|g|b"}.
+    Returns the list of n_out raw outputs."""
+    for i, size in enumerate(n_h):
+        p = "layer_%d/" % i
+        assert params[p + "V"].shape[3] == size
+        x = ar_conv2d(x, params[p + "V"], params[p + "g"], params[p + "b"], zerodiagonal=False)
+        if i == 0:
+            x = x + context
+        x = nl(x)
+    outs = []
+    for i, size in enumerate(n_out):
+        p = "layer_out_%d/" % i
+        assert params[p + "V"].shape[3] == size
+        outs.append(ar_conv2d(x, params[p + "V"], params[p + "g"], params[p + "b"], zerodiagonal=True))
+    return outs
+
+
+def iaf_step(z, context, params, n_h):
+    """The core unit: tf_train.py:69-72.
+    m,s = 0.1*ar_multiconv2d(...); z' = (z-m)/exp(s); log-det increment = s (logqs += s).
+    Returns (z_new, arw_logsd)."""
+    n_z = z.shape[1]
+    m_raw, s_raw = ar_multiconv2d(z, context, params, n_h, [n_z, n_z])
+    arw_mean, arw_logsd = m_raw * 0.1, s_raw * 0.1
+    z_new = (z - arw_mean) / np.exp(arw_logsd)
+    return z_new, arw_logsd
+
+
+# --------------------------------------------------------------------------------------
+# a6  diagonal Gaussian
+# --------------------------------------------------------------------------------------
+def gaussian_diag_sample(mean, logvar, noise):
+    """tf_utils/distributions.py:7-8,20-21 with the noise made an explicit input."""
+    return mean + np.exp(0.5 * logvar) * noise
+
+
+def gaussian_diag_logps(mean, logvar, sample):
+    """tf_utils/distributions.py:10."""
+    return -0.5 * (np.log(2 * np.pi) + logvar + np.square(sample - mean) / np.exp(logvar))
+
+
+# --------------------------------------------------------------------------------------
+# a7 / a8  IAFLayer
+# --------------------------------------------------------------------------------------
+def split_channels(x, sizes):
+    """tf_utils/common.py:21-36 on split_dim=1."""
+    assert x.shape[1] == int(np.sum(sizes))
+    ids = np.cumsum([0] + list(sizes))
+    return [x[:, ids[i]:ids[i + 1]] for i in range(len(sizes))]
+
+
+def _sub(params, prefix):
+    n = len(prefix)
+    return {k[n:]: v for k, v in params.items() if k.startswith(prefix)}
+
+
+def iaf_layer_up(inp, params, z_size, h_size):
+    """tf_train.py:29-44, downsample=False.  Returns (output, qz_mean, qz_logsd, up_context)."""
+    p = _sub(params, "up_conv1/")
+    x = conv2d(elu(inp), p["V"], p["g"], p["b"])
+    qz_mean, qz_logsd, up_context, h = split_channels(x, [z_size, z_size, h_size, h_size])
+    p = _sub(params, "up_conv3/")
+    h = conv2d(elu(h), p["V"], p["g"], p["b"])
+    return inp + 0.1 * h, qz_mean, qz_logsd, up_context
+
+
+def posterior_block(qz_mean, qz_logsd, rz_mean, rz_logsd, pz_mean, pz_logsd, up_context, down_context,
+                    eps, ar_params, n_h, kl_min):
+    """tf_train.py:56-85 (mode == "train"): the IAF step with its log-det / KL / free-bits
+    accumulation, i.e. everything between the two out-of-scope convolutions.
+    Returns dict(z, logqs, logps, kl_obj[B], kl_cost[B], z0, arw_logsd)."""
+    prior_mean, prior_logvar = pz_mean, 2 * pz_logsd                           # :56
+    post_mean, post_logvar = rz_mean + qz_mean, 2 * (rz_logsd + qz_logsd)      # :57
+    context = up_context + down_context                                         # :58
+    z0 = gaussian_diag_sample(post_mean, post_logvar, eps)                      # :63
+    logqs = gaussian_diag_logps(post_mean, post_logvar, z0)                     # :68
+    z, arw_logsd = iaf_step(z0, context, ar_params, n_h)                        # :69-71
+    logqs = logqs + arw_logsd                                                   # :72
+    logps = gaussian_diag_logps(prior_mean, prior_logvar, z)                    # :73
+    kl = logqs - logps                                                          # :75
+    n = z.shape[0]
+    if kl_min > 0:                                                              # :77-82
+        kl_ave = np.mean(np.sum(kl, axis=(2, 3)), axis=0, keepdims=True)
+        kl_ave = np.maximum(kl_ave, kl_min)
+        kl_ave = np.tile(kl_ave, [n, 1])
+        kl_obj = np.sum(kl_ave, axis=1)
+    else:                                                                       # :84
+        kl_obj = np.sum(kl, axis=(1, 2, 3))
+    kl_cost = np.sum(kl, axis=(1, 2, 3))                                        # :85
+    return dict(z=z, logqs=logqs, logps=logps, kl_obj=kl_obj, kl_cost=kl_cost, z0=z0, arw_logsd=arw_logsd)
+
+
+def iaf_layer_down(inp, params, qz_mean, qz_logsd, up_context, eps, z_size, h_size, kl_min):
+    """tf_train.py:46-95, mode="train", downsample=False.  Returns (output, kl_obj, kl_cost, block)."""
+    p = _sub(params, "down_conv1/")
+    x = conv2d(elu(inp), p["V"], p["g"], p["b"])                                               # :52-53
+    pz_mean, pz_logsd, rz_mean, rz_logsd, down_context, h_det = split_channels(
+        x, [z_size] * 4 + [h_size] * 2)                                                        # :54
+    blk = posterior_block(qz_mean, qz_logsd, rz_mean, rz_logsd, pz_mean, pz_logsd, up_context, down_context,
+                          eps, _sub(params, "ar_multiconv2d/"), [h_size, h_size], kl_min)
+    h = elu(np.concatenate([blk["z"], h_det], axis=1))                                         # :87-88
+    p = _sub(params, "down_conv2/")
+    h = conv2d(h, p["V"], p["g"], p["b"])                                                      # :93
+    return inp + 0.1 * h, blk["kl_obj"], blk["kl_cost"], blk                                   # :94-95
+
+
+# --------------------------------------------------------------------------------------
+# a9  k-sample importance-weighted bound
+# --------------------------------------------------------------------------------------
+def logsumexp(x):
+    """tf_utils/distributions.py:35-37 (over axis 1)."""
+    x_max = np.max(x, axis=1, keepdims=True)
+    return x_max.reshape([-1]) + np.log(np.sum(np.exp(x - x_max), axis=1))
+
+
+def repeat(x, n):
+    """tf_utils/distributions.py:40-52 == np.repeat(x, n, axis=0)."""
+    if n == 1:
+        return x
+    idx = np.tile(np.arange(x.shape[0]).reshape([-1, 1]), [1, n]).reshape([-1])
+    return x[idx]
+
+
+def compute_lowerbound(log_pxz, sum_kl_costs, k=1):
+    """tf_utils/distributions.py:55-62."""
+    if k == 1:
+        return sum_kl_costs - log_pxz
+    log_pxz = np.reshape(log_pxz, [-1, k])
+    sum_kl_costs = np.reshape(sum_kl_costs, [-1, k])
+    return -(-np.log(float(k)) + logsumexp(log_pxz - sum_kl_costs))
+
+
+def streaming_lowerbound(chunks, k):
+    """Same quantity as compute_lowerbound(k>1) but consuming the k importance weights of each
+    image in chunks (online max / rescaled sum), never materialising [n, k].
+    chunks: iterable of (log_pxz - sum_kl) arrays of shape [n, k_chunk]; sum of k_chunk == k.
+    This is OUR formulation for BASELINE config 5 (k = 10^4); it must equal the reference formula."""
+    run_max = None
+    run_sum = None
+    seen = 0
+    for c in chunks:
+        c = np.asarray(c)
+        m = np.max(c, axis=1)
+        if run_max is None:
+            run_max, run_sum = m, np.sum(np.exp(c - m[:, None]), axis=1)
+        else:
+            new_max = np.maximum(run_max, m)
+            run_sum = run_sum * np.exp(run_max - new_max) + np.sum(np.exp(c - new_max[:, None]), axis=1)
+            run_max = new_max
+        seen += c.shape[1]
+    assert seen == k
+    return -(-np.log(float(k)) + run_max + np.log(run_sum))
+
+
+def discretized_logistic(mean, logscale, sample, binsize=1 / 256.0):
+    """tf_utils/distributions.py:28-32 (adjacent to the path)."""
+    scale = np.exp(logscale)
+    s = (np.floor(sample / binsize) * binsize - mean) / scale
+    sig = lambda t: 1.0 / (1.0 + np.exp(-t))
+    logp = np.log(sig(s + binsize / scale) - sig(s) + 1e-7)
+    return np.sum(logp, axis=(1, 2, 3))
+
+
+# --------------------------------------------------------------------------------------
+# a13  data-parallel gradient averaging + Adamax
+# --------------------------------------------------------------------------------------
+def average_grads(tower_grads):
+    """tf_utils/common.py:78-115, dense branch: per variable sum over towers then / N.
+    tower_grads: list over towers of lists of arrays."""
+    out = []
+    for per_var in zip(*tower_grads):
+        if len(per_var) == 1:
+            out.append(per_var[0])
+            continue
+        g = np.array(per_var[0], copy=True)
+        for t in per_var[1:]:
+            g = g + t
+        out.append(g / len(per_var))
+    return out
+
+
+def adamax_step(var, grad, slot_m, slot_v, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+    """tf_utils/adamax.py:40-56.  NB the reference's slot naming: "v" is the FIRST moment,
+    "m" the infinity norm.  Returns (var, slot_m, slot_v).  PARITY UNPINNED (class is welded to
+    TF's Optimizer base; not executable on the shim)."""
+    v_t = beta1 * slot_v + (1.0 - beta1) * grad                 # :50
+    m_t = np.maximum(beta2 * slot_m + eps, np.abs(grad))        # :52
+    return var - lr * (v_t / m_t), m_t, v_t                     # :53-55
+
+
+def ema_step(shadow, var, decay=0.999):
+    """tf.train.ExponentialMovingAverage(decay=0.999).apply (tf_train.py:157-158), no num_updates:
+    shadow -= (1 - decay) * (shadow - var)."""
+    return shadow - (1.0 - decay) * (shadow - var)
+
+
+# --------------------------------------------------------------------------------------
+# a10-a12  Theano statement of the same operator  (PARITY UNPINNED: source is Python-2-only and
+# its convs are cuDNN-only, so it can be neither imported nor executed here)
+# --------------------------------------------------------------------------------------
+def theano_ar_mask(n_in, n_out, ksize=3, zerodiagonal=True, flipmask=False, pad_channel=True):
+    """graphy/nodes/ar.py:243-264.  OIHW with the optional border-indicator input channel."""
+    _n_in = n_in + (1 if pad_channel else 0)
+    l = (ksize - 1) // 2
+    m = (ksize - 1) // 2
+    mask = np.ones((n_out, _n_in, ksize, ksize), dtype=np.float32)
+    mask[:, :, :l, :] = 0
+    mask[:, :, l, :m] = 0
+    if n_out >= n_in:
+        assert n_out % n_in == 0
+        k = n_out // n_in
+        for i in range(n_in):
+            mask[i * k:(i + 1) * k, i + 1:, l, m] = 0
+            if zerodiagonal:
+                mask[i * k:(i + 1) * k, i:i + 1, l, m] = 0
+    else:
+        assert n_in % n_out == 0
+        k = n_in // n_out
+        for i in range(n_out):
+            mask[i:i + 1, (i + 1) * k:, l, m] = 0
+            if zerodiagonal:
+                mask[i:i + 1, i * k:(i + 1) * k, l, m] = 0
+    if flipmask:
+        mask = mask[::-1, ::-1, ::-1, ::-1]
+    return mask
+
+
+def theano_pad2dwithchannel(x, ksize=3):
+    """graphy/nodes/conv.py:71-83: zero-pad H,W by (k-1)/2 and append a channel that is 1 on
+    the padding ring and 0 inside."""
+    a = (ksize - 1) // 2
+    n, c, h, w = x.shape
+    r = np.zeros((n, c + 1, h + 2 * a, w + 2 * a), dtype=x.dtype)
+    r[:, c, :, :] = 1.0
+    r[:, c, a:-a, a:-a] = 0.0
+    r[:, :c, a:-a, a:-a] = x
+    return r
+
+
+def theano_ar_conv2d(h, w_, b_, s_, n_in, n_out, zerodiagonal=True, flipmask=False):
+    """graphy/nodes/ar.py:304-330 (l2norm=True, logscale=True, pad_channel=True, 'valid').
+    w_ OIHW [n_out, n_in+1, 3, 3].  dnn_conv default conv_mode='conv' => kernel FLIPPED."""
+    ksize = w_.shape[2]
+    mask = theano_ar_mask(n_in, n_out, ksize, zerodiagonal, flipmask, True)
+    hp = theano_pad2dwithchannel(h, ksize)                                   # :309-310
+    kerns = mask * w_                                                        # :312
+    l = (ksize - 1) // 2
+    if zerodiagonal:                                                         # :268-276
+        kerns = kerns.copy()
+        if n_out >= n_in:
+            kerns[:n_out // n_in, :, l, l] = 0.0
+        else:
+            kerns[:1, :, l, l] = 0.0
+    norm = np.sqrt(np.sum(kerns ** 2, axis=(1, 2, 3), keepdims=True)) + 1e-8  # :279-281
+    kerns = kerns / norm
+    kerns = kerns * np.exp(3.0 * s_).reshape([-1, 1, 1, 1])                  # :316-317 (logscale_scale=3)
+    # true convolution, 'valid':  y[o,i,j] = sum_{c,a,b} hp[c, i+a, j+b] * kerns[o,c,K-1-a,K-1-b]
+    kf = kerns[:, :, ::-1, ::-1]
+    n, c, H, W = hp.shape
+    oh, ow = H - ksize + 1, W - ksize + 1
+    y = np.zeros((n, n_out, oh, ow), dtype=np.result_type(hp, kf))
+    for a in range(ksize):
+        for b in range(ksize):
+            y += np.moveaxis(np.tensordot(hp[:, :, a:a + oh, b:b + ow], kf[:, :, a, b], axes=([1], [1])), 3, 1)
+    return y + b_.reshape([1, -1, 1, 1])                                     # :329
+
+
+def theano_multiconv2d(h, context, w, name, n_in, n_h, n_out, flipmask=False):
+    """graphy/nodes/ar.py:378-416 with nl='elu' (graphy/nodes/__init__.py:174-175)."""
+    sizes = [n_in] + list(n_h)
+    for i in range(len(n_h)):
+        p = "%s_%d" % (name, i)
+        h = theano_ar_conv2d(h, w[p + "_w"], w[p + "_b"], w[p + "_s"], sizes[i], sizes[i + 1], False, flipmask)
+        if i == 0:
+            h = h + context
+        h = np.where(h < 0, np.exp(np.minimum(h, 0)) - 1, h)
+    out = []
+    for i in range(len(n_out)):
+        p = "%s_out_%d" % (name, i)
+        out.append(theano_ar_conv2d(h, w[p + "_w"], w[p + "_b"], w[p + "_s"], sizes[-1], n_out[i], True, flipmask))
+    return out
+
+
+def theano_iaf2_nl(z, context, w, name, n_z, n_h, flipmask=False):
+    """models.py:168-175 / 281-285: arw_mean*=.1; arw_logsd*=.1; z=(z-m)/exp(s); logps += s."""
+    arw_mean, arw_logsd = theano_multiconv2d(z, context, w, name, n_z, n_h, [n_z, n_z], flipmask)
+    arw_mean, arw_logsd = 0.1 * arw_mean, 0.1 * arw_logsd
+    return (z - arw_mean) / np.exp(arw_logsd), arw_logsd
+
+
+def theano_free_bits(kl, kl_min):
+    """models.py:455-466: per layer kl [B,Z,H,W] -> scalar objective term."""
+    kl_sum = kl.sum(axis=(1, 2, 3))
+    if kl_min > 0:
+        k = kl.sum(axis=(2, 3)).mean(axis=0)
+        return np.maximum(kl_min, k).sum(), kl_sum
+    return kl_sum, kl_sum
+
+
+LOG2PI = math.log(2 * math.pi)

@@ -1,0 +1,98 @@
+"""Deterministic synthetic inputs shared by make_golden.py (build container, runs the
+reference through tf_shim) and by the tests (which rebuild the SAME inputs and compare the
+oracle / HIP outputs with the stored reference outputs).  Only outputs are stored in the
+.npz fixtures; inputs are regenerated from (case name -> seed) with NumPy's legacy
+RandomState, whose stream is frozen across NumPy versions.
+
+TEST INFRASTRUCTURE ONLY.
+"""
+import zlib
+
+import numpy as np
+
+
+def case_seed(name):
+    return zlib.crc32(name.encode()) & 0x7FFFFFFF
+
+
+def conv_params(rng, n_in, n_out, ksize=3, g_std=0.3, b_std=0.1):
+    """Weight-normed conv variables in the reference's layout (tf_utils/layers.py:53-55):
+    V HWIO [k,k,n_in,n_out] ~ N(0,0.05^2) (layers.py:40 init std), g [n_out], b [n_out]."""
+    V = 0.05 * rng.standard_normal((ksize, ksize, n_in, n_out))
+    g = g_std * rng.standard_normal((n_out,))
+    b = b_std * rng.standard_normal((n_out,))
+    return {"V": V, "g": g, "b": b}
+
+
+def ar_multiconv2d_params(rng, n_z, n_h, n_out):
+    """Variables of ar_multiconv2d (layers.py:159-166): layer_{i} then layer_out_{i}."""
+    p = {}
+    sizes = [n_z] + list(n_h)
+    for i in range(len(n_h)):
+        for k, v in conv_params(rng, sizes[i], sizes[i + 1]).items():
+            p["layer_%d/%s" % (i, k)] = v
+    for i, size in enumerate(n_out):
+        for k, v in conv_params(rng, sizes[-1], size).items():
+            p["layer_out_%d/%s" % (i, k)] = v
+    return p
+
+
+AR_CASES = {
+    # name: (B, n_z, n_h list, H, W)
+    "ar_tiny":      (2, 4, [8, 8], 5, 5),
+    "ar_k_down":    (2, 8, [4, 4], 4, 6),       # n_h < n_z exercises the n_out<n_in mask branch
+    "ar_depth1":    (3, 8, [16], 4, 4),          # depth_ar=1 (BASELINE config 1 structure)
+    "ar_depth4":    (1, 8, [8, 8, 8, 8], 4, 4),  # depth_ar=4, n_h == n_z (config 4 structure)
+    "ar_cfg2_8x8":  (1, 32, [160, 160], 8, 8),   # BASELINE config 2 channel sizes, level 1
+    "ar_cfg1_4x4":  (2, 32, [64], 4, 4),         # BASELINE config 1 channel sizes, level 2
+}
+
+
+def ar_case_inputs(name):
+    B, n_z, n_h, H, W = AR_CASES[name]
+    rng = np.random.RandomState(case_seed(name))
+    params = ar_multiconv2d_params(rng, n_z, n_h, [n_z, n_z])
+    z = rng.standard_normal((B, n_z, H, W))
+    context = rng.standard_normal((B, n_h[0], H, W))
+    return dict(B=B, n_z=n_z, n_h=n_h, H=H, W=W, params=params, z=z, context=context)
+
+
+LAYER_CASES = {
+    # name: (B, z_size, h_size, H, W, kl_min, k)
+    "layer_tiny_fb":   (3, 4, 8, 6, 6, 0.25, 1),
+    "layer_tiny_nofb": (3, 4, 8, 6, 6, 0.0, 1),
+    "layer_k2":        (2, 4, 8, 4, 4, 0.1, 2),
+    "layer_cfg2_8x8":  (2, 32, 160, 8, 8, 0.25, 1),
+}
+
+
+def layer_case_inputs(name):
+    """Variables + inputs for one IAFLayer (tf_train.py:23-95), downsample=False."""
+    B, zs, hs, H, W, kl_min, k = LAYER_CASES[name]
+    rng = np.random.RandomState(case_seed(name))
+    p = {}
+    for kk, v in conv_params(rng, hs, 2 * zs + 2 * hs).items():
+        p["up_conv1/" + kk] = v
+    for kk, v in conv_params(rng, hs, hs).items():
+        p["up_conv3/" + kk] = v
+    for kk, v in conv_params(rng, hs, 4 * zs + 2 * hs).items():
+        p["down_conv1/" + kk] = v
+    for kk, v in ar_multiconv2d_params(rng, zs, [hs, hs], [zs, zs]).items():
+        p["ar_multiconv2d/" + kk] = v
+    for kk, v in conv_params(rng, hs + zs, hs).items():
+        p["down_conv2/" + kk] = v
+    n = B * k
+    up_input = rng.standard_normal((n, hs, H, W))
+    down_input = rng.standard_normal((n, hs, H, W))
+    eps_prior = rng.standard_normal((n, zs, H, W))       # drawn first (tf_train.py:56), unused in train mode
+    eps_post = rng.standard_normal((n, zs, H, W))        # drawn second (tf_train.py:57)
+    return dict(B=B, k=k, z_size=zs, h_size=hs, H=H, W=W, kl_min=kl_min, params=p,
+                up_input=up_input, down_input=down_input, eps_prior=eps_prior, eps_post=eps_post)
+
+
+MASK_CASES = [
+    (32, 160, False), (160, 160, False), (160, 32, True), (32, 64, False), (64, 32, True),
+    (64, 64, False), (64, 64, True), (64, 128, False), (128, 64, True), (64, 192, False),
+    (192, 64, True), (4, 8, False), (8, 4, True), (8, 8, False), (8, 8, True), (4, 4, True),
+    (8, 16, True), (16, 8, False),
+]

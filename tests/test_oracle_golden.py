@@ -1,0 +1,143 @@
+"""Pin the CPU oracle against reference outputs (tests/golden/*.npz, produced by executing the
+reference's own Python through tests/golden/tf_shim.py) and against the reference's
+known-answer tests (tf_utils/distributions_test.py:7-38).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+import golden_inputs as gi
+from oracle import iaf_oracle as O
+
+TOL = dict(rtol=1e-10, atol=1e-11)   # fp64 restatement vs fp64 reference control flow
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+# ---------------------------------------------------------------- a1 / a2
+def test_masks_match_reference(golden_dir):
+    g = _load(golden_dir, "masks")
+    for n_in, n_out, zd in gi.MASK_CASES:
+        key = "%d_%d_%d" % (n_in, n_out, int(zd))
+        np.testing.assert_array_equal(O.get_linear_ar_mask(n_in, n_out, zd), g["lin_" + key].astype(np.float32))
+        np.testing.assert_array_equal(O.get_conv_ar_mask(3, 3, n_in, n_out, zd), g["conv_" + key].astype(np.float32))
+    np.testing.assert_array_equal(O.get_conv_ar_mask(5, 5, 8, 16, False), g["conv5x5_8_16_0"].astype(np.float32))
+
+
+def test_mask_live_mac_count_config2():
+    # live MAC/pixel 23,120 + 115,280 + 2*22,960 = 184,320 of 368,640 dense (exactly 50 %)
+    live = (O.get_conv_ar_mask(3, 3, 32, 160, False).sum() + O.get_conv_ar_mask(3, 3, 160, 160, False).sum()
+            + 2 * O.get_conv_ar_mask(3, 3, 160, 32, True).sum())
+    assert int(live) == 184320
+    assert int(O.get_conv_ar_mask(3, 3, 32, 160, False).sum()) == 23120
+    assert int(O.get_conv_ar_mask(3, 3, 160, 160, False).sum()) == 115280
+    assert int(O.get_conv_ar_mask(3, 3, 160, 32, True).sum()) == 22960
+
+
+def test_mask_rejects_non_multiple():
+    with pytest.raises(AssertionError):
+        O.get_linear_ar_mask(64, 160)        # n_h=160 invalid with n_z=64
+
+
+# ---------------------------------------------------------------- a3 - a5, IAF step
+@pytest.mark.parametrize("name", sorted(gi.AR_CASES))
+def test_ar_multiconv2d_matches_reference(golden_dir, name):
+    g = _load(golden_dir, "ar_multiconv2d")
+    c = gi.ar_case_inputs(name)
+    m_raw, s_raw = O.ar_multiconv2d(c["z"], c["context"], c["params"], c["n_h"], [c["n_z"]] * 2)
+    np.testing.assert_allclose(m_raw, g[name + "/m_raw"], **TOL)
+    np.testing.assert_allclose(s_raw, g[name + "/s_raw"], **TOL)
+    z_new, logsd = O.iaf_step(c["z"], c["context"], c["params"], c["n_h"])
+    np.testing.assert_allclose(z_new, g[name + "/z_new"], **TOL)
+    np.testing.assert_allclose(logsd, g[name + "/logsd"], **TOL)
+
+
+def test_data_dependent_init_matches_reference(golden_dir):
+    g = _load(golden_dir, "init_ar_conv")
+    y, gg, b = O.ar_conv2d_init(g["x"], g["V0"], init_scale=0.7, zerodiagonal=False)
+    np.testing.assert_allclose(y, g["y"], **TOL)
+    np.testing.assert_allclose(gg, g["g"], **TOL)
+    np.testing.assert_allclose(b, g["b"], **TOL)
+
+
+# ---------------------------------------------------------------- a6 - a8 IAFLayer
+@pytest.mark.parametrize("name", sorted(gi.LAYER_CASES))
+def test_iaf_layer_matches_reference(golden_dir, name):
+    g = _load(golden_dir, "iaf_layer")
+    c = gi.layer_case_inputs(name)
+    up_out, qz_mean, qz_logsd, up_context = O.iaf_layer_up(c["up_input"], c["params"], c["z_size"], c["h_size"])
+    np.testing.assert_allclose(up_out, g[name + "/up_out"], **TOL)
+    np.testing.assert_allclose(qz_mean, g[name + "/qz_mean"], **TOL)
+    np.testing.assert_allclose(qz_logsd, g[name + "/qz_logsd"], **TOL)
+    np.testing.assert_allclose(up_context, g[name + "/up_context"], **TOL)
+    output, kl_obj, kl_cost, _ = O.iaf_layer_down(c["down_input"], c["params"], qz_mean, qz_logsd, up_context,
+                                                  c["eps_post"], c["z_size"], c["h_size"], c["kl_min"])
+    np.testing.assert_allclose(output, g[name + "/output"], **TOL)
+    np.testing.assert_allclose(kl_obj, g[name + "/kl_obj"], rtol=1e-10, atol=1e-9)
+    np.testing.assert_allclose(kl_cost, g[name + "/kl_cost"], rtol=1e-10, atol=1e-9)
+
+
+# ---------------------------------------------------------------- a6 / a9 distributions
+def test_distributions_match_reference(golden_dir):
+    g = _load(golden_dir, "distributions")
+    s = O.gaussian_diag_sample(g["mean"], g["logvar"], g["eps"])
+    np.testing.assert_allclose(s, g["sample"], **TOL)
+    np.testing.assert_allclose(O.gaussian_diag_logps(g["mean"], g["logvar"], s), g["logps_self"], **TOL)
+    np.testing.assert_allclose(O.gaussian_diag_logps(g["mean"], g["logvar"], g["other"]), g["logps_other"], **TOL)
+    np.testing.assert_allclose(O.gaussian_diag_logps(g["mean"], g["logvar"], g["other"]), g["logps_fn"], **TOL)
+    np.testing.assert_allclose(O.logsumexp(g["lse_x"]), g["lse"], **TOL)
+    for k in (1, 4, 12):
+        np.testing.assert_allclose(O.compute_lowerbound(g["lb_log_pxz"], g["lb_kl"], k), g["lb_k%d" % k], **TOL)
+    np.testing.assert_array_equal(O.repeat(g["rep_x"], 3), g["rep_3"])
+    np.testing.assert_allclose(O.discretized_logistic(g["dl_mean"], -1.3, g["dl_sample"]), g["dl_logp"], **TOL)
+
+
+def test_reference_known_answer_tests(golden_dir):
+    """tf_utils/distributions_test.py:7-38, expected values recomputed the way the test does."""
+    g = _load(golden_dir, "distributions")
+    a10 = np.arange(10.0)
+    res = np.log(np.sum(np.exp(a10)))                                         # :9
+    assert abs(O.logsumexp(a10.reshape([1, -1]))[0] - res) < 1e-12             # :12-13
+    assert abs(g["kat_lse_arange10"][0] - res) < 1e-12
+    a = np.log(np.array([0.3, 0.3, 0.3, 0.3])).reshape([1, -1])
+    b = np.log(np.array([0.1, 0.5, 0.9, 0.6])).reshape([1, -1])
+    res = -(-np.log(4) + np.log(np.sum(np.exp(a - b))))                       # :19
+    assert abs(np.sum(O.compute_lowerbound(a, b, 4)) - res) < 1e-4             # :21-22 (places=4)
+    assert abs(np.sum(g["kat_lb_k4"]) - res) < 1e-4
+    res = (b - a).sum()                                                       # :28
+    assert abs(np.sum(O.compute_lowerbound(a.reshape([-1, 1]), b.reshape([-1, 1]), 1)) - res) < 1e-4   # :30-31
+    assert abs(np.sum(g["kat_lb_k1"]) - res) < 1e-4
+    x = np.random.RandomState(0).randn(10, 5, 2)
+    np.testing.assert_allclose(O.repeat(x, 2), np.repeat(x, 2, axis=0))       # :33-38
+
+
+def test_streaming_lowerbound_equals_reference_formula():
+    rng = np.random.RandomState(3)
+    n, k = 7, 1000
+    w = -40 + 6 * rng.standard_normal((n, k))
+    ref = O.compute_lowerbound(w.reshape(-1), np.zeros(n * k), k)
+    chunks = [w[:, i:i + 64] for i in range(0, k, 64)]
+    np.testing.assert_allclose(O.streaming_lowerbound(chunks, k), ref, rtol=1e-12, atol=1e-12)
+
+
+# ---------------------------------------------------------------- a13
+def test_split_and_average_grads_match_reference(golden_dir):
+    g = _load(golden_dir, "common")
+    parts = O.split_channels(g["split_x"], [2, 2, 4, 4])
+    for i, p in enumerate(parts):
+        np.testing.assert_array_equal(p, g["split_%d" % i])
+    towers = [[g["tower%d_g%d" % (t, i)] for i in range(3)] for t in range(4)]
+    avg = O.average_grads(towers)
+    for i in range(3):
+        np.testing.assert_allclose(avg[i], g["avg_g%d" % i], rtol=1e-13, atol=1e-15)
+
+
+def test_adamax_slot_semantics():
+    # adamax.py:49-55: "v" first moment, "m" infinity norm
+    var, grad = np.array([1.0, -2.0]), np.array([0.5, -0.25])
+    v1, m1, vv1 = O.adamax_step(var, grad, np.zeros(2), np.zeros(2), lr=0.01)
+    np.testing.assert_allclose(vv1, 0.1 * grad)
+    np.testing.assert_allclose(m1, np.abs(grad))
+    np.testing.assert_allclose(v1, var - 0.01 * 0.1 * np.sign(grad))
