@@ -1,0 +1,264 @@
+#!/usr/bin/env python3
+"""bench.py -- IAF-step throughput of the MI355X engine on BASELINE.json's configs[1].
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (config.workload): "cifar10 n_z=32 n_h=160 depths=[10,10] depth_ar=2 down_iaf2_nl bs=32":
+one STEP = one pass of the IAF hot path (weight prep + ar_multiconv2d + affine transform +
+log-det term, tf_train.py:69-72) over one synthetic batch of 32 through the model's layer schedule:
+10 IAF layers on [32,32,16,16] latents and 10 on [32,32,8,8], each layer with its own weights,
+z and context (seeded N(0,1) data, random-init weights; inputs resident in HBM).
+value = samples/s through the whole IAF stack = N_gpus * 32 / t_step  (weak scaling: each rank
+runs its own batch of 32; the forward path has no collective).
+
+The timed region replays a hipGraph of the step (80 launches); right after it the same step runs
+eagerly with HIP events bracketing every launch of the dominant kernel (the 160->160 masked conv
+at 16x16) to get that kernel's average launch duration for the roofline object.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE config 2: 32)")
+    ap.add_argument("--n-z", type=int, default=32)
+    ap.add_argument("--n-h", type=int, default=160)
+    ap.add_argument("--depth-ar", type=int, default=2)
+    ap.add_argument("--depths", type=str, default="10,10")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--cached-weights", action="store_true",
+                    help="prepare weights once outside the timed region (inference with frozen weights); "
+                         "default re-derives mask*V / weight-norm every step like the reference graph does")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (rank 0, N=1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tune", type=str, default="", help="layer:nt,pxt,wco,ks;... launch-shape override")
+    return ap.parse_args()
+
+
+def make_layer_inputs(rng, B, n_z, n_h, depth_ar, H):
+    import golden_inputs as gi
+    params = gi.ar_multiconv2d_params(rng, n_z, [n_h] * depth_ar, [n_z, n_z])
+    # SURVEY 8d synthetic inputs: V~N(0,.05^2), g,b~N(0,.1^2), z,context~N(0,1)
+    for k in params:
+        if k.endswith("/g") or k.endswith("/b"):
+            params[k] = 0.1 * rng.standard_normal(params[k].shape)
+    z = rng.standard_normal((B, n_z, H, H))
+    ctx = rng.standard_normal((B, n_h, H, H))
+    return params, z, ctx
+
+
+def cpu_baseline(args, depths):
+    """torch-CPU fp32 port (oracle/iaf_cpu_port.py) on a bounded sample of the same workload."""
+    from oracle import iaf_cpu_port as Pt
+    nthreads = os.cpu_count() or 1
+    torch.set_num_threads(nthreads)
+    rng = np.random.RandomState(1)
+    per_level = []
+    budget = args.cpu_seconds / max(len(depths), 1)
+    for lvl, _ in enumerate(depths):
+        H = 16 >> lvl
+        params, z, ctx = make_layer_inputs(rng, args.batch, args.n_z, args.n_h, args.depth_ar, H)
+        tp = Pt.as_torch(params)
+        zt, ct = torch.from_numpy(z.astype(np.float32)), torch.from_numpy(ctx.astype(np.float32))
+
+        def one():
+            w = tp_w if args.cached_weights else Pt.prepare_weights(tp, args.n_z, [args.n_h] * args.depth_ar)
+            return Pt.iaf_step(zt, ct, w, args.depth_ar)
+
+        tp_w = Pt.prepare_weights(tp, args.n_z, [args.n_h] * args.depth_ar)
+        with torch.no_grad():
+            for _ in range(3):
+                one()
+            ts = []
+            t_end = time.perf_counter() + budget
+            while time.perf_counter() < t_end or len(ts) < 5:
+                t0 = time.perf_counter()
+                one()
+                ts.append(time.perf_counter() - t0)
+        per_level.append(float(np.median(ts)))
+    t_model = sum(d * t for d, t in zip(depths, per_level))
+    return {
+        "value": args.batch / t_model, "unit": "samples/s", "cores": nthreads, "kind": "port",
+        "sample": "torch-CPU fp32 port of the same IAF step (oracle/iaf_cpu_port.py), B=%d: median of repeated single "
+                  "IAF steps per level (%s ms at %s), ~%.0f s total, scaled to the depths=%s schedule; the reference has "
+                  "no CPU path (SURVEY D1)" % (args.batch, ",".join("%.2f" % (1e3 * t) for t in per_level),
+                                              ",".join("%dx%d" % (16 >> i, 16 >> i) for i in range(len(depths))),
+                                              args.cpu_seconds, depths),
+        "ms_per_iaf_step": [1e3 * t for t in per_level],
+    }
+
+
+def main():
+    args = parse()
+    depths = [int(d) for d in args.depths.split(",") if d]
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+    if args.gpus != world and rank == 0 and world > 1:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    n_gpus = world
+
+    import iaf_amd
+    iaf_amd._capi.lib()           # fail loudly if the HIP engine is not built
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+    # ---------------- build the layer schedule (every rank its own data: seed + rank)
+    rng = np.random.RandomState(1234 + rank)
+    layers = []
+    for lvl, nlayer in enumerate(depths):
+        H = 16 >> lvl
+        for _ in range(nlayer):
+            params, z, ctx = make_layer_inputs(rng, args.batch, args.n_z, args.n_h, args.depth_ar, H)
+            st = iaf_amd.ARStack(args.n_z, [args.n_h] * args.depth_ar)
+            dp = {k: dev(v) for k, v in params.items()}
+            zd, cd = dev(z), dev(ctx)
+            out = (torch.empty_like(zd), torch.empty_like(zd))
+            st.prepare(dp)
+            layers.append(dict(stack=st, params=dp, z=zd, ctx=cd, out=out, H=H))
+    if args.tune:
+        for item in args.tune.split(";"):
+            lay, shp = item.split(":")
+            nt, pxt, wco, ks = [int(v) for v in shp.split(",")]
+            for L in layers:
+                L["stack"].set_tuning(int(lay), nt, pxt, wco, ks)
+
+    def step():
+        for L in layers:
+            if not args.cached_weights:
+                L["stack"].prepare(L["params"], force=True)     # mask*V, l2-normalise, exp(g) (layers.py:56-60)
+            L["stack"].iaf_step(L["z"], L["ctx"] if args.depth_ar > 0 else None, out=L["out"])
+
+    stream = torch.cuda.Stream()
+    graph = None
+    with torch.cuda.stream(stream):
+        step()                                                   # allocate workspaces, warm caches
+        stream.synchronize()
+        if not args.no_graph:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                step()
+        run = graph.replay if graph is not None else step
+
+        def barrier():
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        for _ in range(args.warmup):
+            run()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run()
+        barrier()
+        elapsed = time.perf_counter() - t0
+
+        # ---------------- kernel leg: eager steps, HIP events around every launch of the dominant kernel
+        dom_layer = max(args.depth_ar - 1, 0)                    # the n_h -> n_h masked conv (layer 1 at depth_ar=2)
+        prof = [L for L in layers if L["H"] == 16]
+        ksteps = max(10, min(args.steps, 50))
+        for L in prof:
+            L["stack"].profile_enable(dom_layer, ksteps + 4)
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        for L in prof:
+            L["stack"].profile_read()
+        for _ in range(ksteps):
+            step()
+        torch.cuda.synchronize()
+        kms = []
+        for L in prof:
+            kms += L["stack"].profile_read()
+            L["stack"].profile_enable(-1, 0)
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = n_gpus * args.batch / (elapsed / args.steps)
+    n_iaf = sum(depths)
+
+    st0 = prof[0]["stack"]
+    lw = st0.layer_work(dom_layer, args.batch, 16, 16)
+    k_avg_ms = float(np.mean(kms)) if kms else float("nan")
+    achieved = lw["live_flops"] / (k_avg_ms * 1e-3) / 1e12
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_dominant_kernel.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {
+        "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+        "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+        "kernel": "iaf_conv_kernel (masked 3x3 conv %d->%d, B=%d 16x16, GEMM layer %d)" % (args.n_h, args.n_h, args.batch, dom_layer),
+        "avg_launch_us": 1e3 * k_avg_ms, "launches_timed": len(kms),
+        "flops_per_launch_live": lw["live_flops"], "flops_per_launch_dense9tap": lw["dense_flops"],
+        "bytes_per_launch": lw["bytes"],
+        "hbm_frac_at_this_rate": (lw["bytes"] / (k_avg_ms * 1e-3) / 1e9) / PEAK_HBM_GBS,
+    }
+    work16 = st0.step_work(args.batch, 16, 16)
+    out = {
+        "metric": "IAF-step samples/sec (down_iaf2_nl posterior stack, forward + log-det)",
+        "value": value, "unit": "samples/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": "cifar10 n_z=%d n_h=%d depths=%s depth_ar=%d down_iaf2_nl bs=%d per GPU (BASELINE configs[1]); "
+                        "one step = %d IAF steps: %s" % (args.n_z, args.n_h, depths, args.depth_ar, args.batch, n_iaf,
+                                                        " + ".join("%d x [%d,%d,%d,%d]" % (d, args.batch, args.n_z, 16 >> i, 16 >> i)
+                                                                   for i, d in enumerate(depths))),
+            "global_batch": n_gpus * args.batch, "iaf_steps_per_step": n_iaf,
+            "iaf_step_samples_per_s": value * n_iaf,
+            "weights": "re-derived every step (mask, l2-norm, exp(g))" if not args.cached_weights else "prepared once",
+            "launch": "hipGraph replay" if graph is not None else "eager",
+            "parallelism": "dp%d (batch-sharded replicas, no forward collective)" % n_gpus,
+            "live_gflop_per_iaf_step_16x16": work16["live_flops"] / 1e9,
+        },
+        "roofline": roofline,
+    }
+    if n_gpus == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, depths)
+        out["config"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,90 @@
+"""ctypes binding of the C ABI in include/iaf_hip.h (built by iaf_amd/build.py into
+iaf_amd/_lib/libiaf_hip.so).  There is NO CPU fallback: if the library is missing or a call
+fails, this module raises."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "libiaf_hip.so")
+
+IAF_OK = 0
+IAF_ERR_NULL = -1
+IAF_ERR_SHAPE = -2
+IAF_ERR_NOT_MULTIPLE = -3
+IAF_ERR_NOT_PREPARED = -4
+IAF_ERR_WORKSPACE = -5
+IAF_ERR_UNSUPPORTED = -6
+IAF_VARIANT_TF = 0
+
+_c_float_p = ctypes.c_void_p      # device pointers travel as integers (tensor.data_ptr())
+_vp = ctypes.c_void_p
+
+# name -> (restype, argtypes); must list every symbol include/iaf_hip.h declares
+SIGNATURES = {
+    "iaf_abi_version": (ctypes.c_int, []),
+    "iaf_error_string": (ctypes.c_char_p, [ctypes.c_int]),
+    "iaf_device_count": (ctypes.c_int, []),
+    "iaf_stack_create": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "iaf_stack_destroy": (ctypes.c_int, [_vp]),
+    "iaf_stack_prepare": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp]),
+    "iaf_stack_workspace_bytes": (ctypes.c_size_t, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "iaf_ar_multiconv2d_forward": (ctypes.c_int, [_vp, _c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_int,
+                                                  ctypes.c_int, ctypes.c_int, _vp, ctypes.c_size_t, _vp]),
+    "iaf_step_forward": (ctypes.c_int, [_vp, _c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_int,
+                                        ctypes.c_int, ctypes.c_int, _vp, ctypes.c_size_t, _vp]),
+    "iaf_posterior_block_forward": (ctypes.c_int, [_vp] + [_c_float_p] * 9 + [ctypes.c_float] + [_c_float_p] * 4 +
+                                    [ctypes.c_int] * 3 + [_vp, ctypes.c_size_t, _vp]),
+    "iaf_gaussian_sample": (ctypes.c_int, [_c_float_p] * 4 + [ctypes.c_size_t, _vp]),
+    "iaf_gaussian_logps": (ctypes.c_int, [_c_float_p] * 4 + [ctypes.c_size_t, _vp]),
+    "iaf_compute_lowerbound": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int, ctypes.c_int, _vp]),
+    "iaf_lowerbound_stream_init": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_int, _vp]),
+    "iaf_lowerbound_stream_update": (ctypes.c_int, [_c_float_p] * 4 + [ctypes.c_int, ctypes.c_int, _vp]),
+    "iaf_lowerbound_stream_finalize": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int, ctypes.c_int, _vp]),
+    "iaf_stack_set_tuning": (ctypes.c_int, [_vp] + [ctypes.c_int] * 5),
+    "iaf_stack_profile_enable": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
+    "iaf_stack_profile_read": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float), ctypes.c_int,
+                                              ctypes.POINTER(ctypes.c_int)]),
+    "iaf_layer_work": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int] +
+                       [ctypes.POINTER(ctypes.c_double)] * 3),
+    "iaf_step_work": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int] + [ctypes.POINTER(ctypes.c_double)] * 3),
+}
+
+
+class IafHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the shared library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise IafHipError("HIP engine not built: %s is missing (run `python -c 'import __graft_entry__ as g; "
+                              "g.build()'` or `python -m iaf_amd.build`). There is no CPU fallback." % LIB_PATH)
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)          # AttributeError here = header/library mismatch
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def error_string(code):
+    return lib().iaf_error_string(int(code)).decode()
+
+
+def check(code):
+    """Map a status to the exception kind the reference raises for the same condition
+    (SURVEY 8b "Errors"): its channel-divisibility asserts -> AssertionError, other bad
+    arguments -> ValueError, device errors -> IafHipError."""
+    if code == IAF_OK:
+        return
+    msg = "iaf_hip: %s (status %d)" % (error_string(code), code)
+    if code == IAF_ERR_NOT_MULTIPLE:
+        raise AssertionError(msg)          # tf_utils/layers.py:116
+    if code in (IAF_ERR_NULL, IAF_ERR_SHAPE, IAF_ERR_WORKSPACE, IAF_ERR_UNSUPPORTED):
+        raise ValueError(msg)
+    raise IafHipError(msg)

@@ -1,0 +1,280 @@
+"""Host-side mirror of the reference's operator interface for the hot path
+(tf_utils/layers.py:115-166): same names, argument meaning and error behaviour; the arithmetic is
+done by the HIP engine through the C ABI.  PyTorch tensors are device storage only.
+
+Variable naming follows the reference's TF scopes so that a weight loader written for it works:
+    <scope>/<name>/layer_{i}/{V,g,b}   and   <scope>/<name>/layer_out_{i}/{V,g,b}
+with V in HWIO [3,3,n_in,n_out] fp32 (layers.py:35,53-55).
+"""
+import contextlib
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _capi
+
+
+# ---------------------------------------------------------------------------------------------
+# masks (host, build time).  Closed forms of the loops at layers.py:115-141.
+# ---------------------------------------------------------------------------------------------
+def get_linear_ar_mask(n_in, n_out, zerodiagonal=False):
+    """Channel MADE mask [n_in, n_out] float32 (tf_utils/layers.py:115-131).
+    n_out >= n_in (k = n_out//n_in): output o belongs to group o//k and sees inputs <= group
+    (< group if zerodiagonal).  n_out < n_in (k = n_in//n_out): output o sees inputs < (o+1)*k
+    (< o*k if zerodiagonal)."""
+    assert n_in % n_out == 0 or n_out % n_in == 0, "%d - %d" % (n_in, n_out)
+    i = np.arange(n_in).reshape(-1, 1)
+    o = np.arange(n_out).reshape(1, -1)
+    if n_out >= n_in:
+        grp = o // (n_out // n_in)
+        live = (i < grp) if zerodiagonal else (i <= grp)
+    else:
+        k = n_in // n_out
+        live = (i < o * k) if zerodiagonal else (i < (o + 1) * k)
+    return live.astype(np.float32)
+
+
+def get_conv_ar_mask(h, w, n_in, n_out, zerodiagonal=False):
+    """Conv MADE mask [h, w, n_in, n_out] float32 (tf_utils/layers.py:134-141): taps above the
+    centre row and left of the centre in the centre row are dead, the centre tap is the channel
+    mask, everything after is full."""
+    l, m = (h - 1) // 2, (w - 1) // 2
+    mask = np.zeros([h, w, n_in, n_out], dtype=np.float32)
+    mask[l, m + 1:] = 1.0
+    mask[l + 1:] = 1.0
+    mask[l, m] = get_linear_ar_mask(n_in, n_out, zerodiagonal)
+    return mask
+
+
+# ---------------------------------------------------------------------------------------------
+# variable store with TF-style scopes
+# ---------------------------------------------------------------------------------------------
+class VariableStore(object):
+    """name -> torch tensor, addressed through nested variable_scope()s like tf.get_variable."""
+
+    def __init__(self):
+        self.vars = {}
+        self._scope = []
+        self._stacks = {}
+
+    def full_name(self, name):
+        return "/".join(self._scope + [name])
+
+    def get(self, name):
+        full = self.full_name(name)
+        if full not in self.vars:
+            raise KeyError("variable %r not in store" % full)
+        return self.vars[full]
+
+    def set(self, full_name, tensor):
+        self.vars[full_name] = tensor
+
+
+_DEFAULT_STORE = VariableStore()
+
+
+def default_store():
+    return _DEFAULT_STORE
+
+
+@contextlib.contextmanager
+def variable_scope(name, store=None):
+    st = store or _DEFAULT_STORE
+    st._scope.append(name)
+    try:
+        yield st
+    finally:
+        st._scope.pop()
+
+
+# ---------------------------------------------------------------------------------------------
+# the engine-backed operator
+# ---------------------------------------------------------------------------------------------
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _check_act(t, name, shape=None):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise ValueError("%s must be a contiguous float32 CUDA tensor (NCHW)" % name)
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError("%s has shape %s, expected %s" % (name, tuple(t.shape), tuple(shape)))
+
+
+class ARStack(object):
+    """One ar_multiconv2d variable set bound to an engine handle (iaf_stack_t).
+
+    n_h: list of hidden sizes (the reference passes [h_size, h_size], tf_train.py:69, or
+    depth_ar*[n_h2], models.py:92) -- all equal; n_out must be [n_z, n_z]."""
+
+    def __init__(self, n_z, n_h, n_out=None, variant=_capi.IAF_VARIANT_TF):
+        n_h = list(n_h)
+        n_out = [n_z, n_z] if n_out is None else list(n_out)
+        sizes = [n_z] + n_h
+        for a, b in zip(sizes[:-1], sizes[1:]):
+            assert a % b == 0 or b % a == 0, "%d - %d" % (a, b)          # layers.py:116
+        for o in n_out:
+            assert sizes[-1] % o == 0 or o % sizes[-1] == 0, "%d - %d" % (sizes[-1], o)
+        if len(set(n_h)) > 1:
+            raise ValueError("the gfx950 engine needs equal hidden sizes, got %r" % (n_h,))
+        if n_out != [n_z, n_z]:
+            raise ValueError("the gfx950 engine implements the (mean, logsd) output pair n_out=[n_z, n_z]")
+        self.n_z, self.n_h_list, self.depth_ar = int(n_z), n_h, len(n_h)
+        self.n_h = int(n_h[0]) if n_h else int(n_z)
+        self._h = ctypes.c_void_p()
+        _capi.check(_capi.lib().iaf_stack_create(ctypes.byref(self._h), self.n_z, self.n_h, self.depth_ar, variant))
+        self._ws = None
+        self._prep_key = None
+        self._keepalive = None
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                _capi.lib().iaf_stack_destroy(h)
+            except Exception:
+                pass
+
+    # -- weights -------------------------------------------------------------------------------
+    def conv_names(self):
+        return ["layer_%d" % i for i in range(self.depth_ar)] + ["layer_out_0", "layer_out_1"]
+
+    def prepare(self, params, force=False):
+        """params: {"layer_0/V": tensor, "layer_0/g": ..., "layer_out_1/b": ...} (device fp32).
+        Re-derives masked weight-normed weights on the GPU (layers.py:56-60); cached until a tensor
+        is replaced or modified in place."""
+        names = self.conv_names()
+        sizes = [self.n_z] + self.n_h_list
+        tens = []
+        for ci, nm in enumerate(names):
+            n_in = sizes[min(ci, self.depth_ar)]
+            n_out = sizes[ci + 1] if ci < self.depth_ar else self.n_z
+            V, g, b = params[nm + "/V"], params[nm + "/g"], params[nm + "/b"]
+            _check_act(V, nm + "/V", (3, 3, n_in, n_out))
+            _check_act(g, nm + "/g", (n_out,))
+            _check_act(b, nm + "/b", (n_out,))
+            tens += [V, g, b]
+        key = tuple((t.data_ptr(), t._version) for t in tens)
+        if not force and key == self._prep_key:
+            return
+        n = len(names)
+        arr = ctypes.c_void_p * n
+        Vp = arr(*[t.data_ptr() for t in tens[0::3]])
+        gp = arr(*[t.data_ptr() for t in tens[1::3]])
+        bp = arr(*[t.data_ptr() for t in tens[2::3]])
+        _capi.check(_capi.lib().iaf_stack_prepare(self._h, Vp, gp, bp, _stream()))
+        self._prep_key, self._keepalive = key, tens
+
+    # -- workspace -----------------------------------------------------------------------------
+    def workspace(self, B, H, W, device):
+        need = int(_capi.lib().iaf_stack_workspace_bytes(self._h, B, H, W))
+        if self._ws is None or self._ws.numel() < need or self._ws.device != device:
+            self._ws = torch.empty(max(need, 256), dtype=torch.uint8, device=device)
+        return self._ws, need
+
+    def set_tuning(self, layer, nt, pxt, wco, ks):
+        _capi.check(_capi.lib().iaf_stack_set_tuning(self._h, layer, nt, pxt, wco, ks))
+
+    def step_work(self, B, H, W):
+        a, b, c = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        _capi.check(_capi.lib().iaf_step_work(self._h, B, H, W, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return dict(live_flops=a.value, dense_flops=b.value, bytes=c.value)
+
+    def layer_work(self, layer, B, H, W):
+        a, b, c = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        _capi.check(_capi.lib().iaf_layer_work(self._h, layer, B, H, W, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return dict(live_flops=a.value, dense_flops=b.value, bytes=c.value)
+
+    def profile_enable(self, layer, max_samples=4096):
+        """bracket every launch of GEMM layer `layer` with HIP events on the launch stream"""
+        _capi.check(_capi.lib().iaf_stack_profile_enable(self._h, layer, max_samples))
+        self._prof_cap = max_samples
+
+    def profile_read(self):
+        cap = getattr(self, "_prof_cap", 0)
+        buf = (ctypes.c_float * max(cap, 1))()
+        n = ctypes.c_int()
+        _capi.check(_capi.lib().iaf_stack_profile_read(self._h, buf, cap, ctypes.byref(n)))
+        return [buf[i] for i in range(n.value)]
+
+    # -- forward -------------------------------------------------------------------------------
+    def _dims(self, z, context):
+        _check_act(z, "z")
+        if z.dim() != 4 or z.shape[1] != self.n_z:
+            raise ValueError("z must be [B, %d, H, W], got %s" % (self.n_z, tuple(z.shape)))
+        B, _, H, W = z.shape
+        if self.depth_ar > 0:
+            _check_act(context, "context", (B, self.n_h, H, W))
+        return int(B), int(H), int(W)
+
+    def ar_multiconv2d(self, z, context, out=None):
+        """layers.py:158-166 -> [m_raw, s_raw]."""
+        B, H, W = self._dims(z, context)
+        m_raw, s_raw = out if out is not None else (torch.empty_like(z), torch.empty_like(z))
+        ws, need = self.workspace(B, H, W, z.device)
+        _capi.check(_capi.lib().iaf_ar_multiconv2d_forward(self._h, _ptr(z), _ptr(context), _ptr(m_raw), _ptr(s_raw),
+                                                           B, H, W, _ptr(ws), need, _stream()))
+        return [m_raw, s_raw]
+
+    def iaf_step(self, z, context, out=None):
+        """tf_train.py:69-72 -> (z_new, logsd);  logqs += logsd is the log-det accumulation."""
+        B, H, W = self._dims(z, context)
+        z_new, logsd = out if out is not None else (torch.empty_like(z), torch.empty_like(z))
+        ws, need = self.workspace(B, H, W, z.device)
+        _capi.check(_capi.lib().iaf_step_forward(self._h, _ptr(z), _ptr(context), _ptr(z_new), _ptr(logsd),
+                                                 B, H, W, _ptr(ws), need, _stream()))
+        return z_new, logsd
+
+    def posterior_block(self, qz_mean, qz_logsd, rz_mean, rz_logsd, pz_mean, pz_logsd, up_context, down_context, eps,
+                        kl_min, want_kl_elem=False):
+        """tf_train.py:56-85 (mode "train") -> dict(z, kl_obj[B], kl_cost[B] [, kl_elem])."""
+        B, H, W = self._dims(qz_mean, up_context)
+        for nm, t in (("qz_logsd", qz_logsd), ("rz_mean", rz_mean), ("rz_logsd", rz_logsd), ("pz_mean", pz_mean),
+                      ("pz_logsd", pz_logsd), ("eps", eps)):
+            _check_act(t, nm, qz_mean.shape)
+        if self.depth_ar > 0:
+            _check_act(down_context, "down_context", up_context.shape)
+        z = torch.empty_like(qz_mean)
+        kl_obj = torch.empty(B, dtype=torch.float32, device=z.device)
+        kl_cost = torch.empty_like(kl_obj)
+        kl_elem = torch.empty_like(qz_mean) if want_kl_elem else None
+        ws, need = self.workspace(B, H, W, z.device)
+        _capi.check(_capi.lib().iaf_posterior_block_forward(
+            self._h, _ptr(qz_mean), _ptr(qz_logsd), _ptr(rz_mean), _ptr(rz_logsd), _ptr(pz_mean), _ptr(pz_logsd),
+            _ptr(up_context), _ptr(down_context), _ptr(eps), float(kl_min), _ptr(z), _ptr(kl_obj), _ptr(kl_cost),
+            _ptr(kl_elem), B, H, W, _ptr(ws), need, _stream()))
+        out = dict(z=z, kl_obj=kl_obj, kl_cost=kl_cost)
+        if want_kl_elem:
+            out["kl_elem"] = kl_elem
+        return out
+
+
+def _is_elu(nl):
+    return nl in ("elu", None) or getattr(nl, "__name__", "") == "elu"
+
+
+def ar_multiconv2d(name, x, context, n_h, n_out, nl="elu", store=None, **_):
+    """Drop-in for tf_utils/layers.py:158-166 (call site tf_train.py:69):
+        x = ar_multiconv2d("ar_multiconv2d", z, context, [h_size, h_size], [z_size, z_size])
+    Variables are looked up as <current scope>/<name>/layer_{i}/{V,g,b} etc. in `store`."""
+    if not _is_elu(nl):
+        raise ValueError("the gfx950 engine fuses the ELU non-linearity only (layers.py:159 default)")
+    st = store or _DEFAULT_STORE
+    n_z = int(x.shape[1])
+    with variable_scope(name, st):
+        prefix = st.full_name("")
+        key = (prefix, n_z, tuple(n_h), tuple(n_out))
+        stack = st._stacks.get(key)
+        if stack is None:
+            stack = st._stacks[key] = ARStack(n_z, n_h, n_out)
+        params = {}
+        for conv in stack.conv_names():
+            for v in ("V", "g", "b"):
+                params[conv + "/" + v] = st.get(conv + "/" + v)
+    stack.prepare(params)
+    return stack.ar_multiconv2d(x, context)

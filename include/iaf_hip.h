@@ -1,0 +1,133 @@
+/*
+ * iaf_hip.h -- C ABI of the MI355X (gfx950) IAF posterior engine.
+ *
+ * The reference (openai/iaf) has no FFI: its hot path sits behind Python callables.  This ABI is
+ * what a ctypes wrapper carrying those callables' signatures binds (iaf_amd/_capi.py; the
+ * reference-side stub is shown in INTEGRATION.md).  Each entry point cites the reference
+ * interface it replaces (paths relative to the reference tree).
+ *
+ * Conventions
+ *   - every tensor pointer is a DEVICE pointer to contiguous fp32 (torch.Tensor.data_ptr()),
+ *     activations NCHW exactly as the reference's TF path (tf_utils/layers.py:46,64);
+ *   - all pointers are BORROWED for the duration of the call; outputs and the workspace are
+ *     caller-allocated; the engine owns only its packed-weight cache (SURVEY 8b "Ownership");
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); calls are
+ *     asynchronous on it and re-entrant per stack (no global mutable state);
+ *   - return value: 0 = ok, <0 = IAF_ERR_* argument errors (the Python wrapper raises the same
+ *     exception kinds as the reference's asserts), >0 = a hipError_t. Never aborts.
+ */
+#ifndef IAF_HIP_H
+#define IAF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IAF_OK 0
+#define IAF_ERR_NULL (-1)          /* null pointer argument */
+#define IAF_ERR_SHAPE (-2)         /* non-positive / inconsistent dimension */
+#define IAF_ERR_NOT_MULTIPLE (-3)  /* n_h not a multiple of n_z or vice versa (layers.py:116 assert) */
+#define IAF_ERR_NOT_PREPARED (-4)  /* forward called before iaf_stack_prepare */
+#define IAF_ERR_WORKSPACE (-5)     /* workspace too small / misaligned */
+#define IAF_ERR_UNSUPPORTED (-6)   /* shape outside what the gfx950 kernels cover (channels % 16) */
+
+#define IAF_VARIANT_TF 0           /* tf_utils/layers.py statement (parity target) */
+
+/* ABI / build identification; also proves the library loaded. */
+int iaf_abi_version(void);
+const char* iaf_error_string(int code);
+/* number of HIP devices visible; <0 on error */
+int iaf_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * AR stack = the variables of one ar_multiconv2d (tf_utils/layers.py:158-166): depth_ar hidden
+ * masked convs n_z->n_h, n_h->n_h ... and two output convs n_h->n_z ("layer_%d", "layer_out_%d").
+ * depth_ar is len(n_h) (2 in tf_train.py:69; `depth_ar*[n_h2]` in models.py:92).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct iaf_stack iaf_stack_t;
+
+int iaf_stack_create(iaf_stack_t** out, int n_z, int n_h, int depth_ar, int variant);
+int iaf_stack_destroy(iaf_stack_t* s);
+
+/* Replaces get_conv_ar_mask + the weight-norm lines of conv2d (layers.py:134-141, 56-60):
+ *   v = mask*V ; w = exp(g)[o] * v / sqrt(max(sum_{h,w,i} v^2, 1e-12))
+ * and repacks w into MFMA fragment order (dead taps dropped).  V/g/b: arrays of depth_ar+2
+ * device pointers in the order layer_0..layer_{d-1}, layer_out_0, layer_out_1; V is HWIO
+ * [3,3,n_in,n_out] fp32 exactly as the reference variable.  Call again whenever weights change. */
+int iaf_stack_prepare(iaf_stack_t* s, const float* const* V, const float* const* g, const float* const* b,
+                      void* stream);
+
+/* bytes of caller-provided scratch needed by the forward calls for a [B,*,H,W] problem */
+size_t iaf_stack_workspace_bytes(const iaf_stack_t* s, int B, int H, int W);
+
+/* Replaces ar_multiconv2d(name, x, context, n_h, n_out) (layers.py:158-166; call site
+ * tf_train.py:69): z [B,n_z,H,W], context [B,n_h,H,W] -> m_raw, s_raw [B,n_z,H,W]. */
+int iaf_ar_multiconv2d_forward(iaf_stack_t* s, const float* z, const float* context, float* m_raw, float* s_raw,
+                               int B, int H, int W, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The IAF step, tf_train.py:69-72 (models.py:281-285):
+ *   m,s = 0.1*ar_multiconv2d(z, context);  z_new = (z-m)/exp(s);  logsd = s   (logqs += s)
+ * z_new and logsd are [B,n_z,H,W]; z_new may alias z only if the caller no longer needs z. */
+int iaf_step_forward(iaf_stack_t* s, const float* z, const float* context, float* z_new, float* logsd,
+                     int B, int H, int W, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Full posterior block, tf_train.py:56-85 (mode "train"): everything between down_conv1 and
+ * the concat, i.e. posterior sample, logqs, IAF step, log-det accumulation, prior logps, KL and
+ * free bits.  All [B,n_z,H,W] inputs NCHW; up_context/down_context [B,n_h,H,W]; eps is the
+ * N(0,1) noise (an INPUT: parity is on identical eps).  Outputs: z [B,n_z,H,W], kl_obj [B],
+ * kl_cost [B]; kl_elem (may be NULL) receives logqs-logps [B,n_z,H,W]. */
+int iaf_posterior_block_forward(iaf_stack_t* s, const float* qz_mean, const float* qz_logsd,
+                                const float* rz_mean, const float* rz_logsd, const float* pz_mean,
+                                const float* pz_logsd, const float* up_context, const float* down_context,
+                                const float* eps, float kl_min, float* z_out, float* kl_obj, float* kl_cost,
+                                float* kl_elem, int B, int H, int W, void* workspace, size_t workspace_bytes,
+                                void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Elementwise pieces of tf_utils/distributions.py, exposed for the wrappers
+ * ------------------------------------------------------------------------------------------ */
+/* DiagonalGaussian.sample (distributions.py:20-21): out = mean + exp(0.5*logvar)*noise */
+int iaf_gaussian_sample(const float* mean, const float* logvar, const float* noise, float* out, size_t n,
+                        void* stream);
+/* gaussian_diag_logps (distributions.py:10) */
+int iaf_gaussian_logps(const float* mean, const float* logvar, const float* sample, float* out, size_t n,
+                       void* stream);
+
+/* compute_lowerbound (distributions.py:55-62) with k>=1: log_pxz, sum_kl [n*k] -> out [n] */
+int iaf_compute_lowerbound(const float* log_pxz, const float* sum_kl, float* out, int n, int k, void* stream);
+/* Streaming form for k = 10^4 (BASELINE config 5): state = (run_max[n], run_sum[n]); feed chunks of
+ * k_chunk weights per image, then finalize.  Equal to compute_lowerbound on the concatenation. */
+int iaf_lowerbound_stream_init(float* run_max, float* run_sum, int n, void* stream);
+int iaf_lowerbound_stream_update(float* run_max, float* run_sum, const float* log_pxz, const float* sum_kl,
+                                 int n, int k_chunk, void* stream);
+int iaf_lowerbound_stream_finalize(const float* run_max, const float* run_sum, float* out, int n, int k_total,
+                                   void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Tuning / introspection (not part of the reference surface)
+ * ------------------------------------------------------------------------------------------ */
+/* Override the launch shape of GEMM layer `layer` (0..depth_ar): co-tiles per wave, pixel tiles
+ * per workgroup, waves along co, split-K factor.  Returns IAF_ERR_UNSUPPORTED if no such kernel. */
+int iaf_stack_set_tuning(iaf_stack_t* s, int layer, int nt, int pxt, int wco, int ks);
+/* Per-kernel timing with HIP events on the launch stream: every launch of GEMM layer `layer` is
+ * bracketed by an engine-owned event pair (up to max_samples; layer < 0 disables).  Not usable
+ * during stream capture.  iaf_stack_profile_read synchronises the recorded events, writes the
+ * elapsed milliseconds of each sample to ms_out[0..*n_out) and resets the sample counter. */
+int iaf_stack_profile_enable(iaf_stack_t* s, int layer, int max_samples);
+int iaf_stack_profile_read(iaf_stack_t* s, float* ms_out, int capacity, int* n_out);
+/* algorithmic work of one iaf_step_forward call: live (mask-aware) FLOPs and fused bytes
+ * (4*(3*n_z+n_h) B/px + weight bytes) */
+int iaf_step_work(const iaf_stack_t* s, int B, int H, int W, double* live_flops, double* dense_flops,
+                  double* bytes);
+/* the same for one GEMM layer (0..depth_ar): live/dense FLOPs of one launch and the bytes that
+ * launch must move at least once (activations in + out, packed weights, bias, context) */
+int iaf_layer_work(const iaf_stack_t* s, int layer, int B, int H, int W, double* live_flops, double* dense_flops,
+                   double* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IAF_HIP_H */

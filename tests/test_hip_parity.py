@@ -1,0 +1,326 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI (via the ctypes wrappers), is
+compared with (a) the committed reference outputs (tests/golden), (b) the CPU oracle on the same
+seeded inputs, and (c) size-independent properties at BASELINE.json's full sizes.
+
+Tolerance: north_star states 1e-4 fp32 on identical (eps, h) inputs; the tests use
+atol = 1e-4 (+ rtol 1e-4 where values are O(10+), i.e. the KL sums)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import golden_inputs as gi
+from oracle import iaf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+ATOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def amd():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU")
+    import iaf_amd
+    iaf_amd._capi.lib()      # raises if the HIP extension is missing: no silent fallback
+    return iaf_amd
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def dev_params(p):
+    return {k: dev(v) for k, v in p.items()}
+
+
+def host(t):
+    torch.cuda.synchronize()
+    return t.detach().cpu().numpy().astype(np.float64)
+
+
+def f32_params(p):
+    """the oracle sees exactly the fp32-rounded weights the GPU sees"""
+    return {k: np.asarray(v, dtype=np.float32).astype(np.float64) for k, v in p.items()}
+
+
+def f32(a):
+    return np.asarray(a, dtype=np.float32).astype(np.float64)
+
+
+# ---------------------------------------------------------------- golden fixtures (reference outputs)
+@pytest.mark.parametrize("name", ["ar_cfg2_8x8", "ar_cfg1_4x4"])
+def test_ar_multiconv2d_vs_reference_golden(amd, golden_dir, name):
+    g = np.load(os.path.join(golden_dir, "ar_multiconv2d.npz"))
+    c = gi.ar_case_inputs(name)
+    stack = amd.ARStack(c["n_z"], c["n_h"])
+    stack.prepare(dev_params(c["params"]))
+    m_raw, s_raw = stack.ar_multiconv2d(dev(c["z"]), dev(c["context"]))
+    np.testing.assert_allclose(host(m_raw), g[name + "/m_raw"], atol=ATOL, rtol=0)
+    np.testing.assert_allclose(host(s_raw), g[name + "/s_raw"], atol=ATOL, rtol=0)
+    z_new, logsd = stack.iaf_step(dev(c["z"]), dev(c["context"]))
+    np.testing.assert_allclose(host(z_new), g[name + "/z_new"], atol=ATOL, rtol=0)
+    np.testing.assert_allclose(host(logsd), g[name + "/logsd"], atol=ATOL, rtol=0)
+
+
+def test_function_api_with_tf_variable_names(amd, golden_dir):
+    """the reference call site, tf_train.py:69, under its scope names"""
+    g = np.load(os.path.join(golden_dir, "ar_multiconv2d.npz"))
+    c = gi.ar_case_inputs("ar_cfg2_8x8")
+    store = amd.VariableStore()
+    for k, v in c["params"].items():
+        store.set("model/IAF_0_0/ar_multiconv2d/" + k, dev(v))
+    with amd.variable_scope("model", store), amd.variable_scope("IAF_0_0", store):
+        x = amd.ar_multiconv2d("ar_multiconv2d", dev(c["z"]), dev(c["context"]), [160, 160], [32, 32], store=store)
+    np.testing.assert_allclose(host(x[0]), g["ar_cfg2_8x8/m_raw"], atol=ATOL, rtol=0)
+    np.testing.assert_allclose(host(x[1]), g["ar_cfg2_8x8/s_raw"], atol=ATOL, rtol=0)
+
+
+def test_posterior_block_vs_reference_golden_layer(amd, golden_dir):
+    """IAFLayer.down of the reference (tf_train.py:46-95): the out-of-scope convs are taken from the
+    oracle (itself pinned on the same fixture), the posterior block runs on the GPU, and kl_obj/kl_cost
+    must match the REFERENCE outputs."""
+    g = np.load(os.path.join(golden_dir, "iaf_layer.npz"))
+    name = "layer_cfg2_8x8"
+    c = gi.layer_case_inputs(name)
+    zs, hs = c["z_size"], c["h_size"]
+    p = c["params"]
+    pre = O.conv2d(O.elu(c["down_input"]), p["down_conv1/V"], p["down_conv1/g"], p["down_conv1/b"])
+    pz_mean, pz_logsd, rz_mean, rz_logsd, down_context, h_det = O.split_channels(pre, [zs] * 4 + [hs] * 2)
+    post = amd.IAFPosterior(zs, hs, depth_ar=2, kl_min=c["kl_min"])
+    post.load(dev_params({k[len("ar_multiconv2d/"):]: v for k, v in p.items() if k.startswith("ar_multiconv2d/")}))
+    post.set_up_state(dev(g[name + "/qz_mean"]), dev(g[name + "/qz_logsd"]), dev(g[name + "/up_context"]))
+    out = post.down(dev(pz_mean), dev(pz_logsd), dev(rz_mean), dev(rz_logsd), dev(down_context), dev(c["eps_post"]))
+    np.testing.assert_allclose(host(out["kl_obj"]), g[name + "/kl_obj"], atol=2e-3, rtol=1e-4)
+    np.testing.assert_allclose(host(out["kl_cost"]), g[name + "/kl_cost"], atol=2e-3, rtol=1e-4)
+    # and the layer output through the (oracle) down_conv2 using the GPU z
+    h = O.elu(np.concatenate([host(out["z"]), h_det], axis=1))
+    output = c["down_input"] + 0.1 * O.conv2d(h, p["down_conv2/V"], p["down_conv2/g"], p["down_conv2/b"])
+    np.testing.assert_allclose(output, g[name + "/output"], atol=ATOL, rtol=0)
+
+
+# ---------------------------------------------------------------- oracle on seeded inputs
+SHAPES = [
+    # B, n_z, n_h, depth_ar, H, W
+    (4, 32, 160, 2, 16, 16),     # BASELINE config 2, level 0
+    (4, 32, 160, 2, 8, 8),       # config 2, level 1
+    (3, 32, 64, 1, 16, 16),      # config 1
+    (5, 32, 64, 1, 4, 4),        # config 1, level 2
+    (2, 64, 64, 4, 8, 8),        # config 4 (n_h=64 reading)
+    (1, 64, 128, 4, 4, 4),       # config 4, n_h=128
+    (3, 32, 160, 2, 5, 7),       # ragged: pixel count not a multiple of the 16-pixel MFMA tile
+    (1, 16, 16, 2, 3, 3),        # smallest supported channels, tile mostly empty
+    (2, 32, 32, 0, 6, 6),        # depth_ar = 0: outputs read z directly (ar.py:394)
+    (7, 32, 160, 2, 1, 1),       # 1x1 latents: every neighbour tap is padding
+    (2, 48, 96, 2, 4, 4),        # odd chunk count (48/16 = 3), 6 output tiles
+    (1, 32, 160, 2, 32, 32),     # wider than the BASELINE levels
+]
+
+
+def _rand_case(seed, B, n_z, n_h, d, H, W):
+    rng = np.random.RandomState(seed)
+    params = gi.ar_multiconv2d_params(rng, n_z, [n_h] * d, [n_z, n_z])
+    z = rng.standard_normal((B, n_z, H, W))
+    ctx = rng.standard_normal((B, n_h, H, W))
+    return params, z, ctx
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "B%d_z%d_h%d_d%d_%dx%d" % s)
+def test_iaf_step_vs_oracle(amd, shape):
+    B, n_z, n_h, d, H, W = shape
+    params, z, ctx = _rand_case(100 + B + H, *shape)
+    stack = amd.ARStack(n_z, [n_h] * d)
+    stack.prepare(dev_params(params))
+    z_new, logsd = stack.iaf_step(dev(z), dev(ctx) if d > 0 else None)
+    ez, es = O.iaf_step(f32(z), f32(ctx), f32_params(params), [n_h] * d)
+    np.testing.assert_allclose(host(logsd), es, atol=ATOL, rtol=0)
+    np.testing.assert_allclose(host(z_new), ez, atol=ATOL, rtol=0)
+    m_raw, s_raw = stack.ar_multiconv2d(dev(z), dev(ctx) if d > 0 else None)
+    em, esr = O.ar_multiconv2d(f32(z), f32(ctx), f32_params(params), [n_h] * d, [n_z, n_z])
+    np.testing.assert_allclose(host(m_raw), em, atol=ATOL, rtol=0)
+    np.testing.assert_allclose(host(s_raw), esr, atol=ATOL, rtol=0)
+
+
+@pytest.mark.parametrize("tune", [(5, 4, 1, 1), (5, 4, 1, 2), (5, 2, 2, 1), (5, 2, 1, 2), (5, 2, 1, 4), (5, 1, 1, 4),
+                                  (5, 1, 2, 2), (5, 2, 2, 2), (2, 4, 1, 1), (1, 4, 1, 2)])
+def test_every_launch_shape_agrees(amd, tune):
+    """all compiled (co-tiles/wave, pixel-tiles, co-waves, split-K) shapes compute the same conv"""
+    B, n_z, n_h, d, H, W = 3, 32, 160, 2, 8, 8
+    params, z, ctx = _rand_case(7, B, n_z, n_h, d, H, W)
+    stack = amd.ARStack(n_z, [n_h] * d)
+    stack.prepare(dev_params(params))
+    nt, pxt, wco, ks = tune
+    for layer in range(d):
+        stack.set_tuning(layer, nt, pxt, wco, ks)
+    stack.set_tuning(d, 2, pxt, wco, ks)          # output pair: (mean, logsd) tiles must share a wave -> nt even
+    z_new, logsd = stack.iaf_step(dev(z), dev(ctx))
+    ez, es = O.iaf_step(f32(z), f32(ctx), f32_params(params), [n_h] * d)
+    np.testing.assert_allclose(host(logsd), es, atol=ATOL, rtol=0)
+    np.testing.assert_allclose(host(z_new), ez, atol=ATOL, rtol=0)
+
+
+@pytest.mark.parametrize("kl_min", [0.0, 0.25])
+@pytest.mark.parametrize("shape", [(4, 32, 160, 2, 16, 16), (3, 32, 64, 1, 8, 8), (2, 64, 64, 4, 4, 4), (3, 32, 160, 2, 5, 3)],
+                         ids=lambda s: "B%d_z%d_h%d_d%d_%dx%d" % s)
+def test_posterior_block_vs_oracle(amd, shape, kl_min):
+    B, n_z, n_h, d, H, W = shape
+    rng = np.random.RandomState(55)
+    params = gi.ar_multiconv2d_params(rng, n_z, [n_h] * d, [n_z, n_z])
+    f = lambda c: rng.standard_normal((B, c, H, W))
+    qm, ql, rm, rl, pm, pl = f(n_z), 0.25 * f(n_z), f(n_z), 0.25 * f(n_z), f(n_z), 0.25 * f(n_z)
+    uc, dc, eps = f(n_h), f(n_h), f(n_z)
+    stack = amd.ARStack(n_z, [n_h] * d)
+    stack.prepare(dev_params(params))
+    out = stack.posterior_block(dev(qm), dev(ql), dev(rm), dev(rl), dev(pm), dev(pl), dev(uc), dev(dc), dev(eps),
+                                kl_min, want_kl_elem=True)
+    e = O.posterior_block(f32(qm), f32(ql), f32(rm), f32(rl), f32(pm), f32(pl), f32(uc), f32(dc), f32(eps),
+                          f32_params(params), [n_h] * d, kl_min)
+    np.testing.assert_allclose(host(out["z"]), e["z"], atol=ATOL, rtol=0)
+    np.testing.assert_allclose(host(out["kl_elem"]), e["logqs"] - e["logps"], atol=ATOL, rtol=1e-5)
+    np.testing.assert_allclose(host(out["kl_cost"]), e["kl_cost"], atol=2e-3, rtol=1e-4)
+    np.testing.assert_allclose(host(out["kl_obj"]), e["kl_obj"], atol=2e-3, rtol=1e-4)
+
+
+# ---------------------------------------------------------------- distributions
+def test_distributions_vs_reference_golden(amd, golden_dir):
+    g = np.load(os.path.join(golden_dir, "distributions.npz"))
+    q = amd.DiagonalGaussian(dev(g["mean"]), dev(g["logvar"]), noise=dev(g["eps"]))
+    np.testing.assert_allclose(host(q.sample), g["sample"], atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(host(q.logps(dev(g["other"]))), g["logps_other"], atol=1e-4, rtol=1e-5)
+    np.testing.assert_allclose(host(amd.gaussian_diag_logps(dev(g["mean"]), dev(g["logvar"]), dev(g["other"]))),
+                               g["logps_fn"], atol=1e-4, rtol=1e-5)
+    np.testing.assert_allclose(host(amd.logsumexp(dev(g["lse_x"]))), g["lse"], atol=1e-5, rtol=1e-5)
+    for k in (1, 4, 12):
+        got = host(amd.compute_lowerbound(dev(g["lb_log_pxz"]), dev(g["lb_kl"]), k))
+        np.testing.assert_allclose(got, g["lb_k%d" % k], atol=1e-4, rtol=1e-5)
+    np.testing.assert_array_equal(host(amd.repeat(dev(g["rep_x"]), 3)), f32(g["rep_3"]))
+    # the reference's KATs (tf_utils/distributions_test.py:7-31)
+    a = np.log(np.array([0.3, 0.3, 0.3, 0.3])).reshape([1, -1])
+    b = np.log(np.array([0.1, 0.5, 0.9, 0.6])).reshape([1, -1])
+    res = -(-np.log(4) + np.log(np.sum(np.exp(a - b))))
+    assert abs(host(amd.compute_lowerbound(dev(a.reshape(-1)), dev(b.reshape(-1)), 4)).sum() - res) < 1e-4
+    assert abs(host(amd.compute_lowerbound(dev(a.reshape(-1)), dev(b.reshape(-1)), 1)).sum() - (b - a).sum()) < 1e-4
+    lse = host(amd.logsumexp(dev(np.arange(10.0).reshape([1, -1]))))[0]
+    assert abs(lse - np.log(np.sum(np.exp(np.arange(10.0))))) < 1e-5
+
+
+def test_streaming_lowerbound_k10000(amd):
+    """BASELINE config 5: 10,000 importance samples per image, streamed in chunks"""
+    rng = np.random.RandomState(9)
+    n, k, kc = 16, 10000, 625
+    lp = (-7000 + 30 * rng.standard_normal((n, k))).astype(np.float32)
+    kl = (900 + 20 * rng.standard_normal((n, k))).astype(np.float32)
+    s = amd.StreamingLowerBound(n, torch.device("cuda"))
+    for i in range(0, k, kc):
+        s.update(dev(lp[:, i:i + kc]), dev(kl[:, i:i + kc]))
+    got = host(s.result())
+    ref = O.compute_lowerbound(lp.astype(np.float64).reshape(-1), kl.astype(np.float64).reshape(-1), k)
+    np.testing.assert_allclose(got, ref, rtol=2e-6, atol=1e-2)     # values ~ 7.8e3: fp32 ulp is 5e-4
+    one = host(amd.compute_lowerbound(dev(lp.reshape(-1)), dev(kl.reshape(-1)), k))
+    np.testing.assert_allclose(one, ref, rtol=2e-6, atol=1e-2)
+
+
+# ---------------------------------------------------------------- full BASELINE sizes: properties
+def _cfg2_full(amd, H):
+    B, n_z, n_h, d = 32, 32, 160, 2
+    params, z, ctx = _rand_case(2024 + H, B, n_z, n_h, d, H, H)
+    stack = amd.ARStack(n_z, [n_h] * d)
+    stack.prepare(dev_params(params))
+    return stack, params, dev(z), dev(ctx)
+
+
+@pytest.mark.parametrize("H", [16, 8])
+def test_full_size_batch_independence_bit_exact(amd, H):
+    """BASELINE config 2 at full size (B=32): every sample's IAF step is independent of the batch it
+    is in -> running samples one at a time must reproduce the batched result BIT-EXACTLY
+    (same kernel, same per-pixel reduction order)."""
+    stack, _, z, ctx = _cfg2_full(amd, H)
+    zf, sf = stack.iaf_step(z, ctx)
+    for b in (0, 13, 31):
+        zb, sb = stack.iaf_step(z[b:b + 1].contiguous(), ctx[b:b + 1].contiguous())
+        assert torch.equal(zb, zf[b:b + 1]) and torch.equal(sb, sf[b:b + 1])
+
+
+@pytest.mark.parametrize("H", [16, 8])
+def test_full_size_autoregressive_property(amd, H):
+    """Perturbing z at (pixel q, channel c) must leave z_new/logsd bit-identical at every position that
+    precedes it in the IAF ordering (reverse-raster pixel, ascending channel), and the
+    log-det term at the perturbed position itself must not move (strictly triangular s)."""
+    stack, _, z, ctx = _cfg2_full(amd, H)
+    z0, s0 = stack.iaf_step(z, ctx)
+    qh, qw, c = H // 2, H // 2 - 1, 11
+    z2 = z.clone()
+    z2[:, c, qh, qw] += 0.5
+    z1, s1 = stack.iaf_step(z2, ctx)
+    dz = (z1 != z0)
+    ds = (s1 != s0)
+    # allowed to change: pixels strictly before q in raster order, or pixel q itself with channel > c
+    allowed = torch.zeros_like(dz)
+    allowed[:, :, :qh, :] = True
+    allowed[:, :, qh, :qw] = True
+    allowed_s = allowed.clone()
+    allowed_s[:, c + 1:, qh, qw] = True
+    allowed_z = allowed_s.clone()
+    allowed_z[:, c, qh, qw] = True            # z_new at the perturbed position changes through (z - m)
+    assert not (dz & ~allowed_z).any()
+    assert not (ds & ~allowed_s).any()
+    assert ds.any() and dz.any()
+
+
+def test_full_size_identity_when_output_convs_are_zero(amd):
+    """V_out = 0, b_out = 0 -> m = s = 0 -> z_new == z exactly, logsd == 0 (full config-2 size)."""
+    B, n_z, n_h, d, H = 32, 32, 160, 2, 16
+    params, z, ctx = _rand_case(77, B, n_z, n_h, d, H, H)
+    for i in range(2):
+        params["layer_out_%d/V" % i] = np.zeros_like(params["layer_out_%d/V" % i])
+        params["layer_out_%d/b" % i] = np.zeros_like(params["layer_out_%d/b" % i])
+    stack = amd.ARStack(n_z, [n_h] * d)
+    stack.prepare(dev_params(params))
+    zd = dev(z)
+    z_new, logsd = stack.iaf_step(zd, dev(ctx))
+    assert torch.equal(z_new, zd)
+    assert torch.count_nonzero(logsd).item() == 0
+
+
+def test_full_size_vs_oracle_sample_of_batch(amd):
+    """full config-2 launch (B=32, 16x16); the oracle checks 2 of the 32 samples (it is slow)"""
+    stack, params, z, ctx = _cfg2_full(amd, 16)
+    zf, sf = stack.iaf_step(z, ctx)
+    for b in (5, 30):
+        ez, es = O.iaf_step(host(z[b:b + 1]), host(ctx[b:b + 1]), f32_params(params), [160, 160])
+        np.testing.assert_allclose(host(zf[b:b + 1]), ez, atol=ATOL, rtol=0)
+        np.testing.assert_allclose(host(sf[b:b + 1]), es, atol=ATOL, rtol=0)
+
+
+def test_weight_update_invalidates_cache(amd):
+    B, n_z, n_h, d, H = 2, 32, 64, 1, 4
+    params, z, ctx = _rand_case(5, B, n_z, n_h, d, H, H)
+    dp = dev_params(params)
+    stack = amd.ARStack(n_z, [n_h] * d)
+    stack.prepare(dp)
+    a, _ = stack.iaf_step(dev(z), dev(ctx))
+    dp["layer_0/g"].add_(0.5)                       # in-place update bumps tensor._version
+    stack.prepare(dp)
+    b, _ = stack.iaf_step(dev(z), dev(ctx))
+    params["layer_0/g"] = f32(params["layer_0/g"]) + 0.5
+    ez, _ = O.iaf_step(f32(z), f32(ctx), f32_params(params), [n_h] * d)
+    assert not torch.equal(a, b)
+    np.testing.assert_allclose(host(b), ez, atol=ATOL, rtol=0)
+
+
+# ---------------------------------------------------------------- error behaviour (SURVEY 8b "Errors")
+def test_errors_mirror_reference(amd):
+    with pytest.raises(AssertionError):
+        amd.ARStack(64, [160, 160])                  # layers.py:116 assert
+    with pytest.raises(ValueError):
+        amd.ARStack(4, [8, 8])                       # channels not multiples of 16: outside kernel coverage
+    stack = amd.ARStack(32, [64])
+    z = torch.zeros(1, 32, 4, 4, device="cuda")
+    ctx = torch.zeros(1, 64, 4, 4, device="cuda")
+    with pytest.raises(Exception):
+        stack.iaf_step(z, ctx)                       # not prepared
+    with pytest.raises(ValueError):
+        stack.iaf_step(z.cpu(), ctx)                 # host tensor
+    with pytest.raises(ValueError):
+        stack.iaf_step(z, torch.zeros(1, 32, 4, 4, device="cuda"))   # wrong context channels
