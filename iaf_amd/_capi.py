@@ -5,7 +5,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_lib", "libiaf_hip.so")
+LIB_PATH = os.environ.get("IAF_HIP_LIB") or os.path.join(_HERE, "_lib", "libiaf_hip.so")   # env override: dev experiments
 
 IAF_OK = 0
 IAF_ERR_NULL = -1
@@ -44,6 +44,7 @@ SIGNATURES = {
     "iaf_stack_profile_enable": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
     "iaf_stack_profile_read": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float), ctypes.c_int,
                                               ctypes.POINTER(ctypes.c_int)]),
+    "iaf_stack_set_debug": (ctypes.c_int, [_vp, ctypes.c_int, _vp]),
     "iaf_layer_work": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int] +
                        [ctypes.POINTER(ctypes.c_double)] * 3),
     "iaf_step_work": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int] + [ctypes.POINTER(ctypes.c_double)] * 3),

@@ -1,5 +1,9 @@
-"""Build the HIP engine in-tree for gfx950:  python -m iaf_amd.build
-Output: iaf_amd/_lib/libiaf_hip.so (git-ignored; travels to the GPU box with the snapshot)."""
+"""Build the HIP engine in-tree for gfx950:  python -m iaf_amd.build [--force]
+Output: iaf_amd/_lib/libiaf_hip.so (git-ignored; travels to the GPU box with the snapshot).
+
+The masked-conv kernel is instantiated once per launch shape (pxt, wco, ks) in its own translation
+unit (csrc/iaf_conv_inst.hip with -DIAF_PXT/-DIAF_WCO/-DIAF_KS); the units compile in parallel."""
+import concurrent.futures
 import os
 import shutil
 import subprocess
@@ -7,28 +11,52 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SRC = [os.path.join(HERE, "csrc", "iaf_engine.hip")]
-OUT = os.path.join(HERE, "_lib", "libiaf_hip.so")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include")]
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "_lib")
+OBJDIR = os.path.join(LIBDIR, "obj")
+OUT = os.path.join(LIBDIR, "libiaf_hip.so")
+SHAPES = [(4, 1, 1), (4, 1, 2), (2, 2, 1), (2, 2, 2), (2, 1, 2), (2, 1, 4), (1, 1, 4), (1, 2, 2)]   # keep in sync with pick_kernel()
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+CFLAGS += os.environ.get("IAF_EXTRA_CFLAGS", "").split()       # dev experiments only (e.g. -DIAF_EXP_NOREFILL)
+HEADERS = [os.path.join(ROOT, "include", "iaf_hip.h"), os.path.join(CSRC, "iaf_conv_kernel.hpp")]
 
 
-def needs_build():
-    if not os.path.exists(OUT):
+def _units():
+    units = [(os.path.join(CSRC, "iaf_engine.hip"), os.path.join(OBJDIR, "iaf_engine.o"), [])]
+    for pxt, wco, ks in SHAPES:
+        units.append((os.path.join(CSRC, "iaf_conv_inst.hip"), os.path.join(OBJDIR, "iaf_conv_%d_%d_%d.o" % (pxt, wco, ks)),
+                      ["-DIAF_PXT=%d" % pxt, "-DIAF_WCO=%d" % wco, "-DIAF_KS=%d" % ks]))
+    return units
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(OUT)
-    deps = SRC + [os.path.join(ROOT, "include", "iaf_hip.h")]
+    t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
-    if not force and not needs_build():
-        return OUT
+def build(force=False, verbose=True, jobs=None):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = [hipcc] + FLAGS + SRC + ["-o", OUT]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    os.makedirs(OBJDIR, exist_ok=True)
+    todo = []
+    for src, obj, defs in _units():
+        if force or _stale(obj, [src] + HEADERS):
+            todo.append([hipcc] + CFLAGS + defs + ["-c", src, "-o", obj])
+    if todo:
+        jobs = jobs or min(len(todo), os.cpu_count() or 4)
+        if verbose:
+            print("compiling %d translation unit(s) for gfx950 with %d job(s)" % (len(todo), jobs), flush=True)
+        with concurrent.futures.ThreadPoolExecutor(jobs) as ex:
+            for cmd, rc in zip(todo, ex.map(lambda c: subprocess.run(c).returncode, todo)):
+                if rc != 0:
+                    raise RuntimeError("hipcc failed: " + " ".join(cmd))
+    objs = [obj for _, obj, _ in _units()]
+    if force or todo or _stale(OUT, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", OUT]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
     return OUT
 
 

@@ -1,0 +1,36 @@
+// iaf_conv_inst.hip -- instantiates iaf_conv_kernel for ONE launch shape (IAF_PXT, IAF_WCO, IAF_KS) and every
+// (co-tiles per wave, input mode, epilogue).  Built once per shape by iaf_amd/build.py, in parallel.
+#include "iaf_conv_kernel.hpp"
+
+#ifndef IAF_PXT
+#error "compile with -DIAF_PXT=.. -DIAF_WCO=.. -DIAF_KS=.."
+#endif
+
+template <int NT>
+static conv_fn_t pick_mode(int inmode, int epi) {
+    if (epi == EPI_HIDDEN) {
+        if (inmode == IN_PIXMAJOR) return iaf_conv_kernel<NT, IAF_PXT, IAF_WCO, IAF_KS, IN_PIXMAJOR, EPI_HIDDEN>;
+        if (inmode == IN_NCHW) return iaf_conv_kernel<NT, IAF_PXT, IAF_WCO, IAF_KS, IN_NCHW, EPI_HIDDEN>;
+        return iaf_conv_kernel<NT, IAF_PXT, IAF_WCO, IAF_KS, IN_POSTERIOR, EPI_HIDDEN>;
+    }
+    if constexpr (NT % 2 == 0) {
+        if (inmode == IN_PIXMAJOR) return iaf_conv_kernel<NT, IAF_PXT, IAF_WCO, IAF_KS, IN_PIXMAJOR, EPI_OUT>;
+        if (inmode == IN_NCHW) return iaf_conv_kernel<NT, IAF_PXT, IAF_WCO, IAF_KS, IN_NCHW, EPI_OUT>;
+        return iaf_conv_kernel<NT, IAF_PXT, IAF_WCO, IAF_KS, IN_POSTERIOR, EPI_OUT>;
+    }
+    return nullptr;
+}
+
+#define IAF_CAT_(a, b, c, d) a##b##_##c##_##d
+#define IAF_CAT(a, b, c, d) IAF_CAT_(a, b, c, d)
+
+extern "C" conv_fn_t IAF_CAT(iaf_pick_conv_, IAF_PXT, IAF_WCO, IAF_KS)(int nt, int inmode, int epi) {
+    switch (nt) {
+        case 1: return pick_mode<1>(inmode, epi);
+        case 2: return pick_mode<2>(inmode, epi);
+        case 3: return pick_mode<3>(inmode, epi);
+        case 4: return pick_mode<4>(inmode, epi);
+        case 5: return pick_mode<5>(inmode, epi);
+    }
+    return nullptr;
+}

@@ -1,0 +1,399 @@
+// iaf_conv_kernel.hpp -- the masked 3x3 conv implicit-GEMM kernel template (see iaf_engine.hip for the
+// design notes).  Included by iaf_engine.hip (types only) and by iaf_conv_inst.hip (instantiations).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+#include <utility>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N-1>{})
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
+#define NTAPS 5
+// live taps of the TF statement (cross-correlation, mask keeps centre, right, and the row below):
+// (kh,kw) = (1,1) (1,2) (2,0) (2,1) (2,2)  ->  (dh,dw) relative to the output pixel.  Centre first.
+static __device__ __constant__ const int c_tap_dh[NTAPS] = {0, 0, 1, 1, 1};
+static __device__ __constant__ const int c_tap_dw[NTAPS] = {0, 1, -1, 0, 1};
+
+#define EPI_HIDDEN 0   // y = elu(acc + bias [+ ctx (+ ctx2)])  -> pixel-major scratch
+#define EPI_OUT 1      // output pair (mean, logsd) -> NCHW; mode selects raw / IAF step / posterior
+
+#define MODE_RAW 0        // out0 = m_raw, out1 = s_raw                         (layers.py:166)
+#define MODE_IAF 1        // out0 = (z-0.1m)/exp(0.1s), out1 = 0.1s             (tf_train.py:70-72)
+#define MODE_POSTERIOR 2  // MODE_IAF on z0 rebuilt from the posterior inputs, plus kl elements
+
+#define IN_PIXMAJOR 0     // x is [P][c_in] scratch written by a previous EPI_HIDDEN
+#define IN_NCHW 1         // x is an NCHW tensor (z)
+#define IN_POSTERIOR 2    // x = z0 = (qm+rm) + exp(ql+rl)*eps computed on the fly (tf_train.py:57,63)
+
+struct ConvP {
+    const float* x;       // IN_PIXMAJOR / IN_NCHW input
+    const float* wp;      // packed weights [chunk][tap][co_tile][lane 64][4]
+    const float* bias;    // packed bias
+    const int* lim;       // per packed co-tile: number of live 16-channel chunks of the centre tap (unused for now)
+    const float* ctx;     // EPI_HIDDEN: optional NCHW context  [B,cout,H,W]
+    const float* ctx2;    // EPI_HIDDEN: optional second context (up_context + down_context)
+    float* y;             // EPI_HIDDEN output, pixel-major [P][cout]
+    const float* zin;     // EPI_OUT MODE_IAF: z  [B,n_z,H,W]
+    float* out0;          // EPI_OUT: z_new / m_raw
+    float* out1;          // EPI_OUT: logsd / s_raw
+    // posterior inputs (IN_POSTERIOR staging and MODE_POSTERIOR epilogue), all [B,n_z,H,W]
+    const float* qm; const float* ql; const float* rm; const float* rl; const float* pm; const float* pl;
+    const float* eps;
+    float* kl_elem;       // MODE_POSTERIOR: logqs - logps [B,n_z,H,W]
+    int B, H, W, HW, P;   // P = B*H*W
+    int cin, cout;        // GEMM K channels, GEMM N (EPI_OUT: 2*n_z)
+    int nchunk, ncot;
+    int cp;               // padded channel stride of the LDS tile (floats), == cin + 8
+    int nslot;            // staged pixel slots = TM + W + 1 (one-sided halo)
+    int mode;
+    unsigned long long* dbg;   // dev tool: per-workgroup s_memtime stamps [grid][8] (NULL in production)
+};
+
+// ELU with the hardware exponential: exp(v) - 1 for v <= 0 (what TF's fp32 kernel evaluates); abs error < 1e-7
+__device__ __forceinline__ float elu_f(float v) { return v > 0.f ? v : __expf(v) - 1.0f; }
+
+// Tiling (all compile time):
+//   workgroup = PXT pixel tiles (16 px each) x WCO co-groups x KS K-slices, one wave each;
+//   a wave owns NT co-tiles (16 channels each) of one pixel tile for its K slice.
+// MFMA roles (v_mfma_f32_16x16x4_f32, D[i][j] += A[i][k] B[k][j]):
+//   A = weights  : lane l holds W[co = tile*16 + (l&15)][k-slot l>>4]
+//   B = activations: lane l holds X[k-slot l>>4][pixel l&15]
+//   D            : lane l holds D[co = tile*16 + 4*(l>>4) + r][pixel l&15], r = 0..3
+// K order inside a 16-channel chunk is permuted: k-slot kk owns channels 4kk..4kk+3, MFMA j of the chunk
+// consumes channel 4kk+j, so each operand is ONE 16-byte load per lane per 4 MFMAs.
+template <int NT, int PXT, int WCO, int KS, int INMODE, int EPI>
+__global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) {
+    extern __shared__ __attribute__((aligned(16))) f32x4 smem4[];
+    constexpr int TM = 16 * PXT;
+    constexpr int NTHREADS = 64 * PXT * WCO * KS;
+    constexpr int WPK = PXT * WCO;   // waves per K slice
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform on purpose: keeps tile/K-slice indices and
+                                                                 // the weight base pointer in SGPRs (saddr loads, no 64-bit VALU)
+    const int pw = wave % PXT, cw = (wave / PXT) % WCO, kh = wave / WPK;
+    const int P0 = blockIdx.x * TM;
+    const int cot0 = (blockIdx.y * WCO + cw) * NT;
+    const int HW = p.HW, W = p.W;
+    const int cp4 = p.cp >> 2;       // LDS row stride in 16-byte units
+#define IAF_STAMP(k) do { if (p.dbg && tid == 0) p.dbg[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+    IAF_STAMP(0);
+
+    // ================= prologue, ordered by latency: (1) tile loads, (2) weight ring, (3) index math ==========
+    // (1) activation tile: slots [P0, P0+nslot) x cin.  For the pixel-major scratch the tile is ONE contiguous run
+    // of global memory, so the loads need no index math at all and are issued first, all in one batch.
+    const int nq = p.cin >> 2;                     // 16-byte items per pixel
+    const int nitems = p.nslot * nq;
+    constexpr int SU = (INMODE == IN_PIXMAJOR) ? 16 : 4;    // items in flight per thread
+    f32x4 sv[SU];
+    if (INMODE == IN_PIXMAJOR) {
+        const long long rem = (long long)(p.P - P0) * nq;   // items whose pixel exists
+        const int nvalid = rem < nitems ? (int)rem : nitems;
+        const f32x4* src = (const f32x4*)p.x + (size_t)P0 * nq;
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            const int f = tid + u * NTHREADS;
+            sv[u] = src[f < nvalid ? f : nvalid - 1];        // clamped: branch-free; out-of-range items are zeroed below
+            if (f >= nvalid) sv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+
+    // (2) weight ring.  A step is one (chunk, tap): NT x 1 KiB global_load_dwordx4 feeding 4*NT MFMAs.  Weights
+    // come from L2 at ~1 us latency while a step is only 128*NT cycles, so R = 5*RCH steps are kept in flight in
+    // registers (one wave per SIMD owns 512 of them).  Step s lives in ring slot s % R; while step s computes, the
+    // slot consumed by step s-1 is refilled with step s+R-1, the loads interleaved between the MFMAs.  Hence the
+    // prologue fetches R-1 steps.  Loop bodies are straight-line (static slots/taps, no branches) so that hipcc
+    // emits COUNTED s_waitcnt vmcnt(N) and the ring really stays in flight.
+    constexpr int RCH_FULL = (NT >= 4) ? 2 : (NT == 3 ? 3 : (NT == 2 ? 4 : 8));
+    constexpr int RCH = (NTHREADS > 256) ? (RCH_FULL + 1) / 2 : RCH_FULL;   // 2 waves/SIMD: half the registers each
+    constexpr int R = RCH * NTAPS;
+    const size_t wstep = (size_t)p.ncot * 64;   // f32x4 per (chunk,tap) step
+    const int c_begin = (kh * p.nchunk) / KS, c_end = ((kh + 1) * p.nchunk) / KS;
+    const f32x4* wbase = (const f32x4*)p.wp + (size_t)cot0 * 64;   // wave-uniform; lane offset added per load
+    const unsigned ulane = (unsigned)lane;
+    f32x4 wr[R][NT];
+    auto ring_prologue = [&](auto i) {
+        constexpr int I = decltype(i)::value;
+        if (c_begin + I < c_end) {
+            const f32x4* q = wbase + (size_t)(c_begin + I) * NTAPS * wstep;
+#pragma unroll
+            for (int tp = 0; tp < NTAPS; ++tp) {
+                if (I == RCH - 1 && tp == NTAPS - 1) continue;    // slot R-1 is filled by step 0
+#pragma unroll
+                for (int t = 0; t < NT; ++t) wr[I * NTAPS + tp][t] = (q + (size_t)tp * wstep)[ulane + t * 64];
+            }
+        }
+    };
+    ring_prologue(std::integral_constant<int, 0>{});   // chunk 0 now; chunks 1..RCH-1 after the tile is staged
+    IAF_STAMP(1);
+
+    // (3) per-lane geometry: MFMA B operand lane = (pixel l&15, k-slot l>>4)
+    const int pl = lane & 15, kk = lane >> 4;
+    const int Pl = P0 + pw * 16 + pl;
+    const bool pvalid = Pl < p.P;
+    const int bimg = Pl / HW, pp = Pl - bimg * HW;
+    const int h = pp / W, w = pp - h * W;
+    int xa[NTAPS];   // 16-byte offset into the LDS tile of this lane's 4 channels for each tap (chunk 0)
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t) {
+        const int dh = c_tap_dh[t], dw = c_tap_dw[t];
+        const bool v = pvalid && (h + dh < p.H) && (w + dw >= 0) && (w + dw < W);
+        const int slot = pw * 16 + pl + dh * W + dw;
+        xa[t] = (v ? slot : p.nslot) * cp4 + kk;     // image borders read the all-zero slot
+    }
+
+    // (4) tile -> LDS
+    {
+        f32x4* zslot = smem4 + (size_t)p.nslot * cp4;
+        for (int i = tid; i < cp4; i += NTHREADS) zslot[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (INMODE == IN_PIXMAJOR) {
+            const float rnq = 1.0f / (float)nq;
+#pragma unroll
+            for (int u = 0; u < SU; ++u) {
+                const int f = tid + u * NTHREADS;
+                if (f < nitems) {
+                    const int sl = (int)(((float)f + 0.5f) * rnq);
+                    smem4[sl * cp4 + (f - sl * nq)] = sv[u];
+                }
+            }
+            // tiles larger than SU*NTHREADS items (c_in > 192 at TM = 64): plain extra rounds
+            const f32x4* src = (const f32x4*)p.x + (size_t)P0 * nq;
+            for (int f = tid + SU * NTHREADS; f < nitems; f += NTHREADS) {
+                const int sl = (int)(((float)f + 0.5f) * rnq);
+                smem4[sl * cp4 + (f - sl * nq)] = (P0 + sl < p.P) ? src[f] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        } else {
+            for (int base = tid; base < nitems; base += SU * NTHREADS) {
+                int dst[SU];
+#pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    const int idx = base + u * NTHREADS;
+                    dst[u] = -1;
+                    sv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (idx < nitems) {
+                        const int q = idx / p.nslot, sl = idx - q * p.nslot;   // slot fastest: coalesced along pixels
+                        const int Pg = P0 + sl;
+                        dst[u] = sl * cp4 + q;
+                        if (Pg < p.P) {
+                            const int b = Pg / HW, ppx = Pg - b * HW;
+                            const size_t gb = ((size_t)b * p.cin + 4 * q) * HW + ppx;
+                            if (INMODE == IN_NCHW) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) sv[u][r] = p.x[gb + (size_t)r * HW];
+                            } else {   // z0 = (qm+rm) + exp(0.5*2*(ql+rl)) * eps   (tf_train.py:57,63; distributions.py:21)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const size_t i = gb + (size_t)r * HW;
+                                    sv[u][r] = (p.qm[i] + p.rm[i]) + __expf(0.5f * (2.f * (p.ql[i] + p.rl[i]))) * p.eps[i];
+                                }
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < SU; ++u)
+                    if (dst[u] >= 0) smem4[dst[u]] = sv[u];
+            }
+        }
+    }
+    static_for<RCH - 1>([&](auto i) { ring_prologue(std::integral_constant<int, decltype(i)::value + 1>{}); });
+    __syncthreads();
+    IAF_STAMP(2);
+
+    // ================= epilogue work assignment ==========================================================
+    // With split-K the KS waves of one (pixel tile, co group) share the epilogue: wave kh finishes units
+    // u = kh, kh+KS, ...  (unit = one co-tile for EPI_HIDDEN, one (mean, logsd) tile pair for EPI_OUT).
+    constexpr int NUNIT = (EPI == EPI_HIDDEN) ? NT : NT / 2;
+    constexpr int NMY = (NUNIT + KS - 1) / KS;
+    f32x4 pre0[NMY], pre1[NMY];
+    auto prefetch_epilogue = [&]() {     // operands that do not depend on the GEMM: context, z
+        if (!pvalid) return;
+#pragma unroll
+        for (int i = 0; i < NMY; ++i) {
+            const int u = kh + i * KS;
+            if (u >= NUNIT) continue;
+            if (EPI == EPI_HIDDEN) {
+                if (p.ctx) {
+                    const size_t cb = ((size_t)bimg * p.cout + (cot0 + u) * 16 + 4 * kk) * HW + pp;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pre0[i][r] = p.ctx[cb + (size_t)r * HW];
+                    if (p.ctx2) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) pre1[i][r] = p.ctx2[cb + (size_t)r * HW];
+                    }
+                }
+            } else if (p.mode == MODE_IAF) {
+                const size_t zb = ((size_t)bimg * (p.cout >> 1) + ((cot0 + 2 * u) >> 1) * 16 + 4 * kk) * HW + pp;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pre0[i][r] = p.zin[zb + (size_t)r * HW];
+            }
+        }
+    };
+
+    // ================= K loop =============================================================================
+    constexpr int NACC = (NT == 1) ? 2 : NT;   // a lone accumulator would serialise on the 40-cycle MFMA latency
+    f32x4 acc[NACC];
+#pragma unroll
+    for (int t = 0; t < NACC; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // x operand: one ds_read_b128 per step, double-buffered one step ahead (xn is always the NEXT step's operand)
+    f32x4 xn = smem4[xa[0] + c_begin * 4];
+    auto chunk_body = [&](auto slot_c, auto refill_t4, auto refill_own, int chunk) {
+        constexpr int I = decltype(slot_c)::value;
+        constexpr bool RF_T4 = decltype(refill_t4)::value;    // step (chunk, 0) refills step (chunk+RCH-1, tap 4)
+        constexpr bool RF_OWN = decltype(refill_own)::value;  // step (chunk, tp>=1) refills step (chunk+RCH, tp-1)
+#pragma unroll
+        for (int tp = 0; tp < NTAPS; ++tp) {
+            const f32x4 xv = xn;
+            // next step: tap tp+1 of this chunk, or tap 0 of the next chunk (a read past the last chunk stays inside
+            // the padded row of the LDS tile and is never used)
+            xn = (tp + 1 < NTAPS) ? smem4[xa[(tp + 1) % NTAPS] + chunk * 4]
+                                  : smem4[xa[0] + (chunk + 1 < c_end ? chunk + 1 : chunk) * 4];
+            const int PS = (I * NTAPS + tp + R - 1) % R;                      // slot consumed by the previous step
+#ifdef IAF_EXP_NOREFILL
+            const bool rf = false;
+#else
+            const bool rf = (tp == 0) ? RF_T4 : RF_OWN;
+#endif
+            const f32x4* q = wbase + ((size_t)chunk * NTAPS + tp + R - 1) * wstep;   // step s + R - 1
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int a = (NT == 1) ? (j & 1) : t;
+#ifdef IAF_EXP_NOMFMA
+                    asm volatile("" ::"v"(wr[I * NTAPS + tp][t][j]), "v"(xv[j]));
+#else
+                    acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[I * NTAPS + tp][t][j], xv[j], acc[a], 0, 0, 0);
+#endif
+                }
+                if (rf) {   // refill loads ride in the shadow of the MFMAs: tiles j, j+4, ...
+#pragma unroll
+                    for (int t = j; t < NT; t += 4) wr[PS][t] = q[ulane + t * 64];
+                }
+            }
+        }
+    };
+    {
+        using T = std::true_type;
+        using F = std::false_type;
+        int c = c_begin;
+        for (; c + 2 * RCH <= c_end; c += RCH)       // steady state: every step refills
+            static_for<RCH>([&](auto i) { chunk_body(i, T{}, T{}, c + decltype(i)::value); });
+        IAF_STAMP(3);
+        prefetch_epilogue();                         // >= one ring revolution of MFMA work left to hide it
+        static_for<RCH>([&](auto i) {                // drain, first ring revolution
+            const int cc = c + decltype(i)::value;
+            if (cc < c_end) {
+                if (cc + RCH < c_end) chunk_body(i, T{}, T{}, cc);
+                else if (cc + RCH - 1 < c_end) chunk_body(i, T{}, F{}, cc);
+                else chunk_body(i, F{}, F{}, cc);
+            }
+        });
+        static_for<RCH>([&](auto i) {                // drain, second revolution
+            const int cc = c + RCH + decltype(i)::value;
+            if (cc < c_end) chunk_body(i, F{}, F{}, cc);
+        });
+    }
+    if (NT == 1) acc[0] += acc[1];
+    IAF_STAMP(4);
+
+    // ================= split-K reduction through LDS + epilogue ============================================
+    // C/D layout of the 16x16 MFMA: lane holds D[row = 4*(l>>4)+r][col = l&15] = (co = tile*16 + 4*kk + r, pixel pl)
+    f32x4 val[NMY * (EPI == EPI_HIDDEN ? 1 : 2)];
+    if (KS > 1) {
+        float* red = (float*)(smem4 + (size_t)(p.nslot + 1) * cp4);
+        // layout [group = wave % WPK][k slice][tile][4][64 lanes]: conflict-free, every wave writes all its tiles
+        float* wbuf = red + ((size_t)((wave % WPK) * KS + kh) * NT * 4) * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wbuf[(t * 4 + j) * 64] = acc[t][j];
+        __syncthreads();
+        const float* rbuf = red + ((size_t)(wave % WPK) * KS * NT * 4) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < NMY; ++i) {
+            const int u = kh + i * KS;
+            constexpr int TPU = (EPI == EPI_HIDDEN) ? 1 : 2;     // tiles per unit
+#pragma unroll
+            for (int e = 0; e < TPU; ++e) {
+                f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (u < NUNIT) {
+                    const int t = u * TPU + e;
+                    for (int k = 0; k < KS; ++k)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) sum[j] += rbuf[((size_t)(k * NT + t) * 4 + j) * 64];
+                }
+                val[i * TPU + e] = sum;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) val[i] = acc[i];
+    }
+    if (pvalid) {
+#pragma unroll
+        for (int i = 0; i < NMY; ++i) {
+            const int u = kh + i * KS;
+            if (u >= NUNIT) continue;
+            if (EPI == EPI_HIDDEN) {
+                const int co = (cot0 + u) * 16 + 4 * kk;
+                f32x4 v = val[i] + *(const f32x4*)(p.bias + co);
+                if (p.ctx) {   // x += context (layers.py:163-164); context = up_context + down_context (tf_train.py:58)
+                    if (p.ctx2) v += (pre0[i] + pre1[i]);
+                    else v += pre0[i];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = elu_f(v[r]);   // layers.py:165
+                *(f32x4*)(p.y + (size_t)Pl * p.cout + co) = v;
+            } else {
+                const int nz = p.cout >> 1;
+                const int gt = cot0 + 2 * u;              // packed tiles (gt, gt+1) = (mean, logsd) of channel group gt/2
+                const int c0 = (gt >> 1) * 16 + 4 * kk;
+                const f32x4 bm = *(const f32x4*)(p.bias + gt * 16 + 4 * kk);
+                const f32x4 bs = *(const f32x4*)(p.bias + (gt + 1) * 16 + 4 * kk);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const size_t idx = ((size_t)bimg * nz + c0 + r) * HW + pp;
+                    const float m_raw = val[2 * i][r] + bm[r];
+                    const float s_raw = val[2 * i + 1][r] + bs[r];
+                    if (p.mode == MODE_RAW) {
+                        p.out0[idx] = m_raw;
+                        p.out1[idx] = s_raw;
+                    } else if (p.mode == MODE_IAF) {
+                        const float m = m_raw * 0.1f, s = s_raw * 0.1f;        // tf_train.py:70
+                        p.out0[idx] = (pre0[i][r] - m) / __expf(s);            // tf_train.py:71
+                        p.out1[idx] = s;                                        // tf_train.py:72 (logqs += s)
+                    } else {
+                        const float m = m_raw * 0.1f, s = s_raw * 0.1f;
+                        const float mean = p.qm[idx] + p.rm[idx];               // tf_train.py:57
+                        const float logvar = 2.f * (p.ql[idx] + p.rl[idx]);
+                        const float z0 = mean + __expf(0.5f * logvar) * p.eps[idx];                           // :63
+                        const float d0 = z0 - mean;
+                        float logqs = -0.5f * (1.8378770664093453f + logvar + d0 * d0 / __expf(logvar));     // :68
+                        const float z = (z0 - m) / __expf(s);                                                 // :71
+                        logqs += s;                                                                           // :72
+                        const float plv = 2.f * p.pl[idx];                                                    // :56
+                        const float d1 = z - p.pm[idx];
+                        const float logps = -0.5f * (1.8378770664093453f + plv + d1 * d1 / __expf(plv));      // :73
+                        p.out0[idx] = z;
+                        if (p.out1) p.out1[idx] = s;
+                        p.kl_elem[idx] = logqs - logps;                                                       // :75
+                    }
+                }
+            }
+        }
+    }
+    IAF_STAMP(5);
+}
+
+typedef void (*conv_fn_t)(ConvP);

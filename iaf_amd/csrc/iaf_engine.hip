@@ -34,18 +34,10 @@
 
 #include "iaf_hip.h"
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+#include "iaf_conv_kernel.hpp"
 
 #define IAF_ABI_VERSION 1
 #define MAX_GEMM_LAYERS 10   // depth_ar <= 9 hidden + 1 output pair
-#define NTAPS 5
-
-// live taps of the TF statement (cross-correlation, mask keeps centre, right, and the row below):
-// (kh,kw) = (1,1) (1,2) (2,0) (2,1) (2,2)  ->  (dh,dw) relative to the output pixel.  Centre first.
-__device__ __constant__ const int c_tap_dh[NTAPS] = {0, 0, 1, 1, 1};
-__device__ __constant__ const int c_tap_dw[NTAPS] = {0, 1, -1, 0, 1};
-static const int h_tap_kh[NTAPS] = {1, 1, 2, 2, 2};
-static const int h_tap_kw[NTAPS] = {1, 2, 0, 1, 2};
 
 // ---------------------------------------------------------------------------------------------
 // MADE channel mask rule, tf_utils/layers.py:115-131 (Python-2 integer division)
@@ -76,6 +68,10 @@ struct PrepArgs {
     int nlayers;
 };
 
+// Work split: thread (oo = tid&15, cs = tid>>4) owns output channel o = tile*16+oo and input channels
+// ci = cs, cs+16, ...  All of its 5*ceil(n_in/16) filter taps are fetched in ONE batch of independent,
+// branch-free loads (clamped address + mask multiply), kept in registers for the second pass.
+#define PREP_MAXI 16   // n_in <= 256
 __global__ __launch_bounds__(256) void iaf_prep_kernel(PrepArgs a) {
     __shared__ float red[16][17];
     __shared__ float s_scale[16];
@@ -90,290 +86,49 @@ __global__ __launch_bounds__(256) void iaf_prep_kernel(PrepArgs a) {
     const int oo = threadIdx.x & 15, cs = threadIdx.x >> 4;
     const int o = src_tile * 16 + oo;
     const int n_out = L.cout_each, n_in = L.cin;
+    const float gval = L.g[which][o], bval = L.b[which][o];
 
-    // pass 1: sum of squares of the masked filter over (taps, c_in)   (layers.py:57,60)
+    // pass 1: fetch + mask (layers.py:57), sum of squares over (taps, c_in) (layers.py:60)
+    float v[NTAPS][PREP_MAXI];
     float ss = 0.f;
-    for (int t = 0; t < NTAPS; ++t) {
-        const int kh = (t == 0 || t == 1) ? 1 : 2;
-        const int kw = (t == 0) ? 1 : (t == 1 ? 2 : t - 2);
-        const float* Vt = V + (size_t)(kh * 3 + kw) * n_in * n_out;
-        for (int ci = cs; ci < n_in; ci += 16) {
-            const bool live = (t != 0) || made_live(ci, o, n_in, n_out, L.zerodiag);
-            const float v = live ? Vt[(size_t)ci * n_out + o] : 0.f;
-            ss += v * v;
+#pragma unroll
+    for (int it = 0; it < PREP_MAXI; ++it) {
+        const int ci = cs + 16 * it;
+        const int cic = ci < n_in ? ci : n_in - 1;
+        const float in_range = ci < n_in ? 1.f : 0.f;
+        const float centre = made_live(cic, o, n_in, n_out, L.zerodiag) ? in_range : 0.f;
+#pragma unroll
+        for (int t = 0; t < NTAPS; ++t) {
+            const int kh = (t == 0 || t == 1) ? 1 : 2;
+            const int kw = (t == 0) ? 1 : (t == 1 ? 2 : t - 2);
+            const float raw = V[((size_t)(kh * 3 + kw) * n_in + cic) * n_out + o];
+            v[t][it] = raw * (t == 0 ? centre : in_range);
         }
     }
+#pragma unroll
+    for (int it = 0; it < PREP_MAXI; ++it)
+#pragma unroll
+        for (int t = 0; t < NTAPS; ++t) ss += v[t][it] * v[t][it];
     red[cs][oo] = ss;
     __syncthreads();
     if (cs == 0) {
         float tot = 0.f;
         for (int i = 0; i < 16; ++i) tot += red[i][oo];
         // w = exp(g) * v / sqrt(max(sum v^2, 1e-12))
-        s_scale[oo] = expf(L.g[which][o]) / sqrtf(fmaxf(tot, 1e-12f));
-        L.bias[gt * 16 + oo] = L.b[which][o];
+        s_scale[oo] = expf(gval) / sqrtf(fmaxf(tot, 1e-12f));
+        L.bias[gt * 16 + oo] = bval;
     }
     __syncthreads();
     const float scale = s_scale[oo];
-    // pass 2: write fragment-ordered weights.  lane = kk*16+oo holds channels chunk*16+4kk+{0..3}.
-    for (int t = 0; t < NTAPS; ++t) {
-        const int kh = (t == 0 || t == 1) ? 1 : 2;
-        const int kw = (t == 0) ? 1 : (t == 1 ? 2 : t - 2);
-        const float* Vt = V + (size_t)(kh * 3 + kw) * n_in * n_out;
-        for (int ci = cs; ci < n_in; ci += 16) {
-            const bool live = (t != 0) || made_live(ci, o, n_in, n_out, L.zerodiag);
-            const float v = live ? Vt[(size_t)ci * n_out + o] * scale : 0.f;
-            const int chunk = ci >> 4, kk = (ci & 15) >> 2, jj = ci & 3;
-            L.wp[((((size_t)chunk * NTAPS + t) * L.ncot + gt) * 64 + kk * 16 + oo) * 4 + jj] = v;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// masked 3x3 conv as implicit GEMM on v_mfma_f32_16x16x4_f32
-// ---------------------------------------------------------------------------------------------
-#define EPI_HIDDEN 0   // y = elu(acc + bias [+ ctx (+ ctx2)])  -> pixel-major scratch
-#define EPI_OUT 1      // output pair (mean, logsd) -> NCHW; mode selects raw / IAF step / posterior
-
-#define MODE_RAW 0        // out0 = m_raw, out1 = s_raw                         (layers.py:166)
-#define MODE_IAF 1        // out0 = (z-0.1m)/exp(0.1s), out1 = 0.1s             (tf_train.py:70-72)
-#define MODE_POSTERIOR 2  // MODE_IAF on z0 rebuilt from the posterior inputs, plus kl elements
-
-#define IN_PIXMAJOR 0     // x is [P][c_in] scratch written by a previous EPI_HIDDEN
-#define IN_NCHW 1         // x is an NCHW tensor (z)
-#define IN_POSTERIOR 2    // x = z0 = (qm+rm) + exp(ql+rl)*eps computed on the fly (tf_train.py:57,63)
-
-struct ConvP {
-    const float* x;       // IN_PIXMAJOR / IN_NCHW input
-    const float* wp;      // packed weights
-    const float* bias;    // packed bias
-    const int* lim;       // per packed co-tile: number of live 16-channel chunks of the centre tap
-    const float* ctx;     // EPI_HIDDEN: optional NCHW context  [B,cout,H,W]
-    const float* ctx2;    // EPI_HIDDEN: optional second context (up_context + down_context)
-    float* y;             // EPI_HIDDEN output, pixel-major [P][cout]
-    const float* zin;     // EPI_OUT MODE_IAF: z  [B,n_z,H,W]
-    float* out0;          // EPI_OUT: z_new / m_raw
-    float* out1;          // EPI_OUT: logsd / s_raw
-    // posterior inputs (IN_POSTERIOR staging and MODE_POSTERIOR epilogue), all [B,n_z,H,W]
-    const float* qm; const float* ql; const float* rm; const float* rl; const float* pm; const float* pl;
-    const float* eps;
-    float* kl_elem;       // MODE_POSTERIOR: logqs - logps [B,n_z,H,W]
-    int B, H, W, HW, P;   // P = B*H*W
-    int cin, cout;        // GEMM K channels, GEMM N (EPI_OUT: 2*n_z)
-    int nchunk, ncot;
-    int cp;               // padded channel stride of the LDS tile (floats), == cin + 8
-    int nslot;            // staged pixel slots = TM + W + 1 (one-sided halo)
-    int lpp_log2;         // lanes per pixel for pixel-major staging
-    int mode;
-};
-
-__device__ __forceinline__ float elu_f(float v) { return v > 0.f ? v : expm1f(v); }
-
-template <int NT>
-struct StepBuf {
-    f32x4 w[NT];
-    f32x4 x;
-};
-
-template <int NT, int PXT, int WCO, int KS, int INMODE, int EPI>
-__global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int TM = 16 * PXT;
-    constexpr int NTHREADS = 64 * PXT * WCO * KS;
-    constexpr int WPK = PXT * WCO;   // waves per K slice
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int pw = wave % PXT, cw = (wave / PXT) % WCO, kh = wave / WPK;
-    const int P0 = blockIdx.x * TM;
-    const int cot0 = (blockIdx.y * WCO + cw) * NT;
-    const int HW = p.HW, W = p.W;
-
-    // ---------------- stage the activation tile: slots [P0, P0+nslot) x cin, + one zero slot
-    {
-        float* zslot = smem + (size_t)p.nslot * p.cp;
-        for (int i = tid; i < p.cp; i += NTHREADS) zslot[i] = 0.f;
-        const int nq = p.cin >> 2;
-        if (INMODE == IN_PIXMAJOR) {
-            const int lpp = 1 << p.lpp_log2;
-            for (int s = tid >> p.lpp_log2; s < p.nslot; s += (NTHREADS >> p.lpp_log2)) {
-                const int Pg = P0 + s;
-                for (int q = tid & (lpp - 1); q < nq; q += lpp) {
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (Pg < p.P) v = *(const f32x4*)(p.x + (size_t)Pg * p.cin + 4 * q);
-                    *(f32x4*)(smem + (size_t)s * p.cp + 4 * q) = v;
-                }
-            }
-        } else {
-            for (int idx = tid; idx < p.nslot * nq; idx += NTHREADS) {
-                const int q = idx / p.nslot, s = idx - q * p.nslot;   // s fastest: coalesced along pixels
-                const int Pg = P0 + s;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (Pg < p.P) {
-                    const int b = Pg / HW, pp = Pg - b * HW;
-                    const size_t base = ((size_t)b * p.cin + 4 * q) * HW + pp;
-                    if (INMODE == IN_NCHW) {
-                        v.x = p.x[base]; v.y = p.x[base + HW]; v.z = p.x[base + 2 * (size_t)HW]; v.w = p.x[base + 3 * (size_t)HW];
-                    } else {   // z0 = (qm+rm) + exp(0.5*2*(ql+rl)) * eps      (tf_train.py:57,63; distributions.py:21)
+    // pass 2: write fragment-ordered weights.  lane = kk*16+oo holds channels chunk*16+4kk+{0..3};
+    // ci = cs + 16*it  ->  chunk = it, kk = cs>>2, jj = cs&3: a wave writes 256 contiguous bytes.
+    const int kk = cs >> 2, jj = cs & 3;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const size_t i = base + (size_t)r * HW;
-                            v[r] = (p.qm[i] + p.rm[i]) + expf(0.5f * (2.f * (p.ql[i] + p.rl[i]))) * p.eps[i];
-                        }
-                    }
-                }
-                *(f32x4*)(smem + (size_t)s * p.cp + 4 * q) = v;
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---------------- per-lane geometry: MFMA B operand lane = (pixel l&15, k-slot l>>4)
-    const int pl = lane & 15, kk = lane >> 4;
-    const int Pl = P0 + pw * 16 + pl;
-    const bool pvalid = Pl < p.P;
-    const int bimg = Pl / HW, pp = Pl - bimg * HW;
-    const int h = pp / W, w = pp - h * W;
-    int xa[NTAPS];   // float offset into smem of this lane's 4 channels for each tap (chunk 0)
+    for (int it = 0; it < PREP_MAXI; ++it) {
+        if (it < L.nchunk) {
 #pragma unroll
-    for (int t = 0; t < NTAPS; ++t) {
-        const int dh = c_tap_dh[t], dw = c_tap_dw[t];
-        const bool v = pvalid && (h + dh < p.H) && (w + dw >= 0) && (w + dw < W);
-        const int slot = pw * 16 + pl + dh * W + dw;
-        xa[t] = (v ? slot : p.nslot) * p.cp + 4 * kk;
-    }
-    int lim[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) lim[t] = p.lim ? __builtin_amdgcn_readfirstlane(p.lim[cot0 + t]) : p.nchunk;
-
-    const f32x4* wq = (const f32x4*)p.wp + (size_t)cot0 * 64 + lane;
-    const size_t wstep = (size_t)p.ncot * 64;   // f32x4 per (chunk,tap) step
-    const int c_begin = (kh * p.nchunk) / KS, c_end = ((kh + 1) * p.nchunk) / KS;
-
-    f32x4 acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    StepBuf<NT> b0, b1;
-    auto load_step = [&](StepBuf<NT>& bf, int chunk, int tap, int xoff) {
-        const f32x4* q = wq + (size_t)(chunk * NTAPS + tap) * wstep;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) bf.w[t] = q[t * 64];
-        bf.x = *(const f32x4*)(smem + xoff + chunk * 16);
-    };
-    auto compute_step = [&](const StepBuf<NT>& bf, int chunk, bool centre) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            if (centre && chunk >= lim[t]) continue;   // dead 16x16 block of the triangular centre tap
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf.w[t][j], bf.x[j], acc[t], 0, 0, 0);
-        }
-    };
-
-    // flat (chunk, tap) pipeline, one step of register prefetch; NTAPS is odd so the buffer parity
-    // flips every chunk -> process chunks in pairs with static buffer naming.
-    if (c_begin < c_end) {
-        load_step(b0, c_begin, 0, xa[0]);
-        int c = c_begin;
-        for (; c + 1 < c_end; c += 2) {
-            load_step(b1, c, 1, xa[1]);      compute_step(b0, c, true);
-            load_step(b0, c, 2, xa[2]);      compute_step(b1, c, false);
-            load_step(b1, c, 3, xa[3]);      compute_step(b0, c, false);
-            load_step(b0, c, 4, xa[4]);      compute_step(b1, c, false);
-            load_step(b1, c + 1, 0, xa[0]);  compute_step(b0, c, false);
-            load_step(b0, c + 1, 1, xa[1]);  compute_step(b1, c + 1, true);
-            load_step(b1, c + 1, 2, xa[2]);  compute_step(b0, c + 1, false);
-            load_step(b0, c + 1, 3, xa[3]);  compute_step(b1, c + 1, false);
-            load_step(b1, c + 1, 4, xa[4]);  compute_step(b0, c + 1, false);
-            if (c + 2 < c_end) load_step(b0, c + 2, 0, xa[0]);
-            compute_step(b1, c + 1, false);
-        }
-        if (c < c_end) {   // odd tail chunk; b0 holds (c, tap 0)
-            load_step(b1, c, 1, xa[1]);  compute_step(b0, c, true);
-            load_step(b0, c, 2, xa[2]);  compute_step(b1, c, false);
-            load_step(b1, c, 3, xa[3]);  compute_step(b0, c, false);
-            load_step(b0, c, 4, xa[4]);  compute_step(b1, c, false);
-            compute_step(b0, c, false);
-        }
-    }
-
-    // ---------------- split-K reduction through LDS
-    if (KS > 1) {
-        float* red = smem + (size_t)(p.nslot + 1) * p.cp;
-        if (kh > 0) {
-            float* r = red + ((size_t)((kh - 1) * WPK + (wave % WPK)) * NT * 4) * 64 + lane;
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) r[(t * 4 + j) * 64] = acc[t][j];
-        }
-        __syncthreads();
-        if (kh == 0) {
-            for (int k = 1; k < KS; ++k) {
-                const float* r = red + ((size_t)((k - 1) * WPK + wave) * NT * 4) * 64 + lane;
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[t][j] += r[(t * 4 + j) * 64];
-            }
-        }
-    }
-    if (kh != 0 || !pvalid) return;
-
-    // ---------------- epilogues.  C/D layout of 16x16 MFMA: lane holds D[row=4*(l>>4)+r][col=l&15]
-    //                  = (co = tile*16 + 4*kk + r, pixel = pl)
-    if (EPI == EPI_HIDDEN) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int co = (cot0 + t) * 16 + 4 * kk;
-            f32x4 v = acc[t] + *(const f32x4*)(p.bias + co);
-            if (p.ctx) {   // x += context  (layers.py:163-164)
-                const size_t cb = ((size_t)bimg * p.cout + co) * HW + pp;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += p.ctx[cb + (size_t)r * HW];
-                if (p.ctx2) {   // context = up_context + down_context (tf_train.py:58)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += p.ctx2[cb + (size_t)r * HW];
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = elu_f(v[r]);   // layers.py:165
-            *(f32x4*)(p.y + (size_t)Pl * p.cout + co) = v;
-        }
-    } else {
-        const int nz = p.cout >> 1;
-#pragma unroll
-        for (int u = 0; u < NT / 2; ++u) {
-            const int gt = cot0 + 2 * u;              // packed tiles (gt, gt+1) = (mean, logsd) of channel group gt/2
-            const int c0 = (gt >> 1) * 16 + 4 * kk;
-            const f32x4 bm = *(const f32x4*)(p.bias + gt * 16 + 4 * kk);
-            const f32x4 bs = *(const f32x4*)(p.bias + (gt + 1) * 16 + 4 * kk);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const size_t idx = ((size_t)bimg * nz + c0 + r) * HW + pp;
-                const float m_raw = acc[2 * u][r] + bm[r];
-                const float s_raw = acc[2 * u + 1][r] + bs[r];
-                if (p.mode == MODE_RAW) {
-                    p.out0[idx] = m_raw;
-                    p.out1[idx] = s_raw;
-                } else if (p.mode == MODE_IAF) {
-                    const float m = m_raw * 0.1f, s = s_raw * 0.1f;        // tf_train.py:70
-                    p.out0[idx] = (p.zin[idx] - m) / expf(s);              // tf_train.py:71
-                    p.out1[idx] = s;                                        // tf_train.py:72 (logqs += s)
-                } else {
-                    const float m = m_raw * 0.1f, s = s_raw * 0.1f;
-                    const float mean = p.qm[idx] + p.rm[idx];               // tf_train.py:57
-                    const float logvar = 2.f * (p.ql[idx] + p.rl[idx]);
-                    const float z0 = mean + expf(0.5f * logvar) * p.eps[idx];                           // :63
-                    const float d0 = z0 - mean;
-                    float logqs = -0.5f * (1.8378770664093453f + logvar + d0 * d0 / expf(logvar));     // :68
-                    const float z = (z0 - m) / expf(s);                                                 // :71
-                    logqs += s;                                                                         // :72
-                    const float plv = 2.f * p.pl[idx];                                                  // :56
-                    const float d1 = z - p.pm[idx];
-                    const float logps = -0.5f * (1.8378770664093453f + plv + d1 * d1 / expf(plv));      // :73
-                    p.out0[idx] = z;
-                    if (p.out1) p.out1[idx] = s;
-                    p.kl_elem[idx] = logqs - logps;                                                     // :75
-                }
-            }
+            for (int t = 0; t < NTAPS; ++t)
+                L.wp[((((size_t)it * NTAPS + t) * L.ncot + gt) * 64 + kk * 16 + oo) * 4 + jj] = v[t][it] * scale;
         }
     }
 }
@@ -483,8 +238,9 @@ struct GemmLayer {
     float* wp = nullptr;
     float* bias = nullptr;
     int* lim = nullptr;
-    // launch shape
+    // launch shape: fixed by iaf_stack_set_tuning (user_tuned) or chosen per problem size by auto_shape()
     int nt, pxt, wco, ks;
+    bool user_tuned = false;
     double live_macs_per_px, dense_macs_per_px;
 };
 
@@ -495,6 +251,7 @@ struct iaf_stack {
     bool prepared;
     size_t weight_bytes;  // raw V/g/b bytes of the stack (for the algorithmic byte count)
     // optional per-launch event timing of one layer
+    unsigned long long* dbg = nullptr; int dbg_layer = -1;
     int prof_layer = -1, prof_cap = 0, prof_n = 0;
     hipEvent_t* prof_start = nullptr;
     hipEvent_t* prof_stop = nullptr;
@@ -506,52 +263,35 @@ struct iaf_stack {
         if (_e != hipSuccess) return (int)_e;       \
     } while (0)
 
-typedef void (*conv_fn_t)(ConvP);
-
-template <int NT, int PXT, int WCO, int KS>
-static conv_fn_t pick_mode(int inmode, int epi) {
-    if (epi == EPI_HIDDEN) {
-        if (inmode == IN_PIXMAJOR) return iaf_conv_kernel<NT, PXT, WCO, KS, IN_PIXMAJOR, EPI_HIDDEN>;
-        if (inmode == IN_NCHW) return iaf_conv_kernel<NT, PXT, WCO, KS, IN_NCHW, EPI_HIDDEN>;
-        return iaf_conv_kernel<NT, PXT, WCO, KS, IN_POSTERIOR, EPI_HIDDEN>;
-    }
-    if constexpr (NT % 2 == 0) {
-        if (inmode == IN_PIXMAJOR) return iaf_conv_kernel<NT, PXT, WCO, KS, IN_PIXMAJOR, EPI_OUT>;
-        if (inmode == IN_NCHW) return iaf_conv_kernel<NT, PXT, WCO, KS, IN_NCHW, EPI_OUT>;
-        return iaf_conv_kernel<NT, PXT, WCO, KS, IN_POSTERIOR, EPI_OUT>;
-    }
-    return nullptr;
-}
-
-template <int PXT, int WCO, int KS>
-static conv_fn_t pick_nt(int nt, int inmode, int epi) {
-    switch (nt) {
-        case 1: return pick_mode<1, PXT, WCO, KS>(inmode, epi);
-        case 2: return pick_mode<2, PXT, WCO, KS>(inmode, epi);
-        case 3: return pick_mode<3, PXT, WCO, KS>(inmode, epi);
-        case 4: return pick_mode<4, PXT, WCO, KS>(inmode, epi);
-        case 5: return pick_mode<5, PXT, WCO, KS>(inmode, epi);
-    }
-    return nullptr;
-}
+// one translation unit per launch shape (iaf_conv_inst.hip, compiled with -DIAF_PXT/-DIAF_WCO/-DIAF_KS)
+#define IAF_DECL_SHAPE(P, W, K) extern "C" conv_fn_t iaf_pick_conv_##P##_##W##_##K(int nt, int inmode, int epi);
+IAF_DECL_SHAPE(4, 1, 1)
+IAF_DECL_SHAPE(4, 1, 2)
+IAF_DECL_SHAPE(2, 2, 1)
+IAF_DECL_SHAPE(2, 2, 2)
+IAF_DECL_SHAPE(2, 1, 2)
+IAF_DECL_SHAPE(2, 1, 4)
+IAF_DECL_SHAPE(1, 1, 4)
+IAF_DECL_SHAPE(1, 2, 2)
 
 // the launch shapes that are compiled: (pxt, wco, ks)
 static conv_fn_t pick_kernel(int nt, int pxt, int wco, int ks, int inmode, int epi) {
-    if (pxt == 4 && wco == 1 && ks == 1) return pick_nt<4, 1, 1>(nt, inmode, epi);
-    if (pxt == 4 && wco == 1 && ks == 2) return pick_nt<4, 1, 2>(nt, inmode, epi);
-    if (pxt == 2 && wco == 2 && ks == 1) return pick_nt<2, 2, 1>(nt, inmode, epi);
-    if (pxt == 2 && wco == 2 && ks == 2) return pick_nt<2, 2, 2>(nt, inmode, epi);
-    if (pxt == 2 && wco == 1 && ks == 2) return pick_nt<2, 1, 2>(nt, inmode, epi);
-    if (pxt == 2 && wco == 1 && ks == 4) return pick_nt<2, 1, 4>(nt, inmode, epi);
-    if (pxt == 1 && wco == 1 && ks == 4) return pick_nt<1, 1, 4>(nt, inmode, epi);
-    if (pxt == 1 && wco == 2 && ks == 2) return pick_nt<1, 2, 2>(nt, inmode, epi);
+    if (nt < 1 || nt > 5) return nullptr;
+    if (pxt == 4 && wco == 1 && ks == 1) return iaf_pick_conv_4_1_1(nt, inmode, epi);
+    if (pxt == 4 && wco == 1 && ks == 2) return iaf_pick_conv_4_1_2(nt, inmode, epi);
+    if (pxt == 2 && wco == 2 && ks == 1) return iaf_pick_conv_2_2_1(nt, inmode, epi);
+    if (pxt == 2 && wco == 2 && ks == 2) return iaf_pick_conv_2_2_2(nt, inmode, epi);
+    if (pxt == 2 && wco == 1 && ks == 2) return iaf_pick_conv_2_1_2(nt, inmode, epi);
+    if (pxt == 2 && wco == 1 && ks == 4) return iaf_pick_conv_2_1_4(nt, inmode, epi);
+    if (pxt == 1 && wco == 1 && ks == 4) return iaf_pick_conv_1_1_4(nt, inmode, epi);
+    if (pxt == 1 && wco == 2 && ks == 2) return iaf_pick_conv_1_2_2(nt, inmode, epi);
     return nullptr;
 }
 
 static size_t conv_lds_bytes(const GemmLayer& L, int W) {
     const int tm = 16 * L.pxt, nslot = tm + W + 1, cp = L.cin + 8;
     size_t fl = (size_t)(nslot + 1) * cp;
-    if (L.ks > 1) fl += (size_t)(L.ks - 1) * L.pxt * L.wco * L.nt * 256;
+    if (L.ks > 1) fl += (size_t)L.ks * L.pxt * L.wco * L.nt * 256;   // split-K exchange: every wave parks all its tiles
     return fl * sizeof(float);
 }
 
@@ -603,6 +343,7 @@ extern "C" int iaf_stack_create(iaf_stack_t** out, int n_z, int n_h, int depth_a
     if (variant != IAF_VARIANT_TF) return IAF_ERR_UNSUPPORTED;
     if (depth_ar > 0 && !(n_z % n_h == 0 || n_h % n_z == 0)) return IAF_ERR_NOT_MULTIPLE;   // layers.py:116
     if (n_z % 16 != 0 || (depth_ar > 0 && n_h % 16 != 0)) return IAF_ERR_UNSUPPORTED;
+    if (n_z > 16 * PREP_MAXI || n_h > 16 * PREP_MAXI) return IAF_ERR_UNSUPPORTED;
     iaf_stack* s = new (std::nothrow) iaf_stack();
     if (!s) return (int)hipErrorOutOfMemory;
     s->n_z = n_z; s->n_h = n_h; s->depth_ar = depth_ar; s->variant = variant;
@@ -660,6 +401,12 @@ static void prof_free(iaf_stack* s) {
     s->prof_cap = s->prof_n = 0; s->prof_layer = -1;
 }
 
+extern "C" int iaf_stack_set_debug(iaf_stack_t* s, int layer, void* buf) {
+    if (!s) return IAF_ERR_NULL;
+    s->dbg_layer = layer; s->dbg = (unsigned long long*)buf;
+    return IAF_OK;
+}
+
 extern "C" int iaf_stack_profile_enable(iaf_stack_t* s, int layer, int max_samples) {
     if (!s) return IAF_ERR_NULL;
     prof_free(s);
@@ -711,6 +458,7 @@ extern "C" int iaf_stack_set_tuning(iaf_stack_t* s, int layer, int nt, int pxt, 
     if (!pick_kernel(nt, pxt, wco, ks, IN_PIXMAJOR, is_out ? EPI_OUT : EPI_HIDDEN)) return IAF_ERR_UNSUPPORTED;
     if (L.nchunk < ks) return IAF_ERR_UNSUPPORTED;
     L.nt = nt; L.pxt = pxt; L.wco = wco; L.ks = ks;
+    L.user_tuned = true;
     return IAF_OK;
 }
 
@@ -774,7 +522,40 @@ static int carve_ws(const iaf_stack_t* s, int B, int H, int W, void* ws, size_t 
     return IAF_OK;
 }
 
+// Launch-shape model.  At the BASELINE batch sizes the convs are latency-bound (a few thousand pixels for
+// 256 CUs), so the shape is chosen to minimise the longest per-SIMD MFMA chain:
+//   cycles(wave) = (5*nchunk/ks) steps * nt tiles * 4 MFMA * 32 cycles;  waves sharing a SIMD serialise;
+//   T = rounds over the 256 CUs * (cycles(WG) + fixed prologue/epilogue cost).
+// Ties go to fewer rounds, then less split-K, then bigger tiles (more operand reuse).
+static const int k_shapes[][3] = {{4, 1, 1}, {2, 2, 1}, {4, 1, 2}, {2, 2, 2}, {2, 1, 2}, {1, 2, 2}, {2, 1, 4}, {1, 1, 4}};
+
+static void auto_shape(GemmLayer& L, bool is_out, long long P, int W) {
+    double best = 1e30;
+    int bnt = 0, bs = -1;
+    for (int si = 0; si < 8; ++si) {
+        const int pxt = k_shapes[si][0], wco = k_shapes[si][1], ks = k_shapes[si][2];
+        if (L.nchunk < ks) continue;
+        for (int nt = 5; nt >= 1; --nt) {
+            if (is_out && (nt & 1)) continue;
+            if (L.ncot % (nt * wco) != 0) continue;
+            GemmLayer t = L;
+            t.nt = nt; t.pxt = pxt; t.wco = wco; t.ks = ks;
+            if (conv_lds_bytes(t, W) > 160 * 1024) continue;
+            const double wgs = (double)((P + 16 * pxt - 1) / (16 * pxt)) * (L.ncot / (nt * wco));
+            const double rounds = ceil(wgs / 256.0);
+            const double cyc_wave = (5.0 * L.nchunk / ks) * nt * 128.0;
+            const double waves = pxt * wco * ks;
+            const double cyc_wg = cyc_wave * ceil(waves / 4.0);
+            const double T = rounds * (cyc_wg + 6000.0) + 400.0 * (ks - 1) + 1e-3 * si - 1e-2 * nt;
+            if (T < best) { best = T; bnt = nt; bs = si; }
+        }
+    }
+    if (bs >= 0) { L.nt = bnt; L.pxt = k_shapes[bs][0]; L.wco = k_shapes[bs][1]; L.ks = k_shapes[bs][2]; }
+}
+
 static int launch_conv(const iaf_stack_t* s, int layer, ConvP& p, int inmode, hipStream_t st) {
+    if (!s->L[layer].user_tuned)
+        auto_shape(const_cast<iaf_stack*>(s)->L[layer], layer == s->depth_ar, p.P, p.W);
     const GemmLayer& L = s->L[layer];
     const bool is_out = (layer == s->depth_ar);
     conv_fn_t fn = pick_kernel(L.nt, L.pxt, L.wco, L.ks, inmode, is_out ? EPI_OUT : EPI_HIDDEN);
@@ -784,10 +565,7 @@ static int launch_conv(const iaf_stack_t* s, int layer, ConvP& p, int inmode, hi
     p.cin = L.cin; p.cout = L.cout; p.nchunk = L.nchunk; p.ncot = L.ncot;
     p.cp = L.cin + 8;
     p.nslot = tm + p.W + 1;
-    const int nq = L.cin / 4;
-    int lg = 0;
-    while ((1 << lg) < nq && lg < 6) ++lg;
-    p.lpp_log2 = lg;
+    p.dbg = (s->dbg_layer == layer) ? s->dbg : nullptr;
     const size_t lds = conv_lds_bytes(L, p.W);
     if (lds > 160 * 1024) return IAF_ERR_UNSUPPORTED;
     if (lds > 48 * 1024) {   // raise the dynamic-LDS cap once per kernel (never inside a stream capture)

@@ -118,6 +118,9 @@ int iaf_stack_set_tuning(iaf_stack_t* s, int layer, int nt, int pxt, int wco, in
  * elapsed milliseconds of each sample to ms_out[0..*n_out) and resets the sample counter. */
 int iaf_stack_profile_enable(iaf_stack_t* s, int layer, int max_samples);
 int iaf_stack_profile_read(iaf_stack_t* s, float* ms_out, int capacity, int* n_out);
+/* dev tool: every workgroup of GEMM layer `layer` writes 8 s_memtime stamps (kernel start, tile loads
+ * issued, tile staged, steady loop done, K loop done, end) to buf[wg*8..]; buf = NULL disables. */
+int iaf_stack_set_debug(iaf_stack_t* s, int layer, void* buf);
 /* algorithmic work of one iaf_step_forward call: live (mask-aware) FLOPs and fused bytes
  * (4*(3*n_z+n_h) B/px + weight bytes) */
 int iaf_step_work(const iaf_stack_t* s, int B, int H, int W, double* live_flops, double* dense_flops,

@@ -152,6 +152,8 @@ def test_every_launch_shape_agrees(amd, tune):
     stack.prepare(dev_params(params))
     nt, pxt, wco, ks = tune
     for layer in range(d):
+        if layer == 0 and ks > 2:
+            continue                               # layer 0 has only n_z/16 = 2 K-chunks: keep its default shape
         stack.set_tuning(layer, nt, pxt, wco, ks)
     stack.set_tuning(d, 2, pxt, wco, ks)          # output pair: (mean, logsd) tiles must share a wave -> nt even
     z_new, logsd = stack.iaf_step(dev(z), dev(ctx))
@@ -236,6 +238,10 @@ def test_full_size_batch_independence_bit_exact(amd, H):
     is in -> running samples one at a time must reproduce the batched result BIT-EXACTLY
     (same kernel, same per-pixel reduction order)."""
     stack, _, z, ctx = _cfg2_full(amd, H)
+    # pin the launch shapes: the engine otherwise picks a different split-K (= summation order) for B=1 and B=32
+    stack.set_tuning(0, 5, 4, 1, 1)
+    stack.set_tuning(1, 5, 2, 1, 2)
+    stack.set_tuning(2, 2, 2, 2, 1)
     zf, sf = stack.iaf_step(z, ctx)
     for b in (0, 13, 31):
         zb, sb = stack.iaf_step(z[b:b + 1].contiguous(), ctx[b:b + 1].contiguous())
