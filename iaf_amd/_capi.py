@@ -27,6 +27,9 @@ SIGNATURES = {
     "iaf_stack_create": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "iaf_stack_destroy": (ctypes.c_int, [_vp]),
     "iaf_stack_prepare": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp]),
+    "iaf_prep_batch_create": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.c_int]),
+    "iaf_prep_batch_run": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp]),
+    "iaf_prep_batch_destroy": (ctypes.c_int, [_vp]),
     "iaf_stack_workspace_bytes": (ctypes.c_size_t, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "iaf_ar_multiconv2d_forward": (ctypes.c_int, [_vp, _c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_int,
                                                   ctypes.c_int, ctypes.c_int, _vp, ctypes.c_size_t, _vp]),
@@ -44,6 +47,9 @@ SIGNATURES = {
     "iaf_stack_profile_enable": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
     "iaf_stack_profile_read": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float), ctypes.c_int,
                                               ctypes.POINTER(ctypes.c_int)]),
+    "iaf_step_time_layer": (ctypes.c_int, [_vp, ctypes.c_int, _c_float_p, _c_float_p, _c_float_p, _c_float_p,
+                                           ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_size_t, ctypes.c_int,
+                                           _vp, ctypes.POINTER(ctypes.c_float)]),
     "iaf_stack_set_debug": (ctypes.c_int, [_vp, ctypes.c_int, _vp]),
     "iaf_layer_work": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int] +
                        [ctypes.POINTER(ctypes.c_double)] * 3),

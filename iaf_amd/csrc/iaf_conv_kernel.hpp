@@ -120,7 +120,41 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
     const int c_begin = (kh * p.nchunk) / KS, c_end = ((kh + 1) * p.nchunk) / KS;
     const f32x4* wbase = (const f32x4*)p.wp + (size_t)cot0 * 64;   // wave-uniform; lane offset added per load
     const unsigned ulane = (unsigned)lane;
-    f32x4 wr[R][NT];
+    // ---- weight delivery, two variants:
+    //  * PXT == 1 (every wave has its own co-tiles / K slice): the per-wave register ring described above.
+    //  * PXT  > 1 (the PXT waves of a group need the SAME weight tiles): each 1 KiB tile is fetched ONCE per group
+    //    (round-robin over the waves), parked in a double-buffered LDS chunk buffer and read by all waves with
+    //    ds_read_b128.  The CU's address unit handles one 1 KiB wave-load per ~16 cycles and a wave that is stuck
+    //    issuing a load cannot issue MFMAs; sharing cuts that traffic PXT-fold (measured: 873 -> ~670 cycles/step).
+#ifdef IAF_EXP_FORCE_RING
+    constexpr bool SHARED_W = false;
+#else
+    constexpr bool SHARED_W = (PXT > 1);
+#endif
+    constexpr int NTILE_CH = NTAPS * NT;                       // weight tiles per chunk
+    constexpr int NLD = (NTILE_CH + PXT - 1) / PXT;            // tiles fetched per wave per chunk
+    f32x4 wr[SHARED_W ? 1 : R][NT];
+    f32x4 sr[SHARED_W ? NLD : 1];
+    f32x4* wlds = smem4 + (size_t)(p.nslot + 1) * cp4 + (size_t)(wave / PXT) * (2 * NTILE_CH * 64);   // this group's 2 buffers
+    auto issue_stage = [&](int chunk) {       // my share of chunk's tiles -> registers (clamped index: branch-free)
+        const f32x4* q = wbase + (size_t)chunk * NTAPS * wstep;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            int f = pw + i * PXT;
+            f = f < NTILE_CH ? f : NTILE_CH - 1;
+            const int tp = f / NT, t = f - tp * NT;
+            sr[i] = (q + (size_t)tp * wstep + t * 64)[ulane];
+        }
+    };
+    auto write_stage = [&](int buf) {         // registers -> LDS chunk buffer `buf`
+        f32x4* wb = wlds + buf * (NTILE_CH * 64) + lane;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            int f = pw + i * PXT;
+            f = f < NTILE_CH ? f : NTILE_CH - 1;
+            wb[f * 64] = sr[i];
+        }
+    };
     auto ring_prologue = [&](auto i) {
         constexpr int I = decltype(i)::value;
         if (c_begin + I < c_end) {
@@ -133,7 +167,11 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
             }
         }
     };
-    ring_prologue(std::integral_constant<int, 0>{});   // chunk 0 now; chunks 1..RCH-1 after the tile is staged
+    if constexpr (SHARED_W) {
+        if (c_begin < c_end) issue_stage(c_begin);
+    } else {
+        ring_prologue(std::integral_constant<int, 0>{});   // chunk 0 now; chunks 1..RCH-1 after the tile is staged
+    }
     IAF_STAMP(1);
 
     // (3) per-lane geometry: MFMA B operand lane = (pixel l&15, k-slot l>>4)
@@ -205,7 +243,12 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
             }
         }
     }
-    static_for<RCH - 1>([&](auto i) { ring_prologue(std::integral_constant<int, decltype(i)::value + 1>{}); });
+    if constexpr (SHARED_W) {
+        if (c_begin < c_end) write_stage(0);
+        if (c_begin + 1 < c_end) issue_stage(c_begin + 1);
+    } else {
+        static_for<RCH - 1>([&](auto i) { ring_prologue(std::integral_constant<int, decltype(i)::value + 1>{}); });
+    }
     __syncthreads();
     IAF_STAMP(2);
 
@@ -245,6 +288,57 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
 #pragma unroll
     for (int t = 0; t < NACC; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    if constexpr (SHARED_W) {
+        // ---- shared-weight K loop: one chunk per iteration, one barrier per chunk.
+        //   LDS buffer (ci & 1) holds chunk ci; registers sr hold my share of chunk ci+1 (in flight since the middle
+        //   of iteration ci-1).  Mid-iteration: sr -> other buffer (free: everyone left it at the last barrier),
+        //   then fetch my share of chunk ci+2.
+        const int nch = c_end - c_begin;
+        // operands (x fragment + NT weight fragments) are double-buffered across taps: while tap tp's MFMAs run,
+        // tap tp+1's ds_read_b128s are already in flight.  MODE: 0 = steady (park chunk+1, fetch chunk+2 in the
+        // middle), 1 = park only, 2 = last chunk.
+        f32x4 opx[2], opw[2][NT];
+        auto read_ops = [&](int slot, int tp, int chunk, const f32x4* wb) {
+            opx[slot] = smem4[xa[tp] + chunk * 4];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) opw[slot][t] = wb[(tp * NT + t) * 64];
+        };
+        auto compute_chunk = [&](auto mode_c, int chunk, int buf) {
+            constexpr int MODE = decltype(mode_c)::value;
+            const f32x4* wb = wlds + buf * (NTILE_CH * 64) + lane;
+            read_ops(0, 0, chunk, wb);
+#pragma unroll
+            for (int tp = 0; tp < NTAPS; ++tp) {
+                if (tp + 1 < NTAPS) read_ops((tp + 1) & 1, tp + 1, chunk, wb);
+                if (tp == 2 && MODE <= 1) write_stage(buf ^ 1);
+                if (tp == 2 && MODE == 0) issue_stage(chunk + 2);
+                __builtin_amdgcn_sched_barrier(0);   // hipcc otherwise sinks the prefetch reads down to their first use
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const int a = (NT == 1) ? (j & 1) : t;
+                        acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(opw[tp & 1][t][j], opx[tp & 1][j], acc[a], 0, 0, 0);
+                    }
+            }
+        };
+        using M0 = std::integral_constant<int, 0>;
+        using M1 = std::integral_constant<int, 1>;
+        using M2 = std::integral_constant<int, 2>;
+        int ci = 0;
+        for (; ci + 2 < nch; ++ci) {                 // steady state
+            compute_chunk(M0{}, c_begin + ci, ci & 1);
+            __syncthreads();
+        }
+        IAF_STAMP(3);
+        prefetch_epilogue();
+        if (ci + 1 < nch) {                          // second-to-last chunk: park the last one, nothing left to fetch
+            compute_chunk(M1{}, c_begin + ci, ci & 1);
+            __syncthreads();
+            ++ci;
+        }
+        if (ci < nch) compute_chunk(M2{}, c_begin + ci, ci & 1);
+    } else {
     // x operand: one ds_read_b128 per step, double-buffered one step ahead (xn is always the NEXT step's operand)
     f32x4 xn = smem4[xa[0] + c_begin * 4];
     auto chunk_body = [&](auto slot_c, auto refill_t4, auto refill_own, int chunk) {
@@ -304,6 +398,7 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
             if (cc < c_end) chunk_body(i, F{}, F{}, cc);
         });
     }
+    }
     if (NT == 1) acc[0] += acc[1];
     IAF_STAMP(4);
 
@@ -311,7 +406,8 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
     // C/D layout of the 16x16 MFMA: lane holds D[row = 4*(l>>4)+r][col = l&15] = (co = tile*16 + 4*kk + r, pixel pl)
     f32x4 val[NMY * (EPI == EPI_HIDDEN ? 1 : 2)];
     if (KS > 1) {
-        float* red = (float*)(smem4 + (size_t)(p.nslot + 1) * cp4);
+        float* red = (float*)(smem4 + (size_t)(p.nslot + 1) * cp4);   // aliases the (now dead) shared-weight buffers
+        if (SHARED_W) __syncthreads();                                // ... once every wave has left its K loop
         // layout [group = wave % WPK][k slice][tile][4][64 lanes]: conflict-free, every wave writes all its tiles
         float* wbuf = red + ((size_t)((wave % WPK) * KS + kh) * NT * 4) * 64 + lane;
 #pragma unroll

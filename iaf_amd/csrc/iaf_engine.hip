@@ -55,6 +55,11 @@ __host__ __device__ static inline bool made_live(int i, int o, int n_in, int n_o
 // ---------------------------------------------------------------------------------------------
 // weight prep kernel: one workgroup per packed 16-channel output tile
 // ---------------------------------------------------------------------------------------------
+
+// Work split: one workgroup per (packed 16-channel output tile); thread (oo = tid&15, cs = tid>>4) owns output
+// channel o = tile*16+oo and input channels ci = cs, cs+16, ...  All of its 5*NCH filter taps are fetched in ONE
+// batch of independent, branch-free loads, kept in registers for the second pass.  NCH (= n_in/16) is a template
+// parameter so that exactly the needed loads are issued.
 struct PrepLayer {
     const float* V[2];
     const float* g[2];
@@ -68,18 +73,8 @@ struct PrepArgs {
     int nlayers;
 };
 
-// Work split: thread (oo = tid&15, cs = tid>>4) owns output channel o = tile*16+oo and input channels
-// ci = cs, cs+16, ...  All of its 5*ceil(n_in/16) filter taps are fetched in ONE batch of independent,
-// branch-free loads (clamped address + mask multiply), kept in registers for the second pass.
-#define PREP_MAXI 16   // n_in <= 256
-__global__ __launch_bounds__(256) void iaf_prep_kernel(PrepArgs a) {
-    __shared__ float red[16][17];
-    __shared__ float s_scale[16];
-    int li = 0;
-    for (int i = 1; i < a.nlayers; ++i)
-        if ((int)blockIdx.x >= a.L[i].tile_begin) li = i;
-    const PrepLayer& L = a.L[li];
-    const int gt = blockIdx.x - L.tile_begin;            // packed tile inside this GEMM layer
+template <int NCH>
+__device__ __forceinline__ void prep_tile(const PrepLayer& L, int gt, float (*red)[17], float* s_scale) {
     const int which = (L.npair == 2) ? (gt & 1) : 0;     // output pair: even tiles = mean, odd = logsd
     const int src_tile = (L.npair == 2) ? (gt >> 1) : gt;
     const float* __restrict__ V = L.V[which];
@@ -89,26 +84,24 @@ __global__ __launch_bounds__(256) void iaf_prep_kernel(PrepArgs a) {
     const float gval = L.g[which][o], bval = L.b[which][o];
 
     // pass 1: fetch + mask (layers.py:57), sum of squares over (taps, c_in) (layers.py:60)
-    float v[NTAPS][PREP_MAXI];
-    float ss = 0.f;
+    float v[NTAPS][NCH];
 #pragma unroll
-    for (int it = 0; it < PREP_MAXI; ++it) {
+    for (int it = 0; it < NCH; ++it) {
         const int ci = cs + 16 * it;
-        const int cic = ci < n_in ? ci : n_in - 1;
-        const float in_range = ci < n_in ? 1.f : 0.f;
-        const float centre = made_live(cic, o, n_in, n_out, L.zerodiag) ? in_range : 0.f;
 #pragma unroll
         for (int t = 0; t < NTAPS; ++t) {
             const int kh = (t == 0 || t == 1) ? 1 : 2;
             const int kw = (t == 0) ? 1 : (t == 1 ? 2 : t - 2);
-            const float raw = V[((size_t)(kh * 3 + kw) * n_in + cic) * n_out + o];
-            v[t][it] = raw * (t == 0 ? centre : in_range);
+            v[t][it] = V[((size_t)(kh * 3 + kw) * n_in + ci) * n_out + o];
         }
     }
+    float ss = 0.f;
 #pragma unroll
-    for (int it = 0; it < PREP_MAXI; ++it)
+    for (int it = 0; it < NCH; ++it) {
+        if (!made_live(cs + 16 * it, o, n_in, n_out, L.zerodiag)) v[0][it] = 0.f;   // centre tap: channel MADE mask
 #pragma unroll
         for (int t = 0; t < NTAPS; ++t) ss += v[t][it] * v[t][it];
+    }
     red[cs][oo] = ss;
     __syncthreads();
     if (cs == 0) {
@@ -124,13 +117,52 @@ __global__ __launch_bounds__(256) void iaf_prep_kernel(PrepArgs a) {
     // ci = cs + 16*it  ->  chunk = it, kk = cs>>2, jj = cs&3: a wave writes 256 contiguous bytes.
     const int kk = cs >> 2, jj = cs & 3;
 #pragma unroll
-    for (int it = 0; it < PREP_MAXI; ++it) {
-        if (it < L.nchunk) {
+    for (int it = 0; it < NCH; ++it)
 #pragma unroll
-            for (int t = 0; t < NTAPS; ++t)
-                L.wp[((((size_t)it * NTAPS + t) * L.ncot + gt) * 64 + kk * 16 + oo) * 4 + jj] = v[t][it] * scale;
-        }
+        for (int t = 0; t < NTAPS; ++t)
+            L.wp[((((size_t)it * NTAPS + t) * L.ncot + gt) * 64 + kk * 16 + oo) * 4 + jj] = v[t][it] * scale;
+}
+
+#define PREP_MAXI 16   // n_in <= 256
+template <int DUMMY = 0>
+__device__ __forceinline__ void prep_dispatch(const PrepLayer& L, int gt, float (*red)[17], float* s_scale) {
+    switch (L.nchunk) {
+        case 1: prep_tile<1>(L, gt, red, s_scale); break;
+        case 2: prep_tile<2>(L, gt, red, s_scale); break;
+        case 3: prep_tile<3>(L, gt, red, s_scale); break;
+        case 4: prep_tile<4>(L, gt, red, s_scale); break;
+        case 5: prep_tile<5>(L, gt, red, s_scale); break;
+        case 6: prep_tile<6>(L, gt, red, s_scale); break;
+        case 7: prep_tile<7>(L, gt, red, s_scale); break;
+        case 8: prep_tile<8>(L, gt, red, s_scale); break;
+        case 9: prep_tile<9>(L, gt, red, s_scale); break;
+        case 10: prep_tile<10>(L, gt, red, s_scale); break;
+        case 11: prep_tile<11>(L, gt, red, s_scale); break;
+        case 12: prep_tile<12>(L, gt, red, s_scale); break;
+        case 13: prep_tile<13>(L, gt, red, s_scale); break;
+        case 14: prep_tile<14>(L, gt, red, s_scale); break;
+        case 15: prep_tile<15>(L, gt, red, s_scale); break;
+        case 16: prep_tile<16>(L, gt, red, s_scale); break;
     }
+}
+
+// many stacks in one launch: descriptors live in device memory; tile2layer maps a workgroup to its GEMM layer
+__global__ __launch_bounds__(256) void iaf_prep_batch_kernel(const PrepLayer* __restrict__ layers,
+                                                            const int* __restrict__ tile2layer) {
+    __shared__ float red[16][17];
+    __shared__ float s_scale[16];
+    const PrepLayer L = layers[tile2layer[blockIdx.x]];
+    prep_dispatch(L, blockIdx.x - L.tile_begin, red, s_scale);
+}
+
+__global__ __launch_bounds__(256) void iaf_prep_kernel(PrepArgs a) {
+    __shared__ float red[16][17];
+    __shared__ float s_scale[16];
+    int li = 0;
+    for (int i = 1; i < a.nlayers; ++i)
+        if ((int)blockIdx.x >= a.L[i].tile_begin) li = i;
+    const PrepLayer& L = a.L[li];
+    prep_dispatch(L, blockIdx.x - L.tile_begin, red, s_scale);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -291,7 +323,10 @@ static conv_fn_t pick_kernel(int nt, int pxt, int wco, int ks, int inmode, int e
 static size_t conv_lds_bytes(const GemmLayer& L, int W) {
     const int tm = 16 * L.pxt, nslot = tm + W + 1, cp = L.cin + 8;
     size_t fl = (size_t)(nslot + 1) * cp;
-    if (L.ks > 1) fl += (size_t)L.ks * L.pxt * L.wco * L.nt * 256;   // split-K exchange: every wave parks all its tiles
+    size_t wbuf = 0, red = 0;
+    if (L.pxt > 1) wbuf = (size_t)L.wco * L.ks * 2 * NTAPS * L.nt * 256;   // shared weights: 2 chunk buffers per wave group
+    if (L.ks > 1) red = (size_t)L.ks * L.pxt * L.wco * L.nt * 256;          // split-K exchange (aliases the weight buffers)
+    fl += wbuf > red ? wbuf : red;
     return fl * sizeof(float);
 }
 
@@ -488,6 +523,91 @@ extern "C" int iaf_stack_prepare(iaf_stack_t* s, const float* const* V, const fl
     return IAF_OK;
 }
 
+// ---- batched prepare: all stacks of a model in ONE launch (weights of every layer are known at step start)
+struct iaf_prep_batch {
+    int n;
+    iaf_stack** stacks;
+    int nlayers_total, ntiles;
+    PrepLayer* h_layers;   // pinned; read by the async copy (also when a captured graph replays)
+    PrepLayer* d_layers;
+    int* d_tile2layer;
+};
+
+extern "C" int iaf_prep_batch_destroy(iaf_prep_batch_t* b) {
+    if (!b) return IAF_ERR_NULL;
+    if (b->h_layers) (void)hipHostFree(b->h_layers);
+    if (b->d_layers) (void)hipFree(b->d_layers);
+    if (b->d_tile2layer) (void)hipFree(b->d_tile2layer);
+    free(b->stacks);
+    delete b;
+    return IAF_OK;
+}
+
+extern "C" int iaf_prep_batch_create(iaf_prep_batch_t** out, iaf_stack_t* const* stacks, int n) {
+    if (!out || !stacks) return IAF_ERR_NULL;
+    *out = nullptr;
+    if (n <= 0) return IAF_ERR_SHAPE;
+    iaf_prep_batch* b = new (std::nothrow) iaf_prep_batch();
+    if (!b) return (int)hipErrorOutOfMemory;
+    memset(b, 0, sizeof(*b));
+    b->n = n;
+    b->stacks = (iaf_stack**)calloc(n, sizeof(iaf_stack*));
+    int nl = 0, nt = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!stacks[i]) { iaf_prep_batch_destroy(b); return IAF_ERR_NULL; }
+        b->stacks[i] = stacks[i];
+        for (int l = 0; l < stacks[i]->nlayers; ++l) { nl++; nt += stacks[i]->L[l].ncot; }
+    }
+    b->nlayers_total = nl; b->ntiles = nt;
+    int* t2l = (int*)malloc(sizeof(int) * nt);
+    int rc;
+    if ((rc = (int)hipHostMalloc((void**)&b->h_layers, sizeof(PrepLayer) * nl)) != 0 ||
+        (rc = (int)hipMalloc((void**)&b->d_layers, sizeof(PrepLayer) * nl)) != 0 ||
+        (rc = (int)hipMalloc((void**)&b->d_tile2layer, sizeof(int) * nt)) != 0) {
+        free(t2l); iaf_prep_batch_destroy(b); return rc;
+    }
+    memset(b->h_layers, 0, sizeof(PrepLayer) * nl);
+    int li = 0, tile = 0;
+    for (int i = 0; i < n; ++i)
+        for (int l = 0; l < stacks[i]->nlayers; ++l, ++li) {
+            const GemmLayer& L = stacks[i]->L[l];
+            PrepLayer& P = b->h_layers[li];
+            P.wp = L.wp; P.bias = L.bias;
+            P.cin = L.cin; P.cout_each = L.cout / L.npair; P.ncot = L.ncot; P.nchunk = L.nchunk;
+            P.zerodiag = L.zerodiag; P.npair = L.npair; P.tile_begin = tile;
+            for (int t = 0; t < L.ncot; ++t) t2l[tile++] = li;
+        }
+    rc = (int)hipMemcpy(b->d_tile2layer, t2l, sizeof(int) * nt, hipMemcpyHostToDevice);
+    free(t2l);
+    if (rc) { iaf_prep_batch_destroy(b); return rc; }
+    *out = b;
+    return IAF_OK;
+}
+
+extern "C" int iaf_prep_batch_run(iaf_prep_batch_t* b, const float* const* V, const float* const* g,
+                                  const float* const* bias, void* stream) {
+    if (!b || !V || !g || !bias) return IAF_ERR_NULL;
+    int li = 0, ci = 0;   // ci: running conv index over all stacks (depth_ar + 2 convs per stack)
+    for (int i = 0; i < b->n; ++i) {
+        const iaf_stack* s = b->stacks[i];
+        for (int l = 0; l < s->nlayers; ++l, ++li) {
+            PrepLayer& P = b->h_layers[li];
+            const int np = s->L[l].npair;
+            for (int e = 0; e < np; ++e) {
+                if (!V[ci + l + e] || !g[ci + l + e] || !bias[ci + l + e]) return IAF_ERR_NULL;
+                P.V[e] = V[ci + l + e]; P.g[e] = g[ci + l + e]; P.b[e] = bias[ci + l + e];
+            }
+        }
+        ci += s->depth_ar + 2;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(b->d_layers, b->h_layers, sizeof(PrepLayer) * b->nlayers_total, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(iaf_prep_batch_kernel, dim3(b->ntiles), dim3(256), 0, st, b->d_layers, b->d_tile2layer);
+    HIP_TRY(hipGetLastError());
+    for (int i = 0; i < b->n; ++i) b->stacks[i]->prepared = true;
+    return IAF_OK;
+}
+
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 extern "C" size_t iaf_stack_workspace_bytes(const iaf_stack_t* s, int B, int H, int W) {
@@ -594,25 +714,74 @@ static int check_dims(const iaf_stack_t* s, int B, int H, int W) {
     return IAF_OK;
 }
 
-// runs the depth_ar hidden convs + the output pair.  mode selects the final epilogue.
-static int run_stack(iaf_stack_t* s, ConvP base, int first_inmode, const float* ctx, const float* ctx2, const Ws& ws,
-                     hipStream_t st) {
+// the depth_ar hidden convs + the output pair as launch descriptors.  mode (in base) selects the final epilogue.
+struct Launch { int layer; ConvP p; int inmode; };
+static int build_stack(iaf_stack_t* s, ConvP base, int first_inmode, const float* ctx, const float* ctx2, const Ws& ws,
+                       Launch* out) {
     const float* cur = base.x;
-    int inmode = first_inmode;
+    int inmode = first_inmode, n = 0;
     for (int l = 0; l < s->depth_ar; ++l) {
         ConvP p = base;
         p.x = cur;
         p.ctx = (l == 0) ? ctx : nullptr;       // context only after the first conv (layers.py:163)
         p.ctx2 = (l == 0) ? ctx2 : nullptr;
         p.y = ws.hbuf[l & 1];
-        int rc = launch_conv(s, l, p, inmode, st);
-        if (rc) return rc;
+        out[n++] = Launch{l, p, inmode};
         cur = p.y;
         inmode = IN_PIXMAJOR;
     }
     ConvP p = base;
     p.x = cur;
-    return launch_conv(s, s->depth_ar, p, inmode, st);
+    out[n++] = Launch{s->depth_ar, p, inmode};
+    return n;
+}
+
+static int run_stack(iaf_stack_t* s, ConvP base, int first_inmode, const float* ctx, const float* ctx2, const Ws& ws,
+                     hipStream_t st) {
+    Launch ls[MAX_GEMM_LAYERS];
+    const int n = build_stack(s, base, first_inmode, ctx, ctx2, ws, ls);
+    for (int i = 0; i < n; ++i) {
+        int rc = launch_conv(s, ls[i].layer, ls[i].p, ls[i].inmode, st);
+        if (rc) return rc;
+    }
+    return IAF_OK;
+}
+
+extern "C" int iaf_step_time_layer(iaf_stack_t* s, int layer, const float* z, const float* context, float* z_new,
+                                   float* logsd, int B, int H, int W, void* workspace, size_t workspace_bytes, int reps,
+                                   void* stream, float* avg_ms) {
+    int rc = check_dims(s, B, H, W);
+    if (rc) return rc;
+    if (!z || !z_new || !logsd || !avg_ms || (s->depth_ar > 0 && !context)) return IAF_ERR_NULL;
+    if (layer < 0 || layer >= s->nlayers || reps <= 0) return IAF_ERR_SHAPE;
+    Ws ws;
+    if ((rc = carve_ws(s, B, H, W, workspace, workspace_bytes, &ws))) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    ConvP p;
+    memset(&p, 0, sizeof(p));
+    p.B = B; p.H = H; p.W = W; p.HW = H * W; p.P = B * H * W;
+    p.x = z; p.zin = z; p.out0 = z_new; p.out1 = logsd; p.mode = MODE_IAF;
+    Launch ls[MAX_GEMM_LAYERS];
+    const int n = build_stack(s, p, IN_NCHW, context, nullptr, ws, ls);
+    for (int i = 0; i < n; ++i)                      // one full step: every layer's input is valid scratch afterwards
+        if ((rc = launch_conv(s, ls[i].layer, ls[i].p, ls[i].inmode, st))) return rc;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    const int saved = s->prof_layer;
+    s->prof_layer = -1;
+    HIP_TRY(hipEventRecord(e0, st));
+    for (int r = 0; r < reps; ++r)
+        if ((rc = launch_conv(s, ls[layer].layer, ls[layer].p, ls[layer].inmode, st))) break;
+    (void)hipEventRecord(e1, st);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    s->prof_layer = saved;
+    *avg_ms = ms / (float)reps;
+    return rc;
 }
 
 extern "C" int iaf_ar_multiconv2d_forward(iaf_stack_t* s, const float* z, const float* context, float* m_raw,

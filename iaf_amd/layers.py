@@ -170,6 +170,30 @@ class ARStack(object):
         _capi.check(_capi.lib().iaf_stack_prepare(self._h, Vp, gp, bp, _stream()))
         self._prep_key, self._keepalive = key, tens
 
+    def _param_tensors(self, params):
+        names = self.conv_names()
+        sizes = [self.n_z] + self.n_h_list
+        tens = []
+        for ci, nm in enumerate(names):
+            n_in = sizes[min(ci, self.depth_ar)]
+            n_out = sizes[ci + 1] if ci < self.depth_ar else self.n_z
+            V, g, b = params[nm + "/V"], params[nm + "/g"], params[nm + "/b"]
+            _check_act(V, nm + "/V", (3, 3, n_in, n_out))
+            _check_act(g, nm + "/g", (n_out,))
+            _check_act(b, nm + "/b", (n_out,))
+            tens += [V, g, b]
+        return tens
+
+    def time_layer(self, layer, z, context, reps=50):
+        """average duration (ms) of GEMM layer `layer` over `reps` back-to-back launches between one HIP event pair"""
+        B, H, W = self._dims(z, context)
+        ws, need = self.workspace(B, H, W, z.device)
+        zn, ls = torch.empty_like(z), torch.empty_like(z)
+        ms = ctypes.c_float()
+        _capi.check(_capi.lib().iaf_step_time_layer(self._h, layer, _ptr(z), _ptr(context), _ptr(zn), _ptr(ls), B, H, W,
+                                                    _ptr(ws), need, int(reps), _stream(), ctypes.byref(ms)))
+        return ms.value
+
     # -- workspace -----------------------------------------------------------------------------
     def workspace(self, B, H, W, device):
         need = int(_capi.lib().iaf_stack_workspace_bytes(self._h, B, H, W))
@@ -252,6 +276,41 @@ class ARStack(object):
         if want_kl_elem:
             out["kl_elem"] = kl_elem
         return out
+
+
+class PrepBatch(object):
+    """Weight prep (mask, l2-normalise, exp(g), repack) for MANY stacks in one launch -- what a model does once at
+    the start of every step (the reference re-derives the normalised weights inside every conv2d call,
+    layers.py:56-60)."""
+
+    def __init__(self, stacks):
+        self.stacks = list(stacks)
+        arr = (ctypes.c_void_p * len(self.stacks))(*[s._h.value for s in self.stacks])
+        self._h = ctypes.c_void_p()
+        _capi.check(_capi.lib().iaf_prep_batch_create(ctypes.byref(self._h), arr, len(self.stacks)))
+        self._keepalive = None
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                _capi.lib().iaf_prep_batch_destroy(h)
+            except Exception:
+                pass
+
+    def run(self, params_list):
+        tens = []
+        for st, params in zip(self.stacks, params_list):
+            tens += st._param_tensors(params)
+        n = len(tens) // 3
+        arr = ctypes.c_void_p * n
+        Vp = arr(*[t.data_ptr() for t in tens[0::3]])
+        gp = arr(*[t.data_ptr() for t in tens[1::3]])
+        bp = arr(*[t.data_ptr() for t in tens[2::3]])
+        _capi.check(_capi.lib().iaf_prep_batch_run(self._h, Vp, gp, bp, _stream()))
+        self._keepalive = tens
+        for st in self.stacks:
+            st._prep_key = None      # per-stack cache no longer describes what is on the device
 
 
 def _is_elu(nl):

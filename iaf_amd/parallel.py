@@ -1,0 +1,102 @@
+"""Data-parallel structure of the reference (tf_train.py:124-147, tf_utils/common.py:78-115), one process per GPU.
+
+The reference replicates towers inside one TF graph, keeps the variables on the CPU and sums gradients with
+plain `+` ops.  Here every rank owns a full parameter replica in HBM; the only exchange per training step is one
+all-reduce(sum) over a flat fp32 gradient bucket followed by 1/N (== average_dense, common.py:83-86), done by
+RCCL over xGMI (torch.distributed backend "nccl") or gloo on CPU.  The forward IAF path needs no collective:
+every sample is independent and the free-bits mean is over the LOCAL tower batch (tf_train.py:79)."""
+import math
+
+import torch
+import torch.distributed as dist
+
+
+def shard_batch(x, rank=None, world=None):
+    """tf.split(0, num_gpus, x)[rank] (tf_train.py:126): equal contiguous shards of the global batch."""
+    if world is None:
+        world = dist.get_world_size() if dist.is_initialized() else 1
+    if rank is None:
+        rank = dist.get_rank() if dist.is_initialized() else 0
+    n = x.shape[0]
+    if n % world != 0:
+        raise ValueError("global batch %d is not divisible by %d ranks" % (n, world))   # tf.split would raise too
+    per = n // world
+    return x[rank * per:(rank + 1) * per]
+
+
+class GradBucket(object):
+    """Flat fp32 bucket over a list of gradient tensors.  The reference averages 488 tensors one by one
+    (SURVEY 2.2); over xGMI the ring is per-link bound, so one large message (166 MB at the README config)
+    beats 488 small ones.  Buckets are filled in REVERSE parameter order so that a caller overlapping with
+    backward can launch the bucket holding the top-down layers first."""
+
+    def __init__(self, tensors, bucket_bytes=64 << 20):
+        self.tensors = list(tensors)
+        self.buckets = []
+        cur, cur_bytes = [], 0
+        for t in reversed(self.tensors):
+            nb = t.numel() * 4
+            if cur and cur_bytes + nb > bucket_bytes:
+                self.buckets.append(cur)
+                cur, cur_bytes = [], 0
+            cur.append(t)
+            cur_bytes += nb
+        if cur:
+            self.buckets.append(cur)
+
+    def all_reduce_mean(self, group=None, async_op=False):
+        """grad = (sum over ranks) / N for every tensor, in place (common.py:83-86)."""
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        handles = []
+        for b in self.buckets:
+            flat = torch.cat([t.reshape(-1) for t in b])
+            h = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True) if world > 1 else None
+            handles.append((h, flat, b))
+        if async_op:
+            return lambda: self._finish(handles, world)
+        self._finish(handles, world)
+
+    @staticmethod
+    def _finish(handles, world):
+        for h, flat, b in handles:
+            if h is not None:
+                h.wait()
+            flat /= float(world)
+            off = 0
+            for t in b:
+                n = t.numel()
+                t.copy_(flat[off:off + n].view_as(t))
+                off += n
+
+
+def average_grads(grads, group=None):
+    """Drop-in for tf_utils/common.py:78-115 (dense branch) across RANKS instead of in-graph towers:
+    every rank passes its own list of gradient tensors; on return each holds sum/N."""
+    GradBucket(grads).all_reduce_mean(group)
+    return grads
+
+
+def bits_per_dim(local_loss_sum, batch_size_per_rank, num_pixels=3 * 32 * 32, group=None):
+    """tf_train.py:142: add_n(losses) / (ln2 * num_pixels * batch_size * num_gpus)."""
+    t = local_loss_sum.detach().clone().reshape(1).to(torch.float64)
+    world = 1
+    if dist.is_initialized():
+        world = dist.get_world_size(group)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t.item() / (math.log(2.0) * num_pixels * batch_size_per_rank * world)
+
+
+def adamax_step_(var, grad, slot_m, slot_v, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+    """tf_utils/adamax.py:40-56 in place (NB slot "v" = first moment, "m" = infinity norm).  Identical on
+    every replica after average_grads, so parameters stay in sync without a broadcast."""
+    slot_v.mul_(beta1).add_(grad, alpha=1.0 - beta1)
+    torch.maximum(slot_m.mul_(beta2).add_(eps), grad.abs(), out=slot_m)
+    var.addcdiv_(slot_v, slot_m, value=-lr)
+    return var
+
+
+def ema_step_(shadow, var, decay=0.999):
+    """tf.train.ExponentialMovingAverage(0.999).apply (tf_train.py:157-158)."""
+    shadow.sub_(shadow - var, alpha=1.0 - decay)
+    return shadow

@@ -60,6 +60,16 @@ int iaf_stack_destroy(iaf_stack_t* s);
 int iaf_stack_prepare(iaf_stack_t* s, const float* const* V, const float* const* g, const float* const* b,
                       void* stream);
 
+/* The same for MANY stacks in ONE launch: the weights of every IAF layer are known when a step starts, and one
+ * 480-workgroup launch costs about as much as one 24-workgroup launch.  V/g/b are the concatenation, stack by
+ * stack, of the (depth_ar+2) pointers iaf_stack_prepare takes.  The batch object owns pinned + device descriptor
+ * tables; the run is stream-ordered and graph-capturable. */
+typedef struct iaf_prep_batch iaf_prep_batch_t;
+int iaf_prep_batch_create(iaf_prep_batch_t** out, iaf_stack_t* const* stacks, int n);
+int iaf_prep_batch_run(iaf_prep_batch_t* b, const float* const* V, const float* const* g, const float* const* bias,
+                       void* stream);
+int iaf_prep_batch_destroy(iaf_prep_batch_t* b);
+
 /* bytes of caller-provided scratch needed by the forward calls for a [B,*,H,W] problem */
 size_t iaf_stack_workspace_bytes(const iaf_stack_t* s, int B, int H, int W);
 
@@ -118,6 +128,12 @@ int iaf_stack_set_tuning(iaf_stack_t* s, int layer, int nt, int pxt, int wco, in
  * elapsed milliseconds of each sample to ms_out[0..*n_out) and resets the sample counter. */
 int iaf_stack_profile_enable(iaf_stack_t* s, int layer, int max_samples);
 int iaf_stack_profile_read(iaf_stack_t* s, float* ms_out, int capacity, int* n_out);
+/* Roofline timing: runs one full iaf_step (so every layer has valid inputs), then launches GEMM layer `layer`
+ * `reps` times back to back between ONE pair of HIP events on `stream`; *avg_ms = elapsed / reps (includes the
+ * ~1 us inter-launch gap, excludes event/dispatch latency).  Synchronises the stream. */
+int iaf_step_time_layer(iaf_stack_t* s, int layer, const float* z, const float* context, float* z_new, float* logsd,
+                        int B, int H, int W, void* workspace, size_t workspace_bytes, int reps, void* stream,
+                        float* avg_ms);
 /* dev tool: every workgroup of GEMM layer `layer` writes 8 s_memtime stamps (kernel start, tile loads
  * issued, tile staged, steady loop done, K loop done, end) to buf[wg*8..]; buf = NULL disables. */
 int iaf_stack_set_debug(iaf_stack_t* s, int layer, void* buf);

@@ -156,7 +156,10 @@ def test_every_launch_shape_agrees(amd, tune):
             continue                               # layer 0 has only n_z/16 = 2 K-chunks: keep its default shape
         stack.set_tuning(layer, nt, pxt, wco, ks)
     stack.set_tuning(d, 2, pxt, wco, ks)          # output pair: (mean, logsd) tiles must share a wave -> nt even
-    z_new, logsd = stack.iaf_step(dev(z), dev(ctx))
+    try:
+        z_new, logsd = stack.iaf_step(dev(z), dev(ctx))
+    except ValueError as e:                        # shape needs more than 160 KiB of LDS at these channel counts
+        pytest.skip(str(e))
     ez, es = O.iaf_step(f32(z), f32(ctx), f32_params(params), [n_h] * d)
     np.testing.assert_allclose(host(logsd), es, atol=ATOL, rtol=0)
     np.testing.assert_allclose(host(z_new), ez, atol=ATOL, rtol=0)
@@ -297,6 +300,23 @@ def test_full_size_vs_oracle_sample_of_batch(amd):
         ez, es = O.iaf_step(host(z[b:b + 1]), host(ctx[b:b + 1]), f32_params(params), [160, 160])
         np.testing.assert_allclose(host(zf[b:b + 1]), ez, atol=ATOL, rtol=0)
         np.testing.assert_allclose(host(sf[b:b + 1]), es, atol=ATOL, rtol=0)
+
+
+def test_batched_prepare_equals_per_stack_prepare(amd):
+    """PrepBatch (all layers in one launch) must leave exactly the same packed weights as per-stack prepare"""
+    cases = [(32, 160, 2), (32, 64, 1), (64, 64, 4)]
+    stacks_a, stacks_b, plist, ins = [], [], [], []
+    for i, (n_z, n_h, d) in enumerate(cases):
+        params, z, ctx = _rand_case(300 + i, 2, n_z, n_h, d, 4, 4)
+        dp = dev_params(params)
+        a, b = amd.ARStack(n_z, [n_h] * d), amd.ARStack(n_z, [n_h] * d)
+        a.prepare(dp)
+        stacks_a.append(a); stacks_b.append(b); plist.append(dp); ins.append((dev(z), dev(ctx)))
+    amd.PrepBatch(stacks_b).run(plist)
+    for a, b, (z, ctx) in zip(stacks_a, stacks_b, ins):
+        za, sa = a.iaf_step(z, ctx)
+        zb, sb = b.iaf_step(z, ctx)
+        assert torch.equal(za, zb) and torch.equal(sa, sb)
 
 
 def test_weight_update_invalidates_cache(amd):

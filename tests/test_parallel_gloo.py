@@ -1,0 +1,76 @@
+"""world_size-2 gloo tests (CPU) of the data-parallel layer: batch sharding, bucketed gradient averaging
+(== the reference's average_grads on towers, tf_utils/common.py:78-115), bits_per_dim reduction, and replica
+consistency of Adamax after averaged gradients."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import iaf_oracle as O
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from iaf_amd import parallel as par
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "common.npz"))
+    # every rank plays one of the reference's towers (towers 0 and 1 of the golden fixture)
+    grads = [torch.from_numpy(g["tower%d_g%d" % (rank, i)].copy()).float() for i in range(3)]
+    par.GradBucket(grads, bucket_bytes=512).all_reduce_mean()          # small bucket size -> several buckets
+    x = torch.arange(8 * 3, dtype=torch.float32).reshape(8, 3)
+    shard = par.shard_batch(x)
+    bpd = par.bits_per_dim(torch.tensor(100.0 * (rank + 1)), batch_size_per_rank=4)
+    # one Adamax + EMA step from identical state with the averaged gradients: replicas must stay bit-identical
+    var = torch.ones_like(grads[0])
+    m, v = torch.zeros_like(var), torch.zeros_like(var)
+    par.adamax_step_(var, grads[0], m, v, lr=0.002)
+    shadow = par.ema_step_(torch.zeros_like(var), var)
+    out[rank] = dict(grads=[t.numpy() for t in grads], shard=shard.numpy(), bpd=bpd, var=var.numpy(), m=m.numpy(),
+                     v=v.numpy(), shadow=shadow.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_two_ranks_gloo(golden_dir):
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    g = np.load(os.path.join(golden_dir, "common.npz"))
+    towers = [[g["tower%d_g%d" % (t, i)].astype(np.float32).astype(np.float64) for i in range(3)] for t in range(2)]
+    ref = O.average_grads(towers)
+    for r in range(world):
+        for i in range(3):
+            np.testing.assert_allclose(out[r]["grads"][i], ref[i], rtol=1e-6, atol=1e-7)
+    np.testing.assert_array_equal(out[0]["shard"], np.arange(24, dtype=np.float32).reshape(8, 3)[:4])
+    np.testing.assert_array_equal(out[1]["shard"], np.arange(24, dtype=np.float32).reshape(8, 3)[4:])
+    expect_bpd = 300.0 / (np.log(2.0) * 3072 * 4 * 2)                     # tf_train.py:142
+    assert abs(out[0]["bpd"] - expect_bpd) < 1e-12 and abs(out[1]["bpd"] - expect_bpd) < 1e-12
+    for k in ("var", "m", "v", "shadow"):
+        np.testing.assert_array_equal(out[0][k], out[1][k])               # replicas stay in sync
+    ev, em, evv = O.adamax_step(np.ones_like(ref[0]), ref[0], np.zeros_like(ref[0]), np.zeros_like(ref[0]), lr=0.002)
+    np.testing.assert_allclose(out[0]["var"], ev, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(out[0]["m"], em, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(out[0]["v"], evv, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(out[0]["shadow"], O.ema_step(np.zeros_like(ev), ev), rtol=1e-5, atol=1e-7)
+
+
+def test_average_grads_against_reference_golden_four_towers(golden_dir):
+    """single process, the reference's 4-tower fixture: sum then /N"""
+    g = np.load(os.path.join(golden_dir, "common.npz"))
+    towers = [[g["tower%d_g%d" % (t, i)] for i in range(3)] for t in range(4)]
+    avg = O.average_grads(towers)
+    for i in range(3):
+        np.testing.assert_allclose(avg[i], g["avg_g%d" % i], rtol=1e-13, atol=1e-15)
