@@ -59,6 +59,26 @@ struct ConvP {
     unsigned long long* dbg;   // dev tool: per-workgroup s_memtime stamps [grid][8] (NULL in production)
 };
 
+// Pin the order "MFMAs with memory instructions spread evenly between them" inside the current scheduling region:
+// NMF MFMAs, then NRD ds_reads, NWR ds_writes, NLDG global loads, each memory op after its share of the MFMAs.
+// (An LDS/VMEM instruction occupies the wave's issue port for ~25 cycles, an MFMA keeps the pipe busy for 32: a
+// cluster of memory instructions starves the pipe, one between every few MFMAs is free.)
+template <int NMF, int NRD, int NWR, int NLDG>
+__device__ __forceinline__ void sched_interleave() {
+    constexpr int NMEM = NRD + NWR + NLDG;
+    static_for<NMEM>([&](auto m_c) {
+        constexpr int m = decltype(m_c)::value;
+        constexpr int prev = (m * NMF) / (NMEM + 1);
+        constexpr int upto = ((m + 1) * NMF) / (NMEM + 1);
+        if constexpr (upto > prev) __builtin_amdgcn_sched_group_barrier(0x008, upto - prev, 0);
+        if constexpr (m < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);              // DS read
+        else if constexpr (m < NRD + NWR) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
+        else __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                // VMEM read
+    });
+    constexpr int last = (NMEM * NMF) / (NMEM + 1);
+    if constexpr (NMF > last) __builtin_amdgcn_sched_group_barrier(0x008, NMF - last, 0);
+}
+
 // ELU with the hardware exponential: exp(v) - 1 for v <= 0 (what TF's fp32 kernel evaluates); abs error < 1e-7
 __device__ __forceinline__ float elu_f(float v) { return v > 0.f ? v : __expf(v) - 1.0f; }
 
@@ -126,10 +146,13 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
     //    (round-robin over the waves), parked in a double-buffered LDS chunk buffer and read by all waves with
     //    ds_read_b128.  The CU's address unit handles one 1 KiB wave-load per ~16 cycles and a wave that is stuck
     //    issuing a load cannot issue MFMAs; sharing cuts that traffic PXT-fold (measured: 873 -> ~670 cycles/step).
-#ifdef IAF_EXP_FORCE_RING
-    constexpr bool SHARED_W = false;
-#else
+    // Measured on the 160->160 conv at B=32 16x16 (cycles per K step, 640 = MFMA-bound): ring 712, shared 768
+    // (both with the memory instructions interleaved between the MFMAs; 873 / 867 with them clustered).  The ring
+    // is therefore the default; -DIAF_SHARED_W=1 builds the LDS-shared variant.
+#if defined(IAF_SHARED_W) && IAF_SHARED_W
     constexpr bool SHARED_W = (PXT > 1);
+#else
+    constexpr bool SHARED_W = false;
 #endif
     constexpr int NTILE_CH = NTAPS * NT;                       // weight tiles per chunk
     constexpr int NLD = (NTILE_CH + PXT - 1) / PXT;            // tiles fetched per wave per chunk
@@ -257,14 +280,15 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
     // u = kh, kh+KS, ...  (unit = one co-tile for EPI_HIDDEN, one (mean, logsd) tile pair for EPI_OUT).
     constexpr int NUNIT = (EPI == EPI_HIDDEN) ? NT : NT / 2;
     constexpr int NMY = (NUNIT + KS - 1) / KS;
-    f32x4 pre0[NMY], pre1[NMY];
-    auto prefetch_epilogue = [&]() {     // operands that do not depend on the GEMM: context, z
+    f32x4 pre0[NMY], pre1[NMY], pbias[NMY * (EPI == EPI_HIDDEN ? 1 : 2)];
+    auto prefetch_epilogue = [&]() {     // operands that do not depend on the GEMM: bias, context, z
         if (!pvalid) return;
 #pragma unroll
         for (int i = 0; i < NMY; ++i) {
             const int u = kh + i * KS;
             if (u >= NUNIT) continue;
             if (EPI == EPI_HIDDEN) {
+                pbias[i] = *(const f32x4*)(p.bias + (cot0 + u) * 16 + 4 * kk);
                 if (p.ctx) {
                     const size_t cb = ((size_t)bimg * p.cout + (cot0 + u) * 16 + 4 * kk) * HW + pp;
 #pragma unroll
@@ -274,10 +298,14 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
                         for (int r = 0; r < 4; ++r) pre1[i][r] = p.ctx2[cb + (size_t)r * HW];
                     }
                 }
-            } else if (p.mode == MODE_IAF) {
-                const size_t zb = ((size_t)bimg * (p.cout >> 1) + ((cot0 + 2 * u) >> 1) * 16 + 4 * kk) * HW + pp;
+            } else {
+                pbias[2 * i] = *(const f32x4*)(p.bias + (cot0 + 2 * u) * 16 + 4 * kk);
+                pbias[2 * i + 1] = *(const f32x4*)(p.bias + (cot0 + 2 * u + 1) * 16 + 4 * kk);
+                if (p.mode == MODE_IAF) {
+                    const size_t zb = ((size_t)bimg * (p.cout >> 1) + ((cot0 + 2 * u) >> 1) * 16 + 4 * kk) * HW + pp;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) pre0[i][r] = p.zin[zb + (size_t)r * HW];
+                    for (int r = 0; r < 4; ++r) pre0[i][r] = p.zin[zb + (size_t)r * HW];
+                }
             }
         }
     };
@@ -307,20 +335,31 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
             constexpr int MODE = decltype(mode_c)::value;
             const f32x4* wb = wlds + buf * (NTILE_CH * 64) + lane;
             read_ops(0, 0, chunk, wb);
-#pragma unroll
-            for (int tp = 0; tp < NTAPS; ++tp) {
-                if (tp + 1 < NTAPS) read_ops((tp + 1) & 1, tp + 1, chunk, wb);
-                if (tp == 2 && MODE <= 1) write_stage(buf ^ 1);
-                if (tp == 2 && MODE == 0) issue_stage(chunk + 2);
-                __builtin_amdgcn_sched_barrier(0);   // hipcc otherwise sinks the prefetch reads down to their first use
+            static_for<NTAPS>([&](auto tp_c) {
+                constexpr int tp = decltype(tp_c)::value;
+                constexpr bool RD = (tp + 1 < NTAPS);
+                constexpr bool WR = (tp == 2 && MODE <= 1);
+                constexpr bool LDG = (tp == 2 && MODE == 0);
+                if constexpr (RD) read_ops((tp + 1) & 1, tp + 1, chunk, wb);
+                if constexpr (WR) write_stage(buf ^ 1);
+                if constexpr (LDG) issue_stage(chunk + 2);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
                         const int a = (NT == 1) ? (j & 1) : t;
+#ifdef IAF_EXP_STATICOPS
+                        asm volatile("" ::"v"(opw[tp & 1][t][j]));                      // reads still happen and are waited for
+                        acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(sv[t % SU][j], opx[tp & 1][j], acc[a], 0, 0, 0);
+#else
                         acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(opw[tp & 1][t][j], opx[tp & 1][j], acc[a], 0, 0, 0);
+#endif
                     }
-            }
+#ifndef IAF_EXP_NOINTERLEAVE
+                sched_interleave<4 * NT, RD ? NT + 1 : 0, WR ? NLD : 0, LDG ? NLD : 0>();
+#endif
+                __builtin_amdgcn_sched_barrier(0);   // scheduling regions are per tap: nothing migrates across
+            });
         };
         using M0 = std::integral_constant<int, 0>;
         using M1 = std::integral_constant<int, 1>;
@@ -345,18 +384,18 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
         constexpr int I = decltype(slot_c)::value;
         constexpr bool RF_T4 = decltype(refill_t4)::value;    // step (chunk, 0) refills step (chunk+RCH-1, tap 4)
         constexpr bool RF_OWN = decltype(refill_own)::value;  // step (chunk, tp>=1) refills step (chunk+RCH, tp-1)
-#pragma unroll
-        for (int tp = 0; tp < NTAPS; ++tp) {
+        static_for<NTAPS>([&](auto tp_c) {
+            constexpr int tp = decltype(tp_c)::value;
             const f32x4 xv = xn;
             // next step: tap tp+1 of this chunk, or tap 0 of the next chunk (a read past the last chunk stays inside
             // the padded row of the LDS tile and is never used)
             xn = (tp + 1 < NTAPS) ? smem4[xa[(tp + 1) % NTAPS] + chunk * 4]
                                   : smem4[xa[0] + (chunk + 1 < c_end ? chunk + 1 : chunk) * 4];
-            const int PS = (I * NTAPS + tp + R - 1) % R;                      // slot consumed by the previous step
+            constexpr int PS = (I * NTAPS + tp + R - 1) % R;                  // slot consumed by the previous step
 #ifdef IAF_EXP_NOREFILL
-            const bool rf = false;
+            constexpr bool rf = false;
 #else
-            const bool rf = (tp == 0) ? RF_T4 : RF_OWN;
+            constexpr bool rf = (tp == 0) ? RF_T4 : RF_OWN;
 #endif
             const f32x4* q = wbase + ((size_t)chunk * NTAPS + tp + R - 1) * wstep;   // step s + R - 1
 #pragma unroll
@@ -370,12 +409,16 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
                     acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[I * NTAPS + tp][t][j], xv[j], acc[a], 0, 0, 0);
 #endif
                 }
-                if (rf) {   // refill loads ride in the shadow of the MFMAs: tiles j, j+4, ...
-#pragma unroll
-                    for (int t = j; t < NT; t += 4) wr[PS][t] = q[ulane + t * 64];
-                }
             }
-        }
+            if constexpr (rf) {   // refill of the slot the previous step consumed; spread between the MFMAs below
+#pragma unroll
+                for (int t = 0; t < NT; ++t) wr[PS][t] = q[ulane + t * 64];
+            }
+#if !defined(IAF_EXP_NOINTERLEAVE) && !defined(IAF_EXP_NOMFMA)
+            sched_interleave<4 * NT, 1, 0, rf ? NT : 0>();
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+        });
     };
     {
         using T = std::true_type;
@@ -443,7 +486,7 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
             if (u >= NUNIT) continue;
             if (EPI == EPI_HIDDEN) {
                 const int co = (cot0 + u) * 16 + 4 * kk;
-                f32x4 v = val[i] + *(const f32x4*)(p.bias + co);
+                f32x4 v = val[i] + pbias[i];
                 if (p.ctx) {   // x += context (layers.py:163-164); context = up_context + down_context (tf_train.py:58)
                     if (p.ctx2) v += (pre0[i] + pre1[i]);
                     else v += pre0[i];
@@ -455,8 +498,8 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
                 const int nz = p.cout >> 1;
                 const int gt = cot0 + 2 * u;              // packed tiles (gt, gt+1) = (mean, logsd) of channel group gt/2
                 const int c0 = (gt >> 1) * 16 + 4 * kk;
-                const f32x4 bm = *(const f32x4*)(p.bias + gt * 16 + 4 * kk);
-                const f32x4 bs = *(const f32x4*)(p.bias + (gt + 1) * 16 + 4 * kk);
+                const f32x4 bm = pbias[2 * i];
+                const f32x4 bs = pbias[2 * i + 1];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const size_t idx = ((size_t)bimg * nz + c0 + r) * HW + pp;

@@ -351,7 +351,7 @@ extern "C" const char* iaf_error_string(int code) {
         case IAF_ERR_NOT_MULTIPLE: return "n_h must be a multiple of n_z or vice versa";
         case IAF_ERR_NOT_PREPARED: return "iaf_stack_prepare has not been called";
         case IAF_ERR_WORKSPACE: return "workspace too small or misaligned";
-        case IAF_ERR_UNSUPPORTED: return "shape not covered by the gfx950 kernels (channels must be multiples of 16)";
+        case IAF_ERR_UNSUPPORTED: return "not covered by the gfx950 kernels (channels must be multiples of 16 and <= 256; launch shape must fit 160 KiB of LDS)";
     }
     if (code > 0) return hipGetErrorString((hipError_t)code);
     return "unknown error";
