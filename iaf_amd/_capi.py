@@ -15,6 +15,7 @@ IAF_ERR_NOT_PREPARED = -4
 IAF_ERR_WORKSPACE = -5
 IAF_ERR_UNSUPPORTED = -6
 IAF_VARIANT_TF = 0
+IAF_VARIANT_THEANO = 1
 
 _c_float_p = ctypes.c_void_p      # device pointers travel as integers (tensor.data_ptr())
 _vp = ctypes.c_void_p

@@ -19,10 +19,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 #define NTAPS 5
-// live taps of the TF statement (cross-correlation, mask keeps centre, right, and the row below):
-// (kh,kw) = (1,1) (1,2) (2,0) (2,1) (2,2)  ->  (dh,dw) relative to the output pixel.  Centre first.
-static __device__ __constant__ const int c_tap_dh[NTAPS] = {0, 0, 1, 1, 1};
-static __device__ __constant__ const int c_tap_dw[NTAPS] = {0, 1, -1, 0, 1};
+// The 5 live taps are the filter positions (kh,kw) = (1,1) (1,2) (2,0) (2,1) (2,2), centre first; their (dh,dw)
+// relative to the output pixel come from ConvP (TF: (0,0)(0,1)(1,-1)(1,0)(1,1); Theano: the negated set).
 
 #define EPI_HIDDEN 0   // y = elu(acc + bias [+ ctx (+ ctx2)])  -> pixel-major scratch
 #define EPI_OUT 1      // output pair (mean, logsd) -> NCHW; mode selects raw / IAF step / posterior
@@ -56,6 +54,12 @@ struct ConvP {
     int cp;               // padded channel stride of the LDS tile (floats), == cin + 8
     int nslot;            // staged pixel slots = TM + W + 1 (one-sided halo)
     int mode;
+    // tap geometry (runtime so that both statements of the operator share the instantiations):
+    //   TF      (tf_utils/layers.py, cross-correlation): taps look right/below, halo after the tile
+    //   Theano  (graphy/nodes/ar.py + dnn_conv conv_mode='conv', flipped kernel): taps look left/above, halo before
+    int tap_dh[NTAPS], tap_dw[NTAPS];
+    int halo_before;          // staged slots start at pixel P0 - halo_before
+    const float* border;      // Theano pad_channel: [4][cout packed] weight of the border-indicator channel per non-centre tap
     unsigned long long* dbg;   // dev tool: per-workgroup s_memtime stamps [grid][8] (NULL in production)
 };
 
@@ -115,15 +119,18 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
     const int nitems = p.nslot * nq;
     constexpr int SU = (INMODE == IN_PIXMAJOR) ? 16 : 4;    // items in flight per thread
     f32x4 sv[SU];
+    const int Pbase = P0 - p.halo_before;          // global pixel of slot 0 (negative for the first tile of the Theano variant)
+    const int flo = Pbase < 0 ? -Pbase * nq : 0;                       // items whose pixel exists: [flo, fhi)
+    const long long rem = (long long)(p.P - Pbase) * nq;
+    const int fhi = rem < nitems ? (int)rem : nitems;
     if (INMODE == IN_PIXMAJOR) {
-        const long long rem = (long long)(p.P - P0) * nq;   // items whose pixel exists
-        const int nvalid = rem < nitems ? (int)rem : nitems;
-        const f32x4* src = (const f32x4*)p.x + (size_t)P0 * nq;
+        const f32x4* src = (const f32x4*)p.x + (long long)Pbase * nq;
 #pragma unroll
         for (int u = 0; u < SU; ++u) {
             const int f = tid + u * NTHREADS;
-            sv[u] = src[f < nvalid ? f : nvalid - 1];        // clamped: branch-free; out-of-range items are zeroed below
-            if (f >= nvalid) sv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int fc = f < flo ? flo : (f < fhi ? f : fhi - 1);    // clamped: branch-free; out-of-range items zeroed
+            sv[u] = src[fc];
+            if (f < flo || f >= fhi) sv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
 
@@ -204,12 +211,14 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
     const int bimg = Pl / HW, pp = Pl - bimg * HW;
     const int h = pp / W, w = pp - h * W;
     int xa[NTAPS];   // 16-byte offset into the LDS tile of this lane's 4 channels for each tap (chunk 0)
+    unsigned outside = 0;   // bit t: tap t falls outside the image for this lane's pixel (Theano border channel)
 #pragma unroll
     for (int t = 0; t < NTAPS; ++t) {
-        const int dh = c_tap_dh[t], dw = c_tap_dw[t];
-        const bool v = pvalid && (h + dh < p.H) && (w + dw >= 0) && (w + dw < W);
-        const int slot = pw * 16 + pl + dh * W + dw;
+        const int dh = p.tap_dh[t], dw = p.tap_dw[t];
+        const bool v = pvalid && (h + dh >= 0) && (h + dh < p.H) && (w + dw >= 0) && (w + dw < W);
+        const int slot = pw * 16 + pl + dh * W + dw + p.halo_before;
         xa[t] = (v ? slot : p.nslot) * cp4 + kk;     // image borders read the all-zero slot
+        outside |= (v ? 0u : 1u) << t;
     }
 
     // (4) tile -> LDS
@@ -227,10 +236,10 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
                 }
             }
             // tiles larger than SU*NTHREADS items (c_in > 192 at TM = 64): plain extra rounds
-            const f32x4* src = (const f32x4*)p.x + (size_t)P0 * nq;
+            const f32x4* src = (const f32x4*)p.x + (long long)Pbase * nq;
             for (int f = tid + SU * NTHREADS; f < nitems; f += NTHREADS) {
                 const int sl = (int)(((float)f + 0.5f) * rnq);
-                smem4[sl * cp4 + (f - sl * nq)] = (P0 + sl < p.P) ? src[f] : f32x4{0.f, 0.f, 0.f, 0.f};
+                smem4[sl * cp4 + (f - sl * nq)] = (f >= flo && f < fhi) ? src[f] : f32x4{0.f, 0.f, 0.f, 0.f};
             }
         } else {
             for (int base = tid; base < nitems; base += SU * NTHREADS) {
@@ -242,9 +251,9 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
                     sv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
                     if (idx < nitems) {
                         const int q = idx / p.nslot, sl = idx - q * p.nslot;   // slot fastest: coalesced along pixels
-                        const int Pg = P0 + sl;
+                        const int Pg = Pbase + sl;
                         dst[u] = sl * cp4 + q;
-                        if (Pg < p.P) {
+                        if (Pg >= 0 && Pg < p.P) {
                             const int b = Pg / HW, ppx = Pg - b * HW;
                             const size_t gb = ((size_t)b * p.cin + 4 * q) * HW + ppx;
                             if (INMODE == IN_NCHW) {
@@ -487,6 +496,11 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
             if (EPI == EPI_HIDDEN) {
                 const int co = (cot0 + u) * 16 + 4 * kk;
                 f32x4 v = val[i] + pbias[i];
+                if (p.border) {   // Theano pad_channel (conv.py:71-83, ar.py:229-233): taps that fall outside see a 1
+#pragma unroll
+                    for (int t = 1; t < NTAPS; ++t)
+                        if (outside & (1u << t)) v += *(const f32x4*)(p.border + (size_t)(t - 1) * p.cout + co);
+                }
                 if (p.ctx) {   // x += context (layers.py:163-164); context = up_context + down_context (tf_train.py:58)
                     if (p.ctx2) v += (pre0[i] + pre1[i]);
                     else v += pre0[i];
@@ -498,8 +512,16 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
                 const int nz = p.cout >> 1;
                 const int gt = cot0 + 2 * u;              // packed tiles (gt, gt+1) = (mean, logsd) of channel group gt/2
                 const int c0 = (gt >> 1) * 16 + 4 * kk;
-                const f32x4 bm = pbias[2 * i];
-                const f32x4 bs = pbias[2 * i + 1];
+                f32x4 bm = pbias[2 * i];
+                f32x4 bs = pbias[2 * i + 1];
+                if (p.border) {
+#pragma unroll
+                    for (int t = 1; t < NTAPS; ++t)
+                        if (outside & (1u << t)) {
+                            bm += *(const f32x4*)(p.border + (size_t)(t - 1) * p.cout + gt * 16 + 4 * kk);
+                            bs += *(const f32x4*)(p.border + (size_t)(t - 1) * p.cout + (gt + 1) * 16 + 4 * kk);
+                        }
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const size_t idx = ((size_t)bimg * nz + c0 + r) * HW + pp;

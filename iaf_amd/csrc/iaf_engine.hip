@@ -66,7 +66,8 @@ struct PrepLayer {
     const float* b[2];
     float* wp;       // packed weights [chunk][tap][cot][64][4]
     float* bias;     // packed bias [ncot*16]
-    int cin, cout_each, ncot, nchunk, zerodiag, npair, tile_begin;
+    float* border;   // Theano variant: [4][ncot*16] normalised weights of the border-indicator channel (taps 1..4)
+    int cin, cout_each, ncot, nchunk, zerodiag, npair, tile_begin, variant;
 };
 struct PrepArgs {
     PrepLayer L[MAX_GEMM_LAYERS];
@@ -123,9 +124,97 @@ __device__ __forceinline__ void prep_tile(const PrepLayer& L, int gt, float (*re
             L.wp[((((size_t)it * NTAPS + t) * L.ncot + gt) * 64 + kk * 16 + oo) * 4 + jj] = v[t][it] * scale;
 }
 
+// Theano statement of the same weights (graphy/nodes/ar.py:243-330, l2norm=True, logscale=True, pad_channel=True):
+//   w is OIHW [n_out][n_in+1][3][3] (last input channel = border indicator, graphy/nodes/conv.py:71-83),
+//   kerns = mask*w;  kerns /= (sqrt(sum_{i,h,w} kerns^2) + 1e-8);  kerns *= exp(3*s)          (ar.py:312-317, 279-281)
+//   the conv is a TRUE convolution (dnn_conv conv_mode='conv'), so filter position (kh,kw) meets the input at
+//   (dh,dw) = (1-kh, 1-kw): the same 5 live filter positions as the TF statement, looking left/above.
+// L.V = w, L.g = s, L.b = b.  The border channel never enters the GEMM: its 4 non-centre taps go to L.border and are
+// added by the conv epilogue where a tap falls outside the image (its centre tap is always masked).
+template <int NCH>
+__device__ __forceinline__ void prep_tile_theano(const PrepLayer& L, int gt, float (*red)[17], float* s_scale) {
+    const int which = (L.npair == 2) ? (gt & 1) : 0;
+    const int src_tile = (L.npair == 2) ? (gt >> 1) : gt;
+    const float* __restrict__ Wt = L.V[which];
+    const int oo = threadIdx.x & 15, cs = threadIdx.x >> 4;
+    const int o = src_tile * 16 + oo;
+    const int n_out = L.cout_each, n_in = L.cin;
+    const float sval = L.g[which][o], bval = L.b[which][o];
+    const float* wo = Wt + (size_t)o * (n_in + 1) * 9;
+    float v[NTAPS][NCH];
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+        const int ci = cs + 16 * it;
+#pragma unroll
+        for (int t = 0; t < NTAPS; ++t) {
+            const int kh = (t == 0 || t == 1) ? 1 : 2;
+            const int kw = (t == 0) ? 1 : (t == 1 ? 2 : t - 2);
+            v[t][it] = wo[(size_t)ci * 9 + kh * 3 + kw];
+        }
+    }
+    float wb[NTAPS - 1];   // border channel, taps 1..4 (thread cs == 0 accounts for it in the norm)
+#pragma unroll
+    for (int t = 1; t < NTAPS; ++t) {
+        const int kh = (t == 1) ? 1 : 2;
+        const int kw = (t == 1) ? 2 : t - 2;
+        wb[t - 1] = wo[(size_t)n_in * 9 + kh * 3 + kw];
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+        if (!made_live(cs + 16 * it, o, n_in, n_out, L.zerodiag)) v[0][it] = 0.f;   // ar.py:249-262 == the TF rule
+#pragma unroll
+        for (int t = 0; t < NTAPS; ++t) ss += v[t][it] * v[t][it];
+    }
+    if (cs == 0) {
+#pragma unroll
+        for (int t = 0; t < NTAPS - 1; ++t) ss += wb[t] * wb[t];
+    }
+    red[cs][oo] = ss;
+    __syncthreads();
+    if (cs == 0) {
+        float tot = 0.f;
+        for (int i = 0; i < 16; ++i) tot += red[i][oo];
+        const float sc = expf(3.0f * sval) / (sqrtf(tot) + 1e-8f);
+        s_scale[oo] = sc;
+        L.bias[gt * 16 + oo] = bval;
+#pragma unroll
+        for (int t = 0; t < NTAPS - 1; ++t) L.border[(size_t)t * (L.ncot * 16) + gt * 16 + oo] = wb[t] * sc;
+    }
+    __syncthreads();
+    const float scale = s_scale[oo];
+    const int kk = cs >> 2, jj = cs & 3;
+#pragma unroll
+    for (int it = 0; it < NCH; ++it)
+#pragma unroll
+        for (int t = 0; t < NTAPS; ++t)
+            L.wp[((((size_t)it * NTAPS + t) * L.ncot + gt) * 64 + kk * 16 + oo) * 4 + jj] = v[t][it] * scale;
+}
+
 #define PREP_MAXI 16   // n_in <= 256
 template <int DUMMY = 0>
 __device__ __forceinline__ void prep_dispatch(const PrepLayer& L, int gt, float (*red)[17], float* s_scale) {
+    if (L.variant == IAF_VARIANT_THEANO) {
+        switch (L.nchunk) {
+            case 1: prep_tile_theano<1>(L, gt, red, s_scale); break;
+            case 2: prep_tile_theano<2>(L, gt, red, s_scale); break;
+            case 3: prep_tile_theano<3>(L, gt, red, s_scale); break;
+            case 4: prep_tile_theano<4>(L, gt, red, s_scale); break;
+            case 5: prep_tile_theano<5>(L, gt, red, s_scale); break;
+            case 6: prep_tile_theano<6>(L, gt, red, s_scale); break;
+            case 7: prep_tile_theano<7>(L, gt, red, s_scale); break;
+            case 8: prep_tile_theano<8>(L, gt, red, s_scale); break;
+            case 9: prep_tile_theano<9>(L, gt, red, s_scale); break;
+            case 10: prep_tile_theano<10>(L, gt, red, s_scale); break;
+            case 11: prep_tile_theano<11>(L, gt, red, s_scale); break;
+            case 12: prep_tile_theano<12>(L, gt, red, s_scale); break;
+            case 13: prep_tile_theano<13>(L, gt, red, s_scale); break;
+            case 14: prep_tile_theano<14>(L, gt, red, s_scale); break;
+            case 15: prep_tile_theano<15>(L, gt, red, s_scale); break;
+            case 16: prep_tile_theano<16>(L, gt, red, s_scale); break;
+        }
+        return;
+    }
     switch (L.nchunk) {
         case 1: prep_tile<1>(L, gt, red, s_scale); break;
         case 2: prep_tile<2>(L, gt, red, s_scale); break;
@@ -269,6 +358,7 @@ struct GemmLayer {
     int zerodiag, npair;
     float* wp = nullptr;
     float* bias = nullptr;
+    float* border = nullptr;   // Theano variant only
     int* lim = nullptr;
     // launch shape: fixed by iaf_stack_set_tuning (user_tuned) or chosen per problem size by auto_shape()
     int nt, pxt, wco, ks;
@@ -375,7 +465,7 @@ extern "C" int iaf_stack_create(iaf_stack_t** out, int n_z, int n_h, int depth_a
     if (!out) return IAF_ERR_NULL;
     *out = nullptr;
     if (n_z <= 0 || n_h <= 0 || depth_ar < 0 || depth_ar > MAX_GEMM_LAYERS - 1) return IAF_ERR_SHAPE;
-    if (variant != IAF_VARIANT_TF) return IAF_ERR_UNSUPPORTED;
+    if (variant != IAF_VARIANT_TF && variant != IAF_VARIANT_THEANO) return IAF_ERR_UNSUPPORTED;
     if (depth_ar > 0 && !(n_z % n_h == 0 || n_h % n_z == 0)) return IAF_ERR_NOT_MULTIPLE;   // layers.py:116
     if (n_z % 16 != 0 || (depth_ar > 0 && n_h % 16 != 0)) return IAF_ERR_UNSUPPORTED;
     if (n_z > 16 * PREP_MAXI || n_h > 16 * PREP_MAXI) return IAF_ERR_UNSUPPORTED;
@@ -398,10 +488,11 @@ extern "C" int iaf_stack_create(iaf_stack_t** out, int n_z, int n_h, int depth_a
         L.ncot = L.cout / 16;
         default_tuning(L, is_out);
         count_macs(L, cin, each, L.zerodiag, L.npair);
-        s->weight_bytes += (size_t)L.npair * (9 * (size_t)cin * each + 2 * (size_t)each) * sizeof(float);
+        s->weight_bytes += (size_t)L.npair * (9 * (size_t)(cin + (variant == IAF_VARIANT_THEANO ? 1 : 0)) * each + 2 * (size_t)each) * sizeof(float);
         int rc;
         if ((rc = (int)hipMalloc(&L.wp, (size_t)L.nchunk * NTAPS * L.ncot * 256 * sizeof(float))) != 0 ||
             (rc = (int)hipMalloc(&L.bias, (size_t)L.cout * sizeof(float))) != 0 ||
+            (variant == IAF_VARIANT_THEANO && (rc = (int)hipMalloc(&L.border, (size_t)4 * L.cout * sizeof(float))) != 0) ||
             (rc = (int)hipMalloc(&L.lim, (size_t)L.ncot * sizeof(int))) != 0) {
             iaf_stack_destroy(s);
             return rc;
@@ -477,6 +568,7 @@ extern "C" int iaf_stack_destroy(iaf_stack_t* s) {
     for (int l = 0; l < s->nlayers; ++l) {
         if (s->L[l].wp) (void)hipFree(s->L[l].wp);
         if (s->L[l].bias) (void)hipFree(s->L[l].bias);
+        if (s->L[l].border) (void)hipFree(s->L[l].border);
         if (s->L[l].lim) (void)hipFree(s->L[l].lim);
     }
     delete s;
@@ -512,7 +604,7 @@ extern "C" int iaf_stack_prepare(iaf_stack_t* s, const float* const* V, const fl
         PrepLayer& P = a.L[l];
         P.V[0] = V[l]; P.g[0] = g[l]; P.b[0] = b[l];
         if (L.npair == 2) { P.V[1] = V[l + 1]; P.g[1] = g[l + 1]; P.b[1] = b[l + 1]; }
-        P.wp = L.wp; P.bias = L.bias;
+        P.wp = L.wp; P.bias = L.bias; P.border = L.border; P.variant = s->variant;
         P.cin = L.cin; P.cout_each = L.cout / L.npair; P.ncot = L.ncot; P.nchunk = L.nchunk;
         P.zerodiag = L.zerodiag; P.npair = L.npair; P.tile_begin = tiles;
         tiles += L.ncot;
@@ -572,7 +664,7 @@ extern "C" int iaf_prep_batch_create(iaf_prep_batch_t** out, iaf_stack_t* const*
         for (int l = 0; l < stacks[i]->nlayers; ++l, ++li) {
             const GemmLayer& L = stacks[i]->L[l];
             PrepLayer& P = b->h_layers[li];
-            P.wp = L.wp; P.bias = L.bias;
+            P.wp = L.wp; P.bias = L.bias; P.border = L.border; P.variant = stacks[i]->variant;
             P.cin = L.cin; P.cout_each = L.cout / L.npair; P.ncot = L.ncot; P.nchunk = L.nchunk;
             P.zerodiag = L.zerodiag; P.npair = L.npair; P.tile_begin = tile;
             for (int t = 0; t < L.ncot; ++t) t2l[tile++] = li;
@@ -682,6 +774,13 @@ static int launch_conv(const iaf_stack_t* s, int layer, ConvP& p, int inmode, hi
     if (!fn) return IAF_ERR_UNSUPPORTED;
     const int tm = 16 * L.pxt;
     p.wp = L.wp; p.bias = L.bias; p.lim = L.lim;
+    {   // tap geometry of the two statements of the operator (see ConvP)
+        static const int tf_dh[NTAPS] = {0, 0, 1, 1, 1}, tf_dw[NTAPS] = {0, 1, -1, 0, 1};
+        const int sgn = (s->variant == IAF_VARIANT_THEANO) ? -1 : 1;
+        for (int t = 0; t < NTAPS; ++t) { p.tap_dh[t] = sgn * tf_dh[t]; p.tap_dw[t] = sgn * tf_dw[t]; }
+        p.halo_before = (s->variant == IAF_VARIANT_THEANO) ? p.W + 1 : 0;
+        p.border = L.border;
+    }
     p.cin = L.cin; p.cout = L.cout; p.nchunk = L.nchunk; p.ncot = L.ncot;
     p.cp = L.cin + 8;
     p.nslot = tm + p.W + 1;

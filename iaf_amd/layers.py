@@ -113,6 +113,9 @@ class ARStack(object):
     depth_ar*[n_h2], models.py:92) -- all equal; n_out must be [n_z, n_z]."""
 
     def __init__(self, n_z, n_h, n_out=None, variant=_capi.IAF_VARIANT_TF):
+        if variant in ("tf", "theano"):
+            variant = _capi.IAF_VARIANT_THEANO if variant == "theano" else _capi.IAF_VARIANT_TF
+        self.variant = variant
         n_h = list(n_h)
         n_out = [n_z, n_z] if n_out is None else list(n_out)
         sizes = [n_z] + n_h
@@ -149,16 +152,7 @@ class ARStack(object):
         Re-derives masked weight-normed weights on the GPU (layers.py:56-60); cached until a tensor
         is replaced or modified in place."""
         names = self.conv_names()
-        sizes = [self.n_z] + self.n_h_list
-        tens = []
-        for ci, nm in enumerate(names):
-            n_in = sizes[min(ci, self.depth_ar)]
-            n_out = sizes[ci + 1] if ci < self.depth_ar else self.n_z
-            V, g, b = params[nm + "/V"], params[nm + "/g"], params[nm + "/b"]
-            _check_act(V, nm + "/V", (3, 3, n_in, n_out))
-            _check_act(g, nm + "/g", (n_out,))
-            _check_act(b, nm + "/b", (n_out,))
-            tens += [V, g, b]
+        tens = self._param_tensors(params)
         key = tuple((t.data_ptr(), t._version) for t in tens)
         if not force and key == self._prep_key:
             return
@@ -171,16 +165,25 @@ class ARStack(object):
         self._prep_key, self._keepalive = key, tens
 
     def _param_tensors(self, params):
-        names = self.conv_names()
+        """[V, g, b] per conv in engine order.  TF variant: "<conv>/V|g|b", V HWIO [3,3,n_in,n_out] (layers.py:53-55).
+        Theano variant: "<i>_w|_s|_b" and "out_<i>_w|_s|_b" relative to the multiconv2d name, w OIHW
+        [n_out, n_in+1, 3, 3] (ar.py:288-296); the engine's (V, g, b) slots carry (w, s, b)."""
         sizes = [self.n_z] + self.n_h_list
         tens = []
+        theano = self.variant == _capi.IAF_VARIANT_THEANO
+        names = self.conv_names()
         for ci, nm in enumerate(names):
             n_in = sizes[min(ci, self.depth_ar)]
             n_out = sizes[ci + 1] if ci < self.depth_ar else self.n_z
-            V, g, b = params[nm + "/V"], params[nm + "/g"], params[nm + "/b"]
-            _check_act(V, nm + "/V", (3, 3, n_in, n_out))
-            _check_act(g, nm + "/g", (n_out,))
-            _check_act(b, nm + "/b", (n_out,))
+            if theano:
+                base = ("%d" % ci) if ci < self.depth_ar else ("out_%d" % (ci - self.depth_ar))
+                V, g, b = params[base + "_w"], params[base + "_s"], params[base + "_b"]
+                _check_act(V, base + "_w", (n_out, n_in + 1, 3, 3))
+            else:
+                V, g, b = params[nm + "/V"], params[nm + "/g"], params[nm + "/b"]
+                _check_act(V, nm + "/V", (3, 3, n_in, n_out))
+            _check_act(g, nm + " scale", (n_out,))
+            _check_act(b, nm + " bias", (n_out,))
             tens += [V, g, b]
         return tens
 
@@ -311,6 +314,34 @@ class PrepBatch(object):
         self._keepalive = tens
         for st in self.stacks:
             st._prep_key = None      # per-stack cache no longer describes what is on the device
+
+
+class _Struct(object):
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+    def __call__(self, *a, **k):
+        return self.f(*a, **k)
+
+
+def multiconv2d(name, n_in, n_h, n_out, size_kernel=(3, 3), flipmask=False, nl="elu", w=None):
+    """Mirror of graphy/nodes/ar.py:378-423 (the Theano statement of the operator): returns a callable struct
+    `f(h, context, w)` -> [out_0, out_1] reading w[name+'_%d_w'|'_b'|'_s'] and w[name+'_out_%d_...'] (ar.py:288-296),
+    as constructed at models.py:63,92 with flipmask=False and nl='elu' (train.py:61)."""
+    if isinstance(n_out, int):
+        n_out = [n_out]
+    if tuple(size_kernel) != (3, 3) or flipmask or nl != "elu":
+        raise ValueError("the gfx950 engine implements size_kernel=(3,3), flipmask=False, nl='elu'")
+    stack = ARStack(n_in, list(n_h), list(n_out), variant=_capi.IAF_VARIANT_THEANO)
+
+    def f(h, context, w, return_hiddens=False):
+        if return_hiddens:
+            raise ValueError("hidden activations stay on chip; return_hiddens is not available")
+        rel = {k[len(name) + 1:]: v for k, v in w.items() if k.startswith(name + "_")}
+        stack.prepare(rel)
+        return stack.ar_multiconv2d(h, context)
+
+    return _Struct(f=f, w=w, stack=stack, postup=lambda updates, w: updates)
 
 
 def _is_elu(nl):

@@ -35,6 +35,9 @@ extern "C" {
 #define IAF_ERR_UNSUPPORTED (-6)   /* shape outside what the gfx950 kernels cover (channels % 16) */
 
 #define IAF_VARIANT_TF 0           /* tf_utils/layers.py statement (parity target) */
+#define IAF_VARIANT_THEANO 1       /* graphy/nodes/ar.py statement: flipped kernel (taps look left/above), border-indicator
+                                      input channel, exp(3*s) scale, +1e-8 in the norm.  Weights: V[i] = <name>_w OIHW
+                                      [n_out][n_in+1][3][3], g[i] = <name>_s, b[i] = <name>_b (ar.py:288-296) */
 
 /* ABI / build identification; also proves the library loaded. */
 int iaf_abi_version(void);

@@ -187,6 +187,43 @@ def test_posterior_block_vs_oracle(amd, shape, kl_min):
     np.testing.assert_allclose(host(out["kl_obj"]), e["kl_obj"], atol=2e-3, rtol=1e-4)
 
 
+# ---------------------------------------------------------------- Theano statement
+def _theano_params(rng, name, n_z, n_h_list):
+    w = {}
+    sizes = [n_z] + n_h_list
+    for i in range(len(n_h_list)):
+        w["%s_%d_w" % (name, i)] = 0.05 * rng.standard_normal((sizes[i + 1], sizes[i] + 1, 3, 3))
+        w["%s_%d_b" % (name, i)] = 0.1 * rng.standard_normal(sizes[i + 1])
+        w["%s_%d_s" % (name, i)] = 0.1 * rng.standard_normal(sizes[i + 1])
+    for i in range(2):
+        w["%s_out_%d_w" % (name, i)] = 0.05 * rng.standard_normal((n_z, sizes[-1] + 1, 3, 3))
+        w["%s_out_%d_b" % (name, i)] = 0.1 * rng.standard_normal(n_z)
+        w["%s_out_%d_s" % (name, i)] = 0.1 * rng.standard_normal(n_z)
+    return w
+
+
+@pytest.mark.parametrize("shape", [(3, 32, 160, 2, 16, 16), (4, 32, 160, 2, 8, 8), (2, 32, 64, 1, 4, 4), (2, 64, 64, 4, 5, 3),
+                                   (32, 32, 160, 2, 8, 8)], ids=lambda s: "B%d_z%d_h%d_d%d_%dx%d" % s)
+def test_theano_variant_vs_oracle(amd, shape):
+    """graphy/nodes/ar.py multiconv2d + models.py:281-285 on the GPU vs the (unpinned) oracle restatement"""
+    B, n_z, n_h, d, H, W = shape
+    rng = np.random.RandomState(400 + H)
+    name = "1_posterior_conv1"
+    w = _theano_params(rng, name, n_z, [n_h] * d)
+    z = rng.standard_normal((B, n_z, H, W))
+    ctx = rng.standard_normal((B, n_h, H, W))
+    conv = amd.multiconv2d(name, n_z, [n_h] * d, [n_z, n_z], (3, 3), False, nl="elu", w=None)
+    m_raw, s_raw = conv(dev(z), dev(ctx), {k: dev(v) for k, v in w.items()})
+    w32 = {k: f32(v) for k, v in w.items()}
+    em, es = O.theano_multiconv2d(f32(z), f32(ctx), w32, name, n_z, [n_h] * d, [n_z, n_z])
+    np.testing.assert_allclose(host(m_raw), em, atol=ATOL, rtol=0)
+    np.testing.assert_allclose(host(s_raw), es, atol=ATOL, rtol=0)
+    z_new, logsd = conv.stack.iaf_step(dev(z), dev(ctx))
+    ez, el = O.theano_iaf2_nl(f32(z), f32(ctx), w32, name, n_z, [n_h] * d)
+    np.testing.assert_allclose(host(z_new), ez, atol=ATOL, rtol=0)
+    np.testing.assert_allclose(host(logsd), el, atol=ATOL, rtol=0)
+
+
 # ---------------------------------------------------------------- distributions
 def test_distributions_vs_reference_golden(amd, golden_dir):
     g = np.load(os.path.join(golden_dir, "distributions.npz"))
