@@ -437,18 +437,35 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
             static_for<RCH>([&](auto i) { chunk_body(i, T{}, T{}, c + decltype(i)::value); });
         IAF_STAMP(3);
         prefetch_epilogue();                         // >= one ring revolution of MFMA work left to hide it
-        static_for<RCH>([&](auto i) {                // drain, first ring revolution
-            const int cc = c + decltype(i)::value;
-            if (cc < c_end) {
-                if (cc + RCH < c_end) chunk_body(i, T{}, T{}, cc);
-                else if (cc + RCH - 1 < c_end) chunk_body(i, T{}, F{}, cc);
-                else chunk_body(i, F{}, F{}, cc);
-            }
-        });
-        static_for<RCH>([&](auto i) {                // drain, second revolution
-            const int cc = c + RCH + decltype(i)::value;
-            if (cc < c_end) chunk_body(i, F{}, F{}, cc);
-        });
+        // drain: rem < 2*RCH chunks are left and chunk c sits in ring slot 0.  Which steps still refill depends only on
+        // rem, so each value of rem gets its own STRAIGHT-LINE body (per-chunk `if`s here made hipcc emit vmcnt(0) and
+        // expose a full memory latency -- and small problems spend their whole K loop in this code).
+        const int rem = c_end - c;
+        if constexpr (RCH <= 4) {
+            static_for<2 * RCH>([&](auto rem_c) {
+                constexpr int REM = decltype(rem_c)::value;
+                if (rem == REM) {
+                    static_for<REM>([&](auto i_c) {
+                        constexpr int i = decltype(i_c)::value;
+                        chunk_body(std::integral_constant<int, i % RCH>{}, std::bool_constant<(i + RCH - 1 < REM)>{},
+                                   std::bool_constant<(i + RCH < REM)>{}, c + i);
+                    });
+                }
+            });
+        } else {                                     // deep rings (NT == 1): code size wins, keep the generic form
+            static_for<RCH>([&](auto i) {
+                const int cc = c + decltype(i)::value;
+                if (cc < c_end) {
+                    if (cc + RCH < c_end) chunk_body(i, T{}, T{}, cc);
+                    else if (cc + RCH - 1 < c_end) chunk_body(i, T{}, F{}, cc);
+                    else chunk_body(i, F{}, F{}, cc);
+                }
+            });
+            static_for<RCH>([&](auto i) {
+                const int cc = c + RCH + decltype(i)::value;
+                if (cc < c_end) chunk_body(i, F{}, F{}, cc);
+            });
+        }
     }
     }
     if (NT == 1) acc[0] += acc[1];
