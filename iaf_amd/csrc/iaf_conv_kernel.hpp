@@ -28,6 +28,11 @@ __device__ __forceinline__ void static_for(F&& f) {
 #define MODE_RAW 0        // out0 = m_raw, out1 = s_raw                         (layers.py:166)
 #define MODE_IAF 1        // out0 = (z-0.1m)/exp(0.1s), out1 = 0.1s             (tf_train.py:70-72)
 #define MODE_POSTERIOR 2  // MODE_IAF on z0 rebuilt from the posterior inputs, plus kl elements
+// backward (data gradient) modes of EPI_HIDDEN: the same kernel run on the transposed packed weights with the tap
+// table negated computes dX = W^T * dY; the epilogue applies what autodiff applies next.
+#define MODE_DGRAD_ELU 3  // y = acc * elu'(a) with elu'(a) = (h > 0 ? 1 : h + 1), h = saved activation (p.zin, pixel-major);
+                          // optional NCHW copy to p.out0 (d context, layers.py:163-164)
+#define MODE_DGRAD_Z 4    // out0[NCHW] = acc + dz_new * exp(-logsd)   (p.qm = dz_new, p.ql = logsd; tf_train.py:71)
 
 #define IN_PIXMAJOR 0     // x is [P][c_in] scratch written by a previous EPI_HIDDEN
 #define IN_NCHW 1         // x is an NCHW tensor (z)
@@ -297,8 +302,17 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
             const int u = kh + i * KS;
             if (u >= NUNIT) continue;
             if (EPI == EPI_HIDDEN) {
-                pbias[i] = *(const f32x4*)(p.bias + (cot0 + u) * 16 + 4 * kk);
-                if (p.ctx) {
+                pbias[i] = p.bias ? *(const f32x4*)(p.bias + (cot0 + u) * 16 + 4 * kk) : f32x4{0.f, 0.f, 0.f, 0.f};
+                if (p.mode == MODE_DGRAD_ELU) {
+                    pre0[i] = *(const f32x4*)(p.zin + (size_t)Pl * p.cout + (cot0 + u) * 16 + 4 * kk);
+                } else if (p.mode == MODE_DGRAD_Z) {
+                    const size_t cb = ((size_t)bimg * p.cout + (cot0 + u) * 16 + 4 * kk) * HW + pp;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        pre0[i][r] = p.qm[cb + (size_t)r * HW];
+                        pre1[i][r] = p.ql[cb + (size_t)r * HW];
+                    }
+                } else if (p.ctx) {
                     const size_t cb = ((size_t)bimg * p.cout + (cot0 + u) * 16 + 4 * kk) * HW + pp;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) pre0[i][r] = p.ctx[cb + (size_t)r * HW];
@@ -513,6 +527,23 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
             if (EPI == EPI_HIDDEN) {
                 const int co = (cot0 + u) * 16 + 4 * kk;
                 f32x4 v = val[i] + pbias[i];
+                if (p.mode == MODE_DGRAD_ELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] *= (pre0[i][r] > 0.f ? 1.f : pre0[i][r] + 1.f);
+                    *(f32x4*)(p.y + (size_t)Pl * p.cout + co) = v;
+                    if (p.out0) {
+                        const size_t cb = ((size_t)bimg * p.cout + co) * HW + pp;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) p.out0[cb + (size_t)r * HW] = v[r];
+                    }
+                    continue;
+                }
+                if (p.mode == MODE_DGRAD_Z) {
+                    const size_t cb = ((size_t)bimg * p.cout + co) * HW + pp;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) p.out0[cb + (size_t)r * HW] = v[r] + pre0[i][r] * __expf(-pre1[i][r]);
+                    continue;
+                }
                 if (p.border) {   // Theano pad_channel (conv.py:71-83, ar.py:229-233): taps that fall outside see a 1
 #pragma unroll
                     for (int t = 1; t < NTAPS; ++t)

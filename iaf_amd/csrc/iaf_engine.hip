@@ -67,6 +67,7 @@ struct PrepLayer {
     float* wp;       // packed weights [chunk][tap][cot][64][4]
     float* bias;     // packed bias [ncot*16]
     float* border;   // Theano variant: [4][ncot*16] normalised weights of the border-indicator channel (taps 1..4)
+    float* wpt;      // training: TRANSPOSED pack [chunk over packed c_out][tap][c_in tile][64][4] for dX = W^T dY (or NULL)
     int cin, cout_each, ncot, nchunk, zerodiag, npair, tile_begin, variant;
 };
 struct PrepArgs {
@@ -122,6 +123,13 @@ __device__ __forceinline__ void prep_tile(const PrepLayer& L, int gt, float (*re
 #pragma unroll
         for (int t = 0; t < NTAPS; ++t)
             L.wp[((((size_t)it * NTAPS + t) * L.ncot + gt) * 64 + kk * 16 + oo) * 4 + jj] = v[t][it] * scale;
+    if (L.wpt) {   // dgrad operand: K runs over the packed output channels (chunk = gt), N over input tiles (it)
+#pragma unroll
+        for (int it = 0; it < NCH; ++it)
+#pragma unroll
+            for (int t = 0; t < NTAPS; ++t)
+                L.wpt[((((size_t)gt * NTAPS + t) * NCH + it) * 64 + (oo >> 2) * 16 + cs) * 4 + (oo & 3)] = v[t][it] * scale;
+    }
 }
 
 // Theano statement of the same weights (graphy/nodes/ar.py:243-330, l2norm=True, logscale=True, pad_channel=True):
@@ -350,6 +358,172 @@ __global__ void iaf_lb_k1_kernel(const float* log_pxz, const float* sum_kl, floa
 }
 
 // ---------------------------------------------------------------------------------------------
+// backward of the IAF step (what TF autodiff derives from tf_train.py:69-72 + layers.py:52-64,158-166)
+// ---------------------------------------------------------------------------------------------
+// (1) affine + log-det:  z_new = (z - 0.1 m_raw) e^{-0.1 s_raw},  logsd = 0.1 s_raw
+//       d m_raw = -0.1 dz_new e^{-logsd};   d s_raw = 0.1 (dlogsd - dz_new z_new)
+//     written pixel-major in the PACKED channel order of the output GEMM (tiles m0,s0,m1,s1,...), plus a pixel-major
+//     copy of z (operand of the first conv's weight gradient).
+__global__ __launch_bounds__(256) void iaf_bwd_affine_kernel(const float* __restrict__ z, const float* __restrict__ z_new,
+                                                            const float* __restrict__ logsd, const float* __restrict__ dzn,
+                                                            const float* __restrict__ dls, float* __restrict__ dy3,
+                                                            float* __restrict__ zpm, int n_z, int HW, long long total) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        // i runs pixel-major: channel fastest (coalesced writes); NCHW reads are strided but the tensors are tiny
+        const int c = (int)(i % n_z);
+        const long long P = i / n_z;
+        const long long b = P / HW, pp = P - b * HW;
+        const size_t src = ((size_t)b * n_z + c) * HW + pp;
+        const float g = dzn[src], ls = logsd[src];
+        const float dm = -0.1f * g * __expf(-ls);
+        const float ds = 0.1f * (dls[src] - g * z_new[src]);
+        const size_t row = (size_t)P * (2 * n_z) + (size_t)(c >> 4) * 32 + (c & 15);
+        dy3[row] = dm;
+        dy3[row + 16] = ds;
+        zpm[(size_t)P * n_z + c] = z[src];
+    }
+}
+
+// (2) weight gradient of one masked conv:  dW[tap][ci][co] = sum_p X[p + shift(tap)][ci] * dY[p][co]
+//     as MFMA GEMM  D[ci][co] += A[ci][k = pixel] B[k = pixel][co]  on pixel-major X [P][cin] and dY [P][cout].
+//     Workgroup = (tap, pair of ci tiles, pixel range); its 4 waves split the range, reduce through LDS and write one
+//     partial [krange][tap][cin][cout]; the partials are summed by iaf_wn_bwd_kernel.  Operands are dword loads
+//     straight from L1/L2 (A: 2 per K step, B: NCOT per K step for 2*NCOT MFMAs).
+struct WgradP {
+    const float* x;      // [P][cin]
+    const float* dy;     // [P][cout]
+    float* part;         // [nrange][NTAPS][cin][cout]
+    int B, H, W, HW, P, cin, cout, nrange, px_per_range;
+    int tap_dh[NTAPS], tap_dw[NTAPS];
+};
+
+template <int NCOT>
+__global__ __launch_bounds__(256) void iaf_wgrad_kernel(WgradP p) {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tap = blockIdx.x % NTAPS;
+    const int cip = blockIdx.x / NTAPS;            // pair of ci tiles
+    const int range = blockIdx.y;
+    const int cob = blockIdx.z * NCOT * 16;        // this workgroup's first packed output channel
+    const int ci0 = cip * 32;
+    const int nci = (p.cin - ci0 >= 32) ? 2 : 1;   // c_in = 16 has a single tile
+    const int i15 = lane & 15, ks = lane >> 4;
+    const int dh = p.tap_dh[tap], dw = p.tap_dw[tap];
+    f32x4 acc[2][NCOT];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int t = 0; t < NCOT; ++t) acc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int r0 = range * p.px_per_range;
+    const int r1 = min(p.P, r0 + p.px_per_range);
+    // wave w takes K steps w, w+4, ... of the range (4 pixels each)
+    for (int pb = r0 + 4 * wave; pb < r1; pb += 16) {
+        const int pk = pb + ks;                    // this lane's pixel for both operands
+        const bool pv = pk < r1;
+        const int b = pk / p.HW, pp = pk - b * p.HW;
+        const int h = pp / p.W, w = pp - h * p.W;
+        const bool xv = pv && (h + dh >= 0) && (h + dh < p.H) && (w + dw >= 0) && (w + dw < p.W);
+        const long long xp = (long long)pk + dh * p.W + dw;
+        float av[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) av[a] = (xv && a < nci) ? p.x[xp * p.cin + ci0 + a * 16 + i15] : 0.f;
+        float bv[NCOT];
+#pragma unroll
+        for (int t = 0; t < NCOT; ++t) bv[t] = pv ? p.dy[(size_t)pk * p.cout + cob + t * 16 + i15] : 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int t = 0; t < NCOT; ++t) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[t], acc[a][t], 0, 0, 0);
+    }
+    // reduce the 4 waves through LDS: [wave][a][t][r][lane]
+    float* mine = wsm + (size_t)wave * (2 * NCOT * 4 * 64) + lane;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int t = 0; t < NCOT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mine[((a * NCOT + t) * 4 + r) * 64] = acc[a][t][r];
+    __syncthreads();
+    // D layout: lane holds D[row = 4*(l>>4)+r][col = l&15] = (ci = tile*16 + 4*ks + r, co = t*16 + i15)
+    float* out = p.part + (((size_t)range * NTAPS + tap) * p.cin) * p.cout;
+    for (int e = wave; e < 2 * NCOT * 4; e += 4) {            // (a, t, r) triples spread over the waves
+        const int a = e / (NCOT * 4), t = (e / 4) % NCOT, r = e & 3;
+        if (a >= nci) continue;
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sum += wsm[(size_t)k * (2 * NCOT * 4 * 64) + (size_t)e * 64 + lane];
+        out[(size_t)(ci0 + a * 16 + 4 * ks + r) * p.cout + cob + t * 16 + i15] = sum;
+    }
+}
+
+// (3) reduce the partials and push the gradient through mask + weight-norm (layers.py:57,60):
+//       w = e u,  u = v / n,  v = mask V,  n = ||v||_o,  e = exp(g)
+//       dg = sum dW w ;  dv = (e / n) (dW - u (sum dW u)) ;  dV = mask dv ;  db = sum_p dY
+//     One workgroup per 16 output channels (same thread map as the prep kernel).
+struct WnBwdLayer {
+    const float* V; const float* g;      // reference variables of THIS conv (HWIO V)
+    const float* part;                   // [nrange][NTAPS][cin][cout_packed]
+    const float* dy;                     // [P][cout_packed]
+    float* dV; float* dg; float* db;     // outputs: HWIO [3][3][cin][cout], [cout], [cout]
+    int cin, cout, cout_packed, nrange, zerodiag, pack_stride, pack_off;   // packed channel of o: (o/16)*pack_stride*16 + pack_off*16 + o%16
+};
+
+__global__ __launch_bounds__(256) void iaf_wn_bwd_kernel(WnBwdLayer L, int P) {
+    __shared__ float red[3][16][17];
+    __shared__ float s_n[16], s_dot[16];
+    const int oo = threadIdx.x & 15, cs = threadIdx.x >> 4;
+    const int o = blockIdx.x * 16 + oo;
+    const int op = (o >> 4) * L.pack_stride * 16 + L.pack_off * 16 + (o & 15);   // packed channel index
+    const int n_in = L.cin, n_out = L.cout;
+    float ss = 0.f, dot = 0.f, dbs = 0.f;
+    // pass 1: norms and <dW, v>
+    for (int t = 0; t < NTAPS; ++t) {
+        const int kh = (t == 0 || t == 1) ? 1 : 2;
+        const int kw = (t == 0) ? 1 : (t == 1 ? 2 : t - 2);
+        for (int ci = cs; ci < n_in; ci += 16) {
+            const bool live = (t != 0) || made_live(ci, o, n_in, n_out, L.zerodiag);
+            const float v = live ? L.V[((size_t)(kh * 3 + kw) * n_in + ci) * n_out + o] : 0.f;
+            float dW = 0.f;
+            for (int k = 0; k < L.nrange; ++k) dW += L.part[(((size_t)k * NTAPS + t) * n_in + ci) * L.cout_packed + op];
+            ss += v * v;
+            dot += dW * v;
+        }
+    }
+    for (int pix = cs; pix < P; pix += 16) dbs += L.dy[(size_t)pix * L.cout_packed + op];
+    red[0][cs][oo] = ss; red[1][cs][oo] = dot; red[2][cs][oo] = dbs;
+    __syncthreads();
+    if (cs == 0) {
+        float a = 0.f, b = 0.f, c = 0.f;
+        for (int i = 0; i < 16; ++i) { a += red[0][i][oo]; b += red[1][i][oo]; c += red[2][i][oo]; }
+        const float n = sqrtf(fmaxf(a, 1e-12f));
+        const float e = expf(L.g[o]);
+        s_n[oo] = n;
+        s_dot[oo] = b / n;                 // sum dW u
+        L.dg[o] = e * b / n;               // sum dW w
+        L.db[o] = c;
+    }
+    __syncthreads();
+    const float n = s_n[oo], du = s_dot[oo], e = expf(L.g[o]);
+    // pass 2: dV (all 9 taps; the 4 dead taps and masked centre entries are exact zeros)
+    for (int kk9 = 0; kk9 < 9; ++kk9) {
+        const int kh = kk9 / 3, kw = kk9 % 3;
+        const int t = (kh == 1 && kw == 1) ? 0 : (kh == 1 && kw == 2) ? 1 : (kh == 2) ? 2 + kw : -1;
+        for (int ci = cs; ci < n_in; ci += 16) {
+            float outv = 0.f;
+            const bool live = (t >= 0) && ((t != 0) || made_live(ci, o, n_in, n_out, L.zerodiag));
+            if (live) {
+                const float v = L.V[((size_t)kk9 * n_in + ci) * n_out + o];
+                float dW = 0.f;
+                for (int k = 0; k < L.nrange; ++k) dW += L.part[(((size_t)k * NTAPS + t) * n_in + ci) * L.cout_packed + op];
+                outv = (e / n) * (dW - (v / n) * du);
+            }
+            L.dV[((size_t)kk9 * n_in + ci) * n_out + o] = outv;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side: stack object
 // ---------------------------------------------------------------------------------------------
 struct GemmLayer {
@@ -359,6 +533,7 @@ struct GemmLayer {
     float* wp = nullptr;
     float* bias = nullptr;
     float* border = nullptr;   // Theano variant only
+    float* wpt = nullptr;      // transposed pack for dgrad (allocated by iaf_stack_set_training)
     int* lim = nullptr;
     // launch shape: fixed by iaf_stack_set_tuning (user_tuned) or chosen per problem size by auto_shape()
     int nt, pxt, wco, ks;
@@ -370,6 +545,8 @@ struct iaf_stack {
     int n_z, n_h, depth_ar, variant;
     int nlayers;          // depth_ar + 1
     GemmLayer L[MAX_GEMM_LAYERS];
+    GemmLayer T[MAX_GEMM_LAYERS];   // transposed problems (dX = W^T dY) of the same layers; valid when training
+    bool training = false;
     bool prepared;
     size_t weight_bytes;  // raw V/g/b bytes of the stack (for the algorithmic byte count)
     // optional per-launch event timing of one layer
@@ -569,6 +746,7 @@ extern "C" int iaf_stack_destroy(iaf_stack_t* s) {
         if (s->L[l].wp) (void)hipFree(s->L[l].wp);
         if (s->L[l].bias) (void)hipFree(s->L[l].bias);
         if (s->L[l].border) (void)hipFree(s->L[l].border);
+        if (s->L[l].wpt) (void)hipFree(s->L[l].wpt);
         if (s->L[l].lim) (void)hipFree(s->L[l].lim);
     }
     delete s;
@@ -604,7 +782,7 @@ extern "C" int iaf_stack_prepare(iaf_stack_t* s, const float* const* V, const fl
         PrepLayer& P = a.L[l];
         P.V[0] = V[l]; P.g[0] = g[l]; P.b[0] = b[l];
         if (L.npair == 2) { P.V[1] = V[l + 1]; P.g[1] = g[l + 1]; P.b[1] = b[l + 1]; }
-        P.wp = L.wp; P.bias = L.bias; P.border = L.border; P.variant = s->variant;
+        P.wp = L.wp; P.bias = L.bias; P.border = L.border; P.variant = s->variant; P.wpt = L.wpt;
         P.cin = L.cin; P.cout_each = L.cout / L.npair; P.ncot = L.ncot; P.nchunk = L.nchunk;
         P.zerodiag = L.zerodiag; P.npair = L.npair; P.tile_begin = tiles;
         tiles += L.ncot;
@@ -664,7 +842,7 @@ extern "C" int iaf_prep_batch_create(iaf_prep_batch_t** out, iaf_stack_t* const*
         for (int l = 0; l < stacks[i]->nlayers; ++l, ++li) {
             const GemmLayer& L = stacks[i]->L[l];
             PrepLayer& P = b->h_layers[li];
-            P.wp = L.wp; P.bias = L.bias; P.border = L.border; P.variant = stacks[i]->variant;
+            P.wp = L.wp; P.bias = L.bias; P.border = L.border; P.variant = stacks[i]->variant; P.wpt = L.wpt;
             P.cin = L.cin; P.cout_each = L.cout / L.npair; P.ncot = L.ncot; P.nchunk = L.nchunk;
             P.zerodiag = L.zerodiag; P.npair = L.npair; P.tile_begin = tile;
             for (int t = 0; t < L.ncot; ++t) t2l[tile++] = li;
@@ -765,26 +943,25 @@ static void auto_shape(GemmLayer& L, bool is_out, long long P, int W) {
     if (bs >= 0) { L.nt = bnt; L.pxt = k_shapes[bs][0]; L.wco = k_shapes[bs][1]; L.ks = k_shapes[bs][2]; }
 }
 
-static int launch_conv(const iaf_stack_t* s, int layer, ConvP& p, int inmode, hipStream_t st) {
-    if (!s->L[layer].user_tuned)
-        auto_shape(const_cast<iaf_stack*>(s)->L[layer], layer == s->depth_ar, p.P, p.W);
-    const GemmLayer& L = s->L[layer];
-    const bool is_out = (layer == s->depth_ar);
+// launches the conv kernel for GEMM descriptor L (forward layer, or a transposed descriptor for dgrad)
+static int launch_gemm(const iaf_stack_t* s, GemmLayer& L, bool is_out, bool negate_taps, int prof_id, ConvP& p, int inmode,
+                       hipStream_t st) {
+    if (!L.user_tuned) auto_shape(L, is_out, p.P, p.W);
     conv_fn_t fn = pick_kernel(L.nt, L.pxt, L.wco, L.ks, inmode, is_out ? EPI_OUT : EPI_HIDDEN);
     if (!fn) return IAF_ERR_UNSUPPORTED;
     const int tm = 16 * L.pxt;
     p.wp = L.wp; p.bias = L.bias; p.lim = L.lim;
-    {   // tap geometry of the two statements of the operator (see ConvP)
+    {   // tap geometry of the two statements of the operator (see ConvP); the data gradient runs the mirrored taps
         static const int tf_dh[NTAPS] = {0, 0, 1, 1, 1}, tf_dw[NTAPS] = {0, 1, -1, 0, 1};
-        const int sgn = (s->variant == IAF_VARIANT_THEANO) ? -1 : 1;
+        const int sgn = ((s->variant == IAF_VARIANT_THEANO) != negate_taps) ? -1 : 1;
         for (int t = 0; t < NTAPS; ++t) { p.tap_dh[t] = sgn * tf_dh[t]; p.tap_dw[t] = sgn * tf_dw[t]; }
-        p.halo_before = (s->variant == IAF_VARIANT_THEANO) ? p.W + 1 : 0;
-        p.border = L.border;
+        p.halo_before = (sgn < 0) ? p.W + 1 : 0;
+        p.border = negate_taps ? nullptr : L.border;
     }
     p.cin = L.cin; p.cout = L.cout; p.nchunk = L.nchunk; p.ncot = L.ncot;
     p.cp = L.cin + 8;
     p.nslot = tm + p.W + 1;
-    p.dbg = (s->dbg_layer == layer) ? s->dbg : nullptr;
+    p.dbg = (prof_id >= 0 && s->dbg_layer == prof_id) ? s->dbg : nullptr;
     const size_t lds = conv_lds_bytes(L, p.W);
     if (lds > 160 * 1024) return IAF_ERR_UNSUPPORTED;
     if (lds > 48 * 1024) {   // raise the dynamic-LDS cap once per kernel (never inside a stream capture)
@@ -797,12 +974,16 @@ static int launch_conv(const iaf_stack_t* s, int layer, ConvP& p, int inmode, hi
         }
     }
     dim3 grid((p.P + tm - 1) / tm, L.ncot / (L.nt * L.wco));
-    const bool prof = (s->prof_layer == layer && s->prof_n < s->prof_cap);
+    const bool prof = (prof_id >= 0 && s->prof_layer == prof_id && s->prof_n < s->prof_cap);
     iaf_stack* ms = const_cast<iaf_stack*>(s);
     if (prof) HIP_TRY(hipEventRecord(ms->prof_start[ms->prof_n], st));
     hipLaunchKernelGGL(fn, grid, dim3(64 * L.pxt * L.wco * L.ks), lds, st, p);
     if (prof) { HIP_TRY(hipEventRecord(ms->prof_stop[ms->prof_n], st)); ms->prof_n++; }
     return (int)hipGetLastError();
+}
+
+static int launch_conv(const iaf_stack_t* s, int layer, ConvP& p, int inmode, hipStream_t st) {
+    return launch_gemm(s, const_cast<iaf_stack*>(s)->L[layer], layer == s->depth_ar, false, layer, p, inmode, st);
 }
 
 static int check_dims(const iaf_stack_t* s, int B, int H, int W) {
@@ -1006,6 +1187,210 @@ extern "C" int iaf_compute_lowerbound(const float* log_pxz, const float* sum_kl,
     int rc = (int)hipGetLastError();
     HIP_TRY(hipFreeAsync(state, st));
     return rc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// training: forward that keeps the hidden activations + backward
+// ---------------------------------------------------------------------------------------------
+extern "C" int iaf_stack_set_training(iaf_stack_t* s, int on) {
+    if (!s) return IAF_ERR_NULL;
+    if (s->variant != IAF_VARIANT_TF) return IAF_ERR_UNSUPPORTED;
+    if (!on) { s->training = false; return IAF_OK; }
+    for (int l = 0; l < s->nlayers; ++l) {
+        GemmLayer& L = s->L[l];
+        if (!L.wpt) HIP_TRY(hipMalloc(&L.wpt, (size_t)L.nchunk * NTAPS * L.ncot * 256 * sizeof(float)));
+        GemmLayer& T = s->T[l];
+        T = GemmLayer();
+        T.cin = L.cout; T.cout = L.cin; T.nchunk = L.ncot; T.ncot = L.nchunk;
+        T.zerodiag = L.zerodiag; T.npair = 1;
+        T.wp = L.wpt; T.bias = nullptr; T.border = nullptr; T.lim = nullptr; T.wpt = nullptr;
+        T.nt = 1; T.pxt = 4; T.wco = 1; T.ks = 1; T.user_tuned = false;
+    }
+    s->training = true;
+    s->prepared = false;      // the transposed packs are written by the next prepare
+    return IAF_OK;
+}
+
+static int wgrad_nrange(long long P) {
+    long long n = P / 512;
+    if (n < 1) n = 1;
+    if (n > 16) n = 16;
+    return (int)n;
+}
+
+struct TrainWs {
+    float* h[MAX_GEMM_LAYERS];
+    float* da[2];
+    float* dy3;
+    float* zpm;
+    float* part;
+};
+
+static size_t train_ws_floats(const iaf_stack_t* s, long long P, TrainWs* o, float* base) {
+    size_t off = 0;
+    auto take = [&](size_t n) { float* q = base ? base + off : nullptr; off += (n + 63) / 64 * 64; return q; };
+    TrainWs t;
+    for (int l = 0; l < s->depth_ar; ++l) t.h[l] = take((size_t)P * s->n_h);
+    t.da[0] = take((size_t)P * s->n_h);
+    t.da[1] = take((size_t)P * s->n_h);
+    t.dy3 = take((size_t)P * 2 * s->n_z);
+    t.zpm = take((size_t)P * s->n_z);
+    size_t maxw = 0;
+    for (int l = 0; l < s->nlayers; ++l) {
+        const size_t w = (size_t)s->L[l].cin * s->L[l].cout;
+        if (w > maxw) maxw = w;
+    }
+    t.part = take((size_t)wgrad_nrange(P) * NTAPS * maxw);
+    if (o) *o = t;
+    return off;
+}
+
+extern "C" size_t iaf_stack_train_workspace_bytes(const iaf_stack_t* s, int B, int H, int W) {
+    if (!s || B <= 0 || H <= 0 || W <= 0) return 0;
+    return train_ws_floats(s, (long long)B * H * W, nullptr, nullptr) * sizeof(float);
+}
+
+extern "C" int iaf_step_forward_train(iaf_stack_t* s, const float* z, const float* context, float* z_new, float* logsd,
+                                      int B, int H, int W, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_dims(s, B, H, W);
+    if (rc) return rc;
+    if (!s->training) return IAF_ERR_NOT_PREPARED;
+    if (!z || !z_new || !logsd || !workspace || (s->depth_ar > 0 && !context)) return IAF_ERR_NULL;
+    if (((uintptr_t)workspace & 15) != 0 || workspace_bytes < iaf_stack_train_workspace_bytes(s, B, H, W)) return IAF_ERR_WORKSPACE;
+    TrainWs tw;
+    train_ws_floats(s, (long long)B * H * W, &tw, (float*)workspace);
+    hipStream_t st = (hipStream_t)stream;
+    ConvP base;
+    memset(&base, 0, sizeof(base));
+    base.B = B; base.H = H; base.W = W; base.HW = H * W; base.P = B * H * W;
+    base.zin = z; base.out0 = z_new; base.out1 = logsd; base.mode = MODE_IAF;
+    const float* cur = z;
+    int inmode = IN_NCHW;
+    for (int l = 0; l < s->depth_ar; ++l) {       // like run_stack, but every hidden activation gets its own buffer
+        ConvP p = base;
+        p.mode = 0;
+        p.x = cur;
+        p.ctx = (l == 0) ? context : nullptr;
+        p.y = tw.h[l];
+        if ((rc = launch_conv(s, l, p, inmode, st))) return rc;
+        cur = p.y;
+        inmode = IN_PIXMAJOR;
+    }
+    ConvP p = base;
+    p.x = cur;
+    return launch_conv(s, s->depth_ar, p, inmode, st);
+}
+
+template <int NCOT>
+static void launch_wgrad_t(const WgradP& p, dim3 grid, hipStream_t st) {
+    const size_t lds = (size_t)4 * 2 * NCOT * 4 * 64 * sizeof(float);
+    static bool attr_done = false;
+    if (lds > 48 * 1024 && !attr_done) {
+        (void)hipFuncSetAttribute((const void*)iaf_wgrad_kernel<NCOT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(iaf_wgrad_kernel<NCOT>, grid, dim3(256), lds, st, p);
+}
+
+static int launch_wgrad(const iaf_stack_t* s, const GemmLayer& L, const float* x, const float* dy, float* part, int B, int H,
+                        int W, hipStream_t st) {
+    WgradP p;
+    memset(&p, 0, sizeof(p));
+    p.x = x; p.dy = dy; p.part = part;
+    p.B = B; p.H = H; p.W = W; p.HW = H * W; p.P = B * H * W;
+    p.cin = L.cin; p.cout = L.cout;
+    p.nrange = wgrad_nrange(p.P);
+    p.px_per_range = (int)(((long long)p.P + p.nrange - 1) / p.nrange + 15) / 16 * 16;
+    static const int tf_dh[NTAPS] = {0, 0, 1, 1, 1}, tf_dw[NTAPS] = {0, 1, -1, 0, 1};
+    for (int t = 0; t < NTAPS; ++t) { p.tap_dh[t] = tf_dh[t]; p.tap_dw[t] = tf_dw[t]; }
+    static const int cand[] = {16, 12, 10, 8, 6, 5, 4, 3, 2, 1};
+    int ncot = 1;
+    for (int c : cand)
+        if (L.ncot % c == 0) { ncot = c; break; }
+    dim3 grid(NTAPS * ((L.cin + 31) / 32), p.nrange, L.ncot / ncot);
+    switch (ncot) {
+        case 16: launch_wgrad_t<16>(p, grid, st); break;
+        case 12: launch_wgrad_t<12>(p, grid, st); break;
+        case 10: launch_wgrad_t<10>(p, grid, st); break;
+        case 8: launch_wgrad_t<8>(p, grid, st); break;
+        case 6: launch_wgrad_t<6>(p, grid, st); break;
+        case 5: launch_wgrad_t<5>(p, grid, st); break;
+        case 4: launch_wgrad_t<4>(p, grid, st); break;
+        case 3: launch_wgrad_t<3>(p, grid, st); break;
+        case 2: launch_wgrad_t<2>(p, grid, st); break;
+        default: launch_wgrad_t<1>(p, grid, st); break;
+    }
+    (void)s;
+    return (int)hipGetLastError();
+}
+
+extern "C" int iaf_step_backward(iaf_stack_t* s, const float* z, const float* context, const float* z_new,
+                                 const float* logsd, const float* dz_new, const float* dlogsd, float* dz, float* dcontext,
+                                 const float* const* V, const float* const* g, float* const* dV, float* const* dg,
+                                 float* const* db, int B, int H, int W, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
+    int rc = check_dims(s, B, H, W);
+    if (rc) return rc;
+    if (!s->training) return IAF_ERR_NOT_PREPARED;
+    if (!z || !z_new || !logsd || !dz_new || !dlogsd || !dz || !V || !g || !dV || !dg || !db || !workspace) return IAF_ERR_NULL;
+    if (s->depth_ar > 0 && (!context || !dcontext)) return IAF_ERR_NULL;
+    for (int i = 0; i < s->depth_ar + 2; ++i)
+        if (!V[i] || !g[i] || !dV[i] || !dg[i] || !db[i]) return IAF_ERR_NULL;
+    if (((uintptr_t)workspace & 15) != 0 || workspace_bytes < iaf_stack_train_workspace_bytes(s, B, H, W)) return IAF_ERR_WORKSPACE;
+    const int P = B * H * W, d = s->depth_ar;
+    TrainWs tw;
+    train_ws_floats(s, P, &tw, (float*)workspace);
+    hipStream_t st = (hipStream_t)stream;
+    const int nrange = wgrad_nrange(P);
+
+    // (1) affine + log-det backward -> packed pixel-major dY of the output GEMM, pixel-major copy of z
+    {
+        const long long total = (long long)P * s->n_z;
+        long long blocks = (total + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(iaf_bwd_affine_kernel, dim3((unsigned)blocks), dim3(256), 0, st, z, z_new, logsd, dz_new, dlogsd,
+                           tw.dy3, tw.zpm, s->n_z, H * W, total);
+    }
+    ConvP base;
+    memset(&base, 0, sizeof(base));
+    base.B = B; base.H = H; base.W = W; base.HW = H * W; base.P = P;
+
+    auto wn_bwd = [&](int conv_index, const GemmLayer& L, const float* dy, int n_out_each, int pack_stride, int pack_off) {
+        WnBwdLayer w;
+        w.V = V[conv_index]; w.g = g[conv_index];
+        w.part = tw.part; w.dy = dy;
+        w.dV = dV[conv_index]; w.dg = dg[conv_index]; w.db = db[conv_index];
+        w.cin = L.cin; w.cout = n_out_each; w.cout_packed = L.cout; w.nrange = nrange; w.zerodiag = L.zerodiag;
+        w.pack_stride = pack_stride; w.pack_off = pack_off;
+        hipLaunchKernelGGL(iaf_wn_bwd_kernel, dim3(n_out_each / 16), dim3(256), 0, st, w, P);
+    };
+
+    // (2) walk the layers backwards: data gradient (same conv kernel on W^T, mirrored taps), then weight gradient
+    const float* dy = tw.dy3;                       // gradient w.r.t. the output of layer l (packed pixel-major)
+    for (int l = d; l >= 0; --l) {
+        const float* x_in = (l == 0) ? tw.zpm : tw.h[l - 1];     // what layer l read in the forward pass
+        ConvP p = base;
+        p.x = dy;
+        if (l == 0) {                               // dz = W_0^T dY + dz_new e^{-logsd}
+            p.mode = MODE_DGRAD_Z;
+            p.qm = dz_new; p.ql = logsd; p.out0 = dz;
+        } else {                                    // d a_{l-1} = (W_l^T dY) elu'(h_{l-1})   (+ NCHW copy = d context)
+            p.mode = MODE_DGRAD_ELU;
+            p.zin = tw.h[l - 1];
+            p.y = tw.da[(l - 1) & 1];
+            p.out0 = (l - 1 == 0) ? dcontext : nullptr;
+        }
+        if ((rc = launch_gemm(s, s->T[l], false, true, -1, p, IN_PIXMAJOR, st))) return rc;
+        if ((rc = launch_wgrad(s, s->L[l], x_in, dy, tw.part, B, H, W, st))) return rc;
+        if (l == d) {
+            wn_bwd(d, s->L[l], dy, s->n_z, 2, 0);       // layer_out_0 (mean tiles)
+            wn_bwd(d + 1, s->L[l], dy, s->n_z, 2, 1);   // layer_out_1 (logsd tiles)
+        } else {
+            wn_bwd(l, s->L[l], dy, s->L[l].cout, 1, 0);
+        }
+        if (l > 0) dy = tw.da[(l - 1) & 1];
+    }
+    return (int)hipGetLastError();
 }
 
 extern "C" int iaf_layer_work(const iaf_stack_t* s, int layer, int B, int H, int W, double* live_flops,

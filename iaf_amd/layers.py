@@ -257,6 +257,57 @@ class ARStack(object):
                                                  B, H, W, _ptr(ws), need, _stream()))
         return z_new, logsd
 
+    # -- training ---------------------------------------------------------------------
+    def set_training(self, on=True):
+        """allocate the transposed weight packs used by the data-gradient kernels; re-prepare afterwards"""
+        _capi.check(_capi.lib().iaf_stack_set_training(self._h, 1 if on else 0))
+        self._prep_key = None
+        self._train_ws = None
+
+    def _train_workspace(self, B, H, W, device):
+        need = int(_capi.lib().iaf_stack_train_workspace_bytes(self._h, B, H, W))
+        ws = getattr(self, "_train_ws", None)
+        if ws is None or ws.numel() < need or ws.device != device:
+            self._train_ws = torch.empty(max(need, 256), dtype=torch.uint8, device=device)
+        return self._train_ws, need
+
+    def iaf_step_train(self, z, context):
+        """iaf_step that keeps the hidden activations for iaf_step_backward (same outputs as iaf_step)"""
+        B, H, W = self._dims(z, context)
+        z_new, logsd = torch.empty_like(z), torch.empty_like(z)
+        ws, need = self._train_workspace(B, H, W, z.device)
+        _capi.check(_capi.lib().iaf_step_forward_train(self._h, _ptr(z), _ptr(context), _ptr(z_new), _ptr(logsd), B, H, W,
+                                                       _ptr(ws), need, _stream()))
+        return z_new, logsd
+
+    def iaf_step_backward(self, z, context, z_new, logsd, dz_new, dlogsd, params):
+        """Gradients of L (given dL/dz_new, dL/dlogsd) w.r.t. z, context and every V/g/b of `params`
+        (what opt.compute_gradients derives for these lines, tf_train.py:138).  Must follow iaf_step_train on the
+        same inputs.  Returns (dz, dcontext, grads) with grads keyed like params."""
+        B, H, W = self._dims(z, context)
+        for nm, t in (("z_new", z_new), ("logsd", logsd), ("dz_new", dz_new), ("dlogsd", dlogsd)):
+            _check_act(t, nm, z.shape)
+        tens = self._param_tensors(params)
+        names = self.conv_names()
+        grads = {}
+        for ci, nm in enumerate(names):
+            for j, suffix in enumerate(("V", "g", "b")):
+                grads[nm + "/" + suffix] = torch.empty_like(tens[3 * ci + j])
+        n = len(names)
+        arr = ctypes.c_void_p * n
+        Vp = arr(*[t.data_ptr() for t in tens[0::3]])
+        gp = arr(*[t.data_ptr() for t in tens[1::3]])
+        dVp = arr(*[grads[nm + "/V"].data_ptr() for nm in names])
+        dgp = arr(*[grads[nm + "/g"].data_ptr() for nm in names])
+        dbp = arr(*[grads[nm + "/b"].data_ptr() for nm in names])
+        dz = torch.empty_like(z)
+        dctx = torch.empty_like(context) if self.depth_ar > 0 else None
+        ws, need = self._train_workspace(B, H, W, z.device)
+        _capi.check(_capi.lib().iaf_step_backward(self._h, _ptr(z), _ptr(context), _ptr(z_new), _ptr(logsd), _ptr(dz_new),
+                                                  _ptr(dlogsd), _ptr(dz), _ptr(dctx), Vp, gp, dVp, dgp, dbp, B, H, W,
+                                                  _ptr(ws), need, _stream()))
+        return dz, dctx, grads
+
     def posterior_block(self, qz_mean, qz_logsd, rz_mean, rz_logsd, pz_mean, pz_logsd, up_context, down_context, eps,
                         kl_min, want_kl_elem=False):
         """tf_train.py:56-85 (mode "train") -> dict(z, kl_obj[B], kl_cost[B] [, kl_elem])."""

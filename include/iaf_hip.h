@@ -87,6 +87,26 @@ int iaf_ar_multiconv2d_forward(iaf_stack_t* s, const float* z, const float* cont
 int iaf_step_forward(iaf_stack_t* s, const float* z, const float* context, float* z_new, float* logsd,
                      int B, int H, int W, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Training.  The reference never writes a backward pass: TF autodiff derives it from the graph
+ * (opt.compute_gradients, tf_train.py:138).  These entry points compute the same gradients for the IAF step.
+ * TF variant only.
+ * ------------------------------------------------------------------------------------------ */
+/* on != 0: allocate the transposed weight packs; the next iaf_stack_prepare / iaf_prep_batch_run fills them */
+int iaf_stack_set_training(iaf_stack_t* s, int on);
+size_t iaf_stack_train_workspace_bytes(const iaf_stack_t* s, int B, int H, int W);
+/* iaf_step_forward that keeps every hidden activation in `workspace` for iaf_step_backward */
+int iaf_step_forward_train(iaf_stack_t* s, const float* z, const float* context, float* z_new, float* logsd,
+                           int B, int H, int W, void* workspace, size_t workspace_bytes, void* stream);
+/* Given dL/dz_new and dL/dlogsd (both [B,n_z,H,W]) and the SAME workspace the forward_train call filled:
+ *   dz [B,n_z,H,W], dcontext [B,n_h,H,W], and for every conv (order as in iaf_stack_prepare) dV (HWIO, zero where
+ *   the MADE mask is: the mask multiplies V in the graph, layers.py:57), dg, db -- all overwritten.
+ * V/g are the reference variables again (weight-norm backward needs them). */
+int iaf_step_backward(iaf_stack_t* s, const float* z, const float* context, const float* z_new, const float* logsd,
+                      const float* dz_new, const float* dlogsd, float* dz, float* dcontext, const float* const* V,
+                      const float* const* g, float* const* dV, float* const* dg, float* const* db, int B, int H, int W,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
 /* Full posterior block, tf_train.py:56-85 (mode "train"): everything between down_conv1 and
  * the concat, i.e. posterior sample, logqs, IAF step, log-det accumulation, prior logps, KL and
  * free bits.  All [B,n_z,H,W] inputs NCHW; up_context/down_context [B,n_h,H,W]; eps is the

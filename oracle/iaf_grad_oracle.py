@@ -1,0 +1,98 @@
+"""GRADIENT ORACLE for the IAF step -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+The reference never writes its backward pass: TensorFlow derives it (`opt.compute_gradients(obj)`,
+tf_train.py:138; Theano `T.grad`, graphy/misc/optim.py:102).  The oracle therefore restates the FORWARD of the
+path in PyTorch-CPU float64 (same lines as oracle/iaf_oracle.py, which tests hold equal to this) and lets autograd
+derive the gradients -- i.e. it computes exactly what TF's autodiff of the reference graph computes, including the
+mask on dV (the mask multiplies V in the graph, layers.py:57) and the weight-norm chain (layers.py:60).
+tests/test_grad_oracle.py checks forward == NumPy oracle and gradients == central finite differences."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import iaf_oracle as O
+
+LOG2PI = float(np.log(2 * np.pi))
+
+
+def _t(a, grad=False):
+    t = torch.tensor(np.asarray(a, dtype=np.float64))
+    t.requires_grad_(grad)
+    return t
+
+
+def ar_conv2d(x, V, g, b, zerodiagonal):
+    """tf_utils/layers.py:144-154 -> 52-64 (mask, weight-norm, SAME cross-correlation, bias)."""
+    kh, kw, n_in, n_out = V.shape
+    mask = torch.from_numpy(O.get_conv_ar_mask(kh, kw, n_in, n_out, zerodiagonal)).to(torch.float64)
+    v = mask * V
+    w = torch.exp(g).reshape(1, 1, 1, -1) * v / torch.sqrt(torch.clamp((v * v).sum(dim=(0, 1, 2), keepdim=True), min=1e-12))
+    return F.conv2d(x, w.permute(3, 2, 0, 1), b, padding=(kh // 2, kw // 2))
+
+
+def ar_multiconv2d(x, context, params, n_h):
+    """layers.py:158-166"""
+    for i in range(len(n_h)):
+        p = "layer_%d/" % i
+        x = ar_conv2d(x, params[p + "V"], params[p + "g"], params[p + "b"], False)
+        if i == 0:
+            x = x + context
+        x = F.elu(x)
+    return [ar_conv2d(x, params["layer_out_%d/V" % i], params["layer_out_%d/g" % i], params["layer_out_%d/b" % i], True)
+            for i in range(2)]
+
+
+def iaf_step(z, context, params, n_h):
+    """tf_train.py:69-72"""
+    m_raw, s_raw = ar_multiconv2d(z, context, params, n_h)
+    m, s = 0.1 * m_raw, 0.1 * s_raw
+    return (z - m) / torch.exp(s), s
+
+
+def iaf_step_grads(z, context, params, n_h, dz_new, dlogsd):
+    """Gradients of  L = <dz_new, z_new> + <dlogsd, logsd>  w.r.t. z, context and every V/g/b."""
+    zt, ct = _t(z, True), _t(context, True)
+    pt = {k: _t(v, True) for k, v in params.items()}
+    z_new, logsd = iaf_step(zt, ct, pt, n_h)
+    loss = (z_new * _t(dz_new)).sum() + (logsd * _t(dlogsd)).sum()
+    loss.backward()
+    out = {"z": zt.grad.numpy(), "context": ct.grad.numpy() if ct.grad is not None else np.zeros_like(context)}
+    for k, v in pt.items():
+        out[k] = v.grad.numpy()
+    return out, z_new.detach().numpy(), logsd.detach().numpy()
+
+
+def gaussian_diag_logps(mean, logvar, sample):
+    return -0.5 * (LOG2PI + logvar + (sample - mean) ** 2 / torch.exp(logvar))
+
+
+def posterior_block(qm, ql, rm, rl, pm, pl, uc, dc, eps, params, n_h, kl_min):
+    """tf_train.py:56-85 (mode train)."""
+    mean, logvar = rm + qm, 2 * (rl + ql)
+    z0 = mean + torch.exp(0.5 * logvar) * eps
+    logqs = gaussian_diag_logps(mean, logvar, z0)
+    z, s = iaf_step(z0, uc + dc, params, n_h)
+    logqs = logqs + s
+    logps = gaussian_diag_logps(pm, 2 * pl, z)
+    kl = logqs - logps
+    n = z.shape[0]
+    if kl_min > 0:
+        kl_ave = torch.clamp(kl.sum(dim=(2, 3)).mean(dim=0, keepdim=True), min=kl_min)
+        kl_obj = kl_ave.repeat(n, 1).sum(dim=1)
+    else:
+        kl_obj = kl.sum(dim=(1, 2, 3))
+    return z, kl_obj, kl.sum(dim=(1, 2, 3))
+
+
+def posterior_block_grads(inputs, params, n_h, kl_min, dz, dkl_obj):
+    """inputs: dict(qm, ql, rm, rl, pm, pl, uc, dc, eps).  L = <dz, z> + <dkl_obj, kl_obj>."""
+    it = {k: _t(v, k != "eps") for k, v in inputs.items()}
+    pt = {k: _t(v, True) for k, v in params.items()}
+    z, kl_obj, kl_cost = posterior_block(it["qm"], it["ql"], it["rm"], it["rl"], it["pm"], it["pl"], it["uc"], it["dc"],
+                                         it["eps"], pt, n_h, kl_min)
+    loss = (z * _t(dz)).sum() + (kl_obj * _t(dkl_obj)).sum()
+    loss.backward()
+    out = {k: v.grad.numpy() for k, v in it.items() if k != "eps"}
+    for k, v in pt.items():
+        out[k] = v.grad.numpy()
+    return out, z.detach().numpy(), kl_obj.detach().numpy(), kl_cost.detach().numpy()

@@ -187,6 +187,44 @@ def test_posterior_block_vs_oracle(amd, shape, kl_min):
     np.testing.assert_allclose(host(out["kl_obj"]), e["kl_obj"], atol=2e-3, rtol=1e-4)
 
 
+# ---------------------------------------------------------------- backward
+def _rel_close(got, ref, tol, name):
+    scale = max(np.abs(ref).max(), 1e-6)
+    err = np.abs(got - ref).max() / scale
+    assert err < tol, "%s: max err / max|ref| = %.3g (tol %g)" % (name, err, tol)
+
+
+@pytest.mark.parametrize("shape", [(4, 32, 160, 2, 16, 16), (3, 32, 160, 2, 8, 8), (2, 32, 64, 1, 4, 4), (2, 64, 64, 4, 5, 3),
+                                   (2, 32, 32, 0, 6, 6), (3, 16, 48, 2, 4, 4)], ids=lambda s: "B%d_z%d_h%d_d%d_%dx%d" % s)
+def test_iaf_step_backward_vs_autograd_oracle(amd, shape):
+    """dz, dcontext, dV (masked), dg, db against torch-fp64 autograd of the restated forward
+    (= what TF autodiff derives, tf_train.py:138).  Tolerance: 1e-4 of the largest reference entry per tensor."""
+    from oracle import iaf_grad_oracle as G
+    B, n_z, n_h, d, H, W = shape
+    params, z, ctx = _rand_case(900 + H + d, *shape)
+    rng = np.random.RandomState(17)
+    dzn, dls = rng.standard_normal(z.shape), rng.standard_normal(z.shape)
+    stack = amd.ARStack(n_z, [n_h] * d)
+    stack.set_training(True)
+    dp = dev_params(params)
+    stack.prepare(dp)
+    zd, cd = dev(z), (dev(ctx) if d > 0 else None)
+    z_new, logsd = stack.iaf_step_train(zd, cd)
+    z_ref, l_ref = stack.iaf_step(zd, cd)
+    assert torch.equal(z_new, z_ref) and torch.equal(logsd, l_ref)       # training forward == inference forward
+    dz, dctx, grads = stack.iaf_step_backward(zd, cd, z_new, logsd, dev(dzn), dev(dls), dp)
+    ref, _, _ = G.iaf_step_grads(f32(z), f32(ctx), f32_params(params), [n_h] * d, f32(dzn), f32(dls))
+    _rel_close(host(dz), ref["z"], 1e-4, "dz")
+    if d > 0:
+        _rel_close(host(dctx), ref["context"], 1e-4, "dcontext")
+    for k in sorted(params):
+        _rel_close(host(grads[k]), ref[k], 2e-4, k)
+        if k.endswith("/V"):
+            V = params[k]
+            mask = O.get_conv_ar_mask(3, 3, V.shape[2], V.shape[3], k.startswith("layer_out"))
+            assert torch.count_nonzero(grads[k][torch.from_numpy(mask == 0).cuda()]).item() == 0
+
+
 # ---------------------------------------------------------------- Theano statement (SURVEY 8a rows a10-a12)
 def _theano_params(rng, name, n_z, n_h_list):
     w = {}
