@@ -523,9 +523,66 @@ __global__ __launch_bounds__(256) void iaf_wn_bwd_kernel(WnBwdLayer L, int P) {
     }
 }
 
+// (4) posterior block backward, elementwise parts (tf_train.py:56-85 differentiated):
+//   pre : dkl[b,c,:,:] = G[b,c]  (free bits: G = (sum_b' dkl_obj[b']) / B where mean_b S[b,c] > kl_min, else 0;
+//                                  kl_min <= 0: G = dkl_obj[b]);
+//         z0 = mean + e^{lq} eps;  d z_tot = dz + dkl (z - pm) e^{-2 pl};  d pm = -dkl (z - pm) e^{-2 pl};
+//         d pl = dkl (1 - (z - pm)^2 e^{-2 pl});   core inputs: dz_new := dz_tot, dlogsd := dkl  (logqs += s)
+//   post: d mean = dz0;  d lq = dz0 (z0 - mean) - dkl     (d logq0/d mean = 0 and d logq0/d lq = -1 after the
+//         reparametrisation paths cancel analytically)
+__global__ __launch_bounds__(256) void iaf_post_bwd_gate_kernel(const float* __restrict__ S, const float* __restrict__ dkl_obj,
+                                                               float* __restrict__ Gc, int B, int Z, float kl_min) {
+    // one block; Gc[c] = gate(c) * sum_b dkl_obj[b] / B
+    __shared__ float s_sum;
+    if (threadIdx.x == 0) {
+        float a = 0.f;
+        for (int b = 0; b < B; ++b) a += dkl_obj[b];
+        s_sum = a / (float)B;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < Z; c += blockDim.x) {
+        float m = 0.f;
+        for (int b = 0; b < B; ++b) m += S[(size_t)b * Z + c];
+        Gc[c] = (m / (float)B > kl_min) ? s_sum : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void iaf_post_bwd_pre_kernel(const float* qm, const float* ql, const float* rm, const float* rl,
+                                                              const float* pm, const float* pl, const float* eps, const float* z,
+                                                              const float* dz, const float* Gc, const float* dkl_obj, float kl_min,
+                                                              float* z0, float* dzt, float* dkl, float* dpm, float* dpl, int Z,
+                                                              int HW, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t bc = i / HW;
+        const int c = (int)(bc % Z);
+        const size_t b = bc / Z;
+        const float g = (kl_min > 0.f) ? Gc[c] : dkl_obj[b];
+        const float mean = qm[i] + rm[i], lq = ql[i] + rl[i];
+        z0[i] = mean + __expf(0.5f * (2.f * lq)) * eps[i];
+        const float e2 = __expf(-2.f * pl[i]);
+        const float d = z[i] - pm[i];
+        const float gz = dz ? dz[i] : 0.f;
+        dzt[i] = gz + g * d * e2;
+        dkl[i] = g;
+        dpm[i] = -g * d * e2;
+        dpl[i] = g * (1.f - d * d * e2);
+    }
+}
+
+__global__ __launch_bounds__(256) void iaf_post_bwd_post_kernel(const float* qm, const float* rm, const float* z0, const float* dz0,
+                                                               const float* dkl, float* dmean, float* dlq, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float g = dz0[i];
+        dmean[i] = g;
+        dlq[i] = g * (z0[i] - (qm[i] + rm[i])) - dkl[i];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side: stack object
 // ---------------------------------------------------------------------------------------------
+static dim3 ew_grid(size_t n);
+
 struct GemmLayer {
     int cin, cout;        // cout = GEMM N (output pair: 2*n_z)
     int nchunk, ncot;
@@ -1224,6 +1281,10 @@ struct TrainWs {
     float* dy3;
     float* zpm;
     float* part;
+    // posterior block: saved forward values and backward temporaries, all NCHW [P*n_z] unless noted
+    float* logsd; float* klelem; float* z0; float* dzt; float* dkl; float* dz0;
+    float* rowsum;   // [B*n_z]  (P*n_z floats reserved: B <= P)
+    float* gate;     // [n_z]
 };
 
 static size_t train_ws_floats(const iaf_stack_t* s, long long P, TrainWs* o, float* base) {
@@ -1241,6 +1302,10 @@ static size_t train_ws_floats(const iaf_stack_t* s, long long P, TrainWs* o, flo
         if (w > maxw) maxw = w;
     }
     t.part = take((size_t)wgrad_nrange(P) * NTAPS * maxw);
+    t.logsd = take((size_t)P * s->n_z); t.klelem = take((size_t)P * s->n_z); t.z0 = take((size_t)P * s->n_z);
+    t.dzt = take((size_t)P * s->n_z); t.dkl = take((size_t)P * s->n_z); t.dz0 = take((size_t)P * s->n_z);
+    t.rowsum = take((size_t)P * s->n_z);
+    t.gate = take((size_t)s->n_z);
     if (o) *o = t;
     return off;
 }
@@ -1390,6 +1455,82 @@ extern "C" int iaf_step_backward(iaf_stack_t* s, const float* z, const float* co
         }
         if (l > 0) dy = tw.da[(l - 1) & 1];
     }
+    return (int)hipGetLastError();
+}
+
+extern "C" int iaf_posterior_block_forward_train(iaf_stack_t* s, const float* qz_mean, const float* qz_logsd,
+                                                 const float* rz_mean, const float* rz_logsd, const float* pz_mean,
+                                                 const float* pz_logsd, const float* up_context, const float* down_context,
+                                                 const float* eps, float kl_min, float* z_out, float* kl_obj, float* kl_cost,
+                                                 int B, int H, int W, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_dims(s, B, H, W);
+    if (rc) return rc;
+    if (!s->training) return IAF_ERR_NOT_PREPARED;
+    if (!qz_mean || !qz_logsd || !rz_mean || !rz_logsd || !pz_mean || !pz_logsd || !eps || !z_out || !kl_obj || !kl_cost ||
+        !workspace)
+        return IAF_ERR_NULL;
+    if (s->depth_ar > 0 && (!up_context || !down_context)) return IAF_ERR_NULL;
+    if (((uintptr_t)workspace & 15) != 0 || workspace_bytes < iaf_stack_train_workspace_bytes(s, B, H, W)) return IAF_ERR_WORKSPACE;
+    TrainWs tw;
+    train_ws_floats(s, (long long)B * H * W, &tw, (float*)workspace);
+    hipStream_t st = (hipStream_t)stream;
+    ConvP base;
+    memset(&base, 0, sizeof(base));
+    base.B = B; base.H = H; base.W = W; base.HW = H * W; base.P = B * H * W;
+    base.qm = qz_mean; base.ql = qz_logsd; base.rm = rz_mean; base.rl = rz_logsd; base.pm = pz_mean; base.pl = pz_logsd;
+    base.eps = eps;
+    base.out0 = z_out; base.out1 = tw.logsd; base.kl_elem = tw.klelem; base.mode = MODE_POSTERIOR;
+    const float* cur = nullptr;
+    int inmode = IN_POSTERIOR;
+    for (int l = 0; l < s->depth_ar; ++l) {
+        ConvP p = base;
+        p.x = cur;
+        p.ctx = (l == 0) ? up_context : nullptr;
+        p.ctx2 = (l == 0) ? down_context : nullptr;
+        p.y = tw.h[l];
+        if ((rc = launch_conv(s, l, p, inmode, st))) return rc;
+        cur = p.y;
+        inmode = IN_PIXMAJOR;
+    }
+    ConvP p = base;
+    p.x = cur;
+    if ((rc = launch_conv(s, s->depth_ar, p, inmode, st))) return rc;
+    const int rows = B * s->n_z;
+    hipLaunchKernelGGL(iaf_kl_rowsum_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, tw.klelem, tw.rowsum, rows, H * W);
+    hipLaunchKernelGGL(iaf_kl_finish_kernel, dim3(1), dim3(256), 0, st, tw.rowsum, kl_obj, kl_cost, B, s->n_z, kl_min);
+    return (int)hipGetLastError();
+}
+
+extern "C" int iaf_posterior_block_backward(iaf_stack_t* s, const float* qz_mean, const float* qz_logsd, const float* rz_mean,
+                                            const float* rz_logsd, const float* pz_mean, const float* pz_logsd,
+                                            const float* eps, float kl_min, const float* z, const float* dz,
+                                            const float* dkl_obj, float* dmean, float* dlogsd_q, float* dpz_mean,
+                                            float* dpz_logsd, float* dcontext, const float* const* V, const float* const* g,
+                                            float* const* dV, float* const* dg, float* const* db, int B, int H, int W,
+                                            void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_dims(s, B, H, W);
+    if (rc) return rc;
+    if (!s->training) return IAF_ERR_NOT_PREPARED;
+    if (!qz_mean || !qz_logsd || !rz_mean || !rz_logsd || !pz_mean || !pz_logsd || !eps || !z || !dkl_obj || !dmean ||
+        !dlogsd_q || !dpz_mean || !dpz_logsd || !workspace)
+        return IAF_ERR_NULL;
+    if (((uintptr_t)workspace & 15) != 0 || workspace_bytes < iaf_stack_train_workspace_bytes(s, B, H, W)) return IAF_ERR_WORKSPACE;
+    TrainWs tw;
+    train_ws_floats(s, (long long)B * H * W, &tw, (float*)workspace);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = (size_t)B * s->n_z * H * W;
+    if (kl_min > 0.f)
+        hipLaunchKernelGGL(iaf_post_bwd_gate_kernel, dim3(1), dim3(256), 0, st, tw.rowsum, dkl_obj, tw.gate, B, s->n_z, kl_min);
+    hipLaunchKernelGGL(iaf_post_bwd_pre_kernel, ew_grid(n), dim3(256), 0, st, qz_mean, qz_logsd, rz_mean, rz_logsd, pz_mean,
+                       pz_logsd, eps, z, dz, tw.gate, dkl_obj, kl_min, tw.z0, tw.dzt, tw.dkl, dpz_mean, dpz_logsd, s->n_z, H * W,
+                       n);
+    if ((rc = (int)hipGetLastError())) return rc;
+    // core: z := z0, (z_new, logsd) := saved forward values, incoming gradients := (dz_tot, dkl)
+    if ((rc = iaf_step_backward(s, tw.z0, dcontext /* value unused */, z, tw.logsd, tw.dzt, tw.dkl, tw.dz0, dcontext, V, g, dV, dg,
+                                db, B, H, W, workspace, workspace_bytes, stream)))
+        return rc;
+    hipLaunchKernelGGL(iaf_post_bwd_post_kernel, ew_grid(n), dim3(256), 0, st, qz_mean, rz_mean, tw.z0, tw.dz0, tw.dkl, dmean,
+                       dlogsd_q, n);
     return (int)hipGetLastError();
 }
 

@@ -308,6 +308,50 @@ class ARStack(object):
                                                   _ptr(ws), need, _stream()))
         return dz, dctx, grads
 
+    def posterior_block_train(self, qz_mean, qz_logsd, rz_mean, rz_logsd, pz_mean, pz_logsd, up_context, down_context, eps,
+                              kl_min):
+        """posterior_block that keeps what posterior_block_backward needs (same z, kl_obj, kl_cost)"""
+        B, H, W = self._dims(qz_mean, up_context)
+        z = torch.empty_like(qz_mean)
+        kl_obj = torch.empty(B, dtype=torch.float32, device=z.device)
+        kl_cost = torch.empty_like(kl_obj)
+        ws, need = self._train_workspace(B, H, W, z.device)
+        _capi.check(_capi.lib().iaf_posterior_block_forward_train(
+            self._h, _ptr(qz_mean), _ptr(qz_logsd), _ptr(rz_mean), _ptr(rz_logsd), _ptr(pz_mean), _ptr(pz_logsd),
+            _ptr(up_context), _ptr(down_context), _ptr(eps), float(kl_min), _ptr(z), _ptr(kl_obj), _ptr(kl_cost), B, H, W,
+            _ptr(ws), need, _stream()))
+        return dict(z=z, kl_obj=kl_obj, kl_cost=kl_cost)
+
+    def posterior_block_backward(self, qz_mean, qz_logsd, rz_mean, rz_logsd, pz_mean, pz_logsd, eps, kl_min, z, dz, dkl_obj,
+                                 params):
+        """Backward of tf_train.py:56-85.  Returns dict(dmean (= d qz_mean = d rz_mean), dlogsd (= d qz_logsd = d rz_logsd),
+        dpz_mean, dpz_logsd, dcontext (= d up_context = d down_context), grads {conv/V|g|b})."""
+        B, _, H, W = qz_mean.shape
+        B, H, W = int(B), int(H), int(W)
+        tens = self._param_tensors(params)
+        names = self.conv_names()
+        grads = {}
+        for ci, nm in enumerate(names):
+            for j, suffix in enumerate(("V", "g", "b")):
+                grads[nm + "/" + suffix] = torch.empty_like(tens[3 * ci + j])
+        n = len(names)
+        arr = ctypes.c_void_p * n
+        Vp = arr(*[t.data_ptr() for t in tens[0::3]])
+        gp = arr(*[t.data_ptr() for t in tens[1::3]])
+        dVp = arr(*[grads[nm + "/V"].data_ptr() for nm in names])
+        dgp = arr(*[grads[nm + "/g"].data_ptr() for nm in names])
+        dbp = arr(*[grads[nm + "/b"].data_ptr() for nm in names])
+        out = dict(dmean=torch.empty_like(qz_mean), dlogsd=torch.empty_like(qz_mean), dpz_mean=torch.empty_like(qz_mean),
+                   dpz_logsd=torch.empty_like(qz_mean), grads=grads)
+        out["dcontext"] = (torch.empty(B, self.n_h, H, W, dtype=torch.float32, device=qz_mean.device)
+                           if self.depth_ar > 0 else None)
+        ws, need = self._train_workspace(B, H, W, qz_mean.device)
+        _capi.check(_capi.lib().iaf_posterior_block_backward(
+            self._h, _ptr(qz_mean), _ptr(qz_logsd), _ptr(rz_mean), _ptr(rz_logsd), _ptr(pz_mean), _ptr(pz_logsd), _ptr(eps),
+            float(kl_min), _ptr(z), _ptr(dz), _ptr(dkl_obj), _ptr(out["dmean"]), _ptr(out["dlogsd"]), _ptr(out["dpz_mean"]),
+            _ptr(out["dpz_logsd"]), _ptr(out["dcontext"]), Vp, gp, dVp, dgp, dbp, B, H, W, _ptr(ws), need, _stream()))
+        return out
+
     def posterior_block(self, qz_mean, qz_logsd, rz_mean, rz_logsd, pz_mean, pz_logsd, up_context, down_context, eps,
                         kl_min, want_kl_elem=False):
         """tf_train.py:56-85 (mode "train") -> dict(z, kl_obj[B], kl_cost[B] [, kl_elem])."""

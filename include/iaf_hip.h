@@ -107,6 +107,25 @@ int iaf_step_backward(iaf_stack_t* s, const float* z, const float* context, cons
                       const float* const* g, float* const* dV, float* const* dg, float* const* db, int B, int H, int W,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* Training form of the posterior block (below): same outputs, keeps what the backward needs in `workspace`
+ * (iaf_stack_train_workspace_bytes). */
+int iaf_posterior_block_forward_train(iaf_stack_t* s, const float* qz_mean, const float* qz_logsd, const float* rz_mean,
+                                      const float* rz_logsd, const float* pz_mean, const float* pz_logsd,
+                                      const float* up_context, const float* down_context, const float* eps, float kl_min,
+                                      float* z_out, float* kl_obj, float* kl_cost, int B, int H, int W, void* workspace,
+                                      size_t workspace_bytes, void* stream);
+/* Backward of tf_train.py:56-85 given dL/dz [B,n_z,H,W] (may be NULL = 0) and dL/dkl_obj [B]:
+ *   dmean     = dL/d qz_mean  = dL/d rz_mean           dlogsd_q = dL/d qz_logsd = dL/d rz_logsd
+ *   dpz_mean, dpz_logsd, dcontext (= dL/d up_context = dL/d down_context), and dV/dg/db as in iaf_step_backward.
+ * Free bits: the gradient of max(mean_b sum_hw kl, kl_min) is gated per channel (tf_train.py:79-82). */
+int iaf_posterior_block_backward(iaf_stack_t* s, const float* qz_mean, const float* qz_logsd, const float* rz_mean,
+                                 const float* rz_logsd, const float* pz_mean, const float* pz_logsd, const float* eps,
+                                 float kl_min, const float* z, const float* dz, const float* dkl_obj, float* dmean,
+                                 float* dlogsd_q, float* dpz_mean, float* dpz_logsd, float* dcontext,
+                                 const float* const* V, const float* const* g, float* const* dV, float* const* dg,
+                                 float* const* db, int B, int H, int W, void* workspace, size_t workspace_bytes,
+                                 void* stream);
+
 /* Full posterior block, tf_train.py:56-85 (mode "train"): everything between down_conv1 and
  * the concat, i.e. posterior sample, logqs, IAF step, log-det accumulation, prior logps, KL and
  * free bits.  All [B,n_z,H,W] inputs NCHW; up_context/down_context [B,n_h,H,W]; eps is the

@@ -225,6 +225,49 @@ def test_iaf_step_backward_vs_autograd_oracle(amd, shape):
             assert torch.count_nonzero(grads[k][torch.from_numpy(mask == 0).cuda()]).item() == 0
 
 
+@pytest.mark.parametrize("kl_min", [0.0, 0.25])
+@pytest.mark.parametrize("shape", [(4, 32, 160, 2, 16, 16), (3, 32, 64, 1, 8, 8), (2, 64, 64, 4, 4, 4)],
+                         ids=lambda s: "B%d_z%d_h%d_d%d_%dx%d" % s)
+def test_posterior_block_backward_vs_autograd_oracle(amd, shape, kl_min):
+    """full tf_train.py:56-85 backward incl. the free-bits gate: every input gradient and every weight gradient"""
+    from oracle import iaf_grad_oracle as G
+    B, n_z, n_h, d, H, W = shape
+    rng = np.random.RandomState(66)
+    params = gi.ar_multiconv2d_params(rng, n_z, [n_h] * d, [n_z, n_z])
+    f = lambda c: rng.standard_normal((B, c, H, W))
+    # kl_min = 0.25 with these inputs gates SOME channels only when the KL is small: scale logsd so that both cases occur
+    inp = dict(qm=0.1 * f(n_z), ql=0.05 * f(n_z), rm=0.1 * f(n_z), rl=0.05 * f(n_z), pm=0.1 * f(n_z), pl=0.05 * f(n_z), uc=f(n_h), dc=f(n_h), eps=0.05 * f(n_z))
+    dz, dko = rng.standard_normal((B, n_z, H, W)), 1.0 + 0.1 * rng.standard_normal(B)
+    stack = amd.ARStack(n_z, [n_h] * d)
+    stack.set_training(True)
+    dp = dev_params(params)
+    stack.prepare(dp)
+    di = {k: dev(v) for k, v in inp.items()}
+    fw = stack.posterior_block_train(di["qm"], di["ql"], di["rm"], di["rl"], di["pm"], di["pl"], di["uc"], di["dc"], di["eps"], kl_min)
+    bw = stack.posterior_block_backward(di["qm"], di["ql"], di["rm"], di["rl"], di["pm"], di["pl"], di["eps"], kl_min, fw["z"],
+                                        dev(dz), dev(dko), dp)
+    ref, z_ref, klo_ref, klc_ref = G.posterior_block_grads({k: f32(v) for k, v in inp.items()}, f32_params(params), [n_h] * d,
+                                                           kl_min, f32(dz), f32(dko))
+    if kl_min > 0:   # the inputs must exercise BOTH sides of the free-bits max (tf_train.py:80)
+        e = O.posterior_block(*[f32(inp[k]) for k in ("qm", "ql", "rm", "rl", "pm", "pl", "uc", "dc", "eps")], f32_params(params),
+                              [n_h] * d, kl_min)
+        per_c = (e["logqs"] - e["logps"]).sum(axis=(2, 3)).mean(axis=0)
+        assert (per_c > kl_min).any() and (per_c < kl_min).any()
+    np.testing.assert_allclose(host(fw["z"]), z_ref, atol=ATOL, rtol=0)
+    np.testing.assert_allclose(host(fw["kl_obj"]), klo_ref, atol=2e-3, rtol=1e-4)
+    np.testing.assert_allclose(host(fw["kl_cost"]), klc_ref, atol=2e-3, rtol=1e-4)
+    _rel_close(host(bw["dmean"]), ref["qm"], 2e-4, "d qz_mean")
+    _rel_close(host(bw["dmean"]), ref["rm"], 2e-4, "d rz_mean")
+    _rel_close(host(bw["dlogsd"]), ref["ql"], 2e-4, "d qz_logsd")
+    _rel_close(host(bw["dlogsd"]), ref["rl"], 2e-4, "d rz_logsd")
+    _rel_close(host(bw["dpz_mean"]), ref["pm"], 2e-4, "d pz_mean")
+    _rel_close(host(bw["dpz_logsd"]), ref["pl"], 2e-4, "d pz_logsd")
+    _rel_close(host(bw["dcontext"]), ref["uc"], 2e-4, "d up_context")
+    _rel_close(host(bw["dcontext"]), ref["dc"], 2e-4, "d down_context")
+    for k in sorted(params):
+        _rel_close(host(bw["grads"][k]), ref[k], 3e-4, k)
+
+
 # ---------------------------------------------------------------- Theano statement (SURVEY 8a rows a10-a12)
 def _theano_params(rng, name, n_z, n_h_list):
     w = {}
