@@ -50,6 +50,10 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tune", type=str, default="", help="layer:nt,pxt,wco,ks;... launch-shape override")
+    ap.add_argument("--train", action="store_true",
+                    help="extra mode (not the headline metric): data-parallel TRAINING step of the IAF posterior stack -- "
+                         "posterior block forward + backward for every layer, one RCCL all-reduce of the flat gradient "
+                         "buffer, fused Adamax + EMA")
     return ap.parse_args()
 
 
@@ -127,6 +131,80 @@ def cpu_baseline(args, depths):
     }
 
 
+def train_bench(args, depths, dist, rank, n_gpus):
+    """DP training step of the IAF posterior stack (SURVEY 8f-1,2): per step, for every layer, posterior block forward
+    (tf_train.py:56-85) + backward (what opt.compute_gradients derives, tf_train.py:138), gradients written into ONE flat
+    buffer, all-reduce(sum) over ranks (RCCL), fused Adamax(1/N)+EMA (tf_utils/common.py:86, adamax.py:40-56,
+    tf_train.py:157-158).  Synthetic upstream gradients (dz ~ N(0,1), dkl_obj = 1)."""
+    import iaf_amd
+    from iaf_amd import parallel as par
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+    rng = np.random.RandomState(4321 + rank)
+    wrng = np.random.RandomState(99)                      # identical initial weights on every rank
+    layers, named = [], {}
+    for lvl, nlayer in enumerate(depths):
+        H = 16 >> lvl
+        for j in range(nlayer):
+            params, _, _ = make_layer_inputs(wrng, args.batch, args.n_z, args.n_h, args.depth_ar, H)
+            f = lambda c: dev(rng.standard_normal((args.batch, c, H, H)))
+            inp = dict(qm=f(args.n_z), ql=0.1 * f(args.n_z), rm=f(args.n_z), rl=0.1 * f(args.n_z), pm=f(args.n_z),
+                       pl=0.1 * f(args.n_z), uc=f(args.n_h), dc=f(args.n_h), eps=f(args.n_z), dz=f(args.n_z),
+                       dko=torch.ones(args.batch, device="cuda"))
+            st = iaf_amd.ARStack(args.n_z, [args.n_h] * args.depth_ar)
+            st.set_training(True)
+            pre = "IAF_%d_%d/ar_multiconv2d/" % (lvl, j)
+            for k, v in params.items():
+                named[pre + k] = dev(v)
+            layers.append(dict(stack=st, pre=pre, keys=list(params), inp=inp))
+    flat = par.FlatParams(named)
+    for L in layers:
+        L["params"] = {k: flat.p[L["pre"] + k] for k in L["keys"]}
+        L["gradviews"] = {k: flat.g[L["pre"] + k] for k in L["keys"]}
+    prep = iaf_amd.PrepBatch([L["stack"] for L in layers])
+    plist = [L["params"] for L in layers]
+
+    def step():
+        prep.run(plist)
+        for L in layers:
+            i, st = L["inp"], L["stack"]
+            fw = st.posterior_block_train(i["qm"], i["ql"], i["rm"], i["rl"], i["pm"], i["pl"], i["uc"], i["dc"], i["eps"], 0.25)
+            st.posterior_block_backward(i["qm"], i["ql"], i["rm"], i["rl"], i["pm"], i["pl"], i["eps"], 0.25, fw["z"], i["dz"],
+                                        i["dko"], L["params"], grads_out=L["gradviews"])
+        flat.all_reduce_grads()
+        flat.adamax_ema_step(1e-4, world=n_gpus)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "IAF posterior-stack TRAIN-step samples/sec (forward + backward + grad all-reduce + Adamax/EMA)",
+            "value": n_gpus * args.batch / (elapsed / args.steps), "unit": "samples/s", "n_gpus": n_gpus, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "cifar10 n_z=%d n_h=%d depths=%s depth_ar=%d down_iaf2_nl bs=%d per GPU, kl_min=0.25; "
+                                   "%d trainable fp32 parameters in one flat all-reduce bucket (%.1f MB)"
+                                   % (args.n_z, args.n_h, depths, args.depth_ar, args.batch, flat.params.numel(),
+                                      4e-6 * flat.params.numel()),
+                       "global_batch": n_gpus * args.batch, "launch": "eager",
+                       "parallelism": "dp%d (RCCL all-reduce of one flat gradient bucket)" % n_gpus}}))
+
+
 def main():
     args = parse()
     depths = [int(d) for d in args.depths.split(",") if d]
@@ -146,6 +224,11 @@ def main():
 
     import iaf_amd
     iaf_amd._capi.lib()           # fail loudly if the HIP engine is not built
+    if args.train:
+        train_bench(args, depths, dist, rank, n_gpus)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
 
     # ---------------- build the layer schedule (every rank its own data: seed + rank)

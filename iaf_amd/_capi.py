@@ -46,6 +46,7 @@ SIGNATURES = {
                                           [ctypes.c_int] * 3 + [_vp, ctypes.c_size_t, _vp]),
     "iaf_posterior_block_backward": (ctypes.c_int, [_vp] + [_c_float_p] * 7 + [ctypes.c_float] + [_c_float_p] * 8 +
                                      [ctypes.POINTER(_vp)] * 5 + [ctypes.c_int] * 3 + [_vp, ctypes.c_size_t, _vp]),
+    "iaf_adamax_ema_step": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_size_t] + [ctypes.c_float] * 6 + [_vp]),
     "iaf_posterior_block_forward": (ctypes.c_int, [_vp] + [_c_float_p] * 9 + [ctypes.c_float] + [_c_float_p] * 4 +
                                     [ctypes.c_int] * 3 + [_vp, ctypes.c_size_t, _vp]),
     "iaf_gaussian_sample": (ctypes.c_int, [_c_float_p] * 4 + [ctypes.c_size_t, _vp]),

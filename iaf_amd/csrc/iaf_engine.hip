@@ -279,15 +279,23 @@ __global__ __launch_bounds__(256) void iaf_kl_rowsum_kernel(const float* kl, flo
 
 __global__ __launch_bounds__(256) void iaf_kl_finish_kernel(const float* S, float* kl_obj, float* kl_cost, int B, int Z,
                                                            float kl_min) {
+    // S is tiny ([B, Z]); stage it through LDS in one coalesced sweep instead of B*Z dependent global loads
+    __shared__ float sh[8192];
+    __shared__ float part[256];
     __shared__ float s_fb;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, n = B * Z;
+    const bool in_lds = n <= 8192;
+    if (in_lds) {
+        for (int i = tid; i < n; i += 256) sh[i] = S[i];
+        __syncthreads();
+    }
+    const float* src = in_lds ? sh : S;
     if (kl_min > 0.f) {
         // kl_ave[c] = max(mean_b S[b,c], kl_min); kl_obj[b] = sum_c kl_ave[c]   (tf_train.py:79-82)
-        __shared__ float part[256];
         float a = 0.f;
         for (int c = tid; c < Z; c += 256) {
             float m = 0.f;
-            for (int b = 0; b < B; ++b) m += S[(size_t)b * Z + c];
+            for (int b = 0; b < B; ++b) m += src[(size_t)b * Z + c];
             a += fmaxf(m / (float)B, kl_min);
         }
         part[tid] = a;
@@ -301,7 +309,7 @@ __global__ __launch_bounds__(256) void iaf_kl_finish_kernel(const float* S, floa
     }
     for (int b = tid; b < B; b += 256) {
         float a = 0.f;
-        for (int c = 0; c < Z; ++c) a += S[(size_t)b * Z + c];
+        for (int c = 0; c < Z; ++c) a += src[(size_t)b * Z + c];
         kl_cost[b] = a;                                        // tf_train.py:85
         kl_obj[b] = (kl_min > 0.f) ? s_fb : a;                 // tf_train.py:82 / 84
     }
@@ -318,6 +326,40 @@ __global__ void iaf_gauss_logps_kernel(const float* mean, const float* logvar, c
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float d = sample[i] - mean[i];
         out[i] = -0.5f * (1.8378770664093453f + logvar[i] + d * d / expf(logvar[i]));
+    }
+}
+
+// Adamax (tf_utils/adamax.py:40-56; NB the reference's slot naming: "v" = first moment, "m" = infinity norm) fused
+// with the 1/N gradient averaging of average_grads (tf_utils/common.py:86) and the EMA of the parameters
+// (tf_train.py:157-158, decay 0.999).  One pass over flat fp32 buffers: 5 reads + 4 writes per element, HBM-bound.
+__global__ __launch_bounds__(256) void iaf_adamax_ema_kernel(float* __restrict__ var, const float* __restrict__ grad,
+                                                            float* __restrict__ slot_m, float* __restrict__ slot_v,
+                                                            float* __restrict__ ema, size_t n4, size_t n, float lr, float beta1,
+                                                            float beta2, float eps, float ema_decay, float grad_scale) {
+    auto upd = [&](float& w, float g, float& m, float& v, float& e) {
+        g *= grad_scale;
+        v = beta1 * v + (1.f - beta1) * g;                    // adamax.py:50
+        m = fmaxf(beta2 * m + eps, fabsf(g));                 // adamax.py:52
+        w -= lr * (v / m);                                    // adamax.py:53-55
+        e -= (1.f - ema_decay) * (e - w);                     // ExponentialMovingAverage.apply
+    };
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += stride) {
+        f32x4 w = ((f32x4*)var)[i], g = ((const f32x4*)grad)[i], m = ((f32x4*)slot_m)[i], v = ((f32x4*)slot_v)[i];
+        f32x4 e = ema ? ((f32x4*)ema)[i] : w;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float wr_ = w[r], mr = m[r], vr = v[r], er = e[r];
+            upd(wr_, g[r], mr, vr, er);
+            w[r] = wr_; m[r] = mr; v[r] = vr; e[r] = er;
+        }
+        ((f32x4*)var)[i] = w; ((f32x4*)slot_m)[i] = m; ((f32x4*)slot_v)[i] = v;
+        if (ema) ((f32x4*)ema)[i] = e;
+    }
+    for (size_t i = 4 * n4 + blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += stride) {   // tail
+        float e = ema ? ema[i] : var[i];
+        upd(var[i], grad[i], slot_m[i], slot_v[i], e);
+        if (ema) ema[i] = e;
     }
 }
 
@@ -457,40 +499,74 @@ __global__ __launch_bounds__(256) void iaf_wgrad_kernel(WgradP p) {
     }
 }
 
-// (3) reduce the partials and push the gradient through mask + weight-norm (layers.py:57,60):
-//       w = e u,  u = v / n,  v = mask V,  n = ||v||_o,  e = exp(g)
-//       dg = sum dW w ;  dv = (e / n) (dW - u (sum dW u)) ;  dV = mask dv ;  db = sum_p dY
-//     One workgroup per 16 output channels (same thread map as the prep kernel).
-struct WnBwdLayer {
-    const float* V; const float* g;      // reference variables of THIS conv (HWIO V)
-    const float* part;                   // [nrange][NTAPS][cin][cout_packed]
-    const float* dy;                     // [P][cout_packed]
-    float* dV; float* dg; float* db;     // outputs: HWIO [3][3][cin][cout], [cout], [cout]
-    int cin, cout, cout_packed, nrange, zerodiag, pack_stride, pack_off;   // packed channel of o: (o/16)*pack_stride*16 + pack_off*16 + o%16
-};
-
-__global__ __launch_bounds__(256) void iaf_wn_bwd_kernel(WnBwdLayer L, int P) {
-    __shared__ float red[3][16][17];
-    __shared__ float s_n[16], s_dot[16];
-    const int oo = threadIdx.x & 15, cs = threadIdx.x >> 4;
-    const int o = blockIdx.x * 16 + oo;
-    const int op = (o >> 4) * L.pack_stride * 16 + L.pack_off * 16 + (o & 15);   // packed channel index
-    const int n_in = L.cin, n_out = L.cout;
-    float ss = 0.f, dot = 0.f, dbs = 0.f;
-    // pass 1: norms and <dW, v>
-    for (int t = 0; t < NTAPS; ++t) {
-        const int kh = (t == 0 || t == 1) ? 1 : 2;
-        const int kw = (t == 0) ? 1 : (t == 1 ? 2 : t - 2);
-        for (int ci = cs; ci < n_in; ci += 16) {
-            const bool live = (t != 0) || made_live(ci, o, n_in, n_out, L.zerodiag);
-            const float v = live ? L.V[((size_t)(kh * 3 + kw) * n_in + ci) * n_out + o] : 0.f;
-            float dW = 0.f;
-            for (int k = 0; k < L.nrange; ++k) dW += L.part[(((size_t)k * NTAPS + t) * n_in + ci) * L.cout_packed + op];
-            ss += v * v;
-            dot += dW * v;
+// (3a) sum the wgrad partials over the pixel ranges (fully parallel, 16-byte accesses) and, in extra workgroups of the
+//      same launch, column-sum dY over pixel slabs for the bias gradient:
+//        dW[i] = sum_k part[k][i]            blocks [0, nblk_w)
+//        dbp[r][co] = sum_{p in slab r} dY[p][co]   blocks [nblk_w, nblk_w + nslab)
+__global__ __launch_bounds__(256) void iaf_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dW, int nrange,
+                                                              size_t n4, int nblk_w, const float* __restrict__ dy,
+                                                              float* __restrict__ dbp, int P, int cout, int px_per_slab) {
+    if ((int)blockIdx.x < nblk_w) {
+        for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)nblk_w * blockDim.x) {
+            f32x4 a = ((const f32x4*)part)[i];
+            for (int k = 1; k < nrange; ++k) a += ((const f32x4*)part)[(size_t)k * n4 + i];
+            ((f32x4*)dW)[i] = a;
+        }
+    } else {
+        const int slab = blockIdx.x - nblk_w;
+        const int p0 = slab * px_per_slab, p1 = min(P, p0 + px_per_slab);
+        for (int co = threadIdx.x; co < cout; co += blockDim.x) {
+            float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            int pix = p0;
+            for (; pix + 8 <= p1; pix += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a[u] += dy[(size_t)(pix + u) * cout + co];     // 8 independent loads in flight
+            }
+            for (; pix < p1; ++pix) a[0] += dy[(size_t)pix * cout + co];
+            dbp[(size_t)slab * cout + co] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
         }
     }
-    for (int pix = cs; pix < P; pix += 16) dbs += L.dy[(size_t)pix * L.cout_packed + op];
+}
+
+// (3b) push the weight gradient through mask + weight-norm (layers.py:57,60):
+//       w = e u,  u = v / n,  v = mask V,  n = ||v||_o,  e = exp(g)
+//       dg = sum dW w ;  dv = (e / n) (dW - u (sum dW u)) ;  dV = mask dv ;  db = sum_p dY
+//     One workgroup per 16 output channels (same thread map as the prep kernel), all of a thread's loads in one batch.
+struct WnBwdLayer {
+    const float* V; const float* g;      // reference variables of THIS conv (HWIO V)
+    const float* dW;                     // reduced effective-weight gradient [NTAPS][cin][cout_packed]
+    const float* dbp;                    // [nslab][cout_packed] column sums of dY
+    float* dV; float* dg; float* db;     // outputs: HWIO [3][3][cin][cout], [cout], [cout]
+    int cin, cout, cout_packed, nslab, zerodiag, pack_stride, pack_off;   // packed channel of o: (o/16)*pack_stride*16 + pack_off*16 + o%16
+};
+
+template <int NCH>
+__device__ __forceinline__ void wn_bwd_tile(const WnBwdLayer& L, int tile, float (*red)[16][17], float* s_n, float* s_dot) {
+    const int oo = threadIdx.x & 15, cs = threadIdx.x >> 4;
+    const int o = tile * 16 + oo;
+    const int op = (o >> 4) * L.pack_stride * 16 + L.pack_off * 16 + (o & 15);   // packed channel index
+    const int n_in = L.cin, n_out = L.cout;
+    float v[NTAPS][NCH], dw[NTAPS][NCH];
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+        const int ci = cs + 16 * it;
+#pragma unroll
+        for (int t = 0; t < NTAPS; ++t) {
+            const int kh = (t == 0 || t == 1) ? 1 : 2;
+            const int kw = (t == 0) ? 1 : (t == 1 ? 2 : t - 2);
+            v[t][it] = L.V[((size_t)(kh * 3 + kw) * n_in + ci) * n_out + o];
+            dw[t][it] = L.dW[((size_t)t * n_in + ci) * L.cout_packed + op];
+        }
+    }
+    float dbs = 0.f;
+    for (int r = cs; r < L.nslab; r += 16) dbs += L.dbp[(size_t)r * L.cout_packed + op];
+    float ss = 0.f, dot = 0.f;
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+        if (!made_live(cs + 16 * it, o, n_in, n_out, L.zerodiag)) { v[0][it] = 0.f; dw[0][it] = 0.f; }
+#pragma unroll
+        for (int t = 0; t < NTAPS; ++t) { ss += v[t][it] * v[t][it]; dot += dw[t][it] * v[t][it]; }
+    }
     red[0][cs][oo] = ss; red[1][cs][oo] = dot; red[2][cs][oo] = dbs;
     __syncthreads();
     if (cs == 0) {
@@ -505,21 +581,54 @@ __global__ __launch_bounds__(256) void iaf_wn_bwd_kernel(WnBwdLayer L, int P) {
     }
     __syncthreads();
     const float n = s_n[oo], du = s_dot[oo], e = expf(L.g[o]);
-    // pass 2: dV (all 9 taps; the 4 dead taps and masked centre entries are exact zeros)
-    for (int kk9 = 0; kk9 < 9; ++kk9) {
-        const int kh = kk9 / 3, kw = kk9 % 3;
-        const int t = (kh == 1 && kw == 1) ? 0 : (kh == 1 && kw == 2) ? 1 : (kh == 2) ? 2 + kw : -1;
-        for (int ci = cs; ci < n_in; ci += 16) {
+    // dV over all 9 taps: the 4 dead taps and the masked centre entries are exact zeros
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+        const int ci = cs + 16 * it;
+        const bool cl = made_live(ci, o, n_in, n_out, L.zerodiag);
+#pragma unroll
+        for (int kk9 = 0; kk9 < 9; ++kk9) {
+            const int kh = kk9 / 3, kw = kk9 % 3;
+            const int t = (kh == 1 && kw == 1) ? 0 : (kh == 1 && kw == 2) ? 1 : (kh == 2) ? 2 + kw : -1;
             float outv = 0.f;
-            const bool live = (t >= 0) && ((t != 0) || made_live(ci, o, n_in, n_out, L.zerodiag));
-            if (live) {
-                const float v = L.V[((size_t)kk9 * n_in + ci) * n_out + o];
-                float dW = 0.f;
-                for (int k = 0; k < L.nrange; ++k) dW += L.part[(((size_t)k * NTAPS + t) * n_in + ci) * L.cout_packed + op];
-                outv = (e / n) * (dW - (v / n) * du);
-            }
+            if (t > 0 || (t == 0 && cl)) outv = (e / n) * (dw[t < 0 ? 0 : t][it] - (v[t < 0 ? 0 : t][it] / n) * du);
             L.dV[((size_t)kk9 * n_in + ci) * n_out + o] = outv;
         }
+    }
+}
+
+struct WnBwdArgs {
+    WnBwdLayer L[MAX_GEMM_LAYERS + 1];   // one entry per conv (the output pair counts twice)
+    int tile_begin[MAX_GEMM_LAYERS + 2];
+    int n;
+};
+
+// every conv of a stack in one launch: workgroup -> (conv, 16-channel output tile)
+__global__ __launch_bounds__(256) void iaf_wn_bwd_kernel(WnBwdArgs a) {
+    __shared__ float red[3][16][17];
+    __shared__ float s_n[16], s_dot[16];
+    int li = 0;
+    for (int i = 1; i < a.n; ++i)
+        if ((int)blockIdx.x >= a.tile_begin[i]) li = i;
+    const WnBwdLayer& L = a.L[li];
+    const int tile = blockIdx.x - a.tile_begin[li];
+    switch (L.cin >> 4) {
+        case 1: wn_bwd_tile<1>(L, tile, red, s_n, s_dot); break;
+        case 2: wn_bwd_tile<2>(L, tile, red, s_n, s_dot); break;
+        case 3: wn_bwd_tile<3>(L, tile, red, s_n, s_dot); break;
+        case 4: wn_bwd_tile<4>(L, tile, red, s_n, s_dot); break;
+        case 5: wn_bwd_tile<5>(L, tile, red, s_n, s_dot); break;
+        case 6: wn_bwd_tile<6>(L, tile, red, s_n, s_dot); break;
+        case 7: wn_bwd_tile<7>(L, tile, red, s_n, s_dot); break;
+        case 8: wn_bwd_tile<8>(L, tile, red, s_n, s_dot); break;
+        case 9: wn_bwd_tile<9>(L, tile, red, s_n, s_dot); break;
+        case 10: wn_bwd_tile<10>(L, tile, red, s_n, s_dot); break;
+        case 11: wn_bwd_tile<11>(L, tile, red, s_n, s_dot); break;
+        case 12: wn_bwd_tile<12>(L, tile, red, s_n, s_dot); break;
+        case 13: wn_bwd_tile<13>(L, tile, red, s_n, s_dot); break;
+        case 14: wn_bwd_tile<14>(L, tile, red, s_n, s_dot); break;
+        case 15: wn_bwd_tile<15>(L, tile, red, s_n, s_dot); break;
+        case 16: wn_bwd_tile<16>(L, tile, red, s_n, s_dot); break;
     }
 }
 
@@ -1268,8 +1377,11 @@ extern "C" int iaf_stack_set_training(iaf_stack_t* s, int on) {
     return IAF_OK;
 }
 
-static int wgrad_nrange(long long P) {
-    long long n = P / 512;
+// pixel ranges of the weight-gradient GEMM: as many as keep the grid within ONE round of 256 workgroups
+// (grid.x = 5 taps * ceil(cin/32) ci pairs), at least 64 pixels each, at most 16 (the partial buffer is sized for 16)
+static int wgrad_nrange(long long P, int cin = 160) {
+    long long n = 256 / (NTAPS * ((cin + 31) / 32));
+    if (n > P / 64) n = P / 64;
     if (n < 1) n = 1;
     if (n > 16) n = 16;
     return (int)n;
@@ -1281,6 +1393,8 @@ struct TrainWs {
     float* dy3;
     float* zpm;
     float* part;
+    float* dWeff[MAX_GEMM_LAYERS];   // per layer: reduced effective-weight gradient [NTAPS][cin][cout]
+    float* dbp[MAX_GEMM_LAYERS];     // per layer: [<=256 slabs][cout] column sums of dY
     // posterior block: saved forward values and backward temporaries, all NCHW [P*n_z] unless noted
     float* logsd; float* klelem; float* z0; float* dzt; float* dkl; float* dz0;
     float* rowsum;   // [B*n_z]  (P*n_z floats reserved: B <= P)
@@ -1301,7 +1415,11 @@ static size_t train_ws_floats(const iaf_stack_t* s, long long P, TrainWs* o, flo
         const size_t w = (size_t)s->L[l].cin * s->L[l].cout;
         if (w > maxw) maxw = w;
     }
-    t.part = take((size_t)wgrad_nrange(P) * NTAPS * maxw);
+    t.part = take((size_t)16 * NTAPS * maxw);
+    for (int l = 0; l < s->nlayers; ++l) {
+        t.dWeff[l] = take((size_t)NTAPS * s->L[l].cin * s->L[l].cout);
+        t.dbp[l] = take((size_t)256 * s->L[l].cout);
+    }
     t.logsd = take((size_t)P * s->n_z); t.klelem = take((size_t)P * s->n_z); t.z0 = take((size_t)P * s->n_z);
     t.dzt = take((size_t)P * s->n_z); t.dkl = take((size_t)P * s->n_z); t.dz0 = take((size_t)P * s->n_z);
     t.rowsum = take((size_t)P * s->n_z);
@@ -1364,7 +1482,7 @@ static int launch_wgrad(const iaf_stack_t* s, const GemmLayer& L, const float* x
     p.x = x; p.dy = dy; p.part = part;
     p.B = B; p.H = H; p.W = W; p.HW = H * W; p.P = B * H * W;
     p.cin = L.cin; p.cout = L.cout;
-    p.nrange = wgrad_nrange(p.P);
+    p.nrange = wgrad_nrange(p.P, L.cin);
     p.px_per_range = (int)(((long long)p.P + p.nrange - 1) / p.nrange + 15) / 16 * 16;
     static const int tf_dh[NTAPS] = {0, 0, 1, 1, 1}, tf_dw[NTAPS] = {0, 1, -1, 0, 1};
     for (int t = 0; t < NTAPS; ++t) { p.tap_dh[t] = tf_dh[t]; p.tap_dw[t] = tf_dw[t]; }
@@ -1406,7 +1524,6 @@ extern "C" int iaf_step_backward(iaf_stack_t* s, const float* z, const float* co
     TrainWs tw;
     train_ws_floats(s, P, &tw, (float*)workspace);
     hipStream_t st = (hipStream_t)stream;
-    const int nrange = wgrad_nrange(P);
 
     // (1) affine + log-det backward -> packed pixel-major dY of the output GEMM, pixel-major copy of z
     {
@@ -1420,14 +1537,28 @@ extern "C" int iaf_step_backward(iaf_stack_t* s, const float* z, const float* co
     memset(&base, 0, sizeof(base));
     base.B = B; base.H = H; base.W = W; base.HW = H * W; base.P = P;
 
-    auto wn_bwd = [&](int conv_index, const GemmLayer& L, const float* dy, int n_out_each, int pack_stride, int pack_off) {
-        WnBwdLayer w;
+    const int nslab = (P + 31) / 32 < 256 ? (P + 31) / 32 : 256;
+    const int px_per_slab = (P + nslab - 1) / nslab;
+    auto reduce = [&](int l, const float* dy) {     // partials -> dWeff[l], dY column sums -> dbp[l]
+        const GemmLayer& L = s->L[l];
+        const size_t n4 = (size_t)NTAPS * L.cin * L.cout / 4;
+        int nblk = (int)((n4 + 255) / 256);
+        if (nblk > 1024) nblk = 1024;
+        hipLaunchKernelGGL(iaf_wgrad_reduce_kernel, dim3(nblk + nslab), dim3(256), 0, st, tw.part, tw.dWeff[l],
+                           wgrad_nrange(P, L.cin), n4, nblk, dy, tw.dbp[l], P, L.cout, px_per_slab);
+    };
+    WnBwdArgs wa;
+    memset(&wa, 0, sizeof(wa));
+    auto wn_add = [&](int conv_index, int l, int n_out_each, int pack_stride, int pack_off) {
+        const GemmLayer& L = s->L[l];
+        WnBwdLayer& w = wa.L[wa.n];
         w.V = V[conv_index]; w.g = g[conv_index];
-        w.part = tw.part; w.dy = dy;
+        w.dW = tw.dWeff[l]; w.dbp = tw.dbp[l];
         w.dV = dV[conv_index]; w.dg = dg[conv_index]; w.db = db[conv_index];
-        w.cin = L.cin; w.cout = n_out_each; w.cout_packed = L.cout; w.nrange = nrange; w.zerodiag = L.zerodiag;
+        w.cin = L.cin; w.cout = n_out_each; w.cout_packed = L.cout; w.nslab = nslab; w.zerodiag = L.zerodiag;
         w.pack_stride = pack_stride; w.pack_off = pack_off;
-        hipLaunchKernelGGL(iaf_wn_bwd_kernel, dim3(n_out_each / 16), dim3(256), 0, st, w, P);
+        wa.tile_begin[wa.n + 1] = wa.tile_begin[wa.n] + n_out_each / 16;
+        wa.n++;
     };
 
     // (2) walk the layers backwards: data gradient (same conv kernel on W^T, mirrored taps), then weight gradient
@@ -1447,14 +1578,17 @@ extern "C" int iaf_step_backward(iaf_stack_t* s, const float* z, const float* co
         }
         if ((rc = launch_gemm(s, s->T[l], false, true, -1, p, IN_PIXMAJOR, st))) return rc;
         if ((rc = launch_wgrad(s, s->L[l], x_in, dy, tw.part, B, H, W, st))) return rc;
+        reduce(l, dy);
         if (l == d) {
-            wn_bwd(d, s->L[l], dy, s->n_z, 2, 0);       // layer_out_0 (mean tiles)
-            wn_bwd(d + 1, s->L[l], dy, s->n_z, 2, 1);   // layer_out_1 (logsd tiles)
+            wn_add(d, l, s->n_z, 2, 0);       // layer_out_0 (mean tiles)
+            wn_add(d + 1, l, s->n_z, 2, 1);   // layer_out_1 (logsd tiles)
         } else {
-            wn_bwd(l, s->L[l], dy, s->L[l].cout, 1, 0);
+            wn_add(l, l, s->L[l].cout, 1, 0);
         }
         if (l > 0) dy = tw.da[(l - 1) & 1];
     }
+    // (3) mask + weight-norm backward of every conv of the stack in one launch
+    hipLaunchKernelGGL(iaf_wn_bwd_kernel, dim3(wa.tile_begin[wa.n]), dim3(256), 0, st, wa);
     return (int)hipGetLastError();
 }
 
@@ -1531,6 +1665,17 @@ extern "C" int iaf_posterior_block_backward(iaf_stack_t* s, const float* qz_mean
         return rc;
     hipLaunchKernelGGL(iaf_post_bwd_post_kernel, ew_grid(n), dim3(256), 0, st, qz_mean, rz_mean, tw.z0, tw.dz0, tw.dkl, dmean,
                        dlogsd_q, n);
+    return (int)hipGetLastError();
+}
+
+extern "C" int iaf_adamax_ema_step(float* var, const float* grad, float* slot_m, float* slot_v, float* ema, size_t n, float lr,
+                                   float beta1, float beta2, float eps, float ema_decay, float grad_scale, void* stream) {
+    if (!var || !grad || !slot_m || !slot_v) return IAF_ERR_NULL;
+    if (n == 0) return IAF_OK;
+    const bool al = (((uintptr_t)var | (uintptr_t)grad | (uintptr_t)slot_m | (uintptr_t)slot_v | (uintptr_t)ema) & 15) == 0;
+    const size_t n4 = al ? n / 4 : 0;
+    hipLaunchKernelGGL(iaf_adamax_ema_kernel, ew_grid(n4 ? n4 : n), dim3(256), 0, (hipStream_t)stream, var, grad, slot_m, slot_v,
+                       ema, n4, n, lr, beta1, beta2, eps, ema_decay, grad_scale);
     return (int)hipGetLastError();
 }
 

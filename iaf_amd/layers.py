@@ -323,17 +323,20 @@ class ARStack(object):
         return dict(z=z, kl_obj=kl_obj, kl_cost=kl_cost)
 
     def posterior_block_backward(self, qz_mean, qz_logsd, rz_mean, rz_logsd, pz_mean, pz_logsd, eps, kl_min, z, dz, dkl_obj,
-                                 params):
+                                 params, grads_out=None):
         """Backward of tf_train.py:56-85.  Returns dict(dmean (= d qz_mean = d rz_mean), dlogsd (= d qz_logsd = d rz_logsd),
         dpz_mean, dpz_logsd, dcontext (= d up_context = d down_context), grads {conv/V|g|b})."""
         B, _, H, W = qz_mean.shape
         B, H, W = int(B), int(H), int(W)
         tens = self._param_tensors(params)
         names = self.conv_names()
-        grads = {}
+        grads = {} if grads_out is None else grads_out     # grads_out: pre-allocated views (e.g. into a flat bucket)
         for ci, nm in enumerate(names):
             for j, suffix in enumerate(("V", "g", "b")):
-                grads[nm + "/" + suffix] = torch.empty_like(tens[3 * ci + j])
+                if grads_out is None:
+                    grads[nm + "/" + suffix] = torch.empty_like(tens[3 * ci + j])
+                else:
+                    _check_act(grads[nm + "/" + suffix], "grad " + nm + "/" + suffix, tens[3 * ci + j].shape)
         n = len(names)
         arr = ctypes.c_void_p * n
         Vp = arr(*[t.data_ptr() for t in tens[0::3]])

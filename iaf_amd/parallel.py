@@ -11,6 +11,51 @@ import torch
 import torch.distributed as dist
 
 
+class FlatParams(object):
+    """All trainable tensors of a model as views into ONE flat fp32 buffer, with matching flat gradient, Adamax slot and
+    EMA buffers.  The engine's backward writes gradients straight into the views, so a training step needs exactly one
+    all-reduce (the reference sums 488 tensors one by one) and one fused optimiser launch."""
+
+    def __init__(self, named_tensors, device=None):
+        items = list(named_tensors.items())
+        device = device or items[0][1].device
+        total = sum(((t.numel() + 3) // 4) * 4 for _, t in items)     # keep every view 16-byte aligned
+        self.params = torch.empty(total, dtype=torch.float32, device=device)
+        self.grads = torch.zeros_like(self.params)
+        self.slot_m = torch.zeros_like(self.params)
+        self.slot_v = torch.zeros_like(self.params)
+        self.ema = torch.empty_like(self.params)
+        self.p, self.g = {}, {}
+        off = 0
+        for k, t in items:
+            n = t.numel()
+            self.p[k] = self.params[off:off + n].view(t.shape)
+            self.p[k].copy_(t)
+            self.g[k] = self.grads[off:off + n].view(t.shape)
+            off += ((n + 3) // 4) * 4
+        self.ema.copy_(self.params)
+
+    def all_reduce_grads(self, group=None, async_op=False):
+        """sum over ranks (the 1/N is folded into the optimiser kernel)"""
+        if dist.is_initialized() and dist.get_world_size(group) > 1:
+            return dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        return None
+
+    def adamax_ema_step(self, lr, world=1, beta1=0.9, beta2=0.999, eps=1e-8, ema_decay=0.999):
+        if self.params.is_cuda:
+            import ctypes
+            from . import _capi
+            ptr = lambda t: ctypes.c_void_p(t.data_ptr())
+            _capi.check(_capi.lib().iaf_adamax_ema_step(ptr(self.params), ptr(self.grads), ptr(self.slot_m), ptr(self.slot_v),
+                                                        ptr(self.ema), self.params.numel(), lr, beta1, beta2, eps, ema_decay,
+                                                        1.0 / world,
+                                                        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        else:        # host replicas (gloo tests): the same arithmetic with torch ops
+            g = self.grads / float(world)
+            adamax_step_(self.params, g, self.slot_m, self.slot_v, lr, beta1, beta2, eps)
+            ema_step_(self.ema, self.params, ema_decay)
+
+
 def shard_batch(x, rank=None, world=None):
     """tf.split(0, num_gpus, x)[rank] (tf_train.py:126): equal contiguous shards of the global batch."""
     if world is None:

@@ -126,6 +126,13 @@ int iaf_posterior_block_backward(iaf_stack_t* s, const float* qz_mean, const flo
                                  float* const* db, int B, int H, int W, void* workspace, size_t workspace_bytes,
                                  void* stream);
 
+/* Optimiser step on flat fp32 buffers of n elements: Adamax (tf_utils/adamax.py:40-56: slot "v" is the first moment,
+ * slot "m" the infinity norm), on grad*grad_scale (grad_scale = 1/N folds the division of average_grads,
+ * tf_utils/common.py:86, after an all-reduce(sum)), then the EMA of the new parameters (tf_train.py:157-158;
+ * ema may be NULL).  In place. */
+int iaf_adamax_ema_step(float* var, const float* grad, float* slot_m, float* slot_v, float* ema, size_t n, float lr,
+                        float beta1, float beta2, float eps, float ema_decay, float grad_scale, void* stream);
+
 /* Full posterior block, tf_train.py:56-85 (mode "train"): everything between down_conv1 and
  * the concat, i.e. posterior sample, logqs, IAF step, log-det accumulation, prior logps, KL and
  * free bits.  All [B,n_z,H,W] inputs NCHW; up_context/down_context [B,n_h,H,W]; eps is the

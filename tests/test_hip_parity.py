@@ -268,6 +268,35 @@ def test_posterior_block_backward_vs_autograd_oracle(amd, shape, kl_min):
         _rel_close(host(bw["grads"][k]), ref[k], 3e-4, k)
 
 
+def test_adamax_ema_kernel_vs_oracle(amd):
+    """fused Adamax + 1/N + EMA on flat buffers vs tf_utils/adamax.py:40-56 restated in the oracle, 3 steps"""
+    from iaf_amd import parallel as par
+    rng = np.random.RandomState(8)
+    shapes = {"a/V": (3, 3, 32, 160), "a/g": (160,), "a/b": (160,), "odd": (7,)}
+    fp = par.FlatParams({k: dev(rng.standard_normal(s)) for k, s in shapes.items()})
+    var = {k: host(v).copy() for k, v in fp.p.items()}
+    m = {k: np.zeros_like(v) for k, v in var.items()}
+    v_ = {k: np.zeros_like(v) for k, v in var.items()}
+    ema = {k: v.copy() for k, v in var.items()}
+    world, lr = 4, 0.002
+    for step in range(3):
+        grads = {k: rng.standard_normal(s) * (10.0 ** (step - 1)) for k, s in shapes.items()}
+        for k in shapes:
+            fp.g[k].copy_(dev(grads[k]))
+        fp.adamax_ema_step(lr, world=world)
+        for k in shapes:
+            var[k], m[k], v_[k] = O.adamax_step(var[k], f32(grads[k]) / world, m[k], v_[k], lr)
+            ema[k] = O.ema_step(ema[k], var[k])
+    for k in shapes:
+        np.testing.assert_allclose(host(fp.p[k]), var[k], rtol=2e-5, atol=2e-6)
+    off = 0
+    flat_ema = host(fp.ema)
+    for k, s in shapes.items():
+        n = int(np.prod(s))
+        np.testing.assert_allclose(flat_ema[off:off + n].reshape(s), ema[k], rtol=2e-5, atol=2e-6)
+        off += ((n + 3) // 4) * 4
+
+
 # ---------------------------------------------------------------- Theano statement (SURVEY 8a rows a10-a12)
 def _theano_params(rng, name, n_z, n_h_list):
     w = {}
