@@ -67,6 +67,54 @@ def test_dp_two_ranks_gloo(golden_dir):
     np.testing.assert_allclose(out[0]["shadow"], O.ema_step(np.zeros_like(ev), ev), rtol=1e-5, atol=1e-7)
 
 
+def _flat_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from iaf_amd import parallel as par
+    rng = np.random.RandomState(3)                      # identical initial parameters on every rank
+    shapes = {"IAF_0_0/ar_multiconv2d/layer_0/V": (3, 3, 4, 8), "IAF_0_0/ar_multiconv2d/layer_0/g": (8,), "x/odd": (5,)}
+    fp = par.FlatParams({k: torch.from_numpy(rng.standard_normal(s)).float() for k, s in shapes.items()})
+    grng = np.random.RandomState(100 + rank)            # rank-specific gradients (each rank saw its own batch shard)
+    for step in range(3):
+        for k, s in shapes.items():
+            fp.g[k].copy_(torch.from_numpy(grng.standard_normal(s)).float())
+        fp.all_reduce_grads()                           # ONE collective for the whole model
+        fp.adamax_ema_step(0.01, world=world)
+    out[rank] = dict(params=fp.params.numpy().copy(), ema=fp.ema.numpy().copy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_bucket_training_step_two_ranks_gloo():
+    """the DP update path of bench.py --train on host tensors: flat gradient bucket -> all-reduce(sum) -> Adamax on grad/N
+    -> EMA; replicas must end bit-identical and equal to the oracle fed with the tower-averaged gradients"""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_flat_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    np.testing.assert_array_equal(out[0]["params"], out[1]["params"])
+    np.testing.assert_array_equal(out[0]["ema"], out[1]["ema"])
+    rng = np.random.RandomState(3)
+    shapes = {"IAF_0_0/ar_multiconv2d/layer_0/V": (3, 3, 4, 8), "IAF_0_0/ar_multiconv2d/layer_0/g": (8,), "x/odd": (5,)}
+    var = {k: rng.standard_normal(s).astype(np.float32).astype(np.float64) for k, s in shapes.items()}
+    m = {k: np.zeros_like(v) for k, v in var.items()}
+    vv = {k: np.zeros_like(v) for k, v in var.items()}
+    ema = {k: v.copy() for k, v in var.items()}
+    grngs = [np.random.RandomState(100 + r) for r in range(world)]
+    for step in range(3):
+        for k, s in shapes.items():
+            g = O.average_grads([[gr.standard_normal(s).astype(np.float32).astype(np.float64)] for gr in grngs])[0]
+            var[k], m[k], vv[k] = O.adamax_step(var[k], g, m[k], vv[k], 0.01)
+            ema[k] = O.ema_step(ema[k], var[k])
+    off = 0
+    for k, s in shapes.items():
+        n = int(np.prod(s))
+        np.testing.assert_allclose(out[0]["params"][off:off + n].reshape(s), var[k], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(out[0]["ema"][off:off + n].reshape(s), ema[k], rtol=1e-5, atol=1e-6)
+        off += ((n + 3) // 4) * 4
+
+
 def test_average_grads_against_reference_golden_four_towers(golden_dir):
     """single process, the reference's 4-tower fixture: sum then /N"""
     g = np.load(os.path.join(golden_dir, "common.npz"))
