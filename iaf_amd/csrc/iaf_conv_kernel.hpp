@@ -24,12 +24,14 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 #define EPI_HIDDEN 0   // y = elu(acc + bias [+ ctx (+ ctx2)])  -> pixel-major scratch
 #define EPI_OUT 1      // output pair (mean, logsd) -> NCHW; mode selects raw / IAF step / posterior
+#define EPI_DGRAD 2    // data gradient (transposed packs, mirrored taps): mode selects MODE_DGRAD_ELU / MODE_DGRAD_Z
 
 #define MODE_RAW 0        // out0 = m_raw, out1 = s_raw                         (layers.py:166)
 #define MODE_IAF 1        // out0 = (z-0.1m)/exp(0.1s), out1 = 0.1s             (tf_train.py:70-72)
 #define MODE_POSTERIOR 2  // MODE_IAF on z0 rebuilt from the posterior inputs, plus kl elements
-// backward (data gradient) modes of EPI_HIDDEN: the same kernel run on the transposed packed weights with the tap
-// table negated computes dX = W^T * dY; the epilogue applies what autodiff applies next.
+// backward (data gradient) modes of EPI_DGRAD: the same kernel run on the transposed packed weights with the tap
+// table negated computes dX = W^T * dY; the epilogue applies what autodiff applies next.  (Its own compile-time
+// epilogue: as runtime branches inside EPI_HIDDEN these modes cost the forward kernels ~1800 cycles.)
 #define MODE_DGRAD_ELU 3  // y = acc * elu'(a) with elu'(a) = (h > 0 ? 1 : h + 1), h = saved activation (p.zin, pixel-major);
                           // optional NCHW copy to p.out0 (d context, layers.py:163-164)
 #define MODE_DGRAD_Z 4    // out0[NCHW] = acc + dz_new * exp(-logsd)   (p.qm = dz_new, p.ql = logsd; tf_train.py:71)
@@ -292,27 +294,30 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
     // ================= epilogue work assignment ==========================================================
     // With split-K the KS waves of one (pixel tile, co group) share the epilogue: wave kh finishes units
     // u = kh, kh+KS, ...  (unit = one co-tile for EPI_HIDDEN, one (mean, logsd) tile pair for EPI_OUT).
-    constexpr int NUNIT = (EPI == EPI_HIDDEN) ? NT : NT / 2;
+    constexpr bool ONE_TILE_UNITS = (EPI != EPI_OUT);
+    constexpr int NUNIT = ONE_TILE_UNITS ? NT : NT / 2;
     constexpr int NMY = (NUNIT + KS - 1) / KS;
-    f32x4 pre0[NMY], pre1[NMY], pbias[NMY * (EPI == EPI_HIDDEN ? 1 : 2)];
+    f32x4 pre0[NMY], pre1[NMY], pbias[NMY * (ONE_TILE_UNITS ? 1 : 2)];
     auto prefetch_epilogue = [&]() {     // operands that do not depend on the GEMM: bias, context, z
         if (!pvalid) return;
 #pragma unroll
         for (int i = 0; i < NMY; ++i) {
             const int u = kh + i * KS;
             if (u >= NUNIT) continue;
-            if (EPI == EPI_HIDDEN) {
-                pbias[i] = p.bias ? *(const f32x4*)(p.bias + (cot0 + u) * 16 + 4 * kk) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (EPI == EPI_DGRAD) {
                 if (p.mode == MODE_DGRAD_ELU) {
                     pre0[i] = *(const f32x4*)(p.zin + (size_t)Pl * p.cout + (cot0 + u) * 16 + 4 * kk);
-                } else if (p.mode == MODE_DGRAD_Z) {
+                } else {
                     const size_t cb = ((size_t)bimg * p.cout + (cot0 + u) * 16 + 4 * kk) * HW + pp;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         pre0[i][r] = p.qm[cb + (size_t)r * HW];
                         pre1[i][r] = p.ql[cb + (size_t)r * HW];
                     }
-                } else if (p.ctx) {
+                }
+            } else if (EPI == EPI_HIDDEN) {
+                pbias[i] = *(const f32x4*)(p.bias + (cot0 + u) * 16 + 4 * kk);
+                if (p.ctx) {
                     const size_t cb = ((size_t)bimg * p.cout + (cot0 + u) * 16 + 4 * kk) * HW + pp;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) pre0[i][r] = p.ctx[cb + (size_t)r * HW];
@@ -487,7 +492,7 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
 
     // ================= split-K reduction through LDS + epilogue ============================================
     // C/D layout of the 16x16 MFMA: lane holds D[row = 4*(l>>4)+r][col = l&15] = (co = tile*16 + 4*kk + r, pixel pl)
-    f32x4 val[NMY * (EPI == EPI_HIDDEN ? 1 : 2)];
+    f32x4 val[NMY * (ONE_TILE_UNITS ? 1 : 2)];
     if (KS > 1) {
         float* red = (float*)(smem4 + (size_t)(p.nslot + 1) * cp4);   // aliases the (now dead) shared-weight buffers
         if (SHARED_W) __syncthreads();                                // ... once every wave has left its K loop
@@ -502,7 +507,7 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
 #pragma unroll
         for (int i = 0; i < NMY; ++i) {
             const int u = kh + i * KS;
-            constexpr int TPU = (EPI == EPI_HIDDEN) ? 1 : 2;     // tiles per unit
+            constexpr int TPU = ONE_TILE_UNITS ? 1 : 2;           // tiles per unit
 #pragma unroll
             for (int e = 0; e < TPU; ++e) {
                 f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -524,9 +529,9 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
         for (int i = 0; i < NMY; ++i) {
             const int u = kh + i * KS;
             if (u >= NUNIT) continue;
-            if (EPI == EPI_HIDDEN) {
+            if (EPI == EPI_DGRAD) {
                 const int co = (cot0 + u) * 16 + 4 * kk;
-                f32x4 v = val[i] + pbias[i];
+                f32x4 v = val[i];
                 if (p.mode == MODE_DGRAD_ELU) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] *= (pre0[i][r] > 0.f ? 1.f : pre0[i][r] + 1.f);
@@ -536,14 +541,14 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
 #pragma unroll
                         for (int r = 0; r < 4; ++r) p.out0[cb + (size_t)r * HW] = v[r];
                     }
-                    continue;
-                }
-                if (p.mode == MODE_DGRAD_Z) {
+                } else {
                     const size_t cb = ((size_t)bimg * p.cout + co) * HW + pp;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) p.out0[cb + (size_t)r * HW] = v[r] + pre0[i][r] * __expf(-pre1[i][r]);
-                    continue;
                 }
+            } else if (EPI == EPI_HIDDEN) {
+                const int co = (cot0 + u) * 16 + 4 * kk;
+                f32x4 v = val[i] + pbias[i];
                 if (p.border) {   // Theano pad_channel (conv.py:71-83, ar.py:229-233): taps that fall outside see a 1
 #pragma unroll
                     for (int t = 1; t < NTAPS; ++t)

@@ -1110,10 +1110,10 @@ static void auto_shape(GemmLayer& L, bool is_out, long long P, int W) {
 }
 
 // launches the conv kernel for GEMM descriptor L (forward layer, or a transposed descriptor for dgrad)
-static int launch_gemm(const iaf_stack_t* s, GemmLayer& L, bool is_out, bool negate_taps, int prof_id, ConvP& p, int inmode,
+static int launch_gemm(const iaf_stack_t* s, GemmLayer& L, int epi, bool negate_taps, int prof_id, ConvP& p, int inmode,
                        hipStream_t st) {
-    if (!L.user_tuned) auto_shape(L, is_out, p.P, p.W);
-    conv_fn_t fn = pick_kernel(L.nt, L.pxt, L.wco, L.ks, inmode, is_out ? EPI_OUT : EPI_HIDDEN);
+    if (!L.user_tuned) auto_shape(L, epi == EPI_OUT, p.P, p.W);
+    conv_fn_t fn = pick_kernel(L.nt, L.pxt, L.wco, L.ks, inmode, epi);
     if (!fn) return IAF_ERR_UNSUPPORTED;
     const int tm = 16 * L.pxt;
     p.wp = L.wp; p.bias = L.bias; p.lim = L.lim;
@@ -1149,7 +1149,8 @@ static int launch_gemm(const iaf_stack_t* s, GemmLayer& L, bool is_out, bool neg
 }
 
 static int launch_conv(const iaf_stack_t* s, int layer, ConvP& p, int inmode, hipStream_t st) {
-    return launch_gemm(s, const_cast<iaf_stack*>(s)->L[layer], layer == s->depth_ar, false, layer, p, inmode, st);
+    return launch_gemm(s, const_cast<iaf_stack*>(s)->L[layer], layer == s->depth_ar ? EPI_OUT : EPI_HIDDEN, false, layer, p,
+                       inmode, st);
 }
 
 static int check_dims(const iaf_stack_t* s, int B, int H, int W) {
@@ -1576,7 +1577,7 @@ extern "C" int iaf_step_backward(iaf_stack_t* s, const float* z, const float* co
             p.y = tw.da[(l - 1) & 1];
             p.out0 = (l - 1 == 0) ? dcontext : nullptr;
         }
-        if ((rc = launch_gemm(s, s->T[l], false, true, -1, p, IN_PIXMAJOR, st))) return rc;
+        if ((rc = launch_gemm(s, s->T[l], EPI_DGRAD, true, -1, p, IN_PIXMAJOR, st))) return rc;
         if ((rc = launch_wgrad(s, s->L[l], x_in, dy, tw.part, B, H, W, st))) return rc;
         reduce(l, dy);
         if (l == d) {
