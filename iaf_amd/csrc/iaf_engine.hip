@@ -688,6 +688,113 @@ __global__ __launch_bounds__(256) void iaf_post_bwd_post_kernel(const float* qm,
 }
 
 // ---------------------------------------------------------------------------------------------
+// GENERIC FALLBACK: direct (VALU) masked conv for channel counts the MFMA path does not cover (not multiples of 16,
+// or > 256).  Same arithmetic, same fused epilogues, NCHW everywhere, one thread per output element.  Orders of
+// magnitude slower than the MFMA path -- it exists so that every shape the reference accepts (layers.py:116 only asks
+// that n_h and n_z divide each other) runs through the same C ABI; tests hold it to the reference's tiny golden cases.
+// ---------------------------------------------------------------------------------------------
+struct GenPrepLayer {
+    const float* V[2]; const float* g[2]; const float* b[2];
+    float* w;        // effective weights [NTAPS][cin][cout_total]
+    float* bias;     // [cout_total]
+    int cin, cout_each, npair, zerodiag, ch_begin;
+};
+struct GenPrepArgs { GenPrepLayer L[MAX_GEMM_LAYERS]; int nlayers; };
+
+__global__ __launch_bounds__(256) void iaf_generic_prep_kernel(GenPrepArgs a) {
+    __shared__ float red[256];
+    int li = 0;
+    for (int i = 1; i < a.nlayers; ++i)
+        if ((int)blockIdx.x >= a.L[i].ch_begin) li = i;
+    const GenPrepLayer& L = a.L[li];
+    const int oc = blockIdx.x - L.ch_begin;              // channel inside this GEMM layer: [mean channels | logsd channels]
+    const int which = oc / L.cout_each, o = oc - which * L.cout_each;
+    const float* V = L.V[which];
+    const int n_in = L.cin, n_out = L.cout_each, ctot = L.cout_each * L.npair;
+    float ss = 0.f;
+    for (int e = threadIdx.x; e < NTAPS * n_in; e += 256) {
+        const int t = e / n_in, ci = e - t * n_in;
+        const int kh = (t == 0 || t == 1) ? 1 : 2, kw = (t == 0) ? 1 : (t == 1 ? 2 : t - 2);
+        const bool live = (t != 0) || made_live(ci, o, n_in, n_out, L.zerodiag);
+        const float v = live ? V[((size_t)(kh * 3 + kw) * n_in + ci) * n_out + o] : 0.f;
+        ss += v * v;
+    }
+    red[threadIdx.x] = ss;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    const float scale = expf(L.g[which][o]) / sqrtf(fmaxf(red[0], 1e-12f));      // layers.py:60
+    for (int e = threadIdx.x; e < NTAPS * n_in; e += 256) {
+        const int t = e / n_in, ci = e - t * n_in;
+        const int kh = (t == 0 || t == 1) ? 1 : 2, kw = (t == 0) ? 1 : (t == 1 ? 2 : t - 2);
+        const bool live = (t != 0) || made_live(ci, o, n_in, n_out, L.zerodiag);
+        L.w[((size_t)t * n_in + ci) * ctot + oc] = live ? V[((size_t)(kh * 3 + kw) * n_in + ci) * n_out + o] * scale : 0.f;
+    }
+    if (threadIdx.x == 0) L.bias[oc] = L.b[which][o];
+}
+
+struct GenConvP {
+    const float* x;       // NCHW input (NULL in posterior mode for the first layer)
+    const float* w; const float* bias;
+    const float* ctx; const float* ctx2;
+    float* y;             // hidden output, NCHW
+    const float* zin; float* out0; float* out1; float* kl_elem;
+    const float* qm; const float* ql; const float* rm; const float* rl; const float* pm; const float* pl; const float* eps;
+    int B, H, W, cin, cout, nz, mode, is_out, posterior_in;
+};
+
+__device__ __forceinline__ float gen_x(const GenConvP& p, int b, int ci, int hh, int ww) {
+    const size_t i = (((size_t)b * p.cin + ci) * p.H + hh) * p.W + ww;
+    if (!p.posterior_in) return p.x[i];
+    return (p.qm[i] + p.rm[i]) + __expf(0.5f * (2.f * (p.ql[i] + p.rl[i]))) * p.eps[i];      // tf_train.py:57,63
+}
+
+__global__ __launch_bounds__(256) void iaf_generic_conv_kernel(GenConvP p) {
+    const int tap_dh[NTAPS] = {0, 0, 1, 1, 1}, tap_dw[NTAPS] = {0, 1, -1, 0, 1};
+    const int nout = p.is_out ? p.nz : p.cout;
+    const size_t total = (size_t)p.B * nout * p.H * p.W;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ww = (int)(i % p.W);
+        const int hh = (int)((i / p.W) % p.H);
+        const int co = (int)((i / ((size_t)p.W * p.H)) % nout);
+        const int b = (int)(i / ((size_t)p.W * p.H * nout));
+        float a0 = 0.f, a1 = 0.f;
+        for (int t = 0; t < NTAPS; ++t) {
+            const int h2 = hh + tap_dh[t], w2 = ww + tap_dw[t];
+            if (h2 < 0 || h2 >= p.H || w2 < 0 || w2 >= p.W) continue;
+            const float* wt = p.w + (size_t)t * p.cin * p.cout;
+            for (int ci = 0; ci < p.cin; ++ci) {
+                const float xv = gen_x(p, b, ci, h2, w2);
+                a0 = fmaf(xv, wt[(size_t)ci * p.cout + co], a0);
+                if (p.is_out) a1 = fmaf(xv, wt[(size_t)ci * p.cout + p.nz + co], a1);
+            }
+        }
+        if (!p.is_out) {
+            float v = a0 + p.bias[co];
+            if (p.ctx) { v += p.ctx[i]; if (p.ctx2) v += p.ctx2[i]; }
+            p.y[i] = elu_f(v);
+            continue;
+        }
+        const float m_raw = a0 + p.bias[co], s_raw = a1 + p.bias[p.nz + co];
+        if (p.mode == MODE_RAW) { p.out0[i] = m_raw; p.out1[i] = s_raw; continue; }
+        const float m = m_raw * 0.1f, sgm = s_raw * 0.1f;
+        if (p.mode == MODE_IAF) { p.out0[i] = (p.zin[i] - m) / __expf(sgm); p.out1[i] = sgm; continue; }
+        const float mean = p.qm[i] + p.rm[i], logvar = 2.f * (p.ql[i] + p.rl[i]);
+        const float z0 = mean + __expf(0.5f * logvar) * p.eps[i];
+        const float d0 = z0 - mean;
+        float logqs = -0.5f * (1.8378770664093453f + logvar + d0 * d0 / __expf(logvar)) + sgm;
+        const float z = (z0 - m) / __expf(sgm);
+        const float plv = 2.f * p.pl[i], d1 = z - p.pm[i];
+        const float logps = -0.5f * (1.8378770664093453f + plv + d1 * d1 / __expf(plv));
+        p.out0[i] = z;
+        if (p.out1) p.out1[i] = sgm;
+        p.kl_elem[i] = logqs - logps;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side: stack object
 // ---------------------------------------------------------------------------------------------
 static dim3 ew_grid(size_t n);
@@ -713,6 +820,7 @@ struct iaf_stack {
     GemmLayer L[MAX_GEMM_LAYERS];
     GemmLayer T[MAX_GEMM_LAYERS];   // transposed problems (dX = W^T dY) of the same layers; valid when training
     bool training = false;
+    bool generic = false;     // channel counts outside the MFMA path: direct-conv fallback kernels
     bool prepared;
     size_t weight_bytes;  // raw V/g/b bytes of the stack (for the algorithmic byte count)
     // optional per-launch event timing of one layer
@@ -810,10 +918,12 @@ extern "C" int iaf_stack_create(iaf_stack_t** out, int n_z, int n_h, int depth_a
     if (n_z <= 0 || n_h <= 0 || depth_ar < 0 || depth_ar > MAX_GEMM_LAYERS - 1) return IAF_ERR_SHAPE;
     if (variant != IAF_VARIANT_TF && variant != IAF_VARIANT_THEANO) return IAF_ERR_UNSUPPORTED;
     if (depth_ar > 0 && !(n_z % n_h == 0 || n_h % n_z == 0)) return IAF_ERR_NOT_MULTIPLE;   // layers.py:116
-    if (n_z % 16 != 0 || (depth_ar > 0 && n_h % 16 != 0)) return IAF_ERR_UNSUPPORTED;
-    if (n_z > 16 * PREP_MAXI || n_h > 16 * PREP_MAXI) return IAF_ERR_UNSUPPORTED;
+    const bool generic = (n_z % 16 != 0 || (depth_ar > 0 && n_h % 16 != 0) || n_z > 16 * PREP_MAXI ||
+                          (depth_ar > 0 && n_h > 16 * PREP_MAXI));
+    if (generic && variant != IAF_VARIANT_TF) return IAF_ERR_UNSUPPORTED;
     iaf_stack* s = new (std::nothrow) iaf_stack();
     if (!s) return (int)hipErrorOutOfMemory;
+    s->generic = generic;
     s->n_z = n_z; s->n_h = n_h; s->depth_ar = depth_ar; s->variant = variant;
     s->nlayers = depth_ar + 1;
     s->prepared = false;
@@ -827,13 +937,14 @@ extern "C" int iaf_stack_create(iaf_stack_t** out, int n_z, int n_h, int depth_a
         L.npair = is_out ? 2 : 1;
         L.cout = each * L.npair;
         L.zerodiag = is_out ? 1 : 0;          // layers.py:162 (False) / 166 (True)
-        L.nchunk = cin / 16;
-        L.ncot = L.cout / 16;
+        L.nchunk = (cin + 15) / 16;
+        L.ncot = (L.cout + 15) / 16;
         default_tuning(L, is_out);
         count_macs(L, cin, each, L.zerodiag, L.npair);
         s->weight_bytes += (size_t)L.npair * (9 * (size_t)(cin + (variant == IAF_VARIANT_THEANO ? 1 : 0)) * each + 2 * (size_t)each) * sizeof(float);
         int rc;
-        if ((rc = (int)hipMalloc(&L.wp, (size_t)L.nchunk * NTAPS * L.ncot * 256 * sizeof(float))) != 0 ||
+        const size_t wfloats = generic ? (size_t)NTAPS * cin * L.cout : (size_t)L.nchunk * NTAPS * L.ncot * 256;
+        if ((rc = (int)hipMalloc(&L.wp, wfloats * sizeof(float))) != 0 ||
             (rc = (int)hipMalloc(&L.bias, (size_t)L.cout * sizeof(float))) != 0 ||
             (variant == IAF_VARIANT_THEANO && (rc = (int)hipMalloc(&L.border, (size_t)4 * L.cout * sizeof(float))) != 0) ||
             (rc = (int)hipMalloc(&L.lim, (size_t)L.ncot * sizeof(int))) != 0) {
@@ -842,7 +953,7 @@ extern "C" int iaf_stack_create(iaf_stack_t** out, int n_z, int n_h, int depth_a
         }
         // live-chunk limit of the centre tap per packed co-tile (the mask is monotone in c_in)
         int limh[1024];
-        for (int gt = 0; gt < L.ncot; ++gt) {
+        for (int gt = 0; gt < L.ncot && !generic; ++gt) {
             const int src = is_out ? (gt >> 1) : gt;
             int maxci = -1;
             for (int oo = 0; oo < 16; ++oo)
@@ -850,7 +961,7 @@ extern "C" int iaf_stack_create(iaf_stack_t** out, int n_z, int n_h, int depth_a
                     if (made_live(i, src * 16 + oo, cin, each, L.zerodiag) && i > maxci) maxci = i;
             limh[gt] = (maxci + 16) / 16;    // ceil((maxci+1)/16); 0 if nothing live
         }
-        if ((rc = (int)hipMemcpy(L.lim, limh, L.ncot * sizeof(int), hipMemcpyHostToDevice)) != 0) {
+        if (!generic && (rc = (int)hipMemcpy(L.lim, limh, L.ncot * sizeof(int), hipMemcpyHostToDevice)) != 0) {
             iaf_stack_destroy(s);
             return rc;
         }
@@ -922,6 +1033,7 @@ extern "C" int iaf_stack_destroy(iaf_stack_t* s) {
 extern "C" int iaf_stack_set_tuning(iaf_stack_t* s, int layer, int nt, int pxt, int wco, int ks) {
     if (!s) return IAF_ERR_NULL;
     if (layer < 0 || layer >= s->nlayers) return IAF_ERR_SHAPE;
+    if (s->generic) return IAF_ERR_UNSUPPORTED;
     GemmLayer& L = s->L[layer];
     const bool is_out = (layer == s->depth_ar);
     if (nt < 1 || L.ncot % (nt * wco) != 0) return IAF_ERR_UNSUPPORTED;
@@ -939,6 +1051,25 @@ extern "C" int iaf_stack_prepare(iaf_stack_t* s, const float* const* V, const fl
     const int nconv = s->depth_ar + 2;
     for (int i = 0; i < nconv; ++i)
         if (!V[i] || !g[i] || !b[i]) return IAF_ERR_NULL;
+    if (s->generic) {
+        GenPrepArgs ga;
+        memset(&ga, 0, sizeof(ga));
+        ga.nlayers = s->nlayers;
+        int ch = 0;
+        for (int l = 0; l < s->nlayers; ++l) {
+            const GemmLayer& L = s->L[l];
+            GenPrepLayer& P = ga.L[l];
+            P.V[0] = V[l]; P.g[0] = g[l]; P.b[0] = b[l];
+            if (L.npair == 2) { P.V[1] = V[l + 1]; P.g[1] = g[l + 1]; P.b[1] = b[l + 1]; }
+            P.w = L.wp; P.bias = L.bias; P.cin = L.cin; P.cout_each = L.cout / L.npair; P.npair = L.npair;
+            P.zerodiag = L.zerodiag; P.ch_begin = ch;
+            ch += L.cout;
+        }
+        hipLaunchKernelGGL(iaf_generic_prep_kernel, dim3(ch), dim3(256), 0, (hipStream_t)stream, ga);
+        HIP_TRY(hipGetLastError());
+        s->prepared = true;
+        return IAF_OK;
+    }
     PrepArgs a;
     memset(&a, 0, sizeof(a));
     a.nlayers = s->nlayers;
@@ -991,6 +1122,7 @@ extern "C" int iaf_prep_batch_create(iaf_prep_batch_t** out, iaf_stack_t* const*
     int nl = 0, nt = 0;
     for (int i = 0; i < n; ++i) {
         if (!stacks[i]) { iaf_prep_batch_destroy(b); return IAF_ERR_NULL; }
+        if (stacks[i]->generic) { iaf_prep_batch_destroy(b); return IAF_ERR_UNSUPPORTED; }
         b->stacks[i] = stacks[i];
         for (int l = 0; l < stacks[i]->nlayers; ++l) { nl++; nt += stacks[i]->L[l].ncot; }
     }
@@ -1183,8 +1315,34 @@ static int build_stack(iaf_stack_t* s, ConvP base, int first_inmode, const float
     return n;
 }
 
+static int run_stack_generic(iaf_stack_t* s, const ConvP& base, int first_inmode, const float* ctx, const float* ctx2,
+                             const Ws& ws, hipStream_t st) {
+    const float* cur = base.x;
+    for (int l = 0; l <= s->depth_ar; ++l) {
+        const GemmLayer& L = s->L[l];
+        GenConvP p;
+        memset(&p, 0, sizeof(p));
+        p.B = base.B; p.H = base.H; p.W = base.W; p.cin = L.cin; p.cout = L.cout; p.nz = s->n_z;
+        p.w = L.wp; p.bias = L.bias;
+        p.x = cur; p.posterior_in = (l == 0 && first_inmode == IN_POSTERIOR) ? 1 : 0;
+        p.qm = base.qm; p.ql = base.ql; p.rm = base.rm; p.rl = base.rl; p.pm = base.pm; p.pl = base.pl; p.eps = base.eps;
+        p.is_out = (l == s->depth_ar) ? 1 : 0;
+        if (p.is_out) {
+            p.mode = base.mode; p.zin = base.zin; p.out0 = base.out0; p.out1 = base.out1; p.kl_elem = base.kl_elem;
+        } else {
+            p.ctx = (l == 0) ? ctx : nullptr; p.ctx2 = (l == 0) ? ctx2 : nullptr;
+            p.y = ws.hbuf[l & 1];
+        }
+        const size_t total = (size_t)p.B * (p.is_out ? p.nz : p.cout) * p.H * p.W;
+        hipLaunchKernelGGL(iaf_generic_conv_kernel, ew_grid(total), dim3(256), 0, st, p);
+        cur = p.y;
+    }
+    return (int)hipGetLastError();
+}
+
 static int run_stack(iaf_stack_t* s, ConvP base, int first_inmode, const float* ctx, const float* ctx2, const Ws& ws,
                      hipStream_t st) {
+    if (s->generic) return run_stack_generic(s, base, first_inmode, ctx, ctx2, ws, st);
     Launch ls[MAX_GEMM_LAYERS];
     const int n = build_stack(s, base, first_inmode, ctx, ctx2, ws, ls);
     for (int i = 0; i < n; ++i) {
@@ -1201,6 +1359,7 @@ extern "C" int iaf_step_time_layer(iaf_stack_t* s, int layer, const float* z, co
     if (rc) return rc;
     if (!z || !z_new || !logsd || !avg_ms || (s->depth_ar > 0 && !context)) return IAF_ERR_NULL;
     if (layer < 0 || layer >= s->nlayers || reps <= 0) return IAF_ERR_SHAPE;
+    if (s->generic) return IAF_ERR_UNSUPPORTED;
     Ws ws;
     if ((rc = carve_ws(s, B, H, W, workspace, workspace_bytes, &ws))) return rc;
     hipStream_t st = (hipStream_t)stream;
@@ -1361,7 +1520,7 @@ extern "C" int iaf_compute_lowerbound(const float* log_pxz, const float* sum_kl,
 // ---------------------------------------------------------------------------------------------
 extern "C" int iaf_stack_set_training(iaf_stack_t* s, int on) {
     if (!s) return IAF_ERR_NULL;
-    if (s->variant != IAF_VARIANT_TF) return IAF_ERR_UNSUPPORTED;
+    if (s->variant != IAF_VARIANT_TF || s->generic) return IAF_ERR_UNSUPPORTED;
     if (!on) { s->training = false; return IAF_OK; }
     for (int l = 0; l < s->nlayers; ++l) {
         GemmLayer& L = s->L[l];

@@ -51,7 +51,8 @@ def test_argument_validation_mirrors_reference_errors(capi):
     assert lib.iaf_stack_create(None, 32, 160, 2, 0) == capi.IAF_ERR_NULL
     assert lib.iaf_stack_create(ctypes.byref(h), 64, 160, 2, 0) == capi.IAF_ERR_NOT_MULTIPLE   # layers.py:116
     assert lib.iaf_stack_create(ctypes.byref(h), 0, 160, 2, 0) == capi.IAF_ERR_SHAPE
-    assert lib.iaf_stack_create(ctypes.byref(h), 4, 8, 2, 0) == capi.IAF_ERR_UNSUPPORTED       # channels % 16
+    assert lib.iaf_stack_create(ctypes.byref(h), 4, 8, 2, 1) == capi.IAF_ERR_UNSUPPORTED       # channels % 16: the generic
+                                                                                               # fallback is TF-variant only
     assert lib.iaf_stack_create(ctypes.byref(h), 32, 160, 2, 7) == capi.IAF_ERR_UNSUPPORTED    # unknown variant
     with pytest.raises(AssertionError):
         capi.check(capi.IAF_ERR_NOT_MULTIPLE)

@@ -64,6 +64,43 @@ def test_ar_multiconv2d_vs_reference_golden(amd, golden_dir, name):
     np.testing.assert_allclose(host(logsd), g[name + "/logsd"], atol=ATOL, rtol=0)
 
 
+@pytest.mark.parametrize("name", sorted(gi.AR_CASES))
+def test_every_reference_golden_ar_case_on_gpu(amd, golden_dir, name):
+    """ALL committed reference outputs of ar_multiconv2d / the IAF step, including the tiny shapes whose channel counts
+    are not multiples of 16 (these run on the generic direct-conv fallback kernels, same C ABI)"""
+    g = np.load(os.path.join(golden_dir, "ar_multiconv2d.npz"))
+    c = gi.ar_case_inputs(name)
+    stack = amd.ARStack(c["n_z"], c["n_h"])
+    stack.prepare(dev_params(c["params"]))
+    m_raw, s_raw = stack.ar_multiconv2d(dev(c["z"]), dev(c["context"]))
+    np.testing.assert_allclose(host(m_raw), g[name + "/m_raw"], atol=ATOL, rtol=0)
+    np.testing.assert_allclose(host(s_raw), g[name + "/s_raw"], atol=ATOL, rtol=0)
+    z_new, logsd = stack.iaf_step(dev(c["z"]), dev(c["context"]))
+    np.testing.assert_allclose(host(z_new), g[name + "/z_new"], atol=ATOL, rtol=0)
+    np.testing.assert_allclose(host(logsd), g[name + "/logsd"], atol=ATOL, rtol=0)
+
+
+@pytest.mark.parametrize("name", sorted(gi.LAYER_CASES))
+def test_every_reference_golden_layer_case_on_gpu(amd, golden_dir, name):
+    """IAFLayer.down (tf_train.py:46-95) for every committed layer fixture: out-of-scope convs from the oracle, the
+    posterior block on the GPU (generic fallback for the tiny shapes), kl_obj / kl_cost / output vs the REFERENCE outputs"""
+    g = np.load(os.path.join(golden_dir, "iaf_layer.npz"))
+    c = gi.layer_case_inputs(name)
+    zs, hs = c["z_size"], c["h_size"]
+    p = c["params"]
+    pre = O.conv2d(O.elu(c["down_input"]), p["down_conv1/V"], p["down_conv1/g"], p["down_conv1/b"])
+    pz_mean, pz_logsd, rz_mean, rz_logsd, down_context, h_det = O.split_channels(pre, [zs] * 4 + [hs] * 2)
+    post = amd.IAFPosterior(zs, hs, depth_ar=2, kl_min=c["kl_min"])
+    post.load(dev_params({k[len("ar_multiconv2d/"):]: v for k, v in p.items() if k.startswith("ar_multiconv2d/")}))
+    post.set_up_state(dev(g[name + "/qz_mean"]), dev(g[name + "/qz_logsd"]), dev(g[name + "/up_context"]))
+    out = post.down(dev(pz_mean), dev(pz_logsd), dev(rz_mean), dev(rz_logsd), dev(down_context), dev(c["eps_post"]))
+    np.testing.assert_allclose(host(out["kl_obj"]), g[name + "/kl_obj"], atol=2e-3, rtol=1e-4)
+    np.testing.assert_allclose(host(out["kl_cost"]), g[name + "/kl_cost"], atol=2e-3, rtol=1e-4)
+    h = O.elu(np.concatenate([host(out["z"]), h_det], axis=1))
+    output = c["down_input"] + 0.1 * O.conv2d(h, p["down_conv2/V"], p["down_conv2/g"], p["down_conv2/b"])
+    np.testing.assert_allclose(output, g[name + "/output"], atol=ATOL, rtol=0)
+
+
 def test_function_api_with_tf_variable_names(amd, golden_dir):
     """the reference call site, tf_train.py:69, under its scope names"""
     g = np.load(os.path.join(golden_dir, "ar_multiconv2d.npz"))
@@ -498,7 +535,7 @@ def test_errors_mirror_reference(amd):
     with pytest.raises(AssertionError):
         amd.ARStack(64, [160, 160])                  # layers.py:116 assert
     with pytest.raises(ValueError):
-        amd.ARStack(4, [8, 8])                       # channels not multiples of 16: outside kernel coverage
+        amd.ARStack(4, [8, 8], variant="theano")     # channels not multiples of 16: the generic fallback is TF-only
     stack = amd.ARStack(32, [64])
     z = torch.zeros(1, 32, 4, 4, device="cuda")
     ctx = torch.zeros(1, 64, 4, 4, device="cuda")
