@@ -865,7 +865,9 @@ static size_t conv_lds_bytes(const GemmLayer& L, int W) {
     const int tm = 16 * L.pxt, nslot = tm + W + 1, cp = L.cin + 8;
     size_t fl = (size_t)(nslot + 1) * cp;
     size_t wbuf = 0, red = 0;
+#if defined(IAF_SHARED_W) && IAF_SHARED_W
     if (L.pxt > 1) wbuf = (size_t)L.wco * L.ks * 2 * NTAPS * L.nt * 256;   // shared weights: 2 chunk buffers per wave group
+#endif
     if (L.ks > 1) red = (size_t)L.ks * L.pxt * L.wco * L.nt * 256;          // split-K exchange (aliases the weight buffers)
     fl += wbuf > red ? wbuf : red;
     return fl * sizeof(float);
