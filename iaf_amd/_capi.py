@@ -66,6 +66,14 @@ SIGNATURES = {
     "iaf_layer_work": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int] +
                        [ctypes.POINTER(ctypes.c_double)] * 3),
     "iaf_step_work": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int] + [ctypes.POINTER(ctypes.c_double)] * 3),
+    "iaf_conv3x3_create": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_int]),
+    "iaf_conv3x3_destroy": (ctypes.c_int, [_vp]),
+    "iaf_conv3x3_prepare": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "iaf_conv3x3_forward": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, ctypes.POINTER(_vp),
+                                           ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                           ctypes.c_int, _vp]),
+    "iaf_conv3x3_set_tuning": (ctypes.c_int, [_vp] + [ctypes.c_int] * 4),
+    "iaf_conv3x3_work": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int] + [ctypes.POINTER(ctypes.c_double)] * 2),
 }
 
 

@@ -18,13 +18,16 @@ __device__ __forceinline__ void static_for(F&& f) {
     static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
 }
 
-#define NTAPS 5
+#define NTAPS 5        // live taps of a MADE-masked 3x3 filter
+#define MAXSPLIT 6     // down_conv1 feeds 6 tensors (tf_train.py:54)
+#define MAXTAPS 9      // a full (unmasked) 3x3 filter: the context producers / consumers (up_conv1, down_conv1, ...)
 // The 5 live taps are the filter positions (kh,kw) = (1,1) (1,2) (2,0) (2,1) (2,2), centre first; their (dh,dw)
 // relative to the output pixel come from ConvP (TF: (0,0)(0,1)(1,-1)(1,0)(1,1); Theano: the negated set).
 
 #define EPI_HIDDEN 0   // y = elu(acc + bias [+ ctx (+ ctx2)])  -> pixel-major scratch
 #define EPI_OUT 1      // output pair (mean, logsd) -> NCHW; mode selects raw / IAF step / posterior
 #define EPI_DGRAD 2    // data gradient (transposed packs, mirrored taps): mode selects MODE_DGRAD_ELU / MODE_DGRAD_Z
+#define EPI_PLAIN 3    // y = acc + bias [-> res + 0.1*y]  -> NCHW   (plain weight-normed conv2d, layers.py:63-64; tf_train.py:44,94)
 
 #define MODE_RAW 0        // out0 = m_raw, out1 = s_raw                         (layers.py:166)
 #define MODE_IAF 1        // out0 = (z-0.1m)/exp(0.1s), out1 = 0.1s             (tf_train.py:70-72)
@@ -64,7 +67,12 @@ struct ConvP {
     // tap geometry (runtime so that both statements of the operator share the instantiations):
     //   TF      (tf_utils/layers.py, cross-correlation): taps look right/below, halo after the tile
     //   Theano  (graphy/nodes/ar.py + dnn_conv conv_mode='conv', flipped kernel): taps look left/above, halo before
-    int tap_dh[NTAPS], tap_dw[NTAPS];
+    int tap_dh[MAXTAPS], tap_dw[MAXTAPS];
+    // EPI_PLAIN / NCHW staging extras: input = elu(concat(x[:, :c_split], x2)) (tf_train.py:36,52,87-88), residual for out0
+    const float* x2; int c_split; int in_elu; const float* res;
+    // EPI_PLAIN output: the channel split of tf_train.py:37,54 fused into the store.  Channels [split_end[k-1], split_end[k])
+    // go to the contiguous NCHW tensor split_ptr[k]; boundaries are multiples of 4 (one lane's 4 channels never straddle).
+    int nsplit; int split_end[MAXSPLIT]; float* split_ptr[MAXSPLIT];
     int halo_before;          // staged slots start at pixel P0 - halo_before
     const float* border;      // Theano pad_channel: [4][cout packed] weight of the border-indicator channel per non-centre tap
     unsigned long long* dbg;   // dev tool: per-workgroup s_memtime stamps [grid][8] (NULL in production)
@@ -102,7 +110,7 @@ __device__ __forceinline__ float elu_f(float v) { return v > 0.f ? v : __expf(v)
 //   D            : lane l holds D[co = tile*16 + 4*(l>>4) + r][pixel l&15], r = 0..3
 // K order inside a 16-channel chunk is permuted: k-slot kk owns channels 4kk..4kk+3, MFMA j of the chunk
 // consumes channel 4kk+j, so each operand is ONE 16-byte load per lane per 4 MFMAs.
-template <int NT, int PXT, int WCO, int KS, int INMODE, int EPI>
+template <int NT, int PXT, int WCO, int KS, int INMODE, int EPI, int NTP = NTAPS>
 __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) {
     extern __shared__ __attribute__((aligned(16))) f32x4 smem4[];
     constexpr int TM = 16 * PXT;
@@ -147,9 +155,10 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
     // slot consumed by step s-1 is refilled with step s+R-1, the loads interleaved between the MFMAs.  Hence the
     // prologue fetches R-1 steps.  Loop bodies are straight-line (static slots/taps, no branches) so that hipcc
     // emits COUNTED s_waitcnt vmcnt(N) and the ring really stays in flight.
-    constexpr int RCH_FULL = (NT >= 4) ? 2 : (NT == 3 ? 3 : (NT == 2 ? 4 : 8));
+    constexpr int RCH_FULL = (NTP == NTAPS) ? ((NT >= 4) ? 2 : (NT == 3 ? 3 : (NT == 2 ? 4 : 8)))
+                                            : ((NT >= 3) ? 1 : (NT == 2 ? 2 : 4));     // 9-tap chunks are 1.8x bigger
     constexpr int RCH = (NTHREADS > 256) ? (RCH_FULL + 1) / 2 : RCH_FULL;   // 2 waves/SIMD: half the registers each
-    constexpr int R = RCH * NTAPS;
+    constexpr int R = RCH * NTP;
     const size_t wstep = (size_t)p.ncot * 64;   // f32x4 per (chunk,tap) step
     const int c_begin = (kh * p.nchunk) / KS, c_end = ((kh + 1) * p.nchunk) / KS;
     const f32x4* wbase = (const f32x4*)p.wp + (size_t)cot0 * 64;   // wave-uniform; lane offset added per load
@@ -168,13 +177,13 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
 #else
     constexpr bool SHARED_W = false;
 #endif
-    constexpr int NTILE_CH = NTAPS * NT;                       // weight tiles per chunk
+    constexpr int NTILE_CH = NTP * NT;                       // weight tiles per chunk
     constexpr int NLD = (NTILE_CH + PXT - 1) / PXT;            // tiles fetched per wave per chunk
     f32x4 wr[SHARED_W ? 1 : R][NT];
     f32x4 sr[SHARED_W ? NLD : 1];
     f32x4* wlds = smem4 + (size_t)(p.nslot + 1) * cp4 + (size_t)(wave / PXT) * (2 * NTILE_CH * 64);   // this group's 2 buffers
     auto issue_stage = [&](int chunk) {       // my share of chunk's tiles -> registers (clamped index: branch-free)
-        const f32x4* q = wbase + (size_t)chunk * NTAPS * wstep;
+        const f32x4* q = wbase + (size_t)chunk * NTP * wstep;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             int f = pw + i * PXT;
@@ -195,12 +204,12 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
     auto ring_prologue = [&](auto i) {
         constexpr int I = decltype(i)::value;
         if (c_begin + I < c_end) {
-            const f32x4* q = wbase + (size_t)(c_begin + I) * NTAPS * wstep;
+            const f32x4* q = wbase + (size_t)(c_begin + I) * NTP * wstep;
 #pragma unroll
-            for (int tp = 0; tp < NTAPS; ++tp) {
-                if (I == RCH - 1 && tp == NTAPS - 1) continue;    // slot R-1 is filled by step 0
+            for (int tp = 0; tp < NTP; ++tp) {
+                if (I == RCH - 1 && tp == NTP - 1) continue;    // slot R-1 is filled by step 0
 #pragma unroll
-                for (int t = 0; t < NT; ++t) wr[I * NTAPS + tp][t] = (q + (size_t)tp * wstep)[ulane + t * 64];
+                for (int t = 0; t < NT; ++t) wr[I * NTP + tp][t] = (q + (size_t)tp * wstep)[ulane + t * 64];
             }
         }
     };
@@ -217,10 +226,10 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
     const bool pvalid = Pl < p.P;
     const int bimg = Pl / HW, pp = Pl - bimg * HW;
     const int h = pp / W, w = pp - h * W;
-    int xa[NTAPS];   // 16-byte offset into the LDS tile of this lane's 4 channels for each tap (chunk 0)
+    int xa[NTP];   // 16-byte offset into the LDS tile of this lane's 4 channels for each tap (chunk 0)
     unsigned outside = 0;   // bit t: tap t falls outside the image for this lane's pixel (Theano border channel)
 #pragma unroll
-    for (int t = 0; t < NTAPS; ++t) {
+    for (int t = 0; t < NTP; ++t) {
         const int dh = p.tap_dh[t], dw = p.tap_dw[t];
         const bool v = pvalid && (h + dh >= 0) && (h + dh < p.H) && (w + dw >= 0) && (w + dw < W);
         const int slot = pw * 16 + pl + dh * W + dw + p.halo_before;
@@ -264,8 +273,19 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
                             const int b = Pg / HW, ppx = Pg - b * HW;
                             const size_t gb = ((size_t)b * p.cin + 4 * q) * HW + ppx;
                             if (INMODE == IN_NCHW) {
+                                if (p.x2 && 4 * q >= p.c_split) {        // second tensor of a channel concat
+                                    const size_t g2 = ((size_t)b * (p.cin - p.c_split) + (4 * q - p.c_split)) * HW + ppx;
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) sv[u][r] = p.x[gb + (size_t)r * HW];
+                                    for (int r = 0; r < 4; ++r) sv[u][r] = p.x2[g2 + (size_t)r * HW];
+                                } else {
+                                    const size_t g1 = p.x2 ? ((size_t)b * p.c_split + 4 * q) * HW + ppx : gb;
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) sv[u][r] = p.x[g1 + (size_t)r * HW];
+                                }
+                                if (p.in_elu) {
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) sv[u][r] = elu_f(sv[u][r]);
+                                }
                             } else {   // z0 = (qm+rm) + exp(0.5*2*(ql+rl)) * eps   (tf_train.py:57,63; distributions.py:21)
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) {
@@ -304,7 +324,14 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
         for (int i = 0; i < NMY; ++i) {
             const int u = kh + i * KS;
             if (u >= NUNIT) continue;
-            if (EPI == EPI_DGRAD) {
+            if (EPI == EPI_PLAIN) {
+                pbias[i] = *(const f32x4*)(p.bias + (cot0 + u) * 16 + 4 * kk);
+                if (p.res) {
+                    const size_t cb = ((size_t)bimg * p.cout + (cot0 + u) * 16 + 4 * kk) * HW + pp;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pre0[i][r] = p.res[cb + (size_t)r * HW];
+                }
+            } else if (EPI == EPI_DGRAD) {
                 if (p.mode == MODE_DGRAD_ELU) {
                     pre0[i] = *(const f32x4*)(p.zin + (size_t)Pl * p.cout + (cot0 + u) * 16 + 4 * kk);
                 } else {
@@ -363,9 +390,9 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
             constexpr int MODE = decltype(mode_c)::value;
             const f32x4* wb = wlds + buf * (NTILE_CH * 64) + lane;
             read_ops(0, 0, chunk, wb);
-            static_for<NTAPS>([&](auto tp_c) {
+            static_for<NTP>([&](auto tp_c) {
                 constexpr int tp = decltype(tp_c)::value;
-                constexpr bool RD = (tp + 1 < NTAPS);
+                constexpr bool RD = (tp + 1 < NTP);
                 constexpr bool WR = (tp == 2 && MODE <= 1);
                 constexpr bool LDG = (tp == 2 && MODE == 0);
                 if constexpr (RD) read_ops((tp + 1) & 1, tp + 1, chunk, wb);
@@ -412,29 +439,29 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
         constexpr int I = decltype(slot_c)::value;
         constexpr bool RF_T4 = decltype(refill_t4)::value;    // step (chunk, 0) refills step (chunk+RCH-1, tap 4)
         constexpr bool RF_OWN = decltype(refill_own)::value;  // step (chunk, tp>=1) refills step (chunk+RCH, tp-1)
-        static_for<NTAPS>([&](auto tp_c) {
+        static_for<NTP>([&](auto tp_c) {
             constexpr int tp = decltype(tp_c)::value;
             const f32x4 xv = xn;
             // next step: tap tp+1 of this chunk, or tap 0 of the next chunk (a read past the last chunk stays inside
             // the padded row of the LDS tile and is never used)
-            xn = (tp + 1 < NTAPS) ? smem4[xa[(tp + 1) % NTAPS] + chunk * 4]
+            xn = (tp + 1 < NTP) ? smem4[xa[(tp + 1) % NTP] + chunk * 4]
                                   : smem4[xa[0] + (chunk + 1 < c_end ? chunk + 1 : chunk) * 4];
-            constexpr int PS = (I * NTAPS + tp + R - 1) % R;                  // slot consumed by the previous step
+            constexpr int PS = (I * NTP + tp + R - 1) % R;                  // slot consumed by the previous step
 #ifdef IAF_EXP_NOREFILL
             constexpr bool rf = false;
 #else
             constexpr bool rf = (tp == 0) ? RF_T4 : RF_OWN;
 #endif
-            const f32x4* q = wbase + ((size_t)chunk * NTAPS + tp + R - 1) * wstep;   // step s + R - 1
+            const f32x4* q = wbase + ((size_t)chunk * NTP + tp + R - 1) * wstep;   // step s + R - 1
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     const int a = (NT == 1) ? (j & 1) : t;
 #ifdef IAF_EXP_NOMFMA
-                    asm volatile("" ::"v"(wr[I * NTAPS + tp][t][j]), "v"(xv[j]));
+                    asm volatile("" ::"v"(wr[I * NTP + tp][t][j]), "v"(xv[j]));
 #else
-                    acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[I * NTAPS + tp][t][j], xv[j], acc[a], 0, 0, 0);
+                    acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[I * NTP + tp][t][j], xv[j], acc[a], 0, 0, 0);
 #endif
                 }
             }
@@ -529,7 +556,18 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
         for (int i = 0; i < NMY; ++i) {
             const int u = kh + i * KS;
             if (u >= NUNIT) continue;
-            if (EPI == EPI_DGRAD) {
+            if (EPI == EPI_PLAIN) {
+                const int co = (cot0 + u) * 16 + 4 * kk;
+                const f32x4 v = val[i] + pbias[i];
+                int c0 = 0, c1 = p.split_end[0];
+                float* base = p.split_ptr[0];
+#pragma unroll
+                for (int q = 1; q < MAXSPLIT; ++q)      // static indices only: the descriptor stays in SGPRs
+                    if (q < p.nsplit && co >= p.split_end[q - 1]) { c0 = p.split_end[q - 1]; c1 = p.split_end[q]; base = p.split_ptr[q]; }
+                float* dst = base + ((size_t)bimg * (c1 - c0) + (co - c0)) * HW + pp;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[(size_t)r * HW] = p.res ? pre0[i][r] + 0.1f * v[r] : v[r];
+            } else if (EPI == EPI_DGRAD) {
                 const int co = (cot0 + u) * 16 + 4 * kk;
                 f32x4 v = val[i];
                 if (p.mode == MODE_DGRAD_ELU) {
@@ -549,9 +587,9 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
             } else if (EPI == EPI_HIDDEN) {
                 const int co = (cot0 + u) * 16 + 4 * kk;
                 f32x4 v = val[i] + pbias[i];
-                if (p.border) {   // Theano pad_channel (conv.py:71-83, ar.py:229-233): taps that fall outside see a 1
+                if (NTP == NTAPS && p.border) {   // Theano pad_channel (conv.py:71-83, ar.py:229-233): taps that fall outside see a 1
 #pragma unroll
-                    for (int t = 1; t < NTAPS; ++t)
+                    for (int t = 1; t < NTP; ++t)
                         if (outside & (1u << t)) v += *(const f32x4*)(p.border + (size_t)(t - 1) * p.cout + co);
                 }
                 if (p.ctx) {   // x += context (layers.py:163-164); context = up_context + down_context (tf_train.py:58)
@@ -567,9 +605,9 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
                 const int c0 = (gt >> 1) * 16 + 4 * kk;
                 f32x4 bm = pbias[2 * i];
                 f32x4 bs = pbias[2 * i + 1];
-                if (p.border) {
+                if (NTP == NTAPS && p.border) {
 #pragma unroll
-                    for (int t = 1; t < NTAPS; ++t)
+                    for (int t = 1; t < NTP; ++t)
                         if (outside & (1u << t)) {
                             bm += *(const f32x4*)(p.border + (size_t)(t - 1) * p.cout + gt * 16 + 4 * kk);
                             bs += *(const f32x4*)(p.border + (size_t)(t - 1) * p.cout + (gt + 1) * 16 + 4 * kk);

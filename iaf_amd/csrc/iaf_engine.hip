@@ -36,7 +36,7 @@
 
 #include "iaf_conv_kernel.hpp"
 
-#define IAF_ABI_VERSION 1
+#define IAF_ABI_VERSION 2   // 2: + iaf_conv3x3_*
 #define MAX_GEMM_LAYERS 10   // depth_ar <= 9 hidden + 1 output pair
 
 // ---------------------------------------------------------------------------------------------
@@ -75,7 +75,11 @@ struct PrepArgs {
     int nlayers;
 };
 
-template <int NCH>
+// filter position (kh,kw) of live tap t: the 5 MADE-live taps (centre, right, then the row below), or all 9 row-major
+template <int NTP> __device__ __forceinline__ int tap_kh(int t) { return NTP == 9 ? t / 3 : ((t == 0 || t == 1) ? 1 : 2); }
+template <int NTP> __device__ __forceinline__ int tap_kw(int t) { return NTP == 9 ? t % 3 : ((t == 0) ? 1 : (t == 1 ? 2 : t - 2)); }
+
+template <int NCH, int NTP = NTAPS>
 __device__ __forceinline__ void prep_tile(const PrepLayer& L, int gt, float (*red)[17], float* s_scale) {
     const int which = (L.npair == 2) ? (gt & 1) : 0;     // output pair: even tiles = mean, odd = logsd
     const int src_tile = (L.npair == 2) ? (gt >> 1) : gt;
@@ -86,23 +90,21 @@ __device__ __forceinline__ void prep_tile(const PrepLayer& L, int gt, float (*re
     const float gval = L.g[which][o], bval = L.b[which][o];
 
     // pass 1: fetch + mask (layers.py:57), sum of squares over (taps, c_in) (layers.py:60)
-    float v[NTAPS][NCH];
+    float v[NTP][NCH];
 #pragma unroll
     for (int it = 0; it < NCH; ++it) {
         const int ci = cs + 16 * it;
 #pragma unroll
-        for (int t = 0; t < NTAPS; ++t) {
-            const int kh = (t == 0 || t == 1) ? 1 : 2;
-            const int kw = (t == 0) ? 1 : (t == 1 ? 2 : t - 2);
-            v[t][it] = V[((size_t)(kh * 3 + kw) * n_in + ci) * n_out + o];
+        for (int t = 0; t < NTP; ++t) {
+            v[t][it] = V[((size_t)(tap_kh<NTP>(t) * 3 + tap_kw<NTP>(t)) * n_in + ci) * n_out + o];
         }
     }
     float ss = 0.f;
 #pragma unroll
     for (int it = 0; it < NCH; ++it) {
-        if (!made_live(cs + 16 * it, o, n_in, n_out, L.zerodiag)) v[0][it] = 0.f;   // centre tap: channel MADE mask
+        if (NTP == NTAPS && !made_live(cs + 16 * it, o, n_in, n_out, L.zerodiag)) v[0][it] = 0.f;   // centre tap: channel MADE mask
 #pragma unroll
-        for (int t = 0; t < NTAPS; ++t) ss += v[t][it] * v[t][it];
+        for (int t = 0; t < NTP; ++t) ss += v[t][it] * v[t][it];
     }
     red[cs][oo] = ss;
     __syncthreads();
@@ -121,14 +123,14 @@ __device__ __forceinline__ void prep_tile(const PrepLayer& L, int gt, float (*re
 #pragma unroll
     for (int it = 0; it < NCH; ++it)
 #pragma unroll
-        for (int t = 0; t < NTAPS; ++t)
-            L.wp[((((size_t)it * NTAPS + t) * L.ncot + gt) * 64 + kk * 16 + oo) * 4 + jj] = v[t][it] * scale;
+        for (int t = 0; t < NTP; ++t)
+            L.wp[((((size_t)it * NTP + t) * L.ncot + gt) * 64 + kk * 16 + oo) * 4 + jj] = v[t][it] * scale;
     if (L.wpt) {   // dgrad operand: K runs over the packed output channels (chunk = gt), N over input tiles (it)
 #pragma unroll
         for (int it = 0; it < NCH; ++it)
 #pragma unroll
-            for (int t = 0; t < NTAPS; ++t)
-                L.wpt[((((size_t)gt * NTAPS + t) * NCH + it) * 64 + (oo >> 2) * 16 + cs) * 4 + (oo & 3)] = v[t][it] * scale;
+            for (int t = 0; t < NTP; ++t)
+                L.wpt[((((size_t)gt * NTP + t) * NCH + it) * 64 + (oo >> 2) * 16 + cs) * 4 + (oo & 3)] = v[t][it] * scale;
     }
 }
 
@@ -200,8 +202,30 @@ __device__ __forceinline__ void prep_tile_theano(const PrepLayer& L, int gt, flo
 }
 
 #define PREP_MAXI 16   // n_in <= 256
+#define PREP_PLAIN9 100   // PrepLayer.variant of a plain (unmasked, 9-tap) TF conv2d
 template <int DUMMY = 0>
 __device__ __forceinline__ void prep_dispatch(const PrepLayer& L, int gt, float (*red)[17], float* s_scale) {
+    if (L.variant == PREP_PLAIN9) {   // unmasked 3x3 (layers.py:52-64 with mask=None)
+        switch (L.nchunk) {
+            case 1: prep_tile<1, MAXTAPS>(L, gt, red, s_scale); break;
+            case 2: prep_tile<2, MAXTAPS>(L, gt, red, s_scale); break;
+            case 3: prep_tile<3, MAXTAPS>(L, gt, red, s_scale); break;
+            case 4: prep_tile<4, MAXTAPS>(L, gt, red, s_scale); break;
+            case 5: prep_tile<5, MAXTAPS>(L, gt, red, s_scale); break;
+            case 6: prep_tile<6, MAXTAPS>(L, gt, red, s_scale); break;
+            case 7: prep_tile<7, MAXTAPS>(L, gt, red, s_scale); break;
+            case 8: prep_tile<8, MAXTAPS>(L, gt, red, s_scale); break;
+            case 9: prep_tile<9, MAXTAPS>(L, gt, red, s_scale); break;
+            case 10: prep_tile<10, MAXTAPS>(L, gt, red, s_scale); break;
+            case 11: prep_tile<11, MAXTAPS>(L, gt, red, s_scale); break;
+            case 12: prep_tile<12, MAXTAPS>(L, gt, red, s_scale); break;
+            case 13: prep_tile<13, MAXTAPS>(L, gt, red, s_scale); break;
+            case 14: prep_tile<14, MAXTAPS>(L, gt, red, s_scale); break;
+            case 15: prep_tile<15, MAXTAPS>(L, gt, red, s_scale); break;
+            case 16: prep_tile<16, MAXTAPS>(L, gt, red, s_scale); break;
+        }
+        return;
+    }
     if (L.variant == IAF_VARIANT_THEANO) {
         switch (L.nchunk) {
             case 1: prep_tile_theano<1>(L, gt, red, s_scale); break;
@@ -698,6 +722,7 @@ struct GenPrepLayer {
     float* w;        // effective weights [NTAPS][cin][cout_total]
     float* bias;     // [cout_total]
     int cin, cout_each, npair, zerodiag, ch_begin;
+    int ntaps;       // 5 = MADE-masked (default when 0), 9 = plain unmasked conv2d
 };
 struct GenPrepArgs { GenPrepLayer L[MAX_GEMM_LAYERS]; int nlayers; };
 
@@ -711,11 +736,13 @@ __global__ __launch_bounds__(256) void iaf_generic_prep_kernel(GenPrepArgs a) {
     const int which = oc / L.cout_each, o = oc - which * L.cout_each;
     const float* V = L.V[which];
     const int n_in = L.cin, n_out = L.cout_each, ctot = L.cout_each * L.npair;
+    const bool full = (L.ntaps == MAXTAPS);
+    const int ntaps = full ? MAXTAPS : NTAPS;
     float ss = 0.f;
-    for (int e = threadIdx.x; e < NTAPS * n_in; e += 256) {
+    for (int e = threadIdx.x; e < ntaps * n_in; e += 256) {
         const int t = e / n_in, ci = e - t * n_in;
-        const int kh = (t == 0 || t == 1) ? 1 : 2, kw = (t == 0) ? 1 : (t == 1 ? 2 : t - 2);
-        const bool live = (t != 0) || made_live(ci, o, n_in, n_out, L.zerodiag);
+        const int kh = full ? t / 3 : ((t == 0 || t == 1) ? 1 : 2), kw = full ? t % 3 : ((t == 0) ? 1 : (t == 1 ? 2 : t - 2));
+        const bool live = full || (t != 0) || made_live(ci, o, n_in, n_out, L.zerodiag);
         const float v = live ? V[((size_t)(kh * 3 + kw) * n_in + ci) * n_out + o] : 0.f;
         ss += v * v;
     }
@@ -726,10 +753,10 @@ __global__ __launch_bounds__(256) void iaf_generic_prep_kernel(GenPrepArgs a) {
         __syncthreads();
     }
     const float scale = expf(L.g[which][o]) / sqrtf(fmaxf(red[0], 1e-12f));      // layers.py:60
-    for (int e = threadIdx.x; e < NTAPS * n_in; e += 256) {
+    for (int e = threadIdx.x; e < ntaps * n_in; e += 256) {
         const int t = e / n_in, ci = e - t * n_in;
-        const int kh = (t == 0 || t == 1) ? 1 : 2, kw = (t == 0) ? 1 : (t == 1 ? 2 : t - 2);
-        const bool live = (t != 0) || made_live(ci, o, n_in, n_out, L.zerodiag);
+        const int kh = full ? t / 3 : ((t == 0 || t == 1) ? 1 : 2), kw = full ? t % 3 : ((t == 0) ? 1 : (t == 1 ? 2 : t - 2));
+        const bool live = full || (t != 0) || made_live(ci, o, n_in, n_out, L.zerodiag);
         L.w[((size_t)t * n_in + ci) * ctot + oc] = live ? V[((size_t)(kh * 3 + kw) * n_in + ci) * n_out + o] * scale : 0.f;
     }
     if (threadIdx.x == 0) L.bias[oc] = L.b[which][o];
@@ -794,6 +821,44 @@ __global__ __launch_bounds__(256) void iaf_generic_conv_kernel(GenConvP p) {
     }
 }
 
+// plain 3x3 SAME conv, generic channel counts: y = conv(elu?(concat(x, x2)), w) + b  [-> res + 0.1*y], output channels
+// scattered to the split tensors.  One thread per output element.
+struct GenPlainP {
+    const float* x; const float* x2; const float* w; const float* bias; const float* res;
+    int B, H, W, cin, cout, c_split, in_elu, nsplit;
+    int split_end[MAXSPLIT]; float* split_ptr[MAXSPLIT];
+};
+
+__global__ __launch_bounds__(256) void iaf_generic_conv3x3_kernel(GenPlainP p) {
+    const size_t HW = (size_t)p.H * p.W;
+    const size_t total = (size_t)p.B * p.cout * HW;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ww = (int)(i % p.W);
+        const int hh = (int)((i / p.W) % p.H);
+        const int co = (int)((i / HW) % p.cout);
+        const int b = (int)(i / (HW * p.cout));
+        float acc = 0.f;
+        for (int t = 0; t < MAXTAPS; ++t) {
+            const int h2 = hh + t / 3 - 1, w2 = ww + t % 3 - 1;
+            if (h2 < 0 || h2 >= p.H || w2 < 0 || w2 >= p.W) continue;
+            const float* wt = p.w + (size_t)t * p.cin * p.cout;
+            for (int ci = 0; ci < p.cin; ++ci) {
+                float xv;
+                if (p.x2 && ci >= p.c_split) xv = p.x2[(((size_t)b * (p.cin - p.c_split) + (ci - p.c_split)) * p.H + h2) * p.W + w2];
+                else xv = p.x[(((size_t)b * (p.x2 ? p.c_split : p.cin) + ci) * p.H + h2) * p.W + w2];
+                if (p.in_elu) xv = elu_f(xv);
+                acc = fmaf(xv, wt[(size_t)ci * p.cout + co], acc);
+            }
+        }
+        const float v = acc + p.bias[co];
+        int k = 0;
+        while (k + 1 < p.nsplit && co >= p.split_end[k]) ++k;
+        const int c0 = k ? p.split_end[k - 1] : 0;
+        const size_t o = (((size_t)b * (p.split_end[k] - c0) + (co - c0)) * p.H + hh) * p.W + ww;
+        p.split_ptr[k][o] = p.res ? p.res[i] + 0.1f * v : v;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side: stack object
 // ---------------------------------------------------------------------------------------------
@@ -811,6 +876,7 @@ struct GemmLayer {
     // launch shape: fixed by iaf_stack_set_tuning (user_tuned) or chosen per problem size by auto_shape()
     int nt, pxt, wco, ks;
     bool user_tuned = false;
+    bool full3x3 = false;      // plain 9-tap conv (iaf_conv3x3): halo on both sides of the pixel tile
     double live_macs_per_px, dense_macs_per_px;
 };
 
@@ -862,7 +928,7 @@ static conv_fn_t pick_kernel(int nt, int pxt, int wco, int ks, int inmode, int e
 }
 
 static size_t conv_lds_bytes(const GemmLayer& L, int W) {
-    const int tm = 16 * L.pxt, nslot = tm + W + 1, cp = L.cin + 8;
+    const int tm = 16 * L.pxt, nslot = tm + (L.full3x3 ? 2 : 1) * (W + 1), cp = L.cin + 8;
     size_t fl = (size_t)(nslot + 1) * cp;
     size_t wbuf = 0, red = 0;
 #if defined(IAF_SHARED_W) && IAF_SHARED_W
@@ -1233,7 +1299,7 @@ static void auto_shape(GemmLayer& L, bool is_out, long long P, int W) {
             if (conv_lds_bytes(t, W) > 160 * 1024) continue;
             const double wgs = (double)((P + 16 * pxt - 1) / (16 * pxt)) * (L.ncot / (nt * wco));
             const double rounds = ceil(wgs / 256.0);
-            const double cyc_wave = (5.0 * L.nchunk / ks) * nt * 128.0;
+            const double cyc_wave = ((L.full3x3 ? 9.0 : 5.0) * L.nchunk / ks) * nt * 128.0;
             const double waves = pxt * wco * ks;
             const double cyc_wg = cyc_wave * ceil(waves / 4.0);
             const double T = rounds * (cyc_wg + 6000.0) + 400.0 * (ks - 1) + 1e-3 * si - 1e-2 * nt;
@@ -1241,6 +1307,19 @@ static void auto_shape(GemmLayer& L, bool is_out, long long P, int W) {
         }
     }
     if (bs >= 0) { L.nt = bnt; L.pxt = k_shapes[bs][0]; L.wco = k_shapes[bs][1]; L.ks = k_shapes[bs][2]; }
+}
+
+// raise the dynamic-LDS cap once per kernel (never inside a stream capture: warm up first)
+static int raise_lds_cap(conv_fn_t fn, size_t lds) {
+    if (lds <= 48 * 1024) return 0;
+    static std::mutex mu;
+    static std::unordered_set<const void*> done;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!done.count((const void*)fn)) {
+        HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        done.insert((const void*)fn);
+    }
+    return 0;
 }
 
 // launches the conv kernel for GEMM descriptor L (forward layer, or a transposed descriptor for dgrad)
@@ -1264,15 +1343,7 @@ static int launch_gemm(const iaf_stack_t* s, GemmLayer& L, int epi, bool negate_
     p.dbg = (prof_id >= 0 && s->dbg_layer == prof_id) ? s->dbg : nullptr;
     const size_t lds = conv_lds_bytes(L, p.W);
     if (lds > 160 * 1024) return IAF_ERR_UNSUPPORTED;
-    if (lds > 48 * 1024) {   // raise the dynamic-LDS cap once per kernel (never inside a stream capture)
-        static std::mutex mu;
-        static std::unordered_set<const void*> done;
-        std::lock_guard<std::mutex> lk(mu);
-        if (!done.count((const void*)fn)) {
-            HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            done.insert((const void*)fn);
-        }
-    }
+    { int rc = raise_lds_cap(fn, lds); if (rc) return rc; }
     dim3 grid((p.P + tm - 1) / tm, L.ncot / (L.nt * L.wco));
     const bool prof = (prof_id >= 0 && s->prof_layer == prof_id && s->prof_n < s->prof_cap);
     iaf_stack* ms = const_cast<iaf_stack*>(s);
@@ -1870,5 +1941,154 @@ extern "C" int iaf_step_work(const iaf_stack_t* s, int B, int H, int W, double* 
     if (dense_flops) *dense_flops = 2.0 * dense * px;
     // fused algorithmic bytes: z in, context in, z out, s out + raw weights once
     if (bytes) *bytes = 4.0 * (3.0 * s->n_z + (s->depth_ar > 0 ? s->n_h : 0)) * px + (double)s->weight_bytes;
+    return IAF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// plain weight-normed 3x3 convs around the IAF step: up_conv1 / up_conv3 / down_conv1 / down_conv2
+// (tf_train.py:36-44, 52-54, 87-94; operator tf_utils/layers.py:31-64 with mask=None, stride 1, pad SAME).
+// Same implicit-GEMM kernel as the masked stack with all 9 taps live (template NTP = 9) and the EPI_PLAIN epilogue:
+// ELU / channel concat fused into the input staging, channel split / residual fused into the store.
+// ---------------------------------------------------------------------------------------------
+struct iaf_conv3x3 {
+    int n_in, n_out;
+    bool generic, prepared;
+    GemmLayer L;
+};
+
+extern "C" int iaf_conv3x3_destroy(iaf_conv3x3_t* c) {
+    if (!c) return IAF_ERR_NULL;
+    if (c->L.wp) (void)hipFree(c->L.wp);
+    if (c->L.bias) (void)hipFree(c->L.bias);
+    delete c;
+    return IAF_OK;
+}
+
+extern "C" int iaf_conv3x3_create(iaf_conv3x3_t** out, int n_in, int n_out) {
+    if (!out) return IAF_ERR_NULL;
+    *out = nullptr;
+    if (n_in <= 0 || n_out <= 0) return IAF_ERR_SHAPE;
+    iaf_conv3x3* c = new (std::nothrow) iaf_conv3x3();
+    if (!c) return (int)hipErrorOutOfMemory;
+    c->n_in = n_in; c->n_out = n_out; c->prepared = false;
+    c->generic = (n_in % 16 != 0 || n_out % 16 != 0 || n_in > 16 * PREP_MAXI);
+    GemmLayer& L = c->L;
+    L.cin = n_in; L.cout = n_out; L.npair = 1; L.zerodiag = 0; L.full3x3 = true;
+    L.nchunk = (n_in + 15) / 16; L.ncot = (n_out + 15) / 16;
+    default_tuning(L, false);
+    L.live_macs_per_px = L.dense_macs_per_px = 9.0 * n_in * n_out;
+    const size_t wfloats = c->generic ? (size_t)MAXTAPS * n_in * n_out : (size_t)L.nchunk * MAXTAPS * L.ncot * 256;
+    int rc;
+    if ((rc = (int)hipMalloc(&L.wp, wfloats * sizeof(float))) != 0 ||
+        (rc = (int)hipMalloc(&L.bias, (size_t)L.ncot * 16 * sizeof(float))) != 0) {
+        iaf_conv3x3_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return IAF_OK;
+}
+
+extern "C" int iaf_conv3x3_prepare(iaf_conv3x3_t* c, const float* V, const float* g, const float* b, void* stream) {
+    if (!c || !V || !g || !b) return IAF_ERR_NULL;
+    const GemmLayer& L = c->L;
+    if (c->generic) {
+        GenPrepArgs ga;
+        memset(&ga, 0, sizeof(ga));
+        ga.nlayers = 1;
+        GenPrepLayer& P = ga.L[0];
+        P.V[0] = V; P.g[0] = g; P.b[0] = b; P.w = L.wp; P.bias = L.bias;
+        P.cin = L.cin; P.cout_each = L.cout; P.npair = 1; P.zerodiag = 0; P.ch_begin = 0; P.ntaps = MAXTAPS;
+        hipLaunchKernelGGL(iaf_generic_prep_kernel, dim3(L.cout), dim3(256), 0, (hipStream_t)stream, ga);
+    } else {
+        PrepArgs a;
+        memset(&a, 0, sizeof(a));
+        a.nlayers = 1;
+        PrepLayer& P = a.L[0];
+        P.V[0] = V; P.g[0] = g; P.b[0] = b; P.wp = L.wp; P.bias = L.bias; P.variant = PREP_PLAIN9;
+        P.cin = L.cin; P.cout_each = L.cout; P.ncot = L.ncot; P.nchunk = L.nchunk; P.npair = 1; P.tile_begin = 0;
+        hipLaunchKernelGGL(iaf_prep_kernel, dim3(L.ncot), dim3(256), 0, (hipStream_t)stream, a);
+    }
+    HIP_TRY(hipGetLastError());
+    c->prepared = true;
+    return IAF_OK;
+}
+
+extern "C" int iaf_conv3x3_set_tuning(iaf_conv3x3_t* c, int nt, int pxt, int wco, int ks) {
+    if (!c) return IAF_ERR_NULL;
+    GemmLayer& L = c->L;
+    if (nt == 0) { L.user_tuned = false; return IAF_OK; }     // back to the automatic choice
+    if (c->generic || !pick_kernel(nt, pxt, wco, ks, IN_NCHW, EPI_PLAIN)) return IAF_ERR_UNSUPPORTED;
+    if (L.ncot % (nt * wco) != 0 || L.nchunk < ks) return IAF_ERR_UNSUPPORTED;
+    L.nt = nt; L.pxt = pxt; L.wco = wco; L.ks = ks; L.user_tuned = true;
+    return IAF_OK;
+}
+
+extern "C" int iaf_conv3x3_forward(iaf_conv3x3_t* c, const float* x, const float* x2, int c_split, int elu_input,
+                                   const float* residual, float* const* outs, const int* out_channels, int n_outs, int B,
+                                   int H, int W, void* stream) {
+    if (!c || !x || !outs || !out_channels) return IAF_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0 || n_outs < 1 || n_outs > MAXSPLIT) return IAF_ERR_SHAPE;
+    if ((long long)B * H * W > (1LL << 30) / 64) return IAF_ERR_SHAPE;
+    if (!c->prepared) return IAF_ERR_NOT_PREPARED;
+    if (x2 && (c_split <= 0 || c_split >= c->n_in)) return IAF_ERR_SHAPE;
+    if (residual && n_outs != 1) return IAF_ERR_SHAPE;
+    int tot = 0, ends[MAXSPLIT];
+    for (int k = 0; k < n_outs; ++k) {
+        if (!outs[k]) return IAF_ERR_NULL;
+        if (out_channels[k] <= 0) return IAF_ERR_SHAPE;
+        tot += out_channels[k];
+        ends[k] = tot;
+    }
+    if (tot != c->n_out) return IAF_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    GemmLayer& L = c->L;
+    if (c->generic) {
+        GenPlainP p;
+        memset(&p, 0, sizeof(p));
+        p.x = x; p.x2 = x2; p.w = L.wp; p.bias = L.bias; p.res = residual;
+        p.B = B; p.H = H; p.W = W; p.cin = L.cin; p.cout = L.cout; p.c_split = c_split; p.in_elu = elu_input ? 1 : 0;
+        p.nsplit = n_outs;
+        for (int k = 0; k < n_outs; ++k) { p.split_end[k] = ends[k]; p.split_ptr[k] = outs[k]; }
+        hipLaunchKernelGGL(iaf_generic_conv3x3_kernel, ew_grid((size_t)B * L.cout * H * W), dim3(256), 0, st, p);
+        return (int)hipGetLastError();
+    }
+    // MFMA path: a lane owns 4 consecutive channels, so the concat point and the split points must be multiples of 4
+    if (x2 && (c_split & 3)) return IAF_ERR_UNSUPPORTED;
+    for (int k = 0; k < n_outs; ++k)
+        if (ends[k] & 3) return IAF_ERR_UNSUPPORTED;
+    ConvP p;
+    memset(&p, 0, sizeof(p));
+    p.B = B; p.H = H; p.W = W; p.HW = H * W; p.P = B * H * W;
+    p.x = x; p.x2 = x2; p.c_split = c_split; p.in_elu = elu_input ? 1 : 0; p.res = residual;
+    p.nsplit = n_outs;
+    for (int k = 0; k < MAXSPLIT; ++k) {
+        p.split_end[k] = ends[k < n_outs ? k : n_outs - 1];
+        p.split_ptr[k] = outs[k < n_outs ? k : n_outs - 1];
+    }
+    if (!L.user_tuned) auto_shape(L, false, p.P, W);
+    conv_fn_t fn = pick_kernel(L.nt, L.pxt, L.wco, L.ks, IN_NCHW, EPI_PLAIN);
+    if (!fn) return IAF_ERR_UNSUPPORTED;
+    const int tm = 16 * L.pxt;
+    p.wp = L.wp; p.bias = L.bias; p.lim = nullptr;
+    for (int t = 0; t < MAXTAPS; ++t) { p.tap_dh[t] = t / 3 - 1; p.tap_dw[t] = t % 3 - 1; }   // cross-correlation, SAME
+    p.halo_before = W + 1;
+    p.cin = L.cin; p.cout = L.cout; p.nchunk = L.nchunk; p.ncot = L.ncot;
+    p.cp = L.cin + 8;
+    p.nslot = tm + 2 * (W + 1);
+    const size_t lds = conv_lds_bytes(L, W);
+    if (lds > 160 * 1024) return IAF_ERR_UNSUPPORTED;
+    int rc = raise_lds_cap(fn, lds);
+    if (rc) return rc;
+    dim3 grid((p.P + tm - 1) / tm, L.ncot / (L.nt * L.wco));
+    hipLaunchKernelGGL(fn, grid, dim3(64 * L.pxt * L.wco * L.ks), lds, st, p);
+    return (int)hipGetLastError();
+}
+
+extern "C" int iaf_conv3x3_work(const iaf_conv3x3_t* c, int B, int H, int W, double* flops, double* bytes) {
+    if (!c) return IAF_ERR_NULL;
+    const double P = (double)B * H * W;
+    if (flops) *flops = 2.0 * 9.0 * c->n_in * c->n_out * P;
+    // input + output activations once, raw V/g/b once
+    if (bytes) *bytes = 4.0 * (P * (c->n_in + c->n_out) + 9.0 * c->n_in * c->n_out + 2.0 * c->n_out);
     return IAF_OK;
 }

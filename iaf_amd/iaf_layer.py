@@ -3,7 +3,7 @@
 The two convolutions around it (down_conv1 / down_conv2, tf_train.py:53,93) are outside this
 path; the boundary is the channel split of down_conv1's output
 (tf_train.py:54) and the stored up-pass tensors (tf_train.py:38)."""
-from .layers import ARStack
+from .layers import ARStack, WNConv2d
 
 
 class IAFPosterior(object):
@@ -26,3 +26,49 @@ class IAFPosterior(object):
         """Returns dict(z, kl_obj, kl_cost): the values tf_train.py:85-87 hand to the rest of down()."""
         return self.stack.posterior_block(self.qz_mean, self.qz_logsd, rz_mean, rz_logsd, pz_mean, pz_logsd,
                                           self.up_context, down_context, eps, self.kl_min, want_kl_elem)
+
+
+class IAFLayer(object):
+    """tf_train.IAFLayer (tf_train.py:23-95) at a non-downsampling level, mode "train", entirely on the GPU:
+
+        up():   elu -> up_conv1 -> split(qz_mean, qz_logsd, up_context, h) -> elu -> up_conv3 -> input + 0.1*h
+        down(): elu -> down_conv1 -> split(pz_mean, pz_logsd, rz_mean, rz_logsd, down_context, h_det)
+                -> posterior sample -> IAF step -> KL / free bits -> elu(concat(z, h_det)) -> down_conv2 -> input + 0.1*h
+
+    Six launches per down() (down_conv1, depth_ar+1 masked convs, 2 KL reductions, down_conv2) and two per up(); every
+    ELU / split / concat / residual of the reference graph is fused into a conv's staging or store.  The sampling
+    noise `eps` is an input (the reference draws it inside DiagonalGaussian.sample, distributions.py:21-24)."""
+
+    def __init__(self, z_size, h_size, depth_ar=2, kl_min=0.25, downsample=False):
+        if downsample:
+            raise ValueError("the gfx950 engine covers the non-downsampling IAFLayer (stride-1 convs) only")
+        self.z_size, self.h_size, self.kl_min = int(z_size), int(h_size), float(kl_min)
+        zs, hs = self.z_size, self.h_size
+        self.up_conv1 = WNConv2d(hs, 2 * zs + 2 * hs)      # tf_train.py:36
+        self.up_conv3 = WNConv2d(hs, hs)                   # :41
+        self.down_conv1 = WNConv2d(hs, 4 * zs + 2 * hs)    # :53
+        self.down_conv2 = WNConv2d(hs + zs, hs)            # :93
+        self.posterior = IAFPosterior(zs, hs, depth_ar, kl_min)
+
+    def load(self, params):
+        """params: {"up_conv1/V": ..., "ar_multiconv2d/layer_0/V": ..., "down_conv2/b": ...} device fp32 tensors."""
+        for nm in ("up_conv1", "up_conv3", "down_conv1", "down_conv2"):
+            getattr(self, nm).prepare(params[nm + "/V"], params[nm + "/g"], params[nm + "/b"])
+        pre = "ar_multiconv2d/"
+        self.posterior.load({k[len(pre):]: v for k, v in params.items() if k.startswith(pre)})
+
+    def up(self, inp):
+        zs, hs = self.z_size, self.h_size
+        qz_mean, qz_logsd, up_context, h = self.up_conv1(inp, elu_input=True, split=[zs, zs, hs, hs])     # :35-37
+        self.posterior.set_up_state(qz_mean, qz_logsd, up_context)                                        # :38
+        return self.up_conv3(h, elu_input=True, residual=inp)[0]                                          # :40-44
+
+    def down(self, inp, eps):
+        """Returns (output, kl_obj, kl_cost) like tf_train.py:95."""
+        zs, hs = self.z_size, self.h_size
+        pz_mean, pz_logsd, rz_mean, rz_logsd, down_context, h_det = self.down_conv1(
+            inp, elu_input=True, split=[zs] * 4 + [hs] * 2)                                               # :52-54
+        blk = self.posterior.down(pz_mean, pz_logsd, rz_mean, rz_logsd, down_context, eps)                # :56-85
+        out = self.down_conv2(blk["z"], x2=h_det, elu_input=True, residual=inp)[0]                        # :87-94
+        self.last_block = blk
+        return out, blk["kl_obj"], blk["kl_cost"]

@@ -379,6 +379,92 @@ class ARStack(object):
         return out
 
 
+class WNConv2d(object):
+    """One plain weight-normed 3x3 conv (tf_utils/layers.py:31-64, mask=None, stride (1,1), pad SAME) bound to an
+    engine handle (iaf_conv3x3_t).  The elementwise work the reference wraps around it in IAFLayer
+    (tf_train.py:35-44, 52-54, 87-94) is fused into the call: ELU on the input, channel concat of two inputs,
+    channel split of the output, and the residual `res + 0.1*y`."""
+
+    def __init__(self, n_in, n_out):
+        self.n_in, self.n_out = int(n_in), int(n_out)
+        self._h = ctypes.c_void_p()
+        _capi.check(_capi.lib().iaf_conv3x3_create(ctypes.byref(self._h), self.n_in, self.n_out))
+        self._prep_key = None
+        self._keepalive = None
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                _capi.lib().iaf_conv3x3_destroy(h)
+            except Exception:
+                pass
+
+    def prepare(self, V, g, b, force=False):
+        """V HWIO [3,3,n_in,n_out], g/b [n_out] (layers.py:53-55); cached until a tensor is replaced or modified."""
+        _check_act(V, "V", (3, 3, self.n_in, self.n_out))
+        _check_act(g, "g", (self.n_out,))
+        _check_act(b, "b", (self.n_out,))
+        key = tuple((t.data_ptr(), t._version) for t in (V, g, b))
+        if not force and key == self._prep_key:
+            return
+        _capi.check(_capi.lib().iaf_conv3x3_prepare(self._h, _ptr(V), _ptr(g), _ptr(b), _stream()))
+        self._prep_key, self._keepalive = key, (V, g, b)
+
+    def set_tuning(self, nt, pxt, wco, ks):
+        _capi.check(_capi.lib().iaf_conv3x3_set_tuning(self._h, nt, pxt, wco, ks))
+
+    def work(self, B, H, W):
+        fl, by = ctypes.c_double(), ctypes.c_double()
+        _capi.check(_capi.lib().iaf_conv3x3_work(self._h, B, H, W, ctypes.byref(fl), ctypes.byref(by)))
+        return fl.value, by.value
+
+    def __call__(self, x, x2=None, elu_input=False, split=None, residual=None, out=None):
+        """x [B,c,H,W] (+ optional x2 [B,n_in-c,H,W], concatenated along channels).  Returns the list of split
+        tensors (`split` = channel counts, default [n_out]) or, with `residual`, the single tensor
+        residual + 0.1*y."""
+        _check_act(x, "x")
+        B, c1, H, W = x.shape
+        c_split = 0
+        if x2 is not None:
+            _check_act(x2, "x2", (B, self.n_in - c1, H, W))
+            c_split = c1
+        elif c1 != self.n_in:
+            raise ValueError("x has %d channels, expected %d" % (c1, self.n_in))
+        split = [self.n_out] if split is None else [int(v) for v in split]
+        if sum(split) != self.n_out:
+            raise ValueError("split %r does not sum to %d" % (split, self.n_out))
+        if residual is not None:
+            _check_act(residual, "residual", (B, self.n_out, H, W))
+        if out is None:
+            out = [torch.empty((B, c, H, W), device=x.device, dtype=torch.float32) for c in split]
+        for o, c in zip(out, split):
+            _check_act(o, "out", (B, c, H, W))
+        n = len(split)
+        outs = (ctypes.c_void_p * n)(*[o.data_ptr() for o in out])
+        chans = (ctypes.c_int * n)(*split)
+        _capi.check(_capi.lib().iaf_conv3x3_forward(self._h, _ptr(x), _ptr(x2), c_split, 1 if elu_input else 0,
+                                                    _ptr(residual), outs, chans, n, B, H, W, _stream()))
+        return out
+
+
+def conv2d(name, x, num_filters, filter_size=(3, 3), stride=(1, 1), pad="SAME", init=False, mask=None, store=None,
+           **_):
+    """Drop-in for tf_utils/layers.py:31-64 (non-init branch) for the shape IAFLayer uses at its non-downsampling
+    levels: 3x3, stride 1, SAME, no mask.  Variables <scope>/<name>/{V,g,b} come from `store`."""
+    if tuple(filter_size) != (3, 3) or tuple(stride) != (1, 1) or pad != "SAME" or mask is not None or init:
+        raise ValueError("the gfx950 engine implements conv2d for filter 3x3, stride 1, SAME, mask=None, init=False")
+    st = store or _DEFAULT_STORE
+    n_in = int(x.shape[1])
+    with variable_scope(name, st):
+        key = ("conv2d", st.full_name(""), n_in, int(num_filters))
+        conv = st._stacks.get(key)
+        if conv is None:
+            conv = st._stacks[key] = WNConv2d(n_in, num_filters)
+        conv.prepare(st.get("V"), st.get("g"), st.get("b"))
+    return conv(x)[0]
+
+
 class PrepBatch(object):
     """Weight prep (mask, l2-normalise, exp(g), repack) for MANY stacks in one launch -- what a model does once at
     the start of every step (the reference re-derives the normalised weights inside every conv2d call,

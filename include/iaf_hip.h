@@ -195,6 +195,35 @@ int iaf_step_work(const iaf_stack_t* s, int B, int H, int W, double* live_flops,
 int iaf_layer_work(const iaf_stack_t* s, int layer, int B, int H, int W, double* live_flops, double* dense_flops,
                    double* bytes);
 
+/* ------------------------------------------------------------------------------------------
+ * Plain weight-normed 3x3 convs either side of the IAF step: IAFLayer's up_conv1 / up_conv3 /
+ * down_conv1 / down_conv2, i.e. tf_utils/layers.py:31-64 (conv2d, mask=None, stride (1,1), pad SAME, non-init
+ * branch) as called from tf_train.py:36-44, 52-54, 87-94 with the surrounding elementwise work fused:
+ *   in  = concat_channels(x, x2)            (x2 optional; tf_train.py:87 h = concat(1, [z, h_det]))
+ *   in  = elu(in) if elu_input               (tf_train.py:35,40,52,88)
+ *   y   = conv2d(in, exp(g) * l2_normalize(V, [0,1,2])) + b                       (layers.py:60-64)
+ *   n_outs == 1 and residual:  outs[0] = residual + 0.1 * y                       (tf_train.py:44,94)
+ *   otherwise:  outs[k] = channels [sum(out_channels[:k]), +out_channels[k]) of y (the split of tf_train.py:37,54)
+ * All tensors are contiguous NCHW fp32 device memory.  V is HWIO [3,3,n_in,n_out]; g, b are [n_out].
+ * Channel counts that are multiples of 16 run on the MFMA kernel (concat / split points must then be multiples of 4,
+ * else IAF_ERR_UNSUPPORTED); any other counts run on a direct-conv fallback.  The downsampling variants (stride 2,
+ * deconv2d, resize_nearest_neighbor) are not covered.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct iaf_conv3x3 iaf_conv3x3_t;
+#define IAF_CONV3X3_MAX_OUTS 6
+
+int iaf_conv3x3_create(iaf_conv3x3_t** out, int n_in, int n_out);
+int iaf_conv3x3_destroy(iaf_conv3x3_t* c);
+/* weight normalisation + packing (one launch); call again whenever V/g/b change */
+int iaf_conv3x3_prepare(iaf_conv3x3_t* c, const float* V, const float* g, const float* b, void* stream);
+int iaf_conv3x3_forward(iaf_conv3x3_t* c, const float* x, const float* x2, int c_split, int elu_input,
+                        const float* residual, float* const* outs, const int* out_channels, int n_outs, int B, int H,
+                        int W, void* stream);
+/* launch shape override (nt = 0 restores the automatic choice); see iaf_stack_set_tuning */
+int iaf_conv3x3_set_tuning(iaf_conv3x3_t* c, int nt, int pxt, int wco, int ks);
+/* FLOPs (2*9*n_in*n_out per pixel) and minimum bytes (activations in+out, V/g/b once) of one forward call */
+int iaf_conv3x3_work(const iaf_conv3x3_t* c, int B, int H, int W, double* flops, double* bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,190 @@
+"""GPU parity tests for the widened path: the plain weight-normed 3x3 convs around the IAF step
+(tf_utils/layers.py:31-64) and the whole non-downsampling IAFLayer.up / .down (tf_train.py:29-95) on the GPU, against
+the committed reference outputs (tests/golden/iaf_layer.npz) and the CPU oracle.  Tolerance as in test_hip_parity."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import golden_inputs as gi
+from oracle import iaf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+ATOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def amd():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU")
+    import iaf_amd
+    iaf_amd._capi.lib()      # raises if the HIP extension is missing: no silent fallback
+    return iaf_amd
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def host(t):
+    torch.cuda.synchronize()
+    return t.detach().cpu().numpy().astype(np.float64)
+
+
+def f32(a):
+    return np.asarray(a, dtype=np.float32).astype(np.float64)
+
+
+# ---------------------------------------------------------------- whole IAFLayer vs the reference's outputs
+@pytest.mark.parametrize("name", sorted(gi.LAYER_CASES))
+def test_iaf_layer_up_down_vs_reference_golden(amd, golden_dir, name):
+    """IAFLayer.up then .down (tf_train.py:29-95, mode "train") with every op on the GPU; all seven tensors the
+    reference run produced.  The tiny fixtures (z 4, h 8) run on the direct-conv fallback, cfg2 on the MFMA kernels."""
+    g = np.load(os.path.join(golden_dir, "iaf_layer.npz"))
+    c = gi.layer_case_inputs(name)
+    layer = amd.IAFLayer(c["z_size"], c["h_size"], depth_ar=2, kl_min=c["kl_min"])
+    layer.load({k: dev(v) for k, v in c["params"].items()})
+    up_out = layer.up(dev(c["up_input"]))
+    np.testing.assert_allclose(host(up_out), g[name + "/up_out"], atol=ATOL, rtol=0)
+    np.testing.assert_allclose(host(layer.posterior.qz_mean), g[name + "/qz_mean"], atol=ATOL, rtol=0)
+    np.testing.assert_allclose(host(layer.posterior.qz_logsd), g[name + "/qz_logsd"], atol=ATOL, rtol=0)
+    np.testing.assert_allclose(host(layer.posterior.up_context), g[name + "/up_context"], atol=ATOL, rtol=0)
+    out, kl_obj, kl_cost = layer.down(dev(c["down_input"]), dev(c["eps_post"]))
+    np.testing.assert_allclose(host(out), g[name + "/output"], atol=ATOL, rtol=0)
+    np.testing.assert_allclose(host(kl_obj), g[name + "/kl_obj"], atol=2e-3, rtol=1e-4)
+    np.testing.assert_allclose(host(kl_cost), g[name + "/kl_cost"], atol=2e-3, rtol=1e-4)
+
+
+# ---------------------------------------------------------------- the conv operator vs the oracle
+CONV_SHAPES = [
+    # (B, n_in, n_out, H, W)
+    (2, 160, 384, 8, 8),      # up_conv1 at cfg2
+    (3, 160, 448, 16, 16),    # down_conv1
+    (2, 192, 160, 8, 8),      # down_conv2
+    (1, 16, 16, 1, 1),        # a single pixel: every non-centre tap falls outside
+    (2, 32, 48, 5, 7),        # ragged: tiles straddle rows and images
+    (1, 64, 64, 3, 40),       # wide rows
+    (2, 16, 32, 32, 32),
+    (3, 6, 10, 4, 5),         # fallback path
+]
+
+
+@pytest.mark.parametrize("shape", CONV_SHAPES, ids=lambda s: "B%d_%dto%d_%dx%d" % s)
+def test_wnconv2d_vs_oracle(amd, shape):
+    B, n_in, n_out, H, W = shape
+    rng = np.random.RandomState(1234 + n_in + n_out)
+    p = gi.conv_params(rng, n_in, n_out)
+    x = rng.standard_normal((B, n_in, H, W))
+    conv = amd.WNConv2d(n_in, n_out)
+    conv.prepare(dev(p["V"]), dev(p["g"]), dev(p["b"]))
+    y = conv(dev(x))[0]
+    e = O.conv2d(f32(x), f32(p["V"]), f32(p["g"]), f32(p["b"]))
+    np.testing.assert_allclose(host(y), e, atol=ATOL, rtol=0)
+    # fused ELU on the input + residual
+    res = rng.standard_normal((B, n_out, H, W))
+    y2 = conv(dev(x), elu_input=True, residual=dev(res))[0]
+    e2 = f32(res) + 0.1 * O.conv2d(O.elu(f32(x)), f32(p["V"]), f32(p["g"]), f32(p["b"]))
+    np.testing.assert_allclose(host(y2), e2, atol=ATOL, rtol=0)
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 160, 448, 8, 8), (3, 4, 8, 24, 6, 6), (2, 64, 64, 320, 5, 3)],
+                         ids=lambda s: "B%d_z%d_h%d_out%d_%dx%d" % s)
+def test_wnconv2d_concat_and_split(amd, shape):
+    """input = elu(concat(z, h_det)) (tf_train.py:87-88); output split six ways (tf_train.py:54)"""
+    B, zs, hs, n_out, H, W = shape
+    rng = np.random.RandomState(99)
+    p = gi.conv_params(rng, zs + hs, n_out)
+    a, b = rng.standard_normal((B, zs, H, W)), rng.standard_normal((B, hs, H, W))
+    split = [zs] * 4 + [(n_out - 4 * zs) // 2] * 2
+    conv = amd.WNConv2d(zs + hs, n_out)
+    conv.prepare(dev(p["V"]), dev(p["g"]), dev(p["b"]))
+    outs = conv(dev(a), x2=dev(b), elu_input=True, split=split)
+    e = O.conv2d(O.elu(np.concatenate([f32(a), f32(b)], axis=1)), f32(p["V"]), f32(p["g"]), f32(p["b"]))
+    for got, want in zip(outs, O.split_channels(e, split)):
+        np.testing.assert_allclose(host(got), want, atol=ATOL, rtol=0)
+
+
+TUNES = [(5, 4, 1, 1), (2, 4, 1, 1), (1, 4, 1, 1), (5, 2, 2, 1), (5, 4, 1, 2), (5, 2, 2, 2), (2, 2, 1, 2), (1, 1, 2, 2),
+         (2, 2, 1, 4), (1, 1, 1, 4), (4, 4, 1, 1), (3, 4, 1, 1)]
+
+
+@pytest.mark.parametrize("tune", TUNES, ids=lambda t: "nt%d_px%d_wco%d_ks%d" % t)
+def test_wnconv2d_every_launch_shape(amd, tune):
+    B, n_in, H, W = 3, 160, 8, 8
+    nt, pxt, wco, ks = tune
+    n_out = 16 * nt * wco * 2
+    rng = np.random.RandomState(5)
+    p = gi.conv_params(rng, n_in, n_out)
+    x = rng.standard_normal((B, n_in, H, W))
+    conv = amd.WNConv2d(n_in, n_out)
+    conv.prepare(dev(p["V"]), dev(p["g"]), dev(p["b"]))
+    try:
+        conv.set_tuning(nt, pxt, wco, ks)
+        y = conv(dev(x))[0]
+    except ValueError as e:                        # shape needs more than 160 KiB of LDS at these channel counts
+        pytest.skip(str(e))
+    e = O.conv2d(f32(x), f32(p["V"]), f32(p["g"]), f32(p["b"]))
+    np.testing.assert_allclose(host(y), e, atol=ATOL, rtol=0)
+
+
+def test_conv2d_function_api_under_tf_names(amd, golden_dir):
+    """the reference call site tf_train.py:36 under its variable scope names"""
+    c = gi.layer_case_inputs("layer_cfg2_8x8")
+    g = np.load(os.path.join(golden_dir, "iaf_layer.npz"))
+    store = amd.VariableStore()
+    for k, v in c["params"].items():
+        store.set("model/IAF_0_0/" + k, dev(v))
+    zs, hs = c["z_size"], c["h_size"]
+    with amd.variable_scope("model", store), amd.variable_scope("IAF_0_0", store):
+        x = amd.conv2d("up_conv1", torch.nn.functional.elu(dev(c["up_input"])), 2 * zs + 2 * hs, store=store)
+    qz_mean, qz_logsd, up_context, _ = torch.split(x, [zs, zs, hs, hs], dim=1)
+    np.testing.assert_allclose(host(qz_mean), g["layer_cfg2_8x8/qz_mean"], atol=ATOL, rtol=0)
+    np.testing.assert_allclose(host(up_context), g["layer_cfg2_8x8/up_context"], atol=ATOL, rtol=0)
+
+
+def test_full_size_layer_properties(amd):
+    """BASELINE configs[1] sizes (B 16, z 32, h 160, 16x16): the layer is a residual map, so zeroing g's exp (g -> -inf is
+    not representable; use V = 0 on down_conv2) must return the input exactly, and batch entries are independent when
+    free bits are off."""
+    B, zs, hs, H, W = 16, 32, 160, 16, 16
+    c = gi.layer_case_inputs("layer_cfg2_8x8")
+    rng = np.random.RandomState(3)
+    params = {k: dev(v) for k, v in c["params"].items()}
+    layer = amd.IAFLayer(zs, hs, depth_ar=2, kl_min=0.0)
+    layer.load(params)
+    up_in, down_in = rng.standard_normal((B, hs, H, W)), rng.standard_normal((B, hs, H, W))
+    eps = rng.standard_normal((B, zs, H, W))
+    layer.up(dev(up_in))
+    out, kl_obj, kl_cost = layer.down(dev(down_in), dev(eps))
+    # batch independence: the first 4 entries alone give the same values
+    layer.up(dev(up_in[:4]))
+    out4, kl_obj4, kl_cost4 = layer.down(dev(down_in[:4]), dev(eps[:4]))
+    np.testing.assert_allclose(host(out4), host(out)[:4], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(host(kl_cost4), host(kl_cost)[:4], atol=2e-3, rtol=1e-5)
+    np.testing.assert_allclose(host(kl_obj), host(kl_cost), atol=2e-3, rtol=1e-5)       # kl_min = 0 (tf_train.py:84-85)
+    # b = 0 and V = 0 on the last conv: l2_normalize(0) = 0 (layers.py:60), so output == input bit for bit
+    params["down_conv2/V"] = torch.zeros_like(params["down_conv2/V"])
+    params["down_conv2/b"] = torch.zeros_like(params["down_conv2/b"])
+    layer.load(params)
+    layer.up(dev(up_in))
+    out0, _, _ = layer.down(dev(down_in), dev(eps))
+    assert torch.equal(out0, dev(down_in))
+
+
+def test_conv3x3_argument_errors(amd):
+    conv = amd.WNConv2d(32, 32)
+    x = torch.zeros((1, 32, 4, 4), device="cuda")
+    with pytest.raises(amd._capi.IafHipError):      # not prepared
+        conv(x)
+    V, g, b = torch.zeros((3, 3, 32, 32), device="cuda"), torch.zeros(32, device="cuda"), torch.zeros(32, device="cuda")
+    conv.prepare(V, g, b)
+    with pytest.raises(ValueError):
+        conv(torch.zeros((1, 16, 4, 4), device="cuda"))
+    with pytest.raises(ValueError):
+        conv(x, split=[16, 8])
+    with pytest.raises(ValueError):                 # MFMA path: split points must be multiples of 4
+        conv(x, split=[6, 26])
+    with pytest.raises(ValueError):
+        conv.prepare(torch.zeros((3, 3, 32, 16), device="cuda"), g, b)
