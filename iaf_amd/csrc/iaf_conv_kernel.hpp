@@ -44,8 +44,23 @@ __device__ __forceinline__ void static_for(F&& f) {
 #define IN_POSTERIOR 2    // x = z0 = (qm+rm) + exp(ql+rl)*eps computed on the fly (tf_train.py:57,63)
 
 struct ConvP {
+    // Field order = order of first use: the kernel pulls the whole descriptor into SGPRs in one batch of scalar loads
+    // at its first instruction (pin_descriptor), so the kernarg cache lines miss in parallel instead of one after another.
     const float* x;       // IN_PIXMAJOR / IN_NCHW input
     const float* wp;      // packed weights [chunk][tap][co_tile][lane 64][4]
+    int B, H, W, HW, P;   // P = B*H*W
+    int cin, cout;        // GEMM K channels, GEMM N (EPI_OUT: 2*n_z)
+    int nchunk, ncot;
+    int cp;               // padded channel stride of the LDS tile (floats), == cin + 8
+    int nslot;            // staged pixel slots = TM + W + 1 (one-sided halo; both sides for the full 3x3)
+    int mode;
+    int halo_before;      // staged slots start at pixel P0 - halo_before
+    int in_elu;           // EPI_PLAIN: ELU on the staged input (tf_train.py:35,40,52,88)
+    int gx;               // gridDim.x (read from here: the hidden kernarg lives in another, cold, cache line)
+    // tap geometry (runtime so that both statements of the operator share the instantiations):
+    //   TF      (tf_utils/layers.py, cross-correlation): taps look right/below, halo after the tile
+    //   Theano  (graphy/nodes/ar.py + dnn_conv conv_mode='conv', flipped kernel): taps look left/above, halo before
+    int tap_dh[MAXTAPS], tap_dw[MAXTAPS];
     const float* bias;    // packed bias
     const int* lim;       // per packed co-tile: number of live 16-channel chunks of the centre tap (unused for now)
     const float* ctx;     // EPI_HIDDEN: optional NCHW context  [B,cout,H,W]
@@ -54,28 +69,17 @@ struct ConvP {
     const float* zin;     // EPI_OUT MODE_IAF: z  [B,n_z,H,W]
     float* out0;          // EPI_OUT: z_new / m_raw
     float* out1;          // EPI_OUT: logsd / s_raw
+    const float* border;  // Theano pad_channel: [4][cout packed] weight of the border-indicator channel per non-centre tap
+    unsigned long long* dbg;   // dev tool: per-workgroup s_memtime stamps [grid][8] (NULL in production)
     // posterior inputs (IN_POSTERIOR staging and MODE_POSTERIOR epilogue), all [B,n_z,H,W]
     const float* qm; const float* ql; const float* rm; const float* rl; const float* pm; const float* pl;
     const float* eps;
     float* kl_elem;       // MODE_POSTERIOR: logqs - logps [B,n_z,H,W]
-    int B, H, W, HW, P;   // P = B*H*W
-    int cin, cout;        // GEMM K channels, GEMM N (EPI_OUT: 2*n_z)
-    int nchunk, ncot;
-    int cp;               // padded channel stride of the LDS tile (floats), == cin + 8
-    int nslot;            // staged pixel slots = TM + W + 1 (one-sided halo)
-    int mode;
-    // tap geometry (runtime so that both statements of the operator share the instantiations):
-    //   TF      (tf_utils/layers.py, cross-correlation): taps look right/below, halo after the tile
-    //   Theano  (graphy/nodes/ar.py + dnn_conv conv_mode='conv', flipped kernel): taps look left/above, halo before
-    int tap_dh[MAXTAPS], tap_dw[MAXTAPS];
-    // EPI_PLAIN / NCHW staging extras: input = elu(concat(x[:, :c_split], x2)) (tf_train.py:36,52,87-88), residual for out0
-    const float* x2; int c_split; int in_elu; const float* res;
+    // EPI_PLAIN extras: input = elu(concat(x[:, :c_split], x2)) (tf_train.py:36,52,87-88), residual for the output
+    const float* x2; const float* res; int c_split;
     // EPI_PLAIN output: the channel split of tf_train.py:37,54 fused into the store.  Channels [split_end[k-1], split_end[k])
     // go to the contiguous NCHW tensor split_ptr[k]; boundaries are multiples of 4 (one lane's 4 channels never straddle).
     int nsplit; int split_end[MAXSPLIT]; float* split_ptr[MAXSPLIT];
-    int halo_before;          // staged slots start at pixel P0 - halo_before
-    const float* border;      // Theano pad_channel: [4][cout packed] weight of the border-indicator channel per non-centre tap
-    unsigned long long* dbg;   // dev tool: per-workgroup s_memtime stamps [grid][8] (NULL in production)
 };
 
 // Pin the order "MFMAs with memory instructions spread evenly between them" inside the current scheduling region:
@@ -122,9 +126,25 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
     const int pw = wave % PXT, cw = (wave / PXT) % WCO, kh = wave / WPK;
     const int P0 = blockIdx.x * TM;
     const int cot0 = (blockIdx.y * WCO + cw) * NT;
+    // Pull the descriptor into SGPRs NOW, as one batch: left to itself the compiler loads each kernarg field right
+    // before its first use, and the prologue becomes a chain of ~10 dependent scalar-cache misses (measured: each extra
+    // cold kernarg line costs 0.15-0.25 us of a 6-22 us kernel).
+    asm volatile("" ::"s"(p.x), "s"(p.wp), "s"(p.B), "s"(p.H), "s"(p.W), "s"(p.HW), "s"(p.P), "s"(p.cin), "s"(p.cout),
+                 "s"(p.nchunk), "s"(p.ncot), "s"(p.cp), "s"(p.nslot), "s"(p.mode), "s"(p.halo_before), "s"(p.gx));
+    asm volatile("" ::"s"(p.tap_dh[0]), "s"(p.tap_dh[1]), "s"(p.tap_dh[2]), "s"(p.tap_dh[3]), "s"(p.tap_dh[4]), "s"(p.tap_dw[0]),
+                 "s"(p.tap_dw[1]), "s"(p.tap_dw[2]), "s"(p.tap_dw[3]), "s"(p.tap_dw[4]));
+    if constexpr (NTP == MAXTAPS)
+        asm volatile("" ::"s"(p.tap_dh[5]), "s"(p.tap_dh[6]), "s"(p.tap_dh[7]), "s"(p.tap_dh[8]), "s"(p.tap_dw[5]), "s"(p.tap_dw[6]),
+                     "s"(p.tap_dw[7]), "s"(p.tap_dw[8]));
+    asm volatile("" ::"s"(p.bias), "s"(p.ctx), "s"(p.ctx2), "s"(p.y), "s"(p.zin), "s"(p.out0), "s"(p.out1), "s"(p.border),
+                 "s"(p.dbg));
+    if constexpr (INMODE == IN_POSTERIOR || EPI == EPI_OUT)
+        asm volatile("" ::"s"(p.qm), "s"(p.ql), "s"(p.rm), "s"(p.rl), "s"(p.pm), "s"(p.pl), "s"(p.eps), "s"(p.kl_elem));
+    if constexpr (EPI == EPI_PLAIN)
+        asm volatile("" ::"s"(p.x2), "s"(p.res), "s"(p.c_split), "s"(p.in_elu), "s"(p.nsplit));
     const int HW = p.HW, W = p.W;
     const int cp4 = p.cp >> 2;       // LDS row stride in 16-byte units
-#define IAF_STAMP(k) do { if (p.dbg && tid == 0) p.dbg[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#define IAF_STAMP(k) do { if (p.dbg && tid == 0) p.dbg[((size_t)blockIdx.y * p.gx + blockIdx.x) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
     IAF_STAMP(0);
 
     // ================= prologue, ordered by latency: (1) tile loads, (2) weight ring, (3) index math ==========
@@ -273,16 +293,16 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
                             const int b = Pg / HW, ppx = Pg - b * HW;
                             const size_t gb = ((size_t)b * p.cin + 4 * q) * HW + ppx;
                             if (INMODE == IN_NCHW) {
-                                if (p.x2 && 4 * q >= p.c_split) {        // second tensor of a channel concat
+                                if (EPI == EPI_PLAIN && p.x2 && 4 * q >= p.c_split) {        // second tensor of a channel concat
                                     const size_t g2 = ((size_t)b * (p.cin - p.c_split) + (4 * q - p.c_split)) * HW + ppx;
 #pragma unroll
                                     for (int r = 0; r < 4; ++r) sv[u][r] = p.x2[g2 + (size_t)r * HW];
                                 } else {
-                                    const size_t g1 = p.x2 ? ((size_t)b * p.c_split + 4 * q) * HW + ppx : gb;
+                                    const size_t g1 = (EPI == EPI_PLAIN && p.x2) ? ((size_t)b * p.c_split + 4 * q) * HW + ppx : gb;
 #pragma unroll
                                     for (int r = 0; r < 4; ++r) sv[u][r] = p.x[g1 + (size_t)r * HW];
                                 }
-                                if (p.in_elu) {
+                                if (EPI == EPI_PLAIN && p.in_elu) {
 #pragma unroll
                                     for (int r = 0; r < 4; ++r) sv[u][r] = elu_f(sv[u][r]);
                                 }

@@ -205,27 +205,6 @@ __device__ __forceinline__ void prep_tile_theano(const PrepLayer& L, int gt, flo
 #define PREP_PLAIN9 100   // PrepLayer.variant of a plain (unmasked, 9-tap) TF conv2d
 template <int DUMMY = 0>
 __device__ __forceinline__ void prep_dispatch(const PrepLayer& L, int gt, float (*red)[17], float* s_scale) {
-    if (L.variant == PREP_PLAIN9) {   // unmasked 3x3 (layers.py:52-64 with mask=None)
-        switch (L.nchunk) {
-            case 1: prep_tile<1, MAXTAPS>(L, gt, red, s_scale); break;
-            case 2: prep_tile<2, MAXTAPS>(L, gt, red, s_scale); break;
-            case 3: prep_tile<3, MAXTAPS>(L, gt, red, s_scale); break;
-            case 4: prep_tile<4, MAXTAPS>(L, gt, red, s_scale); break;
-            case 5: prep_tile<5, MAXTAPS>(L, gt, red, s_scale); break;
-            case 6: prep_tile<6, MAXTAPS>(L, gt, red, s_scale); break;
-            case 7: prep_tile<7, MAXTAPS>(L, gt, red, s_scale); break;
-            case 8: prep_tile<8, MAXTAPS>(L, gt, red, s_scale); break;
-            case 9: prep_tile<9, MAXTAPS>(L, gt, red, s_scale); break;
-            case 10: prep_tile<10, MAXTAPS>(L, gt, red, s_scale); break;
-            case 11: prep_tile<11, MAXTAPS>(L, gt, red, s_scale); break;
-            case 12: prep_tile<12, MAXTAPS>(L, gt, red, s_scale); break;
-            case 13: prep_tile<13, MAXTAPS>(L, gt, red, s_scale); break;
-            case 14: prep_tile<14, MAXTAPS>(L, gt, red, s_scale); break;
-            case 15: prep_tile<15, MAXTAPS>(L, gt, red, s_scale); break;
-            case 16: prep_tile<16, MAXTAPS>(L, gt, red, s_scale); break;
-        }
-        return;
-    }
     if (L.variant == IAF_VARIANT_THEANO) {
         switch (L.nchunk) {
             case 1: prep_tile_theano<1>(L, gt, red, s_scale); break;
@@ -274,6 +253,34 @@ __global__ __launch_bounds__(256) void iaf_prep_batch_kernel(const PrepLayer* __
     __shared__ float s_scale[16];
     const PrepLayer L = layers[tile2layer[blockIdx.x]];
     prep_dispatch(L, blockIdx.x - L.tile_begin, red, s_scale);
+}
+
+// plain (unmasked, 9-tap) convs: their own kernel so that the 9-tap register footprint does not tax the masked prep.
+// tile2layer == NULL: a single layer.
+__global__ __launch_bounds__(256) void iaf_prep_plain_kernel(const PrepLayer* __restrict__ layers,
+                                                            const int* __restrict__ tile2layer) {
+    __shared__ float red[16][17];
+    __shared__ float s_scale[16];
+    const PrepLayer L = layers[tile2layer ? tile2layer[blockIdx.x] : 0];
+    const int gt = blockIdx.x - L.tile_begin;
+    switch (L.nchunk) {
+        case 1: prep_tile<1, MAXTAPS>(L, gt, red, s_scale); break;
+        case 2: prep_tile<2, MAXTAPS>(L, gt, red, s_scale); break;
+        case 3: prep_tile<3, MAXTAPS>(L, gt, red, s_scale); break;
+        case 4: prep_tile<4, MAXTAPS>(L, gt, red, s_scale); break;
+        case 5: prep_tile<5, MAXTAPS>(L, gt, red, s_scale); break;
+        case 6: prep_tile<6, MAXTAPS>(L, gt, red, s_scale); break;
+        case 7: prep_tile<7, MAXTAPS>(L, gt, red, s_scale); break;
+        case 8: prep_tile<8, MAXTAPS>(L, gt, red, s_scale); break;
+        case 9: prep_tile<9, MAXTAPS>(L, gt, red, s_scale); break;
+        case 10: prep_tile<10, MAXTAPS>(L, gt, red, s_scale); break;
+        case 11: prep_tile<11, MAXTAPS>(L, gt, red, s_scale); break;
+        case 12: prep_tile<12, MAXTAPS>(L, gt, red, s_scale); break;
+        case 13: prep_tile<13, MAXTAPS>(L, gt, red, s_scale); break;
+        case 14: prep_tile<14, MAXTAPS>(L, gt, red, s_scale); break;
+        case 15: prep_tile<15, MAXTAPS>(L, gt, red, s_scale); break;
+        case 16: prep_tile<16, MAXTAPS>(L, gt, red, s_scale); break;
+    }
 }
 
 __global__ __launch_bounds__(256) void iaf_prep_kernel(PrepArgs a) {
@@ -1348,6 +1355,7 @@ static int launch_gemm(const iaf_stack_t* s, GemmLayer& L, int epi, bool negate_
     const bool prof = (prof_id >= 0 && s->prof_layer == prof_id && s->prof_n < s->prof_cap);
     iaf_stack* ms = const_cast<iaf_stack*>(s);
     if (prof) HIP_TRY(hipEventRecord(ms->prof_start[ms->prof_n], st));
+    p.gx = (int)grid.x;
     hipLaunchKernelGGL(fn, grid, dim3(64 * L.pxt * L.wco * L.ks), lds, st, p);
     if (prof) { HIP_TRY(hipEventRecord(ms->prof_stop[ms->prof_n], st)); ms->prof_n++; }
     return (int)hipGetLastError();
@@ -1954,12 +1962,16 @@ struct iaf_conv3x3 {
     int n_in, n_out;
     bool generic, prepared;
     GemmLayer L;
+    PrepLayer* h_desc = nullptr;   // pinned staging of the prep descriptor
+    PrepLayer* d_desc = nullptr;
 };
 
 extern "C" int iaf_conv3x3_destroy(iaf_conv3x3_t* c) {
     if (!c) return IAF_ERR_NULL;
     if (c->L.wp) (void)hipFree(c->L.wp);
     if (c->L.bias) (void)hipFree(c->L.bias);
+    if (c->h_desc) (void)hipHostFree(c->h_desc);
+    if (c->d_desc) (void)hipFree(c->d_desc);
     delete c;
     return IAF_OK;
 }
@@ -1980,7 +1992,9 @@ extern "C" int iaf_conv3x3_create(iaf_conv3x3_t** out, int n_in, int n_out) {
     const size_t wfloats = c->generic ? (size_t)MAXTAPS * n_in * n_out : (size_t)L.nchunk * MAXTAPS * L.ncot * 256;
     int rc;
     if ((rc = (int)hipMalloc(&L.wp, wfloats * sizeof(float))) != 0 ||
-        (rc = (int)hipMalloc(&L.bias, (size_t)L.ncot * 16 * sizeof(float))) != 0) {
+        (rc = (int)hipMalloc(&L.bias, (size_t)L.ncot * 16 * sizeof(float))) != 0 ||
+        (rc = (int)hipHostMalloc((void**)&c->h_desc, sizeof(PrepLayer))) != 0 ||
+        (rc = (int)hipMalloc((void**)&c->d_desc, sizeof(PrepLayer))) != 0) {
         iaf_conv3x3_destroy(c);
         return rc;
     }
@@ -2000,13 +2014,12 @@ extern "C" int iaf_conv3x3_prepare(iaf_conv3x3_t* c, const float* V, const float
         P.cin = L.cin; P.cout_each = L.cout; P.npair = 1; P.zerodiag = 0; P.ch_begin = 0; P.ntaps = MAXTAPS;
         hipLaunchKernelGGL(iaf_generic_prep_kernel, dim3(L.cout), dim3(256), 0, (hipStream_t)stream, ga);
     } else {
-        PrepArgs a;
-        memset(&a, 0, sizeof(a));
-        a.nlayers = 1;
-        PrepLayer& P = a.L[0];
+        PrepLayer& P = *c->h_desc;
+        memset(&P, 0, sizeof(P));
         P.V[0] = V; P.g[0] = g; P.b[0] = b; P.wp = L.wp; P.bias = L.bias; P.variant = PREP_PLAIN9;
         P.cin = L.cin; P.cout_each = L.cout; P.ncot = L.ncot; P.nchunk = L.nchunk; P.npair = 1; P.tile_begin = 0;
-        hipLaunchKernelGGL(iaf_prep_kernel, dim3(L.ncot), dim3(256), 0, (hipStream_t)stream, a);
+        HIP_TRY(hipMemcpyAsync(c->d_desc, c->h_desc, sizeof(PrepLayer), hipMemcpyHostToDevice, (hipStream_t)stream));
+        hipLaunchKernelGGL(iaf_prep_plain_kernel, dim3(L.ncot), dim3(256), 0, (hipStream_t)stream, c->d_desc, (const int*)nullptr);
     }
     HIP_TRY(hipGetLastError());
     c->prepared = true;
@@ -2080,6 +2093,7 @@ extern "C" int iaf_conv3x3_forward(iaf_conv3x3_t* c, const float* x, const float
     int rc = raise_lds_cap(fn, lds);
     if (rc) return rc;
     dim3 grid((p.P + tm - 1) / tm, L.ncot / (L.nt * L.wco));
+    p.gx = (int)grid.x;
     hipLaunchKernelGGL(fn, grid, dim3(64 * L.pxt * L.wco * L.ks), lds, st, p);
     return (int)hipGetLastError();
 }
