@@ -72,6 +72,10 @@ SIGNATURES = {
     "iaf_conv3x3_forward": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, ctypes.POINTER(_vp),
                                            ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                            ctypes.c_int, _vp]),
+    "iaf_conv3x3_autotune": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, ctypes.POINTER(_vp),
+                                            ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                            ctypes.c_int, ctypes.c_int, _vp, ctypes.POINTER(ctypes.c_int),
+                                            ctypes.POINTER(ctypes.c_float)]),
     "iaf_conv3x3_set_tuning": (ctypes.c_int, [_vp] + [ctypes.c_int] * 4),
     "iaf_conv3x3_work": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int] + [ctypes.POINTER(ctypes.c_double)] * 2),
 }

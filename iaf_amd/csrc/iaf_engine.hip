@@ -2098,6 +2098,52 @@ extern "C" int iaf_conv3x3_forward(iaf_conv3x3_t* c, const float* x, const float
     return (int)hipGetLastError();
 }
 
+// Times every compiled launch shape on the caller's own buffers (the forward is idempotent) and pins the fastest;
+// the counterpart of the cuDNN algorithm search the reference's tf.nn.conv2d performs.  Synchronises the stream.
+extern "C" int iaf_conv3x3_autotune(iaf_conv3x3_t* c, const float* x, const float* x2, int c_split, int elu_input,
+                                    const float* residual, float* const* outs, const int* out_channels, int n_outs, int B,
+                                    int H, int W, int reps, void* stream, int* best_shape, float* best_us) {
+    if (!c) return IAF_ERR_NULL;
+    if (c->generic) return IAF_OK;
+    if (reps <= 0) reps = 20;
+    hipStream_t st = (hipStream_t)stream;
+    GemmLayer& L = c->L;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    float best = 1e30f;
+    int bsh[4] = {L.nt, L.pxt, L.wco, L.ks};
+    int rc = IAF_OK;
+    for (int si = 0; si < 8 && rc == IAF_OK; ++si)
+        for (int nt = 5; nt >= 1 && rc == IAF_OK; --nt) {
+            const int pxt = k_shapes[si][0], wco = k_shapes[si][1], ks = k_shapes[si][2];
+            if (L.ncot % (nt * wco) != 0 || L.nchunk < ks) continue;
+            GemmLayer t = L;
+            t.nt = nt; t.pxt = pxt; t.wco = wco; t.ks = ks;
+            if (conv_lds_bytes(t, W) > 160 * 1024) continue;
+            L.nt = nt; L.pxt = pxt; L.wco = wco; L.ks = ks; L.user_tuned = true;
+            for (int r = 0; r < 3 && rc == IAF_OK; ++r)
+                rc = iaf_conv3x3_forward(c, x, x2, c_split, elu_input, residual, outs, out_channels, n_outs, B, H, W, stream);
+            if (rc == IAF_ERR_UNSUPPORTED) { rc = IAF_OK; continue; }
+            if (rc) break;
+            (void)hipEventRecord(e0, st);
+            for (int r = 0; r < reps && rc == IAF_OK; ++r)
+                rc = iaf_conv3x3_forward(c, x, x2, c_split, elu_input, residual, outs, out_channels, n_outs, B, H, W, stream);
+            (void)hipEventRecord(e1, st);
+            if (rc) break;
+            if ((rc = (int)hipEventSynchronize(e1)) != 0) break;
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            if (ms < best) { best = ms; bsh[0] = nt; bsh[1] = pxt; bsh[2] = wco; bsh[3] = ks; }
+        }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    L.nt = bsh[0]; L.pxt = bsh[1]; L.wco = bsh[2]; L.ks = bsh[3]; L.user_tuned = true;
+    if (best_shape) for (int i = 0; i < 4; ++i) best_shape[i] = bsh[i];
+    if (best_us) *best_us = best * 1e3f / reps;
+    return rc;
+}
+
 extern "C" int iaf_conv3x3_work(const iaf_conv3x3_t* c, int B, int H, int W, double* flops, double* bytes) {
     if (!c) return IAF_ERR_NULL;
     const double P = (double)B * H * W;

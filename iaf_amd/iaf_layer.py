@@ -57,18 +57,20 @@ class IAFLayer(object):
         pre = "ar_multiconv2d/"
         self.posterior.load({k[len(pre):]: v for k, v in params.items() if k.startswith(pre)})
 
-    def up(self, inp):
+    def up(self, inp, autotune=False):
         zs, hs = self.z_size, self.h_size
-        qz_mean, qz_logsd, up_context, h = self.up_conv1(inp, elu_input=True, split=[zs, zs, hs, hs])     # :35-37
+        qz_mean, qz_logsd, up_context, h = self.up_conv1(inp, elu_input=True, split=[zs, zs, hs, hs],
+                                                         autotune=autotune)                               # :35-37
         self.posterior.set_up_state(qz_mean, qz_logsd, up_context)                                        # :38
-        return self.up_conv3(h, elu_input=True, residual=inp)[0]                                          # :40-44
+        return self.up_conv3(h, elu_input=True, residual=inp, autotune=autotune)[0]                       # :40-44
 
-    def down(self, inp, eps):
-        """Returns (output, kl_obj, kl_cost) like tf_train.py:95."""
+    def down(self, inp, eps, autotune=False):
+        """Returns (output, kl_obj, kl_cost) like tf_train.py:95.  autotune=True: the first call at a new (B,H,W)
+        searches the launch shapes of the plain convs (what cuDNN's algorithm search does for the reference)."""
         zs, hs = self.z_size, self.h_size
         pz_mean, pz_logsd, rz_mean, rz_logsd, down_context, h_det = self.down_conv1(
-            inp, elu_input=True, split=[zs] * 4 + [hs] * 2)                                               # :52-54
+            inp, elu_input=True, split=[zs] * 4 + [hs] * 2, autotune=autotune)                            # :52-54
         blk = self.posterior.down(pz_mean, pz_logsd, rz_mean, rz_logsd, down_context, eps)                # :56-85
-        out = self.down_conv2(blk["z"], x2=h_det, elu_input=True, residual=inp)[0]                        # :87-94
+        out = self.down_conv2(blk["z"], x2=h_det, elu_input=True, residual=inp, autotune=autotune)[0]     # :87-94
         self.last_block = blk
         return out, blk["kl_obj"], blk["kl_cost"]

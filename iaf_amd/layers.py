@@ -389,6 +389,7 @@ class WNConv2d(object):
         self.n_in, self.n_out = int(n_in), int(n_out)
         self._h = ctypes.c_void_p()
         _capi.check(_capi.lib().iaf_conv3x3_create(ctypes.byref(self._h), self.n_in, self.n_out))
+        self._tuned, self._cur_tune = {}, None      # (B,H,W) -> launch shape found by autotune
         self._prep_key = None
         self._keepalive = None
 
@@ -419,7 +420,7 @@ class WNConv2d(object):
         _capi.check(_capi.lib().iaf_conv3x3_work(self._h, B, H, W, ctypes.byref(fl), ctypes.byref(by)))
         return fl.value, by.value
 
-    def __call__(self, x, x2=None, elu_input=False, split=None, residual=None, out=None):
+    def __call__(self, x, x2=None, elu_input=False, split=None, residual=None, out=None, autotune=False):
         """x [B,c,H,W] (+ optional x2 [B,n_in-c,H,W], concatenated along channels).  Returns the list of split
         tensors (`split` = channel counts, default [n_out]) or, with `residual`, the single tensor
         residual + 0.1*y."""
@@ -443,6 +444,21 @@ class WNConv2d(object):
         n = len(split)
         outs = (ctypes.c_void_p * n)(*[o.data_ptr() for o in out])
         chans = (ctypes.c_int * n)(*split)
+        key = (B, H, W)
+        if autotune and key not in self._tuned:
+            sh, us = (ctypes.c_int * 4)(), ctypes.c_float()
+            _capi.check(_capi.lib().iaf_conv3x3_autotune(self._h, _ptr(x), _ptr(x2), c_split, 1 if elu_input else 0,
+                                                         _ptr(residual), outs, chans, n, B, H, W, 20, _stream(), sh,
+                                                         ctypes.byref(us)))
+            self._tuned[key] = tuple(sh)
+            self._cur_tune = key
+            return out
+        if key in self._tuned and self._cur_tune != key:
+            self.set_tuning(*self._tuned[key])
+            self._cur_tune = key
+        elif key not in self._tuned and self._cur_tune is not None:
+            self.set_tuning(0, 0, 0, 0)
+            self._cur_tune = None
         _capi.check(_capi.lib().iaf_conv3x3_forward(self._h, _ptr(x), _ptr(x2), c_split, 1 if elu_input else 0,
                                                     _ptr(residual), outs, chans, n, B, H, W, _stream()))
         return out

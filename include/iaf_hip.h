@@ -221,6 +221,12 @@ int iaf_conv3x3_forward(iaf_conv3x3_t* c, const float* x, const float* x2, int c
                         int W, void* stream);
 /* launch shape override (nt = 0 restores the automatic choice); see iaf_stack_set_tuning */
 int iaf_conv3x3_set_tuning(iaf_conv3x3_t* c, int nt, int pxt, int wco, int ks);
+/* times every compiled launch shape with `reps` back-to-back forwards on the caller's buffers (same arguments as
+ * iaf_conv3x3_forward; outputs end up holding the forward result), pins the fastest as if by set_tuning, and reports it
+ * (best_shape[4] = nt,pxt,wco,ks; best_us per call; both optional).  Synchronises the stream; not capturable. */
+int iaf_conv3x3_autotune(iaf_conv3x3_t* c, const float* x, const float* x2, int c_split, int elu_input,
+                         const float* residual, float* const* outs, const int* out_channels, int n_outs, int B, int H,
+                         int W, int reps, void* stream, int* best_shape, float* best_us);
 /* FLOPs (2*9*n_in*n_out per pixel) and minimum bytes (activations in+out, V/g/b once) of one forward call */
 int iaf_conv3x3_work(const iaf_conv3x3_t* c, int B, int H, int W, double* flops, double* bytes);
 

@@ -188,3 +188,19 @@ def test_conv3x3_argument_errors(amd):
         conv(x, split=[6, 26])
     with pytest.raises(ValueError):
         conv.prepare(torch.zeros((3, 3, 32, 16), device="cuda"), g, b)
+
+
+def test_autotuned_layer_matches_reference_golden(amd, golden_dir):
+    """the launch-shape search must not change results: cfg2 fixture again with autotune on, then a plain call"""
+    name = "layer_cfg2_8x8"
+    g = np.load(os.path.join(golden_dir, "iaf_layer.npz"))
+    c = gi.layer_case_inputs(name)
+    layer = amd.IAFLayer(c["z_size"], c["h_size"], depth_ar=2, kl_min=c["kl_min"])
+    layer.load({k: dev(v) for k, v in c["params"].items()})
+    for tune in (True, False):
+        up_out = layer.up(dev(c["up_input"]), autotune=tune)
+        out, kl_obj, kl_cost = layer.down(dev(c["down_input"]), dev(c["eps_post"]), autotune=tune)
+        np.testing.assert_allclose(host(up_out), g[name + "/up_out"], atol=ATOL, rtol=0)
+        np.testing.assert_allclose(host(out), g[name + "/output"], atol=ATOL, rtol=0)
+        np.testing.assert_allclose(host(kl_cost), g[name + "/kl_cost"], atol=2e-3, rtol=1e-4)
+    assert layer.up_conv1._tuned and layer.down_conv2._tuned
