@@ -67,7 +67,11 @@ SIGNATURES = {
                        [ctypes.POINTER(ctypes.c_double)] * 3),
     "iaf_step_work": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int] + [ctypes.POINTER(ctypes.c_double)] * 3),
     "iaf_conv3x3_create": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_int]),
+    "iaf_conv3x3_create_masked": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "iaf_conv3x3_destroy": (ctypes.c_int, [_vp]),
+    "iaf_datainit_normalize": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, _vp]),
+    "iaf_discretized_logistic": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, ctypes.c_int, ctypes.c_size_t,
+                                                ctypes.c_float, _vp]),
     "iaf_conv3x3_prepare": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "iaf_conv3x3_forward": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, ctypes.POINTER(_vp),
                                            ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int, ctypes.c_int,

@@ -8,6 +8,10 @@
 
 template <int NT>
 static conv_fn_t pick_mode(int inmode, int epi) {
+    if (epi == EPI_PLAIN5) {  // one masked conv on its own (ar_conv2d, layers.py:144-154): raw NCHW output
+        if (inmode == IN_NCHW) return iaf_conv_kernel<NT, IAF_PXT, IAF_WCO, IAF_KS, IN_NCHW, EPI_PLAIN, NTAPS>;
+        return nullptr;
+    }
     if (epi == EPI_PLAIN) {   // plain 9-tap weight-normed conv (context producers / consumers): NCHW in, NCHW out
         if (inmode == IN_NCHW) return iaf_conv_kernel<NT, IAF_PXT, IAF_WCO, IAF_KS, IN_NCHW, EPI_PLAIN, MAXTAPS>;
         return nullptr;

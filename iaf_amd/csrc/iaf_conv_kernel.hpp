@@ -27,6 +27,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 #define EPI_HIDDEN 0   // y = elu(acc + bias [+ ctx (+ ctx2)])  -> pixel-major scratch
 #define EPI_OUT 1      // output pair (mean, logsd) -> NCHW; mode selects raw / IAF step / posterior
 #define EPI_DGRAD 2    // data gradient (transposed packs, mirrored taps): mode selects MODE_DGRAD_ELU / MODE_DGRAD_Z
+#define EPI_PLAIN5 4   // host-side selector only: EPI_PLAIN with the 5 masked taps (a single ar_conv2d)
 #define EPI_PLAIN 3    // y = acc + bias [-> res + 0.1*y]  -> NCHW   (plain weight-normed conv2d, layers.py:63-64; tf_train.py:44,94)
 
 #define MODE_RAW 0        // out0 = m_raw, out1 = s_raw                         (layers.py:166)

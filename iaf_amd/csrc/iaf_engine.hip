@@ -719,6 +719,72 @@ __global__ __launch_bounds__(256) void iaf_post_bwd_post_kernel(const float* qm,
 }
 
 // ---------------------------------------------------------------------------------------------
+// data-dependent init, tf_utils/layers.py:45-51: per-channel moments of x_init = conv(x, l2norm(mask*V)) over (N,H,W),
+//   scale = init_scale / sqrt(var + 1e-10);  g = log(scale)/3;  b = -mean*scale;  y = scale*(x_init - mean)
+// One workgroup per channel; two passes (mean, then centred variance) in a fixed tree order.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void iaf_datainit_kernel(const float* x, const float* __restrict__ add, float* y,
+                                                          float* __restrict__ g, float* __restrict__ b, int B, int C, int HW,
+                                                          float init_scale) {
+    __shared__ float red[4];
+    const int c = blockIdx.x;
+    const int n = B * HW;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) { const int bb = i / HW; s += x[((size_t)bb * C + c) * HW + (i - bb * HW)]; }
+    const float mean = block_sum_256(s, red) / (float)n;
+    float q = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int bb = i / HW;
+        const float d = x[((size_t)bb * C + c) * HW + (i - bb * HW)] - mean;
+        q += d * d;
+    }
+    const float var = block_sum_256(q, red) / (float)n;          // tf.nn.moments: biased
+    const float scale = init_scale / sqrtf(var + 1e-10f);
+    if (threadIdx.x == 0) { g[c] = logf(scale) / 3.0f; b[c] = -mean * scale; }
+    if (y)
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int bb = i / HW;
+            const size_t o = ((size_t)bb * C + c) * HW + (i - bb * HW);
+            y[o] = scale * (x[o] - mean) + (add ? add[o] : 0.f);
+        }
+}
+
+// discretized logistic log-likelihood, tf_utils/distributions.py:28-32 (call site tf_train.py:210): one workgroup per
+// batch row, out[b] = sum log(sigmoid(s + binsize/scale) - sigmoid(s) + 1e-7), s = (floor(x/binsize)*binsize - mean)/scale
+__global__ __launch_bounds__(256) void iaf_disc_logistic_kernel(const float* __restrict__ mean, const float* __restrict__ logscale,
+                                                               int scalar_scale, const float* __restrict__ sample,
+                                                               float* __restrict__ out, size_t n, float binsize) {
+    __shared__ float red[4];
+    const size_t base = (size_t)blockIdx.x * n;
+    float acc = 0.f;
+    for (size_t i = threadIdx.x; i < n; i += 256) {
+        const float scale = expf(scalar_scale ? logscale[0] : logscale[base + i]);
+        const float s = (floorf(sample[base + i] / binsize) * binsize - mean[base + i]) / scale;
+        // sigmoid(s+d) - sigmoid(s), evaluated on the side where both terms are small (sigmoid(t) = 1 - sigmoid(-t)):
+        // the literal fp32 form cancels to ~1e-7 absolute in the upper tail, the size of the +1e-7 floor itself
+        const float d = binsize / scale;
+        float diff;
+        if (s > 0.f) {
+            const float e0 = expf(-s), e1 = expf(-(s + d));
+            diff = e0 / (1.0f + e0) - e1 / (1.0f + e1);
+        } else {
+            diff = 1.0f / (1.0f + expf(-(s + d))) - 1.0f / (1.0f + expf(-s));
+        }
+        acc += logf(diff + 1e-7f);
+    }
+    const float tot = block_sum_256(acc, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = tot;
+}
+
+// ---------------------------------------------------------------------------------------------
 // GENERIC FALLBACK: direct (VALU) masked conv for channel counts the MFMA path does not cover (not multiples of 16,
 // or > 256).  Same arithmetic, same fused epilogues, NCHW everywhere, one thread per output element.  Orders of
 // magnitude slower than the MFMA path -- it exists so that every shape the reference accepts (layers.py:116 only asks
@@ -729,7 +795,8 @@ struct GenPrepLayer {
     float* w;        // effective weights [NTAPS][cin][cout_total]
     float* bias;     // [cout_total]
     int cin, cout_each, npair, zerodiag, ch_begin;
-    int ntaps;       // 5 = MADE-masked (default when 0), 9 = plain unmasked conv2d
+    int ntaps;       // 5 = MADE-masked (default when 0), 9 = all nine filter positions stored
+    int mask9;       // ntaps == 9 only: 0 = unmasked conv2d, 1 = ar_conv2d mask (dead taps stored as zeros)
 };
 struct GenPrepArgs { GenPrepLayer L[MAX_GEMM_LAYERS]; int nlayers; };
 
@@ -749,7 +816,9 @@ __global__ __launch_bounds__(256) void iaf_generic_prep_kernel(GenPrepArgs a) {
     for (int e = threadIdx.x; e < ntaps * n_in; e += 256) {
         const int t = e / n_in, ci = e - t * n_in;
         const int kh = full ? t / 3 : ((t == 0 || t == 1) ? 1 : 2), kw = full ? t % 3 : ((t == 0) ? 1 : (t == 1 ? 2 : t - 2));
-        const bool live = full || (t != 0) || made_live(ci, o, n_in, n_out, L.zerodiag);
+        const bool live = full ? (!L.mask9 || kh == 2 || (kh == 1 && kw == 2) ||
+                                  (kh == 1 && kw == 1 && made_live(ci, o, n_in, n_out, L.zerodiag)))   // layers.py:134-141
+                               : ((t != 0) || made_live(ci, o, n_in, n_out, L.zerodiag));
         const float v = live ? V[((size_t)(kh * 3 + kw) * n_in + ci) * n_out + o] : 0.f;
         ss += v * v;
     }
@@ -763,7 +832,9 @@ __global__ __launch_bounds__(256) void iaf_generic_prep_kernel(GenPrepArgs a) {
     for (int e = threadIdx.x; e < ntaps * n_in; e += 256) {
         const int t = e / n_in, ci = e - t * n_in;
         const int kh = full ? t / 3 : ((t == 0 || t == 1) ? 1 : 2), kw = full ? t % 3 : ((t == 0) ? 1 : (t == 1 ? 2 : t - 2));
-        const bool live = full || (t != 0) || made_live(ci, o, n_in, n_out, L.zerodiag);
+        const bool live = full ? (!L.mask9 || kh == 2 || (kh == 1 && kw == 2) ||
+                                  (kh == 1 && kw == 1 && made_live(ci, o, n_in, n_out, L.zerodiag)))   // layers.py:134-141
+                               : ((t != 0) || made_live(ci, o, n_in, n_out, L.zerodiag));
         L.w[((size_t)t * n_in + ci) * ctot + oc] = live ? V[((size_t)(kh * 3 + kw) * n_in + ci) * n_out + o] * scale : 0.f;
     }
     if (threadIdx.x == 0) L.bias[oc] = L.b[which][o];
@@ -1960,6 +2031,7 @@ extern "C" int iaf_step_work(const iaf_stack_t* s, int B, int H, int W, double* 
 // ---------------------------------------------------------------------------------------------
 struct iaf_conv3x3 {
     int n_in, n_out;
+    int mask_mode;     // 0 plain conv2d, 1 ar_conv2d(zerodiagonal=False), 2 ar_conv2d(zerodiagonal=True)
     bool generic, prepared;
     GemmLayer L;
     PrepLayer* h_desc = nullptr;   // pinned staging of the prep descriptor
@@ -1976,19 +2048,27 @@ extern "C" int iaf_conv3x3_destroy(iaf_conv3x3_t* c) {
     return IAF_OK;
 }
 
-extern "C" int iaf_conv3x3_create(iaf_conv3x3_t** out, int n_in, int n_out) {
+static int conv3x3_create(iaf_conv3x3_t** out, int n_in, int n_out, int mask_mode);
+extern "C" int iaf_conv3x3_create(iaf_conv3x3_t** out, int n_in, int n_out) { return conv3x3_create(out, n_in, n_out, 0); }
+extern "C" int iaf_conv3x3_create_masked(iaf_conv3x3_t** out, int n_in, int n_out, int zerodiagonal) {
+    if (n_in > 0 && n_out > 0 && !(n_in % n_out == 0 || n_out % n_in == 0)) return IAF_ERR_NOT_MULTIPLE;   // layers.py:116
+    return conv3x3_create(out, n_in, n_out, zerodiagonal ? 2 : 1);
+}
+
+static int conv3x3_create(iaf_conv3x3_t** out, int n_in, int n_out, int mask_mode) {
     if (!out) return IAF_ERR_NULL;
     *out = nullptr;
     if (n_in <= 0 || n_out <= 0) return IAF_ERR_SHAPE;
     iaf_conv3x3* c = new (std::nothrow) iaf_conv3x3();
     if (!c) return (int)hipErrorOutOfMemory;
-    c->n_in = n_in; c->n_out = n_out; c->prepared = false;
+    c->n_in = n_in; c->n_out = n_out; c->prepared = false; c->mask_mode = mask_mode;
     c->generic = (n_in % 16 != 0 || n_out % 16 != 0 || n_in > 16 * PREP_MAXI);
     GemmLayer& L = c->L;
-    L.cin = n_in; L.cout = n_out; L.npair = 1; L.zerodiag = 0; L.full3x3 = true;
+    L.cin = n_in; L.cout = n_out; L.npair = 1; L.zerodiag = (mask_mode == 2) ? 1 : 0; L.full3x3 = (mask_mode == 0);
     L.nchunk = (n_in + 15) / 16; L.ncot = (n_out + 15) / 16;
     default_tuning(L, false);
     L.live_macs_per_px = L.dense_macs_per_px = 9.0 * n_in * n_out;
+    if (mask_mode) count_macs(L, n_in, n_out, L.zerodiag, 1);
     const size_t wfloats = c->generic ? (size_t)MAXTAPS * n_in * n_out : (size_t)L.nchunk * MAXTAPS * L.ncot * 256;
     int rc;
     if ((rc = (int)hipMalloc(&L.wp, wfloats * sizeof(float))) != 0 ||
@@ -2011,8 +2091,17 @@ extern "C" int iaf_conv3x3_prepare(iaf_conv3x3_t* c, const float* V, const float
         ga.nlayers = 1;
         GenPrepLayer& P = ga.L[0];
         P.V[0] = V; P.g[0] = g; P.b[0] = b; P.w = L.wp; P.bias = L.bias;
-        P.cin = L.cin; P.cout_each = L.cout; P.npair = 1; P.zerodiag = 0; P.ch_begin = 0; P.ntaps = MAXTAPS;
+        P.cin = L.cin; P.cout_each = L.cout; P.npair = 1; P.zerodiag = L.zerodiag; P.ch_begin = 0; P.ntaps = MAXTAPS;
+        P.mask9 = c->mask_mode ? 1 : 0;
         hipLaunchKernelGGL(iaf_generic_prep_kernel, dim3(L.cout), dim3(256), 0, (hipStream_t)stream, ga);
+    } else if (c->mask_mode) {    // the masked prep of the stack, one layer
+        PrepArgs a;
+        memset(&a, 0, sizeof(a));
+        a.nlayers = 1;
+        PrepLayer& P = a.L[0];
+        P.V[0] = V; P.g[0] = g; P.b[0] = b; P.wp = L.wp; P.bias = L.bias; P.variant = IAF_VARIANT_TF;
+        P.cin = L.cin; P.cout_each = L.cout; P.ncot = L.ncot; P.nchunk = L.nchunk; P.zerodiag = L.zerodiag; P.npair = 1;
+        hipLaunchKernelGGL(iaf_prep_kernel, dim3(L.ncot), dim3(256), 0, (hipStream_t)stream, a);
     } else {
         PrepLayer& P = *c->h_desc;
         memset(&P, 0, sizeof(P));
@@ -2030,7 +2119,7 @@ extern "C" int iaf_conv3x3_set_tuning(iaf_conv3x3_t* c, int nt, int pxt, int wco
     if (!c) return IAF_ERR_NULL;
     GemmLayer& L = c->L;
     if (nt == 0) { L.user_tuned = false; return IAF_OK; }     // back to the automatic choice
-    if (c->generic || !pick_kernel(nt, pxt, wco, ks, IN_NCHW, EPI_PLAIN)) return IAF_ERR_UNSUPPORTED;
+    if (c->generic || !pick_kernel(nt, pxt, wco, ks, IN_NCHW, c->mask_mode ? EPI_PLAIN5 : EPI_PLAIN)) return IAF_ERR_UNSUPPORTED;
     if (L.ncot % (nt * wco) != 0 || L.nchunk < ks) return IAF_ERR_UNSUPPORTED;
     L.nt = nt; L.pxt = pxt; L.wco = wco; L.ks = ks; L.user_tuned = true;
     return IAF_OK;
@@ -2079,15 +2168,22 @@ extern "C" int iaf_conv3x3_forward(iaf_conv3x3_t* c, const float* x, const float
         p.split_ptr[k] = outs[k < n_outs ? k : n_outs - 1];
     }
     if (!L.user_tuned) auto_shape(L, false, p.P, W);
-    conv_fn_t fn = pick_kernel(L.nt, L.pxt, L.wco, L.ks, IN_NCHW, EPI_PLAIN);
+    conv_fn_t fn = pick_kernel(L.nt, L.pxt, L.wco, L.ks, IN_NCHW, c->mask_mode ? EPI_PLAIN5 : EPI_PLAIN);
     if (!fn) return IAF_ERR_UNSUPPORTED;
     const int tm = 16 * L.pxt;
     p.wp = L.wp; p.bias = L.bias; p.lim = nullptr;
-    for (int t = 0; t < MAXTAPS; ++t) { p.tap_dh[t] = t / 3 - 1; p.tap_dw[t] = t % 3 - 1; }   // cross-correlation, SAME
-    p.halo_before = W + 1;
+    if (c->mask_mode) {     // the 5 live taps of the MADE-masked filter: look right / below only
+        static const int tf_dh[NTAPS] = {0, 0, 1, 1, 1}, tf_dw[NTAPS] = {0, 1, -1, 0, 1};
+        for (int t = 0; t < NTAPS; ++t) { p.tap_dh[t] = tf_dh[t]; p.tap_dw[t] = tf_dw[t]; }
+        p.halo_before = 0;
+        p.nslot = tm + W + 1;
+    } else {
+        for (int t = 0; t < MAXTAPS; ++t) { p.tap_dh[t] = t / 3 - 1; p.tap_dw[t] = t % 3 - 1; }   // cross-correlation, SAME
+        p.halo_before = W + 1;
+        p.nslot = tm + 2 * (W + 1);
+    }
     p.cin = L.cin; p.cout = L.cout; p.nchunk = L.nchunk; p.ncot = L.ncot;
     p.cp = L.cin + 8;
-    p.nslot = tm + 2 * (W + 1);
     const size_t lds = conv_lds_bytes(L, W);
     if (lds > 160 * 1024) return IAF_ERR_UNSUPPORTED;
     int rc = raise_lds_cap(fn, lds);
@@ -2147,8 +2243,25 @@ extern "C" int iaf_conv3x3_autotune(iaf_conv3x3_t* c, const float* x, const floa
 extern "C" int iaf_conv3x3_work(const iaf_conv3x3_t* c, int B, int H, int W, double* flops, double* bytes) {
     if (!c) return IAF_ERR_NULL;
     const double P = (double)B * H * W;
-    if (flops) *flops = 2.0 * 9.0 * c->n_in * c->n_out * P;
+    if (flops) *flops = 2.0 * c->L.live_macs_per_px * P;
     // input + output activations once, raw V/g/b once
     if (bytes) *bytes = 4.0 * (P * (c->n_in + c->n_out) + 9.0 * c->n_in * c->n_out + 2.0 * c->n_out);
     return IAF_OK;
+}
+
+extern "C" int iaf_datainit_normalize(const float* x_init, const float* add, float* y, float* g, float* b, int B, int C,
+                                      int HW, float init_scale, void* stream) {
+    if (!x_init || !g || !b) return IAF_ERR_NULL;
+    if (B <= 0 || C <= 0 || HW <= 0) return IAF_ERR_SHAPE;
+    hipLaunchKernelGGL(iaf_datainit_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x_init, add, y, g, b, B, C, HW, init_scale);
+    return (int)hipGetLastError();
+}
+
+extern "C" int iaf_discretized_logistic(const float* mean, const float* logscale, int logscale_is_scalar, const float* sample,
+                                        float* out, int B, size_t n_per_row, float binsize, void* stream) {
+    if (!mean || !logscale || !sample || !out) return IAF_ERR_NULL;
+    if (B <= 0 || n_per_row == 0 || !(binsize > 0.f)) return IAF_ERR_SHAPE;
+    hipLaunchKernelGGL(iaf_disc_logistic_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, mean, logscale,
+                       logscale_is_scalar ? 1 : 0, sample, out, n_per_row, binsize);
+    return (int)hipGetLastError();
 }

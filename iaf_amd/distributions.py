@@ -96,3 +96,22 @@ class StreamingLowerBound(object):
         _capi.check(_capi.lib().iaf_lowerbound_stream_finalize(_ptr(self.run_max), _ptr(self.run_sum), _ptr(out),
                                                                self.n, self.k, _stream()))
         return out
+
+
+def discretized_logistic(mean, logscale, binsize=1 / 256.0, sample=None):
+    """distributions.py:28-32 (call site tf_train.py:210: logscale is the scalar variable dec_log_stdv).
+    Returns the log-likelihood summed over every axis but the first, [B]."""
+    _check_act(mean, "mean")
+    _check_act(sample, "sample", mean.shape)
+    if not isinstance(logscale, torch.Tensor):
+        logscale = torch.full((1,), float(logscale), device=mean.device, dtype=torch.float32)
+    scalar = logscale.numel() == 1
+    if not scalar:
+        _check_act(logscale, "logscale", mean.shape)
+    else:
+        logscale = logscale.reshape(1).contiguous()
+    B = int(mean.shape[0])
+    out = torch.empty((B,), device=mean.device, dtype=torch.float32)
+    _capi.check(_capi.lib().iaf_discretized_logistic(_ptr(mean), _ptr(logscale), 1 if scalar else 0, _ptr(sample), _ptr(out), B,
+                                                     mean.numel() // B, float(binsize), _stream()))
+    return out

@@ -385,10 +385,15 @@ class WNConv2d(object):
     (tf_train.py:35-44, 52-54, 87-94) is fused into the call: ELU on the input, channel concat of two inputs,
     channel split of the output, and the residual `res + 0.1*y`."""
 
-    def __init__(self, n_in, n_out):
-        self.n_in, self.n_out = int(n_in), int(n_out)
+    def __init__(self, n_in, n_out, ar_mask=None):
+        """ar_mask: None = plain conv2d; False / True = ar_conv2d with zerodiagonal=False / True (layers.py:144-154)."""
+        self.n_in, self.n_out, self.ar_mask = int(n_in), int(n_out), ar_mask
         self._h = ctypes.c_void_p()
-        _capi.check(_capi.lib().iaf_conv3x3_create(ctypes.byref(self._h), self.n_in, self.n_out))
+        if ar_mask is None:
+            _capi.check(_capi.lib().iaf_conv3x3_create(ctypes.byref(self._h), self.n_in, self.n_out))
+        else:
+            _capi.check(_capi.lib().iaf_conv3x3_create_masked(ctypes.byref(self._h), self.n_in, self.n_out,
+                                                              1 if ar_mask else 0))
         self._tuned, self._cur_tune = {}, None      # (B,H,W) -> launch shape found by autotune
         self._prep_key = None
         self._keepalive = None
@@ -414,6 +419,22 @@ class WNConv2d(object):
 
     def set_tuning(self, nt, pxt, wco, ks):
         _capi.check(_capi.lib().iaf_conv3x3_set_tuning(self._h, nt, pxt, wco, ks))
+
+    def init(self, x, V, init_scale=0.1, x2=None, elu_input=False, add=None):
+        """Data-dependent initialisation, the init=True branch of conv2d (layers.py:38-51).  Returns (y, g, b):
+        y = scale*(x_init - mean) [+ add], g = log(scale)/3, b = -mean*scale with the moments of
+        x_init = conv(x, l2_normalize(mask*V)) over (N,H,W).  Leaves the conv prepared with (V, g, b)."""
+        zeros = torch.zeros(self.n_out, device=V.device, dtype=torch.float32)
+        self.prepare(V, zeros, zeros.clone(), force=True)      # exp(0) * l2_normalize(mask*V), bias 0  (:44-45)
+        x_init = self(x, x2=x2, elu_input=elu_input)[0]
+        B, _, H, W = x_init.shape
+        if add is not None:
+            _check_act(add, "add", tuple(x_init.shape))
+        g, b = torch.empty_like(zeros), torch.empty_like(zeros)
+        _capi.check(_capi.lib().iaf_datainit_normalize(_ptr(x_init), _ptr(add), _ptr(x_init), _ptr(g), _ptr(b), B,
+                                                       self.n_out, H * W, float(init_scale), _stream()))
+        self.prepare(V, g, b, force=True)
+        return x_init, g, b
 
     def work(self, B, H, W):
         fl, by = ctypes.c_double(), ctypes.c_double()
@@ -464,21 +485,38 @@ class WNConv2d(object):
         return out
 
 
-def conv2d(name, x, num_filters, filter_size=(3, 3), stride=(1, 1), pad="SAME", init=False, mask=None, store=None,
-           **_):
-    """Drop-in for tf_utils/layers.py:31-64 (non-init branch) for the shape IAFLayer uses at its non-downsampling
-    levels: 3x3, stride 1, SAME, no mask.  Variables <scope>/<name>/{V,g,b} come from `store`."""
-    if tuple(filter_size) != (3, 3) or tuple(stride) != (1, 1) or pad != "SAME" or mask is not None or init:
-        raise ValueError("the gfx950 engine implements conv2d for filter 3x3, stride 1, SAME, mask=None, init=False")
-    st = store or _DEFAULT_STORE
+def _conv_op(name, x, num_filters, ar_mask, init, init_scale, st):
     n_in = int(x.shape[1])
     with variable_scope(name, st):
-        key = ("conv2d", st.full_name(""), n_in, int(num_filters))
+        key = ("conv2d", st.full_name(""), n_in, int(num_filters), ar_mask)
         conv = st._stacks.get(key)
         if conv is None:
-            conv = st._stacks[key] = WNConv2d(n_in, num_filters)
+            conv = st._stacks[key] = WNConv2d(n_in, num_filters, ar_mask)
+        if init:      # layers.py:38-51: V keeps its initial value, g and b are created from the data
+            y, g, b = conv.init(x, st.get("V"), init_scale)
+            st.set(st.full_name("g"), g)
+            st.set(st.full_name("b"), b)
+            return y
         conv.prepare(st.get("V"), st.get("g"), st.get("b"))
     return conv(x)[0]
+
+
+def conv2d(name, x, num_filters, filter_size=(3, 3), stride=(1, 1), pad="SAME", init_scale=0.1, init=False, mask=None,
+           store=None, **_):
+    """Drop-in for tf_utils/layers.py:31-64 for the shape IAFLayer uses at its non-downsampling levels: 3x3, stride 1,
+    SAME, no mask (masked: ar_conv2d below).  Variables <scope>/<name>/{V,g,b} come from `store`; with init=True V must
+    hold its initial value and g, b are written to the store."""
+    if tuple(filter_size) != (3, 3) or tuple(stride) != (1, 1) or pad != "SAME" or mask is not None:
+        raise ValueError("the gfx950 engine implements conv2d for filter 3x3, stride 1, SAME, mask=None")
+    return _conv_op(name, x, num_filters, None, init, init_scale, store or _DEFAULT_STORE)
+
+
+def ar_conv2d(name, x, num_filters, filter_size=(3, 3), stride=(1, 1), pad="SAME", init_scale=1., zerodiagonal=True,
+              init=False, store=None, **_):
+    """Drop-in for tf_utils/layers.py:144-154: one MADE-masked weight-normed conv."""
+    if tuple(filter_size) != (3, 3) or tuple(stride) != (1, 1) or pad != "SAME":
+        raise ValueError("the gfx950 engine implements ar_conv2d for filter 3x3, stride 1, SAME")
+    return _conv_op(name, x, num_filters, bool(zerodiagonal), init, init_scale, store or _DEFAULT_STORE)
 
 
 class PrepBatch(object):
@@ -548,7 +586,29 @@ def _is_elu(nl):
     return nl in ("elu", None) or getattr(nl, "__name__", "") == "elu"
 
 
-def ar_multiconv2d(name, x, context, n_h, n_out, nl="elu", store=None, **_):
+def _ar_multiconv2d_init(x, context, n_h, n_out, st):
+    """layers.py:158-166 with init=True arriving through arg_scope (tf_train.py:175): every masked conv is initialised
+    from the data flowing through the stack; the context is added to the first layer's NORMALISED output (:163-164)."""
+    h, first = x, True
+    for i, size in enumerate(n_h):
+        with variable_scope("layer_%d" % i, st):
+            conv = WNConv2d(int(h.shape[1]), size, ar_mask=False)
+            h, g, b = conv.init(h, st.get("V"), 1.0, elu_input=not first, add=context if i == 0 else None)
+            st.set(st.full_name("g"), g)
+            st.set(st.full_name("b"), b)
+        first = False
+    outs = []
+    for i, size in enumerate(n_out):
+        with variable_scope("layer_out_%d" % i, st):
+            conv = WNConv2d(int(h.shape[1]), size, ar_mask=True)
+            y, g, b = conv.init(h, st.get("V"), 1.0, elu_input=not first)
+            st.set(st.full_name("g"), g)
+            st.set(st.full_name("b"), b)
+            outs.append(y)
+    return outs
+
+
+def ar_multiconv2d(name, x, context, n_h, n_out, nl="elu", store=None, init=False, **_):
     """Drop-in for tf_utils/layers.py:158-166 (call site tf_train.py:69):
         x = ar_multiconv2d("ar_multiconv2d", z, context, [h_size, h_size], [z_size, z_size])
     Variables are looked up as <current scope>/<name>/layer_{i}/{V,g,b} etc. in `store`."""
@@ -556,6 +616,9 @@ def ar_multiconv2d(name, x, context, n_h, n_out, nl="elu", store=None, **_):
         raise ValueError("the gfx950 engine fuses the ELU non-linearity only (layers.py:159 default)")
     st = store or _DEFAULT_STORE
     n_z = int(x.shape[1])
+    if init:
+        with variable_scope(name, st):
+            return _ar_multiconv2d_init(x, context, list(n_h), list(n_out), st)
     with variable_scope(name, st):
         prefix = st.full_name("")
         key = (prefix, n_z, tuple(n_h), tuple(n_out))

@@ -213,6 +213,9 @@ typedef struct iaf_conv3x3 iaf_conv3x3_t;
 #define IAF_CONV3X3_MAX_OUTS 6
 
 int iaf_conv3x3_create(iaf_conv3x3_t** out, int n_in, int n_out);
+/* one MADE-masked conv on its own: ar_conv2d(name, x, num_filters, zerodiagonal=...) (tf_utils/layers.py:144-154),
+ * same object type and calls as the plain conv.  IAF_ERR_NOT_MULTIPLE unless n_in | n_out or n_out | n_in (:116). */
+int iaf_conv3x3_create_masked(iaf_conv3x3_t** out, int n_in, int n_out, int zerodiagonal);
 int iaf_conv3x3_destroy(iaf_conv3x3_t* c);
 /* weight normalisation + packing (one launch); call again whenever V/g/b change */
 int iaf_conv3x3_prepare(iaf_conv3x3_t* c, const float* V, const float* g, const float* b, void* stream);
@@ -229,6 +232,22 @@ int iaf_conv3x3_autotune(iaf_conv3x3_t* c, const float* x, const float* x2, int 
                          int W, int reps, void* stream, int* best_shape, float* best_us);
 /* FLOPs (2*9*n_in*n_out per pixel) and minimum bytes (activations in+out, V/g/b once) of one forward call */
 int iaf_conv3x3_work(const iaf_conv3x3_t* c, int B, int H, int W, double* flops, double* bytes);
+
+/* ------------------------------------------------------------------------------------------
+ * Data-dependent initialisation, the init=True branch of conv2d (tf_utils/layers.py:38-51).  The caller runs the conv
+ * with g = 0, b = 0 (so the prepared weights are l2_normalize(mask*V), :44-45) to get x_init [B,C,H,W]; this call then
+ * computes, per channel over (N,H,W):  scale = init_scale / sqrt(var + 1e-10),  g = log(scale)/3,  b = -mean*scale,
+ * y = scale * (x_init - mean) [+ add]  (:47-51; y may be NULL or alias x_init; `add`, optional, is the context that
+ * ar_multiconv2d adds to its first layer, layers.py:163-164).
+ * ------------------------------------------------------------------------------------------ */
+int iaf_datainit_normalize(const float* x_init, const float* add, float* y, float* g, float* b, int B, int C, int HW,
+                           float init_scale, void* stream);
+
+/* discretized_logistic(mean, logscale, binsize, sample) (tf_utils/distributions.py:28-32; tf_train.py:210):
+ * out[b] = sum over the n_per_row elements of row b.  logscale: one device scalar (logscale_is_scalar, the reference's
+ * dec_log_stdv) or a tensor shaped like mean. */
+int iaf_discretized_logistic(const float* mean, const float* logscale, int logscale_is_scalar, const float* sample,
+                             float* out, int B, size_t n_per_row, float binsize, void* stream);
 
 #ifdef __cplusplus
 }

@@ -204,3 +204,96 @@ def test_autotuned_layer_matches_reference_golden(amd, golden_dir):
         np.testing.assert_allclose(host(out), g[name + "/output"], atol=ATOL, rtol=0)
         np.testing.assert_allclose(host(kl_cost), g[name + "/kl_cost"], atol=2e-3, rtol=1e-4)
     assert layer.up_conv1._tuned and layer.down_conv2._tuned
+
+
+# ---------------------------------------------------------------- ar_conv2d on its own, data-dependent init, likelihood
+@pytest.mark.parametrize("shape", [(2, 32, 160, False, 8, 8), (2, 160, 32, True, 8, 8), (3, 64, 64, True, 5, 7),
+                                   (3, 64, 64, False, 5, 7), (2, 4, 8, False, 6, 6), (2, 8, 4, True, 6, 6)],
+                         ids=lambda s: "B%d_%dto%d_zd%d_%dx%d" % s)
+def test_ar_conv2d_single_vs_oracle(amd, shape):
+    """one masked conv through the operator API (layers.py:144-154), both mask variants, MFMA and fallback paths"""
+    B, n_in, n_out, zd, H, W = shape
+    rng = np.random.RandomState(77)
+    p = gi.conv_params(rng, n_in, n_out)
+    x = rng.standard_normal((B, n_in, H, W))
+    store = amd.VariableStore()
+    for k, v in p.items():
+        store.set("m/c/" + k, dev(v))
+    with amd.variable_scope("m", store):
+        y = amd.ar_conv2d("c", dev(x), n_out, zerodiagonal=zd, store=store)
+    e = O.ar_conv2d(f32(x), f32(p["V"]), f32(p["g"]), f32(p["b"]), zerodiagonal=zd)
+    np.testing.assert_allclose(host(y), e, atol=ATOL, rtol=0)
+
+
+def test_data_dependent_init_vs_reference_golden(amd, golden_dir):
+    """the init=True branch (layers.py:38-51) on the reference's own output: ar_conv2d("c", x, 16, zerodiagonal=False,
+    init_scale=0.7) under arg_scope(init=True)"""
+    g = np.load(os.path.join(golden_dir, "init_ar_conv.npz"))
+    store = amd.VariableStore()
+    store.set("c/V", dev(g["V0"]))
+    y = amd.ar_conv2d("c", dev(g["x"]), 16, zerodiagonal=False, init_scale=0.7, init=True, store=store)
+    np.testing.assert_allclose(host(y), g["y"], atol=ATOL, rtol=0)
+    np.testing.assert_allclose(host(store.vars["c/g"]), g["g"], atol=1e-5, rtol=0)
+    np.testing.assert_allclose(host(store.vars["c/b"]), g["b"], atol=1e-5, rtol=0)
+    # the non-init branch with the variables just created (the reference's quirk: g = log(scale)/3 but w = exp(g)*...)
+    y2 = amd.ar_conv2d("c", dev(g["x"]), 16, zerodiagonal=False, store=store)
+    e2 = O.ar_conv2d(f32(g["x"]), f32(g["V0"]), g["g"], g["b"], zerodiagonal=False)
+    np.testing.assert_allclose(host(y2), e2, atol=ATOL, rtol=0)
+
+
+@pytest.mark.parametrize("shape", [(4, 32, 160, 8, 8), (3, 4, 8, 6, 6)], ids=lambda s: "B%d_z%d_h%d_%dx%d" % s)
+def test_ar_multiconv2d_init_vs_oracle(amd, shape):
+    """ar_multiconv2d with init=True arriving via arg_scope (tf_train.py:175, layers.py:160): layer-by-layer
+    data-dependent init; the oracle composes layers.py:38-51 the way layers.py:161-166 chains it"""
+    B, zs, hs, H, W = shape
+    rng = np.random.RandomState(31)
+    z, ctx = rng.standard_normal((B, zs, H, W)), rng.standard_normal((B, hs, H, W))
+    V = {"layer_0": 0.05 * rng.standard_normal((3, 3, zs, hs)), "layer_1": 0.05 * rng.standard_normal((3, 3, hs, hs)),
+         "layer_out_0": 0.05 * rng.standard_normal((3, 3, hs, zs)), "layer_out_1": 0.05 * rng.standard_normal((3, 3, hs, zs))}
+    store = amd.VariableStore()
+    for k, v in V.items():
+        store.set("s/" + k + "/V", dev(v))
+    outs = amd.ar_multiconv2d("s", dev(z), dev(ctx), [hs, hs], [zs, zs], store=store, init=True)
+    h = f32(z)
+    exp_gb = {}
+    for i, nm in enumerate(["layer_0", "layer_1"]):
+        mask = O.get_conv_ar_mask(3, 3, h.shape[1], hs, False)
+        y, g_, b_ = O.conv2d_init(h, f32(V[nm]), init_scale=1.0, mask=mask)
+        exp_gb[nm] = (g_, b_)
+        if i == 0:
+            y = y + f32(ctx)
+        h = O.elu(y)
+    for i, nm in enumerate(["layer_out_0", "layer_out_1"]):
+        mask = O.get_conv_ar_mask(3, 3, hs, zs, True)
+        y, g_, b_ = O.conv2d_init(h, f32(V[nm]), init_scale=1.0, mask=mask)
+        exp_gb[nm] = (g_, b_)
+        np.testing.assert_allclose(host(outs[i]), y, atol=2e-4, rtol=0)      # unit-variance outputs, 3 normalisations deep
+    for nm, (g_, b_) in exp_gb.items():
+        np.testing.assert_allclose(host(store.vars["s/" + nm + "/g"]), g_, atol=2e-5, rtol=0)
+        np.testing.assert_allclose(host(store.vars["s/" + nm + "/b"]), b_, atol=2e-4, rtol=0)
+    # the initialised stack then runs through the fused engine path and reproduces the init-mode outputs
+    again = amd.ar_multiconv2d("s", dev(z), dev(ctx), [hs, hs], [zs, zs], store=store)
+    exp = O.ar_multiconv2d(f32(z), f32(ctx), {k[2:]: host(v) for k, v in store.vars.items()}, [hs, hs], [zs, zs])
+    np.testing.assert_allclose(host(again[0]), exp[0], atol=ATOL, rtol=0)
+
+
+def test_discretized_logistic_vs_reference_golden(amd, golden_dir):
+    g = np.load(os.path.join(golden_dir, "distributions.npz"))
+    out = amd.discretized_logistic(dev(g["dl_mean"]), -1.3, sample=dev(g["dl_sample"]))
+    np.testing.assert_allclose(host(out), g["dl_logp"], rtol=2e-5, atol=1e-3)
+
+
+def test_discretized_logistic_cifar_shape_vs_oracle(amd):
+    """tf_train.py:210 shape: x, orig_x [B,3,32,32], dec_log_stdv a scalar variable"""
+    rng = np.random.RandomState(8)
+    B = 32
+    mean = rng.uniform(-0.6, 0.6, (B, 3, 32, 32))
+    sample = np.floor(rng.uniform(0, 256, (B, 3, 32, 32))) / 256.0 - 0.5
+    ls = torch.tensor([-2.0], device="cuda")
+    out = amd.discretized_logistic(dev(mean), ls, sample=dev(sample))
+    e = O.discretized_logistic(f32(mean), -2.0, f32(sample))
+    np.testing.assert_allclose(host(out), e, rtol=2e-5, atol=1e-2)
+    # per-element logscale tensor
+    lst = rng.uniform(-2.5, -1.0, mean.shape)
+    out = amd.discretized_logistic(dev(mean), dev(lst), sample=dev(sample))
+    np.testing.assert_allclose(host(out), O.discretized_logistic(f32(mean), f32(lst), f32(sample)), rtol=2e-5, atol=1e-2)
