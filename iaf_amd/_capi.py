@@ -36,6 +36,9 @@ SIGNATURES = {
                                                   ctypes.c_int, ctypes.c_int, _vp, ctypes.c_size_t, _vp]),
     "iaf_step_forward": (ctypes.c_int, [_vp, _c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_int,
                                         ctypes.c_int, ctypes.c_int, _vp, ctypes.c_size_t, _vp]),
+    "iaf_step_inverse": (ctypes.c_int, [_vp, _c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_int, _vp, ctypes.c_size_t, ctypes.c_int, ctypes.c_float, ctypes.c_int, _vp,
+                                        ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_float)]),
     "iaf_stack_set_training": (ctypes.c_int, [_vp, ctypes.c_int]),
     "iaf_stack_train_workspace_bytes": (ctypes.c_size_t, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "iaf_step_forward_train": (ctypes.c_int, [_vp, _c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_int,

@@ -33,6 +33,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 #define MODE_RAW 0        // out0 = m_raw, out1 = s_raw                         (layers.py:166)
 #define MODE_IAF 1        // out0 = (z-0.1m)/exp(0.1s), out1 = 0.1s             (tf_train.py:70-72)
 #define MODE_POSTERIOR 2  // MODE_IAF on z0 rebuilt from the posterior inputs, plus kl elements
+#define MODE_INVERSE 5    // one Jacobi sweep of the inverse flow: out0 = zin*exp(0.1s) + 0.1m, out1 = 0.1s (x = current z0 estimate)
 // backward (data gradient) modes of EPI_DGRAD: the same kernel run on the transposed packed weights with the tap
 // table negated computes dX = W^T * dY; the epilogue applies what autodiff applies next.  (Its own compile-time
 // epilogue: as runtime branches inside EPI_HIDDEN these modes cost the forward kernels ~1800 cycles.)
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
             } else {
                 pbias[2 * i] = *(const f32x4*)(p.bias + (cot0 + 2 * u) * 16 + 4 * kk);
                 pbias[2 * i + 1] = *(const f32x4*)(p.bias + (cot0 + 2 * u + 1) * 16 + 4 * kk);
-                if (p.mode == MODE_IAF) {
+                if (p.mode == MODE_IAF || p.mode == MODE_INVERSE) {
                     const size_t zb = ((size_t)bimg * (p.cout >> 1) + ((cot0 + 2 * u) >> 1) * 16 + 4 * kk) * HW + pp;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) pre0[i][r] = p.zin[zb + (size_t)r * HW];
@@ -646,6 +647,10 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
                         const float m = m_raw * 0.1f, s = s_raw * 0.1f;        // tf_train.py:70
                         p.out0[idx] = (pre0[i][r] - m) / __expf(s);            // tf_train.py:71
                         p.out1[idx] = s;                                        // tf_train.py:72 (logqs += s)
+                    } else if (p.mode == MODE_INVERSE) {
+                        const float m = m_raw * 0.1f, s = s_raw * 0.1f;
+                        p.out0[idx] = pre0[i][r] * __expf(s) + m;              // tf_train.py:71 solved for the input
+                        p.out1[idx] = s;
                     } else {
                         const float m = m_raw * 0.1f, s = s_raw * 0.1f;
                         const float mean = p.qm[idx] + p.rm[idx];               // tf_train.py:57

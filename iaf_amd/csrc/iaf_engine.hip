@@ -349,6 +349,18 @@ __global__ __launch_bounds__(256) void iaf_kl_finish_kernel(const float* S, floa
 // ---------------------------------------------------------------------------------------------
 // elementwise distributions (tf_utils/distributions.py)
 // ---------------------------------------------------------------------------------------------
+// max |a - b| over n elements -> *out (float bits; non-negative floats order like unsigned ints).  NaN counts as +inf.
+__global__ __launch_bounds__(256) void iaf_maxdiff_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n,
+                                                         unsigned* out) {
+    float m = 0.f;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float d = fabsf(a[i] - b[i]);
+        m = (d > m || d != d) ? (d != d ? __builtin_inff() : d) : m;
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
 __global__ void iaf_gauss_sample_kernel(const float* mean, const float* logvar, const float* noise, float* out, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         out[i] = mean[i] + expf(0.5f * logvar[i]) * noise[i];
@@ -886,6 +898,7 @@ __global__ __launch_bounds__(256) void iaf_generic_conv_kernel(GenConvP p) {
         if (p.mode == MODE_RAW) { p.out0[i] = m_raw; p.out1[i] = s_raw; continue; }
         const float m = m_raw * 0.1f, sgm = s_raw * 0.1f;
         if (p.mode == MODE_IAF) { p.out0[i] = (p.zin[i] - m) / __expf(sgm); p.out1[i] = sgm; continue; }
+        if (p.mode == MODE_INVERSE) { p.out0[i] = p.zin[i] * __expf(sgm) + m; p.out1[i] = sgm; continue; }
         const float mean = p.qm[i] + p.rm[i], logvar = 2.f * (p.ql[i] + p.rl[i]);
         const float z0 = mean + __expf(0.5f * logvar) * p.eps[i];
         const float d0 = z0 - mean;
@@ -1569,6 +1582,58 @@ extern "C" int iaf_step_forward(iaf_stack_t* s, const float* z, const float* con
     p.B = B; p.H = H; p.W = W; p.HW = H * W; p.P = B * H * W;
     p.x = z; p.zin = z; p.out0 = z_new; p.out1 = logsd; p.mode = MODE_IAF;
     return run_stack(s, p, IN_NCHW, context, nullptr, ws, (hipStream_t)stream);
+}
+
+// Inverse of the IAF step: given the flow OUTPUT z, find z0 with (z0 - m(z0))/exp(s(z0)) = z.
+// m, s at a position depend only on z0 at earlier positions of the autoregressive order, so the Jacobi iteration
+//   z0 <- z * exp(s(z0)) + m(z0)
+// fixes at least one more position per sweep (exact after at most H*W*n_z sweeps) and, because the reference scales
+// m and s by 0.1, contracts to fp32 precision in a handful of sweeps; every sweep is one full-width run of the conv
+// stack instead of H*W*n_z dependent scalar steps.
+extern "C" int iaf_step_inverse(iaf_stack_t* s, const float* z, const float* context, float* z0, float* logsd, int B, int H,
+                                int W, void* workspace, size_t workspace_bytes, int max_sweeps, float tol, int check_every,
+                                void* stream, int* sweeps_done, float* residual) {
+    int rc = check_dims(s, B, H, W);
+    if (rc) return rc;
+    if (!z || !z0 || !logsd || (s->depth_ar > 0 && !context)) return IAF_ERR_NULL;
+    if (max_sweeps <= 0 || check_every < 0 || tol < 0.f) return IAF_ERR_SHAPE;
+    Ws ws;
+    if ((rc = carve_ws(s, B, H, W, workspace, workspace_bytes, &ws))) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = (size_t)B * s->n_z * H * W;
+    // ping-pong between the caller's z0 and the workspace's kl_elem plane, arranged so that the last sweep lands in z0
+    float* buf[2] = {z0, ws.kl_elem};
+    unsigned* d_res = (unsigned*)ws.rowsum;               // [B*n_z] floats are free during the inverse: first word
+    const bool checking = (tol > 0.f && check_every > 0);
+    ConvP p;
+    memset(&p, 0, sizeof(p));
+    p.B = B; p.H = H; p.W = W; p.HW = H * W; p.P = B * H * W;
+    p.zin = z; p.out1 = logsd; p.mode = MODE_INVERSE;
+    const float* cur = z;                                 // initial guess z0 = z (m = 0, s = 0)
+    int k = 0, done = 0;
+    float res = -1.f;
+    while (done < max_sweeps) {
+        // choose the target so that parity works out if we stop at max_sweeps; an early stop may need one copy
+        float* dst = buf[(max_sweeps - 1 - done) & 1];
+        p.x = cur; p.out0 = dst;
+        if ((rc = run_stack(s, p, IN_NCHW, context, nullptr, ws, st))) return rc;
+        ++done;
+        if (checking && (++k == check_every || done == max_sweeps)) {
+            k = 0;
+            HIP_TRY(hipMemsetAsync(d_res, 0, sizeof(unsigned), st));
+            hipLaunchKernelGGL(iaf_maxdiff_kernel, ew_grid(n), dim3(256), 0, st, (const float*)dst, cur, n, d_res);
+            unsigned bits = 0;
+            HIP_TRY(hipMemcpyAsync(&bits, d_res, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            memcpy(&res, &bits, sizeof(float));
+            if (res <= tol) { cur = dst; break; }
+        }
+        cur = dst;
+    }
+    if (cur != z0) HIP_TRY(hipMemcpyAsync(z0, cur, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (sweeps_done) *sweeps_done = done;
+    if (residual) *residual = res;
+    return IAF_OK;
 }
 
 extern "C" int iaf_posterior_block_forward(iaf_stack_t* s, const float* qz_mean, const float* qz_logsd,

@@ -257,6 +257,19 @@ class ARStack(object):
                                                  B, H, W, _ptr(ws), need, _stream()))
         return z_new, logsd
 
+    def iaf_step_inverse(self, z, context, max_sweeps=64, tol=1e-6, check_every=4, out=None):
+        """The inverse of iaf_step: z0 with iaf_step(z0, context)[0] == z (density evaluation of an arbitrary z; not in
+        the reference).  Jacobi sweeps z0 <- z*exp(s(z0)) + m(z0); returns (z0, logsd, sweeps, residual).
+        tol=0 runs exactly max_sweeps sweeps without synchronising (H*W*n_z sweeps are exact for any weights)."""
+        B, H, W = self._dims(z, context)
+        z0, logsd = out if out is not None else (torch.empty_like(z), torch.empty_like(z))
+        ws, need = self.workspace(B, H, W, z.device)
+        n, res = ctypes.c_int(), ctypes.c_float()
+        _capi.check(_capi.lib().iaf_step_inverse(self._h, _ptr(z), _ptr(context), _ptr(z0), _ptr(logsd), B, H, W,
+                                                 _ptr(ws), need, int(max_sweeps), float(tol), int(check_every), _stream(),
+                                                 ctypes.byref(n), ctypes.byref(res)))
+        return z0, logsd, n.value, res.value
+
     # -- training (SURVEY 8f-1) ---------------------------------------------------------------------
     def set_training(self, on=True):
         """allocate the transposed weight packs used by the data-gradient kernels; re-prepare afterwards"""

@@ -87,6 +87,20 @@ int iaf_ar_multiconv2d_forward(iaf_stack_t* s, const float* z, const float* cont
 int iaf_step_forward(iaf_stack_t* s, const float* z, const float* context, float* z_new, float* logsd,
                      int B, int H, int W, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Inverse of the IAF step: given the flow output z (what iaf_step_forward wrote to z_new) and the context, recover
+ * z0 with (z0 - m(z0))/exp(s(z0)) == z, and logsd = s(z0).  The reference never inverts the flow (sample mode bypasses
+ * it, tf_train.py:60-66) -- this is the density-evaluation direction SURVEY D3 / 8f-4 lists; it is checked by round trip
+ * against iaf_step_forward.  Method: Jacobi sweeps z0 <- z*exp(s(z0)) + m(z0), each one full run of the conv stack; a
+ * sweep finalises at least one more position of the autoregressive order, so H*W*n_z sweeps are exact for any weights,
+ * and with the reference's 0.1 scaling a handful reach fp32 precision.
+ *   max_sweeps  upper bound (and the exact count when tol == 0: then the call never synchronises and can be captured);
+ *   tol > 0     stop when max|z0_new - z0_old| <= tol, tested every check_every sweeps (each test synchronises);
+ *   sweeps_done / residual (optional): sweeps run, last tested max update (-1 if never tested).
+ * z0 must not alias z.  Workspace: iaf_stack_workspace_bytes. */
+int iaf_step_inverse(iaf_stack_t* s, const float* z, const float* context, float* z0, float* logsd, int B, int H, int W,
+                     void* workspace, size_t workspace_bytes, int max_sweeps, float tol, int check_every, void* stream,
+                     int* sweeps_done, float* residual);
+
 /* ------------------------------------------------------------------------------------------
  * Training.  The reference never writes a backward pass: TF autodiff derives it from the graph
  * (opt.compute_gradients, tf_train.py:138).  These entry points compute the same gradients for the IAF step.

@@ -545,3 +545,60 @@ def test_errors_mirror_reference(amd):
         stack.iaf_step(z.cpu(), ctx)                 # host tensor
     with pytest.raises(ValueError):
         stack.iaf_step(z, torch.zeros(1, 32, 4, 4, device="cuda"))   # wrong context channels
+
+
+# ---------------------------------------------------------------- inverse flow: round trips
+@pytest.mark.parametrize("shape", [(32, 32, 160, 2, 16, 16), (4, 32, 64, 1, 8, 8), (2, 64, 64, 4, 4, 4), (3, 4, 8, 2, 5, 5)],
+                         ids=lambda s: "B%d_z%d_h%d_d%d_%dx%d" % s)
+def test_inverse_flow_round_trip(amd, shape):
+    """iaf_step_inverse(iaf_step(z0)) == z0 and iaf_step(iaf_step_inverse(z)) == z, logsd identical both ways
+    (BASELINE configs[1] size first; reference-scale weights; the last shape runs on the generic kernels)"""
+    B, n_z, n_h, d, H, W = shape
+    params, z0, ctx = _rand_case(21, B, n_z, n_h, d, H, W)
+    stack = amd.ARStack(n_z, [n_h] * d)
+    stack.prepare(dev_params(params))
+    z, logsd = stack.iaf_step(dev(z0), dev(ctx))
+    back, logsd_b, sweeps, res = stack.iaf_step_inverse(z, dev(ctx), max_sweeps=200, tol=1e-6, check_every=2)
+    assert res <= 1e-6 and sweeps < 60, (sweeps, res)
+    np.testing.assert_allclose(host(back), f32(z0), atol=2e-5, rtol=0)
+    np.testing.assert_allclose(host(logsd_b), host(logsd), atol=2e-5, rtol=0)
+    # the other composition, from an arbitrary z
+    zt = dev(np.random.RandomState(5).standard_normal(z0.shape))
+    inv, _, _, _ = stack.iaf_step_inverse(zt, dev(ctx), max_sweeps=200, tol=1e-6, check_every=2)
+    again, _ = stack.iaf_step(inv, dev(ctx))
+    np.testing.assert_allclose(host(again), host(zt), atol=2e-5, rtol=0)
+    # the oracle's forward agrees at the recovered point
+    ez, _ = O.iaf_step(host(inv), f32(ctx), f32_params(params), [n_h] * d)
+    np.testing.assert_allclose(ez, host(zt), atol=ATOL, rtol=0)
+
+
+def test_inverse_flow_is_exact_after_one_sweep_per_position(amd):
+    """strong coupling (weights x30: the Jacobi map is no contraction) on a 2x2 image with n_z = 4: the iteration must
+    still be EXACT after H*W*n_z = 16 sweeps, because sweep t finalises every position of autoregressive depth <= t"""
+    B, n_z, n_h, d, H, W = 2, 4, 8, 2, 2, 2
+    params, z0, ctx = _rand_case(3, B, n_z, n_h, d, H, W)
+    for k in params:
+        if k.endswith("/g"):
+            params[k] = params[k] + np.log(30.0) / 3           # 3 convs deep: m, s about 30x larger
+    stack = amd.ARStack(n_z, [n_h] * d)
+    stack.prepare(dev_params(params))
+    z, _ = stack.iaf_step(dev(z0), dev(ctx))
+    few, _, _, _ = stack.iaf_step_inverse(z, dev(ctx), max_sweeps=3, tol=0.0)
+    assert np.abs(host(few) - f32(z0)).max() > 1e-3             # not converged yet: the coupling is strong
+    full, _, n, _ = stack.iaf_step_inverse(z, dev(ctx), max_sweeps=H * W * n_z, tol=0.0)
+    assert n == H * W * n_z
+    np.testing.assert_allclose(host(full), f32(z0), atol=1e-4 * max(1.0, np.abs(z0).max()), rtol=1e-4)
+
+
+def test_inverse_flow_theano_variant_round_trip(amd):
+    """the Theano statement looks left/above: the same Jacobi sweep inverts it (the order is mirrored, not the method)"""
+    B, n_z, n_h, d, H, W = 3, 32, 64, 2, 8, 8
+    rng = np.random.RandomState(12)
+    w = _theano_params(rng, "q", n_z, [n_h] * d)
+    z0, ctx = rng.standard_normal((B, n_z, H, W)), rng.standard_normal((B, n_h, H, W))
+    stack = amd.ARStack(n_z, [n_h] * d, variant="theano")
+    stack.prepare({k[2:]: dev(v) for k, v in w.items()})
+    z, logsd = stack.iaf_step(dev(z0), dev(ctx))
+    back, logsd_b, sweeps, res = stack.iaf_step_inverse(z, dev(ctx), max_sweeps=200, tol=1e-6, check_every=2)
+    assert res <= 1e-6
+    np.testing.assert_allclose(host(back), f32(z0), atol=2e-5, rtol=0)
