@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tune", type=str, default="", help="layer:nt,pxt,wco,ks;... launch-shape override")
+    ap.add_argument("--layers", action="store_true",
+                    help="widened workload (SURVEY 8f-4): whole IAFLayers (plain convs + posterior block), forward")
     ap.add_argument("--train", action="store_true",
                     help="extra mode (not the headline metric): data-parallel TRAINING step of the IAF posterior stack -- "
                          "posterior block forward + backward for every layer, one RCCL all-reduce of the flat gradient "
@@ -205,6 +207,134 @@ def train_bench(args, depths, dist, rank, n_gpus):
                        "parallelism": "dp%d (RCCL all-reduce of one flat gradient bucket)" % n_gpus}}))
 
 
+def layers_bench(args, depths, dist, rank, n_gpus):
+    """SURVEY 8f-4 widening: whole non-downsampling IAFLayers (tf_train.py:23-95), forward, mode "train": per step the
+    bottom-up pass (`up`, chained within a level) then the top-down pass (`down`, chained within a level) of
+    sum(depths) layers; all weight-norm reparametrisations re-derived every step in two batched launches."""
+    import golden_inputs as gi
+    import iaf_amd
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+    rng = np.random.RandomState(777 + rank)
+    wrng = np.random.RandomState(5)
+    zs, hs, B = args.n_z, args.n_h, args.batch
+    levels = []
+    for lvl, nlayer in enumerate(depths):
+        H = 16 >> lvl
+        L = []
+        for _ in range(nlayer):
+            p = {}
+            for nm, (ci, co) in (("up_conv1", (hs, 2 * zs + 2 * hs)), ("up_conv3", (hs, hs)),
+                                 ("down_conv1", (hs, 4 * zs + 2 * hs)), ("down_conv2", (hs + zs, hs))):
+                for k, v in gi.conv_params(wrng, ci, co).items():
+                    p[nm + "/" + k] = dev(v)
+            for k, v in gi.ar_multiconv2d_params(wrng, zs, [hs] * args.depth_ar, [zs, zs]).items():
+                p["ar_multiconv2d/" + k] = dev(v)
+            layer = iaf_amd.IAFLayer(zs, hs, depth_ar=args.depth_ar, kl_min=0.25)
+            layer.load(p)
+            L.append(dict(layer=layer, params=p, eps=dev(rng.standard_normal((B, zs, H, H)))))
+        levels.append(dict(H=H, layers=L, up_in=dev(rng.standard_normal((B, hs, H, H))),
+                           down_in=dev(rng.standard_normal((B, hs, H, H)))))
+    all_layers = [L for lv in levels for L in lv["layers"]]
+    prep_s = iaf_amd.PrepBatch([L["layer"].posterior.stack for L in all_layers])
+    prep_c = iaf_amd.ConvPrepBatch([c for L in all_layers for c in L["layer"].convs()])
+    splist = [iaf_amd.IAFLayer.stack_params(L["params"]) for L in all_layers]
+    cplist = [t for L in all_layers for t in iaf_amd.IAFLayer.conv_params(L["params"])]
+
+    def step(autotune=False):
+        if not args.cached_weights:
+            prep_s.run(splist)
+            prep_c.run(cplist)
+        outs = []
+        for lv in levels:                         # bottom-up (tf_train.py:188-192)
+            h = lv["up_in"]
+            for L in lv["layers"]:
+                h = L["layer"].up(h, autotune=autotune)
+        for lv in reversed(levels):               # top-down (tf_train.py:195-200)
+            h = lv["down_in"]
+            for L in reversed(lv["layers"]):
+                h, kl_obj, kl_cost = L["layer"].down(h, L["eps"], autotune=autotune)
+                outs.append((kl_obj, kl_cost))
+            outs.append(h)
+        return outs
+
+    stream = torch.cuda.Stream()
+    graph = None
+    with torch.cuda.stream(stream):
+        step()
+        step(autotune=True)                       # launch-shape search of the plain convs (cuDNN's algorithm search)
+        stream.synchronize()
+        if not args.no_graph:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                keep = step()
+        run = graph.replay if graph is not None else step
+
+        def barrier():
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        for _ in range(args.warmup):
+            run()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run()
+        barrier()
+        elapsed = time.perf_counter() - t0
+
+        # dominant kernel of this mode: down_conv1 (n_h -> 4 n_z + 2 n_h) at 16x16; 50 back-to-back launches per layer
+        # between one event pair on the launch stream
+        kt = []
+        for L in levels[0]["layers"]:
+            cv = L["layer"].down_conv1
+            x = levels[0]["down_in"]
+            call = lambda: cv(x, elu_input=True, split=[zs] * 4 + [hs] * 2)
+            call()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream)
+            for _ in range(50):
+                call()
+            b.record(stream)
+            b.synchronize()
+            kt.append(a.elapsed_time(b) / 50)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        return
+    cv = levels[0]["layers"][0]["layer"].down_conv1
+    fl, by = cv.work(B, 16, 16)
+    k_ms = float(np.mean(kt))
+    achieved = fl / (k_ms * 1e-3) / 1e12
+    total_fl = 0.0
+    for lv in levels:
+        for L in lv["layers"]:
+            total_fl += sum(c.work(B, lv["H"], lv["H"])[0] for c in L["layer"].convs())
+            total_fl += L["layer"].posterior.stack.step_work(B, lv["H"], lv["H"])["live_flops"]
+    print(json.dumps({
+        "metric": "IAFLayer forward samples/sec (up + down of every layer: 4 plain weight-normed convs + IAF posterior block)",
+        "value": n_gpus * B / (elapsed / args.steps), "unit": "samples/s", "n_gpus": n_gpus, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "cifar10 z_size=%d h_size=%d depths=%s depth_ar=%d bs=%d per GPU, kl_min=0.25: %d non-downsampling "
+                               "IAFLayers (tf_train.py:23-95), up pass then down pass, chained within a level"
+                               % (zs, hs, depths, args.depth_ar, B, len(all_layers)),
+                   "global_batch": n_gpus * B, "launch": "hipGraph replay" if graph is not None else "eager",
+                   "weights": "re-derived every step (2 batched launches)" if not args.cached_weights else "prepared once",
+                   "live_gflop_per_step": total_fl / 1e9,
+                   "model_tflops": total_fl / (elapsed / args.steps) / 1e12,
+                   "parallelism": "dp%d (batch-sharded replicas, no forward collective)" % n_gpus},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                     "kernel": "iaf_conv_kernel<.., EPI_PLAIN, 9 taps> (down_conv1 %d->%d, B=%d 16x16)" % (cv.n_in, cv.n_out, B),
+                     "avg_launch_us": 1e3 * k_ms, "launches_timed": 50 * len(kt), "flops_per_launch": fl,
+                     "bytes_per_launch": by, "hbm_frac_at_this_rate": (by / (k_ms * 1e-3) / 1e9) / PEAK_HBM_GBS,
+                     "timing": "HIP events on the launch stream around 50 back-to-back launches per 16x16 layer"}}))
+
+
 def main():
     args = parse()
     depths = [int(d) for d in args.depths.split(",") if d]
@@ -224,6 +354,11 @@ def main():
 
     import iaf_amd
     iaf_amd._capi.lib()           # fail loudly if the HIP engine is not built
+    if args.layers:
+        layers_bench(args, depths, dist, rank, n_gpus)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     if args.train:
         train_bench(args, depths, dist, rank, n_gpus)
         if dist is not None:

@@ -2180,6 +2180,81 @@ extern "C" int iaf_conv3x3_prepare(iaf_conv3x3_t* c, const float* V, const float
     return IAF_OK;
 }
 
+// weight prep of many plain convs in one launch (the four convs of every IAFLayer of a model): descriptors in device
+// memory, refreshed per run like iaf_prep_batch_run
+struct iaf_conv3x3_prep_batch {
+    int n, ntiles;
+    iaf_conv3x3** convs;
+    PrepLayer* h_layers;
+    PrepLayer* d_layers;
+    int* d_tile2layer;
+};
+
+extern "C" int iaf_conv3x3_prep_batch_destroy(iaf_conv3x3_prep_batch_t* b) {
+    if (!b) return IAF_ERR_NULL;
+    if (b->h_layers) (void)hipHostFree(b->h_layers);
+    if (b->d_layers) (void)hipFree(b->d_layers);
+    if (b->d_tile2layer) (void)hipFree(b->d_tile2layer);
+    free(b->convs);
+    delete b;
+    return IAF_OK;
+}
+
+extern "C" int iaf_conv3x3_prep_batch_create(iaf_conv3x3_prep_batch_t** out, iaf_conv3x3_t* const* convs, int n) {
+    if (!out || !convs) return IAF_ERR_NULL;
+    *out = nullptr;
+    if (n <= 0) return IAF_ERR_SHAPE;
+    iaf_conv3x3_prep_batch* b = new (std::nothrow) iaf_conv3x3_prep_batch();
+    if (!b) return (int)hipErrorOutOfMemory;
+    memset(b, 0, sizeof(*b));
+    b->n = n;
+    b->convs = (iaf_conv3x3**)calloc(n, sizeof(iaf_conv3x3*));
+    int nt = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!convs[i]) { iaf_conv3x3_prep_batch_destroy(b); return IAF_ERR_NULL; }
+        if (convs[i]->generic || convs[i]->mask_mode) { iaf_conv3x3_prep_batch_destroy(b); return IAF_ERR_UNSUPPORTED; }
+        b->convs[i] = convs[i];
+        nt += convs[i]->L.ncot;
+    }
+    b->ntiles = nt;
+    int* t2l = (int*)malloc(sizeof(int) * nt);
+    int rc;
+    if ((rc = (int)hipHostMalloc((void**)&b->h_layers, sizeof(PrepLayer) * n)) != 0 ||
+        (rc = (int)hipMalloc((void**)&b->d_layers, sizeof(PrepLayer) * n)) != 0 ||
+        (rc = (int)hipMalloc((void**)&b->d_tile2layer, sizeof(int) * nt)) != 0) {
+        free(t2l); iaf_conv3x3_prep_batch_destroy(b); return rc;
+    }
+    memset(b->h_layers, 0, sizeof(PrepLayer) * n);
+    int tile = 0;
+    for (int i = 0; i < n; ++i) {
+        const GemmLayer& L = convs[i]->L;
+        PrepLayer& P = b->h_layers[i];
+        P.wp = L.wp; P.bias = L.bias; P.variant = PREP_PLAIN9;
+        P.cin = L.cin; P.cout_each = L.cout; P.ncot = L.ncot; P.nchunk = L.nchunk; P.npair = 1; P.tile_begin = tile;
+        for (int t = 0; t < L.ncot; ++t) t2l[tile++] = i;
+    }
+    rc = (int)hipMemcpy(b->d_tile2layer, t2l, sizeof(int) * nt, hipMemcpyHostToDevice);
+    free(t2l);
+    if (rc) { iaf_conv3x3_prep_batch_destroy(b); return rc; }
+    *out = b;
+    return IAF_OK;
+}
+
+extern "C" int iaf_conv3x3_prep_batch_run(iaf_conv3x3_prep_batch_t* b, const float* const* V, const float* const* g,
+                                          const float* const* bias, void* stream) {
+    if (!b || !V || !g || !bias) return IAF_ERR_NULL;
+    for (int i = 0; i < b->n; ++i) {
+        if (!V[i] || !g[i] || !bias[i]) return IAF_ERR_NULL;
+        b->h_layers[i].V[0] = V[i]; b->h_layers[i].g[0] = g[i]; b->h_layers[i].b[0] = bias[i];
+    }
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(b->d_layers, b->h_layers, sizeof(PrepLayer) * b->n, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(iaf_prep_plain_kernel, dim3(b->ntiles), dim3(256), 0, st, b->d_layers, b->d_tile2layer);
+    HIP_TRY(hipGetLastError());
+    for (int i = 0; i < b->n; ++i) b->convs[i]->prepared = true;
+    return IAF_OK;
+}
+
 extern "C" int iaf_conv3x3_set_tuning(iaf_conv3x3_t* c, int nt, int pxt, int wco, int ks) {
     if (!c) return IAF_ERR_NULL;
     GemmLayer& L = c->L;

@@ -57,6 +57,21 @@ class IAFLayer(object):
         pre = "ar_multiconv2d/"
         self.posterior.load({k[len(pre):]: v for k, v in params.items() if k.startswith(pre)})
 
+    CONVS = ("up_conv1", "up_conv3", "down_conv1", "down_conv2")
+
+    def convs(self):
+        return [getattr(self, nm) for nm in self.CONVS]
+
+    @staticmethod
+    def conv_params(params):
+        """the (V, g, b) tuples of one layer's plain convs in `convs()` order (for ConvPrepBatch.run)"""
+        return [(params[nm + "/V"], params[nm + "/g"], params[nm + "/b"]) for nm in IAFLayer.CONVS]
+
+    @staticmethod
+    def stack_params(params):
+        pre = "ar_multiconv2d/"
+        return {k[len(pre):]: v for k, v in params.items() if k.startswith(pre)}
+
     def up(self, inp, autotune=False):
         zs, hs = self.z_size, self.h_size
         qz_mean, qz_logsd, up_context, h = self.up_conv1(inp, elu_input=True, split=[zs, zs, hs, hs],

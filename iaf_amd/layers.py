@@ -567,6 +567,43 @@ class PrepBatch(object):
             st._prep_key = None      # per-stack cache no longer describes what is on the device
 
 
+class ConvPrepBatch(object):
+    """PrepBatch for the plain convs: l2-normalise, exp(g), repack of MANY WNConv2d objects in one launch."""
+
+    def __init__(self, convs):
+        self.convs = list(convs)
+        arr = (ctypes.c_void_p * len(self.convs))(*[c._h.value for c in self.convs])
+        self._h = ctypes.c_void_p()
+        _capi.check(_capi.lib().iaf_conv3x3_prep_batch_create(ctypes.byref(self._h), arr, len(self.convs)))
+        self._keepalive = None
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                _capi.lib().iaf_conv3x3_prep_batch_destroy(h)
+            except Exception:
+                pass
+
+    def run(self, vgb_list):
+        """vgb_list: one (V, g, b) tuple of device tensors per conv, in construction order."""
+        tens = []
+        for c, (V, g, b) in zip(self.convs, vgb_list):
+            _check_act(V, "V", (3, 3, c.n_in, c.n_out))
+            _check_act(g, "g", (c.n_out,))
+            _check_act(b, "b", (c.n_out,))
+            tens += [V, g, b]
+        n = len(self.convs)
+        arr = ctypes.c_void_p * n
+        Vp = arr(*[t.data_ptr() for t in tens[0::3]])
+        gp = arr(*[t.data_ptr() for t in tens[1::3]])
+        bp = arr(*[t.data_ptr() for t in tens[2::3]])
+        _capi.check(_capi.lib().iaf_conv3x3_prep_batch_run(self._h, Vp, gp, bp, _stream()))
+        self._keepalive = tens
+        for c in self.convs:
+            c._prep_key = None
+
+
 class _Struct(object):
     def __init__(self, **kw):
         self.__dict__.update(kw)

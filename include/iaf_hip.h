@@ -236,6 +236,13 @@ int iaf_conv3x3_prepare(iaf_conv3x3_t* c, const float* V, const float* g, const 
 int iaf_conv3x3_forward(iaf_conv3x3_t* c, const float* x, const float* x2, int c_split, int elu_input,
                         const float* residual, float* const* outs, const int* out_channels, int n_outs, int B, int H,
                         int W, void* stream);
+/* weight prep of n plain convs (not the masked kind, MFMA-path channel counts) in ONE launch; V/g/b: n pointers each,
+ * in the order of `convs`.  The counterpart of iaf_prep_batch_* for the convs around the IAF step. */
+typedef struct iaf_conv3x3_prep_batch iaf_conv3x3_prep_batch_t;
+int iaf_conv3x3_prep_batch_create(iaf_conv3x3_prep_batch_t** out, iaf_conv3x3_t* const* convs, int n);
+int iaf_conv3x3_prep_batch_run(iaf_conv3x3_prep_batch_t* b, const float* const* V, const float* const* g,
+                               const float* const* bias, void* stream);
+int iaf_conv3x3_prep_batch_destroy(iaf_conv3x3_prep_batch_t* b);
 /* launch shape override (nt = 0 restores the automatic choice); see iaf_stack_set_tuning */
 int iaf_conv3x3_set_tuning(iaf_conv3x3_t* c, int nt, int pxt, int wco, int ks);
 /* times every compiled launch shape with `reps` back-to-back forwards on the caller's buffers (same arguments as

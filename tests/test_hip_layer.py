@@ -297,3 +297,21 @@ def test_discretized_logistic_cifar_shape_vs_oracle(amd):
     lst = rng.uniform(-2.5, -1.0, mean.shape)
     out = amd.discretized_logistic(dev(mean), dev(lst), sample=dev(sample))
     np.testing.assert_allclose(host(out), O.discretized_logistic(f32(mean), f32(lst), f32(sample)), rtol=2e-5, atol=1e-2)
+
+
+def test_conv_prep_batch_equals_individual_prepare(amd, golden_dir):
+    """one batched weight-prep launch for all plain convs of a layer == per-conv prepare: cfg2 fixture end to end"""
+    name = "layer_cfg2_8x8"
+    g = np.load(os.path.join(golden_dir, "iaf_layer.npz"))
+    c = gi.layer_case_inputs(name)
+    params = {k: dev(v) for k, v in c["params"].items()}
+    layer = amd.IAFLayer(c["z_size"], c["h_size"], depth_ar=2, kl_min=c["kl_min"])
+    junk = {k: torch.randn_like(v) for k, v in params.items()}
+    layer.load(junk)                                         # make sure stale packs cannot pass
+    amd.ConvPrepBatch(layer.convs()).run(amd.IAFLayer.conv_params(params))
+    amd.PrepBatch([layer.posterior.stack]).run([amd.IAFLayer.stack_params(params)])
+    up_out = layer.up(dev(c["up_input"]))
+    out, kl_obj, kl_cost = layer.down(dev(c["down_input"]), dev(c["eps_post"]))
+    np.testing.assert_allclose(host(up_out), g[name + "/up_out"], atol=ATOL, rtol=0)
+    np.testing.assert_allclose(host(out), g[name + "/output"], atol=ATOL, rtol=0)
+    np.testing.assert_allclose(host(kl_obj), g[name + "/kl_obj"], atol=2e-3, rtol=1e-4)
