@@ -82,6 +82,12 @@ SIGNATURES = {
     "iaf_conv3x3_prep_batch_create": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.c_int]),
     "iaf_conv3x3_prep_batch_run": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp]),
     "iaf_conv3x3_prep_batch_destroy": (ctypes.c_int, [_vp]),
+    "iaf_conv3x3_set_training": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "iaf_conv3x3_train_workspace_bytes": (ctypes.c_size_t, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "iaf_conv3x3_backward": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_vp),
+                                            ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_float, ctypes.POINTER(_vp),
+                                            ctypes.POINTER(ctypes.c_int), ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp,
+                                            ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_size_t, _vp]),
     "iaf_conv3x3_autotune": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, ctypes.POINTER(_vp),
                                             ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                             ctypes.c_int, ctypes.c_int, _vp, ctypes.POINTER(ctypes.c_int),

@@ -16,6 +16,10 @@ static conv_fn_t pick_mode(int inmode, int epi) {
         if (inmode == IN_NCHW) return iaf_conv_kernel<NT, IAF_PXT, IAF_WCO, IAF_KS, IN_NCHW, EPI_PLAIN, MAXTAPS>;
         return nullptr;
     }
+    if (epi == EPI_DGRAD9) {  // data gradient of a plain 9-tap conv: pixel-major dY in, NCHW (split) out
+        if (inmode == IN_PIXMAJOR) return iaf_conv_kernel<NT, IAF_PXT, IAF_WCO, IAF_KS, IN_PIXMAJOR, EPI_DGRAD, MAXTAPS>;
+        return nullptr;
+    }
     if (epi == EPI_DGRAD) {   // data gradient: always reads pixel-major scratch
         if (inmode == IN_PIXMAJOR) return iaf_conv_kernel<NT, IAF_PXT, IAF_WCO, IAF_KS, IN_PIXMAJOR, EPI_DGRAD>;
         return nullptr;

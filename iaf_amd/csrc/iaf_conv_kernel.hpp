@@ -28,11 +28,13 @@ __device__ __forceinline__ void static_for(F&& f) {
 #define EPI_OUT 1      // output pair (mean, logsd) -> NCHW; mode selects raw / IAF step / posterior
 #define EPI_DGRAD 2    // data gradient (transposed packs, mirrored taps): mode selects MODE_DGRAD_ELU / MODE_DGRAD_Z
 #define EPI_PLAIN5 4   // host-side selector only: EPI_PLAIN with the 5 masked taps (a single ar_conv2d)
+#define EPI_DGRAD9 5   // host-side selector only: EPI_DGRAD with all 9 taps (data gradient of a plain conv)
 #define EPI_PLAIN 3    // y = acc + bias [-> res + 0.1*y]  -> NCHW   (plain weight-normed conv2d, layers.py:63-64; tf_train.py:44,94)
 
 #define MODE_RAW 0        // out0 = m_raw, out1 = s_raw                         (layers.py:166)
 #define MODE_IAF 1        // out0 = (z-0.1m)/exp(0.1s), out1 = 0.1s             (tf_train.py:70-72)
 #define MODE_POSTERIOR 2  // MODE_IAF on z0 rebuilt from the posterior inputs, plus kl elements
+#define MODE_DGRAD_PLAIN 6 // EPI_DGRAD of a plain conv: dx = res + elu'(xe) * (W^T dY) -> NCHW through the split table
 #define MODE_INVERSE 5    // one Jacobi sweep of the inverse flow: out0 = zin*exp(0.1s) + 0.1m, out1 = 0.1s (x = current z0 estimate)
 // backward (data gradient) modes of EPI_DGRAD: the same kernel run on the transposed packed weights with the tap
 // table negated computes dX = W^T * dY; the epilogue applies what autodiff applies next.  (Its own compile-time
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
                  "s"(p.dbg));
     if constexpr (INMODE == IN_POSTERIOR || EPI == EPI_OUT)
         asm volatile("" ::"s"(p.qm), "s"(p.ql), "s"(p.rm), "s"(p.rl), "s"(p.pm), "s"(p.pl), "s"(p.eps), "s"(p.kl_elem));
-    if constexpr (EPI == EPI_PLAIN)
+    if constexpr (EPI == EPI_PLAIN || (EPI == EPI_DGRAD && NTP == MAXTAPS))
         asm volatile("" ::"s"(p.x2), "s"(p.res), "s"(p.c_split), "s"(p.in_elu), "s"(p.nsplit));
     const int HW = p.HW, W = p.W;
     const int cp4 = p.cp >> 2;       // LDS row stride in 16-byte units
@@ -356,6 +358,13 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
             } else if (EPI == EPI_DGRAD) {
                 if (p.mode == MODE_DGRAD_ELU) {
                     pre0[i] = *(const f32x4*)(p.zin + (size_t)Pl * p.cout + (cot0 + u) * 16 + 4 * kk);
+                } else if (p.mode == MODE_DGRAD_PLAIN) {
+                    if (p.zin) pre0[i] = *(const f32x4*)(p.zin + (size_t)Pl * p.cout + (cot0 + u) * 16 + 4 * kk);
+                    if (p.res) {
+                        const size_t cb = ((size_t)bimg * p.cout + (cot0 + u) * 16 + 4 * kk) * HW + pp;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) pre1[i][r] = p.res[cb + (size_t)r * HW];
+                    }
                 } else {
                     const size_t cb = ((size_t)bimg * p.cout + (cot0 + u) * 16 + 4 * kk) * HW + pp;
 #pragma unroll
@@ -601,6 +610,19 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
 #pragma unroll
                         for (int r = 0; r < 4; ++r) p.out0[cb + (size_t)r * HW] = v[r];
                     }
+                } else if (p.mode == MODE_DGRAD_PLAIN) {
+                    if (p.zin) {       // the forward staged elu(x): xe > 0 <=> x > 0, elu'(x) = 1 or xe + 1
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] *= (pre0[i][r] > 0.f ? 1.f : pre0[i][r] + 1.f);
+                    }
+                    int c0 = 0, c1 = p.split_end[0];
+                    float* base = p.split_ptr[0];
+#pragma unroll
+                    for (int q = 1; q < MAXSPLIT; ++q)
+                        if (q < p.nsplit && co >= p.split_end[q - 1]) { c0 = p.split_end[q - 1]; c1 = p.split_end[q]; base = p.split_ptr[q]; }
+                    float* dst = base + ((size_t)bimg * (c1 - c0) + (co - c0)) * HW + pp;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dst[(size_t)r * HW] = p.res ? pre1[i][r] + v[r] : v[r];
                 } else {
                     const size_t cb = ((size_t)bimg * p.cout + co) * HW + pp;
 #pragma unroll

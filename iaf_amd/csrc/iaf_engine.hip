@@ -477,9 +477,10 @@ __global__ __launch_bounds__(256) void iaf_bwd_affine_kernel(const float* __rest
 struct WgradP {
     const float* x;      // [P][cin]
     const float* dy;     // [P][cout]
-    float* part;         // [nrange][NTAPS][cin][cout]
+    float* part;         // [nrange][ntaps][cin][cout]
     int B, H, W, HW, P, cin, cout, nrange, px_per_range;
-    int tap_dh[NTAPS], tap_dw[NTAPS];
+    int ntaps;           // 5 (masked) or 9 (plain)
+    int tap_dh[MAXTAPS], tap_dw[MAXTAPS];
 };
 
 template <int NCOT>
@@ -487,8 +488,8 @@ __global__ __launch_bounds__(256) void iaf_wgrad_kernel(WgradP p) {
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tap = blockIdx.x % NTAPS;
-    const int cip = blockIdx.x / NTAPS;            // pair of ci tiles
+    const int tap = blockIdx.x % p.ntaps;
+    const int cip = blockIdx.x / p.ntaps;          // pair of ci tiles
     const int range = blockIdx.y;
     const int cob = blockIdx.z * NCOT * 16;        // this workgroup's first packed output channel
     const int ci0 = cip * 32;
@@ -531,7 +532,7 @@ __global__ __launch_bounds__(256) void iaf_wgrad_kernel(WgradP p) {
             for (int r = 0; r < 4; ++r) mine[((a * NCOT + t) * 4 + r) * 64] = acc[a][t][r];
     __syncthreads();
     // D layout: lane holds D[row = 4*(l>>4)+r][col = l&15] = (ci = tile*16 + 4*ks + r, co = t*16 + i15)
-    float* out = p.part + (((size_t)range * NTAPS + tap) * p.cin) * p.cout;
+    float* out = p.part + (((size_t)range * p.ntaps + tap) * p.cin) * p.cout;
     for (int e = wave; e < 2 * NCOT * 4; e += 4) {            // (a, t, r) triples spread over the waves
         const int a = e / (NCOT * 4), t = (e / 4) % NCOT, r = e & 3;
         if (a >= nci) continue;
@@ -672,6 +673,100 @@ __global__ __launch_bounds__(256) void iaf_wn_bwd_kernel(WnBwdArgs a) {
         case 14: wn_bwd_tile<14>(L, tile, red, s_n, s_dot); break;
         case 15: wn_bwd_tile<15>(L, tile, red, s_n, s_dot); break;
         case 16: wn_bwd_tile<16>(L, tile, red, s_n, s_dot); break;
+    }
+}
+
+// plain convs: NCHW -> pixel-major staging of the backward operands.  dst[P][C] = scale * act(concat_k src_k)[b, c, p]
+// (act = ELU when elu is set).  Up to MAXSPLIT sources; boundaries are multiples of 4.  A thread owns 4 channels of a pixel:
+// reads are coalesced along pixels (64 lanes = 64 consecutive pixels), the write is one 16-byte store.
+struct PackP {
+    const float* src[MAXSPLIT]; int end[MAXSPLIT]; int nsrc;
+    float* dst; int C, HW, P; float scale; int elu;
+};
+__global__ __launch_bounds__(256) void iaf_pack_pixmajor_kernel(PackP p) {
+    const int px = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int c = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 4;
+    if (px >= p.P || c >= p.C) return;
+    int k = 0;
+    while (k + 1 < p.nsrc && c >= p.end[k]) ++k;
+    const int c0 = k ? p.end[k - 1] : 0, ck = p.end[k] - c0;
+    const int b = px / p.HW, pp = px - b * p.HW;
+    const float* s = p.src[k] + ((size_t)b * ck + (c - c0)) * p.HW + pp;
+    f32x4 v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float t = s[(size_t)r * p.HW];
+        if (p.elu) t = elu_f(t);
+        v[r] = t * p.scale;
+    }
+    *(f32x4*)(p.dst + (size_t)px * p.C + c) = v;
+}
+
+// weight-norm backward of a plain (unmasked, 9-tap) conv, layers.py:60:  w = e u, u = V/n, n = ||V||_o, e = exp(g)
+//   dg = sum dW w;  dV = (e/n)(dW - u (sum dW u));  db = sum_p dY.   Same thread map as wn_bwd_tile; own kernel (18*NCH
+//   live registers per thread would halve the occupancy of the masked one).
+template <int NCH>
+__device__ __forceinline__ void wn_bwd_plain_tile(const WnBwdLayer& L, int tile, float (*red)[16][17], float* s_n, float* s_dot) {
+    const int oo = threadIdx.x & 15, cs = threadIdx.x >> 4;
+    const int o = tile * 16 + oo;
+    const int n_in = L.cin, n_out = L.cout;
+    float v[MAXTAPS][NCH], dw[MAXTAPS][NCH];
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+        const int ci = cs + 16 * it;
+#pragma unroll
+        for (int t = 0; t < MAXTAPS; ++t) {
+            v[t][it] = L.V[((size_t)t * n_in + ci) * n_out + o];
+            dw[t][it] = L.dW[((size_t)t * n_in + ci) * L.cout_packed + o];
+        }
+    }
+    float dbs = 0.f;
+    for (int r = cs; r < L.nslab; r += 16) dbs += L.dbp[(size_t)r * L.cout_packed + o];
+    float ss = 0.f, dot = 0.f;
+#pragma unroll
+    for (int it = 0; it < NCH; ++it)
+#pragma unroll
+        for (int t = 0; t < MAXTAPS; ++t) { ss += v[t][it] * v[t][it]; dot += dw[t][it] * v[t][it]; }
+    red[0][cs][oo] = ss; red[1][cs][oo] = dot; red[2][cs][oo] = dbs;
+    __syncthreads();
+    if (cs == 0) {
+        float a = 0.f, b = 0.f, c = 0.f;
+        for (int i = 0; i < 16; ++i) { a += red[0][i][oo]; b += red[1][i][oo]; c += red[2][i][oo]; }
+        const float n = sqrtf(fmaxf(a, 1e-12f));
+        s_n[oo] = n;
+        s_dot[oo] = b / n;
+        L.dg[o] = expf(L.g[o]) * b / n;
+        L.db[o] = c;
+    }
+    __syncthreads();
+    const float n = s_n[oo], du = s_dot[oo], e = expf(L.g[o]);
+#pragma unroll
+    for (int it = 0; it < NCH; ++it)
+#pragma unroll
+        for (int t = 0; t < MAXTAPS; ++t)
+            L.dV[((size_t)t * n_in + cs + 16 * it) * n_out + o] = (e / n) * (dw[t][it] - (v[t][it] / n) * du);
+}
+
+__global__ __launch_bounds__(256) void iaf_wn_bwd_plain_kernel(WnBwdLayer L) {
+    __shared__ float red[3][16][17];
+    __shared__ float s_n[16], s_dot[16];
+    switch (L.cin >> 4) {
+        case 1: wn_bwd_plain_tile<1>(L, blockIdx.x, red, s_n, s_dot); break;
+        case 2: wn_bwd_plain_tile<2>(L, blockIdx.x, red, s_n, s_dot); break;
+        case 3: wn_bwd_plain_tile<3>(L, blockIdx.x, red, s_n, s_dot); break;
+        case 4: wn_bwd_plain_tile<4>(L, blockIdx.x, red, s_n, s_dot); break;
+        case 5: wn_bwd_plain_tile<5>(L, blockIdx.x, red, s_n, s_dot); break;
+        case 6: wn_bwd_plain_tile<6>(L, blockIdx.x, red, s_n, s_dot); break;
+        case 7: wn_bwd_plain_tile<7>(L, blockIdx.x, red, s_n, s_dot); break;
+        case 8: wn_bwd_plain_tile<8>(L, blockIdx.x, red, s_n, s_dot); break;
+        case 9: wn_bwd_plain_tile<9>(L, blockIdx.x, red, s_n, s_dot); break;
+        case 10: wn_bwd_plain_tile<10>(L, blockIdx.x, red, s_n, s_dot); break;
+        case 11: wn_bwd_plain_tile<11>(L, blockIdx.x, red, s_n, s_dot); break;
+        case 12: wn_bwd_plain_tile<12>(L, blockIdx.x, red, s_n, s_dot); break;
+        case 13: wn_bwd_plain_tile<13>(L, blockIdx.x, red, s_n, s_dot); break;
+        case 14: wn_bwd_plain_tile<14>(L, blockIdx.x, red, s_n, s_dot); break;
+        case 15: wn_bwd_plain_tile<15>(L, blockIdx.x, red, s_n, s_dot); break;
+        case 16: wn_bwd_plain_tile<16>(L, blockIdx.x, red, s_n, s_dot); break;
     }
 }
 
@@ -1756,8 +1851,8 @@ extern "C" int iaf_stack_set_training(iaf_stack_t* s, int on) {
 
 // pixel ranges of the weight-gradient GEMM: as many as keep the grid within ONE round of 256 workgroups
 // (grid.x = 5 taps * ceil(cin/32) ci pairs), at least 64 pixels each, at most 16 (the partial buffer is sized for 16)
-static int wgrad_nrange(long long P, int cin = 160) {
-    long long n = 256 / (NTAPS * ((cin + 31) / 32));
+static int wgrad_nrange(long long P, int cin = 160, int ntaps = NTAPS) {
+    long long n = 256 / (ntaps * ((cin + 31) / 32));
     if (n > P / 64) n = P / 64;
     if (n < 1) n = 1;
     if (n > 16) n = 16;
@@ -1859,15 +1954,20 @@ static int launch_wgrad(const iaf_stack_t* s, const GemmLayer& L, const float* x
     p.x = x; p.dy = dy; p.part = part;
     p.B = B; p.H = H; p.W = W; p.HW = H * W; p.P = B * H * W;
     p.cin = L.cin; p.cout = L.cout;
-    p.nrange = wgrad_nrange(p.P, L.cin);
+    const int ntaps = L.full3x3 ? MAXTAPS : NTAPS;
+    p.ntaps = ntaps;
+    p.nrange = wgrad_nrange(p.P, L.cin, ntaps);
     p.px_per_range = (int)(((long long)p.P + p.nrange - 1) / p.nrange + 15) / 16 * 16;
     static const int tf_dh[NTAPS] = {0, 0, 1, 1, 1}, tf_dw[NTAPS] = {0, 1, -1, 0, 1};
-    for (int t = 0; t < NTAPS; ++t) { p.tap_dh[t] = tf_dh[t]; p.tap_dw[t] = tf_dw[t]; }
+    for (int t = 0; t < ntaps; ++t) {
+        p.tap_dh[t] = L.full3x3 ? t / 3 - 1 : tf_dh[t];
+        p.tap_dw[t] = L.full3x3 ? t % 3 - 1 : tf_dw[t];
+    }
     static const int cand[] = {16, 12, 10, 8, 6, 5, 4, 3, 2, 1};
     int ncot = 1;
     for (int c : cand)
         if (L.ncot % c == 0) { ncot = c; break; }
-    dim3 grid(NTAPS * ((L.cin + 31) / 32), p.nrange, L.ncot / ncot);
+    dim3 grid(ntaps * ((L.cin + 31) / 32), p.nrange, L.ncot / ncot);
     switch (ncot) {
         case 16: launch_wgrad_t<16>(p, grid, st); break;
         case 12: launch_wgrad_t<12>(p, grid, st); break;
@@ -2101,12 +2201,15 @@ struct iaf_conv3x3 {
     GemmLayer L;
     PrepLayer* h_desc = nullptr;   // pinned staging of the prep descriptor
     PrepLayer* d_desc = nullptr;
+    bool training = false;
+    GemmLayer T;                   // transposed problem dX = W^T dY (valid when training)
 };
 
 extern "C" int iaf_conv3x3_destroy(iaf_conv3x3_t* c) {
     if (!c) return IAF_ERR_NULL;
     if (c->L.wp) (void)hipFree(c->L.wp);
     if (c->L.bias) (void)hipFree(c->L.bias);
+    if (c->L.wpt) (void)hipFree(c->L.wpt);
     if (c->h_desc) (void)hipHostFree(c->h_desc);
     if (c->d_desc) (void)hipFree(c->d_desc);
     delete c;
@@ -2171,6 +2274,7 @@ extern "C" int iaf_conv3x3_prepare(iaf_conv3x3_t* c, const float* V, const float
         PrepLayer& P = *c->h_desc;
         memset(&P, 0, sizeof(P));
         P.V[0] = V; P.g[0] = g; P.b[0] = b; P.wp = L.wp; P.bias = L.bias; P.variant = PREP_PLAIN9;
+        P.wpt = c->training ? L.wpt : nullptr;
         P.cin = L.cin; P.cout_each = L.cout; P.ncot = L.ncot; P.nchunk = L.nchunk; P.npair = 1; P.tile_begin = 0;
         HIP_TRY(hipMemcpyAsync(c->d_desc, c->h_desc, sizeof(PrepLayer), hipMemcpyHostToDevice, (hipStream_t)stream));
         hipLaunchKernelGGL(iaf_prep_plain_kernel, dim3(L.ncot), dim3(256), 0, (hipStream_t)stream, c->d_desc, (const int*)nullptr);
@@ -2246,6 +2350,7 @@ extern "C" int iaf_conv3x3_prep_batch_run(iaf_conv3x3_prep_batch_t* b, const flo
     for (int i = 0; i < b->n; ++i) {
         if (!V[i] || !g[i] || !bias[i]) return IAF_ERR_NULL;
         b->h_layers[i].V[0] = V[i]; b->h_layers[i].g[0] = g[i]; b->h_layers[i].b[0] = bias[i];
+        b->h_layers[i].wpt = b->convs[i]->training ? b->convs[i]->L.wpt : nullptr;
     }
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipMemcpyAsync(b->d_layers, b->h_layers, sizeof(PrepLayer) * b->n, hipMemcpyHostToDevice, st));
@@ -2263,6 +2368,36 @@ extern "C" int iaf_conv3x3_set_tuning(iaf_conv3x3_t* c, int nt, int pxt, int wco
     if (L.ncot % (nt * wco) != 0 || L.nchunk < ks) return IAF_ERR_UNSUPPORTED;
     L.nt = nt; L.pxt = pxt; L.wco = wco; L.ks = ks; L.user_tuned = true;
     return IAF_OK;
+}
+
+// launch of the conv kernel for a plain / single masked conv descriptor (forward, or its transposed problem with the
+// taps mirrored for the data gradient)
+static int conv3x3_launch(GemmLayer& L, ConvP& p, int epi_sel, int inmode, bool masked, bool mirror, hipStream_t st) {
+    if (!L.user_tuned) auto_shape(L, false, p.P, p.W);
+    conv_fn_t fn = pick_kernel(L.nt, L.pxt, L.wco, L.ks, inmode, epi_sel);
+    if (!fn) return IAF_ERR_UNSUPPORTED;
+    const int tm = 16 * L.pxt, W = p.W, sgn = mirror ? -1 : 1;
+    p.wp = L.wp; p.bias = L.bias; p.lim = nullptr;
+    if (masked) {     // the 5 live taps of the MADE-masked filter: look right / below only
+        static const int tf_dh[NTAPS] = {0, 0, 1, 1, 1}, tf_dw[NTAPS] = {0, 1, -1, 0, 1};
+        for (int t = 0; t < NTAPS; ++t) { p.tap_dh[t] = sgn * tf_dh[t]; p.tap_dw[t] = sgn * tf_dw[t]; }
+        p.halo_before = mirror ? W + 1 : 0;
+        p.nslot = tm + W + 1;
+    } else {
+        for (int t = 0; t < MAXTAPS; ++t) { p.tap_dh[t] = sgn * (t / 3 - 1); p.tap_dw[t] = sgn * (t % 3 - 1); }   // cross-correlation, SAME
+        p.halo_before = W + 1;
+        p.nslot = tm + 2 * (W + 1);
+    }
+    p.cin = L.cin; p.cout = L.cout; p.nchunk = L.nchunk; p.ncot = L.ncot;
+    p.cp = L.cin + 8;
+    const size_t lds = conv_lds_bytes(L, W);
+    if (lds > 160 * 1024) return IAF_ERR_UNSUPPORTED;
+    int rc = raise_lds_cap(fn, lds);
+    if (rc) return rc;
+    dim3 grid((p.P + tm - 1) / tm, L.ncot / (L.nt * L.wco));
+    p.gx = (int)grid.x;
+    hipLaunchKernelGGL(fn, grid, dim3(64 * L.pxt * L.wco * L.ks), lds, st, p);
+    return (int)hipGetLastError();
 }
 
 extern "C" int iaf_conv3x3_forward(iaf_conv3x3_t* c, const float* x, const float* x2, int c_split, int elu_input,
@@ -2307,35 +2442,9 @@ extern "C" int iaf_conv3x3_forward(iaf_conv3x3_t* c, const float* x, const float
         p.split_end[k] = ends[k < n_outs ? k : n_outs - 1];
         p.split_ptr[k] = outs[k < n_outs ? k : n_outs - 1];
     }
-    if (!L.user_tuned) auto_shape(L, false, p.P, W);
-    conv_fn_t fn = pick_kernel(L.nt, L.pxt, L.wco, L.ks, IN_NCHW, c->mask_mode ? EPI_PLAIN5 : EPI_PLAIN);
-    if (!fn) return IAF_ERR_UNSUPPORTED;
-    const int tm = 16 * L.pxt;
-    p.wp = L.wp; p.bias = L.bias; p.lim = nullptr;
-    if (c->mask_mode) {     // the 5 live taps of the MADE-masked filter: look right / below only
-        static const int tf_dh[NTAPS] = {0, 0, 1, 1, 1}, tf_dw[NTAPS] = {0, 1, -1, 0, 1};
-        for (int t = 0; t < NTAPS; ++t) { p.tap_dh[t] = tf_dh[t]; p.tap_dw[t] = tf_dw[t]; }
-        p.halo_before = 0;
-        p.nslot = tm + W + 1;
-    } else {
-        for (int t = 0; t < MAXTAPS; ++t) { p.tap_dh[t] = t / 3 - 1; p.tap_dw[t] = t % 3 - 1; }   // cross-correlation, SAME
-        p.halo_before = W + 1;
-        p.nslot = tm + 2 * (W + 1);
-    }
-    p.cin = L.cin; p.cout = L.cout; p.nchunk = L.nchunk; p.ncot = L.ncot;
-    p.cp = L.cin + 8;
-    const size_t lds = conv_lds_bytes(L, W);
-    if (lds > 160 * 1024) return IAF_ERR_UNSUPPORTED;
-    int rc = raise_lds_cap(fn, lds);
-    if (rc) return rc;
-    dim3 grid((p.P + tm - 1) / tm, L.ncot / (L.nt * L.wco));
-    p.gx = (int)grid.x;
-    hipLaunchKernelGGL(fn, grid, dim3(64 * L.pxt * L.wco * L.ks), lds, st, p);
-    return (int)hipGetLastError();
+    return conv3x3_launch(L, p, c->mask_mode ? EPI_PLAIN5 : EPI_PLAIN, IN_NCHW, c->mask_mode != 0, false, st);
 }
 
-// Times every compiled launch shape on the caller's own buffers (the forward is idempotent) and pins the fastest;
-// the counterpart of the cuDNN algorithm search the reference's tf.nn.conv2d performs.  Synchronises the stream.
 extern "C" int iaf_conv3x3_autotune(iaf_conv3x3_t* c, const float* x, const float* x2, int c_split, int elu_input,
                                     const float* residual, float* const* outs, const int* out_channels, int n_outs, int B,
                                     int H, int W, int reps, void* stream, int* best_shape, float* best_us) {
@@ -2403,5 +2512,136 @@ extern "C" int iaf_discretized_logistic(const float* mean, const float* logscale
     if (B <= 0 || n_per_row == 0 || !(binsize > 0.f)) return IAF_ERR_SHAPE;
     hipLaunchKernelGGL(iaf_disc_logistic_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, mean, logscale,
                        logscale_is_scalar ? 1 : 0, sample, out, n_per_row, binsize);
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward of a plain conv (what TF's autodiff derives for layers.py:52-64 inside IAFLayer, tf_train.py:138):
+//   forward   y = conv(a, w) + b,  a = act(concat(x, x2)),  w = exp(g) V / ||V||_o
+//   given     dY (as up to 6 NCHW tensors -- the gradients of the split outputs -- times dy_scale)
+//   computes  dX = [dx_residual +] act'(.) * (W^T dY)   -> NCHW, split like the forward concat
+//             dV, dg (through the weight norm), db
+// Passes: (1) pack dY and a pixel-major, (2) data gradient = the SAME conv kernel on the transposed packs with mirrored
+// taps (EPI_DGRAD, 9 taps), (3) MFMA weight gradient over pixel ranges + reduce, (4) weight-norm backward.
+// ---------------------------------------------------------------------------------------------
+extern "C" int iaf_conv3x3_set_training(iaf_conv3x3_t* c, int on) {
+    if (!c) return IAF_ERR_NULL;
+    if (c->generic || c->mask_mode) return IAF_ERR_UNSUPPORTED;
+    if (!on) { c->training = false; return IAF_OK; }
+    GemmLayer& L = c->L;
+    if (!L.wpt) HIP_TRY(hipMalloc(&L.wpt, (size_t)L.nchunk * MAXTAPS * L.ncot * 256 * sizeof(float)));
+    GemmLayer& T = c->T;
+    T = GemmLayer();
+    T.cin = L.cout; T.cout = L.cin; T.nchunk = L.ncot; T.ncot = L.nchunk; T.zerodiag = 0; T.npair = 1; T.full3x3 = true;
+    T.wp = L.wpt; T.nt = 1; T.pxt = 4; T.wco = 1; T.ks = 1; T.user_tuned = false;
+    c->training = true;
+    c->prepared = false;      // the transposed pack is written by the next prepare
+    return IAF_OK;
+}
+
+struct ConvTrainWs { float* xe; float* dyc; float* part; float* dW; float* dbp; };
+static size_t conv3x3_train_ws_floats(const iaf_conv3x3* c, long long P, ConvTrainWs* o, float* base) {
+    size_t off = 0;
+    auto take = [&](size_t n) { float* q = base ? base + off : nullptr; off += (n + 63) / 64 * 64; return q; };
+    ConvTrainWs t;
+    t.xe = take((size_t)P * c->n_in);
+    t.dyc = take((size_t)P * c->n_out);
+    t.part = take((size_t)16 * MAXTAPS * c->n_in * c->n_out);
+    t.dW = take((size_t)MAXTAPS * c->n_in * c->n_out);
+    t.dbp = take((size_t)256 * c->n_out);
+    if (o) *o = t;
+    return off;
+}
+
+extern "C" size_t iaf_conv3x3_train_workspace_bytes(const iaf_conv3x3_t* c, int B, int H, int W) {
+    if (!c || B <= 0 || H <= 0 || W <= 0) return 0;
+    return conv3x3_train_ws_floats(c, (long long)B * H * W, nullptr, nullptr) * sizeof(float);
+}
+
+static int pack_pixmajor(const float* const* src, const int* chans, int n, float* dst, int C, int HW, int P, float scale,
+                         int elu, hipStream_t st) {
+    PackP p;
+    memset(&p, 0, sizeof(p));
+    int tot = 0;
+    for (int k = 0; k < n; ++k) { tot += chans[k]; p.src[k] = src[k]; p.end[k] = tot; }
+    p.nsrc = n; p.dst = dst; p.C = C; p.HW = HW; p.P = P; p.scale = scale; p.elu = elu;
+    hipLaunchKernelGGL(iaf_pack_pixmajor_kernel, dim3((P + 63) / 64, (C + 15) / 16), dim3(256), 0, st, p);
+    return (int)hipGetLastError();
+}
+
+extern "C" int iaf_conv3x3_backward(iaf_conv3x3_t* c, const float* x, const float* x2, int c_split, int elu_input,
+                                    const float* const* dys, const int* dy_channels, int n_dys, float dy_scale,
+                                    float* const* dxs, const int* dx_channels, int n_dxs, const float* dx_residual,
+                                    const float* V, const float* g, float* dV, float* dg, float* db, int B, int H, int W,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+    if (!c || !x || !dys || !dy_channels || !V || !g || !dV || !dg || !db || !workspace) return IAF_ERR_NULL;
+    if (!c->training || !c->prepared) return IAF_ERR_NOT_PREPARED;
+    if (B <= 0 || H <= 0 || W <= 0 || n_dys < 1 || n_dys > MAXSPLIT || n_dxs < 0 || n_dxs > MAXSPLIT) return IAF_ERR_SHAPE;
+    if ((long long)B * H * W > (1LL << 30) / 64) return IAF_ERR_SHAPE;
+    if (x2 && (c_split <= 0 || c_split >= c->n_in || (c_split & 3))) return IAF_ERR_SHAPE;
+    if (n_dxs && (!dxs || !dx_channels)) return IAF_ERR_NULL;
+    if (dx_residual && n_dxs != 1) return IAF_ERR_SHAPE;
+    int tot = 0;
+    for (int k = 0; k < n_dys; ++k) {
+        if (!dys[k]) return IAF_ERR_NULL;
+        if (dy_channels[k] <= 0 || (dy_channels[k] & 3)) return IAF_ERR_SHAPE;
+        tot += dy_channels[k];
+    }
+    if (tot != c->n_out) return IAF_ERR_SHAPE;
+    int dends[MAXSPLIT];
+    tot = 0;
+    for (int k = 0; k < n_dxs; ++k) {
+        if (!dxs[k]) return IAF_ERR_NULL;
+        if (dx_channels[k] <= 0 || (dx_channels[k] & 3)) return IAF_ERR_SHAPE;
+        tot += dx_channels[k];
+        dends[k] = tot;
+    }
+    if (n_dxs && tot != c->n_in) return IAF_ERR_SHAPE;
+    if (((uintptr_t)workspace & 15) != 0 || workspace_bytes < iaf_conv3x3_train_workspace_bytes(c, B, H, W)) return IAF_ERR_WORKSPACE;
+    const int P = B * H * W, HW = H * W;
+    ConvTrainWs tw;
+    conv3x3_train_ws_floats(c, P, &tw, (float*)workspace);
+    hipStream_t st = (hipStream_t)stream;
+    GemmLayer& L = c->L;
+    int rc;
+    // (1) operands, pixel-major
+    if ((rc = pack_pixmajor(dys, dy_channels, n_dys, tw.dyc, c->n_out, HW, P, dy_scale, 0, st))) return rc;
+    {
+        const float* xs[2] = {x, x2};
+        const int xc[2] = {x2 ? c_split : c->n_in, c->n_in - c_split};
+        if ((rc = pack_pixmajor(xs, xc, x2 ? 2 : 1, tw.xe, c->n_in, HW, P, 1.0f, elu_input ? 1 : 0, st))) return rc;
+    }
+    // (2) data gradient
+    if (n_dxs) {
+        ConvP p;
+        memset(&p, 0, sizeof(p));
+        p.B = B; p.H = H; p.W = W; p.HW = HW; p.P = P;
+        p.x = tw.dyc; p.mode = MODE_DGRAD_PLAIN;
+        p.zin = elu_input ? tw.xe : nullptr;
+        p.res = dx_residual;
+        p.nsplit = n_dxs;
+        for (int k = 0; k < MAXSPLIT; ++k) {
+            p.split_end[k] = dends[k < n_dxs ? k : n_dxs - 1];
+            p.split_ptr[k] = dxs[k < n_dxs ? k : n_dxs - 1];
+        }
+        if ((rc = conv3x3_launch(c->T, p, EPI_DGRAD9, IN_PIXMAJOR, false, true, st))) return rc;
+    }
+    // (3) weight gradient: partials over pixel ranges, then reduce (+ column sums of dY for db)
+    if ((rc = launch_wgrad(nullptr, L, tw.xe, tw.dyc, tw.part, B, H, W, st))) return rc;
+    const int nslab = (P + 31) / 32 < 256 ? (P + 31) / 32 : 256;
+    const int px_per_slab = (P + nslab - 1) / nslab;
+    {
+        const size_t n4 = (size_t)MAXTAPS * L.cin * L.cout / 4;
+        int nblk = (int)((n4 + 255) / 256);
+        if (nblk > 1024) nblk = 1024;
+        hipLaunchKernelGGL(iaf_wgrad_reduce_kernel, dim3(nblk + nslab), dim3(256), 0, st, tw.part, tw.dW,
+                           wgrad_nrange(P, L.cin, MAXTAPS), n4, nblk, (const float*)tw.dyc, tw.dbp, P, L.cout, px_per_slab);
+    }
+    // (4) through the weight norm
+    WnBwdLayer w;
+    memset(&w, 0, sizeof(w));
+    w.V = V; w.g = g; w.dW = tw.dW; w.dbp = tw.dbp; w.dV = dV; w.dg = dg; w.db = db;
+    w.cin = L.cin; w.cout = L.cout; w.cout_packed = L.cout; w.nslab = nslab; w.pack_stride = 1;
+    hipLaunchKernelGGL(iaf_wn_bwd_plain_kernel, dim3(L.cout / 16), dim3(256), 0, st, w);
     return (int)hipGetLastError();
 }

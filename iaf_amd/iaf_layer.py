@@ -3,6 +3,8 @@
 The two convolutions around it (down_conv1 / down_conv2, tf_train.py:53,93) are outside this
 path; the boundary is the channel split of down_conv1's output
 (tf_train.py:54) and the stored up-pass tensors (tf_train.py:38)."""
+import torch
+
 from .layers import ARStack, WNConv2d
 
 
@@ -89,3 +91,73 @@ class IAFLayer(object):
         out = self.down_conv2(blk["z"], x2=h_det, elu_input=True, residual=inp, autotune=autotune)[0]     # :87-94
         self.last_block = blk
         return out, blk["kl_obj"], blk["kl_cost"]
+
+    # -- training: forward that keeps what the backward needs, and the backward (tf_train.py:138 for this layer) -----
+    def set_training(self, on=True):
+        for c in self.convs():
+            c.set_training(on)
+        self.posterior.stack.set_training(on)
+
+    def up_train(self, inp):
+        zs, hs = self.z_size, self.h_size
+        qz_mean, qz_logsd, up_context, h = self.up_conv1(inp, elu_input=True, split=[zs, zs, hs, hs])
+        self.posterior.set_up_state(qz_mean, qz_logsd, up_context)
+        out = self.up_conv3(h, elu_input=True, residual=inp)[0]
+        self._up_saved = dict(inp=inp, h=h)
+        return out
+
+    def down_train(self, inp, eps):
+        zs, hs = self.z_size, self.h_size
+        pz_mean, pz_logsd, rz_mean, rz_logsd, down_context, h_det = self.down_conv1(
+            inp, elu_input=True, split=[zs] * 4 + [hs] * 2)
+        po = self.posterior
+        blk = po.stack.posterior_block_train(po.qz_mean, po.qz_logsd, rz_mean, rz_logsd, pz_mean, pz_logsd, po.up_context,
+                                             down_context, eps, self.kl_min)
+        out = self.down_conv2(blk["z"], x2=h_det, elu_input=True, residual=inp)[0]
+        self._down_saved = dict(inp=inp, eps=eps, pz_mean=pz_mean, pz_logsd=pz_logsd, rz_mean=rz_mean, rz_logsd=rz_logsd,
+                                h_det=h_det, z=blk["z"])
+        return out, blk["kl_obj"], blk["kl_cost"]
+
+    def down_backward(self, d_out, d_kl_obj, params, grads=None):
+        """Backward of down_train.  d_out: gradient of `output`; d_kl_obj [B]: gradient of kl_obj (kl_cost is reporting
+        only, tf_train.py:204-206).  Returns d_input; the gradients flowing to the up pass (d qz_mean, d qz_logsd,
+        d up_context) are kept for up_backward.  Parameter gradients land in `grads` (name -> tensor, allocated if absent)."""
+        grads = {} if grads is None else grads
+        sv, po = self._down_saved, self.posterior
+        zs, hs = self.z_size, self.h_size
+
+        def gslot(nm):
+            return tuple(grads.setdefault(nm + "/" + k, torch.empty_like(params[nm + "/" + k])) for k in ("V", "g", "b"))
+
+        # output = input + 0.1*down_conv2(elu(concat(z, h_det)))                                    (tf_train.py:87-94)
+        (d_z, d_h_det), _, _, _ = self.down_conv2.backward(
+            sv["z"], [d_out], params["down_conv2/V"], params["down_conv2/g"], x2=sv["h_det"], elu_input=True, dy_scale=0.1,
+            grads_out=gslot("down_conv2"))
+        # the IAF posterior block                                                                   (tf_train.py:56-85)
+        pre = "ar_multiconv2d/"
+        sp = IAFLayer.stack_params(params)
+        sg = {k: grads.setdefault(pre + k, torch.empty_like(v)) for k, v in sp.items()}
+        pb = po.stack.posterior_block_backward(po.qz_mean, po.qz_logsd, sv["rz_mean"], sv["rz_logsd"], sv["pz_mean"],
+                                               sv["pz_logsd"], sv["eps"], self.kl_min, sv["z"], d_z, d_kl_obj, sp,
+                                               grads_out=sg)
+        self._to_up = dict(d_qz_mean=pb["dmean"], d_qz_logsd=pb["dlogsd"], d_up_context=pb["dcontext"])
+        # x = down_conv1(elu(input)) split six ways; d input = d_out + elu'(input) * W^T dY          (tf_train.py:52-54, 94)
+        (d_inp,), _, _, _ = self.down_conv1.backward(
+            sv["inp"], [pb["dpz_mean"], pb["dpz_logsd"], pb["dmean"], pb["dlogsd"], pb["dcontext"], d_h_det],
+            params["down_conv1/V"], params["down_conv1/g"], elu_input=True, dx_residual=d_out, grads_out=gslot("down_conv1"))
+        return d_inp
+
+    def up_backward(self, d_out, params, grads=None):
+        """Backward of up_train (after down_backward of the same layer).  Returns d_input."""
+        grads = {} if grads is None else grads
+        sv, tu = self._up_saved, self._to_up
+
+        def gslot(nm):
+            return tuple(grads.setdefault(nm + "/" + k, torch.empty_like(params[nm + "/" + k])) for k in ("V", "g", "b"))
+
+        (d_h,), _, _, _ = self.up_conv3.backward(sv["h"], [d_out], params["up_conv3/V"], params["up_conv3/g"], elu_input=True,
+                                                 dy_scale=0.1, grads_out=gslot("up_conv3"))                  # :40-44
+        (d_inp,), _, _, _ = self.up_conv1.backward(
+            sv["inp"], [tu["d_qz_mean"], tu["d_qz_logsd"], tu["d_up_context"], d_h], params["up_conv1/V"],
+            params["up_conv1/g"], elu_input=True, dx_residual=d_out, grads_out=gslot("up_conv1"))            # :35-38
+        return d_inp

@@ -433,6 +433,53 @@ class WNConv2d(object):
     def set_tuning(self, nt, pxt, wco, ks):
         _capi.check(_capi.lib().iaf_conv3x3_set_tuning(self._h, nt, pxt, wco, ks))
 
+    # -- training --------------------------------------------------------------------------------
+    _shared_ws = {}     # device -> one scratch buffer shared by all plain convs (they run one after another)
+
+    def set_training(self, on=True):
+        """allocate the transposed weight pack the data gradient uses; the next prepare fills it"""
+        _capi.check(_capi.lib().iaf_conv3x3_set_training(self._h, 1 if on else 0))
+        self._prep_key = None
+
+    def backward(self, x, dys, V, g, x2=None, elu_input=False, dy_scale=1.0, want_dx=True, dx_residual=None,
+                 grads_out=None):
+        """Backward of __call__ (what TF autodiff derives for layers.py:52-64 and the elu/concat/split/residual around it).
+        dys: gradients of the split outputs (same shapes as __call__ returned); dy_scale multiplies them (0.1 for the
+        residual form).  Returns (dxs, dV, dg, db): dxs = gradients w.r.t. [x] or [x, x2] (None if not want_dx),
+        = [dx_residual +] act'(input) * W^T dY."""
+        _check_act(x, "x")
+        B, c1, H, W = (int(v) for v in x.shape)
+        c_split = 0
+        if x2 is not None:
+            _check_act(x2, "x2", (B, self.n_in - c1, H, W))
+            c_split = c1
+        for d in dys:
+            _check_act(d, "dy")
+        n = len(dys)
+        dyp = (ctypes.c_void_p * n)(*[d.data_ptr() for d in dys])
+        dyc = (ctypes.c_int * n)(*[int(d.shape[1]) for d in dys])
+        dxs = None
+        ndx, dxp, dxc = 0, None, None
+        if want_dx:
+            dxs = [torch.empty_like(x)] + ([torch.empty_like(x2)] if x2 is not None else [])
+            ndx = len(dxs)
+            dxp = (ctypes.c_void_p * ndx)(*[d.data_ptr() for d in dxs])
+            dxc = (ctypes.c_int * ndx)(*[int(d.shape[1]) for d in dxs])
+            if dx_residual is not None:
+                _check_act(dx_residual, "dx_residual", tuple(x.shape))
+        if grads_out is None:
+            dV, dg, db = torch.empty_like(V), torch.empty_like(g), torch.empty_like(g)
+        else:
+            dV, dg, db = grads_out
+        need = _capi.lib().iaf_conv3x3_train_workspace_bytes(self._h, B, H, W)
+        ws = WNConv2d._shared_ws.get(x.device)
+        if ws is None or ws.numel() * 4 < need:
+            ws = WNConv2d._shared_ws[x.device] = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
+        _capi.check(_capi.lib().iaf_conv3x3_backward(
+            self._h, _ptr(x), _ptr(x2), c_split, 1 if elu_input else 0, dyp, dyc, n, float(dy_scale), dxp, dxc, ndx,
+            _ptr(dx_residual), _ptr(V), _ptr(g), _ptr(dV), _ptr(dg), _ptr(db), B, H, W, _ptr(ws), need, _stream()))
+        return dxs, dV, dg, db
+
     def init(self, x, V, init_scale=0.1, x2=None, elu_input=False, add=None):
         """Data-dependent initialisation, the init=True branch of conv2d (layers.py:38-51).  Returns (y, g, b):
         y = scale*(x_init - mean) [+ add], g = log(scale)/3, b = -mean*scale with the moments of

@@ -243,6 +243,20 @@ int iaf_conv3x3_prep_batch_create(iaf_conv3x3_prep_batch_t** out, iaf_conv3x3_t*
 int iaf_conv3x3_prep_batch_run(iaf_conv3x3_prep_batch_t* b, const float* const* V, const float* const* g,
                                const float* const* bias, void* stream);
 int iaf_conv3x3_prep_batch_destroy(iaf_conv3x3_prep_batch_t* b);
+/* ---- training of the plain convs: what opt.compute_gradients (tf_train.py:138) derives for layers.py:52-64 ----
+ * iaf_conv3x3_set_training(1) allocates the transposed weight pack; the NEXT prepare fills it.  MFMA-path plain convs only.
+ * iaf_conv3x3_backward: forward was  y = conv(act(concat(x, x2)), exp(g) V/||V||) + b  with y handed out as n_dys split
+ * tensors.  Inputs: the forward inputs again, the gradients dys[k] ([B, dy_channels[k], H, W]) of the split outputs and
+ * a common factor dy_scale (0.1 when the forward folded `input + 0.1*y`).  Outputs: dxs[k] = gradient w.r.t. the forward
+ * input(s) split like the forward concat ([x] or [x | x2]), = [dx_residual +] act'(.) * (W^T dY)  (n_dxs = 0 skips it;
+ * dx_residual only with n_dxs == 1: the `input +` branch of tf_train.py:44,94);  dV [3,3,n_in,n_out], dg, db [n_out]. */
+int iaf_conv3x3_set_training(iaf_conv3x3_t* c, int on);
+size_t iaf_conv3x3_train_workspace_bytes(const iaf_conv3x3_t* c, int B, int H, int W);
+int iaf_conv3x3_backward(iaf_conv3x3_t* c, const float* x, const float* x2, int c_split, int elu_input,
+                         const float* const* dys, const int* dy_channels, int n_dys, float dy_scale, float* const* dxs,
+                         const int* dx_channels, int n_dxs, const float* dx_residual, const float* V, const float* g,
+                         float* dV, float* dg, float* db, int B, int H, int W, void* workspace, size_t workspace_bytes,
+                         void* stream);
 /* launch shape override (nt = 0 restores the automatic choice); see iaf_stack_set_tuning */
 int iaf_conv3x3_set_tuning(iaf_conv3x3_t* c, int nt, int pxt, int wco, int ks);
 /* times every compiled launch shape with `reps` back-to-back forwards on the caller's buffers (same arguments as

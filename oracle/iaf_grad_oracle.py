@@ -96,3 +96,42 @@ def posterior_block_grads(inputs, params, n_h, kl_min, dz, dkl_obj):
     for k, v in pt.items():
         out[k] = v.grad.numpy()
     return out, z.detach().numpy(), kl_obj.detach().numpy(), kl_cost.detach().numpy()
+
+
+# --------------------------------------------------------------------------------------
+# whole non-downsampling IAFLayer (tf_train.py:23-95), for the backward of the plain convs
+# --------------------------------------------------------------------------------------
+def conv2d(x, V, g, b):
+    """tf_utils/layers.py:52-64, mask=None."""
+    w = torch.exp(g).reshape(1, 1, 1, -1) * V / torch.sqrt(torch.clamp((V * V).sum(dim=(0, 1, 2), keepdim=True), min=1e-12))
+    return F.conv2d(x, w.permute(3, 2, 0, 1), b, padding=(1, 1))
+
+
+def iaf_layer(up_inp, down_inp, eps, params, z_size, h_size, kl_min):
+    """up (tf_train.py:29-44) then down (46-95), mode train, downsample False."""
+    zs, hs = z_size, h_size
+    x = conv2d(F.elu(up_inp), params["up_conv1/V"], params["up_conv1/g"], params["up_conv1/b"])
+    qz_mean, qz_logsd, up_context, h = torch.split(x, [zs, zs, hs, hs], dim=1)
+    h = conv2d(F.elu(h), params["up_conv3/V"], params["up_conv3/g"], params["up_conv3/b"])
+    up_out = up_inp + 0.1 * h
+    x = conv2d(F.elu(down_inp), params["down_conv1/V"], params["down_conv1/g"], params["down_conv1/b"])
+    pz_mean, pz_logsd, rz_mean, rz_logsd, down_context, h_det = torch.split(x, [zs] * 4 + [hs] * 2, dim=1)
+    sp = {k[len("ar_multiconv2d/"):]: v for k, v in params.items() if k.startswith("ar_multiconv2d/")}
+    n_h = [hs] * sum(1 for k in sp if k.startswith("layer_") and not k.startswith("layer_out") and k.endswith("/g"))
+    z, kl_obj, kl_cost = posterior_block(qz_mean, qz_logsd, rz_mean, rz_logsd, pz_mean, pz_logsd, up_context, down_context,
+                                         eps, sp, n_h, kl_min)
+    h = conv2d(F.elu(torch.cat([z, h_det], dim=1)), params["down_conv2/V"], params["down_conv2/g"], params["down_conv2/b"])
+    return up_out, down_inp + 0.1 * h, kl_obj, kl_cost
+
+
+def iaf_layer_grads(up_inp, down_inp, eps, params, z_size, h_size, kl_min, d_up_out, d_down_out, d_kl_obj):
+    """L = <d_up_out, up_out> + <d_down_out, output> + <d_kl_obj, kl_obj>; gradients w.r.t. both inputs and every variable."""
+    ut, dt = _t(up_inp, True), _t(down_inp, True)
+    pt = {k: _t(v, True) for k, v in params.items()}
+    up_out, out, kl_obj, kl_cost = iaf_layer(ut, dt, _t(eps), pt, z_size, h_size, kl_min)
+    loss = (up_out * _t(d_up_out)).sum() + (out * _t(d_down_out)).sum() + (kl_obj * _t(d_kl_obj)).sum()
+    loss.backward()
+    grads = {k: v.grad.numpy() for k, v in pt.items()}
+    fw = dict(up_out=up_out.detach().numpy(), output=out.detach().numpy(), kl_obj=kl_obj.detach().numpy(),
+              kl_cost=kl_cost.detach().numpy())
+    return dict(up_inp=ut.grad.numpy(), down_inp=dt.grad.numpy(), params=grads), fw

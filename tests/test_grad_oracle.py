@@ -81,3 +81,63 @@ def test_posterior_block_forward_matches_numpy_oracle():
         np.testing.assert_allclose(z, e["z"], rtol=1e-11, atol=1e-12)
         np.testing.assert_allclose(kl_obj, e["kl_obj"], rtol=1e-11, atol=1e-11)
         np.testing.assert_allclose(kl_cost, e["kl_cost"], rtol=1e-11, atol=1e-11)
+
+
+# ---------------------------------------------------------------- whole IAFLayer (plain convs + posterior block)
+def test_layer_forward_matches_reference_golden_and_numpy_oracle(golden_dir):
+    """pins the torch restatement of IAFLayer.up/.down that the layer-gradient oracle differentiates"""
+    import os
+    g = np.load(os.path.join(golden_dir, "iaf_layer.npz"))
+    for name in ("layer_tiny_fb", "layer_tiny_nofb", "layer_k2"):
+        c = gi.layer_case_inputs(name)
+        zero = np.zeros_like
+        _, fw = G.iaf_layer_grads(c["up_input"], c["down_input"], c["eps_post"], c["params"], c["z_size"], c["h_size"],
+                                  c["kl_min"], zero(c["up_input"]), zero(c["down_input"]), np.zeros(c["up_input"].shape[0]))
+        np.testing.assert_allclose(fw["up_out"], g[name + "/up_out"], rtol=1e-5, atol=1e-5)      # fixtures are fp32 runs
+        np.testing.assert_allclose(fw["output"], g[name + "/output"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(fw["kl_obj"], g[name + "/kl_obj"], rtol=1e-5, atol=1e-4)
+        np.testing.assert_allclose(fw["kl_cost"], g[name + "/kl_cost"], rtol=1e-5, atol=1e-4)
+        up_out, qm, ql, uc = O.iaf_layer_up(c["up_input"], c["params"], c["z_size"], c["h_size"])
+        out, kl_obj, kl_cost, _ = O.iaf_layer_down(c["down_input"], c["params"], qm, ql, uc, c["eps_post"], c["z_size"],
+                                                   c["h_size"], c["kl_min"])
+        np.testing.assert_allclose(fw["up_out"], up_out, rtol=1e-11, atol=1e-11)
+        np.testing.assert_allclose(fw["output"], out, rtol=1e-11, atol=1e-11)
+        np.testing.assert_allclose(fw["kl_obj"], kl_obj, rtol=1e-11, atol=1e-10)
+
+
+def test_layer_gradients_match_finite_differences():
+    c = gi.layer_case_inputs("layer_tiny_fb")
+    rng = np.random.RandomState(11)
+    dU, dD = rng.standard_normal(c["up_input"].shape), rng.standard_normal(c["down_input"].shape)
+    dK = rng.standard_normal(c["up_input"].shape[0])
+    args = (c["z_size"], c["h_size"], c["kl_min"])
+    grads, _ = G.iaf_layer_grads(c["up_input"], c["down_input"], c["eps_post"], c["params"], *args, dU, dD, dK)
+
+    def loss(u, d, pp):
+        up_out, qm, ql, uc = O.iaf_layer_up(u, pp, c["z_size"], c["h_size"])
+        out, kl_obj, _, _ = O.iaf_layer_down(d, pp, qm, ql, uc, c["eps_post"], *args)
+        return (up_out * dU).sum() + (out * dD).sum() + (kl_obj * dK).sum()
+
+    eps = 1e-6
+    for name in ["up_inp", "down_inp", "up_conv1/V", "up_conv1/g", "up_conv3/V", "down_conv1/V", "down_conv1/b",
+                 "down_conv2/V", "down_conv2/g", "ar_multiconv2d/layer_0/V"]:
+        base = {"up_inp": c["up_input"], "down_inp": c["down_input"]}.get(name, c["params"].get(name))
+        got = grads[name] if name in grads else grads["params"][name]
+        for _ in range(4):
+            idx = tuple(rng.randint(0, s) for s in base.shape)
+
+            def at(delta):
+                arr = base.copy()
+                arr[idx] += delta
+                pp = dict(c["params"])
+                u, d = c["up_input"], c["down_input"]
+                if name == "up_inp":
+                    u = arr
+                elif name == "down_inp":
+                    d = arr
+                else:
+                    pp[name] = arr
+                return loss(u, d, pp)
+
+            fd = (at(eps) - at(-eps)) / (2 * eps)
+            assert abs(fd - got[idx]) < 2e-6 * max(1.0, abs(fd)), (name, idx, fd, got[idx])

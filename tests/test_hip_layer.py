@@ -315,3 +315,68 @@ def test_conv_prep_batch_equals_individual_prepare(amd, golden_dir):
     np.testing.assert_allclose(host(up_out), g[name + "/up_out"], atol=ATOL, rtol=0)
     np.testing.assert_allclose(host(out), g[name + "/output"], atol=ATOL, rtol=0)
     np.testing.assert_allclose(host(kl_obj), g[name + "/kl_obj"], atol=2e-3, rtol=1e-4)
+
+
+# ---------------------------------------------------------------- backward of the plain convs and of the whole layer
+def _relerr(got, want):
+    return np.abs(got - want).max() / max(np.abs(want).max(), 1e-30)
+
+
+@pytest.mark.parametrize("shape", [(3, 160, 384, 8, 8), (2, 192, 160, 16, 16), (2, 32, 48, 5, 7), (4, 160, 448, 8, 8)],
+                         ids=lambda s: "B%d_%dto%d_%dx%d" % s)
+def test_wnconv2d_backward_vs_autograd_oracle(amd, shape):
+    """L = <dy, res + 0.1*conv(elu(x))>: dx, dV, dg, db against torch-fp64 autograd of layers.py:52-64"""
+    from oracle import iaf_grad_oracle as G
+    B, n_in, n_out, H, W = shape
+    rng = np.random.RandomState(71)
+    p = gi.conv_params(rng, n_in, n_out)
+    x, dy = rng.standard_normal((B, n_in, H, W)), rng.standard_normal((B, n_out, H, W))
+    xt = G._t(f32(x), True)
+    pt = {k: G._t(f32(v), True) for k, v in p.items()}
+    y = 0.1 * G.conv2d(torch.nn.functional.elu(xt), pt["V"], pt["g"], pt["b"])
+    (y * G._t(f32(dy))).sum().backward()
+    conv = amd.WNConv2d(n_in, n_out)
+    conv.set_training(True)
+    V, g, b = dev(p["V"]), dev(p["g"]), dev(p["b"])
+    conv.prepare(V, g, b)
+    half = n_out // 2 // 4 * 4
+    dyd = dev(dy)
+    dys = [dyd[:, :half].contiguous(), dyd[:, half:].contiguous()]             # gradient arrives as split tensors
+    res = dev(rng.standard_normal(x.shape))
+    (dx,), dV, dg, db = conv.backward(dev(x), dys, V, g, elu_input=True, dy_scale=0.1, dx_residual=res)
+    assert _relerr(host(dx) - host(res), xt.grad.numpy()) < 1e-4
+    assert _relerr(host(dV), pt["V"].grad.numpy()) < 1e-4
+    assert _relerr(host(dg), pt["g"].grad.numpy()) < 1e-4
+    assert _relerr(host(db), pt["b"].grad.numpy()) < 1e-4
+
+
+@pytest.mark.parametrize("kl_min", [0.25, 0.0])
+def test_iaf_layer_backward_vs_autograd_oracle(amd, kl_min):
+    """whole IAFLayer (up + down) at z 32 / h 160, 8x8: gradients of L = <dU, up_out> + <dD, output> + <dK, kl_obj>
+    w.r.t. both inputs and all 28 variables vs torch-fp64 autograd of the restated layer (itself pinned to the reference
+    fixtures and finite differences in tests/test_grad_oracle.py).  Bar: 1e-4 of the tensor's max |reference|."""
+    from oracle import iaf_grad_oracle as G
+    c = gi.layer_case_inputs("layer_cfg2_8x8")
+    zs, hs = c["z_size"], c["h_size"]
+    rng = np.random.RandomState(9)
+    up_in, down_in, eps = c["up_input"], c["down_input"], c["eps_post"]
+    dU, dD, dK = rng.standard_normal(up_in.shape), rng.standard_normal(down_in.shape), rng.standard_normal(up_in.shape[0])
+    p32 = {k: f32(v) for k, v in c["params"].items()}
+    want, fw = G.iaf_layer_grads(f32(up_in), f32(down_in), f32(eps), p32, zs, hs, kl_min, f32(dU), f32(dD), f32(dK))
+    params = {k: dev(v) for k, v in c["params"].items()}
+    layer = amd.IAFLayer(zs, hs, depth_ar=2, kl_min=kl_min)
+    layer.set_training(True)
+    layer.load(params)
+    up_out = layer.up_train(dev(up_in))
+    out, kl_obj, kl_cost = layer.down_train(dev(down_in), dev(eps))
+    np.testing.assert_allclose(host(up_out), fw["up_out"], atol=ATOL, rtol=0)
+    np.testing.assert_allclose(host(out), fw["output"], atol=ATOL, rtol=0)
+    np.testing.assert_allclose(host(kl_obj), fw["kl_obj"], atol=2e-3, rtol=1e-4)
+    grads = {}
+    d_down_in = layer.down_backward(dev(dD), dev(dK), params, grads)
+    d_up_in = layer.up_backward(dev(dU), params, grads)
+    assert _relerr(host(d_down_in), want["down_inp"]) < 1e-4
+    assert _relerr(host(d_up_in), want["up_inp"]) < 1e-4
+    assert sorted(grads) == sorted(want["params"])
+    worst = max((_relerr(host(grads[k]), want["params"][k]), k) for k in grads)
+    assert worst[0] < 1e-4, worst
