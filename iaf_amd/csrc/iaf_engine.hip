@@ -481,10 +481,27 @@ struct WgradP {
     int B, H, W, HW, P, cin, cout, nrange, px_per_range;
     int ntaps;           // 5 (masked) or 9 (plain)
     int tap_dh[MAXTAPS], tap_dw[MAXTAPS];
+    const unsigned short* tapmask;   // [P]: bit (dh+1)*3+(dw+1) set when pixel p's neighbour (dh,dw) lies inside its image
 };
 
+// border table of the weight gradient: the 9 in-image bits of every pixel, computed once per backward instead of two
+// integer divisions per K step per lane (which cost as much issue time as the MFMAs of the step)
+__global__ __launch_bounds__(256) void iaf_tapmask_kernel(unsigned short* __restrict__ mask, int H, int W, int P) {
+    const int px = blockIdx.x * 256 + threadIdx.x;
+    if (px >= P) return;
+    const int pp = px % (H * W);
+    const int h = pp / W, w = pp - h * W;
+    unsigned m = 0;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int dh = t / 3 - 1, dw = t % 3 - 1;
+        if (h + dh >= 0 && h + dh < H && w + dw >= 0 && w + dw < W) m |= 1u << t;
+    }
+    mask[px] = (unsigned short)m;
+}
+
 template <int NCOT>
-__global__ __launch_bounds__(256) void iaf_wgrad_kernel(WgradP p) {
+__global__ __launch_bounds__(256, 2) void iaf_wgrad_kernel(WgradP p) {
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -496,6 +513,7 @@ __global__ __launch_bounds__(256) void iaf_wgrad_kernel(WgradP p) {
     const int nci = (p.cin - ci0 >= 32) ? 2 : 1;   // c_in = 16 has a single tile
     const int i15 = lane & 15, ks = lane >> 4;
     const int dh = p.tap_dh[tap], dw = p.tap_dw[tap];
+    const int tapbit = (dh + 1) * 3 + (dw + 1), shift = dh * p.W + dw;
     f32x4 acc[2][NCOT];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -503,43 +521,69 @@ __global__ __launch_bounds__(256) void iaf_wgrad_kernel(WgradP p) {
         for (int t = 0; t < NCOT; ++t) acc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int r0 = range * p.px_per_range;
     const int r1 = min(p.P, r0 + p.px_per_range);
-    // wave w takes K steps w, w+4, ... of the range (4 pixels each)
-    for (int pb = r0 + 4 * wave; pb < r1; pb += 16) {
-        const int pk = pb + ks;                    // this lane's pixel for both operands
-        const bool pv = pk < r1;
-        const int b = pk / p.HW, pp = pk - b * p.HW;
-        const int h = pp / p.W, w = pp - h * p.W;
-        const bool xv = pv && (h + dh >= 0) && (h + dh < p.H) && (w + dw >= 0) && (w + dw < p.W);
-        const long long xp = (long long)pk + dh * p.W + dw;
-        float av[2];
+    // wave w takes K steps w, w+4, ... of the range (4 pixels each).  The operands of step k+1 are requested before the
+    // MFMAs of step k issue: with one wave per SIMD nothing else hides the ~1 us global-load latency.
+    // Software pipeline, one K step deep: the loads of step k+1 are issued, THEN the MFMAs of step k run, THEN the loaded
+    // values are masked (select) into the operand registers.  Loads are unconditional (addresses clamped into the
+    // tensors, zeroing by select): a branch around a load, or a select right behind it, makes the wave wait for the
+    // load before the MFMAs are issued and the prefetch is for nothing (sched_barrier pins the three phases).
+    const int start = r0 + 4 * wave;
+    const int nstep = (r1 - start + 15) / 16;              // steps of this wave (<= 0: nothing to do)
+    float av[2], bv[NCOT];                                 // operands of the current step
+    float ra[2], rb[NCOT];                                 // raw loads of the next step
+    bool nxv = false, npv = false;
+    auto issue = [&](int pb) {
+        const int pk = pb + ks;                            // this lane's pixel for both operands
+        npv = pk < r1;
+        const int pkc = npv ? pk : r1 - 1;
+        nxv = npv && ((p.tapmask[pkc] >> tapbit) & 1);
+        const long long xp = nxv ? (long long)pkc + shift : (long long)pkc;
+        const float* xr = p.x + xp * p.cin + ci0 + i15;
+        const float* dr = p.dy + (size_t)pkc * p.cout + cob + i15;
+        ra[0] = xr[0];
+        ra[1] = xr[nci == 2 ? 16 : 0];
 #pragma unroll
-        for (int a = 0; a < 2; ++a) av[a] = (xv && a < nci) ? p.x[xp * p.cin + ci0 + a * 16 + i15] : 0.f;
-        float bv[NCOT];
+        for (int t = 0; t < NCOT; ++t) rb[t] = dr[t * 16];
+    };
+    auto take = [&]() {
+        av[0] = nxv ? ra[0] : 0.f;
+        av[1] = (nxv && nci == 2) ? ra[1] : 0.f;
 #pragma unroll
-        for (int t = 0; t < NCOT; ++t) bv[t] = pv ? p.dy[(size_t)pk * p.cout + cob + t * 16 + i15] : 0.f;
+        for (int t = 0; t < NCOT; ++t) bv[t] = npv ? rb[t] : 0.f;
+    };
+    issue(start);
+    take();
+    for (int k = 0; k < nstep; ++k) {
+        issue(start + 16 * (k + 1));                       // beyond the range: clamped address, masked to zero
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int t = 0; t < NCOT; ++t) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[t], acc[a][t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        take();
     }
-    // reduce the 4 waves through LDS: [wave][a][t][r][lane]
-    float* mine = wsm + (size_t)wave * (2 * NCOT * 4 * 64) + lane;
+    // reduce the 4 waves through LDS, one ci tile (a) at a time: [wave][t][r][lane] -- half the LDS of doing both at once,
+    // which is what lets two workgroups share a CU (two waves per SIMD hide each other's load latency)
+    // D layout: lane holds D[row = 4*(l>>4)+r][col = l&15] = (ci = tile*16 + 4*ks + r, co = t*16 + i15)
+    float* out = p.part + (((size_t)range * p.ntaps + tap) * p.cin) * p.cout;
+    float* mine = wsm + (size_t)wave * (NCOT * 4 * 64) + lane;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 2; ++a) {
+        if (a) __syncthreads();
 #pragma unroll
         for (int t = 0; t < NCOT; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) mine[((a * NCOT + t) * 4 + r) * 64] = acc[a][t][r];
-    __syncthreads();
-    // D layout: lane holds D[row = 4*(l>>4)+r][col = l&15] = (ci = tile*16 + 4*ks + r, co = t*16 + i15)
-    float* out = p.part + (((size_t)range * p.ntaps + tap) * p.cin) * p.cout;
-    for (int e = wave; e < 2 * NCOT * 4; e += 4) {            // (a, t, r) triples spread over the waves
-        const int a = e / (NCOT * 4), t = (e / 4) % NCOT, r = e & 3;
-        if (a >= nci) continue;
-        float sum = 0.f;
+            for (int r = 0; r < 4; ++r) mine[(t * 4 + r) * 64] = acc[a][t][r];
+        __syncthreads();
+        if (a < nci)
+            for (int e = wave; e < NCOT * 4; e += 4) {            // (t, r) pairs spread over the waves
+                const int t = e >> 2, r = e & 3;
+                float sum = 0.f;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) sum += wsm[(size_t)k * (2 * NCOT * 4 * 64) + (size_t)e * 64 + lane];
-        out[(size_t)(ci0 + a * 16 + 4 * ks + r) * p.cout + cob + t * 16 + i15] = sum;
+                for (int k = 0; k < 4; ++k) sum += wsm[(size_t)k * (NCOT * 4 * 64) + (size_t)e * 64 + lane];
+                out[(size_t)(ci0 + a * 16 + 4 * ks + r) * p.cout + cob + t * 16 + i15] = sum;
+            }
     }
 }
 
@@ -1852,7 +1896,7 @@ extern "C" int iaf_stack_set_training(iaf_stack_t* s, int on) {
 // pixel ranges of the weight-gradient GEMM: as many as keep the grid within ONE round of 256 workgroups
 // (grid.x = 5 taps * ceil(cin/32) ci pairs), at least 64 pixels each, at most 16 (the partial buffer is sized for 16)
 static int wgrad_nrange(long long P, int cin = 160, int ntaps = NTAPS) {
-    long long n = 256 / (ntaps * ((cin + 31) / 32));
+    long long n = 512 / (ntaps * ((cin + 31) / 32));      // two workgroups per CU are resident
     if (n > P / 64) n = P / 64;
     if (n < 1) n = 1;
     if (n > 16) n = 16;
@@ -1871,6 +1915,7 @@ struct TrainWs {
     float* logsd; float* klelem; float* z0; float* dzt; float* dkl; float* dz0;
     float* rowsum;   // [B*n_z]  (P*n_z floats reserved: B <= P)
     float* gate;     // [n_z]
+    unsigned short* tapmask;   // [P] border bits for the weight gradient
 };
 
 static size_t train_ws_floats(const iaf_stack_t* s, long long P, TrainWs* o, float* base) {
@@ -1896,6 +1941,7 @@ static size_t train_ws_floats(const iaf_stack_t* s, long long P, TrainWs* o, flo
     t.dzt = take((size_t)P * s->n_z); t.dkl = take((size_t)P * s->n_z); t.dz0 = take((size_t)P * s->n_z);
     t.rowsum = take((size_t)P * s->n_z);
     t.gate = take((size_t)s->n_z);
+    t.tapmask = (unsigned short*)take(((size_t)P + 1) / 2);
     if (o) *o = t;
     return off;
 }
@@ -1938,7 +1984,7 @@ extern "C" int iaf_step_forward_train(iaf_stack_t* s, const float* z, const floa
 
 template <int NCOT>
 static void launch_wgrad_t(const WgradP& p, dim3 grid, hipStream_t st) {
-    const size_t lds = (size_t)4 * 2 * NCOT * 4 * 64 * sizeof(float);
+    const size_t lds = (size_t)4 * NCOT * 4 * 64 * sizeof(float);
     static bool attr_done = false;
     if (lds > 48 * 1024 && !attr_done) {
         (void)hipFuncSetAttribute((const void*)iaf_wgrad_kernel<NCOT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1947,11 +1993,17 @@ static void launch_wgrad_t(const WgradP& p, dim3 grid, hipStream_t st) {
     hipLaunchKernelGGL(iaf_wgrad_kernel<NCOT>, grid, dim3(256), lds, st, p);
 }
 
-static int launch_wgrad(const iaf_stack_t* s, const GemmLayer& L, const float* x, const float* dy, float* part, int B, int H,
-                        int W, hipStream_t st) {
+static int launch_tapmask(unsigned short* mask, int B, int H, int W, hipStream_t st) {
+    const int P = B * H * W;
+    hipLaunchKernelGGL(iaf_tapmask_kernel, dim3((P + 255) / 256), dim3(256), 0, st, mask, H, W, P);
+    return (int)hipGetLastError();
+}
+
+static int launch_wgrad(const iaf_stack_t* s, const GemmLayer& L, const float* x, const float* dy, float* part,
+                        const unsigned short* tapmask, int B, int H, int W, hipStream_t st) {
     WgradP p;
     memset(&p, 0, sizeof(p));
-    p.x = x; p.dy = dy; p.part = part;
+    p.x = x; p.dy = dy; p.part = part; p.tapmask = tapmask;
     p.B = B; p.H = H; p.W = W; p.HW = H * W; p.P = B * H * W;
     p.cin = L.cin; p.cout = L.cout;
     const int ntaps = L.full3x3 ? MAXTAPS : NTAPS;
@@ -1963,14 +2015,15 @@ static int launch_wgrad(const iaf_stack_t* s, const GemmLayer& L, const float* x
         p.tap_dh[t] = L.full3x3 ? t / 3 - 1 : tf_dh[t];
         p.tap_dw[t] = L.full3x3 ? t % 3 - 1 : tf_dw[t];
     }
-    static const int cand[] = {16, 12, 10, 8, 6, 5, 4, 3, 2, 1};
+    static const int cand[] = {14, 12, 10, 8, 7, 6, 5, 4, 3, 2, 1};
     int ncot = 1;
     for (int c : cand)
         if (L.ncot % c == 0) { ncot = c; break; }
     dim3 grid(ntaps * ((L.cin + 31) / 32), p.nrange, L.ncot / ncot);
     switch (ncot) {
-        case 16: launch_wgrad_t<16>(p, grid, st); break;
+        case 14: launch_wgrad_t<14>(p, grid, st); break;
         case 12: launch_wgrad_t<12>(p, grid, st); break;
+        case 7: launch_wgrad_t<7>(p, grid, st); break;
         case 10: launch_wgrad_t<10>(p, grid, st); break;
         case 8: launch_wgrad_t<8>(p, grid, st); break;
         case 6: launch_wgrad_t<6>(p, grid, st); break;
@@ -2038,6 +2091,7 @@ extern "C" int iaf_step_backward(iaf_stack_t* s, const float* z, const float* co
         wa.n++;
     };
 
+    if ((rc = launch_tapmask(tw.tapmask, B, H, W, st))) return rc;
     // (2) walk the layers backwards: data gradient (same conv kernel on W^T, mirrored taps), then weight gradient
     const float* dy = tw.dy3;                       // gradient w.r.t. the output of layer l (packed pixel-major)
     for (int l = d; l >= 0; --l) {
@@ -2054,7 +2108,7 @@ extern "C" int iaf_step_backward(iaf_stack_t* s, const float* z, const float* co
             p.out0 = (l - 1 == 0) ? dcontext : nullptr;
         }
         if ((rc = launch_gemm(s, s->T[l], EPI_DGRAD, true, -1, p, IN_PIXMAJOR, st))) return rc;
-        if ((rc = launch_wgrad(s, s->L[l], x_in, dy, tw.part, B, H, W, st))) return rc;
+        if ((rc = launch_wgrad(s, s->L[l], x_in, dy, tw.part, tw.tapmask, B, H, W, st))) return rc;
         reduce(l, dy);
         if (l == d) {
             wn_add(d, l, s->n_z, 2, 0);       // layer_out_0 (mean tiles)
@@ -2539,7 +2593,7 @@ extern "C" int iaf_conv3x3_set_training(iaf_conv3x3_t* c, int on) {
     return IAF_OK;
 }
 
-struct ConvTrainWs { float* xe; float* dyc; float* part; float* dW; float* dbp; };
+struct ConvTrainWs { float* xe; float* dyc; float* part; float* dW; float* dbp; unsigned short* tapmask; };
 static size_t conv3x3_train_ws_floats(const iaf_conv3x3* c, long long P, ConvTrainWs* o, float* base) {
     size_t off = 0;
     auto take = [&](size_t n) { float* q = base ? base + off : nullptr; off += (n + 63) / 64 * 64; return q; };
@@ -2549,6 +2603,7 @@ static size_t conv3x3_train_ws_floats(const iaf_conv3x3* c, long long P, ConvTra
     t.part = take((size_t)16 * MAXTAPS * c->n_in * c->n_out);
     t.dW = take((size_t)MAXTAPS * c->n_in * c->n_out);
     t.dbp = take((size_t)256 * c->n_out);
+    t.tapmask = (unsigned short*)take(((size_t)P + 1) / 2);
     if (o) *o = t;
     return off;
 }
@@ -2627,7 +2682,8 @@ extern "C" int iaf_conv3x3_backward(iaf_conv3x3_t* c, const float* x, const floa
         if ((rc = conv3x3_launch(c->T, p, EPI_DGRAD9, IN_PIXMAJOR, false, true, st))) return rc;
     }
     // (3) weight gradient: partials over pixel ranges, then reduce (+ column sums of dY for db)
-    if ((rc = launch_wgrad(nullptr, L, tw.xe, tw.dyc, tw.part, B, H, W, st))) return rc;
+    if ((rc = launch_tapmask(tw.tapmask, B, H, W, st))) return rc;
+    if ((rc = launch_wgrad(nullptr, L, tw.xe, tw.dyc, tw.part, tw.tapmask, B, H, W, st))) return rc;
     const int nslab = (P + 31) / 32 < 256 ? (P + 31) / 32 : 256;
     const int px_per_slab = (P + nslab - 1) / nslab;
     {
