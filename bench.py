@@ -181,14 +181,38 @@ def train_bench(args, depths, dist, rank, n_gpus):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # the compute part of the step (everything but the gradient exchange and the update) replays as one hipGraph; the
+    # all-reduce and the fused Adamax+EMA follow on the same stream
+    def compute():
+        prep.run(plist)
+        for L in layers:
+            i, st = L["inp"], L["stack"]
+            fw = st.posterior_block_train(i["qm"], i["ql"], i["rm"], i["rl"], i["pm"], i["pl"], i["uc"], i["dc"], i["eps"], 0.25)
+            st.posterior_block_backward(i["qm"], i["ql"], i["rm"], i["rl"], i["pm"], i["pl"], i["eps"], 0.25, fw["z"], i["dz"],
+                                        i["dko"], L["params"], grads_out=L["gradviews"])
+
+    stream = torch.cuda.Stream()
+    graph = None
+    with torch.cuda.stream(stream):
         step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
+        stream.synchronize()
+        if not args.no_graph:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                compute()
+
+            def step():  # noqa: F811
+                graph.replay()
+                flat.all_reduce_grads()
+                flat.adamax_ema_step(1e-4, world=n_gpus)
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        elapsed = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -203,7 +227,8 @@ def train_bench(args, depths, dist, rank, n_gpus):
                                    "%d trainable fp32 parameters in one flat all-reduce bucket (%.1f MB)"
                                    % (args.n_z, args.n_h, depths, args.depth_ar, args.batch, flat.params.numel(),
                                       4e-6 * flat.params.numel()),
-                       "global_batch": n_gpus * args.batch, "launch": "eager",
+                       "global_batch": n_gpus * args.batch,
+                       "launch": "hipGraph replay of forward+backward, then all-reduce + update" if graph is not None else "eager",
                        "parallelism": "dp%d (RCCL all-reduce of one flat gradient bucket)" % n_gpus}}))
 
 
@@ -335,6 +360,124 @@ def layers_bench(args, depths, dist, rank, n_gpus):
                      "timing": "HIP events on the launch stream around 50 back-to-back launches per 16x16 layer"}}))
 
 
+def layers_train_bench(args, depths, dist, rank, n_gpus):
+    """DP training step of whole IAFLayers (SURVEY 8f-4 + 8f-1,2): weight prep, up pass, down pass, backward of both
+    passes (every plain conv and the posterior block), gradients written into ONE flat buffer, all-reduce(sum) over
+    ranks, fused Adamax(1/N)+EMA.  Synthetic upstream gradients (d output ~ N(0,1), d kl_obj = 1)."""
+    import golden_inputs as gi
+    import iaf_amd
+    from iaf_amd import parallel as par
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+    rng = np.random.RandomState(4321 + rank)
+    wrng = np.random.RandomState(99)
+    zs, hs, B = args.n_z, args.n_h, args.batch
+    named, levels = {}, []
+    for lvl, nlayer in enumerate(depths):
+        H = 16 >> lvl
+        L = []
+        for j in range(nlayer):
+            pre = "IAF_%d_%d/" % (lvl, j)
+            for nm, (ci, co) in (("up_conv1", (hs, 2 * zs + 2 * hs)), ("up_conv3", (hs, hs)),
+                                 ("down_conv1", (hs, 4 * zs + 2 * hs)), ("down_conv2", (hs + zs, hs))):
+                for k, v in gi.conv_params(wrng, ci, co).items():
+                    named[pre + nm + "/" + k] = dev(v)
+            for k, v in gi.ar_multiconv2d_params(wrng, zs, [hs] * args.depth_ar, [zs, zs]).items():
+                named[pre + "ar_multiconv2d/" + k] = dev(v)
+            layer = iaf_amd.IAFLayer(zs, hs, depth_ar=args.depth_ar, kl_min=0.25)
+            layer.set_training(True)
+            L.append(dict(layer=layer, pre=pre, eps=dev(rng.standard_normal((B, zs, H, H)))))
+        f = lambda: dev(rng.standard_normal((B, hs, H, H)))
+        levels.append(dict(H=H, layers=L, up_in=f(), down_in=f(), d_up=f(), d_down=f()))
+    flat = par.FlatParams(named)
+    all_layers = [L for lv in levels for L in lv["layers"]]
+    for L in all_layers:
+        n = len(L["pre"])
+        L["params"] = {k[n:]: v for k, v in flat.p.items() if k.startswith(L["pre"])}
+        L["grads"] = {k[n:]: v for k, v in flat.g.items() if k.startswith(L["pre"])}
+    prep_s = iaf_amd.PrepBatch([L["layer"].posterior.stack for L in all_layers])
+    prep_c = iaf_amd.ConvPrepBatch([c for L in all_layers for c in L["layer"].convs()])
+    splist = [iaf_amd.IAFLayer.stack_params(L["params"]) for L in all_layers]
+    cplist = [t for L in all_layers for t in iaf_amd.IAFLayer.conv_params(L["params"])]
+    dko = torch.ones(B, device="cuda")
+
+    def compute():
+        prep_s.run(splist)
+        prep_c.run(cplist)
+        for lv in levels:
+            h = lv["up_in"]
+            for L in lv["layers"]:
+                h = L["layer"].up_train(h)
+        for lv in reversed(levels):
+            h = lv["down_in"]
+            for L in reversed(lv["layers"]):
+                h, _, _ = L["layer"].down_train(h, L["eps"])
+        for lv in levels:                                   # backward of the top-down pass, in reverse
+            d = lv["d_down"]
+            for L in lv["layers"]:
+                d = L["layer"].down_backward(d, dko, L["params"], L["grads"])
+        for lv in reversed(levels):                         # backward of the bottom-up pass, in reverse
+            d = lv["d_up"]
+            for L in reversed(lv["layers"]):
+                d = L["layer"].up_backward(d, L["params"], L["grads"])
+
+    def step():
+        compute()
+        flat.all_reduce_grads()
+        flat.adamax_ema_step(1e-4, world=n_gpus)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    stream = torch.cuda.Stream()
+    graph = None
+    with torch.cuda.stream(stream):
+        step()
+        stream.synchronize()
+        if not args.no_graph:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                compute()
+
+            def step():  # noqa: F811
+                graph.replay()
+                flat.all_reduce_grads()
+                flat.adamax_ema_step(1e-4, world=n_gpus)
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        fwd_fl = 0.0
+        for lv in levels:
+            for L in lv["layers"]:
+                fwd_fl += sum(c.work(B, lv["H"], lv["H"])[0] for c in L["layer"].convs())
+                fwd_fl += L["layer"].posterior.stack.step_work(B, lv["H"], lv["H"])["live_flops"]
+        print(json.dumps({
+            "metric": "IAFLayer TRAIN-step samples/sec (forward + backward of every layer + grad all-reduce + Adamax/EMA)",
+            "value": n_gpus * B / (elapsed / args.steps), "unit": "samples/s", "n_gpus": n_gpus, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "cifar10 z_size=%d h_size=%d depths=%s depth_ar=%d bs=%d per GPU, kl_min=0.25: %d "
+                                   "non-downsampling IAFLayers; %d trainable fp32 parameters in one flat all-reduce bucket (%.1f MB)"
+                                   % (zs, hs, depths, args.depth_ar, B, len(all_layers), flat.params.numel(),
+                                      4e-6 * flat.params.numel()),
+                       "global_batch": n_gpus * B,
+                       "launch": "hipGraph replay of forward+backward, then all-reduce + update" if graph is not None else "eager",
+                       "model_tflops_fwd_plus_bwd": 3.0 * fwd_fl / (elapsed / args.steps) / 1e12,
+                       "parallelism": "dp%d (RCCL all-reduce of one flat gradient bucket)" % n_gpus}}))
+
+
 def main():
     args = parse()
     depths = [int(d) for d in args.depths.split(",") if d]
@@ -354,6 +497,11 @@ def main():
 
     import iaf_amd
     iaf_amd._capi.lib()           # fail loudly if the HIP engine is not built
+    if args.layers and args.train:
+        layers_train_bench(args, depths, dist, rank, n_gpus)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     if args.layers:
         layers_bench(args, depths, dist, rank, n_gpus)
         if dist is not None:
