@@ -24,6 +24,13 @@ static conv_fn_t pick_mode(int inmode, int epi) {
         if (inmode == IN_PIXMAJOR) return iaf_conv_kernel<NT, IAF_PXT, IAF_WCO, IAF_KS, IN_PIXMAJOR, EPI_DGRAD>;
         return nullptr;
     }
+    if (epi == EPI_HIDDEN_DEEP) {   // double-depth ring: only the shape / tile counts the single-round case uses
+#if IAF_PXT == 4 && IAF_WCO == 1 && IAF_KS == 1
+        if constexpr (NT >= 4)
+            if (inmode == IN_PIXMAJOR) return iaf_conv_kernel<NT, IAF_PXT, IAF_WCO, IAF_KS, IN_PIXMAJOR, EPI_HIDDEN, NTAPS, true>;
+#endif
+        return nullptr;
+    }
     if (epi == EPI_HIDDEN) {
         if (inmode == IN_PIXMAJOR) return iaf_conv_kernel<NT, IAF_PXT, IAF_WCO, IAF_KS, IN_PIXMAJOR, EPI_HIDDEN>;
         if (inmode == IN_NCHW) return iaf_conv_kernel<NT, IAF_PXT, IAF_WCO, IAF_KS, IN_NCHW, EPI_HIDDEN>;

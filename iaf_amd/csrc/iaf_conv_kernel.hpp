@@ -29,6 +29,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 #define EPI_DGRAD 2    // data gradient (transposed packs, mirrored taps): mode selects MODE_DGRAD_ELU / MODE_DGRAD_Z
 #define EPI_PLAIN5 4   // host-side selector only: EPI_PLAIN with the 5 masked taps (a single ar_conv2d)
 #define EPI_DGRAD9 5   // host-side selector only: EPI_DGRAD with all 9 taps (data gradient of a plain conv)
+#define EPI_HIDDEN_DEEP 6   // host-side selector only: EPI_HIDDEN, pixel-major input, double-depth weight ring
 #define EPI_PLAIN 3    // y = acc + bias [-> res + 0.1*y]  -> NCHW   (plain weight-normed conv2d, layers.py:63-64; tf_train.py:44,94)
 
 #define MODE_RAW 0        // out0 = m_raw, out1 = s_raw                         (layers.py:166)
@@ -118,7 +119,7 @@ __device__ __forceinline__ float elu_f(float v) { return v > 0.f ? v : __expf(v)
 //   D            : lane l holds D[co = tile*16 + 4*(l>>4) + r][pixel l&15], r = 0..3
 // K order inside a 16-channel chunk is permuted: k-slot kk owns channels 4kk..4kk+3, MFMA j of the chunk
 // consumes channel 4kk+j, so each operand is ONE 16-byte load per lane per 4 MFMAs.
-template <int NT, int PXT, int WCO, int KS, int INMODE, int EPI, int NTP = NTAPS>
+template <int NT, int PXT, int WCO, int KS, int INMODE, int EPI, int NTP = NTAPS, bool DEEP = false>
 __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) {
     extern __shared__ __attribute__((aligned(16))) f32x4 smem4[];
     constexpr int TM = 16 * PXT;
@@ -179,9 +180,12 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
     // slot consumed by step s-1 is refilled with step s+R-1, the loads interleaved between the MFMAs.  Hence the
     // prologue fetches R-1 steps.  Loop bodies are straight-line (static slots/taps, no branches) so that hipcc
     // emits COUNTED s_waitcnt vmcnt(N) and the ring really stays in flight.
-    constexpr int RCH_FULL = (NTP == NTAPS) ? ((NT >= 4) ? 2 : (NT == 3 ? 3 : (NT == 2 ? 4 : 8)))
-                                            : ((NT >= 3) ? 1 : (NT == 2 ? 2 : 4));     // 9-tap chunks are 1.8x bigger
-    constexpr int RCH = (NTHREADS > 256) ? (RCH_FULL + 1) / 2 : RCH_FULL;   // 2 waves/SIMD: half the registers each
+    // Depth: one chunk (5 or 9 steps) for NT >= 4, two for NT = 2..3, four for NT = 1 -- about 180 VGPRs at NT = 5, so
+    // two workgroups share a CU and one's prologue/epilogue overlaps the other's K loop (measured: 3-20 % faster on every
+    // BASELINE config than a ring twice as deep with one workgroup per CU).  DEEP doubles it: only worth it when the whole
+    // grid is a single round of workgroups (nothing to overlap with), i.e. the 160->160 conv at B = 32, 16x16.
+    constexpr int RCH_BASE = (NTP == NTAPS) ? ((NT >= 4) ? 1 : (NT >= 2 ? 2 : 4)) : ((NT >= 2) ? 1 : 2);
+    constexpr int RCH = DEEP ? 2 * RCH_BASE : RCH_BASE;
     constexpr int R = RCH * NTP;
     const size_t wstep = (size_t)p.ncot * 64;   // f32x4 per (chunk,tap) step
     const int c_begin = (kh * p.nchunk) / KS, c_end = ((kh + 1) * p.nchunk) / KS;

@@ -1556,9 +1556,13 @@ static int raise_lds_cap(conv_fn_t fn, size_t lds) {
 static int launch_gemm(const iaf_stack_t* s, GemmLayer& L, int epi, bool negate_taps, int prof_id, ConvP& p, int inmode,
                        hipStream_t st) {
     if (!L.user_tuned) auto_shape(L, epi == EPI_OUT, p.P, p.W);
-    conv_fn_t fn = pick_kernel(L.nt, L.pxt, L.wco, L.ks, inmode, epi);
-    if (!fn) return IAF_ERR_UNSUPPORTED;
     const int tm = 16 * L.pxt;
+    conv_fn_t fn = nullptr;
+    // a grid of at most one workgroup per CU has nothing to overlap a prologue with: use the double-depth weight ring
+    if (epi == EPI_HIDDEN && inmode == IN_PIXMAJOR && ((p.P + tm - 1) / tm) * (L.ncot / (L.nt * L.wco)) <= 256)
+        fn = pick_kernel(L.nt, L.pxt, L.wco, L.ks, inmode, EPI_HIDDEN_DEEP);
+    if (!fn) fn = pick_kernel(L.nt, L.pxt, L.wco, L.ks, inmode, epi);
+    if (!fn) return IAF_ERR_UNSUPPORTED;
     p.wp = L.wp; p.bias = L.bias; p.lim = L.lim;
     {   // tap geometry of the two statements of the operator (see ConvP); the data gradient runs the mirrored taps
         static const int tf_dh[NTAPS] = {0, 0, 1, 1, 1}, tf_dw[NTAPS] = {0, 1, -1, 0, 1};
