@@ -18,7 +18,8 @@ OUT = os.path.join(LIBDIR, "libiaf_hip.so")
 SHAPES = [(4, 1, 1), (4, 1, 2), (2, 2, 1), (2, 2, 2), (2, 1, 2), (2, 1, 4), (1, 1, 4), (1, 2, 2)]   # keep in sync with pick_kernel()
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 CFLAGS += os.environ.get("IAF_EXTRA_CFLAGS", "").split()       # dev experiments only (e.g. -DIAF_EXP_NOREFILL)
-HEADERS = [os.path.join(ROOT, "include", "iaf_hip.h"), os.path.join(CSRC, "iaf_conv_kernel.hpp")]
+HEADERS = [os.path.join(ROOT, "include", "iaf_hip.h")] + sorted(
+    os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp"))   # any header change rebuilds every unit
 
 
 def _units():

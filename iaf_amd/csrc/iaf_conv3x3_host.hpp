@@ -1,0 +1,463 @@
+// iaf_conv3x3_host.hpp -- host side + C ABI of the plain / single masked 3x3 convs (iaf_conv3x3_*), data-dependent init and the likelihood.
+// Part of the single translation unit iaf_engine.hip (included there, in order; not a standalone header).
+#pragma once
+
+// ---------------------------------------------------------------------------------------------
+// plain weight-normed 3x3 convs around the IAF step: up_conv1 / up_conv3 / down_conv1 / down_conv2
+// (tf_train.py:36-44, 52-54, 87-94; operator tf_utils/layers.py:31-64 with mask=None, stride 1, pad SAME).
+// Same implicit-GEMM kernel as the masked stack with all 9 taps live (template NTP = 9) and the EPI_PLAIN epilogue:
+// ELU / channel concat fused into the input staging, channel split / residual fused into the store.
+// ---------------------------------------------------------------------------------------------
+struct iaf_conv3x3 {
+    int n_in, n_out;
+    int mask_mode;     // 0 plain conv2d, 1 ar_conv2d(zerodiagonal=False), 2 ar_conv2d(zerodiagonal=True)
+    bool generic, prepared;
+    GemmLayer L;
+    PrepLayer* h_desc = nullptr;   // pinned staging of the prep descriptor
+    PrepLayer* d_desc = nullptr;
+    bool training = false;
+    GemmLayer T;                   // transposed problem dX = W^T dY (valid when training)
+};
+
+extern "C" int iaf_conv3x3_destroy(iaf_conv3x3_t* c) {
+    if (!c) return IAF_ERR_NULL;
+    if (c->L.wp) (void)hipFree(c->L.wp);
+    if (c->L.bias) (void)hipFree(c->L.bias);
+    if (c->L.wpt) (void)hipFree(c->L.wpt);
+    if (c->h_desc) (void)hipHostFree(c->h_desc);
+    if (c->d_desc) (void)hipFree(c->d_desc);
+    delete c;
+    return IAF_OK;
+}
+
+static int conv3x3_create(iaf_conv3x3_t** out, int n_in, int n_out, int mask_mode);
+extern "C" int iaf_conv3x3_create(iaf_conv3x3_t** out, int n_in, int n_out) { return conv3x3_create(out, n_in, n_out, 0); }
+extern "C" int iaf_conv3x3_create_masked(iaf_conv3x3_t** out, int n_in, int n_out, int zerodiagonal) {
+    if (n_in > 0 && n_out > 0 && !(n_in % n_out == 0 || n_out % n_in == 0)) return IAF_ERR_NOT_MULTIPLE;   // layers.py:116
+    return conv3x3_create(out, n_in, n_out, zerodiagonal ? 2 : 1);
+}
+
+static int conv3x3_create(iaf_conv3x3_t** out, int n_in, int n_out, int mask_mode) {
+    if (!out) return IAF_ERR_NULL;
+    *out = nullptr;
+    if (n_in <= 0 || n_out <= 0) return IAF_ERR_SHAPE;
+    iaf_conv3x3* c = new (std::nothrow) iaf_conv3x3();
+    if (!c) return (int)hipErrorOutOfMemory;
+    c->n_in = n_in; c->n_out = n_out; c->prepared = false; c->mask_mode = mask_mode;
+    c->generic = (n_in % 16 != 0 || n_out % 16 != 0 || n_in > 16 * PREP_MAXI);
+    GemmLayer& L = c->L;
+    L.cin = n_in; L.cout = n_out; L.npair = 1; L.zerodiag = (mask_mode == 2) ? 1 : 0; L.full3x3 = (mask_mode == 0);
+    L.nchunk = (n_in + 15) / 16; L.ncot = (n_out + 15) / 16;
+    default_tuning(L, false);
+    L.live_macs_per_px = L.dense_macs_per_px = 9.0 * n_in * n_out;
+    if (mask_mode) count_macs(L, n_in, n_out, L.zerodiag, 1);
+    const size_t wfloats = c->generic ? (size_t)MAXTAPS * n_in * n_out : (size_t)L.nchunk * MAXTAPS * L.ncot * 256;
+    int rc;
+    if ((rc = (int)hipMalloc(&L.wp, wfloats * sizeof(float))) != 0 ||
+        (rc = (int)hipMalloc(&L.bias, (size_t)L.ncot * 16 * sizeof(float))) != 0 ||
+        (rc = (int)hipHostMalloc((void**)&c->h_desc, sizeof(PrepLayer))) != 0 ||
+        (rc = (int)hipMalloc((void**)&c->d_desc, sizeof(PrepLayer))) != 0) {
+        iaf_conv3x3_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return IAF_OK;
+}
+
+extern "C" int iaf_conv3x3_prepare(iaf_conv3x3_t* c, const float* V, const float* g, const float* b, void* stream) {
+    if (!c || !V || !g || !b) return IAF_ERR_NULL;
+    const GemmLayer& L = c->L;
+    if (c->generic) {
+        GenPrepArgs ga;
+        memset(&ga, 0, sizeof(ga));
+        ga.nlayers = 1;
+        GenPrepLayer& P = ga.L[0];
+        P.V[0] = V; P.g[0] = g; P.b[0] = b; P.w = L.wp; P.bias = L.bias;
+        P.cin = L.cin; P.cout_each = L.cout; P.npair = 1; P.zerodiag = L.zerodiag; P.ch_begin = 0; P.ntaps = MAXTAPS;
+        P.mask9 = c->mask_mode ? 1 : 0;
+        hipLaunchKernelGGL(iaf_generic_prep_kernel, dim3(L.cout), dim3(256), 0, (hipStream_t)stream, ga);
+    } else if (c->mask_mode) {    // the masked prep of the stack, one layer
+        PrepArgs a;
+        memset(&a, 0, sizeof(a));
+        a.nlayers = 1;
+        PrepLayer& P = a.L[0];
+        P.V[0] = V; P.g[0] = g; P.b[0] = b; P.wp = L.wp; P.bias = L.bias; P.variant = IAF_VARIANT_TF;
+        P.cin = L.cin; P.cout_each = L.cout; P.ncot = L.ncot; P.nchunk = L.nchunk; P.zerodiag = L.zerodiag; P.npair = 1;
+        hipLaunchKernelGGL(iaf_prep_kernel, dim3(L.ncot), dim3(256), 0, (hipStream_t)stream, a);
+    } else {
+        PrepLayer& P = *c->h_desc;
+        memset(&P, 0, sizeof(P));
+        P.V[0] = V; P.g[0] = g; P.b[0] = b; P.wp = L.wp; P.bias = L.bias; P.variant = PREP_PLAIN9;
+        P.wpt = c->training ? L.wpt : nullptr;
+        P.cin = L.cin; P.cout_each = L.cout; P.ncot = L.ncot; P.nchunk = L.nchunk; P.npair = 1; P.tile_begin = 0;
+        HIP_TRY(hipMemcpyAsync(c->d_desc, c->h_desc, sizeof(PrepLayer), hipMemcpyHostToDevice, (hipStream_t)stream));
+        hipLaunchKernelGGL(iaf_prep_plain_kernel, dim3(L.ncot), dim3(256), 0, (hipStream_t)stream, c->d_desc, (const int*)nullptr);
+    }
+    HIP_TRY(hipGetLastError());
+    c->prepared = true;
+    return IAF_OK;
+}
+
+// weight prep of many plain convs in one launch (the four convs of every IAFLayer of a model): descriptors in device
+// memory, refreshed per run like iaf_prep_batch_run
+struct iaf_conv3x3_prep_batch {
+    int n, ntiles;
+    iaf_conv3x3** convs;
+    PrepLayer* h_layers;
+    PrepLayer* d_layers;
+    int* d_tile2layer;
+};
+
+extern "C" int iaf_conv3x3_prep_batch_destroy(iaf_conv3x3_prep_batch_t* b) {
+    if (!b) return IAF_ERR_NULL;
+    if (b->h_layers) (void)hipHostFree(b->h_layers);
+    if (b->d_layers) (void)hipFree(b->d_layers);
+    if (b->d_tile2layer) (void)hipFree(b->d_tile2layer);
+    free(b->convs);
+    delete b;
+    return IAF_OK;
+}
+
+extern "C" int iaf_conv3x3_prep_batch_create(iaf_conv3x3_prep_batch_t** out, iaf_conv3x3_t* const* convs, int n) {
+    if (!out || !convs) return IAF_ERR_NULL;
+    *out = nullptr;
+    if (n <= 0) return IAF_ERR_SHAPE;
+    iaf_conv3x3_prep_batch* b = new (std::nothrow) iaf_conv3x3_prep_batch();
+    if (!b) return (int)hipErrorOutOfMemory;
+    memset(b, 0, sizeof(*b));
+    b->n = n;
+    b->convs = (iaf_conv3x3**)calloc(n, sizeof(iaf_conv3x3*));
+    int nt = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!convs[i]) { iaf_conv3x3_prep_batch_destroy(b); return IAF_ERR_NULL; }
+        if (convs[i]->generic || convs[i]->mask_mode) { iaf_conv3x3_prep_batch_destroy(b); return IAF_ERR_UNSUPPORTED; }
+        b->convs[i] = convs[i];
+        nt += convs[i]->L.ncot;
+    }
+    b->ntiles = nt;
+    int* t2l = (int*)malloc(sizeof(int) * nt);
+    int rc;
+    if ((rc = (int)hipHostMalloc((void**)&b->h_layers, sizeof(PrepLayer) * n)) != 0 ||
+        (rc = (int)hipMalloc((void**)&b->d_layers, sizeof(PrepLayer) * n)) != 0 ||
+        (rc = (int)hipMalloc((void**)&b->d_tile2layer, sizeof(int) * nt)) != 0) {
+        free(t2l); iaf_conv3x3_prep_batch_destroy(b); return rc;
+    }
+    memset(b->h_layers, 0, sizeof(PrepLayer) * n);
+    int tile = 0;
+    for (int i = 0; i < n; ++i) {
+        const GemmLayer& L = convs[i]->L;
+        PrepLayer& P = b->h_layers[i];
+        P.wp = L.wp; P.bias = L.bias; P.variant = PREP_PLAIN9;
+        P.cin = L.cin; P.cout_each = L.cout; P.ncot = L.ncot; P.nchunk = L.nchunk; P.npair = 1; P.tile_begin = tile;
+        for (int t = 0; t < L.ncot; ++t) t2l[tile++] = i;
+    }
+    rc = (int)hipMemcpy(b->d_tile2layer, t2l, sizeof(int) * nt, hipMemcpyHostToDevice);
+    free(t2l);
+    if (rc) { iaf_conv3x3_prep_batch_destroy(b); return rc; }
+    *out = b;
+    return IAF_OK;
+}
+
+extern "C" int iaf_conv3x3_prep_batch_run(iaf_conv3x3_prep_batch_t* b, const float* const* V, const float* const* g,
+                                          const float* const* bias, void* stream) {
+    if (!b || !V || !g || !bias) return IAF_ERR_NULL;
+    for (int i = 0; i < b->n; ++i) {
+        if (!V[i] || !g[i] || !bias[i]) return IAF_ERR_NULL;
+        b->h_layers[i].V[0] = V[i]; b->h_layers[i].g[0] = g[i]; b->h_layers[i].b[0] = bias[i];
+        b->h_layers[i].wpt = b->convs[i]->training ? b->convs[i]->L.wpt : nullptr;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(b->d_layers, b->h_layers, sizeof(PrepLayer) * b->n, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(iaf_prep_plain_kernel, dim3(b->ntiles), dim3(256), 0, st, b->d_layers, b->d_tile2layer);
+    HIP_TRY(hipGetLastError());
+    for (int i = 0; i < b->n; ++i) b->convs[i]->prepared = true;
+    return IAF_OK;
+}
+
+extern "C" int iaf_conv3x3_set_tuning(iaf_conv3x3_t* c, int nt, int pxt, int wco, int ks) {
+    if (!c) return IAF_ERR_NULL;
+    GemmLayer& L = c->L;
+    if (nt == 0) { L.user_tuned = false; return IAF_OK; }     // back to the automatic choice
+    if (c->generic || !pick_kernel(nt, pxt, wco, ks, IN_NCHW, c->mask_mode ? EPI_PLAIN5 : EPI_PLAIN)) return IAF_ERR_UNSUPPORTED;
+    if (L.ncot % (nt * wco) != 0 || L.nchunk < ks) return IAF_ERR_UNSUPPORTED;
+    L.nt = nt; L.pxt = pxt; L.wco = wco; L.ks = ks; L.user_tuned = true;
+    return IAF_OK;
+}
+
+// launch of the conv kernel for a plain / single masked conv descriptor (forward, or its transposed problem with the
+// taps mirrored for the data gradient)
+static int conv3x3_launch(GemmLayer& L, ConvP& p, int epi_sel, int inmode, bool masked, bool mirror, hipStream_t st) {
+    if (!L.user_tuned) auto_shape(L, false, p.P, p.W);
+    conv_fn_t fn = pick_kernel(L.nt, L.pxt, L.wco, L.ks, inmode, epi_sel);
+    if (!fn) return IAF_ERR_UNSUPPORTED;
+    const int tm = 16 * L.pxt, W = p.W, sgn = mirror ? -1 : 1;
+    p.wp = L.wp; p.bias = L.bias; p.lim = nullptr;
+    if (masked) {     // the 5 live taps of the MADE-masked filter: look right / below only
+        static const int tf_dh[NTAPS] = {0, 0, 1, 1, 1}, tf_dw[NTAPS] = {0, 1, -1, 0, 1};
+        for (int t = 0; t < NTAPS; ++t) { p.tap_dh[t] = sgn * tf_dh[t]; p.tap_dw[t] = sgn * tf_dw[t]; }
+        p.halo_before = mirror ? W + 1 : 0;
+        p.nslot = tm + W + 1;
+    } else {
+        for (int t = 0; t < MAXTAPS; ++t) { p.tap_dh[t] = sgn * (t / 3 - 1); p.tap_dw[t] = sgn * (t % 3 - 1); }   // cross-correlation, SAME
+        p.halo_before = W + 1;
+        p.nslot = tm + 2 * (W + 1);
+    }
+    p.cin = L.cin; p.cout = L.cout; p.nchunk = L.nchunk; p.ncot = L.ncot;
+    p.cp = L.cin + 8;
+    const size_t lds = conv_lds_bytes(L, W);
+    if (lds > 160 * 1024) return IAF_ERR_UNSUPPORTED;
+    int rc = raise_lds_cap(fn, lds);
+    if (rc) return rc;
+    dim3 grid((p.P + tm - 1) / tm, L.ncot / (L.nt * L.wco));
+    p.gx = (int)grid.x;
+    hipLaunchKernelGGL(fn, grid, dim3(64 * L.pxt * L.wco * L.ks), lds, st, p);
+    return (int)hipGetLastError();
+}
+
+extern "C" int iaf_conv3x3_forward(iaf_conv3x3_t* c, const float* x, const float* x2, int c_split, int elu_input,
+                                   const float* residual, float* const* outs, const int* out_channels, int n_outs, int B,
+                                   int H, int W, void* stream) {
+    if (!c || !x || !outs || !out_channels) return IAF_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0 || n_outs < 1 || n_outs > MAXSPLIT) return IAF_ERR_SHAPE;
+    if ((long long)B * H * W > (1LL << 30) / 64) return IAF_ERR_SHAPE;
+    if (!c->prepared) return IAF_ERR_NOT_PREPARED;
+    if (x2 && (c_split <= 0 || c_split >= c->n_in)) return IAF_ERR_SHAPE;
+    if (residual && n_outs != 1) return IAF_ERR_SHAPE;
+    int tot = 0, ends[MAXSPLIT];
+    for (int k = 0; k < n_outs; ++k) {
+        if (!outs[k]) return IAF_ERR_NULL;
+        if (out_channels[k] <= 0) return IAF_ERR_SHAPE;
+        tot += out_channels[k];
+        ends[k] = tot;
+    }
+    if (tot != c->n_out) return IAF_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    GemmLayer& L = c->L;
+    if (c->generic) {
+        GenPlainP p;
+        memset(&p, 0, sizeof(p));
+        p.x = x; p.x2 = x2; p.w = L.wp; p.bias = L.bias; p.res = residual;
+        p.B = B; p.H = H; p.W = W; p.cin = L.cin; p.cout = L.cout; p.c_split = c_split; p.in_elu = elu_input ? 1 : 0;
+        p.nsplit = n_outs;
+        for (int k = 0; k < n_outs; ++k) { p.split_end[k] = ends[k]; p.split_ptr[k] = outs[k]; }
+        hipLaunchKernelGGL(iaf_generic_conv3x3_kernel, ew_grid((size_t)B * L.cout * H * W), dim3(256), 0, st, p);
+        return (int)hipGetLastError();
+    }
+    // MFMA path: a lane owns 4 consecutive channels, so the concat point and the split points must be multiples of 4
+    if (x2 && (c_split & 3)) return IAF_ERR_UNSUPPORTED;
+    for (int k = 0; k < n_outs; ++k)
+        if (ends[k] & 3) return IAF_ERR_UNSUPPORTED;
+    ConvP p;
+    memset(&p, 0, sizeof(p));
+    p.B = B; p.H = H; p.W = W; p.HW = H * W; p.P = B * H * W;
+    p.x = x; p.x2 = x2; p.c_split = c_split; p.in_elu = elu_input ? 1 : 0; p.res = residual;
+    p.nsplit = n_outs;
+    for (int k = 0; k < MAXSPLIT; ++k) {
+        p.split_end[k] = ends[k < n_outs ? k : n_outs - 1];
+        p.split_ptr[k] = outs[k < n_outs ? k : n_outs - 1];
+    }
+    return conv3x3_launch(L, p, c->mask_mode ? EPI_PLAIN5 : EPI_PLAIN, IN_NCHW, c->mask_mode != 0, false, st);
+}
+
+extern "C" int iaf_conv3x3_autotune(iaf_conv3x3_t* c, const float* x, const float* x2, int c_split, int elu_input,
+                                    const float* residual, float* const* outs, const int* out_channels, int n_outs, int B,
+                                    int H, int W, int reps, void* stream, int* best_shape, float* best_us) {
+    if (!c) return IAF_ERR_NULL;
+    if (c->generic) return IAF_OK;
+    if (reps <= 0) reps = 20;
+    hipStream_t st = (hipStream_t)stream;
+    GemmLayer& L = c->L;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    float best = 1e30f;
+    int bsh[4] = {L.nt, L.pxt, L.wco, L.ks};
+    int rc = IAF_OK;
+    for (int si = 0; si < 8 && rc == IAF_OK; ++si)
+        for (int nt = 5; nt >= 1 && rc == IAF_OK; --nt) {
+            const int pxt = k_shapes[si][0], wco = k_shapes[si][1], ks = k_shapes[si][2];
+            if (L.ncot % (nt * wco) != 0 || L.nchunk < ks) continue;
+            GemmLayer t = L;
+            t.nt = nt; t.pxt = pxt; t.wco = wco; t.ks = ks;
+            if (conv_lds_bytes(t, W) > 160 * 1024) continue;
+            L.nt = nt; L.pxt = pxt; L.wco = wco; L.ks = ks; L.user_tuned = true;
+            for (int r = 0; r < 3 && rc == IAF_OK; ++r)
+                rc = iaf_conv3x3_forward(c, x, x2, c_split, elu_input, residual, outs, out_channels, n_outs, B, H, W, stream);
+            if (rc == IAF_ERR_UNSUPPORTED) { rc = IAF_OK; continue; }
+            if (rc) break;
+            (void)hipEventRecord(e0, st);
+            for (int r = 0; r < reps && rc == IAF_OK; ++r)
+                rc = iaf_conv3x3_forward(c, x, x2, c_split, elu_input, residual, outs, out_channels, n_outs, B, H, W, stream);
+            (void)hipEventRecord(e1, st);
+            if (rc) break;
+            if ((rc = (int)hipEventSynchronize(e1)) != 0) break;
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            if (ms < best) { best = ms; bsh[0] = nt; bsh[1] = pxt; bsh[2] = wco; bsh[3] = ks; }
+        }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    L.nt = bsh[0]; L.pxt = bsh[1]; L.wco = bsh[2]; L.ks = bsh[3]; L.user_tuned = true;
+    if (best_shape) for (int i = 0; i < 4; ++i) best_shape[i] = bsh[i];
+    if (best_us) *best_us = best * 1e3f / reps;
+    return rc;
+}
+
+extern "C" int iaf_conv3x3_work(const iaf_conv3x3_t* c, int B, int H, int W, double* flops, double* bytes) {
+    if (!c) return IAF_ERR_NULL;
+    const double P = (double)B * H * W;
+    if (flops) *flops = 2.0 * c->L.live_macs_per_px * P;
+    // input + output activations once, raw V/g/b once
+    if (bytes) *bytes = 4.0 * (P * (c->n_in + c->n_out) + 9.0 * c->n_in * c->n_out + 2.0 * c->n_out);
+    return IAF_OK;
+}
+
+extern "C" int iaf_datainit_normalize(const float* x_init, const float* add, float* y, float* g, float* b, int B, int C,
+                                      int HW, float init_scale, void* stream) {
+    if (!x_init || !g || !b) return IAF_ERR_NULL;
+    if (B <= 0 || C <= 0 || HW <= 0) return IAF_ERR_SHAPE;
+    hipLaunchKernelGGL(iaf_datainit_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x_init, add, y, g, b, B, C, HW, init_scale);
+    return (int)hipGetLastError();
+}
+
+extern "C" int iaf_discretized_logistic(const float* mean, const float* logscale, int logscale_is_scalar, const float* sample,
+                                        float* out, int B, size_t n_per_row, float binsize, void* stream) {
+    if (!mean || !logscale || !sample || !out) return IAF_ERR_NULL;
+    if (B <= 0 || n_per_row == 0 || !(binsize > 0.f)) return IAF_ERR_SHAPE;
+    hipLaunchKernelGGL(iaf_disc_logistic_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, mean, logscale,
+                       logscale_is_scalar ? 1 : 0, sample, out, n_per_row, binsize);
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward of a plain conv (what TF's autodiff derives for layers.py:52-64 inside IAFLayer, tf_train.py:138):
+//   forward   y = conv(a, w) + b,  a = act(concat(x, x2)),  w = exp(g) V / ||V||_o
+//   given     dY (as up to 6 NCHW tensors -- the gradients of the split outputs -- times dy_scale)
+//   computes  dX = [dx_residual +] act'(.) * (W^T dY)   -> NCHW, split like the forward concat
+//             dV, dg (through the weight norm), db
+// Passes: (1) pack dY and a pixel-major, (2) data gradient = the SAME conv kernel on the transposed packs with mirrored
+// taps (EPI_DGRAD, 9 taps), (3) MFMA weight gradient over pixel ranges + reduce, (4) weight-norm backward.
+// ---------------------------------------------------------------------------------------------
+extern "C" int iaf_conv3x3_set_training(iaf_conv3x3_t* c, int on) {
+    if (!c) return IAF_ERR_NULL;
+    if (c->generic || c->mask_mode) return IAF_ERR_UNSUPPORTED;
+    if (!on) { c->training = false; return IAF_OK; }
+    GemmLayer& L = c->L;
+    if (!L.wpt) HIP_TRY(hipMalloc(&L.wpt, (size_t)L.nchunk * MAXTAPS * L.ncot * 256 * sizeof(float)));
+    GemmLayer& T = c->T;
+    T = GemmLayer();
+    T.cin = L.cout; T.cout = L.cin; T.nchunk = L.ncot; T.ncot = L.nchunk; T.zerodiag = 0; T.npair = 1; T.full3x3 = true;
+    T.wp = L.wpt; T.nt = 1; T.pxt = 4; T.wco = 1; T.ks = 1; T.user_tuned = false;
+    c->training = true;
+    c->prepared = false;      // the transposed pack is written by the next prepare
+    return IAF_OK;
+}
+
+struct ConvTrainWs { float* xe; float* dyc; float* part; float* dW; float* dbp; unsigned short* tapmask; };
+static size_t conv3x3_train_ws_floats(const iaf_conv3x3* c, long long P, ConvTrainWs* o, float* base) {
+    size_t off = 0;
+    auto take = [&](size_t n) { float* q = base ? base + off : nullptr; off += (n + 63) / 64 * 64; return q; };
+    ConvTrainWs t;
+    t.xe = take((size_t)P * c->n_in);
+    t.dyc = take((size_t)P * c->n_out);
+    t.part = take((size_t)16 * MAXTAPS * c->n_in * c->n_out);
+    t.dW = take((size_t)MAXTAPS * c->n_in * c->n_out);
+    t.dbp = take((size_t)256 * c->n_out);
+    t.tapmask = (unsigned short*)take(((size_t)P + 1) / 2);
+    if (o) *o = t;
+    return off;
+}
+
+extern "C" size_t iaf_conv3x3_train_workspace_bytes(const iaf_conv3x3_t* c, int B, int H, int W) {
+    if (!c || B <= 0 || H <= 0 || W <= 0) return 0;
+    return conv3x3_train_ws_floats(c, (long long)B * H * W, nullptr, nullptr) * sizeof(float);
+}
+
+static int pack_pixmajor(const float* const* src, const int* chans, int n, float* dst, int C, int HW, int P, float scale,
+                         int elu, hipStream_t st) {
+    PackP p;
+    memset(&p, 0, sizeof(p));
+    int tot = 0;
+    for (int k = 0; k < n; ++k) { tot += chans[k]; p.src[k] = src[k]; p.end[k] = tot; }
+    p.nsrc = n; p.dst = dst; p.C = C; p.HW = HW; p.P = P; p.scale = scale; p.elu = elu;
+    hipLaunchKernelGGL(iaf_pack_pixmajor_kernel, dim3((P + 63) / 64, (C + 15) / 16), dim3(256), 0, st, p);
+    return (int)hipGetLastError();
+}
+
+extern "C" int iaf_conv3x3_backward(iaf_conv3x3_t* c, const float* x, const float* x2, int c_split, int elu_input,
+                                    const float* const* dys, const int* dy_channels, int n_dys, float dy_scale,
+                                    float* const* dxs, const int* dx_channels, int n_dxs, const float* dx_residual,
+                                    const float* V, const float* g, float* dV, float* dg, float* db, int B, int H, int W,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+    if (!c || !x || !dys || !dy_channels || !V || !g || !dV || !dg || !db || !workspace) return IAF_ERR_NULL;
+    if (!c->training || !c->prepared) return IAF_ERR_NOT_PREPARED;
+    if (B <= 0 || H <= 0 || W <= 0 || n_dys < 1 || n_dys > MAXSPLIT || n_dxs < 0 || n_dxs > MAXSPLIT) return IAF_ERR_SHAPE;
+    if ((long long)B * H * W > (1LL << 30) / 64) return IAF_ERR_SHAPE;
+    if (x2 && (c_split <= 0 || c_split >= c->n_in || (c_split & 3))) return IAF_ERR_SHAPE;
+    if (n_dxs && (!dxs || !dx_channels)) return IAF_ERR_NULL;
+    if (dx_residual && n_dxs != 1) return IAF_ERR_SHAPE;
+    int tot = 0;
+    for (int k = 0; k < n_dys; ++k) {
+        if (!dys[k]) return IAF_ERR_NULL;
+        if (dy_channels[k] <= 0 || (dy_channels[k] & 3)) return IAF_ERR_SHAPE;
+        tot += dy_channels[k];
+    }
+    if (tot != c->n_out) return IAF_ERR_SHAPE;
+    int dends[MAXSPLIT];
+    tot = 0;
+    for (int k = 0; k < n_dxs; ++k) {
+        if (!dxs[k]) return IAF_ERR_NULL;
+        if (dx_channels[k] <= 0 || (dx_channels[k] & 3)) return IAF_ERR_SHAPE;
+        tot += dx_channels[k];
+        dends[k] = tot;
+    }
+    if (n_dxs && tot != c->n_in) return IAF_ERR_SHAPE;
+    if (((uintptr_t)workspace & 15) != 0 || workspace_bytes < iaf_conv3x3_train_workspace_bytes(c, B, H, W)) return IAF_ERR_WORKSPACE;
+    const int P = B * H * W, HW = H * W;
+    ConvTrainWs tw;
+    conv3x3_train_ws_floats(c, P, &tw, (float*)workspace);
+    hipStream_t st = (hipStream_t)stream;
+    GemmLayer& L = c->L;
+    int rc;
+    // (1) operands, pixel-major
+    if ((rc = pack_pixmajor(dys, dy_channels, n_dys, tw.dyc, c->n_out, HW, P, dy_scale, 0, st))) return rc;
+    {
+        const float* xs[2] = {x, x2};
+        const int xc[2] = {x2 ? c_split : c->n_in, c->n_in - c_split};
+        if ((rc = pack_pixmajor(xs, xc, x2 ? 2 : 1, tw.xe, c->n_in, HW, P, 1.0f, elu_input ? 1 : 0, st))) return rc;
+    }
+    // (2) data gradient
+    if (n_dxs) {
+        ConvP p;
+        memset(&p, 0, sizeof(p));
+        p.B = B; p.H = H; p.W = W; p.HW = HW; p.P = P;
+        p.x = tw.dyc; p.mode = MODE_DGRAD_PLAIN;
+        p.zin = elu_input ? tw.xe : nullptr;
+        p.res = dx_residual;
+        p.nsplit = n_dxs;
+        for (int k = 0; k < MAXSPLIT; ++k) {
+            p.split_end[k] = dends[k < n_dxs ? k : n_dxs - 1];
+            p.split_ptr[k] = dxs[k < n_dxs ? k : n_dxs - 1];
+        }
+        if ((rc = conv3x3_launch(c->T, p, EPI_DGRAD9, IN_PIXMAJOR, false, true, st))) return rc;
+    }
+    // (3) weight gradient: partials over pixel ranges, then reduce (+ column sums of dY for db)
+    if ((rc = launch_tapmask(tw.tapmask, B, H, W, st))) return rc;
+    if ((rc = launch_wgrad(nullptr, L, tw.xe, tw.dyc, tw.part, tw.tapmask, B, H, W, st))) return rc;
+    const int nslab = (P + 31) / 32 < 256 ? (P + 31) / 32 : 256;
+    const int px_per_slab = (P + nslab - 1) / nslab;
+    {
+        const size_t n4 = (size_t)MAXTAPS * L.cin * L.cout / 4;
+        int nblk = (int)((n4 + 255) / 256);
+        if (nblk > 1024) nblk = 1024;
+        hipLaunchKernelGGL(iaf_wgrad_reduce_kernel, dim3(nblk + nslab), dim3(256), 0, st, tw.part, tw.dW,
+                           wgrad_nrange(P, L.cin, MAXTAPS), n4, nblk, (const float*)tw.dyc, tw.dbp, P, L.cout, px_per_slab);
+    }
+    // (4) through the weight norm
+    WnBwdLayer w;
+    memset(&w, 0, sizeof(w));
+    w.V = V; w.g = g; w.dW = tw.dW; w.dbp = tw.dbp; w.dV = dV; w.dg = dg; w.db = db;
+    w.cin = L.cin; w.cout = L.cout; w.cout_packed = L.cout; w.nslab = nslab; w.pack_stride = 1;
+    hipLaunchKernelGGL(iaf_wn_bwd_plain_kernel, dim3(L.cout / 16), dim3(256), 0, st, w);
+    return (int)hipGetLastError();
+}

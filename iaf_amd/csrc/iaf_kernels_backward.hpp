@@ -1,0 +1,430 @@
+// iaf_kernels_backward.hpp -- backward kernels: affine/log-det, border-bit table, MFMA weight gradient + reduce, weight-norm backward (masked and plain), pixel-major staging, posterior-block elementwise.
+// Part of the single translation unit iaf_engine.hip (included there, in order; not a standalone header).
+#pragma once
+
+// ---------------------------------------------------------------------------------------------
+// backward of the IAF step (what TF autodiff derives from tf_train.py:69-72 + layers.py:52-64,158-166)
+// ---------------------------------------------------------------------------------------------
+// (1) affine + log-det:  z_new = (z - 0.1 m_raw) e^{-0.1 s_raw},  logsd = 0.1 s_raw
+//       d m_raw = -0.1 dz_new e^{-logsd};   d s_raw = 0.1 (dlogsd - dz_new z_new)
+//     written pixel-major in the PACKED channel order of the output GEMM (tiles m0,s0,m1,s1,...), plus a pixel-major
+//     copy of z (operand of the first conv's weight gradient).
+__global__ __launch_bounds__(256) void iaf_bwd_affine_kernel(const float* __restrict__ z, const float* __restrict__ z_new,
+                                                            const float* __restrict__ logsd, const float* __restrict__ dzn,
+                                                            const float* __restrict__ dls, float* __restrict__ dy3,
+                                                            float* __restrict__ zpm, int n_z, int HW, long long total) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        // i runs pixel-major: channel fastest (coalesced writes); NCHW reads are strided but the tensors are tiny
+        const int c = (int)(i % n_z);
+        const long long P = i / n_z;
+        const long long b = P / HW, pp = P - b * HW;
+        const size_t src = ((size_t)b * n_z + c) * HW + pp;
+        const float g = dzn[src], ls = logsd[src];
+        const float dm = -0.1f * g * __expf(-ls);
+        const float ds = 0.1f * (dls[src] - g * z_new[src]);
+        const size_t row = (size_t)P * (2 * n_z) + (size_t)(c >> 4) * 32 + (c & 15);
+        dy3[row] = dm;
+        dy3[row + 16] = ds;
+        zpm[(size_t)P * n_z + c] = z[src];
+    }
+}
+
+// (2) weight gradient of one masked conv:  dW[tap][ci][co] = sum_p X[p + shift(tap)][ci] * dY[p][co]
+//     as MFMA GEMM  D[ci][co] += A[ci][k = pixel] B[k = pixel][co]  on pixel-major X [P][cin] and dY [P][cout].
+//     Workgroup = (tap, pair of ci tiles, pixel range); its 4 waves split the range, reduce through LDS and write one
+//     partial [krange][tap][cin][cout]; the partials are summed by iaf_wn_bwd_kernel.  Operands are dword loads
+//     straight from L1/L2 (A: 2 per K step, B: NCOT per K step for 2*NCOT MFMAs).
+struct WgradP {
+    const float* x;      // [P][cin]
+    const float* dy;     // [P][cout]
+    float* part;         // [nrange][ntaps][cin][cout]
+    int B, H, W, HW, P, cin, cout, nrange, px_per_range;
+    int ntaps;           // 5 (masked) or 9 (plain)
+    int tap_dh[MAXTAPS], tap_dw[MAXTAPS];
+    const unsigned short* tapmask;   // [P]: bit (dh+1)*3+(dw+1) set when pixel p's neighbour (dh,dw) lies inside its image
+};
+
+// border table of the weight gradient: the 9 in-image bits of every pixel, computed once per backward instead of two
+// integer divisions per K step per lane (which cost as much issue time as the MFMAs of the step)
+__global__ __launch_bounds__(256) void iaf_tapmask_kernel(unsigned short* __restrict__ mask, int H, int W, int P) {
+    const int px = blockIdx.x * 256 + threadIdx.x;
+    if (px >= P) return;
+    const int pp = px % (H * W);
+    const int h = pp / W, w = pp - h * W;
+    unsigned m = 0;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int dh = t / 3 - 1, dw = t % 3 - 1;
+        if (h + dh >= 0 && h + dh < H && w + dw >= 0 && w + dw < W) m |= 1u << t;
+    }
+    mask[px] = (unsigned short)m;
+}
+
+template <int NCOT>
+__global__ __launch_bounds__(256, 2) void iaf_wgrad_kernel(WgradP p) {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tap = blockIdx.x % p.ntaps;
+    const int cip = blockIdx.x / p.ntaps;          // pair of ci tiles
+    const int range = blockIdx.y;
+    const int cob = blockIdx.z * NCOT * 16;        // this workgroup's first packed output channel
+    const int ci0 = cip * 32;
+    const int nci = (p.cin - ci0 >= 32) ? 2 : 1;   // c_in = 16 has a single tile
+    const int i15 = lane & 15, ks = lane >> 4;
+    const int dh = p.tap_dh[tap], dw = p.tap_dw[tap];
+    const int tapbit = (dh + 1) * 3 + (dw + 1), shift = dh * p.W + dw;
+    f32x4 acc[2][NCOT];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int t = 0; t < NCOT; ++t) acc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int r0 = range * p.px_per_range;
+    const int r1 = min(p.P, r0 + p.px_per_range);
+    // wave w takes K steps w, w+4, ... of the range (4 pixels each).  The operands of step k+1 are requested before the
+    // MFMAs of step k issue: with one wave per SIMD nothing else hides the ~1 us global-load latency.
+    // Software pipeline, one K step deep: the loads of step k+1 are issued, THEN the MFMAs of step k run, THEN the loaded
+    // values are masked (select) into the operand registers.  Loads are unconditional (addresses clamped into the
+    // tensors, zeroing by select): a branch around a load, or a select right behind it, makes the wave wait for the
+    // load before the MFMAs are issued and the prefetch is for nothing (sched_barrier pins the three phases).
+    const int start = r0 + 4 * wave;
+    const int nstep = (r1 - start + 15) / 16;              // steps of this wave (<= 0: nothing to do)
+    float av[2], bv[NCOT];                                 // operands of the current step
+    float ra[2], rb[NCOT];                                 // raw loads of the next step
+    bool nxv = false, npv = false;
+    auto issue = [&](int pb) {
+        const int pk = pb + ks;                            // this lane's pixel for both operands
+        npv = pk < r1;
+        const int pkc = npv ? pk : r1 - 1;
+        nxv = npv && ((p.tapmask[pkc] >> tapbit) & 1);
+        const long long xp = nxv ? (long long)pkc + shift : (long long)pkc;
+        const float* xr = p.x + xp * p.cin + ci0 + i15;
+        const float* dr = p.dy + (size_t)pkc * p.cout + cob + i15;
+        ra[0] = xr[0];
+        ra[1] = xr[nci == 2 ? 16 : 0];
+#pragma unroll
+        for (int t = 0; t < NCOT; ++t) rb[t] = dr[t * 16];
+    };
+    auto take = [&]() {
+        av[0] = nxv ? ra[0] : 0.f;
+        av[1] = (nxv && nci == 2) ? ra[1] : 0.f;
+#pragma unroll
+        for (int t = 0; t < NCOT; ++t) bv[t] = npv ? rb[t] : 0.f;
+    };
+    issue(start);
+    take();
+    for (int k = 0; k < nstep; ++k) {
+        issue(start + 16 * (k + 1));                       // beyond the range: clamped address, masked to zero
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int t = 0; t < NCOT; ++t) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[t], acc[a][t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        take();
+    }
+    // reduce the 4 waves through LDS, one ci tile (a) at a time: [wave][t][r][lane] -- half the LDS of doing both at once,
+    // which is what lets two workgroups share a CU (two waves per SIMD hide each other's load latency)
+    // D layout: lane holds D[row = 4*(l>>4)+r][col = l&15] = (ci = tile*16 + 4*ks + r, co = t*16 + i15)
+    float* out = p.part + (((size_t)range * p.ntaps + tap) * p.cin) * p.cout;
+    float* mine = wsm + (size_t)wave * (NCOT * 4 * 64) + lane;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        if (a) __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NCOT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mine[(t * 4 + r) * 64] = acc[a][t][r];
+        __syncthreads();
+        if (a < nci)
+            for (int e = wave; e < NCOT * 4; e += 4) {            // (t, r) pairs spread over the waves
+                const int t = e >> 2, r = e & 3;
+                float sum = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sum += wsm[(size_t)k * (NCOT * 4 * 64) + (size_t)e * 64 + lane];
+                out[(size_t)(ci0 + a * 16 + 4 * ks + r) * p.cout + cob + t * 16 + i15] = sum;
+            }
+    }
+}
+
+// (3a) sum the wgrad partials over the pixel ranges (fully parallel, 16-byte accesses) and, in extra workgroups of the
+//      same launch, column-sum dY over pixel slabs for the bias gradient:
+//        dW[i] = sum_k part[k][i]            blocks [0, nblk_w)
+//        dbp[r][co] = sum_{p in slab r} dY[p][co]   blocks [nblk_w, nblk_w + nslab)
+__global__ __launch_bounds__(256) void iaf_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dW, int nrange,
+                                                              size_t n4, int nblk_w, const float* __restrict__ dy,
+                                                              float* __restrict__ dbp, int P, int cout, int px_per_slab) {
+    if ((int)blockIdx.x < nblk_w) {
+        for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)nblk_w * blockDim.x) {
+            f32x4 a = ((const f32x4*)part)[i];
+            for (int k = 1; k < nrange; ++k) a += ((const f32x4*)part)[(size_t)k * n4 + i];
+            ((f32x4*)dW)[i] = a;
+        }
+    } else {
+        const int slab = blockIdx.x - nblk_w;
+        const int p0 = slab * px_per_slab, p1 = min(P, p0 + px_per_slab);
+        for (int co = threadIdx.x; co < cout; co += blockDim.x) {
+            float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            int pix = p0;
+            for (; pix + 8 <= p1; pix += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a[u] += dy[(size_t)(pix + u) * cout + co];     // 8 independent loads in flight
+            }
+            for (; pix < p1; ++pix) a[0] += dy[(size_t)pix * cout + co];
+            dbp[(size_t)slab * cout + co] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+        }
+    }
+}
+
+// (3b) push the weight gradient through mask + weight-norm (layers.py:57,60):
+//       w = e u,  u = v / n,  v = mask V,  n = ||v||_o,  e = exp(g)
+//       dg = sum dW w ;  dv = (e / n) (dW - u (sum dW u)) ;  dV = mask dv ;  db = sum_p dY
+//     One workgroup per 16 output channels (same thread map as the prep kernel), all of a thread's loads in one batch.
+struct WnBwdLayer {
+    const float* V; const float* g;      // reference variables of THIS conv (HWIO V)
+    const float* dW;                     // reduced effective-weight gradient [NTAPS][cin][cout_packed]
+    const float* dbp;                    // [nslab][cout_packed] column sums of dY
+    float* dV; float* dg; float* db;     // outputs: HWIO [3][3][cin][cout], [cout], [cout]
+    int cin, cout, cout_packed, nslab, zerodiag, pack_stride, pack_off;   // packed channel of o: (o/16)*pack_stride*16 + pack_off*16 + o%16
+};
+
+template <int NCH>
+__device__ __forceinline__ void wn_bwd_tile(const WnBwdLayer& L, int tile, float (*red)[16][17], float* s_n, float* s_dot) {
+    const int oo = threadIdx.x & 15, cs = threadIdx.x >> 4;
+    const int o = tile * 16 + oo;
+    const int op = (o >> 4) * L.pack_stride * 16 + L.pack_off * 16 + (o & 15);   // packed channel index
+    const int n_in = L.cin, n_out = L.cout;
+    float v[NTAPS][NCH], dw[NTAPS][NCH];
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+        const int ci = cs + 16 * it;
+#pragma unroll
+        for (int t = 0; t < NTAPS; ++t) {
+            const int kh = (t == 0 || t == 1) ? 1 : 2;
+            const int kw = (t == 0) ? 1 : (t == 1 ? 2 : t - 2);
+            v[t][it] = L.V[((size_t)(kh * 3 + kw) * n_in + ci) * n_out + o];
+            dw[t][it] = L.dW[((size_t)t * n_in + ci) * L.cout_packed + op];
+        }
+    }
+    float dbs = 0.f;
+    for (int r = cs; r < L.nslab; r += 16) dbs += L.dbp[(size_t)r * L.cout_packed + op];
+    float ss = 0.f, dot = 0.f;
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+        if (!made_live(cs + 16 * it, o, n_in, n_out, L.zerodiag)) { v[0][it] = 0.f; dw[0][it] = 0.f; }
+#pragma unroll
+        for (int t = 0; t < NTAPS; ++t) { ss += v[t][it] * v[t][it]; dot += dw[t][it] * v[t][it]; }
+    }
+    red[0][cs][oo] = ss; red[1][cs][oo] = dot; red[2][cs][oo] = dbs;
+    __syncthreads();
+    if (cs == 0) {
+        float a = 0.f, b = 0.f, c = 0.f;
+        for (int i = 0; i < 16; ++i) { a += red[0][i][oo]; b += red[1][i][oo]; c += red[2][i][oo]; }
+        const float n = sqrtf(fmaxf(a, 1e-12f));
+        const float e = expf(L.g[o]);
+        s_n[oo] = n;
+        s_dot[oo] = b / n;                 // sum dW u
+        L.dg[o] = e * b / n;               // sum dW w
+        L.db[o] = c;
+    }
+    __syncthreads();
+    const float n = s_n[oo], du = s_dot[oo], e = expf(L.g[o]);
+    // dV over all 9 taps: the 4 dead taps and the masked centre entries are exact zeros
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+        const int ci = cs + 16 * it;
+        const bool cl = made_live(ci, o, n_in, n_out, L.zerodiag);
+#pragma unroll
+        for (int kk9 = 0; kk9 < 9; ++kk9) {
+            const int kh = kk9 / 3, kw = kk9 % 3;
+            const int t = (kh == 1 && kw == 1) ? 0 : (kh == 1 && kw == 2) ? 1 : (kh == 2) ? 2 + kw : -1;
+            float outv = 0.f;
+            if (t > 0 || (t == 0 && cl)) outv = (e / n) * (dw[t < 0 ? 0 : t][it] - (v[t < 0 ? 0 : t][it] / n) * du);
+            L.dV[((size_t)kk9 * n_in + ci) * n_out + o] = outv;
+        }
+    }
+}
+
+struct WnBwdArgs {
+    WnBwdLayer L[MAX_GEMM_LAYERS + 1];   // one entry per conv (the output pair counts twice)
+    int tile_begin[MAX_GEMM_LAYERS + 2];
+    int n;
+};
+
+// every conv of a stack in one launch: workgroup -> (conv, 16-channel output tile)
+__global__ __launch_bounds__(256) void iaf_wn_bwd_kernel(WnBwdArgs a) {
+    __shared__ float red[3][16][17];
+    __shared__ float s_n[16], s_dot[16];
+    int li = 0;
+    for (int i = 1; i < a.n; ++i)
+        if ((int)blockIdx.x >= a.tile_begin[i]) li = i;
+    const WnBwdLayer& L = a.L[li];
+    const int tile = blockIdx.x - a.tile_begin[li];
+    switch (L.cin >> 4) {
+        case 1: wn_bwd_tile<1>(L, tile, red, s_n, s_dot); break;
+        case 2: wn_bwd_tile<2>(L, tile, red, s_n, s_dot); break;
+        case 3: wn_bwd_tile<3>(L, tile, red, s_n, s_dot); break;
+        case 4: wn_bwd_tile<4>(L, tile, red, s_n, s_dot); break;
+        case 5: wn_bwd_tile<5>(L, tile, red, s_n, s_dot); break;
+        case 6: wn_bwd_tile<6>(L, tile, red, s_n, s_dot); break;
+        case 7: wn_bwd_tile<7>(L, tile, red, s_n, s_dot); break;
+        case 8: wn_bwd_tile<8>(L, tile, red, s_n, s_dot); break;
+        case 9: wn_bwd_tile<9>(L, tile, red, s_n, s_dot); break;
+        case 10: wn_bwd_tile<10>(L, tile, red, s_n, s_dot); break;
+        case 11: wn_bwd_tile<11>(L, tile, red, s_n, s_dot); break;
+        case 12: wn_bwd_tile<12>(L, tile, red, s_n, s_dot); break;
+        case 13: wn_bwd_tile<13>(L, tile, red, s_n, s_dot); break;
+        case 14: wn_bwd_tile<14>(L, tile, red, s_n, s_dot); break;
+        case 15: wn_bwd_tile<15>(L, tile, red, s_n, s_dot); break;
+        case 16: wn_bwd_tile<16>(L, tile, red, s_n, s_dot); break;
+    }
+}
+
+// plain convs: NCHW -> pixel-major staging of the backward operands.  dst[P][C] = scale * act(concat_k src_k)[b, c, p]
+// (act = ELU when elu is set).  Up to MAXSPLIT sources; boundaries are multiples of 4.  A thread owns 4 channels of a pixel:
+// reads are coalesced along pixels (64 lanes = 64 consecutive pixels), the write is one 16-byte store.
+struct PackP {
+    const float* src[MAXSPLIT]; int end[MAXSPLIT]; int nsrc;
+    float* dst; int C, HW, P; float scale; int elu;
+};
+__global__ __launch_bounds__(256) void iaf_pack_pixmajor_kernel(PackP p) {
+    const int px = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int c = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 4;
+    if (px >= p.P || c >= p.C) return;
+    int k = 0;
+    while (k + 1 < p.nsrc && c >= p.end[k]) ++k;
+    const int c0 = k ? p.end[k - 1] : 0, ck = p.end[k] - c0;
+    const int b = px / p.HW, pp = px - b * p.HW;
+    const float* s = p.src[k] + ((size_t)b * ck + (c - c0)) * p.HW + pp;
+    f32x4 v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float t = s[(size_t)r * p.HW];
+        if (p.elu) t = elu_f(t);
+        v[r] = t * p.scale;
+    }
+    *(f32x4*)(p.dst + (size_t)px * p.C + c) = v;
+}
+
+// weight-norm backward of a plain (unmasked, 9-tap) conv, layers.py:60:  w = e u, u = V/n, n = ||V||_o, e = exp(g)
+//   dg = sum dW w;  dV = (e/n)(dW - u (sum dW u));  db = sum_p dY.   Same thread map as wn_bwd_tile; own kernel (18*NCH
+//   live registers per thread would halve the occupancy of the masked one).
+template <int NCH>
+__device__ __forceinline__ void wn_bwd_plain_tile(const WnBwdLayer& L, int tile, float (*red)[16][17], float* s_n, float* s_dot) {
+    const int oo = threadIdx.x & 15, cs = threadIdx.x >> 4;
+    const int o = tile * 16 + oo;
+    const int n_in = L.cin, n_out = L.cout;
+    float v[MAXTAPS][NCH], dw[MAXTAPS][NCH];
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+        const int ci = cs + 16 * it;
+#pragma unroll
+        for (int t = 0; t < MAXTAPS; ++t) {
+            v[t][it] = L.V[((size_t)t * n_in + ci) * n_out + o];
+            dw[t][it] = L.dW[((size_t)t * n_in + ci) * L.cout_packed + o];
+        }
+    }
+    float dbs = 0.f;
+    for (int r = cs; r < L.nslab; r += 16) dbs += L.dbp[(size_t)r * L.cout_packed + o];
+    float ss = 0.f, dot = 0.f;
+#pragma unroll
+    for (int it = 0; it < NCH; ++it)
+#pragma unroll
+        for (int t = 0; t < MAXTAPS; ++t) { ss += v[t][it] * v[t][it]; dot += dw[t][it] * v[t][it]; }
+    red[0][cs][oo] = ss; red[1][cs][oo] = dot; red[2][cs][oo] = dbs;
+    __syncthreads();
+    if (cs == 0) {
+        float a = 0.f, b = 0.f, c = 0.f;
+        for (int i = 0; i < 16; ++i) { a += red[0][i][oo]; b += red[1][i][oo]; c += red[2][i][oo]; }
+        const float n = sqrtf(fmaxf(a, 1e-12f));
+        s_n[oo] = n;
+        s_dot[oo] = b / n;
+        L.dg[o] = expf(L.g[o]) * b / n;
+        L.db[o] = c;
+    }
+    __syncthreads();
+    const float n = s_n[oo], du = s_dot[oo], e = expf(L.g[o]);
+#pragma unroll
+    for (int it = 0; it < NCH; ++it)
+#pragma unroll
+        for (int t = 0; t < MAXTAPS; ++t)
+            L.dV[((size_t)t * n_in + cs + 16 * it) * n_out + o] = (e / n) * (dw[t][it] - (v[t][it] / n) * du);
+}
+
+__global__ __launch_bounds__(256) void iaf_wn_bwd_plain_kernel(WnBwdLayer L) {
+    __shared__ float red[3][16][17];
+    __shared__ float s_n[16], s_dot[16];
+    switch (L.cin >> 4) {
+        case 1: wn_bwd_plain_tile<1>(L, blockIdx.x, red, s_n, s_dot); break;
+        case 2: wn_bwd_plain_tile<2>(L, blockIdx.x, red, s_n, s_dot); break;
+        case 3: wn_bwd_plain_tile<3>(L, blockIdx.x, red, s_n, s_dot); break;
+        case 4: wn_bwd_plain_tile<4>(L, blockIdx.x, red, s_n, s_dot); break;
+        case 5: wn_bwd_plain_tile<5>(L, blockIdx.x, red, s_n, s_dot); break;
+        case 6: wn_bwd_plain_tile<6>(L, blockIdx.x, red, s_n, s_dot); break;
+        case 7: wn_bwd_plain_tile<7>(L, blockIdx.x, red, s_n, s_dot); break;
+        case 8: wn_bwd_plain_tile<8>(L, blockIdx.x, red, s_n, s_dot); break;
+        case 9: wn_bwd_plain_tile<9>(L, blockIdx.x, red, s_n, s_dot); break;
+        case 10: wn_bwd_plain_tile<10>(L, blockIdx.x, red, s_n, s_dot); break;
+        case 11: wn_bwd_plain_tile<11>(L, blockIdx.x, red, s_n, s_dot); break;
+        case 12: wn_bwd_plain_tile<12>(L, blockIdx.x, red, s_n, s_dot); break;
+        case 13: wn_bwd_plain_tile<13>(L, blockIdx.x, red, s_n, s_dot); break;
+        case 14: wn_bwd_plain_tile<14>(L, blockIdx.x, red, s_n, s_dot); break;
+        case 15: wn_bwd_plain_tile<15>(L, blockIdx.x, red, s_n, s_dot); break;
+        case 16: wn_bwd_plain_tile<16>(L, blockIdx.x, red, s_n, s_dot); break;
+    }
+}
+
+// (4) posterior block backward, elementwise parts (tf_train.py:56-85 differentiated):
+//   pre : dkl[b,c,:,:] = G[b,c]  (free bits: G = (sum_b' dkl_obj[b']) / B where mean_b S[b,c] > kl_min, else 0;
+//                                  kl_min <= 0: G = dkl_obj[b]);
+//         z0 = mean + e^{lq} eps;  d z_tot = dz + dkl (z - pm) e^{-2 pl};  d pm = -dkl (z - pm) e^{-2 pl};
+//         d pl = dkl (1 - (z - pm)^2 e^{-2 pl});   core inputs: dz_new := dz_tot, dlogsd := dkl  (logqs += s)
+//   post: d mean = dz0;  d lq = dz0 (z0 - mean) - dkl     (d logq0/d mean = 0 and d logq0/d lq = -1 after the
+//         reparametrisation paths cancel analytically)
+__global__ __launch_bounds__(256) void iaf_post_bwd_gate_kernel(const float* __restrict__ S, const float* __restrict__ dkl_obj,
+                                                               float* __restrict__ Gc, int B, int Z, float kl_min) {
+    // one block; Gc[c] = gate(c) * sum_b dkl_obj[b] / B
+    __shared__ float s_sum;
+    if (threadIdx.x == 0) {
+        float a = 0.f;
+        for (int b = 0; b < B; ++b) a += dkl_obj[b];
+        s_sum = a / (float)B;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < Z; c += blockDim.x) {
+        float m = 0.f;
+        for (int b = 0; b < B; ++b) m += S[(size_t)b * Z + c];
+        Gc[c] = (m / (float)B > kl_min) ? s_sum : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void iaf_post_bwd_pre_kernel(const float* qm, const float* ql, const float* rm, const float* rl,
+                                                              const float* pm, const float* pl, const float* eps, const float* z,
+                                                              const float* dz, const float* Gc, const float* dkl_obj, float kl_min,
+                                                              float* z0, float* dzt, float* dkl, float* dpm, float* dpl, int Z,
+                                                              int HW, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t bc = i / HW;
+        const int c = (int)(bc % Z);
+        const size_t b = bc / Z;
+        const float g = (kl_min > 0.f) ? Gc[c] : dkl_obj[b];
+        const float mean = qm[i] + rm[i], lq = ql[i] + rl[i];
+        z0[i] = mean + __expf(0.5f * (2.f * lq)) * eps[i];
+        const float e2 = __expf(-2.f * pl[i]);
+        const float d = z[i] - pm[i];
+        const float gz = dz ? dz[i] : 0.f;
+        dzt[i] = gz + g * d * e2;
+        dkl[i] = g;
+        dpm[i] = -g * d * e2;
+        dpl[i] = g * (1.f - d * d * e2);
+    }
+}
+
+__global__ __launch_bounds__(256) void iaf_post_bwd_post_kernel(const float* qm, const float* rm, const float* z0, const float* dz0,
+                                                               const float* dkl, float* dmean, float* dlq, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float g = dz0[i];
+        dmean[i] = g;
+        dlq[i] = g * (z0[i] - (qm[i] + rm[i])) - dkl[i];
+    }
+}

@@ -1,0 +1,218 @@
+// iaf_kernels_misc.hpp -- small forward kernels: KL / free-bits reductions, Gaussian sample/logps, max-diff, Adamax+EMA, streaming lower bound, data-dependent init, discretized logistic.
+// Part of the single translation unit iaf_engine.hip (included there, in order; not a standalone header).
+#pragma once
+
+// ---------------------------------------------------------------------------------------------
+// KL / free-bits reduction, tf_train.py:77-85.  kl_elem [B,Z,H,W] -> kl_cost[B], kl_obj[B].
+// One workgroup: deterministic tree order.  S[b,c] = sum_{H,W} kl.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void iaf_kl_rowsum_kernel(const float* kl, float* S, int rows, int HW) {
+    // one wave per (b,c) row
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float a = 0.f;
+    for (int i = lane; i < HW; i += 64) a += kl[(size_t)row * HW + i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o);
+    if (lane == 0) S[row] = a;
+}
+
+__global__ __launch_bounds__(256) void iaf_kl_finish_kernel(const float* S, float* kl_obj, float* kl_cost, int B, int Z,
+                                                           float kl_min) {
+    // S is tiny ([B, Z]); stage it through LDS in one coalesced sweep instead of B*Z dependent global loads
+    __shared__ float sh[8192];
+    __shared__ float part[256];
+    __shared__ float s_fb;
+    const int tid = threadIdx.x, n = B * Z;
+    const bool in_lds = n <= 8192;
+    if (in_lds) {
+        for (int i = tid; i < n; i += 256) sh[i] = S[i];
+        __syncthreads();
+    }
+    const float* src = in_lds ? sh : S;
+    if (kl_min > 0.f) {
+        // kl_ave[c] = max(mean_b S[b,c], kl_min); kl_obj[b] = sum_c kl_ave[c]   (tf_train.py:79-82)
+        float a = 0.f;
+        for (int c = tid; c < Z; c += 256) {
+            float m = 0.f;
+            for (int b = 0; b < B; ++b) m += src[(size_t)b * Z + c];
+            a += fmaxf(m / (float)B, kl_min);
+        }
+        part[tid] = a;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) part[tid] += part[tid + o];
+            __syncthreads();
+        }
+        if (tid == 0) s_fb = part[0];
+        __syncthreads();
+    }
+    for (int b = tid; b < B; b += 256) {
+        float a = 0.f;
+        for (int c = 0; c < Z; ++c) a += src[(size_t)b * Z + c];
+        kl_cost[b] = a;                                        // tf_train.py:85
+        kl_obj[b] = (kl_min > 0.f) ? s_fb : a;                 // tf_train.py:82 / 84
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// elementwise distributions (tf_utils/distributions.py)
+// ---------------------------------------------------------------------------------------------
+// max |a - b| over n elements -> *out (float bits; non-negative floats order like unsigned ints).  NaN counts as +inf.
+__global__ __launch_bounds__(256) void iaf_maxdiff_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n,
+                                                         unsigned* out) {
+    float m = 0.f;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float d = fabsf(a[i] - b[i]);
+        m = (d > m || d != d) ? (d != d ? __builtin_inff() : d) : m;
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
+__global__ void iaf_gauss_sample_kernel(const float* mean, const float* logvar, const float* noise, float* out, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = mean[i] + expf(0.5f * logvar[i]) * noise[i];
+}
+__global__ void iaf_gauss_logps_kernel(const float* mean, const float* logvar, const float* sample, float* out, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float d = sample[i] - mean[i];
+        out[i] = -0.5f * (1.8378770664093453f + logvar[i] + d * d / expf(logvar[i]));
+    }
+}
+
+// Adamax (tf_utils/adamax.py:40-56; NB the reference's slot naming: "v" = first moment, "m" = infinity norm) fused
+// with the 1/N gradient averaging of average_grads (tf_utils/common.py:86) and the EMA of the parameters
+// (tf_train.py:157-158, decay 0.999).  One pass over flat fp32 buffers: 5 reads + 4 writes per element, HBM-bound.
+__global__ __launch_bounds__(256) void iaf_adamax_ema_kernel(float* __restrict__ var, const float* __restrict__ grad,
+                                                            float* __restrict__ slot_m, float* __restrict__ slot_v,
+                                                            float* __restrict__ ema, size_t n4, size_t n, float lr, float beta1,
+                                                            float beta2, float eps, float ema_decay, float grad_scale) {
+    auto upd = [&](float& w, float g, float& m, float& v, float& e) {
+        g *= grad_scale;
+        v = beta1 * v + (1.f - beta1) * g;                    // adamax.py:50
+        m = fmaxf(beta2 * m + eps, fabsf(g));                 // adamax.py:52
+        w -= lr * (v / m);                                    // adamax.py:53-55
+        e -= (1.f - ema_decay) * (e - w);                     // ExponentialMovingAverage.apply
+    };
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += stride) {
+        f32x4 w = ((f32x4*)var)[i], g = ((const f32x4*)grad)[i], m = ((f32x4*)slot_m)[i], v = ((f32x4*)slot_v)[i];
+        f32x4 e = ema ? ((f32x4*)ema)[i] : w;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float wr_ = w[r], mr = m[r], vr = v[r], er = e[r];
+            upd(wr_, g[r], mr, vr, er);
+            w[r] = wr_; m[r] = mr; v[r] = vr; e[r] = er;
+        }
+        ((f32x4*)var)[i] = w; ((f32x4*)slot_m)[i] = m; ((f32x4*)slot_v)[i] = v;
+        if (ema) ((f32x4*)ema)[i] = e;
+    }
+    for (size_t i = 4 * n4 + blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += stride) {   // tail
+        float e = ema ? ema[i] : var[i];
+        upd(var[i], grad[i], slot_m[i], slot_v[i], e);
+        if (ema) ema[i] = e;
+    }
+}
+
+// streaming logsumexp over k importance weights per image: one wave per image
+__global__ __launch_bounds__(256) void iaf_lb_update_kernel(float* run_max, float* run_sum, const float* log_pxz,
+                                                           const float* sum_kl, int n, int kc) {
+    const int img = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (img >= n) return;
+    const float* a = log_pxz + (size_t)img * kc;
+    const float* b = sum_kl + (size_t)img * kc;
+    float m = -INFINITY;
+    for (int i = lane; i < kc; i += 64) m = fmaxf(m, a[i] - b[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    const float old_m = run_max[img];
+    const float new_m = fmaxf(old_m, m);
+    float s = 0.f;
+    for (int i = lane; i < kc; i += 64) s += expf((a[i] - b[i]) - new_m);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) {
+        const float old_s = run_sum[img];
+        run_sum[img] = (old_m == -INFINITY ? 0.f : old_s * expf(old_m - new_m)) + s;
+        run_max[img] = new_m;
+    }
+}
+__global__ void iaf_lb_init_kernel(float* run_max, float* run_sum, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { run_max[i] = -INFINITY; run_sum[i] = 0.f; }
+}
+__global__ void iaf_lb_finalize_kernel(const float* run_max, const float* run_sum, float* out, int n, int k) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = -(-logf((float)k) + run_max[i] + logf(run_sum[i]));   // distributions.py:62
+}
+__global__ void iaf_lb_k1_kernel(const float* log_pxz, const float* sum_kl, float* out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = sum_kl[i] - log_pxz[i];                                 // distributions.py:57
+}
+
+// ---------------------------------------------------------------------------------------------
+// data-dependent init, tf_utils/layers.py:45-51: per-channel moments of x_init = conv(x, l2norm(mask*V)) over (N,H,W),
+//   scale = init_scale / sqrt(var + 1e-10);  g = log(scale)/3;  b = -mean*scale;  y = scale*(x_init - mean)
+// One workgroup per channel; two passes (mean, then centred variance) in a fixed tree order.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void iaf_datainit_kernel(const float* x, const float* __restrict__ add, float* y,
+                                                          float* __restrict__ g, float* __restrict__ b, int B, int C, int HW,
+                                                          float init_scale) {
+    __shared__ float red[4];
+    const int c = blockIdx.x;
+    const int n = B * HW;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) { const int bb = i / HW; s += x[((size_t)bb * C + c) * HW + (i - bb * HW)]; }
+    const float mean = block_sum_256(s, red) / (float)n;
+    float q = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int bb = i / HW;
+        const float d = x[((size_t)bb * C + c) * HW + (i - bb * HW)] - mean;
+        q += d * d;
+    }
+    const float var = block_sum_256(q, red) / (float)n;          // tf.nn.moments: biased
+    const float scale = init_scale / sqrtf(var + 1e-10f);
+    if (threadIdx.x == 0) { g[c] = logf(scale) / 3.0f; b[c] = -mean * scale; }
+    if (y)
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int bb = i / HW;
+            const size_t o = ((size_t)bb * C + c) * HW + (i - bb * HW);
+            y[o] = scale * (x[o] - mean) + (add ? add[o] : 0.f);
+        }
+}
+
+// discretized logistic log-likelihood, tf_utils/distributions.py:28-32 (call site tf_train.py:210): one workgroup per
+// batch row, out[b] = sum log(sigmoid(s + binsize/scale) - sigmoid(s) + 1e-7), s = (floor(x/binsize)*binsize - mean)/scale
+__global__ __launch_bounds__(256) void iaf_disc_logistic_kernel(const float* __restrict__ mean, const float* __restrict__ logscale,
+                                                               int scalar_scale, const float* __restrict__ sample,
+                                                               float* __restrict__ out, size_t n, float binsize) {
+    __shared__ float red[4];
+    const size_t base = (size_t)blockIdx.x * n;
+    float acc = 0.f;
+    for (size_t i = threadIdx.x; i < n; i += 256) {
+        const float scale = expf(scalar_scale ? logscale[0] : logscale[base + i]);
+        const float s = (floorf(sample[base + i] / binsize) * binsize - mean[base + i]) / scale;
+        // sigmoid(s+d) - sigmoid(s), evaluated on the side where both terms are small (sigmoid(t) = 1 - sigmoid(-t)):
+        // the literal fp32 form cancels to ~1e-7 absolute in the upper tail, the size of the +1e-7 floor itself
+        const float d = binsize / scale;
+        float diff;
+        if (s > 0.f) {
+            const float e0 = expf(-s), e1 = expf(-(s + d));
+            diff = e0 / (1.0f + e0) - e1 / (1.0f + e1);
+        } else {
+            diff = 1.0f / (1.0f + expf(-(s + d))) - 1.0f / (1.0f + expf(-s));
+        }
+        acc += logf(diff + 1e-7f);
+    }
+    const float tot = block_sum_256(acc, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = tot;
+}

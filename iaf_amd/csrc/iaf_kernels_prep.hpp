@@ -1,0 +1,257 @@
+// iaf_kernels_prep.hpp -- weight prep kernels: MADE mask rule, weight norm, repack into MFMA fragment order (masked 5-tap, Theano, plain 9-tap).
+// Part of the single translation unit iaf_engine.hip (included there, in order; not a standalone header).
+#pragma once
+
+// ---------------------------------------------------------------------------------------------
+// MADE channel mask rule, tf_utils/layers.py:115-131 (Python-2 integer division)
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ static inline bool made_live(int i, int o, int n_in, int n_out, int zerodiag) {
+    if (n_out >= n_in) {
+        const int k = n_out / n_in;
+        const int grp = o / k;                       // out-group index == highest visible input
+        return zerodiag ? (i < grp) : (i <= grp);
+    }
+    const int k = n_in / n_out;
+    return zerodiag ? (i < o * k) : (i < (o + 1) * k);
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight prep kernel: one workgroup per packed 16-channel output tile
+// ---------------------------------------------------------------------------------------------
+
+// Work split: one workgroup per (packed 16-channel output tile); thread (oo = tid&15, cs = tid>>4) owns output
+// channel o = tile*16+oo and input channels ci = cs, cs+16, ...  All of its 5*NCH filter taps are fetched in ONE
+// batch of independent, branch-free loads, kept in registers for the second pass.  NCH (= n_in/16) is a template
+// parameter so that exactly the needed loads are issued.
+struct PrepLayer {
+    const float* V[2];
+    const float* g[2];
+    const float* b[2];
+    float* wp;       // packed weights [chunk][tap][cot][64][4]
+    float* bias;     // packed bias [ncot*16]
+    float* border;   // Theano variant: [4][ncot*16] normalised weights of the border-indicator channel (taps 1..4)
+    float* wpt;      // training: TRANSPOSED pack [chunk over packed c_out][tap][c_in tile][64][4] for dX = W^T dY (or NULL)
+    int cin, cout_each, ncot, nchunk, zerodiag, npair, tile_begin, variant;
+};
+struct PrepArgs {
+    PrepLayer L[MAX_GEMM_LAYERS];
+    int nlayers;
+};
+
+// filter position (kh,kw) of live tap t: the 5 MADE-live taps (centre, right, then the row below), or all 9 row-major
+template <int NTP> __device__ __forceinline__ int tap_kh(int t) { return NTP == 9 ? t / 3 : ((t == 0 || t == 1) ? 1 : 2); }
+template <int NTP> __device__ __forceinline__ int tap_kw(int t) { return NTP == 9 ? t % 3 : ((t == 0) ? 1 : (t == 1 ? 2 : t - 2)); }
+
+template <int NCH, int NTP = NTAPS>
+__device__ __forceinline__ void prep_tile(const PrepLayer& L, int gt, float (*red)[17], float* s_scale) {
+    const int which = (L.npair == 2) ? (gt & 1) : 0;     // output pair: even tiles = mean, odd = logsd
+    const int src_tile = (L.npair == 2) ? (gt >> 1) : gt;
+    const float* __restrict__ V = L.V[which];
+    const int oo = threadIdx.x & 15, cs = threadIdx.x >> 4;
+    const int o = src_tile * 16 + oo;
+    const int n_out = L.cout_each, n_in = L.cin;
+    const float gval = L.g[which][o], bval = L.b[which][o];
+
+    // pass 1: fetch + mask (layers.py:57), sum of squares over (taps, c_in) (layers.py:60)
+    float v[NTP][NCH];
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+        const int ci = cs + 16 * it;
+#pragma unroll
+        for (int t = 0; t < NTP; ++t) {
+            v[t][it] = V[((size_t)(tap_kh<NTP>(t) * 3 + tap_kw<NTP>(t)) * n_in + ci) * n_out + o];
+        }
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+        if (NTP == NTAPS && !made_live(cs + 16 * it, o, n_in, n_out, L.zerodiag)) v[0][it] = 0.f;   // centre tap: channel MADE mask
+#pragma unroll
+        for (int t = 0; t < NTP; ++t) ss += v[t][it] * v[t][it];
+    }
+    red[cs][oo] = ss;
+    __syncthreads();
+    if (cs == 0) {
+        float tot = 0.f;
+        for (int i = 0; i < 16; ++i) tot += red[i][oo];
+        // w = exp(g) * v / sqrt(max(sum v^2, 1e-12))
+        s_scale[oo] = expf(gval) / sqrtf(fmaxf(tot, 1e-12f));
+        L.bias[gt * 16 + oo] = bval;
+    }
+    __syncthreads();
+    const float scale = s_scale[oo];
+    // pass 2: write fragment-ordered weights.  lane = kk*16+oo holds channels chunk*16+4kk+{0..3};
+    // ci = cs + 16*it  ->  chunk = it, kk = cs>>2, jj = cs&3: a wave writes 256 contiguous bytes.
+    const int kk = cs >> 2, jj = cs & 3;
+#pragma unroll
+    for (int it = 0; it < NCH; ++it)
+#pragma unroll
+        for (int t = 0; t < NTP; ++t)
+            L.wp[((((size_t)it * NTP + t) * L.ncot + gt) * 64 + kk * 16 + oo) * 4 + jj] = v[t][it] * scale;
+    if (L.wpt) {   // dgrad operand: K runs over the packed output channels (chunk = gt), N over input tiles (it)
+#pragma unroll
+        for (int it = 0; it < NCH; ++it)
+#pragma unroll
+            for (int t = 0; t < NTP; ++t)
+                L.wpt[((((size_t)gt * NTP + t) * NCH + it) * 64 + (oo >> 2) * 16 + cs) * 4 + (oo & 3)] = v[t][it] * scale;
+    }
+}
+
+// Theano statement of the same weights (graphy/nodes/ar.py:243-330, l2norm=True, logscale=True, pad_channel=True):
+//   w is OIHW [n_out][n_in+1][3][3] (last input channel = border indicator, graphy/nodes/conv.py:71-83),
+//   kerns = mask*w;  kerns /= (sqrt(sum_{i,h,w} kerns^2) + 1e-8);  kerns *= exp(3*s)          (ar.py:312-317, 279-281)
+//   the conv is a TRUE convolution (dnn_conv conv_mode='conv'), so filter position (kh,kw) meets the input at
+//   (dh,dw) = (1-kh, 1-kw): the same 5 live filter positions as the TF statement, looking left/above.
+// L.V = w, L.g = s, L.b = b.  The border channel never enters the GEMM: its 4 non-centre taps go to L.border and are
+// added by the conv epilogue where a tap falls outside the image (its centre tap is always masked).
+template <int NCH>
+__device__ __forceinline__ void prep_tile_theano(const PrepLayer& L, int gt, float (*red)[17], float* s_scale) {
+    const int which = (L.npair == 2) ? (gt & 1) : 0;
+    const int src_tile = (L.npair == 2) ? (gt >> 1) : gt;
+    const float* __restrict__ Wt = L.V[which];
+    const int oo = threadIdx.x & 15, cs = threadIdx.x >> 4;
+    const int o = src_tile * 16 + oo;
+    const int n_out = L.cout_each, n_in = L.cin;
+    const float sval = L.g[which][o], bval = L.b[which][o];
+    const float* wo = Wt + (size_t)o * (n_in + 1) * 9;
+    float v[NTAPS][NCH];
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+        const int ci = cs + 16 * it;
+#pragma unroll
+        for (int t = 0; t < NTAPS; ++t) {
+            const int kh = (t == 0 || t == 1) ? 1 : 2;
+            const int kw = (t == 0) ? 1 : (t == 1 ? 2 : t - 2);
+            v[t][it] = wo[(size_t)ci * 9 + kh * 3 + kw];
+        }
+    }
+    float wb[NTAPS - 1];   // border channel, taps 1..4 (thread cs == 0 accounts for it in the norm)
+#pragma unroll
+    for (int t = 1; t < NTAPS; ++t) {
+        const int kh = (t == 1) ? 1 : 2;
+        const int kw = (t == 1) ? 2 : t - 2;
+        wb[t - 1] = wo[(size_t)n_in * 9 + kh * 3 + kw];
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+        if (!made_live(cs + 16 * it, o, n_in, n_out, L.zerodiag)) v[0][it] = 0.f;   // ar.py:249-262 == the TF rule
+#pragma unroll
+        for (int t = 0; t < NTAPS; ++t) ss += v[t][it] * v[t][it];
+    }
+    if (cs == 0) {
+#pragma unroll
+        for (int t = 0; t < NTAPS - 1; ++t) ss += wb[t] * wb[t];
+    }
+    red[cs][oo] = ss;
+    __syncthreads();
+    if (cs == 0) {
+        float tot = 0.f;
+        for (int i = 0; i < 16; ++i) tot += red[i][oo];
+        const float sc = expf(3.0f * sval) / (sqrtf(tot) + 1e-8f);
+        s_scale[oo] = sc;
+        L.bias[gt * 16 + oo] = bval;
+#pragma unroll
+        for (int t = 0; t < NTAPS - 1; ++t) L.border[(size_t)t * (L.ncot * 16) + gt * 16 + oo] = wb[t] * sc;
+    }
+    __syncthreads();
+    const float scale = s_scale[oo];
+    const int kk = cs >> 2, jj = cs & 3;
+#pragma unroll
+    for (int it = 0; it < NCH; ++it)
+#pragma unroll
+        for (int t = 0; t < NTAPS; ++t)
+            L.wp[((((size_t)it * NTAPS + t) * L.ncot + gt) * 64 + kk * 16 + oo) * 4 + jj] = v[t][it] * scale;
+}
+
+#define PREP_MAXI 16   // n_in <= 256
+#define PREP_PLAIN9 100   // PrepLayer.variant of a plain (unmasked, 9-tap) TF conv2d
+template <int DUMMY = 0>
+__device__ __forceinline__ void prep_dispatch(const PrepLayer& L, int gt, float (*red)[17], float* s_scale) {
+    if (L.variant == IAF_VARIANT_THEANO) {
+        switch (L.nchunk) {
+            case 1: prep_tile_theano<1>(L, gt, red, s_scale); break;
+            case 2: prep_tile_theano<2>(L, gt, red, s_scale); break;
+            case 3: prep_tile_theano<3>(L, gt, red, s_scale); break;
+            case 4: prep_tile_theano<4>(L, gt, red, s_scale); break;
+            case 5: prep_tile_theano<5>(L, gt, red, s_scale); break;
+            case 6: prep_tile_theano<6>(L, gt, red, s_scale); break;
+            case 7: prep_tile_theano<7>(L, gt, red, s_scale); break;
+            case 8: prep_tile_theano<8>(L, gt, red, s_scale); break;
+            case 9: prep_tile_theano<9>(L, gt, red, s_scale); break;
+            case 10: prep_tile_theano<10>(L, gt, red, s_scale); break;
+            case 11: prep_tile_theano<11>(L, gt, red, s_scale); break;
+            case 12: prep_tile_theano<12>(L, gt, red, s_scale); break;
+            case 13: prep_tile_theano<13>(L, gt, red, s_scale); break;
+            case 14: prep_tile_theano<14>(L, gt, red, s_scale); break;
+            case 15: prep_tile_theano<15>(L, gt, red, s_scale); break;
+            case 16: prep_tile_theano<16>(L, gt, red, s_scale); break;
+        }
+        return;
+    }
+    switch (L.nchunk) {
+        case 1: prep_tile<1>(L, gt, red, s_scale); break;
+        case 2: prep_tile<2>(L, gt, red, s_scale); break;
+        case 3: prep_tile<3>(L, gt, red, s_scale); break;
+        case 4: prep_tile<4>(L, gt, red, s_scale); break;
+        case 5: prep_tile<5>(L, gt, red, s_scale); break;
+        case 6: prep_tile<6>(L, gt, red, s_scale); break;
+        case 7: prep_tile<7>(L, gt, red, s_scale); break;
+        case 8: prep_tile<8>(L, gt, red, s_scale); break;
+        case 9: prep_tile<9>(L, gt, red, s_scale); break;
+        case 10: prep_tile<10>(L, gt, red, s_scale); break;
+        case 11: prep_tile<11>(L, gt, red, s_scale); break;
+        case 12: prep_tile<12>(L, gt, red, s_scale); break;
+        case 13: prep_tile<13>(L, gt, red, s_scale); break;
+        case 14: prep_tile<14>(L, gt, red, s_scale); break;
+        case 15: prep_tile<15>(L, gt, red, s_scale); break;
+        case 16: prep_tile<16>(L, gt, red, s_scale); break;
+    }
+}
+
+// many stacks in one launch: descriptors live in device memory; tile2layer maps a workgroup to its GEMM layer
+__global__ __launch_bounds__(256) void iaf_prep_batch_kernel(const PrepLayer* __restrict__ layers,
+                                                            const int* __restrict__ tile2layer) {
+    __shared__ float red[16][17];
+    __shared__ float s_scale[16];
+    const PrepLayer L = layers[tile2layer[blockIdx.x]];
+    prep_dispatch(L, blockIdx.x - L.tile_begin, red, s_scale);
+}
+
+// plain (unmasked, 9-tap) convs: their own kernel so that the 9-tap register footprint does not tax the masked prep.
+// tile2layer == NULL: a single layer.
+__global__ __launch_bounds__(256) void iaf_prep_plain_kernel(const PrepLayer* __restrict__ layers,
+                                                            const int* __restrict__ tile2layer) {
+    __shared__ float red[16][17];
+    __shared__ float s_scale[16];
+    const PrepLayer L = layers[tile2layer ? tile2layer[blockIdx.x] : 0];
+    const int gt = blockIdx.x - L.tile_begin;
+    switch (L.nchunk) {
+        case 1: prep_tile<1, MAXTAPS>(L, gt, red, s_scale); break;
+        case 2: prep_tile<2, MAXTAPS>(L, gt, red, s_scale); break;
+        case 3: prep_tile<3, MAXTAPS>(L, gt, red, s_scale); break;
+        case 4: prep_tile<4, MAXTAPS>(L, gt, red, s_scale); break;
+        case 5: prep_tile<5, MAXTAPS>(L, gt, red, s_scale); break;
+        case 6: prep_tile<6, MAXTAPS>(L, gt, red, s_scale); break;
+        case 7: prep_tile<7, MAXTAPS>(L, gt, red, s_scale); break;
+        case 8: prep_tile<8, MAXTAPS>(L, gt, red, s_scale); break;
+        case 9: prep_tile<9, MAXTAPS>(L, gt, red, s_scale); break;
+        case 10: prep_tile<10, MAXTAPS>(L, gt, red, s_scale); break;
+        case 11: prep_tile<11, MAXTAPS>(L, gt, red, s_scale); break;
+        case 12: prep_tile<12, MAXTAPS>(L, gt, red, s_scale); break;
+        case 13: prep_tile<13, MAXTAPS>(L, gt, red, s_scale); break;
+        case 14: prep_tile<14, MAXTAPS>(L, gt, red, s_scale); break;
+        case 15: prep_tile<15, MAXTAPS>(L, gt, red, s_scale); break;
+        case 16: prep_tile<16, MAXTAPS>(L, gt, red, s_scale); break;
+    }
+}
+
+__global__ __launch_bounds__(256) void iaf_prep_kernel(PrepArgs a) {
+    __shared__ float red[16][17];
+    __shared__ float s_scale[16];
+    int li = 0;
+    for (int i = 1; i < a.nlayers; ++i)
+        if ((int)blockIdx.x >= a.L[i].tile_begin) li = i;
+    const PrepLayer& L = a.L[li];
+    prep_dispatch(L, blockIdx.x - L.tile_begin, red, s_scale);
+}
