@@ -579,6 +579,20 @@ def ar_conv2d(name, x, num_filters, filter_size=(3, 3), stride=(1, 1), pad="SAME
     return _conv_op(name, x, num_filters, bool(zerodiagonal), init, init_scale, store or _DEFAULT_STORE)
 
 
+def split(x, split_dim, split_sizes):
+    """tf_utils/common.py:21-36: cut `x` along `split_dim` into pieces of the given sizes (the boundary between
+    down_conv1 / up_conv1 and the IAF step, tf_train.py:37,54).  Same failure mode as the reference: sizes that do not
+    add up fail its assert (common.py:24).  Device-side copies by torch (plumbing); WNConv2d(split=...) avoids them altogether by
+    writing the pieces directly."""
+    n = int(x.shape[split_dim])
+    assert sum(split_sizes) == n, "split sizes %r do not add up to dimension %d" % (list(split_sizes), n)   # common.py:24
+    out, begin = [], 0
+    for size in split_sizes:
+        out.append(x.narrow(split_dim, begin, size).contiguous())
+        begin += size
+    return out
+
+
 class PrepBatch(object):
     """Weight prep (mask, l2-normalise, exp(g), repack) for MANY stacks in one launch -- what a model does once at
     the start of every step (the reference re-derives the normalised weights inside every conv2d call,

@@ -70,3 +70,17 @@ def test_tf_scope_filter_and_ema():
     for k, v in c["params"].items():
         np.testing.assert_array_equal(raw[k], v.astype(np.float32))
         np.testing.assert_array_equal(ema[k], (v * 0.5).astype(np.float32))
+
+
+def test_split_mirror_of_common_split():
+    """tf_utils/common.py:21-36 on host tensors: slices in order, assert on sizes that do not add up"""
+    import pytest
+    import torch
+    import iaf_amd
+    x = torch.arange(2 * 12 * 3, dtype=torch.float32).reshape(2, 12, 3)
+    parts = iaf_amd.split(x, 1, [4, 4, 2, 2])
+    assert [tuple(p.shape) for p in parts] == [(2, 4, 3), (2, 4, 3), (2, 2, 3), (2, 2, 3)]
+    assert all(p.is_contiguous() for p in parts)
+    assert torch.equal(torch.cat(parts, dim=1), x)
+    with pytest.raises(AssertionError):
+        iaf_amd.split(x, 1, [4, 4, 2])
