@@ -106,6 +106,7 @@ struct iaf_conv3x3_prep_batch {
     PrepLayer* h_layers;
     PrepLayer* d_layers;
     int* d_tile2layer;
+    bool uploaded;
 };
 
 extern "C" int iaf_conv3x3_prep_batch_destroy(iaf_conv3x3_prep_batch_t* b) {
@@ -161,13 +162,19 @@ extern "C" int iaf_conv3x3_prep_batch_create(iaf_conv3x3_prep_batch_t** out, iaf
 extern "C" int iaf_conv3x3_prep_batch_run(iaf_conv3x3_prep_batch_t* b, const float* const* V, const float* const* g,
                                           const float* const* bias, void* stream) {
     if (!b || !V || !g || !bias) return IAF_ERR_NULL;
+    bool changed = !b->uploaded;
     for (int i = 0; i < b->n; ++i) {
         if (!V[i] || !g[i] || !bias[i]) return IAF_ERR_NULL;
-        b->h_layers[i].V[0] = V[i]; b->h_layers[i].g[0] = g[i]; b->h_layers[i].b[0] = bias[i];
-        b->h_layers[i].wpt = b->convs[i]->training ? b->convs[i]->L.wpt : nullptr;
+        PrepLayer& P = b->h_layers[i];
+        float* wpt = b->convs[i]->training ? b->convs[i]->L.wpt : nullptr;
+        changed |= (P.V[0] != V[i]) | (P.g[0] != g[i]) | (P.b[0] != bias[i]) | (P.wpt != wpt);
+        P.V[0] = V[i]; P.g[0] = g[i]; P.b[0] = bias[i]; P.wpt = wpt;
     }
     hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(hipMemcpyAsync(b->d_layers, b->h_layers, sizeof(PrepLayer) * b->n, hipMemcpyHostToDevice, st));
+    if (changed) {     // see iaf_prep_batch_run
+        HIP_TRY(hipMemcpyAsync(b->d_layers, b->h_layers, sizeof(PrepLayer) * b->n, hipMemcpyHostToDevice, st));
+        b->uploaded = true;
+    }
     hipLaunchKernelGGL(iaf_prep_plain_kernel, dim3(b->ntiles), dim3(256), 0, st, b->d_layers, b->d_tile2layer);
     HIP_TRY(hipGetLastError());
     for (int i = 0; i < b->n; ++i) b->convs[i]->prepared = true;

@@ -361,6 +361,7 @@ struct iaf_prep_batch {
     PrepLayer* h_layers;   // pinned; read by the async copy (also when a captured graph replays)
     PrepLayer* d_layers;
     int* d_tile2layer;
+    bool uploaded;         // d_layers holds the current h_layers
 };
 
 extern "C" int iaf_prep_batch_destroy(iaf_prep_batch_t* b) {
@@ -419,6 +420,7 @@ extern "C" int iaf_prep_batch_run(iaf_prep_batch_t* b, const float* const* V, co
                                   const float* const* bias, void* stream) {
     if (!b || !V || !g || !bias) return IAF_ERR_NULL;
     int li = 0, ci = 0;   // ci: running conv index over all stacks (depth_ar + 2 convs per stack)
+    bool changed = !b->uploaded;
     for (int i = 0; i < b->n; ++i) {
         const iaf_stack* s = b->stacks[i];
         for (int l = 0; l < s->nlayers; ++l, ++li) {
@@ -426,13 +428,20 @@ extern "C" int iaf_prep_batch_run(iaf_prep_batch_t* b, const float* const* V, co
             const int np = s->L[l].npair;
             for (int e = 0; e < np; ++e) {
                 if (!V[ci + l + e] || !g[ci + l + e] || !bias[ci + l + e]) return IAF_ERR_NULL;
+                changed |= (P.V[e] != V[ci + l + e]) | (P.g[e] != g[ci + l + e]) | (P.b[e] != bias[ci + l + e]);
                 P.V[e] = V[ci + l + e]; P.g[e] = g[ci + l + e]; P.b[e] = bias[ci + l + e];
             }
+            changed |= (P.wpt != s->L[l].wpt);       // training switched on/off since the last run
+            P.wpt = s->L[l].wpt;
         }
         ci += s->depth_ar + 2;
     }
     hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(hipMemcpyAsync(b->d_layers, b->h_layers, sizeof(PrepLayer) * b->nlayers_total, hipMemcpyHostToDevice, st));
+    // the descriptor table only travels when a pointer in it changed (a training loop passes the same buffers every step)
+    if (changed) {
+        HIP_TRY(hipMemcpyAsync(b->d_layers, b->h_layers, sizeof(PrepLayer) * b->nlayers_total, hipMemcpyHostToDevice, st));
+        b->uploaded = true;
+    }
     hipLaunchKernelGGL(iaf_prep_batch_kernel, dim3(b->ntiles), dim3(256), 0, st, b->d_layers, b->d_tile2layer);
     HIP_TRY(hipGetLastError());
     for (int i = 0; i < b->n; ++i) b->stacks[i]->prepared = true;
