@@ -163,15 +163,12 @@ def train_bench(args, depths, dist, rank, n_gpus):
         L["params"] = {k: flat.p[L["pre"] + k] for k in L["keys"]}
         L["gradviews"] = {k: flat.g[L["pre"] + k] for k in L["keys"]}
     prep = iaf_amd.PrepBatch([L["stack"] for L in layers])
+    wnb = iaf_amd.WnBwdBatch(stacks=[L["stack"] for L in layers])     # mask + weight-norm backward: one launch per model
     plist = [L["params"] for L in layers]
+    glist = [L["gradviews"] for L in layers]
 
     def step():
-        prep.run(plist)
-        for L in layers:
-            i, st = L["inp"], L["stack"]
-            fw = st.posterior_block_train(i["qm"], i["ql"], i["rm"], i["rl"], i["pm"], i["pl"], i["uc"], i["dc"], i["eps"], 0.25)
-            st.posterior_block_backward(i["qm"], i["ql"], i["rm"], i["rl"], i["pm"], i["pl"], i["eps"], 0.25, fw["z"], i["dz"],
-                                        i["dko"], L["params"], grads_out=L["gradviews"])
+        compute()
         flat.all_reduce_grads()
         flat.adamax_ema_step(1e-4, world=n_gpus)
 
@@ -190,6 +187,7 @@ def train_bench(args, depths, dist, rank, n_gpus):
             fw = st.posterior_block_train(i["qm"], i["ql"], i["rm"], i["rl"], i["pm"], i["pl"], i["uc"], i["dc"], i["eps"], 0.25)
             st.posterior_block_backward(i["qm"], i["ql"], i["rm"], i["rl"], i["pm"], i["pl"], i["eps"], 0.25, fw["z"], i["dz"],
                                         i["dko"], L["params"], grads_out=L["gradviews"])
+        wnb.run(stack_params=plist, stack_grads=glist)
 
     stream = torch.cuda.Stream()
     graph = None
@@ -399,6 +397,10 @@ def layers_train_bench(args, depths, dist, rank, n_gpus):
     splist = [iaf_amd.IAFLayer.stack_params(L["params"]) for L in all_layers]
     cplist = [t for L in all_layers for t in iaf_amd.IAFLayer.conv_params(L["params"])]
     dko = torch.ones(B, device="cuda")
+    wnb = iaf_amd.WnBwdBatch(stacks=[L["layer"].posterior.stack for L in all_layers],
+                             convs=[c for L in all_layers for c in L["layer"].convs()])
+    sglist = [iaf_amd.IAFLayer.stack_params(L["grads"]) for L in all_layers]
+    cglist = [t for L in all_layers for t in iaf_amd.IAFLayer.conv_params(L["grads"])]
 
     def compute():
         prep_s.run(splist)
@@ -419,6 +421,7 @@ def layers_train_bench(args, depths, dist, rank, n_gpus):
             d = lv["d_up"]
             for L in reversed(lv["layers"]):
                 d = L["layer"].up_backward(d, L["params"], L["grads"])
+        wnb.run(stack_params=splist, stack_grads=sglist, conv_params=cplist, conv_grads=cglist)
 
     def step():
         compute()

@@ -39,6 +39,14 @@ SIGNATURES = {
     "iaf_step_inverse": (ctypes.c_int, [_vp, _c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_int, _vp, ctypes.c_size_t, ctypes.c_int, ctypes.c_float, ctypes.c_int, _vp,
                                         ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_float)]),
+    "iaf_stack_set_defer_weightnorm": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "iaf_wn_bwd_batch_create": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.c_int]),
+    "iaf_wn_bwd_batch_run": (ctypes.c_int, [_vp] + [ctypes.POINTER(_vp)] * 5 + [_vp]),
+    "iaf_wn_bwd_batch_destroy": (ctypes.c_int, [_vp]),
+    "iaf_conv3x3_set_defer_weightnorm": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "iaf_conv3x3_wn_bwd_batch_create": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.c_int]),
+    "iaf_conv3x3_wn_bwd_batch_run": (ctypes.c_int, [_vp] + [ctypes.POINTER(_vp)] * 5 + [_vp]),
+    "iaf_conv3x3_wn_bwd_batch_destroy": (ctypes.c_int, [_vp]),
     "iaf_stack_set_training": (ctypes.c_int, [_vp, ctypes.c_int]),
     "iaf_stack_train_workspace_bytes": (ctypes.c_size_t, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "iaf_step_forward_train": (ctypes.c_int, [_vp, _c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_int,

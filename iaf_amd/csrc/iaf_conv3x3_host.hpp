@@ -17,6 +17,11 @@ struct iaf_conv3x3 {
     PrepLayer* d_desc = nullptr;
     bool training = false;
     GemmLayer T;                   // transposed problem dX = W^T dY (valid when training)
+    // deferred weight-norm backward (iaf_conv3x3_wn_bwd_batch_run): the reduced dW / db partials live here, not in the
+    // (shared) workspace
+    bool defer_wn = false;
+    float* own_dW = nullptr; float* own_dbp = nullptr;
+    int pend_nslab = 0; bool pending = false;
 };
 
 extern "C" int iaf_conv3x3_destroy(iaf_conv3x3_t* c) {
@@ -24,6 +29,8 @@ extern "C" int iaf_conv3x3_destroy(iaf_conv3x3_t* c) {
     if (c->L.wp) (void)hipFree(c->L.wp);
     if (c->L.bias) (void)hipFree(c->L.bias);
     if (c->L.wpt) (void)hipFree(c->L.wpt);
+    if (c->own_dW) (void)hipFree(c->own_dW);
+    if (c->own_dbp) (void)hipFree(c->own_dbp);
     if (c->h_desc) (void)hipHostFree(c->h_desc);
     if (c->d_desc) (void)hipFree(c->d_desc);
     delete c;
@@ -213,7 +220,7 @@ static int conv3x3_launch(GemmLayer& L, ConvP& p, int epi_sel, int inmode, bool 
     p.cp = L.cin + 8;
     const size_t lds = conv_lds_bytes(L, W);
     if (lds > 160 * 1024) return IAF_ERR_UNSUPPORTED;
-    int rc = raise_lds_cap(fn, lds);
+    int rc = raise_lds_cap((const void*)fn, lds);
     if (rc) return rc;
     dim3 grid((p.P + tm - 1) / tm, L.ncot / (L.nt * L.wco));
     p.gx = (int)grid.x;
@@ -453,18 +460,126 @@ extern "C" int iaf_conv3x3_backward(iaf_conv3x3_t* c, const float* x, const floa
     if ((rc = launch_wgrad(nullptr, L, tw.xe, tw.dyc, tw.part, tw.tapmask, B, H, W, st))) return rc;
     const int nslab = (P + 31) / 32 < 256 ? (P + 31) / 32 : 256;
     const int px_per_slab = (P + nslab - 1) / nslab;
+    float* dWbuf = c->defer_wn ? c->own_dW : tw.dW;
+    float* dbpbuf = c->defer_wn ? c->own_dbp : tw.dbp;
     {
         const size_t n4 = (size_t)MAXTAPS * L.cin * L.cout / 4;
         int nblk = (int)((n4 + 255) / 256);
         if (nblk > 1024) nblk = 1024;
-        hipLaunchKernelGGL(iaf_wgrad_reduce_kernel, dim3(nblk + nslab), dim3(256), 0, st, tw.part, tw.dW,
-                           wgrad_nrange(P, L.cin, MAXTAPS), n4, nblk, (const float*)tw.dyc, tw.dbp, P, L.cout, px_per_slab);
+        hipLaunchKernelGGL(iaf_wgrad_reduce_kernel, dim3(nblk + nslab), dim3(256), 0, st, tw.part, dWbuf,
+                           wgrad_nrange(P, L.cin, MAXTAPS), n4, nblk, (const float*)tw.dyc, dbpbuf, P, L.cout, px_per_slab);
     }
-    // (4) through the weight norm
+    // (4) through the weight norm -- now, or in iaf_conv3x3_wn_bwd_batch_run with every other conv of the model
+    if (c->defer_wn) {
+        c->pend_nslab = nslab; c->pending = true;
+        return (int)hipGetLastError();
+    }
     WnBwdLayer w;
     memset(&w, 0, sizeof(w));
-    w.V = V; w.g = g; w.dW = tw.dW; w.dbp = tw.dbp; w.dV = dV; w.dg = dg; w.db = db;
+    w.V = V; w.g = g; w.dW = dWbuf; w.dbp = dbpbuf; w.dV = dV; w.dg = dg; w.db = db;
     w.cin = L.cin; w.cout = L.cout; w.cout_packed = L.cout; w.nslab = nslab; w.pack_stride = 1;
     hipLaunchKernelGGL(iaf_wn_bwd_plain_kernel, dim3(L.cout / 16), dim3(256), 0, st, w);
+    return (int)hipGetLastError();
+}
+
+// ---- deferred weight-norm backward of many plain convs in one launch ----------------------------------------------
+extern "C" int iaf_conv3x3_set_defer_weightnorm(iaf_conv3x3_t* c, int on) {
+    if (!c) return IAF_ERR_NULL;
+    if (on && !c->training) return IAF_ERR_NOT_PREPARED;
+    if (on) {
+        if (!c->own_dW) HIP_TRY(hipMalloc(&c->own_dW, (size_t)MAXTAPS * c->n_in * c->n_out * sizeof(float)));
+        if (!c->own_dbp) HIP_TRY(hipMalloc(&c->own_dbp, (size_t)256 * c->n_out * sizeof(float)));
+    }
+    c->defer_wn = on != 0;
+    c->pending = false;
+    return IAF_OK;
+}
+
+struct iaf_conv3x3_wn_bwd_batch {
+    int n, ntiles;
+    iaf_conv3x3** convs;
+    WnBwdLayer* h_layers;
+    WnBwdLayer* d_layers;
+    int* d_tile2layer;
+    int* d_tile_begin;
+    bool uploaded;
+};
+
+extern "C" int iaf_conv3x3_wn_bwd_batch_destroy(iaf_conv3x3_wn_bwd_batch_t* b) {
+    if (!b) return IAF_ERR_NULL;
+    if (b->h_layers) (void)hipHostFree(b->h_layers);
+    if (b->d_layers) (void)hipFree(b->d_layers);
+    if (b->d_tile2layer) (void)hipFree(b->d_tile2layer);
+    if (b->d_tile_begin) (void)hipFree(b->d_tile_begin);
+    free(b->convs);
+    delete b;
+    return IAF_OK;
+}
+
+extern "C" int iaf_conv3x3_wn_bwd_batch_create(iaf_conv3x3_wn_bwd_batch_t** out, iaf_conv3x3_t* const* convs, int n) {
+    if (!out || !convs) return IAF_ERR_NULL;
+    *out = nullptr;
+    if (n <= 0) return IAF_ERR_SHAPE;
+    iaf_conv3x3_wn_bwd_batch* b = new (std::nothrow) iaf_conv3x3_wn_bwd_batch();
+    if (!b) return (int)hipErrorOutOfMemory;
+    memset(b, 0, sizeof(*b));
+    b->n = n;
+    b->convs = (iaf_conv3x3**)calloc(n, sizeof(iaf_conv3x3*));
+    int nt = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!convs[i]) { iaf_conv3x3_wn_bwd_batch_destroy(b); return IAF_ERR_NULL; }
+        if (convs[i]->generic || convs[i]->mask_mode) { iaf_conv3x3_wn_bwd_batch_destroy(b); return IAF_ERR_UNSUPPORTED; }
+        b->convs[i] = convs[i];
+        nt += convs[i]->L.ncot;
+    }
+    b->ntiles = nt;
+    int* t2l = (int*)malloc(sizeof(int) * nt);
+    int* tb = (int*)malloc(sizeof(int) * (n + 1));
+    int rc;
+    if ((rc = (int)hipHostMalloc((void**)&b->h_layers, sizeof(WnBwdLayer) * n)) != 0 ||
+        (rc = (int)hipMalloc((void**)&b->d_layers, sizeof(WnBwdLayer) * n)) != 0 ||
+        (rc = (int)hipMalloc((void**)&b->d_tile2layer, sizeof(int) * nt)) != 0 ||
+        (rc = (int)hipMalloc((void**)&b->d_tile_begin, sizeof(int) * (n + 1))) != 0) {
+        free(t2l); free(tb); iaf_conv3x3_wn_bwd_batch_destroy(b); return rc;
+    }
+    memset(b->h_layers, 0, sizeof(WnBwdLayer) * n);
+    int tile = 0;
+    for (int i = 0; i < n; ++i) {
+        const GemmLayer& L = convs[i]->L;
+        WnBwdLayer& w = b->h_layers[i];
+        w.cin = L.cin; w.cout = L.cout; w.cout_packed = L.cout; w.pack_stride = 1;
+        tb[i] = tile;
+        for (int t = 0; t < L.ncot; ++t) t2l[tile++] = i;
+    }
+    tb[n] = tile;
+    rc = (int)hipMemcpy(b->d_tile2layer, t2l, sizeof(int) * nt, hipMemcpyHostToDevice);
+    if (!rc) rc = (int)hipMemcpy(b->d_tile_begin, tb, sizeof(int) * (n + 1), hipMemcpyHostToDevice);
+    free(t2l); free(tb);
+    if (rc) { iaf_conv3x3_wn_bwd_batch_destroy(b); return rc; }
+    *out = b;
+    return IAF_OK;
+}
+
+extern "C" int iaf_conv3x3_wn_bwd_batch_run(iaf_conv3x3_wn_bwd_batch_t* b, const float* const* V, const float* const* g,
+                                            float* const* dV, float* const* dg, float* const* db, void* stream) {
+    if (!b || !V || !g || !dV || !dg || !db) return IAF_ERR_NULL;
+    bool changed = !b->uploaded;
+    for (int i = 0; i < b->n; ++i) {
+        iaf_conv3x3* c = b->convs[i];
+        if (!c->defer_wn || !c->pending) return IAF_ERR_NOT_PREPARED;
+        if (!V[i] || !g[i] || !dV[i] || !dg[i] || !db[i]) return IAF_ERR_NULL;
+        WnBwdLayer& w = b->h_layers[i];
+        changed |= (w.V != V[i]) | (w.g != g[i]) | (w.dV != dV[i]) | (w.dg != dg[i]) | (w.db != db[i]) |
+                   (w.dW != c->own_dW) | (w.dbp != c->own_dbp) | (w.nslab != c->pend_nslab);
+        w.V = V[i]; w.g = g[i]; w.dV = dV[i]; w.dg = dg[i]; w.db = db[i];
+        w.dW = c->own_dW; w.dbp = c->own_dbp; w.nslab = c->pend_nslab;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (changed) {
+        HIP_TRY(hipMemcpyAsync(b->d_layers, b->h_layers, sizeof(WnBwdLayer) * b->n, hipMemcpyHostToDevice, st));
+        b->uploaded = true;
+    }
+    hipLaunchKernelGGL(iaf_wn_bwd_plain_batch_kernel, dim3(b->ntiles), dim3(256), 0, st, b->d_layers, b->d_tile2layer,
+                       b->d_tile_begin);
     return (int)hipGetLastError();
 }

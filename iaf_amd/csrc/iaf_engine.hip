@@ -81,6 +81,8 @@ struct iaf_stack {
     GemmLayer L[MAX_GEMM_LAYERS];
     GemmLayer T[MAX_GEMM_LAYERS];   // transposed problems (dX = W^T dY) of the same layers; valid when training
     bool training = false;
+    bool defer_wn = false;    // backward leaves the weight-norm pass to iaf_wn_bwd_batch_run (one launch per model)
+    float* pend_ws = nullptr; int pend_B = 0, pend_H = 0, pend_W = 0;   // ... which finds dWeff / dbp through these
     bool generic = false;     // channel counts outside the MFMA path: direct-conv fallback kernels
     bool prepared;
     size_t weight_bytes;  // raw V/g/b bytes of the stack (for the algorithmic byte count)
@@ -514,14 +516,14 @@ static void auto_shape(GemmLayer& L, bool is_out, long long P, int W) {
 }
 
 // raise the dynamic-LDS cap once per kernel (never inside a stream capture: warm up first)
-static int raise_lds_cap(conv_fn_t fn, size_t lds) {
+static int raise_lds_cap(const void* fn, size_t lds) {
     if (lds <= 48 * 1024) return 0;
     static std::mutex mu;
     static std::unordered_set<const void*> done;
     std::lock_guard<std::mutex> lk(mu);
-    if (!done.count((const void*)fn)) {
-        HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        done.insert((const void*)fn);
+    if (!done.count(fn)) {
+        HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        done.insert(fn);
     }
     return 0;
 }
@@ -551,7 +553,7 @@ static int launch_gemm(const iaf_stack_t* s, GemmLayer& L, int epi, bool negate_
     p.dbg = (prof_id >= 0 && s->dbg_layer == prof_id) ? s->dbg : nullptr;
     const size_t lds = conv_lds_bytes(L, p.W);
     if (lds > 160 * 1024) return IAF_ERR_UNSUPPORTED;
-    { int rc = raise_lds_cap(fn, lds); if (rc) return rc; }
+    { int rc = raise_lds_cap((const void*)fn, lds); if (rc) return rc; }
     dim3 grid((p.P + tm - 1) / tm, L.ncot / (L.nt * L.wco));
     const bool prof = (prof_id >= 0 && s->prof_layer == prof_id && s->prof_n < s->prof_cap);
     iaf_stack* ms = const_cast<iaf_stack*>(s);
@@ -963,11 +965,7 @@ extern "C" int iaf_step_forward_train(iaf_stack_t* s, const float* z, const floa
 template <int NCOT>
 static void launch_wgrad_t(const WgradP& p, dim3 grid, hipStream_t st) {
     const size_t lds = (size_t)4 * NCOT * 4 * 64 * sizeof(float);
-    static bool attr_done = false;
-    if (lds > 48 * 1024 && !attr_done) {
-        (void)hipFuncSetAttribute((const void*)iaf_wgrad_kernel<NCOT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
+    (void)raise_lds_cap((const void*)iaf_wgrad_kernel<NCOT>, lds);
     hipLaunchKernelGGL(iaf_wgrad_kernel<NCOT>, grid, dim3(256), lds, st, p);
 }
 
@@ -1096,8 +1094,123 @@ extern "C" int iaf_step_backward(iaf_stack_t* s, const float* z, const float* co
         }
         if (l > 0) dy = tw.da[(l - 1) & 1];
     }
-    // (3) mask + weight-norm backward of every conv of the stack in one launch
+    // (3) mask + weight-norm backward of every conv of the stack in one launch -- or left to iaf_wn_bwd_batch_run
+    if (s->defer_wn) {
+        s->pend_ws = (float*)workspace; s->pend_B = B; s->pend_H = H; s->pend_W = W;
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(iaf_wn_bwd_kernel, dim3(wa.tile_begin[wa.n]), dim3(256), 0, st, wa);
+    return (int)hipGetLastError();
+}
+
+// ---- deferred weight-norm backward of many stacks in one launch ------------------------------------------------
+extern "C" int iaf_stack_set_defer_weightnorm(iaf_stack_t* s, int on) {
+    if (!s) return IAF_ERR_NULL;
+    s->defer_wn = on != 0;
+    s->pend_ws = nullptr;
+    return IAF_OK;
+}
+
+struct iaf_wn_bwd_batch {
+    int n, nconv, ntiles;
+    iaf_stack** stacks;
+    WnBwdLayer* h_layers;   // pinned
+    WnBwdLayer* d_layers;
+    int* d_tile2layer;
+    int* d_tile_begin;
+    bool uploaded;
+};
+
+extern "C" int iaf_wn_bwd_batch_destroy(iaf_wn_bwd_batch_t* b) {
+    if (!b) return IAF_ERR_NULL;
+    if (b->h_layers) (void)hipHostFree(b->h_layers);
+    if (b->d_layers) (void)hipFree(b->d_layers);
+    if (b->d_tile2layer) (void)hipFree(b->d_tile2layer);
+    if (b->d_tile_begin) (void)hipFree(b->d_tile_begin);
+    free(b->stacks);
+    delete b;
+    return IAF_OK;
+}
+
+extern "C" int iaf_wn_bwd_batch_create(iaf_wn_bwd_batch_t** out, iaf_stack_t* const* stacks, int n) {
+    if (!out || !stacks) return IAF_ERR_NULL;
+    *out = nullptr;
+    if (n <= 0) return IAF_ERR_SHAPE;
+    iaf_wn_bwd_batch* b = new (std::nothrow) iaf_wn_bwd_batch();
+    if (!b) return (int)hipErrorOutOfMemory;
+    memset(b, 0, sizeof(*b));
+    b->n = n;
+    b->stacks = (iaf_stack**)calloc(n, sizeof(iaf_stack*));
+    int nconv = 0, nt = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!stacks[i]) { iaf_wn_bwd_batch_destroy(b); return IAF_ERR_NULL; }
+        if (stacks[i]->generic || stacks[i]->variant != IAF_VARIANT_TF) { iaf_wn_bwd_batch_destroy(b); return IAF_ERR_UNSUPPORTED; }
+        b->stacks[i] = stacks[i];
+        nconv += stacks[i]->depth_ar + 2;
+        for (int l = 0; l < stacks[i]->nlayers; ++l) nt += stacks[i]->L[l].cout / 16;   // output pair: 2 * n_z/16 tiles
+    }
+    b->nconv = nconv; b->ntiles = nt;
+    int* t2l = (int*)malloc(sizeof(int) * nt);
+    int* tb = (int*)malloc(sizeof(int) * (nconv + 1));
+    int rc;
+    if ((rc = (int)hipHostMalloc((void**)&b->h_layers, sizeof(WnBwdLayer) * nconv)) != 0 ||
+        (rc = (int)hipMalloc((void**)&b->d_layers, sizeof(WnBwdLayer) * nconv)) != 0 ||
+        (rc = (int)hipMalloc((void**)&b->d_tile2layer, sizeof(int) * nt)) != 0 ||
+        (rc = (int)hipMalloc((void**)&b->d_tile_begin, sizeof(int) * (nconv + 1))) != 0) {
+        free(t2l); free(tb); iaf_wn_bwd_batch_destroy(b); return rc;
+    }
+    memset(b->h_layers, 0, sizeof(WnBwdLayer) * nconv);
+    int ci = 0, tile = 0;
+    for (int i = 0; i < n; ++i) {
+        const iaf_stack* s = stacks[i];
+        for (int c = 0; c < s->depth_ar + 2; ++c, ++ci) {       // conv order of iaf_stack_prepare
+            const int l = c < s->depth_ar ? c : s->depth_ar;
+            const GemmLayer& L = s->L[l];
+            WnBwdLayer& w = b->h_layers[ci];
+            const bool pair = (l == s->depth_ar);
+            w.cin = L.cin; w.cout = pair ? s->n_z : L.cout; w.cout_packed = L.cout; w.zerodiag = L.zerodiag;
+            w.pack_stride = pair ? 2 : 1; w.pack_off = pair ? c - s->depth_ar : 0;
+            tb[ci] = tile;
+            for (int t = 0; t < w.cout / 16; ++t) t2l[tile++] = ci;
+        }
+    }
+    tb[ci] = tile;
+    rc = (int)hipMemcpy(b->d_tile2layer, t2l, sizeof(int) * nt, hipMemcpyHostToDevice);
+    if (!rc) rc = (int)hipMemcpy(b->d_tile_begin, tb, sizeof(int) * (nconv + 1), hipMemcpyHostToDevice);
+    free(t2l); free(tb);
+    if (rc) { iaf_wn_bwd_batch_destroy(b); return rc; }
+    *out = b;
+    return IAF_OK;
+}
+
+extern "C" int iaf_wn_bwd_batch_run(iaf_wn_bwd_batch_t* b, const float* const* V, const float* const* g, float* const* dV,
+                                    float* const* dg, float* const* db, void* stream) {
+    if (!b || !V || !g || !dV || !dg || !db) return IAF_ERR_NULL;
+    bool changed = !b->uploaded;
+    int ci = 0;
+    for (int i = 0; i < b->n; ++i) {
+        const iaf_stack* s = b->stacks[i];
+        if (!s->defer_wn || !s->pend_ws) return IAF_ERR_NOT_PREPARED;      // no deferred backward pending on this stack
+        const long long P = (long long)s->pend_B * s->pend_H * s->pend_W;
+        TrainWs tw;
+        train_ws_floats(s, P, &tw, s->pend_ws);
+        const int nslab = (P + 31) / 32 < 256 ? (int)((P + 31) / 32) : 256;
+        for (int c = 0; c < s->depth_ar + 2; ++c, ++ci) {
+            if (!V[ci] || !g[ci] || !dV[ci] || !dg[ci] || !db[ci]) return IAF_ERR_NULL;
+            const int l = c < s->depth_ar ? c : s->depth_ar;
+            WnBwdLayer& w = b->h_layers[ci];
+            changed |= (w.V != V[ci]) | (w.g != g[ci]) | (w.dV != dV[ci]) | (w.dg != dg[ci]) | (w.db != db[ci]) |
+                       (w.dW != tw.dWeff[l]) | (w.dbp != tw.dbp[l]) | (w.nslab != nslab);
+            w.V = V[ci]; w.g = g[ci]; w.dV = dV[ci]; w.dg = dg[ci]; w.db = db[ci];
+            w.dW = tw.dWeff[l]; w.dbp = tw.dbp[l]; w.nslab = nslab;
+        }
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (changed) {
+        HIP_TRY(hipMemcpyAsync(b->d_layers, b->h_layers, sizeof(WnBwdLayer) * b->nconv, hipMemcpyHostToDevice, st));
+        b->uploaded = true;
+    }
+    hipLaunchKernelGGL(iaf_wn_bwd_batch_kernel, dim3(b->ntiles), dim3(256), 0, st, b->d_layers, b->d_tile2layer, b->d_tile_begin);
     return (int)hipGetLastError();
 }
 

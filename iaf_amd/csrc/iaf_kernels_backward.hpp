@@ -280,6 +280,36 @@ __global__ __launch_bounds__(256) void iaf_wn_bwd_kernel(WnBwdArgs a) {
     }
 }
 
+// the same for the convs of MANY stacks (a whole model) in one launch: descriptors in device memory.  A stack's own launch
+// has 24 workgroups for 256 CUs and is bound by one CU's address unit (~21 us); batched, the model's 480 tiles cost about
+// the same as one stack alone.
+__global__ __launch_bounds__(256) void iaf_wn_bwd_batch_kernel(const WnBwdLayer* __restrict__ layers, const int* __restrict__ tile2layer,
+                                                              const int* __restrict__ tile_begin) {
+    __shared__ float red[3][16][17];
+    __shared__ float s_n[16], s_dot[16];
+    const int li = tile2layer[blockIdx.x];
+    const WnBwdLayer L = layers[li];
+    const int tile = blockIdx.x - tile_begin[li];
+    switch (L.cin >> 4) {
+        case 1: wn_bwd_tile<1>(L, tile, red, s_n, s_dot); break;
+        case 2: wn_bwd_tile<2>(L, tile, red, s_n, s_dot); break;
+        case 3: wn_bwd_tile<3>(L, tile, red, s_n, s_dot); break;
+        case 4: wn_bwd_tile<4>(L, tile, red, s_n, s_dot); break;
+        case 5: wn_bwd_tile<5>(L, tile, red, s_n, s_dot); break;
+        case 6: wn_bwd_tile<6>(L, tile, red, s_n, s_dot); break;
+        case 7: wn_bwd_tile<7>(L, tile, red, s_n, s_dot); break;
+        case 8: wn_bwd_tile<8>(L, tile, red, s_n, s_dot); break;
+        case 9: wn_bwd_tile<9>(L, tile, red, s_n, s_dot); break;
+        case 10: wn_bwd_tile<10>(L, tile, red, s_n, s_dot); break;
+        case 11: wn_bwd_tile<11>(L, tile, red, s_n, s_dot); break;
+        case 12: wn_bwd_tile<12>(L, tile, red, s_n, s_dot); break;
+        case 13: wn_bwd_tile<13>(L, tile, red, s_n, s_dot); break;
+        case 14: wn_bwd_tile<14>(L, tile, red, s_n, s_dot); break;
+        case 15: wn_bwd_tile<15>(L, tile, red, s_n, s_dot); break;
+        case 16: wn_bwd_tile<16>(L, tile, red, s_n, s_dot); break;
+    }
+}
+
 // plain convs: NCHW -> pixel-major staging of the backward operands.  dst[P][C] = scale * act(concat_k src_k)[b, c, p]
 // (act = ELU when elu is set).  Up to MAXSPLIT sources; boundaries are multiples of 4.  A thread owns 4 channels of a pixel:
 // reads are coalesced along pixels (64 lanes = 64 consecutive pixels), the write is one 16-byte store.
@@ -371,6 +401,34 @@ __global__ __launch_bounds__(256) void iaf_wn_bwd_plain_kernel(WnBwdLayer L) {
         case 14: wn_bwd_plain_tile<14>(L, blockIdx.x, red, s_n, s_dot); break;
         case 15: wn_bwd_plain_tile<15>(L, blockIdx.x, red, s_n, s_dot); break;
         case 16: wn_bwd_plain_tile<16>(L, blockIdx.x, red, s_n, s_dot); break;
+    }
+}
+
+__global__ __launch_bounds__(256) void iaf_wn_bwd_plain_batch_kernel(const WnBwdLayer* __restrict__ layers,
+                                                                    const int* __restrict__ tile2layer,
+                                                                    const int* __restrict__ tile_begin) {
+    __shared__ float red[3][16][17];
+    __shared__ float s_n[16], s_dot[16];
+    const int li = tile2layer[blockIdx.x];
+    const WnBwdLayer L = layers[li];
+    const int tile = blockIdx.x - tile_begin[li];
+    switch (L.cin >> 4) {
+        case 1: wn_bwd_plain_tile<1>(L, tile, red, s_n, s_dot); break;
+        case 2: wn_bwd_plain_tile<2>(L, tile, red, s_n, s_dot); break;
+        case 3: wn_bwd_plain_tile<3>(L, tile, red, s_n, s_dot); break;
+        case 4: wn_bwd_plain_tile<4>(L, tile, red, s_n, s_dot); break;
+        case 5: wn_bwd_plain_tile<5>(L, tile, red, s_n, s_dot); break;
+        case 6: wn_bwd_plain_tile<6>(L, tile, red, s_n, s_dot); break;
+        case 7: wn_bwd_plain_tile<7>(L, tile, red, s_n, s_dot); break;
+        case 8: wn_bwd_plain_tile<8>(L, tile, red, s_n, s_dot); break;
+        case 9: wn_bwd_plain_tile<9>(L, tile, red, s_n, s_dot); break;
+        case 10: wn_bwd_plain_tile<10>(L, tile, red, s_n, s_dot); break;
+        case 11: wn_bwd_plain_tile<11>(L, tile, red, s_n, s_dot); break;
+        case 12: wn_bwd_plain_tile<12>(L, tile, red, s_n, s_dot); break;
+        case 13: wn_bwd_plain_tile<13>(L, tile, red, s_n, s_dot); break;
+        case 14: wn_bwd_plain_tile<14>(L, tile, red, s_n, s_dot); break;
+        case 15: wn_bwd_plain_tile<15>(L, tile, red, s_n, s_dot); break;
+        case 16: wn_bwd_plain_tile<16>(L, tile, red, s_n, s_dot); break;
     }
 }
 

@@ -665,6 +665,62 @@ class ConvPrepBatch(object):
             c._prep_key = None
 
 
+class WnBwdBatch(object):
+    """Deferred mask + weight-norm backward of MANY stacks and / or plain convs: their backward calls stop after the
+    weight-gradient reduction and `run` finishes all of them in one launch per kind (a stack's own pass is 24
+    workgroups on a 256-CU chip).  Construction switches the objects to deferred mode."""
+
+    def __init__(self, stacks=(), convs=()):
+        self.stacks, self.convs = list(stacks), list(convs)
+        self._hs = self._hc = None
+        lib = _capi.lib()
+        if self.stacks:
+            for st in self.stacks:
+                _capi.check(lib.iaf_stack_set_defer_weightnorm(st._h, 1))
+            arr = (ctypes.c_void_p * len(self.stacks))(*[st._h.value for st in self.stacks])
+            self._hs = ctypes.c_void_p()
+            _capi.check(lib.iaf_wn_bwd_batch_create(ctypes.byref(self._hs), arr, len(self.stacks)))
+        if self.convs:
+            for c in self.convs:
+                _capi.check(lib.iaf_conv3x3_set_defer_weightnorm(c._h, 1))
+            arr = (ctypes.c_void_p * len(self.convs))(*[c._h.value for c in self.convs])
+            self._hc = ctypes.c_void_p()
+            _capi.check(lib.iaf_conv3x3_wn_bwd_batch_create(ctypes.byref(self._hc), arr, len(self.convs)))
+
+    def __del__(self):
+        try:
+            lib = _capi.lib()
+            if getattr(self, "_hs", None):
+                lib.iaf_wn_bwd_batch_destroy(self._hs)
+            if getattr(self, "_hc", None):
+                lib.iaf_conv3x3_wn_bwd_batch_destroy(self._hc)
+        except Exception:
+            pass
+
+    @staticmethod
+    def _tables(tens):
+        arr = ctypes.c_void_p * len(tens)
+        return arr(*[t.data_ptr() for t in tens])
+
+    def run(self, stack_params=(), stack_grads=(), conv_params=(), conv_grads=()):
+        """stack_params / stack_grads: one {conv/V|g|b: tensor} dict per stack (as for PrepBatch.run and
+        posterior_block_backward(grads_out=)); conv_params / conv_grads: one (V, g, b) / (dV, dg, db) tuple per conv."""
+        lib = _capi.lib()
+        if self._hs:
+            V, g, dV, dg, db = [], [], [], [], []
+            for st, p, gr in zip(self.stacks, stack_params, stack_grads):
+                for nm in st.conv_names():
+                    V.append(p[nm + "/V"]); g.append(p[nm + "/g"])
+                    dV.append(gr[nm + "/V"]); dg.append(gr[nm + "/g"]); db.append(gr[nm + "/b"])
+            _capi.check(lib.iaf_wn_bwd_batch_run(self._hs, self._tables(V), self._tables(g), self._tables(dV),
+                                                 self._tables(dg), self._tables(db), _stream()))
+        if self._hc:
+            V = [p[0] for p in conv_params]; g = [p[1] for p in conv_params]
+            dV = [q[0] for q in conv_grads]; dg = [q[1] for q in conv_grads]; db = [q[2] for q in conv_grads]
+            _capi.check(lib.iaf_conv3x3_wn_bwd_batch_run(self._hc, self._tables(V), self._tables(g), self._tables(dV),
+                                                         self._tables(dg), self._tables(db), _stream()))
+
+
 class _Struct(object):
     def __init__(self, **kw):
         self.__dict__.update(kw)

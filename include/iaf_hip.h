@@ -121,6 +121,19 @@ int iaf_step_backward(iaf_stack_t* s, const float* z, const float* context, cons
                       const float* const* g, float* const* dV, float* const* dg, float* const* db, int B, int H, int W,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* Deferred weight-norm backward.  A stack's own mask + weight-norm pass is a 24-workgroup launch (~21 us, bound by one CU's
+ * address unit); a model has tens of stacks.  iaf_stack_set_defer_weightnorm(s, 1) makes iaf_step_backward /
+ * iaf_posterior_block_backward stop after the weight-gradient reduction (dV/dg/db are NOT written; the reduced gradient
+ * stays in that call's workspace, which must stay untouched); iaf_wn_bwd_batch_run then finishes ALL stacks of the batch in
+ * one launch.  V/g/dV/dg/db: one pointer per conv over all stacks, in iaf_prep_batch_run order.
+ * IAF_ERR_NOT_PREPARED if a stack of the batch has no deferred backward pending. */
+typedef struct iaf_wn_bwd_batch iaf_wn_bwd_batch_t;
+int iaf_stack_set_defer_weightnorm(iaf_stack_t* s, int on);
+int iaf_wn_bwd_batch_create(iaf_wn_bwd_batch_t** out, iaf_stack_t* const* stacks, int n);
+int iaf_wn_bwd_batch_run(iaf_wn_bwd_batch_t* b, const float* const* V, const float* const* g, float* const* dV,
+                         float* const* dg, float* const* db, void* stream);
+int iaf_wn_bwd_batch_destroy(iaf_wn_bwd_batch_t* b);
+
 /* Training form of the posterior block (below): same outputs, keeps what the backward needs in `workspace`
  * (iaf_stack_train_workspace_bytes). */
 int iaf_posterior_block_forward_train(iaf_stack_t* s, const float* qz_mean, const float* qz_logsd, const float* rz_mean,
@@ -257,6 +270,14 @@ int iaf_conv3x3_backward(iaf_conv3x3_t* c, const float* x, const float* x2, int 
                          const int* dx_channels, int n_dxs, const float* dx_residual, const float* V, const float* g,
                          float* dV, float* dg, float* db, int B, int H, int W, void* workspace, size_t workspace_bytes,
                          void* stream);
+/* the same deferral for the plain convs (needs set_training first): iaf_conv3x3_backward keeps the reduced dW / db
+ * partials inside the object and leaves dV/dg/db to one iaf_conv3x3_wn_bwd_batch_run over all convs of the model */
+typedef struct iaf_conv3x3_wn_bwd_batch iaf_conv3x3_wn_bwd_batch_t;
+int iaf_conv3x3_set_defer_weightnorm(iaf_conv3x3_t* c, int on);
+int iaf_conv3x3_wn_bwd_batch_create(iaf_conv3x3_wn_bwd_batch_t** out, iaf_conv3x3_t* const* convs, int n);
+int iaf_conv3x3_wn_bwd_batch_run(iaf_conv3x3_wn_bwd_batch_t* b, const float* const* V, const float* const* g,
+                                 float* const* dV, float* const* dg, float* const* db, void* stream);
+int iaf_conv3x3_wn_bwd_batch_destroy(iaf_conv3x3_wn_bwd_batch_t* b);
 /* launch shape override (nt = 0 restores the automatic choice); see iaf_stack_set_tuning */
 int iaf_conv3x3_set_tuning(iaf_conv3x3_t* c, int nt, int pxt, int wco, int ks);
 /* times every compiled launch shape with `reps` back-to-back forwards on the caller's buffers (same arguments as

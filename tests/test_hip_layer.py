@@ -380,3 +380,54 @@ def test_iaf_layer_backward_vs_autograd_oracle(amd, kl_min):
     assert sorted(grads) == sorted(want["params"])
     worst = max((_relerr(host(grads[k]), want["params"][k]), k) for k in grads)
     assert worst[0] < 1e-4, worst
+
+
+def test_deferred_weightnorm_backward_equals_immediate(amd):
+    """two layers of different spatial size: backward with the weight-norm pass deferred to ONE batched launch per kind
+    must give exactly the gradients of the per-layer launches"""
+    c = gi.layer_case_inputs("layer_cfg2_8x8")
+    zs, hs = c["z_size"], c["h_size"]
+    rng = np.random.RandomState(4)
+    sizes = [(2, 8, 8), (3, 4, 4)]
+    layers, data = [], []
+    for (B, H, W) in sizes:
+        params = {k: dev(v + 0.01 * rng.standard_normal(v.shape)) for k, v in c["params"].items()}
+        layer = amd.IAFLayer(zs, hs, depth_ar=2, kl_min=0.25)
+        layer.set_training(True)
+        layer.load(params)
+        f = lambda ch: dev(rng.standard_normal((B, ch, H, W)))
+        data.append(dict(params=params, up=f(hs), down=f(hs), eps=f(zs), dU=f(hs), dD=f(hs), dK=dev(rng.standard_normal(B))))
+        layers.append(layer)
+
+    def run(defer):
+        grads = [dict() for _ in layers]
+        batch = None
+        if defer:
+            batch = amd.WnBwdBatch(stacks=[L.posterior.stack for L in layers], convs=[cv for L in layers for cv in L.convs()])
+            for g_, d in zip(grads, data):          # deferred mode writes through the batch: allocate the slots up front
+                for k, v in d["params"].items():
+                    g_[k] = torch.zeros_like(v)
+        outs = []
+        for L, d, g_ in zip(layers, data, grads):
+            L.up_train(d["up"])
+            L.down_train(d["down"], d["eps"])
+            dd = L.down_backward(d["dD"], d["dK"], d["params"], g_)
+            du = L.up_backward(d["dU"], d["params"], g_)
+            outs.append((dd, du))
+        if defer:
+            batch.run(stack_params=[amd.IAFLayer.stack_params(d["params"]) for d in data],
+                      stack_grads=[amd.IAFLayer.stack_params(g_) for g_ in grads],
+                      conv_params=[t for d in data for t in amd.IAFLayer.conv_params(d["params"])],
+                      conv_grads=[t for g_ in grads for t in amd.IAFLayer.conv_params(g_)])
+        torch.cuda.synchronize()
+        return grads, outs
+
+    g0, o0 = run(False)
+    g0 = [{k: v.clone() for k, v in g_.items()} for g_ in g0]
+    g1, o1 = run(True)
+    for a, b in zip(o0, o1):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for ga, gb in zip(g0, g1):
+        assert sorted(ga) == sorted(gb)
+        for k in ga:
+            assert torch.equal(ga[k], gb[k]), k
