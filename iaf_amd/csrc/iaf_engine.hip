@@ -38,6 +38,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <new>
 #include <unordered_set>
@@ -885,10 +886,10 @@ static int wgrad_nrange(long long P, int cin = 160, int ntaps = NTAPS) {
 
 struct TrainWs {
     float* h[MAX_GEMM_LAYERS];
-    float* da[2];
+    float* da[MAX_GEMM_LAYERS];      // d a_l (packed pixel-major), one per hidden layer: all still needed by the single reduce
     float* dy3;
     float* zpm;
-    float* part;
+    float* part[MAX_GEMM_LAYERS];    // per layer: weight-gradient partials [nrange][NTAPS][cin][cout]
     float* dWeff[MAX_GEMM_LAYERS];   // per layer: reduced effective-weight gradient [NTAPS][cin][cout]
     float* dbp[MAX_GEMM_LAYERS];     // per layer: [<=256 slabs][cout] column sums of dY
     // posterior block: saved forward values and backward temporaries, all NCHW [P*n_z] unless noted
@@ -903,17 +904,11 @@ static size_t train_ws_floats(const iaf_stack_t* s, long long P, TrainWs* o, flo
     auto take = [&](size_t n) { float* q = base ? base + off : nullptr; off += (n + 63) / 64 * 64; return q; };
     TrainWs t;
     for (int l = 0; l < s->depth_ar; ++l) t.h[l] = take((size_t)P * s->n_h);
-    t.da[0] = take((size_t)P * s->n_h);
-    t.da[1] = take((size_t)P * s->n_h);
+    for (int l = 0; l < s->depth_ar; ++l) t.da[l] = take((size_t)P * s->n_h);
     t.dy3 = take((size_t)P * 2 * s->n_z);
     t.zpm = take((size_t)P * s->n_z);
-    size_t maxw = 0;
     for (int l = 0; l < s->nlayers; ++l) {
-        const size_t w = (size_t)s->L[l].cin * s->L[l].cout;
-        if (w > maxw) maxw = w;
-    }
-    t.part = take((size_t)16 * NTAPS * maxw);
-    for (int l = 0; l < s->nlayers; ++l) {
+        t.part[l] = take((size_t)16 * NTAPS * s->L[l].cin * s->L[l].cout);
         t.dWeff[l] = take((size_t)NTAPS * s->L[l].cin * s->L[l].cout);
         t.dbp[l] = take((size_t)256 * s->L[l].cout);
     }
@@ -973,6 +968,34 @@ static int launch_tapmask(unsigned short* mask, int B, int H, int W, hipStream_t
     const int P = B * H * W;
     hipLaunchKernelGGL(iaf_tapmask_kernel, dim3((P + 255) / 256), dim3(256), 0, st, mask, H, W, P);
     return (int)hipGetLastError();
+}
+
+// The border table depends only on (B, H, W): built once per device and shape, then shared by every backward call
+// (it was a 4 us launch per layer per step).  First use allocates and synchronises, which a capturing stream must
+// not do: then the caller's workspace copy is filled in-stream instead.
+static int tapmask_for(int B, int H, int W, hipStream_t st, unsigned short* ws_copy, const unsigned short** out) {
+    struct Key { int dev, B, H, W; bool operator<(const Key& o) const { return memcmp(this, &o, sizeof(Key)) < 0; } };
+    static std::mutex mu;
+    static std::map<Key, unsigned short*> cache;
+    Key k{0, B, H, W};
+    HIP_TRY(hipGetDevice(&k.dev));
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(k);
+    if (it != cache.end()) { *out = it->second; return 0; }
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &cs);
+    if (cs != hipStreamCaptureStatusNone) {
+        *out = ws_copy;
+        return launch_tapmask(ws_copy, B, H, W, st);
+    }
+    unsigned short* buf = nullptr;
+    HIP_TRY(hipMalloc((void**)&buf, ((size_t)B * H * W + 1) / 2 * 4));
+    int rc = launch_tapmask(buf, B, H, W, st);
+    if (!rc) rc = (int)hipStreamSynchronize(st);
+    if (rc) { (void)hipFree(buf); return rc; }
+    cache[k] = buf;
+    *out = buf;
+    return 0;
 }
 
 static int launch_wgrad(const iaf_stack_t* s, const GemmLayer& L, const float* x, const float* dy, float* part,
@@ -1045,13 +1068,19 @@ extern "C" int iaf_step_backward(iaf_stack_t* s, const float* z, const float* co
 
     const int nslab = (P + 31) / 32 < 256 ? (P + 31) / 32 : 256;
     const int px_per_slab = (P + nslab - 1) / nslab;
-    auto reduce = [&](int l, const float* dy) {     // partials -> dWeff[l], dY column sums -> dbp[l]
+    ReduceArgs ra;                                  // one reduce launch for all layers, after the walk
+    memset(&ra, 0, sizeof(ra));
+    ra.nslab = nslab; ra.P = P; ra.px_per_slab = px_per_slab;
+    auto reduce_add = [&](int l, const float* dy) {   // partials -> dWeff[l], dY column sums -> dbp[l]
         const GemmLayer& L = s->L[l];
-        const size_t n4 = (size_t)NTAPS * L.cin * L.cout / 4;
-        int nblk = (int)((n4 + 255) / 256);
-        if (nblk > 1024) nblk = 1024;
-        hipLaunchKernelGGL(iaf_wgrad_reduce_kernel, dim3(nblk + nslab), dim3(256), 0, st, tw.part, tw.dWeff[l],
-                           wgrad_nrange(P, L.cin), n4, nblk, dy, tw.dbp[l], P, L.cout, px_per_slab);
+        ReduceLayer& r = ra.L[ra.n++];
+        r.part = tw.part[l]; r.dW = tw.dWeff[l]; r.n4 = (size_t)NTAPS * L.cin * L.cout / 4;
+        r.nrange = wgrad_nrange(P, L.cin);
+        int nblk = (int)((r.n4 + 255) / 256);
+        if (nblk > 256) nblk = 256;
+        r.blk_begin = ra.nblk_total;
+        ra.nblk_total += nblk;
+        r.dy = dy; r.dbp = tw.dbp[l]; r.cout = L.cout;
     };
     WnBwdArgs wa;
     memset(&wa, 0, sizeof(wa));
@@ -1067,7 +1096,8 @@ extern "C" int iaf_step_backward(iaf_stack_t* s, const float* z, const float* co
         wa.n++;
     };
 
-    if ((rc = launch_tapmask(tw.tapmask, B, H, W, st))) return rc;
+    const unsigned short* tapmask = nullptr;
+    if ((rc = tapmask_for(B, H, W, st, tw.tapmask, &tapmask))) return rc;
     // (2) walk the layers backwards: data gradient (same conv kernel on W^T, mirrored taps), then weight gradient
     const float* dy = tw.dy3;                       // gradient w.r.t. the output of layer l (packed pixel-major)
     for (int l = d; l >= 0; --l) {
@@ -1080,20 +1110,21 @@ extern "C" int iaf_step_backward(iaf_stack_t* s, const float* z, const float* co
         } else {                                    // d a_{l-1} = (W_l^T dY) elu'(h_{l-1})   (+ NCHW copy = d context)
             p.mode = MODE_DGRAD_ELU;
             p.zin = tw.h[l - 1];
-            p.y = tw.da[(l - 1) & 1];
+            p.y = tw.da[l - 1];
             p.out0 = (l - 1 == 0) ? dcontext : nullptr;
         }
         if ((rc = launch_gemm(s, s->T[l], EPI_DGRAD, true, -1, p, IN_PIXMAJOR, st))) return rc;
-        if ((rc = launch_wgrad(s, s->L[l], x_in, dy, tw.part, tw.tapmask, B, H, W, st))) return rc;
-        reduce(l, dy);
+        if ((rc = launch_wgrad(s, s->L[l], x_in, dy, tw.part[l], tapmask, B, H, W, st))) return rc;
+        reduce_add(l, dy);
         if (l == d) {
             wn_add(d, l, s->n_z, 2, 0);       // layer_out_0 (mean tiles)
             wn_add(d + 1, l, s->n_z, 2, 1);   // layer_out_1 (logsd tiles)
         } else {
             wn_add(l, l, s->L[l].cout, 1, 0);
         }
-        if (l > 0) dy = tw.da[(l - 1) & 1];
+        if (l > 0) dy = tw.da[l - 1];
     }
+    hipLaunchKernelGGL(iaf_wgrad_reduce_multi_kernel, dim3(ra.nblk_total + ra.n * nslab), dim3(256), 0, st, ra);
     // (3) mask + weight-norm backward of every conv of the stack in one launch -- or left to iaf_wn_bwd_batch_run
     if (s->defer_wn) {
         s->pend_ws = (float*)workspace; s->pend_B = B; s->pend_H = H; s->pend_W = W;

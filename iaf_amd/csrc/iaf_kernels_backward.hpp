@@ -176,6 +176,50 @@ __global__ __launch_bounds__(256) void iaf_wgrad_reduce_kernel(const float* __re
     }
 }
 
+// (3a') the same for ALL GEMM layers of a stack in one launch (three 5 us launches per stack otherwise): block ranges per
+//       layer for the partial sums, then nslab blocks per layer for the dY column sums.
+struct ReduceLayer {
+    const float* part; float* dW; size_t n4; int nrange; int blk_begin;
+    const float* dy; float* dbp; int cout;
+};
+struct ReduceArgs { ReduceLayer L[MAX_GEMM_LAYERS]; int n, nblk_total, nslab, P, px_per_slab; };
+
+__global__ __launch_bounds__(256) void iaf_wgrad_reduce_multi_kernel(ReduceArgs a) {
+    if ((int)blockIdx.x < a.nblk_total) {
+        int li = 0;
+        for (int i = 1; i < a.n; ++i)
+            if ((int)blockIdx.x >= a.L[i].blk_begin) li = i;
+        const float* part = a.L[li].part;
+        float* dW = a.L[li].dW;
+        const size_t n4 = a.L[li].n4;
+        const int nrange = a.L[li].nrange;
+        const int nblk = ((li + 1 < a.n) ? a.L[li + 1].blk_begin : a.nblk_total) - a.L[li].blk_begin;
+        const int blk = blockIdx.x - a.L[li].blk_begin;
+        for (size_t i = blk * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)nblk * blockDim.x) {
+            f32x4 v = ((const f32x4*)part)[i];
+            for (int k = 1; k < nrange; ++k) v += ((const f32x4*)part)[(size_t)k * n4 + i];
+            ((f32x4*)dW)[i] = v;
+        }
+    } else {
+        const int idx = blockIdx.x - a.nblk_total;
+        const int li = idx / a.nslab, slab = idx - li * a.nslab;
+        const float* dy = a.L[li].dy;
+        float* dbp = a.L[li].dbp;
+        const int cout = a.L[li].cout;
+        const int p0 = slab * a.px_per_slab, p1 = min(a.P, p0 + a.px_per_slab);
+        for (int co = threadIdx.x; co < cout; co += blockDim.x) {
+            float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            int pix = p0;
+            for (; pix + 8 <= p1; pix += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s8[u] += dy[(size_t)(pix + u) * cout + co];
+            }
+            for (; pix < p1; ++pix) s8[0] += dy[(size_t)pix * cout + co];
+            dbp[(size_t)slab * cout + co] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+        }
+    }
+}
+
 // (3b) push the weight gradient through mask + weight-norm (layers.py:57,60):
 //       w = e u,  u = v / n,  v = mask V,  n = ||v||_o,  e = exp(g)
 //       dg = sum dW w ;  dv = (e / n) (dW - u (sum dW u)) ;  dV = mask dv ;  db = sum_p dY
