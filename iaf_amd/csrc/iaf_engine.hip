@@ -779,7 +779,7 @@ extern "C" int iaf_posterior_block_forward(iaf_stack_t* s, const float* qz_mean,
     if ((rc = run_stack(s, p, IN_POSTERIOR, up_context, down_context, ws, st))) return rc;
     const int rows = B * s->n_z;
     hipLaunchKernelGGL(iaf_kl_rowsum_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, p.kl_elem, ws.rowsum, rows, H * W);
-    hipLaunchKernelGGL(iaf_kl_finish_kernel, dim3(1), dim3(256), 0, st, ws.rowsum, kl_obj, kl_cost, B, s->n_z, kl_min);
+    hipLaunchKernelGGL(iaf_kl_finish_kernel, dim3(1), dim3(256), 0, st, ws.rowsum, kl_obj, kl_cost, B, s->n_z, kl_min, (float*)nullptr);
     return (int)hipGetLastError();
 }
 
@@ -1284,7 +1284,7 @@ extern "C" int iaf_posterior_block_forward_train(iaf_stack_t* s, const float* qz
     if ((rc = launch_conv(s, s->depth_ar, p, inmode, st))) return rc;
     const int rows = B * s->n_z;
     hipLaunchKernelGGL(iaf_kl_rowsum_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, tw.klelem, tw.rowsum, rows, H * W);
-    hipLaunchKernelGGL(iaf_kl_finish_kernel, dim3(1), dim3(256), 0, st, tw.rowsum, kl_obj, kl_cost, B, s->n_z, kl_min);
+    hipLaunchKernelGGL(iaf_kl_finish_kernel, dim3(1), dim3(256), 0, st, tw.rowsum, kl_obj, kl_cost, B, s->n_z, kl_min, tw.gate);
     return (int)hipGetLastError();
 }
 
@@ -1306,11 +1306,10 @@ extern "C" int iaf_posterior_block_backward(iaf_stack_t* s, const float* qz_mean
     train_ws_floats(s, (long long)B * H * W, &tw, (float*)workspace);
     hipStream_t st = (hipStream_t)stream;
     const size_t n = (size_t)B * s->n_z * H * W;
-    if (kl_min > 0.f)
-        hipLaunchKernelGGL(iaf_post_bwd_gate_kernel, dim3(1), dim3(256), 0, st, tw.rowsum, dkl_obj, tw.gate, B, s->n_z, kl_min);
+    // the free-bits gate [n_z] was left in the workspace by iaf_posterior_block_forward_train (same kl_min)
     hipLaunchKernelGGL(iaf_post_bwd_pre_kernel, ew_grid(n), dim3(256), 0, st, qz_mean, qz_logsd, rz_mean, rz_logsd, pz_mean,
-                       pz_logsd, eps, z, dz, tw.gate, dkl_obj, kl_min, tw.z0, tw.dzt, tw.dkl, dpz_mean, dpz_logsd, s->n_z, H * W,
-                       n);
+                       pz_logsd, eps, z, dz, tw.gate, dkl_obj, kl_min, tw.z0, tw.dzt, tw.dkl, dpz_mean, dpz_logsd, B, s->n_z,
+                       H * W, n);
     if ((rc = (int)hipGetLastError())) return rc;
     // core: z := z0, (z_new, logsd) := saved forward values, incoming gradients := (dz_tot, dkl)
     if ((rc = iaf_step_backward(s, tw.z0, dcontext /* value unused */, z, tw.logsd, tw.dzt, tw.dkl, tw.dz0, dcontext, V, g, dV, dg,

@@ -477,39 +477,34 @@ __global__ __launch_bounds__(256) void iaf_wn_bwd_plain_batch_kernel(const WnBwd
 }
 
 // (4) posterior block backward, elementwise parts (tf_train.py:56-85 differentiated):
-//   pre : dkl[b,c,:,:] = G[b,c]  (free bits: G = (sum_b' dkl_obj[b']) / B where mean_b S[b,c] > kl_min, else 0;
+//   pre : dkl[b,c,:,:] = G[b,c]  (free bits: G = gate[c] (sum_b' dkl_obj[b']) / B, gate = [mean_b S[b,c] > kl_min];
 //                                  kl_min <= 0: G = dkl_obj[b]);
 //         z0 = mean + e^{lq} eps;  d z_tot = dz + dkl (z - pm) e^{-2 pl};  d pm = -dkl (z - pm) e^{-2 pl};
 //         d pl = dkl (1 - (z - pm)^2 e^{-2 pl});   core inputs: dz_new := dz_tot, dlogsd := dkl  (logqs += s)
 //   post: d mean = dz0;  d lq = dz0 (z0 - mean) - dkl     (d logq0/d mean = 0 and d logq0/d lq = -1 after the
 //         reparametrisation paths cancel analytically)
-__global__ __launch_bounds__(256) void iaf_post_bwd_gate_kernel(const float* __restrict__ S, const float* __restrict__ dkl_obj,
-                                                               float* __restrict__ Gc, int B, int Z, float kl_min) {
-    // one block; Gc[c] = gate(c) * sum_b dkl_obj[b] / B
-    __shared__ float s_sum;
-    if (threadIdx.x == 0) {
-        float a = 0.f;
-        for (int b = 0; b < B; ++b) a += dkl_obj[b];
-        s_sum = a / (float)B;
-    }
-    __syncthreads();
-    for (int c = threadIdx.x; c < Z; c += blockDim.x) {
-        float m = 0.f;
-        for (int b = 0; b < B; ++b) m += S[(size_t)b * Z + c];
-        Gc[c] = (m / (float)B > kl_min) ? s_sum : 0.f;
-    }
-}
-
+// gate[c] in {0,1} comes from the forward (iaf_kl_finish_kernel); the common factor (sum_b dkl_obj[b]) / B is rebuilt per
+// workgroup from the B-vector (a separate one-block launch used to do both).
 __global__ __launch_bounds__(256) void iaf_post_bwd_pre_kernel(const float* qm, const float* ql, const float* rm, const float* rl,
                                                               const float* pm, const float* pl, const float* eps, const float* z,
-                                                              const float* dz, const float* Gc, const float* dkl_obj, float kl_min,
-                                                              float* z0, float* dzt, float* dkl, float* dpm, float* dpl, int Z,
+                                                              const float* dz, const float* gate, const float* dkl_obj, float kl_min,
+                                                              float* z0, float* dzt, float* dkl, float* dpm, float* dpl, int B, int Z,
                                                               int HW, size_t n) {
+    __shared__ float s_part[4];
+    float gsum = 0.f;
+    if (kl_min > 0.f) {
+        float a = 0.f;
+        for (int b = threadIdx.x; b < B; b += 256) a += dkl_obj[b];
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
+        if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = a;
+        __syncthreads();
+        gsum = ((s_part[0] + s_part[1]) + (s_part[2] + s_part[3])) / (float)B;
+    }
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const size_t bc = i / HW;
         const int c = (int)(bc % Z);
         const size_t b = bc / Z;
-        const float g = (kl_min > 0.f) ? Gc[c] : dkl_obj[b];
+        const float g = (kl_min > 0.f) ? gate[c] * gsum : dkl_obj[b];
         const float mean = qm[i] + rm[i], lq = ql[i] + rl[i];
         z0[i] = mean + __expf(0.5f * (2.f * lq)) * eps[i];
         const float e2 = __expf(-2.f * pl[i]);

@@ -17,8 +17,10 @@ __global__ __launch_bounds__(256) void iaf_kl_rowsum_kernel(const float* kl, flo
     if (lane == 0) S[row] = a;
 }
 
+// gate (optional, [Z]): 1 where the free-bits max() passes the gradient (mean_b S[b,c] > kl_min), else 0 -- what the
+// backward of tf_train.py:79-80 needs; written here because the batch mean is already on hand.
 __global__ __launch_bounds__(256) void iaf_kl_finish_kernel(const float* S, float* kl_obj, float* kl_cost, int B, int Z,
-                                                           float kl_min) {
+                                                           float kl_min, float* gate = nullptr) {
     // S is tiny ([B, Z]); stage it through LDS in one coalesced sweep instead of B*Z dependent global loads
     __shared__ float sh[8192];
     __shared__ float part[256];
@@ -37,6 +39,7 @@ __global__ __launch_bounds__(256) void iaf_kl_finish_kernel(const float* S, floa
             float m = 0.f;
             for (int b = 0; b < B; ++b) m += src[(size_t)b * Z + c];
             a += fmaxf(m / (float)B, kl_min);
+            if (gate) gate[c] = (m / (float)B > kl_min) ? 1.f : 0.f;
         }
         part[tid] = a;
         __syncthreads();

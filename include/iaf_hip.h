@@ -144,7 +144,8 @@ int iaf_posterior_block_forward_train(iaf_stack_t* s, const float* qz_mean, cons
 /* Backward of tf_train.py:56-85 given dL/dz [B,n_z,H,W] (may be NULL = 0) and dL/dkl_obj [B]:
  *   dmean     = dL/d qz_mean  = dL/d rz_mean           dlogsd_q = dL/d qz_logsd = dL/d rz_logsd
  *   dpz_mean, dpz_logsd, dcontext (= dL/d up_context = dL/d down_context), and dV/dg/db as in iaf_step_backward.
- * Free bits: the gradient of max(mean_b sum_hw kl, kl_min) is gated per channel (tf_train.py:79-82). */
+ * Free bits: the gradient of max(mean_b sum_hw kl, kl_min) is gated per channel (tf_train.py:79-82); the gate is left
+ * in the workspace by iaf_posterior_block_forward_train, so kl_min must be the value that call used. */
 int iaf_posterior_block_backward(iaf_stack_t* s, const float* qz_mean, const float* qz_logsd, const float* rz_mean,
                                  const float* rz_logsd, const float* pz_mean, const float* pz_logsd, const float* eps,
                                  float kl_min, const float* z, const float* dz, const float* dkl_obj, float* dmean,
