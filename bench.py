@@ -490,7 +490,19 @@ def main():
     if world > 1 or os.environ.get("IAF_BENCH_FORCE_DIST"):      # the env switch exercises the RCCL path on one GPU
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # RCCL prints a banner (ROCm version / hostname / library path) to STDOUT when its first communicator comes up;
+        # the contract is ONE JSON line on stdout, so that happens with fd 1 pointed at stderr
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
     else:
         dist = None
         torch.cuda.set_device(0)
