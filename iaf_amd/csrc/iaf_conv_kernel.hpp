@@ -175,8 +175,8 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
     }
 
     // (2) weight ring.  A step is one (chunk, tap): NT x 1 KiB global_load_dwordx4 feeding 4*NT MFMAs.  Weights
-    // come from L2 at ~1 us latency while a step is only 128*NT cycles, so R = 5*RCH steps are kept in flight in
-    // registers (one wave per SIMD owns 512 of them).  Step s lives in ring slot s % R; while step s computes, the
+    // come from L2 at ~1 us latency while a step is only 128*NT cycles, so R = NTP*RCH steps are kept in flight in
+    // registers.  Step s lives in ring slot s % R; while step s computes, the
     // slot consumed by step s-1 is refilled with step s+R-1, the loads interleaved between the MFMAs.  Hence the
     // prologue fetches R-1 steps.  Loop bodies are straight-line (static slots/taps, no branches) so that hipcc
     // emits COUNTED s_waitcnt vmcnt(N) and the ring really stays in flight.
@@ -191,15 +191,13 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
     const int c_begin = (kh * p.nchunk) / KS, c_end = ((kh + 1) * p.nchunk) / KS;
     const f32x4* wbase = (const f32x4*)p.wp + (size_t)cot0 * 64;   // wave-uniform; lane offset added per load
     const unsigned ulane = (unsigned)lane;
-    // ---- weight delivery, two variants:
-    //  * PXT == 1 (every wave has its own co-tiles / K slice): the per-wave register ring described above.
-    //  * PXT  > 1 (the PXT waves of a group need the SAME weight tiles): each 1 KiB tile is fetched ONCE per group
-    //    (round-robin over the waves), parked in a double-buffered LDS chunk buffer and read by all waves with
-    //    ds_read_b128.  The CU's address unit handles one 1 KiB wave-load per ~16 cycles and a wave that is stuck
-    //    issuing a load cannot issue MFMAs; sharing cuts that traffic PXT-fold (measured: 873 -> ~670 cycles/step).
-    // Measured on the 160->160 conv at B=32 16x16 (cycles per K step, 640 = MFMA-bound): ring 712, shared 768
-    // (both with the memory instructions interleaved between the MFMAs; 873 / 867 with them clustered).  The ring
-    // is therefore the default; -DIAF_SHARED_W=1 builds the LDS-shared variant.
+    // ---- weight delivery: the per-wave register ring above is what ships.  An ablation variant for PXT > 1 (the PXT
+    //  waves of a group need the SAME weight tiles) is kept behind -DIAF_SHARED_W=1: each 1 KiB tile fetched ONCE per
+    //  group, parked in a double-buffered LDS chunk buffer and read by all waves with ds_read_b128 (the CU's address unit
+    //  handles one 1 KiB wave-load per ~16 cycles, and sharing cuts that traffic PXT-fold).  Measured on the 160->160
+    //  conv at B=32 16x16 (cycles per K step, 640 = MFMA-bound): ring 712, shared 768, both with the memory instructions
+    //  interleaved between the MFMAs (873 / 867 with them clustered) -- the extra LDS reads cost more issue slots than
+    //  the saved global loads.
 #if defined(IAF_SHARED_W) && IAF_SHARED_W
     constexpr bool SHARED_W = (PXT > 1);
 #else
