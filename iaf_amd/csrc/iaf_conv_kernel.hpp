@@ -189,6 +189,7 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
     constexpr int R = RCH * NTP;
     const size_t wstep = (size_t)p.ncot * 64;   // f32x4 per (chunk,tap) step
     const int c_begin = (kh * p.nchunk) / KS, c_end = ((kh + 1) * p.nchunk) / KS;
+    const bool ramp = DEEP && RCH == 2 && (c_begin + 2 * RCH <= c_end);   // see the prologue / RAMP body
     const f32x4* wbase = (const f32x4*)p.wp + (size_t)cot0 * 64;   // wave-uniform; lane offset added per load
     const unsigned ulane = (unsigned)lane;
     // ---- weight delivery: the per-wave register ring above is what ships.  An ablation variant for PXT > 1 (the PXT
@@ -332,7 +333,10 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
         if (c_begin < c_end) write_stage(0);
         if (c_begin + 1 < c_end) issue_stage(c_begin + 1);
     } else {
-        static_for<RCH - 1>([&](auto i) { ring_prologue(std::integral_constant<int, decltype(i)::value + 1>{}); });
+        // DEEP (two chunks): with enough chunks to run the steady loop, the second chunk's prologue loads are NOT issued
+        // here -- 4*NT more 1 KiB loads per wave through an address unit that is the prologue's bottleneck -- but ride along
+        // with the MFMAs of the first chunk (RAMP body below).
+        if (!ramp) static_for<RCH - 1>([&](auto i) { ring_prologue(std::integral_constant<int, decltype(i)::value + 1>{}); });
     }
     __syncthreads();
     IAF_STAMP(2);
@@ -468,10 +472,11 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
     } else {
     // x operand: one ds_read_b128 per step, double-buffered one step ahead (xn is always the NEXT step's operand)
     f32x4 xn = smem4[xa[0] + c_begin * 4];
-    auto chunk_body = [&](auto slot_c, auto refill_t4, auto refill_own, int chunk) {
+    auto chunk_body = [&](auto slot_c, auto refill_t4, auto refill_own, int chunk, auto ramp_c) {
         constexpr int I = decltype(slot_c)::value;
         constexpr bool RF_T4 = decltype(refill_t4)::value;    // step (chunk, 0) refills step (chunk+RCH-1, tap 4)
         constexpr bool RF_OWN = decltype(refill_own)::value;  // step (chunk, tp>=1) refills step (chunk+RCH, tp-1)
+        constexpr bool RAMP = decltype(ramp_c)::value;        // first chunk of a DEEP ring: also fetch (chunk+1, tp) for tp < NTP-1
         static_for<NTP>([&](auto tp_c) {
             constexpr int tp = decltype(tp_c)::value;
             const f32x4 xv = xn;
@@ -502,8 +507,14 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
 #pragma unroll
                 for (int t = 0; t < NT; ++t) wr[PS][t] = q[ulane + t * 64];
             }
+            constexpr bool rmp = RAMP && (tp + 1 < NTP);      // slot (1, NTP-1) is filled by step (chunk, 0)'s refill
+            if constexpr (rmp) {
+                const f32x4* q2 = wbase + ((size_t)(chunk + 1) * NTP + tp) * wstep;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) wr[NTP + tp][t] = q2[ulane + t * 64];
+            }
 #if !defined(IAF_EXP_NOINTERLEAVE) && !defined(IAF_EXP_NOMFMA)
-            sched_interleave<4 * NT, 1, 0, rf ? NT : 0>();
+            sched_interleave<4 * NT, 1, 0, (rf ? NT : 0) + (rmp ? NT : 0)>();
             __builtin_amdgcn_sched_barrier(0);
 #endif
         });
@@ -512,8 +523,15 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
         using T = std::true_type;
         using F = std::false_type;
         int c = c_begin;
+        if constexpr (DEEP && RCH == 2) {
+            if (ramp) {                                  // first ring revolution with the second chunk still arriving
+                chunk_body(std::integral_constant<int, 0>{}, T{}, T{}, c, T{});
+                chunk_body(std::integral_constant<int, 1>{}, T{}, T{}, c + 1, F{});
+                c += RCH;
+            }
+        }
         for (; c + 2 * RCH <= c_end; c += RCH)       // steady state: every step refills
-            static_for<RCH>([&](auto i) { chunk_body(i, T{}, T{}, c + decltype(i)::value); });
+            static_for<RCH>([&](auto i) { chunk_body(i, T{}, T{}, c + decltype(i)::value, F{}); });
         IAF_STAMP(3);
         prefetch_epilogue();                         // >= one ring revolution of MFMA work left to hide it
         // drain: rem < 2*RCH chunks are left and chunk c sits in ring slot 0.  Which steps still refill depends only on
@@ -527,7 +545,7 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
                     static_for<REM>([&](auto i_c) {
                         constexpr int i = decltype(i_c)::value;
                         chunk_body(std::integral_constant<int, i % RCH>{}, std::bool_constant<(i + RCH - 1 < REM)>{},
-                                   std::bool_constant<(i + RCH < REM)>{}, c + i);
+                                   std::bool_constant<(i + RCH < REM)>{}, c + i, F{});
                     });
                 }
             });
@@ -535,14 +553,14 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
             static_for<RCH>([&](auto i) {
                 const int cc = c + decltype(i)::value;
                 if (cc < c_end) {
-                    if (cc + RCH < c_end) chunk_body(i, T{}, T{}, cc);
-                    else if (cc + RCH - 1 < c_end) chunk_body(i, T{}, F{}, cc);
-                    else chunk_body(i, F{}, F{}, cc);
+                    if (cc + RCH < c_end) chunk_body(i, T{}, T{}, cc, F{});
+                    else if (cc + RCH - 1 < c_end) chunk_body(i, T{}, F{}, cc, F{});
+                    else chunk_body(i, F{}, F{}, cc, F{});
                 }
             });
             static_for<RCH>([&](auto i) {
                 const int cc = c + RCH + decltype(i)::value;
-                if (cc < c_end) chunk_body(i, F{}, F{}, cc);
+                if (cc < c_end) chunk_body(i, F{}, F{}, cc, F{});
             });
         }
     }
