@@ -431,3 +431,35 @@ def test_deferred_weightnorm_backward_equals_immediate(amd):
         assert sorted(ga) == sorted(gb)
         for k in ga:
             assert torch.equal(ga[k], gb[k]), k
+
+
+def test_batch_objects_reject_misuse(amd):
+    """the batched prep / deferred weight-norm entry points report misuse through status codes, not crashes"""
+    masked = amd.WNConv2d(32, 32, ar_mask=True)
+    with pytest.raises(ValueError):                       # batched prep is for plain convs (IAF_ERR_UNSUPPORTED)
+        amd.ConvPrepBatch([masked])
+    tiny = amd.WNConv2d(6, 10)                            # fallback-path conv: no training support
+    with pytest.raises(ValueError):
+        tiny.set_training(True)
+    conv = amd.WNConv2d(32, 32)
+    with pytest.raises(amd._capi.IafHipError):            # deferral needs set_training first (IAF_ERR_NOT_PREPARED)
+        amd.WnBwdBatch(convs=[conv])
+    conv.set_training(True)
+    V, g, b = torch.randn((3, 3, 32, 32), device="cuda") * 0.05, torch.zeros(32, device="cuda"), torch.zeros(32, device="cuda")
+    conv.prepare(V, g, b)
+    batch = amd.WnBwdBatch(convs=[conv])
+    grads = (torch.zeros_like(V), torch.zeros_like(g), torch.zeros_like(b))
+    with pytest.raises(amd._capi.IafHipError):            # nothing pending yet
+        batch.run(conv_params=[(V, g, b)], conv_grads=[grads])
+    x, dy = torch.randn((2, 32, 4, 4), device="cuda"), torch.randn((2, 32, 4, 4), device="cuda")
+    conv(x)
+    (dx,), dV, dg, db = conv.backward(x, [dy], V, g, grads_out=grads)
+    batch.run(conv_params=[(V, g, b)], conv_grads=[grads])
+    torch.cuda.synchronize()
+    assert torch.isfinite(grads[0]).all() and float(grads[0].abs().max()) > 0
+    stack = amd.ARStack(32, [64])
+    rng = np.random.RandomState(0)
+    sp = {k: dev(v) for k, v in gi.ar_multiconv2d_params(rng, 32, [64], [32, 32]).items()}
+    sb = amd.WnBwdBatch(stacks=[stack])
+    with pytest.raises(amd._capi.IafHipError):            # no deferred backward pending on the stack
+        sb.run(stack_params=[sp], stack_grads=[{k: torch.zeros_like(v) for k, v in sp.items()}])
