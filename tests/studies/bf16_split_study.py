@@ -2,7 +2,7 @@
 """CPU numerics study (no GPU): how accurate is the IAF stack when each fp32 conv is emulated with products of bf16
 splits accumulated in fp32 (what a bf16-MFMA kernel would compute)?  Max abs error vs fp64 of (m_raw, s_raw, z_new)."""
 import sys, numpy as np, torch
-import os; ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,ROOT); sys.path.insert(0,os.path.join(ROOT,'tests','golden'))
+import os; ROOT=os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0,ROOT); sys.path.insert(0,os.path.join(ROOT,'tests','golden'))
 import golden_inputs as gi
 from oracle import iaf_oracle as O
 import torch.nn.functional as F
