@@ -10,8 +10,11 @@ Parity pinning: the reference cannot be installed here (TensorFlow/Theano absent
 own Python for this path IS executed, unmodified, on a NumPy stand-in for the TF leaf ops
 (tests/golden/tf_shim.py + make_golden.py).  tests/test_oracle_golden.py checks every
 function below against those reference outputs and against the reference's known-answer
-tests (tf_utils/distributions_test.py:7-38).  The Theano-variant functions at the bottom
-have NO such pin (Python-2-only source, cuDNN-only convs): "parity unpinned" for those.
+tests (tf_utils/distributions_test.py:7-38).  The Theano statement (graphy/nodes/ar.py, conv.py:pad2dwithchannel,
+nodes/__init__.py:nonlinearity, rand.py:gaussian_diag) is pinned the same way: its Python-2 source goes through lib2to3
+in memory and runs on tests/golden/theano_shim.py (make_golden_theano.py); tf_utils/adamax.py runs unmodified on variable
+stubs (make_golden_adamax.py).  Still restated without a pin: the three affine lines of models.py:170-175 / 281-285
+(models.py is a 600-line Python-2 graph builder that needs all of Theano) and the EMA update (a TF library class).
 
 Every function cites the reference file:line (relative to /root/reference) it follows.
 """
@@ -321,8 +324,8 @@ def average_grads(tower_grads):
 
 def adamax_step(var, grad, slot_m, slot_v, lr, beta1=0.9, beta2=0.999, eps=1e-8):
     """tf_utils/adamax.py:40-56.  NB the reference's slot naming: "v" is the FIRST moment,
-    "m" the infinity norm.  Returns (var, slot_m, slot_v).  PARITY UNPINNED (class is welded to
-    TF's Optimizer base; not executable on the shim)."""
+    "m" the infinity norm.  Returns (var, slot_m, slot_v).  Pinned bit-for-bit against the reference file itself
+    (tests/golden/adamax.npz, tests/test_oracle_golden.py::test_adamax_matches_reference)."""
     v_t = beta1 * slot_v + (1.0 - beta1) * grad                 # :50
     m_t = np.maximum(beta2 * slot_m + eps, np.abs(grad))        # :52
     return var - lr * (v_t / m_t), m_t, v_t                     # :53-55
@@ -335,8 +338,8 @@ def ema_step(shadow, var, decay=0.999):
 
 
 # --------------------------------------------------------------------------------------
-# a10-a12  Theano statement of the same operator  (PARITY UNPINNED: source is Python-2-only and
-# its convs are cuDNN-only, so it can be neither imported nor executed here)
+# a10-a12  Theano statement of the same operator.  Pinned against the reference's own ar.py / conv.py run on a NumPy
+# Theano stand-in (tests/golden/theano_ar.npz); only the cuDNN conv primitive is supplied by the stand-in.
 # --------------------------------------------------------------------------------------
 def theano_ar_mask(n_in, n_out, ksize=3, zerodiagonal=True, flipmask=False, pad_channel=True):
     """graphy/nodes/ar.py:243-264.  OIHW with the optional border-indicator input channel."""

@@ -96,3 +96,34 @@ MASK_CASES = [
     (192, 64, True), (4, 8, False), (8, 4, True), (8, 8, False), (8, 8, True), (4, 4, True),
     (8, 16, True), (16, 8, False),
 ]
+
+
+# ---------------------------------------------------------------- Theano statement (graphy/nodes/ar.py)
+THEANO_CASES = {
+    # name: (B, n_z, n_h list, H, W, flipmask)
+    "th_cfg2_8x8": (2, 32, [160, 160], 8, 8, False),
+    "th_cfg1_4x4": (3, 32, [64], 4, 4, False),
+    "th_tiny": (2, 4, [8, 8], 5, 3, False),
+    "th_deep": (2, 16, [16, 16, 16], 4, 4, False),
+}
+THEANO_NAME = "1_posterior_conv1"
+
+
+def theano_case_inputs(cname):
+    """weights in the reference's own layout (ar.py:288-296): <name>_<i>_w [n_out, n_in+1, 3, 3], _b, _s; z; context"""
+    B, n_z, n_h_list, H, W, _ = THEANO_CASES[cname]
+    name = THEANO_NAME
+    rng = np.random.RandomState(case_seed(cname))
+    sizes = [n_z] + list(n_h_list)
+    w = {}
+    for i in range(len(n_h_list)):
+        w["%s_%d_w" % (name, i)] = 0.05 * rng.standard_normal((sizes[i + 1], sizes[i] + 1, 3, 3))
+        w["%s_%d_b" % (name, i)] = 0.1 * rng.standard_normal(sizes[i + 1])
+        w["%s_%d_s" % (name, i)] = 0.1 * rng.standard_normal(sizes[i + 1])
+    for i in range(2):
+        w["%s_out_%d_w" % (name, i)] = 0.05 * rng.standard_normal((n_z, sizes[-1] + 1, 3, 3))
+        w["%s_out_%d_b" % (name, i)] = 0.1 * rng.standard_normal(n_z)
+        w["%s_out_%d_s" % (name, i)] = 0.1 * rng.standard_normal(n_z)
+    z = rng.standard_normal((B, n_z, H, W))
+    ctx = rng.standard_normal((B, sizes[-1] if n_h_list else n_z, H, W))
+    return w, z, ctx

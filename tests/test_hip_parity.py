@@ -352,7 +352,9 @@ def _theano_params(rng, name, n_z, n_h_list):
 @pytest.mark.parametrize("shape", [(3, 32, 160, 2, 16, 16), (4, 32, 160, 2, 8, 8), (2, 32, 64, 1, 4, 4), (2, 64, 64, 4, 5, 3),
                                    (32, 32, 160, 2, 8, 8)], ids=lambda s: "B%d_z%d_h%d_d%d_%dx%d" % s)
 def test_theano_variant_vs_oracle(amd, shape):
-    """graphy/nodes/ar.py multiconv2d + models.py:281-285 on the GPU vs the (unpinned) oracle restatement"""
+    """graphy/nodes/ar.py multiconv2d + models.py:281-285 on the GPU vs the oracle restatement (itself pinned to the
+    reference's ar.py outputs, tests/test_oracle_golden.py; the reference outputs themselves are checked in
+    test_theano_variant_vs_reference_golden)"""
     B, n_z, n_h, d, H, W = shape
     rng = np.random.RandomState(400 + H)
     name = "1_posterior_conv1"
@@ -602,3 +604,35 @@ def test_inverse_flow_theano_variant_round_trip(amd):
     back, logsd_b, sweeps, res = stack.iaf_step_inverse(z, dev(ctx), max_sweeps=200, tol=1e-6, check_every=2)
     assert res <= 1e-6
     np.testing.assert_allclose(host(back), f32(z0), atol=2e-5, rtol=0)
+
+
+@pytest.mark.parametrize("cname", ["th_cfg2_8x8", "th_cfg1_4x4", "th_deep"])
+def test_theano_variant_vs_reference_golden(amd, golden_dir, cname):
+    """the Theano statement on the GPU against outputs of the reference's OWN graphy/nodes/ar.py (executed on
+    tests/golden/theano_shim.py): raw outputs and the up/down_iaf2_nl step (models.py:170-175, 281-285)"""
+    g = np.load(os.path.join(golden_dir, "theano_ar.npz"))
+    B, n_z, n_h, H, W, flip = gi.THEANO_CASES[cname]
+    w, z, ctx = gi.theano_case_inputs(cname)
+    conv = amd.multiconv2d(gi.THEANO_NAME, n_z, n_h, [n_z, n_z], (3, 3), flip, nl="elu", w=None)
+    m_raw, s_raw = conv(dev(z), dev(ctx), {k: dev(v) for k, v in w.items()})
+    np.testing.assert_allclose(host(m_raw), g[cname + "/m_raw"], atol=ATOL, rtol=0)
+    np.testing.assert_allclose(host(s_raw), g[cname + "/s_raw"], atol=ATOL, rtol=0)
+    z_new, logsd = conv.stack.iaf_step(dev(z), dev(ctx))
+    m, s = 0.1 * g[cname + "/m_raw"], 0.1 * g[cname + "/s_raw"]
+    np.testing.assert_allclose(host(z_new), (f32(z) - m) / np.exp(s), atol=ATOL, rtol=0)
+    np.testing.assert_allclose(host(logsd), s, atol=ATOL, rtol=0)
+
+
+def test_adamax_kernel_vs_reference_golden(amd, golden_dir):
+    """the fused Adamax kernel against six steps of the reference's OWN tf_utils/adamax.py (tests/golden/adamax.npz):
+    parameters and both slots (the reference's names: slot "v" = first moment, "m" = infinity norm)"""
+    from iaf_amd import parallel as par
+    g = np.load(os.path.join(golden_dir, "adamax.npz"))
+    fp = par.FlatParams({"p": dev(g["var0"])})
+    for t in range(g["grads"].shape[0]):
+        fp.g["p"].copy_(dev(g["grads"][t]))
+        fp.adamax_ema_step(float(g["lr"]), world=1)
+        np.testing.assert_allclose(host(fp.p["p"]), g["var_%d" % t], rtol=2e-5, atol=2e-6)
+        n = g["var0"].size
+        np.testing.assert_allclose(host(fp.slot_m)[:n], g["m_%d" % t], rtol=2e-5, atol=1e-7)
+        np.testing.assert_allclose(host(fp.slot_v)[:n], g["v_%d" % t], rtol=2e-5, atol=1e-7)

@@ -141,3 +141,41 @@ def test_adamax_slot_semantics():
     np.testing.assert_allclose(vv1, 0.1 * grad)
     np.testing.assert_allclose(m1, np.abs(grad))
     np.testing.assert_allclose(v1, var - 0.01 * 0.1 * np.sign(grad))
+
+
+# ---------------------------------------------------------------- a10 / a11: the Theano statement, pinned
+# tests/golden/theano_ar.npz holds outputs of the reference's OWN Theano-side source (graphy/nodes/ar.py, conv.py,
+# __init__.py, rand.py) executed eagerly on tests/golden/theano_shim.py after an in-memory lib2to3 pass
+# (tests/golden/make_golden_theano.py).
+@pytest.mark.parametrize("cname", sorted(gi.THEANO_CASES))
+def test_theano_multiconv2d_matches_reference(golden_dir, cname):
+    g = _load(golden_dir, "theano_ar")
+    B, n_z, n_h, H, W, flip = gi.THEANO_CASES[cname]
+    w, z, ctx = gi.theano_case_inputs(cname)
+    m_raw, s_raw = O.theano_multiconv2d(z, ctx, w, gi.THEANO_NAME, n_z, n_h, [n_z, n_z], flipmask=flip)
+    np.testing.assert_allclose(m_raw, g[cname + "/m_raw"], **TOL)
+    np.testing.assert_allclose(s_raw, g[cname + "/s_raw"], **TOL)
+
+
+def test_theano_single_conv_pad_channel_and_gaussian_match_reference(golden_dir):
+    g = _load(golden_dir, "theano_ar")
+    for zd in (False, True):
+        k = "conv_zd%d" % int(zd)
+        y = O.theano_ar_conv2d(g[k + "/x"], g[k + "/w"], g[k + "/b"], g[k + "/s"], 8, 16, zerodiagonal=zd)
+        np.testing.assert_allclose(y, g[k + "/y"], **TOL)                                      # ar.py:200-375
+    np.testing.assert_array_equal(O.theano_pad2dwithchannel(g["pad/x"]), g["pad/y"])         # conv.py:71-83
+    np.testing.assert_allclose(O.gaussian_diag_logps(g["gauss/mean"], g["gauss/logvar"], g["gauss/sample"]),
+                               g["gauss/logps"], **TOL)                                       # rand.py:78-87
+
+
+# ---------------------------------------------------------------- a13 / 8f-2: Adamax, pinned
+def test_adamax_matches_reference(golden_dir):
+    """tests/golden/adamax.npz: six steps of the reference's own tf_utils/adamax.py (AdamaxOptimizer._apply_dense,
+    executed unmodified on NumPy-backed variable stubs, tests/golden/make_golden_adamax.py)"""
+    g = _load(golden_dir, "adamax")
+    var, m, v = g["var0"].copy(), np.zeros_like(g["var0"]), np.zeros_like(g["var0"])
+    for t in range(g["grads"].shape[0]):
+        var, m, v = O.adamax_step(var, g["grads"][t], m, v, float(g["lr"]))
+        np.testing.assert_array_equal(var, g["var_%d" % t])
+        np.testing.assert_array_equal(m, g["m_%d" % t])
+        np.testing.assert_array_equal(v, g["v_%d" % t])
