@@ -402,25 +402,25 @@ def layers_train_bench(args, depths, dist, rank, n_gpus):
     sglist = [iaf_amd.IAFLayer.stack_params(L["grads"]) for L in all_layers]
     cglist = [t for L in all_layers for t in iaf_amd.IAFLayer.conv_params(L["grads"])]
 
-    def compute():
+    def compute(tune=False):
         prep_s.run(splist)
         prep_c.run(cplist)
         for lv in levels:
             h = lv["up_in"]
             for L in lv["layers"]:
-                h = L["layer"].up_train(h)
+                h = L["layer"].up_train(h, autotune=tune)
         for lv in reversed(levels):
             h = lv["down_in"]
             for L in reversed(lv["layers"]):
-                h, _, _ = L["layer"].down_train(h, L["eps"])
+                h, _, _ = L["layer"].down_train(h, L["eps"], autotune=tune)
         for lv in levels:                                   # backward of the top-down pass, in reverse
             d = lv["d_down"]
             for L in lv["layers"]:
-                d = L["layer"].down_backward(d, dko, L["params"], L["grads"])
+                d = L["layer"].down_backward(d, dko, L["params"], L["grads"], autotune=tune)
         for lv in reversed(levels):                         # backward of the bottom-up pass, in reverse
             d = lv["d_up"]
             for L in reversed(lv["layers"]):
-                d = L["layer"].up_backward(d, L["params"], L["grads"])
+                d = L["layer"].up_backward(d, L["params"], L["grads"], autotune=tune)
         wnb.run(stack_params=splist, stack_grads=sglist, conv_params=cplist, conv_grads=cglist)
 
     def step():
@@ -438,6 +438,7 @@ def layers_train_bench(args, depths, dist, rank, n_gpus):
     graph = None
     with torch.cuda.stream(stream):
         step()
+        compute(tune=True)             # launch-shape search of the plain convs, forward and data gradient (cuDNN's autotune)
         stream.synchronize()
         if not args.no_graph:
             graph = torch.cuda.CUDAGraph()

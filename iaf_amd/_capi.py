@@ -96,6 +96,12 @@ SIGNATURES = {
                                             ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_float, ctypes.POINTER(_vp),
                                             ctypes.POINTER(ctypes.c_int), ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp,
                                             ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_size_t, _vp]),
+    "iaf_conv3x3_autotune_backward": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_vp),
+                                                     ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_float,
+                                                     ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_int), ctypes.c_int, _vp, _vp,
+                                                     _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp,
+                                                     ctypes.c_size_t, ctypes.c_int, _vp, ctypes.POINTER(ctypes.c_int),
+                                                     ctypes.POINTER(ctypes.c_float)]),
     "iaf_conv3x3_autotune": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, ctypes.POINTER(_vp),
                                             ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                             ctypes.c_int, ctypes.c_int, _vp, ctypes.POINTER(ctypes.c_int),

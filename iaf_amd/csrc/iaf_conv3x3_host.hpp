@@ -483,6 +483,62 @@ extern "C" int iaf_conv3x3_backward(iaf_conv3x3_t* c, const float* x, const floa
     return (int)hipGetLastError();
 }
 
+// Launch-shape search for the data gradient (the transposed problem has its own best shape): times whole
+// iaf_conv3x3_backward calls -- everything but the dgrad launch is the same for every candidate -- and pins the fastest.
+extern "C" int iaf_conv3x3_autotune_backward(iaf_conv3x3_t* c, const float* x, const float* x2, int c_split, int elu_input,
+                                             const float* const* dys, const int* dy_channels, int n_dys, float dy_scale,
+                                             float* const* dxs, const int* dx_channels, int n_dxs, const float* dx_residual,
+                                             const float* V, const float* g, float* dV, float* dg, float* db, int B, int H,
+                                             int W, void* workspace, size_t workspace_bytes, int reps, void* stream,
+                                             int* best_shape, float* best_us) {
+    if (!c) return IAF_ERR_NULL;
+    if (!c->training) return IAF_ERR_NOT_PREPARED;
+    if (reps <= 0) reps = 10;
+    hipStream_t st = (hipStream_t)stream;
+    GemmLayer& T = c->T;
+    if (n_dxs == 0) return IAF_OK;          // no data gradient requested: nothing to tune
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    const bool was_pending = c->pending;
+    float best = 1e30f;
+    int bsh[4] = {T.nt, T.pxt, T.wco, T.ks};
+    int rc = IAF_OK;
+    auto run = [&]() {
+        return iaf_conv3x3_backward(c, x, x2, c_split, elu_input, dys, dy_channels, n_dys, dy_scale, dxs, dx_channels, n_dxs,
+                                    dx_residual, V, g, dV, dg, db, B, H, W, workspace, workspace_bytes, stream);
+    };
+    for (int si = 0; si < 8 && rc == IAF_OK; ++si)
+        for (int nt = 5; nt >= 1 && rc == IAF_OK; --nt) {
+            const int pxt = k_shapes[si][0], wco = k_shapes[si][1], ks = k_shapes[si][2];
+            if (T.ncot % (nt * wco) != 0 || T.nchunk < ks) continue;
+            GemmLayer t = T;
+            t.nt = nt; t.pxt = pxt; t.wco = wco; t.ks = ks;
+            if (conv_lds_bytes(t, W) > 160 * 1024) continue;
+            if (!pick_kernel(nt, pxt, wco, ks, IN_PIXMAJOR, EPI_DGRAD9)) continue;
+            T.nt = nt; T.pxt = pxt; T.wco = wco; T.ks = ks; T.user_tuned = true;
+            for (int r = 0; r < 2 && rc == IAF_OK; ++r) rc = run();
+            if (rc == IAF_ERR_UNSUPPORTED) { rc = IAF_OK; continue; }
+            if (rc) break;
+            (void)hipEventRecord(e0, st);
+            for (int r = 0; r < reps && rc == IAF_OK; ++r) rc = run();
+            (void)hipEventRecord(e1, st);
+            if (rc) break;
+            if ((rc = (int)hipEventSynchronize(e1)) != 0) break;
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            if (ms < best) { best = ms; bsh[0] = nt; bsh[1] = pxt; bsh[2] = wco; bsh[3] = ks; }
+        }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    T.nt = bsh[0]; T.pxt = bsh[1]; T.wco = bsh[2]; T.ks = bsh[3]; T.user_tuned = true;
+    if (rc == IAF_OK) rc = run();           // leave the outputs as computed with the chosen shape
+    (void)was_pending;
+    if (best_shape) for (int i = 0; i < 4; ++i) best_shape[i] = bsh[i];
+    if (best_us) *best_us = best * 1e3f / reps;
+    return rc;
+}
+
 // ---- deferred weight-norm backward of many plain convs in one launch ----------------------------------------------
 extern "C" int iaf_conv3x3_set_defer_weightnorm(iaf_conv3x3_t* c, int on) {
     if (!c) return IAF_ERR_NULL;

@@ -98,27 +98,27 @@ class IAFLayer(object):
             c.set_training(on)
         self.posterior.stack.set_training(on)
 
-    def up_train(self, inp):
+    def up_train(self, inp, autotune=False):
         zs, hs = self.z_size, self.h_size
-        qz_mean, qz_logsd, up_context, h = self.up_conv1(inp, elu_input=True, split=[zs, zs, hs, hs])
+        qz_mean, qz_logsd, up_context, h = self.up_conv1(inp, elu_input=True, split=[zs, zs, hs, hs], autotune=autotune)
         self.posterior.set_up_state(qz_mean, qz_logsd, up_context)
-        out = self.up_conv3(h, elu_input=True, residual=inp)[0]
+        out = self.up_conv3(h, elu_input=True, residual=inp, autotune=autotune)[0]
         self._up_saved = dict(inp=inp, h=h)
         return out
 
-    def down_train(self, inp, eps):
+    def down_train(self, inp, eps, autotune=False):
         zs, hs = self.z_size, self.h_size
         pz_mean, pz_logsd, rz_mean, rz_logsd, down_context, h_det = self.down_conv1(
-            inp, elu_input=True, split=[zs] * 4 + [hs] * 2)
+            inp, elu_input=True, split=[zs] * 4 + [hs] * 2, autotune=autotune)
         po = self.posterior
         blk = po.stack.posterior_block_train(po.qz_mean, po.qz_logsd, rz_mean, rz_logsd, pz_mean, pz_logsd, po.up_context,
                                              down_context, eps, self.kl_min)
-        out = self.down_conv2(blk["z"], x2=h_det, elu_input=True, residual=inp)[0]
+        out = self.down_conv2(blk["z"], x2=h_det, elu_input=True, residual=inp, autotune=autotune)[0]
         self._down_saved = dict(inp=inp, eps=eps, pz_mean=pz_mean, pz_logsd=pz_logsd, rz_mean=rz_mean, rz_logsd=rz_logsd,
                                 h_det=h_det, z=blk["z"])
         return out, blk["kl_obj"], blk["kl_cost"]
 
-    def down_backward(self, d_out, d_kl_obj, params, grads=None):
+    def down_backward(self, d_out, d_kl_obj, params, grads=None, autotune=False):
         """Backward of down_train.  d_out: gradient of `output`; d_kl_obj [B]: gradient of kl_obj (kl_cost is reporting
         only, tf_train.py:204-206).  Returns d_input; the gradients flowing to the up pass (d qz_mean, d qz_logsd,
         d up_context) are kept for up_backward.  Parameter gradients land in `grads` (name -> tensor, allocated if absent)."""
@@ -132,7 +132,7 @@ class IAFLayer(object):
         # output = input + 0.1*down_conv2(elu(concat(z, h_det)))                                    (tf_train.py:87-94)
         (d_z, d_h_det), _, _, _ = self.down_conv2.backward(
             sv["z"], [d_out], params["down_conv2/V"], params["down_conv2/g"], x2=sv["h_det"], elu_input=True, dy_scale=0.1,
-            grads_out=gslot("down_conv2"))
+            grads_out=gslot("down_conv2"), autotune=autotune)
         # the IAF posterior block                                                                   (tf_train.py:56-85)
         pre = "ar_multiconv2d/"
         sp = IAFLayer.stack_params(params)
@@ -144,10 +144,11 @@ class IAFLayer(object):
         # x = down_conv1(elu(input)) split six ways; d input = d_out + elu'(input) * W^T dY          (tf_train.py:52-54, 94)
         (d_inp,), _, _, _ = self.down_conv1.backward(
             sv["inp"], [pb["dpz_mean"], pb["dpz_logsd"], pb["dmean"], pb["dlogsd"], pb["dcontext"], d_h_det],
-            params["down_conv1/V"], params["down_conv1/g"], elu_input=True, dx_residual=d_out, grads_out=gslot("down_conv1"))
+            params["down_conv1/V"], params["down_conv1/g"], elu_input=True, dx_residual=d_out, grads_out=gslot("down_conv1"),
+            autotune=autotune)
         return d_inp
 
-    def up_backward(self, d_out, params, grads=None):
+    def up_backward(self, d_out, params, grads=None, autotune=False):
         """Backward of up_train (after down_backward of the same layer).  Returns d_input."""
         grads = {} if grads is None else grads
         sv, tu = self._up_saved, self._to_up
@@ -156,8 +157,8 @@ class IAFLayer(object):
             return tuple(grads.setdefault(nm + "/" + k, torch.empty_like(params[nm + "/" + k])) for k in ("V", "g", "b"))
 
         (d_h,), _, _, _ = self.up_conv3.backward(sv["h"], [d_out], params["up_conv3/V"], params["up_conv3/g"], elu_input=True,
-                                                 dy_scale=0.1, grads_out=gslot("up_conv3"))                  # :40-44
+                                                 dy_scale=0.1, grads_out=gslot("up_conv3"), autotune=autotune)   # :40-44
         (d_inp,), _, _, _ = self.up_conv1.backward(
             sv["inp"], [tu["d_qz_mean"], tu["d_qz_logsd"], tu["d_up_context"], d_h], params["up_conv1/V"],
-            params["up_conv1/g"], elu_input=True, dx_residual=d_out, grads_out=gslot("up_conv1"))            # :35-38
+            params["up_conv1/g"], elu_input=True, dx_residual=d_out, grads_out=gslot("up_conv1"), autotune=autotune)   # :35-38
         return d_inp

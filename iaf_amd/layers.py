@@ -442,7 +442,7 @@ class WNConv2d(object):
         self._prep_key = None
 
     def backward(self, x, dys, V, g, x2=None, elu_input=False, dy_scale=1.0, want_dx=True, dx_residual=None,
-                 grads_out=None):
+                 grads_out=None, autotune=False):
         """Backward of __call__ (what TF autodiff derives for layers.py:52-64 and the elu/concat/split/residual around it).
         dys: gradients of the split outputs (same shapes as __call__ returned); dy_scale multiplies them (0.1 for the
         residual form).  Returns (dxs, dV, dg, db): dxs = gradients w.r.t. [x] or [x, x2] (None if not want_dx),
@@ -475,6 +475,15 @@ class WNConv2d(object):
         ws = WNConv2d._shared_ws.get(x.device)
         if ws is None or ws.numel() * 4 < need:
             ws = WNConv2d._shared_ws[x.device] = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
+        key = ("bwd", B, H, W)
+        if autotune and want_dx and key not in self._tuned:       # first call at this size: search the dgrad launch shape
+            sh, us = (ctypes.c_int * 4)(), ctypes.c_float()
+            _capi.check(_capi.lib().iaf_conv3x3_autotune_backward(
+                self._h, _ptr(x), _ptr(x2), c_split, 1 if elu_input else 0, dyp, dyc, n, float(dy_scale), dxp, dxc, ndx,
+                _ptr(dx_residual), _ptr(V), _ptr(g), _ptr(dV), _ptr(dg), _ptr(db), B, H, W, _ptr(ws), need, 10, _stream(),
+                sh, ctypes.byref(us)))
+            self._tuned[key] = tuple(sh)
+            return dxs, dV, dg, db
         _capi.check(_capi.lib().iaf_conv3x3_backward(
             self._h, _ptr(x), _ptr(x2), c_split, 1 if elu_input else 0, dyp, dyc, n, float(dy_scale), dxp, dxc, ndx,
             _ptr(dx_residual), _ptr(V), _ptr(g), _ptr(dV), _ptr(dg), _ptr(db), B, H, W, _ptr(ws), need, _stream()))

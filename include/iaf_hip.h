@@ -271,6 +271,15 @@ int iaf_conv3x3_backward(iaf_conv3x3_t* c, const float* x, const float* x2, int 
                          const int* dx_channels, int n_dxs, const float* dx_residual, const float* V, const float* g,
                          float* dV, float* dg, float* db, int B, int H, int W, void* workspace, size_t workspace_bytes,
                          void* stream);
+/* launch-shape search for the data gradient of iaf_conv3x3_backward (same arguments, + reps): times whole backward calls
+ * per candidate shape of the transposed problem and pins the fastest; outputs end up as a normal backward call leaves
+ * them.  Synchronises the stream; not capturable. */
+int iaf_conv3x3_autotune_backward(iaf_conv3x3_t* c, const float* x, const float* x2, int c_split, int elu_input,
+                                  const float* const* dys, const int* dy_channels, int n_dys, float dy_scale,
+                                  float* const* dxs, const int* dx_channels, int n_dxs, const float* dx_residual,
+                                  const float* V, const float* g, float* dV, float* dg, float* db, int B, int H, int W,
+                                  void* workspace, size_t workspace_bytes, int reps, void* stream, int* best_shape,
+                                  float* best_us);
 /* the same deferral for the plain convs (needs set_training first): iaf_conv3x3_backward keeps the reduced dW / db
  * partials inside the object and leaves dV/dg/db to one iaf_conv3x3_wn_bwd_batch_run over all convs of the model */
 typedef struct iaf_conv3x3_wn_bwd_batch iaf_conv3x3_wn_bwd_batch_t;

@@ -463,3 +463,23 @@ def test_batch_objects_reject_misuse(amd):
     sb = amd.WnBwdBatch(stacks=[stack])
     with pytest.raises(amd._capi.IafHipError):            # no deferred backward pending on the stack
         sb.run(stack_params=[sp], stack_grads=[{k: torch.zeros_like(v) for k, v in sp.items()}])
+
+
+def test_backward_autotune_keeps_gradients(amd):
+    """the data-gradient launch-shape search may pick a split-K shape (different summation order): gradients must stay
+    within fp32 round-off of the untuned call"""
+    rng = np.random.RandomState(17)
+    n_in, n_out, B, H, W = 160, 160, 4, 8, 8
+    p = gi.conv_params(rng, n_in, n_out)
+    V, g, b = dev(p["V"]), dev(p["g"]), dev(p["b"])
+    x, dy = dev(rng.standard_normal((B, n_in, H, W))), dev(rng.standard_normal((B, n_out, H, W)))
+    conv = amd.WNConv2d(n_in, n_out)
+    conv.set_training(True)
+    conv.prepare(V, g, b)
+    conv(x, elu_input=True)
+    (dx0,), dV0, dg0, db0 = conv.backward(x, [dy], V, g, elu_input=True)
+    (dx1,), dV1, dg1, db1 = conv.backward(x, [dy], V, g, elu_input=True, autotune=True)
+    (dx2,), dV2, dg2, db2 = conv.backward(x, [dy], V, g, elu_input=True)          # now with the tuned shape pinned
+    assert ("bwd", B, H, W) in conv._tuned
+    for a, b_ in ((dx0, dx1), (dx0, dx2), (dV0, dV1), (dV0, dV2), (dg0, dg2), (db0, db2)):
+        np.testing.assert_allclose(host(a), host(b_), atol=1e-5 * float(a.abs().max()) + 1e-7, rtol=0)
