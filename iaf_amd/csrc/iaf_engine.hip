@@ -877,7 +877,8 @@ extern "C" int iaf_stack_set_training(iaf_stack_t* s, int on) {
 // pixel ranges of the weight-gradient GEMM: as many as keep the grid within ONE round of 256 workgroups
 // (grid.x = 5 taps * ceil(cin/32) ci pairs), at least 64 pixels each, at most 16 (the partial buffer is sized for 16)
 static int wgrad_nrange(long long P, int cin = 160, int ntaps = NTAPS) {
-    long long n = 512 / (ntaps * ((cin + 31) / 32));      // two workgroups per CU are resident
+    static const long long target = getenv("IAF_WGRAD_TARGET") ? atoll(getenv("IAF_WGRAD_TARGET")) : 512;   // dev knob
+    long long n = target / (ntaps * ((cin + 31) / 32));      // workgroups to aim for (2-3 per CU are resident)
     if (n > P / 64) n = P / 64;
     if (n < 1) n = 1;
     if (n > 16) n = 16;
