@@ -636,3 +636,23 @@ def test_adamax_kernel_vs_reference_golden(amd, golden_dir):
         n = g["var0"].size
         np.testing.assert_allclose(host(fp.slot_m)[:n], g["m_%d" % t], rtol=2e-5, atol=1e-7)
         np.testing.assert_allclose(host(fp.slot_v)[:n], g["v_%d" % t], rtol=2e-5, atol=1e-7)
+
+
+def test_multi_round_grid_matches_oracle_and_small_batch(amd):
+    """B = 64 at 16x16 gives the 160->160 conv 512 workgroups: more than one per CU, i.e. the single-chunk weight ring
+    with two co-resident workgroups instead of the double-depth variant every smaller test gets.  Checked against the
+    oracle on the first two images (samples are independent) and against a B = 32 run of the same rows."""
+    B, n_z, n_h, d, H, W = 64, 32, 160, 2, 16, 16
+    params, z, ctx = _rand_case(77, B, n_z, n_h, d, H, W)
+    stack = amd.ARStack(n_z, [n_h] * d)
+    stack.prepare(dev_params(params))
+    z_new, logsd = stack.iaf_step(dev(z), dev(ctx))
+    ez, es = O.iaf_step(f32(z[:2]), f32(ctx[:2]), f32_params(params), [n_h] * d)
+    np.testing.assert_allclose(host(z_new)[:2], ez, atol=ATOL, rtol=0)
+    np.testing.assert_allclose(host(logsd)[:2], es, atol=ATOL, rtol=0)
+    z32, l32 = stack.iaf_step(dev(z[32:]), dev(ctx[32:]))
+    np.testing.assert_allclose(host(z_new)[32:], host(z32), atol=2e-6, rtol=0)
+    np.testing.assert_allclose(host(logsd)[32:], host(l32), atol=2e-6, rtol=0)
+    # the posterior block and the inverse on the large grid as well
+    back, _, _, res = stack.iaf_step_inverse(z_new, dev(ctx), max_sweeps=60, tol=1e-6, check_every=2)
+    np.testing.assert_allclose(host(back), f32(z), atol=5e-5, rtol=0)
