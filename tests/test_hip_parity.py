@@ -263,7 +263,8 @@ def test_iaf_step_backward_vs_autograd_oracle(amd, shape):
 
 
 @pytest.mark.parametrize("kl_min", [0.0, 0.25])
-@pytest.mark.parametrize("shape", [(4, 32, 160, 2, 16, 16), (3, 32, 64, 1, 8, 8), (2, 64, 64, 4, 4, 4)],
+@pytest.mark.parametrize("shape", [(4, 32, 160, 2, 16, 16), (3, 32, 64, 1, 8, 8), (2, 64, 64, 4, 4, 4),
+                                   (32, 32, 160, 2, 16, 16)],      # last: BASELINE configs[1] at full size
                          ids=lambda s: "B%d_z%d_h%d_d%d_%dx%d" % s)
 def test_posterior_block_backward_vs_autograd_oracle(amd, shape, kl_min):
     """full tf_train.py:56-85 backward incl. the free-bits gate: every input gradient and every weight gradient"""
