@@ -350,8 +350,9 @@ def test_wnconv2d_backward_vs_autograd_oracle(amd, shape):
     assert _relerr(host(db), pt["b"].grad.numpy()) < 1e-4
 
 
+@pytest.mark.parametrize("size", [None, (8, 16, 16)], ids=["fixture_B2_8x8", "B8_16x16"])
 @pytest.mark.parametrize("kl_min", [0.25, 0.0])
-def test_iaf_layer_backward_vs_autograd_oracle(amd, kl_min):
+def test_iaf_layer_backward_vs_autograd_oracle(amd, kl_min, size):
     """whole IAFLayer (up + down) at z 32 / h 160, 8x8: gradients of L = <dU, up_out> + <dD, output> + <dK, kl_obj>
     w.r.t. both inputs and all 28 variables vs torch-fp64 autograd of the restated layer (itself pinned to the reference
     fixtures and finite differences in tests/test_grad_oracle.py).  Bar: 1e-4 of the tensor's max |reference|."""
@@ -360,6 +361,11 @@ def test_iaf_layer_backward_vs_autograd_oracle(amd, kl_min):
     zs, hs = c["z_size"], c["h_size"]
     rng = np.random.RandomState(9)
     up_in, down_in, eps = c["up_input"], c["down_input"], c["eps_post"]
+    if size is not None:        # a larger problem: 11 pixel ranges in the weight gradient, the last one partial
+        B, H, W = size
+        # N(0,1) inputs through these random convs give posterior log-stds of several units on a few of the 65k latent
+        # positions (|z| reaches 1e4, where fp32 itself is only good to 1e-3): keep the larger case in a sane range
+        up_in, down_in, eps = (0.3 * rng.standard_normal((B, ch, H, W)) for ch in (hs, hs, zs))
     dU, dD, dK = rng.standard_normal(up_in.shape), rng.standard_normal(down_in.shape), rng.standard_normal(up_in.shape[0])
     p32 = {k: f32(v) for k, v in c["params"].items()}
     want, fw = G.iaf_layer_grads(f32(up_in), f32(down_in), f32(eps), p32, zs, hs, kl_min, f32(dU), f32(dD), f32(dK))
@@ -370,7 +376,7 @@ def test_iaf_layer_backward_vs_autograd_oracle(amd, kl_min):
     up_out = layer.up_train(dev(up_in))
     out, kl_obj, kl_cost = layer.down_train(dev(down_in), dev(eps))
     np.testing.assert_allclose(host(up_out), fw["up_out"], atol=ATOL, rtol=0)
-    np.testing.assert_allclose(host(out), fw["output"], atol=ATOL, rtol=0)
+    np.testing.assert_allclose(host(out), fw["output"], atol=ATOL * max(1.0, np.abs(fw["output"]).max()), rtol=0)
     np.testing.assert_allclose(host(kl_obj), fw["kl_obj"], atol=2e-3, rtol=1e-4)
     grads = {}
     d_down_in = layer.down_backward(dev(dD), dev(dK), params, grads)
