@@ -12,7 +12,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-LIBDIR = os.path.join(HERE, "_lib")
+# IAF_BUILD_TAG=<tag> (with IAF_EXTRA_CFLAGS) builds an experiment library next to the product one, in _lib_<tag>/;
+# load it with IAF_HIP_LIB=<path> (iaf_amd/_capi.py).  The product library is always _lib/libiaf_hip.so.
+_TAG = os.environ.get("IAF_BUILD_TAG", "")
+LIBDIR = os.path.join(HERE, "_lib" + ("_" + _TAG if _TAG else ""))
 OBJDIR = os.path.join(LIBDIR, "obj")
 OUT = os.path.join(LIBDIR, "libiaf_hip.so")
 SHAPES = [(4, 1, 1), (4, 1, 2), (2, 2, 1), (2, 2, 2), (2, 1, 2), (2, 1, 4), (1, 1, 4), (1, 2, 2)]   # keep in sync with pick_kernel()

@@ -224,6 +224,7 @@ static int conv3x3_launch(GemmLayer& L, ConvP& p, int epi_sel, int inmode, bool 
     if (rc) return rc;
     dim3 grid((p.P + tm - 1) / tm, L.ncot / (L.nt * L.wco));
     p.gx = (int)grid.x;
+    p.lds_bytes = (int)lds;
     hipLaunchKernelGGL(fn, grid, dim3(64 * L.pxt * L.wco * L.ks), lds, st, p);
     return (int)hipGetLastError();
 }

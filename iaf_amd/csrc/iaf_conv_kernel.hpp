@@ -85,6 +85,7 @@ struct ConvP {
     // EPI_PLAIN output: the channel split of tf_train.py:37,54 fused into the store.  Channels [split_end[k-1], split_end[k])
     // go to the contiguous NCHW tensor split_ptr[k]; boundaries are multiples of 4 (one lane's 4 channels never straddle).
     int nsplit; int split_end[MAXSPLIT]; float* split_ptr[MAXSPLIT];
+    int lds_bytes;        // dynamic LDS of this launch (read only by the -DIAF_EXP_POISON_LDS soak build)
 };
 
 // Pin the order "MFMAs with memory instructions spread evenly between them" inside the current scheduling region:
@@ -151,6 +152,12 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
     const int cp4 = p.cp >> 2;       // LDS row stride in 16-byte units
 #define IAF_STAMP(k) do { if (p.dbg && tid == 0) p.dbg[((size_t)blockIdx.y * p.gx + blockIdx.x) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
     IAF_STAMP(0);
+#ifdef IAF_EXP_POISON_LDS
+    // soak build (tools/soak.py): every LDS word starts as a signalling pattern, so a read of a word this launch never
+    // wrote -- left-over data of the previous workgroup on the CU in a production build -- turns the output into NaN
+    for (int i = tid; i < (p.lds_bytes >> 4); i += NTHREADS) smem4[i] = f32x4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
+    __syncthreads();
+#endif
 
     // ================= prologue, ordered by latency: (1) tile loads, (2) weight ring, (3) index math ==========
     // (1) activation tile: slots [P0, P0+nslot) x cin.  For the pixel-major scratch the tile is ONE contiguous run

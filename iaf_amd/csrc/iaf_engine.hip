@@ -560,6 +560,7 @@ static int launch_gemm(const iaf_stack_t* s, GemmLayer& L, int epi, bool negate_
     iaf_stack* ms = const_cast<iaf_stack*>(s);
     if (prof) HIP_TRY(hipEventRecord(ms->prof_start[ms->prof_n], st));
     p.gx = (int)grid.x;
+    p.lds_bytes = (int)lds;
     hipLaunchKernelGGL(fn, grid, dim3(64 * L.pxt * L.wco * L.ks), lds, st, p);
     if (prof) { HIP_TRY(hipEventRecord(ms->prof_stop[ms->prof_n], st)); ms->prof_n++; }
     return (int)hipGetLastError();

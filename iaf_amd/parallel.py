@@ -50,6 +50,9 @@ class FlatParams(object):
                                                         ptr(self.ema), self.params.numel(), lr, beta1, beta2, eps, ema_decay,
                                                         1.0 / world,
                                                         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            # the launch wrote through raw pointers: tell torch, so that (data_ptr, _version)-keyed caches downstream
+            # (ARStack.prepare, WNConv2d.prepare, IAFLayer.load) see new weights.  Views share the base's counter.
+            torch.autograd.graph.increment_version((self.params, self.ema, self.slot_m, self.slot_v))
         else:        # host replicas (gloo tests): the same arithmetic with torch ops
             g = self.grads / float(world)
             adamax_step_(self.params, g, self.slot_m, self.slot_v, lr, beta1, beta2, eps)

@@ -1,0 +1,156 @@
+"""Every BASELINE.json config, at its STATED size, against the CPU oracle over the WHOLE batch (VERDICT r01 row g):
+one test id per config x latent level.  The oracle (oracle/iaf_oracle.py, pinned to the reference's own outputs in
+tests/test_oracle_golden.py) sees exactly the fp32-rounded inputs and weights the GPU sees.
+
+  config 1  n_z=32 n_h=64  depth_ar=1  B=16   levels 16/8/4     (train.py:19 default batch; depths [2,2,2])
+  config 2  n_z=32 n_h=160 depth_ar=2  B=32   levels 16/8       (depths [10,10])
+  config 4  n_z=64 n_h in {64,128,192} depth_ar=4 B=32 levels 16/8/4, TF statement AND the Theano statement it is
+            quoted on (up_iaf2_nl, models.py:168-176): SURVEY D5 -- the reference leaves n_h of this config open
+  config 5  config-2 weights, B=256 rows per pass (IW-ELBO eval), levels 16/8
+
+Checked per case: the IAF step (tf_train.py:69-72: z_new, logsd = log-det term) and the extended unit (posterior block,
+tf_train.py:56-85: z, kl elements, kl_cost, kl_obj with free bits).  Tolerance: north_star's 1e-4 absolute on O(1)
+tensors; the per-image KL sums over n_z*H*W elements are held to 1e-4 relative (+2e-3 absolute)."""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+import golden_inputs as gi
+from oracle import iaf_oracle as O
+
+pytestmark = pytest.mark.gpu
+ATOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def amd():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU")
+    import iaf_amd
+    iaf_amd._capi.lib()
+    return iaf_amd
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def host(t):
+    torch.cuda.synchronize()
+    return t.detach().cpu().numpy().astype(np.float64)
+
+
+def f32(a):
+    return np.asarray(a, dtype=np.float32).astype(np.float64)
+
+
+def _seed(name):
+    return zlib.crc32(name.encode()) % 1000
+
+
+CONFIGS = []
+for _H in (16, 8, 4):
+    CONFIGS.append(("config1", 16, 32, 64, 1, _H))
+for _H in (16, 8):
+    CONFIGS.append(("config2", 32, 32, 160, 2, _H))
+for _nh in (64, 128, 192):
+    for _H in (16, 8, 4):
+        CONFIGS.append(("config4_nh%d" % _nh, 32, 64, _nh, 4, _H))
+for _H in (16, 8):
+    CONFIGS.append(("config5", 256, 32, 160, 2, _H))
+IDS = ["%s_B%d_%dx%d" % (c[0], c[1], c[5], c[5]) for c in CONFIGS]
+
+
+def _oracle_batched(fn, B, chunk=32):
+    """the oracle in chunks of the batch (its einsum temporaries stay small); every sample is checked"""
+    outs = None
+    for b0 in range(0, B, chunk):
+        r = fn(slice(b0, min(B, b0 + chunk)))
+        r = r if isinstance(r, tuple) else (r,)
+        outs = [[x] for x in r] if outs is None else [o + [x] for o, x in zip(outs, r)]
+    return [np.concatenate(o, axis=0) for o in outs]
+
+
+@pytest.mark.parametrize("cfg", CONFIGS, ids=IDS)
+def test_iaf_step_full_size_vs_oracle(amd, cfg):
+    name, B, n_z, n_h, d, H = cfg
+    rng = np.random.RandomState(_seed(name) + H)
+    params = gi.ar_multiconv2d_params(rng, n_z, [n_h] * d, [n_z, n_z])
+    z, ctx = rng.standard_normal((B, n_z, H, H)), rng.standard_normal((B, n_h, H, H))
+    stack = amd.ARStack(n_z, [n_h] * d)
+    stack.prepare({k: dev(v) for k, v in params.items()})
+    z_new, logsd = stack.iaf_step(dev(z), dev(ctx))
+    p32 = {k: f32(v) for k, v in params.items()}
+    ez, es = _oracle_batched(lambda s: O.iaf_step(f32(z[s]), f32(ctx[s]), p32, [n_h] * d), B)
+    np.testing.assert_allclose(host(logsd), es, atol=ATOL, rtol=0)
+    np.testing.assert_allclose(host(z_new), ez, atol=ATOL, rtol=0)
+    assert np.isfinite(host(z_new)).all()
+
+
+@pytest.mark.parametrize("cfg", CONFIGS, ids=IDS)
+def test_posterior_block_full_size_vs_oracle(amd, cfg):
+    """the extended unit of SURVEY 8d: sample + logqs + IAF step + log-det + logps + KL + free bits (kl_min = 0.25,
+    the README training value) in the fused posterior-block launch sequence"""
+    name, B, n_z, n_h, d, H = cfg
+    kl_min = 0.25
+    rng = np.random.RandomState(_seed(name) + 50 + H)
+    params = gi.ar_multiconv2d_params(rng, n_z, [n_h] * d, [n_z, n_z])
+    f = lambda c: rng.standard_normal((B, c, H, H))
+    qm, ql, rm, rl, pm, pl = f(n_z), 0.25 * f(n_z), f(n_z), 0.25 * f(n_z), f(n_z), 0.25 * f(n_z)
+    uc, dc, eps = f(n_h), f(n_h), f(n_z)
+    stack = amd.ARStack(n_z, [n_h] * d)
+    stack.prepare({k: dev(v) for k, v in params.items()})
+    out = stack.posterior_block(dev(qm), dev(ql), dev(rm), dev(rl), dev(pm), dev(pl), dev(uc), dev(dc), dev(eps),
+                                kl_min, want_kl_elem=True)
+    p32 = {k: f32(v) for k, v in params.items()}
+    # the free-bits mean is over the WHOLE local batch (tf_train.py:79): z / kl elements per chunk, the reductions here
+    def part(s):
+        e = O.posterior_block(f32(qm[s]), f32(ql[s]), f32(rm[s]), f32(rl[s]), f32(pm[s]), f32(pl[s]), f32(uc[s]),
+                              f32(dc[s]), f32(eps[s]), p32, [n_h] * d, kl_min)
+        return e["z"], e["logqs"] - e["logps"]
+    ez, ekl = _oracle_batched(part, B)
+    np.testing.assert_allclose(host(out["z"]), ez, atol=ATOL, rtol=0)
+    np.testing.assert_allclose(host(out["kl_elem"]), ekl, atol=ATOL, rtol=1e-5)
+    kl_cost = ekl.sum(axis=(1, 2, 3))                                              # tf_train.py:85
+    kl_ave = ekl.sum(axis=(2, 3)).mean(axis=0, keepdims=True)                      # :79
+    kl_obj = np.tile(np.maximum(kl_ave, kl_min), (B, 1)).sum(axis=1)               # :80-82
+    np.testing.assert_allclose(host(out["kl_cost"]), kl_cost, atol=2e-3, rtol=1e-4)
+    np.testing.assert_allclose(host(out["kl_obj"]), kl_obj, atol=2e-3, rtol=1e-4)
+
+
+def _theano_params(rng, name, n_z, n_h_list):
+    w = {}
+    sizes = [n_z] + n_h_list
+    for i in range(len(n_h_list)):
+        w["%s_%d_w" % (name, i)] = 0.05 * rng.standard_normal((sizes[i + 1], sizes[i] + 1, 3, 3))
+        w["%s_%d_b" % (name, i)] = 0.1 * rng.standard_normal(sizes[i + 1])
+        w["%s_%d_s" % (name, i)] = 0.1 * rng.standard_normal(sizes[i + 1])
+    for i in range(2):
+        w["%s_out_%d_w" % (name, i)] = 0.05 * rng.standard_normal((n_z, sizes[-1] + 1, 3, 3))
+        w["%s_out_%d_b" % (name, i)] = 0.1 * rng.standard_normal(n_z)
+        w["%s_out_%d_s" % (name, i)] = 0.1 * rng.standard_normal(n_z)
+    return w
+
+
+@pytest.mark.parametrize("cfg", [c for c in CONFIGS if c[0].startswith("config4") or c[0] == "config1"],
+                         ids=[i for c, i in zip(CONFIGS, IDS) if c[0].startswith("config4") or c[0] == "config1"])
+def test_theano_statement_full_size_vs_oracle(amd, cfg):
+    """configs 1 and 4 are quoted on the Theano path (train.py / models.py up_iaf2_nl, models.py:168-176): the Theano
+    statement of the operator (flipped kernel, border channel, exp(3s), +1e-8) at full size, whole batch"""
+    name, B, n_z, n_h, d, H = cfg
+    rng = np.random.RandomState(_seed(name) + 70 + H)
+    nm = "1_posterior_conv1"
+    w = _theano_params(rng, nm, n_z, [n_h] * d)
+    z, ctx = rng.standard_normal((B, n_z, H, H)), rng.standard_normal((B, n_h, H, H))
+    conv = amd.multiconv2d(nm, n_z, [n_h] * d, [n_z, n_z], (3, 3), False, nl="elu", w=None)
+    m_raw, s_raw = conv(dev(z), dev(ctx), {k: dev(v) for k, v in w.items()})
+    z_new, logsd = conv.stack.iaf_step(dev(z), dev(ctx))
+    w32 = {k: f32(v) for k, v in w.items()}
+    em, es = _oracle_batched(lambda s: O.theano_multiconv2d(f32(z[s]), f32(ctx[s]), w32, nm, n_z, [n_h] * d, [n_z, n_z]), B)
+    np.testing.assert_allclose(host(m_raw), em, atol=ATOL, rtol=0)
+    np.testing.assert_allclose(host(s_raw), es, atol=ATOL, rtol=0)
+    ez, el = _oracle_batched(lambda s: O.theano_iaf2_nl(f32(z[s]), f32(ctx[s]), w32, nm, n_z, [n_h] * d), B)
+    np.testing.assert_allclose(host(z_new), ez, atol=ATOL, rtol=0)
+    np.testing.assert_allclose(host(logsd), el, atol=ATOL, rtol=0)

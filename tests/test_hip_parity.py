@@ -456,23 +456,28 @@ def test_full_size_autoregressive_property(amd, H):
     allowed_z = allowed_s.clone()
     allowed_z[:, c, qh, qw] = True            # z_new at the perturbed position changes through (z - m)
 
-    def attempt():
-        z0, s0 = stack.iaf_step(z, ctx)
-        z1, s1 = stack.iaf_step(z2, ctx)
-        torch.cuda.synchronize()
-        dz, ds = (z1 != z0), (s1 != s0)
-        return int((dz & ~allowed_z).sum()), int((ds & ~allowed_s).sum()), bool(ds.any() and dz.any())
+    z0, s0 = stack.iaf_step(z, ctx)
+    z1, s1 = stack.iaf_step(z2, ctx)
+    torch.cuda.synchronize()
+    dz, ds = (z1 != z0), (s1 != s0)
+    # no retry: round 1 saw ONE violation in ~700 runs of this test on a development build; the round-2 soak
+    # (tools/soak.py: 2 x 20,000 steady iterations with churn + 2 x 1,500 fresh stacks, production and LDS-poisoned
+    # builds, every output compared bit for bit) did not reproduce it, and test_iaf_step_determinism_soak
+    # below keeps a short version of that soak in every GPU run.
+    assert int((dz & ~allowed_z).sum()) == 0
+    assert int((ds & ~allowed_s).sum()) == 0
+    assert bool(ds.any() and dz.any())
 
-    vz, vs, moved = attempt()
-    if vz or vs:
-        # Seen ONCE in ~700 runs and never reproduced (tools/fresh_repro.py, tools/flaky_check.py): report loudly, then
-        # require a clean, repeatable second attempt so that a systematic leak still fails.
-        print("WARNING: autoregressive violation on first attempt: z %d, logsd %d elements" % (vz, vs))
-        vz, vs, moved = attempt()
-        assert (vz, vs) == (0, 0)
-        assert attempt()[:2] == (0, 0)
-    assert (vz, vs) == (0, 0)
-    assert moved
+
+@pytest.mark.parametrize("H", [16, 8])
+def test_iaf_step_determinism_soak(amd, H):
+    """identical inputs -> bit-identical outputs, over 1500 back-to-back steps with churn (training traffic on a second
+    stack, allocator traffic, stacks created and destroyed while work is queued) and 100 freshly created stacks"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("iaf_soak", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "soak.py"))
+    soak = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(soak)
+    assert soak.run(32, H, 1500, 100) == 0
 
 
 def test_full_size_identity_when_output_convs_are_zero(amd):
@@ -657,3 +662,26 @@ def test_multi_round_grid_matches_oracle_and_small_batch(amd):
     # the posterior block and the inverse on the large grid as well
     back, _, _, res = stack.iaf_step_inverse(z_new, dev(ctx), max_sweeps=60, tol=1e-6, check_every=2)
     np.testing.assert_allclose(host(back), f32(z), atol=5e-5, rtol=0)
+
+
+def test_prepare_sees_weights_updated_by_the_device_optimiser(amd):
+    """FlatParams.adamax_ema_step writes the parameters through raw pointers; the (data_ptr, _version)-keyed
+    prepare cache of ARStack must still notice, i.e. a step followed by prepare() uses the UPDATED weights"""
+    from iaf_amd import parallel as par
+    B, n_z, n_h, d, H = 2, 32, 64, 1, 4
+    params, z, ctx = _rand_case(31, B, n_z, n_h, d, H, H)
+    fp = par.FlatParams(dev_params(params))
+    stack = amd.ARStack(n_z, [n_h] * d)
+    stack.prepare(fp.p)
+    before = host(stack.iaf_step(dev(z), dev(ctx))[0])
+    rng = np.random.RandomState(3)
+    for k in fp.g:
+        fp.g[k].copy_(dev(rng.standard_normal(fp.g[k].shape)))
+    fp.adamax_ema_step(0.05)
+    stack.prepare(fp.p)                                   # must NOT be skipped as "unchanged"
+    z_new, logsd = stack.iaf_step(dev(z), dev(ctx))
+    new_params = {k: host(v) for k, v in fp.p.items()}
+    ez, es = O.iaf_step(f32(z), f32(ctx), new_params, [n_h] * d)
+    np.testing.assert_allclose(host(z_new), ez, atol=ATOL, rtol=0)
+    np.testing.assert_allclose(host(logsd), es, atol=ATOL, rtol=0)
+    assert np.abs(host(z_new) - before).max() > 1e-3      # and the update was large enough to matter
