@@ -2,7 +2,11 @@
 """bench.py -- IAF-step throughput of the MI355X engine on BASELINE.json's configs[1].
 
   python bench.py --gpus N --steps K --warmup W
-  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  N>1: one rank per GPU over RCCL.  Launched either by the driver as `python -m torch.distributed.run --nnodes=1
+  --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...` (RANK/LOCAL_RANK/WORLD_SIZE in the
+  env), or plainly as `python bench.py --gpus N`, in which case bench.py starts those N ranks itself.  It refuses to
+  run when fewer than N GPUs are visible or when WORLD_SIZE disagrees with --gpus; `n_gpus` in the JSON line is the
+  number of ranks that took part, read back from the communicator (`rccl_ranks`, one entry per rank in `devices`).
 
 Workload (config.workload): "cifar10 n_z=32 n_h=160 depths=[10,10] depth_ar=2 down_iaf2_nl bs=32":
 one STEP = one pass of the IAF hot path (weight prep + ar_multiconv2d + affine transform +
@@ -56,7 +60,96 @@ def parse():
                     help="extra mode (not the headline metric): data-parallel TRAINING step of the IAF posterior stack -- "
                          "posterior block forward + backward for every layer, one RCCL all-reduce of the flat gradient "
                          "buffer, fused Adamax + EMA")
+    ap.add_argument("--ar-buckets", type=int, default=4,
+                    help="--train: number of gradient all-reduce buckets overlapped with the backward pass")
+    ap.add_argument("--iw-eval", action="store_true",
+                    help="extra mode: BASELINE configs[4] -- importance-weighted ELBO evaluation, rows of --batch (256) "
+                         "importance samples per pass through every layer's posterior block, k samples per image streamed "
+                         "through the online log-sum-exp")
+    ap.add_argument("--iw-k", type=int, default=10000, help="--iw-eval: importance samples per image")
     return ap.parse_args()
+
+
+RANK_INFO = {}
+
+
+def emit(out):
+    """rank 0's ONE JSON line; every mode reports who actually took part (read back from the communicator)"""
+    out = dict(out)
+    out["rccl_ranks"] = RANK_INFO.get("rccl_ranks")
+    out["devices"] = RANK_INFO.get("devices")
+    print(json.dumps(out))
+    sys.stdout.flush()
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (torch.distributed.run, one process
+    per GPU, rendezvous on 127.0.0.1) and hand their stdout through -- rank 0 prints the JSON line."""
+    import subprocess
+    ndev = torch.cuda.device_count()
+    if ndev < args.gpus:
+        sys.exit("bench.py: --gpus %d but only %d GPU(s) visible on this node" % (args.gpus, ndev))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this driver (RCCL / tensor sharing)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def init_ranks(args):
+    """-> (dist or None, rank, n_ranks, info).  n_ranks is what the communicator reports, not what --gpus asked for."""
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args)                                  # does not return
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: launch one rank per requested GPU" % (args.gpus, world))
+    if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
+        sys.exit("bench.py: rank %d needs GPU %d but %d GPU(s) are visible" % (rank, local_rank, torch.cuda.device_count()))
+    torch.cuda.set_device(local_rank)
+    info = {"rccl_ranks": None, "devices": ["rank0:cuda:%d %s" % (local_rank, torch.cuda.get_device_name(local_rank))]}
+    if world == 1 and not os.environ.get("IAF_BENCH_FORCE_DIST"):     # the env switch exercises the RCCL path on one GPU
+        return None, 0, 1, info
+    import torch.distributed as dist
+    # RCCL prints a banner (ROCm version / hostname / library path) to STDOUT when its first communicator comes up;
+    # the contract is ONE JSON line on stdout, so that happens with fd 1 pointed at stderr
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.barrier()
+        # read the participants back from the communicator: every rank contributes 1 and its device identity
+        ones = torch.ones(1, device="cuda")
+        dist.all_reduce(ones)
+        props = torch.cuda.get_device_properties(local_rank)
+        ident = "rank%d:cuda:%d %s %s" % (rank, local_rank, props.name, getattr(props, "uuid", ""))
+        idents = [None] * dist.get_world_size()
+        dist.all_gather_object(idents, ident)
+        torch.cuda.synchronize()
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+    info = {"rccl_ranks": int(ones.item()), "devices": idents}
+    if info["rccl_ranks"] != dist.get_world_size() or len(set(idents)) != len(idents):
+        sys.exit("bench.py: communicator reports %r ranks / devices %r" % (info["rccl_ranks"], idents))
+    return dist, rank, dist.get_world_size(), info
 
 
 def make_layer_inputs(rng, B, n_z, n_h, depth_ar, H):
@@ -133,11 +226,105 @@ def cpu_baseline(args, depths):
     }
 
 
+def _chunks(lst, n):
+    n = max(1, min(n, len(lst)))
+    return [lst[i * len(lst) // n:(i + 1) * len(lst) // n] for i in range(n)]
+
+
+def _time_exchange(flat, red, dist, reps=5):
+    """the gradient exchange alone: `reps` all-reduces of the whole flat bucket between one event pair (ms each)"""
+    if not red.active:
+        return None
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    dist.all_reduce(flat.grads)
+    a.record()
+    for _ in range(reps):
+        dist.all_reduce(flat.grads)
+    b.record()
+    b.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+def _run_segmented(args, segments, red, flat, n_gpus, dist):
+    """Shared driver of the two training modes.  `segments[i]()` enqueues the compute that completes gradient bucket i
+    (segment 0 also holds weight prep and the forward pass); each segment replays as its own hipGraph and bucket i's
+    all-reduce is issued right behind it, overlapping the remaining segments (parallel.OverlappedGradReduce)."""
+    nb = len(segments)
+
+    def step_eager():
+        for i in range(nb):
+            segments[i]()
+            red.reduce(i)
+        red.wait()
+        flat.adamax_ema_step(1e-4, world=n_gpus)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    stream = torch.cuda.Stream()
+    graphs = None
+    with torch.cuda.stream(stream):
+        step_eager()
+        stream.synchronize()
+        step = step_eager
+        if not args.no_graph:
+            graphs = []
+            for i in range(nb):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=stream):
+                    segments[i]()
+                graphs.append(g)
+
+            def step():  # noqa: F811
+                for i in range(nb):
+                    graphs[i].replay()
+                    red.reduce(i)
+                red.wait()
+                flat.adamax_ema_step(1e-4, world=n_gpus)
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        # the same step without the exchange, and the exchange alone: how much of it the overlap hides
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = max(3, min(args.steps, 10))
+        a.record()
+        for _ in range(reps):
+            for i in range(nb):
+                (graphs[i].replay if graphs is not None else segments[i])()
+            flat.adamax_ema_step(1e-4, world=n_gpus)
+        b.record()
+        b.synchronize()
+        compute_ms = a.elapsed_time(b) / reps
+        exch_ms = _time_exchange(flat, red, dist)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    step_ms = 1e3 * elapsed / args.steps
+    exchange = {"collective": "all-reduce(sum) fp32, 1/N folded into the Adamax kernel (tf_utils/common.py:83-86)",
+                "executed": bool(red.active), "buckets": nb,
+                "bucket_mb": [4e-6 * (hi - lo) for lo, hi in red.bounds],
+                "alone_ms": exch_ms, "step_without_exchange_ms": compute_ms,
+                "exposed_ms": (step_ms - compute_ms) if red.active else 0.0,
+                "overlap": "bucket i is reduced while the backward segments i+1.. run (issued behind its segment's graph)"}
+    return elapsed, graphs is not None, exchange
+
+
 def train_bench(args, depths, dist, rank, n_gpus):
     """DP training step of the IAF posterior stack (SURVEY 8f-1,2): per step, for every layer, posterior block forward
     (tf_train.py:56-85) + backward (what opt.compute_gradients derives, tf_train.py:138), gradients written into ONE flat
-    buffer, all-reduce(sum) over ranks (RCCL), fused Adamax(1/N)+EMA (tf_utils/common.py:86, adamax.py:40-56,
-    tf_train.py:157-158).  Synthetic upstream gradients (dz ~ N(0,1), dkl_obj = 1)."""
+    buffer laid out in completion order, bucketed all-reduce(sum) over ranks (RCCL) overlapped with the remaining
+    backward, fused Adamax(1/N)+EMA (tf_utils/common.py:86, adamax.py:40-56, tf_train.py:157-158).  Synthetic upstream
+    gradients (dz ~ N(0,1), dkl_obj = 1)."""
     import iaf_amd
     from iaf_amd import parallel as par
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
@@ -158,76 +345,45 @@ def train_bench(args, depths, dist, rank, n_gpus):
             for k, v in params.items():
                 named[pre + k] = dev(v)
             layers.append(dict(stack=st, pre=pre, keys=list(params), inp=inp))
-    flat = par.FlatParams(named)
+    flat = par.FlatParams(named)          # `named` is in layer order == the order this step completes the gradients
     for L in layers:
         L["params"] = {k: flat.p[L["pre"] + k] for k in L["keys"]}
         L["gradviews"] = {k: flat.g[L["pre"] + k] for k in L["keys"]}
+    groups = _chunks(layers, args.ar_buckets)
+    bounds = par.OverlappedGradReduce.bounds_from_groups(flat, [[L["pre"] + k for L in g for k in L["keys"]] for g in groups])
+    red = par.OverlappedGradReduce(flat, bounds, force=bool(os.environ.get("IAF_BENCH_FORCE_DIST")))
     prep = iaf_amd.PrepBatch([L["stack"] for L in layers])
-    wnb = iaf_amd.WnBwdBatch(stacks=[L["stack"] for L in layers])     # mask + weight-norm backward: one launch per model
     plist = [L["params"] for L in layers]
-    glist = [L["gradviews"] for L in layers]
+    # mask + weight-norm backward: one launch per bucket (it finishes the bucket's dV / dg)
+    wnbs = [iaf_amd.WnBwdBatch(stacks=[L["stack"] for L in g]) for g in groups]
 
-    def step():
-        compute()
-        flat.all_reduce_grads()
-        flat.adamax_ema_step(1e-4, world=n_gpus)
+    def make_segment(bi):
+        def seg():
+            if bi == 0:
+                prep.run(plist)
+            for L in groups[bi]:
+                i, st = L["inp"], L["stack"]
+                fw = st.posterior_block_train(i["qm"], i["ql"], i["rm"], i["rl"], i["pm"], i["pl"], i["uc"], i["dc"], i["eps"], 0.25)
+                st.posterior_block_backward(i["qm"], i["ql"], i["rm"], i["rl"], i["pm"], i["pl"], i["eps"], 0.25, fw["z"], i["dz"],
+                                            i["dko"], L["params"], grads_out=L["gradviews"])
+            wnbs[bi].run(stack_params=[L["params"] for L in groups[bi]], stack_grads=[L["gradviews"] for L in groups[bi]])
+        return seg
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # the compute part of the step (everything but the gradient exchange and the update) replays as one hipGraph; the
-    # all-reduce and the fused Adamax+EMA follow on the same stream
-    def compute():
-        prep.run(plist)
-        for L in layers:
-            i, st = L["inp"], L["stack"]
-            fw = st.posterior_block_train(i["qm"], i["ql"], i["rm"], i["rl"], i["pm"], i["pl"], i["uc"], i["dc"], i["eps"], 0.25)
-            st.posterior_block_backward(i["qm"], i["ql"], i["rm"], i["rl"], i["pm"], i["pl"], i["eps"], 0.25, fw["z"], i["dz"],
-                                        i["dko"], L["params"], grads_out=L["gradviews"])
-        wnb.run(stack_params=plist, stack_grads=glist)
-
-    stream = torch.cuda.Stream()
-    graph = None
-    with torch.cuda.stream(stream):
-        step()
-        stream.synchronize()
-        if not args.no_graph:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=stream):
-                compute()
-
-            def step():  # noqa: F811
-                graph.replay()
-                flat.all_reduce_grads()
-                flat.adamax_ema_step(1e-4, world=n_gpus)
-        for _ in range(args.warmup):
-            step()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        barrier()
-        elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, graphed, exchange = _run_segmented(args, [make_segment(i) for i in range(len(groups))], red, flat, n_gpus, dist)
     if rank == 0:
-        print(json.dumps({
+        emit({
             "metric": "IAF posterior-stack TRAIN-step samples/sec (forward + backward + grad all-reduce + Adamax/EMA)",
             "value": n_gpus * args.batch / (elapsed / args.steps), "unit": "samples/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "cifar10 n_z=%d n_h=%d depths=%s depth_ar=%d down_iaf2_nl bs=%d per GPU, kl_min=0.25; "
-                                   "%d trainable fp32 parameters in one flat all-reduce bucket (%.1f MB)"
+                                   "%d trainable fp32 parameters in one flat gradient buffer (%.1f MB)"
                                    % (args.n_z, args.n_h, depths, args.depth_ar, args.batch, flat.params.numel(),
                                       4e-6 * flat.params.numel()),
                        "global_batch": n_gpus * args.batch,
-                       "launch": "hipGraph replay of forward+backward, then all-reduce + update" if graph is not None else "eager",
-                       "parallelism": "dp%d (RCCL all-reduce of one flat gradient bucket)" % n_gpus}}))
+                       "launch": "hipGraph replay per gradient bucket, all-reduce behind each, then the update" if graphed else "eager",
+                       "parallelism": "dp%d (RCCL all-reduce of %d gradient buckets, overlapped with backward)" % (n_gpus, len(groups))},
+            "exchange": exchange})
 
 
 def layers_bench(args, depths, dist, rank, n_gpus):
@@ -337,7 +493,7 @@ def layers_bench(args, depths, dist, rank, n_gpus):
         for L in lv["layers"]:
             total_fl += sum(c.work(B, lv["H"], lv["H"])[0] for c in L["layer"].convs())
             total_fl += L["layer"].posterior.stack.step_work(B, lv["H"], lv["H"])["live_flops"]
-    print(json.dumps({
+    emit({
         "metric": "IAFLayer forward samples/sec (up + down of every layer: 4 plain weight-normed convs + IAF posterior block)",
         "value": n_gpus * B / (elapsed / args.steps), "unit": "samples/s", "n_gpus": n_gpus, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
@@ -355,13 +511,15 @@ def layers_bench(args, depths, dist, rank, n_gpus):
                      "kernel": "iaf_conv_kernel<.., EPI_PLAIN, 9 taps> (down_conv1 %d->%d, B=%d 16x16)" % (cv.n_in, cv.n_out, B),
                      "avg_launch_us": 1e3 * k_ms, "launches_timed": 50 * len(kt), "flops_per_launch": fl,
                      "bytes_per_launch": by, "hbm_frac_at_this_rate": (by / (k_ms * 1e-3) / 1e9) / PEAK_HBM_GBS,
-                     "timing": "HIP events on the launch stream around 50 back-to-back launches per 16x16 layer"}}))
+                     "timing": "HIP events on the launch stream around 50 back-to-back launches per 16x16 layer"}})
 
 
 def layers_train_bench(args, depths, dist, rank, n_gpus):
     """DP training step of whole IAFLayers (SURVEY 8f-4 + 8f-1,2): weight prep, up pass, down pass, backward of both
-    passes (every plain conv and the posterior block), gradients written into ONE flat buffer, all-reduce(sum) over
-    ranks, fused Adamax(1/N)+EMA.  Synthetic upstream gradients (d output ~ N(0,1), d kl_obj = 1)."""
+    passes (every plain conv and the posterior block), gradients written into ONE flat buffer laid out in the order the
+    backward completes them (top-down-pass parameters layer by layer, then bottom-up-pass parameters in reverse), bucketed
+    all-reduce(sum) over ranks overlapped with the remaining backward, fused Adamax(1/N)+EMA.  Synthetic upstream
+    gradients (d output ~ N(0,1), d kl_obj = 1)."""
     import golden_inputs as gi
     import iaf_amd
     from iaf_amd import parallel as par
@@ -369,147 +527,148 @@ def layers_train_bench(args, depths, dist, rank, n_gpus):
     rng = np.random.RandomState(4321 + rank)
     wrng = np.random.RandomState(99)
     zs, hs, B = args.n_z, args.n_h, args.batch
-    named, levels = {}, []
+    DOWN = (("down_conv1", (hs, 4 * zs + 2 * hs)), ("down_conv2", (hs + zs, hs)))
+    UP = (("up_conv1", (hs, 2 * zs + 2 * hs)), ("up_conv3", (hs, hs)))
+    host, levels = {}, []
     for lvl, nlayer in enumerate(depths):
         H = 16 >> lvl
         L = []
         for j in range(nlayer):
             pre = "IAF_%d_%d/" % (lvl, j)
-            for nm, (ci, co) in (("up_conv1", (hs, 2 * zs + 2 * hs)), ("up_conv3", (hs, hs)),
-                                 ("down_conv1", (hs, 4 * zs + 2 * hs)), ("down_conv2", (hs + zs, hs))):
+            for nm, (ci, co) in UP + DOWN:
                 for k, v in gi.conv_params(wrng, ci, co).items():
-                    named[pre + nm + "/" + k] = dev(v)
+                    host[pre + nm + "/" + k] = v
             for k, v in gi.ar_multiconv2d_params(wrng, zs, [hs] * args.depth_ar, [zs, zs]).items():
-                named[pre + "ar_multiconv2d/" + k] = dev(v)
+                host[pre + "ar_multiconv2d/" + k] = v
             layer = iaf_amd.IAFLayer(zs, hs, depth_ar=args.depth_ar, kl_min=0.25)
             layer.set_training(True)
             L.append(dict(layer=layer, pre=pre, eps=dev(rng.standard_normal((B, zs, H, H)))))
         f = lambda: dev(rng.standard_normal((B, hs, H, H)))
         levels.append(dict(H=H, layers=L, up_in=f(), down_in=f(), d_up=f(), d_down=f()))
-    flat = par.FlatParams(named)
     all_layers = [L for lv in levels for L in lv["layers"]]
+    for lv in levels:
+        for i, L in enumerate(lv["layers"]):
+            L["lv"], L["first"], L["last"] = lv, i == 0, i == len(lv["layers"]) - 1
+    # completion order of the gradients: down_backward visits levels / layers in forward order and finishes each
+    # layer's down_conv1, down_conv2 and ar_multiconv2d; up_backward then runs in reverse and finishes up_conv1/3
+    down_order = all_layers
+    up_order = [L for lv in reversed(levels) for L in reversed(lv["layers"])]
+    is_down = lambda k: ("/down_conv" in k) or ("/ar_multiconv2d/" in k)
+    named = {}
+    for L in down_order:
+        for k, v in host.items():
+            if k.startswith(L["pre"]) and is_down(k):
+                named[k] = dev(v)
+    for L in up_order:
+        for k, v in host.items():
+            if k.startswith(L["pre"]) and not is_down(k):
+                named[k] = dev(v)
+    flat = par.FlatParams(named)
     for L in all_layers:
         n = len(L["pre"])
         L["params"] = {k[n:]: v for k, v in flat.p.items() if k.startswith(L["pre"])}
         L["grads"] = {k[n:]: v for k, v in flat.g.items() if k.startswith(L["pre"])}
+    nb = max(1, args.ar_buckets)
+    dgroups = _chunks(down_order, (nb + 1) // 2)
+    ugroups = _chunks(up_order, nb // 2) if nb >= 2 else []
+    if not ugroups:                                       # a single bucket: everything completes at the very end
+        names = [[k for k in named]]
+    else:
+        names = [[k for L in g for k in named if k.startswith(L["pre"]) and is_down(k)] for g in dgroups] + \
+                [[k for L in g for k in named if k.startswith(L["pre"]) and not is_down(k)] for g in ugroups]
+    red = par.OverlappedGradReduce(flat, par.OverlappedGradReduce.bounds_from_groups(flat, names),
+                                   force=bool(os.environ.get("IAF_BENCH_FORCE_DIST")))
     prep_s = iaf_amd.PrepBatch([L["layer"].posterior.stack for L in all_layers])
     prep_c = iaf_amd.ConvPrepBatch([c for L in all_layers for c in L["layer"].convs()])
     splist = [iaf_amd.IAFLayer.stack_params(L["params"]) for L in all_layers]
     cplist = [t for L in all_layers for t in iaf_amd.IAFLayer.conv_params(L["params"])]
     dko = torch.ones(B, device="cuda")
-    wnb = iaf_amd.WnBwdBatch(stacks=[L["layer"].posterior.stack for L in all_layers],
-                             convs=[c for L in all_layers for c in L["layer"].convs()])
-    sglist = [iaf_amd.IAFLayer.stack_params(L["grads"]) for L in all_layers]
-    cglist = [t for L in all_layers for t in iaf_amd.IAFLayer.conv_params(L["grads"])]
+    tup = lambda d, nm: (d[nm + "/V"], d[nm + "/g"], d[nm + "/b"])
 
-    def compute(tune=False):
+    def wn_batch(group, down):
+        """deferred mask + weight-norm backward of the parameters a segment completes"""
+        convs = [getattr(L["layer"], nm) for L in group for nm, _ in (DOWN if down else UP)]
+        stacks = [L["layer"].posterior.stack for L in group] if down else []
+        w = iaf_amd.WnBwdBatch(stacks=stacks, convs=convs)
+        cp = [tup(L["params"], nm) for L in group for nm, _ in (DOWN if down else UP)]
+        cg = [tup(L["grads"], nm) for L in group for nm, _ in (DOWN if down else UP)]
+        sp = [iaf_amd.IAFLayer.stack_params(L["params"]) for L in group] if down else []
+        sg = [iaf_amd.IAFLayer.stack_params(L["grads"]) for L in group] if down else []
+        return lambda: w.run(stack_params=sp, stack_grads=sg, conv_params=cp, conv_grads=cg)
+
+    tune = [False]
+    carry = {}
+
+    def forward():
         prep_s.run(splist)
         prep_c.run(cplist)
         for lv in levels:
             h = lv["up_in"]
             for L in lv["layers"]:
-                h = L["layer"].up_train(h, autotune=tune)
+                h = L["layer"].up_train(h, autotune=tune[0])
         for lv in reversed(levels):
             h = lv["down_in"]
             for L in reversed(lv["layers"]):
-                h, _, _ = L["layer"].down_train(h, L["eps"], autotune=tune)
-        for lv in levels:                                   # backward of the top-down pass, in reverse
-            d = lv["d_down"]
-            for L in lv["layers"]:
-                d = L["layer"].down_backward(d, dko, L["params"], L["grads"], autotune=tune)
-        for lv in reversed(levels):                         # backward of the bottom-up pass, in reverse
-            d = lv["d_up"]
-            for L in reversed(lv["layers"]):
-                d = L["layer"].up_backward(d, L["params"], L["grads"], autotune=tune)
-        wnb.run(stack_params=splist, stack_grads=sglist, conv_params=cplist, conv_grads=cglist)
+                h, _, _ = L["layer"].down_train(h, L["eps"], autotune=tune[0])
 
-    def step():
-        compute()
-        flat.all_reduce_grads()
-        flat.adamax_ema_step(1e-4, world=n_gpus)
+    def down_bwd(group):                                  # backward of the top-down pass, layer by layer
+        for L in group:
+            d = L["lv"]["d_down"] if L["first"] else carry["d"]
+            carry["d"] = L["layer"].down_backward(d, dko, L["params"], L["grads"], autotune=tune[0])
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+    def up_bwd(group):                                    # backward of the bottom-up pass, in reverse
+        for L in group:
+            d = L["lv"]["d_up"] if L["last"] else carry["u"]
+            carry["u"] = L["layer"].up_backward(d, L["params"], L["grads"], autotune=tune[0])
 
-    stream = torch.cuda.Stream()
-    graph = None
-    with torch.cuda.stream(stream):
-        step()
-        compute(tune=True)             # launch-shape search of the plain convs, forward and data gradient (cuDNN's autotune)
-        stream.synchronize()
-        if not args.no_graph:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=stream):
-                compute()
+    segments = []
+    if not ugroups:
+        wd, wu = wn_batch(down_order, True), wn_batch(up_order, False)
+        segments.append(lambda: (forward(), down_bwd(down_order), up_bwd(up_order), wd(), wu()))
+    else:
+        for gi_, g in enumerate(dgroups):
+            w = wn_batch(g, True)
+            segments.append((lambda g=g, w=w, first=(gi_ == 0): ((forward() if first else None), down_bwd(g), w())))
+        for g in ugroups:
+            w = wn_batch(g, False)
+            segments.append((lambda g=g, w=w: (up_bwd(g), w())))
 
-            def step():  # noqa: F811
-                graph.replay()
-                flat.all_reduce_grads()
-                flat.adamax_ema_step(1e-4, world=n_gpus)
-        for _ in range(args.warmup):
-            step()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        barrier()
-        elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # launch-shape search of the plain convs, forward and data gradient (cuDNN's autotune), before anything is captured
+    for sgm in segments:
+        sgm()
+    tune[0] = True
+    for sgm in segments:
+        sgm()
+    tune[0] = False
+    torch.cuda.synchronize()
+    elapsed, graphed, exchange = _run_segmented(args, segments, red, flat, n_gpus, dist)
     if rank == 0:
         fwd_fl = 0.0
         for lv in levels:
             for L in lv["layers"]:
                 fwd_fl += sum(c.work(B, lv["H"], lv["H"])[0] for c in L["layer"].convs())
                 fwd_fl += L["layer"].posterior.stack.step_work(B, lv["H"], lv["H"])["live_flops"]
-        print(json.dumps({
+        emit({
             "metric": "IAFLayer TRAIN-step samples/sec (forward + backward of every layer + grad all-reduce + Adamax/EMA)",
             "value": n_gpus * B / (elapsed / args.steps), "unit": "samples/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "cifar10 z_size=%d h_size=%d depths=%s depth_ar=%d bs=%d per GPU, kl_min=0.25: %d "
-                                   "non-downsampling IAFLayers; %d trainable fp32 parameters in one flat all-reduce bucket (%.1f MB)"
+                                   "non-downsampling IAFLayers; %d trainable fp32 parameters in one flat gradient buffer (%.1f MB)"
                                    % (zs, hs, depths, args.depth_ar, B, len(all_layers), flat.params.numel(),
                                       4e-6 * flat.params.numel()),
                        "global_batch": n_gpus * B,
-                       "launch": "hipGraph replay of forward+backward, then all-reduce + update" if graph is not None else "eager",
+                       "launch": "hipGraph replay per gradient bucket, all-reduce behind each, then the update" if graphed else "eager",
                        "model_tflops_fwd_plus_bwd": 3.0 * fwd_fl / (elapsed / args.steps) / 1e12,
-                       "parallelism": "dp%d (RCCL all-reduce of one flat gradient bucket)" % n_gpus}}))
+                       "parallelism": "dp%d (RCCL all-reduce of %d gradient buckets, overlapped with backward)" % (n_gpus, len(segments))},
+            "exchange": exchange})
 
 
 def main():
     args = parse()
     depths = [int(d) for d in args.depths.split(",") if d]
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 or os.environ.get("IAF_BENCH_FORCE_DIST"):      # the env switch exercises the RCCL path on one GPU
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        # RCCL prints a banner (ROCm version / hostname / library path) to STDOUT when its first communicator comes up;
-        # the contract is ONE JSON line on stdout, so that happens with fd 1 pointed at stderr
-        sys.stdout.flush()
-        saved = os.dup(1)
-        os.dup2(2, 1)
-        try:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-            dist.barrier()
-            torch.cuda.synchronize()
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved, 1)
-            os.close(saved)
-    else:
-        dist = None
-        torch.cuda.set_device(0)
-    if args.gpus != world and rank == 0 and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
-    n_gpus = world
+    dist, rank, n_gpus, rank_info = init_ranks(args)
+    RANK_INFO.update(rank_info)
 
     import iaf_amd
     iaf_amd._capi.lib()           # fail loudly if the HIP engine is not built
@@ -606,6 +765,42 @@ def main():
         # primary figure: N back-to-back launches of the dominant kernel between ONE event pair (no per-launch
         # event/dispatch latency), averaged over the 16x16 layers
         kbatch = [L["stack"].time_layer(dom_layer, L["z"], L["ctx"] if args.depth_ar > 0 else None, reps=50) for L in prof]
+        # every GEMM layer of the IAF step at every latent level, same method (first layer of each level), and the
+        # extended unit of SURVEY 8d (posterior block: sample + logqs + IAF step + log-det + logps + KL / free bits)
+        ktable, xunit = [], []
+        for lvl, nlayer in enumerate(depths):
+            if nlayer == 0:
+                continue
+            H = 16 >> lvl
+            L = [x for x in layers if x["H"] == H][0]
+            st = L["stack"]
+            cin = args.n_z
+            for gl in range(args.depth_ar + 1):
+                cout = args.n_h if gl < args.depth_ar else 2 * args.n_z
+                ms = st.time_layer(gl, L["z"], L["ctx"] if args.depth_ar > 0 else None, reps=50)
+                w = st.layer_work(gl, args.batch, H, H)
+                tf_ = w["live_flops"] / (ms * 1e-3) / 1e12
+                ktable.append({"layer": "masked conv %d->%d%s" % (cin, cout, " (mean,logsd pair + affine/log-det epilogue)" if gl == args.depth_ar else ""),
+                               "latent": "%dx%d" % (H, H), "us": 1e3 * ms, "live_gflop": w["live_flops"] / 1e9,
+                               "live_tflops": tf_, "frac": tf_ / PEAK_F32_MFMA_TFLOPS})
+                cin = args.n_h
+            if args.depth_ar > 0:
+                f = lambda c, sc=1.0: sc * torch.randn(args.batch, c, H, H, device="cuda")
+                pin = [f(args.n_z), f(args.n_z, 0.25), f(args.n_z), f(args.n_z, 0.25), f(args.n_z), f(args.n_z, 0.25),
+                       f(args.n_h), f(args.n_h), f(args.n_z)]
+                st.posterior_block(*pin, 0.25)
+                ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ea.record(stream)
+                for _ in range(30):
+                    st.posterior_block(*pin, 0.25)
+                eb.record(stream)
+                eb.synchronize()
+                us = 1e3 * ea.elapsed_time(eb) / 30
+                sw = st.step_work(args.batch, H, H)
+                xunit.append({"latent": "%dx%d" % (H, H), "us": us, "samples_per_s": args.batch / (us * 1e-6),
+                              "live_tflops": sw["live_flops"] / (us * 1e-6) / 1e12,
+                              "frac": sw["live_flops"] / (us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                              "launches": "%d masked convs + 2 KL reductions, eager" % (args.depth_ar + 1)})
 
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -646,6 +841,21 @@ def main():
         "hbm_frac_at_this_rate": (lw["bytes"] / (k_avg_ms * 1e-3) / 1e9) / PEAK_HBM_GBS,
     }
     work16 = st0.step_work(args.batch, 16, 16)
+    step_flops = sum(d * st0.step_work(args.batch, 16 >> i, 16 >> i)["live_flops"] for i, d in enumerate(depths))
+    step_tf = step_flops / (ms_per_step * 1e-3) / 1e12
+    roofline["step"] = {"live_flops_per_step": step_flops, "ms_per_step": ms_per_step, "achieved": step_tf,
+                        "frac": step_tf / PEAK_F32_MFMA_TFLOPS,
+                        "note": "the whole timed step (weight prep + every conv launch + gaps) against the same fp32-MFMA peak"}
+    roofline["kernels"] = ktable
+    roofline["extended_unit"] = xunit
+    rp = os.path.join(ROOT, "profiles", "rocprof_dominant_kernel.json")
+    if os.path.exists(rp):
+        try:
+            rj = json.load(open(rp))
+            roofline["rocprof"] = {"avg_launch_us": rj.get("avg_launch_us"), "source": rj.get("source"),
+                                   "frac": lw["live_flops"] / (rj["avg_launch_us"] * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS}
+        except Exception:
+            pass
     out = {
         "metric": "IAF-step samples/sec (down_iaf2_nl posterior stack, forward + log-det)",
         "value": value, "unit": "samples/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
@@ -668,7 +878,7 @@ def main():
     if n_gpus == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, depths)
         out["config"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
-    print(json.dumps(out))
+    emit(out)
     if dist is not None:
         dist.destroy_process_group()
 

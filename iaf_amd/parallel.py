@@ -41,6 +41,12 @@ class FlatParams(object):
             return dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
         return None
 
+    def offset_of(self, name):
+        """(first element, one past the last element) of parameter `name` inside the flat buffers"""
+        v = self.p[name]
+        lo = (v.data_ptr() - self.params.data_ptr()) // 4
+        return lo, lo + v.numel()
+
     def adamax_ema_step(self, lr, world=1, beta1=0.9, beta2=0.999, eps=1e-8, ema_decay=0.999):
         if self.params.is_cuda:
             import ctypes
@@ -57,6 +63,47 @@ class FlatParams(object):
             g = self.grads / float(world)
             adamax_step_(self.params, g, self.slot_m, self.slot_v, lr, beta1, beta2, eps)
             ema_step_(self.ema, self.params, ema_decay)
+
+
+class OverlappedGradReduce(object):
+    """The gradient exchange of a training step (tf_utils/common.py:83-86: sum over towers, then 1/N) as a few large
+    all-reduces that OVERLAP the backward pass.  The flat gradient buffer is laid out in the order backward finishes
+    the gradients and cut into contiguous buckets [lo, hi); `reduce(i)` is called right after the kernels that
+    complete bucket i were enqueued: torch.distributed makes the collective's stream wait for exactly that point of
+    the compute stream, so bucket i travels over xGMI while the backward of the remaining layers runs, and `wait()`
+    joins the streams before the optimiser.  xGMI rings are per-link bound, so the buckets stay large (tens of MB);
+    the 1/N is folded into the fused Adamax kernel.  `force` runs the collective even at world size 1 (single-GPU
+    boxes: the RCCL path still executes)."""
+
+    def __init__(self, flat, bounds, group=None, force=False):
+        self.flat, self.group = flat, group
+        self.bounds = [(int(a), int(b)) for a, b in bounds]
+        n = flat.grads.numel()
+        assert self.bounds and self.bounds[0][0] == 0 and self.bounds[-1][1] == n, "buckets must tile the flat buffer"
+        assert all(a[1] == b[0] for a, b in zip(self.bounds[:-1], self.bounds[1:])), "buckets must be contiguous"
+        self.active = dist.is_initialized() and (dist.get_world_size(group) > 1 or force)
+        self.works = []
+
+    @staticmethod
+    def bounds_from_groups(flat, groups):
+        """groups: list of lists of parameter names, in completion order and in the flat buffer's order"""
+        out, lo = [], 0
+        for i, names in enumerate(groups):
+            hi = max(flat.offset_of(k)[1] for k in names)
+            hi = flat.grads.numel() if i == len(groups) - 1 else ((hi + 3) // 4) * 4
+            out.append((lo, hi))
+            lo = hi
+        return out
+
+    def reduce(self, i):
+        if self.active:
+            lo, hi = self.bounds[i]
+            self.works.append(dist.all_reduce(self.flat.grads[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        self.works = []
 
 
 def shard_batch(x, rank=None, world=None):

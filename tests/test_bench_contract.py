@@ -1,0 +1,54 @@
+"""bench.py's launch contract: `--gpus N` must really run N ranks or refuse."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, env_extra=None, timeout=600):
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, BENCH] + args, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_refuses_more_gpus_than_visible():
+    n = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    r = _run(["--gpus", str(n + 1), "--steps", "1", "--warmup", "0"])
+    assert r.returncode != 0
+    assert "GPU(s)" in r.stderr and not r.stdout.strip()
+
+
+def test_refuses_world_size_mismatch():
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
+@pytest.mark.gpu
+def test_plain_invocation_with_two_gpus_runs_two_rccl_ranks():
+    """`python bench.py --gpus 2` with no launcher: bench.py spawns the ranks itself, the JSON line reports the ranks
+    the communicator saw.  Needs a box with >= 2 GPUs (the gpurun boxes have one: skipped there)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    r = _run(["--gpus", "2", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and len(line["devices"]) == 2
+
+
+@pytest.mark.gpu
+def test_train_mode_executes_the_rccl_exchange_on_one_gpu():
+    """IAF_BENCH_FORCE_DIST=1: a one-rank RCCL communicator, so the bucketed all-reduce path of --train really runs on
+    the hardware that is there (the exchange is reported as executed, with its own timing)"""
+    r = _run(["--train", "--steps", "3", "--warmup", "1", "--depths", "2,2"], {"IAF_BENCH_FORCE_DIST": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["rccl_ranks"] == 1 and line["exchange"]["executed"] is True
+    assert line["exchange"]["buckets"] >= 2 and line["exchange"]["alone_ms"] > 0

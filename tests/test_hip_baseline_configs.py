@@ -68,7 +68,7 @@ def _oracle_batched(fn, B, chunk=32):
     outs = None
     for b0 in range(0, B, chunk):
         r = fn(slice(b0, min(B, b0 + chunk)))
-        r = r if isinstance(r, tuple) else (r,)
+        r = tuple(r) if isinstance(r, (tuple, list)) else (r,)
         outs = [[x] for x in r] if outs is None else [o + [x] for o, x in zip(outs, r)]
     return [np.concatenate(o, axis=0) for o in outs]
 

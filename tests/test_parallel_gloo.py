@@ -122,3 +122,48 @@ def test_average_grads_against_reference_golden_four_towers(golden_dir):
     avg = O.average_grads(towers)
     for i in range(3):
         np.testing.assert_allclose(avg[i], g["avg_g%d" % i], rtol=1e-13, atol=1e-15)
+
+
+def _overlap_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from iaf_amd import parallel as par
+    rng = np.random.RandomState(3)
+    # completion order of a two-layer model: the down-pass parameters of layers 0, 1, then the up-pass parameters of 1, 0
+    names = ["IAF_0_0/down_conv1/V", "IAF_0_0/ar_multiconv2d/layer_0/g", "IAF_0_1/down_conv1/V", "IAF_0_1/odd",
+             "IAF_0_1/up_conv1/V", "IAF_0_0/up_conv1/V"]
+    shapes = [(3, 3, 4, 6), (7,), (3, 3, 4, 6), (5,), (3, 3, 2, 4), (3, 3, 2, 4)]
+    fp = par.FlatParams({k: torch.from_numpy(rng.standard_normal(s)).float() for k, s in zip(names, shapes)})
+    groups = [names[0:2], names[2:4], names[4:6]]
+    bounds = par.OverlappedGradReduce.bounds_from_groups(fp, groups)
+    red = par.OverlappedGradReduce(fp, bounds)
+    grng = np.random.RandomState(100 + rank)
+    for bi, grp in enumerate(groups):                  # "backward" fills bucket bi, then its all-reduce is issued
+        for k in grp:
+            fp.g[k].copy_(torch.from_numpy(grng.standard_normal(fp.g[k].shape)).float())
+        red.reduce(bi)
+    red.wait()
+    fp.adamax_ema_step(0.01, world=world)
+    out[rank] = dict(grads=fp.grads.numpy().copy(), params=fp.params.numpy().copy(), bounds=bounds,
+                     offs=[fp.offset_of(k) for k in names])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_bucketed_grad_reduce_two_ranks_gloo():
+    """the bucketed all-reduce issued bucket by bucket as backward completes them == one all-reduce(sum) of the
+    whole gradient buffer (tf_utils/common.py:83-86 before the 1/N), on every rank"""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_overlap_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    np.testing.assert_array_equal(out[0]["grads"], out[1]["grads"])
+    np.testing.assert_array_equal(out[0]["params"], out[1]["params"])
+    bounds = out[0]["bounds"]
+    assert bounds[0][0] == 0 and all(a[1] == b[0] for a, b in zip(bounds[:-1], bounds[1:])) and all(b % 4 == 0 for _, b in bounds)
+    shapes = [(3, 3, 4, 6), (7,), (3, 3, 4, 6), (5,), (3, 3, 2, 4), (3, 3, 2, 4)]
+    grngs = [np.random.RandomState(100 + r) for r in range(world)]
+    for (lo, hi), s in zip(out[0]["offs"], shapes):
+        tot = sum(gr.standard_normal(s).astype(np.float32) for gr in grngs)
+        np.testing.assert_allclose(out[0]["grads"][lo:hi].reshape(s), tot, rtol=1e-6, atol=1e-6)
