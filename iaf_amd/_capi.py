@@ -14,6 +14,8 @@ IAF_ERR_NOT_MULTIPLE = -3
 IAF_ERR_NOT_PREPARED = -4
 IAF_ERR_WORKSPACE = -5
 IAF_ERR_UNSUPPORTED = -6
+IAF_PRECISION_F32 = 0
+IAF_PRECISION_BF16X3 = 1
 IAF_VARIANT_TF = 0
 IAF_VARIANT_THEANO = 1
 
@@ -67,6 +69,9 @@ SIGNATURES = {
     "iaf_lowerbound_stream_update": (ctypes.c_int, [_c_float_p] * 4 + [ctypes.c_int, ctypes.c_int, _vp]),
     "iaf_lowerbound_stream_finalize": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int, ctypes.c_int, _vp]),
     "iaf_stack_set_tuning": (ctypes.c_int, [_vp] + [ctypes.c_int] * 5),
+    "iaf_stack_set_precision": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "iaf_stack_get_precision": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "iaf_stack_set_tuning_bf3": (ctypes.c_int, [_vp] + [ctypes.c_int] * 5),
     "iaf_stack_profile_enable": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
     "iaf_stack_profile_read": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float), ctypes.c_int,
                                               ctypes.POINTER(ctypes.c_int)]),
@@ -115,6 +120,11 @@ class IafHipError(RuntimeError):
     pass
 
 
+class UnsupportedError(ValueError):
+    """IAF_ERR_UNSUPPORTED: a shape / launch shape the gfx950 kernels do not cover (a ValueError like other bad
+    arguments, but its own class so that callers -- and tests -- can tell "not covered" from a genuine argument error)"""
+
+
 _lib = None
 
 
@@ -146,6 +156,8 @@ def check(code):
     msg = "iaf_hip: %s (status %d)" % (error_string(code), code)
     if code == IAF_ERR_NOT_MULTIPLE:
         raise AssertionError(msg)          # tf_utils/layers.py:116
-    if code in (IAF_ERR_NULL, IAF_ERR_SHAPE, IAF_ERR_WORKSPACE, IAF_ERR_UNSUPPORTED):
+    if code == IAF_ERR_UNSUPPORTED:
+        raise UnsupportedError(msg)
+    if code in (IAF_ERR_NULL, IAF_ERR_SHAPE, IAF_ERR_WORKSPACE):
         raise ValueError(msg)
     raise IafHipError(msg)

@@ -1,0 +1,325 @@
+// iaf_conv_bf3.hpp -- the masked 3x3 conv of the IAF step on the bf16 matrix cores at fp32 accuracy ("bf16x3").
+//
+// Why: the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32, iaf_conv_kernel.hpp) runs at the fp32 VECTOR rate, 1/16 of the bf16
+// MFMA rate.  Every fp32 operand is the exact sum of three bf16 numbers, x = xh + xm + xl (8 significand bits each,
+// |xm| <= 2^-9|x|, |xl| <= 2^-18|x|), so a product of two fp32 numbers is the sum of nine bf16 products; the three
+// smallest (m*l, l*m, l*l <= 2^-27 relative) are below fp32 resolution and are dropped.  The remaining SIX products
+//     w_h x_h + w_h x_m + w_m x_h + w_h x_l + w_l x_h + w_m x_m
+// are accumulated in the fp32 accumulator of v_mfma_f32_16x16x32_bf16: 6 MFMAs of 16 cycles per K = 32 instead of 8 of
+// 32 cycles -- 2.7x the matrix-core throughput.  Products of bf16 pairs are exact in fp32, and the accumulation is fp32
+// like the exact path's, so the result carries fp32-grade error (measured against an fp64 evaluation: not larger than the
+// fp32 MFMA chain's, tests/test_hip_bf3.py and DESIGN.md 4.7).  Masked weights are exactly zero in all three planes, so
+// the autoregressive structure stays bit-exact.
+//
+// Data flow (differs from the fp32 kernel because the operand rate per MFMA cycle is ~4x higher):
+//   weights      prep kernel writes three bf16 planes in fragment order  [step = (c_in pair of 32, tap)][co tile][plane]
+//                [lane 64][8 bf16]: one (step, tile, plane) fragment = 1 KiB = one global_load_dwordx4 per wave.
+//   activations  staged once per workgroup into LDS as three bf16 planes per pixel slot ([slot][plane][c_in], +16 B pad:
+//                slot stride = 8*odd dwords, ds_read_b128 conflict-free); split fp32 -> 3 x bf16 while staging.
+//   tiling       workgroup = PXT x KS waves.  A wave owns PPW pixel tiles (16 px) x NT co tiles (16 ch) -- every weight
+//                fragment it fetches is used by PPW pixel tiles (register blocking along pixels: the weight stream into a
+//                CU, not the MFMA pipe, is the limit at BASELINE batch sizes) -- for ONE slice of the K steps; the KS
+//                waves of a group split the steps of the same tile (nothing shared, no barrier in the K loop) and
+//                exchange partial sums through LDS at the end.
+//   K loop       steps (pair, tap) with a register ring of RD+1 step slots; refills are clamped to the wave's last step
+//                so every body is branch-free straight-line code (counted s_waitcnt).
+// Epilogues: the same fused epilogues as the fp32 kernel (bias + context + ELU -> pixel-major scratch; output pair ->
+// affine transform + log-det term / posterior KL elements), shared code in iaf_conv_epilogue.hpp.
+#pragma once
+#include "iaf_conv_epilogue.hpp"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// x = h + m + l exactly up to 2^-27|x|; each part a bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32)
+__device__ __forceinline__ void bf3_split2(f32x2 x, unsigned& h, unsigned& m, unsigned& l) {
+    const bf16x2 hb = __builtin_convertvector(x, bf16x2);
+    const f32x2 r1 = x - __builtin_convertvector(hb, f32x2);
+    const bf16x2 mb = __builtin_convertvector(r1, bf16x2);
+    const f32x2 r2 = r1 - __builtin_convertvector(mb, f32x2);
+    const bf16x2 lb = __builtin_convertvector(r2, bf16x2);
+    h = __builtin_bit_cast(unsigned, hb);
+    m = __builtin_bit_cast(unsigned, mb);
+    l = __builtin_bit_cast(unsigned, lb);
+}
+
+// 4 consecutive channels of one pixel slot -> the three planes of the LDS tile (8 bytes each)
+__device__ __forceinline__ void bf3_store4(char* smem, int slot, int q, f32x4 v, int s16, int cin8) {
+    unsigned h0, m0, l0, h1, m1, l1;
+    bf3_split2(f32x2{v[0], v[1]}, h0, m0, l0);
+    bf3_split2(f32x2{v[2], v[3]}, h1, m1, l1);
+    char* base = smem + ((size_t)slot * s16 << 4) + q * 8;
+    *(u32x2*)(base) = u32x2{h0, h1};
+    *(u32x2*)(base + ((size_t)cin8 << 4)) = u32x2{m0, m1};
+    *(u32x2*)(base + ((size_t)cin8 << 5)) = u32x2{l0, l1};
+}
+
+template <int NT, int PPW, int PXT, int KS, int INMODE, int EPI>
+__global__ __launch_bounds__(64 * PXT * KS) void iaf_conv_bf3_kernel(ConvP p) {
+    extern __shared__ __attribute__((aligned(16))) f32x4 smem4[];
+    char* smem = (char*)smem4;
+    constexpr int NTP = NTAPS;
+    constexpr int TM = 16 * PPW * PXT;
+    constexpr int NTHREADS = 64 * PXT * KS;
+    constexpr int RD = (PPW >= 2) ? 1 : 2;   // ring look-ahead in steps (a step is PPW*NT*6 MFMAs of 16 cycles)
+    constexpr int U = RD + 1;                                   // ring slots
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pw = wave % PXT, kh = wave / PXT;
+    const int P0 = blockIdx.x * TM;
+    const int cot0 = blockIdx.y * NT;
+    asm volatile("" ::"s"(p.x), "s"(p.wp), "s"(p.B), "s"(p.H), "s"(p.W), "s"(p.HW), "s"(p.P), "s"(p.cin), "s"(p.cout),
+                 "s"(p.nchunk), "s"(p.ncot), "s"(p.nslot), "s"(p.mode), "s"(p.halo_before));
+    asm volatile("" ::"s"(p.tap_dh[0]), "s"(p.tap_dh[1]), "s"(p.tap_dh[2]), "s"(p.tap_dh[3]), "s"(p.tap_dh[4]), "s"(p.tap_dw[0]),
+                 "s"(p.tap_dw[1]), "s"(p.tap_dw[2]), "s"(p.tap_dw[3]), "s"(p.tap_dw[4]));
+    asm volatile("" ::"s"(p.bias), "s"(p.ctx), "s"(p.ctx2), "s"(p.y), "s"(p.zin), "s"(p.out0), "s"(p.out1), "s"(p.border));
+    if constexpr (INMODE == IN_POSTERIOR || EPI == EPI_OUT)
+        asm volatile("" ::"s"(p.qm), "s"(p.ql), "s"(p.rm), "s"(p.rl), "s"(p.pm), "s"(p.pl), "s"(p.eps), "s"(p.kl_elem));
+    const int HW = p.HW, W = p.W;
+    const int cin8 = p.cin >> 3;           // one plane of one slot, in 16-byte units
+    const int s16 = 3 * cin8 + 2;          // slot stride in 16-byte units (3 planes + 32 B pad)
+    const int npair = p.nchunk >> 1;       // c_in / 32
+
+    // ================= prologue (1): activation tile loads ============================================================
+    const int nq = p.cin >> 2;                     // 4-channel items per pixel
+    const int nitems = p.nslot * nq;
+    constexpr int SU = (INMODE == IN_PIXMAJOR) ? 16 : 4;
+    f32x4 sv[SU];
+    const int Pbase = P0 - p.halo_before;
+    const int flo = Pbase < 0 ? -Pbase * nq : 0;
+    const long long rem = (long long)(p.P - Pbase) * nq;
+    const int fhi = rem < nitems ? (int)rem : nitems;
+    if (INMODE == IN_PIXMAJOR) {
+        const f32x4* src = (const f32x4*)p.x + (long long)Pbase * nq;
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            const int f = tid + u * NTHREADS;
+            const int fc = f < flo ? flo : (f < fhi ? f : fhi - 1);
+            sv[u] = src[fc];
+            if (f < flo || f >= fhi) sv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+
+    // ================= prologue (2): weight ring ======================================================================
+    // step s = pair * 5 + tap; wave kh owns steps [s0, s1).  One step = NT tiles x 3 planes x 1 KiB, contiguous.
+    const int S = npair * NTP;
+    const int s0 = (kh * S) / KS, s1 = ((kh + 1) * S) / KS;
+    const size_t wstep = (size_t)p.ncot * 3 * 64;                               // f32x4 per step
+    const f32x4* wbase = (const f32x4*)p.wp + (size_t)cot0 * 3 * 64 + lane;    // this wave's tiles, this lane's 16 bytes
+    f32x4 wr[U][NT][3];
+    auto load_step = [&](auto slot_c, int s) {
+        constexpr int I = decltype(slot_c)::value;
+        const int sc = s < s1 ? s : s1 - 1;                                     // clamped: branch-free, redundant at the tail
+        const f32x4* q = wbase + (size_t)sc * wstep;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int pn = 0; pn < 3; ++pn) wr[I][t][pn] = q[(t * 3 + pn) * 64];
+    };
+    static_for<RD>([&](auto i) { load_step(i, s0 + decltype(i)::value); });
+
+    // ================= prologue (3): per-lane geometry ================================================================
+    const int pl = lane & 15, kk = lane >> 4;
+    // x operand address of (pixel tile q, tap t) = xbase[q] + toff(t) when the tap lands inside the image, else the all-zero
+    // slot; toff is wave-uniform.  (Kept as base + validity bits, selected arithmetically per step: a per-tap address
+    // ARRAY indexed by the runtime tap would be placed in scratch memory.)
+    int xbase[PPW];
+    unsigned xvalid[PPW];
+    const int zaddr = p.nslot * s16 + kk;
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) {
+        const int tl = (pw * PPW + q) * 16 + pl;      // pixel index inside the workgroup tile
+        const int Pl = P0 + tl;
+        const bool pvalid = Pl < p.P;
+        const int bimg = Pl / HW, pp = Pl - bimg * HW;
+        const int h = pp / W, w = pp - h * W;
+        unsigned m = 0;
+#pragma unroll
+        for (int t = 0; t < NTP; ++t) {
+            const int dh = p.tap_dh[t], dw = p.tap_dw[t];
+            const bool v = pvalid && (h + dh >= 0) && (h + dh < p.H) && (w + dw >= 0) && (w + dw < W);
+            m |= (v ? 1u : 0u) << t;
+        }
+        xvalid[q] = m;
+        xbase[q] = (tl + p.halo_before) * s16 + kk;
+    }
+
+    // ================= prologue (4): tile -> LDS, split into three bf16 planes ========================================
+    {
+        f32x4* zslot = smem4 + (size_t)p.nslot * s16;
+        for (int i = tid; i < s16; i += NTHREADS) zslot[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (INMODE == IN_PIXMAJOR) {
+            const float rnq = 1.0f / (float)nq;
+#pragma unroll
+            for (int u = 0; u < SU; ++u) {
+                const int f = tid + u * NTHREADS;
+                if (f < nitems) {
+                    const int sl = (int)(((float)f + 0.5f) * rnq);
+                    bf3_store4(smem, sl, f - sl * nq, sv[u], s16, cin8);
+                }
+            }
+            const f32x4* src = (const f32x4*)p.x + (long long)Pbase * nq;
+            for (int f = tid + SU * NTHREADS; f < nitems; f += NTHREADS) {
+                const int sl = (int)(((float)f + 0.5f) * rnq);
+                bf3_store4(smem, sl, f - sl * nq, (f >= flo && f < fhi) ? src[f] : f32x4{0.f, 0.f, 0.f, 0.f}, s16, cin8);
+            }
+        } else {
+            for (int base = tid; base < nitems; base += SU * NTHREADS) {
+                int dq[SU], dsl[SU];
+#pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    const int idx = base + u * NTHREADS;
+                    dsl[u] = -1; dq[u] = 0;
+                    sv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (idx < nitems) {
+                        const int q = idx / p.nslot, sl = idx - q * p.nslot;   // slot fastest: coalesced along pixels
+                        const int Pg = Pbase + sl;
+                        dsl[u] = sl; dq[u] = q;
+                        if (Pg >= 0 && Pg < p.P) {
+                            const int b = Pg / HW, ppx = Pg - b * HW;
+                            const size_t gb = ((size_t)b * p.cin + 4 * q) * HW + ppx;
+                            if (INMODE == IN_NCHW) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) sv[u][r] = p.x[gb + (size_t)r * HW];
+                            } else {   // z0 = (qm+rm) + exp(ql+rl) * eps   (tf_train.py:57,63; distributions.py:21)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const size_t i = gb + (size_t)r * HW;
+                                    sv[u][r] = (p.qm[i] + p.rm[i]) + __expf(0.5f * (2.f * (p.ql[i] + p.rl[i]))) * p.eps[i];
+                                }
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < SU; ++u)
+                    if (dsl[u] >= 0) bf3_store4(smem, dsl[u], dq[u], sv[u], s16, cin8);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ================= K loop =========================================================================================
+    f32x4 acc[PPW][NT];
+#pragma unroll
+    for (int q = 0; q < PPW; ++q)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // x operand address of (pixel tile q, step s): tap and pair are wave-uniform
+    auto xaddr = [&](auto q_c, int s) -> int {
+        constexpr int q = decltype(q_c)::value;
+        const int sc = s < s1 ? s : s1 - 1;
+        const int pair = sc / NTP, tap = sc - pair * NTP;
+        int dh = p.tap_dh[0], dw = p.tap_dw[0];                      // scalar selects on kernel arguments
+        dh = tap == 1 ? p.tap_dh[1] : dh; dw = tap == 1 ? p.tap_dw[1] : dw;
+        dh = tap == 2 ? p.tap_dh[2] : dh; dw = tap == 2 ? p.tap_dw[2] : dw;
+        dh = tap == 3 ? p.tap_dh[3] : dh; dw = tap == 3 ? p.tap_dw[3] : dw;
+        dh = tap == 4 ? p.tap_dh[4] : dh; dw = tap == 4 ? p.tap_dw[4] : dw;
+        const int toff = (dh * W + dw) * s16;
+        const int mask = -(int)((xvalid[q] >> tap) & 1u);              // all ones when the tap is inside the image
+        return zaddr + pair * 4 + (mask & (xbase[q] + toff - zaddr));  // branch-free: a ?: here becomes control flow
+    };
+    f32x4 xn[3];      // the NEXT (step, pixel tile)'s three planes, in flight while the current one is multiplied
+    {
+        const int a = xaddr(std::integral_constant<int, 0>{}, s0);
+        xn[0] = smem4[a]; xn[1] = smem4[a + cin8]; xn[2] = smem4[a + 2 * cin8];
+    }
+    auto step_body = [&](auto slot_c, int s) {
+        constexpr int I = decltype(slot_c)::value;
+        load_step(std::integral_constant<int, (I + RD) % U>{}, s + RD);       // refill the slot consumed RD steps from now
+        static_for<PPW>([&](auto q_c) {
+            constexpr int q = decltype(q_c)::value;
+            const bf16x8 xh = __builtin_bit_cast(bf16x8, xn[0]);
+            const bf16x8 xm = __builtin_bit_cast(bf16x8, xn[1]);
+            const bf16x8 xl = __builtin_bit_cast(bf16x8, xn[2]);
+            {   // prefetch the next pixel tile of this step, or tile 0 of the next step
+                const int a = (q + 1 < PPW) ? xaddr(std::integral_constant<int, (q + 1) % PPW>{}, s)
+                                            : xaddr(std::integral_constant<int, 0>{}, s + 1);
+                xn[0] = smem4[a]; xn[1] = smem4[a + cin8]; xn[2] = smem4[a + 2 * cin8];
+            }
+            // six products per co tile, interleaved over the tiles so that consecutive MFMAs hit different accumulators;
+            // the small terms first
+#define IAF_BF3_PROD(WP, XV)                                                                                      \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                                 \
+        acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wr[I][t][WP]), XV, acc[q][t], 0, 0, 0);
+            IAF_BF3_PROD(2, xh)   // w_l x_h
+            IAF_BF3_PROD(0, xl)   // w_h x_l
+            IAF_BF3_PROD(1, xm)   // w_m x_m
+            IAF_BF3_PROD(1, xh)   // w_m x_h
+            IAF_BF3_PROD(0, xm)   // w_h x_m
+            IAF_BF3_PROD(0, xh)   // w_h x_h
+#undef IAF_BF3_PROD
+        });
+    };
+    {
+        int s = s0;
+        for (; s + U <= s1; s += U)
+            static_for<U>([&](auto i) { step_body(i, s + decltype(i)::value); });
+        const int r = s1 - s;                       // 0 .. U-1 steps left; chunk at s sits in ring slot 0
+        static_for<U>([&](auto r_c) {
+            constexpr int R = decltype(r_c)::value;
+            if (R > 0 && r == R) static_for<R>([&](auto i) { step_body(i, s + decltype(i)::value); });
+        });
+    }
+
+    // ================= split-K exchange through LDS + epilogue ========================================================
+    // item = (pixel tile q of this wave group, epilogue unit u); the KS waves of a group share the items round-robin
+    constexpr bool ONE_TILE_UNITS = (EPI != EPI_OUT);
+    constexpr int TPU = ONE_TILE_UNITS ? 1 : 2;
+    constexpr int NUNIT = NT / TPU;
+    constexpr int NITEM = PPW * NUNIT;
+    constexpr int NMY = (NITEM + KS - 1) / KS;
+    EpiGeom g[NMY];
+    EpiOps ops[NMY];
+#pragma unroll
+    for (int i = 0; i < NMY; ++i) {
+        const int item = kh + i * KS;
+        const int q = item / NUNIT, u = item - q * NUNIT;
+        g[i] = epi_geom(p, P0 + (pw * PPW + q) * 16 + pl, kk, item < NITEM);
+        epi_load<EPI>(p, g[i], cot0 + u * TPU, ops[i]);
+    }
+    f32x4 val[NMY][TPU];
+    if constexpr (KS > 1) {
+        __syncthreads();                                       // every wave is done reading the activation tile
+        float* red = (float*)smem4;                            // [pw][kh][q][t][4][64 lanes]
+        float* wbuf = red + ((size_t)((pw * KS + kh) * PPW * NT) * 4) * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < PPW; ++q)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wbuf[((q * NT + t) * 4 + j) * 64] = acc[q][t][j];
+        __syncthreads();
+        const float* rbuf = red + ((size_t)(pw * KS * PPW * NT) * 4) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < NMY; ++i) {
+            const int item = kh + i * KS;
+            const int q = item / NUNIT, u = item - q * NUNIT;
+#pragma unroll
+            for (int e = 0; e < TPU; ++e) {
+                f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (item < NITEM) {
+                    const int t = u * TPU + e;
+                    for (int k = 0; k < KS; ++k)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) sum[j] += rbuf[((size_t)((k * PPW + q) * NT + t) * 4 + j) * 64];
+                }
+                val[i][e] = sum;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NMY; ++i)          // KS == 1: item i = (q, u) with static indices
+#pragma unroll
+            for (int e = 0; e < TPU; ++e) val[i][e] = acc[i / NUNIT][(i % NUNIT) * TPU + e];
+    }
+#pragma unroll
+    for (int i = 0; i < NMY; ++i) {
+        const int item = kh + i * KS;
+        const int u = item % NUNIT;
+        epi_apply<EPI, NTP>(p, g[i], cot0 + u * TPU, val[i][0], val[i][TPU - 1], ops[i]);
+    }
+}

@@ -68,6 +68,9 @@ struct GemmLayer {
     float* bias = nullptr;
     float* border = nullptr;   // Theano variant only
     float* wpt = nullptr;      // transposed pack for dgrad (allocated by iaf_stack_set_training)
+    void* wp3 = nullptr;       // bf16x3 pack for iaf_conv_bf3_kernel (c_in % 32 == 0 only)
+    int b_nt = 0, b_ppw = 0, b_pxt = 0, b_ks = 0;   // bf16x3 launch shape (auto or iaf_stack_set_tuning_bf3)
+    bool b_user_tuned = false;
     int* lim = nullptr;
     // launch shape: fixed by iaf_stack_set_tuning (user_tuned) or chosen per problem size by auto_shape()
     int nt, pxt, wco, ks;
@@ -85,6 +88,7 @@ struct iaf_stack {
     bool defer_wn = false;    // backward leaves the weight-norm pass to iaf_wn_bwd_batch_run (one launch per model)
     float* pend_ws = nullptr; int pend_B = 0, pend_H = 0, pend_W = 0;   // ... which finds dWeff / dbp through these
     bool generic = false;     // channel counts outside the MFMA path: direct-conv fallback kernels
+    int precision = IAF_PRECISION_BF16X3;   // forward convs: bf16x3 split products on the bf16 MFMA, or the exact fp32 MFMA
     bool prepared;
     size_t weight_bytes;  // raw V/g/b bytes of the stack (for the algorithmic byte count)
     // optional per-launch event timing of one layer
@@ -110,6 +114,26 @@ IAF_DECL_SHAPE(2, 1, 2)
 IAF_DECL_SHAPE(2, 1, 4)
 IAF_DECL_SHAPE(1, 1, 4)
 IAF_DECL_SHAPE(1, 2, 2)
+
+// bf16x3 kernels (iaf_conv_bf3.hpp), one translation unit per (ppw, pxt, ks)
+#define IAF_DECL_BF3(P, X, K) extern "C" conv_fn_t iaf_pick_bf3_##P##_##X##_##K(int nt, int inmode, int epi);
+IAF_DECL_BF3(4, 1, 4)
+IAF_DECL_BF3(2, 1, 4)
+IAF_DECL_BF3(1, 1, 4)
+IAF_DECL_BF3(1, 4, 1)
+static const int k_bf3_shapes[][3] = {{4, 1, 4}, {2, 1, 4}, {1, 1, 4}, {1, 4, 1}};   // keep in sync with iaf_amd/build.py
+static conv_fn_t pick_bf3(int nt, int ppw, int pxt, int ks, int inmode, int epi) {
+    if (ppw == 4 && pxt == 1 && ks == 4) return iaf_pick_bf3_4_1_4(nt, inmode, epi);
+    if (ppw == 2 && pxt == 1 && ks == 4) return iaf_pick_bf3_2_1_4(nt, inmode, epi);
+    if (ppw == 1 && pxt == 1 && ks == 4) return iaf_pick_bf3_1_1_4(nt, inmode, epi);
+    if (ppw == 1 && pxt == 4 && ks == 1) return iaf_pick_bf3_1_4_1(nt, inmode, epi);
+    return nullptr;
+}
+static size_t bf3_lds_bytes(int cin, int W, int nt, int ppw, int pxt, int ks) {
+    const size_t tile = (size_t)(16 * ppw * pxt + W + 1 + 1) * (3 * (cin / 8) + 2) * 16;
+    const size_t red = ks > 1 ? (size_t)pxt * ks * ppw * nt * 1024 : 0;     // split-K exchange aliases the (dead) tile
+    return tile > red ? tile : red;
+}
 
 // the launch shapes that are compiled: (pxt, wco, ks)
 static conv_fn_t pick_kernel(int nt, int pxt, int wco, int ks, int inmode, int epi) {
@@ -213,7 +237,9 @@ extern "C" int iaf_stack_create(iaf_stack_t** out, int n_z, int n_h, int depth_a
         if ((rc = (int)hipMalloc(&L.wp, wfloats * sizeof(float))) != 0 ||
             (rc = (int)hipMalloc(&L.bias, (size_t)L.cout * sizeof(float))) != 0 ||
             (variant == IAF_VARIANT_THEANO && (rc = (int)hipMalloc(&L.border, (size_t)4 * L.cout * sizeof(float))) != 0) ||
-            (rc = (int)hipMalloc(&L.lim, (size_t)L.ncot * sizeof(int))) != 0) {
+            (rc = (int)hipMalloc(&L.lim, (size_t)L.ncot * sizeof(int))) != 0 ||
+            (!generic && cin % 32 == 0 &&
+             (rc = (int)hipMalloc(&L.wp3, (size_t)(cin / 32) * NTAPS * L.ncot * 3 * 1024)) != 0)) {
             iaf_stack_destroy(s);
             return rc;
         }
@@ -290,6 +316,7 @@ extern "C" int iaf_stack_destroy(iaf_stack_t* s) {
         if (s->L[l].bias) (void)hipFree(s->L[l].bias);
         if (s->L[l].border) (void)hipFree(s->L[l].border);
         if (s->L[l].wpt) (void)hipFree(s->L[l].wpt);
+        if (s->L[l].wp3) (void)hipFree(s->L[l].wp3);
         if (s->L[l].lim) (void)hipFree(s->L[l].lim);
     }
     delete s;
@@ -308,6 +335,39 @@ extern "C" int iaf_stack_set_tuning(iaf_stack_t* s, int layer, int nt, int pxt, 
     if (L.nchunk < ks) return IAF_ERR_UNSUPPORTED;
     L.nt = nt; L.pxt = pxt; L.wco = wco; L.ks = ks;
     L.user_tuned = true;
+    return IAF_OK;
+}
+
+static bool auto_shape_bf3(GemmLayer& L, bool is_out, long long P, int W);
+
+extern "C" int iaf_stack_set_precision(iaf_stack_t* s, int precision) {
+    if (!s) return IAF_ERR_NULL;
+    if (precision != IAF_PRECISION_F32 && precision != IAF_PRECISION_BF16X3) return IAF_ERR_SHAPE;
+    s->precision = precision;
+    return IAF_OK;
+}
+
+extern "C" int iaf_stack_get_precision(const iaf_stack_t* s, int layer) {
+    if (!s || layer < 0 || layer >= s->nlayers) return IAF_ERR_NULL;
+    const GemmLayer& L = s->L[layer];
+    const bool is_out = (layer == s->depth_ar);
+    // what a forward launch of this layer will run (the output pair of a depth_ar = 0 stack reads z directly: fp32 kernel)
+    if (s->precision == IAF_PRECISION_BF16X3 && L.wp3 && !(is_out && s->depth_ar == 0)) {
+        GemmLayer t = L;
+        if (t.b_user_tuned || auto_shape_bf3(t, is_out, 16 * 256, 16)) return IAF_PRECISION_BF16X3;
+    }
+    return IAF_PRECISION_F32;
+}
+
+extern "C" int iaf_stack_set_tuning_bf3(iaf_stack_t* s, int layer, int nt, int ppw, int pxt, int ks) {
+    if (!s) return IAF_ERR_NULL;
+    if (layer < 0 || layer >= s->nlayers) return IAF_ERR_SHAPE;
+    GemmLayer& L = s->L[layer];
+    if (nt == 0) { L.b_user_tuned = false; return IAF_OK; }      // back to the automatic choice
+    const bool is_out = (layer == s->depth_ar);
+    if (!L.wp3 || L.ncot % nt != 0 || (is_out && (nt & 1))) return IAF_ERR_UNSUPPORTED;
+    if (!pick_bf3(nt, ppw, pxt, ks, IN_PIXMAJOR, is_out ? EPI_OUT : EPI_HIDDEN)) return IAF_ERR_UNSUPPORTED;
+    L.b_nt = nt; L.b_ppw = ppw; L.b_pxt = pxt; L.b_ks = ks; L.b_user_tuned = true;
     return IAF_OK;
 }
 
@@ -345,7 +405,7 @@ extern "C" int iaf_stack_prepare(iaf_stack_t* s, const float* const* V, const fl
         PrepLayer& P = a.L[l];
         P.V[0] = V[l]; P.g[0] = g[l]; P.b[0] = b[l];
         if (L.npair == 2) { P.V[1] = V[l + 1]; P.g[1] = g[l + 1]; P.b[1] = b[l + 1]; }
-        P.wp = L.wp; P.bias = L.bias; P.border = L.border; P.variant = s->variant; P.wpt = L.wpt;
+        P.wp = L.wp; P.bias = L.bias; P.border = L.border; P.variant = s->variant; P.wpt = L.wpt; P.wp3 = L.wp3;
         P.cin = L.cin; P.cout_each = L.cout / L.npair; P.ncot = L.ncot; P.nchunk = L.nchunk;
         P.zerodiag = L.zerodiag; P.npair = L.npair; P.tile_begin = tiles;
         tiles += L.ncot;
@@ -407,7 +467,7 @@ extern "C" int iaf_prep_batch_create(iaf_prep_batch_t** out, iaf_stack_t* const*
         for (int l = 0; l < stacks[i]->nlayers; ++l, ++li) {
             const GemmLayer& L = stacks[i]->L[l];
             PrepLayer& P = b->h_layers[li];
-            P.wp = L.wp; P.bias = L.bias; P.border = L.border; P.variant = stacks[i]->variant; P.wpt = L.wpt;
+            P.wp = L.wp; P.bias = L.bias; P.border = L.border; P.variant = stacks[i]->variant; P.wpt = L.wpt; P.wp3 = L.wp3;
             P.cin = L.cin; P.cout_each = L.cout / L.npair; P.ncot = L.ncot; P.nchunk = L.nchunk;
             P.zerodiag = L.zerodiag; P.npair = L.npair; P.tile_begin = tile;
             for (int t = 0; t < L.ncot; ++t) t2l[tile++] = li;
@@ -529,18 +589,60 @@ static int raise_lds_cap(const void* fn, size_t lds) {
     return 0;
 }
 
+// bf16x3 launch shape.  Per CU the weight stream (every wave fetches its own fragments: 1 KiB per wave-load through an
+// address unit that moves ~64 B/clk) and the MFMA pipe (6 MFMAs of ~17 cycles per tile pair per step) run concurrently;
+// a workgroup costs max(of the two) + a fixed prologue/epilogue, plus the split-K exchange.  Ties: fewer rounds first.
+static bool auto_shape_bf3(GemmLayer& L, bool is_out, long long P, int W) {
+    double best = 1e30;
+    int bi = -1, bnt = 0;
+    const int S = (L.cin / 32) * NTAPS;
+    for (int si = 0; si < 4; ++si) {
+        const int ppw = k_bf3_shapes[si][0], pxt = k_bf3_shapes[si][1], ks = k_bf3_shapes[si][2];
+        static const int nts[3] = {5, 4, 2};
+        for (int ni = 0; ni < 3; ++ni) {
+            const int nt = nts[ni];
+            if (L.ncot % nt != 0 || (is_out && (nt & 1))) continue;
+            if (!pick_bf3(nt, ppw, pxt, ks, IN_PIXMAJOR, is_out ? EPI_OUT : EPI_HIDDEN)) continue;
+            if (bf3_lds_bytes(L.cin, W, nt, ppw, pxt, ks) > 160 * 1024) continue;
+            const double wgs = (double)((P + 16 * ppw * pxt - 1) / (16 * ppw * pxt)) * (L.ncot / nt);
+            const double rounds = ceil(wgs / 256.0);
+            const double steps = ceil((double)S / ks);
+            const double mfma = steps * ppw * nt * 6 * 17.0 * ceil(pxt * ks / 4.0);
+            const double addr = steps * nt * 3 * 16.0 * pxt * ks;
+            const double T = rounds * ((mfma > addr ? mfma : addr) + 7000.0) + (ks > 1 ? 1500.0 : 0.0) + 1e-3 * si;
+            if (T < best) { best = T; bi = si; bnt = nt; }
+        }
+    }
+    if (bi < 0) return false;
+    L.b_nt = bnt; L.b_ppw = k_bf3_shapes[bi][0]; L.b_pxt = k_bf3_shapes[bi][1]; L.b_ks = k_bf3_shapes[bi][2];
+    return true;
+}
+
 // launches the conv kernel for GEMM descriptor L (forward layer, or a transposed descriptor for dgrad)
 static int launch_gemm(const iaf_stack_t* s, GemmLayer& L, int epi, bool negate_taps, int prof_id, ConvP& p, int inmode,
                        hipStream_t st) {
-    if (!L.user_tuned) auto_shape(L, epi == EPI_OUT, p.P, p.W);
-    const int tm = 16 * L.pxt;
     conv_fn_t fn = nullptr;
+    bool bf3 = false;
+    // forward convs of the stack go to the bf16 matrix cores (bf16x3 split products, fp32-grade) when the layer has a
+    // bf16x3 pack and a compiled shape covers it; everything else runs the exact-fp32 MFMA kernel
+    if (s->precision == IAF_PRECISION_BF16X3 && L.wp3 && !negate_taps && (epi == EPI_HIDDEN || epi == EPI_OUT) &&
+        (epi == EPI_HIDDEN || inmode == IN_PIXMAJOR)) {
+        if (L.b_user_tuned || auto_shape_bf3(L, epi == EPI_OUT, p.P, p.W)) {
+            fn = pick_bf3(L.b_nt, L.b_ppw, L.b_pxt, L.b_ks, inmode, epi);
+            if (fn && bf3_lds_bytes(L.cin, p.W, L.b_nt, L.b_ppw, L.b_pxt, L.b_ks) > 160 * 1024) fn = nullptr;
+            bf3 = fn != nullptr;
+        }
+    }
+    if (!bf3 && !L.user_tuned) auto_shape(L, epi == EPI_OUT, p.P, p.W);
+    const int tm = bf3 ? 16 * L.b_ppw * L.b_pxt : 16 * L.pxt;
+    const int yg = bf3 ? L.ncot / L.b_nt : L.ncot / (L.nt * L.wco);
+    const int nthreads = bf3 ? 64 * L.b_pxt * L.b_ks : 64 * L.pxt * L.wco * L.ks;
     // a grid of at most one workgroup per CU has nothing to overlap a prologue with: use the double-depth weight ring
-    if (epi == EPI_HIDDEN && inmode == IN_PIXMAJOR && ((p.P + tm - 1) / tm) * (L.ncot / (L.nt * L.wco)) <= 256)
+    if (!bf3 && epi == EPI_HIDDEN && inmode == IN_PIXMAJOR && ((p.P + tm - 1) / tm) * (L.ncot / (L.nt * L.wco)) <= 256)
         fn = pick_kernel(L.nt, L.pxt, L.wco, L.ks, inmode, EPI_HIDDEN_DEEP);
     if (!fn) fn = pick_kernel(L.nt, L.pxt, L.wco, L.ks, inmode, epi);
     if (!fn) return IAF_ERR_UNSUPPORTED;
-    p.wp = L.wp; p.bias = L.bias; p.lim = L.lim;
+    p.wp = bf3 ? (const float*)L.wp3 : L.wp; p.bias = L.bias; p.lim = L.lim;
     {   // tap geometry of the two statements of the operator (see ConvP); the data gradient runs the mirrored taps
         static const int tf_dh[NTAPS] = {0, 0, 1, 1, 1}, tf_dw[NTAPS] = {0, 1, -1, 0, 1};
         const int sgn = ((s->variant == IAF_VARIANT_THEANO) != negate_taps) ? -1 : 1;
@@ -552,16 +654,16 @@ static int launch_gemm(const iaf_stack_t* s, GemmLayer& L, int epi, bool negate_
     p.cp = L.cin + 8;
     p.nslot = tm + p.W + 1;
     p.dbg = (prof_id >= 0 && s->dbg_layer == prof_id) ? s->dbg : nullptr;
-    const size_t lds = conv_lds_bytes(L, p.W);
+    const size_t lds = bf3 ? bf3_lds_bytes(L.cin, p.W, L.b_nt, L.b_ppw, L.b_pxt, L.b_ks) : conv_lds_bytes(L, p.W);
     if (lds > 160 * 1024) return IAF_ERR_UNSUPPORTED;
     { int rc = raise_lds_cap((const void*)fn, lds); if (rc) return rc; }
-    dim3 grid((p.P + tm - 1) / tm, L.ncot / (L.nt * L.wco));
+    dim3 grid((p.P + tm - 1) / tm, yg);
     const bool prof = (prof_id >= 0 && s->prof_layer == prof_id && s->prof_n < s->prof_cap);
     iaf_stack* ms = const_cast<iaf_stack*>(s);
     if (prof) HIP_TRY(hipEventRecord(ms->prof_start[ms->prof_n], st));
     p.gx = (int)grid.x;
     p.lds_bytes = (int)lds;
-    hipLaunchKernelGGL(fn, grid, dim3(64 * L.pxt * L.wco * L.ks), lds, st, p);
+    hipLaunchKernelGGL(fn, grid, dim3(nthreads), lds, st, p);
     if (prof) { HIP_TRY(hipEventRecord(ms->prof_stop[ms->prof_n], st)); ms->prof_n++; }
     return (int)hipGetLastError();
 }

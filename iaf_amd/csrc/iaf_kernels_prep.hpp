@@ -31,6 +31,7 @@ struct PrepLayer {
     float* bias;     // packed bias [ncot*16]
     float* border;   // Theano variant: [4][ncot*16] normalised weights of the border-indicator channel (taps 1..4)
     float* wpt;      // training: TRANSPOSED pack [chunk over packed c_out][tap][c_in tile][64][4] for dX = W^T dY (or NULL)
+    void* wp3;       // bf16x3 pack (iaf_conv_bf3.hpp): [c_in pair of 32][tap][cot][plane h/m/l][lane 64][8 bf16] (or NULL)
     int cin, cout_each, ncot, nchunk, zerodiag, npair, tile_begin, variant;
 };
 struct PrepArgs {
@@ -41,6 +42,18 @@ struct PrepArgs {
 // filter position (kh,kw) of live tap t: the 5 MADE-live taps (centre, right, then the row below), or all 9 row-major
 template <int NTP> __device__ __forceinline__ int tap_kh(int t) { return NTP == 9 ? t / 3 : ((t == 0 || t == 1) ? 1 : 2); }
 template <int NTP> __device__ __forceinline__ int tap_kw(int t) { return NTP == 9 ? t % 3 : ((t == 0) ? 1 : (t == 1 ? 2 : t - 2)); }
+
+// one weight -> its three bf16 parts (w = h + m + l up to 2^-27|w|, round-to-nearest-even each), written to the three
+// planes of the bf16x3 pack: lane (kk = (ci%32)/8, oo) of fragment (pair = ci/32, tap, cot), element ci%8
+__device__ __forceinline__ void prep_store_bf3(void* wp3, int ncot, int ntp, int gt, int t, int ci, int oo, float w) {
+    const __bf16 hb = (__bf16)w;
+    const float r1 = w - (float)hb;
+    const __bf16 mb = (__bf16)r1;
+    const __bf16 lb = (__bf16)(r1 - (float)mb);
+    const int pair = ci >> 5, kk = (ci >> 3) & 3, e = ci & 7;
+    __bf16* q = (__bf16*)wp3 + ((((size_t)(pair * ntp + t) * ncot + gt) * 3) * 64 + kk * 16 + oo) * 8 + e;
+    q[0] = hb; q[512] = mb; q[1024] = lb;
+}
 
 template <int NCH, int NTP = NTAPS>
 __device__ __forceinline__ void prep_tile(const PrepLayer& L, int gt, float (*red)[17], float* s_scale) {
@@ -94,6 +107,12 @@ __device__ __forceinline__ void prep_tile(const PrepLayer& L, int gt, float (*re
 #pragma unroll
             for (int t = 0; t < NTP; ++t)
                 L.wpt[((((size_t)gt * NTP + t) * NCH + it) * 64 + (oo >> 2) * 16 + cs) * 4 + (oo & 3)] = v[t][it] * scale;
+    }
+    if (NTP == NTAPS && L.wp3) {
+#pragma unroll
+        for (int it = 0; it < NCH; ++it)
+#pragma unroll
+            for (int t = 0; t < NTP; ++t) prep_store_bf3(L.wp3, L.ncot, NTP, gt, t, cs + 16 * it, oo, v[t][it] * scale);
     }
 }
 
@@ -162,6 +181,12 @@ __device__ __forceinline__ void prep_tile_theano(const PrepLayer& L, int gt, flo
 #pragma unroll
         for (int t = 0; t < NTAPS; ++t)
             L.wp[((((size_t)it * NTAPS + t) * L.ncot + gt) * 64 + kk * 16 + oo) * 4 + jj] = v[t][it] * scale;
+    if (L.wp3) {
+#pragma unroll
+        for (int it = 0; it < NCH; ++it)
+#pragma unroll
+            for (int t = 0; t < NTAPS; ++t) prep_store_bf3(L.wp3, L.ncot, NTAPS, gt, t, cs + 16 * it, oo, v[t][it] * scale);
+    }
 }
 
 #define PREP_MAXI 16   // n_in <= 256

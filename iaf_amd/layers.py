@@ -8,6 +8,7 @@ with V in HWIO [3,3,n_in,n_out] fp32 (layers.py:35,53-55).
 """
 import contextlib
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -131,6 +132,8 @@ class ARStack(object):
         self.n_h = int(n_h[0]) if n_h else int(n_z)
         self._h = ctypes.c_void_p()
         _capi.check(_capi.lib().iaf_stack_create(ctypes.byref(self._h), self.n_z, self.n_h, self.depth_ar, variant))
+        if os.environ.get("IAF_PRECISION"):          # process-wide override of the default (bf16x3): "f32" | "bf16x3"
+            self.set_precision(os.environ["IAF_PRECISION"])
         self._ws = None
         self._prep_key = None
         self._keepalive = None
@@ -206,6 +209,22 @@ class ARStack(object):
 
     def set_tuning(self, layer, nt, pxt, wco, ks):
         _capi.check(_capi.lib().iaf_stack_set_tuning(self._h, layer, nt, pxt, wco, ks))
+
+    def set_precision(self, precision):
+        """"bf16x3" (default): forward masked convs on the bf16 matrix cores as six split products, fp32-grade;
+        "f32": the exact-fp32 MFMA (bit-equal to an fmaf chain).  See include/iaf_hip.h."""
+        code = {"f32": _capi.IAF_PRECISION_F32, "bf16x3": _capi.IAF_PRECISION_BF16X3}.get(precision, precision)
+        _capi.check(_capi.lib().iaf_stack_set_precision(self._h, int(code)))
+
+    def layer_precision(self, layer):
+        """what GEMM layer `layer` will run: "bf16x3" or "f32" (layers the bf16x3 kernels do not cover stay fp32)"""
+        code = _capi.lib().iaf_stack_get_precision(self._h, int(layer))
+        if code < 0:
+            _capi.check(code)
+        return "bf16x3" if code == _capi.IAF_PRECISION_BF16X3 else "f32"
+
+    def set_tuning_bf3(self, layer, nt, ppw, pxt, ks):
+        _capi.check(_capi.lib().iaf_stack_set_tuning_bf3(self._h, layer, nt, ppw, pxt, ks))
 
     def step_work(self, B, H, W):
         a, b, c = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()

@@ -199,6 +199,22 @@ int iaf_lowerbound_stream_finalize(const float* run_max, const float* run_sum, f
 /* Override the launch shape of GEMM layer `layer` (0..depth_ar): co-tiles per wave, pixel tiles
  * per workgroup, waves along co, split-K factor.  Returns IAF_ERR_UNSUPPORTED if no such kernel. */
 int iaf_stack_set_tuning(iaf_stack_t* s, int layer, int nt, int pxt, int wco, int ks);
+
+/* Arithmetic of the forward masked convs (the reference runs cuDNN fp32 convs, tf_utils/layers.py:64):
+ *   IAF_PRECISION_BF16X3 (default)  every fp32 operand split into three bf16 parts, the six leading part-products
+ *       accumulated in fp32 on the bf16 matrix cores (v_mfma_f32_16x16x32_bf16): fp32-grade results (error vs an fp64
+ *       evaluation not larger than the fp32 chain's) at 2.7x the matrix-core rate of
+ *   IAF_PRECISION_F32               the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32), bit-equal to an fmaf chain.
+ * Layers the bf16x3 kernels do not cover (c_in not a multiple of 32, co-tile counts without a compiled shape, the data
+ * gradients, the plain 9-tap convs) run the fp32 kernel in either mode; iaf_stack_get_precision reports what GEMM layer
+ * `layer` will run.  Outputs of the two modes differ by fp32 round-off only; each is deterministic. */
+#define IAF_PRECISION_F32 0
+#define IAF_PRECISION_BF16X3 1
+int iaf_stack_set_precision(iaf_stack_t* s, int precision);
+int iaf_stack_get_precision(const iaf_stack_t* s, int layer);
+/* launch shape of the bf16x3 kernel for GEMM layer `layer`: co tiles per wave, pixel tiles per wave, waves along
+ * pixels, K-slice waves (nt = 0 restores the automatic choice) */
+int iaf_stack_set_tuning_bf3(iaf_stack_t* s, int layer, int nt, int ppw, int pxt, int ks);
 /* Per-kernel timing with HIP events on the launch stream: every launch of GEMM layer `layer` is
  * bracketed by an engine-owned event pair (up to max_samples; layer < 0 disables).  Not usable
  * during stream capture.  iaf_stack_profile_read synchronises the recorded events, writes the
