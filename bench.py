@@ -34,6 +34,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA; a bf16x3 fp32-grade product costs 6 bf16 products
+PEAK_BF16X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 PEAK_HBM_GBS = 8000.0
 
 
@@ -60,6 +62,12 @@ def parse():
                     help="extra mode (not the headline metric): data-parallel TRAINING step of the IAF posterior stack -- "
                          "posterior block forward + backward for every layer, one RCCL all-reduce of the flat gradient "
                          "buffer, fused Adamax + EMA")
+    ap.add_argument("--precision", type=str, default="bf16x3", choices=["bf16x3", "f32"],
+                    help="arithmetic of the forward masked convs: bf16x3 = fp32 operands split into three bf16 parts, six "
+                         "part-products accumulated in fp32 on the bf16 matrix cores (fp32-grade; the engine's default); "
+                         "f32 = the exact-fp32 MFMA everywhere")
+    ap.add_argument("--no-autotune", action="store_true",
+                    help="skip the per-layer kernel/launch-shape search (iaf_stack_autotune) before the timed region")
     ap.add_argument("--ar-buckets", type=int, default=4,
                     help="--train: number of gradient all-reduce buckets overlapped with the backward pass")
     ap.add_argument("--iw-eval", action="store_true",
@@ -700,6 +708,7 @@ def main():
             dp = {k: dev(v) for k, v in params.items()}
             zd, cd = dev(z), dev(ctx)
             out = (torch.empty_like(zd), torch.empty_like(zd))
+            st.set_precision(args.precision)
             st.prepare(dp)
             layers.append(dict(stack=st, params=dp, z=zd, ctx=cd, out=out, H=H))
     if args.tune:
@@ -711,6 +720,13 @@ def main():
 
     prep = iaf_amd.PrepBatch([L["stack"] for L in layers])
     plist = [L["params"] for L in layers]
+    tuned = {}
+    if not args.no_autotune and not args.tune and args.depth_ar > 0:
+        # kernel family + launch shape per layer, measured on this box for this size (the cuDNN algorithm search of the
+        # reference's convs); outside the timed region, before the graph is captured
+        for L in layers:
+            picks = L["stack"].autotune(L["z"], L["ctx"], reps=20)
+            tuned.setdefault("%dx%d" % (L["H"], L["H"]), [c for c, _ in picks])
 
     def step():
         if not args.cached_weights:
@@ -781,7 +797,7 @@ def main():
                 w = st.layer_work(gl, args.batch, H, H)
                 tf_ = w["live_flops"] / (ms * 1e-3) / 1e12
                 ktable.append({"layer": "masked conv %d->%d%s" % (cin, cout, " (mean,logsd pair + affine/log-det epilogue)" if gl == args.depth_ar else ""),
-                               "latent": "%dx%d" % (H, H), "us": 1e3 * ms, "live_gflop": w["live_flops"] / 1e9,
+                               "latent": "%dx%d" % (H, H), "kernel": st.layer_precision(gl, args.batch, H, H), "us": 1e3 * ms, "live_gflop": w["live_flops"] / 1e9,
                                "live_tflops": tf_, "frac": tf_ / PEAK_F32_MFMA_TFLOPS})
                 cin = args.n_h
             if args.depth_ar > 0:
@@ -828,9 +844,15 @@ def main():
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
+    dom_kernel = st0.layer_precision(dom_layer, args.batch, 16, 16)
+    dom_peak = PEAK_BF16X3_TFLOPS if dom_kernel == "bf16x3" else PEAK_F32_MFMA_TFLOPS
     roofline = {
-        "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-        "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+        "bound": "mfma", "achieved": achieved, "peak": dom_peak, "unit": "TFLOP/s",
+        "frac": achieved / dom_peak, "traffic": traffic,
+        "peak_note": "fp32-equivalent FLOPs; peak = dense bf16 MFMA 2500 TF / 6 part-products per product for the bf16x3 "
+                     "kernel, 157.3 TF (exact-fp32 MFMA) for the fp32 kernel" ,
+        "dominant_kernel_family": dom_kernel,
+        "frac_of_f32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS,
         "kernel": "iaf_conv_kernel (masked 3x3 conv %d->%d, B=%d 16x16, GEMM layer %d)" % (args.n_h, args.n_h, args.batch, dom_layer),
         "avg_launch_us": 1e3 * k_avg_ms, "launches_timed": 50 * len(kbatch),
         "timing": "HIP events on the launch stream around 50 back-to-back launches per 16x16 layer (includes the "
@@ -860,7 +882,8 @@ def main():
         "metric": "IAF-step samples/sec (down_iaf2_nl posterior stack, forward + log-det)",
         "value": value, "unit": "samples/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32" if args.precision == "f32" else "f32 (operands split into 3 bf16 parts, 6 part-products on the bf16 MFMA, fp32 accumulate: fp32-grade error)",
+        "data": "synthetic",
         "config": {
             "workload": "cifar10 n_z=%d n_h=%d depths=%s depth_ar=%d down_iaf2_nl bs=%d per GPU (BASELINE configs[1]); "
                         "one step = %d IAF steps: %s" % (args.n_z, args.n_h, depths, args.depth_ar, args.batch, n_iaf,
@@ -872,6 +895,8 @@ def main():
             "launch": "hipGraph replay" if graph is not None else "eager",
             "parallelism": "dp%d (batch-sharded replicas, no forward collective)" % n_gpus,
             "live_gflop_per_iaf_step_16x16": work16["live_flops"] / 1e9,
+            "precision": args.precision,
+            "kernels_chosen": tuned if tuned else "static rule (no autotune)",
         },
         "roofline": roofline,
     }

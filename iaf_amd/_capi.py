@@ -70,8 +70,11 @@ SIGNATURES = {
     "iaf_lowerbound_stream_finalize": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int, ctypes.c_int, _vp]),
     "iaf_stack_set_tuning": (ctypes.c_int, [_vp] + [ctypes.c_int] * 5),
     "iaf_stack_set_precision": (ctypes.c_int, [_vp, ctypes.c_int]),
-    "iaf_stack_get_precision": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "iaf_stack_get_precision": (ctypes.c_int, [_vp] + [ctypes.c_int] * 4),
     "iaf_stack_set_tuning_bf3": (ctypes.c_int, [_vp] + [ctypes.c_int] * 5),
+    "iaf_stack_autotune": (ctypes.c_int, [_vp, _c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_int, _vp, ctypes.c_size_t, ctypes.c_int, _vp, ctypes.POINTER(ctypes.c_int),
+                                          ctypes.POINTER(ctypes.c_float)]),
     "iaf_stack_profile_enable": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
     "iaf_stack_profile_read": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float), ctypes.c_int,
                                               ctypes.POINTER(ctypes.c_int)]),

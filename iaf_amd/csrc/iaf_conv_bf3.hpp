@@ -81,17 +81,20 @@ __global__ __launch_bounds__(64 * PXT * KS) void iaf_conv_bf3_kernel(ConvP p) {
     const int cin8 = p.cin >> 3;           // one plane of one slot, in 16-byte units
     const int s16 = 3 * cin8 + 2;          // slot stride in 16-byte units (3 planes + 32 B pad)
     const int npair = p.nchunk >> 1;       // c_in / 32
+#define IAF_BSTAMP(k) do { if (p.dbg && tid == 0) p.dbg[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+    IAF_BSTAMP(0);
 
     // ================= prologue (1): activation tile loads ============================================================
-    const int nq = p.cin >> 2;                     // 4-channel items per pixel
+    // items per pixel: 4-channel fp32 quads, or (pre-split input) the 16-byte chunks of the pixel's three bf16 planes
+    const int nq = (INMODE == IN_PIXMAJOR3) ? 3 * cin8 : (p.cin >> 2);
     const int nitems = p.nslot * nq;
-    constexpr int SU = (INMODE == IN_PIXMAJOR) ? 16 : 4;
+    constexpr int SU = (INMODE == IN_PIXMAJOR || INMODE == IN_PIXMAJOR3) ? 16 : 4;
     f32x4 sv[SU];
     const int Pbase = P0 - p.halo_before;
     const int flo = Pbase < 0 ? -Pbase * nq : 0;
     const long long rem = (long long)(p.P - Pbase) * nq;
     const int fhi = rem < nitems ? (int)rem : nitems;
-    if (INMODE == IN_PIXMAJOR) {
+    if (INMODE == IN_PIXMAJOR || INMODE == IN_PIXMAJOR3) {
         const f32x4* src = (const f32x4*)p.x + (long long)Pbase * nq;
 #pragma unroll
         for (int u = 0; u < SU; ++u) {
@@ -109,16 +112,20 @@ __global__ __launch_bounds__(64 * PXT * KS) void iaf_conv_bf3_kernel(ConvP p) {
     const size_t wstep = (size_t)p.ncot * 3 * 64;                               // f32x4 per step
     const f32x4* wbase = (const f32x4*)p.wp + (size_t)cot0 * 3 * 64 + lane;    // this wave's tiles, this lane's 16 bytes
     f32x4 wr[U][NT][3];
-    auto load_step = [&](auto slot_c, int s) {
-        constexpr int I = decltype(slot_c)::value;
+    // fragments [lo, hi) of step s -> ring slot I (a step's refill is issued in PPW parts, one per pixel-tile group of
+    // MFMAs, so that the loads sit BETWEEN the MFMAs instead of in a cluster that starves the pipe)
+    auto load_part = [&](auto slot_c, auto lo_c, auto hi_c, int s) {
+        constexpr int I = decltype(slot_c)::value, LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
         const int sc = s < s1 ? s : s1 - 1;                                     // clamped: branch-free, redundant at the tail
         const f32x4* q = wbase + (size_t)sc * wstep;
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int pn = 0; pn < 3; ++pn) wr[I][t][pn] = q[(t * 3 + pn) * 64];
+        for (int f = LO; f < HI; ++f) wr[I][f / 3][f % 3] = q[f * 64];
+    };
+    auto load_step = [&](auto slot_c, int s) {
+        load_part(slot_c, std::integral_constant<int, 0>{}, std::integral_constant<int, NT * 3>{}, s);
     };
     static_for<RD>([&](auto i) { load_step(i, s0 + decltype(i)::value); });
+    IAF_BSTAMP(1);
 
     // ================= prologue (3): per-lane geometry ================================================================
     const int pl = lane & 15, kk = lane >> 4;
@@ -133,8 +140,9 @@ __global__ __launch_bounds__(64 * PXT * KS) void iaf_conv_bf3_kernel(ConvP p) {
         const int tl = (pw * PPW + q) * 16 + pl;      // pixel index inside the workgroup tile
         const int Pl = P0 + tl;
         const bool pvalid = Pl < p.P;
-        const int bimg = Pl / HW, pp = Pl - bimg * HW;
-        const int h = pp / W, w = pp - h * W;
+        int bimg, pp, h, w;
+        fast_divmod(Pl, HW, 1.0f / (float)HW, bimg, pp);
+        fast_divmod(pp, W, 1.0f / (float)W, h, w);
         unsigned m = 0;
 #pragma unroll
         for (int t = 0; t < NTP; ++t) {
@@ -150,7 +158,22 @@ __global__ __launch_bounds__(64 * PXT * KS) void iaf_conv_bf3_kernel(ConvP p) {
     {
         f32x4* zslot = smem4 + (size_t)p.nslot * s16;
         for (int i = tid; i < s16; i += NTHREADS) zslot[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (INMODE == IN_PIXMAJOR) {
+        if (INMODE == IN_PIXMAJOR3) {      // already three bf16 planes per pixel: straight 16-byte copies
+            const float rnq = 1.0f / (float)nq;
+#pragma unroll
+            for (int u = 0; u < SU; ++u) {
+                const int f = tid + u * NTHREADS;
+                if (f < nitems) {
+                    const int sl = (int)(((float)f + 0.5f) * rnq);
+                    smem4[sl * s16 + (f - sl * nq)] = sv[u];
+                }
+            }
+            const f32x4* src = (const f32x4*)p.x + (long long)Pbase * nq;
+            for (int f = tid + SU * NTHREADS; f < nitems; f += NTHREADS) {
+                const int sl = (int)(((float)f + 0.5f) * rnq);
+                smem4[sl * s16 + (f - sl * nq)] = (f >= flo && f < fhi) ? src[f] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        } else if (INMODE == IN_PIXMAJOR) {
             const float rnq = 1.0f / (float)nq;
 #pragma unroll
             for (int u = 0; u < SU; ++u) {
@@ -200,6 +223,7 @@ __global__ __launch_bounds__(64 * PXT * KS) void iaf_conv_bf3_kernel(ConvP p) {
         }
     }
     __syncthreads();
+    IAF_BSTAMP(2);
 
     // ================= K loop =========================================================================================
     f32x4 acc[PPW][NT];
@@ -229,9 +253,14 @@ __global__ __launch_bounds__(64 * PXT * KS) void iaf_conv_bf3_kernel(ConvP p) {
     }
     auto step_body = [&](auto slot_c, int s) {
         constexpr int I = decltype(slot_c)::value;
-        load_step(std::integral_constant<int, (I + RD) % U>{}, s + RD);       // refill the slot consumed RD steps from now
         static_for<PPW>([&](auto q_c) {
             constexpr int q = decltype(q_c)::value;
+            // refill (this group's share) of the slot consumed RD steps from now; the last group of a multi-group step issues
+            // none, so that every fragment has at least one group of MFMAs (~500 cycles) to arrive
+            constexpr int NG = PPW > 1 ? PPW - 1 : 1;
+            constexpr int LO = q < NG ? (q * NT * 3) / NG : NT * 3, HI = q < NG ? ((q + 1) * NT * 3) / NG : NT * 3;
+            load_part(std::integral_constant<int, (I + RD) % U>{}, std::integral_constant<int, LO>{},
+                      std::integral_constant<int, HI>{}, s + RD);
             const bf16x8 xh = __builtin_bit_cast(bf16x8, xn[0]);
             const bf16x8 xm = __builtin_bit_cast(bf16x8, xn[1]);
             const bf16x8 xl = __builtin_bit_cast(bf16x8, xn[2]);
@@ -252,6 +281,8 @@ __global__ __launch_bounds__(64 * PXT * KS) void iaf_conv_bf3_kernel(ConvP p) {
             IAF_BF3_PROD(0, xm)   // w_h x_m
             IAF_BF3_PROD(0, xh)   // w_h x_h
 #undef IAF_BF3_PROD
+            sched_interleave<6 * NT, 3, 0, HI - LO>();
+            __builtin_amdgcn_sched_barrier(0);
         });
     };
     {
@@ -265,6 +296,7 @@ __global__ __launch_bounds__(64 * PXT * KS) void iaf_conv_bf3_kernel(ConvP p) {
         });
     }
 
+    IAF_BSTAMP(3);
     // ================= split-K exchange through LDS + epilogue ========================================================
     // item = (pixel tile q of this wave group, epilogue unit u); the KS waves of a group share the items round-robin
     constexpr bool ONE_TILE_UNITS = (EPI != EPI_OUT);
@@ -284,16 +316,14 @@ __global__ __launch_bounds__(64 * PXT * KS) void iaf_conv_bf3_kernel(ConvP p) {
     f32x4 val[NMY][TPU];
     if constexpr (KS > 1) {
         __syncthreads();                                       // every wave is done reading the activation tile
-        float* red = (float*)smem4;                            // [pw][kh][q][t][4][64 lanes]
-        float* wbuf = red + ((size_t)((pw * KS + kh) * PPW * NT) * 4) * 64 + lane;
+        f32x4* red = smem4;                                    // [pw][kh][q][t][64 lanes] x 16 bytes
+        f32x4* wbuf = red + (size_t)((pw * KS + kh) * PPW * NT) * 64 + lane;
 #pragma unroll
         for (int q = 0; q < PPW; ++q)
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) wbuf[((q * NT + t) * 4 + j) * 64] = acc[q][t][j];
+            for (int t = 0; t < NT; ++t) wbuf[(q * NT + t) * 64] = acc[q][t];
         __syncthreads();
-        const float* rbuf = red + ((size_t)(pw * KS * PPW * NT) * 4) * 64 + lane;
+        const f32x4* rbuf = red + (size_t)(pw * KS * PPW * NT) * 64 + lane;
 #pragma unroll
         for (int i = 0; i < NMY; ++i) {
             const int item = kh + i * KS;
@@ -303,9 +333,8 @@ __global__ __launch_bounds__(64 * PXT * KS) void iaf_conv_bf3_kernel(ConvP p) {
                 f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (item < NITEM) {
                     const int t = u * TPU + e;
-                    for (int k = 0; k < KS; ++k)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) sum[j] += rbuf[((size_t)((k * PPW + q) * NT + t) * 4 + j) * 64];
+                    for (int k = 0; k < KS; ++k) sum += rbuf[(size_t)((k * PPW + q) * NT + t) * 64];
                 }
                 val[i][e] = sum;
             }
@@ -316,10 +345,12 @@ __global__ __launch_bounds__(64 * PXT * KS) void iaf_conv_bf3_kernel(ConvP p) {
 #pragma unroll
             for (int e = 0; e < TPU; ++e) val[i][e] = acc[i / NUNIT][(i % NUNIT) * TPU + e];
     }
+    IAF_BSTAMP(4);
 #pragma unroll
     for (int i = 0; i < NMY; ++i) {
         const int item = kh + i * KS;
         const int u = item % NUNIT;
         epi_apply<EPI, NTP>(p, g[i], cot0 + u * TPU, val[i][0], val[i][TPU - 1], ops[i]);
     }
+    IAF_BSTAMP(5);
 }

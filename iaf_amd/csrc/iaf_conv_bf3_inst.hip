@@ -11,13 +11,16 @@ template <int NT>
 static conv_fn_t pick_mode_bf3(int inmode, int epi) {
     if (epi == EPI_HIDDEN) {
         if (inmode == IN_PIXMAJOR) return iaf_conv_bf3_kernel<NT, IAF_PPW, IAF_PXT, IAF_KS, IN_PIXMAJOR, EPI_HIDDEN>;
+        if (inmode == IN_PIXMAJOR3) return iaf_conv_bf3_kernel<NT, IAF_PPW, IAF_PXT, IAF_KS, IN_PIXMAJOR3, EPI_HIDDEN>;
         if (inmode == IN_NCHW) return iaf_conv_bf3_kernel<NT, IAF_PPW, IAF_PXT, IAF_KS, IN_NCHW, EPI_HIDDEN>;
         if (inmode == IN_POSTERIOR) return iaf_conv_bf3_kernel<NT, IAF_PPW, IAF_PXT, IAF_KS, IN_POSTERIOR, EPI_HIDDEN>;
         return nullptr;
     }
     if (epi == EPI_OUT) {     // the output pair always reads the last hidden layer (depth_ar = 0 stays on the fp32 kernel)
-        if constexpr (NT % 2 == 0)
+        if constexpr (NT % 2 == 0) {
             if (inmode == IN_PIXMAJOR) return iaf_conv_bf3_kernel<NT, IAF_PPW, IAF_PXT, IAF_KS, IN_PIXMAJOR, EPI_OUT>;
+            if (inmode == IN_PIXMAJOR3) return iaf_conv_bf3_kernel<NT, IAF_PPW, IAF_PXT, IAF_KS, IN_PIXMAJOR3, EPI_OUT>;
+        }
         return nullptr;
     }
     return nullptr;

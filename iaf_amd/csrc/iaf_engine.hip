@@ -71,6 +71,8 @@ struct GemmLayer {
     void* wp3 = nullptr;       // bf16x3 pack for iaf_conv_bf3_kernel (c_in % 32 == 0 only)
     int b_nt = 0, b_ppw = 0, b_pxt = 0, b_ks = 0;   // bf16x3 launch shape (auto or iaf_stack_set_tuning_bf3)
     bool b_user_tuned = false;
+    // result of iaf_stack_autotune for one problem size: which kernel family and which bf16x3 shape won the timing
+    long long tuned_P = -1; int tuned_W = -1; bool tuned_bf3 = false; int t_nt = 0, t_ppw = 0, t_pxt = 0, t_ks = 0;
     int* lim = nullptr;
     // launch shape: fixed by iaf_stack_set_tuning (user_tuned) or chosen per problem size by auto_shape()
     int nt, pxt, wco, ks;
@@ -338,7 +340,7 @@ extern "C" int iaf_stack_set_tuning(iaf_stack_t* s, int layer, int nt, int pxt, 
     return IAF_OK;
 }
 
-static bool auto_shape_bf3(GemmLayer& L, bool is_out, long long P, int W);
+static bool bf3_select(const iaf_stack_t* s, GemmLayer& L, int epi, bool negate_taps, bool pix_input, long long P, int W);
 
 extern "C" int iaf_stack_set_precision(iaf_stack_t* s, int precision) {
     if (!s) return IAF_ERR_NULL;
@@ -347,16 +349,14 @@ extern "C" int iaf_stack_set_precision(iaf_stack_t* s, int precision) {
     return IAF_OK;
 }
 
-extern "C" int iaf_stack_get_precision(const iaf_stack_t* s, int layer) {
+extern "C" int iaf_stack_get_precision(const iaf_stack_t* s, int layer, int B, int H, int W) {
     if (!s || layer < 0 || layer >= s->nlayers) return IAF_ERR_NULL;
-    const GemmLayer& L = s->L[layer];
+    if (B <= 0 || H <= 0 || W <= 0) return IAF_ERR_SHAPE;
+    GemmLayer t = s->L[layer];
     const bool is_out = (layer == s->depth_ar);
-    // what a forward launch of this layer will run (the output pair of a depth_ar = 0 stack reads z directly: fp32 kernel)
-    if (s->precision == IAF_PRECISION_BF16X3 && L.wp3 && !(is_out && s->depth_ar == 0)) {
-        GemmLayer t = L;
-        if (t.b_user_tuned || auto_shape_bf3(t, is_out, 16 * 256, 16)) return IAF_PRECISION_BF16X3;
-    }
-    return IAF_PRECISION_F32;
+    // what a forward launch of this layer at this size will run (same decision function as the launch)
+    return bf3_select(s, t, is_out ? EPI_OUT : EPI_HIDDEN, false, !(is_out && s->depth_ar == 0) && (layer > 0 || !is_out),
+                      (long long)B * H * W, W) ? IAF_PRECISION_BF16X3 : IAF_PRECISION_F32;
 }
 
 extern "C" int iaf_stack_set_tuning_bf3(iaf_stack_t* s, int layer, int nt, int ppw, int pxt, int ks) {
@@ -589,33 +589,39 @@ static int raise_lds_cap(const void* fn, size_t lds) {
     return 0;
 }
 
-// bf16x3 launch shape.  Per CU the weight stream (every wave fetches its own fragments: 1 KiB per wave-load through an
-// address unit that moves ~64 B/clk) and the MFMA pipe (6 MFMAs of ~17 cycles per tile pair per step) run concurrently;
-// a workgroup costs max(of the two) + a fixed prologue/epilogue, plus the split-K exchange.  Ties: fewer rounds first.
+// bf16x3 launch shape without a timing run (iaf_stack_autotune measures instead).  What the sweeps on one MI355X show
+// (tools/bf3_sweep.py, profiles/r02/bf3_sweep_*.txt): below ~4096 pixels a conv launch is all prologue / exchange /
+// epilogue latency and the exact-fp32 kernel is as fast or faster -> not selected; above, K-slicing over 4 waves with two
+// pixel tiles per wave wins (two workgroups share a CU and overlap each other's phases), except for a single c_in pair
+// (c_in = 32: 5 steps), where four waves along pixels without K-slicing do.
 static bool auto_shape_bf3(GemmLayer& L, bool is_out, long long P, int W) {
-    double best = 1e30;
-    int bi = -1, bnt = 0;
-    const int S = (L.cin / 32) * NTAPS;
-    for (int si = 0; si < 4; ++si) {
-        const int ppw = k_bf3_shapes[si][0], pxt = k_bf3_shapes[si][1], ks = k_bf3_shapes[si][2];
-        static const int nts[3] = {5, 4, 2};
-        for (int ni = 0; ni < 3; ++ni) {
-            const int nt = nts[ni];
-            if (L.ncot % nt != 0 || (is_out && (nt & 1))) continue;
-            if (!pick_bf3(nt, ppw, pxt, ks, IN_PIXMAJOR, is_out ? EPI_OUT : EPI_HIDDEN)) continue;
-            if (bf3_lds_bytes(L.cin, W, nt, ppw, pxt, ks) > 160 * 1024) continue;
-            const double wgs = (double)((P + 16 * ppw * pxt - 1) / (16 * ppw * pxt)) * (L.ncot / nt);
-            const double rounds = ceil(wgs / 256.0);
-            const double steps = ceil((double)S / ks);
-            const double mfma = steps * ppw * nt * 6 * 17.0 * ceil(pxt * ks / 4.0);
-            const double addr = steps * nt * 3 * 16.0 * pxt * ks;
-            const double T = rounds * ((mfma > addr ? mfma : addr) + 7000.0) + (ks > 1 ? 1500.0 : 0.0) + 1e-3 * si;
-            if (T < best) { best = T; bi = si; bnt = nt; }
-        }
+    if (P < 4096) return false;
+    static const int nts[3] = {5, 4, 2};
+    const bool short_k = (L.cin / 32) == 1;
+    for (int ni = 0; ni < 3; ++ni) {
+        const int nt = nts[ni];
+        if (L.ncot % nt != 0 || (is_out && (nt & 1))) continue;
+        int ppw = short_k ? 1 : 2, pxt = short_k ? 4 : 1, ks = short_k ? 1 : 4;
+        if (short_k && nt == 5 && L.ncot % 2 == 0) continue;          // c_in = 32 prefers nt = 2
+        if (is_out && P >= 32768 && nt == 4) ppw = 4;
+        if (!pick_bf3(nt, ppw, pxt, ks, IN_PIXMAJOR, is_out ? EPI_OUT : EPI_HIDDEN)) continue;
+        if (bf3_lds_bytes(L.cin, W, nt, ppw, pxt, ks) > 160 * 1024) continue;
+        L.b_nt = nt; L.b_ppw = ppw; L.b_pxt = pxt; L.b_ks = ks;
+        return true;
     }
-    if (bi < 0) return false;
-    L.b_nt = bnt; L.b_ppw = k_bf3_shapes[bi][0]; L.b_pxt = k_bf3_shapes[bi][1]; L.b_ks = k_bf3_shapes[bi][2];
-    return true;
+    return false;
+}
+
+// will a forward launch of this layer run the bf16x3 kernel?  (also fixes L.b_* to the shape it will use)
+static bool bf3_select(const iaf_stack_t* s, GemmLayer& L, int epi, bool negate_taps, bool pix_input, long long P, int W) {
+    if (s->precision != IAF_PRECISION_BF16X3 || !L.wp3 || negate_taps) return false;
+    if (!(epi == EPI_HIDDEN || (epi == EPI_OUT && pix_input))) return false;
+    if (!L.b_user_tuned && L.tuned_P == P && L.tuned_W == W) {       // measured for exactly this problem size
+        if (!L.tuned_bf3) return false;
+        L.b_nt = L.t_nt; L.b_ppw = L.t_ppw; L.b_pxt = L.t_pxt; L.b_ks = L.t_ks;
+    } else if (!L.b_user_tuned && !auto_shape_bf3(L, epi == EPI_OUT, P, W)) return false;
+    if (!pick_bf3(L.b_nt, L.b_ppw, L.b_pxt, L.b_ks, IN_PIXMAJOR, epi)) return false;
+    return bf3_lds_bytes(L.cin, W, L.b_nt, L.b_ppw, L.b_pxt, L.b_ks) <= 160 * 1024;
 }
 
 // launches the conv kernel for GEMM descriptor L (forward layer, or a transposed descriptor for dgrad)
@@ -625,14 +631,11 @@ static int launch_gemm(const iaf_stack_t* s, GemmLayer& L, int epi, bool negate_
     bool bf3 = false;
     // forward convs of the stack go to the bf16 matrix cores (bf16x3 split products, fp32-grade) when the layer has a
     // bf16x3 pack and a compiled shape covers it; everything else runs the exact-fp32 MFMA kernel
-    if (s->precision == IAF_PRECISION_BF16X3 && L.wp3 && !negate_taps && (epi == EPI_HIDDEN || epi == EPI_OUT) &&
-        (epi == EPI_HIDDEN || inmode == IN_PIXMAJOR)) {
-        if (L.b_user_tuned || auto_shape_bf3(L, epi == EPI_OUT, p.P, p.W)) {
-            fn = pick_bf3(L.b_nt, L.b_ppw, L.b_pxt, L.b_ks, inmode, epi);
-            if (fn && bf3_lds_bytes(L.cin, p.W, L.b_nt, L.b_ppw, L.b_pxt, L.b_ks) > 160 * 1024) fn = nullptr;
-            bf3 = fn != nullptr;
-        }
+    if (bf3_select(s, L, epi, negate_taps, inmode == IN_PIXMAJOR || inmode == IN_PIXMAJOR3, p.P, p.W)) {
+        fn = pick_bf3(L.b_nt, L.b_ppw, L.b_pxt, L.b_ks, inmode, epi);
+        bf3 = fn != nullptr;
     }
+    if (!bf3 && (inmode == IN_PIXMAJOR3 || p.y3 || (epi == EPI_HIDDEN && !p.y))) return IAF_ERR_UNSUPPORTED;   // (host logic error)
     if (!bf3 && !L.user_tuned) auto_shape(L, epi == EPI_OUT, p.P, p.W);
     const int tm = bf3 ? 16 * L.b_ppw * L.b_pxt : 16 * L.pxt;
     const int yg = bf3 ? L.ncot / L.b_nt : L.ncot / (L.nt * L.wco);
@@ -775,6 +778,56 @@ extern "C" int iaf_step_time_layer(iaf_stack_t* s, int layer, const float* z, co
     (void)hipEventDestroy(e1);
     s->prof_layer = saved;
     *avg_ms = ms / (float)reps;
+    return rc;
+}
+
+// Launch-shape / kernel-family search for one problem size (the counterpart of the cuDNN algorithm search behind the
+// reference's tf.nn.conv2d): every GEMM layer is timed as the exact-fp32 kernel (its automatic shape) and as every
+// compiled bf16x3 shape, `reps` back-to-back launches per event pair on the caller's buffers; the winner is remembered
+// for (B*H*W, W) and used by every later forward launch of that size.  chosen[l] = 0 (fp32 kernel) or
+// nt*1000 + ppw*100 + pxt*10 + ks; us[l] = its time.  Synchronises; do not call inside a stream capture.
+extern "C" int iaf_stack_autotune(iaf_stack_t* s, const float* z, const float* context, float* z_new, float* logsd, int B,
+                                  int H, int W, void* workspace, size_t workspace_bytes, int reps, void* stream,
+                                  int* chosen, float* us) {
+    int rc = check_dims(s, B, H, W);
+    if (rc) return rc;
+    if (s->generic) return IAF_OK;
+    if (reps <= 0) return IAF_ERR_SHAPE;
+    const long long P = (long long)B * H * W;
+    const int saved_prec = s->precision;
+    for (int l = 0; l < s->nlayers; ++l) {
+        GemmLayer& L = s->L[l];
+        const bool is_out = (l == s->depth_ar);
+        L.tuned_P = -1;
+        float best = 0.f, ms = 0.f;
+        s->precision = IAF_PRECISION_F32;
+        if ((rc = iaf_step_time_layer(s, l, z, context, z_new, logsd, B, H, W, workspace, workspace_bytes, reps, stream, &ms))) break;
+        best = ms;
+        int bsel[4] = {0, 0, 0, 0};
+        if (saved_prec == IAF_PRECISION_BF16X3 && L.wp3 && !(is_out && s->depth_ar == 0)) {
+            s->precision = IAF_PRECISION_BF16X3;
+            const bool ut = L.b_user_tuned;
+            const int sv[4] = {L.b_nt, L.b_ppw, L.b_pxt, L.b_ks};
+            static const int nts[3] = {5, 4, 2};
+            for (int si = 0; si < 4 && !rc; ++si)
+                for (int ni = 0; ni < 3 && !rc; ++ni) {
+                    const int nt = nts[ni], ppw = k_bf3_shapes[si][0], pxt = k_bf3_shapes[si][1], ks = k_bf3_shapes[si][2];
+                    if (L.ncot % nt != 0 || (is_out && (nt & 1))) continue;
+                    if (!pick_bf3(nt, ppw, pxt, ks, IN_PIXMAJOR, is_out ? EPI_OUT : EPI_HIDDEN)) continue;
+                    if (bf3_lds_bytes(L.cin, W, nt, ppw, pxt, ks) > 160 * 1024) continue;
+                    L.b_nt = nt; L.b_ppw = ppw; L.b_pxt = pxt; L.b_ks = ks; L.b_user_tuned = true;
+                    rc = iaf_step_time_layer(s, l, z, context, z_new, logsd, B, H, W, workspace, workspace_bytes, reps, stream, &ms);
+                    if (!rc && ms < best) { best = ms; bsel[0] = nt; bsel[1] = ppw; bsel[2] = pxt; bsel[3] = ks; }
+                }
+            L.b_user_tuned = ut; L.b_nt = sv[0]; L.b_ppw = sv[1]; L.b_pxt = sv[2]; L.b_ks = sv[3];
+        }
+        if (rc) break;
+        L.tuned_P = P; L.tuned_W = W; L.tuned_bf3 = bsel[0] != 0;
+        L.t_nt = bsel[0]; L.t_ppw = bsel[1]; L.t_pxt = bsel[2]; L.t_ks = bsel[3];
+        if (chosen) chosen[l] = bsel[0] * 1000 + bsel[1] * 100 + bsel[2] * 10 + bsel[3];
+        if (us) us[l] = 1e3f * best;
+    }
+    s->precision = saved_prec;
     return rc;
 }
 

@@ -216,12 +216,30 @@ class ARStack(object):
         code = {"f32": _capi.IAF_PRECISION_F32, "bf16x3": _capi.IAF_PRECISION_BF16X3}.get(precision, precision)
         _capi.check(_capi.lib().iaf_stack_set_precision(self._h, int(code)))
 
-    def layer_precision(self, layer):
-        """what GEMM layer `layer` will run: "bf16x3" or "f32" (layers the bf16x3 kernels do not cover stay fp32)"""
-        code = _capi.lib().iaf_stack_get_precision(self._h, int(layer))
+    def layer_precision(self, layer, B, H, W):
+        """what a forward launch of GEMM layer `layer` at this size will run: "bf16x3" or "f32" (layers the bf16x3 kernels
+        do not cover, or small launches they do not speed up, stay on the fp32 kernel)"""
+        code = _capi.lib().iaf_stack_get_precision(self._h, int(layer), int(B), int(H), int(W))
         if code < 0:
             _capi.check(code)
         return "bf16x3" if code == _capi.IAF_PRECISION_BF16X3 else "f32"
+
+    def autotune(self, z, context, reps=20):
+        """time every GEMM layer as the exact-fp32 kernel and as every compiled bf16x3 launch shape on these buffers and
+        keep the fastest for this (B, H, W) -- what cuDNN's algorithm search does for the reference's convs.  Returns
+        [(choice, us)] per layer, choice = "f32" or "bf16x3(nt,ppw,pxt,ks)".  Synchronises: call before graph capture."""
+        B, H, W = self._dims(z, context)
+        ws, need = self.workspace(B, H, W, z.device)
+        zn, ls = torch.empty_like(z), torch.empty_like(z)
+        n = self.depth_ar + 1
+        chosen, us = (ctypes.c_int * n)(), (ctypes.c_float * n)()
+        _capi.check(_capi.lib().iaf_stack_autotune(self._h, _ptr(z), _ptr(context), _ptr(zn), _ptr(ls), B, H, W, _ptr(ws), need,
+                                                   int(reps), _stream(), chosen, us))
+        out = []
+        for i in range(n):
+            c = chosen[i]
+            out.append(("f32" if c == 0 else "bf16x3(%d,%d,%d,%d)" % (c // 1000, c // 100 % 10, c // 10 % 10, c % 10), us[i]))
+        return out
 
     def set_tuning_bf3(self, layer, nt, ppw, pxt, ks):
         _capi.check(_capi.lib().iaf_stack_set_tuning_bf3(self._h, layer, nt, ppw, pxt, ks))

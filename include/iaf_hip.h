@@ -206,15 +206,24 @@ int iaf_stack_set_tuning(iaf_stack_t* s, int layer, int nt, int pxt, int wco, in
  *       evaluation not larger than the fp32 chain's) at 2.7x the matrix-core rate of
  *   IAF_PRECISION_F32               the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32), bit-equal to an fmaf chain.
  * Layers the bf16x3 kernels do not cover (c_in not a multiple of 32, co-tile counts without a compiled shape, the data
- * gradients, the plain 9-tap convs) run the fp32 kernel in either mode; iaf_stack_get_precision reports what GEMM layer
- * `layer` will run.  Outputs of the two modes differ by fp32 round-off only; each is deterministic. */
+ * gradients, the plain 9-tap convs) or do not speed up (fewer than ~4096 pixels per launch, unless autotuned or a shape
+ * is pinned) run the fp32 kernel in either mode; iaf_stack_get_precision reports what GEMM layer `layer` will run at a
+ * given problem size.  Outputs of the two modes differ by fp32 round-off only; each is deterministic. */
 #define IAF_PRECISION_F32 0
 #define IAF_PRECISION_BF16X3 1
 int iaf_stack_set_precision(iaf_stack_t* s, int precision);
-int iaf_stack_get_precision(const iaf_stack_t* s, int layer);
+int iaf_stack_get_precision(const iaf_stack_t* s, int layer, int B, int H, int W);
 /* launch shape of the bf16x3 kernel for GEMM layer `layer`: co tiles per wave, pixel tiles per wave, waves along
  * pixels, K-slice waves (nt = 0 restores the automatic choice) */
 int iaf_stack_set_tuning_bf3(iaf_stack_t* s, int layer, int nt, int ppw, int pxt, int ks);
+/* Kernel-family / launch-shape search for one problem size -- the counterpart of the cuDNN algorithm search behind the
+ * reference's tf.nn.conv2d (tf_utils/layers.py:64): times every GEMM layer as the exact-fp32 kernel and as every compiled
+ * bf16x3 shape (`reps` back-to-back launches each, on the caller's buffers) and remembers the winner for (B*H*W, W).
+ * chosen[l] (optional, depth_ar+1 entries) = 0 for the fp32 kernel or nt*1000 + ppw*100 + pxt*10 + ks; us[l] its time.
+ * Synchronises the stream: call it before capturing a graph.  Results of later launches are unaffected beyond fp32
+ * round-off (both families meet the same parity bar). */
+int iaf_stack_autotune(iaf_stack_t* s, const float* z, const float* context, float* z_new, float* logsd, int B, int H, int W,
+                       void* workspace, size_t workspace_bytes, int reps, void* stream, int* chosen, float* us);
 /* Per-kernel timing with HIP events on the launch stream: every launch of GEMM layer `layer` is
  * bracketed by an engine-owned event pair (up to max_samples; layer < 0 disables).  Not usable
  * during stream capture.  iaf_stack_profile_read synchronises the recorded events, writes the
