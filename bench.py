@@ -79,6 +79,7 @@ def parse():
 
 
 RANK_INFO = {}
+OUT_FD = [None]
 
 
 def emit(out):
@@ -86,8 +87,13 @@ def emit(out):
     out = dict(out)
     out["rccl_ranks"] = RANK_INFO.get("rccl_ranks")
     out["devices"] = RANK_INFO.get("devices")
-    print(json.dumps(out))
-    sys.stdout.flush()
+    line = json.dumps(out) + "\n"
+    if OUT_FD[0] is not None:          # multi-rank runs: fd 1 points at stderr (RCCL banners), the JSON goes to the real stdout
+        sys.stdout.flush()
+        os.write(OUT_FD[0], line.encode())
+    else:
+        sys.stdout.write(line)
+        sys.stdout.flush()
 
 
 def free_port():
@@ -129,31 +135,27 @@ def init_ranks(args):
     if world == 1 and not os.environ.get("IAF_BENCH_FORCE_DIST"):     # the env switch exercises the RCCL path on one GPU
         return None, 0, 1, info
     import torch.distributed as dist
-    # RCCL prints a banner (ROCm version / hostname / library path) to STDOUT when its first communicator comes up;
-    # the contract is ONE JSON line on stdout, so that happens with fd 1 pointed at stderr
+    # RCCL prints a banner (ROCm version / hostname / library path) to STDOUT whenever a communicator comes up (the first
+    # collective on a stream, possibly long after init); the contract is ONE JSON line on stdout, so for the rest of the
+    # process fd 1 points at stderr and emit() writes the JSON line to the saved, real stdout
     sys.stdout.flush()
-    saved = os.dup(1)
+    OUT_FD[0] = os.dup(1)
     os.dup2(2, 1)
-    try:
-        if world == 1:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", str(free_port()))
-            os.environ.setdefault("RANK", "0")
-            os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        dist.barrier()
-        # read the participants back from the communicator: every rank contributes 1 and its device identity
-        ones = torch.ones(1, device="cuda")
-        dist.all_reduce(ones)
-        props = torch.cuda.get_device_properties(local_rank)
-        ident = "rank%d:cuda:%d %s %s" % (rank, local_rank, props.name, getattr(props, "uuid", ""))
-        idents = [None] * dist.get_world_size()
-        dist.all_gather_object(idents, ident)
-        torch.cuda.synchronize()
-    finally:
-        sys.stdout.flush()
-        os.dup2(saved, 1)
-        os.close(saved)
+    if world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dist.barrier()
+    # read the participants back from the communicator: every rank contributes 1 and its device identity
+    ones = torch.ones(1, device="cuda")
+    dist.all_reduce(ones)
+    props = torch.cuda.get_device_properties(local_rank)
+    ident = "rank%d:cuda:%d %s %s" % (rank, local_rank, props.name, getattr(props, "uuid", ""))
+    idents = [None] * dist.get_world_size()
+    dist.all_gather_object(idents, ident)
+    torch.cuda.synchronize()
     info = {"rccl_ranks": int(ones.item()), "devices": idents}
     if info["rccl_ranks"] != dist.get_world_size() or len(set(idents)) != len(idents):
         sys.exit("bench.py: communicator reports %r ranks / devices %r" % (info["rccl_ranks"], idents))
@@ -804,7 +806,9 @@ def main():
                 f = lambda c, sc=1.0: sc * torch.randn(args.batch, c, H, H, device="cuda")
                 pin = [f(args.n_z), f(args.n_z, 0.25), f(args.n_z), f(args.n_z, 0.25), f(args.n_z), f(args.n_z, 0.25),
                        f(args.n_h), f(args.n_h), f(args.n_z)]
-                st.posterior_block(*pin, 0.25)
+                for _ in range(3):
+                    st.posterior_block(*pin, 0.25)
+                stream.synchronize()
                 ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ea.record(stream)
                 for _ in range(30):

@@ -61,7 +61,7 @@ static int conv3x3_create(iaf_conv3x3_t** out, int n_in, int n_out, int mask_mod
     const size_t wfloats = c->generic ? (size_t)MAXTAPS * n_in * n_out : (size_t)L.nchunk * MAXTAPS * L.ncot * 256;
     int rc;
     if ((rc = (int)hipMalloc(&L.wp, wfloats * sizeof(float))) != 0 ||
-        (rc = (int)hipMalloc(&L.bias, (size_t)L.ncot * 16 * sizeof(float))) != 0 ||
+        (rc = (int)hipMalloc(&L.bias, ((size_t)L.ncot * 16 + (size_t)n_in) * sizeof(float))) != 0 ||   // + deconv norms
         (rc = (int)hipHostMalloc((void**)&c->h_desc, sizeof(PrepLayer))) != 0 ||
         (rc = (int)hipMalloc((void**)&c->d_desc, sizeof(PrepLayer))) != 0) {
         iaf_conv3x3_destroy(c);
@@ -103,6 +103,54 @@ extern "C" int iaf_conv3x3_prepare(iaf_conv3x3_t* c, const float* V, const float
     HIP_TRY(hipGetLastError());
     c->prepared = true;
     return IAF_OK;
+}
+
+// deconv2d("down_deconv2") of a downsampling IAFLayer (tf_train.py:91; tf_utils/layers.py:67-112): V is [3,3,n_out,n_in].
+// The object is an ordinary iaf_conv3x3 (n_in, n_out) afterwards: run it with iaf_conv3x3_forward on the zero-inserted
+// input (iaf_resample2 mode IAF_RESAMPLE_UP_ZERO_ODD) at the OUTPUT resolution.  Forward only.
+extern "C" int iaf_conv3x3_prepare_deconv(iaf_conv3x3_t* c, const float* V, const float* g, const float* b, void* stream) {
+    if (!c || !V || !g || !b) return IAF_ERR_NULL;
+    if (c->mask_mode) return IAF_ERR_UNSUPPORTED;
+    GemmLayer& L = c->L;
+    hipStream_t st = (hipStream_t)stream;
+    float* inv_norm = L.bias + (size_t)L.ncot * 16;    // n_in floats behind the packed bias (conv3x3_create)
+    hipLaunchKernelGGL(iaf_deconv_norm_kernel, dim3(L.cin), dim3(256), 0, st, V, inv_norm, L.cin, L.cout);
+    const size_t total = (size_t)9 * L.cin * L.cout;
+    unsigned blocks = (unsigned)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(iaf_deconv_pack_kernel, dim3(blocks), dim3(256), 0, st, V, g, b, (const float*)inv_norm, L.wp, L.bias,
+                       L.cin, L.cout, L.ncot, c->generic ? 1 : 0);
+    HIP_TRY(hipGetLastError());
+    c->prepared = true;
+    return IAF_OK;
+}
+
+// 2x resampling of an NCHW tensor (modes: IAF_RESAMPLE_* in include/iaf_hip.h); H, W = size of the SMALLER tensor
+extern "C" int iaf_resample2(const float* src, float* dst, int B, int C, int H, int W, int mode, void* stream) {
+    if (!src || !dst) return IAF_ERR_NULL;
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || mode < 0 || mode > 3) return IAF_ERR_SHAPE;
+    const bool down = (mode == IAF_RESAMPLE_DOWN_EVEN || mode == IAF_RESAMPLE_DOWN_ODD);
+    const size_t n_dst = (size_t)B * C * H * W * (down ? 1 : 4);
+    hipLaunchKernelGGL(iaf_resample2_kernel, ew_grid(n_dst), dim3(256), 0, (hipStream_t)stream, src, dst, n_dst, H, W, mode);
+    return (int)hipGetLastError();
+}
+
+// eps' with (qm+rm) + exp(ql+rl) * eps' == z: the posterior noise that reproduces a given sample z (mode "init" of
+// IAFLayer.down runs the posterior block on a PRIOR sample, tf_train.py:60-61,67-85)
+__global__ __launch_bounds__(256) void iaf_noise_from_sample_kernel(const float* __restrict__ z, const float* __restrict__ qm,
+                                                                   const float* __restrict__ ql, const float* __restrict__ rm,
+                                                                   const float* __restrict__ rl, float* __restrict__ eps, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        eps[i] = (z[i] - (qm[i] + rm[i])) * __expf(-(ql[i] + rl[i]));
+}
+extern "C" int iaf_noise_from_sample(const float* z, const float* qz_mean, const float* qz_logsd, const float* rz_mean,
+                                     const float* rz_logsd, float* eps_out, size_t n, void* stream) {
+    if (!z || !qz_mean || !qz_logsd || !rz_mean || !rz_logsd || !eps_out) return IAF_ERR_NULL;
+    if (n == 0) return IAF_ERR_SHAPE;
+    hipLaunchKernelGGL(iaf_noise_from_sample_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)stream, z, qz_mean, qz_logsd, rz_mean,
+                       rz_logsd, eps_out, n);
+    return (int)hipGetLastError();
 }
 
 // weight prep of many plain convs in one launch (the four convs of every IAFLayer of a model): descriptors in device

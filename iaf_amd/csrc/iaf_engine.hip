@@ -30,6 +30,7 @@
 //   iaf_kernels_misc.hpp      KL + free bits, Gaussian, Adamax+EMA, lower bound, data-dependent init, likelihood
 //   iaf_kernels_backward.hpp  weight gradient, weight-norm backward, staging, posterior-block backward pieces
 //   iaf_kernels_generic.hpp   direct-conv fallback for channel counts outside the MFMA path
+//   iaf_kernels_resample.hpp  2x resampling and the deconv2d weight prep (downsampling IAFLayer)
 //   (this file)               stack object, launch logic, C ABI of the masked stack, forward / inverse / training
 //   iaf_conv3x3_host.hpp      C ABI of the plain and single masked 3x3 convs, init, likelihood
 #include <hip/hip_runtime.h>
@@ -54,6 +55,7 @@
 #include "iaf_kernels_misc.hpp"
 #include "iaf_kernels_backward.hpp"
 #include "iaf_kernels_generic.hpp"
+#include "iaf_kernels_resample.hpp"
 
 // ---------------------------------------------------------------------------------------------
 // host side: stack object

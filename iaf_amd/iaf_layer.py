@@ -3,9 +3,12 @@
 The two convolutions around it (down_conv1 / down_conv2, tf_train.py:53,93) are outside this
 path; the boundary is the channel split of down_conv1's output
 (tf_train.py:54) and the stored up-pass tensors (tf_train.py:38)."""
+import ctypes
+
 import torch
 
-from .layers import ARStack, WNConv2d
+from . import _capi
+from .layers import ARStack, WNConv2d, resample2, _ptr, _stream
 
 
 class IAFPosterior(object):
@@ -30,8 +33,17 @@ class IAFPosterior(object):
                                           self.up_context, down_context, eps, self.kl_min, want_kl_elem)
 
 
+def gaussian_sample(mean, logsd, eps):
+    """DiagonalGaussian(mean, 2*logsd).sample with the given noise (distributions.py:21-24; tf_train.py:56,61)"""
+    out = torch.empty_like(mean)
+    logvar = logsd * 2.0
+    _capi.check(_capi.lib().iaf_gaussian_sample(_ptr(mean), _ptr(logvar), _ptr(eps), _ptr(out), mean.numel(), _stream()))
+    return out
+
+
 class IAFLayer(object):
-    """tf_train.IAFLayer (tf_train.py:23-95) at a non-downsampling level, mode "train", entirely on the GPU:
+    """tf_train.IAFLayer (tf_train.py:23-95), entirely on the GPU; modes "train" / "init" / "sample" (tf_train.py:60-66),
+    with or without downsampling (tf_train.py:33,42-43,89-91):
 
         up():   elu -> up_conv1 -> split(qz_mean, qz_logsd, up_context, h) -> elu -> up_conv3 -> input + 0.1*h
         down(): elu -> down_conv1 -> split(pz_mean, pz_logsd, rz_mean, rz_logsd, down_context, h_det)
@@ -41,21 +53,36 @@ class IAFLayer(object):
     ELU / split / concat / residual of the reference graph is fused into a conv's staging or store.  The sampling
     noise `eps` is an input (the reference draws it inside DiagonalGaussian.sample, distributions.py:21-24)."""
 
-    def __init__(self, z_size, h_size, depth_ar=2, kl_min=0.25, downsample=False):
-        if downsample:
-            raise ValueError("the gfx950 engine covers the non-downsampling IAFLayer (stride-1 convs) only")
+    def __init__(self, z_size, h_size, depth_ar=2, kl_min=0.25, downsample=False, mode="train"):
+        """downsample=True: the first layer of a coarser level (tf_train.py:196) -- up() halves the resolution (stride-2
+        up_conv1, residual resize 0.5), down() doubles it (down_deconv2 instead of down_conv2, residual resize 2).
+        The strided ops run on the stride-1 conv kernel (full-resolution conv + subsample; zero-inserted input + rotated
+        filter, csrc/iaf_kernels_resample.hpp): forward only."""
+        if mode not in ("train", "init", "sample"):
+            raise ValueError("mode must be 'train', 'init' or 'sample' (tf_train.py:60-66), got %r" % (mode,))
         self.z_size, self.h_size, self.kl_min = int(z_size), int(h_size), float(kl_min)
+        self.downsample, self.mode = bool(downsample), mode
         zs, hs = self.z_size, self.h_size
         self.up_conv1 = WNConv2d(hs, 2 * zs + 2 * hs)      # tf_train.py:36
         self.up_conv3 = WNConv2d(hs, hs)                   # :41
         self.down_conv1 = WNConv2d(hs, 4 * zs + 2 * hs)    # :53
-        self.down_conv2 = WNConv2d(hs + zs, hs)            # :93
+        self.down_conv2 = WNConv2d(hs + zs, hs)            # :93 (down_deconv2, :91, when downsampling)
         self.posterior = IAFPosterior(zs, hs, depth_ar, kl_min)
 
+    @property
+    def last_conv_name(self):
+        return "down_deconv2" if self.downsample else "down_conv2"
+
     def load(self, params):
-        """params: {"up_conv1/V": ..., "ar_multiconv2d/layer_0/V": ..., "down_conv2/b": ...} device fp32 tensors."""
-        for nm in ("up_conv1", "up_conv3", "down_conv1", "down_conv2"):
+        """params: {"up_conv1/V": ..., "ar_multiconv2d/layer_0/V": ..., "down_conv2/b": ...} device fp32 tensors
+        ("down_deconv2/..." with V [3,3,h_size,h_size+z_size] for a downsampling layer, tf_train.py:91)."""
+        for nm in ("up_conv1", "up_conv3", "down_conv1"):
             getattr(self, nm).prepare(params[nm + "/V"], params[nm + "/g"], params[nm + "/b"])
+        nm = self.last_conv_name
+        if self.downsample:
+            self.down_conv2.prepare_deconv(params[nm + "/V"], params[nm + "/g"], params[nm + "/b"])
+        else:
+            self.down_conv2.prepare(params[nm + "/V"], params[nm + "/g"], params[nm + "/b"])
         pre = "ar_multiconv2d/"
         self.posterior.load({k[len(pre):]: v for k, v in params.items() if k.startswith(pre)})
 
@@ -76,24 +103,53 @@ class IAFLayer(object):
 
     def up(self, inp, autotune=False):
         zs, hs = self.z_size, self.h_size
-        qz_mean, qz_logsd, up_context, h = self.up_conv1(inp, elu_input=True, split=[zs, zs, hs, hs],
-                                                         autotune=autotune)                               # :35-37
+        parts = self.up_conv1(inp, elu_input=True, split=[zs, zs, hs, hs], autotune=autotune)             # :35-37
+        if self.downsample:
+            # stride [2,2], SAME (:33,36): output (i,j) of the strided conv is output (2i+1, 2j+1) of the stride-1 conv
+            parts = [resample2(t, "down_odd") for t in parts]
+            inp = resample2(inp, "down_even")                                                             # :42-43
+        qz_mean, qz_logsd, up_context, h = parts
         self.posterior.set_up_state(qz_mean, qz_logsd, up_context)                                        # :38
         return self.up_conv3(h, elu_input=True, residual=inp, autotune=autotune)[0]                       # :40-44
 
-    def down(self, inp, eps, autotune=False):
-        """Returns (output, kl_obj, kl_cost) like tf_train.py:95.  autotune=True: the first call at a new (B,H,W)
-        searches the launch shapes of the plain convs (what cuDNN's algorithm search does for the reference)."""
+    def down(self, inp, eps, autotune=False, eps_prior=None):
+        """Returns (output, kl_obj, kl_cost) like tf_train.py:95.  `eps` is the posterior noise (mode "train"),
+        `eps_prior` the prior noise modes "init" / "sample" draw instead (tf_train.py:60-61).  autotune=True: the first
+        call at a new (B,H,W) searches the launch shapes of the plain convs (cuDNN's algorithm search in the reference)."""
         zs, hs = self.z_size, self.h_size
         pz_mean, pz_logsd, rz_mean, rz_logsd, down_context, h_det = self.down_conv1(
             inp, elu_input=True, split=[zs] * 4 + [hs] * 2, autotune=autotune)                            # :52-54
-        blk = self.posterior.down(pz_mean, pz_logsd, rz_mean, rz_logsd, down_context, eps)                # :56-85
-        out = self.down_conv2(blk["z"], x2=h_det, elu_input=True, residual=inp, autotune=autotune)[0]     # :87-94
+        po = self.posterior
+        if self.mode == "train":
+            blk = po.down(pz_mean, pz_logsd, rz_mean, rz_logsd, down_context, eps)                        # :56-85
+        else:
+            if eps_prior is None:
+                raise ValueError("modes 'init' and 'sample' sample the PRIOR (tf_train.py:60-61): pass eps_prior")
+            z0 = gaussian_sample(pz_mean, pz_logsd, eps_prior)                                            # :56,61
+            if self.mode == "sample":                                                                     # :65-66
+                zero = torch.zeros(z0.shape[0], dtype=torch.float32, device=z0.device)
+                blk = dict(z=z0, kl_obj=zero, kl_cost=zero.clone())
+            else:
+                # "init": logqs, the IAF step and the KL run on the prior sample (:67-85) -- the fused posterior block
+                # with the posterior noise that reproduces z0
+                eps_eq = torch.empty_like(z0)
+                _capi.check(_capi.lib().iaf_noise_from_sample(_ptr(z0), _ptr(po.qz_mean), _ptr(po.qz_logsd), _ptr(rz_mean),
+                                                              _ptr(rz_logsd), _ptr(eps_eq), z0.numel(), _stream()))
+                blk = po.down(pz_mean, pz_logsd, rz_mean, rz_logsd, down_context, eps_eq)
+        if self.downsample:
+            # h = deconv2d(elu(concat(z, h_det))) (:87-91): elu(0) = 0, so the zero-inserted inputs go through the conv's
+            # own ELU / concat staging; input = resize_nearest_neighbor(input, 2) is the residual (:90,94)
+            out = self.down_conv2(resample2(blk["z"], "up_zero_odd"), x2=resample2(h_det, "up_zero_odd"), elu_input=True,
+                                  residual=resample2(inp, "up_nearest"), autotune=autotune)[0]
+        else:
+            out = self.down_conv2(blk["z"], x2=h_det, elu_input=True, residual=inp, autotune=autotune)[0]  # :87-94
         self.last_block = blk
         return out, blk["kl_obj"], blk["kl_cost"]
 
     # -- training: forward that keeps what the backward needs, and the backward (tf_train.py:138 for this layer) -----
     def set_training(self, on=True):
+        if on and self.downsample:
+            raise _capi.UnsupportedError("the downsampling IAFLayer is forward only on the gfx950 engine")
         for c in self.convs():
             c.set_training(on)
         self.posterior.stack.set_training(on)

@@ -429,6 +429,38 @@ class ARStack(object):
         return out
 
 
+RESAMPLE_MODES = {"down_even": 0, "down_odd": 1, "up_nearest": 2, "up_zero_odd": 3}
+
+
+def resample2(x, mode):
+    """2x resampling of an NCHW tensor on the GPU (include/iaf_hip.h, iaf_resample2):
+    "down_even" == resize_nearest_neighbor(x, 0.5), "up_nearest" == resize_nearest_neighbor(x, 2) (layers.py:169-175);
+    "down_odd" keeps what a stride-2 SAME 3x3 conv keeps of the stride-1 conv; "up_zero_odd" is the zero-inserted
+    input of conv2d_transpose."""
+    _check_act(x, "x")
+    B, C, H, W = (int(v) for v in x.shape)
+    m = RESAMPLE_MODES[mode]
+    if m < 2:
+        if H % 2 or W % 2:
+            raise ValueError("2x downsampling needs even H and W, got %dx%d" % (H, W))
+        out = torch.empty((B, C, H // 2, W // 2), dtype=x.dtype, device=x.device)
+        hs, ws = H // 2, W // 2
+    else:
+        out = torch.empty((B, C, 2 * H, 2 * W), dtype=x.dtype, device=x.device)
+        hs, ws = H, W
+    _capi.check(_capi.lib().iaf_resample2(_ptr(x), _ptr(out), B, C, hs, ws, m, _stream()))
+    return out
+
+
+def resize_nearest_neighbor(x, scale):
+    """tf_utils/layers.py:169-175 for the two scales the reference uses (tf_train.py:43,90)"""
+    if scale == 0.5:
+        return resample2(x, "down_even")
+    if scale == 2:
+        return resample2(x, "up_nearest")
+    raise ValueError("the gfx950 engine resizes by 0.5 or 2 (the IAFLayer uses), got %r" % (scale,))
+
+
 class WNConv2d(object):
     """One plain weight-normed 3x3 conv (tf_utils/layers.py:31-64, mask=None, stride (1,1), pad SAME) bound to an
     engine handle (iaf_conv3x3_t).  The elementwise work the reference wraps around it in IAFLayer
@@ -465,6 +497,18 @@ class WNConv2d(object):
         if not force and key == self._prep_key:
             return
         _capi.check(_capi.lib().iaf_conv3x3_prepare(self._h, _ptr(V), _ptr(g), _ptr(b), _stream()))
+        self._prep_key, self._keepalive = key, (V, g, b)
+
+    def prepare_deconv(self, V, g, b, force=False):
+        """deconv2d variables (layers.py:83-112): V [3,3,n_out,n_in].  Afterwards __call__ on the zero-inserted input
+        (resample2(x, "up_zero_odd")) at the output resolution equals the reference's conv2d_transpose(SAME, stride 2) + b."""
+        _check_act(V, "V", (3, 3, self.n_out, self.n_in))
+        _check_act(g, "g", (self.n_out,))
+        _check_act(b, "b", (self.n_out,))
+        key = ("deconv",) + tuple((t.data_ptr(), t._version) for t in (V, g, b))
+        if not force and key == self._prep_key:
+            return
+        _capi.check(_capi.lib().iaf_conv3x3_prepare_deconv(self._h, _ptr(V), _ptr(g), _ptr(b), _stream()))
         self._prep_key, self._keepalive = key, (V, g, b)
 
     def set_tuning(self, nt, pxt, wco, ks):

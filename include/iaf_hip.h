@@ -340,6 +340,29 @@ int iaf_datainit_normalize(const float* x_init, const float* add, float* y, floa
 int iaf_discretized_logistic(const float* mean, const float* logscale, int logscale_is_scalar, const float* sample,
                              float* out, int B, size_t n_per_row, float binsize, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * The DOWNSAMPLING IAFLayer (tf_train.py:33,42-43,89-91): stride-2 up_conv1, resize_nearest_neighbor, deconv2d
+ * ------------------------------------------------------------------------------------------ */
+/* 2x resampling of an NCHW tensor; H, W = size of the SMALLER of the two tensors.
+ *   DOWN_EVEN  dst[i,j] = src[2i,2j]      == resize_nearest_neighbor(x, 0.5)   (tf_utils/layers.py:169-175, tf_train.py:43)
+ *   DOWN_ODD   dst[i,j] = src[2i+1,2j+1]  the outputs conv2d(stride=[2,2], SAME) keeps of the stride-1 conv (tf_train.py:33,36)
+ *   UP_NEAREST dst[y,x] = src[y/2,x/2]    == resize_nearest_neighbor(x, 2)     (tf_train.py:90)
+ *   UP_ZERO_ODD dst[2i+1,2j+1] = src[i,j], 0 elsewhere: the zero-inserted input of conv2d_transpose (layers.py:67-80) */
+#define IAF_RESAMPLE_DOWN_EVEN 0
+#define IAF_RESAMPLE_DOWN_ODD 1
+#define IAF_RESAMPLE_UP_NEAREST 2
+#define IAF_RESAMPLE_UP_ZERO_ODD 3
+int iaf_resample2(const float* src, float* dst, int B, int C, int H, int W, int mode, void* stream);
+/* deconv2d(name, x, num_filters, stride=(2,2)) (tf_utils/layers.py:83-112): V is [3,3,n_out,n_in]; the reference's weight
+ * norm runs over (kh,kw,n_OUT) per INPUT channel (layers.py:104) and is kept.  Prepares an iaf_conv3x3 (n_in, n_out) so
+ * that iaf_conv3x3_forward on the UP_ZERO_ODD-resampled input, at the output resolution, equals the reference's
+ * conv2d_transpose(SAME, stride 2) + b.  Forward only. */
+int iaf_conv3x3_prepare_deconv(iaf_conv3x3_t* c, const float* V, const float* g, const float* b, void* stream);
+/* eps_out with (qz_mean+rz_mean) + exp(qz_logsd+rz_logsd)*eps_out == z: mode "init" of IAFLayer.down runs the posterior
+ * block on a PRIOR sample (tf_train.py:60-61, 67-85) */
+int iaf_noise_from_sample(const float* z, const float* qz_mean, const float* qz_logsd, const float* rz_mean,
+                          const float* rz_logsd, float* eps_out, size_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -118,6 +118,44 @@ def conv2d_init(x, V0, stride=(1, 1), init_scale=0.1, mask=None):
     return y, g, b
 
 
+def deconv2d(x, V, g, b, stride=(2, 2)):
+    """tf_utils/layers.py:83-112 (non-init branch) + my_deconv2d (67-80): V is [kh, kw, n_out, n_in]; the weight norm is
+    `exp(g)[o] * l2_normalize(V, [0, 1, 2])`, i.e. the norm runs over (kh, kw, n_OUT) per INPUT channel (the reference
+    normalises the deconv filter over its first three axes like the conv filter, whose third axis is n_in); then
+    tf.nn.conv2d_transpose(SAME, stride 2, output = 2x input).  Restated as a gather: output (y, x) collects input
+    (i, j) through tap (a, b) where y = 2i + a - pad_t (pad_t = 0 for k = 3, s = 2, SAME)."""
+    kh, kw, co, ci = V.shape
+    w = np.exp(g).reshape([1, 1, co, 1]) * l2_normalize(V, (0, 1, 2))
+    n, c, hh, ww = x.shape
+    assert c == ci
+    sh, sw = stride
+    oh, ow = hh * sh, ww * sw
+    _, pt, _ = _same_pad(oh, kh, sh)
+    _, pl, _ = _same_pad(ow, kw, sw)
+    y = np.zeros((n, co, oh, ow), dtype=np.result_type(x, w))
+    for a in range(kh):
+        for bb in range(kw):
+            # rows y with (y + pt - a) divisible by sh and the quotient inside the input
+            ys = [yy for yy in range(oh) if (yy + pt - a) % sh == 0 and 0 <= (yy + pt - a) // sh < hh]
+            xs = [xx for xx in range(ow) if (xx + pl - bb) % sw == 0 and 0 <= (xx + pl - bb) // sw < ww]
+            if not ys or not xs:
+                continue
+            iy = [(yy + pt - a) // sh for yy in ys]
+            ix = [(xx + pl - bb) // sw for xx in xs]
+            patch = x[:, :, iy][:, :, :, ix]                                       # [n, ci, len(ys), len(xs)]
+            y[np.ix_(range(n), range(co), ys, xs)] += np.einsum("nchw,oc->nohw", patch, w[a, bb])
+    return y + b.reshape([1, -1, 1, 1])
+
+
+def resize_nearest_neighbor(x, scale):
+    """tf_utils/layers.py:169-175 (tf.image.resize_nearest_neighbor, align_corners=False): out[y] = in[floor(y / scale)]"""
+    n, c, hh, ww = x.shape
+    oh, ow = int(hh * scale), int(ww * scale)
+    iy = np.minimum((np.arange(oh) * (hh / float(oh))).astype(int), hh - 1)
+    ix = np.minimum((np.arange(ow) * (ww / float(ow))).astype(int), ww - 1)
+    return x[:, :, iy][:, :, :, ix]
+
+
 def elu(x):
     """tf.nn.elu (layers.py:159 default nl)."""
     return np.where(x > 0, x, np.expm1(np.minimum(x, 0)))
@@ -197,13 +235,15 @@ def _sub(params, prefix):
     return {k[n:]: v for k, v in params.items() if k.startswith(prefix)}
 
 
-def iaf_layer_up(inp, params, z_size, h_size):
-    """tf_train.py:29-44, downsample=False.  Returns (output, qz_mean, qz_logsd, up_context)."""
+def iaf_layer_up(inp, params, z_size, h_size, downsample=False):
+    """tf_train.py:29-44.  Returns (output, qz_mean, qz_logsd, up_context)."""
     p = _sub(params, "up_conv1/")
-    x = conv2d(elu(inp), p["V"], p["g"], p["b"])
+    x = conv2d(elu(inp), p["V"], p["g"], p["b"], stride=(2, 2) if downsample else (1, 1))      # :33-36
     qz_mean, qz_logsd, up_context, h = split_channels(x, [z_size, z_size, h_size, h_size])
     p = _sub(params, "up_conv3/")
     h = conv2d(elu(h), p["V"], p["g"], p["b"])
+    if downsample:
+        inp = resize_nearest_neighbor(inp, 0.5)                                                # :42-43
     return inp + 0.1 * h, qz_mean, qz_logsd, up_context
 
 
@@ -233,17 +273,37 @@ def posterior_block(qz_mean, qz_logsd, rz_mean, rz_logsd, pz_mean, pz_logsd, up_
     return dict(z=z, logqs=logqs, logps=logps, kl_obj=kl_obj, kl_cost=kl_cost, z0=z0, arw_logsd=arw_logsd)
 
 
-def iaf_layer_down(inp, params, qz_mean, qz_logsd, up_context, eps, z_size, h_size, kl_min):
-    """tf_train.py:46-95, mode="train", downsample=False.  Returns (output, kl_obj, kl_cost, block)."""
+def iaf_layer_down(inp, params, qz_mean, qz_logsd, up_context, eps, z_size, h_size, kl_min, mode="train",
+                   downsample=False, eps_prior=None):
+    """tf_train.py:46-95.  mode "train": z0 = posterior sample (eps); "init": z0 = PRIOR sample (eps_prior), the IAF step
+    and the KL run on it (:60-61, 67-85); "sample": z = prior sample, no IAF, kl = 0 (:60-61, 65-66).
+    Returns (output, kl_obj, kl_cost, block)."""
     p = _sub(params, "down_conv1/")
     x = conv2d(elu(inp), p["V"], p["g"], p["b"])                                               # :52-53
     pz_mean, pz_logsd, rz_mean, rz_logsd, down_context, h_det = split_channels(
         x, [z_size] * 4 + [h_size] * 2)                                                        # :54
-    blk = posterior_block(qz_mean, qz_logsd, rz_mean, rz_logsd, pz_mean, pz_logsd, up_context, down_context,
-                          eps, _sub(params, "ar_multiconv2d/"), [h_size, h_size], kl_min)
+    if mode == "train":
+        blk = posterior_block(qz_mean, qz_logsd, rz_mean, rz_logsd, pz_mean, pz_logsd, up_context, down_context,
+                              eps, _sub(params, "ar_multiconv2d/"), [h_size, h_size], kl_min)
+    else:
+        z0 = gaussian_diag_sample(pz_mean, 2 * pz_logsd, eps_prior)                            # :60-61
+        if mode == "sample":
+            n = z0.shape[0]
+            blk = dict(z=z0, kl_obj=np.zeros(n), kl_cost=np.zeros(n))                          # :65-66
+        else:
+            # the same lines as "train" with z0 from the prior: express it as the posterior noise that yields z0
+            post_mean, post_logsd = rz_mean + qz_mean, rz_logsd + qz_logsd
+            eps_eq = (z0 - post_mean) / np.exp(post_logsd)
+            blk = posterior_block(qz_mean, qz_logsd, rz_mean, rz_logsd, pz_mean, pz_logsd, up_context, down_context,
+                                  eps_eq, _sub(params, "ar_multiconv2d/"), [h_size, h_size], kl_min)
     h = elu(np.concatenate([blk["z"], h_det], axis=1))                                         # :87-88
-    p = _sub(params, "down_conv2/")
-    h = conv2d(h, p["V"], p["g"], p["b"])                                                      # :93
+    if downsample:
+        inp = resize_nearest_neighbor(inp, 2)                                                  # :90
+        p = _sub(params, "down_deconv2/")
+        h = deconv2d(h, p["V"], p["g"], p["b"])                                                # :91
+    else:
+        p = _sub(params, "down_conv2/")
+        h = conv2d(h, p["V"], p["g"], p["b"])                                                  # :93
     return inp + 0.1 * h, blk["kl_obj"], blk["kl_cost"], blk                                   # :94-95
 
 

@@ -90,6 +90,52 @@ def layer_case_inputs(name):
                 up_input=up_input, down_input=down_input, eps_prior=eps_prior, eps_post=eps_post)
 
 
+# downsampling IAFLayer (tf_train.py:33,42-43,89-91) and the init / sample modes (tf_train.py:60-66)
+LAYER_DS_CASES = {
+    # name: (B, z_size, h_size, H, W of the up-pass INPUT, kl_min, k, mode, downsample)
+    "layer_ds_tiny":     (2, 4, 8, 8, 8, 0.25, 1, "train", True),
+    "layer_ds_cfg2":     (2, 32, 160, 16, 16, 0.25, 1, "train", True),
+    "layer_tiny_init":   (3, 4, 8, 6, 6, 0.25, 1, "init", False),
+    "layer_tiny_sample": (3, 4, 8, 6, 6, 0.25, 1, "sample", False),
+    "layer_ds_init":     (2, 16, 32, 8, 8, 0.1, 1, "init", True),
+    "layer_cfg2_init":   (2, 32, 160, 8, 8, 0.25, 1, "init", False),
+}
+
+
+def deconv_params(rng, n_in, n_out, k=3):
+    """deconv2d variables (layers.py:83-112): V is [k, k, n_out, n_in]"""
+    return {"V": 0.05 * rng.standard_normal((k, k, n_out, n_in)), "g": 0.1 * rng.standard_normal(n_out),
+            "b": 0.1 * rng.standard_normal(n_out)}
+
+
+def layer_ds_case_inputs(name):
+    B, zs, hs, H, W, kl_min, k, mode, ds = LAYER_DS_CASES[name]
+    rng = np.random.RandomState(case_seed(name))
+    p = {}
+    for kk, v in conv_params(rng, hs, 2 * zs + 2 * hs).items():
+        p["up_conv1/" + kk] = v
+    for kk, v in conv_params(rng, hs, hs).items():
+        p["up_conv3/" + kk] = v
+    for kk, v in conv_params(rng, hs, 4 * zs + 2 * hs).items():
+        p["down_conv1/" + kk] = v
+    for kk, v in ar_multiconv2d_params(rng, zs, [hs, hs], [zs, zs]).items():
+        p["ar_multiconv2d/" + kk] = v
+    if ds:
+        for kk, v in deconv_params(rng, hs + zs, hs).items():
+            p["down_deconv2/" + kk] = v
+    else:
+        for kk, v in conv_params(rng, hs + zs, hs).items():
+            p["down_conv2/" + kk] = v
+    n = B * k
+    Hl, Wl = (H // 2, W // 2) if ds else (H, W)          # resolution of the latent / of the down-pass input
+    up_input = rng.standard_normal((n, hs, H, W))
+    down_input = rng.standard_normal((n, hs, Hl, Wl))
+    eps_prior = rng.standard_normal((n, zs, Hl, Wl))
+    eps_post = rng.standard_normal((n, zs, Hl, Wl))
+    return dict(B=B, k=k, z_size=zs, h_size=hs, H=H, W=W, kl_min=kl_min, mode=mode, downsample=ds, params=p,
+                up_input=up_input, down_input=down_input, eps_prior=eps_prior, eps_post=eps_post)
+
+
 MASK_CASES = [
     (32, 160, False), (160, 160, False), (160, 32, True), (32, 64, False), (64, 32, True),
     (64, 64, False), (64, 64, True), (64, 128, False), (128, 64, True), (64, 192, False),

@@ -212,6 +212,44 @@ def nn_conv2d(x, w, strides, padding, data_format="NHWC", name=None):
     return T(y)
 
 
+def nn_conv2d_transpose(x, filters, output_shape, strides, padding="SAME", data_format="NHWC", name=None):
+    """tf.nn.conv2d_transpose = the gradient of tf.nn.conv2d with respect to its input: x NHWC [n,h,w,c_in], filters
+    [kh,kw,c_out,c_in], result NHWC `output_shape`.  Written as the adjoint (scatter) of the forward conv whose input is
+    the result: forward output (i,j) reads input (i*s + a - pad_t, j*s + b - pad_l), so x[i,j]*f[a,b] lands there."""
+    assert data_format == "NHWC" and padding == "SAME"
+    x = np.asarray(x)
+    f = np.asarray(filters)
+    n, hh, ww, ci = x.shape
+    kh, kw, co, ci2 = f.shape
+    assert ci2 == ci
+    sh, sw = int(strides[1]), int(strides[2])
+    on, oh, ow, oc = [int(v) for v in output_shape]
+    assert on == n and oc == co
+    fh, pt, _ = _same_pad(oh, kh, sh)
+    fw, pl, _ = _same_pad(ow, kw, sw)
+    assert (fh, fw) == (hh, ww), "output_shape inconsistent with the forward conv"
+    y = np.zeros((n, oh, ow, co), dtype=np.result_type(x, f))
+    for i in range(hh):
+        for j in range(ww):
+            for a in range(kh):
+                for b in range(kw):
+                    yy, xx = i * sh + a - pt, j * sw + b - pl
+                    if 0 <= yy < oh and 0 <= xx < ow:
+                        y[:, yy, xx, :] += x[:, i, j, :] @ f[a, b].T
+    return T(y)
+
+
+def image_resize_nearest_neighbor(images, size, align_corners=False, name=None):
+    """tf.image.resize_nearest_neighbor (align_corners=False): out[y,x] = in[min(floor(y*in_h/out_h), in_h-1), ...], NHWC"""
+    assert not align_corners
+    x = np.asarray(images)
+    n, hh, ww, c = x.shape
+    oh, ow = int(size[0]), int(size[1])
+    iy = np.minimum(np.floor(np.arange(oh) * (hh / float(oh))).astype(int), hh - 1)
+    ix = np.minimum(np.floor(np.arange(ow) * (ww / float(ow))).astype(int), ww - 1)
+    return T(x[:, iy][:, :, ix])
+
+
 def nn_l2_normalize(x, dim, epsilon=1e-12, name=None):
     """tf.nn.l2_normalize: x * rsqrt(max(sum(x**2, dim, keepdims), epsilon))."""
     x = np.asarray(x)
@@ -399,7 +437,11 @@ def build_modules():
 
     nn = types.ModuleType("tensorflow.nn")
     nn.conv2d, nn.l2_normalize, nn.elu, nn.moments = nn_conv2d, nn_l2_normalize, nn_elu, nn_moments
+    nn.conv2d_transpose = nn_conv2d_transpose
     tf.nn = nn
+    image = types.ModuleType("tensorflow.image")
+    image.resize_nearest_neighbor = image_resize_nearest_neighbor
+    tf.image = image
 
     test = types.ModuleType("tensorflow.test")
     test_util = types.ModuleType("tensorflow.test.test_util")

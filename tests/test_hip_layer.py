@@ -489,3 +489,104 @@ def test_backward_autotune_keeps_gradients(amd):
     assert ("bwd", B, H, W) in conv._tuned
     for a, b_ in ((dx0, dx1), (dx0, dx2), (dV0, dV1), (dV0, dV2), (dg0, dg2), (db0, db2)):
         np.testing.assert_allclose(host(a), host(b_), atol=1e-5 * float(a.abs().max()) + 1e-7, rtol=0)
+
+
+# ---------------------------------------------------------------- downsampling IAFLayer, init / sample modes (tf_train.py:33,42-43,60-66,89-91)
+def test_resample_and_deconv_vs_reference_golden(amd, golden_dir):
+    """resize_nearest_neighbor (layers.py:169-175) and deconv2d (layers.py:67-112) against the outputs of the reference's
+    own functions: deconv = zero-insert + the stride-1 conv kernel with the rotated, deconv-normalised filter"""
+    g = np.load(os.path.join(golden_dir, "iaf_layer_ds.npz"))
+    np.testing.assert_array_equal(host(amd.resize_nearest_neighbor(dev(g["resize/x"]), 0.5)), f32(g["resize/half"]))
+    np.testing.assert_array_equal(host(amd.resize_nearest_neighbor(dev(g["resize/x"]), 2)), f32(g["resize/double"]))
+    x = g["deconv/x"]
+    conv = amd.WNConv2d(x.shape[1], g["deconv/V"].shape[2])
+    conv.prepare_deconv(dev(g["deconv/V"]), dev(g["deconv/g"]), dev(g["deconv/b"]))
+    y = conv(amd.resample2(dev(x), "up_zero_odd"))[0]
+    np.testing.assert_allclose(host(y), g["deconv/y"], atol=ATOL, rtol=0)
+
+
+@pytest.mark.parametrize("shape", [(2, 48, 32, 8, 8), (3, 192, 160, 8, 8), (1, 16, 16, 3, 5)], ids=lambda s: "B%d_%d_%d_%dx%d" % s)
+def test_deconv2d_vs_oracle(amd, shape):
+    """MFMA path of the deconv (channels % 16 == 0), incl. the down_deconv2 shape 192 -> 160 at 8x8 -> 16x16"""
+    B, n_in, n_out, H, W = shape
+    rng = np.random.RandomState(12)
+    p = gi.deconv_params(rng, n_in, n_out)
+    x = rng.standard_normal((B, n_in, H, W))
+    conv = amd.WNConv2d(n_in, n_out)
+    conv.prepare_deconv(dev(p["V"]), dev(p["g"]), dev(p["b"]))
+    y = conv(amd.resample2(dev(x), "up_zero_odd"))[0]
+    e = O.deconv2d(f32(x), f32(p["V"]), f32(p["g"]), f32(p["b"]))
+    np.testing.assert_allclose(host(y), e, atol=ATOL, rtol=0)
+
+
+@pytest.mark.parametrize("name", sorted(gi.LAYER_DS_CASES))
+def test_iaf_layer_downsample_and_modes_vs_reference_golden(amd, golden_dir, name):
+    """IAFLayer.up/.down with downsample=True and in modes "init" / "sample", every op on the GPU, against the outputs
+    of the reference's own tf_train.IAFLayer (tests/golden/make_golden.py: gen_layers_ds)"""
+    g = np.load(os.path.join(golden_dir, "iaf_layer_ds.npz"))
+    c = gi.layer_ds_case_inputs(name)
+    layer = amd.IAFLayer(c["z_size"], c["h_size"], depth_ar=2, kl_min=c["kl_min"], downsample=c["downsample"], mode=c["mode"])
+    layer.load({k: dev(v) for k, v in c["params"].items()})
+    up_out = layer.up(dev(c["up_input"]))
+    np.testing.assert_allclose(host(up_out), g[name + "/up_out"], atol=ATOL, rtol=0)
+    po = layer.posterior
+    np.testing.assert_allclose(host(po.qz_mean), g[name + "/qz_mean"], atol=ATOL, rtol=0)
+    np.testing.assert_allclose(host(po.qz_logsd), g[name + "/qz_logsd"], atol=ATOL, rtol=0)
+    np.testing.assert_allclose(host(po.up_context), g[name + "/up_context"], atol=ATOL, rtol=0)
+    out, kl_obj, kl_cost = layer.down(dev(c["down_input"]), dev(c["eps_post"]), eps_prior=dev(c["eps_prior"]))
+    np.testing.assert_allclose(host(out), g[name + "/output"], atol=2 * ATOL, rtol=0)
+    np.testing.assert_allclose(host(kl_obj), g[name + "/kl_obj"], atol=2e-3, rtol=2e-4)
+    np.testing.assert_allclose(host(kl_cost), g[name + "/kl_cost"], atol=2e-3, rtol=2e-4)
+    if c["downsample"]:
+        assert tuple(up_out.shape[2:]) == (c["H"] // 2, c["W"] // 2) and tuple(out.shape[2:]) == (c["H"], c["W"])
+
+
+def test_two_level_stack_chains_through_the_downsampling_layer(amd):
+    """BASELINE configs[1] structure at reduced depth: level 0 at 16x16, level 1 at 8x8 whose first layer downsamples
+    (tf_train.py:188-200): the up pass goes 16x16 -> 8x8, the down pass 8x8 -> 16x16, against the oracle's layers"""
+    zs, hs, B = 32, 160, 2
+    rng = np.random.RandomState(77)
+    spec = [(0, False), (0, False), (1, True), (1, False)]         # (level, downsample) in up-pass order
+    layers, params = [], []
+    for lvl, ds in spec:
+        p = {}
+        for nm, (ci, co) in (("up_conv1", (hs, 2 * zs + 2 * hs)), ("up_conv3", (hs, hs)), ("down_conv1", (hs, 4 * zs + 2 * hs))):
+            for k, v in gi.conv_params(rng, ci, co).items():
+                p[nm + "/" + k] = v
+        for k, v in gi.ar_multiconv2d_params(rng, zs, [hs, hs], [zs, zs]).items():
+            p["ar_multiconv2d/" + k] = v
+        last = gi.deconv_params(rng, hs + zs, hs) if ds else gi.conv_params(rng, hs + zs, hs)
+        for k, v in last.items():
+            p[("down_deconv2/" if ds else "down_conv2/") + k] = v
+        L = amd.IAFLayer(zs, hs, depth_ar=2, kl_min=0.25, downsample=ds)
+        L.load({k: dev(v) for k, v in p.items()})
+        layers.append(L); params.append(p)
+    x = 0.5 * rng.standard_normal((B, hs, 16, 16))
+    h_top = 0.5 * rng.standard_normal((B, hs, 8, 8))
+    eps = [0.5 * rng.standard_normal((B, zs, 16 >> lvl, 16 >> lvl)) for lvl, _ in spec]
+    # GPU
+    h = dev(x)
+    for L in layers:
+        h = L.up(h)
+    assert tuple(h.shape) == (B, hs, 8, 8)
+    d = dev(h_top)
+    kls = []
+    for L, e in zip(reversed(layers), reversed(eps)):
+        d, kl_obj, kl_cost = L.down(d, dev(e))
+        kls.append(kl_cost)
+    assert tuple(d.shape) == (B, hs, 16, 16)
+    # oracle
+    eh, st = f32(x), []
+    for (lvl, ds), p in zip(spec, params):
+        p32 = {k: f32(v) for k, v in p.items()}
+        eh, qm, ql, uc = O.iaf_layer_up(eh, p32, zs, hs, downsample=ds)
+        st.append((qm, ql, uc))
+    ed, ekl = f32(h_top), []
+    for (lvl, ds), p, (qm, ql, uc), e in zip(reversed(spec), reversed(params), reversed(st), reversed(eps)):
+        p32 = {k: f32(v) for k, v in p.items()}
+        ed, _, klc, _ = O.iaf_layer_down(ed, p32, qm, ql, uc, f32(e), zs, hs, 0.25, downsample=ds)
+        ekl.append(klc)
+    np.testing.assert_allclose(host(h), eh, atol=2 * ATOL, rtol=0)
+    np.testing.assert_allclose(host(d), ed, atol=5 * ATOL, rtol=0)
+    for a, b in zip(kls, ekl):
+        np.testing.assert_allclose(host(a), b, atol=5e-3, rtol=3e-4)

@@ -179,3 +179,30 @@ def test_adamax_matches_reference(golden_dir):
         np.testing.assert_array_equal(var, g["var_%d" % t])
         np.testing.assert_array_equal(m, g["m_%d" % t])
         np.testing.assert_array_equal(v, g["v_%d" % t])
+
+
+# ---------------------------------------------------------------- downsampling IAFLayer, init / sample modes
+def test_deconv2d_and_resize_vs_reference_golden(golden_dir):
+    """tf_utils/layers.py:67-112 (deconv2d incl. its over-(kh,kw,out) weight norm) and 169-175 (resize_nearest_neighbor)"""
+    g = np.load(os.path.join(golden_dir, "iaf_layer_ds.npz"))
+    y = O.deconv2d(g["deconv/x"], g["deconv/V"], g["deconv/g"], g["deconv/b"])
+    np.testing.assert_allclose(y, g["deconv/y"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_array_equal(O.resize_nearest_neighbor(g["resize/x"], 0.5), g["resize/half"])
+    np.testing.assert_array_equal(O.resize_nearest_neighbor(g["resize/x"], 2), g["resize/double"])
+
+
+@pytest.mark.parametrize("name", sorted(gi.LAYER_DS_CASES))
+def test_iaf_layer_downsample_and_modes_vs_reference_golden(golden_dir, name):
+    """tf_train.IAFLayer.up/.down with downsample=True (stride-2 up_conv1, resize 0.5 / 2, down_deconv2) and modes
+    "init" / "sample" (tf_train.py:33,42-43,60-66,89-91), executed from the reference's own source"""
+    g = np.load(os.path.join(golden_dir, "iaf_layer_ds.npz"))
+    c = gi.layer_ds_case_inputs(name)
+    zs, hs = c["z_size"], c["h_size"]
+    up_out, qz_mean, qz_logsd, up_context = O.iaf_layer_up(c["up_input"], c["params"], zs, hs, downsample=c["downsample"])
+    for k, v in (("up_out", up_out), ("qz_mean", qz_mean), ("qz_logsd", qz_logsd), ("up_context", up_context)):
+        np.testing.assert_allclose(v, g[name + "/" + k], rtol=1e-10, atol=1e-12)
+    out, kl_obj, kl_cost, _ = O.iaf_layer_down(c["down_input"], c["params"], qz_mean, qz_logsd, up_context, c["eps_post"], zs, hs,
+                                               c["kl_min"], mode=c["mode"], downsample=c["downsample"], eps_prior=c["eps_prior"])
+    np.testing.assert_allclose(out, g[name + "/output"], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(kl_obj, g[name + "/kl_obj"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(kl_cost, g[name + "/kl_cost"], rtol=1e-9, atol=1e-9)
