@@ -397,9 +397,10 @@ def train_bench(args, depths, dist, rank, n_gpus):
 
 
 def layers_bench(args, depths, dist, rank, n_gpus):
-    """SURVEY 8f-4 widening: whole non-downsampling IAFLayers (tf_train.py:23-95), forward, mode "train": per step the
-    bottom-up pass (`up`, chained within a level) then the top-down pass (`down`, chained within a level) of
-    sum(depths) layers; all weight-norm reparametrisations re-derived every step in two batched launches."""
+    """SURVEY 8f-4 widening: the whole IAFLayer stack of BASELINE configs[1] as ONE connected model (tf_train.py:188-200),
+    forward, mode "train": the bottom-up pass through every layer -- the first layer of each coarser level downsamples
+    (tf_train.py:196: stride-2 up_conv1, resize 0.5) -- then the top-down pass back (down_deconv2 + resize 2 in the
+    downsampling layer); all weight-norm reparametrisations re-derived every step in batched launches."""
     import golden_inputs as gi
     import iaf_amd
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
@@ -410,41 +411,64 @@ def layers_bench(args, depths, dist, rank, n_gpus):
     for lvl, nlayer in enumerate(depths):
         H = 16 >> lvl
         L = []
-        for _ in range(nlayer):
+        for j in range(nlayer):
+            ds = lvl > 0 and j == 0                                         # tf_train.py:196
             p = {}
             for nm, (ci, co) in (("up_conv1", (hs, 2 * zs + 2 * hs)), ("up_conv3", (hs, hs)),
-                                 ("down_conv1", (hs, 4 * zs + 2 * hs)), ("down_conv2", (hs + zs, hs))):
+                                 ("down_conv1", (hs, 4 * zs + 2 * hs))):
                 for k, v in gi.conv_params(wrng, ci, co).items():
                     p[nm + "/" + k] = dev(v)
+            last = gi.deconv_params(wrng, hs + zs, hs) if ds else gi.conv_params(wrng, hs + zs, hs)
+            for k, v in last.items():
+                p[("down_deconv2/" if ds else "down_conv2/") + k] = dev(v)
             for k, v in gi.ar_multiconv2d_params(wrng, zs, [hs] * args.depth_ar, [zs, zs]).items():
                 p["ar_multiconv2d/" + k] = dev(v)
-            layer = iaf_amd.IAFLayer(zs, hs, depth_ar=args.depth_ar, kl_min=0.25)
+            layer = iaf_amd.IAFLayer(zs, hs, depth_ar=args.depth_ar, kl_min=0.25, downsample=ds)
+            layer.posterior.stack.set_precision(args.precision)
             layer.load(p)
             L.append(dict(layer=layer, params=p, eps=dev(rng.standard_normal((B, zs, H, H)))))
-        levels.append(dict(H=H, layers=L, up_in=dev(rng.standard_normal((B, hs, H, H))),
-                           down_in=dev(rng.standard_normal((B, hs, H, H)))))
+        levels.append(dict(H=H, layers=L))
+    up_in = dev(0.5 * rng.standard_normal((B, hs, 16, 16)))
+    Htop = 16 >> (len(depths) - 1)
+    down_in = dev(0.5 * rng.standard_normal((B, hs, Htop, Htop)))
     all_layers = [L for lv in levels for L in lv["layers"]]
     prep_s = iaf_amd.PrepBatch([L["layer"].posterior.stack for L in all_layers])
-    prep_c = iaf_amd.ConvPrepBatch([c for L in all_layers for c in L["layer"].convs()])
+    # plain convs in one batched prep launch; a downsampling layer's deconv has its own (two small launches)
+    bconvs, cplist, deconvs = [], [], []
+    for L in all_layers:
+        lay, p = L["layer"], L["params"]
+        for nm in ("up_conv1", "up_conv3", "down_conv1") + (() if lay.downsample else ("down_conv2",)):
+            bconvs.append(getattr(lay, nm))
+            cplist.append((p[nm + "/V"], p[nm + "/g"], p[nm + "/b"]))
+        if lay.downsample:
+            deconvs.append((lay.down_conv2, p["down_deconv2/V"], p["down_deconv2/g"], p["down_deconv2/b"]))
+    prep_c = iaf_amd.ConvPrepBatch(bconvs)
     splist = [iaf_amd.IAFLayer.stack_params(L["params"]) for L in all_layers]
-    cplist = [t for L in all_layers for t in iaf_amd.IAFLayer.conv_params(L["params"])]
 
     def step(autotune=False):
         if not args.cached_weights:
             prep_s.run(splist)
             prep_c.run(cplist)
+            for cv, V, g, b in deconvs:
+                cv.prepare_deconv(V, g, b, force=True)
         outs = []
-        for lv in levels:                         # bottom-up (tf_train.py:188-192)
-            h = lv["up_in"]
+        h = up_in
+        for lv in levels:                         # bottom-up (tf_train.py:188-192), chained across levels
             for L in lv["layers"]:
                 h = L["layer"].up(h, autotune=autotune)
+        h = down_in
         for lv in reversed(levels):               # top-down (tf_train.py:195-200)
-            h = lv["down_in"]
             for L in reversed(lv["layers"]):
                 h, kl_obj, kl_cost = L["layer"].down(h, L["eps"], autotune=autotune)
                 outs.append((kl_obj, kl_cost))
-            outs.append(h)
+        outs.append(h)
         return outs
+
+    if not args.no_autotune and args.depth_ar > 0:      # masked stacks: kernel family / launch shape per layer
+        for lv in levels:
+            for L in lv["layers"]:
+                H = lv["H"]
+                L["layer"].posterior.stack.autotune(torch.randn(B, zs, H, H, device="cuda"), torch.randn(B, hs, H, H, device="cuda"), reps=10)
 
     stream = torch.cuda.Stream()
     graph = None
@@ -478,7 +502,7 @@ def layers_bench(args, depths, dist, rank, n_gpus):
         kt = []
         for L in levels[0]["layers"]:
             cv = L["layer"].down_conv1
-            x = levels[0]["down_in"]
+            x = up_in
             call = lambda: cv(x, elu_input=True, split=[zs] * 4 + [hs] * 2)
             call()
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -501,6 +525,7 @@ def layers_bench(args, depths, dist, rank, n_gpus):
     total_fl = 0.0
     for lv in levels:
         for L in lv["layers"]:
+            # useful FLOPs: a downsampling layer's strided convs are counted at their minimal cost (they run at 4x that)
             total_fl += sum(c.work(B, lv["H"], lv["H"])[0] for c in L["layer"].convs())
             total_fl += L["layer"].posterior.stack.step_work(B, lv["H"], lv["H"])["live_flops"]
     emit({
@@ -508,9 +533,10 @@ def layers_bench(args, depths, dist, rank, n_gpus):
         "value": n_gpus * B / (elapsed / args.steps), "unit": "samples/s", "n_gpus": n_gpus, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "cifar10 z_size=%d h_size=%d depths=%s depth_ar=%d bs=%d per GPU, kl_min=0.25: %d non-downsampling "
-                               "IAFLayers (tf_train.py:23-95), up pass then down pass, chained within a level"
-                               % (zs, hs, depths, args.depth_ar, B, len(all_layers)),
+        "config": {"workload": "cifar10 z_size=%d h_size=%d depths=%s depth_ar=%d bs=%d per GPU, kl_min=0.25: %d IAFLayers "
+                               "(tf_train.py:23-95) as one connected model -- up pass 16x16 -> %dx%d through the downsampling "
+                               "layer of each coarser level, then the down pass back"
+                               % (zs, hs, depths, args.depth_ar, B, len(all_layers), Htop, Htop),
                    "global_batch": n_gpus * B, "launch": "hipGraph replay" if graph is not None else "eager",
                    "weights": "re-derived every step (2 batched launches)" if not args.cached_weights else "prepared once",
                    "live_gflop_per_step": total_fl / 1e9,
