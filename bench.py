@@ -700,6 +700,105 @@ def layers_train_bench(args, depths, dist, rank, n_gpus):
             "exchange": exchange})
 
 
+def iw_eval_bench(args, depths, dist, rank, n_gpus):
+    """BASELINE configs[4]: importance-weighted ELBO evaluation, inference only.  One STEP = one pass of `--batch` (256)
+    rows -- 256 images x 1 importance sample (the Theano driver's order, train.py:194-203) -- through the fused posterior
+    block of every layer (10 at 16x16 + 10 at 8x8: sample, logqs, IAF step, log-det, logps, KL sums), the column sum of
+    the per-layer KL costs (tf_train.py:198-200) and the update of the per-image running log-sum-exp
+    (distributions.py:55-62 without ever materialising the [n, k] weights).  k = --iw-k passes complete one estimate;
+    value = importance samples (rows) per second, config.images_per_s_at_k = value / k.  log p(x|z) comes from the
+    decoder (out of scope): synthetic."""
+    import iaf_amd
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+    B = args.batch
+    rng = np.random.RandomState(2468 + rank)
+    wrng = np.random.RandomState(99)
+    stacks, inputs = [], []
+    for lvl, nlayer in enumerate(depths):
+        H = 16 >> lvl
+        for _ in range(nlayer):
+            params, _, _ = make_layer_inputs(wrng, B, args.n_z, args.n_h, args.depth_ar, H)
+            st = iaf_amd.ARStack(args.n_z, [args.n_h] * args.depth_ar)
+            st.set_precision(args.precision)
+            st.prepare({k: dev(v) for k, v in params.items()})
+            f = lambda c, sc=1.0: dev(sc * rng.standard_normal((B, c, H, H)))
+            inputs.append((f(args.n_z), f(args.n_z, 0.25), f(args.n_z), f(args.n_z, 0.25), f(args.n_z), f(args.n_z, 0.25),
+                           f(args.n_h), f(args.n_h), f(args.n_z)))
+            if not args.no_autotune and args.depth_ar > 0:
+                st.autotune(inputs[-1][0], inputs[-1][6], reps=10)
+            stacks.append(st)
+    log_pxz = dev(-7000.0 + 30.0 * rng.standard_normal(B))
+    ev = iaf_amd.IWEvaluator(stacks, kl_min=0.25)
+
+    def one_pass():
+        ev.run_pass(inputs, log_pxz)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    stream = torch.cuda.Stream()
+    graph = None
+    with torch.cuda.stream(stream):
+        one_pass()
+        stream.synchronize()
+        if not args.no_graph:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                one_pass()
+        run = graph.replay if graph is not None else one_pass
+        for _ in range(args.warmup):
+            run()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        # dominant kernel: the n_h -> n_h masked conv at 16x16 with B rows
+        dom = max(args.depth_ar - 1, 0)
+        z16, c16 = inputs[0][0], inputs[0][6]
+        k_ms = float(np.mean([stacks[i].time_layer(dom, z16, c16, reps=20) for i in range(min(3, depths[0]))]))
+        if graph is not None:
+            ev.state.k += args.warmup + args.steps      # replays folded passes into the device state behind Python's back
+        bound = ev.result()
+        torch.cuda.synchronize()
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        return
+    lw = stacks[0].layer_work(dom, B, 16, 16)
+    kern = stacks[0].layer_precision(dom, B, 16, 16)
+    peak = PEAK_BF16X3_TFLOPS if kern == "bf16x3" else PEAK_F32_MFMA_TFLOPS
+    ach = lw["live_flops"] / (k_ms * 1e-3) / 1e12
+    step_fl = sum(d * stacks[0].step_work(B, 16 >> i, 16 >> i)["live_flops"] for i, d in enumerate(depths))
+    rows_per_s = n_gpus * B / (elapsed / args.steps)
+    emit({
+        "metric": "IW-ELBO evaluation importance-samples/sec (posterior blocks of every layer + streaming log-sum-exp)",
+        "value": rows_per_s, "unit": "samples/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if args.precision == "f32" else "f32 (bf16x3 split-product MFMA where it wins, fp32 accumulate)",
+        "data": "synthetic",
+        "config": {"workload": "10000-sample importance-weighted ELBO eval, inference only (BASELINE configs[4]): cifar10 n_z=%d "
+                               "n_h=%d depths=%s depth_ar=%d, %d rows per pass (= %d images x 1 sample), k = %d passes per estimate"
+                               % (args.n_z, args.n_h, depths, args.depth_ar, B, B, args.iw_k),
+                   "global_batch": n_gpus * B, "k": args.iw_k, "images_per_s_at_k": rows_per_s / args.iw_k,
+                   "seconds_per_estimate_of_%d_images" % B: args.iw_k * elapsed / args.steps,
+                   "launch": "hipGraph replay of one pass" if graph is not None else "eager",
+                   "passes_folded_so_far": ev.k, "finite_bound": bool(torch.isfinite(bound).all().item()),
+                   "model_tflops": step_fl / (elapsed / args.steps) / 1e12,
+                   "parallelism": "dp%d (images sharded over ranks, no collective)" % n_gpus},
+        "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                     "frac_of_f32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS, "dominant_kernel_family": kern,
+                     "kernel": "masked 3x3 conv %d->%d, B=%d 16x16" % (args.n_h, args.n_h, B), "avg_launch_us": 1e3 * k_ms,
+                     "flops_per_launch_live": lw["live_flops"], "bytes_per_launch": lw["bytes"],
+                     "step": {"live_flops_per_step": step_fl, "frac_of_f32_mfma_peak": step_fl / (elapsed / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS}}})
+
+
 def main():
     args = parse()
     depths = [int(d) for d in args.depths.split(",") if d]
@@ -708,6 +807,13 @@ def main():
 
     import iaf_amd
     iaf_amd._capi.lib()           # fail loudly if the HIP engine is not built
+    if args.iw_eval:
+        if args.batch == 32:
+            args.batch = 256              # configs[4]: bs = 256
+        iw_eval_bench(args, depths, dist, rank, n_gpus)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     if args.layers and args.train:
         layers_train_bench(args, depths, dist, rank, n_gpus)
         if dist is not None:

@@ -8,7 +8,8 @@ from .layers import (ARStack, PrepBatch, ConvPrepBatch, WnBwdBatch, WNConv2d, co
 from .distributions import (DiagonalGaussian, discretized_logistic, compute_lowerbound, gaussian_diag_logps, logsumexp, repeat,  # noqa: F401
                             StreamingLowerBound)
 from .iaf_layer import IAFPosterior, IAFLayer  # noqa: F401
+from .iw_eval import IWEvaluator  # noqa: F401
 
 __all__ = ["IafHipError", "UnsupportedError", "ARStack", "PrepBatch", "VariableStore", "ar_multiconv2d", "get_conv_ar_mask", "get_linear_ar_mask", "multiconv2d", "variable_scope",
            "default_store", "DiagonalGaussian", "compute_lowerbound", "gaussian_diag_logps", "logsumexp", "repeat",
-           "StreamingLowerBound", "IAFPosterior", "IAFLayer", "WNConv2d", "ConvPrepBatch", "WnBwdBatch", "conv2d", "ar_conv2d", "discretized_logistic", "split", "resample2", "resize_nearest_neighbor"]
+           "StreamingLowerBound", "IAFPosterior", "IAFLayer", "IWEvaluator", "WNConv2d", "ConvPrepBatch", "WnBwdBatch", "conv2d", "ar_conv2d", "discretized_logistic", "split", "resample2", "resize_nearest_neighbor"]

@@ -85,6 +85,7 @@ SIGNATURES = {
     "iaf_layer_work": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int] +
                        [ctypes.POINTER(ctypes.c_double)] * 3),
     "iaf_step_work": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int] + [ctypes.POINTER(ctypes.c_double)] * 3),
+    "iaf_colsum": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, _vp]),
     "iaf_resample2": (ctypes.c_int, [_c_float_p, _c_float_p] + [ctypes.c_int] * 5 + [_vp]),
     "iaf_conv3x3_prepare_deconv": (ctypes.c_int, [_vp, _c_float_p, _c_float_p, _c_float_p, _vp]),
     "iaf_noise_from_sample": (ctypes.c_int, [_c_float_p] * 6 + [ctypes.c_size_t, _vp]),

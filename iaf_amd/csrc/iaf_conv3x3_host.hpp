@@ -153,6 +153,22 @@ extern "C" int iaf_noise_from_sample(const float* z, const float* qz_mean, const
     return (int)hipGetLastError();
 }
 
+// out[j] = sum_i mat[i][j]: the per-row KL costs of all layers of a model -> sum_kl_costs (tf_train.py:198-200:
+// `kl_cost += cur_cost` over the layer loop), the second argument of compute_lowerbound
+__global__ __launch_bounds__(256) void iaf_colsum_kernel(const float* __restrict__ mat, float* __restrict__ out, int m, int n) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    float s = 0.f;
+    for (int i = 0; i < m; ++i) s += mat[(size_t)i * n + j];
+    out[j] = s;
+}
+extern "C" int iaf_colsum(const float* mat, float* out, int m, int n, void* stream) {
+    if (!mat || !out) return IAF_ERR_NULL;
+    if (m <= 0 || n <= 0) return IAF_ERR_SHAPE;
+    hipLaunchKernelGGL(iaf_colsum_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, mat, out, m, n);
+    return (int)hipGetLastError();
+}
+
 // weight prep of many plain convs in one launch (the four convs of every IAFLayer of a model): descriptors in device
 // memory, refreshed per run like iaf_prep_batch_run
 struct iaf_conv3x3_prep_batch {

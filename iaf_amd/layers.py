@@ -406,17 +406,22 @@ class ARStack(object):
         return out
 
     def posterior_block(self, qz_mean, qz_logsd, rz_mean, rz_logsd, pz_mean, pz_logsd, up_context, down_context, eps,
-                        kl_min, want_kl_elem=False):
-        """tf_train.py:56-85 (mode "train") -> dict(z, kl_obj[B], kl_cost[B] [, kl_elem])."""
+                        kl_min, want_kl_elem=False, out=None):
+        """tf_train.py:56-85 (mode "train") -> dict(z, kl_obj[B], kl_cost[B] [, kl_elem]).
+        out: optional dict of pre-allocated result tensors (z, kl_obj, kl_cost) -- e.g. rows of a [layers, B] matrix."""
         B, H, W = self._dims(qz_mean, up_context)
         for nm, t in (("qz_logsd", qz_logsd), ("rz_mean", rz_mean), ("rz_logsd", rz_logsd), ("pz_mean", pz_mean),
                       ("pz_logsd", pz_logsd), ("eps", eps)):
             _check_act(t, nm, qz_mean.shape)
         if self.depth_ar > 0:
             _check_act(down_context, "down_context", up_context.shape)
-        z = torch.empty_like(qz_mean)
-        kl_obj = torch.empty(B, dtype=torch.float32, device=z.device)
-        kl_cost = torch.empty_like(kl_obj)
+        out = out or {}
+        z = out.get("z") if out.get("z") is not None else torch.empty_like(qz_mean)
+        kl_obj = out.get("kl_obj") if out.get("kl_obj") is not None else torch.empty(B, dtype=torch.float32, device=z.device)
+        kl_cost = out.get("kl_cost") if out.get("kl_cost") is not None else torch.empty(B, dtype=torch.float32, device=z.device)
+        _check_act(z, "out z", qz_mean.shape)
+        _check_act(kl_obj, "out kl_obj", (B,))
+        _check_act(kl_cost, "out kl_cost", (B,))
         kl_elem = torch.empty_like(qz_mean) if want_kl_elem else None
         ws, need = self.workspace(B, H, W, z.device)
         _capi.check(_capi.lib().iaf_posterior_block_forward(

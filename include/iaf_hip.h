@@ -190,6 +190,9 @@ int iaf_compute_lowerbound(const float* log_pxz, const float* sum_kl, float* out
 int iaf_lowerbound_stream_init(float* run_max, float* run_sum, int n, void* stream);
 int iaf_lowerbound_stream_update(float* run_max, float* run_sum, const float* log_pxz, const float* sum_kl,
                                  int n, int k_chunk, void* stream);
+/* out[j] = sum_i mat[i*n + j], i < m: the running `kl_cost += cur_cost` over a model's layers (tf_train.py:198-200) when
+ * every layer wrote its [n] KL costs into one row of a [m, n] matrix */
+int iaf_colsum(const float* mat, float* out, int m, int n, void* stream);
 int iaf_lowerbound_stream_finalize(const float* run_max, const float* run_sum, float* out, int n, int k_total,
                                    void* stream);
 

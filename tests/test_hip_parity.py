@@ -687,3 +687,32 @@ def test_prepare_sees_weights_updated_by_the_device_optimiser(amd):
     np.testing.assert_allclose(host(z_new), ez, atol=ATOL, rtol=0)
     np.testing.assert_allclose(host(logsd), es, atol=ATOL, rtol=0)
     assert np.abs(host(z_new) - before).max() > 1e-3      # and the update was large enough to matter
+
+
+def test_iw_evaluator_streamed_bound_vs_compute_lowerbound(amd):
+    """BASELINE configs[4] code path (iaf_amd.IWEvaluator: posterior block of every layer -> column sum of the KL costs ->
+    streaming log-sum-exp) at a small k against the reference formula on the MATERIALISED weights: the oracle's posterior
+    blocks give sum_kl [n, k], compute_lowerbound(log_pxz, sum_kl, k) (distributions.py:55-62) the bound"""
+    n, k, n_z, n_h, d = 6, 7, 32, 64, 1
+    rng = np.random.RandomState(31)
+    cfgs = [(8, 8), (4, 4)]                                           # two "layers" at two resolutions
+    stacks, fixed, params = [], [], []
+    for H, W in cfgs:
+        p = gi.ar_multiconv2d_params(rng, n_z, [n_h] * d, [n_z, n_z])
+        st = amd.ARStack(n_z, [n_h] * d)
+        st.prepare(dev_params(p))
+        f = lambda c, sc=1.0: sc * rng.standard_normal((n, c, H, W))
+        fixed.append([f(n_z), 0.25 * f(n_z), f(n_z), 0.25 * f(n_z), f(n_z), 0.25 * f(n_z), f(n_h), f(n_h)])
+        stacks.append(st); params.append(p)
+    ev = amd.IWEvaluator(stacks, kl_min=0.25)
+    lp = -300.0 + 10.0 * rng.standard_normal((n, k))
+    sum_kl = np.zeros((n, k))
+    for j in range(k):
+        eps = [rng.standard_normal((n, n_z, H, W)) for H, W in cfgs]
+        ev.run_pass([tuple(dev(a) for a in fx) + (dev(e),) for fx, e in zip(fixed, eps)], dev(lp[:, j]))
+        for fx, e, p in zip(fixed, eps, params):
+            blk = O.posterior_block(*[f32(a) for a in fx], f32(e), f32_params(p), [n_h] * d, 0.25)
+            sum_kl[:, j] += blk["kl_cost"]
+    assert ev.k == k
+    ref = O.compute_lowerbound(f32(lp).reshape(-1), sum_kl.reshape(-1), k)
+    np.testing.assert_allclose(host(ev.result()), ref, rtol=2e-5, atol=5e-3)
