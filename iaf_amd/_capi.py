@@ -18,6 +18,7 @@ IAF_PRECISION_F32 = 0
 IAF_PRECISION_BF16X3 = 1
 IAF_VARIANT_TF = 0
 IAF_VARIANT_THEANO = 1
+IAF_VARIANT_THEANO_FLIPMASK = 2
 
 _c_float_p = ctypes.c_void_p      # device pointers travel as integers (tensor.data_ptr())
 _vp = ctypes.c_void_p
@@ -85,6 +86,8 @@ SIGNATURES = {
     "iaf_layer_work": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int] +
                        [ctypes.POINTER(ctypes.c_double)] * 3),
     "iaf_step_work": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int] + [ctypes.POINTER(ctypes.c_double)] * 3),
+    "iaf_kl_free_bits": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 3 + [ctypes.c_float, _c_float_p, _vp]),
+    "iaf_kl_combine": (ctypes.c_int, [_c_float_p] * 4 + [ctypes.c_size_t, _vp]),
     "iaf_colsum": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, _vp]),
     "iaf_resample2": (ctypes.c_int, [_c_float_p, _c_float_p] + [ctypes.c_int] * 5 + [_vp]),
     "iaf_conv3x3_prepare_deconv": (ctypes.c_int, [_vp, _c_float_p, _c_float_p, _c_float_p, _vp]),

@@ -153,6 +153,20 @@ extern "C" int iaf_noise_from_sample(const float* z, const float* qz_mean, const
     return (int)hipGetLastError();
 }
 
+// kl = logq0 + logdet - logp: models.py:175,298,328 when the three terms come from separate launches (posterior
+// 'up_iaf2_nl': the IAF step runs in the up pass, the prior is only known in the down pass)
+__global__ __launch_bounds__(256) void iaf_kl_combine_kernel(const float* __restrict__ logq0, const float* __restrict__ logdet,
+                                                            const float* __restrict__ logp, float* __restrict__ kl, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) kl[i] = (logq0[i] + logdet[i]) - logp[i];
+}
+extern "C" int iaf_kl_combine(const float* logq0, const float* logdet, const float* logp, float* kl, size_t n, void* stream) {
+    if (!logq0 || !logdet || !logp || !kl) return IAF_ERR_NULL;
+    if (n == 0) return IAF_ERR_SHAPE;
+    hipLaunchKernelGGL(iaf_kl_combine_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)stream, logq0, logdet, logp, kl, n);
+    return (int)hipGetLastError();
+}
+
 // out[j] = sum_i mat[i][j]: the per-row KL costs of all layers of a model -> sum_kl_costs (tf_train.py:198-200:
 // `kl_cost += cur_cost` over the layer loop), the second argument of compute_lowerbound
 __global__ __launch_bounds__(256) void iaf_colsum_kernel(const float* __restrict__ mat, float* __restrict__ out, int m, int n) {

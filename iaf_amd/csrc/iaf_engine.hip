@@ -210,7 +210,7 @@ extern "C" int iaf_stack_create(iaf_stack_t** out, int n_z, int n_h, int depth_a
     if (!out) return IAF_ERR_NULL;
     *out = nullptr;
     if (n_z <= 0 || n_h <= 0 || depth_ar < 0 || depth_ar > MAX_GEMM_LAYERS - 1) return IAF_ERR_SHAPE;
-    if (variant != IAF_VARIANT_TF && variant != IAF_VARIANT_THEANO) return IAF_ERR_UNSUPPORTED;
+    if (variant != IAF_VARIANT_TF && variant != IAF_VARIANT_THEANO && variant != IAF_VARIANT_THEANO_FLIPMASK) return IAF_ERR_UNSUPPORTED;
     if (depth_ar > 0 && !(n_z % n_h == 0 || n_h % n_z == 0)) return IAF_ERR_NOT_MULTIPLE;   // layers.py:116
     const bool generic = (n_z % 16 != 0 || (depth_ar > 0 && n_h % 16 != 0) || n_z > 16 * PREP_MAXI ||
                           (depth_ar > 0 && n_h > 16 * PREP_MAXI));
@@ -235,12 +235,12 @@ extern "C" int iaf_stack_create(iaf_stack_t** out, int n_z, int n_h, int depth_a
         L.ncot = (L.cout + 15) / 16;
         default_tuning(L, is_out);
         count_macs(L, cin, each, L.zerodiag, L.npair);
-        s->weight_bytes += (size_t)L.npair * (9 * (size_t)(cin + (variant == IAF_VARIANT_THEANO ? 1 : 0)) * each + 2 * (size_t)each) * sizeof(float);
+        s->weight_bytes += (size_t)L.npair * (9 * (size_t)(cin + (variant != IAF_VARIANT_TF ? 1 : 0)) * each + 2 * (size_t)each) * sizeof(float);
         int rc;
         const size_t wfloats = generic ? (size_t)NTAPS * cin * L.cout : (size_t)L.nchunk * NTAPS * L.ncot * 256;
         if ((rc = (int)hipMalloc(&L.wp, wfloats * sizeof(float))) != 0 ||
             (rc = (int)hipMalloc(&L.bias, (size_t)L.cout * sizeof(float))) != 0 ||
-            (variant == IAF_VARIANT_THEANO && (rc = (int)hipMalloc(&L.border, (size_t)4 * L.cout * sizeof(float))) != 0) ||
+            (variant != IAF_VARIANT_TF && (rc = (int)hipMalloc(&L.border, (size_t)4 * L.cout * sizeof(float))) != 0) ||
             (rc = (int)hipMalloc(&L.lim, (size_t)L.ncot * sizeof(int))) != 0 ||
             (!generic && cin % 32 == 0 &&
              (rc = (int)hipMalloc(&L.wp3, (size_t)(cin / 32) * NTAPS * L.ncot * 3 * 1024)) != 0)) {
@@ -938,6 +938,19 @@ extern "C" int iaf_posterior_block_forward(iaf_stack_t* s, const float* qz_mean,
     const int rows = B * s->n_z;
     hipLaunchKernelGGL(iaf_kl_rowsum_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, p.kl_elem, ws.rowsum, rows, H * W);
     hipLaunchKernelGGL(iaf_kl_finish_kernel, dim3(1), dim3(256), 0, st, ws.rowsum, kl_obj, kl_cost, B, s->n_z, kl_min, (float*)nullptr);
+    return (int)hipGetLastError();
+}
+
+// free bits on given KL elements (tf_train.py:77-85; models.py:455-466): kl_elem [B,C,H,W] -> kl_obj [B], kl_cost [B];
+// scratch: B*C floats
+extern "C" int iaf_kl_free_bits(const float* kl_elem, float* kl_obj, float* kl_cost, int B, int C, int HW, float kl_min,
+                                float* scratch, void* stream) {
+    if (!kl_elem || !kl_obj || !kl_cost || !scratch) return IAF_ERR_NULL;
+    if (B <= 0 || C <= 0 || HW <= 0) return IAF_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int rows = B * C;
+    hipLaunchKernelGGL(iaf_kl_rowsum_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, kl_elem, scratch, rows, HW);
+    hipLaunchKernelGGL(iaf_kl_finish_kernel, dim3(1), dim3(256), 0, st, (const float*)scratch, kl_obj, kl_cost, B, C, kl_min, (float*)nullptr);
     return (int)hipGetLastError();
 }
 

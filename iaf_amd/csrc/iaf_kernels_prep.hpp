@@ -131,6 +131,13 @@ __device__ __forceinline__ void prep_tile_theano(const PrepLayer& L, int gt, flo
     const int oo = threadIdx.x & 15, cs = threadIdx.x >> 4;
     const int o = src_tile * 16 + oo;
     const int n_out = L.cout_each, n_in = L.cin;
+    // flipmask=True (ar.py:263-264): mask = mask[::-1,::-1,::-1,::-1] over [n_out, n_in+1, 3, 3].  The spatial flip moves
+    // the live filter positions to the mirrored ones (tap t then reads filter position (2-kh, 2-kw) and -- the conv being
+    // a true convolution -- looks right/below like the TF statement; the launch picks that geometry); the channel flips
+    // turn the centre-tap rule into  live'(i, o) = live(n_in - i, n_out-1-o)  over the n_in+1 channels INCLUDING the
+    // border-indicator channel (index n_in): real channel 0 maps to the (always masked) border column, and the border
+    // channel's own centre tap maps to column 0 -- it multiplies zeros inside the image but it does enter the l2 norm.
+    const bool flip = (L.variant == IAF_VARIANT_THEANO_FLIPMASK);
     const float sval = L.g[which][o], bval = L.b[which][o];
     const float* wo = Wt + (size_t)o * (n_in + 1) * 9;
     float v[NTAPS][NCH];
@@ -141,7 +148,7 @@ __device__ __forceinline__ void prep_tile_theano(const PrepLayer& L, int gt, flo
         for (int t = 0; t < NTAPS; ++t) {
             const int kh = (t == 0 || t == 1) ? 1 : 2;
             const int kw = (t == 0) ? 1 : (t == 1 ? 2 : t - 2);
-            v[t][it] = wo[(size_t)ci * 9 + kh * 3 + kw];
+            v[t][it] = wo[(size_t)ci * 9 + (flip ? (2 - kh) * 3 + (2 - kw) : kh * 3 + kw)];
         }
     }
     float wb[NTAPS - 1];   // border channel, taps 1..4 (thread cs == 0 accounts for it in the norm)
@@ -149,18 +156,29 @@ __device__ __forceinline__ void prep_tile_theano(const PrepLayer& L, int gt, flo
     for (int t = 1; t < NTAPS; ++t) {
         const int kh = (t == 1) ? 1 : 2;
         const int kw = (t == 1) ? 2 : t - 2;
-        wb[t - 1] = wo[(size_t)n_in * 9 + kh * 3 + kw];
+        wb[t - 1] = wo[(size_t)n_in * 9 + (flip ? (2 - kh) * 3 + (2 - kw) : kh * 3 + kw)];
     }
+    // l2normalize() first zeroes the centre tap of output rows [0, n_out/n_in) (or row 0) when zerodiagonal
+    // (ar.py:268-276): a no-op for the plain mask (those rows see nothing), live weights for the flipped one
+    const int k0 = (n_out >= n_in) ? n_out / n_in : 1;
+    const bool row_zeroed = L.zerodiag && o < k0;
     float ss = 0.f;
 #pragma unroll
     for (int it = 0; it < NCH; ++it) {
-        if (!made_live(cs + 16 * it, o, n_in, n_out, L.zerodiag)) v[0][it] = 0.f;   // ar.py:249-262 == the TF rule
+        const int ci = cs + 16 * it;
+        const bool live = flip ? (ci >= 1 && made_live(n_in - ci, n_out - 1 - o, n_in, n_out, L.zerodiag))
+                               : made_live(ci, o, n_in, n_out, L.zerodiag);   // ar.py:249-262 == the TF rule
+        if (!live || row_zeroed) v[0][it] = 0.f;
 #pragma unroll
         for (int t = 0; t < NTAPS; ++t) ss += v[t][it] * v[t][it];
     }
     if (cs == 0) {
 #pragma unroll
         for (int t = 0; t < NTAPS - 1; ++t) ss += wb[t] * wb[t];
+        if (flip && !row_zeroed && made_live(0, n_out - 1 - o, n_in, n_out, L.zerodiag)) {
+            const float wc = wo[(size_t)n_in * 9 + 4];       // border channel, centre tap: in the norm only
+            ss += wc * wc;
+        }
     }
     red[cs][oo] = ss;
     __syncthreads();
@@ -193,7 +211,7 @@ __device__ __forceinline__ void prep_tile_theano(const PrepLayer& L, int gt, flo
 #define PREP_PLAIN9 100   // PrepLayer.variant of a plain (unmasked, 9-tap) TF conv2d
 template <int DUMMY = 0>
 __device__ __forceinline__ void prep_dispatch(const PrepLayer& L, int gt, float (*red)[17], float* s_scale) {
-    if (L.variant == IAF_VARIANT_THEANO) {
+    if (L.variant == IAF_VARIANT_THEANO || L.variant == IAF_VARIANT_THEANO_FLIPMASK) {
         switch (L.nchunk) {
             case 1: prep_tile_theano<1>(L, gt, red, s_scale); break;
             case 2: prep_tile_theano<2>(L, gt, red, s_scale); break;

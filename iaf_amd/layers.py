@@ -114,8 +114,9 @@ class ARStack(object):
     depth_ar*[n_h2], models.py:92) -- all equal; n_out must be [n_z, n_z]."""
 
     def __init__(self, n_z, n_h, n_out=None, variant=_capi.IAF_VARIANT_TF):
-        if variant in ("tf", "theano"):
-            variant = _capi.IAF_VARIANT_THEANO if variant == "theano" else _capi.IAF_VARIANT_TF
+        if variant in ("tf", "theano", "theano_flipmask"):
+            variant = {"tf": _capi.IAF_VARIANT_TF, "theano": _capi.IAF_VARIANT_THEANO,
+                       "theano_flipmask": _capi.IAF_VARIANT_THEANO_FLIPMASK}[variant]
         self.variant = variant
         n_h = list(n_h)
         n_out = [n_z, n_z] if n_out is None else list(n_out)
@@ -173,7 +174,7 @@ class ARStack(object):
         [n_out, n_in+1, 3, 3] (ar.py:288-296); the engine's (V, g, b) slots carry (w, s, b)."""
         sizes = [self.n_z] + self.n_h_list
         tens = []
-        theano = self.variant == _capi.IAF_VARIANT_THEANO
+        theano = self.variant in (_capi.IAF_VARIANT_THEANO, _capi.IAF_VARIANT_THEANO_FLIPMASK)
         names = self.conv_names()
         for ci, nm in enumerate(names):
             n_in = sizes[min(ci, self.depth_ar)]
@@ -688,6 +689,18 @@ def split(x, split_dim, split_sizes):
     return out
 
 
+def kl_free_bits(kl, kl_min):
+    """[B, C, H, W] KL elements -> (kl_cost [B], kl_obj [B]) (tf_train.py:77-85) with the engine's reduction kernels"""
+    _check_act(kl, "kl")
+    B, C, H, W = (int(v) for v in kl.shape)
+    kl_obj = torch.empty(B, dtype=torch.float32, device=kl.device)
+    kl_cost = torch.empty_like(kl_obj)
+    scratch = torch.empty(B * C, dtype=torch.float32, device=kl.device)
+    _capi.check(_capi.lib().iaf_kl_free_bits(_ptr(kl), _ptr(kl_obj), _ptr(kl_cost), B, C, H * W, float(kl_min), _ptr(scratch),
+                                             _stream()))
+    return kl_cost, kl_obj
+
+
 class PrepBatch(object):
     """Weight prep (mask, l2-normalise, exp(g), repack) for MANY stacks in one launch -- what a model does once at
     the start of every step (the reference re-derives the normalised weights inside every conv2d call,
@@ -827,12 +840,13 @@ class _Struct(object):
 def multiconv2d(name, n_in, n_h, n_out, size_kernel=(3, 3), flipmask=False, nl="elu", w=None):
     """Mirror of graphy/nodes/ar.py:378-423 (the Theano statement of the operator): returns a callable struct
     `f(h, context, w)` -> [out_0, out_1] reading w[name+'_%d_w'|'_b'|'_s'] and w[name+'_out_%d_...'] (ar.py:288-296),
-    as constructed at models.py:63,92 with flipmask=False and nl='elu' (train.py:61)."""
+    as constructed at models.py:63,92 with nl='elu' (train.py:61); flipmask as in ar.py:263-264."""
     if isinstance(n_out, int):
         n_out = [n_out]
-    if tuple(size_kernel) != (3, 3) or flipmask or nl != "elu":
-        raise ValueError("the gfx950 engine implements size_kernel=(3,3), flipmask=False, nl='elu'")
-    stack = ARStack(n_in, list(n_h), list(n_out), variant=_capi.IAF_VARIANT_THEANO)
+    if tuple(size_kernel) != (3, 3) or nl != "elu":
+        raise ValueError("the gfx950 engine implements size_kernel=(3,3), nl='elu'")
+    stack = ARStack(n_in, list(n_h), list(n_out),
+                    variant=_capi.IAF_VARIANT_THEANO_FLIPMASK if flipmask else _capi.IAF_VARIANT_THEANO)
 
     def f(h, context, w, return_hiddens=False):
         if return_hiddens:

@@ -38,6 +38,8 @@ extern "C" {
 #define IAF_VARIANT_THEANO 1       /* graphy/nodes/ar.py statement: flipped kernel (taps look left/above), border-indicator
                                       input channel, exp(3*s) scale, +1e-8 in the norm.  Weights: V[i] = <name>_w OIHW
                                       [n_out][n_in+1][3][3], g[i] = <name>_s, b[i] = <name>_b (ar.py:288-296) */
+#define IAF_VARIANT_THEANO_FLIPMASK 2   /* the same with flipmask=True (graphy/nodes/ar.py:263-264): mask reversed along all four axes, so
+                                        * the conv depends on pixels right/below and on the HIGHER-numbered channels */
 
 /* ABI / build identification; also proves the library loaded. */
 int iaf_abi_version(void);
@@ -190,6 +192,14 @@ int iaf_compute_lowerbound(const float* log_pxz, const float* sum_kl, float* out
 int iaf_lowerbound_stream_init(float* run_max, float* run_sum, int n, void* stream);
 int iaf_lowerbound_stream_update(float* run_max, float* run_sum, const float* log_pxz, const float* sum_kl,
                                  int n, int k_chunk, void* stream);
+/* Free bits on given KL elements (tf_train.py:77-85): kl_cost[b] = sum_{c,h,w} kl; kl_obj[b] = sum_c max(mean_b sum_{h,w} kl,
+ * kl_min) (kl_min > 0) or kl_cost[b].  The Theano objective adds that per-layer value once, as a scalar (models.py:458-461).
+ * scratch: B*C floats. */
+int iaf_kl_free_bits(const float* kl_elem, float* kl_obj, float* kl_cost, int B, int C, int HW, float kl_min, float* scratch,
+                     void* stream);
+/* kl[i] = logq0[i] + logdet[i] - logp[i] (models.py:175, 298, 328), for posteriors whose three terms come from separate
+ * launches ('up_iaf2_nl': IAF step in the bottom-up pass, prior density in the top-down pass) */
+int iaf_kl_combine(const float* logq0, const float* logdet, const float* logp, float* kl, size_t n, void* stream);
 /* out[j] = sum_i mat[i*n + j], i < m: the running `kl_cost += cur_cost` over a model's layers (tf_train.py:198-200) when
  * every layer wrote its [n] KL costs into one row of a [m, n] matrix */
 int iaf_colsum(const float* mat, float* out, int m, int n, void* stream);

@@ -501,3 +501,64 @@ def theano_free_bits(kl, kl_min):
 
 
 LOG2PI = math.log(2 * math.pi)
+
+
+def theano_conv2d(h, w_, b_, s_):
+    """graphy/nodes/conv.py:122-260 (the plain conv around the IAF step: pad_channel=True, 'valid', l2norm=True,
+    logscale=True, no down/upsampling): kerns = w / sqrt(sum_{i,h,w} w^2) (NO epsilon, :163-165) * exp(3 s); true
+    convolution on the zero-padded input with the border-indicator channel; + b."""
+    ksize = w_.shape[2]
+    hp = theano_pad2dwithchannel(h, ksize)
+    kerns = w_ / np.sqrt(np.sum(w_ ** 2, axis=(1, 2, 3), keepdims=True))
+    kerns = kerns * np.exp(3.0 * s_).reshape([-1, 1, 1, 1])
+    kf = kerns[:, :, ::-1, ::-1]
+    n, c, H, W = hp.shape
+    oh, ow = H - ksize + 1, W - ksize + 1
+    y = np.zeros((n, w_.shape[0], oh, ow), dtype=np.result_type(hp, kf))
+    for a in range(ksize):
+        for b in range(ksize):
+            y += np.moveaxis(np.tensordot(hp[:, :, a:a + oh, b:b + ow], kf[:, :, a, b], axes=([1], [1])), 3, 1)
+    return y + b_.reshape([1, -1, 1, 1])
+
+
+def _theano_elu(h):
+    return np.where(h < 0, np.exp(np.minimum(h, 0)) - 1, h)
+
+
+def theano_cvae_layer(name, posterior, w, n_h, n_z, depth_ar, up_input, down_input, eps_up, eps_down, flipmask=False):
+    """models.cvae_layer (models.py:14-345) with prior 'diag', nl 'elu', no downsampling, for the two posteriors BASELINE
+    names: 'down_iaf2_nl' (:138-146 channel order, :201-210, 272-285, 295-298, 317-328) and 'up_iaf2_nl' (:168-176).
+    Channel order of up_conv1: [h_det, qz_mean, qz_logsd, context]; of down_conv1: [h_det, pz_mean, pz_logsd | rz_mean,
+    rz_logsd, down_context]; concat order [h_det, z] (:180, 318).  Returns dict(up_out, down_out, kl, z)."""
+    cw = lambda nm: (w[name + nm + "_w"], w[name + nm + "_b"], w[name + nm + "_s"])
+    pc = name + "_posterior_conv1"
+    h = theano_conv2d(_theano_elu(up_input), *cw("_up_conv1_1"))                                   # :139
+    h_det, qz_mean, qz_logsd = h[:, :n_h], h[:, n_h:n_h + n_z], h[:, n_h + n_z:n_h + 2 * n_z]        # :141-143
+    context = h[:, n_h + 2 * n_z:n_h + 2 * n_z + n_h]
+    res = {}
+    if posterior == "up_iaf2_nl":                                                                  # :168-176
+        z0 = qz_mean + np.exp(qz_logsd) * eps_up
+        logqs = gaussian_diag_logps(qz_mean, 2 * qz_logsd, z0)
+        z, arw_logsd = theano_iaf2_nl(z0, context, w, pc, n_z, [n_h] * depth_ar, flipmask)
+        logqs = logqs + arw_logsd
+        hu = np.concatenate([h_det, z], axis=1)
+    else:                                                                                          # :180-182
+        hu = h_det
+    res["up_out"] = up_input + 0.1 * theano_conv2d(_theano_elu(hu), *cw("_up_conv2"))             # :192
+    h = theano_conv2d(_theano_elu(down_input), *cw("_down_conv1"))                                 # :204-206
+    ncp = n_h + 2 * n_z                                                                            # n_conv_down_prior
+    if posterior == "down_iaf2_nl":                                                                # :272-285
+        rz_mean, rz_logsd = h[:, ncp:ncp + n_z], h[:, ncp + n_z:ncp + 2 * n_z]
+        post_mean, post_logvar = qz_mean + rz_mean, 2 * qz_logsd + 2 * rz_logsd
+        z0 = post_mean + np.exp(0.5 * post_logvar) * eps_down
+        logqs = gaussian_diag_logps(post_mean, post_logvar, z0)
+        down_context = h[:, ncp + 2 * n_z:ncp + 2 * n_z + n_h]
+        z, arw_logsd = theano_iaf2_nl(z0, context + down_context, w, pc, n_z, [n_h] * depth_ar, flipmask)
+        logqs = logqs + arw_logsd
+    pz_mean, pz_logsd = h[:, n_h:n_h + n_z], h[:, n_h + n_z:n_h + 2 * n_z]                          # :296-297
+    logps = gaussian_diag_logps(pz_mean, 2 * pz_logsd, z)                                          # :298
+    hd = np.concatenate([h[:, :n_h], z], axis=1)                                                   # :317-318
+    res["down_out"] = down_input + 0.1 * theano_conv2d(_theano_elu(hd), *cw("_down_conv2_1"))      # :325
+    res["kl"], res["z"] = logqs - logps, z
+    res["up_conv1"], res["down_conv1"] = theano_conv2d(_theano_elu(up_input), *cw("_up_conv1_1")), h
+    return res

@@ -151,8 +151,31 @@ THEANO_CASES = {
     "th_cfg1_4x4": (3, 32, [64], 4, 4, False),
     "th_tiny": (2, 4, [8, 8], 5, 3, False),
     "th_deep": (2, 16, [16, 16, 16], 4, 4, False),
+    "th_flip_cfg2_8x8": (2, 32, [160, 160], 8, 8, True),       # flipmask=True (ar.py:263-264)
+    "th_flip_tiny": (2, 4, [8, 8], 5, 3, True),
+    "th_flip_16_32": (3, 16, [32], 6, 5, True),
+}
+# the reference's cvae_layer (models.py:14-345) executed as a whole: (posterior, B, n_h, n_z, depth_ar, H, W, kl_min)
+CVAE_CASES = {
+    "cvae_down_iaf2_nl": ("down_iaf2_nl", 3, 32, 16, 2, 6, 5, 0.25),
+    "cvae_down_iaf2_nl_64": ("down_iaf2_nl", 2, 64, 32, 2, 8, 8, 0.25),
+    "cvae_up_iaf2_nl": ("up_iaf2_nl", 3, 32, 16, 2, 6, 5, 0.1),
+    "cvae_up_iaf2_nl_d4": ("up_iaf2_nl", 2, 64, 64, 4, 4, 4, 0.0),     # BASELINE configs[3]: n_z=64, depth_ar=4
 }
 THEANO_NAME = "1_posterior_conv1"
+
+
+def cvae_case_inputs(cname, shapes):
+    """weights (in sorted key order, shapes as the reference's constructors created them), inputs and noise of one
+    cvae_layer fixture -- regenerated from the case seed, like every other fixture's inputs"""
+    posterior, B, n_h, n_z, depth_ar, H, W, kl_min = CVAE_CASES[cname]
+    rng = np.random.RandomState(case_seed(cname))
+    w = {}
+    for k in sorted(shapes):
+        w[k] = (0.05 if k.endswith("_w") else 0.1) * rng.standard_normal(tuple(int(v) for v in shapes[k]))
+    up_input, down_input = rng.standard_normal((B, n_h, H, W)), rng.standard_normal((B, n_h, H, W))
+    eps_up, eps_down = rng.standard_normal((B, n_z, H, W)), rng.standard_normal((B, n_z, H, W))
+    return dict(w=w, up_input=up_input, down_input=down_input, eps_up=eps_up, eps_down=eps_down)
 
 
 def theano_case_inputs(cname):

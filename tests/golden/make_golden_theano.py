@@ -50,6 +50,56 @@ with contextlib.redirect_stdout(io.StringIO()):
     N.ar = load_py2("graphy.nodes.ar", "graphy/nodes/ar.py")
 
 
+class _NoiseQueue(object):
+    """stands in for G.rng_curand (graphy/__init__.py:17-21): hands out the fixture's noise in call order"""
+    def __init__(self):
+        self.q = []
+
+    def normal(self, size=None, **kw):
+        a = self.q.pop(0)
+        assert tuple(a.shape) == tuple(int(v) for v in size), (a.shape, size)
+        return S.TT(a)
+
+
+NOISE = _NoiseQueue()
+G.rng_curand = NOISE
+
+
+def gen_cvae_layers():
+    """models.cvae_layer (models.py:14-345) itself -- up(), down_q() with posterior down_iaf2_nl / up_iaf2_nl -- on random
+    weights; plus the free-bits lines of cvae1 (models.py:454-466, restated here: they sit inside the model function)."""
+    with contextlib.redirect_stdout(io.StringIO()):
+        models = load_py2("models", "models.py")
+    out = {}
+    for cname, (posterior, B, n_h, n_z, depth_ar, H, W, kl_min) in gi.CVAE_CASES.items():
+        w = {}
+        with contextlib.redirect_stdout(io.StringIO()):
+            layer = models.cvae_layer("1", "diag", posterior, P(n_h), P(n_h), P(n_z), P(depth_ar), False, "elu", (P(3), P(3)),
+                                      False, "nn", w)
+        shapes = {k: w[k].a.shape for k in w}
+        c = gi.cvae_case_inputs(cname, shapes)
+        for k in sorted(w):
+            w[k].set_value(c["w"][k])
+            out["%s/w_shape/%s" % (cname, k)] = np.asarray(shapes[k], dtype=np.int64)
+        up_input, down_input, eps_up, eps_down = c["up_input"], c["down_input"], c["eps_up"], c["eps_down"]
+        NOISE.q[:] = [eps_up] + ([eps_down] if posterior.startswith("down") else [])
+        with contextlib.redirect_stdout(io.StringIO()):
+            up_out = layer.up(S.TT(up_input), w)
+            down_out, kl = layer.down_q(S.TT(down_input), True, w)
+        assert not NOISE.q
+        kl = kl.a
+        kl_sum = kl.sum(axis=(1, 2, 3))                                        # models.py:455
+        if kl_min > 0:                                                         # :458-461
+            obj_kl = np.maximum(np.asarray(kl_min), kl.sum(axis=(2, 3)).mean(axis=0)).sum()
+        else:
+            obj_kl = kl_sum                                                    # :466
+        out.update({cname + "/up_out": up_out.a, cname + "/down_out": down_out.a,
+                    cname + "/kl": kl, cname + "/kl_sum": kl_sum, cname + "/obj_kl": np.asarray(obj_kl)})
+    path = os.path.join(HERE, "theano_cvae_layer.npz")
+    np.savez_compressed(path, **out)
+    print("wrote theano_cvae_layer.npz %.1f KiB, %d arrays" % (os.path.getsize(path) / 1024.0, len(out)))
+
+
 def main():
     out = {}
     for cname, (B, n_z, n_h, H, W, flip) in gi.THEANO_CASES.items():
@@ -65,19 +115,20 @@ def main():
             m_raw, s_raw = f(S.TT(z), S.TT(ctx), w)      # models.py:170, 281
         out[cname + "/m_raw"] = m_raw.a
         out[cname + "/s_raw"] = s_raw.a
-    # one conv on its own, both mask variants (ar.py:200-375)
-    for zd in (False, True):
-        rng = np.random.RandomState(77 + zd)
-        n_in, n_out, B, H, W = 8, 16, 2, 4, 5
+    # one conv on its own, both mask variants x flipmask (ar.py:200-375), n_out > n_in and n_out < n_in
+    for zd, flip, n_in, n_out in ((False, False, 8, 16), (True, False, 8, 16), (False, True, 16, 32), (True, True, 16, 32),
+                                  (True, True, 32, 16), (False, False, 32, 16)):
+        rng = np.random.RandomState(77 + zd + 2 * flip + n_in)
+        B, H, W = 2, 4, 5
         w = {}
         with contextlib.redirect_stdout(io.StringIO()):
-            f = N.ar.conv2d("c", P(n_in), P(n_out), (P(3), P(3)), zd, False, w=w)
+            f = N.ar.conv2d("c", P(n_in), P(n_out), (P(3), P(3)), zd, flip, w=w)
             wv = 0.05 * rng.standard_normal((n_out, n_in + 1, 3, 3))
             bv, sv = 0.1 * rng.standard_normal(n_out), 0.1 * rng.standard_normal(n_out)
             w["c_w"].set_value(wv); w["c_b"].set_value(bv); w["c_s"].set_value(sv)
             x = rng.standard_normal((B, n_in, H, W))
             y = f(S.TT(x), w)
-        key = "conv_zd%d" % int(zd)
+        key = "conv_zd%d" % int(zd) if (not flip and n_in == 8) else "conv_zd%d_flip%d_%d_%d" % (int(zd), int(flip), n_in, n_out)
         out[key + "/w"], out[key + "/b"], out[key + "/s"], out[key + "/x"], out[key + "/y"] = wv, bv, sv, x, y.a
     # pad2dwithchannel (conv.py:71-83)
     x = np.arange(2 * 3 * 2 * 3, dtype=np.float64).reshape(2, 3, 2, 3)
@@ -95,3 +146,4 @@ def main():
 
 if __name__ == "__main__":
     main()
+    gen_cvae_layers()

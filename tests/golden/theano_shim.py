@@ -131,6 +131,7 @@ def install():
     T.zeros = lambda shape, dtype=None: TT(np.zeros(tuple(int(s) for s in shape)))
     T.constant = lambda x: TT(x)
     T.switch = lambda c, a, b: TT(np.where(_v(c), _v(a), _v(b)))
+    T.concatenate = lambda xs, axis=0: TT(np.concatenate([_v(x) for x in xs], axis=axis))
 
     def set_subtensor(sub, val):
         base, idx = sub._base

@@ -716,3 +716,59 @@ def test_iw_evaluator_streamed_bound_vs_compute_lowerbound(amd):
     assert ev.k == k
     ref = O.compute_lowerbound(f32(lp).reshape(-1), sum_kl.reshape(-1), k)
     np.testing.assert_allclose(host(ev.result()), ref, rtol=2e-5, atol=5e-3)
+
+
+# ---------------------------------------------------------------- Theano rows a10 / a12: flipmask, the cvae_layer wrapper
+@pytest.mark.parametrize("cname", ["th_flip_cfg2_8x8", "th_flip_16_32"])
+def test_theano_flipmask_vs_reference_golden(amd, golden_dir, cname):
+    """flipmask=True (graphy/nodes/ar.py:263-264) against the outputs of the reference's own ar.py"""
+    g = np.load(os.path.join(golden_dir, "theano_ar.npz"))
+    B, n_z, n_h, H, W, flip = gi.THEANO_CASES[cname]
+    w, z, ctx = gi.theano_case_inputs(cname)
+    conv = amd.multiconv2d(gi.THEANO_NAME, n_z, n_h, [n_z, n_z], (3, 3), True, nl="elu", w=None)
+    m_raw, s_raw = conv(dev(z), dev(ctx), {k: dev(v) for k, v in w.items()})
+    np.testing.assert_allclose(host(m_raw), g[cname + "/m_raw"], atol=ATOL, rtol=0)
+    np.testing.assert_allclose(host(s_raw), g[cname + "/s_raw"], atol=ATOL, rtol=0)
+
+
+@pytest.mark.parametrize("shape", [(3, 32, 160, 2, 8, 8), (2, 64, 64, 4, 5, 3), (2, 32, 16, 1, 4, 4)], ids=lambda s: "B%d_z%d_h%d_d%d_%dx%d" % s)
+def test_theano_flipmask_vs_oracle(amd, shape):
+    """flipmask incl. n_h < n_z and the zerodiagonal quirk of l2normalize (ar.py:268-276) on the flipped mask"""
+    B, n_z, n_h, d, H, W = shape
+    rng = np.random.RandomState(500 + H)
+    name = "1_posterior_conv1"
+    w = _theano_params(rng, name, n_z, [n_h] * d)
+    z, ctx = rng.standard_normal((B, n_z, H, W)), rng.standard_normal((B, n_h, H, W))
+    conv = amd.multiconv2d(name, n_z, [n_h] * d, [n_z, n_z], (3, 3), True, nl="elu", w=None)
+    m_raw, s_raw = conv(dev(z), dev(ctx), {k: dev(v) for k, v in w.items()})
+    w32 = {k: f32(v) for k, v in w.items()}
+    em, es = O.theano_multiconv2d(f32(z), f32(ctx), w32, name, n_z, [n_h] * d, [n_z, n_z], flipmask=True)
+    np.testing.assert_allclose(host(m_raw), em, atol=ATOL, rtol=0)
+    np.testing.assert_allclose(host(s_raw), es, atol=ATOL, rtol=0)
+
+
+@pytest.mark.parametrize("cname", sorted(gi.CVAE_CASES))
+def test_cvae_layer_wrapper_vs_reference_golden(amd, golden_dir, cname):
+    """models.cvae_layer (posterior down_iaf2_nl / up_iaf2_nl) through iaf_amd.CVAELayerIAF: the plain Theano convs come
+    from the oracle (out of scope, pinned on the same fixture), slicing in the reference's channel order, the IAF
+    posterior and the Theano free bits on the GPU; compared with what the reference's own models.py produced"""
+    posterior, B, n_h, n_z, depth_ar, H, W, kl_min = gi.CVAE_CASES[cname]
+    g = np.load(os.path.join(golden_dir, "theano_cvae_layer.npz"))
+    pre = cname + "/w_shape/"
+    c = gi.cvae_case_inputs(cname, {k[len(pre):]: g[k] for k in g.files if k.startswith(pre)})
+    w32 = {k: f32(v) for k, v in c["w"].items()}
+    ref = O.theano_cvae_layer("1", posterior, w32, n_h, n_z, depth_ar, f32(c["up_input"]), f32(c["down_input"]), f32(c["eps_up"]),
+                              f32(c["eps_down"]))
+    layer = amd.CVAELayerIAF("1", n_h, n_z, depth_ar, posterior=posterior, kl_min=kl_min)
+    layer.load({k: dev(v) for k, v in c["w"].items()})
+    hu = layer.up(dev(ref["up_conv1"]), eps=dev(c["eps_up"]))
+    cw = lambda nm: (w32["1" + nm + "_w"], w32["1" + nm + "_b"], w32["1" + nm + "_s"])
+    elu = lambda t: np.where(t < 0, np.exp(np.minimum(t, 0)) - 1, t)
+    up_out = f32(c["up_input"]) + 0.1 * O.theano_conv2d(elu(host(hu)), *cw("_up_conv2"))
+    np.testing.assert_allclose(up_out, g[cname + "/up_out"], atol=ATOL, rtol=0)
+    d = layer.down_q(dev(ref["down_conv1"]), eps=dev(c["eps_down"]))
+    np.testing.assert_allclose(host(d["kl"]), g[cname + "/kl"], atol=ATOL, rtol=1e-5)
+    np.testing.assert_allclose(host(d["kl_sum"]), g[cname + "/kl_sum"], atol=2e-3, rtol=1e-4)
+    np.testing.assert_allclose(host(d["obj_kl"]), g[cname + "/obj_kl"], atol=2e-3, rtol=1e-4)
+    down_out = f32(c["down_input"]) + 0.1 * O.theano_conv2d(elu(host(d["h"])), *cw("_down_conv2_1"))
+    np.testing.assert_allclose(down_out, g[cname + "/down_out"], atol=ATOL, rtol=0)

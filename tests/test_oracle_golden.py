@@ -206,3 +206,43 @@ def test_iaf_layer_downsample_and_modes_vs_reference_golden(golden_dir, name):
     np.testing.assert_allclose(out, g[name + "/output"], rtol=1e-9, atol=1e-10)
     np.testing.assert_allclose(kl_obj, g[name + "/kl_obj"], rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(kl_cost, g[name + "/kl_cost"], rtol=1e-9, atol=1e-9)
+
+
+# ---------------------------------------------------------------- Theano: flipmask and the whole cvae_layer
+@pytest.mark.parametrize("key,zd,flip,n_in,n_out", [("conv_zd0_flip1_16_32", False, True, 16, 32), ("conv_zd1_flip1_16_32", True, True, 16, 32),
+                                                    ("conv_zd1_flip1_32_16", True, True, 32, 16), ("conv_zd0_flip0_32_16", False, False, 32, 16)])
+def test_theano_single_conv_flipmask_vs_reference_golden(golden_dir, key, zd, flip, n_in, n_out):
+    g = np.load(os.path.join(golden_dir, "theano_ar.npz"))
+    y = O.theano_ar_conv2d(g[key + "/x"], g[key + "/w"], g[key + "/b"], g[key + "/s"], n_in, n_out, zd, flip)
+    np.testing.assert_allclose(y, g[key + "/y"], rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize("cname", sorted(k for k, v in gi.THEANO_CASES.items() if v[5]))
+def test_theano_multiconv2d_flipmask_vs_reference_golden(golden_dir, cname):
+    g = np.load(os.path.join(golden_dir, "theano_ar.npz"))
+    B, n_z, n_h, H, W, flip = gi.THEANO_CASES[cname]
+    w, z, ctx = gi.theano_case_inputs(cname)
+    m, s = O.theano_multiconv2d(z, ctx, w, gi.THEANO_NAME, n_z, n_h, [n_z, n_z], flipmask=True)
+    np.testing.assert_allclose(m, g[cname + "/m_raw"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(s, g[cname + "/s_raw"], rtol=1e-10, atol=1e-12)
+
+
+def _cvae_case(golden_dir, cname):
+    g = np.load(os.path.join(golden_dir, "theano_cvae_layer.npz"))
+    pre = cname + "/w_shape/"
+    shapes = {k[len(pre):]: g[k] for k in g.files if k.startswith(pre)}
+    return g, gi.cvae_case_inputs(cname, shapes)
+
+
+@pytest.mark.parametrize("cname", sorted(gi.CVAE_CASES))
+def test_theano_cvae_layer_vs_reference_golden(golden_dir, cname):
+    """models.cvae_layer.up / .down_q executed from the reference's own models.py (make_golden_theano.py: gen_cvae_layers)"""
+    posterior, B, n_h, n_z, depth_ar, H, W, kl_min = gi.CVAE_CASES[cname]
+    g, c = _cvae_case(golden_dir, cname)
+    r = O.theano_cvae_layer("1", posterior, c["w"], n_h, n_z, depth_ar, c["up_input"], c["down_input"], c["eps_up"], c["eps_down"])
+    np.testing.assert_allclose(r["up_out"], g[cname + "/up_out"], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(r["down_out"], g[cname + "/down_out"], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(r["kl"], g[cname + "/kl"], rtol=1e-9, atol=1e-9)
+    obj, kl_sum = O.theano_free_bits(r["kl"], kl_min)
+    np.testing.assert_allclose(kl_sum, g[cname + "/kl_sum"], rtol=1e-10)
+    np.testing.assert_allclose(obj, g[cname + "/obj_kl"], rtol=1e-10)
