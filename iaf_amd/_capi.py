@@ -89,6 +89,7 @@ SIGNATURES = {
     "iaf_kl_free_bits": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 3 + [ctypes.c_float, _c_float_p, _vp]),
     "iaf_kl_combine": (ctypes.c_int, [_c_float_p] * 4 + [ctypes.c_size_t, _vp]),
     "iaf_colsum": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, _vp]),
+    "iaf_conv3x3_create_masked_theano": (ctypes.c_int, [ctypes.POINTER(_vp)] + [ctypes.c_int] * 4),
     "iaf_resample2": (ctypes.c_int, [_c_float_p, _c_float_p] + [ctypes.c_int] * 5 + [_vp]),
     "iaf_conv3x3_prepare_deconv": (ctypes.c_int, [_vp, _c_float_p, _c_float_p, _c_float_p, _vp]),
     "iaf_noise_from_sample": (ctypes.c_int, [_c_float_p] * 6 + [ctypes.c_size_t, _vp]),

@@ -11,6 +11,7 @@
 struct iaf_conv3x3 {
     int n_in, n_out;
     int mask_mode;     // 0 plain conv2d, 1 ar_conv2d(zerodiagonal=False), 2 ar_conv2d(zerodiagonal=True)
+    int variant = IAF_VARIANT_TF;   // masked convs only: the Theano statements of ar.conv2d (graphy/nodes/ar.py:200-375)
     bool generic, prepared;
     GemmLayer L;
     PrepLayer* h_desc = nullptr;   // pinned staging of the prep descriptor
@@ -29,6 +30,7 @@ extern "C" int iaf_conv3x3_destroy(iaf_conv3x3_t* c) {
     if (c->L.wp) (void)hipFree(c->L.wp);
     if (c->L.bias) (void)hipFree(c->L.bias);
     if (c->L.wpt) (void)hipFree(c->L.wpt);
+    if (c->L.border) (void)hipFree(c->L.border);
     if (c->own_dW) (void)hipFree(c->own_dW);
     if (c->own_dbp) (void)hipFree(c->own_dbp);
     if (c->h_desc) (void)hipHostFree(c->h_desc);
@@ -42,6 +44,19 @@ extern "C" int iaf_conv3x3_create(iaf_conv3x3_t** out, int n_in, int n_out) { re
 extern "C" int iaf_conv3x3_create_masked(iaf_conv3x3_t** out, int n_in, int n_out, int zerodiagonal) {
     if (n_in > 0 && n_out > 0 && !(n_in % n_out == 0 || n_out % n_in == 0)) return IAF_ERR_NOT_MULTIPLE;   // layers.py:116
     return conv3x3_create(out, n_in, n_out, zerodiagonal ? 2 : 1);
+}
+
+// N.ar.conv2d(name, n_in, n_out, (3,3), zerodiagonal, flipmask, w=w) of the Theano path (graphy/nodes/ar.py:200-375; e.g.
+// posteriors 'up_iaf1' / 'down_iaf2', models.py:53-55,73-79): weights w OIHW [n_out][n_in+1][3][3], s, b.  Forward only.
+extern "C" int iaf_conv3x3_create_masked_theano(iaf_conv3x3_t** out, int n_in, int n_out, int zerodiagonal, int flipmask) {
+    if (n_in > 0 && n_out > 0 && !(n_in % n_out == 0 || n_out % n_in == 0)) return IAF_ERR_NOT_MULTIPLE;   // ar.py:250,257
+    int rc = conv3x3_create(out, n_in, n_out, zerodiagonal ? 2 : 1);
+    if (rc) return rc;
+    iaf_conv3x3* c = *out;
+    if (c->generic) { iaf_conv3x3_destroy(c); *out = nullptr; return IAF_ERR_UNSUPPORTED; }
+    c->variant = flipmask ? IAF_VARIANT_THEANO_FLIPMASK : IAF_VARIANT_THEANO;
+    if ((rc = (int)hipMalloc(&c->L.border, (size_t)4 * c->L.ncot * 16 * sizeof(float))) != 0) { iaf_conv3x3_destroy(c); *out = nullptr; return rc; }
+    return IAF_OK;
 }
 
 static int conv3x3_create(iaf_conv3x3_t** out, int n_in, int n_out, int mask_mode) {
@@ -88,7 +103,7 @@ extern "C" int iaf_conv3x3_prepare(iaf_conv3x3_t* c, const float* V, const float
         memset(&a, 0, sizeof(a));
         a.nlayers = 1;
         PrepLayer& P = a.L[0];
-        P.V[0] = V; P.g[0] = g; P.b[0] = b; P.wp = L.wp; P.bias = L.bias; P.variant = IAF_VARIANT_TF;
+        P.V[0] = V; P.g[0] = g; P.b[0] = b; P.wp = L.wp; P.bias = L.bias; P.variant = c->variant; P.border = L.border;
         P.cin = L.cin; P.cout_each = L.cout; P.ncot = L.ncot; P.nchunk = L.nchunk; P.zerodiag = L.zerodiag; P.npair = 1;
         hipLaunchKernelGGL(iaf_prep_kernel, dim3(L.ncot), dim3(256), 0, (hipStream_t)stream, a);
     } else {
@@ -278,16 +293,19 @@ extern "C" int iaf_conv3x3_set_tuning(iaf_conv3x3_t* c, int nt, int pxt, int wco
 
 // launch of the conv kernel for a plain / single masked conv descriptor (forward, or its transposed problem with the
 // taps mirrored for the data gradient)
-static int conv3x3_launch(GemmLayer& L, ConvP& p, int epi_sel, int inmode, bool masked, bool mirror, hipStream_t st) {
+static int conv3x3_launch(GemmLayer& L, ConvP& p, int epi_sel, int inmode, bool masked, bool mirror, hipStream_t st,
+                          int variant = IAF_VARIANT_TF) {
     if (!L.user_tuned) auto_shape(L, false, p.P, p.W);
     conv_fn_t fn = pick_kernel(L.nt, L.pxt, L.wco, L.ks, inmode, epi_sel);
     if (!fn) return IAF_ERR_UNSUPPORTED;
-    const int tm = 16 * L.pxt, W = p.W, sgn = mirror ? -1 : 1;
+    // Theano's true convolution looks left/above (taps negated); flipmask turns it back (see launch_gemm)
+    const int tm = 16 * L.pxt, W = p.W, sgn = ((variant == IAF_VARIANT_THEANO) != mirror) ? -1 : 1;
+    p.border = (masked && !mirror) ? L.border : nullptr;
     p.wp = L.wp; p.bias = L.bias; p.lim = nullptr;
     if (masked) {     // the 5 live taps of the MADE-masked filter: look right / below only
         static const int tf_dh[NTAPS] = {0, 0, 1, 1, 1}, tf_dw[NTAPS] = {0, 1, -1, 0, 1};
         for (int t = 0; t < NTAPS; ++t) { p.tap_dh[t] = sgn * tf_dh[t]; p.tap_dw[t] = sgn * tf_dw[t]; }
-        p.halo_before = mirror ? W + 1 : 0;
+        p.halo_before = (sgn < 0) ? W + 1 : 0;
         p.nslot = tm + W + 1;
     } else {
         for (int t = 0; t < MAXTAPS; ++t) { p.tap_dh[t] = sgn * (t / 3 - 1); p.tap_dw[t] = sgn * (t % 3 - 1); }   // cross-correlation, SAME
@@ -349,7 +367,7 @@ extern "C" int iaf_conv3x3_forward(iaf_conv3x3_t* c, const float* x, const float
         p.split_end[k] = ends[k < n_outs ? k : n_outs - 1];
         p.split_ptr[k] = outs[k < n_outs ? k : n_outs - 1];
     }
-    return conv3x3_launch(L, p, c->mask_mode ? EPI_PLAIN5 : EPI_PLAIN, IN_NCHW, c->mask_mode != 0, false, st);
+    return conv3x3_launch(L, p, c->mask_mode ? EPI_PLAIN5 : EPI_PLAIN, IN_NCHW, c->mask_mode != 0, false, st, c->variant);
 }
 
 extern "C" int iaf_conv3x3_autotune(iaf_conv3x3_t* c, const float* x, const float* x2, int c_split, int elu_input,

@@ -619,7 +619,12 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
             if (u >= NUNIT) continue;
             if (EPI == EPI_PLAIN) {
                 const int co = (cot0 + u) * 16 + 4 * kk;
-                const f32x4 v = val[i] + pbias[i];
+                f32x4 v = val[i] + pbias[i];
+                if (NTP == NTAPS && p.border) {   // a single Theano ar.conv2d (graphy/nodes/ar.py:200-375): border-indicator channel
+#pragma unroll
+                    for (int t = 1; t < NTP; ++t)
+                        if (outside & (1u << t)) v += *(const f32x4*)(p.border + (size_t)(t - 1) * p.cout + co);
+                }
                 int c0 = 0, c1 = p.split_end[0];
                 float* base = p.split_ptr[0];
 #pragma unroll

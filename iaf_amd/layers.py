@@ -473,11 +473,18 @@ class WNConv2d(object):
     (tf_train.py:35-44, 52-54, 87-94) is fused into the call: ELU on the input, channel concat of two inputs,
     channel split of the output, and the residual `res + 0.1*y`."""
 
-    def __init__(self, n_in, n_out, ar_mask=None):
-        """ar_mask: None = plain conv2d; False / True = ar_conv2d with zerodiagonal=False / True (layers.py:144-154)."""
-        self.n_in, self.n_out, self.ar_mask = int(n_in), int(n_out), ar_mask
+    def __init__(self, n_in, n_out, ar_mask=None, theano=False, flipmask=False):
+        """ar_mask: None = plain conv2d; False / True = ar_conv2d with zerodiagonal=False / True (layers.py:144-154).
+        theano=True (masked only): the Theano statement, N.ar.conv2d (graphy/nodes/ar.py:200-375), optionally flipmask;
+        prepare() then takes (w OIHW [n_out, n_in+1, 3, 3], s, b)."""
+        self.n_in, self.n_out, self.ar_mask, self.theano = int(n_in), int(n_out), ar_mask, bool(theano)
         self._h = ctypes.c_void_p()
-        if ar_mask is None:
+        if theano:
+            if ar_mask is None:
+                raise ValueError("theano=True is the masked conv N.ar.conv2d: pass ar_mask=False/True (zerodiagonal)")
+            _capi.check(_capi.lib().iaf_conv3x3_create_masked_theano(ctypes.byref(self._h), self.n_in, self.n_out,
+                                                                     1 if ar_mask else 0, 1 if flipmask else 0))
+        elif ar_mask is None:
             _capi.check(_capi.lib().iaf_conv3x3_create(ctypes.byref(self._h), self.n_in, self.n_out))
         else:
             _capi.check(_capi.lib().iaf_conv3x3_create_masked(ctypes.byref(self._h), self.n_in, self.n_out,
@@ -495,8 +502,9 @@ class WNConv2d(object):
                 pass
 
     def prepare(self, V, g, b, force=False):
-        """V HWIO [3,3,n_in,n_out], g/b [n_out] (layers.py:53-55); cached until a tensor is replaced or modified."""
-        _check_act(V, "V", (3, 3, self.n_in, self.n_out))
+        """V HWIO [3,3,n_in,n_out], g/b [n_out] (layers.py:53-55); cached until a tensor is replaced or modified.
+        (theano=True: V = w OIHW [n_out, n_in+1, 3, 3], g = s, ar.py:288-296.)"""
+        _check_act(V, "V", (self.n_out, self.n_in + 1, 3, 3) if self.theano else (3, 3, self.n_in, self.n_out))
         _check_act(g, "g", (self.n_out,))
         _check_act(b, "b", (self.n_out,))
         key = tuple((t.data_ptr(), t._version) for t in (V, g, b))
@@ -856,6 +864,21 @@ def multiconv2d(name, n_in, n_h, n_out, size_kernel=(3, 3), flipmask=False, nl="
         return stack.ar_multiconv2d(h, context)
 
     return _Struct(f=f, w=w, stack=stack, postup=lambda updates, w: updates)
+
+
+def ar_conv2d_theano(name, n_in, n_out, size_kernel=(3, 3), zerodiagonal=True, flipmask=False, w=None):
+    """Mirror of N.ar.conv2d (graphy/nodes/ar.py:200-375) with its defaults pad_channel=True, border_mode='valid',
+    l2norm=True: returns a callable struct f(h, w) reading w[name+'_w'|'_b'|'_s']."""
+    if tuple(size_kernel) != (3, 3):
+        raise ValueError("the gfx950 engine implements size_kernel=(3,3)")
+    assert n_out % n_in == 0 or n_in % n_out == 0                                  # ar.py:250,257
+    conv = WNConv2d(n_in, n_out, ar_mask=bool(zerodiagonal), theano=True, flipmask=flipmask)
+
+    def f(h, w):
+        conv.prepare(w[name + "_w"], w[name + "_s"], w[name + "_b"])
+        return conv(h)[0]
+
+    return _Struct(f=f, w=w, conv=conv, postup=lambda updates, w: updates)
 
 
 def _is_elu(nl):

@@ -282,6 +282,11 @@ int iaf_conv3x3_create(iaf_conv3x3_t** out, int n_in, int n_out);
 /* one MADE-masked conv on its own: ar_conv2d(name, x, num_filters, zerodiagonal=...) (tf_utils/layers.py:144-154),
  * same object type and calls as the plain conv.  IAF_ERR_NOT_MULTIPLE unless n_in | n_out or n_out | n_in (:116). */
 int iaf_conv3x3_create_masked(iaf_conv3x3_t** out, int n_in, int n_out, int zerodiagonal);
+/* One masked conv of the THEANO path on its own: N.ar.conv2d(name, n_in, n_out, (3,3), zerodiagonal, flipmask, w=w)
+ * (graphy/nodes/ar.py:200-375, used by posteriors 'up_iaf1' / 'down_iaf2' ..., models.py:53-55, 73-79).  prepare() then takes
+ * V = <name>_w OIHW [n_out][n_in+1][3][3] (border-indicator channel last), g = <name>_s (applied as exp(3 s)), b = <name>_b.
+ * Channels must be multiples of 16.  Forward only. */
+int iaf_conv3x3_create_masked_theano(iaf_conv3x3_t** out, int n_in, int n_out, int zerodiagonal, int flipmask);
 int iaf_conv3x3_destroy(iaf_conv3x3_t* c);
 /* weight normalisation + packing (one launch); call again whenever V/g/b change */
 int iaf_conv3x3_prepare(iaf_conv3x3_t* c, const float* V, const float* g, const float* b, void* stream);

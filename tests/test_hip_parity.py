@@ -772,3 +772,28 @@ def test_cvae_layer_wrapper_vs_reference_golden(amd, golden_dir, cname):
     np.testing.assert_allclose(host(d["obj_kl"]), g[cname + "/obj_kl"], atol=2e-3, rtol=1e-4)
     down_out = f32(c["down_input"]) + 0.1 * O.theano_conv2d(elu(host(d["h"])), *cw("_down_conv2_1"))
     np.testing.assert_allclose(down_out, g[cname + "/down_out"], atol=ATOL, rtol=0)
+
+
+@pytest.mark.parametrize("key,zd,flip,n_in,n_out", [("conv_zd0_flip1_16_32", False, True, 16, 32), ("conv_zd1_flip1_16_32", True, True, 16, 32),
+                                                    ("conv_zd1_flip1_32_16", True, True, 32, 16), ("conv_zd0_flip0_32_16", False, False, 32, 16)])
+def test_theano_single_ar_conv2d_vs_reference_golden(amd, golden_dir, key, zd, flip, n_in, n_out):
+    """N.ar.conv2d on its own (graphy/nodes/ar.py:200-375), both mask variants, with and without flipmask, n_out above and
+    below n_in, against the outputs of the reference's own ar.py"""
+    g = np.load(os.path.join(golden_dir, "theano_ar.npz"))
+    w = {"c_w": dev(g[key + "/w"]), "c_b": dev(g[key + "/b"]), "c_s": dev(g[key + "/s"])}
+    f = amd.ar_conv2d_theano("c", n_in, n_out, (3, 3), zd, flip, w=w)
+    y = f(dev(g[key + "/x"]), w)
+    np.testing.assert_allclose(host(y), g[key + "/y"], atol=ATOL, rtol=0)
+
+
+@pytest.mark.parametrize("zd", [False, True])
+@pytest.mark.parametrize("flip", [False, True])
+def test_theano_single_ar_conv2d_vs_oracle(amd, zd, flip):
+    B, n_in, n_out, H, W = 4, 32, 64, 8, 8          # the 'up_iaf2' posterior's conv shape n_z -> 2 n_z (models.py:55)
+    rng = np.random.RandomState(91)
+    wv, bv, sv = 0.05 * rng.standard_normal((n_out, n_in + 1, 3, 3)), 0.1 * rng.standard_normal(n_out), 0.1 * rng.standard_normal(n_out)
+    x = rng.standard_normal((B, n_in, H, W))
+    w = {"q_w": dev(wv), "q_b": dev(bv), "q_s": dev(sv)}
+    y = amd.ar_conv2d_theano("q", n_in, n_out, (3, 3), zd, flip, w=w)(dev(x), w)
+    e = O.theano_ar_conv2d(f32(x), f32(wv), f32(bv), f32(sv), n_in, n_out, zd, flip)
+    np.testing.assert_allclose(host(y), e, atol=ATOL, rtol=0)
