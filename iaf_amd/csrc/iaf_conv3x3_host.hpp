@@ -203,7 +203,9 @@ extern "C" int iaf_colsum(const float* mat, float* out, int m, int n, void* stre
 struct iaf_conv3x3_prep_batch {
     int n, ntiles;
     iaf_conv3x3** convs;
-    PrepLayer* h_layers;
+    PrepLayer* h_layers;   // current descriptor table (host)
+    PrepLayer* h_ring;     // pinned snapshots for the async uploads (see iaf_prep_batch)
+    int ring_i;
     PrepLayer* d_layers;
     int* d_tile2layer;
     bool uploaded;
@@ -211,7 +213,8 @@ struct iaf_conv3x3_prep_batch {
 
 extern "C" int iaf_conv3x3_prep_batch_destroy(iaf_conv3x3_prep_batch_t* b) {
     if (!b) return IAF_ERR_NULL;
-    if (b->h_layers) (void)hipHostFree(b->h_layers);
+    free(b->h_layers);
+    if (b->h_ring) (void)hipHostFree(b->h_ring);
     if (b->d_layers) (void)hipFree(b->d_layers);
     if (b->d_tile2layer) (void)hipFree(b->d_tile2layer);
     free(b->convs);
@@ -238,12 +241,13 @@ extern "C" int iaf_conv3x3_prep_batch_create(iaf_conv3x3_prep_batch_t** out, iaf
     b->ntiles = nt;
     int* t2l = (int*)malloc(sizeof(int) * nt);
     int rc;
-    if ((rc = (int)hipHostMalloc((void**)&b->h_layers, sizeof(PrepLayer) * n)) != 0 ||
+    b->h_layers = (PrepLayer*)calloc(n, sizeof(PrepLayer));
+    if (!b->h_layers) { free(t2l); iaf_conv3x3_prep_batch_destroy(b); return (int)hipErrorOutOfMemory; }
+    if ((rc = (int)hipHostMalloc((void**)&b->h_ring, sizeof(PrepLayer) * n * PREP_RING)) != 0 ||
         (rc = (int)hipMalloc((void**)&b->d_layers, sizeof(PrepLayer) * n)) != 0 ||
         (rc = (int)hipMalloc((void**)&b->d_tile2layer, sizeof(int) * nt)) != 0) {
         free(t2l); iaf_conv3x3_prep_batch_destroy(b); return rc;
     }
-    memset(b->h_layers, 0, sizeof(PrepLayer) * n);
     int tile = 0;
     for (int i = 0; i < n; ++i) {
         const GemmLayer& L = convs[i]->L;
@@ -272,7 +276,10 @@ extern "C" int iaf_conv3x3_prep_batch_run(iaf_conv3x3_prep_batch_t* b, const flo
     }
     hipStream_t st = (hipStream_t)stream;
     if (changed) {     // see iaf_prep_batch_run
-        HIP_TRY(hipMemcpyAsync(b->d_layers, b->h_layers, sizeof(PrepLayer) * b->n, hipMemcpyHostToDevice, st));
+        PrepLayer* snap = b->h_ring + (size_t)b->ring_i * b->n;
+        b->ring_i = (b->ring_i + 1) % PREP_RING;
+        memcpy(snap, b->h_layers, sizeof(PrepLayer) * b->n);
+        HIP_TRY(hipMemcpyAsync(b->d_layers, snap, sizeof(PrepLayer) * b->n, hipMemcpyHostToDevice, st));
         b->uploaded = true;
     }
     hipLaunchKernelGGL(iaf_prep_plain_kernel, dim3(b->ntiles), dim3(256), 0, st, b->d_layers, b->d_tile2layer);
@@ -295,7 +302,15 @@ extern "C" int iaf_conv3x3_set_tuning(iaf_conv3x3_t* c, int nt, int pxt, int wco
 // taps mirrored for the data gradient)
 static int conv3x3_launch(GemmLayer& L, ConvP& p, int epi_sel, int inmode, bool masked, bool mirror, hipStream_t st,
                           int variant = IAF_VARIANT_TF) {
-    if (!L.user_tuned) auto_shape(L, false, p.P, p.W);
+    if (!L.user_tuned) {
+        GemmLayer t = L;
+        t.nt = L.t_nt; t.pxt = L.t_ppw; t.wco = L.t_pxt; t.ks = L.t_ks;
+        if (L.tuned_P == p.P && L.tuned_W == p.W && L.t_nt > 0 && conv_lds_bytes(t, p.W) <= 160 * 1024) {
+            L.nt = t.nt; L.pxt = t.pxt; L.wco = t.wco; L.ks = t.ks;     // measured for this size (iaf_conv3x3_autotune_backward)
+        } else {
+            auto_shape(L, false, p.P, p.W);
+        }
+    }
     conv_fn_t fn = pick_kernel(L.nt, L.pxt, L.wco, L.ks, inmode, epi_sel);
     if (!fn) return IAF_ERR_UNSUPPORTED;
     // Theano's true convolution looks left/above (taps negated); flipmask turns it back (see launch_gemm)
@@ -628,7 +643,11 @@ extern "C" int iaf_conv3x3_autotune_backward(iaf_conv3x3_t* c, const float* x, c
         }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    T.nt = bsh[0]; T.pxt = bsh[1]; T.wco = bsh[2]; T.ks = bsh[3]; T.user_tuned = true;
+    // remember the winner for THIS problem size only (t_* hold (nt, pxt, wco, ks) here): a backward at another size goes
+    // back to the automatic shape instead of inheriting a shape tuned -- and LDS-sized -- for this one
+    T.user_tuned = false;
+    T.tuned_P = (long long)B * H * W; T.tuned_W = W;
+    T.t_nt = bsh[0]; T.t_ppw = bsh[1]; T.t_pxt = bsh[2]; T.t_ks = bsh[3];
     if (rc == IAF_OK) rc = run();           // leave the outputs as computed with the chosen shape
     (void)was_pending;
     if (best_shape) for (int i = 0; i < 4; ++i) best_shape[i] = bsh[i];

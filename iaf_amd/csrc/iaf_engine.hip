@@ -418,12 +418,15 @@ extern "C" int iaf_stack_prepare(iaf_stack_t* s, const float* const* V, const fl
     return IAF_OK;
 }
 
+#define PREP_RING 4
 // ---- batched prepare: all stacks of a model in ONE launch (weights of every layer are known at step start)
 struct iaf_prep_batch {
     int n;
     iaf_stack** stacks;
     int nlayers_total, ntiles;
-    PrepLayer* h_layers;   // pinned; read by the async copy (also when a captured graph replays)
+    PrepLayer* h_layers;   // the current descriptor table (host; mutated by every run)
+    PrepLayer* h_ring;     // pinned staging, PREP_RING snapshots of h_layers: an async upload reads ITS OWN snapshot, so a
+    int ring_i;            // later run may rewrite h_layers while earlier uploads are still pending (also under graph replay)
     PrepLayer* d_layers;
     int* d_tile2layer;
     bool uploaded;         // d_layers holds the current h_layers
@@ -431,7 +434,8 @@ struct iaf_prep_batch {
 
 extern "C" int iaf_prep_batch_destroy(iaf_prep_batch_t* b) {
     if (!b) return IAF_ERR_NULL;
-    if (b->h_layers) (void)hipHostFree(b->h_layers);
+    free(b->h_layers);
+    if (b->h_ring) (void)hipHostFree(b->h_ring);
     if (b->d_layers) (void)hipFree(b->d_layers);
     if (b->d_tile2layer) (void)hipFree(b->d_tile2layer);
     free(b->stacks);
@@ -458,12 +462,13 @@ extern "C" int iaf_prep_batch_create(iaf_prep_batch_t** out, iaf_stack_t* const*
     b->nlayers_total = nl; b->ntiles = nt;
     int* t2l = (int*)malloc(sizeof(int) * nt);
     int rc;
-    if ((rc = (int)hipHostMalloc((void**)&b->h_layers, sizeof(PrepLayer) * nl)) != 0 ||
+    b->h_layers = (PrepLayer*)calloc(nl, sizeof(PrepLayer));
+    if (!b->h_layers) { free(t2l); iaf_prep_batch_destroy(b); return (int)hipErrorOutOfMemory; }
+    if ((rc = (int)hipHostMalloc((void**)&b->h_ring, sizeof(PrepLayer) * nl * PREP_RING)) != 0 ||
         (rc = (int)hipMalloc((void**)&b->d_layers, sizeof(PrepLayer) * nl)) != 0 ||
         (rc = (int)hipMalloc((void**)&b->d_tile2layer, sizeof(int) * nt)) != 0) {
         free(t2l); iaf_prep_batch_destroy(b); return rc;
     }
-    memset(b->h_layers, 0, sizeof(PrepLayer) * nl);
     int li = 0, tile = 0;
     for (int i = 0; i < n; ++i)
         for (int l = 0; l < stacks[i]->nlayers; ++l, ++li) {
@@ -504,7 +509,10 @@ extern "C" int iaf_prep_batch_run(iaf_prep_batch_t* b, const float* const* V, co
     hipStream_t st = (hipStream_t)stream;
     // the descriptor table only travels when a pointer in it changed (a training loop passes the same buffers every step)
     if (changed) {
-        HIP_TRY(hipMemcpyAsync(b->d_layers, b->h_layers, sizeof(PrepLayer) * b->nlayers_total, hipMemcpyHostToDevice, st));
+        PrepLayer* snap = b->h_ring + (size_t)b->ring_i * b->nlayers_total;
+        b->ring_i = (b->ring_i + 1) % PREP_RING;
+        memcpy(snap, b->h_layers, sizeof(PrepLayer) * b->nlayers_total);
+        HIP_TRY(hipMemcpyAsync(b->d_layers, snap, sizeof(PrepLayer) * b->nlayers_total, hipMemcpyHostToDevice, st));
         b->uploaded = true;
     }
     hipLaunchKernelGGL(iaf_prep_batch_kernel, dim3(b->ntiles), dim3(256), 0, st, b->d_layers, b->d_tile2layer);

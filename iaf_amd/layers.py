@@ -363,6 +363,7 @@ class ARStack(object):
                               kl_min):
         """posterior_block that keeps what posterior_block_backward needs (same z, kl_obj, kl_cost)"""
         B, H, W = self._dims(qz_mean, up_context)
+        self._check_posterior_inputs(qz_mean, qz_logsd, rz_mean, rz_logsd, pz_mean, pz_logsd, eps, up_context, down_context)
         z = torch.empty_like(qz_mean)
         kl_obj = torch.empty(B, dtype=torch.float32, device=z.device)
         kl_cost = torch.empty_like(kl_obj)
@@ -377,8 +378,17 @@ class ARStack(object):
                                  params, grads_out=None):
         """Backward of tf_train.py:56-85.  Returns dict(dmean (= d qz_mean = d rz_mean), dlogsd (= d qz_logsd = d rz_logsd),
         dpz_mean, dpz_logsd, dcontext (= d up_context = d down_context), grads {conv/V|g|b})."""
+        _check_act(qz_mean, "qz_mean")
+        if qz_mean.dim() != 4 or qz_mean.shape[1] != self.n_z:
+            raise ValueError("qz_mean must be [B, %d, H, W], got %s" % (self.n_z, tuple(qz_mean.shape)))
         B, _, H, W = qz_mean.shape
         B, H, W = int(B), int(H), int(W)
+        self._check_posterior_inputs(qz_mean, qz_logsd, rz_mean, rz_logsd, pz_mean, pz_logsd, eps)
+        _check_act(z, "z", qz_mean.shape)
+        _check_act(dz, "dz", qz_mean.shape)
+        if dkl_obj is None:
+            raise ValueError("dkl_obj (gradient of kl_obj, [B]) is required")
+        _check_act(dkl_obj, "dkl_obj", (B,))
         tens = self._param_tensors(params)
         names = self.conv_names()
         grads = {} if grads_out is None else grads_out     # grads_out: pre-allocated views (e.g. into a flat bucket)
@@ -405,6 +415,15 @@ class ARStack(object):
             float(kl_min), _ptr(z), _ptr(dz), _ptr(dkl_obj), _ptr(out["dmean"]), _ptr(out["dlogsd"]), _ptr(out["dpz_mean"]),
             _ptr(out["dpz_logsd"]), _ptr(out["dcontext"]), Vp, gp, dVp, dgp, dbp, B, H, W, _ptr(ws), need, _stream()))
         return out
+
+    def _check_posterior_inputs(self, qz_mean, qz_logsd, rz_mean, rz_logsd, pz_mean, pz_logsd, eps, up_context=None,
+                                down_context=None):
+        """every raw pointer handed to the engine is a contiguous fp32 CUDA tensor of the shape the kernels index with"""
+        for nm, t in (("qz_logsd", qz_logsd), ("rz_mean", rz_mean), ("rz_logsd", rz_logsd), ("pz_mean", pz_mean),
+                      ("pz_logsd", pz_logsd), ("eps", eps)):
+            _check_act(t, nm, qz_mean.shape)
+        if self.depth_ar > 0 and up_context is not None:
+            _check_act(down_context, "down_context", up_context.shape)
 
     def posterior_block(self, qz_mean, qz_logsd, rz_mean, rz_logsd, pz_mean, pz_logsd, up_context, down_context, eps,
                         kl_min, want_kl_elem=False, out=None):
