@@ -773,7 +773,7 @@ def iw_eval_bench(args, depths, dist, rank, n_gpus):
         return
     lw = stacks[0].layer_work(dom, B, 16, 16)
     kern = stacks[0].layer_precision(dom, B, 16, 16)
-    peak = PEAK_BF16X3_TFLOPS if kern == "bf16x3" else PEAK_F32_MFMA_TFLOPS
+    peak = PEAK_F32_MFMA_TFLOPS          # same yardstick as the headline line (see there)
     ach = lw["live_flops"] / (k_ms * 1e-3) / 1e12
     step_fl = sum(d * stacks[0].step_work(B, 16 >> i, 16 >> i)["live_flops"] for i, d in enumerate(depths))
     rows_per_s = n_gpus * B / (elapsed / args.steps)
@@ -793,7 +793,7 @@ def iw_eval_bench(args, depths, dist, rank, n_gpus):
                    "model_tflops": step_fl / (elapsed / args.steps) / 1e12,
                    "parallelism": "dp%d (images sharded over ranks, no collective)" % n_gpus},
         "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
-                     "frac_of_f32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS, "dominant_kernel_family": kern,
+                     "frac_of_bf16x3_peak": (ach / PEAK_BF16X3_TFLOPS) if kern == "bf16x3" else None, "dominant_kernel_family": kern,
                      "kernel": "masked 3x3 conv %d->%d, B=%d 16x16" % (args.n_h, args.n_h, B), "avg_launch_us": 1e3 * k_ms,
                      "flops_per_launch_live": lw["live_flops"], "bytes_per_launch": lw["bytes"],
                      "step": {"live_flops_per_step": step_fl, "frac_of_f32_mfma_peak": step_fl / (elapsed / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS}}})
@@ -981,15 +981,17 @@ def main():
         except Exception:
             traffic = None
     dom_kernel = st0.layer_precision(dom_layer, args.batch, 16, 16)
-    dom_peak = PEAK_BF16X3_TFLOPS if dom_kernel == "bf16x3" else PEAK_F32_MFMA_TFLOPS
     roofline = {
-        "bound": "mfma", "achieved": achieved, "peak": dom_peak, "unit": "TFLOP/s",
-        "frac": achieved / dom_peak, "traffic": traffic,
-        "peak_note": "fp32-equivalent FLOPs; peak = dense bf16 MFMA 2500 TF / 6 part-products per product for the bf16x3 "
-                     "kernel, 157.3 TF (exact-fp32 MFMA) for the fp32 kernel" ,
+        # yardstick = the dense fp32 MFMA peak, for both kernel families: the path computes fp32 products with fp32
+        # accumulation (dtype f32) and this is the peak the exact-fp32 kernel -- and round 1 -- are priced against.  The
+        # bf16x3 kernel gets the same fp32-grade result out of the bf16 matrix cores (6 bf16 MFMA products per fp32
+        # product), whose own ceiling for this arithmetic is 2500/6 = 416.7 TF: reported next to it.
+        "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+        "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
         "dominant_kernel_family": dom_kernel,
-        "frac_of_f32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS,
-        "kernel": "iaf_conv_kernel (masked 3x3 conv %d->%d, B=%d 16x16, GEMM layer %d)" % (args.n_h, args.n_h, args.batch, dom_layer),
+        "frac_of_bf16x3_peak": (achieved / PEAK_BF16X3_TFLOPS) if dom_kernel == "bf16x3" else None,
+        "peak_bf16x3": PEAK_BF16X3_TFLOPS,
+        "kernel": "%s (masked 3x3 conv %d->%d, B=%d 16x16, GEMM layer %d)" % ("iaf_conv_bf3_kernel" if dom_kernel == "bf16x3" else "iaf_conv_kernel", args.n_h, args.n_h, args.batch, dom_layer),
         "avg_launch_us": 1e3 * k_avg_ms, "launches_timed": 50 * len(kbatch),
         "timing": "HIP events on the launch stream around 50 back-to-back launches per 16x16 layer (includes the "
                   "inter-launch gap); per-launch event brackets inside full steps read %.2f us over %d launches "

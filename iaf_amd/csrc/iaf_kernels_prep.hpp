@@ -43,16 +43,63 @@ struct PrepArgs {
 template <int NTP> __device__ __forceinline__ int tap_kh(int t) { return NTP == 9 ? t / 3 : ((t == 0 || t == 1) ? 1 : 2); }
 template <int NTP> __device__ __forceinline__ int tap_kw(int t) { return NTP == 9 ? t % 3 : ((t == 0) ? 1 : (t == 1 ? 2 : t - 2)); }
 
-// one weight -> its three bf16 parts (w = h + m + l up to 2^-27|w|, round-to-nearest-even each), written to the three
-// planes of the bf16x3 pack: lane (kk = (ci%32)/8, oo) of fragment (pair = ci/32, tap, cot), element ci%8
-__device__ __forceinline__ void prep_store_bf3(void* wp3, int ncot, int ntp, int gt, int t, int ci, int oo, float w) {
-    const __bf16 hb = (__bf16)w;
-    const float r1 = w - (float)hb;
-    const __bf16 mb = (__bf16)r1;
-    const __bf16 lb = (__bf16)(r1 - (float)mb);
-    const int pair = ci >> 5, kk = (ci >> 3) & 3, e = ci & 7;
-    __bf16* q = (__bf16*)wp3 + ((((size_t)(pair * ntp + t) * ncot + gt) * 3) * 64 + kk * 16 + oo) * 8 + e;
-    q[0] = hb; q[512] = mb; q[1024] = lb;
+// The bf16x3 pack of one 16-channel output tile (iaf_conv_bf3.hpp): [c_in pair of 32][tap][cot][plane h/m/l][lane 64]
+// [8 bf16].  A second sweep over the (L2-hot) weights with the FRAGMENT's thread mapping -- thread = (lane = kk*16+oo,
+// quarter) owns the 8 consecutive input channels of one lane of one (pair, tap) fragment -- so that every store is a
+// full 16 bytes per lane, 1 KiB contiguous per wave (per-element 2-byte stores from the first sweep's mapping doubled
+// the prep kernel's time).  Same mask / scale as the fp32 pack: s_scale[] holds the per-channel norm factor.
+__device__ __forceinline__ void prep_bf3_pass(const PrepLayer& L, int gt, const float* s_scale) {
+    typedef __bf16 pb16x2 __attribute__((ext_vector_type(2)));
+    typedef float pf32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned pu32x4 __attribute__((ext_vector_type(4)));
+    const int which = (L.npair == 2) ? (gt & 1) : 0;
+    const int src_tile = (L.npair == 2) ? (gt >> 1) : gt;
+    const float* __restrict__ V = L.V[which];
+    const int lane = threadIdx.x & 63, quarter = threadIdx.x >> 6;
+    const int oo = lane & 15, kk = lane >> 4;
+    const int o = src_tile * 16 + oo;
+    const int n_out = L.cout_each, n_in = L.cin;
+    const bool theano = (L.variant == IAF_VARIANT_THEANO || L.variant == IAF_VARIANT_THEANO_FLIPMASK);
+    const bool flip = (L.variant == IAF_VARIANT_THEANO_FLIPMASK);
+    const int k0 = (n_out >= n_in) ? n_out / n_in : 1;
+    const bool row_zeroed = theano && L.zerodiag && o < k0;         // ar.py:268-276 (see prep_tile_theano)
+    const float scale = s_scale[oo];
+    const int nunit = (n_in >> 5) * NTAPS;
+    for (int u = quarter; u < nunit; u += 4) {
+        const int pair = u / NTAPS, t = u - pair * NTAPS;
+        const int kh = (t == 0 || t == 1) ? 1 : 2;
+        const int kw = (t == 0) ? 1 : (t == 1 ? 2 : t - 2);
+        float w[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int ci = pair * 32 + 8 * kk + e;
+            float x;
+            bool live = true;
+            if (theano) {
+                x = V[((size_t)o * (n_in + 1) + ci) * 9 + (flip ? (2 - kh) * 3 + (2 - kw) : kh * 3 + kw)];
+                if (t == 0)
+                    live = !row_zeroed && (flip ? (ci >= 1 && made_live(n_in - ci, n_out - 1 - o, n_in, n_out, L.zerodiag))
+                                                : made_live(ci, o, n_in, n_out, L.zerodiag));
+            } else {
+                x = V[((size_t)(kh * 3 + kw) * n_in + ci) * n_out + o];
+                if (t == 0) live = made_live(ci, o, n_in, n_out, L.zerodiag);
+            }
+            w[e] = live ? x * scale : 0.f;
+        }
+        pu32x4 ph, pm, pl;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const pf32x2 x = {w[2 * i], w[2 * i + 1]};
+            const pb16x2 hb = __builtin_convertvector(x, pb16x2);
+            const pf32x2 r1 = x - __builtin_convertvector(hb, pf32x2);
+            const pb16x2 mb = __builtin_convertvector(r1, pb16x2);
+            const pf32x2 r2 = r1 - __builtin_convertvector(mb, pf32x2);
+            const pb16x2 lb = __builtin_convertvector(r2, pb16x2);
+            ph[i] = __builtin_bit_cast(unsigned, hb); pm[i] = __builtin_bit_cast(unsigned, mb); pl[i] = __builtin_bit_cast(unsigned, lb);
+        }
+        pu32x4* q = (pu32x4*)L.wp3 + (((size_t)(pair * NTAPS + t) * L.ncot + gt) * 3) * 64 + lane;
+        q[0] = ph; q[64] = pm; q[128] = pl;
+    }
 }
 
 template <int NCH, int NTP = NTAPS>
@@ -108,12 +155,7 @@ __device__ __forceinline__ void prep_tile(const PrepLayer& L, int gt, float (*re
             for (int t = 0; t < NTP; ++t)
                 L.wpt[((((size_t)gt * NTP + t) * NCH + it) * 64 + (oo >> 2) * 16 + cs) * 4 + (oo & 3)] = v[t][it] * scale;
     }
-    if (NTP == NTAPS && L.wp3) {
-#pragma unroll
-        for (int it = 0; it < NCH; ++it)
-#pragma unroll
-            for (int t = 0; t < NTP; ++t) prep_store_bf3(L.wp3, L.ncot, NTP, gt, t, cs + 16 * it, oo, v[t][it] * scale);
-    }
+    if (NTP == NTAPS && L.wp3) prep_bf3_pass(L, gt, s_scale);
 }
 
 // Theano statement of the same weights (graphy/nodes/ar.py:243-330, l2norm=True, logscale=True, pad_channel=True):
@@ -199,12 +241,7 @@ __device__ __forceinline__ void prep_tile_theano(const PrepLayer& L, int gt, flo
 #pragma unroll
         for (int t = 0; t < NTAPS; ++t)
             L.wp[((((size_t)it * NTAPS + t) * L.ncot + gt) * 64 + kk * 16 + oo) * 4 + jj] = v[t][it] * scale;
-    if (L.wp3) {
-#pragma unroll
-        for (int it = 0; it < NCH; ++it)
-#pragma unroll
-            for (int t = 0; t < NTAPS; ++t) prep_store_bf3(L.wp3, L.ncot, NTAPS, gt, t, cs + 16 * it, oo, v[t][it] * scale);
-    }
+    if (L.wp3) prep_bf3_pass(L, gt, s_scale);
 }
 
 #define PREP_MAXI 16   // n_in <= 256

@@ -47,8 +47,8 @@ def timed(fn, inner=20, reps=30):
 
 def main():
     dev = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).cuda()
-    print("| config | latent | IAF step us | samples/s | live GFLOP | TFLOP/s | posterior block us |")
-    print("|---|---|---|---|---|---|---|")
+    print("| config | latent | IAF step us | samples/s | live GFLOP | TFLOP/s | posterior block us | kernels (autotuned per layer) |")
+    print("|---|---|---|---|---|---|---|---|")
     for name, B, n_z, n_h, d, levels in CONFIGS:
         rng = np.random.RandomState(0)
         params = gi.ar_multiconv2d_params(rng, n_z, [n_h] * d, [n_z, n_z])
@@ -58,13 +58,14 @@ def main():
             f = lambda c: dev(rng.standard_normal((B, c, hw, hw)))
             z, ctx = f(n_z), f(n_h)
             out = (torch.empty_like(z), torch.empty_like(z))
+            picks = st.autotune(z, ctx, reps=10)
             t_step = timed(lambda: st.iaf_step(z, ctx, out=out))
             qm, ql, rm, rl, pm, pl, eps, dc = f(n_z), 0.25 * f(n_z), f(n_z), 0.25 * f(n_z), f(n_z), 0.25 * f(n_z), f(n_z), f(n_h)
             t_blk = timed(lambda: st.posterior_block(qm, ql, rm, rl, pm, pl, ctx, dc, eps, 0.25), inner=10, reps=20)
             w = st.step_work(B, hw, hw)
-            print("| %s | [%d,%d,%d,%d] | %.1f | %.0f | %.3f | %.1f | %.1f |" %
+            print("| %s | [%d,%d,%d,%d] | %.1f | %.0f | %.3f | %.1f | %.1f | %s |" %
                   (name, B, n_z, hw, hw, 1e6 * t_step, B / t_step, w["live_flops"] / 1e9, w["live_flops"] / t_step / 1e12,
-                   1e6 * t_blk))
+                   1e6 * t_blk, " ".join(c for c, _ in picks)))
 
 
 if __name__ == "__main__":

@@ -1,26 +1,42 @@
+# Refresh the measured evidence under gpurun_out/r02/ (copied to profiles/r02/ afterwards):  gpurun -- 'bash tools/refresh_profiles.sh'
 set -x
 R=$GRAFT_REPO_ROOT
-mkdir -p $R/gpurun_out/r01
+O=$R/gpurun_out/r02
+mkdir -p $O/pmc
 cd /tmp && export TMPDIR=/tmp
-python -m pytest $R/tests -q -m gpu 2>&1 | tail -4 > $R/gpurun_out/r01/pytest_gpu.txt
-python $R/bench.py > $R/gpurun_out/r01/bench_n1.json 2> /dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb -o bench -- python $R/bench.py --no-cpu-baseline > $R/gpurun_out/r01/bench_rocprof_line.json 2>/dev/null
-cp /tmp/pb/*kernel_stats.csv $R/gpurun_out/r01/bench_kernel_stats.csv
+python -m pytest $R/tests -q -m gpu 2>&1 | tail -4 > $O/pytest_gpu.txt
+python $R/bench.py > $O/bench_n1.json 2> /dev/null
+python $R/bench.py --precision f32 > $O/bench_f32_n1.json 2> /dev/null
+python $R/bench.py --layers > $O/bench_layers_n1.json 2> /dev/null
+python $R/bench.py --iw-eval --steps 100 > $O/bench_iw_eval_n1.json 2> /dev/null
+IAF_BENCH_FORCE_DIST=1 python $R/bench.py --train --steps 50 > $O/bench_train_n1.json 2> /dev/null
+IAF_BENCH_FORCE_DIST=1 python $R/bench.py --train --layers --steps 20 --warmup 5 > $O/bench_train_layers_n1.json 2> /dev/null
+# kernel trace of the SAME command as the headline bench line
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb -o bench -- python $R/bench.py --no-cpu-baseline > $O/bench_rocprof_line.json 2>/dev/null
+cp /tmp/pb/*kernel_stats.csv $O/bench_kernel_stats.csv
 python - <<'PY'
 import csv, collections, glob, os
 f = glob.glob('/tmp/pb/*kernel_trace.csv')[0]
 acc = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
-    acc[(r['Kernel_Name'], r['Grid_Size_X'] if 'Grid_Size_X' in r else r.get('Grid_Size',''))].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
-out = os.environ['GRAFT_REPO_ROOT'] + '/gpurun_out/r01/bench_kernel_trace_by_grid.csv'
+    acc[(r['Kernel_Name'], r.get('Grid_Size_X', r.get('Grid_Size', '')), r.get('Workgroup_Size_X', r.get('Workgroup_Size', '')))].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+out = os.environ['GRAFT_REPO_ROOT'] + '/gpurun_out/r02/bench_kernel_trace_by_grid.csv'
 with open(out, 'w') as o:
-    o.write('kernel,grid_x,calls,avg_ns,total_ns\n')
-    for (k, g), v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
-        o.write('"%s",%s,%d,%.1f,%d\n' % (k, g, len(v), sum(v) / len(v), sum(v)))
+    o.write('kernel,grid_x,wg_x,calls,avg_ns,total_ns\n')
+    for (k, g, w), v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
+        o.write('"%s",%s,%s,%d,%.1f,%d\n' % (k, g, w, len(v), sum(v) / len(v), sum(v)))
 PY
-for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -o pmc -- python $R/tools/run_step.py --hw 16 --reps 10 > /dev/null 2>&1
-  cp /tmp/pmc_$c/*counter_collection.csv $R/gpurun_out/r01/${c}_counter_collection.csv
+# PMC passes (one counter set per pass) on the dominant kernel with the launch shapes the bench's autotune picks
+for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS"; do
+  n=$(echo $c | tr ' ' '_')
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$n -o pmc -- python $R/tools/run_step.py --hw 16 --reps 10 --precision bf16x3 --tune-bf3 "0:2,1,4,1;1:5,2,1,4;2:2,2,1,4" > /dev/null 2>&1
+  cp /tmp/pmc_$n/*counter_collection.csv $O/pmc/bf16x3_${n}_counter_collection.csv
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmcf_$n -o pmc -- python $R/tools/run_step.py --hw 16 --reps 10 --precision f32 > /dev/null 2>&1
+  cp /tmp/pmcf_$n/*counter_collection.csv $O/pmc/f32_${n}_counter_collection.csv
 done
-python $R/tools/bench_configs.py > $R/gpurun_out/r01/bench_configs.md 2>/dev/null
-tail -3 $R/gpurun_out/r01/pytest_gpu.txt; cut -c1-250 $R/gpurun_out/r01/bench_n1.json
+python $R/tools/pmc_summary.py $O/pmc > $O/pmc_summary.txt 2>&1
+python $R/tools/bf3_sweep.py --sweep > $O/bf3_sweep_B32.txt 2>&1
+python $R/tools/bf3_sweep.py --sweep --batch 256 --hw 16 > $O/bf3_sweep_B256.txt 2>&1
+python $R/tools/bench_configs.py > $O/bench_configs.md 2>/dev/null
+(python $R/tools/soak.py --iters 200000 --fresh 3000) > $O/soak_prod_long.txt 2>&1
+tail -3 $O/pytest_gpu.txt; cut -c1-300 $O/bench_n1.json; tail -2 $O/soak_prod_long.txt
