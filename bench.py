@@ -66,6 +66,8 @@ def parse():
                     help="arithmetic of the forward masked convs: bf16x3 = fp32 operands split into three bf16 parts, six "
                          "part-products accumulated in fp32 on the bf16 matrix cores (fp32-grade; the engine's default); "
                          "f32 = the exact-fp32 MFMA everywhere")
+    ap.add_argument("--no-fuse", action="store_true",
+                    help="never run the first masked conv inside the second one's kernel (iaf_stack_set_fuse_first)")
     ap.add_argument("--no-autotune", action="store_true",
                     help="skip the per-layer kernel/launch-shape search (iaf_stack_autotune) before the timed region")
     ap.add_argument("--ar-buckets", type=int, default=4,
@@ -843,6 +845,8 @@ def main():
             zd, cd = dev(z), dev(ctx)
             out = (torch.empty_like(zd), torch.empty_like(zd))
             st.set_precision(args.precision)
+            if args.no_fuse:
+                st.set_fuse_first("never")
             st.prepare(dp)
             layers.append(dict(stack=st, params=dp, z=zd, ctx=cd, out=out, H=H))
     if args.tune:
@@ -860,6 +864,7 @@ def main():
         # reference's convs); outside the timed region, before the graph is captured
         for L in layers:
             picks = L["stack"].autotune(L["z"], L["ctx"], reps=20)
+            L["fused"] = picks[0][0] == "fused into next"
             tuned.setdefault("%dx%d" % (L["H"], L["H"]), [c for c, _ in picks])
 
     def step():
@@ -914,7 +919,10 @@ def main():
             L["stack"].profile_enable(-1, 0)
         # primary figure: N back-to-back launches of the dominant kernel between ONE event pair (no per-launch
         # event/dispatch latency), averaged over the 16x16 layers
-        kbatch = [L["stack"].time_layer(dom_layer, L["z"], L["ctx"] if args.depth_ar > 0 else None, reps=50) for L in prof]
+        fused16 = dom_layer == 1 and bool(prof) and all(L.get("fused") for L in prof)     # every 16x16 stack tuned to the fused launch
+        kbatch = [L["stack"].time_layer(-1 if fused16 else dom_layer, L["z"], L["ctx"] if args.depth_ar > 0 else None, reps=50)
+                  for L in prof if fused16 or not L.get("fused")] or \
+                 [L["stack"].time_layer(-1, L["z"], L["ctx"], reps=50) for L in prof]
         # every GEMM layer of the IAF step at every latent level, same method (first layer of each level), and the
         # extended unit of SURVEY 8d (posterior block: sample + logqs + IAF step + log-det + logps + KL / free bits)
         ktable, xunit = [], []
@@ -925,15 +933,26 @@ def main():
             L = [x for x in layers if x["H"] == H][0]
             st = L["stack"]
             cin = args.n_z
+            fused = bool(L.get("fused"))
             for gl in range(args.depth_ar + 1):
                 cout = args.n_h if gl < args.depth_ar else 2 * args.n_z
-                ms = st.time_layer(gl, L["z"], L["ctx"] if args.depth_ar > 0 else None, reps=50)
+                name = "masked conv %d->%d%s" % (cin, cout, " (mean,logsd pair + affine/log-det epilogue)" if gl == args.depth_ar else "")
                 w = st.layer_work(gl, args.batch, H, H)
-                tf_ = w["live_flops"] / (ms * 1e-3) / 1e12
-                ktable.append({"layer": "masked conv %d->%d%s" % (cin, cout, " (mean,logsd pair + affine/log-det epilogue)" if gl == args.depth_ar else ""),
-                               "latent": "%dx%d" % (H, H), "kernel": st.layer_precision(gl, args.batch, H, H), "us": 1e3 * ms, "live_gflop": w["live_flops"] / 1e9,
-                               "live_tflops": tf_, "frac": tf_ / PEAK_F32_MFMA_TFLOPS})
                 cin = args.n_h
+                if fused and gl == 0:
+                    w0 = w
+                    continue                      # computed inside the next launch
+                if fused and gl == 1:
+                    ms = st.time_layer(-1, L["z"], L["ctx"], reps=50)
+                    w = {k: w[k] + w0[k] for k in w}
+                    name = "masked conv %d->%d + %s, ONE launch (first layer fused into the prologue)" % (args.n_z, args.n_h, name)
+                    kern = "bf16x3"
+                else:
+                    ms = st.time_layer(gl, L["z"], L["ctx"] if args.depth_ar > 0 else None, reps=50)
+                    kern = st.layer_precision(gl, args.batch, H, H)
+                tf_ = w["live_flops"] / (ms * 1e-3) / 1e12
+                ktable.append({"layer": name, "latent": "%dx%d" % (H, H), "kernel": kern, "us": 1e3 * ms,
+                               "live_gflop": w["live_flops"] / 1e9, "live_tflops": tf_, "frac": tf_ / PEAK_F32_MFMA_TFLOPS})
             if args.depth_ar > 0:
                 f = lambda c, sc=1.0: sc * torch.randn(args.batch, c, H, H, device="cuda")
                 pin = [f(args.n_z), f(args.n_z, 0.25), f(args.n_z), f(args.n_z, 0.25), f(args.n_z), f(args.n_z, 0.25),
@@ -970,6 +989,10 @@ def main():
 
     st0 = prof[0]["stack"]
     lw = st0.layer_work(dom_layer, args.batch, 16, 16)
+    if fused16:                      # the launch also computes the first masked conv (on tile + halo): count its useful work once
+        lw0 = st0.layer_work(0, args.batch, 16, 16)
+        lw = {"live_flops": lw["live_flops"] + lw0["live_flops"], "dense_flops": lw["dense_flops"] + lw0["dense_flops"],
+              "bytes": lw["bytes"] + lw0["bytes"] - 2.0 * 4.0 * args.batch * args.n_h * 256}   # its output never reaches HBM
     k_avg_ms = float(np.mean(kbatch))
     k_brk_ms = float(np.mean(kms)) if kms else float("nan")
     achieved = lw["live_flops"] / (k_avg_ms * 1e-3) / 1e12
@@ -991,7 +1014,8 @@ def main():
         "dominant_kernel_family": dom_kernel,
         "frac_of_bf16x3_peak": (achieved / PEAK_BF16X3_TFLOPS) if dom_kernel == "bf16x3" else None,
         "peak_bf16x3": PEAK_BF16X3_TFLOPS,
-        "kernel": "%s (masked 3x3 conv %d->%d, B=%d 16x16, GEMM layer %d)" % ("iaf_conv_bf3_kernel" if dom_kernel == "bf16x3" else "iaf_conv_kernel", args.n_h, args.n_h, args.batch, dom_layer),
+        "kernel": ("iaf_conv_bf3_kernel<IN_FUSED0> (masked 3x3 convs %d->%d and %d->%d in ONE launch, B=%d 16x16)" % (args.n_z, args.n_h, args.n_h, args.n_h, args.batch)) if fused16 else
+                  "%s (masked 3x3 conv %d->%d, B=%d 16x16, GEMM layer %d)" % ("iaf_conv_bf3_kernel" if dom_kernel == "bf16x3" else "iaf_conv_kernel", args.n_h, args.n_h, args.batch, dom_layer),
         "avg_launch_us": 1e3 * k_avg_ms, "launches_timed": 50 * len(kbatch),
         "timing": "HIP events on the launch stream around 50 back-to-back launches per 16x16 layer (includes the "
                   "inter-launch gap); per-launch event brackets inside full steps read %.2f us over %d launches "

@@ -16,7 +16,7 @@
 //                [lane 64][8 bf16]: one (step, tile, plane) fragment = 1 KiB = one global_load_dwordx4 per wave.
 //   activations  staged once per workgroup into LDS as three bf16 planes per pixel slot ([slot][plane][c_in], +16 B pad:
 //                slot stride = 8*odd dwords, ds_read_b128 conflict-free); split fp32 -> 3 x bf16 while staging.
-//   tiling       workgroup = PXT x KS waves.  A wave owns PPW pixel tiles (16 px) x NT co tiles (16 ch) -- every weight
+//   tiling       workgroup = PXT x WCO x KS waves (WCO co groups share one staged activation tile).  A wave owns PPW pixel tiles (16 px) x NT co tiles (16 ch) -- every weight
 //                fragment it fetches is used by PPW pixel tiles (register blocking along pixels: the weight stream into a
 //                CU, not the MFMA pipe, is the limit at BASELINE batch sizes) -- for ONE slice of the K steps; the KS
 //                waves of a group split the steps of the same tile (nothing shared, no barrier in the K loop) and
@@ -56,20 +56,21 @@ __device__ __forceinline__ void bf3_store4(char* smem, int slot, int q, f32x4 v,
     *(u32x2*)(base + ((size_t)cin8 << 5)) = u32x2{l0, l1};
 }
 
-template <int NT, int PPW, int PXT, int KS, int INMODE, int EPI>
-__global__ __launch_bounds__(64 * PXT * KS) void iaf_conv_bf3_kernel(ConvP p) {
+template <int NT, int PPW, int PXT, int KS, int INMODE, int EPI, int WCO = 1>
+__global__ __launch_bounds__(64 * PXT * KS * WCO) void iaf_conv_bf3_kernel(ConvP p) {
     extern __shared__ __attribute__((aligned(16))) f32x4 smem4[];
     char* smem = (char*)smem4;
     constexpr int NTP = NTAPS;
     constexpr int TM = 16 * PPW * PXT;
-    constexpr int NTHREADS = 64 * PXT * KS;
+    constexpr int NTHREADS = 64 * PXT * KS * WCO;   // WCO co groups share ONE staged activation tile
     constexpr int RD = (PPW >= 2) ? 1 : 2;   // ring look-ahead in steps (a step is PPW*NT*6 MFMAs of 16 cycles)
     constexpr int U = RD + 1;                                   // ring slots
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pw = wave % PXT, kh = wave / PXT;
+    const int pw = wave % PXT, cw = (wave / PXT) % WCO, kh = wave / (PXT * WCO);
+    const int grp = cw * PXT + pw;         // the KS waves with the same (pixel block, co group) exchange partial sums
     const int P0 = blockIdx.x * TM;
-    const int cot0 = blockIdx.y * NT;
+    const int cot0 = (blockIdx.y * WCO + cw) * NT;
     asm volatile("" ::"s"(p.x), "s"(p.wp), "s"(p.B), "s"(p.H), "s"(p.W), "s"(p.HW), "s"(p.P), "s"(p.cin), "s"(p.cout),
                  "s"(p.nchunk), "s"(p.ncot), "s"(p.nslot), "s"(p.mode), "s"(p.halo_before));
     asm volatile("" ::"s"(p.tap_dh[0]), "s"(p.tap_dh[1]), "s"(p.tap_dh[2]), "s"(p.tap_dh[3]), "s"(p.tap_dh[4]), "s"(p.tap_dw[0]),
@@ -85,16 +86,15 @@ __global__ __launch_bounds__(64 * PXT * KS) void iaf_conv_bf3_kernel(ConvP p) {
     IAF_BSTAMP(0);
 
     // ================= prologue (1): activation tile loads ============================================================
-    // items per pixel: 4-channel fp32 quads, or (pre-split input) the 16-byte chunks of the pixel's three bf16 planes
-    const int nq = (INMODE == IN_PIXMAJOR3) ? 3 * cin8 : (p.cin >> 2);
+    const int nq = p.cin >> 2;                     // 4-channel items per pixel
     const int nitems = p.nslot * nq;
-    constexpr int SU = (INMODE == IN_PIXMAJOR || INMODE == IN_PIXMAJOR3) ? 16 : 4;
+    constexpr int SU = (INMODE == IN_PIXMAJOR) ? 16 : 4;
     f32x4 sv[SU];
     const int Pbase = P0 - p.halo_before;
     const int flo = Pbase < 0 ? -Pbase * nq : 0;
     const long long rem = (long long)(p.P - Pbase) * nq;
     const int fhi = rem < nitems ? (int)rem : nitems;
-    if (INMODE == IN_PIXMAJOR || INMODE == IN_PIXMAJOR3) {
+    if (INMODE == IN_PIXMAJOR) {
         const f32x4* src = (const f32x4*)p.x + (long long)Pbase * nq;
 #pragma unroll
         for (int u = 0; u < SU; ++u) {
@@ -154,26 +154,157 @@ __global__ __launch_bounds__(64 * PXT * KS) void iaf_conv_bf3_kernel(ConvP p) {
         xbase[q] = (tl + p.halo_before) * s16 + kk;
     }
 
+    // NCHW source (z, or the posterior sample computed on the fly) -> three bf16 planes of an LDS tile of `nsl` slots
+    auto stage_nchw = [&](char* region, int nsl, int cin_, int s16_, int cin8_, const float* xsrc, bool posterior) {
+        const int nit = nsl * (cin_ >> 2);
+        for (int base = tid; base < nit; base += 4 * NTHREADS) {
+            int dq[4], dsl[4];
+            f32x4 v4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * NTHREADS;
+                dsl[u] = -1; dq[u] = 0;
+                v4[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (idx < nit) {
+                    const int q = idx / nsl, sl = idx - q * nsl;               // slot fastest: coalesced along pixels
+                    const int Pg = Pbase + sl;
+                    dsl[u] = sl; dq[u] = q;
+                    if (Pg >= 0 && Pg < p.P) {
+                        const int b = Pg / HW, ppx = Pg - b * HW;
+                        const size_t gb = ((size_t)b * cin_ + 4 * q) * HW + ppx;
+                        if (!posterior) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v4[u][r] = xsrc[gb + (size_t)r * HW];
+                        } else {   // z0 = (qm+rm) + exp(ql+rl) * eps   (tf_train.py:57,63; distributions.py:21)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const size_t i = gb + (size_t)r * HW;
+                                v4[u][r] = (p.qm[i] + p.rm[i]) + __expf(0.5f * (2.f * (p.ql[i] + p.rl[i]))) * p.eps[i];
+                            }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (dsl[u] >= 0) bf3_store4(region, dsl[u], dq[u], v4[u], s16_, cin8_);
+        }
+    };
+
+    // IN_FUSED0: the stack's first masked conv (c_in = 32: five steps) is computed HERE instead of in a launch of its
+    // own -- its output, the hidden activation this kernel's K loop consumes, goes straight into the LDS tile and never
+    // touches HBM.  z is staged with a double halo (nslot + W + 1 slots); every wave computes all pixel tiles of the
+    // tile (+ halo) for its own co tiles (tiles w, w + NW, ...: distinct weights per wave, held in registers), applies
+    // bias + context + ELU (layers.py:163-165) and writes the three bf16 planes.  TF statement only (no halo before).
+    auto fused_layer0 = [&]() {
+        constexpr int NW = PXT * WCO * KS;
+        constexpr int NTL = (NW >= 8) ? 2 : 3;              // co tiles of the fused layer per wave (c_h <= 16*NW*NTL)
+        const int z8 = p.f_cin >> 3, z16 = 3 * z8 + 2;
+        const int nslot0 = p.nslot + W + 1;
+        char* zreg = smem + ((size_t)(p.nslot + 1) * s16 << 4);
+        f32x4* zreg4 = (f32x4*)zreg;
+        const int ncot0 = p.nchunk;                         // the fused layer's c_out = this layer's c_in
+        const int npt = (p.nslot + 15) >> 4;                // pixel tiles of the hidden tile (+ halo)
+        // co tiles of this wave: tile `wave` for every pixel tile, and further tiles w + NW, w + 2 NW ...  With 8 waves
+        // and at most 2 tiles beyond the first 8 (c_h = 160: tiles 8, 9) those are dealt out per (tile, pixel tile) --
+        // wave w takes (8 + w/4, pixel tile w%4) -- so every wave multiplies 5 units instead of waves 0, 1 doing 8
+        const bool balanced = (NW == 8) && (ncot0 - NW <= 2) && (npt <= 4);
+        int tile_of[NTL];
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) tile_of[j] = (balanced && j == 1) ? NW + (wave >> 2) : wave + j * NW;
+        // its weights: [tap 5][ncot0][plane 3][lane][8 bf16] (one c_in pair), all of them in registers
+        f32x4 wf[NTAPS][NTL][3];
+        const f32x4* fw = (const f32x4*)p.f_wp + lane;
+        f32x4 bi[NTL];
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) {
+            const int tc = tile_of[j] < ncot0 ? tile_of[j] : ncot0 - 1;
+#pragma unroll
+            for (int tp = 0; tp < NTAPS; ++tp)
+#pragma unroll
+                for (int pn = 0; pn < 3; ++pn) wf[tp][j][pn] = fw[(((size_t)tp * ncot0 + tc) * 3 + pn) * 64];
+            bi[j] = *(const f32x4*)(p.f_bias + tc * 16 + 4 * kk);
+        }
+        for (int i = tid; i < z16; i += NTHREADS) zreg4[(size_t)nslot0 * z16 + i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        stage_nchw(zreg, nslot0, p.f_cin, z16, z8, p.f_x, p.f_x == nullptr);
+        const int zzero = nslot0 * z16 + kk;
+        // context (+ second context) of this lane's 4 channels of every co tile at pixel tile q: fetched one pixel
+        // tile AHEAD of the MFMAs that need it
+        auto load_ctx = [&](int q, f32x4* cx) {
+            const int sl = q * 16 + pl, Pl = P0 + sl;
+            const bool live = q < npt && sl < p.nslot && Pl < p.P;
+            int bimg, pp;
+            fast_divmod(Pl, HW, 1.0f / (float)HW, bimg, pp);
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) {
+                cx[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const bool act = tile_of[j] < ncot0 && (!(balanced && j == 1) || q == (wave & 3));
+                if (act && live && p.f_ctx) {
+                    const size_t cb = ((size_t)bimg * p.cin + tile_of[j] * 16 + 4 * kk) * HW + pp;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) cx[j][r] = p.f_ctx[cb + (size_t)r * HW];
+                    if (p.f_ctx2) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) cx[j][r] += p.f_ctx2[cb + (size_t)r * HW];
+                    }
+                }
+            }
+        };
+        f32x4 cxn[NTL];
+        load_ctx(0, cxn);
+        __syncthreads();
+        for (int q = 0; q < npt; ++q) {
+            const int sl = q * 16 + pl;                      // slot of the hidden tile this lane's pixel column is
+            const int Pl = P0 + sl;
+            const bool live = sl < p.nslot && Pl < p.P;
+            int bimg, pp, h, w;
+            fast_divmod(Pl, HW, 1.0f / (float)HW, bimg, pp);
+            fast_divmod(pp, W, 1.0f / (float)W, h, w);
+            f32x4 cx[NTL];
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) cx[j] = cxn[j];
+            load_ctx(q + 1, cxn);
+            const bool act1 = !balanced || q == (wave & 3);   // is the second tile slot at work on this pixel tile?
+            f32x4 a0[NTL];
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) a0[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int tp = 0; tp < NTAPS; ++tp) {
+                const int dh = p.tap_dh[tp], dw = p.tap_dw[tp];
+                const bool v = live && (h + dh >= 0) && (h + dh < p.H) && (w + dw >= 0) && (w + dw < W);
+                const int za = zzero + ((v ? -1 : 0) & ((sl + dh * W + dw) * z16 + kk - zzero));
+                const bf16x8 xh = __builtin_bit_cast(bf16x8, zreg4[za]);
+                const bf16x8 xm = __builtin_bit_cast(bf16x8, zreg4[za + z8]);
+                const bf16x8 xl = __builtin_bit_cast(bf16x8, zreg4[za + 2 * z8]);
+#define IAF_BF3_PROD0(J, WP, XV) a0[J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[tp][J][WP]), XV, a0[J], 0, 0, 0);
+#define IAF_BF3_SIX(J) IAF_BF3_PROD0(J, 2, xh) IAF_BF3_PROD0(J, 0, xl) IAF_BF3_PROD0(J, 1, xm) IAF_BF3_PROD0(J, 1, xh) IAF_BF3_PROD0(J, 0, xm) IAF_BF3_PROD0(J, 0, xh)
+                IAF_BF3_SIX(0)
+                if constexpr (NTL > 1) { if (act1) { IAF_BF3_SIX(1) } }
+                if constexpr (NTL > 2) { IAF_BF3_SIX(2) }
+#undef IAF_BF3_SIX
+#undef IAF_BF3_PROD0
+            }
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) {
+                const bool act = tile_of[j] < ncot0 && (j != 1 || act1);
+                if (act && sl < p.nslot) {
+                    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};             // pixels past the end of the batch: a zero row
+                    if (live) {
+                        v = a0[j] + bi[j] + cx[j];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = elu_f(v[r]);
+                    }
+                    bf3_store4(smem, sl, tile_of[j] * 4 + kk, v, s16, cin8);
+                }
+            }
+        }
+    };
+
     // ================= prologue (4): tile -> LDS, split into three bf16 planes ========================================
     {
         f32x4* zslot = smem4 + (size_t)p.nslot * s16;
         for (int i = tid; i < s16; i += NTHREADS) zslot[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (INMODE == IN_PIXMAJOR3) {      // already three bf16 planes per pixel: straight 16-byte copies
-            const float rnq = 1.0f / (float)nq;
-#pragma unroll
-            for (int u = 0; u < SU; ++u) {
-                const int f = tid + u * NTHREADS;
-                if (f < nitems) {
-                    const int sl = (int)(((float)f + 0.5f) * rnq);
-                    smem4[sl * s16 + (f - sl * nq)] = sv[u];
-                }
-            }
-            const f32x4* src = (const f32x4*)p.x + (long long)Pbase * nq;
-            for (int f = tid + SU * NTHREADS; f < nitems; f += NTHREADS) {
-                const int sl = (int)(((float)f + 0.5f) * rnq);
-                smem4[sl * s16 + (f - sl * nq)] = (f >= flo && f < fhi) ? src[f] : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-        } else if (INMODE == IN_PIXMAJOR) {
+        if (INMODE == IN_PIXMAJOR) {
             const float rnq = 1.0f / (float)nq;
 #pragma unroll
             for (int u = 0; u < SU; ++u) {
@@ -188,40 +319,11 @@ __global__ __launch_bounds__(64 * PXT * KS) void iaf_conv_bf3_kernel(ConvP p) {
                 const int sl = (int)(((float)f + 0.5f) * rnq);
                 bf3_store4(smem, sl, f - sl * nq, (f >= flo && f < fhi) ? src[f] : f32x4{0.f, 0.f, 0.f, 0.f}, s16, cin8);
             }
-        } else {
-            for (int base = tid; base < nitems; base += SU * NTHREADS) {
-                int dq[SU], dsl[SU];
-#pragma unroll
-                for (int u = 0; u < SU; ++u) {
-                    const int idx = base + u * NTHREADS;
-                    dsl[u] = -1; dq[u] = 0;
-                    sv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (idx < nitems) {
-                        const int q = idx / p.nslot, sl = idx - q * p.nslot;   // slot fastest: coalesced along pixels
-                        const int Pg = Pbase + sl;
-                        dsl[u] = sl; dq[u] = q;
-                        if (Pg >= 0 && Pg < p.P) {
-                            const int b = Pg / HW, ppx = Pg - b * HW;
-                            const size_t gb = ((size_t)b * p.cin + 4 * q) * HW + ppx;
-                            if (INMODE == IN_NCHW) {
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) sv[u][r] = p.x[gb + (size_t)r * HW];
-                            } else {   // z0 = (qm+rm) + exp(ql+rl) * eps   (tf_train.py:57,63; distributions.py:21)
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) {
-                                    const size_t i = gb + (size_t)r * HW;
-                                    sv[u][r] = (p.qm[i] + p.rm[i]) + __expf(0.5f * (2.f * (p.ql[i] + p.rl[i]))) * p.eps[i];
-                                }
-                            }
-                        }
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < SU; ++u)
-                    if (dsl[u] >= 0) bf3_store4(smem, dsl[u], dq[u], sv[u], s16, cin8);
-            }
+        } else if (INMODE == IN_NCHW || INMODE == IN_POSTERIOR) {
+            stage_nchw(smem, p.nslot, p.cin, s16, cin8, p.x, INMODE == IN_POSTERIOR);
         }
     }
+    if constexpr (INMODE == IN_FUSED0) { IAF_BSTAMP(6); fused_layer0(); IAF_BSTAMP(7); }
     __syncthreads();
     IAF_BSTAMP(2);
 
@@ -317,13 +419,13 @@ __global__ __launch_bounds__(64 * PXT * KS) void iaf_conv_bf3_kernel(ConvP p) {
     if constexpr (KS > 1) {
         __syncthreads();                                       // every wave is done reading the activation tile
         f32x4* red = smem4;                                    // [pw][kh][q][t][64 lanes] x 16 bytes
-        f32x4* wbuf = red + (size_t)((pw * KS + kh) * PPW * NT) * 64 + lane;
+        f32x4* wbuf = red + (size_t)((grp * KS + kh) * PPW * NT) * 64 + lane;
 #pragma unroll
         for (int q = 0; q < PPW; ++q)
 #pragma unroll
             for (int t = 0; t < NT; ++t) wbuf[(q * NT + t) * 64] = acc[q][t];
         __syncthreads();
-        const f32x4* rbuf = red + (size_t)(pw * KS * PPW * NT) * 64 + lane;
+        const f32x4* rbuf = red + (size_t)(grp * KS * PPW * NT) * 64 + lane;
 #pragma unroll
         for (int i = 0; i < NMY; ++i) {
             const int item = kh + i * KS;

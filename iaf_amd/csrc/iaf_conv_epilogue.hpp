@@ -44,28 +44,6 @@ __device__ __forceinline__ EpiGeom epi_geom(const ConvP& p, int Pl, int kk, bool
     return g;
 }
 
-// hidden activation -> three bf16 planes (v = h + m + l up to 2^-27|v|), pixel-major [P][plane][cout]
-__device__ __forceinline__ void epi_store_bf3(void* y3, int Pl, int cout, int co, f32x4 v) {
-    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-    typedef float f32x2_t __attribute__((ext_vector_type(2)));
-    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-    unsigned hh[2], mm[2], ll[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const f32x2_t x = {v[2 * i], v[2 * i + 1]};
-        const bf16x2_t hb = __builtin_convertvector(x, bf16x2_t);
-        const f32x2_t r1 = x - __builtin_convertvector(hb, f32x2_t);
-        const bf16x2_t mb = __builtin_convertvector(r1, bf16x2_t);
-        const f32x2_t r2 = r1 - __builtin_convertvector(mb, f32x2_t);
-        const bf16x2_t lb = __builtin_convertvector(r2, bf16x2_t);
-        hh[i] = __builtin_bit_cast(unsigned, hb); mm[i] = __builtin_bit_cast(unsigned, mb); ll[i] = __builtin_bit_cast(unsigned, lb);
-    }
-    char* base = (char*)y3 + ((size_t)Pl * 3 * cout + co) * 2;
-    *(u32x2_t*)(base) = u32x2_t{hh[0], hh[1]};
-    *(u32x2_t*)(base + (size_t)cout * 2) = u32x2_t{mm[0], mm[1]};
-    *(u32x2_t*)(base + (size_t)cout * 4) = u32x2_t{ll[0], ll[1]};
-}
-
 // operands of the epilogue that do not depend on the GEMM (issued before the split-K exchange so their latency hides)
 template <int EPI>
 __device__ __forceinline__ void epi_load(const ConvP& p, const EpiGeom& g, int cot, EpiOps& o) {
@@ -112,8 +90,7 @@ __device__ __forceinline__ void epi_apply(const ConvP& p, const EpiGeom& g, int 
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = elu_f(v[r]);   // layers.py:165
-        if (p.y) *(f32x4*)(p.y + (size_t)g.Pl * p.cout + co) = v;
-        if (p.y3) epi_store_bf3(p.y3, g.Pl, p.cout, co, v);
+        *(f32x4*)(p.y + (size_t)g.Pl * p.cout + co) = v;
     } else {
         const int nz = p.cout >> 1;
         const int c0 = (cot >> 1) * 16 + 4 * g.kk;       // packed tiles (cot, cot+1) = (mean, logsd) of channel group cot/2

@@ -47,7 +47,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 #define IN_PIXMAJOR 0     // x is [P][c_in] scratch written by a previous EPI_HIDDEN
 #define IN_NCHW 1         // x is an NCHW tensor (z)
 #define IN_POSTERIOR 2    // x = z0 = (qm+rm) + exp(ql+rl)*eps computed on the fly (tf_train.py:57,63)
-#define IN_PIXMAJOR3 3    // bf16x3 kernels only: x is [P][plane h/m/l][c_in] bf16 scratch written by a bf16x3 EPI_HIDDEN (ConvP.y3)
+#define IN_FUSED0 4       // bf16x3 kernels only: the stack's first masked conv (ConvP.f_*) is computed in this kernel's prologue,
+                          // straight into the LDS tile the K loop reads (iaf_conv_bf3.hpp)
 
 struct ConvP {
     // Field order = order of first use: the kernel pulls the whole descriptor into SGPRs in one batch of scalar loads
@@ -87,8 +88,9 @@ struct ConvP {
     // go to the contiguous NCHW tensor split_ptr[k]; boundaries are multiples of 4 (one lane's 4 channels never straddle).
     int nsplit; int split_end[MAXSPLIT]; float* split_ptr[MAXSPLIT];
     int lds_bytes;        // dynamic LDS of this launch (read only by the -DIAF_EXP_POISON_LDS soak build)
-    void* y3;             // bf16x3 EPI_HIDDEN: output already split into three bf16 planes, pixel-major [P][3][cout]
-                          // (what the next bf16x3 conv stages with plain 16-byte copies); p.y may then be NULL
+    // IN_FUSED0: the fused first layer -- its bf16x3 pack / bias, its NCHW input z (NULL: the posterior sample from
+    // qm/rm/ql/rl/eps), its c_in (32) and the context(s) added to its output (layers.py:163-164; tf_train.py:58)
+    const void* f_wp; const float* f_bias; const float* f_x; int f_cin; const float* f_ctx; const float* f_ctx2;
 };
 
 // Pin the order "MFMAs with memory instructions spread evenly between them" inside the current scheduling region:

@@ -71,10 +71,13 @@ struct GemmLayer {
     float* border = nullptr;   // Theano variant only
     float* wpt = nullptr;      // transposed pack for dgrad (allocated by iaf_stack_set_training)
     void* wp3 = nullptr;       // bf16x3 pack for iaf_conv_bf3_kernel (c_in % 32 == 0 only)
-    int b_nt = 0, b_ppw = 0, b_pxt = 0, b_ks = 0;   // bf16x3 launch shape (auto or iaf_stack_set_tuning_bf3)
+    int b_nt = 0, b_ppw = 0, b_pxt = 0, b_ks = 0, b_wco = 1;   // bf16x3 launch shape (auto or iaf_stack_set_tuning_bf3)
     bool b_user_tuned = false;
     // result of iaf_stack_autotune for one problem size: which kernel family and which bf16x3 shape won the timing
-    long long tuned_P = -1; int tuned_W = -1; bool tuned_bf3 = false; int t_nt = 0, t_ppw = 0, t_pxt = 0, t_ks = 0;
+    long long tuned_P = -1; int tuned_W = -1; bool tuned_bf3 = false; int t_nt = 0, t_ppw = 0, t_pxt = 0, t_ks = 0, t_wco = 1;
+    // layer 1 only: the first layer fused into this layer's kernel (IN_FUSED0): result of iaf_stack_autotune for one size
+    long long fz_P = -1; int fz_W = -1; bool fz_on = false; int fz[5] = {0, 0, 0, 0, 1};
+    float tuned_us = 0.f;      // time of the winner of the last iaf_stack_autotune
     int* lim = nullptr;
     // launch shape: fixed by iaf_stack_set_tuning (user_tuned) or chosen per problem size by auto_shape()
     int nt, pxt, wco, ks;
@@ -93,6 +96,8 @@ struct iaf_stack {
     float* pend_ws = nullptr; int pend_B = 0, pend_H = 0, pend_W = 0;   // ... which finds dWeff / dbp through these
     bool generic = false;     // channel counts outside the MFMA path: direct-conv fallback kernels
     int precision = IAF_PRECISION_BF16X3;   // forward convs: bf16x3 split products on the bf16 MFMA, or the exact fp32 MFMA
+    int fuse_first = 2;       // first masked conv fused into the second one's kernel: 0 never, 1 whenever possible, 2 only where
+                              // iaf_stack_autotune measured it faster (on MI355X at the BASELINE sizes it is not: DESIGN.md 4.8)
     bool prepared;
     size_t weight_bytes;  // raw V/g/b bytes of the stack (for the algorithmic byte count)
     // optional per-launch event timing of one layer
@@ -119,23 +124,28 @@ IAF_DECL_SHAPE(2, 1, 4)
 IAF_DECL_SHAPE(1, 1, 4)
 IAF_DECL_SHAPE(1, 2, 2)
 
-// bf16x3 kernels (iaf_conv_bf3.hpp), one translation unit per (ppw, pxt, ks)
-#define IAF_DECL_BF3(P, X, K) extern "C" conv_fn_t iaf_pick_bf3_##P##_##X##_##K(int nt, int inmode, int epi);
-IAF_DECL_BF3(4, 1, 4)
-IAF_DECL_BF3(2, 1, 4)
-IAF_DECL_BF3(1, 1, 4)
-IAF_DECL_BF3(1, 4, 1)
-static const int k_bf3_shapes[][3] = {{4, 1, 4}, {2, 1, 4}, {1, 1, 4}, {1, 4, 1}};   // keep in sync with iaf_amd/build.py
-static conv_fn_t pick_bf3(int nt, int ppw, int pxt, int ks, int inmode, int epi) {
-    if (ppw == 4 && pxt == 1 && ks == 4) return iaf_pick_bf3_4_1_4(nt, inmode, epi);
-    if (ppw == 2 && pxt == 1 && ks == 4) return iaf_pick_bf3_2_1_4(nt, inmode, epi);
-    if (ppw == 1 && pxt == 1 && ks == 4) return iaf_pick_bf3_1_1_4(nt, inmode, epi);
-    if (ppw == 1 && pxt == 4 && ks == 1) return iaf_pick_bf3_1_4_1(nt, inmode, epi);
+// bf16x3 kernels (iaf_conv_bf3.hpp), one translation unit per (ppw, pxt, ks, wco)
+#define IAF_DECL_BF3(P, X, K, C) extern "C" conv_fn_t iaf_pick_bf3_##P##_##X##_##K##_##C(int nt, int inmode, int epi);
+IAF_DECL_BF3(4, 1, 4, 1)
+IAF_DECL_BF3(2, 1, 4, 1)
+IAF_DECL_BF3(1, 1, 4, 1)
+IAF_DECL_BF3(1, 4, 1, 1)
+IAF_DECL_BF3(2, 1, 4, 2)
+IAF_DECL_BF3(1, 1, 4, 2)
+#define N_BF3_SHAPES 6
+static const int k_bf3_shapes[N_BF3_SHAPES][4] = {{4, 1, 4, 1}, {2, 1, 4, 1}, {1, 1, 4, 1}, {1, 4, 1, 1}, {2, 1, 4, 2}, {1, 1, 4, 2}};   // keep in sync with iaf_amd/build.py
+static conv_fn_t pick_bf3(int nt, int ppw, int pxt, int ks, int inmode, int epi, int wco = 1) {
+    if (ppw == 4 && pxt == 1 && ks == 4 && wco == 1) return iaf_pick_bf3_4_1_4_1(nt, inmode, epi);
+    if (ppw == 2 && pxt == 1 && ks == 4 && wco == 1) return iaf_pick_bf3_2_1_4_1(nt, inmode, epi);
+    if (ppw == 1 && pxt == 1 && ks == 4 && wco == 1) return iaf_pick_bf3_1_1_4_1(nt, inmode, epi);
+    if (ppw == 1 && pxt == 4 && ks == 1 && wco == 1) return iaf_pick_bf3_1_4_1_1(nt, inmode, epi);
+    if (ppw == 2 && pxt == 1 && ks == 4 && wco == 2) return iaf_pick_bf3_2_1_4_2(nt, inmode, epi);
+    if (ppw == 1 && pxt == 1 && ks == 4 && wco == 2) return iaf_pick_bf3_1_1_4_2(nt, inmode, epi);
     return nullptr;
 }
-static size_t bf3_lds_bytes(int cin, int W, int nt, int ppw, int pxt, int ks) {
+static size_t bf3_lds_bytes(int cin, int W, int nt, int ppw, int pxt, int ks, int wco = 1) {
     const size_t tile = (size_t)(16 * ppw * pxt + W + 1 + 1) * (3 * (cin / 8) + 2) * 16;
-    const size_t red = ks > 1 ? (size_t)pxt * ks * ppw * nt * 1024 : 0;     // split-K exchange aliases the (dead) tile
+    const size_t red = ks > 1 ? (size_t)pxt * wco * ks * ppw * nt * 1024 : 0;     // split-K exchange aliases the (dead) tile
     return tile > red ? tile : red;
 }
 
@@ -361,15 +371,17 @@ extern "C" int iaf_stack_get_precision(const iaf_stack_t* s, int layer, int B, i
                       (long long)B * H * W, W) ? IAF_PRECISION_BF16X3 : IAF_PRECISION_F32;
 }
 
-extern "C" int iaf_stack_set_tuning_bf3(iaf_stack_t* s, int layer, int nt, int ppw, int pxt, int ks) {
+extern "C" int iaf_stack_set_tuning_bf3(iaf_stack_t* s, int layer, int nt, int ppw, int pxt, int ks, int wco) {
     if (!s) return IAF_ERR_NULL;
     if (layer < 0 || layer >= s->nlayers) return IAF_ERR_SHAPE;
     GemmLayer& L = s->L[layer];
     if (nt == 0) { L.b_user_tuned = false; return IAF_OK; }      // back to the automatic choice
     const bool is_out = (layer == s->depth_ar);
     if (!L.wp3 || L.ncot % nt != 0 || (is_out && (nt & 1))) return IAF_ERR_UNSUPPORTED;
-    if (!pick_bf3(nt, ppw, pxt, ks, IN_PIXMAJOR, is_out ? EPI_OUT : EPI_HIDDEN)) return IAF_ERR_UNSUPPORTED;
-    L.b_nt = nt; L.b_ppw = ppw; L.b_pxt = pxt; L.b_ks = ks; L.b_user_tuned = true;
+    if (wco < 1) wco = 1;
+    if (L.ncot % (nt * wco) != 0) return IAF_ERR_UNSUPPORTED;
+    if (!pick_bf3(nt, ppw, pxt, ks, IN_PIXMAJOR, is_out ? EPI_OUT : EPI_HIDDEN, wco)) return IAF_ERR_UNSUPPORTED;
+    L.b_nt = nt; L.b_ppw = ppw; L.b_pxt = pxt; L.b_ks = ks; L.b_wco = wco; L.b_user_tuned = true;
     return IAF_OK;
 }
 
@@ -599,6 +611,27 @@ static int raise_lds_cap(const void* fn, size_t lds) {
     return 0;
 }
 
+// IN_FUSED0 adds the double-halo z tile behind the hidden tile
+static size_t bf3_fused_lds_bytes(int cin, int cin0, int W, int nt, int ppw, int pxt, int ks, int wco) {
+    const int nslot = 16 * ppw * pxt + W + 1;
+    const size_t tile = (size_t)(nslot + 1) * (3 * (cin / 8) + 2) * 16 + (size_t)(nslot + W + 1 + 1) * (3 * (cin0 / 8) + 2) * 16;
+    const size_t red = ks > 1 ? (size_t)pxt * wco * ks * ppw * nt * 1024 : 0;
+    return tile > red ? tile : red;
+}
+// can layer 0 be computed inside layer 1's bf16x3 kernel with this shape?
+static bool fuse_shape_ok(const iaf_stack_t* s, int nt, int ppw, int pxt, int ks, int wco, int W) {
+    if (s->depth_ar < 1 || s->variant != IAF_VARIANT_TF || s->generic || s->precision != IAF_PRECISION_BF16X3) return false;
+    const GemmLayer& A = s->L[0];
+    const GemmLayer& Bl = s->L[1];
+    if (!A.wp3 || !Bl.wp3 || A.cin != 32) return false;
+    const int epi = (s->depth_ar == 1) ? EPI_OUT : EPI_HIDDEN;
+    if (Bl.ncot % (nt * wco) != 0 || (epi == EPI_OUT && (nt & 1))) return false;
+    if (!pick_bf3(nt, ppw, pxt, ks, IN_FUSED0, epi, wco)) return false;
+    const int nw = pxt * wco * ks, ntl = nw >= 8 ? 2 : 3;
+    if (A.ncot > nw * ntl) return false;
+    return bf3_fused_lds_bytes(Bl.cin, A.cin, W, nt, ppw, pxt, ks, wco) <= 160 * 1024;
+}
+
 // bf16x3 launch shape without a timing run (iaf_stack_autotune measures instead).  What the sweeps on one MI355X show
 // (tools/bf3_sweep.py, profiles/r02/bf3_sweep_*.txt): below ~4096 pixels a conv launch is all prologue / exchange /
 // epilogue latency and the exact-fp32 kernel is as fast or faster -> not selected; above, K-slicing over 4 waves with two
@@ -616,7 +649,7 @@ static bool auto_shape_bf3(GemmLayer& L, bool is_out, long long P, int W) {
         if (is_out && P >= 32768 && nt == 4) ppw = 4;
         if (!pick_bf3(nt, ppw, pxt, ks, IN_PIXMAJOR, is_out ? EPI_OUT : EPI_HIDDEN)) continue;
         if (bf3_lds_bytes(L.cin, W, nt, ppw, pxt, ks) > 160 * 1024) continue;
-        L.b_nt = nt; L.b_ppw = ppw; L.b_pxt = pxt; L.b_ks = ks;
+        L.b_nt = nt; L.b_ppw = ppw; L.b_pxt = pxt; L.b_ks = ks; L.b_wco = 1;
         return true;
     }
     return false;
@@ -628,28 +661,32 @@ static bool bf3_select(const iaf_stack_t* s, GemmLayer& L, int epi, bool negate_
     if (!(epi == EPI_HIDDEN || (epi == EPI_OUT && pix_input))) return false;
     if (!L.b_user_tuned && L.tuned_P == P && L.tuned_W == W) {       // measured for exactly this problem size
         if (!L.tuned_bf3) return false;
-        L.b_nt = L.t_nt; L.b_ppw = L.t_ppw; L.b_pxt = L.t_pxt; L.b_ks = L.t_ks;
+        L.b_nt = L.t_nt; L.b_ppw = L.t_ppw; L.b_pxt = L.t_pxt; L.b_ks = L.t_ks; L.b_wco = L.t_wco;
     } else if (!L.b_user_tuned && !auto_shape_bf3(L, epi == EPI_OUT, P, W)) return false;
-    if (!pick_bf3(L.b_nt, L.b_ppw, L.b_pxt, L.b_ks, IN_PIXMAJOR, epi)) return false;
-    return bf3_lds_bytes(L.cin, W, L.b_nt, L.b_ppw, L.b_pxt, L.b_ks) <= 160 * 1024;
+    if (!pick_bf3(L.b_nt, L.b_ppw, L.b_pxt, L.b_ks, IN_PIXMAJOR, epi, L.b_wco)) return false;
+    return bf3_lds_bytes(L.cin, W, L.b_nt, L.b_ppw, L.b_pxt, L.b_ks, L.b_wco) <= 160 * 1024;
 }
 
 // launches the conv kernel for GEMM descriptor L (forward layer, or a transposed descriptor for dgrad)
 static int launch_gemm(const iaf_stack_t* s, GemmLayer& L, int epi, bool negate_taps, int prof_id, ConvP& p, int inmode,
-                       hipStream_t st) {
+                       hipStream_t st, const int* force = nullptr) {
     conv_fn_t fn = nullptr;
     bool bf3 = false;
     // forward convs of the stack go to the bf16 matrix cores (bf16x3 split products, fp32-grade) when the layer has a
     // bf16x3 pack and a compiled shape covers it; everything else runs the exact-fp32 MFMA kernel
-    if (bf3_select(s, L, epi, negate_taps, inmode == IN_PIXMAJOR || inmode == IN_PIXMAJOR3, p.P, p.W)) {
-        fn = pick_bf3(L.b_nt, L.b_ppw, L.b_pxt, L.b_ks, inmode, epi);
+    if (force && force[0]) {            // shape fixed by the caller (the fused first layer decided on it)
+        L.b_nt = force[0]; L.b_ppw = force[1]; L.b_pxt = force[2]; L.b_ks = force[3]; L.b_wco = force[4];
+        fn = pick_bf3(L.b_nt, L.b_ppw, L.b_pxt, L.b_ks, inmode, epi, L.b_wco);
+        bf3 = fn != nullptr;
+    } else if (bf3_select(s, L, epi, negate_taps, inmode == IN_PIXMAJOR, p.P, p.W)) {
+        fn = pick_bf3(L.b_nt, L.b_ppw, L.b_pxt, L.b_ks, inmode, epi, L.b_wco);
         bf3 = fn != nullptr;
     }
-    if (!bf3 && (inmode == IN_PIXMAJOR3 || p.y3 || (epi == EPI_HIDDEN && !p.y))) return IAF_ERR_UNSUPPORTED;   // (host logic error)
+    if (!bf3 && inmode == IN_FUSED0) return IAF_ERR_UNSUPPORTED;   // (host logic error)
     if (!bf3 && !L.user_tuned) auto_shape(L, epi == EPI_OUT, p.P, p.W);
     const int tm = bf3 ? 16 * L.b_ppw * L.b_pxt : 16 * L.pxt;
-    const int yg = bf3 ? L.ncot / L.b_nt : L.ncot / (L.nt * L.wco);
-    const int nthreads = bf3 ? 64 * L.b_pxt * L.b_ks : 64 * L.pxt * L.wco * L.ks;
+    const int yg = bf3 ? L.ncot / (L.b_nt * L.b_wco) : L.ncot / (L.nt * L.wco);
+    const int nthreads = bf3 ? 64 * L.b_pxt * L.b_ks * L.b_wco : 64 * L.pxt * L.wco * L.ks;
     // a grid of at most one workgroup per CU has nothing to overlap a prologue with: use the double-depth weight ring
     if (!bf3 && epi == EPI_HIDDEN && inmode == IN_PIXMAJOR && ((p.P + tm - 1) / tm) * (L.ncot / (L.nt * L.wco)) <= 256)
         fn = pick_kernel(L.nt, L.pxt, L.wco, L.ks, inmode, EPI_HIDDEN_DEEP);
@@ -667,7 +704,9 @@ static int launch_gemm(const iaf_stack_t* s, GemmLayer& L, int epi, bool negate_
     p.cp = L.cin + 8;
     p.nslot = tm + p.W + 1;
     p.dbg = (prof_id >= 0 && s->dbg_layer == prof_id) ? s->dbg : nullptr;
-    const size_t lds = bf3 ? bf3_lds_bytes(L.cin, p.W, L.b_nt, L.b_ppw, L.b_pxt, L.b_ks) : conv_lds_bytes(L, p.W);
+    const size_t lds = !bf3 ? conv_lds_bytes(L, p.W)
+                     : inmode == IN_FUSED0 ? bf3_fused_lds_bytes(L.cin, p.f_cin, p.W, L.b_nt, L.b_ppw, L.b_pxt, L.b_ks, L.b_wco)
+                                           : bf3_lds_bytes(L.cin, p.W, L.b_nt, L.b_ppw, L.b_pxt, L.b_ks, L.b_wco);
     if (lds > 160 * 1024) return IAF_ERR_UNSUPPORTED;
     { int rc = raise_lds_cap((const void*)fn, lds); if (rc) return rc; }
     dim3 grid((p.P + tm - 1) / tm, yg);
@@ -681,9 +720,9 @@ static int launch_gemm(const iaf_stack_t* s, GemmLayer& L, int epi, bool negate_
     return (int)hipGetLastError();
 }
 
-static int launch_conv(const iaf_stack_t* s, int layer, ConvP& p, int inmode, hipStream_t st) {
+static int launch_conv(const iaf_stack_t* s, int layer, ConvP& p, int inmode, hipStream_t st, const int* force = nullptr) {
     return launch_gemm(s, const_cast<iaf_stack*>(s)->L[layer], layer == s->depth_ar ? EPI_OUT : EPI_HIDDEN, false, layer, p,
-                       inmode, st);
+                       inmode, st, force);
 }
 
 static int check_dims(const iaf_stack_t* s, int B, int H, int W) {
@@ -695,9 +734,26 @@ static int check_dims(const iaf_stack_t* s, int B, int H, int W) {
 }
 
 // the depth_ar hidden convs + the output pair as launch descriptors.  mode (in base) selects the final epilogue.
-struct Launch { int layer; ConvP p; int inmode; };
+struct Launch { int layer; ConvP p; int inmode; int force[5]; };
+// Should (and can) the first masked conv run inside the second one's kernel for this problem size?  -> shape in fz[5]
+static bool fuse_decide(iaf_stack_t* s, long long P, int W, int* fz) {
+    if (s->fuse_first == 0 || s->depth_ar < 1) return false;
+    GemmLayer& L1 = s->L[1];
+    if (s->fuse_first == 2 && L1.fz_P == P && L1.fz_W == W) {           // measured by iaf_stack_autotune
+        for (int i = 0; i < 5; ++i) fz[i] = L1.fz[i];
+        return L1.fz_on && fuse_shape_ok(s, fz[0], fz[1], fz[2], fz[3], fz[4], W);
+    }
+    if (s->fuse_first != 1) return false;       // "auto" without a measurement for this size: separate launches
+    // "always": the shape layer 1 would run anyway, if it can carry the fused layer
+    const bool is_out = (s->depth_ar == 1);
+    GemmLayer t = L1;
+    if (!bf3_select(s, t, is_out ? EPI_OUT : EPI_HIDDEN, false, true, P, W)) return false;
+    fz[0] = t.b_nt; fz[1] = t.b_ppw; fz[2] = t.b_pxt; fz[3] = t.b_ks; fz[4] = t.b_wco;
+    return fuse_shape_ok(s, fz[0], fz[1], fz[2], fz[3], fz[4], W);
+}
+
 static int build_stack(iaf_stack_t* s, ConvP base, int first_inmode, const float* ctx, const float* ctx2, const Ws& ws,
-                       Launch* out) {
+                       Launch* out, bool allow_fuse = true) {
     const float* cur = base.x;
     int inmode = first_inmode, n = 0;
     for (int l = 0; l < s->depth_ar; ++l) {
@@ -706,13 +762,27 @@ static int build_stack(iaf_stack_t* s, ConvP base, int first_inmode, const float
         p.ctx = (l == 0) ? ctx : nullptr;       // context only after the first conv (layers.py:163)
         p.ctx2 = (l == 0) ? ctx2 : nullptr;
         p.y = ws.hbuf[l & 1];
-        out[n++] = Launch{l, p, inmode};
+        out[n++] = Launch{l, p, inmode, {0, 0, 0, 0, 1}};
         cur = p.y;
         inmode = IN_PIXMAJOR;
     }
     ConvP p = base;
     p.x = cur;
-    out[n++] = Launch{s->depth_ar, p, inmode};
+    out[n++] = Launch{s->depth_ar, p, inmode, {0, 0, 0, 0, 1}};
+    // the first masked conv inside the second one's kernel (IN_FUSED0): one launch less, no HBM round trip of its output
+    int fz[5];
+    if (allow_fuse && n >= 2 && (first_inmode == IN_NCHW || first_inmode == IN_POSTERIOR) && fuse_decide(s, base.P, base.W, fz)) {
+        Launch& a = out[0];
+        Launch& b = out[1];
+        b.p.f_wp = s->L[0].wp3; b.p.f_bias = s->L[0].bias; b.p.f_cin = s->L[0].cin;
+        b.p.f_x = (first_inmode == IN_NCHW) ? a.p.x : nullptr;      // NULL: the posterior sample from qm / rm / ql / rl / eps
+        b.p.f_ctx = a.p.ctx; b.p.f_ctx2 = a.p.ctx2;
+        b.p.x = nullptr;
+        b.inmode = IN_FUSED0;
+        for (int i = 0; i < 5; ++i) b.force[i] = fz[i];
+        for (int i = 1; i < n; ++i) out[i - 1] = out[i];
+        --n;
+    }
     return n;
 }
 
@@ -747,7 +817,7 @@ static int run_stack(iaf_stack_t* s, ConvP base, int first_inmode, const float* 
     Launch ls[MAX_GEMM_LAYERS];
     const int n = build_stack(s, base, first_inmode, ctx, ctx2, ws, ls);
     for (int i = 0; i < n; ++i) {
-        int rc = launch_conv(s, ls[i].layer, ls[i].p, ls[i].inmode, st);
+        int rc = launch_conv(s, ls[i].layer, ls[i].p, ls[i].inmode, st, ls[i].force);
         if (rc) return rc;
     }
     return IAF_OK;
@@ -759,7 +829,8 @@ extern "C" int iaf_step_time_layer(iaf_stack_t* s, int layer, const float* z, co
     int rc = check_dims(s, B, H, W);
     if (rc) return rc;
     if (!z || !z_new || !logsd || !avg_ms || (s->depth_ar > 0 && !context)) return IAF_ERR_NULL;
-    if (layer < 0 || layer >= s->nlayers || reps <= 0) return IAF_ERR_SHAPE;
+    // layer = -1: the FUSED launch (first masked conv inside the second one's kernel), if the stack would use it at this size
+    if (layer < -1 || layer >= s->nlayers || reps <= 0) return IAF_ERR_SHAPE;
     if (s->generic) return IAF_ERR_UNSUPPORTED;
     Ws ws;
     if ((rc = carve_ws(s, B, H, W, workspace, workspace_bytes, &ws))) return rc;
@@ -769,9 +840,14 @@ extern "C" int iaf_step_time_layer(iaf_stack_t* s, int layer, const float* z, co
     p.B = B; p.H = H; p.W = W; p.HW = H * W; p.P = B * H * W;
     p.x = z; p.zin = z; p.out0 = z_new; p.out1 = logsd; p.mode = MODE_IAF;
     Launch ls[MAX_GEMM_LAYERS];
-    const int n = build_stack(s, p, IN_NCHW, context, nullptr, ws, ls);
+    int n = build_stack(s, p, IN_NCHW, context, nullptr, ws, ls, false);      // single layers are timed unfused
     for (int i = 0; i < n; ++i)                      // one full step: every layer's input is valid scratch afterwards
-        if ((rc = launch_conv(s, ls[i].layer, ls[i].p, ls[i].inmode, st))) return rc;
+        if ((rc = launch_conv(s, ls[i].layer, ls[i].p, ls[i].inmode, st, ls[i].force))) return rc;
+    if (layer == -1) {
+        n = build_stack(s, p, IN_NCHW, context, nullptr, ws, ls, true);
+        if (ls[0].inmode != IN_FUSED0) return IAF_ERR_UNSUPPORTED;
+        layer = 0;
+    }
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
@@ -779,7 +855,7 @@ extern "C" int iaf_step_time_layer(iaf_stack_t* s, int layer, const float* z, co
     s->prof_layer = -1;
     HIP_TRY(hipEventRecord(e0, st));
     for (int r = 0; r < reps; ++r)
-        if ((rc = launch_conv(s, ls[layer].layer, ls[layer].p, ls[layer].inmode, st))) break;
+        if ((rc = launch_conv(s, ls[layer].layer, ls[layer].p, ls[layer].inmode, st, ls[layer].force))) break;
     (void)hipEventRecord(e1, st);
     (void)hipEventSynchronize(e1);
     float ms = 0.f;
@@ -795,7 +871,7 @@ extern "C" int iaf_step_time_layer(iaf_stack_t* s, int layer, const float* z, co
 // reference's tf.nn.conv2d): every GEMM layer is timed as the exact-fp32 kernel (its automatic shape) and as every
 // compiled bf16x3 shape, `reps` back-to-back launches per event pair on the caller's buffers; the winner is remembered
 // for (B*H*W, W) and used by every later forward launch of that size.  chosen[l] = 0 (fp32 kernel) or
-// nt*1000 + ppw*100 + pxt*10 + ks; us[l] = its time.  Synchronises; do not call inside a stream capture.
+// nt*10000 + ppw*1000 + pxt*100 + ks*10 + wco; us[l] = its time.  Synchronises; do not call inside a stream capture.
 extern "C" int iaf_stack_autotune(iaf_stack_t* s, const float* z, const float* context, float* z_new, float* logsd, int B,
                                   int H, int W, void* workspace, size_t workspace_bytes, int reps, void* stream,
                                   int* chosen, float* us) {
@@ -813,32 +889,70 @@ extern "C" int iaf_stack_autotune(iaf_stack_t* s, const float* z, const float* c
         s->precision = IAF_PRECISION_F32;
         if ((rc = iaf_step_time_layer(s, l, z, context, z_new, logsd, B, H, W, workspace, workspace_bytes, reps, stream, &ms))) break;
         best = ms;
-        int bsel[4] = {0, 0, 0, 0};
+        int bsel[5] = {0, 0, 0, 0, 1};
         if (saved_prec == IAF_PRECISION_BF16X3 && L.wp3 && !(is_out && s->depth_ar == 0)) {
             s->precision = IAF_PRECISION_BF16X3;
             const bool ut = L.b_user_tuned;
-            const int sv[4] = {L.b_nt, L.b_ppw, L.b_pxt, L.b_ks};
+            const int sv[5] = {L.b_nt, L.b_ppw, L.b_pxt, L.b_ks, L.b_wco};
             static const int nts[3] = {5, 4, 2};
-            for (int si = 0; si < 4 && !rc; ++si)
+            for (int si = 0; si < N_BF3_SHAPES && !rc; ++si)
                 for (int ni = 0; ni < 3 && !rc; ++ni) {
                     const int nt = nts[ni], ppw = k_bf3_shapes[si][0], pxt = k_bf3_shapes[si][1], ks = k_bf3_shapes[si][2];
-                    if (L.ncot % nt != 0 || (is_out && (nt & 1))) continue;
-                    if (!pick_bf3(nt, ppw, pxt, ks, IN_PIXMAJOR, is_out ? EPI_OUT : EPI_HIDDEN)) continue;
-                    if (bf3_lds_bytes(L.cin, W, nt, ppw, pxt, ks) > 160 * 1024) continue;
-                    L.b_nt = nt; L.b_ppw = ppw; L.b_pxt = pxt; L.b_ks = ks; L.b_user_tuned = true;
+                    const int wco = k_bf3_shapes[si][3];
+                    if (L.ncot % (nt * wco) != 0 || (is_out && (nt & 1))) continue;
+                    if (!pick_bf3(nt, ppw, pxt, ks, IN_PIXMAJOR, is_out ? EPI_OUT : EPI_HIDDEN, wco)) continue;
+                    if (bf3_lds_bytes(L.cin, W, nt, ppw, pxt, ks, wco) > 160 * 1024) continue;
+                    L.b_nt = nt; L.b_ppw = ppw; L.b_pxt = pxt; L.b_ks = ks; L.b_wco = wco; L.b_user_tuned = true;
                     rc = iaf_step_time_layer(s, l, z, context, z_new, logsd, B, H, W, workspace, workspace_bytes, reps, stream, &ms);
-                    if (!rc && ms < best) { best = ms; bsel[0] = nt; bsel[1] = ppw; bsel[2] = pxt; bsel[3] = ks; }
+                    if (!rc && ms < best) { best = ms; bsel[0] = nt; bsel[1] = ppw; bsel[2] = pxt; bsel[3] = ks; bsel[4] = wco; }
                 }
-            L.b_user_tuned = ut; L.b_nt = sv[0]; L.b_ppw = sv[1]; L.b_pxt = sv[2]; L.b_ks = sv[3];
+            L.b_user_tuned = ut; L.b_nt = sv[0]; L.b_ppw = sv[1]; L.b_pxt = sv[2]; L.b_ks = sv[3]; L.b_wco = sv[4];
         }
         if (rc) break;
         L.tuned_P = P; L.tuned_W = W; L.tuned_bf3 = bsel[0] != 0;
-        L.t_nt = bsel[0]; L.t_ppw = bsel[1]; L.t_pxt = bsel[2]; L.t_ks = bsel[3];
-        if (chosen) chosen[l] = bsel[0] * 1000 + bsel[1] * 100 + bsel[2] * 10 + bsel[3];
+        L.t_nt = bsel[0]; L.t_ppw = bsel[1]; L.t_pxt = bsel[2]; L.t_ks = bsel[3]; L.t_wco = bsel[4];
+        if (chosen) chosen[l] = bsel[0] ? bsel[0] * 10000 + bsel[1] * 1000 + bsel[2] * 100 + bsel[3] * 10 + bsel[4] : 0;
         if (us) us[l] = 1e3f * best;
+        L.tuned_us = 1e3f * best;
     }
     s->precision = saved_prec;
+    // the first masked conv fused into the second one's kernel: every shape that can carry it, against the two separate
+    // launches (+ the launch boundary between them, which back-to-back timing of single kernels does not see)
+    if (!rc && s->depth_ar >= 1 && s->fuse_first != 0) {
+        GemmLayer& L1 = s->L[1];
+        L1.fz_P = -1;
+        const int saved_mode = s->fuse_first;
+        float best = 1e30f, ms = 0.f;
+        int bz[5] = {0, 0, 0, 0, 1};
+        static const int nts[3] = {5, 4, 2};
+        for (int si = 0; si < N_BF3_SHAPES && !rc; ++si)
+            for (int ni = 0; ni < 3 && !rc; ++ni) {
+                const int nt = nts[ni];
+                const int* sh = k_bf3_shapes[si];
+                if (!fuse_shape_ok(s, nt, sh[0], sh[1], sh[2], sh[3], W)) continue;
+                L1.fz_P = P; L1.fz_W = W; L1.fz_on = true;
+                L1.fz[0] = nt; L1.fz[1] = sh[0]; L1.fz[2] = sh[1]; L1.fz[3] = sh[2]; L1.fz[4] = sh[3];
+                s->fuse_first = 2;
+                rc = iaf_step_time_layer(s, -1, z, context, z_new, logsd, B, H, W, workspace, workspace_bytes, reps, stream, &ms);
+                if (rc == IAF_ERR_UNSUPPORTED) { rc = IAF_OK; continue; }
+                if (!rc && ms < best) { best = ms; for (int i = 0; i < 5; ++i) bz[i] = L1.fz[i]; }
+            }
+        s->fuse_first = saved_mode;
+        const float separate = s->L[0].tuned_us + L1.tuned_us + 1.0f;        // ~1 us: the boundary a fused launch removes
+        L1.fz_P = P; L1.fz_W = W;
+        L1.fz_on = (bz[0] != 0) && (1e3f * best < 0.90f * separate);         // only on a clear win (single timings are noisy)
+        for (int i = 0; i < 5; ++i) L1.fz[i] = bz[i];
+        if (L1.fz_on && chosen) { chosen[0] = -1; chosen[1] = bz[0] * 10000 + bz[1] * 1000 + bz[2] * 100 + bz[3] * 10 + bz[4]; }
+        if (L1.fz_on && us) { us[0] = 0.f; us[1] = 1e3f * best; }
+    }
     return rc;
+}
+
+extern "C" int iaf_stack_set_fuse_first(iaf_stack_t* s, int mode) {
+    if (!s) return IAF_ERR_NULL;
+    if (mode < 0 || mode > 2) return IAF_ERR_SHAPE;
+    s->fuse_first = mode;
+    return IAF_OK;
 }
 
 extern "C" int iaf_ar_multiconv2d_forward(iaf_stack_t* s, const float* z, const float* context, float* m_raw,

@@ -44,14 +44,14 @@ template <int NTP> __device__ __forceinline__ int tap_kh(int t) { return NTP == 
 template <int NTP> __device__ __forceinline__ int tap_kw(int t) { return NTP == 9 ? t % 3 : ((t == 0) ? 1 : (t == 1 ? 2 : t - 2)); }
 
 // The bf16x3 pack of one 16-channel output tile (iaf_conv_bf3.hpp): [c_in pair of 32][tap][cot][plane h/m/l][lane 64]
-// [8 bf16].  A second sweep over the (L2-hot) weights with the FRAGMENT's thread mapping -- thread = (lane = kk*16+oo,
-// quarter) owns the 8 consecutive input channels of one lane of one (pair, tap) fragment -- so that every store is a
-// full 16 bytes per lane, 1 KiB contiguous per wave (per-element 2-byte stores from the first sweep's mapping doubled
-// the prep kernel's time).  Same mask / scale as the fp32 pack: s_scale[] holds the per-channel norm factor.
-__device__ __forceinline__ void prep_bf3_pass(const PrepLayer& L, int gt, const float* s_scale) {
-    typedef __bf16 pb16x2 __attribute__((ext_vector_type(2)));
-    typedef float pf32x2 __attribute__((ext_vector_type(2)));
-    typedef unsigned pu32x4 __attribute__((ext_vector_type(4)));
+// [8 bf16].  A second pass over the weights with the FRAGMENT's thread mapping -- thread = (lane = kk*16+oo, quarter)
+// owns the 8 consecutive input channels of one lane of one (pair, tap) fragment -- so that every store is a full 16
+// bytes per lane, 1 KiB contiguous per wave (per-element 2-byte stores from the first pass's mapping doubled the prep
+// kernel's time).  Split in two: the LOADS (mask applied) are issued together with the first pass's, before the norm
+// reduction they do not depend on; the scale, the three-way split and the stores follow once s_scale[] is known.
+#define PREP_BF3_UPQ(NCH) ((((NCH) / 2) * NTAPS + 3) / 4)      // (pair, tap) units per quarter of the workgroup
+template <int NCH>
+__device__ __forceinline__ void prep_bf3_load(const PrepLayer& L, int gt, float (*w)[8]) {
     const int which = (L.npair == 2) ? (gt & 1) : 0;
     const int src_tile = (L.npair == 2) ? (gt >> 1) : gt;
     const float* __restrict__ V = L.V[which];
@@ -63,13 +63,14 @@ __device__ __forceinline__ void prep_bf3_pass(const PrepLayer& L, int gt, const 
     const bool flip = (L.variant == IAF_VARIANT_THEANO_FLIPMASK);
     const int k0 = (n_out >= n_in) ? n_out / n_in : 1;
     const bool row_zeroed = theano && L.zerodiag && o < k0;         // ar.py:268-276 (see prep_tile_theano)
-    const float scale = s_scale[oo];
-    const int nunit = (n_in >> 5) * NTAPS;
-    for (int u = quarter; u < nunit; u += 4) {
+    constexpr int NUNIT = (NCH / 2) * NTAPS;
+#pragma unroll
+    for (int i = 0; i < PREP_BF3_UPQ(NCH); ++i) {
+        const int uu = quarter + 4 * i;
+        const int u = uu < NUNIT ? uu : NUNIT - 1;                  // clamped: the surplus slot is loaded, never stored
         const int pair = u / NTAPS, t = u - pair * NTAPS;
         const int kh = (t == 0 || t == 1) ? 1 : 2;
         const int kw = (t == 0) ? 1 : (t == 1 ? 2 : t - 2);
-        float w[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int ci = pair * 32 + 8 * kk + e;
@@ -84,18 +85,34 @@ __device__ __forceinline__ void prep_bf3_pass(const PrepLayer& L, int gt, const 
                 x = V[((size_t)(kh * 3 + kw) * n_in + ci) * n_out + o];
                 if (t == 0) live = made_live(ci, o, n_in, n_out, L.zerodiag);
             }
-            w[e] = live ? x * scale : 0.f;
+            w[i][e] = live ? x : 0.f;
         }
+    }
+}
+
+template <int NCH>
+__device__ __forceinline__ void prep_bf3_store(const PrepLayer& L, int gt, const float (*w)[8], const float* s_scale) {
+    typedef __bf16 pb16x2 __attribute__((ext_vector_type(2)));
+    typedef float pf32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned pu32x4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63, quarter = threadIdx.x >> 6;
+    const float scale = s_scale[lane & 15];
+    constexpr int NUNIT = (NCH / 2) * NTAPS;
+#pragma unroll
+    for (int i = 0; i < PREP_BF3_UPQ(NCH); ++i) {
+        const int u = quarter + 4 * i;
+        if (u >= NUNIT) continue;
+        const int pair = u / NTAPS, t = u - pair * NTAPS;
         pu32x4 ph, pm, pl;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const pf32x2 x = {w[2 * i], w[2 * i + 1]};
+        for (int k = 0; k < 4; ++k) {
+            const pf32x2 x = {w[i][2 * k] * scale, w[i][2 * k + 1] * scale};
             const pb16x2 hb = __builtin_convertvector(x, pb16x2);
             const pf32x2 r1 = x - __builtin_convertvector(hb, pf32x2);
             const pb16x2 mb = __builtin_convertvector(r1, pb16x2);
             const pf32x2 r2 = r1 - __builtin_convertvector(mb, pf32x2);
             const pb16x2 lb = __builtin_convertvector(r2, pb16x2);
-            ph[i] = __builtin_bit_cast(unsigned, hb); pm[i] = __builtin_bit_cast(unsigned, mb); pl[i] = __builtin_bit_cast(unsigned, lb);
+            ph[k] = __builtin_bit_cast(unsigned, hb); pm[k] = __builtin_bit_cast(unsigned, mb); pl[k] = __builtin_bit_cast(unsigned, lb);
         }
         pu32x4* q = (pu32x4*)L.wp3 + (((size_t)(pair * NTAPS + t) * L.ncot + gt) * 3) * 64 + lane;
         q[0] = ph; q[64] = pm; q[128] = pl;
@@ -112,6 +129,9 @@ __device__ __forceinline__ void prep_tile(const PrepLayer& L, int gt, float (*re
     const int n_out = L.cout_each, n_in = L.cin;
     const float gval = L.g[which][o], bval = L.b[which][o];
 
+    constexpr bool BF3 = (NTP == NTAPS) && (NCH % 2 == 0);
+    float w3[BF3 ? PREP_BF3_UPQ(NCH) : 1][8];
+    if constexpr (BF3) { if (L.wp3) prep_bf3_load<NCH>(L, gt, w3); }
     // pass 1: fetch + mask (layers.py:57), sum of squares over (taps, c_in) (layers.py:60)
     float v[NTP][NCH];
 #pragma unroll
@@ -155,7 +175,7 @@ __device__ __forceinline__ void prep_tile(const PrepLayer& L, int gt, float (*re
             for (int t = 0; t < NTP; ++t)
                 L.wpt[((((size_t)gt * NTP + t) * NCH + it) * 64 + (oo >> 2) * 16 + cs) * 4 + (oo & 3)] = v[t][it] * scale;
     }
-    if (NTP == NTAPS && L.wp3) prep_bf3_pass(L, gt, s_scale);
+    if constexpr (BF3) { if (L.wp3) prep_bf3_store<NCH>(L, gt, w3, s_scale); }
 }
 
 // Theano statement of the same weights (graphy/nodes/ar.py:243-330, l2norm=True, logscale=True, pad_channel=True):
@@ -182,6 +202,9 @@ __device__ __forceinline__ void prep_tile_theano(const PrepLayer& L, int gt, flo
     const bool flip = (L.variant == IAF_VARIANT_THEANO_FLIPMASK);
     const float sval = L.g[which][o], bval = L.b[which][o];
     const float* wo = Wt + (size_t)o * (n_in + 1) * 9;
+    constexpr bool BF3 = (NCH % 2 == 0);
+    float w3[BF3 ? PREP_BF3_UPQ(NCH) : 1][8];
+    if constexpr (BF3) { if (L.wp3) prep_bf3_load<NCH>(L, gt, w3); }
     float v[NTAPS][NCH];
 #pragma unroll
     for (int it = 0; it < NCH; ++it) {
@@ -241,7 +264,7 @@ __device__ __forceinline__ void prep_tile_theano(const PrepLayer& L, int gt, flo
 #pragma unroll
         for (int t = 0; t < NTAPS; ++t)
             L.wp[((((size_t)it * NTAPS + t) * L.ncot + gt) * 64 + kk * 16 + oo) * 4 + jj] = v[t][it] * scale;
-    if (L.wp3) prep_bf3_pass(L, gt, s_scale);
+    if constexpr (BF3) { if (L.wp3) prep_bf3_store<NCH>(L, gt, w3, s_scale); }
 }
 
 #define PREP_MAXI 16   // n_in <= 256

@@ -192,7 +192,8 @@ class ARStack(object):
         return tens
 
     def time_layer(self, layer, z, context, reps=50):
-        """average duration (ms) of GEMM layer `layer` over `reps` back-to-back launches between one HIP event pair"""
+        """average duration (ms) of GEMM layer `layer` over `reps` back-to-back launches between one HIP event pair;
+        layer = -1: the fused launch of layers 0+1 (UnsupportedError if the stack would not fuse at this size)"""
         B, H, W = self._dims(z, context)
         ws, need = self.workspace(B, H, W, z.device)
         zn, ls = torch.empty_like(z), torch.empty_like(z)
@@ -228,7 +229,7 @@ class ARStack(object):
     def autotune(self, z, context, reps=20):
         """time every GEMM layer as the exact-fp32 kernel and as every compiled bf16x3 launch shape on these buffers and
         keep the fastest for this (B, H, W) -- what cuDNN's algorithm search does for the reference's convs.  Returns
-        [(choice, us)] per layer, choice = "f32" or "bf16x3(nt,ppw,pxt,ks)".  Synchronises: call before graph capture."""
+        [(choice, us)] per layer, choice = "f32" or "bf16x3(nt,ppw,pxt,ks,wco)".  Synchronises: call before graph capture."""
         B, H, W = self._dims(z, context)
         ws, need = self.workspace(B, H, W, z.device)
         zn, ls = torch.empty_like(z), torch.empty_like(z)
@@ -239,11 +240,21 @@ class ARStack(object):
         out = []
         for i in range(n):
             c = chosen[i]
-            out.append(("f32" if c == 0 else "bf16x3(%d,%d,%d,%d)" % (c // 1000, c // 100 % 10, c // 10 % 10, c % 10), us[i]))
+            name = "f32" if c == 0 else ("fused into next" if c < 0 else
+                                         "bf16x3(%d,%d,%d,%d,%d)" % (c // 10000, c // 1000 % 10, c // 100 % 10, c // 10 % 10, c % 10))
+            if c > 0 and i == 1 and chosen[0] < 0:
+                name += "+layer0"
+            out.append((name, us[i]))
         return out
 
-    def set_tuning_bf3(self, layer, nt, ppw, pxt, ks):
-        _capi.check(_capi.lib().iaf_stack_set_tuning_bf3(self._h, layer, nt, ppw, pxt, ks))
+    def set_fuse_first(self, mode):
+        """first masked conv inside the second one's kernel: "never" | "always" (whenever the kernels allow) | "auto"
+        (default: only where autotune measured it clearly faster).  See include/iaf_hip.h."""
+        code = {"never": 0, "always": 1, "auto": 2}.get(mode, mode)
+        _capi.check(_capi.lib().iaf_stack_set_fuse_first(self._h, int(code)))
+
+    def set_tuning_bf3(self, layer, nt, ppw, pxt, ks, wco=1):
+        _capi.check(_capi.lib().iaf_stack_set_tuning_bf3(self._h, layer, nt, ppw, pxt, ks, wco))
 
     def step_work(self, B, H, W):
         a, b, c = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()

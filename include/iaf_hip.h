@@ -227,14 +227,22 @@ int iaf_stack_set_tuning(iaf_stack_t* s, int layer, int nt, int pxt, int wco, in
 int iaf_stack_set_precision(iaf_stack_t* s, int precision);
 int iaf_stack_get_precision(const iaf_stack_t* s, int layer, int B, int H, int W);
 /* launch shape of the bf16x3 kernel for GEMM layer `layer`: co tiles per wave, pixel tiles per wave, waves along
- * pixels, K-slice waves (nt = 0 restores the automatic choice) */
-int iaf_stack_set_tuning_bf3(iaf_stack_t* s, int layer, int nt, int ppw, int pxt, int ks);
+ * pixels, K-slice waves, co groups sharing one staged activation tile (nt = 0 restores the automatic choice) */
+int iaf_stack_set_tuning_bf3(iaf_stack_t* s, int layer, int nt, int ppw, int pxt, int ks, int wco);
 /* Kernel-family / launch-shape search for one problem size -- the counterpart of the cuDNN algorithm search behind the
  * reference's tf.nn.conv2d (tf_utils/layers.py:64): times every GEMM layer as the exact-fp32 kernel and as every compiled
  * bf16x3 shape (`reps` back-to-back launches each, on the caller's buffers) and remembers the winner for (B*H*W, W).
- * chosen[l] (optional, depth_ar+1 entries) = 0 for the fp32 kernel or nt*1000 + ppw*100 + pxt*10 + ks; us[l] its time.
+ * chosen[l] (optional, depth_ar+1 entries) = 0 for the fp32 kernel or nt*10000 + ppw*1000 + pxt*100 + ks*10 + wco; us[l] its time.
  * Synchronises the stream: call it before capturing a graph.  Results of later launches are unaffected beyond fp32
  * round-off (both families meet the same parity bar). */
+/* The first masked conv of a stack (c_in = n_z = 32: five K steps) can run INSIDE the second one's bf16x3 kernel: its
+ * output goes straight into that kernel's LDS tile (recomputed on the halo) -- one launch and one HBM round trip less per
+ * IAF step.  mode 0 = never, 1 = whenever the kernels allow it, 2 (default) = only where iaf_stack_autotune measured it
+ * clearly faster for the problem size (on MI355X at the BASELINE sizes the fused prologue is a latency chain that costs
+ * more than the launch it saves, DESIGN.md 4.8, so the default in practice runs separate launches).  TF statement, bf16x3 precision, n_z = 32 only; results equal the unfused
+ * path's bit for bit (the same products in the same order).  In iaf_stack_autotune's report a fused pair shows as
+ * chosen[0] = -1 and chosen[1] = the fused kernel's shape. */
+int iaf_stack_set_fuse_first(iaf_stack_t* s, int mode);
 int iaf_stack_autotune(iaf_stack_t* s, const float* z, const float* context, float* z_new, float* logsd, int B, int H, int W,
                        void* workspace, size_t workspace_bytes, int reps, void* stream, int* chosen, float* us);
 /* Per-kernel timing with HIP events on the launch stream: every launch of GEMM layer `layer` is
@@ -245,7 +253,8 @@ int iaf_stack_profile_enable(iaf_stack_t* s, int layer, int max_samples);
 int iaf_stack_profile_read(iaf_stack_t* s, float* ms_out, int capacity, int* n_out);
 /* Roofline timing: runs one full iaf_step (so every layer has valid inputs), then launches GEMM layer `layer`
  * `reps` times back to back between ONE pair of HIP events on `stream`; *avg_ms = elapsed / reps (includes the
- * ~1 us inter-launch gap, excludes event/dispatch latency).  Synchronises the stream. */
+ * ~1 us inter-launch gap, excludes event/dispatch latency).  Synchronises the stream.  layer = -1 times the FUSED launch
+ * (layers 0+1 in one kernel, iaf_stack_set_fuse_first) or returns IAF_ERR_UNSUPPORTED if the stack would not fuse here. */
 int iaf_step_time_layer(iaf_stack_t* s, int layer, const float* z, const float* context, float* z_new, float* logsd,
                         int B, int H, int W, void* workspace, size_t workspace_bytes, int reps, void* stream,
                         float* avg_ms);

@@ -97,25 +97,25 @@ def test_bf16x3_error_is_fp32_grade(amd, shape):
     assert err["bf16x3"] <= 2.0 * err["f32"] + 1e-6                      # ... and the split products are no worse
 
 
-BF3_SHAPES = [(4, 1, 4), (2, 1, 4), (1, 1, 4), (1, 4, 1)]
+BF3_SHAPES = [(4, 1, 4, 1), (2, 1, 4, 1), (1, 1, 4, 1), (1, 4, 1, 1), (2, 1, 4, 2), (1, 1, 4, 2)]
 
 
-@pytest.mark.parametrize("shp", BF3_SHAPES, ids=lambda s: "ppw%d_pxt%d_ks%d" % s)
+@pytest.mark.parametrize("shp", BF3_SHAPES, ids=lambda s: "ppw%d_pxt%d_ks%d_wco%d" % s)
 @pytest.mark.parametrize("cfg", [(5, 32, 160, 2, 8, 8), (3, 64, 128, 4, 5, 7), (32, 32, 160, 2, 16, 16)],
                          ids=lambda s: "B%d_z%d_h%d_d%d_%dx%d" % s)
 def test_every_bf16x3_launch_shape_agrees(amd, shp, cfg):
     B, n_z, n_h, d, H, W = cfg
-    ppw, pxt, ks = shp
+    ppw, pxt, ks, wco = shp
     params, z, ctx = _case(41, *cfg)
     st = amd.ARStack(n_z, [n_h] * d)
     st.prepare({k: dev(v) for k, v in params.items()})
     hid_tiles, out_tiles = n_h // 16, 2 * n_z // 16
-    nt_h = [n for n in (5, 4, 2) if hid_tiles % n == 0][0]
-    nt_o = [n for n in (4, 2) if out_tiles % n == 0][0]
+    nt_h = [n for n in (5, 4, 2) if hid_tiles % (n * wco) == 0][0]
+    nt_o = [n for n in (4, 2) if out_tiles % (n * wco) == 0][0]
     try:
         for layer in range(d):
-            st.set_tuning_bf3(layer, nt_h, ppw, pxt, ks)
-        st.set_tuning_bf3(d, nt_o, ppw, pxt, ks)
+            st.set_tuning_bf3(layer, nt_h, ppw, pxt, ks, wco)
+        st.set_tuning_bf3(d, nt_o, ppw, pxt, ks, wco)
         z_new, logsd = st.iaf_step(dev(z), dev(ctx))
     except amd.UnsupportedError as e:
         pytest.skip(str(e))
@@ -235,10 +235,11 @@ def test_autotune_picks_a_kernel_per_layer_and_keeps_parity(amd):
     st = amd.ARStack(n_z, [n_h] * d)
     st.prepare({k: dev(v) for k, v in params.items()})
     picks = st.autotune(dev(z), dev(ctx), reps=10)
-    assert len(picks) == d + 1 and all(us > 0 for _, us in picks)
+    assert len(picks) == d + 1 and all(us > 0 or c == "fused into next" for c, us in picks)
     print("autotune:", picks)
     for layer, (choice, _) in enumerate(picks):
-        assert st.layer_precision(layer, B, H, W) == ("f32" if choice == "f32" else "bf16x3")
+        if choice != "fused into next" and not choice.endswith("+layer0"):
+            assert st.layer_precision(layer, B, H, W) == ("f32" if choice == "f32" else "bf16x3")
     z_new, logsd = st.iaf_step(dev(z), dev(ctx))
     p32 = {k: f32(v) for k, v in params.items()}
     ez, es = [], []
@@ -247,3 +248,75 @@ def test_autotune_picks_a_kernel_per_layer_and_keeps_parity(amd):
         ez.append(a); es.append(b)
     np.testing.assert_allclose(host(z_new), np.concatenate(ez), atol=ATOL, rtol=0)
     np.testing.assert_allclose(host(logsd), np.concatenate(es), atol=ATOL, rtol=0)
+
+
+# ---------------------------------------------------------------- first masked conv fused into the second one's kernel (IN_FUSED0)
+@pytest.mark.parametrize("shp", [(5, 2, 1, 4, 1), (5, 1, 1, 4, 1), (5, 2, 1, 4, 2), (2, 2, 1, 4, 1), (2, 1, 1, 4, 1)],
+                         ids=lambda s: "nt%d_ppw%d_pxt%d_ks%d_wco%d" % s)
+@pytest.mark.parametrize("cfg", [(32, 32, 160, 2, 16, 16), (32, 32, 160, 2, 8, 8), (3, 32, 160, 2, 5, 7), (16, 32, 64, 1, 8, 8),
+                                 (2, 32, 128, 3, 4, 4)], ids=lambda s: "B%d_z%d_h%d_d%d_%dx%d" % s)
+def test_fused_first_layer_vs_oracle_and_unfused(amd, shp, cfg):
+    """IN_FUSED0: layer 0 (32 -> n_h) computed in the prologue of layer 1's kernel (layer 1 = a hidden layer, or the output
+    pair when depth_ar = 1), straight into its LDS tile.  Checked against the oracle, against the unfused path, and bit for
+    bit against the unfused path when that runs layer 0 without K-slicing (same products in the same order)."""
+    B, n_z, n_h, d, H, W = cfg
+    nt, ppw, pxt, ks, wco = shp
+    params, z, ctx = _case(77, *cfg)
+    dp = {k: dev(v) for k, v in params.items()}
+    zd, cd = dev(z), dev(ctx)
+    tiles1 = (n_h if d > 1 else 2 * n_z) // 16
+    if tiles1 % (nt * wco) or (d == 1 and nt % 2):
+        pytest.skip("layer 1 has %d co tiles" % tiles1)
+    ref = amd.ARStack(n_z, [n_h] * d)
+    ref.set_fuse_first("never")
+    ref.prepare(dp)
+    nt0 = [n for n in (5, 4, 2) if (n_h // 16) % n == 0][0]
+    ref.set_tuning_bf3(0, nt0, 1, 4, 1)                      # layer 0 without K-slicing
+    ref.set_tuning_bf3(1, nt, ppw, pxt, ks, wco)
+    st = amd.ARStack(n_z, [n_h] * d)
+    st.set_fuse_first("always")
+    st.prepare(dp)
+    st.set_tuning_bf3(1, nt, ppw, pxt, ks, wco)
+    try:
+        fused_us = 1e3 * st.time_layer(-1, zd, cd, reps=3)  # raises UnsupportedError if this shape cannot carry the fused layer
+    except amd.UnsupportedError as e:
+        pytest.skip(str(e))
+    assert fused_us > 0
+    z_ref, s_ref = ref.iaf_step(zd, cd)
+    z_new, logsd = st.iaf_step(zd, cd)
+    assert torch.equal(z_new, z_ref) and torch.equal(logsd, s_ref)
+    p32 = {k: f32(v) for k, v in params.items()}
+    ez, es = [], []
+    for b0 in range(0, B, 16):
+        a, b = O.iaf_step(f32(z[b0:b0 + 16]), f32(ctx[b0:b0 + 16]), p32, [n_h] * d)
+        ez.append(a); es.append(b)
+    np.testing.assert_allclose(host(z_new), np.concatenate(ez), atol=ATOL, rtol=0)
+    np.testing.assert_allclose(host(logsd), np.concatenate(es), atol=ATOL, rtol=0)
+
+
+@pytest.mark.parametrize("kl_min", [0.0, 0.25])
+def test_fused_first_layer_posterior_block(amd, kl_min):
+    """the fused prologue with the posterior sample as its input (z0 from qm / rm / ql / rl / eps) and two contexts"""
+    B, n_z, n_h, d, H, W = 8, 32, 160, 2, 16, 16
+    rng = np.random.RandomState(56)
+    params = gi.ar_multiconv2d_params(rng, n_z, [n_h] * d, [n_z, n_z])
+    f = lambda c: rng.standard_normal((B, c, H, W))
+    qm, ql, rm, rl, pm, pl = f(n_z), 0.25 * f(n_z), f(n_z), 0.25 * f(n_z), f(n_z), 0.25 * f(n_z)
+    uc, dc, eps = f(n_h), f(n_h), f(n_z)
+    e = O.posterior_block(f32(qm), f32(ql), f32(rm), f32(rl), f32(pm), f32(pl), f32(uc), f32(dc), f32(eps),
+                          {k: f32(v) for k, v in params.items()}, [n_h] * d, kl_min)
+    outs = {}
+    for mode in ("always", "never"):
+        st = amd.ARStack(n_z, [n_h] * d)
+        st.set_fuse_first(mode)
+        st.prepare({k: dev(v) for k, v in params.items()})
+        st.set_tuning_bf3(0, 5, 1, 4, 1)
+        st.set_tuning_bf3(1, 5, 2, 1, 4)
+        st.set_tuning_bf3(2, 2, 2, 1, 4)
+        out = st.posterior_block(dev(qm), dev(ql), dev(rm), dev(rl), dev(pm), dev(pl), dev(uc), dev(dc), dev(eps),
+                                 kl_min, want_kl_elem=True)
+        np.testing.assert_allclose(host(out["z"]), e["z"], atol=ATOL, rtol=0)
+        np.testing.assert_allclose(host(out["kl_elem"]), e["logqs"] - e["logps"], atol=ATOL, rtol=1e-5)
+        np.testing.assert_allclose(host(out["kl_obj"]), e["kl_obj"], atol=2e-3, rtol=1e-4)
+        outs[mode] = out
+    assert torch.equal(outs["always"]["z"], outs["never"]["z"]) and torch.equal(outs["always"]["kl_elem"], outs["never"]["kl_elem"])

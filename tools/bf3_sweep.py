@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 import golden_inputs as gi  # noqa: E402
 import iaf_amd  # noqa: E402
 
-BF3_SHAPES = [(4, 1, 4), (2, 1, 4), (1, 1, 4), (1, 4, 1)]
+BF3_SHAPES = [(4, 1, 4, 1), (2, 1, 4, 1), (1, 1, 4, 1), (1, 4, 1, 1), (2, 1, 4, 2), (1, 1, 4, 2)]
 
 
 def main():
@@ -46,7 +46,7 @@ def main():
                 w = st.layer_work(layer, a.batch, H, H)
                 tot[prec] += us
                 print("B=%d %dx%d layer %d %-7s (runs %s) %8.2f us  %6.1f TF live" %
-                      (a.batch, H, H, layer, prec, st.layer_precision(layer), us, w["live_flops"] / us / 1e6), flush=True)
+                      (a.batch, H, H, layer, prec, st.layer_precision(layer, a.batch, H, H), us, w["live_flops"] / us / 1e6), flush=True)
         print("B=%d %dx%d IAF step (sum of layers): f32 %.1f us, bf16x3 %.1f us  (x%.2f)" %
               (a.batch, H, H, tot["f32"], tot["bf16x3"], tot["f32"] / tot["bf16x3"]), flush=True)
         if not a.sweep:
@@ -60,17 +60,19 @@ def main():
             for nt in ((4, 2) if is_out else (5, 4, 2)):
                 if ncot % nt:
                     continue
-                for (ppw, pxt, ks) in BF3_SHAPES:
+                for (ppw, pxt, ks, wco) in BF3_SHAPES:
+                    if ncot % (nt * wco):
+                        continue
                     try:
-                        st.set_tuning_bf3(layer, nt, ppw, pxt, ks)
+                        st.set_tuning_bf3(layer, nt, ppw, pxt, ks, wco)
                         st.iaf_step(z, ctx)
                         us = 1e3 * min(st.time_layer(layer, z, ctx, reps=50) for _ in range(2))
                     except ValueError as e:
                         continue
-                    res.append((us, nt, ppw, pxt, ks))
+                    res.append((us, nt, ppw, pxt, ks, wco))
             res.sort()
-            for us, nt, ppw, pxt, ks in res:
-                print("   layer %d  %8.2f us  nt=%d ppw=%d pxt=%d ks=%d" % (layer, us, nt, ppw, pxt, ks), flush=True)
+            for us, nt, ppw, pxt, ks, wco in res:
+                print("   layer %d  %8.2f us  nt=%d ppw=%d pxt=%d ks=%d wco=%d" % (layer, us, nt, ppw, pxt, ks, wco), flush=True)
             st.set_tuning_bf3(layer, 0, 0, 0, 0)
 
 
