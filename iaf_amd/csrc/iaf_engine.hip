@@ -1150,7 +1150,7 @@ extern "C" int iaf_compute_lowerbound(const float* log_pxz, const float* sum_kl,
 // ---------------------------------------------------------------------------------------------
 extern "C" int iaf_stack_set_training(iaf_stack_t* s, int on) {
     if (!s) return IAF_ERR_NULL;
-    if (s->variant != IAF_VARIANT_TF || s->generic) return IAF_ERR_UNSUPPORTED;
+    if (s->generic) return IAF_ERR_UNSUPPORTED;
     if (!on) { s->training = false; return IAF_OK; }
     for (int l = 0; l < s->nlayers; ++l) {
         GemmLayer& L = s->L[l];
@@ -1186,6 +1186,7 @@ struct TrainWs {
     float* part[MAX_GEMM_LAYERS];    // per layer: weight-gradient partials [nrange][NTAPS][cin][cout]
     float* dWeff[MAX_GEMM_LAYERS];   // per layer: reduced effective-weight gradient [NTAPS][cin][cout]
     float* dbp[MAX_GEMM_LAYERS];     // per layer: [<=256 slabs][cout] column sums of dY
+    float* dbrd[MAX_GEMM_LAYERS];    // Theano statement, per layer: [<=256 slabs][4][cout] border-channel weight gradient partials
     // posterior block: saved forward values and backward temporaries, all NCHW [P*n_z] unless noted
     float* logsd; float* klelem; float* z0; float* dzt; float* dkl; float* dz0;
     float* rowsum;   // [B*n_z]  (P*n_z floats reserved: B <= P)
@@ -1205,6 +1206,7 @@ static size_t train_ws_floats(const iaf_stack_t* s, long long P, TrainWs* o, flo
         t.part[l] = take((size_t)16 * NTAPS * s->L[l].cin * s->L[l].cout);
         t.dWeff[l] = take((size_t)NTAPS * s->L[l].cin * s->L[l].cout);
         t.dbp[l] = take((size_t)256 * s->L[l].cout);
+        t.dbrd[l] = (s->variant != IAF_VARIANT_TF) ? take((size_t)256 * (NTAPS - 1) * s->L[l].cout) : nullptr;
     }
     t.logsd = take((size_t)P * s->n_z); t.klelem = take((size_t)P * s->n_z); t.z0 = take((size_t)P * s->n_z);
     t.dzt = take((size_t)P * s->n_z); t.dkl = take((size_t)P * s->n_z); t.dz0 = take((size_t)P * s->n_z);
@@ -1292,8 +1294,9 @@ static int tapmask_for(int B, int H, int W, hipStream_t st, unsigned short* ws_c
     return 0;
 }
 
+// tap_sign = -1: the Theano statement's taps look left / above (launch_gemm)
 static int launch_wgrad(const iaf_stack_t* s, const GemmLayer& L, const float* x, const float* dy, float* part,
-                        const unsigned short* tapmask, int B, int H, int W, hipStream_t st) {
+                        const unsigned short* tapmask, int B, int H, int W, hipStream_t st, int tap_sign = 1) {
     WgradP p;
     memset(&p, 0, sizeof(p));
     p.x = x; p.dy = dy; p.part = part; p.tapmask = tapmask;
@@ -1305,8 +1308,8 @@ static int launch_wgrad(const iaf_stack_t* s, const GemmLayer& L, const float* x
     p.px_per_range = (int)(((long long)p.P + p.nrange - 1) / p.nrange + 15) / 16 * 16;
     static const int tf_dh[NTAPS] = {0, 0, 1, 1, 1}, tf_dw[NTAPS] = {0, 1, -1, 0, 1};
     for (int t = 0; t < ntaps; ++t) {
-        p.tap_dh[t] = L.full3x3 ? t / 3 - 1 : tf_dh[t];
-        p.tap_dw[t] = L.full3x3 ? t % 3 - 1 : tf_dw[t];
+        p.tap_dh[t] = L.full3x3 ? t / 3 - 1 : tap_sign * tf_dh[t];
+        p.tap_dw[t] = L.full3x3 ? t % 3 - 1 : tap_sign * tf_dw[t];
     }
     static const int cand[] = {14, 12, 10, 8, 7, 6, 5, 4, 3, 2, 1};
     int ncot = 1;
@@ -1374,8 +1377,9 @@ extern "C" int iaf_step_backward(iaf_stack_t* s, const float* z, const float* co
         if (nblk > 256) nblk = 256;
         r.blk_begin = ra.nblk_total;
         ra.nblk_total += nblk;
-        r.dy = dy; r.dbp = tw.dbp[l]; r.cout = L.cout;
+        r.dy = dy; r.dbp = tw.dbp[l]; r.cout = L.cout; r.dbrd = tw.dbrd[l];
     };
+    const int tap_sign = (s->variant == IAF_VARIANT_THEANO) ? -1 : 1;
     WnBwdArgs wa;
     memset(&wa, 0, sizeof(wa));
     auto wn_add = [&](int conv_index, int l, int n_out_each, int pack_stride, int pack_off) {
@@ -1386,12 +1390,18 @@ extern "C" int iaf_step_backward(iaf_stack_t* s, const float* z, const float* co
         w.dV = dV[conv_index]; w.dg = dg[conv_index]; w.db = db[conv_index];
         w.cin = L.cin; w.cout = n_out_each; w.cout_packed = L.cout; w.nslab = nslab; w.zerodiag = L.zerodiag;
         w.pack_stride = pack_stride; w.pack_off = pack_off;
+        w.dbrd = tw.dbrd[l]; w.variant = s->variant;
         wa.tile_begin[wa.n + 1] = wa.tile_begin[wa.n] + n_out_each / 16;
         wa.n++;
     };
 
     const unsigned short* tapmask = nullptr;
     if ((rc = tapmask_for(B, H, W, st, tw.tapmask, &tapmask))) return rc;
+    ra.tapmask = tapmask;
+    {
+        static const int tf_dh[NTAPS] = {0, 0, 1, 1, 1}, tf_dw[NTAPS] = {0, 1, -1, 0, 1};
+        for (int t = 1; t < NTAPS; ++t) ra.brd_bit[t - 1] = (tap_sign * tf_dh[t] + 1) * 3 + (tap_sign * tf_dw[t] + 1);
+    }
     // (2) walk the layers backwards: data gradient (same conv kernel on W^T, mirrored taps), then weight gradient
     const float* dy = tw.dy3;                       // gradient w.r.t. the output of layer l (packed pixel-major)
     for (int l = d; l >= 0; --l) {
@@ -1408,7 +1418,7 @@ extern "C" int iaf_step_backward(iaf_stack_t* s, const float* z, const float* co
             p.out0 = (l - 1 == 0) ? dcontext : nullptr;
         }
         if ((rc = launch_gemm(s, s->T[l], EPI_DGRAD, true, -1, p, IN_PIXMAJOR, st))) return rc;
-        if ((rc = launch_wgrad(s, s->L[l], x_in, dy, tw.part[l], tapmask, B, H, W, st))) return rc;
+        if ((rc = launch_wgrad(s, s->L[l], x_in, dy, tw.part[l], tapmask, B, H, W, st, tap_sign))) return rc;
         reduce_add(l, dy);
         if (l == d) {
             wn_add(d, l, s->n_z, 2, 0);       // layer_out_0 (mean tiles)
@@ -1469,7 +1479,7 @@ extern "C" int iaf_wn_bwd_batch_create(iaf_wn_bwd_batch_t** out, iaf_stack_t* co
     int nconv = 0, nt = 0;
     for (int i = 0; i < n; ++i) {
         if (!stacks[i]) { iaf_wn_bwd_batch_destroy(b); return IAF_ERR_NULL; }
-        if (stacks[i]->generic || stacks[i]->variant != IAF_VARIANT_TF) { iaf_wn_bwd_batch_destroy(b); return IAF_ERR_UNSUPPORTED; }
+        if (stacks[i]->generic) { iaf_wn_bwd_batch_destroy(b); return IAF_ERR_UNSUPPORTED; }
         b->stacks[i] = stacks[i];
         nconv += stacks[i]->depth_ar + 2;
         for (int l = 0; l < stacks[i]->nlayers; ++l) nt += stacks[i]->L[l].cout / 16;   // output pair: 2 * n_z/16 tiles
@@ -1495,6 +1505,7 @@ extern "C" int iaf_wn_bwd_batch_create(iaf_wn_bwd_batch_t** out, iaf_stack_t* co
             const bool pair = (l == s->depth_ar);
             w.cin = L.cin; w.cout = pair ? s->n_z : L.cout; w.cout_packed = L.cout; w.zerodiag = L.zerodiag;
             w.pack_stride = pair ? 2 : 1; w.pack_off = pair ? c - s->depth_ar : 0;
+            w.variant = s->variant;
             tb[ci] = tile;
             for (int t = 0; t < w.cout / 16; ++t) t2l[tile++] = ci;
         }
@@ -1525,9 +1536,9 @@ extern "C" int iaf_wn_bwd_batch_run(iaf_wn_bwd_batch_t* b, const float* const* V
             const int l = c < s->depth_ar ? c : s->depth_ar;
             WnBwdLayer& w = b->h_layers[ci];
             changed |= (w.V != V[ci]) | (w.g != g[ci]) | (w.dV != dV[ci]) | (w.dg != dg[ci]) | (w.db != db[ci]) |
-                       (w.dW != tw.dWeff[l]) | (w.dbp != tw.dbp[l]) | (w.nslab != nslab);
+                       (w.dW != tw.dWeff[l]) | (w.dbp != tw.dbp[l]) | (w.dbrd != tw.dbrd[l]) | (w.nslab != nslab);
             w.V = V[ci]; w.g = g[ci]; w.dV = dV[ci]; w.dg = dg[ci]; w.db = db[ci];
-            w.dW = tw.dWeff[l]; w.dbp = tw.dbp[l]; w.nslab = nslab;
+            w.dW = tw.dWeff[l]; w.dbp = tw.dbp[l]; w.dbrd = tw.dbrd[l]; w.nslab = nslab;
         }
     }
     hipStream_t st = (hipStream_t)stream;

@@ -181,8 +181,12 @@ __global__ __launch_bounds__(256) void iaf_wgrad_reduce_kernel(const float* __re
 struct ReduceLayer {
     const float* part; float* dW; size_t n4; int nrange; int blk_begin;
     const float* dy; float* dbp; int cout;
+    float* dbrd;      // Theano statement: [nslab][4][cout] sums of dY over the pixels whose tap t = 1..4 falls outside (or NULL)
 };
-struct ReduceArgs { ReduceLayer L[MAX_GEMM_LAYERS]; int n, nblk_total, nslab, P, px_per_slab; };
+struct ReduceArgs {
+    ReduceLayer L[MAX_GEMM_LAYERS]; int n, nblk_total, nslab, P, px_per_slab;
+    const unsigned short* tapmask; int brd_bit[NTAPS - 1];    // in-image bit of taps 1..4 in the border table
+};
 
 __global__ __launch_bounds__(256) void iaf_wgrad_reduce_multi_kernel(ReduceArgs a) {
     if ((int)blockIdx.x < a.nblk_total) {
@@ -217,6 +221,23 @@ __global__ __launch_bounds__(256) void iaf_wgrad_reduce_multi_kernel(ReduceArgs 
             for (; pix < p1; ++pix) s8[0] += dy[(size_t)pix * cout + co];
             dbp[(size_t)slab * cout + co] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
         }
+        // gradient of the border-indicator channel's weights (conv.py:71-83): that channel is 1 exactly where a tap
+        // leaves the image, so d border[t][co] = sum of dY[p][co] over the pixels p whose tap t falls outside
+        float* dbrd = a.L[li].dbrd;
+        if (dbrd) {
+            for (int co = threadIdx.x; co < cout; co += blockDim.x) {
+                float sb[NTAPS - 1] = {0.f, 0.f, 0.f, 0.f};
+                for (int pix = p0; pix < p1; ++pix) {
+                    const unsigned m = a.tapmask[pix];
+                    if (m == 0x1ffu) continue;                       // interior pixel (uniform over the workgroup)
+                    const float v = dy[(size_t)pix * cout + co];
+#pragma unroll
+                    for (int t = 0; t < NTAPS - 1; ++t) sb[t] += ((m >> a.brd_bit[t]) & 1u) ? 0.f : v;
+                }
+#pragma unroll
+                for (int t = 0; t < NTAPS - 1; ++t) dbrd[((size_t)slab * (NTAPS - 1) + t) * cout + co] = sb[t];
+            }
+        }
     }
 }
 
@@ -230,6 +251,9 @@ struct WnBwdLayer {
     const float* dbp;                    // [nslab][cout_packed] column sums of dY
     float* dV; float* dg; float* db;     // outputs: HWIO [3][3][cin][cout], [cout], [cout]
     int cin, cout, cout_packed, nslab, zerodiag, pack_stride, pack_off;   // packed channel of o: (o/16)*pack_stride*16 + pack_off*16 + o%16
+    // Theano statement (variant != IAF_VARIANT_TF): V = w OIHW [cout][cin+1][3][3], g = s, dV / dg the same shapes;
+    // dbrd = [nslab][4][cout_packed] partial gradients of the border channel's taps 1..4
+    const float* dbrd; int variant;
 };
 
 template <int NCH>
@@ -289,21 +313,138 @@ __device__ __forceinline__ void wn_bwd_tile(const WnBwdLayer& L, int tile, float
     }
 }
 
-struct WnBwdArgs {
-    WnBwdLayer L[MAX_GEMM_LAYERS + 1];   // one entry per conv (the output pair counts twice)
-    int tile_begin[MAX_GEMM_LAYERS + 2];
-    int n;
-};
+// (3b') the same through the Theano statement of the weights (graphy/nodes/ar.py:266-281,312-317; see prep_tile_theano):
+//       k = mask w (centre tap of the first rows zeroed, ar.py:268-276),  n = ||k||_o over (c_in + border channel, taps),
+//       W = e k / (n + 1e-8),  e = exp(3 s)
+//       ds = 3 sum dW W ;  dk = (e / (n + 1e-8)) (dW - (k / n) (sum dW k) / (n + 1e-8)) ;  dw = mask dk ;  db = sum_p dY
+//     The border channel's taps 1..4 are weights like any other (their dW comes from the reduce kernel's dbrd sums); with
+//     flipmask its centre tap is live in the norm only (it multiplies zeros inside the image): dW = 0 there, dk != 0.
+template <int NCH>
+__device__ __forceinline__ void wn_bwd_tile_theano(const WnBwdLayer& L, int tile, float (*red)[16][17], float* s_n, float* s_dot) {
+    const int oo = threadIdx.x & 15, cs = threadIdx.x >> 4;
+    const int o = tile * 16 + oo;
+    const int op = (o >> 4) * L.pack_stride * 16 + L.pack_off * 16 + (o & 15);
+    const int n_in = L.cin, n_out = L.cout;
+    const bool flip = (L.variant == IAF_VARIANT_THEANO_FLIPMASK);
+    const float* wo = L.V + (size_t)o * (n_in + 1) * 9;
+    float* dwo = L.dV + (size_t)o * (n_in + 1) * 9;
+    float v[NTAPS][NCH], dw[NTAPS][NCH];
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+        const int ci = cs + 16 * it;
+#pragma unroll
+        for (int t = 0; t < NTAPS; ++t) {
+            const int kh = (t == 0 || t == 1) ? 1 : 2;
+            const int kw = (t == 0) ? 1 : (t == 1 ? 2 : t - 2);
+            v[t][it] = wo[(size_t)ci * 9 + (flip ? (2 - kh) * 3 + (2 - kw) : kh * 3 + kw)];
+            dw[t][it] = L.dW[((size_t)t * n_in + ci) * L.cout_packed + op];
+        }
+    }
+    float dbs = 0.f, dbr[NTAPS - 1] = {0.f, 0.f, 0.f, 0.f};
+    for (int r = cs; r < L.nslab; r += 16) {
+        dbs += L.dbp[(size_t)r * L.cout_packed + op];
+#pragma unroll
+        for (int t = 0; t < NTAPS - 1; ++t) dbr[t] += L.dbrd[((size_t)r * (NTAPS - 1) + t) * L.cout_packed + op];
+    }
+    const int k0 = (n_out >= n_in) ? n_out / n_in : 1;
+    const bool row_zeroed = L.zerodiag && o < k0;
+    float ss = 0.f, dot = 0.f;
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+        const int ci = cs + 16 * it;
+        const bool live = flip ? (ci >= 1 && made_live(n_in - ci, n_out - 1 - o, n_in, n_out, L.zerodiag))
+                               : made_live(ci, o, n_in, n_out, L.zerodiag);
+        if (!live || row_zeroed) { v[0][it] = 0.f; dw[0][it] = 0.f; }
+#pragma unroll
+        for (int t = 0; t < NTAPS; ++t) { ss += v[t][it] * v[t][it]; dot += dw[t][it] * v[t][it]; }
+    }
+    red[0][cs][oo] = ss; red[1][cs][oo] = dot; red[2][cs][oo] = dbs;
+#pragma unroll
+    for (int t = 0; t < NTAPS - 1; ++t) red[3 + t][cs][oo] = dbr[t];
+    __syncthreads();
+    // border channel (thread cs == 0): weights of taps 1..4, the flipped mask's centre entry
+    float wb[NTAPS - 1], dwb[NTAPS - 1], wc = 0.f;
+    const bool centre_in_norm = flip && !row_zeroed && made_live(0, n_out - 1 - o, n_in, n_out, L.zerodiag);
+    if (cs == 0) {
+        float a = 0.f, b = 0.f, c = 0.f;
+#pragma unroll
+        for (int t = 0; t < NTAPS - 1; ++t) dwb[t] = 0.f;
+        for (int i = 0; i < 16; ++i) {
+            a += red[0][i][oo]; b += red[1][i][oo]; c += red[2][i][oo];
+#pragma unroll
+            for (int t = 0; t < NTAPS - 1; ++t) dwb[t] += red[3 + t][i][oo];
+        }
+#pragma unroll
+        for (int t = 1; t < NTAPS; ++t) {
+            const int kh = (t == 1) ? 1 : 2;
+            const int kw = (t == 1) ? 2 : t - 2;
+            wb[t - 1] = wo[(size_t)n_in * 9 + (flip ? (2 - kh) * 3 + (2 - kw) : kh * 3 + kw)];
+            a += wb[t - 1] * wb[t - 1];
+            b += dwb[t - 1] * wb[t - 1];
+        }
+        if (centre_in_norm) { wc = wo[(size_t)n_in * 9 + 4]; a += wc * wc; }
+        const float n = sqrtf(a), ne = n + 1e-8f;
+        const float e = expf(3.0f * L.g[o]);
+        s_n[oo] = n;
+        s_dot[oo] = b / ne;                     // sum dW k / (n + eps)
+        L.dg[o] = 3.0f * e * b / ne;            // 3 sum dW W
+        L.db[o] = c;
+    }
+    __syncthreads();
+    const float n = s_n[oo], du = s_dot[oo], ne = n + 1e-8f;
+    const float en = expf(3.0f * L.g[o]) / ne, rn = n > 0.f ? 1.0f / n : 0.f;
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+        const int ci = cs + 16 * it;
+        const bool cl = !row_zeroed && (flip ? (ci >= 1 && made_live(n_in - ci, n_out - 1 - o, n_in, n_out, L.zerodiag))
+                                             : made_live(ci, o, n_in, n_out, L.zerodiag));
+#pragma unroll
+        for (int pos = 0; pos < 9; ++pos) {
+            const int q = flip ? 8 - pos : pos;       // filter position in the unflipped frame
+            const int kh = q / 3, kw = q % 3;
+            const int t = (kh == 1 && kw == 1) ? 0 : (kh == 1 && kw == 2) ? 1 : (kh == 2) ? 2 + kw : -1;
+            float outv = 0.f;
+            if (t > 0 || (t == 0 && cl)) outv = en * (dw[t < 0 ? 0 : t][it] - (v[t < 0 ? 0 : t][it] * rn) * du);
+            dwo[(size_t)ci * 9 + pos] = outv;
+        }
+    }
+    if (cs == 0) {
+#pragma unroll
+        for (int pos = 0; pos < 9; ++pos) {
+            const int q = flip ? 8 - pos : pos;
+            const int kh = q / 3, kw = q % 3;
+            const int t = (kh == 1 && kw == 1) ? 0 : (kh == 1 && kw == 2) ? 1 : (kh == 2) ? 2 + kw : -1;
+            float outv = 0.f;
+            if (t > 0) outv = en * (dwb[t - 1] - (wb[t - 1] * rn) * du);
+            else if (t == 0 && centre_in_norm) outv = en * (0.f - (wc * rn) * du);
+            dwo[(size_t)n_in * 9 + pos] = outv;
+        }
+    }
+}
 
-// every conv of a stack in one launch: workgroup -> (conv, 16-channel output tile)
-__global__ __launch_bounds__(256) void iaf_wn_bwd_kernel(WnBwdArgs a) {
-    __shared__ float red[3][16][17];
-    __shared__ float s_n[16], s_dot[16];
-    int li = 0;
-    for (int i = 1; i < a.n; ++i)
-        if ((int)blockIdx.x >= a.tile_begin[i]) li = i;
-    const WnBwdLayer& L = a.L[li];
-    const int tile = blockIdx.x - a.tile_begin[li];
+template <int DUMMY = 0>
+__device__ __forceinline__ void wn_bwd_dispatch(const WnBwdLayer& L, int tile, float (*red)[16][17], float* s_n, float* s_dot) {
+    if (L.variant != IAF_VARIANT_TF) {
+        switch (L.cin >> 4) {
+            case 1: wn_bwd_tile_theano<1>(L, tile, red, s_n, s_dot); break;
+            case 2: wn_bwd_tile_theano<2>(L, tile, red, s_n, s_dot); break;
+            case 3: wn_bwd_tile_theano<3>(L, tile, red, s_n, s_dot); break;
+            case 4: wn_bwd_tile_theano<4>(L, tile, red, s_n, s_dot); break;
+            case 5: wn_bwd_tile_theano<5>(L, tile, red, s_n, s_dot); break;
+            case 6: wn_bwd_tile_theano<6>(L, tile, red, s_n, s_dot); break;
+            case 7: wn_bwd_tile_theano<7>(L, tile, red, s_n, s_dot); break;
+            case 8: wn_bwd_tile_theano<8>(L, tile, red, s_n, s_dot); break;
+            case 9: wn_bwd_tile_theano<9>(L, tile, red, s_n, s_dot); break;
+            case 10: wn_bwd_tile_theano<10>(L, tile, red, s_n, s_dot); break;
+            case 11: wn_bwd_tile_theano<11>(L, tile, red, s_n, s_dot); break;
+            case 12: wn_bwd_tile_theano<12>(L, tile, red, s_n, s_dot); break;
+            case 13: wn_bwd_tile_theano<13>(L, tile, red, s_n, s_dot); break;
+            case 14: wn_bwd_tile_theano<14>(L, tile, red, s_n, s_dot); break;
+            case 15: wn_bwd_tile_theano<15>(L, tile, red, s_n, s_dot); break;
+            case 16: wn_bwd_tile_theano<16>(L, tile, red, s_n, s_dot); break;
+        }
+        return;
+    }
     switch (L.cin >> 4) {
         case 1: wn_bwd_tile<1>(L, tile, red, s_n, s_dot); break;
         case 2: wn_bwd_tile<2>(L, tile, red, s_n, s_dot); break;
@@ -324,34 +465,32 @@ __global__ __launch_bounds__(256) void iaf_wn_bwd_kernel(WnBwdArgs a) {
     }
 }
 
+struct WnBwdArgs {
+    WnBwdLayer L[MAX_GEMM_LAYERS + 1];   // one entry per conv (the output pair counts twice)
+    int tile_begin[MAX_GEMM_LAYERS + 2];
+    int n;
+};
+
+// every conv of a stack in one launch: workgroup -> (conv, 16-channel output tile)
+__global__ __launch_bounds__(256) void iaf_wn_bwd_kernel(WnBwdArgs a) {
+    __shared__ float red[3 + NTAPS - 1][16][17];
+    __shared__ float s_n[16], s_dot[16];
+    int li = 0;
+    for (int i = 1; i < a.n; ++i)
+        if ((int)blockIdx.x >= a.tile_begin[i]) li = i;
+    wn_bwd_dispatch(a.L[li], blockIdx.x - a.tile_begin[li], red, s_n, s_dot);
+}
+
 // the same for the convs of MANY stacks (a whole model) in one launch: descriptors in device memory.  A stack's own launch
 // has 24 workgroups for 256 CUs and is bound by one CU's address unit (~21 us); batched, the model's 480 tiles cost about
 // the same as one stack alone.
 __global__ __launch_bounds__(256) void iaf_wn_bwd_batch_kernel(const WnBwdLayer* __restrict__ layers, const int* __restrict__ tile2layer,
                                                               const int* __restrict__ tile_begin) {
-    __shared__ float red[3][16][17];
+    __shared__ float red[3 + NTAPS - 1][16][17];
     __shared__ float s_n[16], s_dot[16];
     const int li = tile2layer[blockIdx.x];
     const WnBwdLayer L = layers[li];
-    const int tile = blockIdx.x - tile_begin[li];
-    switch (L.cin >> 4) {
-        case 1: wn_bwd_tile<1>(L, tile, red, s_n, s_dot); break;
-        case 2: wn_bwd_tile<2>(L, tile, red, s_n, s_dot); break;
-        case 3: wn_bwd_tile<3>(L, tile, red, s_n, s_dot); break;
-        case 4: wn_bwd_tile<4>(L, tile, red, s_n, s_dot); break;
-        case 5: wn_bwd_tile<5>(L, tile, red, s_n, s_dot); break;
-        case 6: wn_bwd_tile<6>(L, tile, red, s_n, s_dot); break;
-        case 7: wn_bwd_tile<7>(L, tile, red, s_n, s_dot); break;
-        case 8: wn_bwd_tile<8>(L, tile, red, s_n, s_dot); break;
-        case 9: wn_bwd_tile<9>(L, tile, red, s_n, s_dot); break;
-        case 10: wn_bwd_tile<10>(L, tile, red, s_n, s_dot); break;
-        case 11: wn_bwd_tile<11>(L, tile, red, s_n, s_dot); break;
-        case 12: wn_bwd_tile<12>(L, tile, red, s_n, s_dot); break;
-        case 13: wn_bwd_tile<13>(L, tile, red, s_n, s_dot); break;
-        case 14: wn_bwd_tile<14>(L, tile, red, s_n, s_dot); break;
-        case 15: wn_bwd_tile<15>(L, tile, red, s_n, s_dot); break;
-        case 16: wn_bwd_tile<16>(L, tile, red, s_n, s_dot); break;
-    }
+    wn_bwd_dispatch(L, blockIdx.x - tile_begin[li], red, s_n, s_dot);
 }
 
 // plain convs: NCHW -> pixel-major staging of the backward operands.  dst[P][C] = scale * act(concat_k src_k)[b, c, p]

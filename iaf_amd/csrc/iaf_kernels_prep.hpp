@@ -264,6 +264,13 @@ __device__ __forceinline__ void prep_tile_theano(const PrepLayer& L, int gt, flo
 #pragma unroll
         for (int t = 0; t < NTAPS; ++t)
             L.wp[((((size_t)it * NTAPS + t) * L.ncot + gt) * 64 + kk * 16 + oo) * 4 + jj] = v[t][it] * scale;
+    if (L.wpt) {   // dgrad operand, as in prep_tile (the border channel carries no data gradient)
+#pragma unroll
+        for (int it = 0; it < NCH; ++it)
+#pragma unroll
+            for (int t = 0; t < NTAPS; ++t)
+                L.wpt[((((size_t)gt * NTAPS + t) * NCH + it) * 64 + (oo >> 2) * 16 + cs) * 4 + (oo & 3)] = v[t][it] * scale;
+    }
     if constexpr (BF3) { if (L.wp3) prep_bf3_store<NCH>(L, gt, w3, s_scale); }
 }
 

@@ -191,6 +191,13 @@ class ARStack(object):
             tens += [V, g, b]
         return tens
 
+    def _grad_keys(self):
+        """per conv, the keys its (V, g, b) slots go by in a params / grads dict (see _param_tensors)"""
+        if self.variant in (_capi.IAF_VARIANT_THEANO, _capi.IAF_VARIANT_THEANO_FLIPMASK):
+            bases = ["%d" % i for i in range(self.depth_ar)] + ["out_0", "out_1"]
+            return [(b + "_w", b + "_s", b + "_b") for b in bases]
+        return [(nm + "/V", nm + "/g", nm + "/b") for nm in self.conv_names()]
+
     def time_layer(self, layer, z, context, reps=50):
         """average duration (ms) of GEMM layer `layer` over `reps` back-to-back launches between one HIP event pair;
         layer = -1: the fused launch of layers 0+1 (UnsupportedError if the stack would not fuse at this size)"""
@@ -350,18 +357,18 @@ class ARStack(object):
         for nm, t in (("z_new", z_new), ("logsd", logsd), ("dz_new", dz_new), ("dlogsd", dlogsd)):
             _check_act(t, nm, z.shape)
         tens = self._param_tensors(params)
-        names = self.conv_names()
+        keys = self._grad_keys()
         grads = {}
-        for ci, nm in enumerate(names):
-            for j, suffix in enumerate(("V", "g", "b")):
-                grads[nm + "/" + suffix] = torch.empty_like(tens[3 * ci + j])
-        n = len(names)
+        for ci, ks in enumerate(keys):
+            for j in range(3):
+                grads[ks[j]] = torch.empty_like(tens[3 * ci + j])
+        n = len(keys)
         arr = ctypes.c_void_p * n
         Vp = arr(*[t.data_ptr() for t in tens[0::3]])
         gp = arr(*[t.data_ptr() for t in tens[1::3]])
-        dVp = arr(*[grads[nm + "/V"].data_ptr() for nm in names])
-        dgp = arr(*[grads[nm + "/g"].data_ptr() for nm in names])
-        dbp = arr(*[grads[nm + "/b"].data_ptr() for nm in names])
+        dVp = arr(*[grads[ks[0]].data_ptr() for ks in keys])
+        dgp = arr(*[grads[ks[1]].data_ptr() for ks in keys])
+        dbp = arr(*[grads[ks[2]].data_ptr() for ks in keys])
         dz = torch.empty_like(z)
         dctx = torch.empty_like(context) if self.depth_ar > 0 else None
         ws, need = self._train_workspace(B, H, W, z.device)
@@ -401,21 +408,21 @@ class ARStack(object):
             raise ValueError("dkl_obj (gradient of kl_obj, [B]) is required")
         _check_act(dkl_obj, "dkl_obj", (B,))
         tens = self._param_tensors(params)
-        names = self.conv_names()
+        keys = self._grad_keys()
         grads = {} if grads_out is None else grads_out     # grads_out: pre-allocated views (e.g. into a flat bucket)
-        for ci, nm in enumerate(names):
-            for j, suffix in enumerate(("V", "g", "b")):
+        for ci, ks in enumerate(keys):
+            for j in range(3):
                 if grads_out is None:
-                    grads[nm + "/" + suffix] = torch.empty_like(tens[3 * ci + j])
+                    grads[ks[j]] = torch.empty_like(tens[3 * ci + j])
                 else:
-                    _check_act(grads[nm + "/" + suffix], "grad " + nm + "/" + suffix, tens[3 * ci + j].shape)
-        n = len(names)
+                    _check_act(grads[ks[j]], "grad " + ks[j], tens[3 * ci + j].shape)
+        n = len(keys)
         arr = ctypes.c_void_p * n
         Vp = arr(*[t.data_ptr() for t in tens[0::3]])
         gp = arr(*[t.data_ptr() for t in tens[1::3]])
-        dVp = arr(*[grads[nm + "/V"].data_ptr() for nm in names])
-        dgp = arr(*[grads[nm + "/g"].data_ptr() for nm in names])
-        dbp = arr(*[grads[nm + "/b"].data_ptr() for nm in names])
+        dVp = arr(*[grads[ks[0]].data_ptr() for ks in keys])
+        dgp = arr(*[grads[ks[1]].data_ptr() for ks in keys])
+        dbp = arr(*[grads[ks[2]].data_ptr() for ks in keys])
         out = dict(dmean=torch.empty_like(qz_mean), dlogsd=torch.empty_like(qz_mean), dpz_mean=torch.empty_like(qz_mean),
                    dpz_logsd=torch.empty_like(qz_mean), grads=grads)
         out["dcontext"] = (torch.empty(B, self.n_h, H, W, dtype=torch.float32, device=qz_mean.device)
@@ -855,9 +862,9 @@ class WnBwdBatch(object):
         if self._hs:
             V, g, dV, dg, db = [], [], [], [], []
             for st, p, gr in zip(self.stacks, stack_params, stack_grads):
-                for nm in st.conv_names():
-                    V.append(p[nm + "/V"]); g.append(p[nm + "/g"])
-                    dV.append(gr[nm + "/V"]); dg.append(gr[nm + "/g"]); db.append(gr[nm + "/b"])
+                for kV, kg, kb in st._grad_keys():
+                    V.append(p[kV]); g.append(p[kg])
+                    dV.append(gr[kV]); dg.append(gr[kg]); db.append(gr[kb])
             _capi.check(lib.iaf_wn_bwd_batch_run(self._hs, self._tables(V), self._tables(g), self._tables(dV),
                                                  self._tables(dg), self._tables(db), _stream()))
         if self._hc:

@@ -135,3 +135,60 @@ def iaf_layer_grads(up_inp, down_inp, eps, params, z_size, h_size, kl_min, d_up_
     fw = dict(up_out=up_out.detach().numpy(), output=out.detach().numpy(), kl_obj=kl_obj.detach().numpy(),
               kl_cost=kl_cost.detach().numpy())
     return dict(up_inp=ut.grad.numpy(), down_inp=dt.grad.numpy(), params=grads), fw
+
+
+# --------------------------------------------------------------------------------------
+# the Theano statement of the same operator (graphy/nodes/ar.py, graphy/nodes/conv.py), for T.grad
+# (graphy/misc/optim.py:102) of the lines models.py:168-176 / 272-285
+# --------------------------------------------------------------------------------------
+def theano_ar_conv2d(h, w_, b_, s_, n_in, n_out, zerodiagonal=True, flipmask=False):
+    """graphy/nodes/ar.py:304-330 as oracle/iaf_oracle.py:theano_ar_conv2d states it: mask, centre rows zeroed
+    (set_subtensor, :268-276), kerns / (norm + 1e-8) * exp(3 s), border-indicator channel, true convolution 'valid'."""
+    mask = torch.from_numpy(np.ascontiguousarray(O.theano_ar_mask(n_in, n_out, 3, zerodiagonal, flipmask, True))).to(torch.float64)
+    n, c, H, W = h.shape
+    hp = torch.zeros((n, c + 1, H + 2, W + 2), dtype=torch.float64)
+    hp[:, c] = 1.0
+    hp[:, c, 1:-1, 1:-1] = 0.0
+    hp = hp.clone()
+    hp[:, :c, 1:-1, 1:-1] = h                                       # conv.py:71-83
+    kerns = mask * w_
+    if zerodiagonal:
+        keep = torch.ones_like(kerns)
+        keep[:(n_out // n_in if n_out >= n_in else 1), :, 1, 1] = 0.0
+        kerns = kerns * keep
+    norm = torch.sqrt((kerns ** 2).sum(dim=(1, 2, 3), keepdim=True)) + 1e-8
+    kerns = kerns / norm * torch.exp(3.0 * s_).reshape(-1, 1, 1, 1)
+    return F.conv2d(hp, torch.flip(kerns, dims=(2, 3)), b_)        # conv_mode='conv': the kernel is flipped
+
+
+def theano_multiconv2d(h, context, w, name, n_in, n_h, n_out, flipmask=False):
+    """graphy/nodes/ar.py:378-416, nl='elu'"""
+    sizes = [n_in] + list(n_h)
+    for i in range(len(n_h)):
+        p = "%s_%d" % (name, i)
+        h = theano_ar_conv2d(h, w[p + "_w"], w[p + "_b"], w[p + "_s"], sizes[i], sizes[i + 1], False, flipmask)
+        if i == 0:
+            h = h + context
+        h = F.elu(h)
+    return [theano_ar_conv2d(h, w["%s_out_%d_w" % (name, i)], w["%s_out_%d_b" % (name, i)], w["%s_out_%d_s" % (name, i)],
+                             sizes[-1], n_out[i], True, flipmask) for i in range(len(n_out))]
+
+
+def theano_iaf2_nl(z, context, w, name, n_z, n_h, flipmask=False):
+    """models.py:168-175 / 281-285"""
+    m_raw, s_raw = theano_multiconv2d(z, context, w, name, n_z, n_h, [n_z, n_z], flipmask)
+    m, s = 0.1 * m_raw, 0.1 * s_raw
+    return (z - m) / torch.exp(s), s
+
+
+def theano_iaf2_nl_grads(z, context, w, name, n_z, n_h, dz_new, dlogsd, flipmask=False):
+    """Gradients of  L = <dz_new, z_new> + <dlogsd, logsd>  w.r.t. z, context and every _w/_s/_b."""
+    zt, ct = _t(z, True), _t(context, True)
+    wt = {k: _t(v, True) for k, v in w.items()}
+    z_new, logsd = theano_iaf2_nl(zt, ct, wt, name, n_z, n_h, flipmask)
+    loss = (z_new * _t(dz_new)).sum() + (logsd * _t(dlogsd)).sum()
+    loss.backward()
+    out = {"z": zt.grad.numpy(), "context": ct.grad.numpy()}
+    for k, v in wt.items():
+        out[k] = v.grad.numpy()
+    return out, z_new.detach().numpy(), logsd.detach().numpy()

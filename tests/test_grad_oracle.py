@@ -141,3 +141,78 @@ def test_layer_gradients_match_finite_differences():
 
             fd = (at(eps) - at(-eps)) / (2 * eps)
             assert abs(fd - got[idx]) < 2e-6 * max(1.0, abs(fd)), (name, idx, fd, got[idx])
+
+
+# ---------------------------------------------------------------- the Theano statement (graphy/nodes/ar.py) of the same step
+def _theano_case(seed, B=2, n_z=4, n_h=(8, 8), H=4, W=3):
+    rng = np.random.RandomState(seed)
+    nm = "c"
+    w, sizes = {}, [n_z] + list(n_h)
+    for i in range(len(n_h)):
+        w["%s_%d_w" % (nm, i)] = 0.3 * rng.standard_normal((sizes[i + 1], sizes[i] + 1, 3, 3))
+        w["%s_%d_b" % (nm, i)] = 0.1 * rng.standard_normal(sizes[i + 1])
+        w["%s_%d_s" % (nm, i)] = 0.1 * rng.standard_normal(sizes[i + 1])
+    for i in range(2):
+        w["%s_out_%d_w" % (nm, i)] = 0.3 * rng.standard_normal((n_z, sizes[-1] + 1, 3, 3))
+        w["%s_out_%d_b" % (nm, i)] = 0.1 * rng.standard_normal(n_z)
+        w["%s_out_%d_s" % (nm, i)] = 0.1 * rng.standard_normal(n_z)
+    z, ctx = rng.standard_normal((B, n_z, H, W)), rng.standard_normal((B, n_h[0], H, W))
+    return nm, w, z, ctx, rng.standard_normal(z.shape), rng.standard_normal(z.shape)
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("flip", [False, True], ids=["plain", "flipmask"])
+def test_theano_forward_matches_numpy_oracle(flip):
+    nm, w, z, ctx, dzn, dls = _theano_case(11)
+    _, zn, ls = G.theano_iaf2_nl_grads(z, ctx, w, nm, 4, [8, 8], dzn, dls, flipmask=flip)
+    ez, es = O.theano_iaf2_nl(z, ctx, w, nm, 4, [8, 8], flipmask=flip)
+    np.testing.assert_allclose(zn, ez, rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(ls, es, rtol=1e-11, atol=1e-12)
+
+
+@pytest.mark.parametrize("flip", [False, True], ids=["plain", "flipmask"])
+def test_theano_gradients_match_finite_differences(flip):
+    nm, w, z, ctx, dzn, dls = _theano_case(12)
+    grads, _, _ = G.theano_iaf2_nl_grads(z, ctx, w, nm, 4, [8, 8], dzn, dls, flipmask=flip)
+
+    def loss(zz, cc, ww):
+        a, b = O.theano_iaf2_nl(zz, cc, ww, nm, 4, [8, 8], flipmask=flip)
+        return (a * dzn).sum() + (b * dls).sum()
+
+    rng = np.random.RandomState(0)
+    eps = 1e-6
+    for name, base in [("z", z), ("context", ctx)] + [(k, w[k]) for k in ("c_0_w", "c_1_w", "c_1_s", "c_out_0_w", "c_out_1_w",
+                                                                           "c_out_1_b", "c_out_0_s")]:
+        for _ in range(8):
+            idx = tuple(rng.randint(0, s) for s in base.shape)
+
+            def at(delta):
+                arr = base.copy()
+                arr[idx] += delta
+                ww = dict(w)
+                zz, cc = z, ctx
+                if name == "z":
+                    zz = arr
+                elif name == "context":
+                    cc = arr
+                else:
+                    ww[name] = arr
+                return loss(zz, cc, ww)
+
+            fd = (at(eps) - at(-eps)) / (2 * eps)
+            assert abs(fd - grads[name][idx]) < 1e-6 * max(1.0, abs(fd)), (name, idx, fd, grads[name][idx])
+
+
+def test_theano_masked_and_border_weight_gradients():
+    """masked entries of w get an exact zero; the border channel's live taps do get a gradient (they are weights like any
+    other, ar.py:288-296 + conv.py:71-83)"""
+    nm, w, z, ctx, dzn, dls = _theano_case(13)
+    for flip in (False, True):
+        grads, _, _ = G.theano_iaf2_nl_grads(z, ctx, w, nm, 4, [8, 8], dzn, dls, flipmask=flip)
+        for key, n_in, n_out, zd in (("c_0_w", 4, 8, False), ("c_1_w", 8, 8, False), ("c_out_0_w", 8, 4, True)):
+            mask = O.theano_ar_mask(n_in, n_out, 3, zd, flip, True)
+            assert (grads[key][mask == 0] == 0).all()
+            live_border = grads[key][:, n_in][mask[:, n_in] == 1]
+            assert np.abs(live_border).max() > 0

@@ -351,6 +351,96 @@ def _theano_params(rng, name, n_z, n_h_list):
     return w
 
 
+@pytest.mark.parametrize("flip", [False, True], ids=["plain", "flipmask"])
+@pytest.mark.parametrize("shape", [(4, 32, 160, 2, 16, 16), (3, 32, 160, 2, 8, 8), (2, 32, 64, 1, 4, 4), (2, 64, 64, 4, 5, 3),
+                                   (2, 64, 192, 4, 8, 8), (3, 16, 48, 2, 4, 4)], ids=lambda s: "B%d_z%d_h%d_d%d_%dx%d" % s)
+def test_theano_step_backward_vs_autograd_oracle(amd, shape, flip):
+    """backward of the Theano statement (models.py:168-175 through graphy/nodes/ar.py; T.grad, graphy/misc/optim.py:102):
+    dz, dcontext, dw (OIHW incl. the border-indicator channel; masked entries exactly zero), ds, db against torch-fp64
+    autograd of the restated forward.  Tolerance as for the TF statement."""
+    from oracle import iaf_grad_oracle as G
+    B, n_z, n_h, d, H, W = shape
+    rng = np.random.RandomState(300 + H + d + (7 if flip else 0))
+    w = _theano_params(rng, "q", n_z, [n_h] * d)
+    z, ctx = rng.standard_normal((B, n_z, H, W)), rng.standard_normal((B, n_h, H, W))
+    dzn, dls = rng.standard_normal(z.shape), rng.standard_normal(z.shape)
+    stack = amd.ARStack(n_z, [n_h] * d, variant="theano_flipmask" if flip else "theano")
+    stack.set_training(True)
+    rel = {k[2:]: dev(v) for k, v in w.items()}
+    stack.prepare(rel)
+    zd, cd = dev(z), dev(ctx)
+    z_new, logsd = stack.iaf_step_train(zd, cd)
+    z_ref, l_ref = stack.iaf_step(zd, cd)
+    assert torch.equal(z_new, z_ref) and torch.equal(logsd, l_ref)
+    dz, dctx, grads = stack.iaf_step_backward(zd, cd, z_new, logsd, dev(dzn), dev(dls), rel)
+    ref, ez, el = G.theano_iaf2_nl_grads(f32(z), f32(ctx), {k: f32(v) for k, v in w.items()}, "q", n_z, [n_h] * d, f32(dzn),
+                                         f32(dls), flipmask=flip)
+    np.testing.assert_allclose(host(z_new), ez, atol=ATOL, rtol=0)
+    _rel_close(host(dz), ref["z"], 1e-4, "dz")
+    _rel_close(host(dctx), ref["context"], 1e-4, "dcontext")
+    sizes = [n_z] + [n_h] * d
+    for k in sorted(rel):
+        _rel_close(host(grads[k]), ref["q_" + k], 2e-4, k)
+        if k.endswith("_w"):
+            out = k.startswith("out_")
+            n_in = sizes[-1] if out else sizes[int(k.split("_")[0])]
+            mask = np.ascontiguousarray(O.theano_ar_mask(n_in, w["q_" + k].shape[0], 3, out, flip, True))
+            assert torch.count_nonzero(grads[k][torch.from_numpy(mask == 0).cuda()]).item() == 0
+            gb = host(grads[k])[:, n_in]                 # the border channel's own gradient is part of the comparison
+            assert np.abs(gb).max() > 0
+    # the deferred (batched over stacks) weight-norm backward gives the same gradients
+    batch = amd.WnBwdBatch(stacks=[stack])
+    g2 = {k: torch.zeros_like(v) for k, v in rel.items()}
+    stack.iaf_step_train(zd, cd)
+    stack.iaf_step_backward(zd, cd, z_new, logsd, dev(dzn), dev(dls), rel)
+    batch.run(stack_params=[rel], stack_grads=[g2])
+    for k in rel:
+        assert torch.equal(g2[k], grads[k]), k
+
+
+def test_theano_posterior_block_backward_vs_autograd_oracle(amd):
+    """the posterior block (sample, logqs, IAF step, logps, KL, free bits) trained through the Theano statement of the
+    stack: same block arithmetic as models.py:272-298 (0.1 scaling, logqs += s); every input and weight gradient"""
+    from oracle import iaf_grad_oracle as G
+    B, n_z, n_h, d, H, W = 3, 32, 64, 2, 8, 8
+    kl_min = 0.25
+    rng = np.random.RandomState(77)
+    w = _theano_params(rng, "q", n_z, [n_h] * d)
+    f = lambda c, s=1.0: s * rng.standard_normal((B, c, H, W))
+    inp = dict(qm=f(n_z), ql=f(n_z, 0.25), rm=f(n_z), rl=f(n_z, 0.25), pm=f(n_z), pl=f(n_z, 0.25), uc=f(n_h), dc=f(n_h),
+               eps=f(n_z))
+    dz, dko = rng.standard_normal((B, n_z, H, W)), rng.standard_normal(B)
+    stack = amd.ARStack(n_z, [n_h] * d, variant="theano")
+    stack.set_training(True)
+    rel = {k[2:]: dev(v) for k, v in w.items()}
+    stack.prepare(rel)
+    di = {k: dev(v) for k, v in inp.items()}
+    fw = stack.posterior_block_train(di["qm"], di["ql"], di["rm"], di["rl"], di["pm"], di["pl"], di["uc"], di["dc"], di["eps"],
+                                     kl_min)
+    bw = stack.posterior_block_backward(di["qm"], di["ql"], di["rm"], di["rl"], di["pm"], di["pl"], di["eps"], kl_min, fw["z"],
+                                        dev(dz), dev(dko), rel)
+    # the oracle: the TF-stated block with its iaf_step swapped for the Theano statement's
+    it = {k: G._t(f32(v), k != "eps") for k, v in inp.items()}
+    wt = {k: G._t(f32(v), True) for k, v in w.items()}
+    orig = G.iaf_step
+    G.iaf_step = lambda z0, c, p, nh: G.theano_iaf2_nl(z0, c, p, "q", n_z, nh)
+    try:
+        z, kl_obj, kl_cost = G.posterior_block(it["qm"], it["ql"], it["rm"], it["rl"], it["pm"], it["pl"], it["uc"], it["dc"],
+                                               it["eps"], wt, [n_h] * d, kl_min)
+    finally:
+        G.iaf_step = orig
+    ((z * G._t(f32(dz))).sum() + (kl_obj * G._t(f32(dko))).sum()).backward()
+    np.testing.assert_allclose(host(fw["z"]), z.detach().numpy(), atol=ATOL, rtol=0)
+    np.testing.assert_allclose(host(fw["kl_obj"]), kl_obj.detach().numpy(), atol=2e-3, rtol=1e-4)
+    _rel_close(host(bw["dmean"]), it["qm"].grad.numpy(), 1e-4, "dmean")
+    _rel_close(host(bw["dlogsd"]), it["ql"].grad.numpy(), 1e-4, "dlogsd")
+    _rel_close(host(bw["dpz_mean"]), it["pm"].grad.numpy(), 1e-4, "dpz_mean")
+    _rel_close(host(bw["dpz_logsd"]), it["pl"].grad.numpy(), 1e-4, "dpz_logsd")
+    _rel_close(host(bw["dcontext"]), it["uc"].grad.numpy(), 1e-4, "dcontext")
+    for k in sorted(rel):
+        _rel_close(host(bw["grads"][k]), wt["q_" + k].grad.numpy(), 2e-4, k)
+
+
 @pytest.mark.parametrize("shape", [(3, 32, 160, 2, 16, 16), (4, 32, 160, 2, 8, 8), (2, 32, 64, 1, 4, 4), (2, 64, 64, 4, 5, 3),
                                    (32, 32, 160, 2, 8, 8)], ids=lambda s: "B%d_z%d_h%d_d%d_%dx%d" % s)
 def test_theano_variant_vs_oracle(amd, shape):
