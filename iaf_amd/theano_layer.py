@@ -29,11 +29,20 @@ class CVAELayerIAF(object):
         self.stack = ARStack(self.n_z, [self.n_h] * self.depth_ar,
                              variant=_capi.IAF_VARIANT_THEANO_FLIPMASK if flipmask else _capi.IAF_VARIANT_THEANO)
         self._st = None
+        self.training = False
+        self._rel = None
+
+    def set_training(self, on=True):
+        """keep what backward() needs in up() / down_q() (call load() again afterwards: the data-gradient weight packs are
+        written by the next prepare)"""
+        self.stack.set_training(on)
+        self.training = bool(on)
 
     def load(self, w):
         """w: the reference's parameter dict; reads w[name + '_posterior_conv1_<i>_w|_b|_s'] and '..._out_<i>_...'"""
         pre = self.name + "_posterior_conv1_"
-        self.stack.prepare({k[len(pre):]: v for k, v in w.items() if k.startswith(pre)})
+        self._rel = {k[len(pre):]: v for k, v in w.items() if k.startswith(pre)}
+        self.stack.prepare(self._rel)
 
     def up(self, h, eps=None):
         """h: output of up_conv1 [B, 2 n_h + 2 n_z, H, W].  Returns the input of up_conv2 (before its nonlinearity):
@@ -46,8 +55,8 @@ class CVAELayerIAF(object):
                 raise ValueError("'up_iaf2_nl' samples the posterior in the up pass: pass eps")
             z0 = gaussian_sample(qz_mean, qz_logsd, eps)                                          # rand.py:81-83
             logq0 = gaussian_diag_logps(qz_mean, qz_logsd * 2.0, z0)                              # rand.py:85-86
-            z, logdet = self.stack.iaf_step(z0, context)                                          # models.py:170-173
-            st.update(z=z, logq0=logq0, logdet=logdet)
+            z, logdet = (self.stack.iaf_step_train if self.training else self.stack.iaf_step)(z0, context)   # models.py:170-173
+            st.update(z=z, logq0=logq0, logdet=logdet, z0=z0, eps=eps)
             out = torch.cat([h_det, z], dim=1)                                                    # :176
         else:
             out = h_det
@@ -61,6 +70,12 @@ class CVAELayerIAF(object):
         n_h, n_z, st = self.n_h, self.n_z, self._st
         if self.posterior == "down_iaf2_nl":
             h_det, pz_mean, pz_logsd, rz_mean, rz_logsd, down_context = split(h, 1, [n_h, n_z, n_z, n_z, n_z, n_h])
+            if self.training:
+                blk = self.stack.posterior_block_train(st["qz_mean"], st["qz_logsd"], rz_mean, rz_logsd, pz_mean, pz_logsd,
+                                                       st["context"], down_context, eps, self.kl_min)
+                st.update(rz_mean=rz_mean, rz_logsd=rz_logsd, pz_mean=pz_mean, pz_logsd=pz_logsd, eps=eps, z=blk["z"])
+                obj_kl = blk["kl_obj"][0] if self.kl_min > 0 else blk["kl_cost"]
+                return dict(h=torch.cat([h_det, blk["z"]], dim=1), z=blk["z"], kl=None, kl_sum=blk["kl_cost"], obj_kl=obj_kl)
             blk = self.stack.posterior_block(st["qz_mean"], st["qz_logsd"], rz_mean, rz_logsd, pz_mean, pz_logsd, st["context"],
                                              down_context, eps, self.kl_min, want_kl_elem=True)   # :272-285, 296-298
             z, kl, kl_sum, kl_obj = blk["z"], blk["kl_elem"], blk["kl_cost"], blk["kl_obj"]
@@ -72,10 +87,59 @@ class CVAELayerIAF(object):
             _capi.check(_capi.lib().iaf_kl_combine(_ptr(st["logq0"]), _ptr(st["logdet"]), _ptr(logp), _ptr(kl), kl.numel(),
                                                    _stream()))
             kl_sum, kl_obj = kl_reduce(kl, self.kl_min)
+            st.update(pz_mean=pz_mean, pz_logsd=pz_logsd, kl=kl)
         # TF: kl_obj[b] = sum_c max(mean_b sum_hw kl, kl_min) for every b (tf_train.py:79-82); Theano adds that SCALAR
         # once per layer (models.py:460-461)
         obj_kl = kl_obj[0] if self.kl_min > 0 else kl_sum
         return dict(h=torch.cat([h_det, z], dim=1), z=z, kl=kl, kl_sum=kl_sum, obj_kl=obj_kl)
+
+
+    def backward(self, d_h, d_obj=None, d_up=None):
+        """T.grad (graphy/misc/optim.py:102) of  <d_up, up()> + <d_h, down_q()['h']> + <d_obj, obj_kl>  through the lines
+        models.py:139-146,168-176,272-298,454-466.  Must follow up() and down_q() in training mode on the same inputs.
+        d_h: gradient of concat([h_det, z]) [B, n_h + n_z, H, W];  d_up: gradient of what up() returned (None = zeros);
+        d_obj: gradient of obj_kl (a scalar with free bits, [B] without; None = ones).  Returns dict(d_up_conv1, d_down_conv1
+        -- gradients of the two conv outputs in the reference's channel order -- and grads keyed like the reference's w)."""
+        if not self.training or self._st is None or "z" not in self._st:
+            raise RuntimeError("backward() follows up() and down_q() in training mode")
+        n_h, n_z, st = self.n_h, self.n_z, self._st
+        z = st["z"]
+        B = z.shape[0]
+        d_hdet, dz = d_h[:, :n_h], d_h[:, n_h:].contiguous()
+        if self.kl_min > 0:      # obj_kl is ONE scalar per layer (models.py:460-461): d obj / d kl[b,c,:,:] = gate[c] / B
+            dko = torch.zeros(B, dtype=torch.float32, device=z.device)
+            dko[0] = 1.0 if d_obj is None else float(d_obj)
+        else:
+            dko = torch.ones(B, dtype=torch.float32, device=z.device) if d_obj is None else d_obj.contiguous()
+        pre = self.name + "_posterior_conv1_"
+        if self.posterior == "down_iaf2_nl":
+            bw = self.stack.posterior_block_backward(st["qz_mean"], st["qz_logsd"], st["rz_mean"], st["rz_logsd"], st["pz_mean"],
+                                                     st["pz_logsd"], st["eps"], self.kl_min, z, dz, dko, self._rel)
+            d_up_hdet = d_up if d_up is not None else torch.zeros_like(d_hdet)
+            d_uc1 = torch.cat([d_up_hdet, bw["dmean"], bw["dlogsd"], bw["dcontext"]], dim=1)                     # :141-143
+            d_dc1 = torch.cat([d_hdet, bw["dpz_mean"], bw["dpz_logsd"], bw["dmean"], bw["dlogsd"], bw["dcontext"]], dim=1)
+            grads = bw["grads"]
+        else:
+            # kl = logq0 + logdet - logp(z): gate the per-element gradient G as the free bits prescribe, push it through
+            # logp (prior side and z), the IAF step, and the reparametrised sample z0 = qz_mean + exp(qz_logsd) eps
+            if self.kl_min > 0:
+                gate = (st["kl"].sum(dim=(2, 3)).mean(dim=0) > self.kl_min).to(torch.float32)
+                G = (gate * (dko.sum() / B)).view(1, n_z, 1, 1).expand_as(z)
+            else:
+                G = dko.view(B, 1, 1, 1).expand_as(z)
+            e2 = torch.exp(-2.0 * st["pz_logsd"])
+            dlt = z - st["pz_mean"]
+            dz_tot = dz + G * dlt * e2                                       # -G dlogp/dz
+            if d_up is not None:
+                dz_tot = dz_tot + d_up[:, n_h:]
+            dz0, dctx, grads = self.stack.iaf_step_backward(st["z0"], st["context"], z, st["logdet"], dz_tot.contiguous(),
+                                                            G.contiguous(), self._rel)
+            d_qm = dz0                                                       # logq0 = -(log 2pi + 2 qz_logsd + eps^2) / 2
+            d_ql = dz0 * (st["z0"] - st["qz_mean"]) - G
+            d_up_hdet = d_up[:, :n_h] if d_up is not None else torch.zeros_like(d_hdet)
+            d_uc1 = torch.cat([d_up_hdet, d_qm, d_ql, dctx], dim=1)
+            d_dc1 = torch.cat([d_hdet, -G * dlt * e2, G * (1.0 - dlt * dlt * e2)], dim=1)
+        return dict(d_up_conv1=d_uc1, d_down_conv1=d_dc1, grads={pre + k: v for k, v in grads.items()})
 
 
 def kl_reduce(kl, kl_min):

@@ -105,8 +105,9 @@ int iaf_step_inverse(iaf_stack_t* s, const float* z, const float* context, float
 
 /* ------------------------------------------------------------------------------------------
  * Training.  The reference never writes a backward pass: TF autodiff derives it from the graph
- * (opt.compute_gradients, tf_train.py:138).  These entry points compute the same gradients for the IAF step.
- * TF variant only.
+ * (opt.compute_gradients, tf_train.py:138; Theano: T.grad, graphy/misc/optim.py:102).  These entry points compute the
+ * same gradients for the IAF step, for every variant.  With IAF_VARIANT_THEANO[_FLIPMASK] the (V, g, b) / (dV, dg, db)
+ * slots carry (w, s, b): w and dw are OIHW [n_out][n_in+1][3][3] including the border-indicator channel (ar.py:288-296).
  * ------------------------------------------------------------------------------------------ */
 /* on != 0: allocate the transposed weight packs; the next iaf_stack_prepare / iaf_prep_batch_run fills them */
 int iaf_stack_set_training(iaf_stack_t* s, int on);

@@ -192,3 +192,41 @@ def theano_iaf2_nl_grads(z, context, w, name, n_z, n_h, dz_new, dlogsd, flipmask
     for k, v in wt.items():
         out[k] = v.grad.numpy()
     return out, z_new.detach().numpy(), logsd.detach().numpy()
+
+
+def theano_cvae_iaf(posterior, h_up, h_dn, eps, w, name, n_h, n_z, depth_ar, kl_min, flipmask=False):
+    """The part of models.cvae_layer between its plain convs (oracle/iaf_oracle.py:theano_cvae_layer restates the whole
+    layer): h_up / h_dn are the outputs of up_conv1 / down_conv1 in the reference's channel order (models.py:141-143,
+    273-279, 296-297).  Returns (what up_conv2 reads, what down_conv2 reads = concat([h_det, z]), kl, obj_kl (:454-466))."""
+    pc = name + "_posterior_conv1"
+    h_det_u, qm, ql, ctx = torch.split(h_up, [n_h, n_z, n_z, n_h], dim=1)
+    if posterior == "up_iaf2_nl":                                                      # :168-176
+        z0 = qm + torch.exp(ql) * eps
+        logqs = gaussian_diag_logps(qm, 2 * ql, z0)
+        z, s = theano_iaf2_nl(z0, ctx, w, pc, n_z, [n_h] * depth_ar, flipmask)
+        logqs = logqs + s
+        up_out = torch.cat([h_det_u, z], dim=1)
+        h_det, pm, pl = torch.split(h_dn, [n_h, n_z, n_z], dim=1)
+    else:                                                                              # :272-285
+        up_out = h_det_u
+        h_det, pm, pl, rm, rl, dctx = torch.split(h_dn, [n_h, n_z, n_z, n_z, n_z, n_h], dim=1)
+        mean, logvar = qm + rm, 2 * ql + 2 * rl
+        z0 = mean + torch.exp(0.5 * logvar) * eps
+        logqs = gaussian_diag_logps(mean, logvar, z0)
+        z, s = theano_iaf2_nl(z0, ctx + dctx, w, pc, n_z, [n_h] * depth_ar, flipmask)
+        logqs = logqs + s
+    kl = logqs - gaussian_diag_logps(pm, 2 * pl, z)                                     # :298, 328
+    kl_sum = kl.sum(dim=(1, 2, 3))
+    obj = torch.clamp(kl.sum(dim=(2, 3)).mean(dim=0), min=kl_min).sum() if kl_min > 0 else kl_sum   # :458-466
+    return up_out, torch.cat([h_det, z], dim=1), kl, obj
+
+
+def theano_cvae_iaf_grads(posterior, h_up, h_dn, eps, w, name, n_h, n_z, depth_ar, kl_min, d_up, d_h, d_obj, flipmask=False):
+    """L = <d_up, up_out> + <d_h, h_out> + <d_obj, obj_kl>; gradients w.r.t. both conv outputs and every stack weight."""
+    ut, dt = _t(h_up, True), _t(h_dn, True)
+    wt = {k: _t(v, True) for k, v in w.items()}
+    up_out, h_out, kl, obj = theano_cvae_iaf(posterior, ut, dt, _t(eps), wt, name, n_h, n_z, depth_ar, kl_min, flipmask)
+    loss = (up_out * _t(d_up)).sum() + (h_out * _t(d_h)).sum() + (obj * _t(d_obj)).sum()
+    loss.backward()
+    fw = dict(up_out=up_out.detach().numpy(), h=h_out.detach().numpy(), kl=kl.detach().numpy(), obj_kl=obj.detach().numpy())
+    return dict(h_up=ut.grad.numpy(), h_dn=dt.grad.numpy(), w={k: v.grad.numpy() for k, v in wt.items()}), fw

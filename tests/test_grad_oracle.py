@@ -216,3 +216,25 @@ def test_theano_masked_and_border_weight_gradients():
             assert (grads[key][mask == 0] == 0).all()
             live_border = grads[key][:, n_in][mask[:, n_in] == 1]
             assert np.abs(live_border).max() > 0
+
+
+@pytest.mark.parametrize("cname", sorted(gi.CVAE_CASES))
+def test_theano_cvae_iaf_forward_matches_reference_golden(golden_dir, cname):
+    """the autograd oracle's statement of the layer's IAF part, fed the conv outputs of the NumPy oracle, reproduces what the
+    reference's own models.py produced (kl, obj_kl) -- so its gradients are T.grad's"""
+    import os
+    posterior, B, n_h, n_z, depth_ar, H, W, kl_min = gi.CVAE_CASES[cname]
+    g = np.load(os.path.join(golden_dir, "theano_cvae_layer.npz"))
+    pre = cname + "/w_shape/"
+    c = gi.cvae_case_inputs(cname, {k[len(pre):]: g[k] for k in g.files if k.startswith(pre)})
+    ref = O.theano_cvae_layer("1", posterior, c["w"], n_h, n_z, depth_ar, c["up_input"], c["down_input"], c["eps_up"], c["eps_down"])
+    eps = c["eps_up"] if posterior == "up_iaf2_nl" else c["eps_down"]
+    sw = {k: v for k, v in c["w"].items() if "_posterior_conv1_" in k}
+    zero = lambda a: np.zeros_like(a)
+    n_up = n_h + n_z if posterior == "up_iaf2_nl" else n_h
+    _, fw = G.theano_cvae_iaf_grads(posterior, ref["up_conv1"], ref["down_conv1"], eps, sw, "1", n_h, n_z, depth_ar, kl_min,
+                                    np.zeros((B, n_up, H, W)), np.zeros((B, n_h + n_z, H, W)),
+                                    np.zeros(()) if kl_min > 0 else np.zeros(B))
+    np.testing.assert_allclose(fw["kl"], g[cname + "/kl"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(fw["obj_kl"], g[cname + "/obj_kl"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(fw["h"][:, n_h:], ref["z"], rtol=1e-10, atol=1e-10)

@@ -864,6 +864,44 @@ def test_cvae_layer_wrapper_vs_reference_golden(amd, golden_dir, cname):
     np.testing.assert_allclose(down_out, g[cname + "/down_out"], atol=ATOL, rtol=0)
 
 
+@pytest.mark.parametrize("kl_min", [0.0, 0.25])
+@pytest.mark.parametrize("posterior", ["down_iaf2_nl", "up_iaf2_nl"])
+def test_cvae_layer_wrapper_backward_vs_autograd_oracle(amd, posterior, kl_min):
+    """training through the Theano layer's IAF part (models.py:139-146,168-176,272-298,454-466): gradients of both conv
+    outputs (reference channel order) and of every stack weight, incl. the scalar free-bits objective"""
+    from oracle import iaf_grad_oracle as G
+    B, n_h, n_z, d, H, W = 3, 64, 32, 2, 8, 8
+    rng = np.random.RandomState(5 + int(kl_min * 8))
+    w = {"1_posterior_conv1_" + k[2:]: v for k, v in _theano_params(rng, "q", n_z, [n_h] * d).items()}
+    up_ch = 2 * n_h + 2 * n_z
+    dn_ch = 2 * n_h + 4 * n_z if posterior == "down_iaf2_nl" else n_h + 2 * n_z
+    h_up, h_dn = rng.standard_normal((B, up_ch, H, W)), rng.standard_normal((B, dn_ch, H, W))
+    h_up[:, n_h + n_z:n_h + 2 * n_z] *= 0.25                        # qz_logsd
+    h_dn[:, n_h + n_z:n_h + 2 * n_z] *= 0.25                        # pz_logsd
+    if posterior == "down_iaf2_nl":
+        h_dn[:, n_h + 3 * n_z:n_h + 4 * n_z] *= 0.25                # rz_logsd
+    eps = rng.standard_normal((B, n_z, H, W))
+    n_up = n_h + n_z if posterior == "up_iaf2_nl" else n_h
+    d_up, d_h = rng.standard_normal((B, n_up, H, W)), rng.standard_normal((B, n_h + n_z, H, W))
+    d_obj = np.asarray(0.7) if kl_min > 0 else rng.standard_normal(B)
+    layer = amd.CVAELayerIAF("1", n_h, n_z, d, posterior=posterior, kl_min=kl_min)
+    layer.set_training(True)
+    layer.load({k: dev(v) for k, v in w.items()})
+    up_out = layer.up(dev(h_up), eps=dev(eps))
+    dq = layer.down_q(dev(h_dn), eps=dev(eps))
+    bw = layer.backward(dev(d_h), d_obj=(0.7 if kl_min > 0 else dev(d_obj)), d_up=dev(d_up))
+    ref, fw = G.theano_cvae_iaf_grads(posterior, f32(h_up), f32(h_dn), f32(eps), {k: f32(v) for k, v in w.items()}, "1", n_h, n_z,
+                                      d, kl_min, f32(d_up), f32(d_h), f32(d_obj))
+    np.testing.assert_allclose(host(up_out), fw["up_out"], atol=ATOL, rtol=0)
+    np.testing.assert_allclose(host(dq["h"]), fw["h"], atol=ATOL, rtol=0)
+    np.testing.assert_allclose(host(dq["obj_kl"]), fw["obj_kl"], atol=2e-3, rtol=1e-4)
+    _rel_close(host(bw["d_up_conv1"]), ref["h_up"], 1e-4, "d_up_conv1")
+    _rel_close(host(bw["d_down_conv1"]), ref["h_dn"], 1e-4, "d_down_conv1")
+    assert set(bw["grads"]) == set(w)
+    for k in sorted(w):
+        _rel_close(host(bw["grads"][k]), ref["w"][k], 2e-4, k)
+
+
 @pytest.mark.parametrize("key,zd,flip,n_in,n_out", [("conv_zd0_flip1_16_32", False, True, 16, 32), ("conv_zd1_flip1_16_32", True, True, 16, 32),
                                                     ("conv_zd1_flip1_32_16", True, True, 32, 16), ("conv_zd0_flip0_32_16", False, False, 32, 16)])
 def test_theano_single_ar_conv2d_vs_reference_golden(amd, golden_dir, key, zd, flip, n_in, n_out):
