@@ -580,7 +580,7 @@ extern "C" int iaf_conv3x3_backward(iaf_conv3x3_t* c, const float* x, const floa
         int nblk = (int)((n4 + 255) / 256);
         if (nblk > 1024) nblk = 1024;
         hipLaunchKernelGGL(iaf_wgrad_reduce_kernel, dim3(nblk + nslab), dim3(256), 0, st, tw.part, dWbuf,
-                           wgrad_nrange(P, L.cin, MAXTAPS), n4, nblk, (const float*)tw.dyc, dbpbuf, P, L.cout, px_per_slab);
+                           wgrad_nrange(P, L.cin, MAXTAPS, L.cout), n4, nblk, (const float*)tw.dyc, dbpbuf, P, L.cout, px_per_slab);
     }
     // (4) through the weight norm -- now, or in iaf_conv3x3_wn_bwd_batch_run with every other conv of the model
     if (c->defer_wn) {

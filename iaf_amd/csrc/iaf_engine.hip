@@ -1169,14 +1169,61 @@ extern "C" int iaf_stack_set_training(iaf_stack_t* s, int on) {
 
 // pixel ranges of the weight-gradient GEMM: as many as keep the grid within ONE round of 256 workgroups
 // (grid.x = 5 taps * ceil(cin/32) ci pairs), at least 64 pixels each, at most 16 (the partial buffer is sized for 16)
-static int wgrad_nrange(long long P, int cin = 160, int ntaps = NTAPS) {
-    static const long long target = getenv("IAF_WGRAD_TARGET") ? atoll(getenv("IAF_WGRAD_TARGET")) : 512;   // dev knob
-    long long n = target / (ntaps * ((cin + 31) / 32));      // workgroups to aim for (2-3 per CU are resident)
-    if (n > P / 64) n = P / 64;
-    if (n < 1) n = 1;
-    if (n > 16) n = 16;
-    return (int)n;
+// ---- launch plan of the weight-gradient GEMM --------------------------------------------------------------------
+// wide-load shape (BW, NB) for `cout` packed output channels: 16-byte dY loads when cout % 64 == 0, 8-byte ones otherwise
+static bool wgrad_wide_shape(int cout, int* bw, int* nb) {
+    static const char* env = getenv("IAF_WGRAD_WIDE");       // dev knob: "0" = off, "BW,NB" = forced
+    if (env && env[0] == '0') return false;
+    if (env && sscanf(env, "%d,%d", bw, nb) == 2) return cout % (*bw * *nb * 16) == 0;
+    if (cout % 32 != 0) return false;
+    if (cout % 64 == 0) {
+        const int n = cout / 64;
+        *bw = 4;
+        *nb = (n % 3 == 0) ? 3 : (n % 2 == 0) ? 2 : 1;
+        if (*nb > 1 || n == 1) return true;
+    }
+    const int n = cout / 32;
+    *bw = 2;
+    for (int c = 7; c >= 1; --c)
+        if (n % c == 0) { *nb = c; break; }
+    return true;
 }
+
+struct WgradPlan { int bw, nb, ncot, gx, gz, nrange; };   // bw > 0: iaf_wgrad_wide_kernel<bw, nb>, else iaf_wgrad_kernel<ncot>
+
+// Pixel ranges (the K split across workgroups; the partial buffer holds 16): a workgroup has ~5 us of fixed cost
+// (launch, first loads, the LDS reduction, its partial), equal-sized workgroups run in lockstep rounds, and two resident
+// workgroups per CU hide each other's load latency.  Measured on the layer's convs at 16x16 and 8x8 (B=32): 8 ranges
+// when an operand-block sweep already has >= 40 workgroups (the 9-tap convs), 16 otherwise (the masked stack).
+static WgradPlan wgrad_plan(long long P, int cin, int cout, int ntaps) {
+    WgradPlan w;
+    memset(&w, 0, sizeof(w));
+    w.gx = ntaps * ((cin + 31) / 32);
+    const bool off32 = P * (cin > cout ? cin : cout) * 4 < (1LL << 32);      // the wide kernel's operand offsets are 32-bit
+    if (off32 && cin % 16 == 0 && wgrad_wide_shape(cout, &w.bw, &w.nb)) {
+        w.gz = cout / (w.bw * w.nb * 16);
+    } else {
+        static const int cand[] = {14, 12, 10, 8, 7, 6, 5, 4, 3, 2, 1};
+        w.bw = w.nb = 0;
+        w.ncot = 1;
+        for (int c : cand)
+            if ((cout / 16) % c == 0) { w.ncot = c; break; }
+        w.gz = (cout / 16) / w.ncot;
+    }
+    static const int force = getenv("IAF_WGRAD_NRANGE") ? atoi(getenv("IAF_WGRAD_NRANGE")) : 0;               // dev knob
+    long long n;
+    if (force > 0 && force <= 16 && force <= P / 16) n = force;
+    else if (P / 64 >= 16) n = (w.gx * w.gz >= 40) ? 8 : 16;
+    else if (P / 64 >= 8) n = 8;
+    else {
+        n = 512 / w.gx;
+        if (n > P / 64) n = P / 64;
+        if (n < 1) n = 1;
+    }
+    w.nrange = (int)n;
+    return w;
+}
+static int wgrad_nrange(long long P, int cin, int ntaps, int cout) { return wgrad_plan(P, cin, cout, ntaps).nrange; }
 
 struct TrainWs {
     float* h[MAX_GEMM_LAYERS];
@@ -1253,11 +1300,26 @@ extern "C" int iaf_step_forward_train(iaf_stack_t* s, const float* z, const floa
     return launch_conv(s, s->depth_ar, p, inmode, st);
 }
 
+// 1-D grid over (operand block, pixel range, output block), see wgrad_decode
+static dim3 wgrad_grid(WgradP& p, int gx, int gz) {
+    p.gx = gx; p.gz = gz;
+    return dim3(gx * gz * p.nrange);
+}
+
 template <int NCOT>
-static void launch_wgrad_t(const WgradP& p, dim3 grid, hipStream_t st) {
+static void launch_wgrad_t(WgradP& p, const WgradPlan& w, hipStream_t st) {
+    const dim3 grid = wgrad_grid(p, w.gx, w.gz);
     const size_t lds = (size_t)4 * NCOT * 4 * 64 * sizeof(float);
-    (void)raise_lds_cap((const void*)iaf_wgrad_kernel<NCOT>, lds);
-    hipLaunchKernelGGL(iaf_wgrad_kernel<NCOT>, grid, dim3(256), lds, st, p);
+    (void)raise_lds_cap((const void*)iaf_wgrad_kernel<NCOT, 2>, lds);
+    hipLaunchKernelGGL((iaf_wgrad_kernel<NCOT, 2>), grid, dim3(256), lds, st, p);
+}
+
+template <int BW, int NB>
+static void launch_wgrad_wide_t(WgradP& p, const WgradPlan& w, hipStream_t st) {
+    const size_t lds = (size_t)4 * BW * NB * 4 * 64 * sizeof(float);
+    const dim3 grid = wgrad_grid(p, w.gx, w.gz);
+    (void)raise_lds_cap((const void*)iaf_wgrad_wide_kernel<BW, NB, 2>, lds);
+    hipLaunchKernelGGL((iaf_wgrad_wide_kernel<BW, NB, 2>), grid, dim3(256), lds, st, p);
 }
 
 static int launch_tapmask(unsigned short* mask, int B, int H, int W, hipStream_t st) {
@@ -1304,30 +1366,43 @@ static int launch_wgrad(const iaf_stack_t* s, const GemmLayer& L, const float* x
     p.cin = L.cin; p.cout = L.cout;
     const int ntaps = L.full3x3 ? MAXTAPS : NTAPS;
     p.ntaps = ntaps;
-    p.nrange = wgrad_nrange(p.P, L.cin, ntaps);
+    const WgradPlan w = wgrad_plan(p.P, L.cin, L.cout, ntaps);
+    p.nrange = w.nrange;
     p.px_per_range = (int)(((long long)p.P + p.nrange - 1) / p.nrange + 15) / 16 * 16;
     static const int tf_dh[NTAPS] = {0, 0, 1, 1, 1}, tf_dw[NTAPS] = {0, 1, -1, 0, 1};
     for (int t = 0; t < ntaps; ++t) {
         p.tap_dh[t] = L.full3x3 ? t / 3 - 1 : tap_sign * tf_dh[t];
         p.tap_dw[t] = L.full3x3 ? t % 3 - 1 : tap_sign * tf_dw[t];
     }
-    static const int cand[] = {14, 12, 10, 8, 7, 6, 5, 4, 3, 2, 1};
-    int ncot = 1;
-    for (int c : cand)
-        if (L.ncot % c == 0) { ncot = c; break; }
-    dim3 grid(ntaps * ((L.cin + 31) / 32), p.nrange, L.ncot / ncot);
-    switch (ncot) {
-        case 14: launch_wgrad_t<14>(p, grid, st); break;
-        case 12: launch_wgrad_t<12>(p, grid, st); break;
-        case 7: launch_wgrad_t<7>(p, grid, st); break;
-        case 10: launch_wgrad_t<10>(p, grid, st); break;
-        case 8: launch_wgrad_t<8>(p, grid, st); break;
-        case 6: launch_wgrad_t<6>(p, grid, st); break;
-        case 5: launch_wgrad_t<5>(p, grid, st); break;
-        case 4: launch_wgrad_t<4>(p, grid, st); break;
-        case 3: launch_wgrad_t<3>(p, grid, st); break;
-        case 2: launch_wgrad_t<2>(p, grid, st); break;
-        default: launch_wgrad_t<1>(p, grid, st); break;
+    if (w.bw) {
+        switch (w.bw * 10 + w.nb) {
+            case 41: launch_wgrad_wide_t<4, 1>(p, w, st); break;
+            case 42: launch_wgrad_wide_t<4, 2>(p, w, st); break;
+            case 43: launch_wgrad_wide_t<4, 3>(p, w, st); break;
+            case 21: launch_wgrad_wide_t<2, 1>(p, w, st); break;
+            case 22: launch_wgrad_wide_t<2, 2>(p, w, st); break;
+            case 23: launch_wgrad_wide_t<2, 3>(p, w, st); break;
+            case 24: launch_wgrad_wide_t<2, 4>(p, w, st); break;
+            case 25: launch_wgrad_wide_t<2, 5>(p, w, st); break;
+            case 26: launch_wgrad_wide_t<2, 6>(p, w, st); break;
+            case 27: launch_wgrad_wide_t<2, 7>(p, w, st); break;
+            default: return IAF_ERR_UNSUPPORTED;       // (a forced IAF_WGRAD_WIDE shape that is not compiled)
+        }
+        (void)s;
+        return (int)hipGetLastError();
+    }
+    switch (w.ncot) {
+        case 14: launch_wgrad_t<14>(p, w, st); break;
+        case 12: launch_wgrad_t<12>(p, w, st); break;
+        case 7: launch_wgrad_t<7>(p, w, st); break;
+        case 10: launch_wgrad_t<10>(p, w, st); break;
+        case 8: launch_wgrad_t<8>(p, w, st); break;
+        case 6: launch_wgrad_t<6>(p, w, st); break;
+        case 5: launch_wgrad_t<5>(p, w, st); break;
+        case 4: launch_wgrad_t<4>(p, w, st); break;
+        case 3: launch_wgrad_t<3>(p, w, st); break;
+        case 2: launch_wgrad_t<2>(p, w, st); break;
+        default: launch_wgrad_t<1>(p, w, st); break;
     }
     (void)s;
     return (int)hipGetLastError();
@@ -1372,7 +1447,7 @@ extern "C" int iaf_step_backward(iaf_stack_t* s, const float* z, const float* co
         const GemmLayer& L = s->L[l];
         ReduceLayer& r = ra.L[ra.n++];
         r.part = tw.part[l]; r.dW = tw.dWeff[l]; r.n4 = (size_t)NTAPS * L.cin * L.cout / 4;
-        r.nrange = wgrad_nrange(P, L.cin);
+        r.nrange = wgrad_nrange(P, L.cin, NTAPS, L.cout);
         int nblk = (int)((r.n4 + 255) / 256);
         if (nblk > 256) nblk = 256;
         r.blk_begin = ra.nblk_total;

@@ -42,7 +42,20 @@ struct WgradP {
     int ntaps;           // 5 (masked) or 9 (plain)
     int tap_dh[MAXTAPS], tap_dw[MAXTAPS];
     const unsigned short* tapmask;   // [P]: bit (dh+1)*3+(dw+1) set when pixel p's neighbour (dh,dw) lies inside its image
+    int gx, gz;          // workgroups per pixel range: gx = ntaps * ceil(cin/32) operand blocks, gz output-channel blocks
 };
+
+// Workgroup -> (operand block x, pixel range, output block z), 1-D grid, the workgroups of a pixel range adjacent.
+// (Dealing whole pixel ranges to each XCD -- workgroup i runs on XCD i % 8, each XCD has its own 4 MB L2 -- so that an
+// L2 only ever sees 1/8 of the pixels was measured and changed nothing: the operand streams are not L2-capacity bound.)
+__device__ __forceinline__ void wgrad_decode(const WgradP& p, int& x, int& range, int& z) {
+    const int per_range = p.gx * p.gz;
+    const int v = blockIdx.x;
+    range = v / per_range;
+    const int rem = v - range * per_range;
+    z = rem / p.gx;
+    x = rem - z * p.gx;
+}
 
 // border table of the weight gradient: the 9 in-image bits of every pixel, computed once per backward instead of two
 // integer divisions per K step per lane (which cost as much issue time as the MFMAs of the step)
@@ -60,15 +73,16 @@ __global__ __launch_bounds__(256) void iaf_tapmask_kernel(unsigned short* __rest
     mask[px] = (unsigned short)m;
 }
 
-template <int NCOT>
+template <int NCOT, int D>
 __global__ __launch_bounds__(256, 2) void iaf_wgrad_kernel(WgradP p) {
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tap = blockIdx.x % p.ntaps;
-    const int cip = blockIdx.x / p.ntaps;          // pair of ci tiles
-    const int range = blockIdx.y;
-    const int cob = blockIdx.z * NCOT * 16;        // this workgroup's first packed output channel
+    int bx, range, bz;
+    wgrad_decode(p, bx, range, bz);
+    const int tap = bx % p.ntaps;
+    const int cip = bx / p.ntaps;                  // pair of ci tiles
+    const int cob = bz * NCOT * 16;                // this workgroup's first packed output channel
     const int ci0 = cip * 32;
     const int nci = (p.cin - ci0 >= 32) ? 2 : 1;   // c_in = 16 has a single tile
     const int i15 = lane & 15, ks = lane >> 4;
@@ -81,47 +95,66 @@ __global__ __launch_bounds__(256, 2) void iaf_wgrad_kernel(WgradP p) {
         for (int t = 0; t < NCOT; ++t) acc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int r0 = range * p.px_per_range;
     const int r1 = min(p.P, r0 + p.px_per_range);
-    // wave w takes K steps w, w+4, ... of the range (4 pixels each).  The operands of step k+1 are requested before the
-    // MFMAs of step k issue: with one wave per SIMD nothing else hides the ~1 us global-load latency.
-    // Software pipeline, one K step deep: the loads of step k+1 are issued, THEN the MFMAs of step k run, THEN the loaded
-    // values are masked (select) into the operand registers.  Loads are unconditional (addresses clamped into the
-    // tensors, zeroing by select): a branch around a load, or a select right behind it, makes the wave wait for the
-    // load before the MFMAs are issued and the prefetch is for nothing (sched_barrier pins the three phases).
+    // wave w takes K steps w, w+4, ... of the range (4 pixels each).  With two waves per SIMD nothing but the wave's own
+    // prefetch hides the global-load latency (several hundred ns under load, i.e. more than one K step of MFMAs): the raw
+    // operands of the next D steps sit in a register ring.  Per step: the border selects of the oldest slot (its loads were
+    // issued D steps ago), then the MFMAs with the loads of step k+D into that slot spread between them.  Loads are
+    // unconditional and their addresses do not depend on loaded data (the shifted pixel is clamped into the tensor, the
+    // border bit only feeds the select): a load behind a load, a branch around a load or a select right behind it would put
+    // the wave to sleep before its MFMAs are issued.
     const int start = r0 + 4 * wave;
     const int nstep = (r1 - start + 15) / 16;              // steps of this wave (<= 0: nothing to do)
     float av[2], bv[NCOT];                                 // operands of the current step
-    float ra[2], rb[NCOT];                                 // raw loads of the next step
-    bool nxv = false, npv = false;
-    auto issue = [&](int pb) {
+    float ra[D][2], rb[D][NCOT];                           // raw loads of the steps in flight
+    unsigned rm[D];
+    bool rv[D];
+    const int xoff = ci0 + i15, xoff1 = ci0 + i15 + (nci == 2 ? 16 : 0);
+    auto issue = [&](int slot, int pb) {
         const int pk = pb + ks;                            // this lane's pixel for both operands
-        npv = pk < r1;
-        const int pkc = npv ? pk : r1 - 1;
-        nxv = npv && ((p.tapmask[pkc] >> tapbit) & 1);
-        const long long xp = nxv ? (long long)pkc + shift : (long long)pkc;
-        const float* xr = p.x + xp * p.cin + ci0 + i15;
+        rv[slot] = pk < r1;
+        const int pkc = rv[slot] ? pk : r1 - 1;
+        int xp = pkc + shift;
+        xp = xp < 0 ? 0 : (xp >= p.P ? p.P - 1 : xp);
+        rm[slot] = p.tapmask[pkc];
+        const float* xr = p.x + (size_t)xp * p.cin;
         const float* dr = p.dy + (size_t)pkc * p.cout + cob + i15;
-        ra[0] = xr[0];
-        ra[1] = xr[nci == 2 ? 16 : 0];
+        ra[slot][0] = xr[xoff];
+        ra[slot][1] = xr[xoff1];
 #pragma unroll
-        for (int t = 0; t < NCOT; ++t) rb[t] = dr[t * 16];
+        for (int t = 0; t < NCOT; ++t) rb[slot][t] = dr[t * 16];
     };
-    auto take = [&]() {
-        av[0] = nxv ? ra[0] : 0.f;
-        av[1] = (nxv && nci == 2) ? ra[1] : 0.f;
+    auto take = [&](int slot) {
+        const bool nxv = rv[slot] && ((rm[slot] >> tapbit) & 1u);
+        av[0] = nxv ? ra[slot][0] : 0.f;
+        av[1] = (nxv && nci == 2) ? ra[slot][1] : 0.f;
 #pragma unroll
-        for (int t = 0; t < NCOT; ++t) bv[t] = npv ? rb[t] : 0.f;
+        for (int t = 0; t < NCOT; ++t) bv[t] = rv[slot] ? rb[slot][t] : 0.f;
     };
-    issue(start);
-    take();
-    for (int k = 0; k < nstep; ++k) {
-        issue(start + 16 * (k + 1));                       // beyond the range: clamped address, masked to zero
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int t = 0; t < NCOT; ++t) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[t], acc[a][t], 0, 0, 0);
+    for (int d = 0; d < D; ++d) {       // slot by slot, as the loop issues them: its counted waits (vmcnt) assume that order
+        issue(d, start + 16 * d);
         __builtin_amdgcn_sched_barrier(0);
-        take();
+    }
+    for (int k = 0; k < nstep; k += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            take(d);            // (a trailing partial group runs on clamped addresses and zero operands)
+            __builtin_amdgcn_sched_barrier(0);
+            issue(d, start + 16 * (k + d + D));            // beyond the range: clamped address, masked to zero
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int t = 0; t < NCOT; ++t) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[t], acc[a][t], 0, 0, 0);
+            static_for<2 * NCOT>([&](auto m_c) {            // address arithmetic and loads spread between the MFMAs (see (2'))
+                constexpr int m = decltype(m_c)::value;
+                constexpr int NLD = NCOT + 3, FIRST = (2 * NCOT) / 4, SPAN = 2 * NCOT - FIRST;
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                if constexpr (m >= FIRST && ((m - FIRST) * NLD) / SPAN != ((m - FIRST + 1) * NLD) / SPAN)
+                    __builtin_amdgcn_sched_group_barrier(0x020, ((m - FIRST + 1) * NLD) / SPAN - ((m - FIRST) * NLD) / SPAN, 0);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     // reduce the 4 waves through LDS, one ci tile (a) at a time: [wave][t][r][lane] -- half the LDS of doing both at once,
     // which is what lets two workgroups share a CU (two waves per SIMD hide each other's load latency)
@@ -144,6 +177,123 @@ __global__ __launch_bounds__(256, 2) void iaf_wgrad_kernel(WgradP p) {
                 for (int k = 0; k < 4; ++k) sum += wsm[(size_t)k * (NCOT * 4 * 64) + (size_t)e * 64 + lane];
                 out[(size_t)(ci0 + a * 16 + 4 * ks + r) * p.cout + cob + t * 16 + i15] = sum;
             }
+    }
+}
+
+// (2') the same GEMM with WIDE operand loads.  A lane's 8-byte load of X brings channels (2 i15, 2 i15 + 1) of its pixel and
+//      its BW*4-byte loads of dY bring BW consecutive output channels: element j of a load feeds MFMA tile j, whose rows /
+//      columns are therefore the channels {base + width*i + j} -- a permutation of the 16x16 tiles that only the write-out
+//      needs to know about.  One load instruction per 2 (X) or BW (dY) tiles instead of one per tile: the K loop of (2) is
+//      bound by the number of vector-memory instructions per MFMA, not by their latency (a deeper ring changes nothing).
+//      Workgroup = (tap, 32 input channels, pixel range, NB*BW output tiles); needs cin % 16 == 0, cout % (16 BW NB) == 0.
+template <int BW, int NB, int D>
+__global__ __launch_bounds__(256, 2) void iaf_wgrad_wide_kernel(WgradP p) {
+    constexpr int NBT = BW * NB;
+    typedef float fA __attribute__((ext_vector_type(2)));
+    typedef float fB __attribute__((ext_vector_type(BW)));
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bx, range, bz;
+    wgrad_decode(p, bx, range, bz);
+    const int tap = bx % p.ntaps;
+    const int cip = bx / p.ntaps;
+    const int cob = bz * NBT * 16;
+    const int ci0 = cip * 32;
+    const int i15 = lane & 15, ks = lane >> 4;
+    const bool civ = ci0 + 2 * i15 + 1 < p.cin;        // cin % 32 == 16: the last block's lanes i15 >= 8 hold nothing
+    const int dh = p.tap_dh[tap], dw = p.tap_dw[tap];
+    const int tapbit = (dh + 1) * 3 + (dw + 1), shift = dh * p.W + dw;
+    f32x4 acc[2][NBT];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int t = 0; t < NBT; ++t) acc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int r0 = range * p.px_per_range;
+    const int r1 = min(p.P, r0 + p.px_per_range);
+    const int start = r0 + 4 * wave;
+    const int nstep = (r1 - start + 15) / 16;
+    float av[2], bv[NBT];
+    fA ra[D];
+    fB rb[D][NB];
+    unsigned rm[D];
+    bool rv[D];
+    // addresses as uniform base + 32-bit byte offset (host guarantees the tensors are < 4 GiB): a handful of full-rate
+    // VALU instructions per step, which the scheduler is told to spread -- with the loads -- between the MFMAs of the
+    // step (an in-order wave that issues its 30 VALU + 5 VMEM instructions in a block leaves its SIMD's MFMA pipe to
+    // the other resident wave for ~250 of every ~1000 cycles; measured, the two did not fill each other's gaps).
+    const unsigned cin4 = (unsigned)p.cin * 4u, cout4 = (unsigned)p.cout * 4u;
+    const unsigned xlane = (unsigned)(civ ? ci0 + 2 * i15 : ci0) * 4u, dlane = (unsigned)(cob + BW * i15) * 4u;
+    const char* xb = (const char*)p.x;
+    const char* db = (const char*)p.dy;
+    const char* mb = (const char*)p.tapmask;
+    auto issue = [&](int slot, int pb) {
+        const int pk = pb + ks;
+        rv[slot] = pk < r1;
+        const int pkc = min(pk, r1 - 1);
+        const int xp = max(0, min(pkc + shift, p.P - 1));
+        rm[slot] = *(const unsigned short*)(mb + (unsigned)pkc * 2u);
+        ra[slot] = *(const fA*)(xb + (__umul24((unsigned)xp, cin4) + xlane));
+        const unsigned doff = __umul24((unsigned)pkc, cout4) + dlane;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) rb[slot][nb] = *(const fB*)(db + (doff + (unsigned)(nb * 16 * BW * 4)));
+    };
+    auto take = [&](int slot) {
+        const bool nxv = civ && rv[slot] && ((rm[slot] >> tapbit) & 1u);
+        av[0] = nxv ? ra[slot][0] : 0.f;
+        av[1] = nxv ? ra[slot][1] : 0.f;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int e = 0; e < BW; ++e) bv[nb * BW + e] = rv[slot] ? rb[slot][nb][e] : 0.f;
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) {       // slot by slot, as the loop issues them: its counted waits (vmcnt) assume that order
+        issue(d, start + 16 * d);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    for (int k = 0; k < nstep; k += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            take(d);            // (a trailing partial group runs on clamped addresses and zero operands)
+            __builtin_amdgcn_sched_barrier(0);
+            issue(d, start + 16 * (k + d + D));
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int t = 0; t < NBT; ++t) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[t], acc[a][t], 0, 0, 0);
+            // one MFMA, then up to two of the step's address instructions; the loads from the second quarter on
+            static_for<2 * NBT>([&](auto m_c) {
+                constexpr int m = decltype(m_c)::value;
+                constexpr int NLD = NB + 2, FIRST = (2 * NBT) / 4, SPAN = 2 * NBT - FIRST;
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                if constexpr (m >= FIRST && ((m - FIRST) * NLD) / SPAN != ((m - FIRST + 1) * NLD) / SPAN)
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // reduce the 4 waves through LDS as in (2); tile (a, t = nb*BW + e) holds
+    //   rows ci = ci0 + 2 (4 ks + r) + a,   columns co = cob + nb*16*BW + BW*i15 + e
+    float* out = p.part + (((size_t)range * p.ntaps + tap) * p.cin) * p.cout;
+    float* mine = wsm + (size_t)wave * (NBT * 4 * 64) + lane;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        if (a) __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NBT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mine[(t * 4 + r) * 64] = acc[a][t][r];
+        __syncthreads();
+        for (int e = wave; e < NBT * 4; e += 4) {
+            const int t = e >> 2, r = e & 3;
+            const int ci = ci0 + 2 * (4 * ks + r) + a;
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sum += wsm[(size_t)k * (NBT * 4 * 64) + (size_t)e * 64 + lane];
+            if (ci < p.cin) out[(size_t)ci * p.cout + cob + (t / BW) * 16 * BW + BW * i15 + (t % BW)] = sum;
+        }
     }
 }
 
