@@ -68,6 +68,8 @@ def parse():
                          "f32 = the exact-fp32 MFMA everywhere")
     ap.add_argument("--no-fuse", action="store_true",
                     help="never run the first masked conv inside the second one's kernel (iaf_stack_set_fuse_first)")
+    ap.add_argument("--no-fuse-step", action="store_true",
+                    help="run every IAF step layer by layer instead of as one launch (iaf_stack_set_fuse_step)")
     ap.add_argument("--no-autotune", action="store_true",
                     help="skip the per-layer kernel/launch-shape search (iaf_stack_autotune) before the timed region")
     ap.add_argument("--ar-buckets", type=int, default=4,
@@ -801,6 +803,16 @@ def iw_eval_bench(args, depths, dist, rank, n_gpus):
                      "step": {"live_flops_per_step": step_fl, "frac_of_f32_mfma_peak": step_fl / (elapsed / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS}}})
 
 
+def _halo_note(st, R, args):
+    """how many MACs the one-launch step issues per live MAC: hidden layer l is computed on R + depth_ar - l rows per R
+    output rows (iaf_step_fused.hpp); roofline figures count the live ones only"""
+    d = args.depth_ar
+    live = [st.layer_work(l, args.batch, 16, 16)["live_flops"] for l in range(d + 1)]
+    issued = sum(live[l] * (R + d - l) / R for l in range(d)) + live[d]
+    return "the launch multiplies %.2fx the live MACs (halo rows of the hidden layers recomputed per %d-row workgroup); only live MACs are counted" % (
+        issued / sum(live), R)
+
+
 def main():
     args = parse()
     depths = [int(d) for d in args.depths.split(",") if d]
@@ -847,8 +859,10 @@ def main():
             st.set_precision(args.precision)
             if args.no_fuse:
                 st.set_fuse_first("never")
+            if args.no_fuse_step:
+                st.set_fuse_step("never")
             st.prepare(dp)
-            layers.append(dict(stack=st, params=dp, z=zd, ctx=cd, out=out, H=H))
+            layers.append(dict(stack=st, params=dp, z=zd, ctx=cd, out=out, H=H, one=st.step_is_fused(args.batch, H, H)))
     if args.tune:
         for item in args.tune.split(";"):
             lay, shp = item.split(":")
@@ -863,6 +877,9 @@ def main():
         # kernel family + launch shape per layer, measured on this box for this size (the cuDNN algorithm search of the
         # reference's convs); outside the timed region, before the graph is captured
         for L in layers:
+            if L["one"]:             # the step runs as ONE launch at this size: no per-layer kernels to choose between
+                tuned.setdefault("%dx%d" % (L["H"], L["H"]), ["whole step in one launch (%d rows per workgroup)" % L["one"]])
+                continue
             picks = L["stack"].autotune(L["z"], L["ctx"], reps=20)
             L["fused"] = picks[0][0] == "fused into next"
             tuned.setdefault("%dx%d" % (L["H"], L["H"]), [c for c, _ in picks])
@@ -902,9 +919,10 @@ def main():
         # ---------------- kernel leg: eager steps, HIP events around every launch of the dominant kernel
         dom_layer = max(args.depth_ar - 1, 0)                    # the n_h -> n_h masked conv (layer 1 at depth_ar=2)
         prof = [L for L in layers if L["H"] == 16]
+        one16 = bool(prof) and all(L["one"] for L in prof)       # the 16x16 steps run as ONE launch each: that is the kernel
         ksteps = max(10, min(args.steps, 50))
         for L in prof:
-            L["stack"].profile_enable(dom_layer, ksteps + 4)
+            L["stack"].profile_enable(-2 if one16 else dom_layer, ksteps + 4)
         for _ in range(3):
             step()
         torch.cuda.synchronize()
@@ -919,10 +937,13 @@ def main():
             L["stack"].profile_enable(-1, 0)
         # primary figure: N back-to-back launches of the dominant kernel between ONE event pair (no per-launch
         # event/dispatch latency), averaged over the 16x16 layers
-        fused16 = dom_layer == 1 and bool(prof) and all(L.get("fused") for L in prof)     # every 16x16 stack tuned to the fused launch
-        kbatch = [L["stack"].time_layer(-1 if fused16 else dom_layer, L["z"], L["ctx"] if args.depth_ar > 0 else None, reps=50)
-                  for L in prof if fused16 or not L.get("fused")] or \
-                 [L["stack"].time_layer(-1, L["z"], L["ctx"], reps=50) for L in prof]
+        fused16 = (not one16) and dom_layer == 1 and bool(prof) and all(L.get("fused") for L in prof)     # every 16x16 stack tuned to the fused launch
+        if one16:
+            kbatch = [L["stack"].time_layer(-2, L["z"], L["ctx"], reps=50) for L in prof]
+        else:
+            kbatch = [L["stack"].time_layer(-1 if fused16 else dom_layer, L["z"], L["ctx"] if args.depth_ar > 0 else None, reps=50)
+                      for L in prof if fused16 or not L.get("fused")] or \
+                     [L["stack"].time_layer(-1, L["z"], L["ctx"], reps=50) for L in prof]
         # every GEMM layer of the IAF step at every latent level, same method (first layer of each level), and the
         # extended unit of SURVEY 8d (posterior block: sample + logqs + IAF step + log-det + logps + KL / free bits)
         ktable, xunit = [], []
@@ -934,7 +955,15 @@ def main():
             st = L["stack"]
             cin = args.n_z
             fused = bool(L.get("fused"))
-            for gl in range(args.depth_ar + 1):
+            if L["one"]:
+                ms = st.time_layer(-2, L["z"], L["ctx"], reps=50)
+                w = st.step_work(args.batch, H, H)
+                tf_ = w["live_flops"] / (ms * 1e-3) / 1e12
+                ktable.append({"layer": "IAF step: masked convs %d->%d%s->%d (mean,logsd pair) + affine/log-det, ONE launch, %d rows per workgroup"
+                                        % (args.n_z, args.n_h, "->%d" % args.n_h if args.depth_ar > 1 else "", 2 * args.n_z, L["one"]),
+                               "latent": "%dx%d" % (H, H), "kernel": "bf16x3", "us": 1e3 * ms, "live_gflop": w["live_flops"] / 1e9,
+                               "live_tflops": tf_, "frac": tf_ / PEAK_F32_MFMA_TFLOPS})
+            for gl in range(args.depth_ar + 1) if not L["one"] else ():
                 cout = args.n_h if gl < args.depth_ar else 2 * args.n_z
                 name = "masked conv %d->%d%s" % (cin, cout, " (mean,logsd pair + affine/log-det epilogue)" if gl == args.depth_ar else "")
                 w = st.layer_work(gl, args.batch, H, H)
@@ -989,6 +1018,8 @@ def main():
 
     st0 = prof[0]["stack"]
     lw = st0.layer_work(dom_layer, args.batch, 16, 16)
+    if one16:                        # the launch is the whole step: its live flops and the step's algorithmic bytes
+        lw = st0.step_work(args.batch, 16, 16)
     if fused16:                      # the launch also computes the first masked conv (on tile + halo): count its useful work once
         lw0 = st0.layer_work(0, args.batch, 16, 16)
         lw = {"live_flops": lw["live_flops"] + lw0["live_flops"], "dense_flops": lw["dense_flops"] + lw0["dense_flops"],
@@ -1003,7 +1034,7 @@ def main():
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    dom_kernel = st0.layer_precision(dom_layer, args.batch, 16, 16)
+    dom_kernel = "bf16x3" if one16 else st0.layer_precision(dom_layer, args.batch, 16, 16)
     roofline = {
         # yardstick = the dense fp32 MFMA peak, for both kernel families: the path computes fp32 products with fp32
         # accumulation (dtype f32) and this is the peak the exact-fp32 kernel -- and round 1 -- are priced against.  The
@@ -1014,13 +1045,16 @@ def main():
         "dominant_kernel_family": dom_kernel,
         "frac_of_bf16x3_peak": (achieved / PEAK_BF16X3_TFLOPS) if dom_kernel == "bf16x3" else None,
         "peak_bf16x3": PEAK_BF16X3_TFLOPS,
-        "kernel": ("iaf_conv_bf3_kernel<IN_FUSED0> (masked 3x3 convs %d->%d and %d->%d in ONE launch, B=%d 16x16)" % (args.n_z, args.n_h, args.n_h, args.n_h, args.batch)) if fused16 else
+        "kernel": ("iaf_step_fused_kernel (one IAF step = masked 3x3 convs %d->%d%s->%d + affine/log-det in ONE launch, B=%d 16x16)"
+                   % (args.n_z, args.n_h, "->%d" % args.n_h if args.depth_ar > 1 else "", 2 * args.n_z, args.batch)) if one16 else
+                  ("iaf_conv_bf3_kernel<IN_FUSED0> (masked 3x3 convs %d->%d and %d->%d in ONE launch, B=%d 16x16)" % (args.n_z, args.n_h, args.n_h, args.n_h, args.batch)) if fused16 else
                   "%s (masked 3x3 conv %d->%d, B=%d 16x16, GEMM layer %d)" % ("iaf_conv_bf3_kernel" if dom_kernel == "bf16x3" else "iaf_conv_kernel", args.n_h, args.n_h, args.batch, dom_layer),
         "avg_launch_us": 1e3 * k_avg_ms, "launches_timed": 50 * len(kbatch),
         "timing": "HIP events on the launch stream around 50 back-to-back launches per 16x16 layer (includes the "
                   "inter-launch gap); per-launch event brackets inside full steps read %.2f us over %d launches "
                   "(adds event/dispatch latency)" % (1e3 * k_brk_ms, len(kms)),
         "flops_per_launch_live": lw["live_flops"], "flops_per_launch_dense9tap": lw["dense_flops"],
+        "halo_recompute": _halo_note(st0, prof[0]["one"], args) if one16 else None,
         "bytes_per_launch": lw["bytes"],
         "hbm_frac_at_this_rate": (lw["bytes"] / (k_avg_ms * 1e-3) / 1e9) / PEAK_HBM_GBS,
     }

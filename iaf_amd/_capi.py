@@ -74,6 +74,8 @@ SIGNATURES = {
     "iaf_stack_get_precision": (ctypes.c_int, [_vp] + [ctypes.c_int] * 4),
     "iaf_stack_set_tuning_bf3": (ctypes.c_int, [_vp] + [ctypes.c_int] * 6),
     "iaf_stack_set_fuse_first": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "iaf_stack_set_fuse_step": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "iaf_stack_step_is_fused": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "iaf_stack_autotune": (ctypes.c_int, [_vp, _c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int,
                                           ctypes.c_int, _vp, ctypes.c_size_t, ctypes.c_int, _vp, ctypes.POINTER(ctypes.c_int),
                                           ctypes.POINTER(ctypes.c_float)]),

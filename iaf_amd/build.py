@@ -34,6 +34,10 @@ def _units():
     for ppw, pxt, ks, wco in BF3_SHAPES:
         units.append((os.path.join(CSRC, "iaf_conv_bf3_inst.hip"), os.path.join(OBJDIR, "iaf_bf3_%d_%d_%d_%d.o" % (ppw, pxt, ks, wco)),
                       ["-DIAF_PPW=%d" % ppw, "-DIAF_PXT=%d" % pxt, "-DIAF_KS=%d" % ks, "-DIAF_WCO=%d" % wco]))
+    # accumulators in architectural VGPRs: left to itself the register allocator puts them in AGPRs and rotates them through
+    # VGPR copies inside the K loop (48 v_accvgpr moves per 162 MFMAs)
+    units.append((os.path.join(CSRC, "iaf_step_fused_inst.hip"), os.path.join(OBJDIR, "iaf_step_fused.o"),
+                  ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]))
     return units
 
 

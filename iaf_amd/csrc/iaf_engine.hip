@@ -51,6 +51,7 @@
 #define IAF_ABI_VERSION 2   // 2: + iaf_conv3x3_*
 #define MAX_GEMM_LAYERS 10   // depth_ar <= 9 hidden + 1 output pair
 
+#include "iaf_step_fused_types.hpp"
 #include "iaf_kernels_prep.hpp"
 #include "iaf_kernels_misc.hpp"
 #include "iaf_kernels_backward.hpp"
@@ -98,6 +99,7 @@ struct iaf_stack {
     int precision = IAF_PRECISION_BF16X3;   // forward convs: bf16x3 split products on the bf16 MFMA, or the exact fp32 MFMA
     int fuse_first = 2;       // first masked conv fused into the second one's kernel: 0 never, 1 whenever possible, 2 only where
                               // iaf_stack_autotune measured it faster (on MI355X at the BASELINE sizes it is not: DESIGN.md 4.8)
+    int fuse_step = 1;        // the whole step as ONE launch (iaf_step_fused.hpp) where a compiled geometry covers it: 0 never, 1 yes
     bool prepared;
     size_t weight_bytes;  // raw V/g/b bytes of the stack (for the algorithmic byte count)
     // optional per-launch event timing of one layer
@@ -296,7 +298,7 @@ extern "C" int iaf_stack_set_debug(iaf_stack_t* s, int layer, void* buf) {
 extern "C" int iaf_stack_profile_enable(iaf_stack_t* s, int layer, int max_samples) {
     if (!s) return IAF_ERR_NULL;
     prof_free(s);
-    if (layer < 0) return IAF_OK;
+    if (layer < 0 && layer != -2) return IAF_OK;       // -2: the one-launch step (iaf_step_fused.hpp)
     if (layer >= s->nlayers || max_samples <= 0 || max_samples > (1 << 20)) return IAF_ERR_SHAPE;
     s->prof_start = (hipEvent_t*)calloc(max_samples, sizeof(hipEvent_t));
     s->prof_stop = (hipEvent_t*)calloc(max_samples, sizeof(hipEvent_t));
@@ -811,9 +813,53 @@ static int run_stack_generic(iaf_stack_t* s, const ConvP& base, int first_inmode
     return (int)hipGetLastError();
 }
 
+// The whole step in one launch (iaf_step_fused.hpp): TF statement, bf16x3 precision, a compiled geometry for (n_h, n_z,
+// depth_ar, W) -- everything else takes the layer-by-layer path.  Output rows per workgroup: 2 at 16 pixels per row; at 8,
+// one row while that still leaves fewer than two workgroups per CU (less halo recompute per row otherwise).
+static step_fn_t fused_step_plan(const iaf_stack_t* s, int B, int H, int W, int* R, size_t* lds) {
+    static const int env = getenv("IAF_FUSE_STEP") ? atoi(getenv("IAF_FUSE_STEP")) : -1;       // dev knob: 0 / 1
+    const int mode = env >= 0 ? env : s->fuse_step;
+    if (!mode || s->generic || s->variant != IAF_VARIANT_TF || s->precision != IAF_PRECISION_BF16X3) return nullptr;
+    if (s->depth_ar < 1 || s->depth_ar > 2 || (s->n_h & 15) || (s->n_z & 15)) return nullptr;
+    if (s->fuse_first == 1) return nullptr;                  // the caller asked for the layer-by-layer variant with a fused first conv
+    for (int l = 0; l < s->nlayers; ++l)                      // ... or pinned a per-layer launch shape: the layer-by-layer path is meant
+        if (!s->L[l].wp3 || s->L[l].user_tuned || s->L[l].b_user_tuned) return nullptr;
+    static const int forceR = getenv("IAF_FUSE_STEP_R") ? atoi(getenv("IAF_FUSE_STEP_R")) : 0;  // dev knob
+    *R = forceR ? forceR : (W == 16 ? 2 : ((long long)B * H >= 1024 ? 2 : 1));
+    step_fn_t fn = iaf_pick_step_fused(s->n_h / 16, s->n_z / 16, s->depth_ar, W, *R, lds);
+    if (!fn || *lds > 160 * 1024) return nullptr;
+    return fn;
+}
+
+static int launch_fused_step(iaf_stack_t* s, step_fn_t fn, int R, size_t lds, const ConvP& base, int first_inmode, const float* ctx,
+                             const float* ctx2, hipStream_t st) {
+    StepP q;
+    memset(&q, 0, sizeof(q));
+    q.z = (first_inmode == IN_POSTERIOR) ? nullptr : base.x;
+    q.ctx = ctx; q.ctx2 = ctx2;
+    for (int l = 0; l < s->nlayers; ++l) { q.wp3[l] = s->L[l].wp3; q.bias[l] = s->L[l].bias; }
+    q.zin = base.zin; q.out0 = base.out0; q.out1 = base.out1; q.kl_elem = base.kl_elem;
+    q.qm = base.qm; q.ql = base.ql; q.rm = base.rm; q.rl = base.rl; q.pm = base.pm; q.pl = base.pl; q.eps = base.eps;
+    q.B = base.B; q.H = base.H; q.HW = base.HW; q.mode = base.mode;
+    q.nrb = (base.H + R - 1) / R;
+    q.dbg = (s->dbg_layer == -2) ? s->dbg : nullptr;
+    { int rc = raise_lds_cap((const void*)fn, lds); if (rc) return rc; }
+    const bool prof = (s->prof_layer == -2 && s->prof_n < s->prof_cap);
+    if (prof) HIP_TRY(hipEventRecord(s->prof_start[s->prof_n], st));
+    hipLaunchKernelGGL(fn, dim3(base.B * q.nrb), dim3(256), lds, st, q);
+    if (prof) { HIP_TRY(hipEventRecord(s->prof_stop[s->prof_n], st)); s->prof_n++; }
+    return (int)hipGetLastError();
+}
+
 static int run_stack(iaf_stack_t* s, ConvP base, int first_inmode, const float* ctx, const float* ctx2, const Ws& ws,
                      hipStream_t st) {
     if (s->generic) return run_stack_generic(s, base, first_inmode, ctx, ctx2, ws, st);
+    if (first_inmode == IN_NCHW || first_inmode == IN_POSTERIOR) {
+        int R = 0;
+        size_t lds = 0;
+        if (step_fn_t fn = fused_step_plan(s, base.B, base.H, base.W, &R, &lds))
+            return launch_fused_step(s, fn, R, lds, base, first_inmode, ctx, ctx2, st);
+    }
     Launch ls[MAX_GEMM_LAYERS];
     const int n = build_stack(s, base, first_inmode, ctx, ctx2, ws, ls);
     for (int i = 0; i < n; ++i) {
@@ -830,7 +876,7 @@ extern "C" int iaf_step_time_layer(iaf_stack_t* s, int layer, const float* z, co
     if (rc) return rc;
     if (!z || !z_new || !logsd || !avg_ms || (s->depth_ar > 0 && !context)) return IAF_ERR_NULL;
     // layer = -1: the FUSED launch (first masked conv inside the second one's kernel), if the stack would use it at this size
-    if (layer < -1 || layer >= s->nlayers || reps <= 0) return IAF_ERR_SHAPE;
+    if (layer < -2 || layer >= s->nlayers || reps <= 0) return IAF_ERR_SHAPE;
     if (s->generic) return IAF_ERR_UNSUPPORTED;
     Ws ws;
     if ((rc = carve_ws(s, B, H, W, workspace, workspace_bytes, &ws))) return rc;
@@ -839,6 +885,30 @@ extern "C" int iaf_step_time_layer(iaf_stack_t* s, int layer, const float* z, co
     memset(&p, 0, sizeof(p));
     p.B = B; p.H = H; p.W = W; p.HW = H * W; p.P = B * H * W;
     p.x = z; p.zin = z; p.out0 = z_new; p.out1 = logsd; p.mode = MODE_IAF;
+    if (layer == -2) {                // the whole step as ONE launch (iaf_step_fused.hpp), if the stack runs it that way here
+        int R = 0;
+        size_t lds = 0;
+        step_fn_t fn = fused_step_plan(s, B, H, W, &R, &lds);
+        if (!fn) return IAF_ERR_UNSUPPORTED;
+        if ((rc = launch_fused_step(s, fn, R, lds, p, IN_NCHW, context, nullptr, st))) return rc;
+        hipEvent_t e0, e1;
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        const int saved = s->prof_layer;
+        s->prof_layer = -1;
+        HIP_TRY(hipEventRecord(e0, st));
+        for (int r = 0; r < reps; ++r)
+            if ((rc = launch_fused_step(s, fn, R, lds, p, IN_NCHW, context, nullptr, st))) break;
+        (void)hipEventRecord(e1, st);
+        (void)hipEventSynchronize(e1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        s->prof_layer = saved;
+        *avg_ms = ms / (float)reps;
+        return rc;
+    }
     Launch ls[MAX_GEMM_LAYERS];
     int n = build_stack(s, p, IN_NCHW, context, nullptr, ws, ls, false);      // single layers are timed unfused
     for (int i = 0; i < n; ++i)                      // one full step: every layer's input is valid scratch afterwards
@@ -946,6 +1016,20 @@ extern "C" int iaf_stack_autotune(iaf_stack_t* s, const float* z, const float* c
         if (L1.fz_on && us) { us[0] = 0.f; us[1] = 1e3f * best; }
     }
     return rc;
+}
+
+extern "C" int iaf_stack_set_fuse_step(iaf_stack_t* s, int mode) {
+    if (!s) return IAF_ERR_NULL;
+    if (mode < 0 || mode > 1) return IAF_ERR_SHAPE;
+    s->fuse_step = mode;
+    return IAF_OK;
+}
+
+extern "C" int iaf_stack_step_is_fused(const iaf_stack_t* s, int B, int H, int W) {
+    if (!s || B <= 0 || H <= 0 || W <= 0) return 0;
+    int R = 0;
+    size_t lds = 0;
+    return fused_step_plan(s, B, H, W, &R, &lds) ? R : 0;
 }
 
 extern "C" int iaf_stack_set_fuse_first(iaf_stack_t* s, int mode) {

@@ -1,0 +1,438 @@
+// iaf_step_fused.hpp -- one IAF step (tf_train.py:69-72: ar_multiconv2d + affine transform + log-det term; with the
+// posterior sample in front and the KL elements behind it: tf_train.py:56-75) as ONE kernel launch.
+//
+// Why: at BASELINE batch sizes a step is depth_ar + 1 dependent launches of 6-18 us each, every one a latency chain
+// (descriptor fetch, first loads, tile staging, split-K exchange, epilogue, the gap to the next launch) that is longer
+// than its arithmetic.  The masked convs only look right and below -- taps (0,0) (0,1) (1,-1) (1,0) (1,1)
+// -- so a workgroup that owns R full-width output rows of one image needs, per layer down the stack, ONE more row of the
+// layer below and no columns beyond the image: it can compute all layers for its rows by itself, with the hidden
+// activations in LDS and no synchronisation with any other workgroup.  Rows needed (depth_ar = D):
+//     z: R+D+1   h_0: R+D   h_1: R+D-1  ...  h_{D-1}: R+1   output: R
+// The halo rows are recomputed by the neighbouring workgroup (R = 2, D = 2: the first layer is computed twice, the second
+// 1.5 times); what is bought with that is one launch per step instead of three, no HBM round trip of the hidden
+// activations, no split-K exchange, and weight / context loads of the next phase in flight during the current one.
+//
+// Arithmetic: the bf16x3 scheme of iaf_conv_bf3.hpp (three bf16 planes per operand, six products, fp32 accumulate) on
+// v_mfma_f32_16x16x32_bf16, reading the same fragment-ordered weight packs (PrepLayer.wp3).
+// LDS: three regions (z, h_even, h_odd) of pixel slots [row][W + 2 columns][plane h/m/l][channels] -- the two extra
+// columns and the rows past the image bottom hold zeros, so tap addressing is pure arithmetic (no validity masks).
+// Work split: 4 waves, one per SIMD.  Hidden layers: wave w owns co tiles w, w+4, ... of every pixel tile (its weight
+// stream is disjoint from the other waves'; the activation fragments come from LDS); the tiles left over when the count is
+// not a multiple of 4 (n_h = 160: tiles 8, 9) are dealt out per (tile, pixel tile) so that every wave multiplies the
+// same number of units.  Output pair (too few tiles to split by tile alone): two tile groups x two halves of the K steps,
+// the partial sums meet in an exchange buffer.
+#pragma once
+#include "iaf_conv_bf3.hpp"
+#include "iaf_step_fused_types.hpp"
+
+template <int NHT, int NZT, int DEPTH, int W, int R>
+struct StepGeom {
+    static constexpr int NZ = 16 * NZT, NH = 16 * NHT;
+    static constexpr int RS = W + 2;                           // slots per row (zero column on either side)
+    static constexpr int Z8 = NZ / 8, Z16 = 3 * Z8 + 2;        // z slot: planes + pad, in 16-byte units (stride = 8 * odd dwords)
+    static constexpr int H8 = NH / 8, H16 = 3 * H8 + 2;
+    static constexpr int RZ = R + DEPTH + 1;
+    static constexpr int rows_h(int l) { return R + DEPTH - l; }
+    static constexpr int ZREG = 0;                                               // region offsets in 16-byte units
+    static constexpr int HREG0 = ZREG + RZ * RS * Z16;
+    static constexpr int HREG1 = HREG0 + rows_h(0) * RS * H16;
+    static constexpr int END = HREG1 + (DEPTH >= 2 ? rows_h(1) * RS * H16 : 0);
+    static constexpr int XB_STRIDE = 2 * NZ + 1;                                 // output exchange buffer [wave 4][pixel][2 n_z] floats
+    // ... over the z and h_0 regions, both dead when the output pair (which reads h_1) is multiplied; behind everything
+    // when there is a single hidden layer (the output pair reads h_0 then)
+    static constexpr int XB_OFF = DEPTH >= 2 ? 0 : END;
+    static constexpr size_t xb_bytes() { return (size_t)4 * R * W * XB_STRIDE * 4; }
+    static constexpr size_t lds_bytes() {
+        const size_t a = (size_t)END * 16, b = (size_t)XB_OFF * 16 + xb_bytes();
+        return a > b ? a : b;
+    }
+};
+
+// pixel tiles [lo, hi) of a phase with NPT tiles that group g of GN wave groups covers with its left-over co tile
+constexpr int fused_extra_mask(int npt, int gn, int g) {
+    const int lo = (g * npt + gn - 1) / gn, hi = ((g + 1) * npt + gn - 1) / gn;
+    int m = 0;
+    for (int q = lo; q < hi; ++q) m |= 1 << q;
+    return m;
+}
+
+template <int NHT, int NZT, int DEPTH, int W, int R>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void iaf_step_fused_kernel(StepP p) {
+    typedef StepGeom<NHT, NZT, DEPTH, W, R> G;
+    static_assert(DEPTH >= 1 && DEPTH <= 2, "hidden regions ping-pong between two LDS buffers holding h_0 and h_1");
+    static_assert((W & (W - 1)) == 0 && W <= 16, "full-width rows of 4, 8 or 16 pixels");
+    extern __shared__ __attribute__((aligned(16))) f32x4 smem4[];
+    char* smem = (char*)smem4;
+    constexpr int NZ = G::NZ, NH = G::NH, RS = G::RS, Z8 = G::Z8, Z16 = G::Z16, H8 = G::H8, H16 = G::H16, RZ = G::RZ;
+    constexpr int NW = 4;                                        // waves
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pl = lane & 15, kk = lane >> 4;
+    const int b = blockIdx.x / p.nrb, r0 = (blockIdx.x - b * p.nrb) * R;
+    const int H = p.H, HW = p.HW;
+#define IAF_FSTAMP(k) do { if (p.dbg && tid == 0) p.dbg[(size_t)blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+    IAF_FSTAMP(0);
+
+    // ---- co tiles of a hidden layer per wave: NFULL rounds of 4 + (NX left-over tiles shared by groups of GN waves) ------
+    constexpr int NFULL = NHT / NW, NX = NHT % NW;
+    constexpr bool XSPLIT = NX > 0 && NW % NX == 0;              // left-over tiles dealt out per (tile, pixel tile)
+    constexpr int GN = XSPLIT ? NW / NX : 1;                     // waves sharing one left-over tile
+    constexpr int NTWH = NFULL + (NX ? 1 : 0);                   // tile slots per wave
+    constexpr int OKS = 2;                                       // output pair: K split in OKS parts, NW / OKS tile groups
+    constexpr int NTWO = 2 * NZT * OKS / NW;                     // tile slots per wave
+    static_assert((2 * NZT * OKS) % NW == 0, "output tiles must split evenly over the wave groups");
+    int htile[NTWH];
+#pragma unroll
+    for (int j = 0; j < NTWH; ++j) htile[j] = (j < NFULL) ? wave + NW * j : (XSPLIT ? NW * NFULL + wave % NX : wave + NW * j);
+    const int xg = XSPLIT ? wave / NX : 0;                       // this wave's group for the left-over tile
+
+    // ---- weight fragments: [step = pair * 5 + tap][co tile][plane][lane][8 bf16] -> ring of U step slots per phase ----
+    constexpr int RD = 2, U = RD + 1;
+    // fragments [LO, HI) of step s (steps past s_end reload its last step; tiles past the layer's are clamped)
+    auto ring_load = [&](auto lo_c, auto hi_c, f32x4 (*dst)[3], const f32x4* wbase, int ncot, const int* tiles, int s_end, int s) {
+        constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+        const int sc = s < s_end ? s : s_end - 1;
+        const f32x4* q = wbase + (size_t)sc * ncot * 3 * 64;
+#pragma unroll
+        for (int f = LO; f < HI; ++f) {
+            const int j = f / 3, pn = f - 3 * j;
+            const int tc = tiles[j] < ncot ? tiles[j] : ncot - 1;
+            dst[j][pn] = q[((size_t)tc * 3 + pn) * 64];
+        }
+    };
+
+    // ---- prologue: z rows first (the first conv cannot start without them), then the first weight steps; zero columns
+    // while both travel; z -> LDS ---------------------------------------------------------------------------------------
+    constexpr int NPT0 = (G::rows_h(0) * W + 15) / 16;
+    constexpr int NPX = RZ * W, NIT = NPX * (NZ / 4), ZU = (NIT + 255) / 256;
+    f32x4 zv[ZU];
+#pragma unroll
+    for (int u = 0; u < ZU; ++u) {
+        const int idx = tid + u * 256;
+        const int ic = idx < NIT ? idx : NIT - 1;
+        const int q = ic / NPX, px = ic - q * NPX;                 // pixel fastest: coalesced along a row
+        const int row = px / W, col = px - row * W;
+        const int rr = r0 + row < H ? r0 + row : H - 1;            // rows past the image: a valid address, zeroed below
+        const size_t gb = ((size_t)b * NZ + 4 * q) * HW + (size_t)rr * W + col;
+        if (p.z) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) zv[u][r] = p.z[gb + (size_t)r * HW];
+        } else {   // z0 = (qm+rm) + exp(ql+rl) * eps   (tf_train.py:57,63; distributions.py:21)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const size_t i = gb + (size_t)r * HW;
+                zv[u][r] = (p.qm[i] + p.rm[i]) + __expf(0.5f * (2.f * (p.ql[i] + p.rl[i]))) * p.eps[i];
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 wr0[U][NTWH][3];
+    const f32x4* wb0 = (const f32x4*)p.wp3[0] + lane;
+    static_for<RD>([&](auto i) {
+        ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWH * 3>{}, wr0[decltype(i)::value], wb0, NHT, htile,
+                  (NZ / 32) * NTAPS, decltype(i)::value);
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        constexpr int ZROWS = RZ, H0ROWS = G::rows_h(0), H1ROWS = DEPTH >= 2 ? G::rows_h(1) : 0;
+        for (int i = tid; i < ZROWS * 2 * Z16; i += 256) {
+            const int rs = i / Z16, u = i - rs * Z16;
+            smem4[G::ZREG + ((rs >> 1) * RS + (rs & 1) * (W + 1)) * Z16 + u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        for (int i = tid; i < (H0ROWS + H1ROWS) * 2 * H16; i += 256) {
+            const int rs = i / H16, u = i - rs * H16;
+            const int row = rs >> 1;
+            const int base = row < H0ROWS ? G::HREG0 + row * RS * H16 : G::HREG1 + (row - H0ROWS) * RS * H16;
+            smem4[base + (rs & 1) * (W + 1) * H16 + u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < ZU; ++u) {
+            const int idx = tid + u * 256;
+            if (idx < NIT) {
+                const int q = idx / NPX, px = idx - q * NPX;
+                const int row = px / W, col = px - row * W;
+                const f32x4 v = r0 + row < H ? zv[u] : f32x4{0.f, 0.f, 0.f, 0.f};
+                bf3_store4(smem + (size_t)G::ZREG * 16, row * RS + col + 1, q, v, Z16, Z8);
+            }
+        }
+    }
+    __syncthreads();
+    IAF_FSTAMP(1);
+
+    // ---- one conv phase: acc[q][j] = sum over steps [s0, nstep) of W[step][tiles[j]] x X[pixel tile q, step] --------------
+    // in_reg / in_s16 / in_c8: the input region (16-byte units); ROWS * W output pixels in NPT tiles.  The LAST tile slot is
+    // multiplied only for the pixel tiles in EMASK (the wave's share of a left-over tile); all others for every pixel tile.
+    auto conv_phase = [&](auto npt_c, auto ntw_c, auto rows_c, auto emask_c, int in_reg, int in_s16, int in_c8, const f32x4* wbase,
+                          int ncot, const int* tiles, int s0, int nstep, f32x4 (*wr)[decltype(ntw_c)::value][3],
+                          f32x4 (*acc_out)[decltype(ntw_c)::value]) {
+        constexpr int NPT = decltype(npt_c)::value, NTW = decltype(ntw_c)::value, ROWS = decltype(rows_c)::value;
+        constexpr int EMASK = decltype(emask_c)::value;
+        f32x4 acc[NPT][NTW];
+        int xb[NPT];
+#pragma unroll
+        for (int q = 0; q < NPT; ++q) {
+            int pix = q * 16 + pl;
+            pix = pix < ROWS * W ? pix : ROWS * W - 1;             // partially filled tile: a valid address, result unused
+            const int row = pix / W, col = pix - row * W;
+            xb[q] = in_reg + (row * RS + col + 1) * in_s16 + kk;
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) acc[q][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        auto xaddr = [&](auto q_c, int s) -> int {
+            const int sc = s < nstep ? s : nstep - 1;
+            const int pair = sc / NTAPS, tap = sc - pair * NTAPS;
+            const int toff = tap < 2 ? tap : RS + tap - 3;          // slots: (0,0) (0,1) (1,-1) (1,0) (1,1)
+            return xb[decltype(q_c)::value] + toff * in_s16 + pair * 4;
+        };
+        f32x4 xn[3];
+        {
+            const int a = xaddr(std::integral_constant<int, 0>{}, s0);
+            xn[0] = smem4[a]; xn[1] = smem4[a + in_c8]; xn[2] = smem4[a + 2 * in_c8];
+        }
+        auto step_body = [&](auto slot_c, int s) {
+            constexpr int I = decltype(slot_c)::value;
+            static_for<NPT>([&](auto q_c) {
+                constexpr int q = decltype(q_c)::value;
+                constexpr int NTQ = ((EMASK >> q) & 1) ? NTW : NTW - 1;      // tile slots multiplied for this pixel tile
+                // this pixel tile's share of the refill of the slot consumed RD steps from now
+                constexpr int LO = (q * NTW * 3) / NPT, HI = ((q + 1) * NTW * 3) / NPT;
+#ifndef IAF_EXP_FUSED_NOREFILL
+                ring_load(std::integral_constant<int, LO>{}, std::integral_constant<int, HI>{}, wr[(I + RD) % U], wbase, ncot, tiles, nstep,
+                          s + RD);
+#endif
+                const bf16x8 xh = __builtin_bit_cast(bf16x8, xn[0]);
+                const bf16x8 xm = __builtin_bit_cast(bf16x8, xn[1]);
+                const bf16x8 xl = __builtin_bit_cast(bf16x8, xn[2]);
+#ifndef IAF_EXP_FUSED_NOLDS
+                {
+                    const int a = (q + 1 < NPT) ? xaddr(std::integral_constant<int, (q + 1) % NPT>{}, s)
+                                                : xaddr(std::integral_constant<int, 0>{}, s + 1);
+                    xn[0] = smem4[a]; xn[1] = smem4[a + in_c8]; xn[2] = smem4[a + 2 * in_c8];
+                }
+#endif
+#define IAF_FPROD(WP, XV)                                                                                         \
+    _Pragma("unroll") for (int j = 0; j < NTQ; ++j)                                                                \
+        acc[q][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wr[I][j][WP]), XV, acc[q][j], 0, 0, 0);
+                IAF_FPROD(2, xh)
+                IAF_FPROD(0, xl)
+                IAF_FPROD(1, xm)
+                IAF_FPROD(1, xh)
+                IAF_FPROD(0, xm)
+                IAF_FPROD(0, xh)
+#undef IAF_FPROD
+                sched_interleave<6 * NTQ, 3, 0, HI - LO>();
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+        int s = s0;                                                  // ring slot of step s: (s - s0) % U
+        for (; s + U <= nstep; s += U)
+            static_for<U>([&](auto i) { step_body(i, s + decltype(i)::value); });
+        const int rem = nstep - s;
+        static_for<U>([&](auto r_c) {
+            constexpr int RR = decltype(r_c)::value;
+            if (RR > 0 && rem == RR) static_for<RR>([&](auto i) { step_body(i, s + decltype(i)::value); });
+        });
+#pragma unroll
+        for (int q = 0; q < NPT; ++q)
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) acc_out[q][j] = acc[q][j];
+    };
+
+    // context operands of the first epilogue (the lane's 4 channels of every unit it owns), issued after the z barrier:
+    // they have the whole first conv to arrive
+    f32x4 cx[NPT0][NTWH];
+    auto load_ctx = [&](auto emask_c) {
+        constexpr int EMASK = decltype(emask_c)::value;
+#pragma unroll
+        for (int q = 0; q < NPT0; ++q) {
+            const int pix = q * 16 + pl, row = pix / W, col = pix - row * W;
+            const bool live = pix < G::rows_h(0) * W && r0 + row < H;
+#pragma unroll
+            for (int j = 0; j < NTWH; ++j) {
+                cx[q][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const bool mine = !(j == NTWH - 1 && !((EMASK >> q) & 1));
+                if (mine && live && htile[j] < NHT && p.ctx) {
+                    const size_t cb = ((size_t)b * NH + htile[j] * 16 + 4 * kk) * HW + (size_t)(r0 + row) * W + col;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) cx[q][j][r] = p.ctx[cb + (size_t)r * HW];
+                    if (p.ctx2) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) cx[q][j][r] += p.ctx2[cb + (size_t)r * HW];
+                    }
+                }
+            }
+        }
+    };
+
+    // hidden epilogue: bias (+ context) + ELU (layers.py:63-64,163-165) -> the three planes of the next region; rows past the
+    // image bottom become the zero rows the layer above pads with
+    auto hidden_epilogue = [&](auto npt_c, auto rows_c, auto emask_c, auto ctx_c, f32x4 (*acc)[NTWH], const float* bias, int out_reg) {
+        constexpr int NPT = decltype(npt_c)::value, ROWS = decltype(rows_c)::value, EMASK = decltype(emask_c)::value;
+        constexpr bool WITH_CTX = decltype(ctx_c)::value != 0;
+#pragma unroll
+        for (int j = 0; j < NTWH; ++j) {
+            if (htile[j] >= NHT) continue;
+            const f32x4 bi = *(const f32x4*)(bias + htile[j] * 16 + 4 * kk);
+#pragma unroll
+            for (int q = 0; q < NPT; ++q) {
+                if (j == NTWH - 1 && !((EMASK >> q) & 1)) continue;
+                const int pix = q * 16 + pl;
+                if (pix >= ROWS * W) continue;
+                const int row = pix / W, col = pix - row * W;
+                f32x4 v = acc[q][j] + bi;
+                if constexpr (WITH_CTX) v += cx[q < NPT0 ? q : 0][j];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = elu_f(v[r]);
+                if (r0 + row >= H) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                bf3_store4(smem + (size_t)out_reg * 16, row * RS + col + 1, htile[j] * 4 + kk, v, H16, H8);
+            }
+        }
+    };
+
+    // ---- hidden layers ---------------------------------------------------------------------------------------------
+    constexpr int NSTEP_H = (NH / 32) * NTAPS;
+    const int okh = wave % OKS;                                  // this wave's K part / tile group of the output pair
+    const int so0 = (okh * NSTEP_H) / OKS, so1 = ((okh + 1) * NSTEP_H) / OKS;
+    int otile[NTWO];
+#pragma unroll
+    for (int j = 0; j < NTWO; ++j) otile[j] = (wave / OKS) * NTWO + j;
+    f32x4 wr1[U][NTWH][3];           // ring of the second hidden layer (DEPTH == 2)
+    f32x4 wro[U][NTWO][3];           // ring of the output pair
+    const f32x4* wbo = (const f32x4*)p.wp3[DEPTH] + lane;
+    auto preload_out = [&]() {
+        static_for<RD>([&](auto i) {
+            ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWO * 3>{}, wro[decltype(i)::value], wbo, 2 * NZT,
+                      otile, so1, so0 + decltype(i)::value);
+        });
+    };
+    // every wave group runs its own instantiation of a hidden phase (the left-over tile's pixel tiles are compile time)
+    static_for<GN>([&](auto g_c) {
+        constexpr int GI = decltype(g_c)::value;
+        if (xg != GI) return;
+        constexpr int EM0 = (NX == 0 || !XSPLIT) ? (1 << NPT0) - 1 : fused_extra_mask(NPT0, GN, GI);
+        load_ctx(std::integral_constant<int, EM0>{});
+        f32x4 acc0[NPT0][NTWH];
+        conv_phase(std::integral_constant<int, NPT0>{}, std::integral_constant<int, NTWH>{}, std::integral_constant<int, G::rows_h(0)>{},
+                   std::integral_constant<int, EM0>{}, G::ZREG, Z16, Z8, wb0, NHT, htile, 0, (NZ / 32) * NTAPS, wr0, acc0);
+        // the next phase's first weight steps travel while this phase's epilogue runs
+        if constexpr (DEPTH >= 2) {
+            const f32x4* wb1 = (const f32x4*)p.wp3[1] + lane;
+            static_for<RD>([&](auto i) {
+                ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWH * 3>{}, wr1[decltype(i)::value], wb1, NHT,
+                          htile, NSTEP_H, decltype(i)::value);
+            });
+        } else {
+            preload_out();
+        }
+        hidden_epilogue(std::integral_constant<int, NPT0>{}, std::integral_constant<int, G::rows_h(0)>{},
+                        std::integral_constant<int, EM0>{}, std::integral_constant<int, 1>{}, acc0, p.bias[0], G::HREG0);
+    });
+    __syncthreads();
+    IAF_FSTAMP(2);
+    if constexpr (DEPTH >= 2) {
+        constexpr int NPT1 = (G::rows_h(1) * W + 15) / 16;
+        static_for<GN>([&](auto g_c) {
+            constexpr int GI = decltype(g_c)::value;
+            if (xg != GI) return;
+            constexpr int EM1 = (NX == 0 || !XSPLIT) ? (1 << NPT1) - 1 : fused_extra_mask(NPT1, GN, GI);
+            f32x4 acc1[NPT1][NTWH];
+            const f32x4* wb1 = (const f32x4*)p.wp3[1] + lane;
+            conv_phase(std::integral_constant<int, NPT1>{}, std::integral_constant<int, NTWH>{}, std::integral_constant<int, G::rows_h(1)>{},
+                       std::integral_constant<int, EM1>{}, G::HREG0, H16, H8, wb1, NHT, htile, 0, NSTEP_H, wr1, acc1);
+            preload_out();
+            hidden_epilogue(std::integral_constant<int, NPT1>{}, std::integral_constant<int, G::rows_h(1)>{},
+                            std::integral_constant<int, EM1>{}, std::integral_constant<int, 0>{}, acc1, p.bias[1], G::HREG1);
+        });
+        __syncthreads();
+    }
+    IAF_FSTAMP(3);
+
+    // ---- output pair: packed tiles (m_0, s_0, m_1, s_1, ...), partial sums -> exchange buffer [K part][pixel][2 n_z] -------
+    // (the operands of the final transform are fetched first: they travel while the output pair is multiplied)
+    constexpr int NPTO = (R * W + 15) / 16;
+    constexpr int NEL = (NZ * R * W + 255) / 256;
+    float fz[NEL], fq[NEL][6];
+    float fb[NEL][2];
+#pragma unroll
+    for (int e = 0; e < NEL; ++e) {
+        const int idx = tid + e * 256;
+        const int ic = idx < NZ * R * W ? idx : NZ * R * W - 1;
+        const int c = ic / (R * W), pix = ic - c * (R * W);
+        const int rr = r0 + pix / W < H ? r0 + pix / W : H - 1;
+        const size_t gi = ((size_t)b * NZ + c) * HW + (size_t)rr * W + (pix & (W - 1));
+        const int cm = (c >> 4) * 32 + (c & 15);
+        fb[e][0] = p.bias[DEPTH][cm]; fb[e][1] = p.bias[DEPTH][cm + 16];
+        fz[e] = 0.f;
+        if (p.mode == MODE_IAF || p.mode == MODE_INVERSE) fz[e] = p.zin[gi];
+        if (p.mode == MODE_POSTERIOR) {
+            fq[e][0] = p.qm[gi] + p.rm[gi]; fq[e][1] = p.ql[gi] + p.rl[gi]; fq[e][2] = p.eps[gi];
+            fq[e][3] = p.pm[gi]; fq[e][4] = p.pl[gi];
+        }
+    }
+    float* xbuf = (float*)(smem + (size_t)G::XB_OFF * 16);
+    {
+        f32x4 acco[NPTO][NTWO];
+        conv_phase(std::integral_constant<int, NPTO>{}, std::integral_constant<int, NTWO>{}, std::integral_constant<int, R>{},
+                   std::integral_constant<int, (1 << NPTO) - 1>{}, DEPTH >= 2 ? G::HREG1 : G::HREG0, H16, H8, wbo, 2 * NZT, otile, so0,
+                   so1, wro, acco);
+        IAF_FSTAMP(4);
+        float* mine = xbuf + (size_t)okh * (R * W * G::XB_STRIDE);
+#pragma unroll
+        for (int j = 0; j < NTWO; ++j)
+#pragma unroll
+            for (int q = 0; q < NPTO; ++q) {
+                const int pix = q * 16 + pl;
+                if (pix >= R * W) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mine[pix * G::XB_STRIDE + otile[j] * 16 + 4 * kk + r] = acco[q][j][r];
+            }
+    }
+    __syncthreads();
+
+    // ---- affine transform, log-det term, KL elements (tf_train.py:56-75), NCHW stores coalesced along the rows -------
+#pragma unroll
+    for (int e = 0; e < NEL; ++e) {
+        const int idx = tid + e * 256;
+        if (idx >= NZ * R * W) continue;
+        const int c = idx / (R * W), pix = idx - c * (R * W);
+        const int row = pix / W;
+        if (r0 + row >= H) continue;
+        const size_t gi = ((size_t)b * NZ + c) * HW + (size_t)r0 * W + pix;
+        const int cm = (c >> 4) * 32 + (c & 15);
+        float m_raw = fb[e][0], s_raw = fb[e][1];
+#pragma unroll
+        for (int k = 0; k < OKS; ++k) {
+            m_raw += xbuf[k * (R * W * G::XB_STRIDE) + pix * G::XB_STRIDE + cm];
+            s_raw += xbuf[k * (R * W * G::XB_STRIDE) + pix * G::XB_STRIDE + cm + 16];
+        }
+        if (p.mode == MODE_RAW) {
+            p.out0[gi] = m_raw;
+            p.out1[gi] = s_raw;
+        } else if (p.mode == MODE_IAF) {
+            const float m = m_raw * 0.1f, s = s_raw * 0.1f;        // tf_train.py:70
+            p.out0[gi] = (fz[e] - m) / __expf(s);                  // tf_train.py:71
+            p.out1[gi] = s;                                        // tf_train.py:72
+        } else if (p.mode == MODE_INVERSE) {
+            const float m = m_raw * 0.1f, s = s_raw * 0.1f;
+            p.out0[gi] = fz[e] * __expf(s) + m;
+            p.out1[gi] = s;
+        } else {
+            const float m = m_raw * 0.1f, s = s_raw * 0.1f;
+            const float mean = fq[e][0];                            // tf_train.py:57
+            const float logvar = 2.f * fq[e][1];
+            const float z0 = mean + __expf(0.5f * logvar) * fq[e][2];                             // :63
+            const float d0 = z0 - mean;
+            float logqs = -0.5f * (1.8378770664093453f + logvar + d0 * d0 / __expf(logvar));     // :68
+            const float zz = (z0 - m) / __expf(s);                                                // :71
+            logqs += s;                                                                           // :72
+            const float plv = 2.f * fq[e][4];                                                     // :56
+            const float d1 = zz - fq[e][3];
+            const float logps = -0.5f * (1.8378770664093453f + plv + d1 * d1 / __expf(plv));      // :73
+            p.out0[gi] = zz;
+            if (p.out1) p.out1[gi] = s;
+            p.kl_elem[gi] = logqs - logps;                                                        // :75
+        }
+    }
+    IAF_FSTAMP(5);
+#undef IAF_FSTAMP
+}

@@ -1,0 +1,27 @@
+// iaf_step_fused_inst.hip -- instantiations of the one-launch IAF step (iaf_step_fused.hpp) for the geometries the
+// BASELINE configs use: n_h = 160 / n_z = 32 / depth_ar = 2 (configs 1-2, 5: README run) and n_h = 64 / depth_ar = 1
+// (config 0), images 16 and 8 pixels wide.  Built as its own translation unit by iaf_amd/build.py.
+#include "iaf_step_fused.hpp"
+
+template <int NHT, int NZT, int DEPTH, int W, int R>
+static step_fn_t inst(size_t* lds) {
+    typedef StepGeom<NHT, NZT, DEPTH, W, R> G;
+    static_assert(DEPTH < 2 || G::xb_bytes() <= (size_t)G::HREG1 * 16, "the exchange buffer must fit the z + h_0 regions");
+    *lds = G::lds_bytes();
+    return iaf_step_fused_kernel<NHT, NZT, DEPTH, W, R>;
+}
+
+extern "C" step_fn_t iaf_pick_step_fused(int nht, int nzt, int depth, int W, int R, size_t* lds) {
+    *lds = 0;
+    if (nht == 10 && nzt == 2 && depth == 2) {
+        if (W == 16 && R == 2) return inst<10, 2, 2, 16, 2>(lds);
+        if (W == 8 && R == 1) return inst<10, 2, 2, 8, 1>(lds);
+        if (W == 8 && R == 2) return inst<10, 2, 2, 8, 2>(lds);
+    }
+    if (nht == 4 && nzt == 2 && depth == 1) {
+        if (W == 16 && R == 2) return inst<4, 2, 1, 16, 2>(lds);
+        if (W == 8 && R == 1) return inst<4, 2, 1, 8, 1>(lds);
+        if (W == 8 && R == 2) return inst<4, 2, 1, 8, 2>(lds);
+    }
+    return nullptr;
+}

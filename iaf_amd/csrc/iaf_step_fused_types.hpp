@@ -1,0 +1,21 @@
+// iaf_step_fused_types.hpp -- launch descriptor of the one-launch IAF step (iaf_step_fused.hpp), shared with the host code.
+#pragma once
+
+struct StepP {
+    const float* z;            // [B][n_z][H][W]; NULL: the posterior sample (qm + rm) + exp(ql + rl) * eps
+    const float* ctx;          // [B][n_h][H][W] context added after the first conv (layers.py:163-164)
+    const float* ctx2;         // optional second context (up_context + down_context, tf_train.py:58)
+    const void* wp3[4];        // bf16x3 packs of the D hidden convs and the output pair
+    const float* bias[4];
+    const float* zin;          // MODE_IAF / MODE_INVERSE: the z of the affine transform
+    float* out0;
+    float* out1;
+    float* kl_elem;
+    const float* qm; const float* ql; const float* rm; const float* rl; const float* pm; const float* pl; const float* eps;
+    int B, H, HW, mode, nrb;   // nrb = ceil(H / R) row blocks per image
+    unsigned long long* dbg;   // dev tool: per-workgroup cycle stamps [grid][8]
+};
+
+typedef void (*step_fn_t)(StepP);
+// kernel + dynamic LDS bytes for (n_h / 16, n_z / 16, depth_ar, image width, output rows per workgroup), or NULL
+extern "C" step_fn_t iaf_pick_step_fused(int nht, int nzt, int depth, int W, int R, size_t* lds);

@@ -260,6 +260,16 @@ class ARStack(object):
         code = {"never": 0, "always": 1, "auto": 2}.get(mode, mode)
         _capi.check(_capi.lib().iaf_stack_set_fuse_first(self._h, int(code)))
 
+    def set_fuse_step(self, mode):
+        """the whole IAF step as ONE launch where a compiled geometry covers it: "auto" (default) | "never".
+        See include/iaf_hip.h."""
+        code = {"never": 0, "auto": 1}.get(mode, mode)
+        _capi.check(_capi.lib().iaf_stack_set_fuse_step(self._h, int(code)))
+
+    def step_is_fused(self, B, H, W):
+        """rows per workgroup of the one-launch step at this size, 0 if the step runs layer by layer"""
+        return int(_capi.lib().iaf_stack_step_is_fused(self._h, int(B), int(H), int(W)))
+
     def set_tuning_bf3(self, layer, nt, ppw, pxt, ks, wco=1):
         _capi.check(_capi.lib().iaf_stack_set_tuning_bf3(self._h, layer, nt, ppw, pxt, ks, wco))
 

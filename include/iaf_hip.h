@@ -244,6 +244,16 @@ int iaf_stack_set_tuning_bf3(iaf_stack_t* s, int layer, int nt, int ppw, int pxt
  * path's bit for bit (the same products in the same order).  In iaf_stack_autotune's report a fused pair shows as
  * chosen[0] = -1 and chosen[1] = the fused kernel's shape. */
 int iaf_stack_set_fuse_first(iaf_stack_t* s, int mode);
+/* The whole IAF step (tf_train.py:69-72, or the posterior block's tf_train.py:56-75) as ONE launch: a workgroup owns R
+ * full-width rows of one image and computes every masked conv of the stack for them, hidden activations in LDS, the
+ * halo rows recomputed (the masked convs look only right and below, so no other workgroup is involved).  mode 1 (default):
+ * wherever a compiled geometry covers the problem -- TF statement, bf16x3 precision, (n_h, n_z, depth_ar) = (160, 32, 2)
+ * or (64, 32, 1), images 16 or 8 pixels wide; everything else, and any stack with a pinned per-layer launch shape
+ * (iaf_stack_set_tuning*, fuse_first = 1), takes the layer-by-layer path.  mode 0: never.  Same arithmetic as the
+ * layer-by-layer bf16x3 kernels in a different summation order: results agree to fp32 round-off, not bit for bit.
+ * iaf_stack_step_is_fused: rows per workgroup the step would run with at this size, 0 if it would not run fused. */
+int iaf_stack_set_fuse_step(iaf_stack_t* s, int mode);
+int iaf_stack_step_is_fused(const iaf_stack_t* s, int B, int H, int W);
 int iaf_stack_autotune(iaf_stack_t* s, const float* z, const float* context, float* z_new, float* logsd, int B, int H, int W,
                        void* workspace, size_t workspace_bytes, int reps, void* stream, int* chosen, float* us);
 /* Per-kernel timing with HIP events on the launch stream: every launch of GEMM layer `layer` is
@@ -255,7 +265,9 @@ int iaf_stack_profile_read(iaf_stack_t* s, float* ms_out, int capacity, int* n_o
 /* Roofline timing: runs one full iaf_step (so every layer has valid inputs), then launches GEMM layer `layer`
  * `reps` times back to back between ONE pair of HIP events on `stream`; *avg_ms = elapsed / reps (includes the
  * ~1 us inter-launch gap, excludes event/dispatch latency).  Synchronises the stream.  layer = -1 times the FUSED launch
- * (layers 0+1 in one kernel, iaf_stack_set_fuse_first) or returns IAF_ERR_UNSUPPORTED if the stack would not fuse here. */
+ * (layers 0+1 in one kernel, iaf_stack_set_fuse_first), layer = -2 the whole step as one launch (iaf_stack_set_fuse_step);
+ * IAF_ERR_UNSUPPORTED if the stack would not run that way here.  iaf_stack_profile_enable(layer = -2) brackets the
+ * one-launch step the same way. */
 int iaf_step_time_layer(iaf_stack_t* s, int layer, const float* z, const float* context, float* z_new, float* logsd,
                         int B, int H, int W, void* workspace, size_t workspace_bytes, int reps, void* stream,
                         float* avg_ms);

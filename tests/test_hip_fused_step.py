@@ -1,0 +1,188 @@
+"""The one-launch IAF step (iaf_amd/csrc/iaf_step_fused.hpp: every masked conv of the stack + the affine transform /
+log-det term / KL elements in ONE kernel, a workgroup per R full-width image rows, hidden activations in LDS, halo rows
+recomputed) against the fp64 oracle and against the layer-by-layer kernels it replaces at the BASELINE sizes.
+
+Every other GPU parity test that builds an ARStack(32, [160, 160]) or (32, [64]) on 16- or 8-pixel-wide images already
+runs this kernel (it is the default there); this file pins down (a) WHERE it runs and where it steps aside, (b) all
+four epilogue modes against the oracle incl. image heights that are not a multiple of the rows per workgroup and the
+posterior-sample input, (c) agreement with the layer-by-layer path to fp32 round-off, (d) that a sample's result does not
+depend on its batch and that the autoregressive structure is bit-exact (tf_train.py:69-72 is only a valid flow if
+z_new[i] depends on z[<i] alone)."""
+import numpy as np
+import pytest
+import torch
+
+import golden_inputs as gi
+from oracle import iaf_oracle as O
+
+pytestmark = pytest.mark.gpu
+ATOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def amd():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU")
+    import iaf_amd
+    iaf_amd._capi.lib()
+    return iaf_amd
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def host(t):
+    torch.cuda.synchronize()
+    return t.detach().cpu().numpy().astype(np.float64)
+
+
+def f32(a):
+    return np.asarray(a, dtype=np.float32).astype(np.float64)
+
+
+def _case(seed, B, n_z, n_h, d, H, W):
+    rng = np.random.RandomState(seed)
+    params = gi.ar_multiconv2d_params(rng, n_z, [n_h] * d, [n_z, n_z])
+    return params, rng.standard_normal((B, n_z, H, W)), rng.standard_normal((B, n_h, H, W))
+
+
+def test_where_the_step_runs_as_one_launch(amd):
+    st = amd.ARStack(32, [160, 160])
+    assert st.step_is_fused(32, 16, 16) == 2 and st.step_is_fused(32, 8, 8) == 1 and st.step_is_fused(256, 8, 8) == 2
+    assert st.step_is_fused(3, 5, 16) == 2                       # any height, any batch
+    assert st.step_is_fused(32, 4, 4) == 0                       # no compiled geometry for 4-pixel rows
+    assert amd.ARStack(32, [64]).step_is_fused(16, 16, 16) == 2   # BASELINE configs[0]
+    assert amd.ARStack(64, [192] * 4).step_is_fused(32, 16, 16) == 0
+    assert amd.ARStack(32, [160, 160], variant="theano").step_is_fused(32, 16, 16) == 0
+    st.set_fuse_step("never")
+    assert st.step_is_fused(32, 16, 16) == 0
+    st.set_fuse_step("auto")
+    st.set_precision("f32")                                       # the one-launch step is bf16x3 arithmetic
+    assert st.step_is_fused(32, 16, 16) == 0
+    st.set_precision("bf16x3")
+    st.set_tuning_bf3(1, 5, 2, 1, 4)                              # a pinned per-layer shape means the layer-by-layer path
+    assert st.step_is_fused(32, 16, 16) == 0
+    params, z, ctx = _case(1, 2, 32, 160, 2, 4, 4)
+    st2 = amd.ARStack(32, [160, 160])
+    st2.prepare({k: dev(v) for k, v in params.items()})
+    with pytest.raises(amd.UnsupportedError):
+        st2.time_layer(-2, dev(z), dev(ctx), reps=2)
+
+
+@pytest.mark.parametrize("cfg", [(32, 32, 160, 2, 16, 16), (32, 32, 160, 2, 8, 8), (5, 32, 160, 2, 5, 16), (3, 32, 160, 2, 3, 8),
+                                 (1, 32, 160, 2, 1, 16), (2, 32, 160, 2, 7, 8), (256, 32, 160, 2, 8, 8), (16, 32, 64, 1, 16, 16),
+                                 (16, 32, 64, 1, 8, 8), (4, 32, 64, 1, 3, 16)], ids=lambda s: "B%d_z%d_h%d_d%d_%dx%d" % s)
+def test_iaf_step_and_raw_outputs_vs_oracle(amd, cfg):
+    """tf_train.py:69-72 and layers.py:158-166 through the one-launch step; heights that are not a multiple of the rows
+    per workgroup, single rows, one sample"""
+    B, n_z, n_h, d, H, W = cfg
+    params, z, ctx = _case(300 + H + W + d, *cfg)
+    st = amd.ARStack(n_z, [n_h] * d)
+    assert st.step_is_fused(B, H, W) > 0
+    st.prepare({k: dev(v) for k, v in params.items()})
+    zd, cd = dev(z), dev(ctx)
+    z_new, logsd = st.iaf_step(zd, cd)
+    m_raw, s_raw = st.ar_multiconv2d(zd, cd)
+    p32 = {k: f32(v) for k, v in params.items()}
+    chunk = 32
+    for b0 in range(0, B, chunk):
+        sl = slice(b0, min(B, b0 + chunk))
+        ez, es = O.iaf_step(f32(z[sl]), f32(ctx[sl]), p32, [n_h] * d)
+        np.testing.assert_allclose(host(logsd[sl]), es, atol=ATOL, rtol=0)
+        np.testing.assert_allclose(host(z_new[sl]), ez, atol=ATOL, rtol=0)
+        assert np.abs(host(logsd[sl]) - es).max() < 1e-5          # fp32-grade, not just inside the tolerance
+        em, esr = O.ar_multiconv2d(f32(z[sl]), f32(ctx[sl]), p32, [n_h] * d, [n_z, n_z])
+        np.testing.assert_allclose(host(m_raw[sl]), em, atol=ATOL, rtol=0)
+        np.testing.assert_allclose(host(s_raw[sl]), esr, atol=ATOL, rtol=0)
+    assert st.time_layer(-2, zd, cd, reps=2) > 0
+
+
+@pytest.mark.parametrize("kl_min", [0.0, 0.25])
+@pytest.mark.parametrize("cfg", [(8, 32, 160, 2, 16, 16), (5, 32, 160, 2, 8, 8), (3, 32, 160, 2, 5, 16), (4, 32, 64, 1, 8, 8)],
+                         ids=lambda s: "B%d_z%d_h%d_d%d_%dx%d" % s)
+def test_posterior_block_vs_oracle(amd, cfg, kl_min):
+    """the extended unit (tf_train.py:56-85): posterior sample computed in the staging, two contexts, KL elements and free
+    bits behind the same launch"""
+    B, n_z, n_h, d, H, W = cfg
+    rng = np.random.RandomState(77 + H)
+    params = gi.ar_multiconv2d_params(rng, n_z, [n_h] * d, [n_z, n_z])
+    f = lambda c: rng.standard_normal((B, c, H, W))
+    qm, ql, rm, rl, pm, pl = f(n_z), 0.25 * f(n_z), f(n_z), 0.25 * f(n_z), f(n_z), 0.25 * f(n_z)
+    uc, dc, eps = f(n_h), f(n_h), f(n_z)
+    st = amd.ARStack(n_z, [n_h] * d)
+    assert st.step_is_fused(B, H, W) > 0
+    st.prepare({k: dev(v) for k, v in params.items()})
+    out = st.posterior_block(dev(qm), dev(ql), dev(rm), dev(rl), dev(pm), dev(pl), dev(uc), dev(dc), dev(eps), kl_min,
+                             want_kl_elem=True)
+    e = O.posterior_block(f32(qm), f32(ql), f32(rm), f32(rl), f32(pm), f32(pl), f32(uc), f32(dc), f32(eps),
+                          {k: f32(v) for k, v in params.items()}, [n_h] * d, kl_min)
+    np.testing.assert_allclose(host(out["z"]), e["z"], atol=ATOL, rtol=0)
+    np.testing.assert_allclose(host(out["kl_elem"]), e["logqs"] - e["logps"], atol=ATOL, rtol=1e-5)
+    np.testing.assert_allclose(host(out["kl_cost"]), e["kl_cost"], atol=2e-3, rtol=1e-4)
+    np.testing.assert_allclose(host(out["kl_obj"]), e["kl_obj"], atol=2e-3, rtol=1e-4)
+
+
+@pytest.mark.parametrize("cfg", [(32, 32, 160, 2, 16, 16), (32, 32, 160, 2, 8, 8), (6, 32, 64, 1, 16, 16)],
+                         ids=lambda s: "B%d_z%d_h%d_d%d_%dx%d" % s)
+def test_agrees_with_the_layer_by_layer_path(amd, cfg):
+    """same arithmetic (bf16x3 split products, fp32 accumulate), different summation order: fp32 round-off apart"""
+    B, n_z, n_h, d, H, W = cfg
+    params, z, ctx = _case(500 + H, *cfg)
+    dp = {k: dev(v) for k, v in params.items()}
+    one, lbl = amd.ARStack(n_z, [n_h] * d), amd.ARStack(n_z, [n_h] * d)
+    lbl.set_fuse_step("never")
+    one.prepare(dp)
+    lbl.prepare(dp)
+    assert one.step_is_fused(B, H, W) > 0 and lbl.step_is_fused(B, H, W) == 0
+    za, sa = one.iaf_step(dev(z), dev(ctx))
+    zb, sb = lbl.iaf_step(dev(z), dev(ctx))
+    assert float((sa - sb).abs().max()) < 2e-6 and float((za - zb).abs().max()) < 3e-5
+    # the inverse flow runs its Jacobi sweeps through the same launch
+    z0a = one.iaf_step_inverse(za, dev(ctx))[0]
+    np.testing.assert_allclose(host(z0a), f32(z), atol=2e-4, rtol=0)
+
+
+@pytest.mark.parametrize("H", [16, 8])
+def test_batch_independence_and_ar_structure_bit_exact(amd, H):
+    """a workgroup only ever sees one image: samples run one at a time reproduce the batched result bit for bit; and a
+    perturbation of z at (pixel q, channel c) leaves every position that precedes it in the IAF ordering bit-identical
+    (masked weights are exact zeros in all three bf16 planes; rows a workgroup recomputes for its neighbour's benefit never
+    leave it), also across the row-block boundaries between workgroups"""
+    B, n_z, n_h, d = 32, 32, 160, 2
+    params, z, ctx = _case(2030 + H, B, n_z, n_h, d, H, H)
+    st = amd.ARStack(n_z, [n_h] * d)
+    st.prepare({k: dev(v) for k, v in params.items()})
+    assert st.step_is_fused(B, H, H) > 0 and st.step_is_fused(1, H, H) == st.step_is_fused(B, H, H)
+    zd, cd = dev(z), dev(ctx)
+    zf, sf = st.iaf_step(zd, cd)
+    for b in (0, 13, 31):
+        zb, sb = st.iaf_step(zd[b:b + 1].contiguous(), cd[b:b + 1].contiguous())
+        assert torch.equal(zb, zf[b:b + 1]) and torch.equal(sb, sf[b:b + 1])
+    # the masked convs look right and below (layers.py:133-141): a change of z[c] at pixel (qh, qw) may reach the pixels
+    # above and to the left of it, and channels > c of the same pixel -- everything else must not move by a single bit
+    for (qh, qw, c) in ((H // 2, H // 2 - 1, 11), (H - 1, H - 1, 31), (1, 0, 0), (2, H - 1, 5)):
+        z2 = zd.clone()
+        z2[:, c, qh, qw] += 0.5
+        allowed = torch.zeros(zd.shape, dtype=torch.bool, device="cuda")
+        allowed[:, :, :qh, :] = True
+        allowed[:, :, qh, :qw] = True
+        allowed_s = allowed.clone()
+        allowed_s[:, c + 1:, qh, qw] = True
+        allowed_z = allowed_s.clone()
+        allowed_z[:, c, qh, qw] = True
+        z1, s1 = st.iaf_step(z2, cd)
+        assert int(((z1 != zf) & ~allowed_z).sum()) == 0 and int(((s1 != sf) & ~allowed_s).sum()) == 0
+        assert bool((z1 != zf).any())
+
+
+def test_repeated_launches_are_deterministic(amd):
+    B, n_z, n_h, d, H = 32, 32, 160, 2, 16
+    params, z, ctx = _case(9, B, n_z, n_h, d, H, H)
+    st = amd.ARStack(n_z, [n_h] * d)
+    st.prepare({k: dev(v) for k, v in params.items()})
+    zd, cd = dev(z), dev(ctx)
+    z0, s0 = st.iaf_step(zd, cd)
+    for _ in range(200):
+        z1, s1 = st.iaf_step(zd, cd)
+        assert torch.equal(z1, z0) and torch.equal(s1, s0)

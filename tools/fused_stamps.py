@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""GPU dev tool: per-workgroup cycle stamps of the one-launch IAF step (iaf_step_fused.hpp)."""
+import argparse, ctypes, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import golden_inputs as gi, iaf_amd
+from iaf_amd import _capi
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=32); ap.add_argument("--hw", type=int, default=16)
+ap.add_argument("--n-z", type=int, default=32); ap.add_argument("--n-h", type=int, default=160)
+ap.add_argument("--depth-ar", type=int, default=2); ap.add_argument("--reps", type=int, default=200)
+a = ap.parse_args()
+rng = np.random.RandomState(0)
+params = gi.ar_multiconv2d_params(rng, a.n_z, [a.n_h] * a.depth_ar, [a.n_z, a.n_z])
+dev = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).cuda()
+z = dev(rng.standard_normal((a.batch, a.n_z, a.hw, a.hw))); ctx = dev(rng.standard_normal((a.batch, a.n_h, a.hw, a.hw)))
+st = iaf_amd.ARStack(a.n_z, [a.n_h] * a.depth_ar); st.prepare({k: dev(v) for k, v in params.items()})
+out = (torch.empty_like(z), torch.empty_like(z))
+for _ in range(5):
+    st.iaf_step(z, ctx, out=out)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(a.reps):
+    st.iaf_step(z, ctx, out=out)
+e1.record(); torch.cuda.synchronize()
+print("iaf_step %dx%d B=%d: %.2f us per call (back to back, eager)" % (a.hw, a.hw, a.batch, e0.elapsed_time(e1) / a.reps * 1e3))
+buf = torch.zeros(8 * 65536, dtype=torch.int64, device="cuda")
+_capi.check(_capi.lib().iaf_stack_set_debug(st._h, -2, ctypes.c_void_p(buf.data_ptr())))
+st.iaf_step(z, ctx, out=out); torch.cuda.synchronize()
+_capi.check(_capi.lib().iaf_stack_set_debug(st._h, -1, None))
+t = buf.cpu().numpy().reshape(-1, 8); t = t[t[:, 0] != 0]
+if len(t) == 0:
+    print("the step did not run as one launch at this size"); sys.exit(0)
+names = ["start -> z staged (barrier)", "first conv + epilogue", "second conv + epilogue", "output conv", "exchange + affine + stores"]
+d = np.diff(t[:, :6], axis=1).astype(np.float64)
+print("%d WGs; kernel span %.0f ticks; per-WG total median %.0f; first start->last start %.0f" %
+      (len(t), t[:, 5].max() - t[:, 0].min(), np.median(t[:, 5] - t[:, 0]), t[:, 0].max() - t[:, 0].min()))
+for i, n in enumerate(names):
+    print("    %-32s median %8.0f   max %8.0f ticks" % (n, np.median(d[:, i]), d[:, i].max()))
