@@ -857,7 +857,8 @@ static int run_stack(iaf_stack_t* s, ConvP base, int first_inmode, const float* 
     if (first_inmode == IN_NCHW || first_inmode == IN_POSTERIOR) {
         int R = 0;
         size_t lds = 0;
-        if (step_fn_t fn = fused_step_plan(s, base.B, base.H, base.W, &R, &lds))
+        const bool aligned = (((uintptr_t)ctx | (uintptr_t)ctx2) & 15) == 0;      // it fetches the contexts 16 bytes at a time
+        if (step_fn_t fn = aligned ? fused_step_plan(s, base.B, base.H, base.W, &R, &lds) : nullptr)
             return launch_fused_step(s, fn, R, lds, base, first_inmode, ctx, ctx2, st);
     }
     Launch ls[MAX_GEMM_LAYERS];

@@ -42,9 +42,17 @@ struct StepGeom {
     // when there is a single hidden layer (the output pair reads h_0 then)
     static constexpr int XB_OFF = DEPTH >= 2 ? 0 : END;
     static constexpr size_t xb_bytes() { return (size_t)4 * R * W * XB_STRIDE * 4; }
+    // context of the first epilogue, staged [channel][pixel of the h_0 rows] (+4 floats: conflict-free for the epilogue's
+    // lanes = 16 pixels x 4 channel groups): in the h_1 region, which the first conv does not touch; behind everything when
+    // there is a single hidden layer
+    static constexpr int CPX = (R + DEPTH) * W, CSTR = CPX + 4;
+    static constexpr int CTX_OFF = DEPTH >= 2 ? HREG1 : END;
+    static constexpr size_t ctx_bytes() { return (size_t)NH * CSTR * 4; }
     static constexpr size_t lds_bytes() {
-        const size_t a = (size_t)END * 16, b = (size_t)XB_OFF * 16 + xb_bytes();
-        return a > b ? a : b;
+        size_t a = (size_t)END * 16;
+        const size_t b = (size_t)XB_OFF * 16 + xb_bytes(), c = (size_t)CTX_OFF * 16 + ctx_bytes();
+        a = a > b ? a : b;
+        return a > c ? a : c;
     }
 };
 
@@ -133,8 +141,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                   (NZ / 32) * NTAPS, decltype(i)::value);
     });
     __builtin_amdgcn_sched_barrier(0);
+    // context rows of this workgroup: per channel one contiguous run of CPX pixels (full-width rows) -> 16-byte loads,
+    // 4 channels per wave instruction; summed with the second context here
+    constexpr int CPX = G::CPX, CSTR = G::CSTR, CG = CPX / 4, NCIT = NH * CG, NCI = (NCIT + 255) / 256;
+    f32x4 cv[NCI];
     {
-        constexpr int ZROWS = RZ, H0ROWS = G::rows_h(0), H1ROWS = DEPTH >= 2 ? G::rows_h(1) : 0;
+        const int vpx = (H - r0) * W < CPX ? (H - r0) * W : CPX;       // pixels of those rows that lie inside the image
+#pragma unroll
+        for (int u = 0; u < NCI; ++u) {
+            const int idx = tid + u * 256;
+            const int ic = idx < NCIT ? idx : NCIT - 1;
+            const int c = ic / CG, g4 = (ic - c * CG) * 4;
+            cv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p.ctx && g4 < vpx) {
+                const size_t gi = ((size_t)b * NH + c) * HW + (size_t)r0 * W + g4;
+                cv[u] = *(const f32x4*)(p.ctx + gi);
+                if (p.ctx2) cv[u] += *(const f32x4*)(p.ctx2 + gi);
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        constexpr int ZROWS = RZ, H0ROWS = G::rows_h(0), H1ROWS = 0;      // (h_1's zero columns: after the first layer)
         for (int i = tid; i < ZROWS * 2 * Z16; i += 256) {
             const int rs = i / Z16, u = i - rs * Z16;
             smem4[G::ZREG + ((rs >> 1) * RS + (rs & 1) * (W + 1)) * Z16 + u] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -158,6 +186,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     __syncthreads();
     IAF_FSTAMP(1);
+    // the context rows go to LDS after the first conv's K loop (they had all of it to arrive), then a barrier, then its epilogue
+    auto store_ctx = [&]() {
+        float* creg = (float*)(smem + (size_t)G::CTX_OFF * 16);
+#pragma unroll
+        for (int u = 0; u < NCI; ++u) {
+            const int idx = tid + u * 256;
+            if (idx < NCIT) {
+                const int c = idx / CG, g4 = (idx - c * CG) * 4;
+                *(f32x4*)(creg + c * CSTR + g4) = cv[u];
+            }
+        }
+    };
 
     // ---- one conv phase: acc[q][j] = sum over steps [s0, nstep) of W[step][tiles[j]] x X[pixel tile q, step] --------------
     // in_reg / in_s16 / in_c8: the input region (16-byte units); ROWS * W output pixels in NPT tiles.  The LAST tile slot is
@@ -238,41 +278,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int j = 0; j < NTW; ++j) acc_out[q][j] = acc[q][j];
     };
 
-    // context operands of the first epilogue (the lane's 4 channels of every unit it owns), issued after the z barrier:
-    // they have the whole first conv to arrive
-    f32x4 cx[NPT0][NTWH];
-    auto load_ctx = [&](auto emask_c) {
-        constexpr int EMASK = decltype(emask_c)::value;
-#pragma unroll
-        for (int q = 0; q < NPT0; ++q) {
-            const int pix = q * 16 + pl, row = pix / W, col = pix - row * W;
-            const bool live = pix < G::rows_h(0) * W && r0 + row < H;
-#pragma unroll
-            for (int j = 0; j < NTWH; ++j) {
-                cx[q][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                const bool mine = !(j == NTWH - 1 && !((EMASK >> q) & 1));
-                if (mine && live && htile[j] < NHT && p.ctx) {
-                    const size_t cb = ((size_t)b * NH + htile[j] * 16 + 4 * kk) * HW + (size_t)(r0 + row) * W + col;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) cx[q][j][r] = p.ctx[cb + (size_t)r * HW];
-                    if (p.ctx2) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) cx[q][j][r] += p.ctx2[cb + (size_t)r * HW];
-                    }
-                }
-            }
-        }
-    };
-
     // hidden epilogue: bias (+ context) + ELU (layers.py:63-64,163-165) -> the three planes of the next region; rows past the
     // image bottom become the zero rows the layer above pads with
-    auto hidden_epilogue = [&](auto npt_c, auto rows_c, auto emask_c, auto ctx_c, f32x4 (*acc)[NTWH], const float* bias, int out_reg) {
+    auto load_bias = [&](const float* bias, f32x4* bi) {       // issued before a phase's K loop, used by its epilogue
+#pragma unroll
+        for (int j = 0; j < NTWH; ++j) bi[j] = *(const f32x4*)(bias + (htile[j] < NHT ? htile[j] : NHT - 1) * 16 + 4 * kk);
+    };
+    auto hidden_epilogue = [&](auto npt_c, auto rows_c, auto emask_c, auto ctx_c, f32x4 (*acc)[NTWH], const f32x4* bias, int out_reg) {
         constexpr int NPT = decltype(npt_c)::value, ROWS = decltype(rows_c)::value, EMASK = decltype(emask_c)::value;
         constexpr bool WITH_CTX = decltype(ctx_c)::value != 0;
+        f32x4 cxv[WITH_CTX ? NPT : 1][NTWH];                     // all context reads in flight together, ahead of the arithmetic
+        if constexpr (WITH_CTX) {
+#pragma unroll
+            for (int j = 0; j < NTWH; ++j)
+#pragma unroll
+                for (int q = 0; q < NPT; ++q) {
+                    int pix = q * 16 + pl;
+                    pix = pix < ROWS * W ? pix : ROWS * W - 1;
+                    const int tl = htile[j] < NHT ? htile[j] : NHT - 1;
+                    const float* cr = (const float*)(smem + (size_t)G::CTX_OFF * 16) + (tl * 16 + 4 * kk) * G::CSTR + pix;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) cxv[q][j][r] = cr[r * G::CSTR];
+                }
+        }
 #pragma unroll
         for (int j = 0; j < NTWH; ++j) {
             if (htile[j] >= NHT) continue;
-            const f32x4 bi = *(const f32x4*)(bias + htile[j] * 16 + 4 * kk);
+            const f32x4 bi = bias[j];
 #pragma unroll
             for (int q = 0; q < NPT; ++q) {
                 if (j == NTWH - 1 && !((EMASK >> q) & 1)) continue;
@@ -280,7 +312,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 if (pix >= ROWS * W) continue;
                 const int row = pix / W, col = pix - row * W;
                 f32x4 v = acc[q][j] + bi;
-                if constexpr (WITH_CTX) v += cx[q < NPT0 ? q : 0][j];
+                if constexpr (WITH_CTX) v += cxv[q][j];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = elu_f(v[r]);
                 if (r0 + row >= H) v = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -310,10 +342,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         constexpr int GI = decltype(g_c)::value;
         if (xg != GI) return;
         constexpr int EM0 = (NX == 0 || !XSPLIT) ? (1 << NPT0) - 1 : fused_extra_mask(NPT0, GN, GI);
-        load_ctx(std::integral_constant<int, EM0>{});
-        f32x4 acc0[NPT0][NTWH];
+        f32x4 acc0[NPT0][NTWH], bi0[NTWH];
+        load_bias(p.bias[0], bi0);
         conv_phase(std::integral_constant<int, NPT0>{}, std::integral_constant<int, NTWH>{}, std::integral_constant<int, G::rows_h(0)>{},
                    std::integral_constant<int, EM0>{}, G::ZREG, Z16, Z8, wb0, NHT, htile, 0, (NZ / 32) * NTAPS, wr0, acc0);
+        IAF_FSTAMP(6);
+        store_ctx();
         // the next phase's first weight steps travel while this phase's epilogue runs
         if constexpr (DEPTH >= 2) {
             const f32x4* wb1 = (const f32x4*)p.wp3[1] + lane;
@@ -324,24 +358,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         } else {
             preload_out();
         }
+        __syncthreads();                                         // (every wave runs exactly one of the GN instantiations)
+#ifdef IAF_EXP_STAMP_MID
+        IAF_FSTAMP(7);
+#endif
         hidden_epilogue(std::integral_constant<int, NPT0>{}, std::integral_constant<int, G::rows_h(0)>{},
-                        std::integral_constant<int, EM0>{}, std::integral_constant<int, 1>{}, acc0, p.bias[0], G::HREG0);
+                        std::integral_constant<int, EM0>{}, std::integral_constant<int, 1>{}, acc0, bi0, G::HREG0);
     });
     __syncthreads();
     IAF_FSTAMP(2);
     if constexpr (DEPTH >= 2) {
+        {   // the staged context sat in the h_1 region: its zero columns again, before the layer's epilogue fills the rest
+            constexpr int H1ROWS = G::rows_h(1);
+            for (int i = tid; i < H1ROWS * 2 * H16; i += 256) {
+                const int rs = i / H16, u = i - rs * H16;
+                smem4[G::HREG1 + ((rs >> 1) * RS + (rs & 1) * (W + 1)) * H16 + u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
         constexpr int NPT1 = (G::rows_h(1) * W + 15) / 16;
         static_for<GN>([&](auto g_c) {
             constexpr int GI = decltype(g_c)::value;
             if (xg != GI) return;
             constexpr int EM1 = (NX == 0 || !XSPLIT) ? (1 << NPT1) - 1 : fused_extra_mask(NPT1, GN, GI);
-            f32x4 acc1[NPT1][NTWH];
+            f32x4 acc1[NPT1][NTWH], bi1[NTWH];
+            load_bias(p.bias[1], bi1);
             const f32x4* wb1 = (const f32x4*)p.wp3[1] + lane;
             conv_phase(std::integral_constant<int, NPT1>{}, std::integral_constant<int, NTWH>{}, std::integral_constant<int, G::rows_h(1)>{},
                        std::integral_constant<int, EM1>{}, G::HREG0, H16, H8, wb1, NHT, htile, 0, NSTEP_H, wr1, acc1);
+#ifndef IAF_EXP_STAMP_MID
+            IAF_FSTAMP(7);
+#endif
             preload_out();
             hidden_epilogue(std::integral_constant<int, NPT1>{}, std::integral_constant<int, G::rows_h(1)>{},
-                            std::integral_constant<int, EM1>{}, std::integral_constant<int, 0>{}, acc1, p.bias[1], G::HREG1);
+                            std::integral_constant<int, EM1>{}, std::integral_constant<int, 0>{}, acc1, bi1, G::HREG1);
         });
         __syncthreads();
     }

@@ -7,6 +7,8 @@ template <int NHT, int NZT, int DEPTH, int W, int R>
 static step_fn_t inst(size_t* lds) {
     typedef StepGeom<NHT, NZT, DEPTH, W, R> G;
     static_assert(DEPTH < 2 || G::xb_bytes() <= (size_t)G::HREG1 * 16, "the exchange buffer must fit the z + h_0 regions");
+    static_assert(DEPTH < 2 || G::ctx_bytes() <= (size_t)(G::END - G::HREG1) * 16, "the staged context must fit the h_1 region");
+    static_assert((G::CSTR & 15) == 4 || (G::CSTR & 15) == 12, "context rows: 4 channel groups x 16 pixels must hit 64 distinct banks");
     *lds = G::lds_bytes();
     return iaf_step_fused_kernel<NHT, NZT, DEPTH, W, R>;
 }

@@ -39,3 +39,6 @@ print("%d WGs; kernel span %.0f ticks; per-WG total median %.0f; first start->la
       (len(t), t[:, 5].max() - t[:, 0].min(), np.median(t[:, 5] - t[:, 0]), t[:, 0].max() - t[:, 0].min()))
 for i, n in enumerate(names):
     print("    %-32s median %8.0f   max %8.0f ticks" % (n, np.median(d[:, i]), d[:, i].max()))
+if (t[:, 6] != 0).all():
+    print("    of which: first conv K loop %.0f, its epilogue + barrier %.0f; second conv K loop %.0f, its epilogue + barrier %.0f (wave 0)" % (
+        np.median(t[:, 6] - t[:, 1]), np.median(t[:, 2] - t[:, 6]), np.median(t[:, 7] - t[:, 2]), np.median(t[:, 3] - t[:, 7])))

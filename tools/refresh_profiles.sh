@@ -7,6 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 python -m pytest $R/tests -q -m gpu 2>&1 | tail -4 > $O/pytest_gpu.txt
 python $R/bench.py > $O/bench_n1.json 2> /dev/null
 python $R/bench.py --precision f32 > $O/bench_f32_n1.json 2> /dev/null
+python $R/bench.py --no-fuse-step > $O/bench_layer_by_layer_n1.json 2> /dev/null
 python $R/bench.py --layers > $O/bench_layers_n1.json 2> /dev/null
 python $R/bench.py --iw-eval --steps 100 > $O/bench_iw_eval_n1.json 2> /dev/null
 IAF_BENCH_FORCE_DIST=1 python $R/bench.py --train --steps 50 > $O/bench_train_n1.json 2> /dev/null
@@ -26,9 +27,12 @@ with open(out, 'w') as o:
     for (k, g, w), v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
         o.write('"%s",%s,%s,%d,%.1f,%d\n' % (k, g, w, len(v), sum(v) / len(v), sum(v)))
 PY
-# PMC passes (one counter set per pass) on the dominant kernel with the launch shapes the bench's autotune picks
+# PMC passes (one counter set per pass): the one-launch step (default path), and the layer-by-layer kernels it replaced
+# (bf16x3 with the launch shapes the autotune used to pick, and exact fp32)
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS"; do
   n=$(echo $c | tr ' ' '_')
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmcs_$n -o pmc -- python $R/tools/run_step.py --hw 16 --reps 10 --precision bf16x3 > /dev/null 2>&1
+  cp /tmp/pmcs_$n/*counter_collection.csv $O/pmc/step_${n}_counter_collection.csv
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$n -o pmc -- python $R/tools/run_step.py --hw 16 --reps 10 --precision bf16x3 --tune-bf3 "0:2,1,4,1;1:5,2,1,4;2:2,2,1,4" > /dev/null 2>&1
   cp /tmp/pmc_$n/*counter_collection.csv $O/pmc/bf16x3_${n}_counter_collection.csv
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmcf_$n -o pmc -- python $R/tools/run_step.py --hw 16 --reps 10 --precision f32 > /dev/null 2>&1
@@ -38,5 +42,6 @@ python $R/tools/pmc_summary.py $O/pmc > $O/pmc_summary.txt 2>&1
 python $R/tools/bf3_sweep.py --sweep > $O/bf3_sweep_B32.txt 2>&1
 python $R/tools/bf3_sweep.py --sweep --batch 256 --hw 16 > $O/bf3_sweep_B256.txt 2>&1
 python $R/tools/bench_configs.py > $O/bench_configs.md 2>/dev/null
-(python $R/tools/soak.py --iters 200000 --fresh 3000) > $O/soak_prod_long.txt 2>&1
+for hw in 16 8; do python $R/tools/fused_stamps.py --hw $hw; done > $O/fused_step_stamps.txt 2>&1
+(python $R/tools/soak.py --iters 60000 --fresh 1500) > $O/soak_prod_long.txt 2>&1
 tail -3 $O/pytest_gpu.txt; cut -c1-300 $O/bench_n1.json; tail -2 $O/soak_prod_long.txt
