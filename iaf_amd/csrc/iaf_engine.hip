@@ -99,7 +99,10 @@ struct iaf_stack {
     int precision = IAF_PRECISION_BF16X3;   // forward convs: bf16x3 split products on the bf16 MFMA, or the exact fp32 MFMA
     int fuse_first = 2;       // first masked conv fused into the second one's kernel: 0 never, 1 whenever possible, 2 only where
                               // iaf_stack_autotune measured it faster (on MI355X at the BASELINE sizes it is not: DESIGN.md 4.8)
-    int fuse_step = 1;        // the whole step as ONE launch (iaf_step_fused.hpp) where a compiled geometry covers it: 0 never, 1 yes
+    int fuse_step = 1;        // the whole step as ONE launch (iaf_step_fused.hpp): 0 never, 1 where a compiled geometry covers it and
+                              // the size rule / autotune's measurement favours it, 2 wherever a compiled geometry covers it
+    long long fs_P = -1; int fs_W = 0; bool fs_on = false;   // ... unless iaf_stack_autotune measured this size: then what it found
+    int fs_force = -1;        // (autotune's own measurements: -1 off, 0 / 1 = take this path regardless)
     bool prepared;
     size_t weight_bytes;  // raw V/g/b bytes of the stack (for the algorithmic byte count)
     // optional per-launch event timing of one layer
@@ -826,6 +829,15 @@ static step_fn_t fused_step_plan(const iaf_stack_t* s, int B, int H, int W, int*
         if (!s->L[l].wp3 || s->L[l].user_tuned || s->L[l].b_user_tuned) return nullptr;
     static const int forceR = getenv("IAF_FUSE_STEP_R") ? atoi(getenv("IAF_FUSE_STEP_R")) : 0;  // dev knob
     *R = forceR ? forceR : (W == 16 ? 2 : ((long long)B * H >= 1024 ? 2 : 1));
+    // Every workgroup streams the stack's whole weight set (1.2 MB at n_h = 160) out of L2, so the launch's L2 traffic
+    // grows with the workgroup count while the layer-by-layer kernels amortise a weight fetch over more pixels as the batch
+    // grows: measured, the one-launch step wins at 16-pixel rows up to B = 256 and at 8-pixel rows only while one row per
+    // workgroup still fits a round or two of the chip (B = 32: 17 vs 22 us; B = 256: 69 vs 61 us).
+    if (s->fs_force == 0) return nullptr;
+    if (s->fs_force < 0 && mode != 2) {
+        if (s->fs_P == (long long)B * H * W && s->fs_W == W) { if (!s->fs_on) return nullptr; }      // measured for this size
+        else if (W == 8 && (long long)B * H >= 1024) return nullptr;
+    }
     step_fn_t fn = iaf_pick_step_fused(s->n_h / 16, s->n_z / 16, s->depth_ar, W, *R, lds);
     if (!fn || *lds > 160 * 1024) return nullptr;
     return fn;
@@ -987,9 +999,37 @@ extern "C" int iaf_stack_autotune(iaf_stack_t* s, const float* z, const float* c
         L.tuned_us = 1e3f * best;
     }
     s->precision = saved_prec;
+    // the whole step as one launch against the layer-by-layer launches just tuned: `reps` full steps back to back each way
+    if (!rc && s->fuse_step) {
+        s->fs_P = -1;
+        int R = 0;
+        size_t lds = 0;
+        s->fs_force = 1;
+        const bool possible = fused_step_plan(s, B, H, W, &R, &lds) != nullptr;
+        float t[2] = {0.f, 0.f};
+        for (int mode = 0; mode < 2 && possible && !rc; ++mode) {
+            s->fs_force = mode;
+            hipEvent_t e0, e1;
+            if ((rc = iaf_step_forward(s, z, context, z_new, logsd, B, H, W, workspace, workspace_bytes, stream))) break;
+            HIP_TRY(hipEventCreate(&e0));
+            HIP_TRY(hipEventCreate(&e1));
+            HIP_TRY(hipEventRecord(e0, (hipStream_t)stream));
+            for (int r = 0; r < reps && !rc; ++r)
+                rc = iaf_step_forward(s, z, context, z_new, logsd, B, H, W, workspace, workspace_bytes, stream);
+            (void)hipEventRecord(e1, (hipStream_t)stream);
+            (void)hipEventSynchronize(e1);
+            (void)hipEventElapsedTime(&t[mode], e0, e1);
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+        }
+        s->fs_force = -1;
+        if (!rc && possible) { s->fs_P = P; s->fs_W = W; s->fs_on = t[1] < t[0]; }
+        if (!rc && possible && s->fs_on && chosen) for (int l = 0; l < s->nlayers; ++l) chosen[l] = -2;   // -2: part of the one-launch step
+        if (!rc && possible && s->fs_on && us) { for (int l = 0; l < s->nlayers; ++l) us[l] = 0.f; us[s->nlayers - 1] = 1e3f * t[1] / (float)reps; }
+    }
     // the first masked conv fused into the second one's kernel: every shape that can carry it, against the two separate
     // launches (+ the launch boundary between them, which back-to-back timing of single kernels does not see)
-    if (!rc && s->depth_ar >= 1 && s->fuse_first != 0) {
+    if (!rc && s->depth_ar >= 1 && s->fuse_first != 0 && !(s->fs_P == P && s->fs_W == W && s->fs_on)) {
         GemmLayer& L1 = s->L[1];
         L1.fz_P = -1;
         const int saved_mode = s->fuse_first;
@@ -1021,7 +1061,7 @@ extern "C" int iaf_stack_autotune(iaf_stack_t* s, const float* z, const float* c
 
 extern "C" int iaf_stack_set_fuse_step(iaf_stack_t* s, int mode) {
     if (!s) return IAF_ERR_NULL;
-    if (mode < 0 || mode > 1) return IAF_ERR_SHAPE;
+    if (mode < 0 || mode > 2) return IAF_ERR_SHAPE;
     s->fuse_step = mode;
     return IAF_OK;
 }

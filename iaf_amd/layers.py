@@ -236,7 +236,9 @@ class ARStack(object):
     def autotune(self, z, context, reps=20):
         """time every GEMM layer as the exact-fp32 kernel and as every compiled bf16x3 launch shape on these buffers and
         keep the fastest for this (B, H, W) -- what cuDNN's algorithm search does for the reference's convs.  Returns
-        [(choice, us)] per layer, choice = "f32" or "bf16x3(nt,ppw,pxt,ks,wco)".  Synchronises: call before graph capture."""
+        [(choice, us)] per layer, choice = "f32" or "bf16x3(nt,ppw,pxt,ks,wco)"; where the whole step runs faster as ONE
+        launch (iaf_stack_set_fuse_step) every layer reads "one-launch step" and the last entry carries the step's time.
+        Synchronises: call before graph capture."""
         B, H, W = self._dims(z, context)
         ws, need = self.workspace(B, H, W, z.device)
         zn, ls = torch.empty_like(z), torch.empty_like(z)
@@ -247,7 +249,7 @@ class ARStack(object):
         out = []
         for i in range(n):
             c = chosen[i]
-            name = "f32" if c == 0 else ("fused into next" if c < 0 else
+            name = "f32" if c == 0 else ("one-launch step" if c == -2 else "fused into next" if c < 0 else
                                          "bf16x3(%d,%d,%d,%d,%d)" % (c // 10000, c // 1000 % 10, c // 100 % 10, c // 10 % 10, c % 10))
             if c > 0 and i == 1 and chosen[0] < 0:
                 name += "+layer0"
@@ -261,9 +263,9 @@ class ARStack(object):
         _capi.check(_capi.lib().iaf_stack_set_fuse_first(self._h, int(code)))
 
     def set_fuse_step(self, mode):
-        """the whole IAF step as ONE launch where a compiled geometry covers it: "auto" (default) | "never".
-        See include/iaf_hip.h."""
-        code = {"never": 0, "auto": 1}.get(mode, mode)
+        """the whole IAF step as ONE launch: "auto" (default: where a compiled geometry covers it and the size rule or
+        autotune's measurement favours it) | "never" | "always" (wherever a geometry covers it).  See include/iaf_hip.h."""
+        code = {"never": 0, "auto": 1, "always": 2}.get(mode, mode)
         _capi.check(_capi.lib().iaf_stack_set_fuse_step(self._h, int(code)))
 
     def step_is_fused(self, B, H, W):

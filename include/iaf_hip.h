@@ -249,9 +249,13 @@ int iaf_stack_set_fuse_first(iaf_stack_t* s, int mode);
  * halo rows recomputed (the masked convs look only right and below, so no other workgroup is involved).  mode 1 (default):
  * wherever a compiled geometry covers the problem -- TF statement, bf16x3 precision, (n_h, n_z, depth_ar) = (160, 32, 2)
  * or (64, 32, 1), images 16 or 8 pixels wide; everything else, and any stack with a pinned per-layer launch shape
- * (iaf_stack_set_tuning*, fuse_first = 1), takes the layer-by-layer path.  mode 0: never.  Same arithmetic as the
+ * (iaf_stack_set_tuning*, fuse_first = 1), takes the layer-by-layer path.  mode 0: never; mode 2: wherever a geometry
+ * covers it, whatever the size rule or a measurement says.  Same arithmetic as the
  * layer-by-layer bf16x3 kernels in a different summation order: results agree to fp32 round-off, not bit for bit.
- * iaf_stack_step_is_fused: rows per workgroup the step would run with at this size, 0 if it would not run fused. */
+ * Without a measurement the step runs fused at 16-pixel rows, and at 8-pixel rows while B*H < 1024 (every workgroup
+ * streams the whole weight set out of L2: at large batches the layer-by-layer kernels amortise it better);
+ * iaf_stack_autotune times both paths for its problem size and records the winner (chosen[] = -2 for every layer, us[last] =
+ * the step).  iaf_stack_step_is_fused: rows per workgroup the step would run with at this size, 0 if it would not run fused. */
 int iaf_stack_set_fuse_step(iaf_stack_t* s, int mode);
 int iaf_stack_step_is_fused(const iaf_stack_t* s, int B, int H, int W);
 int iaf_stack_autotune(iaf_stack_t* s, const float* z, const float* context, float* z_new, float* logsd, int B, int H, int W,

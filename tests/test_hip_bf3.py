@@ -235,10 +235,14 @@ def test_autotune_picks_a_kernel_per_layer_and_keeps_parity(amd):
     st = amd.ARStack(n_z, [n_h] * d)
     st.prepare({k: dev(v) for k, v in params.items()})
     picks = st.autotune(dev(z), dev(ctx), reps=10)
-    assert len(picks) == d + 1 and all(us > 0 or c == "fused into next" for c, us in picks)
+    assert len(picks) == d + 1 and all(us > 0 or c in ("fused into next", "one-launch step") for c, us in picks)
     print("autotune:", picks)
+    if picks[0][0] == "one-launch step":            # the whole step measured faster as ONE launch (iaf_step_fused.hpp)
+        assert all(c == "one-launch step" for c, _ in picks) and picks[-1][1] > 0 and st.step_is_fused(B, H, W) > 0
+    else:
+        assert st.step_is_fused(B, H, W) == 0
     for layer, (choice, _) in enumerate(picks):
-        if choice != "fused into next" and not choice.endswith("+layer0"):
+        if choice not in ("fused into next", "one-launch step") and not choice.endswith("+layer0"):
             assert st.layer_precision(layer, B, H, W) == ("f32" if choice == "f32" else "bf16x3")
     z_new, logsd = st.iaf_step(dev(z), dev(ctx))
     p32 = {k: f32(v) for k, v in params.items()}
