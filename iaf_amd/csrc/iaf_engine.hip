@@ -828,7 +828,7 @@ static step_fn_t fused_step_plan(const iaf_stack_t* s, int B, int H, int W, int*
     for (int l = 0; l < s->nlayers; ++l)                      // ... or pinned a per-layer launch shape: the layer-by-layer path is meant
         if (!s->L[l].wp3 || s->L[l].user_tuned || s->L[l].b_user_tuned) return nullptr;
     static const int forceR = getenv("IAF_FUSE_STEP_R") ? atoi(getenv("IAF_FUSE_STEP_R")) : 0;  // dev knob
-    *R = forceR ? forceR : (W == 16 ? 2 : ((long long)B * H >= 1024 ? 2 : 1));
+    *R = forceR ? forceR : (W == 16 ? 2 : W == 4 ? 4 : ((long long)B * H >= 1024 ? 2 : 1));
     // Every workgroup streams the stack's whole weight set (1.2 MB at n_h = 160) out of L2, so the launch's L2 traffic
     // grows with the workgroup count while the layer-by-layer kernels amortise a weight fetch over more pixels as the batch
     // grows: measured, the one-launch step wins at 16-pixel rows up to B = 256 and at 8-pixel rows only while one row per

@@ -42,10 +42,10 @@ struct StepGeom {
     // when there is a single hidden layer (the output pair reads h_0 then)
     static constexpr int XB_OFF = DEPTH >= 2 ? 0 : END;
     static constexpr size_t xb_bytes() { return (size_t)4 * R * W * XB_STRIDE * 4; }
-    // context of the first epilogue, staged [channel][pixel of the h_0 rows] (+4 floats: conflict-free for the epilogue's
+    // context of the first epilogue, staged [channel][pixel of the h_0 rows] (row stride = 4 or 12 mod 16 floats: conflict-free for the epilogue's
     // lanes = 16 pixels x 4 channel groups): in the h_1 region, which the first conv does not touch; behind everything when
     // there is a single hidden layer
-    static constexpr int CPX = (R + DEPTH) * W, CSTR = CPX + 4;
+    static constexpr int CPX = (R + DEPTH) * W, CSTR = (CPX % 16 == 0 || CPX % 16 == 8) ? CPX + 4 : CPX;
     static constexpr int CTX_OFF = DEPTH >= 2 ? HREG1 : END;
     static constexpr size_t ctx_bytes() { return (size_t)NH * CSTR * 4; }
     static constexpr size_t lds_bytes() {

@@ -1,6 +1,6 @@
 // iaf_step_fused_inst.hip -- instantiations of the one-launch IAF step (iaf_step_fused.hpp) for the geometries the
 // BASELINE configs use: n_h = 160 / n_z = 32 / depth_ar = 2 (configs 1-2, 5: README run) and n_h = 64 / depth_ar = 1
-// (config 0), images 16 and 8 pixels wide.  Built as its own translation unit by iaf_amd/build.py.
+// (config 0), images 16, 8 and 4 pixels wide (4-pixel rows: one workgroup per four rows, i.e. per 4x4 image).  Built as its own translation unit by iaf_amd/build.py.
 #include "iaf_step_fused.hpp"
 
 template <int NHT, int NZT, int DEPTH, int W, int R>
@@ -19,11 +19,13 @@ extern "C" step_fn_t iaf_pick_step_fused(int nht, int nzt, int depth, int W, int
         if (W == 16 && R == 2) return inst<10, 2, 2, 16, 2>(lds);
         if (W == 8 && R == 1) return inst<10, 2, 2, 8, 1>(lds);
         if (W == 8 && R == 2) return inst<10, 2, 2, 8, 2>(lds);
+        if (W == 4 && R == 4) return inst<10, 2, 2, 4, 4>(lds);
     }
     if (nht == 4 && nzt == 2 && depth == 1) {
         if (W == 16 && R == 2) return inst<4, 2, 1, 16, 2>(lds);
         if (W == 8 && R == 1) return inst<4, 2, 1, 8, 1>(lds);
         if (W == 8 && R == 2) return inst<4, 2, 1, 8, 2>(lds);
+        if (W == 4 && R == 4) return inst<4, 2, 1, 4, 4>(lds);
     }
     return nullptr;
 }

@@ -52,7 +52,8 @@ def test_where_the_step_runs_as_one_launch(amd):
     assert st.step_is_fused(32, 16, 16) == 2 and st.step_is_fused(32, 8, 8) == 1 and st.step_is_fused(256, 16, 16) == 2
     assert st.step_is_fused(256, 8, 8) == 0                      # large batch of small images: layer by layer (weight stream)
     assert st.step_is_fused(3, 5, 16) == 2                       # any height, any batch
-    assert st.step_is_fused(32, 4, 4) == 0                       # no compiled geometry for 4-pixel rows
+    assert st.step_is_fused(32, 4, 4) == 4                       # 4-pixel rows: a whole 4x4 image per workgroup
+    assert st.step_is_fused(32, 32, 32) == 0                     # no compiled geometry for 32-pixel rows
     assert amd.ARStack(32, [64]).step_is_fused(16, 16, 16) == 2   # BASELINE configs[0]
     assert amd.ARStack(64, [192] * 4).step_is_fused(32, 16, 16) == 0
     assert amd.ARStack(32, [160, 160], variant="theano").step_is_fused(32, 16, 16) == 0
@@ -64,7 +65,7 @@ def test_where_the_step_runs_as_one_launch(amd):
     st.set_precision("bf16x3")
     st.set_tuning_bf3(1, 5, 2, 1, 4)                              # a pinned per-layer shape means the layer-by-layer path
     assert st.step_is_fused(32, 16, 16) == 0
-    params, z, ctx = _case(1, 2, 32, 160, 2, 4, 4)
+    params, z, ctx = _case(1, 2, 32, 160, 2, 4, 32)
     st2 = amd.ARStack(32, [160, 160])
     st2.prepare({k: dev(v) for k, v in params.items()})
     with pytest.raises(amd.UnsupportedError):
@@ -73,7 +74,8 @@ def test_where_the_step_runs_as_one_launch(amd):
 
 @pytest.mark.parametrize("cfg", [(32, 32, 160, 2, 16, 16), (32, 32, 160, 2, 8, 8), (5, 32, 160, 2, 5, 16), (3, 32, 160, 2, 3, 8),
                                  (1, 32, 160, 2, 1, 16), (2, 32, 160, 2, 7, 8), (64, 32, 160, 2, 16, 16), (128, 32, 160, 2, 8, 8), (16, 32, 64, 1, 16, 16),
-                                 (16, 32, 64, 1, 8, 8), (4, 32, 64, 1, 3, 16), (128, 32, 64, 1, 8, 8)], ids=lambda s: "B%d_z%d_h%d_d%d_%dx%d" % s)
+                                 (16, 32, 64, 1, 8, 8), (4, 32, 64, 1, 3, 16), (128, 32, 64, 1, 8, 8),
+                                 (16, 32, 64, 1, 4, 4), (32, 32, 160, 2, 4, 4), (5, 32, 160, 2, 3, 4), (3, 32, 64, 1, 9, 4)], ids=lambda s: "B%d_z%d_h%d_d%d_%dx%d" % s)
 def test_iaf_step_and_raw_outputs_vs_oracle(amd, cfg):
     """tf_train.py:69-72 and layers.py:158-166 through the one-launch step; heights that are not a multiple of the rows
     per workgroup, single rows, one sample"""
@@ -82,7 +84,7 @@ def test_iaf_step_and_raw_outputs_vs_oracle(amd, cfg):
     st = amd.ARStack(n_z, [n_h] * d)
     if W == 8 and B * H >= 1024:
         st.set_fuse_step("always")                                # two rows per workgroup at 8-pixel rows: beyond the size rule
-    assert st.step_is_fused(B, H, W) == (2 if (W == 16 or B * H >= 1024) else 1)
+    assert st.step_is_fused(B, H, W) == (4 if W == 4 else 2 if (W == 16 or B * H >= 1024) else 1)
     st.prepare({k: dev(v) for k, v in params.items()})
     zd, cd = dev(z), dev(ctx)
     z_new, logsd = st.iaf_step(zd, cd)
@@ -102,7 +104,8 @@ def test_iaf_step_and_raw_outputs_vs_oracle(amd, cfg):
 
 
 @pytest.mark.parametrize("kl_min", [0.0, 0.25])
-@pytest.mark.parametrize("cfg", [(8, 32, 160, 2, 16, 16), (5, 32, 160, 2, 8, 8), (3, 32, 160, 2, 5, 16), (4, 32, 64, 1, 8, 8)],
+@pytest.mark.parametrize("cfg", [(8, 32, 160, 2, 16, 16), (5, 32, 160, 2, 8, 8), (3, 32, 160, 2, 5, 16), (4, 32, 64, 1, 8, 8),
+                                 (6, 32, 160, 2, 4, 4)],
                          ids=lambda s: "B%d_z%d_h%d_d%d_%dx%d" % s)
 def test_posterior_block_vs_oracle(amd, cfg, kl_min):
     """the extended unit (tf_train.py:56-85): posterior sample computed in the staging, two contexts, KL elements and free
