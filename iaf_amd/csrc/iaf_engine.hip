@@ -844,9 +844,10 @@ static step_fn_t fused_step_plan(const iaf_stack_t* s, int B, int H, int W, int*
 }
 
 static int launch_fused_step(iaf_stack_t* s, step_fn_t fn, int R, size_t lds, const ConvP& base, int first_inmode, const float* ctx,
-                             const float* ctx2, hipStream_t st) {
+                             const float* ctx2, hipStream_t st, float* const* hsave = nullptr) {
     StepP q;
     memset(&q, 0, sizeof(q));
+    if (hsave) { q.hsave[0] = hsave[0]; q.hsave[1] = s->depth_ar > 1 ? hsave[1] : nullptr; }
     q.z = (first_inmode == IN_POSTERIOR) ? nullptr : base.x;
     q.ctx = ctx; q.ctx2 = ctx2;
     for (int l = 0; l < s->nlayers; ++l) { q.wp3[l] = s->L[l].wp3; q.bias[l] = s->L[l].bias; }
@@ -1408,6 +1409,14 @@ extern "C" int iaf_step_forward_train(iaf_stack_t* s, const float* z, const floa
     memset(&base, 0, sizeof(base));
     base.B = B; base.H = H; base.W = W; base.HW = H * W; base.P = B * H * W;
     base.zin = z; base.out0 = z_new; base.out1 = logsd; base.mode = MODE_IAF;
+    base.x = z;
+    {   // the one-launch step, writing the hidden activations of the owned rows where the backward expects them
+        int R = 0;
+        size_t lds = 0;
+        const bool aligned = ((uintptr_t)context & 15) == 0;
+        if (step_fn_t fn = aligned ? fused_step_plan(s, B, H, W, &R, &lds) : nullptr)
+            return launch_fused_step(s, fn, R, lds, base, IN_NCHW, context, nullptr, st, tw.h);
+    }
     const float* cur = z;
     int inmode = IN_NCHW;
     for (int l = 0; l < s->depth_ar; ++l) {       // like run_stack, but every hidden activation gets its own buffer
@@ -1772,9 +1781,19 @@ extern "C" int iaf_posterior_block_forward_train(iaf_stack_t* s, const float* qz
     base.qm = qz_mean; base.ql = qz_logsd; base.rm = rz_mean; base.rl = rz_logsd; base.pm = pz_mean; base.pl = pz_logsd;
     base.eps = eps;
     base.out0 = z_out; base.out1 = tw.logsd; base.kl_elem = tw.klelem; base.mode = MODE_POSTERIOR;
+    bool one_launch = false;
+    {
+        int R = 0;
+        size_t lds = 0;
+        const bool aligned = (((uintptr_t)up_context | (uintptr_t)down_context) & 15) == 0;
+        if (step_fn_t fn = aligned ? fused_step_plan(s, B, H, W, &R, &lds) : nullptr) {
+            if ((rc = launch_fused_step(s, fn, R, lds, base, IN_POSTERIOR, up_context, down_context, st, tw.h))) return rc;
+            one_launch = true;
+        }
+    }
     const float* cur = nullptr;
     int inmode = IN_POSTERIOR;
-    for (int l = 0; l < s->depth_ar; ++l) {
+    for (int l = 0; l < s->depth_ar && !one_launch; ++l) {
         ConvP p = base;
         p.x = cur;
         p.ctx = (l == 0) ? up_context : nullptr;
@@ -1784,9 +1803,11 @@ extern "C" int iaf_posterior_block_forward_train(iaf_stack_t* s, const float* qz
         cur = p.y;
         inmode = IN_PIXMAJOR;
     }
-    ConvP p = base;
-    p.x = cur;
-    if ((rc = launch_conv(s, s->depth_ar, p, inmode, st))) return rc;
+    if (!one_launch) {
+        ConvP p = base;
+        p.x = cur;
+        if ((rc = launch_conv(s, s->depth_ar, p, inmode, st))) return rc;
+    }
     const int rows = B * s->n_z;
     hipLaunchKernelGGL(iaf_kl_rowsum_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, tw.klelem, tw.rowsum, rows, H * W);
     hipLaunchKernelGGL(iaf_kl_finish_kernel, dim3(1), dim3(256), 0, st, tw.rowsum, kl_obj, kl_cost, B, s->n_z, kl_min, tw.gate);

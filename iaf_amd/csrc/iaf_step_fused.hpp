@@ -284,7 +284,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int j = 0; j < NTWH; ++j) bi[j] = *(const f32x4*)(bias + (htile[j] < NHT ? htile[j] : NHT - 1) * 16 + 4 * kk);
     };
-    auto hidden_epilogue = [&](auto npt_c, auto rows_c, auto emask_c, auto ctx_c, f32x4 (*acc)[NTWH], const f32x4* bias, int out_reg) {
+    auto hidden_epilogue = [&](auto npt_c, auto rows_c, auto emask_c, auto ctx_c, f32x4 (*acc)[NTWH], const f32x4* bias, int out_reg,
+                               float* hsave) {
         constexpr int NPT = decltype(npt_c)::value, ROWS = decltype(rows_c)::value, EMASK = decltype(emask_c)::value;
         constexpr bool WITH_CTX = decltype(ctx_c)::value != 0;
         f32x4 cxv[WITH_CTX ? NPT : 1][NTWH];                     // all context reads in flight together, ahead of the arithmetic
@@ -317,6 +318,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 for (int r = 0; r < 4; ++r) v[r] = elu_f(v[r]);
                 if (r0 + row >= H) v = f32x4{0.f, 0.f, 0.f, 0.f};
                 bf3_store4(smem + (size_t)out_reg * 16, row * RS + col + 1, htile[j] * 4 + kk, v, H16, H8);
+                // training: the rows this workgroup OWNS (not its halo) go to HBM for the backward pass
+                if (hsave && row < R && r0 + row < H)
+                    *(f32x4*)(hsave + ((size_t)b * HW + (size_t)(r0 + row) * W + col) * NH + htile[j] * 16 + 4 * kk) = v;
             }
         }
     };
@@ -363,7 +367,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         IAF_FSTAMP(7);
 #endif
         hidden_epilogue(std::integral_constant<int, NPT0>{}, std::integral_constant<int, G::rows_h(0)>{},
-                        std::integral_constant<int, EM0>{}, std::integral_constant<int, 1>{}, acc0, bi0, G::HREG0);
+                        std::integral_constant<int, EM0>{}, std::integral_constant<int, 1>{}, acc0, bi0, G::HREG0, p.hsave[0]);
     });
     __syncthreads();
     IAF_FSTAMP(2);
@@ -390,7 +394,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
             preload_out();
             hidden_epilogue(std::integral_constant<int, NPT1>{}, std::integral_constant<int, G::rows_h(1)>{},
-                            std::integral_constant<int, EM1>{}, std::integral_constant<int, 0>{}, acc1, bi1, G::HREG1);
+                            std::integral_constant<int, EM1>{}, std::integral_constant<int, 0>{}, acc1, bi1, G::HREG1, p.hsave[1]);
         });
         __syncthreads();
     }

@@ -8,6 +8,7 @@ struct StepP {
     const void* wp3[4];        // bf16x3 packs of the D hidden convs and the output pair
     const float* bias[4];
     const float* zin;          // MODE_IAF / MODE_INVERSE: the z of the affine transform
+    float* hsave[2];           // training: hidden activations of the OWNED rows, pixel-major [P][n_h] (what the backward reads), or NULL
     float* out0;
     float* out1;
     float* kl_elem;
