@@ -17,6 +17,7 @@ struct iaf_conv3x3 {
     PrepLayer* h_desc = nullptr;   // pinned staging of the prep descriptor
     PrepLayer* d_desc = nullptr;
     bool training = false;
+    bool deconv = false;           // weights prepared by iaf_conv3x3_prepare_deconv (deconv2d's norm + rotated filter)
     GemmLayer T;                   // transposed problem dX = W^T dY (valid when training)
     // deferred weight-norm backward (iaf_conv3x3_wn_bwd_batch_run): the reduced dW / db partials live here, not in the
     // (shared) workspace
@@ -89,6 +90,7 @@ static int conv3x3_create(iaf_conv3x3_t** out, int n_in, int n_out, int mask_mod
 extern "C" int iaf_conv3x3_prepare(iaf_conv3x3_t* c, const float* V, const float* g, const float* b, void* stream) {
     if (!c || !V || !g || !b) return IAF_ERR_NULL;
     const GemmLayer& L = c->L;
+    c->deconv = false;
     if (c->generic) {
         GenPrepArgs ga;
         memset(&ga, 0, sizeof(ga));
@@ -134,17 +136,18 @@ extern "C" int iaf_conv3x3_prepare_deconv(iaf_conv3x3_t* c, const float* V, cons
     unsigned blocks = (unsigned)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(iaf_deconv_pack_kernel, dim3(blocks), dim3(256), 0, st, V, g, b, (const float*)inv_norm, L.wp, L.bias,
-                       L.cin, L.cout, L.ncot, c->generic ? 1 : 0);
+                       L.cin, L.cout, L.ncot, c->generic ? 1 : 0, (c->training && !c->generic) ? L.wpt : nullptr);
     HIP_TRY(hipGetLastError());
     c->prepared = true;
+    c->deconv = true;
     return IAF_OK;
 }
 
 // 2x resampling of an NCHW tensor (modes: IAF_RESAMPLE_* in include/iaf_hip.h); H, W = size of the SMALLER tensor
 extern "C" int iaf_resample2(const float* src, float* dst, int B, int C, int H, int W, int mode, void* stream) {
     if (!src || !dst) return IAF_ERR_NULL;
-    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || mode < 0 || mode > 3) return IAF_ERR_SHAPE;
-    const bool down = (mode == IAF_RESAMPLE_DOWN_EVEN || mode == IAF_RESAMPLE_DOWN_ODD);
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || mode < 0 || mode > 5) return IAF_ERR_SHAPE;
+    const bool down = (mode == IAF_RESAMPLE_DOWN_EVEN || mode == IAF_RESAMPLE_DOWN_ODD || mode == IAF_RESAMPLE_DOWN_SUM4);
     const size_t n_dst = (size_t)B * C * H * W * (down ? 1 : 4);
     hipLaunchKernelGGL(iaf_resample2_kernel, ew_grid(n_dst), dim3(256), 0, (hipStream_t)stream, src, dst, n_dst, H, W, mode);
     return (int)hipGetLastError();
@@ -583,6 +586,16 @@ extern "C" int iaf_conv3x3_backward(iaf_conv3x3_t* c, const float* x, const floa
                            wgrad_nrange(P, L.cin, MAXTAPS, L.cout), n4, nblk, (const float*)tw.dyc, dbpbuf, P, L.cout, px_per_slab);
     }
     // (4) through the weight norm -- now, or in iaf_conv3x3_wn_bwd_batch_run with every other conv of the model
+    if (c->deconv) {      // deconv2d's norm runs per INPUT channel over the rotated filter (layers.py:104): its own two launches
+        float* inv_norm = L.bias + (size_t)L.ncot * 16;       // (scratch behind the packed bias, as in prepare_deconv)
+        float* S = tw.part;                                    // the range partials are reduced by now
+        hipLaunchKernelGGL(iaf_deconv_bwd_channel_kernel, dim3(L.cin), dim3(256), 0, st, V, g, (const float*)dWbuf, inv_norm, S, L.cin,
+                           L.cout);
+        hipLaunchKernelGGL(iaf_deconv_bwd_apply_kernel, dim3(L.cout), dim3(256), 0, st, V, g, (const float*)dWbuf,
+                           (const float*)inv_norm, (const float*)S, (const float*)dbpbuf, nslab, dV, dg, db, L.cin, L.cout);
+        c->pending = false;
+        return (int)hipGetLastError();
+    }
     if (c->defer_wn) {
         c->pend_nslab = nslab; c->pending = true;
         return (int)hipGetLastError();
@@ -739,9 +752,11 @@ extern "C" int iaf_conv3x3_wn_bwd_batch_run(iaf_conv3x3_wn_bwd_batch_t* b, const
     bool changed = !b->uploaded;
     for (int i = 0; i < b->n; ++i) {
         iaf_conv3x3* c = b->convs[i];
-        if (!c->defer_wn || !c->pending) return IAF_ERR_NOT_PREPARED;
+        if (!c->defer_wn || (!c->pending && !c->deconv)) return IAF_ERR_NOT_PREPARED;
         if (!V[i] || !g[i] || !dV[i] || !dg[i] || !db[i]) return IAF_ERR_NULL;
         WnBwdLayer& w = b->h_layers[i];
+        changed |= (w.skip != (c->deconv ? 1 : 0));
+        w.skip = c->deconv ? 1 : 0;        // a deconv2d pushes its gradient through its own norm inside iaf_conv3x3_backward
         changed |= (w.V != V[i]) | (w.g != g[i]) | (w.dV != dV[i]) | (w.dg != dg[i]) | (w.db != db[i]) |
                    (w.dW != c->own_dW) | (w.dbp != c->own_dbp) | (w.nslab != c->pend_nslab);
         w.V = V[i]; w.g = g[i]; w.dV = dV[i]; w.dg = dg[i]; w.db = db[i];

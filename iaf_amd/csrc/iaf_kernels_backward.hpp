@@ -404,6 +404,7 @@ struct WnBwdLayer {
     // Theano statement (variant != IAF_VARIANT_TF): V = w OIHW [cout][cin+1][3][3], g = s, dV / dg the same shapes;
     // dbrd = [nslab][4][cout_packed] partial gradients of the border channel's taps 1..4
     const float* dbrd; int variant;
+    int skip;            // batched launch: this conv finished its own weight-norm backward already (a deconv2d)
 };
 
 template <int NCH>
@@ -744,6 +745,7 @@ __global__ __launch_bounds__(256) void iaf_wn_bwd_plain_batch_kernel(const WnBwd
     __shared__ float s_n[16], s_dot[16];
     const int li = tile2layer[blockIdx.x];
     const WnBwdLayer L = layers[li];
+    if (L.skip) return;
     const int tile = blockIdx.x - tile_begin[li];
     switch (L.cin >> 4) {
         case 1: wn_bwd_plain_tile<1>(L, tile, red, s_n, s_dot); break;

@@ -22,6 +22,9 @@
 // same number of units.  Output pair (too few tiles to split by tile alone): two tile groups x two halves of the K steps,
 // the partial sums meet in an exchange buffer.
 #pragma once
+#ifndef IAF_FUSED_OKS
+#define IAF_FUSED_OKS 2
+#endif
 #include "iaf_conv_bf3.hpp"
 #include "iaf_step_fused_types.hpp"
 
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     constexpr bool XSPLIT = NX > 0 && NW % NX == 0;              // left-over tiles dealt out per (tile, pixel tile)
     constexpr int GN = XSPLIT ? NW / NX : 1;                     // waves sharing one left-over tile
     constexpr int NTWH = NFULL + (NX ? 1 : 0);                   // tile slots per wave
-    constexpr int OKS = 2;                                       // output pair: K split in OKS parts, NW / OKS tile groups
+    constexpr int OKS = IAF_FUSED_OKS;                           // output pair: K split in OKS parts, NW / OKS tile groups
     constexpr int NTWO = 2 * NZT * OKS / NW;                     // tile slots per wave
     static_assert((2 * NZT * OKS) % NW == 0, "output tiles must split evenly over the wave groups");
     int htile[NTWH];

@@ -57,7 +57,8 @@ class IAFLayer(object):
         """downsample=True: the first layer of a coarser level (tf_train.py:196) -- up() halves the resolution (stride-2
         up_conv1, residual resize 0.5), down() doubles it (down_deconv2 instead of down_conv2, residual resize 2).
         The strided ops run on the stride-1 conv kernel (full-resolution conv + subsample; zero-inserted input + rotated
-        filter, csrc/iaf_kernels_resample.hpp): forward only."""
+        filter, csrc/iaf_kernels_resample.hpp), forward and backward (the adjoint resamplings around the same backward
+        kernels; the deconv's weight norm has its own backward launches)."""
         if mode not in ("train", "init", "sample"):
             raise ValueError("mode must be 'train', 'init' or 'sample' (tf_train.py:60-66), got %r" % (mode,))
         self.z_size, self.h_size, self.kl_min = int(z_size), int(h_size), float(kl_min)
@@ -148,17 +149,20 @@ class IAFLayer(object):
 
     # -- training: forward that keeps what the backward needs, and the backward (tf_train.py:138 for this layer) -----
     def set_training(self, on=True):
-        if on and self.downsample:
-            raise _capi.UnsupportedError("the downsampling IAFLayer is forward only on the gfx950 engine")
         for c in self.convs():
             c.set_training(on)
         self.posterior.stack.set_training(on)
 
     def up_train(self, inp, autotune=False):
         zs, hs = self.z_size, self.h_size
-        qz_mean, qz_logsd, up_context, h = self.up_conv1(inp, elu_input=True, split=[zs, zs, hs, hs], autotune=autotune)
+        parts = self.up_conv1(inp, elu_input=True, split=[zs, zs, hs, hs], autotune=autotune)
+        res = inp
+        if self.downsample:                                       # as in up(): stride-2 conv = stride-1 conv, subsampled
+            parts = [resample2(t, "down_odd") for t in parts]
+            res = resample2(inp, "down_even")
+        qz_mean, qz_logsd, up_context, h = parts
         self.posterior.set_up_state(qz_mean, qz_logsd, up_context)
-        out = self.up_conv3(h, elu_input=True, residual=inp, autotune=autotune)[0]
+        out = self.up_conv3(h, elu_input=True, residual=res, autotune=autotune)[0]
         self._up_saved = dict(inp=inp, h=h)
         return out
 
@@ -169,9 +173,14 @@ class IAFLayer(object):
         po = self.posterior
         blk = po.stack.posterior_block_train(po.qz_mean, po.qz_logsd, rz_mean, rz_logsd, pz_mean, pz_logsd, po.up_context,
                                              down_context, eps, self.kl_min)
-        out = self.down_conv2(blk["z"], x2=h_det, elu_input=True, residual=inp, autotune=autotune)[0]
+        if self.downsample:                                       # as in down(): deconv2d on the zero-inserted inputs
+            zu, hu = resample2(blk["z"], "up_zero_odd"), resample2(h_det, "up_zero_odd")
+            out = self.down_conv2(zu, x2=hu, elu_input=True, residual=resample2(inp, "up_nearest"), autotune=autotune)[0]
+        else:
+            zu, hu = blk["z"], h_det
+            out = self.down_conv2(zu, x2=hu, elu_input=True, residual=inp, autotune=autotune)[0]
         self._down_saved = dict(inp=inp, eps=eps, pz_mean=pz_mean, pz_logsd=pz_logsd, rz_mean=rz_mean, rz_logsd=rz_logsd,
-                                h_det=h_det, z=blk["z"])
+                                h_det=h_det, z=blk["z"], conv2_x=zu, conv2_x2=hu)
         return out, blk["kl_obj"], blk["kl_cost"]
 
     def down_backward(self, d_out, d_kl_obj, params, grads=None, autotune=False):
@@ -186,9 +195,16 @@ class IAFLayer(object):
             return tuple(grads.setdefault(nm + "/" + k, torch.empty_like(params[nm + "/" + k])) for k in ("V", "g", "b"))
 
         # output = input + 0.1*down_conv2(elu(concat(z, h_det)))                                    (tf_train.py:87-94)
+        # downsampling (:89-91): the same conv backward on the zero-inserted inputs -- what reaches the inserted zeros is
+        # dropped ("down_odd" is the adjoint of "up_zero_odd") -- and d input = the 2x2 block sums of d_out (adjoint of
+        # resize_nearest_neighbor(input, 2)); the deconv's own weight norm is differentiated inside conv.backward
+        cn = self.last_conv_name
         (d_z, d_h_det), _, _, _ = self.down_conv2.backward(
-            sv["z"], [d_out], params["down_conv2/V"], params["down_conv2/g"], x2=sv["h_det"], elu_input=True, dy_scale=0.1,
-            grads_out=gslot("down_conv2"), autotune=autotune)
+            sv["conv2_x"], [d_out], params[cn + "/V"], params[cn + "/g"], x2=sv["conv2_x2"], elu_input=True, dy_scale=0.1,
+            grads_out=gslot(cn), autotune=autotune)
+        if self.downsample:
+            d_z, d_h_det = resample2(d_z, "down_odd"), resample2(d_h_det, "down_odd")
+            d_out = resample2(d_out, "down_sum4")
         # the IAF posterior block                                                                   (tf_train.py:56-85)
         pre = "ar_multiconv2d/"
         sp = IAFLayer.stack_params(params)
@@ -214,7 +230,13 @@ class IAFLayer(object):
 
         (d_h,), _, _, _ = self.up_conv3.backward(sv["h"], [d_out], params["up_conv3/V"], params["up_conv3/g"], elu_input=True,
                                                  dy_scale=0.1, grads_out=gslot("up_conv3"), autotune=autotune)   # :40-44
+        dys = [tu["d_qz_mean"], tu["d_qz_logsd"], tu["d_up_context"], d_h]
+        if self.downsample:
+            # stride-2 conv = the stride-1 conv subsampled at the odd positions (:33,36): its gradient is the stride-1 conv's
+            # backward on the zero-inserted dY; the residual resize_nearest_neighbor(input, 0.5) (:43) hands d_out to the even ones
+            dys = [resample2(t, "up_zero_odd") for t in dys]
+            d_out = resample2(d_out, "up_zero_even")
         (d_inp,), _, _, _ = self.up_conv1.backward(
-            sv["inp"], [tu["d_qz_mean"], tu["d_qz_logsd"], tu["d_up_context"], d_h], params["up_conv1/V"],
-            params["up_conv1/g"], elu_input=True, dx_residual=d_out, grads_out=gslot("up_conv1"), autotune=autotune)   # :35-38
+            sv["inp"], dys, params["up_conv1/V"], params["up_conv1/g"], elu_input=True, dx_residual=d_out,
+            grads_out=gslot("up_conv1"), autotune=autotune)                                                        # :35-38
         return d_inp

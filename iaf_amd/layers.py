@@ -484,18 +484,18 @@ class ARStack(object):
         return out
 
 
-RESAMPLE_MODES = {"down_even": 0, "down_odd": 1, "up_nearest": 2, "up_zero_odd": 3}
+RESAMPLE_MODES = {"down_even": 0, "down_odd": 1, "up_nearest": 2, "up_zero_odd": 3, "up_zero_even": 4, "down_sum4": 5}
 
 
 def resample2(x, mode):
     """2x resampling of an NCHW tensor on the GPU (include/iaf_hip.h, iaf_resample2):
     "down_even" == resize_nearest_neighbor(x, 0.5), "up_nearest" == resize_nearest_neighbor(x, 2) (layers.py:169-175);
     "down_odd" keeps what a stride-2 SAME 3x3 conv keeps of the stride-1 conv; "up_zero_odd" is the zero-inserted
-    input of conv2d_transpose."""
+    input of conv2d_transpose; "up_zero_even" / "down_sum4" are the adjoints of "down_even" / "up_nearest" (backward)."""
     _check_act(x, "x")
     B, C, H, W = (int(v) for v in x.shape)
     m = RESAMPLE_MODES[mode]
-    if m < 2:
+    if m in (0, 1, 5):
         if H % 2 or W % 2:
             raise ValueError("2x downsampling needs even H and W, got %dx%d" % (H, W))
         out = torch.empty((B, C, H // 2, W // 2), dtype=x.dtype, device=x.device)

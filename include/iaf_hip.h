@@ -396,6 +396,8 @@ int iaf_discretized_logistic(const float* mean, const float* logscale, int logsc
 #define IAF_RESAMPLE_DOWN_ODD 1
 #define IAF_RESAMPLE_UP_NEAREST 2
 #define IAF_RESAMPLE_UP_ZERO_ODD 3
+#define IAF_RESAMPLE_UP_ZERO_EVEN 4   /* dst[2i,2j] = src[i,j], 0 elsewhere: adjoint of DOWN_EVEN (backward of resize_nearest_neighbor(x, 0.5)) */
+#define IAF_RESAMPLE_DOWN_SUM4 5      /* dst[i,j] = sum of the 2x2 block: adjoint of UP_NEAREST (backward of resize_nearest_neighbor(x, 2)) */
 int iaf_resample2(const float* src, float* dst, int B, int C, int H, int W, int mode, void* stream);
 /* deconv2d(name, x, num_filters, stride=(2,2)) (tf_utils/layers.py:83-112): V is [3,3,n_out,n_in]; the reference's weight
  * norm runs over (kh,kw,n_OUT) per INPUT channel (layers.py:104) and is kept.  Prepares an iaf_conv3x3 (n_in, n_out) so

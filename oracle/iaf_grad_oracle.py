@@ -99,7 +99,7 @@ def posterior_block_grads(inputs, params, n_h, kl_min, dz, dkl_obj):
 
 
 # --------------------------------------------------------------------------------------
-# whole non-downsampling IAFLayer (tf_train.py:23-95), for the backward of the plain convs
+# whole IAFLayer (tf_train.py:23-95), with and without downsampling, for the backward of the plain convs
 # --------------------------------------------------------------------------------------
 def conv2d(x, V, g, b):
     """tf_utils/layers.py:52-64, mask=None."""
@@ -107,28 +107,50 @@ def conv2d(x, V, g, b):
     return F.conv2d(x, w.permute(3, 2, 0, 1), b, padding=(1, 1))
 
 
-def iaf_layer(up_inp, down_inp, eps, params, z_size, h_size, kl_min):
-    """up (tf_train.py:29-44) then down (46-95), mode train, downsample False."""
+def conv2d_stride2(x, V, g, b):
+    """layers.py:52-64 with stride [2,2], SAME: for even sizes TF pads one row / column at the END only."""
+    w = torch.exp(g).reshape(1, 1, 1, -1) * V / torch.sqrt(torch.clamp((V * V).sum(dim=(0, 1, 2), keepdim=True), min=1e-12))
+    return F.conv2d(F.pad(x, (0, 1, 0, 1)), w.permute(3, 2, 0, 1), b, stride=2)
+
+
+def deconv2d(x, V, g, b):
+    """layers.py:83-112 as oracle/iaf_oracle.py:deconv2d states it: V [3,3,n_out,n_in], norm over (kh, kw, n_out) per INPUT
+    channel, conv2d_transpose(SAME, stride 2): the first 2H x 2W of the full transposed conv."""
+    w = torch.exp(g).reshape(1, 1, -1, 1) * V / torch.sqrt(torch.clamp((V * V).sum(dim=(0, 1, 2), keepdim=True), min=1e-12))
+    n, c, hh, ww = x.shape
+    full = F.conv_transpose2d(x, w.permute(3, 2, 0, 1), stride=2)
+    return full[:, :, :2 * hh, :2 * ww] + b.reshape(1, -1, 1, 1)
+
+
+def iaf_layer(up_inp, down_inp, eps, params, z_size, h_size, kl_min, downsample=False):
+    """up (tf_train.py:29-44) then down (46-95), mode train; downsample: stride-2 up_conv1 + resize 0.5 on the way up
+    (:33,42-43), down_deconv2 + resize 2 on the way down (:89-91)."""
     zs, hs = z_size, h_size
-    x = conv2d(F.elu(up_inp), params["up_conv1/V"], params["up_conv1/g"], params["up_conv1/b"])
+    if downsample:
+        x = conv2d_stride2(F.elu(up_inp), params["up_conv1/V"], params["up_conv1/g"], params["up_conv1/b"])
+    else:
+        x = conv2d(F.elu(up_inp), params["up_conv1/V"], params["up_conv1/g"], params["up_conv1/b"])
     qz_mean, qz_logsd, up_context, h = torch.split(x, [zs, zs, hs, hs], dim=1)
     h = conv2d(F.elu(h), params["up_conv3/V"], params["up_conv3/g"], params["up_conv3/b"])
-    up_out = up_inp + 0.1 * h
+    up_out = (up_inp[:, :, ::2, ::2] if downsample else up_inp) + 0.1 * h
     x = conv2d(F.elu(down_inp), params["down_conv1/V"], params["down_conv1/g"], params["down_conv1/b"])
     pz_mean, pz_logsd, rz_mean, rz_logsd, down_context, h_det = torch.split(x, [zs] * 4 + [hs] * 2, dim=1)
     sp = {k[len("ar_multiconv2d/"):]: v for k, v in params.items() if k.startswith("ar_multiconv2d/")}
     n_h = [hs] * sum(1 for k in sp if k.startswith("layer_") and not k.startswith("layer_out") and k.endswith("/g"))
     z, kl_obj, kl_cost = posterior_block(qz_mean, qz_logsd, rz_mean, rz_logsd, pz_mean, pz_logsd, up_context, down_context,
                                          eps, sp, n_h, kl_min)
+    if downsample:
+        h = deconv2d(F.elu(torch.cat([z, h_det], dim=1)), params["down_deconv2/V"], params["down_deconv2/g"], params["down_deconv2/b"])
+        return up_out, down_inp.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3) + 0.1 * h, kl_obj, kl_cost
     h = conv2d(F.elu(torch.cat([z, h_det], dim=1)), params["down_conv2/V"], params["down_conv2/g"], params["down_conv2/b"])
     return up_out, down_inp + 0.1 * h, kl_obj, kl_cost
 
 
-def iaf_layer_grads(up_inp, down_inp, eps, params, z_size, h_size, kl_min, d_up_out, d_down_out, d_kl_obj):
+def iaf_layer_grads(up_inp, down_inp, eps, params, z_size, h_size, kl_min, d_up_out, d_down_out, d_kl_obj, downsample=False):
     """L = <d_up_out, up_out> + <d_down_out, output> + <d_kl_obj, kl_obj>; gradients w.r.t. both inputs and every variable."""
     ut, dt = _t(up_inp, True), _t(down_inp, True)
     pt = {k: _t(v, True) for k, v in params.items()}
-    up_out, out, kl_obj, kl_cost = iaf_layer(ut, dt, _t(eps), pt, z_size, h_size, kl_min)
+    up_out, out, kl_obj, kl_cost = iaf_layer(ut, dt, _t(eps), pt, z_size, h_size, kl_min, downsample)
     loss = (up_out * _t(d_up_out)).sum() + (out * _t(d_down_out)).sum() + (kl_obj * _t(d_kl_obj)).sum()
     loss.backward()
     grads = {k: v.grad.numpy() for k, v in pt.items()}

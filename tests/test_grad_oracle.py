@@ -238,3 +238,60 @@ def test_theano_cvae_iaf_forward_matches_reference_golden(golden_dir, cname):
     np.testing.assert_allclose(fw["kl"], g[cname + "/kl"], rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(fw["obj_kl"], g[cname + "/obj_kl"], rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(fw["h"][:, n_h:], ref["z"], rtol=1e-10, atol=1e-10)
+
+
+# ---------------------------------------------------------------- the downsampling layer (tf_train.py:33,42-43,89-91)
+def test_downsampling_layer_forward_matches_reference_golden(golden_dir):
+    """the torch restatement the gradient oracle differentiates (stride-2 conv, resize 0.5 / 2, deconv2d) reproduces what the
+    reference's own tf_train.IAFLayer(downsample=True) produced"""
+    import os
+    g = np.load(os.path.join(golden_dir, "iaf_layer_ds.npz"))
+    for name in ("layer_ds_tiny", "layer_ds_cfg2"):
+        c = gi.layer_ds_case_inputs(name)
+        zero = np.zeros_like
+        _, fw = G.iaf_layer_grads(c["up_input"], c["down_input"], c["eps_post"], c["params"], c["z_size"], c["h_size"], c["kl_min"],
+                                  np.zeros_like(g[name + "/up_out"]), np.zeros_like(g[name + "/output"]),
+                                  np.zeros(c["up_input"].shape[0]), downsample=True)
+        np.testing.assert_allclose(fw["up_out"], g[name + "/up_out"], rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(fw["output"], g[name + "/output"], rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(fw["kl_obj"], g[name + "/kl_obj"], rtol=1e-9, atol=1e-8)
+
+
+def test_downsampling_layer_gradients_match_finite_differences():
+    c = gi.layer_ds_case_inputs("layer_ds_tiny")
+    zs, hs, kl_min = c["z_size"], c["h_size"], c["kl_min"]
+    rng = np.random.RandomState(12)
+    B, _, H, W = c["up_input"].shape
+    dU, dD = rng.standard_normal((B, hs, H // 2, W // 2)), rng.standard_normal((B, hs, H, W))
+    dK = rng.standard_normal(B)
+    grads, _ = G.iaf_layer_grads(c["up_input"], c["down_input"], c["eps_post"], c["params"], zs, hs, kl_min, dU, dD, dK,
+                                 downsample=True)
+
+    def loss(u, d, pp):
+        up_out, qm, ql, uc = O.iaf_layer_up(u, pp, zs, hs, downsample=True)
+        out, kl_obj, _, _ = O.iaf_layer_down(d, pp, qm, ql, uc, c["eps_post"], zs, hs, kl_min, downsample=True)
+        return (up_out * dU).sum() + (out * dD).sum() + (kl_obj * dK).sum()
+
+    eps = 1e-6
+    for name in ["up_inp", "down_inp", "up_conv1/V", "up_conv1/g", "up_conv3/V", "down_conv1/V", "down_deconv2/V",
+                 "down_deconv2/g", "down_deconv2/b", "ar_multiconv2d/layer_1/V"]:
+        base = {"up_inp": c["up_input"], "down_inp": c["down_input"]}.get(name, c["params"].get(name))
+        got = grads[name] if name in grads else grads["params"][name]
+        for _ in range(5):
+            idx = tuple(rng.randint(0, s) for s in base.shape)
+
+            def at(delta):
+                arr = base.copy()
+                arr[idx] += delta
+                pp = dict(c["params"])
+                u, d = c["up_input"], c["down_input"]
+                if name == "up_inp":
+                    u = arr
+                elif name == "down_inp":
+                    d = arr
+                else:
+                    pp[name] = arr
+                return loss(u, d, pp)
+
+            fd = (at(eps) - at(-eps)) / (2 * eps)
+            assert abs(fd - got[idx]) < 2e-6 * max(1.0, abs(fd)), (name, idx, fd, got[idx])

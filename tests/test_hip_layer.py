@@ -388,6 +388,45 @@ def test_iaf_layer_backward_vs_autograd_oracle(amd, kl_min, size):
     assert worst[0] < 1e-4, worst
 
 
+@pytest.mark.parametrize("kl_min", [0.25, 0.0])
+@pytest.mark.parametrize("size", [(2, 16, 16), (3, 8, 8)], ids=lambda s: "B%d_%dx%d" % s)
+def test_downsampling_iaf_layer_backward_vs_autograd_oracle(amd, kl_min, size):
+    """the first layer of a coarser level (tf_train.py:33,42-43,89-91: stride-2 up_conv1, resize 0.5, down_deconv2, resize 2)
+    trains: gradients w.r.t. both inputs (up input at full resolution, down input at half) and all variables -- incl.
+    down_deconv2 with its per-input-channel weight norm -- vs torch-fp64 autograd of the restated layer, itself pinned to the
+    reference's own IAFLayer(downsample=True) outputs and to finite differences (tests/test_grad_oracle.py)"""
+    from oracle import iaf_grad_oracle as G
+    c = gi.layer_ds_case_inputs("layer_ds_cfg2")
+    zs, hs = c["z_size"], c["h_size"]
+    B, H, W = size
+    rng = np.random.RandomState(19)
+    up_in = 0.3 * rng.standard_normal((B, hs, H, W))
+    down_in, eps = 0.3 * rng.standard_normal((B, hs, H // 2, W // 2)), 0.3 * rng.standard_normal((B, zs, H // 2, W // 2))
+    dU, dD, dK = rng.standard_normal((B, hs, H // 2, W // 2)), rng.standard_normal((B, hs, H, W)), rng.standard_normal(B)
+    p32 = {k: f32(v) for k, v in c["params"].items()}
+    want, fw = G.iaf_layer_grads(f32(up_in), f32(down_in), f32(eps), p32, zs, hs, kl_min, f32(dU), f32(dD), f32(dK), downsample=True)
+    params = {k: dev(v) for k, v in c["params"].items()}
+    layer = amd.IAFLayer(zs, hs, depth_ar=2, kl_min=kl_min, downsample=True)
+    layer.set_training(True)
+    layer.load(params)
+    up_out = layer.up_train(dev(up_in))
+    out, kl_obj, kl_cost = layer.down_train(dev(down_in), dev(eps))
+    np.testing.assert_allclose(host(up_out), fw["up_out"], atol=ATOL, rtol=0)
+    np.testing.assert_allclose(host(out), fw["output"], atol=ATOL * max(1.0, np.abs(fw["output"]).max()), rtol=0)
+    np.testing.assert_allclose(host(kl_obj), fw["kl_obj"], atol=2e-3, rtol=1e-4)
+    grads = {}
+    d_down_in = layer.down_backward(dev(dD), dev(dK), params, grads)
+    d_up_in = layer.up_backward(dev(dU), params, grads)
+    assert tuple(d_down_in.shape) == down_in.shape and tuple(d_up_in.shape) == up_in.shape
+    assert _relerr(host(d_down_in), want["down_inp"]) < 1e-4
+    assert _relerr(host(d_up_in), want["up_inp"]) < 1e-4
+    assert sorted(grads) == sorted(want["params"])
+    worst = max((_relerr(host(grads[k]), want["params"][k]), k) for k in grads)
+    assert worst[0] < 1e-4, worst
+    # inference forward of the same layer object equals the training forward
+    assert torch.equal(layer.up(dev(up_in)), up_out)
+
+
 def test_deferred_weightnorm_backward_equals_immediate(amd):
     """two layers of different spatial size: backward with the weight-norm pass deferred to ONE batched launch per kind
     must give exactly the gradients of the per-layer launches"""
