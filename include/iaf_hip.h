@@ -402,7 +402,8 @@ int iaf_resample2(const float* src, float* dst, int B, int C, int H, int W, int 
 /* deconv2d(name, x, num_filters, stride=(2,2)) (tf_utils/layers.py:83-112): V is [3,3,n_out,n_in]; the reference's weight
  * norm runs over (kh,kw,n_OUT) per INPUT channel (layers.py:104) and is kept.  Prepares an iaf_conv3x3 (n_in, n_out) so
  * that iaf_conv3x3_forward on the UP_ZERO_ODD-resampled input, at the output resolution, equals the reference's
- * conv2d_transpose(SAME, stride 2) + b.  Forward only. */
+ * conv2d_transpose(SAME, stride 2) + b.  iaf_conv3x3_backward of a conv prepared this way differentiates THIS weight
+ * norm (dV in V's [3,3,n_out,n_in] layout) and, when training is on, the prepare also writes the data gradient's pack. */
 int iaf_conv3x3_prepare_deconv(iaf_conv3x3_t* c, const float* V, const float* g, const float* b, void* stream);
 /* eps_out with (qz_mean+rz_mean) + exp(qz_logsd+rz_logsd)*eps_out == z: mode "init" of IAFLayer.down runs the posterior
  * block on a PRIOR sample (tf_train.py:60-61, 67-85) */
