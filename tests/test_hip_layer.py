@@ -427,6 +427,96 @@ def test_downsampling_iaf_layer_backward_vs_autograd_oracle(amd, kl_min, size):
     assert torch.equal(layer.up(dev(up_in)), up_out)
 
 
+def test_two_level_model_trains_end_to_end_vs_autograd_oracle(amd):
+    """BASELINE configs[1] in miniature as ONE connected model (tf_train.py:186-206): a 16x16 layer, then the downsampling
+    layer that opens the 8x8 level, then an 8x8 layer; up pass bottom-up, down pass top-down from h_top, the loss the sum of
+    the kl_obj terms plus a linear read-out of the final output.  Every gradient -- the h_top parameter's, the input's and all
+    variables of the three layers -- against torch-fp64 autograd of the chained restated layers."""
+    from oracle import iaf_grad_oracle as G
+    zs, hs, B, kl_min = 32, 160, 2, 0.25
+    rng = np.random.RandomState(23)
+    cA, cB, cC = (gi.layer_case_inputs("layer_cfg2_8x8"), gi.layer_ds_case_inputs("layer_ds_cfg2"), gi.layer_case_inputs("layer_cfg2_8x8"))
+    pA = {k: v for k, v in cA["params"].items()}
+    pB = {k: v for k, v in cB["params"].items()}
+    pC = {k: v + 0.01 * rng.standard_normal(v.shape) for k, v in cC["params"].items()}
+    x = 0.3 * rng.standard_normal((B, hs, 16, 16))
+    h_top = 0.3 * rng.standard_normal((1, hs, 8, 8))
+    epsA, epsB, epsC = (0.3 * rng.standard_normal((B, zs, s, s)) for s in (16, 8, 8))
+    d_out = rng.standard_normal((B, hs, 16, 16))
+
+    # ---- oracle: chained torch fp64 layers (G.iaf_layer runs up then down of ONE layer: compose by hand)
+    import torch.nn.functional as F
+    t = lambda a, g=False: G._t(f32(a), g)
+    xt, ht = t(x, True), t(h_top, True)
+    PA, PB, PC = ({k: t(v, True) for k, v in p.items()} for p in (pA, pB, pC))
+
+    def up(inp, P, ds):
+        c1 = G.conv2d_stride2 if ds else G.conv2d
+        q = c1(F.elu(inp), P["up_conv1/V"], P["up_conv1/g"], P["up_conv1/b"])
+        qm, ql, uc, h = torch.split(q, [zs, zs, hs, hs], dim=1)
+        h = G.conv2d(F.elu(h), P["up_conv3/V"], P["up_conv3/g"], P["up_conv3/b"])
+        return (inp[:, :, ::2, ::2] if ds else inp) + 0.1 * h, (qm, ql, uc)
+
+    def down(inp, P, st, eps, ds):
+        q = G.conv2d(F.elu(inp), P["down_conv1/V"], P["down_conv1/g"], P["down_conv1/b"])
+        pm, pl, rm, rl, dc, hd = torch.split(q, [zs] * 4 + [hs] * 2, dim=1)
+        sp = {k[len("ar_multiconv2d/"):]: v for k, v in P.items() if k.startswith("ar_multiconv2d/")}
+        z, kl_obj, _ = G.posterior_block(st[0], st[1], rm, rl, pm, pl, st[2], dc, t(eps), sp, [hs, hs], kl_min)
+        cat = F.elu(torch.cat([z, hd], dim=1))
+        if ds:
+            h = G.deconv2d(cat, P["down_deconv2/V"], P["down_deconv2/g"], P["down_deconv2/b"])
+            return inp.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3) + 0.1 * h, kl_obj
+        return inp + 0.1 * G.conv2d(cat, P["down_conv2/V"], P["down_conv2/g"], P["down_conv2/b"]), kl_obj
+
+    hA, sA = up(xt, PA, False)
+    hB, sB = up(hA, PB, True)
+    hC, sC = up(hB, PC, False)
+    hcur = ht.repeat(B, 1, 1, 1)                                      # tf_train.py:186-188 (h_top tiled over the batch)
+    hcur, klC = down(hcur, PC, sC, epsC, False)
+    hcur, klB = down(hcur, PB, sB, epsB, True)
+    hcur, klA = down(hcur, PA, sA, epsA, False)
+    loss = (klA + klB + klC).sum() + (hcur * t(d_out)).sum()
+    loss.backward()
+
+    # ---- the engine
+    layers = [amd.IAFLayer(zs, hs, 2, kl_min), amd.IAFLayer(zs, hs, 2, kl_min, downsample=True), amd.IAFLayer(zs, hs, 2, kl_min)]
+    dps = [{k: dev(v) for k, v in p.items()} for p in (pA, pB, pC)]
+    for L, dp in zip(layers, dps):
+        L.set_training(True)
+        L.load(dp)
+    h = dev(x)
+    for L in layers:
+        h = L.up_train(h)
+    h = dev(h_top).repeat(B, 1, 1, 1).contiguous()
+    kls = []
+    for L, e in zip(reversed(layers), (epsC, epsB, epsA)):
+        h, kl_obj, _ = L.down_train(h, dev(e))
+        kls.append(kl_obj)
+    np.testing.assert_allclose(host(h), hcur.detach().numpy(), atol=2e-4, rtol=0)
+    np.testing.assert_allclose(sum(float(k.sum()) for k in kls), float((klA + klB + klC).sum().detach()), rtol=2e-5)
+    grads = [{}, {}, {}]
+    ones = torch.ones(B, device="cuda")
+    d = dev(d_out)
+    for i in (0, 1, 2):                                               # backward of the down pass, bottom layer first
+        d = layers[i].down_backward(d, ones, dps[i], grads[i])
+    d_h_top = d.sum(dim=0, keepdim=True)
+    d = torch.zeros(B, hs, 8, 8, device="cuda")                       # the top of the up pass feeds nothing else
+    for i in (2, 1, 0):
+        d = layers[i].up_backward(d, dps[i], grads[i])
+    assert _relerr(host(d_h_top), ht.grad.numpy()) < 1e-4
+    assert _relerr(host(d), xt.grad.numpy()) < 1e-4
+    for gi_, P, nm in ((grads[0], PA, "A"), (grads[1], PB, "B"), (grads[2], PC, "C")):
+        assert sorted(gi_) == sorted(P)
+        # (the top layer's up-pass output feeds nothing, tf_train.py:186: autograd leaves its up_conv3 gradients unset, the
+        # engine writes the zeros they are)
+        ref = {k: (P[k].grad.numpy() if P[k].grad is not None else np.zeros(tuple(P[k].shape))) for k in gi_}
+        for k in gi_:
+            if not np.any(ref[k]):
+                assert not np.any(host(gi_[k])), (nm, k)
+        worst = max((_relerr(host(gi_[k]), ref[k]), k) for k in gi_ if np.any(ref[k]))
+        assert worst[0] < 2e-4, (nm,) + worst
+
+
 def test_deferred_weightnorm_backward_equals_immediate(amd):
     """two layers of different spatial size: backward with the weight-norm pass deferred to ONE batched launch per kind
     must give exactly the gradients of the per-layer launches"""
