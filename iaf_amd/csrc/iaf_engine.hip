@@ -816,13 +816,14 @@ static int run_stack_generic(iaf_stack_t* s, const ConvP& base, int first_inmode
     return (int)hipGetLastError();
 }
 
-// The whole step in one launch (iaf_step_fused.hpp): TF statement, bf16x3 precision, a compiled geometry for (n_h, n_z,
-// depth_ar, W) -- everything else takes the layer-by-layer path.  Output rows per workgroup: 2 at 16 pixels per row; at 8,
+// The whole step in one launch (iaf_step_fused.hpp): bf16x3 precision, a compiled geometry for (n_h, n_z, depth_ar, W) --
+// everything else takes the layer-by-layer path.  All three statements of the operator (the Theano one runs on the image
+// rotated by 180 degrees, where its taps are the TF ones).  Output rows per workgroup: 2 at 16 pixels per row; at 8,
 // one row while that still leaves fewer than two workgroups per CU (less halo recompute per row otherwise).
 static step_fn_t fused_step_plan(const iaf_stack_t* s, int B, int H, int W, int* R, size_t* lds) {
     static const int env = getenv("IAF_FUSE_STEP") ? atoi(getenv("IAF_FUSE_STEP")) : -1;       // dev knob: 0 / 1
     const int mode = env >= 0 ? env : s->fuse_step;
-    if (!mode || s->generic || s->variant != IAF_VARIANT_TF || s->precision != IAF_PRECISION_BF16X3) return nullptr;
+    if (!mode || s->generic || s->precision != IAF_PRECISION_BF16X3) return nullptr;
     if (s->depth_ar < 1 || s->depth_ar > 2 || (s->n_h & 15) || (s->n_z & 15)) return nullptr;
     if (s->fuse_first == 1) return nullptr;                  // the caller asked for the layer-by-layer variant with a fused first conv
     for (int l = 0; l < s->nlayers; ++l)                      // ... or pinned a per-layer launch shape: the layer-by-layer path is meant
@@ -855,6 +856,9 @@ static int launch_fused_step(iaf_stack_t* s, step_fn_t fn, int R, size_t lds, co
     q.qm = base.qm; q.ql = base.ql; q.rm = base.rm; q.rl = base.rl; q.pm = base.pm; q.pl = base.pl; q.eps = base.eps;
     q.B = base.B; q.H = base.H; q.HW = base.HW; q.mode = base.mode;
     q.nrb = (base.H + R - 1) / R;
+    q.flip = (s->variant == IAF_VARIANT_THEANO) ? 1 : 0;       // its taps look left / above: the TF geometry on the rotated image
+    if (s->variant != IAF_VARIANT_TF)
+        for (int l = 0; l < s->nlayers; ++l) q.border[l] = s->L[l].border;
     q.dbg = (s->dbg_layer == -2) ? s->dbg : nullptr;
     { int rc = raise_lds_cap((const void*)fn, lds); if (rc) return rc; }
     const bool prof = (s->prof_layer == -2 && s->prof_n < s->prof_cap);

@@ -81,6 +81,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int pl = lane & 15, kk = lane >> 4;
     const int b = blockIdx.x / p.nrb, r0 = (blockIdx.x - b * p.nrb) * R;
     const int H = p.H, HW = p.HW;
+    // pixel offset inside the image of position (image row ir, column col) of the space the kernel computes in
+    auto gpix = [&](int ir, int col) -> size_t { return p.flip ? (size_t)(H - 1 - ir) * W + (W - 1 - col) : (size_t)ir * W + col; };
+    // sum of the border-indicator weights of the taps that leave the image at (ir, col): taps (0,1) (1,-1) (1,0) (1,1)
+    auto border_terms = [&](const float* bt, int cstride, int ch, int ir, int col) -> f32x4 {
+        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+        const bool last_row = ir == H - 1, c0 = col == 0, cl = col == W - 1;
+        if (cl) a += *(const f32x4*)(bt + 0 * cstride + ch);
+        if (last_row || c0) a += *(const f32x4*)(bt + 1 * cstride + ch);
+        if (last_row) a += *(const f32x4*)(bt + 2 * cstride + ch);
+        if (last_row || cl) a += *(const f32x4*)(bt + 3 * cstride + ch);
+        return a;
+    };
 #define IAF_FSTAMP(k) do { if (p.dbg && tid == 0) p.dbg[(size_t)blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
     IAF_FSTAMP(0);
 
@@ -124,7 +136,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int q = ic / NPX, px = ic - q * NPX;                 // pixel fastest: coalesced along a row
         const int row = px / W, col = px - row * W;
         const int rr = r0 + row < H ? r0 + row : H - 1;            // rows past the image: a valid address, zeroed below
-        const size_t gb = ((size_t)b * NZ + 4 * q) * HW + (size_t)rr * W + col;
+        const size_t gb = ((size_t)b * NZ + 4 * q) * HW + gpix(rr, col);
         if (p.z) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) zv[u][r] = p.z[gb + (size_t)r * HW];
@@ -157,9 +169,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int c = ic / CG, g4 = (ic - c * CG) * 4;
             cv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (p.ctx && g4 < vpx) {
-                const size_t gi = ((size_t)b * NH + c) * HW + (size_t)r0 * W + g4;
-                cv[u] = *(const f32x4*)(p.ctx + gi);
-                if (p.ctx2) cv[u] += *(const f32x4*)(p.ctx2 + gi);
+                const int row = g4 / W, col4 = g4 - row * W;           // 4 consecutive columns of one row
+                const size_t gi = ((size_t)b * NH + c) * HW + (p.flip ? gpix(r0 + row, col4 + 3) : gpix(r0 + row, col4));
+                f32x4 t = *(const f32x4*)(p.ctx + gi);
+                if (p.ctx2) t += *(const f32x4*)(p.ctx2 + gi);
+                cv[u] = p.flip ? f32x4{t[3], t[2], t[1], t[0]} : t;
             }
         }
     }
@@ -288,7 +302,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int j = 0; j < NTWH; ++j) bi[j] = *(const f32x4*)(bias + (htile[j] < NHT ? htile[j] : NHT - 1) * 16 + 4 * kk);
     };
     auto hidden_epilogue = [&](auto npt_c, auto rows_c, auto emask_c, auto ctx_c, f32x4 (*acc)[NTWH], const f32x4* bias, int out_reg,
-                               float* hsave) {
+                               float* hsave, const float* bt) {
         constexpr int NPT = decltype(npt_c)::value, ROWS = decltype(rows_c)::value, EMASK = decltype(emask_c)::value;
         constexpr bool WITH_CTX = decltype(ctx_c)::value != 0;
         f32x4 cxv[WITH_CTX ? NPT : 1][NTWH];                     // all context reads in flight together, ahead of the arithmetic
@@ -316,6 +330,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 if (pix >= ROWS * W) continue;
                 const int row = pix / W, col = pix - row * W;
                 f32x4 v = acc[q][j] + bi;
+                if (bt && r0 + row < H) v += border_terms(bt, NH, htile[j] * 16 + 4 * kk, r0 + row, col);     // conv.py:71-83
                 if constexpr (WITH_CTX) v += cxv[q][j];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = elu_f(v[r]);
@@ -323,7 +338,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 bf3_store4(smem + (size_t)out_reg * 16, row * RS + col + 1, htile[j] * 4 + kk, v, H16, H8);
                 // training: the rows this workgroup OWNS (not its halo) go to HBM for the backward pass
                 if (hsave && row < R && r0 + row < H)
-                    *(f32x4*)(hsave + ((size_t)b * HW + (size_t)(r0 + row) * W + col) * NH + htile[j] * 16 + 4 * kk) = v;
+                    *(f32x4*)(hsave + ((size_t)b * HW + gpix(r0 + row, col)) * NH + htile[j] * 16 + 4 * kk) = v;
             }
         }
     };
@@ -370,7 +385,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         IAF_FSTAMP(7);
 #endif
         hidden_epilogue(std::integral_constant<int, NPT0>{}, std::integral_constant<int, G::rows_h(0)>{},
-                        std::integral_constant<int, EM0>{}, std::integral_constant<int, 1>{}, acc0, bi0, G::HREG0, p.hsave[0]);
+                        std::integral_constant<int, EM0>{}, std::integral_constant<int, 1>{}, acc0, bi0, G::HREG0, p.hsave[0], p.border[0]);
     });
     __syncthreads();
     IAF_FSTAMP(2);
@@ -397,7 +412,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
             preload_out();
             hidden_epilogue(std::integral_constant<int, NPT1>{}, std::integral_constant<int, G::rows_h(1)>{},
-                            std::integral_constant<int, EM1>{}, std::integral_constant<int, 0>{}, acc1, bi1, G::HREG1, p.hsave[1]);
+                            std::integral_constant<int, EM1>{}, std::integral_constant<int, 0>{}, acc1, bi1, G::HREG1, p.hsave[1], p.border[1]);
         });
         __syncthreads();
     }
@@ -415,7 +430,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int ic = idx < NZ * R * W ? idx : NZ * R * W - 1;
         const int c = ic / (R * W), pix = ic - c * (R * W);
         const int rr = r0 + pix / W < H ? r0 + pix / W : H - 1;
-        const size_t gi = ((size_t)b * NZ + c) * HW + (size_t)rr * W + (pix & (W - 1));
+        const size_t gi = ((size_t)b * NZ + c) * HW + gpix(rr, pix & (W - 1));
         const int cm = (c >> 4) * 32 + (c & 15);
         fb[e][0] = p.bias[DEPTH][cm]; fb[e][1] = p.bias[DEPTH][cm + 16];
         fz[e] = 0.f;
@@ -453,9 +468,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int c = idx / (R * W), pix = idx - c * (R * W);
         const int row = pix / W;
         if (r0 + row >= H) continue;
-        const size_t gi = ((size_t)b * NZ + c) * HW + (size_t)r0 * W + pix;
+        const size_t gi = ((size_t)b * NZ + c) * HW + gpix(r0 + row, pix - row * W);
         const int cm = (c >> 4) * 32 + (c & 15);
         float m_raw = fb[e][0], s_raw = fb[e][1];
+        if (p.border[DEPTH]) {                                   // the border channel of the output pair's own input
+            const float* bt = p.border[DEPTH];
+            const int col = pix - row * W;
+            const bool last_row = r0 + row == H - 1, c0 = col == 0, cl = col == W - 1;
+            const float w1 = cl ? 1.f : 0.f, w2 = (last_row || c0) ? 1.f : 0.f, w3 = last_row ? 1.f : 0.f, w4 = (last_row || cl) ? 1.f : 0.f;
+            m_raw += w1 * bt[cm] + w2 * bt[2 * NZ + cm] + w3 * bt[4 * NZ + cm] + w4 * bt[6 * NZ + cm];
+            s_raw += w1 * bt[cm + 16] + w2 * bt[2 * NZ + cm + 16] + w3 * bt[4 * NZ + cm + 16] + w4 * bt[6 * NZ + cm + 16];
+        }
 #pragma unroll
         for (int k = 0; k < OKS; ++k) {
             m_raw += xbuf[k * (R * W * G::XB_STRIDE) + pix * G::XB_STRIDE + cm];

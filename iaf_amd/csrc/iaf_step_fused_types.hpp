@@ -14,6 +14,12 @@ struct StepP {
     float* kl_elem;
     const float* qm; const float* ql; const float* rm; const float* rl; const float* pm; const float* pl; const float* eps;
     int B, H, HW, mode, nrb;   // nrb = ceil(H / R) row blocks per image
+    // The Theano statement of the operator (graphy/nodes/ar.py + conv.py): its taps look left / above -- the TF geometry on
+    // the image rotated by 180 degrees, so `flip` makes every global access go through (H-1-row, W-1-col) and nothing else
+    // changes; border[l] = [4][packed c_out of layer l] weights of the border-indicator channel (taps 1..4), added where a
+    // tap leaves the image (NULL for the TF statement)
+    int flip;
+    const float* border[4];
     unsigned long long* dbg;   // dev tool: per-workgroup cycle stamps [grid][8]
 };
 

@@ -247,7 +247,8 @@ int iaf_stack_set_fuse_first(iaf_stack_t* s, int mode);
 /* The whole IAF step (tf_train.py:69-72, or the posterior block's tf_train.py:56-75) as ONE launch: a workgroup owns R
  * full-width rows of one image and computes every masked conv of the stack for them, hidden activations in LDS, the
  * halo rows recomputed (the masked convs look only right and below, so no other workgroup is involved).  mode 1 (default):
- * wherever a compiled geometry covers the problem -- TF statement, bf16x3 precision, (n_h, n_z, depth_ar) = (160, 32, 2)
+ * wherever a compiled geometry covers the problem -- any of the three statements of the operator (the Theano one runs on the
+ * image rotated by 180 degrees, where its taps are the TF ones), bf16x3 precision, (n_h, n_z, depth_ar) = (160, 32, 2)
  * or (64, 32, 1), images 16, 8 or 4 pixels wide; everything else, and any stack with a pinned per-layer launch shape
  * (iaf_stack_set_tuning*, fuse_first = 1), takes the layer-by-layer path.  mode 0: never; mode 2: wherever a geometry
  * covers it, whatever the size rule or a measurement says.  Same arithmetic as the

@@ -56,7 +56,8 @@ def test_where_the_step_runs_as_one_launch(amd):
     assert st.step_is_fused(32, 32, 32) == 0                     # no compiled geometry for 32-pixel rows
     assert amd.ARStack(32, [64]).step_is_fused(16, 16, 16) == 2   # BASELINE configs[0]
     assert amd.ARStack(64, [192] * 4).step_is_fused(32, 16, 16) == 0
-    assert amd.ARStack(32, [160, 160], variant="theano").step_is_fused(32, 16, 16) == 0
+    assert amd.ARStack(32, [160, 160], variant="theano").step_is_fused(32, 16, 16) == 2           # all three statements
+    assert amd.ARStack(32, [160, 160], variant="theano_flipmask").step_is_fused(32, 8, 8) == 1
     st.set_fuse_step("never")
     assert st.step_is_fused(32, 16, 16) == 0
     st.set_fuse_step("auto")
@@ -192,3 +193,47 @@ def test_repeated_launches_are_deterministic(amd):
     for _ in range(200):
         z1, s1 = st.iaf_step(zd, cd)
         assert torch.equal(z1, z0) and torch.equal(s1, s0)
+
+
+def _theano_params(rng, name, n_z, n_h_list):
+    w, sizes = {}, [n_z] + n_h_list
+    for i in range(len(n_h_list)):
+        w["%s_%d_w" % (name, i)] = 0.05 * rng.standard_normal((sizes[i + 1], sizes[i] + 1, 3, 3))
+        w["%s_%d_b" % (name, i)] = 0.1 * rng.standard_normal(sizes[i + 1])
+        w["%s_%d_s" % (name, i)] = 0.1 * rng.standard_normal(sizes[i + 1])
+    for i in range(2):
+        w["%s_out_%d_w" % (name, i)] = 0.05 * rng.standard_normal((n_z, sizes[-1] + 1, 3, 3))
+        w["%s_out_%d_b" % (name, i)] = 0.1 * rng.standard_normal(n_z)
+        w["%s_out_%d_s" % (name, i)] = 0.1 * rng.standard_normal(n_z)
+    return w
+
+
+@pytest.mark.parametrize("flip", [False, True], ids=["plain", "flipmask"])
+@pytest.mark.parametrize("cfg", [(32, 32, 160, 2, 16, 16), (5, 32, 160, 2, 8, 8), (3, 32, 160, 2, 5, 16), (16, 32, 64, 1, 16, 16),
+                                 (4, 32, 64, 1, 7, 8), (6, 32, 64, 1, 4, 4)], ids=lambda s: "B%d_z%d_h%d_d%d_%dx%d" % s)
+def test_theano_statement_through_the_one_launch_step(amd, cfg, flip):
+    """graphy/nodes/ar.py's statement (flipped kernel: taps look left / above; border-indicator channel; exp(3s), +1e-8)
+    runs the same launch on the image rotated by 180 degrees, the border channel as an epilogue term; flipmask=True keeps the
+    TF geometry.  Raw outputs and the up/down_iaf2_nl step (models.py:168-175) vs the oracle, and vs the layer-by-layer path."""
+    B, n_z, n_h, d, H, W = cfg
+    rng = np.random.RandomState(640 + H + W + (3 if flip else 0))
+    w = _theano_params(rng, "q", n_z, [n_h] * d)
+    z, ctx = rng.standard_normal((B, n_z, H, W)), rng.standard_normal((B, n_h, H, W))
+    variant = "theano_flipmask" if flip else "theano"
+    one, lbl = amd.ARStack(n_z, [n_h] * d, variant=variant), amd.ARStack(n_z, [n_h] * d, variant=variant)
+    lbl.set_fuse_step("never")
+    rel = {k[2:]: dev(v) for k, v in w.items()}
+    one.prepare(rel)
+    lbl.prepare(rel)
+    assert one.step_is_fused(B, H, W) > 0 and lbl.step_is_fused(B, H, W) == 0
+    w32 = {k: f32(v) for k, v in w.items()}
+    m_raw, s_raw = one.ar_multiconv2d(dev(z), dev(ctx))
+    em, es = O.theano_multiconv2d(f32(z), f32(ctx), w32, "q", n_z, [n_h] * d, [n_z, n_z], flipmask=flip)
+    np.testing.assert_allclose(host(m_raw), em, atol=ATOL, rtol=0)
+    np.testing.assert_allclose(host(s_raw), es, atol=ATOL, rtol=0)
+    z_new, logsd = one.iaf_step(dev(z), dev(ctx))
+    ez, el = O.theano_iaf2_nl(f32(z), f32(ctx), w32, "q", n_z, [n_h] * d, flipmask=flip)
+    np.testing.assert_allclose(host(z_new), ez, atol=ATOL, rtol=0)
+    np.testing.assert_allclose(host(logsd), el, atol=ATOL, rtol=0)
+    zb, sb = lbl.iaf_step(dev(z), dev(ctx))
+    assert float((logsd - sb).abs().max()) < 2e-6 and float((z_new - zb).abs().max()) < 3e-5
