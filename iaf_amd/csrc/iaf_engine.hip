@@ -839,7 +839,8 @@ static step_fn_t fused_step_plan(const iaf_stack_t* s, int B, int H, int W, int*
         if (s->fs_P == (long long)B * H * W && s->fs_W == W) { if (!s->fs_on) return nullptr; }      // measured for this size
         else if (W == 8 && (long long)B * H >= 1024) return nullptr;
     }
-    step_fn_t fn = iaf_pick_step_fused(s->n_h / 16, s->n_z / 16, s->depth_ar, W, *R, lds);
+    const int var = s->variant == IAF_VARIANT_TF ? 0 : s->variant == IAF_VARIANT_THEANO ? 1 : 2;
+    step_fn_t fn = iaf_pick_step_fused(s->n_h / 16, s->n_z / 16, s->depth_ar, W, *R, var, lds);
     if (!fn || *lds > 160 * 1024) return nullptr;
     return fn;
 }
@@ -856,8 +857,7 @@ static int launch_fused_step(iaf_stack_t* s, step_fn_t fn, int R, size_t lds, co
     q.qm = base.qm; q.ql = base.ql; q.rm = base.rm; q.rl = base.rl; q.pm = base.pm; q.pl = base.pl; q.eps = base.eps;
     q.B = base.B; q.H = base.H; q.HW = base.HW; q.mode = base.mode;
     q.nrb = (base.H + R - 1) / R;
-    q.flip = (s->variant == IAF_VARIANT_THEANO) ? 1 : 0;       // its taps look left / above: the TF geometry on the rotated image
-    if (s->variant != IAF_VARIANT_TF)
+    if (s->variant != IAF_VARIANT_TF)                          // (the kernel variant was picked with the statement)
         for (int l = 0; l < s->nlayers; ++l) q.border[l] = s->L[l].border;
     q.dbg = (s->dbg_layer == -2) ? s->dbg : nullptr;
     { int rc = raise_lds_cap((const void*)fn, lds); if (rc) return rc; }

@@ -67,9 +67,13 @@ constexpr int fused_extra_mask(int npt, int gn, int g) {
     return m;
 }
 
-template <int NHT, int NZT, int DEPTH, int W, int R>
+// VAR: the statement of the operator -- 0 TF, 1 Theano (image rotated by 180 degrees + border channel), 2 Theano with
+// flipmask=True (TF geometry + border channel).  Compile time: as run-time flags these cost the TF path ~1 us per launch
+// (branches around the border loads split the epilogue's basic blocks).
+template <int NHT, int NZT, int DEPTH, int W, int R, int VAR = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void iaf_step_fused_kernel(StepP p) {
     typedef StepGeom<NHT, NZT, DEPTH, W, R> G;
+    constexpr bool FLIP = (VAR == 1), BORDER = (VAR != 0);
     static_assert(DEPTH >= 1 && DEPTH <= 2, "hidden regions ping-pong between two LDS buffers holding h_0 and h_1");
     static_assert((W & (W - 1)) == 0 && W <= 16, "full-width rows of 4, 8 or 16 pixels");
     extern __shared__ __attribute__((aligned(16))) f32x4 smem4[];
@@ -82,7 +86,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int b = blockIdx.x / p.nrb, r0 = (blockIdx.x - b * p.nrb) * R;
     const int H = p.H, HW = p.HW;
     // pixel offset inside the image of position (image row ir, column col) of the space the kernel computes in
-    auto gpix = [&](int ir, int col) -> size_t { return p.flip ? (size_t)(H - 1 - ir) * W + (W - 1 - col) : (size_t)ir * W + col; };
+    // ((H-1-ir) W + (W-1-col) = HW-1 - (ir W + col))
+    auto gpix = [&](int ir, int col) -> size_t { return FLIP ? (size_t)(HW - 1 - (ir * W + col)) : (size_t)(ir * W + col); };
     // sum of the border-indicator weights of the taps that leave the image at (ir, col): taps (0,1) (1,-1) (1,0) (1,1)
     auto border_terms = [&](const float* bt, int cstride, int ch, int ir, int col) -> f32x4 {
         f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -170,10 +175,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             cv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (p.ctx && g4 < vpx) {
                 const int row = g4 / W, col4 = g4 - row * W;           // 4 consecutive columns of one row
-                const size_t gi = ((size_t)b * NH + c) * HW + (p.flip ? gpix(r0 + row, col4 + 3) : gpix(r0 + row, col4));
-                f32x4 t = *(const f32x4*)(p.ctx + gi);
-                if (p.ctx2) t += *(const f32x4*)(p.ctx2 + gi);
-                cv[u] = p.flip ? f32x4{t[3], t[2], t[1], t[0]} : t;
+                const size_t gi = ((size_t)b * NH + c) * HW + gpix(r0 + row, col4 + (FLIP ? 3 : 0));
+                cv[u] = *(const f32x4*)(p.ctx + gi);       // (column order fixed up at store time: touching the value here would
+                if (p.ctx2) cv[u] += *(const f32x4*)(p.ctx2 + gi);   //  make every load wait for the one before)
             }
         }
     }
@@ -211,7 +215,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int idx = tid + u * 256;
             if (idx < NCIT) {
                 const int c = idx / CG, g4 = (idx - c * CG) * 4;
-                *(f32x4*)(creg + c * CSTR + g4) = cv[u];
+                constexpr bool fl = FLIP;                        // rotated image: the 4 columns arrived in reverse order
+                *(f32x4*)(creg + c * CSTR + g4) = f32x4{fl ? cv[u][3] : cv[u][0], fl ? cv[u][2] : cv[u][1], fl ? cv[u][1] : cv[u][2],
+                                                        fl ? cv[u][0] : cv[u][3]};
             }
         }
     };
@@ -330,7 +336,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 if (pix >= ROWS * W) continue;
                 const int row = pix / W, col = pix - row * W;
                 f32x4 v = acc[q][j] + bi;
-                if (bt && r0 + row < H) v += border_terms(bt, NH, htile[j] * 16 + 4 * kk, r0 + row, col);     // conv.py:71-83
+                if constexpr (BORDER) { if (r0 + row < H) v += border_terms(bt, NH, htile[j] * 16 + 4 * kk, r0 + row, col); }   // conv.py:71-83
                 if constexpr (WITH_CTX) v += cxv[q][j];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = elu_f(v[r]);
@@ -471,7 +477,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const size_t gi = ((size_t)b * NZ + c) * HW + gpix(r0 + row, pix - row * W);
         const int cm = (c >> 4) * 32 + (c & 15);
         float m_raw = fb[e][0], s_raw = fb[e][1];
-        if (p.border[DEPTH]) {                                   // the border channel of the output pair's own input
+        if constexpr (BORDER) {                                  // the border channel of the output pair's own input
             const float* bt = p.border[DEPTH];
             const int col = pix - row * W;
             const bool last_row = r0 + row == H - 1, c0 = col == 0, cl = col == W - 1;

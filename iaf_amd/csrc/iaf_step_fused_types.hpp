@@ -15,14 +15,14 @@ struct StepP {
     const float* qm; const float* ql; const float* rm; const float* rl; const float* pm; const float* pl; const float* eps;
     int B, H, HW, mode, nrb;   // nrb = ceil(H / R) row blocks per image
     // The Theano statement of the operator (graphy/nodes/ar.py + conv.py): its taps look left / above -- the TF geometry on
-    // the image rotated by 180 degrees, so `flip` makes every global access go through (H-1-row, W-1-col) and nothing else
-    // changes; border[l] = [4][packed c_out of layer l] weights of the border-indicator channel (taps 1..4), added where a
-    // tap leaves the image (NULL for the TF statement)
-    int flip;
+    // the image rotated by 180 degrees, so that variant of the kernel sends every global access through (H-1-row, W-1-col) and
+    // nothing else changes; border[l] = [4][packed c_out of layer l] weights of the border-indicator channel (taps 1..4), added
+    // where a tap leaves the image (Theano variants only)
     const float* border[4];
     unsigned long long* dbg;   // dev tool: per-workgroup cycle stamps [grid][8]
 };
 
 typedef void (*step_fn_t)(StepP);
 // kernel + dynamic LDS bytes for (n_h / 16, n_z / 16, depth_ar, image width, output rows per workgroup), or NULL
-extern "C" step_fn_t iaf_pick_step_fused(int nht, int nzt, int depth, int W, int R, size_t* lds);
+// var: 0 TF statement, 1 Theano, 2 Theano with flipmask
+extern "C" step_fn_t iaf_pick_step_fused(int nht, int nzt, int depth, int W, int R, int var, size_t* lds);
