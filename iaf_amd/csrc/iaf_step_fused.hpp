@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // while both travel; z -> LDS ---------------------------------------------------------------------------------------
     constexpr int NPT0 = (G::rows_h(0) * W + 15) / 16;
     constexpr int NPX = RZ * W, NIT = NPX * (NZ / 4), ZU = (NIT + 255) / 256;
-    f32x4 zv[ZU];
+    f32x4 zv[ZU], zq[4][ZU];     // posterior input: the five tensors as raw loads, combined once all of them are on their way
 #pragma unroll
     for (int u = 0; u < ZU; ++u) {
         const int idx = tid + u * 256;
@@ -145,11 +145,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (p.z) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) zv[u][r] = p.z[gb + (size_t)r * HW];
-        } else {   // z0 = (qm+rm) + exp(ql+rl) * eps   (tf_train.py:57,63; distributions.py:21)
+        } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const size_t i = gb + (size_t)r * HW;
-                zv[u][r] = (p.qm[i] + p.rm[i]) + __expf(0.5f * (2.f * (p.ql[i] + p.rl[i]))) * p.eps[i];
+                zv[u][r] = p.qm[i]; zq[0][u][r] = p.rm[i]; zq[1][u][r] = p.ql[i]; zq[2][u][r] = p.rl[i]; zq[3][u][r] = p.eps[i];
             }
         }
     }
@@ -164,8 +164,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // context rows of this workgroup: per channel one contiguous run of CPX pixels (full-width rows) -> 16-byte loads,
     // 4 channels per wave instruction; summed with the second context here
     constexpr int CPX = G::CPX, CSTR = G::CSTR, CG = CPX / 4, NCIT = NH * CG, NCI = (NCIT + 255) / 256;
-    f32x4 cv[NCI];
-    {
+    f32x4 cv[NCI], cv2[NCI];     // raw loads: nothing consumes them before the z rows are in LDS (a use right behind a load
+    {                            // would make every load wait for the one before)
         const int vpx = (H - r0) * W < CPX ? (H - r0) * W : CPX;       // pixels of those rows that lie inside the image
 #pragma unroll
         for (int u = 0; u < NCI; ++u) {
@@ -173,11 +173,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int ic = idx < NCIT ? idx : NCIT - 1;
             const int c = ic / CG, g4 = (ic - c * CG) * 4;
             cv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            cv2[u] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (p.ctx && g4 < vpx) {
                 const int row = g4 / W, col4 = g4 - row * W;           // 4 consecutive columns of one row
                 const size_t gi = ((size_t)b * NH + c) * HW + gpix(r0 + row, col4 + (FLIP ? 3 : 0));
-                cv[u] = *(const f32x4*)(p.ctx + gi);       // (column order fixed up at store time: touching the value here would
-                if (p.ctx2) cv[u] += *(const f32x4*)(p.ctx2 + gi);   //  make every load wait for the one before)
+                cv[u] = *(const f32x4*)(p.ctx + gi);       // (column order fixed up at store time)
+                if (p.ctx2) cv2[u] = *(const f32x4*)(p.ctx2 + gi);
             }
         }
     }
@@ -200,10 +201,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if (idx < NIT) {
                 const int q = idx / NPX, px = idx - q * NPX;
                 const int row = px / W, col = px - row * W;
-                const f32x4 v = r0 + row < H ? zv[u] : f32x4{0.f, 0.f, 0.f, 0.f};
+                f32x4 v = zv[u];
+                if (!p.z) {      // z0 = (qm+rm) + exp(ql+rl) * eps   (tf_train.py:57,63; distributions.py:21)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        v[r] = (zv[u][r] + zq[0][u][r]) + __expf(0.5f * (2.f * (zq[1][u][r] + zq[2][u][r]))) * zq[3][u][r];
+                }
+                if (r0 + row >= H) v = f32x4{0.f, 0.f, 0.f, 0.f};
                 bf3_store4(smem + (size_t)G::ZREG * 16, row * RS + col + 1, q, v, Z16, Z8);
             }
         }
+    }
+    if (p.ctx2) {                // up_context + down_context (tf_train.py:58), now that both have had the z staging to arrive
+#pragma unroll
+        for (int u = 0; u < NCI; ++u) cv[u] += cv2[u];
     }
     __syncthreads();
     IAF_FSTAMP(1);
