@@ -389,7 +389,7 @@ def train_bench(args, depths, dist, rank, n_gpus):
             "metric": "IAF posterior-stack TRAIN-step samples/sec (forward + backward + grad all-reduce + Adamax/EMA)",
             "value": n_gpus * args.batch / (elapsed / args.steps), "unit": "samples/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "f32 (forward convs: operands split into 3 bf16 parts, 6 part-products on the bf16 MFMA, fp32 accumulate: fp32-grade error; backward: exact fp32 MFMA)", "data": "synthetic",
             "config": {"workload": "cifar10 n_z=%d n_h=%d depths=%s depth_ar=%d down_iaf2_nl bs=%d per GPU, kl_min=0.25; "
                                    "%d trainable fp32 parameters in one flat gradient buffer (%.1f MB)"
                                    % (args.n_z, args.n_h, depths, args.depth_ar, args.batch, flat.params.numel(),
@@ -429,6 +429,8 @@ def layers_bench(args, depths, dist, rank, n_gpus):
                 p["ar_multiconv2d/" + k] = dev(v)
             layer = iaf_amd.IAFLayer(zs, hs, depth_ar=args.depth_ar, kl_min=0.25, downsample=ds)
             layer.posterior.stack.set_precision(args.precision)
+            for cvx in layer.convs():
+                cvx.set_precision(args.precision)
             layer.load(p)
             L.append(dict(layer=layer, params=p, eps=dev(rng.standard_normal((B, zs, H, H)))))
         levels.append(dict(H=H, layers=L))
@@ -536,7 +538,7 @@ def layers_bench(args, depths, dist, rank, n_gpus):
         "metric": "IAFLayer forward samples/sec (up + down of every layer: 4 plain weight-normed convs + IAF posterior block)",
         "value": n_gpus * B / (elapsed / args.steps), "unit": "samples/s", "n_gpus": n_gpus, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "f32 (forward convs: operands split into 3 bf16 parts, 6 part-products on the bf16 MFMA, fp32 accumulate: fp32-grade error; backward: exact fp32 MFMA)", "data": "synthetic",
         "config": {"workload": "cifar10 z_size=%d h_size=%d depths=%s depth_ar=%d bs=%d per GPU, kl_min=0.25: %d IAFLayers "
                                "(tf_train.py:23-95) as one connected model -- up pass 16x16 -> %dx%d through the downsampling "
                                "layer of each coarser level, then the down pass back"
@@ -548,7 +550,10 @@ def layers_bench(args, depths, dist, rank, n_gpus):
                    "parallelism": "dp%d (batch-sharded replicas, no forward collective)" % n_gpus},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                     "kernel": "iaf_conv_kernel<.., EPI_PLAIN, 9 taps> (down_conv1 %d->%d, B=%d 16x16)" % (cv.n_in, cv.n_out, B),
+                     "kernel": "%s<.., EPI_PLAIN, 9 taps> (down_conv1 %d->%d, B=%d 16x16)" % (
+                         "iaf_conv_bf3_kernel" if cv.runs_bf16x3(B, 16, 16) else "iaf_conv_kernel", cv.n_in, cv.n_out, B),
+                     "dominant_kernel_family": "bf16x3" if cv.runs_bf16x3(B, 16, 16) else "f32",
+                     "frac_of_bf16x3_peak": (achieved / PEAK_BF16X3_TFLOPS) if cv.runs_bf16x3(B, 16, 16) else None,
                      "avg_launch_us": 1e3 * k_ms, "launches_timed": 50 * len(kt), "flops_per_launch": fl,
                      "bytes_per_launch": by, "hbm_frac_at_this_rate": (by / (k_ms * 1e-3) / 1e9) / PEAK_HBM_GBS,
                      "timing": "HIP events on the launch stream around 50 back-to-back launches per 16x16 layer"}})
@@ -581,6 +586,9 @@ def layers_train_bench(args, depths, dist, rank, n_gpus):
             for k, v in gi.ar_multiconv2d_params(wrng, zs, [hs] * args.depth_ar, [zs, zs]).items():
                 host[pre + "ar_multiconv2d/" + k] = v
             layer = iaf_amd.IAFLayer(zs, hs, depth_ar=args.depth_ar, kl_min=0.25)
+            layer.posterior.stack.set_precision(args.precision)
+            for cvx in layer.convs():
+                cvx.set_precision(args.precision)
             layer.set_training(True)
             L.append(dict(layer=layer, pre=pre, eps=dev(rng.standard_normal((B, zs, H, H)))))
         f = lambda: dev(rng.standard_normal((B, hs, H, H)))
@@ -692,7 +700,7 @@ def layers_train_bench(args, depths, dist, rank, n_gpus):
             "metric": "IAFLayer TRAIN-step samples/sec (forward + backward of every layer + grad all-reduce + Adamax/EMA)",
             "value": n_gpus * B / (elapsed / args.steps), "unit": "samples/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "f32 (forward convs: operands split into 3 bf16 parts, 6 part-products on the bf16 MFMA, fp32 accumulate: fp32-grade error; backward: exact fp32 MFMA)", "data": "synthetic",
             "config": {"workload": "cifar10 z_size=%d h_size=%d depths=%s depth_ar=%d bs=%d per GPU, kl_min=0.25: %d "
                                    "non-downsampling IAFLayers; %d trainable fp32 parameters in one flat gradient buffer (%.1f MB)"
                                    % (zs, hs, depths, args.depth_ar, B, len(all_layers), flat.params.numel(),

@@ -19,6 +19,7 @@ LIBDIR = os.path.join(HERE, "_lib" + ("_" + _TAG if _TAG else ""))
 OBJDIR = os.path.join(LIBDIR, "obj")
 OUT = os.path.join(LIBDIR, "libiaf_hip.so")
 SHAPES = [(4, 1, 1), (4, 1, 2), (2, 2, 1), (2, 2, 2), (2, 1, 2), (2, 1, 4), (1, 1, 4), (1, 2, 2)]   # keep in sync with pick_kernel()
+BF3_PLAIN_SHAPES = [(2, 1, 4, 1), (4, 1, 4, 1), (2, 1, 4, 2)]   # 9-tap plain convs: keep in sync with pick_bf3_plain()
 BF3_SHAPES = [(4, 1, 4, 1), (2, 1, 4, 1), (1, 1, 4, 1), (1, 4, 1, 1), (2, 1, 4, 2), (1, 1, 4, 2)]   # (ppw, pxt, ks, wco): keep in sync with pick_bf3()
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 CFLAGS += os.environ.get("IAF_EXTRA_CFLAGS", "").split()       # dev experiments only (e.g. -DIAF_EXP_NOREFILL)
@@ -33,6 +34,9 @@ def _units():
                       ["-DIAF_PXT=%d" % pxt, "-DIAF_WCO=%d" % wco, "-DIAF_KS=%d" % ks]))
     for ppw, pxt, ks, wco in BF3_SHAPES:
         units.append((os.path.join(CSRC, "iaf_conv_bf3_inst.hip"), os.path.join(OBJDIR, "iaf_bf3_%d_%d_%d_%d.o" % (ppw, pxt, ks, wco)),
+                      ["-DIAF_PPW=%d" % ppw, "-DIAF_PXT=%d" % pxt, "-DIAF_KS=%d" % ks, "-DIAF_WCO=%d" % wco]))
+    for ppw, pxt, ks, wco in BF3_PLAIN_SHAPES:
+        units.append((os.path.join(CSRC, "iaf_conv_bf3_plain_inst.hip"), os.path.join(OBJDIR, "iaf_bf3p_%d_%d_%d_%d.o" % (ppw, pxt, ks, wco)),
                       ["-DIAF_PPW=%d" % ppw, "-DIAF_PXT=%d" % pxt, "-DIAF_KS=%d" % ks, "-DIAF_WCO=%d" % wco]))
     # accumulators in architectural VGPRs: left to itself the register allocator puts them in AGPRs and rotates them through
     # VGPR copies inside the K loop (48 v_accvgpr moves per 162 MFMAs)

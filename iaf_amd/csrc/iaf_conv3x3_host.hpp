@@ -18,6 +18,9 @@ struct iaf_conv3x3 {
     PrepLayer* d_desc = nullptr;
     bool training = false;
     bool deconv = false;           // weights prepared by iaf_conv3x3_prepare_deconv (deconv2d's norm + rotated filter)
+    // forward on the bf16 matrix cores (bf16x3 split products, iaf_conv_bf3.hpp with 9 taps): plain convs with c_in % 32 == 0
+    int precision = IAF_PRECISION_BF16X3;
+    int bf3_choice = 1;            // 1 size rule, 2 the shape in L.b_* (pinned by iaf_conv3x3_autotune), 3 fp32 kernel (measured faster)
     GemmLayer T;                   // transposed problem dX = W^T dY (valid when training)
     // deferred weight-norm backward (iaf_conv3x3_wn_bwd_batch_run): the reduced dW / db partials live here, not in the
     // (shared) workspace
@@ -31,6 +34,7 @@ extern "C" int iaf_conv3x3_destroy(iaf_conv3x3_t* c) {
     if (c->L.wp) (void)hipFree(c->L.wp);
     if (c->L.bias) (void)hipFree(c->L.bias);
     if (c->L.wpt) (void)hipFree(c->L.wpt);
+    if (c->L.wp3) (void)hipFree(c->L.wp3);
     if (c->L.border) (void)hipFree(c->L.border);
     if (c->own_dW) (void)hipFree(c->own_dW);
     if (c->own_dbp) (void)hipFree(c->own_dbp);
@@ -83,6 +87,11 @@ static int conv3x3_create(iaf_conv3x3_t** out, int n_in, int n_out, int mask_mod
         iaf_conv3x3_destroy(c);
         return rc;
     }
+    if (!c->generic && mask_mode == 0 && n_in % 32 == 0 &&
+        (rc = (int)hipMalloc(&L.wp3, (size_t)(n_in / 32) * MAXTAPS * L.ncot * 3 * 64 * 16)) != 0) {      // bf16x3 pack
+        iaf_conv3x3_destroy(c);
+        return rc;
+    }
     *out = c;
     return IAF_OK;
 }
@@ -113,6 +122,7 @@ extern "C" int iaf_conv3x3_prepare(iaf_conv3x3_t* c, const float* V, const float
         memset(&P, 0, sizeof(P));
         P.V[0] = V; P.g[0] = g; P.b[0] = b; P.wp = L.wp; P.bias = L.bias; P.variant = PREP_PLAIN9;
         P.wpt = c->training ? L.wpt : nullptr;
+        P.wp3 = L.wp3;
         P.cin = L.cin; P.cout_each = L.cout; P.ncot = L.ncot; P.nchunk = L.nchunk; P.npair = 1; P.tile_begin = 0;
         HIP_TRY(hipMemcpyAsync(c->d_desc, c->h_desc, sizeof(PrepLayer), hipMemcpyHostToDevice, (hipStream_t)stream));
         hipLaunchKernelGGL(iaf_prep_plain_kernel, dim3(L.ncot), dim3(256), 0, (hipStream_t)stream, c->d_desc, (const int*)nullptr);
@@ -255,7 +265,7 @@ extern "C" int iaf_conv3x3_prep_batch_create(iaf_conv3x3_prep_batch_t** out, iaf
     for (int i = 0; i < n; ++i) {
         const GemmLayer& L = convs[i]->L;
         PrepLayer& P = b->h_layers[i];
-        P.wp = L.wp; P.bias = L.bias; P.variant = PREP_PLAIN9;
+        P.wp = L.wp; P.bias = L.bias; P.variant = PREP_PLAIN9; P.wp3 = L.wp3;
         P.cin = L.cin; P.cout_each = L.cout; P.ncot = L.ncot; P.nchunk = L.nchunk; P.npair = 1; P.tile_begin = tile;
         for (int t = 0; t < L.ncot; ++t) t2l[tile++] = i;
     }
@@ -294,17 +304,57 @@ extern "C" int iaf_conv3x3_prep_batch_run(iaf_conv3x3_prep_batch_t* b, const flo
 extern "C" int iaf_conv3x3_set_tuning(iaf_conv3x3_t* c, int nt, int pxt, int wco, int ks) {
     if (!c) return IAF_ERR_NULL;
     GemmLayer& L = c->L;
-    if (nt == 0) { L.user_tuned = false; return IAF_OK; }     // back to the automatic choice
+    if (nt == 0) { L.user_tuned = false; c->bf3_choice = 1; return IAF_OK; }     // back to the automatic choice
+    if (nt < 0) {           // a bf16x3 launch shape, as iaf_conv3x3_autotune reports it: (-nt, ppw, wco, ks), pxt = 1
+        if (c->generic || c->mask_mode || !L.wp3 || L.ncot % (-nt * wco) != 0 || !pick_bf3_plain(-nt, pxt, 1, ks, wco)) return IAF_ERR_UNSUPPORTED;
+        L.b_nt = -nt; L.b_ppw = pxt; L.b_pxt = 1; L.b_ks = ks; L.b_wco = wco;
+        c->bf3_choice = 2;
+        return IAF_OK;
+    }
     if (c->generic || !pick_kernel(nt, pxt, wco, ks, IN_NCHW, c->mask_mode ? EPI_PLAIN5 : EPI_PLAIN)) return IAF_ERR_UNSUPPORTED;
     if (L.ncot % (nt * wco) != 0 || L.nchunk < ks) return IAF_ERR_UNSUPPORTED;
     L.nt = nt; L.pxt = pxt; L.wco = wco; L.ks = ks; L.user_tuned = true;
+    c->bf3_choice = 3;      // a pinned fp32 shape means the fp32 kernel
     return IAF_OK;
 }
 
 // launch of the conv kernel for a plain / single masked conv descriptor (forward, or its transposed problem with the
 // taps mirrored for the data gradient)
+// the plain conv on the bf16 matrix cores: which shape, if any, for this size (choice: see iaf_conv3x3.bf3_choice)
+static bool conv3x3_bf3_shape(GemmLayer& L, int choice, long long P, int W) {
+    if (!L.wp3 || choice == 3) return false;
+    if (choice != 2) {                                            // size rule: worth it from ~4096 pixels on (as for the masked stack)
+        if (P < 4096) return false;
+        static const int nts[3] = {5, 4, 2};
+        L.b_nt = 0;
+        for (int nt : nts)
+            if (L.ncot % nt == 0) { L.b_nt = nt; break; }
+        if (!L.b_nt) return false;
+        L.b_ppw = 2; L.b_pxt = 1; L.b_ks = 4; L.b_wco = 1;
+    }
+    if (L.ncot % (L.b_nt * L.b_wco) != 0 || !pick_bf3_plain(L.b_nt, L.b_ppw, L.b_pxt, L.b_ks, L.b_wco)) return false;
+    return bf3_plain_lds_bytes(L.cin, W, L.b_nt, L.b_ppw, L.b_pxt, L.b_ks, L.b_wco) <= 160 * 1024;
+}
+
 static int conv3x3_launch(GemmLayer& L, ConvP& p, int epi_sel, int inmode, bool masked, bool mirror, hipStream_t st,
-                          int variant = IAF_VARIANT_TF) {
+                          int variant = IAF_VARIANT_TF, int bf3_choice = 3) {
+    if (!masked && !mirror && epi_sel == EPI_PLAIN && inmode == IN_NCHW && conv3x3_bf3_shape(L, bf3_choice, p.P, p.W)) {
+        conv_fn_t fn = pick_bf3_plain(L.b_nt, L.b_ppw, L.b_pxt, L.b_ks, L.b_wco);
+        const int tm = 16 * L.b_ppw * L.b_pxt, W = p.W;
+        p.border = nullptr; p.wp = (const float*)L.wp3; p.bias = L.bias; p.lim = nullptr;
+        for (int t = 0; t < MAXTAPS; ++t) { p.tap_dh[t] = t / 3 - 1; p.tap_dw[t] = t % 3 - 1; }       // cross-correlation, SAME
+        p.halo_before = W + 1;
+        p.nslot = tm + 2 * (W + 1);
+        p.cin = L.cin; p.cout = L.cout; p.nchunk = L.nchunk; p.ncot = L.ncot; p.cp = L.cin + 8;
+        const size_t lds = bf3_plain_lds_bytes(L.cin, W, L.b_nt, L.b_ppw, L.b_pxt, L.b_ks, L.b_wco);
+        int rc = raise_lds_cap((const void*)fn, lds);
+        if (rc) return rc;
+        dim3 grid((p.P + tm - 1) / tm, L.ncot / (L.b_nt * L.b_wco));
+        p.gx = (int)grid.x;
+        p.lds_bytes = (int)lds;
+        hipLaunchKernelGGL(fn, grid, dim3(64 * L.b_pxt * L.b_ks * L.b_wco), lds, st, p);
+        return (int)hipGetLastError();
+    }
     if (!L.user_tuned) {
         GemmLayer t = L;
         t.nt = L.t_nt; t.pxt = L.t_ppw; t.wco = L.t_pxt; t.ks = L.t_ks;
@@ -385,7 +435,23 @@ extern "C" int iaf_conv3x3_forward(iaf_conv3x3_t* c, const float* x, const float
         p.split_end[k] = ends[k < n_outs ? k : n_outs - 1];
         p.split_ptr[k] = outs[k < n_outs ? k : n_outs - 1];
     }
-    return conv3x3_launch(L, p, c->mask_mode ? EPI_PLAIN5 : EPI_PLAIN, IN_NCHW, c->mask_mode != 0, false, st, c->variant);
+    return conv3x3_launch(L, p, c->mask_mode ? EPI_PLAIN5 : EPI_PLAIN, IN_NCHW, c->mask_mode != 0, false, st, c->variant,
+                          (c->precision == IAF_PRECISION_BF16X3 && !c->deconv) ? c->bf3_choice : 3);
+}
+
+// arithmetic of the forward conv: IAF_PRECISION_BF16X3 (default: split products on the bf16 matrix cores where a launch
+// shape covers the problem, fp32-grade) or IAF_PRECISION_F32 (the exact-fp32 MFMA kernel always)
+extern "C" int iaf_conv3x3_set_precision(iaf_conv3x3_t* c, int precision) {
+    if (!c) return IAF_ERR_NULL;
+    if (precision != IAF_PRECISION_F32 && precision != IAF_PRECISION_BF16X3) return IAF_ERR_SHAPE;
+    c->precision = precision;
+    return IAF_OK;
+}
+// 1 if a forward call at this size would run the bf16x3 kernel
+extern "C" int iaf_conv3x3_runs_bf16x3(iaf_conv3x3_t* c, int B, int H, int W) {
+    if (!c || c->generic || c->mask_mode || c->deconv || c->precision != IAF_PRECISION_BF16X3) return 0;
+    GemmLayer t = c->L;
+    return conv3x3_bf3_shape(t, c->bf3_choice, (long long)B * H * W, W) ? 1 : 0;
 }
 
 extern "C" int iaf_conv3x3_autotune(iaf_conv3x3_t* c, const float* x, const float* x2, int c_split, int elu_input,
@@ -402,6 +468,7 @@ extern "C" int iaf_conv3x3_autotune(iaf_conv3x3_t* c, const float* x, const floa
     float best = 1e30f;
     int bsh[4] = {L.nt, L.pxt, L.wco, L.ks};
     int rc = IAF_OK;
+    c->bf3_choice = 3;                  // first the exact-fp32 kernel in every shape ...
     for (int si = 0; si < 8 && rc == IAF_OK; ++si)
         for (int nt = 5; nt >= 1 && rc == IAF_OK; --nt) {
             const int pxt = k_shapes[si][0], wco = k_shapes[si][1], ks = k_shapes[si][2];
@@ -424,10 +491,41 @@ extern "C" int iaf_conv3x3_autotune(iaf_conv3x3_t* c, const float* x, const floa
             (void)hipEventElapsedTime(&ms, e0, e1);
             if (ms < best) { best = ms; bsh[0] = nt; bsh[1] = pxt; bsh[2] = wco; bsh[3] = ks; }
         }
+    L.nt = bsh[0]; L.pxt = bsh[1]; L.wco = bsh[2]; L.ks = bsh[3]; L.user_tuned = true;
+    // ... and the same conv on the bf16 matrix cores, every compiled 9-tap shape
+    int bz[5] = {0, 0, 0, 0, 1};
+    if (rc == IAF_OK && L.wp3 && c->precision == IAF_PRECISION_BF16X3 && !c->mask_mode && !c->deconv) {
+        static const int nts[3] = {5, 4, 2};
+        for (int si = 0; si < N_BF3P_SHAPES && rc == IAF_OK; ++si)
+            for (int nt : nts) {
+                const int* sh = k_bf3p_shapes[si];
+                if (L.ncot % (nt * sh[3]) != 0) continue;
+                L.b_nt = nt; L.b_ppw = sh[0]; L.b_pxt = sh[1]; L.b_ks = sh[2]; L.b_wco = sh[3];
+                c->bf3_choice = 2;
+                GemmLayer t = L;
+                if (!conv3x3_bf3_shape(t, 2, (long long)B * H * W, W)) continue;
+                for (int r = 0; r < 3 && rc == IAF_OK; ++r)
+                    rc = iaf_conv3x3_forward(c, x, x2, c_split, elu_input, residual, outs, out_channels, n_outs, B, H, W, stream);
+                if (rc) break;
+                (void)hipEventRecord(e0, st);
+                for (int r = 0; r < reps && rc == IAF_OK; ++r)
+                    rc = iaf_conv3x3_forward(c, x, x2, c_split, elu_input, residual, outs, out_channels, n_outs, B, H, W, stream);
+                (void)hipEventRecord(e1, st);
+                if (rc) break;
+                if ((rc = (int)hipEventSynchronize(e1)) != 0) break;
+                float ms = 0.f;
+                (void)hipEventElapsedTime(&ms, e0, e1);
+                if (ms < best) { best = ms; bz[0] = nt; bz[1] = sh[0]; bz[2] = sh[1]; bz[3] = sh[2]; bz[4] = sh[3]; }
+            }
+        if (bz[0]) { L.b_nt = bz[0]; L.b_ppw = bz[1]; L.b_pxt = bz[2]; L.b_ks = bz[3]; L.b_wco = bz[4]; c->bf3_choice = 2; }
+        else c->bf3_choice = 3;
+    }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    L.nt = bsh[0]; L.pxt = bsh[1]; L.wco = bsh[2]; L.ks = bsh[3]; L.user_tuned = true;
-    if (best_shape) for (int i = 0; i < 4; ++i) best_shape[i] = bsh[i];
+    if (best_shape) {
+        if (bz[0]) { best_shape[0] = -bz[0]; best_shape[1] = bz[1]; best_shape[2] = bz[4]; best_shape[3] = bz[3]; }   // (-nt, ppw, wco, ks)
+        else for (int i = 0; i < 4; ++i) best_shape[i] = bsh[i];
+    }
     if (best_us) *best_us = best * 1e3f / reps;
     return rc;
 }

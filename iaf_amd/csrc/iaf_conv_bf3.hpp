@@ -56,11 +56,13 @@ __device__ __forceinline__ void bf3_store4(char* smem, int slot, int q, f32x4 v,
     *(u32x2*)(base + ((size_t)cin8 << 5)) = u32x2{l0, l1};
 }
 
-template <int NT, int PPW, int PXT, int KS, int INMODE, int EPI, int WCO = 1>
+// NTP_: taps of the filter -- the 5 live ones of a MADE-masked conv, or all 9 of a plain conv2d (EPI_PLAIN: the convs
+// around the IAF step, tf_train.py:36,41,53,93; halo on both sides of the pixel tile)
+template <int NT, int PPW, int PXT, int KS, int INMODE, int EPI, int WCO = 1, int NTP_ = NTAPS>
 __global__ __launch_bounds__(64 * PXT * KS * WCO) void iaf_conv_bf3_kernel(ConvP p) {
     extern __shared__ __attribute__((aligned(16))) f32x4 smem4[];
     char* smem = (char*)smem4;
-    constexpr int NTP = NTAPS;
+    constexpr int NTP = NTP_;
     constexpr int TM = 16 * PPW * PXT;
     constexpr int NTHREADS = 64 * PXT * KS * WCO;   // WCO co groups share ONE staged activation tile
     constexpr int RD = (PPW >= 2) ? 1 : 2;   // ring look-ahead in steps (a step is PPW*NT*6 MFMAs of 16 cycles)
@@ -75,6 +77,10 @@ __global__ __launch_bounds__(64 * PXT * KS * WCO) void iaf_conv_bf3_kernel(ConvP
                  "s"(p.nchunk), "s"(p.ncot), "s"(p.nslot), "s"(p.mode), "s"(p.halo_before));
     asm volatile("" ::"s"(p.tap_dh[0]), "s"(p.tap_dh[1]), "s"(p.tap_dh[2]), "s"(p.tap_dh[3]), "s"(p.tap_dh[4]), "s"(p.tap_dw[0]),
                  "s"(p.tap_dw[1]), "s"(p.tap_dw[2]), "s"(p.tap_dw[3]), "s"(p.tap_dw[4]));
+    if constexpr (NTP > NTAPS)
+        asm volatile("" ::"s"(p.tap_dh[5]), "s"(p.tap_dh[6]), "s"(p.tap_dh[7]), "s"(p.tap_dh[8]), "s"(p.tap_dw[5]), "s"(p.tap_dw[6]),
+                     "s"(p.tap_dw[7]), "s"(p.tap_dw[8]));
+    if constexpr (EPI == EPI_PLAIN) asm volatile("" ::"s"(p.x2), "s"(p.res), "s"(p.c_split), "s"(p.in_elu), "s"(p.nsplit));
     asm volatile("" ::"s"(p.bias), "s"(p.ctx), "s"(p.ctx2), "s"(p.y), "s"(p.zin), "s"(p.out0), "s"(p.out1), "s"(p.border));
     if constexpr (INMODE == IN_POSTERIOR || EPI == EPI_OUT)
         asm volatile("" ::"s"(p.qm), "s"(p.ql), "s"(p.rm), "s"(p.rl), "s"(p.pm), "s"(p.pl), "s"(p.eps), "s"(p.kl_elem));
@@ -172,7 +178,21 @@ __global__ __launch_bounds__(64 * PXT * KS * WCO) void iaf_conv_bf3_kernel(ConvP
                     if (Pg >= 0 && Pg < p.P) {
                         const int b = Pg / HW, ppx = Pg - b * HW;
                         const size_t gb = ((size_t)b * cin_ + 4 * q) * HW + ppx;
-                        if (!posterior) {
+                        if constexpr (EPI == EPI_PLAIN) {     // input = [elu](concat(x[:, :c_split], x2))  (tf_train.py:36,52,87-88)
+                            if (p.x2 && 4 * q >= p.c_split) {
+                                const size_t g2 = ((size_t)b * (cin_ - p.c_split) + (4 * q - p.c_split)) * HW + ppx;
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) v4[u][r] = p.x2[g2 + (size_t)r * HW];
+                            } else {
+                                const size_t g1 = p.x2 ? ((size_t)b * p.c_split + 4 * q) * HW + ppx : gb;
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) v4[u][r] = xsrc[g1 + (size_t)r * HW];
+                            }
+                            if (p.in_elu) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) v4[u][r] = elu_f(v4[u][r]);
+                            }
+                        } else if (!posterior) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) v4[u][r] = xsrc[gb + (size_t)r * HW];
                         } else {   // z0 = (qm+rm) + exp(ql+rl) * eps   (tf_train.py:57,63; distributions.py:21)
@@ -340,10 +360,10 @@ __global__ __launch_bounds__(64 * PXT * KS * WCO) void iaf_conv_bf3_kernel(ConvP
         const int sc = s < s1 ? s : s1 - 1;
         const int pair = sc / NTP, tap = sc - pair * NTP;
         int dh = p.tap_dh[0], dw = p.tap_dw[0];                      // scalar selects on kernel arguments
-        dh = tap == 1 ? p.tap_dh[1] : dh; dw = tap == 1 ? p.tap_dw[1] : dw;
-        dh = tap == 2 ? p.tap_dh[2] : dh; dw = tap == 2 ? p.tap_dw[2] : dw;
-        dh = tap == 3 ? p.tap_dh[3] : dh; dw = tap == 3 ? p.tap_dw[3] : dw;
-        dh = tap == 4 ? p.tap_dh[4] : dh; dw = tap == 4 ? p.tap_dw[4] : dw;
+        static_for<NTP - 1>([&](auto t_c) {
+            constexpr int t = decltype(t_c)::value + 1;
+            dh = tap == t ? p.tap_dh[t] : dh; dw = tap == t ? p.tap_dw[t] : dw;
+        });
         const int toff = (dh * W + dw) * s16;
         const int mask = -(int)((xvalid[q] >> tap) & 1u);              // all ones when the tap is inside the image
         return zaddr + pair * 4 + (mask & (xbase[q] + toff - zaddr));  // branch-free: a ?: here becomes control flow

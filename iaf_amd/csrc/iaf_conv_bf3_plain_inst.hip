@@ -1,0 +1,23 @@
+// iaf_conv_bf3_plain_inst.hip -- instantiates iaf_conv_bf3_kernel with all 9 taps for the plain weight-normed conv2d around
+// the IAF step (up_conv1/3, down_conv1/2, tf_train.py:36,41,53,93): NCHW input with the graph's elu / concat, EPI_PLAIN
+// epilogue (bias, split store, residual), ONE launch shape per translation unit.  Built by iaf_amd/build.py.
+#include "iaf_conv_bf3.hpp"
+
+#ifndef IAF_WCO
+#define IAF_WCO 1
+#endif
+#ifndef IAF_PPW
+#error "compile with -DIAF_PPW=.. -DIAF_PXT=.. -DIAF_KS=.."
+#endif
+
+#define IAF_CAT_(a, b, c, d, e) a##b##_##c##_##d##_##e
+#define IAF_CAT(a, b, c, d, e) IAF_CAT_(a, b, c, d, e)
+
+extern "C" conv_fn_t IAF_CAT(iaf_pick_bf3p_, IAF_PPW, IAF_PXT, IAF_KS, IAF_WCO)(int nt) {
+    switch (nt) {
+        case 2: return iaf_conv_bf3_kernel<2, IAF_PPW, IAF_PXT, IAF_KS, IN_NCHW, EPI_PLAIN, IAF_WCO, MAXTAPS>;
+        case 4: return iaf_conv_bf3_kernel<4, IAF_PPW, IAF_PXT, IAF_KS, IN_NCHW, EPI_PLAIN, IAF_WCO, MAXTAPS>;
+        case 5: return iaf_conv_bf3_kernel<5, IAF_PPW, IAF_PXT, IAF_KS, IN_NCHW, EPI_PLAIN, IAF_WCO, MAXTAPS>;
+    }
+    return nullptr;
+}

@@ -49,7 +49,14 @@ template <int EPI>
 __device__ __forceinline__ void epi_load(const ConvP& p, const EpiGeom& g, int cot, EpiOps& o) {
     if (!g.pvalid) return;
     const int HW = p.HW;
-    if (EPI == EPI_HIDDEN) {
+    if (EPI == EPI_PLAIN) {         // plain conv2d (layers.py:63-64): bias, and the residual of `input + 0.1 * h` (tf_train.py:44,94)
+        o.b0 = *(const f32x4*)(p.bias + cot * 16 + 4 * g.kk);
+        if (p.res) {
+            const size_t cb = ((size_t)g.bimg * p.cout + cot * 16 + 4 * g.kk) * HW + g.pp;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o.pre0[r] = p.res[cb + (size_t)r * HW];
+        }
+    } else if (EPI == EPI_HIDDEN) {
         o.b0 = *(const f32x4*)(p.bias + cot * 16 + 4 * g.kk);
         if (p.ctx) {
             const size_t cb = ((size_t)g.bimg * p.cout + cot * 16 + 4 * g.kk) * HW + g.pp;
@@ -76,7 +83,18 @@ template <int EPI, int NTP>
 __device__ __forceinline__ void epi_apply(const ConvP& p, const EpiGeom& g, int cot, f32x4 v0, f32x4 v1, const EpiOps& o) {
     if (!g.pvalid) return;
     const int HW = p.HW;
-    if (EPI == EPI_HIDDEN) {
+    if (EPI == EPI_PLAIN) {         // NCHW store with the channel split of tf_train.py:37,54 fused in
+        const int co = cot * 16 + 4 * g.kk;
+        const f32x4 v = v0 + o.b0;
+        int c0 = 0, c1 = p.split_end[0];
+        float* base = p.split_ptr[0];
+#pragma unroll
+        for (int q = 1; q < MAXSPLIT; ++q)      // static indices only: the descriptor stays in SGPRs
+            if (q < p.nsplit && co >= p.split_end[q - 1]) { c0 = p.split_end[q - 1]; c1 = p.split_end[q]; base = p.split_ptr[q]; }
+        float* dst = base + ((size_t)g.bimg * (c1 - c0) + (co - c0)) * HW + g.pp;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[(size_t)r * HW] = p.res ? o.pre0[r] + 0.1f * v[r] : v[r];
+    } else if (EPI == EPI_HIDDEN) {
         const int co = cot * 16 + 4 * g.kk;
         f32x4 v = v0 + o.b0;
         if (p.border) {   // Theano pad_channel (conv.py:71-83, ar.py:229-233): taps that fall outside see a 1

@@ -154,6 +154,25 @@ static size_t bf3_lds_bytes(int cin, int W, int nt, int ppw, int pxt, int ks, in
     return tile > red ? tile : red;
 }
 
+// 9-tap plain convs on the bf16 matrix cores (iaf_conv_bf3_plain_inst.hip): shapes (ppw, pxt, ks, wco); keep in sync with build.py
+#define N_BF3P_SHAPES 3
+static const int k_bf3p_shapes[N_BF3P_SHAPES][4] = {{2, 1, 4, 1}, {4, 1, 4, 1}, {2, 1, 4, 2}};
+extern "C" conv_fn_t iaf_pick_bf3p_2_1_4_1(int nt);
+extern "C" conv_fn_t iaf_pick_bf3p_4_1_4_1(int nt);
+extern "C" conv_fn_t iaf_pick_bf3p_2_1_4_2(int nt);
+static conv_fn_t pick_bf3_plain(int nt, int ppw, int pxt, int ks, int wco) {
+    if (ppw == 2 && pxt == 1 && ks == 4 && wco == 1) return iaf_pick_bf3p_2_1_4_1(nt);
+    if (ppw == 4 && pxt == 1 && ks == 4 && wco == 1) return iaf_pick_bf3p_4_1_4_1(nt);
+    if (ppw == 2 && pxt == 1 && ks == 4 && wco == 2) return iaf_pick_bf3p_2_1_4_2(nt);
+    return nullptr;
+}
+// LDS of a 9-tap bf16x3 launch: the pixel tile with a halo of W + 1 slots on BOTH sides (+ the zero slot)
+static size_t bf3_plain_lds_bytes(int cin, int W, int nt, int ppw, int pxt, int ks, int wco) {
+    const size_t tile = (size_t)(16 * ppw * pxt + 2 * (W + 1) + 1) * (3 * (cin / 8) + 2) * 16;
+    const size_t red = ks > 1 ? (size_t)pxt * wco * ks * ppw * nt * 1024 : 0;
+    return tile > red ? tile : red;
+}
+
 // the launch shapes that are compiled: (pxt, wco, ks)
 static conv_fn_t pick_kernel(int nt, int pxt, int wco, int ks, int inmode, int epi) {
     if (nt < 1 || nt > 5) return nullptr;

@@ -50,7 +50,8 @@ template <int NTP> __device__ __forceinline__ int tap_kw(int t) { return NTP == 
 // kernel's time).  Split in two: the LOADS (mask applied) are issued together with the first pass's, before the norm
 // reduction they do not depend on; the scale, the three-way split and the stores follow once s_scale[] is known.
 #define PREP_BF3_UPQ(NCH) ((((NCH) / 2) * NTAPS + 3) / 4)      // (pair, tap) units per quarter of the workgroup
-template <int NCH>
+#define PREP_BF3_UPQ_T(NCH, NTP) ((((NCH) / 2) * (NTP) + 3) / 4)
+template <int NCH, int NTP = NTAPS>
 __device__ __forceinline__ void prep_bf3_load(const PrepLayer& L, int gt, float (*w)[8]) {
     const int which = (L.npair == 2) ? (gt & 1) : 0;
     const int src_tile = (L.npair == 2) ? (gt >> 1) : gt;
@@ -63,20 +64,21 @@ __device__ __forceinline__ void prep_bf3_load(const PrepLayer& L, int gt, float 
     const bool flip = (L.variant == IAF_VARIANT_THEANO_FLIPMASK);
     const int k0 = (n_out >= n_in) ? n_out / n_in : 1;
     const bool row_zeroed = theano && L.zerodiag && o < k0;         // ar.py:268-276 (see prep_tile_theano)
-    constexpr int NUNIT = (NCH / 2) * NTAPS;
+    constexpr int NUNIT = (NCH / 2) * NTP;
 #pragma unroll
-    for (int i = 0; i < PREP_BF3_UPQ(NCH); ++i) {
+    for (int i = 0; i < PREP_BF3_UPQ_T(NCH, NTP); ++i) {
         const int uu = quarter + 4 * i;
         const int u = uu < NUNIT ? uu : NUNIT - 1;                  // clamped: the surplus slot is loaded, never stored
-        const int pair = u / NTAPS, t = u - pair * NTAPS;
-        const int kh = (t == 0 || t == 1) ? 1 : 2;
-        const int kw = (t == 0) ? 1 : (t == 1 ? 2 : t - 2);
+        const int pair = u / NTP, t = u - pair * NTP;
+        const int kh = tap_kh<NTP>(t), kw = tap_kw<NTP>(t);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int ci = pair * 32 + 8 * kk + e;
             float x;
             bool live = true;
-            if (theano) {
+            if (NTP == MAXTAPS) {                                    // plain conv2d: every tap, no mask
+                x = V[((size_t)(kh * 3 + kw) * n_in + ci) * n_out + o];
+            } else if (theano) {
                 x = V[((size_t)o * (n_in + 1) + ci) * 9 + (flip ? (2 - kh) * 3 + (2 - kw) : kh * 3 + kw)];
                 if (t == 0)
                     live = !row_zeroed && (flip ? (ci >= 1 && made_live(n_in - ci, n_out - 1 - o, n_in, n_out, L.zerodiag))
@@ -90,19 +92,19 @@ __device__ __forceinline__ void prep_bf3_load(const PrepLayer& L, int gt, float 
     }
 }
 
-template <int NCH>
+template <int NCH, int NTP = NTAPS>
 __device__ __forceinline__ void prep_bf3_store(const PrepLayer& L, int gt, const float (*w)[8], const float* s_scale) {
     typedef __bf16 pb16x2 __attribute__((ext_vector_type(2)));
     typedef float pf32x2 __attribute__((ext_vector_type(2)));
     typedef unsigned pu32x4 __attribute__((ext_vector_type(4)));
     const int lane = threadIdx.x & 63, quarter = threadIdx.x >> 6;
     const float scale = s_scale[lane & 15];
-    constexpr int NUNIT = (NCH / 2) * NTAPS;
+    constexpr int NUNIT = (NCH / 2) * NTP;
 #pragma unroll
-    for (int i = 0; i < PREP_BF3_UPQ(NCH); ++i) {
+    for (int i = 0; i < PREP_BF3_UPQ_T(NCH, NTP); ++i) {
         const int u = quarter + 4 * i;
         if (u >= NUNIT) continue;
-        const int pair = u / NTAPS, t = u - pair * NTAPS;
+        const int pair = u / NTP, t = u - pair * NTP;
         pu32x4 ph, pm, pl;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -114,7 +116,7 @@ __device__ __forceinline__ void prep_bf3_store(const PrepLayer& L, int gt, const
             const pb16x2 lb = __builtin_convertvector(r2, pb16x2);
             ph[k] = __builtin_bit_cast(unsigned, hb); pm[k] = __builtin_bit_cast(unsigned, mb); pl[k] = __builtin_bit_cast(unsigned, lb);
         }
-        pu32x4* q = (pu32x4*)L.wp3 + (((size_t)(pair * NTAPS + t) * L.ncot + gt) * 3) * 64 + lane;
+        pu32x4* q = (pu32x4*)L.wp3 + (((size_t)(pair * NTP + t) * L.ncot + gt) * 3) * 64 + lane;
         q[0] = ph; q[64] = pm; q[128] = pl;
     }
 }
@@ -129,9 +131,9 @@ __device__ __forceinline__ void prep_tile(const PrepLayer& L, int gt, float (*re
     const int n_out = L.cout_each, n_in = L.cin;
     const float gval = L.g[which][o], bval = L.b[which][o];
 
-    constexpr bool BF3 = (NTP == NTAPS) && (NCH % 2 == 0);
-    float w3[BF3 ? PREP_BF3_UPQ(NCH) : 1][8];
-    if constexpr (BF3) { if (L.wp3) prep_bf3_load<NCH>(L, gt, w3); }
+    constexpr bool BF3 = (NCH % 2 == 0);
+    float w3[BF3 ? PREP_BF3_UPQ_T(NCH, NTP) : 1][8];
+    if constexpr (BF3) { if (L.wp3) prep_bf3_load<NCH, NTP>(L, gt, w3); }
     // pass 1: fetch + mask (layers.py:57), sum of squares over (taps, c_in) (layers.py:60)
     float v[NTP][NCH];
 #pragma unroll
@@ -175,7 +177,7 @@ __device__ __forceinline__ void prep_tile(const PrepLayer& L, int gt, float (*re
             for (int t = 0; t < NTP; ++t)
                 L.wpt[((((size_t)gt * NTP + t) * NCH + it) * 64 + (oo >> 2) * 16 + cs) * 4 + (oo & 3)] = v[t][it] * scale;
     }
-    if constexpr (BF3) { if (L.wp3) prep_bf3_store<NCH>(L, gt, w3, s_scale); }
+    if constexpr (BF3) { if (L.wp3) prep_bf3_store<NCH, NTP>(L, gt, w3, s_scale); }
 }
 
 // Theano statement of the same weights (graphy/nodes/ar.py:243-330, l2norm=True, logscale=True, pad_channel=True):

@@ -577,6 +577,15 @@ class WNConv2d(object):
     def set_tuning(self, nt, pxt, wco, ks):
         _capi.check(_capi.lib().iaf_conv3x3_set_tuning(self._h, nt, pxt, wco, ks))
 
+    def set_precision(self, precision):
+        """"bf16x3" (default: the forward conv on the bf16 matrix cores with split products, fp32-grade, where a launch shape
+        covers it) or "f32" (the exact-fp32 MFMA kernel always)"""
+        code = {"f32": _capi.IAF_PRECISION_F32, "bf16x3": _capi.IAF_PRECISION_BF16X3}.get(precision, precision)
+        _capi.check(_capi.lib().iaf_conv3x3_set_precision(self._h, int(code)))
+
+    def runs_bf16x3(self, B, H, W):
+        return bool(_capi.lib().iaf_conv3x3_runs_bf16x3(self._h, int(B), int(H), int(W)))
+
     # -- training --------------------------------------------------------------------------------
     _shared_ws = {}     # device -> one scratch buffer shared by all plain convs (they run one after another)
 

@@ -360,9 +360,19 @@ int iaf_conv3x3_wn_bwd_batch_run(iaf_conv3x3_wn_bwd_batch_t* b, const float* con
 int iaf_conv3x3_wn_bwd_batch_destroy(iaf_conv3x3_wn_bwd_batch_t* b);
 /* launch shape override (nt = 0 restores the automatic choice); see iaf_stack_set_tuning */
 int iaf_conv3x3_set_tuning(iaf_conv3x3_t* c, int nt, int pxt, int wco, int ks);
+/* arithmetic of the forward conv, as iaf_stack_set_precision: IAF_PRECISION_BF16X3 (default; plain convs with c_in % 32 == 0
+ * from 4096 pixels on, or as iaf_conv3x3_autotune measured) or IAF_PRECISION_F32 (the exact-fp32 MFMA kernel always; masked
+ * single convs, deconvs and the backward kernels run it regardless).  iaf_conv3x3_runs_bf16x3: 1 if a forward call at this
+ * size would run the bf16x3 kernel. */
+int iaf_conv3x3_set_precision(iaf_conv3x3_t* c, int precision);
+int iaf_conv3x3_runs_bf16x3(iaf_conv3x3_t* c, int B, int H, int W);
 /* times every compiled launch shape with `reps` back-to-back forwards on the caller's buffers (same arguments as
  * iaf_conv3x3_forward; outputs end up holding the forward result), pins the fastest as if by set_tuning, and reports it
- * (best_shape[4] = nt,pxt,wco,ks; best_us per call; both optional).  Synchronises the stream; not capturable. */
+ * (best_shape[4] = nt,pxt,wco,ks; best_us per call; both optional).  With IAF_PRECISION_BF16X3 (the default) a plain conv
+ * with c_in % 32 == 0 is also timed on the bf16 matrix cores (bf16x3 split products, fp32-grade: iaf_conv_bf3.hpp with all 9
+ * taps) in every compiled shape, and the overall winner is pinned: best_shape = (-nt, ppw, wco, ks) then (iaf_conv3x3_set_tuning
+ * accepts that form back).  Synchronises the
+ * stream; not capturable. */
 int iaf_conv3x3_autotune(iaf_conv3x3_t* c, const float* x, const float* x2, int c_split, int elu_input,
                          const float* residual, float* const* outs, const int* out_channels, int n_outs, int B, int H,
                          int W, int reps, void* stream, int* best_shape, float* best_us);

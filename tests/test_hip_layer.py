@@ -129,6 +129,69 @@ def test_wnconv2d_every_launch_shape(amd, tune):
     np.testing.assert_allclose(host(y), e, atol=ATOL, rtol=0)
 
 
+BF3P = [(nt, ppw, wco, 4) for (ppw, wco) in ((2, 1), (4, 1), (2, 2)) for nt in (5, 4, 2)]
+
+
+@pytest.mark.parametrize("shp", BF3P, ids=lambda t: "nt%d_ppw%d_wco%d_ks%d" % t)
+@pytest.mark.parametrize("case", [(3, 160, 320, 8, 8), (32, 160, 160, 16, 16), (2, 32, 40 * 16, 5, 7)], ids=lambda s: "B%d_%dto%d_%dx%d" % s)
+def test_plain_conv_on_the_bf16_matrix_cores_every_shape(amd, shp, case):
+    """the 9-tap plain conv as bf16x3 split products (iaf_conv_bf3.hpp, NTP = 9, halo on both sides of the pixel tile): every
+    compiled launch shape, with the fused ELU / residual, against the oracle -- and fp32-grade, not just inside the tolerance"""
+    B, n_in, n_out, H, W = case
+    nt, ppw, wco, ks = shp
+    if (n_out // 16) % (nt * wco):
+        pytest.skip("this co tiling does not divide %d output tiles" % (n_out // 16))
+    rng = np.random.RandomState(31 + nt + ppw)
+    p = gi.conv_params(rng, n_in, n_out)
+    x, res = rng.standard_normal((B, n_in, H, W)), rng.standard_normal((B, n_out, H, W))
+    conv = amd.WNConv2d(n_in, n_out)
+    conv.prepare(dev(p["V"]), dev(p["g"]), dev(p["b"]))
+    try:
+        conv.set_tuning(-nt, ppw, wco, ks)
+        assert conv.runs_bf16x3(B, H, W)
+        y = conv(dev(x))[0]
+        y2 = conv(dev(x), elu_input=True, residual=dev(res))[0]
+    except amd.UnsupportedError as e:
+        pytest.skip(str(e))
+    e = O.conv2d(f32(x), f32(p["V"]), f32(p["g"]), f32(p["b"]))
+    np.testing.assert_allclose(host(y), e, atol=ATOL, rtol=0)
+    assert np.abs(host(y) - e).max() < 2e-5 * max(1.0, np.abs(e).max())
+    e2 = f32(res) + 0.1 * O.conv2d(O.elu(f32(x)), f32(p["V"]), f32(p["g"]), f32(p["b"]))
+    np.testing.assert_allclose(host(y2), e2, atol=ATOL, rtol=0)
+    conv.set_precision("f32")
+    assert not conv.runs_bf16x3(B, H, W)
+    yf = conv(dev(x))[0]
+    assert float((yf - y).abs().max()) < 3e-5 * max(1.0, np.abs(e).max())
+
+
+def test_plain_conv_bf16x3_concat_split_and_size_rule(amd):
+    """down_conv2 / down_conv1 shapes through the size rule (bf16x3 from 4096 pixels on): concat of two inputs + ELU, output
+    split six ways; below the threshold the exact-fp32 kernel runs"""
+    rng = np.random.RandomState(77)
+    B, zs, hs, H, W = 32, 32, 160, 16, 16
+    p = gi.conv_params(rng, zs + hs, hs)
+    a, b = rng.standard_normal((B, zs, H, W)), rng.standard_normal((B, hs, H, W))
+    conv = amd.WNConv2d(zs + hs, hs)
+    conv.prepare(dev(p["V"]), dev(p["g"]), dev(p["b"]))
+    assert conv.runs_bf16x3(B, H, W) and not conv.runs_bf16x3(2, 8, 8)
+    y = conv(dev(a), x2=dev(b), elu_input=True)[0]
+    chunk = 8
+    for b0 in range(0, B, chunk):
+        e = O.conv2d(O.elu(np.concatenate([f32(a[b0:b0 + chunk]), f32(b[b0:b0 + chunk])], axis=1)), f32(p["V"]), f32(p["g"]), f32(p["b"]))
+        np.testing.assert_allclose(host(y[b0:b0 + chunk]), e, atol=ATOL, rtol=0)
+    n_out = 4 * zs + 2 * hs
+    p = gi.conv_params(rng, hs, n_out)
+    x = rng.standard_normal((B, hs, H, W))
+    conv = amd.WNConv2d(hs, n_out)
+    conv.prepare(dev(p["V"]), dev(p["g"]), dev(p["b"]))
+    assert conv.runs_bf16x3(B, H, W)
+    split = [zs] * 4 + [hs] * 2
+    outs = conv(dev(x), elu_input=True, split=split)
+    e = O.conv2d(O.elu(f32(x[:4])), f32(p["V"]), f32(p["g"]), f32(p["b"]))
+    for got, want in zip(outs, O.split_channels(e, split)):
+        np.testing.assert_allclose(host(got[:4]), want, atol=ATOL, rtol=0)
+
+
 def test_conv2d_function_api_under_tf_names(amd, golden_dir):
     """the reference call site tf_train.py:36 under its variable scope names"""
     c = gi.layer_case_inputs("layer_cfg2_8x8")
