@@ -843,7 +843,7 @@ static step_fn_t fused_step_plan(const iaf_stack_t* s, int B, int H, int W, int*
     static const int env = getenv("IAF_FUSE_STEP") ? atoi(getenv("IAF_FUSE_STEP")) : -1;       // dev knob: 0 / 1
     const int mode = env >= 0 ? env : s->fuse_step;
     if (!mode || s->generic || s->precision != IAF_PRECISION_BF16X3) return nullptr;
-    if (s->depth_ar < 1 || s->depth_ar > 2 || (s->n_h & 15) || (s->n_z & 15)) return nullptr;
+    if (s->depth_ar < 1 || s->depth_ar > 4 || (s->n_h & 15) || (s->n_z & 15)) return nullptr;
     if (s->fuse_first == 1) return nullptr;                  // the caller asked for the layer-by-layer variant with a fused first conv
     for (int l = 0; l < s->nlayers; ++l)                      // ... or pinned a per-layer launch shape: the layer-by-layer path is meant
         if (!s->L[l].wp3 || s->L[l].user_tuned || s->L[l].b_user_tuned) return nullptr;
@@ -868,7 +868,8 @@ static int launch_fused_step(iaf_stack_t* s, step_fn_t fn, int R, size_t lds, co
                              const float* ctx2, hipStream_t st, float* const* hsave = nullptr) {
     StepP q;
     memset(&q, 0, sizeof(q));
-    if (hsave) { q.hsave[0] = hsave[0]; q.hsave[1] = s->depth_ar > 1 ? hsave[1] : nullptr; }
+    if (hsave)
+        for (int l = 0; l < s->depth_ar && l < 4; ++l) q.hsave[l] = hsave[l];
     q.z = (first_inmode == IN_POSTERIOR) ? nullptr : base.x;
     q.ctx = ctx; q.ctx2 = ctx2;
     for (int l = 0; l < s->nlayers; ++l) { q.wp3[l] = s->L[l].wp3; q.bias[l] = s->L[l].bias; }

@@ -41,10 +41,10 @@ struct StepGeom {
     static constexpr int HREG1 = HREG0 + rows_h(0) * RS * H16;
     static constexpr int END = HREG1 + (DEPTH >= 2 ? rows_h(1) * RS * H16 : 0);
     static constexpr int XB_STRIDE = 2 * NZ + 1;                                 // output exchange buffer [wave 4][pixel][2 n_z] floats
-    // ... over the z and h_0 regions, both dead when the output pair (which reads h_1) is multiplied; behind everything
-    // when there is a single hidden layer (the output pair reads h_0 then)
-    static constexpr int XB_OFF = DEPTH >= 2 ? 0 : END;
     static constexpr size_t xb_bytes() { return (size_t)4 * R * W * XB_STRIDE * 4; }
+    // (the last hidden layer sits in the h_odd region for an even depth: z + h_even are dead then; for an odd depth it sits in
+    // h_even: the buffer goes into h_odd if it fits there, else behind everything)
+    static constexpr int XB_OFF = (DEPTH % 2 == 0) ? 0 : (DEPTH >= 3 && xb_bytes() <= (size_t)(END - HREG1) * 16) ? HREG1 : END;
     // context of the first epilogue, staged [channel][pixel of the h_0 rows] (row stride = 4 or 12 mod 16 floats: conflict-free for the epilogue's
     // lanes = 16 pixels x 4 channel groups): in the h_1 region, which the first conv does not touch; behind everything when
     // there is a single hidden layer
@@ -74,7 +74,7 @@ template <int NHT, int NZT, int DEPTH, int W, int R, int VAR = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void iaf_step_fused_kernel(StepP p) {
     typedef StepGeom<NHT, NZT, DEPTH, W, R> G;
     constexpr bool FLIP = (VAR == 1), BORDER = (VAR != 0);
-    static_assert(DEPTH >= 1 && DEPTH <= 2, "hidden regions ping-pong between two LDS buffers holding h_0 and h_1");
+    static_assert(DEPTH >= 1 && DEPTH <= 4, "hidden layers ping-pong between two LDS regions (h_even, h_odd)");
     static_assert((W & (W - 1)) == 0 && W <= 16, "full-width rows of 4, 8 or 16 pixels");
     extern __shared__ __attribute__((aligned(16))) f32x4 smem4[];
     char* smem = (char*)smem4;
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     int otile[NTWO];
 #pragma unroll
     for (int j = 0; j < NTWO; ++j) otile[j] = (wave / OKS) * NTWO + j;
-    f32x4 wr1[U][NTWH][3];           // ring of the second hidden layer (DEPTH == 2)
+    f32x4 wr1[U][NTWH][3];           // hidden layer l uses ring l & 1 (wr0 / wr1): the other one receives layer l + 1's first steps
     f32x4 wro[U][NTWO][3];           // ring of the output pair
     const f32x4* wbo = (const f32x4*)p.wp3[DEPTH] + lane;
     auto preload_out = [&]() {
@@ -375,6 +375,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWO * 3>{}, wro[decltype(i)::value], wbo, 2 * NZT,
                       otile, so1, so0 + decltype(i)::value);
         });
+    };
+    // the weights of the phase after hidden layer l -- the next hidden layer's ring, or the output pair's -- start travelling
+    // while layer l's epilogue runs
+    auto preload_after = [&](auto l_c) {
+        constexpr int l = decltype(l_c)::value;
+        if constexpr (l + 1 < DEPTH) {
+            const f32x4* wbn = (const f32x4*)p.wp3[l + 1] + lane;
+            static_for<RD>([&](auto i) {
+                ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWH * 3>{},
+                          ((l + 1) & 1) ? wr1[decltype(i)::value] : wr0[decltype(i)::value], wbn, NHT, htile, NSTEP_H, decltype(i)::value);
+            });
+        } else {
+            preload_out();
+        }
     };
     // every wave group runs its own instantiation of a hidden phase (the left-over tile's pixel tiles are compile time)
     static_for<GN>([&](auto g_c) {
@@ -387,16 +401,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                    std::integral_constant<int, EM0>{}, G::ZREG, Z16, Z8, wb0, NHT, htile, 0, (NZ / 32) * NTAPS, wr0, acc0);
         IAF_FSTAMP(6);
         store_ctx();
-        // the next phase's first weight steps travel while this phase's epilogue runs
-        if constexpr (DEPTH >= 2) {
-            const f32x4* wb1 = (const f32x4*)p.wp3[1] + lane;
-            static_for<RD>([&](auto i) {
-                ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWH * 3>{}, wr1[decltype(i)::value], wb1, NHT,
-                          htile, NSTEP_H, decltype(i)::value);
-            });
-        } else {
-            preload_out();
-        }
+        preload_after(std::integral_constant<int, 0>{});
         __syncthreads();                                         // (every wave runs exactly one of the GN instantiations)
 #ifdef IAF_EXP_STAMP_MID
         IAF_FSTAMP(7);
@@ -406,33 +411,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     });
     __syncthreads();
     IAF_FSTAMP(2);
-    if constexpr (DEPTH >= 2) {
-        {   // the staged context sat in the h_1 region: its zero columns again, before the layer's epilogue fills the rest
+    static_for<DEPTH - 1>([&](auto lm_c) {
+        constexpr int l = decltype(lm_c)::value + 1;              // hidden layer l reads h_{l-1}, writes h_l into the other region
+        constexpr int IN_REG = ((l - 1) & 1) ? G::HREG1 : G::HREG0, OUT_REG = (l & 1) ? G::HREG1 : G::HREG0;
+        if constexpr (l == 1) {   // the staged context sat in the h_odd region: its zero columns again, before the epilogue fills the rest
             constexpr int H1ROWS = G::rows_h(1);
             for (int i = tid; i < H1ROWS * 2 * H16; i += 256) {
                 const int rs = i / H16, u = i - rs * H16;
                 smem4[G::HREG1 + ((rs >> 1) * RS + (rs & 1) * (W + 1)) * H16 + u] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
-        constexpr int NPT1 = (G::rows_h(1) * W + 15) / 16;
+        constexpr int NPTL = (G::rows_h(l) * W + 15) / 16;
         static_for<GN>([&](auto g_c) {
             constexpr int GI = decltype(g_c)::value;
             if (xg != GI) return;
-            constexpr int EM1 = (NX == 0 || !XSPLIT) ? (1 << NPT1) - 1 : fused_extra_mask(NPT1, GN, GI);
-            f32x4 acc1[NPT1][NTWH], bi1[NTWH];
-            load_bias(p.bias[1], bi1);
-            const f32x4* wb1 = (const f32x4*)p.wp3[1] + lane;
-            conv_phase(std::integral_constant<int, NPT1>{}, std::integral_constant<int, NTWH>{}, std::integral_constant<int, G::rows_h(1)>{},
-                       std::integral_constant<int, EM1>{}, G::HREG0, H16, H8, wb1, NHT, htile, 0, NSTEP_H, wr1, acc1);
+            constexpr int EML = (NX == 0 || !XSPLIT) ? (1 << NPTL) - 1 : fused_extra_mask(NPTL, GN, GI);
+            f32x4 accl[NPTL][NTWH], bil[NTWH];
+            load_bias(p.bias[l], bil);
+            const f32x4* wbl = (const f32x4*)p.wp3[l] + lane;
+            conv_phase(std::integral_constant<int, NPTL>{}, std::integral_constant<int, NTWH>{}, std::integral_constant<int, G::rows_h(l)>{},
+                       std::integral_constant<int, EML>{}, IN_REG, H16, H8, wbl, NHT, htile, 0, NSTEP_H, (l & 1) ? wr1 : wr0, accl);
 #ifndef IAF_EXP_STAMP_MID
-            IAF_FSTAMP(7);
+            if constexpr (l == 1) IAF_FSTAMP(7);
 #endif
-            preload_out();
-            hidden_epilogue(std::integral_constant<int, NPT1>{}, std::integral_constant<int, G::rows_h(1)>{},
-                            std::integral_constant<int, EM1>{}, std::integral_constant<int, 0>{}, acc1, bi1, G::HREG1, p.hsave[1], p.border[1]);
+            preload_after(std::integral_constant<int, l>{});
+            hidden_epilogue(std::integral_constant<int, NPTL>{}, std::integral_constant<int, G::rows_h(l)>{},
+                            std::integral_constant<int, EML>{}, std::integral_constant<int, 0>{}, accl, bil, OUT_REG, p.hsave[l], p.border[l]);
         });
         __syncthreads();
-    }
+    });
     IAF_FSTAMP(3);
 
     // ---- output pair: packed tiles (m_0, s_0, m_1, s_1, ...), partial sums -> exchange buffer [K part][pixel][2 n_z] -------
@@ -461,8 +468,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     {
         f32x4 acco[NPTO][NTWO];
         conv_phase(std::integral_constant<int, NPTO>{}, std::integral_constant<int, NTWO>{}, std::integral_constant<int, R>{},
-                   std::integral_constant<int, (1 << NPTO) - 1>{}, DEPTH >= 2 ? G::HREG1 : G::HREG0, H16, H8, wbo, 2 * NZT, otile, so0,
-                   so1, wro, acco);
+                   std::integral_constant<int, (1 << NPTO) - 1>{}, ((DEPTH - 1) & 1) ? G::HREG1 : G::HREG0, H16, H8, wbo, 2 * NZT, otile,
+                   so0, so1, wro, acco);
         IAF_FSTAMP(4);
         float* mine = xbuf + (size_t)okh * (R * W * G::XB_STRIDE);
 #pragma unroll

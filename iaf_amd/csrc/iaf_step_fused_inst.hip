@@ -1,36 +1,46 @@
 // iaf_step_fused_inst.hip -- instantiations of the one-launch IAF step (iaf_step_fused.hpp) for the geometries the
 // BASELINE configs use: n_h = 160 / n_z = 32 / depth_ar = 2 (configs 1-2, 5: README run) and n_h = 64 / depth_ar = 1
-// (config 0), images 16, 8 and 4 pixels wide (4-pixel rows: one workgroup per four rows, i.e. per 4x4 image).  Built as its own translation unit by iaf_amd/build.py.
+// (config 0), images 16, 8 and 4 pixels wide (4-pixel rows: one workgroup per four rows, i.e. per 4x4 image); and for the deep
+// stack of config 3 (n_z = 64, depth_ar = 4, n_h = 64 / 128 / 192) wherever its five LDS regions fit 160 KiB.  Built as its own translation unit by iaf_amd/build.py.
 #include "iaf_step_fused.hpp"
 
 template <int NHT, int NZT, int DEPTH, int W, int R>
 static step_fn_t inst(int var, size_t* lds) {
     typedef StepGeom<NHT, NZT, DEPTH, W, R> G;
-    static_assert(DEPTH < 2 || G::xb_bytes() <= (size_t)G::HREG1 * 16, "the exchange buffer must fit the z + h_0 regions");
-    static_assert(DEPTH < 2 || G::ctx_bytes() <= (size_t)(G::END - G::HREG1) * 16, "the staged context must fit the h_1 region");
     static_assert((G::CSTR & 15) == 4 || (G::CSTR & 15) == 12, "context rows: 4 channel groups x 16 pixels must hit 64 distinct banks");
-    *lds = G::lds_bytes();
-    switch (var) {
-        case 0: return iaf_step_fused_kernel<NHT, NZT, DEPTH, W, R, 0>;
-        case 1: return iaf_step_fused_kernel<NHT, NZT, DEPTH, W, R, 1>;
-        case 2: return iaf_step_fused_kernel<NHT, NZT, DEPTH, W, R, 2>;
+    // does the geometry fit 160 KiB, the staged context its region, the exchange buffer the regions that are dead by then?
+    constexpr bool fits = G::lds_bytes() <= 160 * 1024 && (DEPTH < 2 || G::ctx_bytes() <= (size_t)(G::END - G::HREG1) * 16) &&
+                          (DEPTH % 2 != 0 || G::xb_bytes() <= (size_t)G::HREG1 * 16);
+    if constexpr (!fits) {
+        (void)var;
+        return nullptr;
+    } else {
+        *lds = G::lds_bytes();
+        switch (var) {
+            case 0: return iaf_step_fused_kernel<NHT, NZT, DEPTH, W, R, 0>;
+            case 1: return iaf_step_fused_kernel<NHT, NZT, DEPTH, W, R, 1>;
+            case 2: return iaf_step_fused_kernel<NHT, NZT, DEPTH, W, R, 2>;
+        }
+        return nullptr;
     }
+}
+
+template <int NHT, int NZT, int DEPTH>
+static step_fn_t inst_wr(int W, int R, int var, size_t* lds) {
+    if (W == 16 && R == 2) return inst<NHT, NZT, DEPTH, 16, 2>(var, lds);
+    if (W == 8 && R == 1) return inst<NHT, NZT, DEPTH, 8, 1>(var, lds);
+    if (W == 8 && R == 2) return inst<NHT, NZT, DEPTH, 8, 2>(var, lds);
+    if (W == 4 && R == 4) return inst<NHT, NZT, DEPTH, 4, 4>(var, lds);
     return nullptr;
 }
 
 extern "C" step_fn_t iaf_pick_step_fused(int nht, int nzt, int depth, int W, int R, int var, size_t* lds) {
     *lds = 0;
-    if (nht == 10 && nzt == 2 && depth == 2) {
-        if (W == 16 && R == 2) return inst<10, 2, 2, 16, 2>(var, lds);
-        if (W == 8 && R == 1) return inst<10, 2, 2, 8, 1>(var, lds);
-        if (W == 8 && R == 2) return inst<10, 2, 2, 8, 2>(var, lds);
-        if (W == 4 && R == 4) return inst<10, 2, 2, 4, 4>(var, lds);
-    }
-    if (nht == 4 && nzt == 2 && depth == 1) {
-        if (W == 16 && R == 2) return inst<4, 2, 1, 16, 2>(var, lds);
-        if (W == 8 && R == 1) return inst<4, 2, 1, 8, 1>(var, lds);
-        if (W == 8 && R == 2) return inst<4, 2, 1, 8, 2>(var, lds);
-        if (W == 4 && R == 4) return inst<4, 2, 1, 4, 4>(var, lds);
-    }
+    if (nht == 10 && nzt == 2 && depth == 2) return inst_wr<10, 2, 2>(W, R, var, lds);      // configs 1-2, 5 (README run)
+    if (nht == 4 && nzt == 2 && depth == 1) return inst_wr<4, 2, 1>(W, R, var, lds);        // config 0
+    // config 3 (up_iaf2_nl, n_z = 64, depth_ar = 4; n_h is not fixed by the reference's scripts): the geometries that fit
+    if (nht == 4 && nzt == 4 && depth == 4) return inst_wr<4, 4, 4>(W, R, var, lds);
+    if (nht == 8 && nzt == 4 && depth == 4) return inst_wr<8, 4, 4>(W, R, var, lds);
+    if (nht == 12 && nzt == 4 && depth == 4) return inst_wr<12, 4, 4>(W, R, var, lds);
     return nullptr;
 }

@@ -5,10 +5,10 @@ struct StepP {
     const float* z;            // [B][n_z][H][W]; NULL: the posterior sample (qm + rm) + exp(ql + rl) * eps
     const float* ctx;          // [B][n_h][H][W] context added after the first conv (layers.py:163-164)
     const float* ctx2;         // optional second context (up_context + down_context, tf_train.py:58)
-    const void* wp3[4];        // bf16x3 packs of the D hidden convs and the output pair
-    const float* bias[4];
+    const void* wp3[5];        // bf16x3 packs of the D <= 4 hidden convs and the output pair
+    const float* bias[5];
     const float* zin;          // MODE_IAF / MODE_INVERSE: the z of the affine transform
-    float* hsave[2];           // training: hidden activations of the OWNED rows, pixel-major [P][n_h] (what the backward reads), or NULL
+    float* hsave[4];           // training: hidden activations of the OWNED rows, pixel-major [P][n_h] (what the backward reads), or NULL
     float* out0;
     float* out1;
     float* kl_elem;
@@ -18,7 +18,7 @@ struct StepP {
     // the image rotated by 180 degrees, so that variant of the kernel sends every global access through (H-1-row, W-1-col) and
     // nothing else changes; border[l] = [4][packed c_out of layer l] weights of the border-indicator channel (taps 1..4), added
     // where a tap leaves the image (Theano variants only)
-    const float* border[4];
+    const float* border[5];
     unsigned long long* dbg;   // dev tool: per-workgroup cycle stamps [grid][8]
 };
 

@@ -249,7 +249,7 @@ int iaf_stack_set_fuse_first(iaf_stack_t* s, int mode);
  * halo rows recomputed (the masked convs look only right and below, so no other workgroup is involved).  mode 1 (default):
  * wherever a compiled geometry covers the problem -- any of the three statements of the operator (the Theano one runs on the
  * image rotated by 180 degrees, where its taps are the TF ones), bf16x3 precision, (n_h, n_z, depth_ar) = (160, 32, 2)
- * or (64, 32, 1), images 16, 8 or 4 pixels wide; everything else, and any stack with a pinned per-layer launch shape
+ * (64, 32, 1) or (64 / 128 / 192, 64, 4) where its LDS regions fit, images 16, 8 or 4 pixels wide; everything else, and any stack with a pinned per-layer launch shape
  * (iaf_stack_set_tuning*, fuse_first = 1), takes the layer-by-layer path.  mode 0: never; mode 2: wherever a geometry
  * covers it, whatever the size rule or a measurement says.  Same arithmetic as the
  * layer-by-layer bf16x3 kernels in a different summation order: results agree to fp32 round-off, not bit for bit.

@@ -55,7 +55,10 @@ def test_where_the_step_runs_as_one_launch(amd):
     assert st.step_is_fused(32, 4, 4) == 4                       # 4-pixel rows: a whole 4x4 image per workgroup
     assert st.step_is_fused(32, 32, 32) == 0                     # no compiled geometry for 32-pixel rows
     assert amd.ARStack(32, [64]).step_is_fused(16, 16, 16) == 2   # BASELINE configs[0]
-    assert amd.ARStack(64, [192] * 4).step_is_fused(32, 16, 16) == 0
+    deep = amd.ARStack(64, [192] * 4)                            # BASELINE configs[3]: five LDS regions
+    assert deep.step_is_fused(32, 16, 16) == 0 and deep.step_is_fused(32, 8, 8) == 1      # 16-pixel rows do not fit at n_h = 192
+    assert amd.ARStack(64, [64] * 4).step_is_fused(32, 16, 16) == 2 and amd.ARStack(64, [128] * 4).step_is_fused(32, 8, 8) == 1
+    assert amd.ARStack(64, [64] * 3).step_is_fused(32, 16, 16) == 0                       # no compiled geometry
     assert amd.ARStack(32, [160, 160], variant="theano").step_is_fused(32, 16, 16) == 2           # all three statements
     assert amd.ARStack(32, [160, 160], variant="theano_flipmask").step_is_fused(32, 8, 8) == 1
     st.set_fuse_step("never")
@@ -76,7 +79,9 @@ def test_where_the_step_runs_as_one_launch(amd):
 @pytest.mark.parametrize("cfg", [(32, 32, 160, 2, 16, 16), (32, 32, 160, 2, 8, 8), (5, 32, 160, 2, 5, 16), (3, 32, 160, 2, 3, 8),
                                  (1, 32, 160, 2, 1, 16), (2, 32, 160, 2, 7, 8), (64, 32, 160, 2, 16, 16), (128, 32, 160, 2, 8, 8), (16, 32, 64, 1, 16, 16),
                                  (16, 32, 64, 1, 8, 8), (4, 32, 64, 1, 3, 16), (128, 32, 64, 1, 8, 8),
-                                 (16, 32, 64, 1, 4, 4), (32, 32, 160, 2, 4, 4), (5, 32, 160, 2, 3, 4), (3, 32, 64, 1, 9, 4)], ids=lambda s: "B%d_z%d_h%d_d%d_%dx%d" % s)
+                                 (16, 32, 64, 1, 4, 4), (32, 32, 160, 2, 4, 4), (5, 32, 160, 2, 3, 4), (3, 32, 64, 1, 9, 4),
+                                 (32, 64, 64, 4, 16, 16), (4, 64, 64, 4, 8, 8), (3, 64, 128, 4, 8, 8), (32, 64, 192, 4, 8, 8),
+                                 (3, 64, 192, 4, 4, 4), (2, 64, 64, 4, 5, 16), (2, 64, 128, 4, 3, 4)], ids=lambda s: "B%d_z%d_h%d_d%d_%dx%d" % s)
 def test_iaf_step_and_raw_outputs_vs_oracle(amd, cfg):
     """tf_train.py:69-72 and layers.py:158-166 through the one-launch step; heights that are not a multiple of the rows
     per workgroup, single rows, one sample"""
