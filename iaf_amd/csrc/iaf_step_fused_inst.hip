@@ -34,13 +34,23 @@ static step_fn_t inst_wr(int W, int R, int var, size_t* lds) {
     return nullptr;
 }
 
-extern "C" step_fn_t iaf_pick_step_fused(int nht, int nzt, int depth, int W, int R, int var, size_t* lds) {
+// two translation units (iaf_amd/build.py: -DIAF_FUSED_PART=0 / 1) so that the build compiles them side by side
+// (no -DIAF_FUSED_PART: both parts in one unit)
+#if !defined(IAF_FUSED_PART) || IAF_FUSED_PART == 0
+extern "C" step_fn_t iaf_pick_step_fused_a(int nht, int nzt, int depth, int W, int R, int var, size_t* lds) {
     *lds = 0;
     if (nht == 10 && nzt == 2 && depth == 2) return inst_wr<10, 2, 2>(W, R, var, lds);      // configs 1-2, 5 (README run)
     if (nht == 4 && nzt == 2 && depth == 1) return inst_wr<4, 2, 1>(W, R, var, lds);        // config 0
-    // config 3 (up_iaf2_nl, n_z = 64, depth_ar = 4; n_h is not fixed by the reference's scripts): the geometries that fit
+    return nullptr;
+}
+#endif
+#if !defined(IAF_FUSED_PART) || IAF_FUSED_PART == 1
+// config 3 (up_iaf2_nl, n_z = 64, depth_ar = 4; n_h is not fixed by the reference's scripts): the geometries that fit
+extern "C" step_fn_t iaf_pick_step_fused_b(int nht, int nzt, int depth, int W, int R, int var, size_t* lds) {
+    *lds = 0;
     if (nht == 4 && nzt == 4 && depth == 4) return inst_wr<4, 4, 4>(W, R, var, lds);
     if (nht == 8 && nzt == 4 && depth == 4) return inst_wr<8, 4, 4>(W, R, var, lds);
     if (nht == 12 && nzt == 4 && depth == 4) return inst_wr<12, 4, 4>(W, R, var, lds);
     return nullptr;
 }
+#endif
