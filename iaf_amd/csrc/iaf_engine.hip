@@ -857,6 +857,13 @@ static step_fn_t fused_step_plan(const iaf_stack_t* s, int B, int H, int W, int*
     if (s->fs_force < 0 && mode != 2) {
         if (s->fs_P == (long long)B * H * W && s->fs_W == W) { if (!s->fs_on) return nullptr; }      // measured for this size
         else if (W == 8 && (long long)B * H >= 1024) return nullptr;
+        else if (W == 4) {
+            // one workgroup per image walks the whole weight set alone: ~12 us per MB of bf16x3 packs (n_h = 64, depth 4: 0.74 MB,
+            // 12.5 us; n_h = 128: 2.2 MB, 27 us), while each layer-by-layer launch costs ~4.6 us of a replayed graph at this size
+            double wmb = 0.0;
+            for (int l = 0; l < s->nlayers; ++l) wmb += 5.0 * s->L[l].cin * s->L[l].cout * 6.0 * 1e-6;
+            if (wmb * 12.3 > 4.6 * s->nlayers) return nullptr;
+        }
     }
     const int var = s->variant == IAF_VARIANT_TF ? 0 : s->variant == IAF_VARIANT_THEANO ? 1 : 2;
     step_fn_t fn = iaf_pick_step_fused(s->n_h / 16, s->n_z / 16, s->depth_ar, W, *R, var, lds);
@@ -1032,21 +1039,46 @@ extern "C" int iaf_stack_autotune(iaf_stack_t* s, const float* z, const float* c
         s->fs_force = 1;
         const bool possible = fused_step_plan(s, B, H, W, &R, &lds) != nullptr;
         float t[2] = {0.f, 0.f};
+        // Timed as `reps` steps captured once and replayed -- the way a sampling / training loop runs them.  Issued one by one,
+        // the layer-by-layer path at the small levels is bound by the host's launch rate and the comparison reads the host, not
+        // the kernels (n_h = 128 at 4x4: eager 5 launches lose to the one launch, replayed they win 23 vs 27 us).  If the
+        // capture is refused (a stream already capturing in this thread), the eager timing stands in.
+        hipStream_t cs = nullptr;
+        const bool own = possible && hipStreamSynchronize((hipStream_t)stream) == hipSuccess &&
+                         hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) == hipSuccess;
         for (int mode = 0; mode < 2 && possible && !rc; ++mode) {
             s->fs_force = mode;
             hipEvent_t e0, e1;
             if ((rc = iaf_step_forward(s, z, context, z_new, logsd, B, H, W, workspace, workspace_bytes, stream))) break;
+            HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+            hipGraphExec_t ge = nullptr;
+            if (own && hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                int crc = 0;
+                for (int r = 0; r < reps && !crc; ++r)
+                    crc = iaf_step_forward(s, z, context, z_new, logsd, B, H, W, workspace, workspace_bytes, cs);
+                hipGraph_t g = nullptr;
+                const bool ended = hipStreamEndCapture(cs, &g) == hipSuccess && g;
+                if (ended && !crc && hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) ge = nullptr;
+                if (g) (void)hipGraphDestroy(g);
+                (void)hipGetLastError();
+            }
+            hipStream_t ts = ge ? cs : (hipStream_t)stream;
+            if (ge) { (void)hipGraphLaunch(ge, cs); (void)hipStreamSynchronize(cs); }      // (the first replay uploads the graph)
             HIP_TRY(hipEventCreate(&e0));
             HIP_TRY(hipEventCreate(&e1));
-            HIP_TRY(hipEventRecord(e0, (hipStream_t)stream));
-            for (int r = 0; r < reps && !rc; ++r)
-                rc = iaf_step_forward(s, z, context, z_new, logsd, B, H, W, workspace, workspace_bytes, stream);
-            (void)hipEventRecord(e1, (hipStream_t)stream);
+            HIP_TRY(hipEventRecord(e0, ts));
+            if (ge) (void)hipGraphLaunch(ge, cs);
+            else
+                for (int r = 0; r < reps && !rc; ++r)
+                    rc = iaf_step_forward(s, z, context, z_new, logsd, B, H, W, workspace, workspace_bytes, stream);
+            (void)hipEventRecord(e1, ts);
             (void)hipEventSynchronize(e1);
             (void)hipEventElapsedTime(&t[mode], e0, e1);
             (void)hipEventDestroy(e0);
             (void)hipEventDestroy(e1);
+            if (ge) (void)hipGraphExecDestroy(ge);
         }
+        if (cs) (void)hipStreamDestroy(cs);
         s->fs_force = -1;
         if (!rc && possible) { s->fs_P = P; s->fs_W = W; s->fs_on = t[1] < t[0]; }
         if (!rc && possible && s->fs_on && chosen) for (int l = 0; l < s->nlayers; ++l) chosen[l] = -2;   // -2: part of the one-launch step

@@ -52,7 +52,9 @@ def test_where_the_step_runs_as_one_launch(amd):
     assert st.step_is_fused(32, 16, 16) == 2 and st.step_is_fused(32, 8, 8) == 1 and st.step_is_fused(256, 16, 16) == 2
     assert st.step_is_fused(256, 8, 8) == 0                      # large batch of small images: layer by layer (weight stream)
     assert st.step_is_fused(3, 5, 16) == 2                       # any height, any batch
-    assert st.step_is_fused(32, 4, 4) == 4                       # 4-pixel rows: a whole 4x4 image per workgroup
+    assert st.step_is_fused(32, 4, 4) == 0                       # 4-pixel rows, one workgroup per image walking 1.2 MB of weights: no
+    assert amd.ARStack(32, [64]).step_is_fused(16, 4, 4) == 4     # ... a whole 4x4 image per workgroup where the weight set is small
+    assert amd.ARStack(64, [64] * 4).step_is_fused(32, 4, 4) == 4 and amd.ARStack(64, [128] * 4).step_is_fused(32, 4, 4) == 0
     assert st.step_is_fused(32, 32, 32) == 0                     # no compiled geometry for 32-pixel rows
     assert amd.ARStack(32, [64]).step_is_fused(16, 16, 16) == 2   # BASELINE configs[0]
     deep = amd.ARStack(64, [192] * 4)                            # BASELINE configs[3]: five LDS regions
@@ -88,8 +90,7 @@ def test_iaf_step_and_raw_outputs_vs_oracle(amd, cfg):
     B, n_z, n_h, d, H, W = cfg
     params, z, ctx = _case(300 + H + W + d, *cfg)
     st = amd.ARStack(n_z, [n_h] * d)
-    if W == 8 and B * H >= 1024:
-        st.set_fuse_step("always")                                # two rows per workgroup at 8-pixel rows: beyond the size rule
+    st.set_fuse_step("always")                                    # also beyond the size rule: wherever a compiled geometry exists
     assert st.step_is_fused(B, H, W) == (4 if W == 4 else 2 if (W == 16 or B * H >= 1024) else 1)
     st.prepare({k: dev(v) for k, v in params.items()})
     zd, cd = dev(z), dev(ctx)
@@ -123,6 +124,7 @@ def test_posterior_block_vs_oracle(amd, cfg, kl_min):
     qm, ql, rm, rl, pm, pl = f(n_z), 0.25 * f(n_z), f(n_z), 0.25 * f(n_z), f(n_z), 0.25 * f(n_z)
     uc, dc, eps = f(n_h), f(n_h), f(n_z)
     st = amd.ARStack(n_z, [n_h] * d)
+    st.set_fuse_step("always")
     assert st.step_is_fused(B, H, W) > 0
     st.prepare({k: dev(v) for k, v in params.items()})
     out = st.posterior_block(dev(qm), dev(ql), dev(rm), dev(rl), dev(pm), dev(pl), dev(uc), dev(dc), dev(eps), kl_min,
