@@ -134,23 +134,37 @@ __device__ __forceinline__ void prep_tile(const PrepLayer& L, int gt, float (*re
     constexpr bool BF3 = (NCH % 2 == 0);
     float w3[BF3 ? PREP_BF3_UPQ_T(NCH, NTP) : 1][8];
     if constexpr (BF3) { if (L.wp3) prep_bf3_load<NCH, NTP>(L, gt, w3); }
-    // pass 1: fetch + mask (layers.py:57), sum of squares over (taps, c_in) (layers.py:60)
-    float v[NTP][NCH];
+    // pass 1: fetch + mask (layers.py:57), sum of squares over (taps, c_in) (layers.py:60).  A thread owns QUADS of four
+    // consecutive input channels, quad q = cs + 16 i (ci = 4q + jj): the four channels of a quad are the four floats a lane
+    // of the MFMA B fragment holds, so pass 2 writes them as ONE 16-byte store and a wave as 1 KiB contiguous (one channel
+    // per thread meant four dword stores 16 B apart).  Measured neutral on the batched launch (28.7 us either way: the launch
+    // is not bound by its store instructions; DESIGN.md 8 lists what is left to look at).
+    constexpr int NQI = (NCH + 3) / 4;
+    float v[NTP][4 * NQI];
 #pragma unroll
-    for (int it = 0; it < NCH; ++it) {
-        const int ci = cs + 16 * it;
+    for (int i = 0; i < NQI; ++i) {
+        const int q = cs + 16 * i;
+        const bool have = (NCH % 4 == 0) || q < 4 * NCH;
 #pragma unroll
-        for (int t = 0; t < NTP; ++t) {
-            v[t][it] = V[((size_t)(tap_kh<NTP>(t) * 3 + tap_kw<NTP>(t)) * n_in + ci) * n_out + o];
+        for (int jj = 0; jj < 4; ++jj) {
+            const int ci = have ? 4 * q + jj : jj;
+#pragma unroll
+            for (int t = 0; t < NTP; ++t) {
+                const float x = V[((size_t)(tap_kh<NTP>(t) * 3 + tap_kw<NTP>(t)) * n_in + ci) * n_out + o];
+                v[t][4 * i + jj] = have ? x : 0.f;
+            }
         }
     }
     float ss = 0.f;
 #pragma unroll
-    for (int it = 0; it < NCH; ++it) {
-        if (NTP == NTAPS && !made_live(cs + 16 * it, o, n_in, n_out, L.zerodiag)) v[0][it] = 0.f;   // centre tap: channel MADE mask
+    for (int i = 0; i < NQI; ++i)
 #pragma unroll
-        for (int t = 0; t < NTP; ++t) ss += v[t][it] * v[t][it];
-    }
+        for (int jj = 0; jj < 4; ++jj) {
+            const int ci = 4 * (cs + 16 * i) + jj;
+            if (NTP == NTAPS && !made_live(ci, o, n_in, n_out, L.zerodiag)) v[0][4 * i + jj] = 0.f;   // centre tap: channel MADE mask
+#pragma unroll
+            for (int t = 0; t < NTP; ++t) ss += v[t][4 * i + jj] * v[t][4 * i + jj];
+        }
     red[cs][oo] = ss;
     __syncthreads();
     if (cs == 0) {
@@ -162,20 +176,31 @@ __device__ __forceinline__ void prep_tile(const PrepLayer& L, int gt, float (*re
     }
     __syncthreads();
     const float scale = s_scale[oo];
-    // pass 2: write fragment-ordered weights.  lane = kk*16+oo holds channels chunk*16+4kk+{0..3};
-    // ci = cs + 16*it  ->  chunk = it, kk = cs>>2, jj = cs&3: a wave writes 256 contiguous bytes.
-    const int kk = cs >> 2, jj = cs & 3;
+    // pass 2: write fragment-ordered weights.  lane = kk*16+oo of chunk `it` holds channels it*16+4kk+{0..3} = quad q with
+    // it = q >> 2, kk = q & 3; a wave's four quads are the four kk of one chunk.
+    typedef float pf32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-    for (int it = 0; it < NCH; ++it)
+    for (int i = 0; i < NQI; ++i) {
+        const int q = cs + 16 * i;
+        if ((NCH % 4 != 0) && q >= 4 * NCH) continue;
 #pragma unroll
-        for (int t = 0; t < NTP; ++t)
-            L.wp[((((size_t)it * NTP + t) * L.ncot + gt) * 64 + kk * 16 + oo) * 4 + jj] = v[t][it] * scale;
-    if (L.wpt) {   // dgrad operand: K runs over the packed output channels (chunk = gt), N over input tiles (it)
+        for (int t = 0; t < NTP; ++t) {
+            const pf32x4 w4 = {v[t][4 * i] * scale, v[t][4 * i + 1] * scale, v[t][4 * i + 2] * scale, v[t][4 * i + 3] * scale};
+            ((pf32x4*)L.wp)[((((size_t)(q >> 2) * NTP + t) * L.ncot + gt) * 64 + (q & 3) * 16 + oo)] = w4;
+        }
+    }
+    if (L.wpt) {   // dgrad operand: K runs over the packed output channels (chunk = gt), N over input tiles (q >> 2)
 #pragma unroll
-        for (int it = 0; it < NCH; ++it)
+        for (int i = 0; i < NQI; ++i) {
+            const int q = cs + 16 * i;
+            if ((NCH % 4 != 0) && q >= 4 * NCH) continue;
 #pragma unroll
             for (int t = 0; t < NTP; ++t)
-                L.wpt[((((size_t)gt * NTP + t) * NCH + it) * 64 + (oo >> 2) * 16 + cs) * 4 + (oo & 3)] = v[t][it] * scale;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+                    L.wpt[((((size_t)gt * NTP + t) * NCH + (q >> 2)) * 64 + (oo >> 2) * 16 + 4 * (q & 3) + jj) * 4 + (oo & 3)] =
+                        v[t][4 * i + jj] * scale;
+        }
     }
     if constexpr (BF3) { if (L.wp3) prep_bf3_store<NCH, NTP>(L, gt, w3, s_scale); }
 }
