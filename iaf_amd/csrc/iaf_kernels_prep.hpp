@@ -39,6 +39,21 @@ struct PrepArgs {
     int nlayers;
 };
 
+// Experiment switch (IAF_EXTRA_CFLAGS=-DIAF_EXP_PREP_SCALAR, not measured yet): the kernels below take a
+// private COPY of their layer descriptor and index its two-element arrays at run time, which the compiler lowers to vector
+// loads of the 120-byte struct + a scratch copy (128 B per thread; 1216 B in iaf_prep_kernel) and keeps every pointer in
+// VGPRs (64-bit VALU address math per load).  The switch reads the descriptor in place (uniform address: scalar loads) and
+// selects the pair member with ?:.
+#ifdef IAF_EXP_PREP_SCALAR
+#define PREP_PICK(arr, which) ((which) ? (arr)[1] : (arr)[0])
+#define PREP_DESC(name, expr) const PrepLayer& name = (expr)
+#define PREP_IDX(x) __builtin_amdgcn_readfirstlane(x)
+#else
+#define PREP_PICK(arr, which) ((arr)[which])
+#define PREP_DESC(name, expr) const PrepLayer name = (expr)
+#define PREP_IDX(x) (x)
+#endif
+
 // filter position (kh,kw) of live tap t: the 5 MADE-live taps (centre, right, then the row below), or all 9 row-major
 template <int NTP> __device__ __forceinline__ int tap_kh(int t) { return NTP == 9 ? t / 3 : ((t == 0 || t == 1) ? 1 : 2); }
 template <int NTP> __device__ __forceinline__ int tap_kw(int t) { return NTP == 9 ? t % 3 : ((t == 0) ? 1 : (t == 1 ? 2 : t - 2)); }
@@ -55,7 +70,7 @@ template <int NCH, int NTP = NTAPS>
 __device__ __forceinline__ void prep_bf3_load(const PrepLayer& L, int gt, float (*w)[8]) {
     const int which = (L.npair == 2) ? (gt & 1) : 0;
     const int src_tile = (L.npair == 2) ? (gt >> 1) : gt;
-    const float* __restrict__ V = L.V[which];
+    const float* __restrict__ V = PREP_PICK(L.V, which);
     const int lane = threadIdx.x & 63, quarter = threadIdx.x >> 6;
     const int oo = lane & 15, kk = lane >> 4;
     const int o = src_tile * 16 + oo;
@@ -125,11 +140,11 @@ template <int NCH, int NTP = NTAPS>
 __device__ __forceinline__ void prep_tile(const PrepLayer& L, int gt, float (*red)[17], float* s_scale) {
     const int which = (L.npair == 2) ? (gt & 1) : 0;     // output pair: even tiles = mean, odd = logsd
     const int src_tile = (L.npair == 2) ? (gt >> 1) : gt;
-    const float* __restrict__ V = L.V[which];
+    const float* __restrict__ V = PREP_PICK(L.V, which);
     const int oo = threadIdx.x & 15, cs = threadIdx.x >> 4;
     const int o = src_tile * 16 + oo;
     const int n_out = L.cout_each, n_in = L.cin;
-    const float gval = L.g[which][o], bval = L.b[which][o];
+    const float gval = PREP_PICK(L.g, which)[o], bval = PREP_PICK(L.b, which)[o];
 
     constexpr bool BF3 = (NCH % 2 == 0);
     float w3[BF3 ? PREP_BF3_UPQ_T(NCH, NTP) : 1][8];
@@ -216,7 +231,7 @@ template <int NCH>
 __device__ __forceinline__ void prep_tile_theano(const PrepLayer& L, int gt, float (*red)[17], float* s_scale) {
     const int which = (L.npair == 2) ? (gt & 1) : 0;
     const int src_tile = (L.npair == 2) ? (gt >> 1) : gt;
-    const float* __restrict__ Wt = L.V[which];
+    const float* __restrict__ Wt = PREP_PICK(L.V, which);
     const int oo = threadIdx.x & 15, cs = threadIdx.x >> 4;
     const int o = src_tile * 16 + oo;
     const int n_out = L.cout_each, n_in = L.cin;
@@ -227,7 +242,7 @@ __device__ __forceinline__ void prep_tile_theano(const PrepLayer& L, int gt, flo
     // border-indicator channel (index n_in): real channel 0 maps to the (always masked) border column, and the border
     // channel's own centre tap maps to column 0 -- it multiplies zeros inside the image but it does enter the l2 norm.
     const bool flip = (L.variant == IAF_VARIANT_THEANO_FLIPMASK);
-    const float sval = L.g[which][o], bval = L.b[which][o];
+    const float sval = PREP_PICK(L.g, which)[o], bval = PREP_PICK(L.b, which)[o];
     const float* wo = Wt + (size_t)o * (n_in + 1) * 9;
     constexpr bool BF3 = (NCH % 2 == 0);
     float w3[BF3 ? PREP_BF3_UPQ(NCH) : 1][8];
@@ -351,7 +366,7 @@ __global__ __launch_bounds__(256) void iaf_prep_batch_kernel(const PrepLayer* __
                                                             const int* __restrict__ tile2layer) {
     __shared__ float red[16][17];
     __shared__ float s_scale[16];
-    const PrepLayer L = layers[tile2layer[blockIdx.x]];
+    PREP_DESC(L, layers[PREP_IDX(tile2layer[blockIdx.x])]);
     prep_dispatch(L, blockIdx.x - L.tile_begin, red, s_scale);
 }
 
@@ -361,7 +376,7 @@ __global__ __launch_bounds__(256) void iaf_prep_plain_kernel(const PrepLayer* __
                                                             const int* __restrict__ tile2layer) {
     __shared__ float red[16][17];
     __shared__ float s_scale[16];
-    const PrepLayer L = layers[tile2layer ? tile2layer[blockIdx.x] : 0];
+    PREP_DESC(L, layers[tile2layer ? PREP_IDX(tile2layer[blockIdx.x]) : 0]);
     const int gt = blockIdx.x - L.tile_begin;
     switch (L.nchunk) {
         case 1: prep_tile<1, MAXTAPS>(L, gt, red, s_scale); break;
@@ -386,9 +401,16 @@ __global__ __launch_bounds__(256) void iaf_prep_plain_kernel(const PrepLayer* __
 __global__ __launch_bounds__(256) void iaf_prep_kernel(PrepArgs a) {
     __shared__ float red[16][17];
     __shared__ float s_scale[16];
+#ifdef IAF_EXP_PREP_SCALAR   // (see PREP_DESC) the by-value argument block indexed at run time is copied to scratch: 1216 B per thread
+    PrepLayer L = a.L[0];
+#pragma unroll
+    for (int i = 1; i < MAX_GEMM_LAYERS; ++i)
+        if (i < a.nlayers && (int)blockIdx.x >= a.L[i].tile_begin) L = a.L[i];
+#else
     int li = 0;
     for (int i = 1; i < a.nlayers; ++i)
         if ((int)blockIdx.x >= a.L[i].tile_begin) li = i;
     const PrepLayer& L = a.L[li];
+#endif
     prep_dispatch(L, blockIdx.x - L.tile_begin, red, s_scale);
 }
