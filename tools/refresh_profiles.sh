@@ -1,7 +1,11 @@
-# Refresh the measured evidence under gpurun_out/r02/ (copied to profiles/r02/ afterwards):  gpurun -- 'bash tools/refresh_profiles.sh'
+# Refresh the measured evidence under gpurun_out/$ROUND/ (copied to profiles/$ROUND/ afterwards):
+#   gpurun --timeout 900 -- 'ROUND=r03 timeout 880 bash tools/refresh_profiles.sh'
+# Every rocprofv3 pass runs under its own `timeout`: counter collection serialises the launches, and a PMC pass over the
+# hipGraph-replayed bench.py did not finish in 400 s (round 2) -- PMC passes go over tools/run_step.py (eager, a few launches).
 set -x
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r02
+RD=${ROUND:-r02}
+O=$R/gpurun_out/$RD
 mkdir -p $O/pmc
 cd /tmp && export TMPDIR=/tmp
 python -m pytest $R/tests -q -m gpu 2>&1 | tail -4 > $O/pytest_gpu.txt
@@ -13,7 +17,7 @@ python $R/bench.py --iw-eval --steps 100 > $O/bench_iw_eval_n1.json 2> /dev/null
 IAF_BENCH_FORCE_DIST=1 python $R/bench.py --train --steps 50 > $O/bench_train_n1.json 2> /dev/null
 IAF_BENCH_FORCE_DIST=1 python $R/bench.py --train --layers --steps 20 --warmup 5 > $O/bench_train_layers_n1.json 2> /dev/null
 # kernel trace of the SAME command as the headline bench line
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb -o bench -- python $R/bench.py --no-cpu-baseline > $O/bench_rocprof_line.json 2>/dev/null
+timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb -o bench -- python $R/bench.py --no-cpu-baseline > $O/bench_rocprof_line.json 2>/dev/null
 cp /tmp/pb/*kernel_stats.csv $O/bench_kernel_stats.csv
 python - <<'PY'
 import csv, collections, glob, os
@@ -21,7 +25,7 @@ f = glob.glob('/tmp/pb/*kernel_trace.csv')[0]
 acc = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
     acc[(r['Kernel_Name'], r.get('Grid_Size_X', r.get('Grid_Size', '')), r.get('Workgroup_Size_X', r.get('Workgroup_Size', '')))].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
-out = os.environ['GRAFT_REPO_ROOT'] + '/gpurun_out/r02/bench_kernel_trace_by_grid.csv'
+out = os.environ['GRAFT_REPO_ROOT'] + '/gpurun_out/' + os.environ.get('ROUND', 'r02') + '/bench_kernel_trace_by_grid.csv'
 with open(out, 'w') as o:
     o.write('kernel,grid_x,wg_x,calls,avg_ns,total_ns\n')
     for (k, g, w), v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
@@ -31,11 +35,11 @@ PY
 # (bf16x3 with the launch shapes the autotune used to pick, and exact fp32)
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS"; do
   n=$(echo $c | tr ' ' '_')
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmcs_$n -o pmc -- python $R/tools/run_step.py --hw 16 --reps 10 --precision bf16x3 > /dev/null 2>&1
+  timeout 90 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmcs_$n -o pmc -- python $R/tools/run_step.py --hw 16 --reps 10 --precision bf16x3 > /dev/null 2>&1
   cp /tmp/pmcs_$n/*counter_collection.csv $O/pmc/step_${n}_counter_collection.csv
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$n -o pmc -- python $R/tools/run_step.py --hw 16 --reps 10 --precision bf16x3 --tune-bf3 "0:2,1,4,1;1:5,2,1,4;2:2,2,1,4" > /dev/null 2>&1
+  timeout 90 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$n -o pmc -- python $R/tools/run_step.py --hw 16 --reps 10 --precision bf16x3 --tune-bf3 "0:2,1,4,1;1:5,2,1,4;2:2,2,1,4" > /dev/null 2>&1
   cp /tmp/pmc_$n/*counter_collection.csv $O/pmc/bf16x3_${n}_counter_collection.csv
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmcf_$n -o pmc -- python $R/tools/run_step.py --hw 16 --reps 10 --precision f32 > /dev/null 2>&1
+  timeout 90 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmcf_$n -o pmc -- python $R/tools/run_step.py --hw 16 --reps 10 --precision f32 > /dev/null 2>&1
   cp /tmp/pmcf_$n/*counter_collection.csv $O/pmc/f32_${n}_counter_collection.csv
 done
 python $R/tools/pmc_summary.py $O/pmc > $O/pmc_summary.txt 2>&1
