@@ -871,10 +871,20 @@ static step_fn_t fused_step_plan(const iaf_stack_t* s, int B, int H, int W, int*
     return fn;
 }
 
+#ifdef IAF_EXP_FUSED_KL
+struct KlFold { float* part; unsigned* cnt; float* kl_obj; float* kl_cost; float* gate; float kl_min; };
+#else
+struct KlFold;
+#endif
 static int launch_fused_step(iaf_stack_t* s, step_fn_t fn, int R, size_t lds, const ConvP& base, int first_inmode, const float* ctx,
-                             const float* ctx2, hipStream_t st, float* const* hsave = nullptr) {
+                             const float* ctx2, hipStream_t st, float* const* hsave = nullptr, const KlFold* kf = nullptr) {
     StepP q;
     memset(&q, 0, sizeof(q));
+#ifdef IAF_EXP_FUSED_KL
+    if (kf) { q.kl_part = kf->part; q.kl_cnt = kf->cnt; q.kl_obj = kf->kl_obj; q.kl_cost = kf->kl_cost; q.kl_gate = kf->gate; q.kl_min = kf->kl_min; }
+#else
+    (void)kf;
+#endif
     if (hsave)
         for (int l = 0; l < s->depth_ar && l < 4; ++l) q.hsave[l] = hsave[l];
     q.z = (first_inmode == IN_POSTERIOR) ? nullptr : base.x;
@@ -1238,6 +1248,28 @@ extern "C" int iaf_posterior_block_forward(iaf_stack_t* s, const float* qz_mean,
     p.B = B; p.H = H; p.W = W; p.HW = H * W; p.P = B * H * W;
     p.qm = qz_mean; p.ql = qz_logsd; p.rm = rz_mean; p.rl = rz_logsd; p.pm = pz_mean; p.pl = pz_logsd; p.eps = eps;
     p.out0 = z_out; p.out1 = nullptr; p.kl_elem = kl_elem ? kl_elem : ws.kl_elem; p.mode = MODE_POSTERIOR;
+#ifdef IAF_EXP_FUSED_KL
+    // the KL reductions inside the one-launch step (StepP::kl_part).  Partial sums and the ticket counter live in the first
+    // hidden-activation buffer of the workspace, which this path does not use (the activations stay in LDS); the last
+    // workgroup stages S[B][n_z] + 258 words in the launch's LDS.
+    if (!s->generic && s->depth_ar > 0) {
+        int R = 0;
+        size_t lds = 0;
+        const bool aligned = (((uintptr_t)up_context | (uintptr_t)down_context) & 15) == 0;
+        step_fn_t fn = aligned ? fused_step_plan(s, B, H, W, &R, &lds) : nullptr;
+        const int nrb = fn ? (H + R - 1) / R : 0;
+        const size_t part_floats = (size_t)B * nrb * s->n_z;
+        if (fn && ((size_t)B * s->n_z + 258) * sizeof(float) <= lds &&
+            (part_floats + 1) * sizeof(float) <= (size_t)B * H * W * s->n_h * sizeof(float)) {
+            KlFold kf;
+            kf.part = ws.hbuf[0]; kf.cnt = (unsigned*)(ws.hbuf[0] + part_floats);
+            kf.kl_obj = kl_obj; kf.kl_cost = kl_cost; kf.gate = nullptr; kf.kl_min = kl_min;
+            HIP_TRY(hipMemsetAsync(kf.cnt, 0, sizeof(unsigned), st));
+            p.kl_elem = kl_elem;                                   // only if the caller wants the tensor
+            return launch_fused_step(s, fn, R, lds, p, IN_POSTERIOR, up_context, down_context, st, nullptr, &kf);
+        }
+    }
+#endif
     if ((rc = run_stack(s, p, IN_POSTERIOR, up_context, down_context, ws, st))) return rc;
     const int rows = B * s->n_z;
     hipLaunchKernelGGL(iaf_kl_rowsum_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, p.kl_elem, ws.rowsum, rows, H * W);

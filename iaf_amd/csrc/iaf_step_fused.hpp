@@ -485,6 +485,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     __syncthreads();
 
     // ---- affine transform, log-det term, KL elements (tf_train.py:56-75), NCHW stores coalesced along the rows -------
+#ifdef IAF_EXP_FUSED_KL
+    float klv[NEL];
+#pragma unroll
+    for (int e = 0; e < NEL; ++e) klv[e] = 0.f;
+#endif
 #pragma unroll
     for (int e = 0; e < NEL; ++e) {
         const int idx = tid + e * 256;
@@ -533,9 +538,81 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const float logps = -0.5f * (1.8378770664093453f + plv + d1 * d1 / __expf(plv));      // :73
             p.out0[gi] = zz;
             if (p.out1) p.out1[gi] = s;
+#ifdef IAF_EXP_FUSED_KL
+            klv[e] = logqs - logps;
+            if (p.kl_elem) p.kl_elem[gi] = klv[e];
+#else
             p.kl_elem[gi] = logqs - logps;                                                        // :75
+#endif
         }
     }
+#ifdef IAF_EXP_FUSED_KL
+    // ---- the block's KL reductions (tf_train.py:77-85) behind the same launch: see StepP::kl_part ---------------------
+    // Hand-off between workgroups: plain stores of the partial sums, every wave drains them, barrier, ONE lane releases at
+    // agent scope and takes the ticket; the last arriver acquires at agent scope (one lane, then a barrier) and reads the
+    // partials with plain vector loads.  No assumption on dispatch order or placement; nobody waits for anybody.
+    if (p.mode == MODE_POSTERIOR && p.kl_part) {
+        constexpr int RW = R * W;
+        static_assert((RW & (RW - 1)) == 0 && RW <= 64 && 256 % RW == 0, "a channel's pixels are RW consecutive lanes of one wave");
+#pragma unroll
+        for (int e = 0; e < NEL; ++e) {
+            float a = klv[e];                                       // (0 for rows past the image bottom and surplus lanes)
+#pragma unroll
+            for (int o = RW / 2; o > 0; o >>= 1) a += __shfl_xor(a, o);
+            const int idx = tid + e * 256;
+            if (idx < NZ * RW && (idx & (RW - 1)) == 0) p.kl_part[(size_t)blockIdx.x * NZ + idx / RW] = a;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                           // (also: every read of the exchange buffer is done, LDS is free)
+        float* sh = (float*)smem;
+        const int n = p.B * NZ;
+        float* red = sh + n;                                       // [256]
+        float* s_fb = sh + n + 256;
+        int* s_last = (int*)(sh + n + 257);
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned ticket = __hip_atomic_fetch_add(p.kl_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *s_last = (ticket == gridDim.x - 1) ? 1 : 0;
+        }
+        __syncthreads();
+        if (*s_last) {
+            if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __syncthreads();
+            float* part = p.kl_part;
+            for (int i = tid; i < n; i += 256) {                   // S[b][c] = sum over the image's row blocks, in row order
+                const int bb = i / NZ, c = i - bb * NZ;
+                float a = 0.f;
+                for (int r = 0; r < p.nrb; ++r) a += part[((size_t)bb * p.nrb + r) * NZ + c];
+                sh[i] = a;
+            }
+            __syncthreads();
+            if (p.kl_min > 0.f) {                                  // kl_ave[c] = max(mean_b S[b,c], kl_min); kl_obj[b] = sum_c kl_ave[c]
+                float a = 0.f;
+                for (int c = tid; c < NZ; c += 256) {
+                    float m = 0.f;
+                    for (int bb = 0; bb < p.B; ++bb) m += sh[bb * NZ + c];
+                    a += fmaxf(m / (float)p.B, p.kl_min);
+                    if (p.kl_gate) p.kl_gate[c] = (m / (float)p.B > p.kl_min) ? 1.f : 0.f;
+                }
+                red[tid] = a;
+                __syncthreads();
+                for (int o = 128; o > 0; o >>= 1) {
+                    if (tid < o) red[tid] += red[tid + o];
+                    __syncthreads();
+                }
+                if (tid == 0) *s_fb = red[0];
+                __syncthreads();
+            }
+            for (int bb = tid; bb < p.B; bb += 256) {
+                float a = 0.f;
+                for (int c = 0; c < NZ; ++c) a += sh[bb * NZ + c];
+                p.kl_cost[bb] = a;                                  // tf_train.py:85
+                p.kl_obj[bb] = (p.kl_min > 0.f) ? *s_fb : a;        // tf_train.py:82 / 84
+            }
+        }
+    }
+#endif
     IAF_FSTAMP(5);
 #undef IAF_FSTAMP
 }

@@ -20,6 +20,19 @@ struct StepP {
     // where a tap leaves the image (Theano variants only)
     const float* border[5];
     unsigned long long* dbg;   // dev tool: per-workgroup cycle stamps [grid][8]
+#ifdef IAF_EXP_FUSED_KL
+    // Experiment (written, not yet run on a GPU): the posterior block's KL reductions inside this launch.
+    // Every workgroup leaves the per-channel sums of its rows' KL elements in kl_part [B * nrb][n_z], takes a ticket from
+    // kl_cnt (zeroed by a memset node ahead of every launch); the workgroup that draws the last ticket sums the partials in a
+    // fixed order and applies the free-bits rule (tf_train.py:77-85) -- what iaf_kl_rowsum_kernel + iaf_kl_finish_kernel do
+    // in two more launches.  kl_elem may then be NULL (no [B, n_z, H, W] KL tensor is written).
+    float* kl_part;
+    unsigned* kl_cnt;
+    float* kl_obj;             // [B]
+    float* kl_cost;            // [B]
+    float* kl_gate;            // [n_z] or NULL (training: where the free-bits max() passes the gradient)
+    float kl_min;
+#endif
 };
 
 typedef void (*step_fn_t)(StepP);
