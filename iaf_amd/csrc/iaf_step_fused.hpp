@@ -548,9 +548,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 #ifdef IAF_EXP_FUSED_KL
     // ---- the block's KL reductions (tf_train.py:77-85) behind the same launch: see StepP::kl_part ---------------------
-    // Hand-off between workgroups: plain stores of the partial sums, every wave drains them, barrier, ONE lane releases at
-    // agent scope and takes the ticket; the last arriver acquires at agent scope (one lane, then a barrier) and reads the
-    // partials with plain vector loads.  No assumption on dispatch order or placement; nobody waits for anybody.
+    // Hand-off between workgroups: write-through stores of the partial sums, every wave drains them, barrier, ONE lane takes
+    // the ticket; the last arriver acquires at agent scope (one lane, then a barrier) and reads the partials with plain
+    // vector loads.  No assumption on dispatch order or placement; nobody waits for anybody.
+    // Measured (round 2, the first form: plain stores + release fence, serial partial loads): results exact to fp32 round-off
+    // against torch reductions of the same KL elements, but 48.3 vs 42.0 us per block at 16x16 and 33.9 vs 27.6 us at 8x8 --
+    // SLOWER than the two launches it replaces.  The release fence wrote back the whole L2 from every workgroup and the last
+    // workgroup's row-block loop ran its loads one latency after the other; this form (write-through partials, no release
+    // fence, eight loads in flight) has not been timed yet.
     if (p.mode == MODE_POSTERIOR && p.kl_part) {
         constexpr int RW = R * W;
         static_assert((RW & (RW - 1)) == 0 && RW <= 64 && 256 % RW == 0, "a channel's pixels are RW consecutive lanes of one wave");
@@ -560,7 +565,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int o = RW / 2; o > 0; o >>= 1) a += __shfl_xor(a, o);
             const int idx = tid + e * 256;
-            if (idx < NZ * RW && (idx & (RW - 1)) == 0) p.kl_part[(size_t)blockIdx.x * NZ + idx / RW] = a;
+            // write-through (agent-scope relaxed atomic store = sc1): the partials reach the memory side without the
+            // release fence's write-back of everything else this L2 holds dirty (the launch's own 1 MB of outputs)
+            if (idx < NZ * RW && (idx & (RW - 1)) == 0)
+                __hip_atomic_store(p.kl_part + (size_t)blockIdx.x * NZ + idx / RW, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                           // (also: every read of the exchange buffer is done, LDS is free)
@@ -569,9 +577,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         float* red = sh + n;                                       // [256]
         float* s_fb = sh + n + 256;
         int* s_last = (int*)(sh + n + 257);
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) {                                            // (every storing wave drained its write-through stores above)
             const unsigned ticket = __hip_atomic_fetch_add(p.kl_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             *s_last = (ticket == gridDim.x - 1) ? 1 : 0;
         }
@@ -583,7 +589,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int i = tid; i < n; i += 256) {                   // S[b][c] = sum over the image's row blocks, in row order
                 const int bb = i / NZ, c = i - bb * NZ;
                 float a = 0.f;
-                for (int r = 0; r < p.nrb; ++r) a += part[((size_t)bb * p.nrb + r) * NZ + c];
+                for (int r0b = 0; r0b < p.nrb; r0b += 8) {          // eight independent loads in flight, summed in row order
+                    float v8[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int r = r0b + k < p.nrb ? r0b + k : p.nrb - 1;
+                        v8[k] = part[((size_t)bb * p.nrb + r) * NZ + c];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) a += (r0b + k < p.nrb) ? v8[k] : 0.f;
+                }
                 sh[i] = a;
             }
             __syncthreads();
