@@ -16,6 +16,9 @@ IAF_ERR_WORKSPACE = -5
 IAF_ERR_UNSUPPORTED = -6
 IAF_PRECISION_F32 = 0
 IAF_PRECISION_BF16X3 = 1
+IAF_PACK_F32 = 1
+IAF_PACK_BF16X3 = 2
+IAF_ABI_VERSION = 3                # must equal the library's iaf_abi_version(): a stale libiaf_hip.so is rejected
 IAF_VARIANT_TF = 0
 IAF_VARIANT_THEANO = 1
 IAF_VARIANT_THEANO_FLIPMASK = 2
@@ -75,6 +78,7 @@ SIGNATURES = {
     "iaf_stack_set_tuning_bf3": (ctypes.c_int, [_vp] + [ctypes.c_int] * 6),
     "iaf_stack_set_fuse_first": (ctypes.c_int, [_vp, ctypes.c_int]),
     "iaf_stack_set_fuse_step": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "iaf_stack_set_packs": (ctypes.c_int, [_vp, ctypes.c_int]),
     "iaf_stack_step_is_fused": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "iaf_stack_autotune": (ctypes.c_int, [_vp, _c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int,
                                           ctypes.c_int, _vp, ctypes.c_size_t, ctypes.c_int, _vp, ctypes.POINTER(ctypes.c_int),
@@ -155,6 +159,9 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)          # AttributeError here = header/library mismatch
             fn.restype, fn.argtypes = res, args
+        if l.iaf_abi_version() != IAF_ABI_VERSION:
+            raise IafHipError("%s has ABI version %d, this package binds version %d: rebuild it (`python -m iaf_amd.build`)"
+                              % (LIB_PATH, l.iaf_abi_version(), IAF_ABI_VERSION))
         _lib = l
     return _lib
 

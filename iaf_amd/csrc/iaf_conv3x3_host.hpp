@@ -217,18 +217,14 @@ struct iaf_conv3x3_prep_batch {
     int n, ntiles;
     iaf_conv3x3** convs;
     PrepLayer* h_layers;   // current descriptor table (host)
-    PrepLayer* h_ring;     // pinned snapshots for the async uploads (see iaf_prep_batch)
-    int ring_i;
-    PrepLayer* d_layers;
+    DescTable tab;         // its way to the device (see DescTable in iaf_engine.hip)
     int* d_tile2layer;
-    bool uploaded;
 };
 
 extern "C" int iaf_conv3x3_prep_batch_destroy(iaf_conv3x3_prep_batch_t* b) {
     if (!b) return IAF_ERR_NULL;
     free(b->h_layers);
-    if (b->h_ring) (void)hipHostFree(b->h_ring);
-    if (b->d_layers) (void)hipFree(b->d_layers);
+    desc_destroy(&b->tab);
     if (b->d_tile2layer) (void)hipFree(b->d_tile2layer);
     free(b->convs);
     delete b;
@@ -256,8 +252,7 @@ extern "C" int iaf_conv3x3_prep_batch_create(iaf_conv3x3_prep_batch_t** out, iaf
     int rc;
     b->h_layers = (PrepLayer*)calloc(n, sizeof(PrepLayer));
     if (!b->h_layers) { free(t2l); iaf_conv3x3_prep_batch_destroy(b); return (int)hipErrorOutOfMemory; }
-    if ((rc = (int)hipHostMalloc((void**)&b->h_ring, sizeof(PrepLayer) * n * PREP_RING)) != 0 ||
-        (rc = (int)hipMalloc((void**)&b->d_layers, sizeof(PrepLayer) * n)) != 0 ||
+    if ((rc = desc_init(&b->tab, sizeof(PrepLayer) * n)) != 0 ||
         (rc = (int)hipMalloc((void**)&b->d_tile2layer, sizeof(int) * nt)) != 0) {
         free(t2l); iaf_conv3x3_prep_batch_destroy(b); return rc;
     }
@@ -279,7 +274,7 @@ extern "C" int iaf_conv3x3_prep_batch_create(iaf_conv3x3_prep_batch_t** out, iaf
 extern "C" int iaf_conv3x3_prep_batch_run(iaf_conv3x3_prep_batch_t* b, const float* const* V, const float* const* g,
                                           const float* const* bias, void* stream) {
     if (!b || !V || !g || !bias) return IAF_ERR_NULL;
-    bool changed = !b->uploaded;
+    bool changed = false;
     for (int i = 0; i < b->n; ++i) {
         if (!V[i] || !g[i] || !bias[i]) return IAF_ERR_NULL;
         PrepLayer& P = b->h_layers[i];
@@ -288,14 +283,9 @@ extern "C" int iaf_conv3x3_prep_batch_run(iaf_conv3x3_prep_batch_t* b, const flo
         P.V[0] = V[i]; P.g[0] = g[i]; P.b[0] = bias[i]; P.wpt = wpt;
     }
     hipStream_t st = (hipStream_t)stream;
-    if (changed) {     // see iaf_prep_batch_run
-        PrepLayer* snap = b->h_ring + (size_t)b->ring_i * b->n;
-        b->ring_i = (b->ring_i + 1) % PREP_RING;
-        memcpy(snap, b->h_layers, sizeof(PrepLayer) * b->n);
-        HIP_TRY(hipMemcpyAsync(b->d_layers, snap, sizeof(PrepLayer) * b->n, hipMemcpyHostToDevice, st));
-        b->uploaded = true;
-    }
-    hipLaunchKernelGGL(iaf_prep_plain_kernel, dim3(b->ntiles), dim3(256), 0, st, b->d_layers, b->d_tile2layer);
+    const void* d_layers = nullptr;     // see iaf_prep_batch_run
+    { int rc = desc_upload(&b->tab, b->h_layers, changed, st, &d_layers); if (rc) return rc; }
+    hipLaunchKernelGGL(iaf_prep_plain_kernel, dim3(b->ntiles), dim3(256), 0, st, (const PrepLayer*)d_layers, b->d_tile2layer);
     HIP_TRY(hipGetLastError());
     for (int i = 0; i < b->n; ++i) b->convs[i]->prepared = true;
     return IAF_OK;
@@ -782,17 +772,16 @@ extern "C" int iaf_conv3x3_set_defer_weightnorm(iaf_conv3x3_t* c, int on) {
 struct iaf_conv3x3_wn_bwd_batch {
     int n, ntiles;
     iaf_conv3x3** convs;
-    WnBwdLayer* h_layers;
-    WnBwdLayer* d_layers;
+    WnBwdLayer* h_layers;   // current descriptor table (host)
+    DescTable tab;          // its way to the device (see DescTable in iaf_engine.hip)
     int* d_tile2layer;
     int* d_tile_begin;
-    bool uploaded;
 };
 
 extern "C" int iaf_conv3x3_wn_bwd_batch_destroy(iaf_conv3x3_wn_bwd_batch_t* b) {
     if (!b) return IAF_ERR_NULL;
-    if (b->h_layers) (void)hipHostFree(b->h_layers);
-    if (b->d_layers) (void)hipFree(b->d_layers);
+    free(b->h_layers);
+    desc_destroy(&b->tab);
     if (b->d_tile2layer) (void)hipFree(b->d_tile2layer);
     if (b->d_tile_begin) (void)hipFree(b->d_tile_begin);
     free(b->convs);
@@ -820,13 +809,13 @@ extern "C" int iaf_conv3x3_wn_bwd_batch_create(iaf_conv3x3_wn_bwd_batch_t** out,
     int* t2l = (int*)malloc(sizeof(int) * nt);
     int* tb = (int*)malloc(sizeof(int) * (n + 1));
     int rc;
-    if ((rc = (int)hipHostMalloc((void**)&b->h_layers, sizeof(WnBwdLayer) * n)) != 0 ||
-        (rc = (int)hipMalloc((void**)&b->d_layers, sizeof(WnBwdLayer) * n)) != 0 ||
+    b->h_layers = (WnBwdLayer*)calloc(n, sizeof(WnBwdLayer));
+    if (!b->h_layers) { free(t2l); free(tb); iaf_conv3x3_wn_bwd_batch_destroy(b); return (int)hipErrorOutOfMemory; }
+    if ((rc = desc_init(&b->tab, sizeof(WnBwdLayer) * n)) != 0 ||
         (rc = (int)hipMalloc((void**)&b->d_tile2layer, sizeof(int) * nt)) != 0 ||
         (rc = (int)hipMalloc((void**)&b->d_tile_begin, sizeof(int) * (n + 1))) != 0) {
         free(t2l); free(tb); iaf_conv3x3_wn_bwd_batch_destroy(b); return rc;
     }
-    memset(b->h_layers, 0, sizeof(WnBwdLayer) * n);
     int tile = 0;
     for (int i = 0; i < n; ++i) {
         const GemmLayer& L = convs[i]->L;
@@ -847,7 +836,7 @@ extern "C" int iaf_conv3x3_wn_bwd_batch_create(iaf_conv3x3_wn_bwd_batch_t** out,
 extern "C" int iaf_conv3x3_wn_bwd_batch_run(iaf_conv3x3_wn_bwd_batch_t* b, const float* const* V, const float* const* g,
                                             float* const* dV, float* const* dg, float* const* db, void* stream) {
     if (!b || !V || !g || !dV || !dg || !db) return IAF_ERR_NULL;
-    bool changed = !b->uploaded;
+    bool changed = false;
     for (int i = 0; i < b->n; ++i) {
         iaf_conv3x3* c = b->convs[i];
         if (!c->defer_wn || (!c->pending && !c->deconv)) return IAF_ERR_NOT_PREPARED;
@@ -861,11 +850,9 @@ extern "C" int iaf_conv3x3_wn_bwd_batch_run(iaf_conv3x3_wn_bwd_batch_t* b, const
         w.dW = c->own_dW; w.dbp = c->own_dbp; w.nslab = c->pend_nslab;
     }
     hipStream_t st = (hipStream_t)stream;
-    if (changed) {
-        HIP_TRY(hipMemcpyAsync(b->d_layers, b->h_layers, sizeof(WnBwdLayer) * b->n, hipMemcpyHostToDevice, st));
-        b->uploaded = true;
-    }
-    hipLaunchKernelGGL(iaf_wn_bwd_plain_batch_kernel, dim3(b->ntiles), dim3(256), 0, st, b->d_layers, b->d_tile2layer,
+    const void* d_layers = nullptr;
+    { int rc = desc_upload(&b->tab, b->h_layers, changed, st, &d_layers); if (rc) return rc; }
+    hipLaunchKernelGGL(iaf_wn_bwd_plain_batch_kernel, dim3(b->ntiles), dim3(256), 0, st, (const WnBwdLayer*)d_layers, b->d_tile2layer,
                        b->d_tile_begin);
     return (int)hipGetLastError();
 }

@@ -48,7 +48,8 @@
 
 #include "iaf_conv_kernel.hpp"
 
-#define IAF_ABI_VERSION 2   // 2: + iaf_conv3x3_*
+#define IAF_ABI_VERSION 3   // 2: + iaf_conv3x3_*; 3: bf16x3 default precision, THEANO_FLIPMASK, negative nt in autotune reports,
+                          //    iaf_stack_set_packs, iaf_comm_* (include/iaf_hip.h)
 #define MAX_GEMM_LAYERS 10   // depth_ar <= 9 hidden + 1 output pair
 
 #include "iaf_step_fused_types.hpp"
@@ -103,6 +104,7 @@ struct iaf_stack {
                               // the size rule / autotune's measurement favours it, 2 wherever a compiled geometry covers it
     long long fs_P = -1; int fs_W = 0; bool fs_on = false;   // ... unless iaf_stack_autotune measured this size: then what it found
     int fs_force = -1;        // (autotune's own measurements: -1 off, 0 / 1 = take this path regardless)
+    bool skip_f32_pack = false;   // iaf_stack_set_packs: the prep launches write the bf16x3 packs only
     bool prepared;
     size_t weight_bytes;  // raw V/g/b bytes of the stack (for the algorithmic byte count)
     // optional per-launch event timing of one layer
@@ -117,6 +119,74 @@ struct iaf_stack {
         hipError_t _e = (expr);                     \
         if (_e != hipSuccess) return (int)_e;       \
     } while (0)
+
+// ---- descriptor table of a batched prep launch: host-built PrepLayer array -> device ---------------------------------
+// (the ring of pinned snapshots had no completion tracking.)  An async upload reads its pinned source when the
+// copy EXECUTES, so the source must stay untouched until then:
+//  * eager streams: PREP_RING pinned snapshots, an event recorded behind each upload; a slot is rewritten only after its
+//    event has completed (the host waits if it ever runs PREP_RING pointer-changing prep runs ahead of the GPU);
+//  * stream capture: the captured copy node reads its source at EVERY replay, so each captured run gets its own pinned
+//    snapshot AND its own device table, frozen for the life of the batch object (PREP_CAPTURE_SLOTS of them, allocated up
+//    front: no allocation inside a capture): a replay neither reads a recycled snapshot nor overwrites the table the eager
+//    runs keep in sync with their host copy.
+#define PREP_RING 4
+#define PREP_CAPTURE_SLOTS 16
+struct DescTable {
+    size_t bytes;
+    char* h_ring;                  // pinned: PREP_RING eager snapshots, then PREP_CAPTURE_SLOTS capture snapshots
+    char* d_tabs;                  // device: table 0 = the eager one, then one per capture slot
+    hipEvent_t ev[PREP_RING];
+    bool pending[PREP_RING];
+    int ring_i, ncap;
+    bool uploaded;                 // the eager device table holds the caller's current host copy
+};
+static size_t desc_stride(const DescTable* t) { return (t->bytes + 255) / 256 * 256; }
+static int desc_init(DescTable* t, size_t bytes) {
+    memset(t, 0, sizeof(*t));
+    t->bytes = bytes;
+    const size_t st = desc_stride(t);
+    HIP_TRY(hipHostMalloc((void**)&t->h_ring, st * (PREP_RING + PREP_CAPTURE_SLOTS)));
+    HIP_TRY(hipMalloc((void**)&t->d_tabs, st * (1 + PREP_CAPTURE_SLOTS)));
+    for (int i = 0; i < PREP_RING; ++i) HIP_TRY(hipEventCreateWithFlags(&t->ev[i], hipEventDisableTiming));
+    return IAF_OK;
+}
+static void desc_destroy(DescTable* t) {
+    for (int i = 0; i < PREP_RING; ++i)
+        if (t->ev[i]) (void)hipEventDestroy(t->ev[i]);
+    if (t->h_ring) (void)hipHostFree(t->h_ring);
+    if (t->d_tabs) (void)hipFree(t->d_tabs);
+    memset(t, 0, sizeof(*t));
+}
+// Makes `host` (t->bytes of descriptors) visible to a kernel launched on `st` behind this call; *d_out = the table to pass.
+// changed: the host copy differs from what the last eager upload carried.
+static int desc_upload(DescTable* t, const void* host, bool changed, hipStream_t st, const void** d_out) {
+    const size_t stride = desc_stride(t);
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (st) (void)hipStreamIsCapturing(st, &cs);
+    if (cs == hipStreamCaptureStatusActive) {
+        if (t->ncap >= PREP_CAPTURE_SLOTS) return IAF_ERR_UNSUPPORTED;       // more captured prep runs than this object carries
+        char* snap = t->h_ring + stride * (PREP_RING + t->ncap);
+        char* dtab = t->d_tabs + stride * (1 + t->ncap);
+        t->ncap++;
+        memcpy(snap, host, t->bytes);
+        HIP_TRY(hipMemcpyAsync(dtab, snap, t->bytes, hipMemcpyHostToDevice, st));
+        *d_out = dtab;
+        return IAF_OK;
+    }
+    if (changed || !t->uploaded) {
+        const int slot = t->ring_i;
+        t->ring_i = (t->ring_i + 1) % PREP_RING;
+        if (t->pending[slot]) { HIP_TRY(hipEventSynchronize(t->ev[slot])); t->pending[slot] = false; }
+        char* snap = t->h_ring + stride * slot;
+        memcpy(snap, host, t->bytes);
+        HIP_TRY(hipMemcpyAsync(t->d_tabs, snap, t->bytes, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipEventRecord(t->ev[slot], st));
+        t->pending[slot] = true;
+        t->uploaded = true;
+    }
+    *d_out = t->d_tabs;
+    return IAF_OK;
+}
 
 // one translation unit per launch shape (iaf_conv_inst.hip, compiled with -DIAF_PXT/-DIAF_WCO/-DIAF_KS)
 #define IAF_DECL_SHAPE(P, W, K) extern "C" conv_fn_t iaf_pick_conv_##P##_##W##_##K(int nt, int inmode, int epi);
@@ -443,7 +513,8 @@ extern "C" int iaf_stack_prepare(iaf_stack_t* s, const float* const* V, const fl
         PrepLayer& P = a.L[l];
         P.V[0] = V[l]; P.g[0] = g[l]; P.b[0] = b[l];
         if (L.npair == 2) { P.V[1] = V[l + 1]; P.g[1] = g[l + 1]; P.b[1] = b[l + 1]; }
-        P.wp = L.wp; P.bias = L.bias; P.border = L.border; P.variant = s->variant; P.wpt = L.wpt; P.wp3 = L.wp3;
+        P.wp = (s->skip_f32_pack && L.wp3) ? nullptr : L.wp;
+        P.bias = L.bias; P.border = L.border; P.variant = s->variant; P.wpt = L.wpt; P.wp3 = L.wp3;
         P.cin = L.cin; P.cout_each = L.cout / L.npair; P.ncot = L.ncot; P.nchunk = L.nchunk;
         P.zerodiag = L.zerodiag; P.npair = L.npair; P.tile_begin = tiles;
         tiles += L.ncot;
@@ -454,25 +525,20 @@ extern "C" int iaf_stack_prepare(iaf_stack_t* s, const float* const* V, const fl
     return IAF_OK;
 }
 
-#define PREP_RING 4
 // ---- batched prepare: all stacks of a model in ONE launch (weights of every layer are known at step start)
 struct iaf_prep_batch {
     int n;
     iaf_stack** stacks;
     int nlayers_total, ntiles;
     PrepLayer* h_layers;   // the current descriptor table (host; mutated by every run)
-    PrepLayer* h_ring;     // pinned staging, PREP_RING snapshots of h_layers: an async upload reads ITS OWN snapshot, so a
-    int ring_i;            // later run may rewrite h_layers while earlier uploads are still pending (also under graph replay)
-    PrepLayer* d_layers;
+    DescTable tab;         // its way to the device (pinned snapshots with completion tracking, per-capture tables)
     int* d_tile2layer;
-    bool uploaded;         // d_layers holds the current h_layers
 };
 
 extern "C" int iaf_prep_batch_destroy(iaf_prep_batch_t* b) {
     if (!b) return IAF_ERR_NULL;
     free(b->h_layers);
-    if (b->h_ring) (void)hipHostFree(b->h_ring);
-    if (b->d_layers) (void)hipFree(b->d_layers);
+    desc_destroy(&b->tab);
     if (b->d_tile2layer) (void)hipFree(b->d_tile2layer);
     free(b->stacks);
     delete b;
@@ -500,8 +566,7 @@ extern "C" int iaf_prep_batch_create(iaf_prep_batch_t** out, iaf_stack_t* const*
     int rc;
     b->h_layers = (PrepLayer*)calloc(nl, sizeof(PrepLayer));
     if (!b->h_layers) { free(t2l); iaf_prep_batch_destroy(b); return (int)hipErrorOutOfMemory; }
-    if ((rc = (int)hipHostMalloc((void**)&b->h_ring, sizeof(PrepLayer) * nl * PREP_RING)) != 0 ||
-        (rc = (int)hipMalloc((void**)&b->d_layers, sizeof(PrepLayer) * nl)) != 0 ||
+    if ((rc = desc_init(&b->tab, sizeof(PrepLayer) * nl)) != 0 ||
         (rc = (int)hipMalloc((void**)&b->d_tile2layer, sizeof(int) * nt)) != 0) {
         free(t2l); iaf_prep_batch_destroy(b); return rc;
     }
@@ -526,7 +591,7 @@ extern "C" int iaf_prep_batch_run(iaf_prep_batch_t* b, const float* const* V, co
                                   const float* const* bias, void* stream) {
     if (!b || !V || !g || !bias) return IAF_ERR_NULL;
     int li = 0, ci = 0;   // ci: running conv index over all stacks (depth_ar + 2 convs per stack)
-    bool changed = !b->uploaded;
+    bool changed = false;
     for (int i = 0; i < b->n; ++i) {
         const iaf_stack* s = b->stacks[i];
         for (int l = 0; l < s->nlayers; ++l, ++li) {
@@ -539,19 +604,17 @@ extern "C" int iaf_prep_batch_run(iaf_prep_batch_t* b, const float* const* V, co
             }
             changed |= (P.wpt != s->L[l].wpt);       // training switched on/off since the last run
             P.wpt = s->L[l].wpt;
+            float* wp = (s->skip_f32_pack && s->L[l].wp3) ? nullptr : s->L[l].wp;      // iaf_stack_set_packs since the last run
+            changed |= (P.wp != wp);
+            P.wp = wp;
         }
         ci += s->depth_ar + 2;
     }
     hipStream_t st = (hipStream_t)stream;
     // the descriptor table only travels when a pointer in it changed (a training loop passes the same buffers every step)
-    if (changed) {
-        PrepLayer* snap = b->h_ring + (size_t)b->ring_i * b->nlayers_total;
-        b->ring_i = (b->ring_i + 1) % PREP_RING;
-        memcpy(snap, b->h_layers, sizeof(PrepLayer) * b->nlayers_total);
-        HIP_TRY(hipMemcpyAsync(b->d_layers, snap, sizeof(PrepLayer) * b->nlayers_total, hipMemcpyHostToDevice, st));
-        b->uploaded = true;
-    }
-    hipLaunchKernelGGL(iaf_prep_batch_kernel, dim3(b->ntiles), dim3(256), 0, st, b->d_layers, b->d_tile2layer);
+    const void* d_layers = nullptr;
+    { int rc = desc_upload(&b->tab, b->h_layers, changed, st, &d_layers); if (rc) return rc; }
+    hipLaunchKernelGGL(iaf_prep_batch_kernel, dim3(b->ntiles), dim3(256), 0, st, (const PrepLayer*)d_layers, b->d_tile2layer);
     HIP_TRY(hipGetLastError());
     for (int i = 0; i < b->n; ++i) b->stacks[i]->prepared = true;
     return IAF_OK;
@@ -707,6 +770,7 @@ static int launch_gemm(const iaf_stack_t* s, GemmLayer& L, int epi, bool negate_
         bf3 = fn != nullptr;
     }
     if (!bf3 && inmode == IN_FUSED0) return IAF_ERR_UNSUPPORTED;   // (host logic error)
+    if (!bf3 && s->skip_f32_pack && L.wp3) return IAF_ERR_NOT_PREPARED;   // iaf_stack_set_packs: this stack's fp32 pack is not kept up to date
     if (!bf3 && !L.user_tuned) auto_shape(L, epi == EPI_OUT, p.P, p.W);
     const int tm = bf3 ? 16 * L.b_ppw * L.b_pxt : 16 * L.pxt;
     const int yg = bf3 ? L.ncot / (L.b_nt * L.b_wco) : L.ncot / (L.nt * L.wco);
@@ -871,20 +935,12 @@ static step_fn_t fused_step_plan(const iaf_stack_t* s, int B, int H, int W, int*
     return fn;
 }
 
-#ifdef IAF_EXP_FUSED_KL
-struct KlFold { float* part; unsigned* cnt; float* kl_obj; float* kl_cost; float* gate; float kl_min; };
-#else
-struct KlFold;
-#endif
+// kl_part: posterior mode only -- per-(row block, channel) sums of the KL elements, [B * nrb][n_z] (StepP::kl_part)
 static int launch_fused_step(iaf_stack_t* s, step_fn_t fn, int R, size_t lds, const ConvP& base, int first_inmode, const float* ctx,
-                             const float* ctx2, hipStream_t st, float* const* hsave = nullptr, const KlFold* kf = nullptr) {
+                             const float* ctx2, hipStream_t st, float* const* hsave = nullptr, float* kl_part = nullptr) {
     StepP q;
     memset(&q, 0, sizeof(q));
-#ifdef IAF_EXP_FUSED_KL
-    if (kf) { q.kl_part = kf->part; q.kl_cnt = kf->cnt; q.kl_obj = kf->kl_obj; q.kl_cost = kf->kl_cost; q.kl_gate = kf->gate; q.kl_min = kf->kl_min; }
-#else
-    (void)kf;
-#endif
+    q.kl_part = kl_part;
     if (hsave)
         for (int l = 0; l < s->depth_ar && l < 4; ++l) q.hsave[l] = hsave[l];
     q.z = (first_inmode == IN_POSTERIOR) ? nullptr : base.x;
@@ -905,6 +961,23 @@ static int launch_fused_step(iaf_stack_t* s, step_fn_t fn, int R, size_t lds, co
     return (int)hipGetLastError();
 }
 
+// The rest of the posterior block's reductions behind a one-launch step that left its partial sums in part [B][nrb][Z]
+// (tf_train.py:77-85): ONE 256-thread launch while one workgroup can walk the partials (B = 32: 8 k loads), a many-workgroup
+// row-block sum in front of it beyond that (config 5, B = 256).  rowsum: [B * Z] floats of scratch.
+static int launch_kl_from_parts(const float* part, float* rowsum, float* kl_obj, float* kl_cost, int B, int Z, int nrb, float kl_min,
+                                float* gate, hipStream_t st) {
+    const long long loads = (long long)B * nrb * Z;
+    if (loads <= 16384) {
+        hipLaunchKernelGGL(iaf_kl_finish_kernel, dim3(1), dim3(256), 0, st, part, kl_obj, kl_cost, B, Z, kl_min, gate, nrb, rowsum);
+    } else {
+        const int n = B * Z;
+        hipLaunchKernelGGL(iaf_kl_partsum_kernel, dim3((n + 255) / 256), dim3(256), 0, st, part, rowsum, n, Z, nrb);
+        hipLaunchKernelGGL(iaf_kl_finish_kernel, dim3(1), dim3(256), 0, st, (const float*)rowsum, kl_obj, kl_cost, B, Z, kl_min, gate, 0,
+                           (float*)nullptr);
+    }
+    return (int)hipGetLastError();
+}
+
 static int run_stack(iaf_stack_t* s, ConvP base, int first_inmode, const float* ctx, const float* ctx2, const Ws& ws,
                      hipStream_t st) {
     if (s->generic) return run_stack_generic(s, base, first_inmode, ctx, ctx2, ws, st);
@@ -922,6 +995,24 @@ static int run_stack(iaf_stack_t* s, ConvP base, int first_inmode, const float* 
         if (rc) return rc;
     }
     return IAF_OK;
+}
+
+// `reps` launches between ONE event pair on `st`; *avg_ms = elapsed / reps.  Releases its events on every path.
+template <class F>
+static int time_reps(hipStream_t st, int reps, float* avg_ms, F&& launch) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = (int)hipEventCreate(&e0);
+    if (!rc) rc = (int)hipEventCreate(&e1);
+    if (!rc) rc = (int)hipEventRecord(e0, st);
+    for (int r = 0; r < reps && !rc; ++r) rc = launch();
+    if (!rc) rc = (int)hipEventRecord(e1, st);
+    if (!rc) rc = (int)hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (!rc) rc = (int)hipEventElapsedTime(&ms, e0, e1);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    *avg_ms = ms / (float)reps;
+    return rc;
 }
 
 extern "C" int iaf_step_time_layer(iaf_stack_t* s, int layer, const float* z, const float* context, float* z_new,
@@ -946,22 +1037,10 @@ extern "C" int iaf_step_time_layer(iaf_stack_t* s, int layer, const float* z, co
         step_fn_t fn = fused_step_plan(s, B, H, W, &R, &lds);
         if (!fn) return IAF_ERR_UNSUPPORTED;
         if ((rc = launch_fused_step(s, fn, R, lds, p, IN_NCHW, context, nullptr, st))) return rc;
-        hipEvent_t e0, e1;
-        HIP_TRY(hipEventCreate(&e0));
-        HIP_TRY(hipEventCreate(&e1));
         const int saved = s->prof_layer;
         s->prof_layer = -1;
-        HIP_TRY(hipEventRecord(e0, st));
-        for (int r = 0; r < reps; ++r)
-            if ((rc = launch_fused_step(s, fn, R, lds, p, IN_NCHW, context, nullptr, st))) break;
-        (void)hipEventRecord(e1, st);
-        (void)hipEventSynchronize(e1);
-        float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, e0, e1);
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
+        rc = time_reps(st, reps, avg_ms, [&]() { return launch_fused_step(s, fn, R, lds, p, IN_NCHW, context, nullptr, st); });
         s->prof_layer = saved;
-        *avg_ms = ms / (float)reps;
         return rc;
     }
     Launch ls[MAX_GEMM_LAYERS];
@@ -973,22 +1052,10 @@ extern "C" int iaf_step_time_layer(iaf_stack_t* s, int layer, const float* z, co
         if (ls[0].inmode != IN_FUSED0) return IAF_ERR_UNSUPPORTED;
         layer = 0;
     }
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
     const int saved = s->prof_layer;
     s->prof_layer = -1;
-    HIP_TRY(hipEventRecord(e0, st));
-    for (int r = 0; r < reps; ++r)
-        if ((rc = launch_conv(s, ls[layer].layer, ls[layer].p, ls[layer].inmode, st, ls[layer].force))) break;
-    (void)hipEventRecord(e1, st);
-    (void)hipEventSynchronize(e1);
-    float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, e0, e1);
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
+    rc = time_reps(st, reps, avg_ms, [&]() { return launch_conv(s, ls[layer].layer, ls[layer].p, ls[layer].inmode, st, ls[layer].force); });
     s->prof_layer = saved;
-    *avg_ms = ms / (float)reps;
     return rc;
 }
 
@@ -1056,36 +1123,37 @@ extern "C" int iaf_stack_autotune(iaf_stack_t* s, const float* z, const float* c
         hipStream_t cs = nullptr;
         const bool own = possible && hipStreamSynchronize((hipStream_t)stream) == hipSuccess &&
                          hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) == hipSuccess;
+        // (no early return inside this loop: fs_force, the capture stream and the events are restored / released on every path)
         for (int mode = 0; mode < 2 && possible && !rc; ++mode) {
             s->fs_force = mode;
-            hipEvent_t e0, e1;
-            if ((rc = iaf_step_forward(s, z, context, z_new, logsd, B, H, W, workspace, workspace_bytes, stream))) break;
-            HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+            hipEvent_t e0 = nullptr, e1 = nullptr;
             hipGraphExec_t ge = nullptr;
-            if (own && hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-                int crc = 0;
-                for (int r = 0; r < reps && !crc; ++r)
-                    crc = iaf_step_forward(s, z, context, z_new, logsd, B, H, W, workspace, workspace_bytes, cs);
-                hipGraph_t g = nullptr;
-                const bool ended = hipStreamEndCapture(cs, &g) == hipSuccess && g;
-                if (ended && !crc && hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) ge = nullptr;
-                if (g) (void)hipGraphDestroy(g);
-                (void)hipGetLastError();
-            }
-            hipStream_t ts = ge ? cs : (hipStream_t)stream;
-            if (ge) { (void)hipGraphLaunch(ge, cs); (void)hipStreamSynchronize(cs); }      // (the first replay uploads the graph)
-            HIP_TRY(hipEventCreate(&e0));
-            HIP_TRY(hipEventCreate(&e1));
-            HIP_TRY(hipEventRecord(e0, ts));
-            if (ge) (void)hipGraphLaunch(ge, cs);
-            else
-                for (int r = 0; r < reps && !rc; ++r)
-                    rc = iaf_step_forward(s, z, context, z_new, logsd, B, H, W, workspace, workspace_bytes, stream);
-            (void)hipEventRecord(e1, ts);
-            (void)hipEventSynchronize(e1);
-            (void)hipEventElapsedTime(&t[mode], e0, e1);
-            (void)hipEventDestroy(e0);
-            (void)hipEventDestroy(e1);
+            do {
+                if ((rc = iaf_step_forward(s, z, context, z_new, logsd, B, H, W, workspace, workspace_bytes, stream))) break;
+                if ((rc = (int)hipStreamSynchronize((hipStream_t)stream))) break;
+                if (own && hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                    int crc = 0;
+                    for (int r = 0; r < reps && !crc; ++r)
+                        crc = iaf_step_forward(s, z, context, z_new, logsd, B, H, W, workspace, workspace_bytes, cs);
+                    hipGraph_t g = nullptr;
+                    const bool ended = hipStreamEndCapture(cs, &g) == hipSuccess && g;
+                    if (ended && !crc && hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) ge = nullptr;
+                    if (g) (void)hipGraphDestroy(g);
+                    (void)hipGetLastError();
+                }
+                hipStream_t ts = ge ? cs : (hipStream_t)stream;
+                if (ge) { (void)hipGraphLaunch(ge, cs); (void)hipStreamSynchronize(cs); }      // (the first replay uploads the graph)
+                if ((rc = (int)hipEventCreate(&e0)) || (rc = (int)hipEventCreate(&e1)) || (rc = (int)hipEventRecord(e0, ts))) break;
+                if (ge) (void)hipGraphLaunch(ge, cs);
+                else
+                    for (int r = 0; r < reps && !rc; ++r)
+                        rc = iaf_step_forward(s, z, context, z_new, logsd, B, H, W, workspace, workspace_bytes, stream);
+                (void)hipEventRecord(e1, ts);
+                (void)hipEventSynchronize(e1);
+                (void)hipEventElapsedTime(&t[mode], e0, e1);
+            } while (0);
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
             if (ge) (void)hipGraphExecDestroy(ge);
         }
         if (cs) (void)hipStreamDestroy(cs);
@@ -1124,6 +1192,20 @@ extern "C" int iaf_stack_autotune(iaf_stack_t* s, const float* z, const float* c
         if (L1.fz_on && us) { us[0] = 0.f; us[1] = 1e3f * best; }
     }
     return rc;
+}
+
+extern "C" int iaf_stack_set_packs(iaf_stack_t* s, int packs) {
+    if (!s) return IAF_ERR_NULL;
+    if (!(packs & IAF_PACK_BF16X3) || (packs & ~(IAF_PACK_F32 | IAF_PACK_BF16X3))) return IAF_ERR_SHAPE;
+    if (!(packs & IAF_PACK_F32)) {            // only a stack whose every layer has a bf16x3 pack can do without the fp32 one
+        if (s->generic || s->training) return IAF_ERR_UNSUPPORTED;
+        for (int l = 0; l < s->nlayers; ++l)
+            if (!s->L[l].wp3) return IAF_ERR_UNSUPPORTED;
+    }
+    const bool skip = !(packs & IAF_PACK_F32);
+    if (skip != s->skip_f32_pack) s->prepared = false;        // the next prepare brings the pack set up to date
+    s->skip_f32_pack = skip;
+    return IAF_OK;
 }
 
 extern "C" int iaf_stack_set_fuse_step(iaf_stack_t* s, int mode) {
@@ -1248,32 +1330,25 @@ extern "C" int iaf_posterior_block_forward(iaf_stack_t* s, const float* qz_mean,
     p.B = B; p.H = H; p.W = W; p.HW = H * W; p.P = B * H * W;
     p.qm = qz_mean; p.ql = qz_logsd; p.rm = rz_mean; p.rl = rz_logsd; p.pm = pz_mean; p.pl = pz_logsd; p.eps = eps;
     p.out0 = z_out; p.out1 = nullptr; p.kl_elem = kl_elem ? kl_elem : ws.kl_elem; p.mode = MODE_POSTERIOR;
-#ifdef IAF_EXP_FUSED_KL
-    // the KL reductions inside the one-launch step (StepP::kl_part).  Partial sums and the ticket counter live in the first
-    // hidden-activation buffer of the workspace, which this path does not use (the activations stay in LDS); the last
-    // workgroup stages S[B][n_z] + 258 words in the launch's LDS.
+    // One-launch step: its final loop leaves per-(row block, channel) sums of the KL elements in the first hidden-activation
+    // buffer of the workspace (which this path does not use: the activations stay in LDS) and ONE small launch finishes the
+    // reductions; the [B, n_z, H, W] KL tensor is written only if the caller asked for it.
     if (!s->generic && s->depth_ar > 0) {
         int R = 0;
         size_t lds = 0;
         const bool aligned = (((uintptr_t)up_context | (uintptr_t)down_context) & 15) == 0;
-        step_fn_t fn = aligned ? fused_step_plan(s, B, H, W, &R, &lds) : nullptr;
-        const int nrb = fn ? (H + R - 1) / R : 0;
-        const size_t part_floats = (size_t)B * nrb * s->n_z;
-        if (fn && ((size_t)B * s->n_z + 258) * sizeof(float) <= lds &&
-            (part_floats + 1) * sizeof(float) <= (size_t)B * H * W * s->n_h * sizeof(float)) {
-            KlFold kf;
-            kf.part = ws.hbuf[0]; kf.cnt = (unsigned*)(ws.hbuf[0] + part_floats);
-            kf.kl_obj = kl_obj; kf.kl_cost = kl_cost; kf.gate = nullptr; kf.kl_min = kl_min;
-            HIP_TRY(hipMemsetAsync(kf.cnt, 0, sizeof(unsigned), st));
-            p.kl_elem = kl_elem;                                   // only if the caller wants the tensor
-            return launch_fused_step(s, fn, R, lds, p, IN_POSTERIOR, up_context, down_context, st, nullptr, &kf);
+        if (step_fn_t fn = aligned ? fused_step_plan(s, B, H, W, &R, &lds) : nullptr) {
+            const int nrb = (H + R - 1) / R;
+            p.kl_elem = kl_elem;
+            if ((rc = launch_fused_step(s, fn, R, lds, p, IN_POSTERIOR, up_context, down_context, st, nullptr, ws.hbuf[0]))) return rc;
+            return launch_kl_from_parts(ws.hbuf[0], ws.rowsum, kl_obj, kl_cost, B, s->n_z, nrb, kl_min, nullptr, st);
         }
     }
-#endif
     if ((rc = run_stack(s, p, IN_POSTERIOR, up_context, down_context, ws, st))) return rc;
     const int rows = B * s->n_z;
     hipLaunchKernelGGL(iaf_kl_rowsum_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, p.kl_elem, ws.rowsum, rows, H * W);
-    hipLaunchKernelGGL(iaf_kl_finish_kernel, dim3(1), dim3(256), 0, st, ws.rowsum, kl_obj, kl_cost, B, s->n_z, kl_min, (float*)nullptr);
+    hipLaunchKernelGGL(iaf_kl_finish_kernel, dim3(1), dim3(256), 0, st, (const float*)ws.rowsum, kl_obj, kl_cost, B, s->n_z, kl_min,
+                       (float*)nullptr, 0, (float*)nullptr);
     return (int)hipGetLastError();
 }
 
@@ -1286,7 +1361,8 @@ extern "C" int iaf_kl_free_bits(const float* kl_elem, float* kl_obj, float* kl_c
     hipStream_t st = (hipStream_t)stream;
     const int rows = B * C;
     hipLaunchKernelGGL(iaf_kl_rowsum_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, kl_elem, scratch, rows, HW);
-    hipLaunchKernelGGL(iaf_kl_finish_kernel, dim3(1), dim3(256), 0, st, (const float*)scratch, kl_obj, kl_cost, B, C, kl_min, (float*)nullptr);
+    hipLaunchKernelGGL(iaf_kl_finish_kernel, dim3(1), dim3(256), 0, st, (const float*)scratch, kl_obj, kl_cost, B, C, kl_min, (float*)nullptr,
+                       0, (float*)nullptr);
     return (int)hipGetLastError();
 }
 
@@ -1377,6 +1453,7 @@ extern "C" int iaf_stack_set_training(iaf_stack_t* s, int on) {
         T.nt = 1; T.pxt = 4; T.wco = 1; T.ks = 1; T.user_tuned = false;
     }
     s->training = true;
+    s->skip_f32_pack = false; // (training keeps every pack: iaf_stack_set_packs refuses training stacks)
     s->prepared = false;      // the transposed packs are written by the next prepare
     return IAF_OK;
 }
@@ -1746,17 +1823,16 @@ extern "C" int iaf_stack_set_defer_weightnorm(iaf_stack_t* s, int on) {
 struct iaf_wn_bwd_batch {
     int n, nconv, ntiles;
     iaf_stack** stacks;
-    WnBwdLayer* h_layers;   // pinned
-    WnBwdLayer* d_layers;
+    WnBwdLayer* h_layers;   // the current descriptor table (host; mutated by every run)
+    DescTable tab;          // its way to the device (see DescTable)
     int* d_tile2layer;
     int* d_tile_begin;
-    bool uploaded;
 };
 
 extern "C" int iaf_wn_bwd_batch_destroy(iaf_wn_bwd_batch_t* b) {
     if (!b) return IAF_ERR_NULL;
-    if (b->h_layers) (void)hipHostFree(b->h_layers);
-    if (b->d_layers) (void)hipFree(b->d_layers);
+    free(b->h_layers);
+    desc_destroy(&b->tab);
     if (b->d_tile2layer) (void)hipFree(b->d_tile2layer);
     if (b->d_tile_begin) (void)hipFree(b->d_tile_begin);
     free(b->stacks);
@@ -1785,13 +1861,13 @@ extern "C" int iaf_wn_bwd_batch_create(iaf_wn_bwd_batch_t** out, iaf_stack_t* co
     int* t2l = (int*)malloc(sizeof(int) * nt);
     int* tb = (int*)malloc(sizeof(int) * (nconv + 1));
     int rc;
-    if ((rc = (int)hipHostMalloc((void**)&b->h_layers, sizeof(WnBwdLayer) * nconv)) != 0 ||
-        (rc = (int)hipMalloc((void**)&b->d_layers, sizeof(WnBwdLayer) * nconv)) != 0 ||
+    b->h_layers = (WnBwdLayer*)calloc(nconv, sizeof(WnBwdLayer));
+    if (!b->h_layers) { free(t2l); free(tb); iaf_wn_bwd_batch_destroy(b); return (int)hipErrorOutOfMemory; }
+    if ((rc = desc_init(&b->tab, sizeof(WnBwdLayer) * nconv)) != 0 ||
         (rc = (int)hipMalloc((void**)&b->d_tile2layer, sizeof(int) * nt)) != 0 ||
         (rc = (int)hipMalloc((void**)&b->d_tile_begin, sizeof(int) * (nconv + 1))) != 0) {
         free(t2l); free(tb); iaf_wn_bwd_batch_destroy(b); return rc;
     }
-    memset(b->h_layers, 0, sizeof(WnBwdLayer) * nconv);
     int ci = 0, tile = 0;
     for (int i = 0; i < n; ++i) {
         const iaf_stack* s = stacks[i];
@@ -1819,7 +1895,7 @@ extern "C" int iaf_wn_bwd_batch_create(iaf_wn_bwd_batch_t** out, iaf_stack_t* co
 extern "C" int iaf_wn_bwd_batch_run(iaf_wn_bwd_batch_t* b, const float* const* V, const float* const* g, float* const* dV,
                                     float* const* dg, float* const* db, void* stream) {
     if (!b || !V || !g || !dV || !dg || !db) return IAF_ERR_NULL;
-    bool changed = !b->uploaded;
+    bool changed = false;
     int ci = 0;
     for (int i = 0; i < b->n; ++i) {
         const iaf_stack* s = b->stacks[i];
@@ -1839,11 +1915,9 @@ extern "C" int iaf_wn_bwd_batch_run(iaf_wn_bwd_batch_t* b, const float* const* V
         }
     }
     hipStream_t st = (hipStream_t)stream;
-    if (changed) {
-        HIP_TRY(hipMemcpyAsync(b->d_layers, b->h_layers, sizeof(WnBwdLayer) * b->nconv, hipMemcpyHostToDevice, st));
-        b->uploaded = true;
-    }
-    hipLaunchKernelGGL(iaf_wn_bwd_batch_kernel, dim3(b->ntiles), dim3(256), 0, st, b->d_layers, b->d_tile2layer, b->d_tile_begin);
+    const void* d_layers = nullptr;
+    { int rc = desc_upload(&b->tab, b->h_layers, changed, st, &d_layers); if (rc) return rc; }
+    hipLaunchKernelGGL(iaf_wn_bwd_batch_kernel, dim3(b->ntiles), dim3(256), 0, st, (const WnBwdLayer*)d_layers, b->d_tile2layer, b->d_tile_begin);
     return (int)hipGetLastError();
 }
 
@@ -1869,19 +1943,20 @@ extern "C" int iaf_posterior_block_forward_train(iaf_stack_t* s, const float* qz
     base.qm = qz_mean; base.ql = qz_logsd; base.rm = rz_mean; base.rl = rz_logsd; base.pm = pz_mean; base.pl = pz_logsd;
     base.eps = eps;
     base.out0 = z_out; base.out1 = tw.logsd; base.kl_elem = tw.klelem; base.mode = MODE_POSTERIOR;
-    bool one_launch = false;
     {
         int R = 0;
         size_t lds = 0;
         const bool aligned = (((uintptr_t)up_context | (uintptr_t)down_context) & 15) == 0;
         if (step_fn_t fn = aligned ? fused_step_plan(s, B, H, W, &R, &lds) : nullptr) {
-            if ((rc = launch_fused_step(s, fn, R, lds, base, IN_POSTERIOR, up_context, down_context, st, tw.h))) return rc;
-            one_launch = true;
+            // (the backward never reads the KL tensor: its buffer takes the per-row-block partial sums instead)
+            base.kl_elem = nullptr;
+            if ((rc = launch_fused_step(s, fn, R, lds, base, IN_POSTERIOR, up_context, down_context, st, tw.h, tw.klelem))) return rc;
+            return launch_kl_from_parts(tw.klelem, tw.rowsum, kl_obj, kl_cost, B, s->n_z, (H + R - 1) / R, kl_min, tw.gate, st);
         }
     }
     const float* cur = nullptr;
     int inmode = IN_POSTERIOR;
-    for (int l = 0; l < s->depth_ar && !one_launch; ++l) {
+    for (int l = 0; l < s->depth_ar; ++l) {
         ConvP p = base;
         p.x = cur;
         p.ctx = (l == 0) ? up_context : nullptr;
@@ -1891,14 +1966,15 @@ extern "C" int iaf_posterior_block_forward_train(iaf_stack_t* s, const float* qz
         cur = p.y;
         inmode = IN_PIXMAJOR;
     }
-    if (!one_launch) {
+    {
         ConvP p = base;
         p.x = cur;
         if ((rc = launch_conv(s, s->depth_ar, p, inmode, st))) return rc;
     }
     const int rows = B * s->n_z;
     hipLaunchKernelGGL(iaf_kl_rowsum_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, tw.klelem, tw.rowsum, rows, H * W);
-    hipLaunchKernelGGL(iaf_kl_finish_kernel, dim3(1), dim3(256), 0, st, tw.rowsum, kl_obj, kl_cost, B, s->n_z, kl_min, tw.gate);
+    hipLaunchKernelGGL(iaf_kl_finish_kernel, dim3(1), dim3(256), 0, st, (const float*)tw.rowsum, kl_obj, kl_cost, B, s->n_z, kl_min, tw.gate, 0,
+                       (float*)nullptr);
     return (int)hipGetLastError();
 }
 

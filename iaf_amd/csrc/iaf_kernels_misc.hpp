@@ -19,19 +19,40 @@ __global__ __launch_bounds__(256) void iaf_kl_rowsum_kernel(const float* kl, flo
 
 // gate (optional, [Z]): 1 where the free-bits max() passes the gradient (mean_b S[b,c] > kl_min), else 0 -- what the
 // backward of tf_train.py:79-80 needs; written here because the batch mean is already on hand.
+// nrb > 0: S holds per-row-block partial sums [B][nrb][Z] (the one-launch step's StepP::kl_part) and the sum over the row
+// blocks -- in row order, eight loads in flight -- is the first thing this launch does; nrb = 0: S is [B][Z].
+// scratch ([B*Z] floats) is only touched when B*Z does not fit the LDS staging.
 __global__ __launch_bounds__(256) void iaf_kl_finish_kernel(const float* S, float* kl_obj, float* kl_cost, int B, int Z,
-                                                           float kl_min, float* gate = nullptr) {
+                                                           float kl_min, float* gate, int nrb, float* scratch) {
     // S is tiny ([B, Z]); stage it through LDS in one coalesced sweep instead of B*Z dependent global loads
     __shared__ float sh[8192];
     __shared__ float part[256];
     __shared__ float s_fb;
     const int tid = threadIdx.x, n = B * Z;
     const bool in_lds = n <= 8192;
-    if (in_lds) {
+    if (nrb > 0) {
+        float* dst = in_lds ? sh : scratch;
+        for (int i = tid; i < n; i += 256) {
+            const int b = i / Z, c = i - b * Z;
+            float a = 0.f;
+            for (int r0 = 0; r0 < nrb; r0 += 8) {
+                float v8[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int r = r0 + k < nrb ? r0 + k : nrb - 1;
+                    v8[k] = S[((size_t)b * nrb + r) * Z + c];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a += (r0 + k < nrb) ? v8[k] : 0.f;
+            }
+            dst[i] = a;
+        }
+        __syncthreads();
+    } else if (in_lds) {
         for (int i = tid; i < n; i += 256) sh[i] = S[i];
         __syncthreads();
     }
-    const float* src = in_lds ? sh : S;
+    const float* src = in_lds ? sh : (nrb > 0 ? scratch : S);
     if (kl_min > 0.f) {
         // kl_ave[c] = max(mean_b S[b,c], kl_min); kl_obj[b] = sum_c kl_ave[c]   (tf_train.py:79-82)
         float a = 0.f;
@@ -56,6 +77,26 @@ __global__ __launch_bounds__(256) void iaf_kl_finish_kernel(const float* S, floa
         kl_cost[b] = a;                                        // tf_train.py:85
         kl_obj[b] = (kl_min > 0.f) ? s_fb : a;                 // tf_train.py:82 / 84
     }
+}
+
+// S[b][c] = sum over the row blocks of the partial sums [B][nrb][Z], in row order: the first phase of the kernel above as
+// its own many-workgroup launch, for batches whose partial sums are too many for ONE workgroup to walk (config 5: B = 256)
+__global__ __launch_bounds__(256) void iaf_kl_partsum_kernel(const float* part, float* S, int n, int Z, int nrb) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int b = i / Z, c = i - b * Z;
+    float a = 0.f;
+    for (int r0 = 0; r0 < nrb; r0 += 8) {
+        float v8[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int r = r0 + k < nrb ? r0 + k : nrb - 1;
+            v8[k] = part[((size_t)b * nrb + r) * Z + c];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a += (r0 + k < nrb) ? v8[k] : 0.f;
+    }
+    S[i] = a;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -39,20 +39,11 @@ struct PrepArgs {
     int nlayers;
 };
 
-// Experiment switch (IAF_EXTRA_CFLAGS=-DIAF_EXP_PREP_SCALAR, not measured yet): the kernels below take a
-// private COPY of their layer descriptor and index its two-element arrays at run time, which the compiler lowers to vector
-// loads of the 120-byte struct + a scratch copy (128 B per thread; 1216 B in iaf_prep_kernel) and keeps every pointer in
-// VGPRs (64-bit VALU address math per load).  The switch reads the descriptor in place (uniform address: scalar loads) and
-// selects the pair member with ?:.
-#ifdef IAF_EXP_PREP_SCALAR
+// The kernels below read their layer descriptor IN PLACE (a uniform address: scalar loads, pointers stay in SGPRs) and
+// select the member of the two-element arrays with ?:.  Round 2's first form took a private copy and indexed the arrays at
+// run time, which the compiler lowered to vector loads of the 120-byte struct + a scratch copy (128 B per thread; 1216 B in
+// iaf_prep_kernel) with every pointer in VGPRs: 9 us of the 29 us batched launch (A/B on one box, 456.9 vs 465.6 us/step).
 #define PREP_PICK(arr, which) ((which) ? (arr)[1] : (arr)[0])
-#define PREP_DESC(name, expr) const PrepLayer& name = (expr)
-#define PREP_IDX(x) __builtin_amdgcn_readfirstlane(x)
-#else
-#define PREP_PICK(arr, which) ((arr)[which])
-#define PREP_DESC(name, expr) const PrepLayer name = (expr)
-#define PREP_IDX(x) (x)
-#endif
 
 // filter position (kh,kw) of live tap t: the 5 MADE-live taps (centre, right, then the row below), or all 9 row-major
 template <int NTP> __device__ __forceinline__ int tap_kh(int t) { return NTP == 9 ? t / 3 : ((t == 0 || t == 1) ? 1 : 2); }
@@ -192,6 +183,7 @@ __device__ __forceinline__ void prep_tile_units(const PrepLayer& L, int gt, floa
         if (u >= NUNIT) continue;
         const int k = u / NTP, t = u - k * NTP;
         // fp32 pack: channels 8k + 4h + {0..3} = chunk k >> 1, fragment lane group kk = 2 (k & 1) + h
+        if (L.wp)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const pf32x4 w4 = {v[i][4 * h] * scale, v[i][4 * h + 1] * scale, v[i][4 * h + 2] * scale, v[i][4 * h + 3] * scale};
@@ -283,6 +275,7 @@ __device__ __forceinline__ void prep_tile(const PrepLayer& L, int gt, float (*re
     // pass 2: write fragment-ordered weights.  lane = kk*16+oo of chunk `it` holds channels it*16+4kk+{0..3} = quad q with
     // it = q >> 2, kk = q & 3; a wave's four quads are the four kk of one chunk.
     typedef float pf32x4 __attribute__((ext_vector_type(4)));
+    if (L.wp)                  // (NULL: the stack only feeds bf16x3 kernels, iaf_stack_set_packs)
 #pragma unroll
     for (int i = 0; i < NQI; ++i) {
         const int q = cs + 16 * i;
@@ -390,6 +383,7 @@ __device__ __forceinline__ void prep_tile_theano(const PrepLayer& L, int gt, flo
     __syncthreads();
     const float scale = s_scale[oo];
     const int kk = cs >> 2, jj = cs & 3;
+    if (L.wp)
 #pragma unroll
     for (int it = 0; it < NCH; ++it)
 #pragma unroll
@@ -455,7 +449,7 @@ __global__ __launch_bounds__(256) void iaf_prep_batch_kernel(const PrepLayer* __
                                                             const int* __restrict__ tile2layer) {
     __shared__ float red[16][17];
     __shared__ float s_scale[16];
-    PREP_DESC(L, layers[PREP_IDX(tile2layer[blockIdx.x])]);
+    const PrepLayer& L = layers[__builtin_amdgcn_readfirstlane(tile2layer[blockIdx.x])];
     prep_dispatch(L, blockIdx.x - L.tile_begin, red, s_scale);
 }
 
@@ -465,7 +459,7 @@ __global__ __launch_bounds__(256) void iaf_prep_plain_kernel(const PrepLayer* __
                                                             const int* __restrict__ tile2layer) {
     __shared__ float red[16][17];
     __shared__ float s_scale[16];
-    PREP_DESC(L, layers[tile2layer ? PREP_IDX(tile2layer[blockIdx.x]) : 0]);
+    const PrepLayer& L = layers[tile2layer ? __builtin_amdgcn_readfirstlane(tile2layer[blockIdx.x]) : 0];
     const int gt = blockIdx.x - L.tile_begin;
     switch (L.nchunk) {
         case 1: prep_tile<1, MAXTAPS>(L, gt, red, s_scale); break;
@@ -490,16 +484,9 @@ __global__ __launch_bounds__(256) void iaf_prep_plain_kernel(const PrepLayer* __
 __global__ __launch_bounds__(256) void iaf_prep_kernel(PrepArgs a) {
     __shared__ float red[16][17];
     __shared__ float s_scale[16];
-#ifdef IAF_EXP_PREP_SCALAR   // (see PREP_DESC) the by-value argument block indexed at run time is copied to scratch: 1216 B per thread
-    PrepLayer L = a.L[0];
+    PrepLayer L = a.L[0];          // (selected with uniform compares: indexing the by-value block at run time copies it to scratch)
 #pragma unroll
     for (int i = 1; i < MAX_GEMM_LAYERS; ++i)
         if (i < a.nlayers && (int)blockIdx.x >= a.L[i].tile_begin) L = a.L[i];
-#else
-    int li = 0;
-    for (int i = 1; i < a.nlayers; ++i)
-        if ((int)blockIdx.x >= a.L[i].tile_begin) li = i;
-    const PrepLayer& L = a.L[li];
-#endif
     prep_dispatch(L, blockIdx.x - L.tile_begin, red, s_scale);
 }

@@ -485,11 +485,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     __syncthreads();
 
     // ---- affine transform, log-det term, KL elements (tf_train.py:56-75), NCHW stores coalesced along the rows -------
-#ifdef IAF_EXP_FUSED_KL
-    float klv[NEL];
+    float klv[NEL];              // (0 for rows past the image bottom and surplus lanes)
 #pragma unroll
     for (int e = 0; e < NEL; ++e) klv[e] = 0.f;
-#endif
 #pragma unroll
     for (int e = 0; e < NEL; ++e) {
         const int idx = tid + e * 256;
@@ -538,96 +536,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const float logps = -0.5f * (1.8378770664093453f + plv + d1 * d1 / __expf(plv));      // :73
             p.out0[gi] = zz;
             if (p.out1) p.out1[gi] = s;
-#ifdef IAF_EXP_FUSED_KL
-            klv[e] = logqs - logps;
+            klv[e] = logqs - logps;                                                               // :75
             if (p.kl_elem) p.kl_elem[gi] = klv[e];
-#else
-            p.kl_elem[gi] = logqs - logps;                                                        // :75
-#endif
         }
     }
-#ifdef IAF_EXP_FUSED_KL
-    // ---- the block's KL reductions (tf_train.py:77-85) behind the same launch: see StepP::kl_part ---------------------
-    // Hand-off between workgroups: write-through stores of the partial sums, every wave drains them, barrier, ONE lane takes
-    // the ticket; the last arriver acquires at agent scope (one lane, then a barrier) and reads the partials with plain
-    // vector loads.  No assumption on dispatch order or placement; nobody waits for anybody.
-    // Measured (round 2, the first form: plain stores + release fence, serial partial loads): results exact to fp32 round-off
-    // against torch reductions of the same KL elements, but 48.3 vs 42.0 us per block at 16x16 and 33.9 vs 27.6 us at 8x8 --
-    // SLOWER than the two launches it replaces.  The release fence wrote back the whole L2 from every workgroup and the last
-    // workgroup's row-block loop ran its loads one latency after the other; this form (write-through partials, no release
-    // fence, eight loads in flight) has not been timed yet.
+    // ---- the block's KL reductions start here (tf_train.py:77, sum over H, W): a channel's R*W pixels are R*W consecutive
+    // lanes of one wave -> butterfly sum, one 4-byte store per (row block, channel); see StepP::kl_part
     if (p.mode == MODE_POSTERIOR && p.kl_part) {
         constexpr int RW = R * W;
         static_assert((RW & (RW - 1)) == 0 && RW <= 64 && 256 % RW == 0, "a channel's pixels are RW consecutive lanes of one wave");
 #pragma unroll
         for (int e = 0; e < NEL; ++e) {
-            float a = klv[e];                                       // (0 for rows past the image bottom and surplus lanes)
+            float a = klv[e];
 #pragma unroll
             for (int o = RW / 2; o > 0; o >>= 1) a += __shfl_xor(a, o);
             const int idx = tid + e * 256;
-            // write-through (agent-scope relaxed atomic store = sc1): the partials reach the memory side without the
-            // release fence's write-back of everything else this L2 holds dirty (the launch's own 1 MB of outputs)
-            if (idx < NZ * RW && (idx & (RW - 1)) == 0)
-                __hip_atomic_store(p.kl_part + (size_t)blockIdx.x * NZ + idx / RW, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                           // (also: every read of the exchange buffer is done, LDS is free)
-        float* sh = (float*)smem;
-        const int n = p.B * NZ;
-        float* red = sh + n;                                       // [256]
-        float* s_fb = sh + n + 256;
-        int* s_last = (int*)(sh + n + 257);
-        if (tid == 0) {                                            // (every storing wave drained its write-through stores above)
-            const unsigned ticket = __hip_atomic_fetch_add(p.kl_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *s_last = (ticket == gridDim.x - 1) ? 1 : 0;
-        }
-        __syncthreads();
-        if (*s_last) {
-            if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            __syncthreads();
-            float* part = p.kl_part;
-            for (int i = tid; i < n; i += 256) {                   // S[b][c] = sum over the image's row blocks, in row order
-                const int bb = i / NZ, c = i - bb * NZ;
-                float a = 0.f;
-                for (int r0b = 0; r0b < p.nrb; r0b += 8) {          // eight independent loads in flight, summed in row order
-                    float v8[8];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const int r = r0b + k < p.nrb ? r0b + k : p.nrb - 1;
-                        v8[k] = part[((size_t)bb * p.nrb + r) * NZ + c];
-                    }
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) a += (r0b + k < p.nrb) ? v8[k] : 0.f;
-                }
-                sh[i] = a;
-            }
-            __syncthreads();
-            if (p.kl_min > 0.f) {                                  // kl_ave[c] = max(mean_b S[b,c], kl_min); kl_obj[b] = sum_c kl_ave[c]
-                float a = 0.f;
-                for (int c = tid; c < NZ; c += 256) {
-                    float m = 0.f;
-                    for (int bb = 0; bb < p.B; ++bb) m += sh[bb * NZ + c];
-                    a += fmaxf(m / (float)p.B, p.kl_min);
-                    if (p.kl_gate) p.kl_gate[c] = (m / (float)p.B > p.kl_min) ? 1.f : 0.f;
-                }
-                red[tid] = a;
-                __syncthreads();
-                for (int o = 128; o > 0; o >>= 1) {
-                    if (tid < o) red[tid] += red[tid + o];
-                    __syncthreads();
-                }
-                if (tid == 0) *s_fb = red[0];
-                __syncthreads();
-            }
-            for (int bb = tid; bb < p.B; bb += 256) {
-                float a = 0.f;
-                for (int c = 0; c < NZ; ++c) a += sh[bb * NZ + c];
-                p.kl_cost[bb] = a;                                  // tf_train.py:85
-                p.kl_obj[bb] = (p.kl_min > 0.f) ? *s_fb : a;        // tf_train.py:82 / 84
-            }
+            if (idx < NZ * RW && (idx & (RW - 1)) == 0) p.kl_part[(size_t)blockIdx.x * NZ + idx / RW] = a;
         }
     }
-#endif
     IAF_FSTAMP(5);
 #undef IAF_FSTAMP
 }

@@ -20,19 +20,12 @@ struct StepP {
     // where a tap leaves the image (Theano variants only)
     const float* border[5];
     unsigned long long* dbg;   // dev tool: per-workgroup cycle stamps [grid][8]
-#ifdef IAF_EXP_FUSED_KL
-    // Experiment (written, not yet run on a GPU): the posterior block's KL reductions inside this launch.
-    // Every workgroup leaves the per-channel sums of its rows' KL elements in kl_part [B * nrb][n_z], takes a ticket from
-    // kl_cnt (zeroed by a memset node ahead of every launch); the workgroup that draws the last ticket sums the partials in a
-    // fixed order and applies the free-bits rule (tf_train.py:77-85) -- what iaf_kl_rowsum_kernel + iaf_kl_finish_kernel do
-    // in two more launches.  kl_elem may then be NULL (no [B, n_z, H, W] KL tensor is written).
+    // Posterior mode: per-channel sums of the workgroup's KL elements, [B * nrb][n_z] -- the first step of the block's
+    // reductions (tf_train.py:77: sum over H, W) leaves the launch as 1/(R*W) of the bytes of the KL tensor, and kl_elem may
+    // then be NULL (no [B, n_z, H, W] KL tensor is written or re-read).  The row blocks are summed in row order, the batch
+    // mean / free-bits max / channel sum applied (tf_train.py:79-85) by iaf_kl_finish_kernel: ONE small launch behind this
+    // one instead of the two (row sums over the KL tensor + finish) of round 2.  NULL: no partial sums are written.
     float* kl_part;
-    unsigned* kl_cnt;
-    float* kl_obj;             // [B]
-    float* kl_cost;            // [B]
-    float* kl_gate;            // [n_z] or NULL (training: where the free-bits max() passes the gradient)
-    float kl_min;
-#endif
 };
 
 typedef void (*step_fn_t)(StepP);

@@ -268,6 +268,20 @@ class ARStack(object):
         code = {"never": 0, "auto": 1, "always": 2}.get(mode, mode)
         _capi.check(_capi.lib().iaf_stack_set_fuse_step(self._h, int(code)))
 
+    def posterior_block_launches(self, B, H, W):
+        """what posterior_block launches at this size (a description for bench lines)"""
+        R = self.step_is_fused(B, H, W)
+        if R:
+            nrb = -(-H // R)
+            return ("1 one-launch IAF step (its final loop leaves per-row-block KL sums) + %d KL reduction launch(es)"
+                    % (1 if B * nrb * self.n_z <= 16384 else 2))
+        return "%d masked convs + 2 KL reductions" % (self.depth_ar + 1)
+
+    def set_packs(self, f32=True):
+        """which weight packs the prep launches keep up to date: f32=False drops the fp32 fragment pack (a stack whose
+        every launch runs on the bf16 matrix cores; a launch that would need it raises).  See include/iaf_hip.h."""
+        _capi.check(_capi.lib().iaf_stack_set_packs(self._h, _capi.IAF_PACK_BF16X3 | (_capi.IAF_PACK_F32 if f32 else 0)))
+
     def step_is_fused(self, B, H, W):
         """rows per workgroup of the one-launch step at this size, 0 if the step runs layer by layer"""
         return int(_capi.lib().iaf_stack_step_is_fused(self._h, int(B), int(H), int(W)))

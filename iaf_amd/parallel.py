@@ -86,13 +86,32 @@ class OverlappedGradReduce(object):
 
     @staticmethod
     def bounds_from_groups(flat, groups):
-        """groups: list of lists of parameter names, in completion order and in the flat buffer's order"""
-        out, lo = [], 0
+        """groups: list of lists of parameter names, in completion order and in the flat buffer's order.  Raises
+        ValueError if a group is not one contiguous run of the flat buffer starting where the previous group ended, or if
+        a parameter is missing / listed twice: a bucket [lo, hi) would then hold gradients of layers whose backward has
+        not run when reduce(i) sends it (silently stale at world size > 1)."""
+        out, lo, seen = [], 0, set()
         for i, names in enumerate(groups):
-            hi = max(flat.offset_of(k)[1] for k in names)
+            spans = sorted(flat.offset_of(k) for k in names)
+            if not spans:
+                raise ValueError("bucket %d is empty" % i)
+            dup = [k for k in names if k in seen]
+            if dup or len(set(names)) != len(names):
+                raise ValueError("bucket %d lists parameters twice: %s" % (i, dup or names))
+            seen.update(names)
+            first = spans[0][0]
+            if first - lo < 0 or first - lo >= 4:          # (a segment may start on the next 16-byte boundary)
+                raise ValueError("bucket %d starts at flat offset %d, the previous bucket ended at %d: the groups are not "
+                                 "in the flat buffer's order" % (i, first, lo))
+            for (a0, a1), (b0, b1) in zip(spans[:-1], spans[1:]):
+                if b0 < a1 or b0 - a1 >= 4:
+                    raise ValueError("bucket %d is not one contiguous run of the flat buffer (gap or overlap at %d..%d)" % (i, a1, b0))
+            hi = spans[-1][1]
             hi = flat.grads.numel() if i == len(groups) - 1 else ((hi + 3) // 4) * 4
             out.append((lo, hi))
             lo = hi
+        if set(flat.p) != seen:
+            raise ValueError("parameters not covered by any bucket: %s" % sorted(set(flat.p) - seen))
         return out
 
     def reduce(self, i):

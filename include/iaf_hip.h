@@ -258,6 +258,17 @@ int iaf_stack_set_fuse_first(iaf_stack_t* s, int mode);
  * iaf_stack_autotune times both paths for its problem size and records the winner (chosen[] = -2 for every layer, us[last] =
  * the step).  iaf_stack_step_is_fused: rows per workgroup the step would run with at this size, 0 if it would not run fused. */
 int iaf_stack_set_fuse_step(iaf_stack_t* s, int mode);
+/* Which packed copies of the weights the prep launches (iaf_stack_prepare, iaf_prep_batch_run) keep up to date: the default
+ * is both -- the fp32 fragment pack of the exact-fp32 kernels AND the bf16x3 pack (10 B written per live weight).  A stack
+ * whose every launch runs on the bf16 matrix cores (the one-launch step, or bf16x3 layer-by-layer kernels: inference at the
+ * BASELINE sizes) can drop the fp32 pack: packs = IAF_PACK_BF16X3 (6 B per weight, -40 % of the prep launch's stores).  A
+ * launch that would need the missing pack then fails with IAF_ERR_NOT_PREPARED instead of reading stale weights; training
+ * stacks and stacks with a layer outside the bf16x3 kernels (c_in not a multiple of 32) refuse with IAF_ERR_UNSUPPORTED.
+ * The reference re-derives w = exp(g) * mask*V / ||mask*V|| every step (layers.py:56-60); which layout it is left in is
+ * this engine's business. */
+#define IAF_PACK_F32 1
+#define IAF_PACK_BF16X3 2
+int iaf_stack_set_packs(iaf_stack_t* s, int packs);
 int iaf_stack_step_is_fused(const iaf_stack_t* s, int B, int H, int W);
 int iaf_stack_autotune(iaf_stack_t* s, const float* z, const float* context, float* z_new, float* logsd, int B, int H, int W,
                        void* workspace, size_t workspace_bytes, int reps, void* stream, int* chosen, float* us);

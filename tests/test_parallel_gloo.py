@@ -167,3 +167,22 @@ def test_overlapped_bucketed_grad_reduce_two_ranks_gloo():
     for (lo, hi), s in zip(out[0]["offs"], shapes):
         tot = sum(gr.standard_normal(s).astype(np.float32) for gr in grngs)
         np.testing.assert_allclose(out[0]["grads"][lo:hi].reshape(s), tot, rtol=1e-6, atol=1e-6)
+
+
+def test_bucket_bounds_reject_misordered_or_incomplete_groups():
+    """bounds_from_groups trusted its docstring contract; a misordered / non-contiguous group would put
+    gradients of layers whose backward has not run yet into a bucket that reduce(i) already sends."""
+    import pytest
+    import iaf_amd.parallel as par
+    named = {"a": torch.zeros(5), "b": torch.zeros(8), "c": torch.zeros(3), "d": torch.zeros(16)}
+    fp = par.FlatParams(named, device="cpu")
+    ok = par.OverlappedGradReduce.bounds_from_groups(fp, [["a", "b"], ["c"], ["d"]])
+    assert ok[0][0] == 0 and ok[-1][1] == fp.grads.numel() and all(x[1] == y[0] for x, y in zip(ok[:-1], ok[1:]))
+    assert ok[0][1] == fp.offset_of("c")[0] and ok[1][1] == fp.offset_of("d")[0]
+    for bad in ([["b", "a"], ["d"], ["c"]],        # completion order differs from the flat order
+                [["a", "c"], ["b"], ["d"]],        # a group that is not one contiguous run
+                [["a", "b"], ["d"]],               # a parameter no bucket covers
+                [["a", "b"], ["b", "c"], ["d"]],   # listed twice
+                [["a", "b"], [], ["c", "d"]]):     # empty bucket
+        with pytest.raises(ValueError):
+            par.OverlappedGradReduce.bounds_from_groups(fp, bad)
