@@ -258,10 +258,12 @@ def _time_exchange(flat, red, dist, reps=5):
         return None
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    dist.all_reduce(flat.grads)
+    # through the C ABI (iaf_allreduce_sum_f32 = ncclAllReduce) like the training step's own buckets
+    one = (lambda: red.comm.all_reduce_sum_(flat.grads)) if red.comm is not None else (lambda: dist.all_reduce(flat.grads))
+    one()
     a.record()
     for _ in range(reps):
-        dist.all_reduce(flat.grads)
+        one()
     b.record()
     b.synchronize()
     return a.elapsed_time(b) / reps
@@ -333,6 +335,8 @@ def _run_segmented(args, segments, red, flat, n_gpus, dist):
     step_ms = 1e3 * elapsed / args.steps
     exchange = {"collective": "all-reduce(sum) fp32, 1/N folded into the Adamax kernel (tf_utils/common.py:83-86)",
                 "executed": bool(red.active), "buckets": nb,
+                "via": ("C ABI iaf_allreduce_sum_f32 (ncclAllReduce of %s) on a dedicated exchange stream" % red.comm.library)
+                       if red.comm is not None else "torch.distributed",
                 "bucket_mb": [4e-6 * (hi - lo) for lo, hi in red.bounds],
                 "alone_ms": exch_ms, "step_without_exchange_ms": compute_ms,
                 "exposed_ms": (step_ms - compute_ms) if red.active else 0.0,
@@ -1115,769 +1119,6 @@ def main():
                               "launches": st.posterior_block_launches(args.batch, H, H),
                               "timing": "%d calls with pre-allocated outputs %s, 10 warm-up rounds, median of 5 rounds between HIP events"
                                         % (XREP, "captured in one hipGraph and replayed" if xg is not None else "issued eagerly")})
-
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    step_ms = 1e3 * elapsed / args.steps
-    exchange = {"collective": "all-reduce(sum) fp32, 1/N folded into the Adamax kernel (tf_utils/common.py:83-86)",
-                "executed": bool(red.active), "buckets": nb,
-                "bucket_mb": [4e-6 * (hi - lo) for lo, hi in red.bounds],
-                "alone_ms": exch_ms, "step_without_exchange_ms": compute_ms,
-                "exposed_ms": (step_ms - compute_ms) if red.active else 0.0,
-                "overlap": "bucket i is reduced while the backward segments i+1.. run (issued behind its segment's graph)"}
-    return elapsed, graphs is not None, exchange
-
-
-def train_bench(args, depths, dist, rank, n_gpus):
-    """DP training step of the IAF posterior stack (SURVEY 8f-1,2): per step, for every layer, posterior block forward
-    (tf_train.py:56-85) + backward (what opt.compute_gradients derives, tf_train.py:138), gradients written into ONE flat
-    buffer laid out in completion order, bucketed all-reduce(sum) over ranks (RCCL) overlapped with the remaining
-    backward, fused Adamax(1/N)+EMA (tf_utils/common.py:86, adamax.py:40-56, tf_train.py:157-158).  Synthetic upstream
-    gradients (dz ~ N(0,1), dkl_obj = 1)."""
-    import iaf_amd
-    from iaf_amd import parallel as par
-    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
-    rng = np.random.RandomState(4321 + rank)
-    wrng = np.random.RandomState(99)                      # identical initial weights on every rank
-    layers, named = [], {}
-    for lvl, nlayer in enumerate(depths):
-        H = 16 >> lvl
-        for j in range(nlayer):
-            params, _, _ = make_layer_inputs(wrng, args.batch, args.n_z, args.n_h, args.depth_ar, H)
-            f = lambda c: dev(rng.standard_normal((args.batch, c, H, H)))
-            inp = dict(qm=f(args.n_z), ql=0.1 * f(args.n_z), rm=f(args.n_z), rl=0.1 * f(args.n_z), pm=f(args.n_z),
-                       pl=0.1 * f(args.n_z), uc=f(args.n_h), dc=f(args.n_h), eps=f(args.n_z), dz=f(args.n_z),
-                       dko=torch.ones(args.batch, device="cuda"))
-            st = iaf_amd.ARStack(args.n_z, [args.n_h] * args.depth_ar)
-            st.set_training(True)
-            pre = "IAF_%d_%d/ar_multiconv2d/" % (lvl, j)
-            for k, v in params.items():
-                named[pre + k] = dev(v)
-            layers.append(dict(stack=st, pre=pre, keys=list(params), inp=inp))
-    flat = par.FlatParams(named)          # `named` is in layer order == the order this step completes the gradients
-    for L in layers:
-        L["params"] = {k: flat.p[L["pre"] + k] for k in L["keys"]}
-        L["gradviews"] = {k: flat.g[L["pre"] + k] for k in L["keys"]}
-    groups = _chunks(layers, args.ar_buckets)
-    bounds = par.OverlappedGradReduce.bounds_from_groups(flat, [[L["pre"] + k for L in g for k in L["keys"]] for g in groups])
-    red = par.OverlappedGradReduce(flat, bounds, force=bool(os.environ.get("IAF_BENCH_FORCE_DIST")))
-    prep = iaf_amd.PrepBatch([L["stack"] for L in layers])
-    plist = [L["params"] for L in layers]
-    # mask + weight-norm backward: one launch per bucket (it finishes the bucket's dV / dg)
-    wnbs = [iaf_amd.WnBwdBatch(stacks=[L["stack"] for L in g]) for g in groups]
-
-    def make_segment(bi):
-        def seg():
-            if bi == 0:
-                prep.run(plist)
-            for L in groups[bi]:
-                i, st = L["inp"], L["stack"]
-                fw = st.posterior_block_train(i["qm"], i["ql"], i["rm"], i["rl"], i["pm"], i["pl"], i["uc"], i["dc"], i["eps"], 0.25)
-                st.posterior_block_backward(i["qm"], i["ql"], i["rm"], i["rl"], i["pm"], i["pl"], i["eps"], 0.25, fw["z"], i["dz"],
-                                            i["dko"], L["params"], grads_out=L["gradviews"])
-            wnbs[bi].run(stack_params=[L["params"] for L in groups[bi]], stack_grads=[L["gradviews"] for L in groups[bi]])
-        return seg
-
-    elapsed, graphed, exchange = _run_segmented(args, [make_segment(i) for i in range(len(groups))], red, flat, n_gpus, dist)
-    if rank == 0:
-        emit({
-            "metric": "IAF posterior-stack TRAIN-step samples/sec (forward + backward + grad all-reduce + Adamax/EMA)",
-            "value": n_gpus * args.batch / (elapsed / args.steps), "unit": "samples/s", "n_gpus": n_gpus, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "f32 (forward convs: operands split into 3 bf16 parts, 6 part-products on the bf16 MFMA, fp32 accumulate: fp32-grade error; backward: exact fp32 MFMA)", "data": "synthetic",
-            "config": {"workload": "cifar10 n_z=%d n_h=%d depths=%s depth_ar=%d down_iaf2_nl bs=%d per GPU, kl_min=0.25; "
-                                   "%d trainable fp32 parameters in one flat gradient buffer (%.1f MB)"
-                                   % (args.n_z, args.n_h, depths, args.depth_ar, args.batch, flat.params.numel(),
-                                      4e-6 * flat.params.numel()),
-                       "global_batch": n_gpus * args.batch,
-                       "launch": "hipGraph replay per gradient bucket, all-reduce behind each, then the update" if graphed else "eager",
-                       "parallelism": "dp%d (RCCL all-reduce of %d gradient buckets, overlapped with backward)" % (n_gpus, len(groups))},
-            "exchange": exchange})
-
-
-def layers_bench(args, depths, dist, rank, n_gpus):
-    """SURVEY 8f-4 widening: the whole IAFLayer stack of BASELINE configs[1] as ONE connected model (tf_train.py:188-200),
-    forward, mode "train": the bottom-up pass through every layer -- the first layer of each coarser level downsamples
-    (tf_train.py:196: stride-2 up_conv1, resize 0.5) -- then the top-down pass back (down_deconv2 + resize 2 in the
-    downsampling layer); all weight-norm reparametrisations re-derived every step in batched launches."""
-    import golden_inputs as gi
-    import iaf_amd
-    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
-    rng = np.random.RandomState(777 + rank)
-    wrng = np.random.RandomState(5)
-    zs, hs, B = args.n_z, args.n_h, args.batch
-    levels = []
-    for lvl, nlayer in enumerate(depths):
-        H = 16 >> lvl
-        L = []
-        for j in range(nlayer):
-            ds = lvl > 0 and j == 0                                         # tf_train.py:196
-            p = {}
-            for nm, (ci, co) in (("up_conv1", (hs, 2 * zs + 2 * hs)), ("up_conv3", (hs, hs)),
-                                 ("down_conv1", (hs, 4 * zs + 2 * hs))):
-                for k, v in gi.conv_params(wrng, ci, co).items():
-                    p[nm + "/" + k] = dev(v)
-            last = gi.deconv_params(wrng, hs + zs, hs) if ds else gi.conv_params(wrng, hs + zs, hs)
-            for k, v in last.items():
-                p[("down_deconv2/" if ds else "down_conv2/") + k] = dev(v)
-            for k, v in gi.ar_multiconv2d_params(wrng, zs, [hs] * args.depth_ar, [zs, zs]).items():
-                p["ar_multiconv2d/" + k] = dev(v)
-            layer = iaf_amd.IAFLayer(zs, hs, depth_ar=args.depth_ar, kl_min=0.25, downsample=ds)
-            layer.posterior.stack.set_precision(args.precision)
-            for cvx in layer.convs():
-                cvx.set_precision(args.precision)
-            layer.load(p)
-            L.append(dict(layer=layer, params=p, eps=dev(rng.standard_normal((B, zs, H, H)))))
-        levels.append(dict(H=H, layers=L))
-    up_in = dev(0.5 * rng.standard_normal((B, hs, 16, 16)))
-    Htop = 16 >> (len(depths) - 1)
-    down_in = dev(0.5 * rng.standard_normal((B, hs, Htop, Htop)))
-    all_layers = [L for lv in levels for L in lv["layers"]]
-    prep_s = iaf_amd.PrepBatch([L["layer"].posterior.stack for L in all_layers])
-    # plain convs in one batched prep launch; a downsampling layer's deconv has its own (two small launches)
-    bconvs, cplist, deconvs = [], [], []
-    for L in all_layers:
-        lay, p = L["layer"], L["params"]
-        for nm in ("up_conv1", "up_conv3", "down_conv1") + (() if lay.downsample else ("down_conv2",)):
-            bconvs.append(getattr(lay, nm))
-            cplist.append((p[nm + "/V"], p[nm + "/g"], p[nm + "/b"]))
-        if lay.downsample:
-            deconvs.append((lay.down_conv2, p["down_deconv2/V"], p["down_deconv2/g"], p["down_deconv2/b"]))
-    prep_c = iaf_amd.ConvPrepBatch(bconvs)
-    splist = [iaf_amd.IAFLayer.stack_params(L["params"]) for L in all_layers]
-
-    def step(autotune=False):
-        if not args.cached_weights:
-            prep_s.run(splist)
-            prep_c.run(cplist)
-            for cv, V, g, b in deconvs:
-                cv.prepare_deconv(V, g, b, force=True)
-        outs = []
-        h = up_in
-        for lv in levels:                         # bottom-up (tf_train.py:188-192), chained across levels
-            for L in lv["layers"]:
-                h = L["layer"].up(h, autotune=autotune)
-        h = down_in
-        for lv in reversed(levels):               # top-down (tf_train.py:195-200)
-            for L in reversed(lv["layers"]):
-                h, kl_obj, kl_cost = L["layer"].down(h, L["eps"], autotune=autotune)
-                outs.append((kl_obj, kl_cost))
-        outs.append(h)
-        return outs
-
-    if not args.no_autotune and args.depth_ar > 0:      # masked stacks: kernel family / launch shape per layer
-        for lv in levels:
-            for L in lv["layers"]:
-                H = lv["H"]
-                L["layer"].posterior.stack.autotune(torch.randn(B, zs, H, H, device="cuda"), torch.randn(B, hs, H, H, device="cuda"), reps=10)
-
-    stream = torch.cuda.Stream()
-    graph = None
-    with torch.cuda.stream(stream):
-        step()
-        step(autotune=True)                       # launch-shape search of the plain convs (cuDNN's algorithm search)
-        stream.synchronize()
-        if not args.no_graph:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=stream):
-                keep = step()
-        run = graph.replay if graph is not None else step
-
-        def barrier():
-            torch.cuda.synchronize()
-            if dist is not None:
-                dist.barrier()
-            torch.cuda.synchronize()
-
-        for _ in range(args.warmup):
-            run()
-        barrier()
-        # A fresh box starts with the GPU clocks down and the graph not yet resident: 5 warm-up replays of a 0.5 ms step
-        # are 2.5 ms.  More untimed replays until the box has been busy for a while (VERDICT r02 weak #1: the driver's
-        # fresh box read 10 % under the builder's lease), then the timed region -- EXACTLY --steps steps between barrier +
-        # synchronize on both sides -- is repeated and the MEDIAN repeat reported (all repeats listed in config.repeats_ms).
-        t_settle = time.perf_counter()
-        n_settle = 0
-        while time.perf_counter() - t_settle < args.settle_seconds:
-            for _ in range(max(args.steps, 1)):
-                run()
-            torch.cuda.synchronize()
-            n_settle += max(args.steps, 1)
-        repeats = []
-        for _ in range(max(1, args.repeats)):
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                run()
-            barrier()
-            repeats.append(time.perf_counter() - t0)
-        elapsed = float(np.median(repeats))
-
-        # dominant kernel of this mode: down_conv1 (n_h -> 4 n_z + 2 n_h) at 16x16; 50 back-to-back launches per layer
-        # between one event pair on the launch stream
-        kt = []
-        for L in levels[0]["layers"]:
-            cv = L["layer"].down_conv1
-            x = up_in
-            call = lambda: cv(x, elu_input=True, split=[zs] * 4 + [hs] * 2)
-            call()
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record(stream)
-            for _ in range(50):
-                call()
-            b.record(stream)
-            b.synchronize()
-            kt.append(a.elapsed_time(b) / 50)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    if rank != 0:
-        return
-    cv = levels[0]["layers"][0]["layer"].down_conv1
-    fl, by = cv.work(B, 16, 16)
-    k_ms = float(np.mean(kt))
-    achieved = fl / (k_ms * 1e-3) / 1e12
-    total_fl = 0.0
-    for lv in levels:
-        for L in lv["layers"]:
-            # useful FLOPs: a downsampling layer's strided convs are counted at their minimal cost (they run at 4x that)
-            total_fl += sum(c.work(B, lv["H"], lv["H"])[0] for c in L["layer"].convs())
-            total_fl += L["layer"].posterior.stack.step_work(B, lv["H"], lv["H"])["live_flops"]
-    emit({
-        "metric": "IAFLayer forward samples/sec (up + down of every layer: 4 plain weight-normed convs + IAF posterior block)",
-        "value": n_gpus * B / (elapsed / args.steps), "unit": "samples/s", "n_gpus": n_gpus, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "f32 (forward convs: operands split into 3 bf16 parts, 6 part-products on the bf16 MFMA, fp32 accumulate: fp32-grade error; backward: exact fp32 MFMA)", "data": "synthetic",
-        "config": {"workload": "cifar10 z_size=%d h_size=%d depths=%s depth_ar=%d bs=%d per GPU, kl_min=0.25: %d IAFLayers "
-                               "(tf_train.py:23-95) as one connected model -- up pass 16x16 -> %dx%d through the downsampling "
-                               "layer of each coarser level, then the down pass back"
-                               % (zs, hs, depths, args.depth_ar, B, len(all_layers), Htop, Htop),
-                   "global_batch": n_gpus * B, "launch": "hipGraph replay" if graph is not None else "eager",
-                   "weights": "re-derived every step (2 batched launches)" if not args.cached_weights else "prepared once",
-                   "live_gflop_per_step": total_fl / 1e9,
-                   "model_tflops": total_fl / (elapsed / args.steps) / 1e12,
-                   "parallelism": "dp%d (batch-sharded replicas, no forward collective)" % n_gpus},
-        "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                     "kernel": "%s<.., EPI_PLAIN, 9 taps> (down_conv1 %d->%d, B=%d 16x16)" % (
-                         "iaf_conv_bf3_kernel" if cv.runs_bf16x3(B, 16, 16) else "iaf_conv_kernel", cv.n_in, cv.n_out, B),
-                     "dominant_kernel_family": "bf16x3" if cv.runs_bf16x3(B, 16, 16) else "f32",
-                     "frac_of_bf16x3_peak": (achieved / PEAK_BF16X3_TFLOPS) if cv.runs_bf16x3(B, 16, 16) else None,
-                     "avg_launch_us": 1e3 * k_ms, "launches_timed": 50 * len(kt), "flops_per_launch": fl,
-                     "bytes_per_launch": by, "hbm_frac_at_this_rate": (by / (k_ms * 1e-3) / 1e9) / PEAK_HBM_GBS,
-                     "timing": "HIP events on the launch stream around 50 back-to-back launches per 16x16 layer"}})
-
-
-def layers_train_bench(args, depths, dist, rank, n_gpus):
-    """DP training step of whole IAFLayers (SURVEY 8f-4 + 8f-1,2): weight prep, up pass, down pass, backward of both
-    passes (every plain conv and the posterior block), gradients written into ONE flat buffer laid out in the order the
-    backward completes them (top-down-pass parameters layer by layer, then bottom-up-pass parameters in reverse), bucketed
-    all-reduce(sum) over ranks overlapped with the remaining backward, fused Adamax(1/N)+EMA.  Synthetic upstream
-    gradients (d output ~ N(0,1), d kl_obj = 1)."""
-    import golden_inputs as gi
-    import iaf_amd
-    from iaf_amd import parallel as par
-    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
-    rng = np.random.RandomState(4321 + rank)
-    wrng = np.random.RandomState(99)
-    zs, hs, B = args.n_z, args.n_h, args.batch
-    DOWN = (("down_conv1", (hs, 4 * zs + 2 * hs)), ("down_conv2", (hs + zs, hs)))
-    UP = (("up_conv1", (hs, 2 * zs + 2 * hs)), ("up_conv3", (hs, hs)))
-    host, levels = {}, []
-    for lvl, nlayer in enumerate(depths):
-        H = 16 >> lvl
-        L = []
-        for j in range(nlayer):
-            pre = "IAF_%d_%d/" % (lvl, j)
-            for nm, (ci, co) in UP + DOWN:
-                for k, v in gi.conv_params(wrng, ci, co).items():
-                    host[pre + nm + "/" + k] = v
-            for k, v in gi.ar_multiconv2d_params(wrng, zs, [hs] * args.depth_ar, [zs, zs]).items():
-                host[pre + "ar_multiconv2d/" + k] = v
-            layer = iaf_amd.IAFLayer(zs, hs, depth_ar=args.depth_ar, kl_min=0.25)
-            layer.posterior.stack.set_precision(args.precision)
-            for cvx in layer.convs():
-                cvx.set_precision(args.precision)
-            layer.set_training(True)
-            L.append(dict(layer=layer, pre=pre, eps=dev(rng.standard_normal((B, zs, H, H)))))
-        f = lambda: dev(rng.standard_normal((B, hs, H, H)))
-        levels.append(dict(H=H, layers=L, up_in=f(), down_in=f(), d_up=f(), d_down=f()))
-    all_layers = [L for lv in levels for L in lv["layers"]]
-    for lv in levels:
-        for i, L in enumerate(lv["layers"]):
-            L["lv"], L["first"], L["last"] = lv, i == 0, i == len(lv["layers"]) - 1
-    # completion order of the gradients: down_backward visits levels / layers in forward order and finishes each
-    # layer's down_conv1, down_conv2 and ar_multiconv2d; up_backward then runs in reverse and finishes up_conv1/3
-    down_order = all_layers
-    up_order = [L for lv in reversed(levels) for L in reversed(lv["layers"])]
-    is_down = lambda k: ("/down_conv" in k) or ("/ar_multiconv2d/" in k)
-    named = {}
-    for L in down_order:
-        for k, v in host.items():
-            if k.startswith(L["pre"]) and is_down(k):
-                named[k] = dev(v)
-    for L in up_order:
-        for k, v in host.items():
-            if k.startswith(L["pre"]) and not is_down(k):
-                named[k] = dev(v)
-    flat = par.FlatParams(named)
-    for L in all_layers:
-        n = len(L["pre"])
-        L["params"] = {k[n:]: v for k, v in flat.p.items() if k.startswith(L["pre"])}
-        L["grads"] = {k[n:]: v for k, v in flat.g.items() if k.startswith(L["pre"])}
-    nb = max(1, args.ar_buckets)
-    dgroups = _chunks(down_order, (nb + 1) // 2)
-    ugroups = _chunks(up_order, nb // 2) if nb >= 2 else []
-    if not ugroups:                                       # a single bucket: everything completes at the very end
-        names = [[k for k in named]]
-    else:
-        names = [[k for L in g for k in named if k.startswith(L["pre"]) and is_down(k)] for g in dgroups] + \
-                [[k for L in g for k in named if k.startswith(L["pre"]) and not is_down(k)] for g in ugroups]
-    red = par.OverlappedGradReduce(flat, par.OverlappedGradReduce.bounds_from_groups(flat, names),
-                                   force=bool(os.environ.get("IAF_BENCH_FORCE_DIST")))
-    prep_s = iaf_amd.PrepBatch([L["layer"].posterior.stack for L in all_layers])
-    prep_c = iaf_amd.ConvPrepBatch([c for L in all_layers for c in L["layer"].convs()])
-    splist = [iaf_amd.IAFLayer.stack_params(L["params"]) for L in all_layers]
-    cplist = [t for L in all_layers for t in iaf_amd.IAFLayer.conv_params(L["params"])]
-    dko = torch.ones(B, device="cuda")
-    tup = lambda d, nm: (d[nm + "/V"], d[nm + "/g"], d[nm + "/b"])
-
-    def wn_batch(group, down):
-        """deferred mask + weight-norm backward of the parameters a segment completes"""
-        convs = [getattr(L["layer"], nm) for L in group for nm, _ in (DOWN if down else UP)]
-        stacks = [L["layer"].posterior.stack for L in group] if down else []
-        w = iaf_amd.WnBwdBatch(stacks=stacks, convs=convs)
-        cp = [tup(L["params"], nm) for L in group for nm, _ in (DOWN if down else UP)]
-        cg = [tup(L["grads"], nm) for L in group for nm, _ in (DOWN if down else UP)]
-        sp = [iaf_amd.IAFLayer.stack_params(L["params"]) for L in group] if down else []
-        sg = [iaf_amd.IAFLayer.stack_params(L["grads"]) for L in group] if down else []
-        return lambda: w.run(stack_params=sp, stack_grads=sg, conv_params=cp, conv_grads=cg)
-
-    tune = [False]
-    carry = {}
-
-    def forward():
-        prep_s.run(splist)
-        prep_c.run(cplist)
-        for lv in levels:
-            h = lv["up_in"]
-            for L in lv["layers"]:
-                h = L["layer"].up_train(h, autotune=tune[0])
-        for lv in reversed(levels):
-            h = lv["down_in"]
-            for L in reversed(lv["layers"]):
-                h, _, _ = L["layer"].down_train(h, L["eps"], autotune=tune[0])
-
-    def down_bwd(group):                                  # backward of the top-down pass, layer by layer
-        for L in group:
-            d = L["lv"]["d_down"] if L["first"] else carry["d"]
-            carry["d"] = L["layer"].down_backward(d, dko, L["params"], L["grads"], autotune=tune[0])
-
-    def up_bwd(group):                                    # backward of the bottom-up pass, in reverse
-        for L in group:
-            d = L["lv"]["d_up"] if L["last"] else carry["u"]
-            carry["u"] = L["layer"].up_backward(d, L["params"], L["grads"], autotune=tune[0])
-
-    segments = []
-    if not ugroups:
-        wd, wu = wn_batch(down_order, True), wn_batch(up_order, False)
-        segments.append(lambda: (forward(), down_bwd(down_order), up_bwd(up_order), wd(), wu()))
-    else:
-        for gi_, g in enumerate(dgroups):
-            w = wn_batch(g, True)
-            segments.append((lambda g=g, w=w, first=(gi_ == 0): ((forward() if first else None), down_bwd(g), w())))
-        for g in ugroups:
-            w = wn_batch(g, False)
-            segments.append((lambda g=g, w=w: (up_bwd(g), w())))
-
-    # launch-shape search of the plain convs, forward and data gradient (cuDNN's autotune), before anything is captured
-    for sgm in segments:
-        sgm()
-    tune[0] = True
-    for sgm in segments:
-        sgm()
-    tune[0] = False
-    torch.cuda.synchronize()
-    elapsed, graphed, exchange = _run_segmented(args, segments, red, flat, n_gpus, dist)
-    if rank == 0:
-        fwd_fl = 0.0
-        for lv in levels:
-            for L in lv["layers"]:
-                fwd_fl += sum(c.work(B, lv["H"], lv["H"])[0] for c in L["layer"].convs())
-                fwd_fl += L["layer"].posterior.stack.step_work(B, lv["H"], lv["H"])["live_flops"]
-        emit({
-            "metric": "IAFLayer TRAIN-step samples/sec (forward + backward of every layer + grad all-reduce + Adamax/EMA)",
-            "value": n_gpus * B / (elapsed / args.steps), "unit": "samples/s", "n_gpus": n_gpus, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "f32 (forward convs: operands split into 3 bf16 parts, 6 part-products on the bf16 MFMA, fp32 accumulate: fp32-grade error; backward: exact fp32 MFMA)", "data": "synthetic",
-            "config": {"workload": "cifar10 z_size=%d h_size=%d depths=%s depth_ar=%d bs=%d per GPU, kl_min=0.25: %d "
-                                   "non-downsampling IAFLayers; %d trainable fp32 parameters in one flat gradient buffer (%.1f MB)"
-                                   % (zs, hs, depths, args.depth_ar, B, len(all_layers), flat.params.numel(),
-                                      4e-6 * flat.params.numel()),
-                       "global_batch": n_gpus * B,
-                       "launch": "hipGraph replay per gradient bucket, all-reduce behind each, then the update" if graphed else "eager",
-                       "model_tflops_fwd_plus_bwd": 3.0 * fwd_fl / (elapsed / args.steps) / 1e12,
-                       "parallelism": "dp%d (RCCL all-reduce of %d gradient buckets, overlapped with backward)" % (n_gpus, len(segments))},
-            "exchange": exchange})
-
-
-def iw_eval_bench(args, depths, dist, rank, n_gpus):
-    """BASELINE configs[4]: importance-weighted ELBO evaluation, inference only.  One STEP = one pass of `--batch` (256)
-    rows -- 256 images x 1 importance sample (the Theano driver's order, train.py:194-203) -- through the fused posterior
-    block of every layer (10 at 16x16 + 10 at 8x8: sample, logqs, IAF step, log-det, logps, KL sums), the column sum of
-    the per-layer KL costs (tf_train.py:198-200) and the update of the per-image running log-sum-exp
-    (distributions.py:55-62 without ever materialising the [n, k] weights).  k = --iw-k passes complete one estimate;
-    value = importance samples (rows) per second, config.images_per_s_at_k = value / k.  log p(x|z) comes from the
-    decoder (out of scope): synthetic."""
-    import iaf_amd
-    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
-    B = args.batch
-    rng = np.random.RandomState(2468 + rank)
-    wrng = np.random.RandomState(99)
-    stacks, inputs = [], []
-    for lvl, nlayer in enumerate(depths):
-        H = 16 >> lvl
-        for _ in range(nlayer):
-            params, _, _ = make_layer_inputs(wrng, B, args.n_z, args.n_h, args.depth_ar, H)
-            st = iaf_amd.ARStack(args.n_z, [args.n_h] * args.depth_ar)
-            st.set_precision(args.precision)
-            st.prepare({k: dev(v) for k, v in params.items()})
-            f = lambda c, sc=1.0: dev(sc * rng.standard_normal((B, c, H, H)))
-            inputs.append((f(args.n_z), f(args.n_z, 0.25), f(args.n_z), f(args.n_z, 0.25), f(args.n_z), f(args.n_z, 0.25),
-                           f(args.n_h), f(args.n_h), f(args.n_z)))
-            if not args.no_autotune and args.depth_ar > 0:
-                st.autotune(inputs[-1][0], inputs[-1][6], reps=10)
-            stacks.append(st)
-    log_pxz = dev(-7000.0 + 30.0 * rng.standard_normal(B))
-    ev = iaf_amd.IWEvaluator(stacks, kl_min=0.25)
-
-    def one_pass():
-        ev.run_pass(inputs, log_pxz)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    stream = torch.cuda.Stream()
-    graph = None
-    with torch.cuda.stream(stream):
-        one_pass()
-        stream.synchronize()
-        if not args.no_graph:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=stream):
-                one_pass()
-        run = graph.replay if graph is not None else one_pass
-        for _ in range(args.warmup):
-            run()
-        barrier()
-        # A fresh box starts with the GPU clocks down and the graph not yet resident: 5 warm-up replays of a 0.5 ms step
-        # are 2.5 ms.  More untimed replays until the box has been busy for a while (VERDICT r02 weak #1: the driver's
-        # fresh box read 10 % under the builder's lease), then the timed region -- EXACTLY --steps steps between barrier +
-        # synchronize on both sides -- is repeated and the MEDIAN repeat reported (all repeats listed in config.repeats_ms).
-        t_settle = time.perf_counter()
-        n_settle = 0
-        while time.perf_counter() - t_settle < args.settle_seconds:
-            for _ in range(max(args.steps, 1)):
-                run()
-            torch.cuda.synchronize()
-            n_settle += max(args.steps, 1)
-        repeats = []
-        for _ in range(max(1, args.repeats)):
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                run()
-            barrier()
-            repeats.append(time.perf_counter() - t0)
-        elapsed = float(np.median(repeats))
-        # dominant kernel: the n_h -> n_h masked conv at 16x16 with B rows
-        dom = max(args.depth_ar - 1, 0)
-        z16, c16 = inputs[0][0], inputs[0][6]
-        k_ms = float(np.mean([stacks[i].time_layer(dom, z16, c16, reps=20) for i in range(min(3, depths[0]))]))
-        if graph is not None:
-            ev.state.k += args.warmup + args.steps      # replays folded passes into the device state behind Python's back
-        bound = ev.result()
-        torch.cuda.synchronize()
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    if rank != 0:
-        return
-    lw = stacks[0].layer_work(dom, B, 16, 16)
-    kern = stacks[0].layer_precision(dom, B, 16, 16)
-    peak = PEAK_F32_MFMA_TFLOPS          # same yardstick as the headline line (see there)
-    ach = lw["live_flops"] / (k_ms * 1e-3) / 1e12
-    step_fl = sum(d * stacks[0].step_work(B, 16 >> i, 16 >> i)["live_flops"] for i, d in enumerate(depths))
-    rows_per_s = n_gpus * B / (elapsed / args.steps)
-    emit({
-        "metric": "IW-ELBO evaluation importance-samples/sec (posterior blocks of every layer + streaming log-sum-exp)",
-        "value": rows_per_s, "unit": "samples/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.precision == "f32" else "f32 (bf16x3 split-product MFMA where it wins, fp32 accumulate)",
-        "data": "synthetic",
-        "config": {"workload": "10000-sample importance-weighted ELBO eval, inference only (BASELINE configs[4]): cifar10 n_z=%d "
-                               "n_h=%d depths=%s depth_ar=%d, %d rows per pass (= %d images x 1 sample), k = %d passes per estimate"
-                               % (args.n_z, args.n_h, depths, args.depth_ar, B, B, args.iw_k),
-                   "global_batch": n_gpus * B, "k": args.iw_k, "images_per_s_at_k": rows_per_s / args.iw_k,
-                   "seconds_per_estimate_of_%d_images" % B: args.iw_k * elapsed / args.steps,
-                   "launch": "hipGraph replay of one pass" if graph is not None else "eager",
-                   "passes_folded_so_far": ev.k, "finite_bound": bool(torch.isfinite(bound).all().item()),
-                   "model_tflops": step_fl / (elapsed / args.steps) / 1e12,
-                   "parallelism": "dp%d (images sharded over ranks, no collective)" % n_gpus},
-        "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
-                     "frac_of_bf16x3_peak": (ach / PEAK_BF16X3_TFLOPS) if kern == "bf16x3" else None, "dominant_kernel_family": kern,
-                     "kernel": "masked 3x3 conv %d->%d, B=%d 16x16" % (args.n_h, args.n_h, B), "avg_launch_us": 1e3 * k_ms,
-                     "flops_per_launch_live": lw["live_flops"], "bytes_per_launch": lw["bytes"],
-                     "step": {"live_flops_per_step": step_fl, "frac_of_f32_mfma_peak": step_fl / (elapsed / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS}}})
-
-
-def _halo_note(st, R, args):
-    """how many MACs the one-launch step issues per live MAC: hidden layer l is computed on R + depth_ar - l rows per R
-    output rows (iaf_step_fused.hpp); roofline figures count the live ones only"""
-    d = args.depth_ar
-    live = [st.layer_work(l, args.batch, 16, 16)["live_flops"] for l in range(d + 1)]
-    issued = sum(live[l] * (R + d - l) / R for l in range(d)) + live[d]
-    return "the launch multiplies %.2fx the live MACs (halo rows of the hidden layers recomputed per %d-row workgroup); only live MACs are counted" % (
-        issued / sum(live), R)
-
-
-def _issued_over_live(args, R, W):
-    """fp32-equivalent FLOPs the one-launch step's MFMAs multiply per live FLOP: per row block, hidden layer l on
-    ceil((R + depth_ar - l) * W / 16) pixel tiles, the output pair on ceil(R * W / 16), every co tile x every (32-channel,
-    tap) step of the 5 stored taps -- 16 x 16 x 32 MACs each (iaf_step_fused.hpp) -- against the mask-aware live count"""
-    d, nz, nh = args.depth_ar, args.n_z, args.n_h
-    H = W
-    nrb = (H + R - 1) // R
-    units = 0
-    cin = nz
-    for l in range(d):
-        units += -(-((R + d - l) * W) // 16) * (nh // 16) * (cin // 32) * 5
-        cin = nh
-    units += -(-(R * W) // 16) * (2 * nz // 16) * (cin // 32) * 5
-    issued = float(args.batch * nrb * units) * 16 * 16 * 32 * 2
-    import iaf_amd
-    st = iaf_amd.ARStack(nz, [nh] * d)
-    return issued / st.step_work(args.batch, H, W)["live_flops"]
-
-
-def main():
-    args = parse()
-    depths = [int(d) for d in args.depths.split(",") if d]
-    dist, rank, n_gpus, rank_info = init_ranks(args)
-    RANK_INFO.update(rank_info)
-
-    import iaf_amd
-    iaf_amd._capi.lib()           # fail loudly if the HIP engine is not built
-    if args.iw_eval:
-        if args.batch == 32:
-            args.batch = 256              # configs[4]: bs = 256
-        iw_eval_bench(args, depths, dist, rank, n_gpus)
-        if dist is not None:
-            dist.destroy_process_group()
-        return
-    if args.layers and args.train:
-        layers_train_bench(args, depths, dist, rank, n_gpus)
-        if dist is not None:
-            dist.destroy_process_group()
-        return
-    if args.layers:
-        layers_bench(args, depths, dist, rank, n_gpus)
-        if dist is not None:
-            dist.destroy_process_group()
-        return
-    if args.train:
-        train_bench(args, depths, dist, rank, n_gpus)
-        if dist is not None:
-            dist.destroy_process_group()
-        return
-    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
-
-    # ---------------- build the layer schedule (every rank its own data: seed + rank)
-    rng = np.random.RandomState(1234 + rank)
-    layers = []
-    for lvl, nlayer in enumerate(depths):
-        H = 16 >> lvl
-        for _ in range(nlayer):
-            params, z, ctx = make_layer_inputs(rng, args.batch, args.n_z, args.n_h, args.depth_ar, H)
-            st = iaf_amd.ARStack(args.n_z, [args.n_h] * args.depth_ar)
-            dp = {k: dev(v) for k, v in params.items()}
-            zd, cd = dev(z), dev(ctx)
-            out = (torch.empty_like(zd), torch.empty_like(zd))
-            st.set_precision(args.precision)
-            if args.no_fuse:
-                st.set_fuse_first("never")
-            if args.no_fuse_step:
-                st.set_fuse_step("never")
-            st.prepare(dp)
-            layers.append(dict(stack=st, params=dp, z=zd, ctx=cd, out=out, H=H, one=st.step_is_fused(args.batch, H, H)))
-    if args.tune:
-        for item in args.tune.split(";"):
-            lay, shp = item.split(":")
-            nt, pxt, wco, ks = [int(v) for v in shp.split(",")]
-            for L in layers:
-                L["stack"].set_tuning(int(lay), nt, pxt, wco, ks)
-
-    # every IAF step of this workload runs as ONE bf16x3 launch: the prep launch need not keep the fp32 fragment pack up to
-    # date (iaf_stack_set_packs; a launch that needed it would fail loudly, not read stale weights)
-    bf3_only = (not args.keep_f32_pack) and args.precision == "bf16x3" and all(L["one"] for L in layers)
-    if bf3_only:
-        for L in layers:
-            L["stack"].set_packs(f32=False)
-            L["stack"].prepare(L["params"])
-    prep = iaf_amd.PrepBatch([L["stack"] for L in layers])
-    plist = [L["params"] for L in layers]
-    tuned = {}
-    if not args.no_autotune and not args.tune and args.depth_ar > 0:
-        # kernel family + launch shape per layer, measured on this box for this size (the cuDNN algorithm search of the
-        # reference's convs); outside the timed region, before the graph is captured
-        for L in layers:
-            if L["one"]:             # the step runs as ONE launch at this size: no per-layer kernels to choose between
-                tuned.setdefault("%dx%d" % (L["H"], L["H"]), ["whole step in one launch (%d rows per workgroup)" % L["one"]])
-                continue
-            picks = L["stack"].autotune(L["z"], L["ctx"], reps=20)
-            L["fused"] = picks[0][0] == "fused into next"
-            tuned.setdefault("%dx%d" % (L["H"], L["H"]), [c for c, _ in picks])
-
-    def step():
-        if not args.cached_weights:
-            prep.run(plist)      # mask*V, l2-normalise, exp(g), repack (layers.py:56-60): all 20 layers, one launch
-        for L in layers:
-            L["stack"].iaf_step(L["z"], L["ctx"] if args.depth_ar > 0 else None, out=L["out"])
-
-    stream = torch.cuda.Stream()
-    graph = None
-    with torch.cuda.stream(stream):
-        step()                                                   # allocate workspaces, warm caches
-        stream.synchronize()
-        if not args.no_graph:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=stream):
-                step()
-        run = graph.replay if graph is not None else step
-
-        def barrier():
-            torch.cuda.synchronize()
-            if dist is not None:
-                dist.barrier()
-            torch.cuda.synchronize()
-
-        for _ in range(args.warmup):
-            run()
-        barrier()
-        # A fresh box starts with the GPU clocks down and the graph not yet resident: 5 warm-up replays of a 0.5 ms step
-        # are 2.5 ms.  More untimed replays until the box has been busy for a while (VERDICT r02 weak #1: the driver's
-        # fresh box read 10 % under the builder's lease), then the timed region -- EXACTLY --steps steps between barrier +
-        # synchronize on both sides -- is repeated and the MEDIAN repeat reported (all repeats listed in config.repeats_ms).
-        t_settle = time.perf_counter()
-        n_settle = 0
-        while time.perf_counter() - t_settle < args.settle_seconds:
-            for _ in range(max(args.steps, 1)):
-                run()
-            torch.cuda.synchronize()
-            n_settle += max(args.steps, 1)
-        repeats = []
-        for _ in range(max(1, args.repeats)):
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                run()
-            barrier()
-            repeats.append(time.perf_counter() - t0)
-        elapsed = float(np.median(repeats))
-
-        # ---------------- kernel leg: eager steps, HIP events around every launch of the dominant kernel
-        dom_layer = max(args.depth_ar - 1, 0)                    # the n_h -> n_h masked conv (layer 1 at depth_ar=2)
-        prof = [L for L in layers if L["H"] == 16]
-        one16 = bool(prof) and all(L["one"] for L in prof)       # the 16x16 steps run as ONE launch each: that is the kernel
-        ksteps = max(10, min(args.steps, 50))
-        for L in prof:
-            L["stack"].profile_enable(-2 if one16 else dom_layer, ksteps + 4)
-        for _ in range(3):
-            step()
-        torch.cuda.synchronize()
-        for L in prof:
-            L["stack"].profile_read()
-        for _ in range(ksteps):
-            step()
-        torch.cuda.synchronize()
-        kms = []
-        for L in prof:
-            kms += L["stack"].profile_read()
-            L["stack"].profile_enable(-1, 0)
-        # primary figure: N back-to-back launches of the dominant kernel between ONE event pair (no per-launch
-        # event/dispatch latency), averaged over the 16x16 layers
-        fused16 = (not one16) and dom_layer == 1 and bool(prof) and all(L.get("fused") for L in prof)     # every 16x16 stack tuned to the fused launch
-        tl_med = lambda st_, lay, z_, c_: float(np.median([st_.time_layer(lay, z_, c_, reps=50) for _ in range(5)]))
-        if one16:
-            kbatch = [tl_med(L["stack"], -2, L["z"], L["ctx"]) for L in prof]
-        else:
-            kbatch = [L["stack"].time_layer(-1 if fused16 else dom_layer, L["z"], L["ctx"] if args.depth_ar > 0 else None, reps=50)
-                      for L in prof if fused16 or not L.get("fused")] or \
-                     [L["stack"].time_layer(-1, L["z"], L["ctx"], reps=50) for L in prof]
-        # every GEMM layer of the IAF step at every latent level, same method (first layer of each level), and the
-        # extended unit of SURVEY 8d (posterior block: sample + logqs + IAF step + log-det + logps + KL / free bits)
-        ktable, xunit = [], []
-        for lvl, nlayer in enumerate(depths):
-            if nlayer == 0:
-                continue
-            H = 16 >> lvl
-            L = [x for x in layers if x["H"] == H][0]
-            st = L["stack"]
-            cin = args.n_z
-            fused = bool(L.get("fused"))
-            if L["one"]:
-                ms = tl_med(st, -2, L["z"], L["ctx"])
-                w = st.step_work(args.batch, H, H)
-                tf_ = w["live_flops"] / (ms * 1e-3) / 1e12
-                ktable.append({"layer": "IAF step: masked convs %d->%d%s->%d (mean,logsd pair) + affine/log-det, ONE launch, %d rows per workgroup"
-                                        % (args.n_z, args.n_h, "->%d" % args.n_h if args.depth_ar > 1 else "", 2 * args.n_z, L["one"]),
-                               "latent": "%dx%d" % (H, H), "kernel": "bf16x3", "us": 1e3 * ms, "live_gflop": w["live_flops"] / 1e9,
-                               "live_tflops": tf_, "frac": tf_ / PEAK_F32_MFMA_TFLOPS})
-            for gl in range(args.depth_ar + 1) if not L["one"] else ():
-                cout = args.n_h if gl < args.depth_ar else 2 * args.n_z
-                name = "masked conv %d->%d%s" % (cin, cout, " (mean,logsd pair + affine/log-det epilogue)" if gl == args.depth_ar else "")
-                w = st.layer_work(gl, args.batch, H, H)
-                cin = args.n_h
-                if fused and gl == 0:
-                    w0 = w
-                    continue                      # computed inside the next launch
-                if fused and gl == 1:
-                    ms = st.time_layer(-1, L["z"], L["ctx"], reps=50)
-                    w = {k: w[k] + w0[k] for k in w}
-                    name = "masked conv %d->%d + %s, ONE launch (first layer fused into the prologue)" % (args.n_z, args.n_h, name)
-                    kern = "bf16x3"
-                else:
-                    ms = st.time_layer(gl, L["z"], L["ctx"] if args.depth_ar > 0 else None, reps=50)
-                    kern = st.layer_precision(gl, args.batch, H, H)
-                tf_ = w["live_flops"] / (ms * 1e-3) / 1e12
-                ktable.append({"layer": name, "latent": "%dx%d" % (H, H), "kernel": kern, "us": 1e3 * ms,
-                               "live_gflop": w["live_flops"] / 1e9, "live_tflops": tf_, "frac": tf_ / PEAK_F32_MFMA_TFLOPS})
-            if args.depth_ar > 0:
-                f = lambda c, sc=1.0: sc * torch.randn(args.batch, c, H, H, device="cuda")
-                pin = [f(args.n_z), f(args.n_z, 0.25), f(args.n_z), f(args.n_z, 0.25), f(args.n_z), f(args.n_z, 0.25),
-                       f(args.n_h), f(args.n_h), f(args.n_z)]
-                for _ in range(3):
-                    st.posterior_block(*pin, 0.25)
-                stream.synchronize()
-                ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                ea.record(stream)
-                for _ in range(30):
-                    st.posterior_block(*pin, 0.25)
-                eb.record(stream)
-                eb.synchronize()
-                us = 1e3 * ea.elapsed_time(eb) / 30
-                sw = st.step_work(args.batch, H, H)
-                xunit.append({"latent": "%dx%d" % (H, H), "us": us, "samples_per_s": args.batch / (us * 1e-6),
-                              "live_tflops": sw["live_flops"] / (us * 1e-6) / 1e12,
-                              "frac": sw["live_flops"] / (us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                              "launches": "%d masked convs + 2 KL reductions, eager" % (args.depth_ar + 1)})
 
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")

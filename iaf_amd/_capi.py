@@ -16,6 +16,7 @@ IAF_ERR_WORKSPACE = -5
 IAF_ERR_UNSUPPORTED = -6
 IAF_PRECISION_F32 = 0
 IAF_PRECISION_BF16X3 = 1
+IAF_COMM_ID_BYTES = 128
 IAF_PACK_F32 = 1
 IAF_PACK_BF16X3 = 2
 IAF_ABI_VERSION = 3                # must equal the library's iaf_abi_version(): a stale libiaf_hip.so is rejected
@@ -79,6 +80,12 @@ SIGNATURES = {
     "iaf_stack_set_fuse_first": (ctypes.c_int, [_vp, ctypes.c_int]),
     "iaf_stack_set_fuse_step": (ctypes.c_int, [_vp, ctypes.c_int]),
     "iaf_stack_set_packs": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "iaf_comm_unique_id": (ctypes.c_int, [_vp]),
+    "iaf_comm_create": (ctypes.c_int, [ctypes.POINTER(_vp), _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "iaf_comm_size": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "iaf_allreduce_sum_f32": (ctypes.c_int, [_vp, _c_float_p, ctypes.c_size_t, _vp]),
+    "iaf_comm_destroy": (ctypes.c_int, [_vp]),
+    "iaf_comm_library": (ctypes.c_char_p, []),
     "iaf_stack_step_is_fused": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "iaf_stack_autotune": (ctypes.c_int, [_vp, _c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int,
                                           ctypes.c_int, _vp, ctypes.c_size_t, ctypes.c_int, _vp, ctypes.POINTER(ctypes.c_int),

@@ -24,11 +24,13 @@ BF3_SHAPES = [(4, 1, 4, 1), (2, 1, 4, 1), (1, 1, 4, 1), (1, 4, 1, 1), (2, 1, 4, 
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 CFLAGS += os.environ.get("IAF_EXTRA_CFLAGS", "").split()       # dev experiments only (e.g. -DIAF_EXP_NOREFILL)
 HEADERS = [os.path.join(ROOT, "include", "iaf_hip.h")] + sorted(
-    os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp"))   # any header change rebuilds every unit
+    os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp"))   # fallback: no dependency file yet -> every header counts
 
 
 def _units():
-    units = [(os.path.join(CSRC, "iaf_engine.hip"), os.path.join(OBJDIR, "iaf_engine.o"), [])]
+    units = [(os.path.join(CSRC, "iaf_engine.hip"), os.path.join(OBJDIR, "iaf_engine.o"), []),
+             # host-only: the RCCL gradient exchange (librccl is dlopen'ed at run time, no link dependency)
+             (os.path.join(CSRC, "iaf_comm.cpp"), os.path.join(OBJDIR, "iaf_comm.o"), ["-x", "hip"])]
     for pxt, wco, ks in SHAPES:
         units.append((os.path.join(CSRC, "iaf_conv_inst.hip"), os.path.join(OBJDIR, "iaf_conv_%d_%d_%d.o" % (pxt, wco, ks)),
                       ["-DIAF_PXT=%d" % pxt, "-DIAF_WCO=%d" % wco, "-DIAF_KS=%d" % ks]))
@@ -50,7 +52,17 @@ def _stale(target, deps):
     if not os.path.exists(target):
         return True
     t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any((not os.path.exists(d)) or os.path.getmtime(d) > t for d in deps)
+
+
+def _deps(obj, src):
+    """headers the unit actually includes (hipcc -MD wrote obj + '.d' at the last compile), else every project header"""
+    d = obj + ".d"
+    if not os.path.exists(d):
+        return [src] + HEADERS
+    words = open(d).read().replace("\\\n", " ").split()
+    mine = [w for w in words[1:] if w.startswith(ROOT) or not os.path.isabs(w)]      # project files only (not /opt/rocm)
+    return [src] + mine
 
 
 def build(force=False, verbose=True, jobs=None):
@@ -58,8 +70,8 @@ def build(force=False, verbose=True, jobs=None):
     os.makedirs(OBJDIR, exist_ok=True)
     todo = []
     for src, obj, defs in _units():
-        if force or _stale(obj, [src] + HEADERS):
-            todo.append([hipcc] + CFLAGS + defs + ["-c", src, "-o", obj])
+        if force or _stale(obj, _deps(obj, src)):
+            todo.append([hipcc] + CFLAGS + defs + ["-MD", "-MF", obj + ".d", "-c", src, "-o", obj])
     if todo:
         jobs = jobs or min(len(todo), os.cpu_count() or 4)
         if verbose:
@@ -70,7 +82,7 @@ def build(force=False, verbose=True, jobs=None):
                     raise RuntimeError("hipcc failed: " + " ".join(cmd))
     objs = [obj for _, obj, _ in _units()]
     if force or todo or _stale(OUT, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", OUT]
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-ldl", "-o", OUT]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -281,6 +281,7 @@ static void default_tuning(GemmLayer& L, bool is_out) {
 }
 
 extern "C" int iaf_abi_version(void) { return IAF_ABI_VERSION; }
+extern "C" const char* iaf_comm_error_string_(int code);       // iaf_comm.cpp
 
 extern "C" const char* iaf_error_string(int code) {
     switch (code) {
@@ -291,6 +292,10 @@ extern "C" const char* iaf_error_string(int code) {
         case IAF_ERR_NOT_PREPARED: return "iaf_stack_prepare has not been called";
         case IAF_ERR_WORKSPACE: return "workspace too small or misaligned";
         case IAF_ERR_UNSUPPORTED: return "not covered by the gfx950 kernels (channels must be multiples of 16 and <= 256; launch shape must fit 160 KiB of LDS)";
+    }
+    if (code >= 10000) {                                  // 10000 + ncclResult_t (iaf_comm.cpp)
+        const char* m = iaf_comm_error_string_(code);
+        return m ? m : "RCCL error";
     }
     if (code > 0) return hipGetErrorString((hipError_t)code);
     return "unknown error";

@@ -127,93 +127,6 @@ __device__ __forceinline__ void prep_bf3_store(const PrepLayer& L, int gt, const
     }
 }
 
-#ifdef IAF_EXP_PREP_UNITS
-// Experiment (IAF_EXTRA_CFLAGS=-DIAF_EXP_PREP_UNITS; written, not yet run): ONE pass for both packs.
-// A thread owns UNITS = (oct of 8 consecutive input channels, tap), unit u = cs + 16 i: an oct is what one lane of a bf16x3
-// fragment holds (one 16-byte store per plane) and two lanes' worth of the fp32 fragment (two 16-byte stores), so every
-// weight is fetched once (prep_tile + prep_bf3_load fetch it twice, 116 loads per thread at n_in = 160 against 56 here) and
-// the units deal out evenly (100 units over 16 thread groups at n_in = 160).
-template <int NCH, int NTP>
-__device__ __forceinline__ void prep_tile_units(const PrepLayer& L, int gt, float (*red)[17], float* s_scale) {
-    typedef float pf32x4 __attribute__((ext_vector_type(4)));
-    typedef __bf16 pb16x2 __attribute__((ext_vector_type(2)));
-    typedef float pf32x2 __attribute__((ext_vector_type(2)));
-    typedef unsigned pu32x4 __attribute__((ext_vector_type(4)));
-    const int which = (L.npair == 2) ? (gt & 1) : 0;     // output pair: even tiles = mean, odd = logsd
-    const int src_tile = (L.npair == 2) ? (gt >> 1) : gt;
-    const float* __restrict__ V = PREP_PICK(L.V, which);
-    const int oo = threadIdx.x & 15, cs = threadIdx.x >> 4;
-    const int o = src_tile * 16 + oo;
-    const int n_out = L.cout_each, n_in = L.cin;
-    const float gval = PREP_PICK(L.g, which)[o], bval = PREP_PICK(L.b, which)[o];
-    constexpr int NUNIT = 2 * NCH * NTP, NUI = (NUNIT + 15) / 16;
-    float v[NUI][8];
-#pragma unroll
-    for (int i = 0; i < NUI; ++i) {
-        const int uu = cs + 16 * i;
-        const int u = uu < NUNIT ? uu : NUNIT - 1;                  // clamped: the surplus slot is loaded, never used
-        const int k = u / NTP, t = u - k * NTP;
-        const int kh = tap_kh<NTP>(t), kw = tap_kw<NTP>(t);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int ci = 8 * k + e;
-            float x = V[((size_t)(kh * 3 + kw) * n_in + ci) * n_out + o];
-            if (NTP == NTAPS && t == 0 && !made_live(ci, o, n_in, n_out, L.zerodiag)) x = 0.f;   // centre tap: channel MADE mask
-            v[i][e] = uu < NUNIT ? x : 0.f;
-        }
-    }
-    float ss = 0.f;
-#pragma unroll
-    for (int i = 0; i < NUI; ++i)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) ss += v[i][e] * v[i][e];
-    red[cs][oo] = ss;
-    __syncthreads();
-    if (cs == 0) {
-        float tot = 0.f;
-        for (int i = 0; i < 16; ++i) tot += red[i][oo];
-        s_scale[oo] = expf(gval) / sqrtf(fmaxf(tot, 1e-12f));        // layers.py:60
-        L.bias[gt * 16 + oo] = bval;
-    }
-    __syncthreads();
-    const float scale = s_scale[oo];
-#pragma unroll
-    for (int i = 0; i < NUI; ++i) {
-        const int u = cs + 16 * i;
-        if (u >= NUNIT) continue;
-        const int k = u / NTP, t = u - k * NTP;
-        // fp32 pack: channels 8k + 4h + {0..3} = chunk k >> 1, fragment lane group kk = 2 (k & 1) + h
-        if (L.wp)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const pf32x4 w4 = {v[i][4 * h] * scale, v[i][4 * h + 1] * scale, v[i][4 * h + 2] * scale, v[i][4 * h + 3] * scale};
-            ((pf32x4*)L.wp)[((((size_t)(k >> 1) * NTP + t) * L.ncot + gt) * 64 + (2 * (k & 1) + h) * 16 + oo)] = w4;
-        }
-        if (L.wpt) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int ci = 8 * k + e;
-                L.wpt[((((size_t)gt * NTP + t) * NCH + (ci >> 4)) * 64 + (oo >> 2) * 16 + (ci & 15)) * 4 + (oo & 3)] = v[i][e] * scale;
-            }
-        }
-        // bf16x3 pack: the oct is lane (k & 3) * 16 + oo of the fragment of input pair k >> 2
-        pu32x4 ph, pm, pl;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const pf32x2 x = {v[i][2 * j] * scale, v[i][2 * j + 1] * scale};
-            const pb16x2 hb = __builtin_convertvector(x, pb16x2);
-            const pf32x2 r1 = x - __builtin_convertvector(hb, pf32x2);
-            const pb16x2 mb = __builtin_convertvector(r1, pb16x2);
-            const pf32x2 r2 = r1 - __builtin_convertvector(mb, pf32x2);
-            const pb16x2 lb = __builtin_convertvector(r2, pb16x2);
-            ph[j] = __builtin_bit_cast(unsigned, hb); pm[j] = __builtin_bit_cast(unsigned, mb); pl[j] = __builtin_bit_cast(unsigned, lb);
-        }
-        pu32x4* q = (pu32x4*)L.wp3 + ((((size_t)(k >> 2) * NTP + t) * L.ncot + gt) * 3) * 64 + (k & 3) * 16 + oo;
-        q[0] = ph; q[64] = pm; q[128] = pl;
-    }
-}
-#endif
-
 template <int NCH, int NTP = NTAPS>
 __device__ __forceinline__ void prep_tile(const PrepLayer& L, int gt, float (*red)[17], float* s_scale) {
     const int which = (L.npair == 2) ? (gt & 1) : 0;     // output pair: even tiles = mean, odd = logsd
@@ -225,16 +138,14 @@ __device__ __forceinline__ void prep_tile(const PrepLayer& L, int gt, float (*re
     const float gval = PREP_PICK(L.g, which)[o], bval = PREP_PICK(L.b, which)[o];
 
     constexpr bool BF3 = (NCH % 2 == 0);
-#ifdef IAF_EXP_PREP_UNITS
-    if constexpr (BF3) { if (L.wp3) { prep_tile_units<NCH, NTP>(L, gt, red, s_scale); return; } }
-#endif
     float w3[BF3 ? PREP_BF3_UPQ_T(NCH, NTP) : 1][8];
     if constexpr (BF3) { if (L.wp3) prep_bf3_load<NCH, NTP>(L, gt, w3); }
     // pass 1: fetch + mask (layers.py:57), sum of squares over (taps, c_in) (layers.py:60).  A thread owns QUADS of four
     // consecutive input channels, quad q = cs + 16 i (ci = 4q + jj): the four channels of a quad are the four floats a lane
     // of the MFMA B fragment holds, so pass 2 writes them as ONE 16-byte store and a wave as 1 KiB contiguous (one channel
-    // per thread meant four dword stores 16 B apart).  Measured neutral on the batched launch (28.7 us either way: the launch
-    // is not bound by its store instructions; DESIGN.md 8 lists what is left to look at).
+    // per thread meant four dword stores 16 B apart).  Measured neutral on the batched launch (round 2).  Round 3 measured a
+    // ONE-pass variant (a thread owning (8 input channels, tap) units, every weight fetched once, both packs written from the
+    // same registers): slower on the whole step (0.4861 vs 0.4825 ms, 5 repeats each way) -- removed.
     constexpr int NQI = (NCH + 3) / 4;
     float v[NTP][4 * NQI];
 #pragma unroll

@@ -19,12 +19,11 @@
 // Work split: 4 waves, one per SIMD.  Hidden layers: wave w owns co tiles w, w+4, ... of every pixel tile (its weight
 // stream is disjoint from the other waves'; the activation fragments come from LDS); the tiles left over when the count is
 // not a multiple of 4 (n_h = 160: tiles 8, 9) are dealt out per (tile, pixel tile) so that every wave multiplies the
-// same number of units.  Output pair (too few tiles to split by tile alone): two tile groups x two halves of the K steps,
-// the partial sums meet in an exchange buffer.
+// same number of units.  Output pair: 2 n_z / 16 tiles dealt out over the 4 waves (one each at n_z = 32), every wave runs the
+// whole K range of its tiles; the results change from the MFMA layout to image rows through an exchange buffer.
+// Ring depth: a weight fragment takes ~1.2 k cycles from L2 when every CU streams, a step lasts only as long as its MFMAs
+// (~17 cycles each): phases with few MFMAs per step (8-pixel rows; the output pair) refill further ahead (fused_ring_depth).
 #pragma once
-#ifndef IAF_FUSED_OKS
-#define IAF_FUSED_OKS 2
-#endif
 #include "iaf_conv_bf3.hpp"
 #include "iaf_step_fused_types.hpp"
 
@@ -40,8 +39,8 @@ struct StepGeom {
     static constexpr int HREG0 = ZREG + RZ * RS * Z16;
     static constexpr int HREG1 = HREG0 + rows_h(0) * RS * H16;
     static constexpr int END = HREG1 + (DEPTH >= 2 ? rows_h(1) * RS * H16 : 0);
-    static constexpr int XB_STRIDE = 2 * NZ + 1;                                 // output exchange buffer [wave 4][pixel][2 n_z] floats
-    static constexpr size_t xb_bytes() { return (size_t)4 * R * W * XB_STRIDE * 4; }
+    static constexpr int XB_STRIDE = 2 * NZ + 1;                                 // output exchange buffer [pixel][2 n_z] floats
+    static constexpr size_t xb_bytes() { return (size_t)R * W * XB_STRIDE * 4; }
     // (the last hidden layer sits in the h_odd region for an even depth: z + h_even are dead then; for an odd depth it sits in
     // h_even: the buffer goes into h_odd if it fits there, else behind everything)
     static constexpr int XB_OFF = (DEPTH % 2 == 0) ? 0 : (DEPTH >= 3 && xb_bytes() <= (size_t)(END - HREG1) * 16) ? HREG1 : END;
@@ -65,6 +64,16 @@ constexpr int fused_extra_mask(int npt, int gn, int g) {
     int m = 0;
     for (int q = lo; q < hi; ++q) m |= 1 << q;
     return m;
+}
+
+// steps of look-ahead of a phase's weight ring: enough MFMA time between the request of a fragment and its use to cover
+// the L2 round trip under load.  Measured with two steps everywhere (round 2): every phase whose steps hold fewer than ~40
+// MFMAs ran at ~600 cycles per STEP whatever its MFMA count (8x8: second conv 15 MFMAs per step at 42 cycles per MFMA, output
+// pair 512 cycles per step; 16x16 output pair 24 MFMAs per step at 27 cycles per MFMA) -- half the fetch latency each.
+constexpr int fused_ring_depth(int mfma_per_step) {
+    const int per = mfma_per_step * 17, need = 1300;
+    const int rd = (need + per - 1) / per;
+    return rd < 2 ? 2 : rd > 6 ? 6 : rd;
 }
 
 // VAR: the statement of the operator -- 0 TF, 1 Theano (image rotated by 180 degrees + border channel), 2 Theano with
@@ -106,16 +115,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     constexpr bool XSPLIT = NX > 0 && NW % NX == 0;              // left-over tiles dealt out per (tile, pixel tile)
     constexpr int GN = XSPLIT ? NW / NX : 1;                     // waves sharing one left-over tile
     constexpr int NTWH = NFULL + (NX ? 1 : 0);                   // tile slots per wave
-    constexpr int OKS = IAF_FUSED_OKS;                           // output pair: K split in OKS parts, NW / OKS tile groups
-    constexpr int NTWO = 2 * NZT * OKS / NW;                     // tile slots per wave
-    static_assert((2 * NZT * OKS) % NW == 0, "output tiles must split evenly over the wave groups");
+    constexpr int NTWO = 2 * NZT / NW;                           // output pair: tiles per wave
+    static_assert((2 * NZT) % NW == 0, "output tiles must split evenly over the waves");
     int htile[NTWH];
 #pragma unroll
     for (int j = 0; j < NTWH; ++j) htile[j] = (j < NFULL) ? wave + NW * j : (XSPLIT ? NW * NFULL + wave % NX : wave + NW * j);
     const int xg = XSPLIT ? wave / NX : 0;                       // this wave's group for the left-over tile
 
     // ---- weight fragments: [step = pair * 5 + tap][co tile][plane][lane][8 bf16] -> ring of U step slots per phase ----
-    constexpr int RD = 2, U = RD + 1;
+    constexpr int NPT0 = (G::rows_h(0) * W + 15) / 16;
+    constexpr int NPTO = (R * W + 15) / 16;
+    // look-ahead per phase (fused_ring_depth): first hidden layer, the other hidden layers (the smallest of them decides: they
+    // share two ring arrays), output pair
+    constexpr int RD0 = fused_ring_depth(NPT0 * NHT * 6 / NW);
+    constexpr int RDH = DEPTH >= 2 ? fused_ring_depth(((G::rows_h(DEPTH - 1) * W + 15) / 16) * NHT * 6 / NW) : 2;
+    constexpr int RDO = fused_ring_depth(NPTO * NTWO * 6);
+    constexpr int UA = (RD0 > RDH || DEPTH < 3 ? RD0 : RDH) + 1;     // slots of ring array A (layers 0, 2): layer 0, and layer 2 if any
+    constexpr int UB = RDH + 1;                                      // ring array B (layers 1, 3)
+    constexpr int UO = RDO + 1;
     // fragments [LO, HI) of step s (steps past s_end reload its last step; tiles past the layer's are clamped)
     auto ring_load = [&](auto lo_c, auto hi_c, f32x4 (*dst)[3], const f32x4* wbase, int ncot, const int* tiles, int s_end, int s) {
         constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
@@ -131,7 +148,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // ---- prologue: z rows first (the first conv cannot start without them), then the first weight steps; zero columns
     // while both travel; z -> LDS ---------------------------------------------------------------------------------------
-    constexpr int NPT0 = (G::rows_h(0) * W + 15) / 16;
     constexpr int NPX = RZ * W, NIT = NPX * (NZ / 4), ZU = (NIT + 255) / 256;
     f32x4 zv[ZU], zq[4][ZU];     // posterior input: the five tensors as raw loads, combined once all of them are on their way
 #pragma unroll
@@ -154,9 +170,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     }
     __builtin_amdgcn_sched_barrier(0);
-    f32x4 wr0[U][NTWH][3];
+    f32x4 wr0[UA][NTWH][3];
     const f32x4* wb0 = (const f32x4*)p.wp3[0] + lane;
-    static_for<RD>([&](auto i) {
+    static_for<RD0>([&](auto i) {
         ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWH * 3>{}, wr0[decltype(i)::value], wb0, NHT, htile,
                   (NZ / 32) * NTAPS, decltype(i)::value);
     });
@@ -236,11 +252,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // ---- one conv phase: acc[q][j] = sum over steps [s0, nstep) of W[step][tiles[j]] x X[pixel tile q, step] --------------
     // in_reg / in_s16 / in_c8: the input region (16-byte units); ROWS * W output pixels in NPT tiles.  The LAST tile slot is
     // multiplied only for the pixel tiles in EMASK (the wave's share of a left-over tile); all others for every pixel tile.
-    auto conv_phase = [&](auto npt_c, auto ntw_c, auto rows_c, auto emask_c, int in_reg, int in_s16, int in_c8, const f32x4* wbase,
+    auto conv_phase = [&](auto rd_c, auto npt_c, auto ntw_c, auto rows_c, auto emask_c, int in_reg, int in_s16, int in_c8, const f32x4* wbase,
                           int ncot, const int* tiles, int s0, int nstep, f32x4 (*wr)[decltype(ntw_c)::value][3],
                           f32x4 (*acc_out)[decltype(ntw_c)::value]) {
         constexpr int NPT = decltype(npt_c)::value, NTW = decltype(ntw_c)::value, ROWS = decltype(rows_c)::value;
         constexpr int EMASK = decltype(emask_c)::value;
+        constexpr int RD = decltype(rd_c)::value, U = RD + 1;      // this phase's look-ahead; it uses slots 0 .. RD of its ring array
         f32x4 acc[NPT][NTW];
         int xb[NPT];
 #pragma unroll
@@ -362,18 +379,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // ---- hidden layers ---------------------------------------------------------------------------------------------
     constexpr int NSTEP_H = (NH / 32) * NTAPS;
-    const int okh = wave % OKS;                                  // this wave's K part / tile group of the output pair
-    const int so0 = (okh * NSTEP_H) / OKS, so1 = ((okh + 1) * NSTEP_H) / OKS;
     int otile[NTWO];
 #pragma unroll
-    for (int j = 0; j < NTWO; ++j) otile[j] = (wave / OKS) * NTWO + j;
-    f32x4 wr1[U][NTWH][3];           // hidden layer l uses ring l & 1 (wr0 / wr1): the other one receives layer l + 1's first steps
-    f32x4 wro[U][NTWO][3];           // ring of the output pair
+    for (int j = 0; j < NTWO; ++j) otile[j] = wave * NTWO + j;
+    f32x4 wr1[UB][NTWH][3];          // hidden layer l uses ring l & 1 (wr0 / wr1): the other one receives layer l + 1's first steps
+    f32x4 wro[UO][NTWO][3];          // ring of the output pair
     const f32x4* wbo = (const f32x4*)p.wp3[DEPTH] + lane;
     auto preload_out = [&]() {
-        static_for<RD>([&](auto i) {
+        static_for<RDO>([&](auto i) {
             ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWO * 3>{}, wro[decltype(i)::value], wbo, 2 * NZT,
-                      otile, so1, so0 + decltype(i)::value);
+                      otile, NSTEP_H, decltype(i)::value);
         });
     };
     // the weights of the phase after hidden layer l -- the next hidden layer's ring, or the output pair's -- start travelling
@@ -382,7 +397,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         constexpr int l = decltype(l_c)::value;
         if constexpr (l + 1 < DEPTH) {
             const f32x4* wbn = (const f32x4*)p.wp3[l + 1] + lane;
-            static_for<RD>([&](auto i) {
+            static_for<RDH>([&](auto i) {
                 ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWH * 3>{},
                           ((l + 1) & 1) ? wr1[decltype(i)::value] : wr0[decltype(i)::value], wbn, NHT, htile, NSTEP_H, decltype(i)::value);
             });
@@ -397,8 +412,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         constexpr int EM0 = (NX == 0 || !XSPLIT) ? (1 << NPT0) - 1 : fused_extra_mask(NPT0, GN, GI);
         f32x4 acc0[NPT0][NTWH], bi0[NTWH];
         load_bias(p.bias[0], bi0);
-        conv_phase(std::integral_constant<int, NPT0>{}, std::integral_constant<int, NTWH>{}, std::integral_constant<int, G::rows_h(0)>{},
-                   std::integral_constant<int, EM0>{}, G::ZREG, Z16, Z8, wb0, NHT, htile, 0, (NZ / 32) * NTAPS, wr0, acc0);
+        conv_phase(std::integral_constant<int, RD0>{}, std::integral_constant<int, NPT0>{}, std::integral_constant<int, NTWH>{},
+                   std::integral_constant<int, G::rows_h(0)>{}, std::integral_constant<int, EM0>{}, G::ZREG, Z16, Z8, wb0, NHT, htile, 0,
+                   (NZ / 32) * NTAPS, wr0, acc0);
         IAF_FSTAMP(6);
         store_ctx();
         preload_after(std::integral_constant<int, 0>{});
@@ -429,8 +445,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             f32x4 accl[NPTL][NTWH], bil[NTWH];
             load_bias(p.bias[l], bil);
             const f32x4* wbl = (const f32x4*)p.wp3[l] + lane;
-            conv_phase(std::integral_constant<int, NPTL>{}, std::integral_constant<int, NTWH>{}, std::integral_constant<int, G::rows_h(l)>{},
-                       std::integral_constant<int, EML>{}, IN_REG, H16, H8, wbl, NHT, htile, 0, NSTEP_H, (l & 1) ? wr1 : wr0, accl);
+            conv_phase(std::integral_constant<int, RDH>{}, std::integral_constant<int, NPTL>{}, std::integral_constant<int, NTWH>{},
+                       std::integral_constant<int, G::rows_h(l)>{}, std::integral_constant<int, EML>{}, IN_REG, H16, H8, wbl, NHT, htile, 0,
+                       NSTEP_H, (l & 1) ? wr1 : wr0, accl);
 #ifndef IAF_EXP_STAMP_MID
             if constexpr (l == 1) IAF_FSTAMP(7);
 #endif
@@ -444,7 +461,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // ---- output pair: packed tiles (m_0, s_0, m_1, s_1, ...), partial sums -> exchange buffer [K part][pixel][2 n_z] -------
     // (the operands of the final transform are fetched first: they travel while the output pair is multiplied)
-    constexpr int NPTO = (R * W + 15) / 16;
     constexpr int NEL = (NZ * R * W + 255) / 256;
     float fz[NEL], fq[NEL][6];
     float fb[NEL][2];
@@ -467,11 +483,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     float* xbuf = (float*)(smem + (size_t)G::XB_OFF * 16);
     {
         f32x4 acco[NPTO][NTWO];
-        conv_phase(std::integral_constant<int, NPTO>{}, std::integral_constant<int, NTWO>{}, std::integral_constant<int, R>{},
-                   std::integral_constant<int, (1 << NPTO) - 1>{}, ((DEPTH - 1) & 1) ? G::HREG1 : G::HREG0, H16, H8, wbo, 2 * NZT, otile,
-                   so0, so1, wro, acco);
+        conv_phase(std::integral_constant<int, RDO>{}, std::integral_constant<int, NPTO>{}, std::integral_constant<int, NTWO>{},
+                   std::integral_constant<int, R>{}, std::integral_constant<int, (1 << NPTO) - 1>{}, ((DEPTH - 1) & 1) ? G::HREG1 : G::HREG0,
+                   H16, H8, wbo, 2 * NZT, otile, 0, NSTEP_H, wro, acco);
         IAF_FSTAMP(4);
-        float* mine = xbuf + (size_t)okh * (R * W * G::XB_STRIDE);
+        float* mine = xbuf;
 #pragma unroll
         for (int j = 0; j < NTWO; ++j)
 #pragma unroll
@@ -506,11 +522,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             m_raw += w1 * bt[cm] + w2 * bt[2 * NZ + cm] + w3 * bt[4 * NZ + cm] + w4 * bt[6 * NZ + cm];
             s_raw += w1 * bt[cm + 16] + w2 * bt[2 * NZ + cm + 16] + w3 * bt[4 * NZ + cm + 16] + w4 * bt[6 * NZ + cm + 16];
         }
-#pragma unroll
-        for (int k = 0; k < OKS; ++k) {
-            m_raw += xbuf[k * (R * W * G::XB_STRIDE) + pix * G::XB_STRIDE + cm];
-            s_raw += xbuf[k * (R * W * G::XB_STRIDE) + pix * G::XB_STRIDE + cm + 16];
-        }
+        m_raw += xbuf[pix * G::XB_STRIDE + cm];
+        s_raw += xbuf[pix * G::XB_STRIDE + cm + 16];
         if (p.mode == MODE_RAW) {
             p.out0[gi] = m_raw;
             p.out1[gi] = s_raw;

@@ -11,6 +11,57 @@ import torch
 import torch.distributed as dist
 
 
+class RcclComm(object):
+    """The gradient exchange through the engine's C ABI (include/iaf_hip.h: iaf_comm_*, csrc/iaf_comm.cpp): an RCCL
+    communicator over this process group's ranks, one GPU per rank, and all-reduce(sum) in place on segments of a device
+    buffer (tf_utils/common.py:83-86; the 1/N rides in the fused Adamax launch).  torch.distributed is used ONCE, to carry
+    the 128-byte communicator id from rank 0 to the others; no collective of the training loop goes through it."""
+
+    def __init__(self, group=None, device=None):
+        import ctypes
+        from . import _capi
+        self._capi, self._ct = _capi, ctypes
+        lib = _capi.lib()
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        idbuf = ctypes.create_string_buffer(_capi.IAF_COMM_ID_BYTES)
+        if self.rank == 0:
+            _capi.check(lib.iaf_comm_unique_id(idbuf))
+        if self.world > 1:
+            box = [bytes(idbuf.raw)]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            idbuf = ctypes.create_string_buffer(box[0], _capi.IAF_COMM_ID_BYTES)
+        h = ctypes.c_void_p()
+        _capi.check(lib.iaf_comm_create(ctypes.byref(h), idbuf, self.rank, self.world, self.device))
+        self._h = h
+        self.library = lib.iaf_comm_library().decode()
+
+    def size(self):
+        r, w = self._ct.c_int(), self._ct.c_int()
+        self._capi.check(self._capi.lib().iaf_comm_size(self._h, self._ct.byref(r), self._ct.byref(w)))
+        return r.value, w.value
+
+    def all_reduce_sum_(self, t, stream=None):
+        """in place on the contiguous fp32 device tensor `t`, asynchronously on `stream` (default: the current one)"""
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise ValueError("all_reduce_sum_ takes a contiguous fp32 device tensor")
+        st = torch.cuda.current_stream() if stream is None else stream
+        self._capi.check(self._capi.lib().iaf_allreduce_sum_f32(self._h, self._ct.c_void_p(t.data_ptr()), t.numel(),
+                                                                self._ct.c_void_p(st.cuda_stream)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._capi.lib().iaf_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class FlatParams(object):
     """All trainable tensors of a model as views into ONE flat fp32 buffer, with matching flat gradient, Adamax slot and
     EMA buffers.  The engine's backward writes gradients straight into the views, so a training step needs exactly one
@@ -35,8 +86,12 @@ class FlatParams(object):
             off += ((n + 3) // 4) * 4
         self.ema.copy_(self.params)
 
-    def all_reduce_grads(self, group=None, async_op=False):
-        """sum over ranks (the 1/N is folded into the optimiser kernel)"""
+    def all_reduce_grads(self, group=None, async_op=False, comm=None):
+        """sum over ranks (the 1/N is folded into the optimiser kernel).  comm: an RcclComm -- the exchange then runs through
+        the engine's C ABI on the current stream (stream-ordered: nothing to wait for on the host)."""
+        if comm is not None:
+            comm.all_reduce_sum_(self.grads)
+            return None
         if dist.is_initialized() and dist.get_world_size(group) > 1:
             return dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
         return None
@@ -73,9 +128,13 @@ class OverlappedGradReduce(object):
     the compute stream, so bucket i travels over xGMI while the backward of the remaining layers runs, and `wait()`
     joins the streams before the optimiser.  xGMI rings are per-link bound, so the buckets stay large (tens of MB);
     the 1/N is folded into the fused Adamax kernel.  `force` runs the collective even at world size 1 (single-GPU
-    boxes: the RCCL path still executes)."""
+    boxes: the RCCL path still executes).
 
-    def __init__(self, flat, bounds, group=None, force=False):
+    Device buffers travel through the engine's C ABI (RcclComm: iaf_allreduce_sum_f32 = ncclAllReduce on a dedicated
+    exchange stream that waits for the point of the compute stream where the bucket was completed); host buffers (the gloo
+    tests of the DP arithmetic) through torch.distributed."""
+
+    def __init__(self, flat, bounds, group=None, force=False, comm=None):
         self.flat, self.group = flat, group
         self.bounds = [(int(a), int(b)) for a, b in bounds]
         n = flat.grads.numel()
@@ -83,6 +142,10 @@ class OverlappedGradReduce(object):
         assert all(a[1] == b[0] for a, b in zip(self.bounds[:-1], self.bounds[1:])), "buckets must be contiguous"
         self.active = dist.is_initialized() and (dist.get_world_size(group) > 1 or force)
         self.works = []
+        self.comm, self.xstream, self._pending = None, None, False
+        if self.active and flat.grads.is_cuda:
+            self.comm = comm if comm is not None else RcclComm(group)
+            self.xstream = torch.cuda.Stream()
 
     @staticmethod
     def bounds_from_groups(flat, groups):
@@ -115,11 +178,20 @@ class OverlappedGradReduce(object):
         return out
 
     def reduce(self, i):
-        if self.active:
-            lo, hi = self.bounds[i]
+        if not self.active:
+            return
+        lo, hi = self.bounds[i]
+        if self.comm is not None:
+            self.xstream.wait_stream(torch.cuda.current_stream())       # the bucket's gradients are complete at this point
+            self.comm.all_reduce_sum_(self.flat.grads[lo:hi], stream=self.xstream)
+            self._pending = True
+        else:
             self.works.append(dist.all_reduce(self.flat.grads[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def wait(self):
+        if self._pending:
+            torch.cuda.current_stream().wait_stream(self.xstream)       # the optimiser runs behind the last bucket
+            self._pending = False
         for w in self.works:
             w.wait()
         self.works = []

@@ -157,6 +157,26 @@ int iaf_posterior_block_backward(iaf_stack_t* s, const float* qz_mean, const flo
                                  float* const* db, int B, int H, int W, void* workspace, size_t workspace_bytes,
                                  void* stream);
 
+/* The gradient exchange of a data-parallel training step: all-reduce(sum) over the ranks' flat fp32 gradient buffers
+ * (tf_utils/common.py:83-86, average_grads: per-variable sum over the towers of tf_train.py:124-147, then 1/N -- the 1/N
+ * rides in iaf_adamax_ema_step's grad_scale).  One process per GPU; RCCL (ncclAllReduce) over xGMI, bound at run time
+ * (dlopen: the copy the process already carries, e.g. PyTorch's, else /opt/rocm/lib/librccl.so.1; iaf_comm_library() says
+ * which).  Protocol: rank 0 calls iaf_comm_unique_id and hands the IAF_COMM_ID_BYTES bytes to every rank by any channel it
+ * has; every rank calls iaf_comm_create (a collective: it returns once all `world` ranks have joined) with its rank and its
+ * HIP device ordinal; iaf_allreduce_sum_f32 reduces buf[0..n) in place across the communicator, asynchronously on `stream`
+ * (device pointer; the call is a collective -- every rank issues the same sequence of calls with the same n); buckets of
+ * tens of MB keep the per-link-bound xGMI rings busy (iaf_amd/parallel.py cuts the flat buffer in completion order).
+ * Errors: IAF_ERR_* for arguments, IAF_ERR_UNSUPPORTED if no RCCL can be loaded, 10000 + ncclResult_t for failures inside
+ * RCCL (iaf_error_string knows them). */
+#define IAF_COMM_ID_BYTES 128
+typedef struct iaf_comm iaf_comm_t;
+int iaf_comm_unique_id(void* id_out);
+int iaf_comm_create(iaf_comm_t** out, const void* id, int rank, int world, int device);
+int iaf_comm_size(const iaf_comm_t* c, int* rank, int* world);
+int iaf_allreduce_sum_f32(iaf_comm_t* c, float* buf, size_t n, void* stream);
+int iaf_comm_destroy(iaf_comm_t* c);
+const char* iaf_comm_library(void);
+
 /* Optimiser step on flat fp32 buffers of n elements: Adamax (tf_utils/adamax.py:40-56: slot "v" is the first moment,
  * slot "m" the infinity norm), on grad*grad_scale (grad_scale = 1/N folds the division of average_grads,
  * tf_utils/common.py:86, after an all-reduce(sum)), then the EMA of the new parameters (tf_train.py:157-158;
