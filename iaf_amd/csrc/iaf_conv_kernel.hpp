@@ -452,16 +452,9 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
                         const int a = (NT == 1) ? (j & 1) : t;
-#ifdef IAF_EXP_STATICOPS
-                        asm volatile("" ::"v"(opw[tp & 1][t][j]));                      // reads still happen and are waited for
-                        acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(sv[t % SU][j], opx[tp & 1][j], acc[a], 0, 0, 0);
-#else
                         acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(opw[tp & 1][t][j], opx[tp & 1][j], acc[a], 0, 0, 0);
-#endif
                     }
-#ifndef IAF_EXP_NOINTERLEAVE
                 sched_interleave<4 * NT, RD ? NT + 1 : 0, WR ? NLD : 0, LDG ? NLD : 0>();
-#endif
                 __builtin_amdgcn_sched_barrier(0);   // scheduling regions are per tap: nothing migrates across
             });
         };
@@ -497,22 +490,14 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
             xn = (tp + 1 < NTP) ? smem4[xa[(tp + 1) % NTP] + chunk * 4]
                                   : smem4[xa[0] + (chunk + 1 < c_end ? chunk + 1 : chunk) * 4];
             constexpr int PS = (I * NTP + tp + R - 1) % R;                  // slot consumed by the previous step
-#ifdef IAF_EXP_NOREFILL
-            constexpr bool rf = false;
-#else
             constexpr bool rf = (tp == 0) ? RF_T4 : RF_OWN;
-#endif
             const f32x4* q = wbase + ((size_t)chunk * NTP + tp + R - 1) * wstep;   // step s + R - 1
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     const int a = (NT == 1) ? (j & 1) : t;
-#ifdef IAF_EXP_NOMFMA
-                    asm volatile("" ::"v"(wr[I * NTP + tp][t][j]), "v"(xv[j]));
-#else
                     acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[I * NTP + tp][t][j], xv[j], acc[a], 0, 0, 0);
-#endif
                 }
             }
             if constexpr (rf) {   // refill of the slot the previous step consumed; spread between the MFMAs below
@@ -525,10 +510,8 @@ __global__ __launch_bounds__(64 * PXT * WCO * KS) void iaf_conv_kernel(ConvP p) 
 #pragma unroll
                 for (int t = 0; t < NT; ++t) wr[NTP + tp][t] = q2[ulane + t * 64];
             }
-#if !defined(IAF_EXP_NOINTERLEAVE) && !defined(IAF_EXP_NOMFMA)
             sched_interleave<4 * NT, 1, 0, (rf ? NT : 0) + (rmp ? NT : 0)>();
             __builtin_amdgcn_sched_barrier(0);
-#endif
         });
     };
     {

@@ -31,21 +31,35 @@ __global__ __launch_bounds__(256) void iaf_kl_finish_kernel(const float* S, floa
     const int tid = threadIdx.x, n = B * Z;
     const bool in_lds = n <= 8192;
     if (nrb > 0) {
+        // item = four consecutive channels of one image: its nrb partial sums are nrb independent 16-byte loads, eight in
+        // flight per round (the whole table in ONE round trip at B = 32, 16x16: 256 items x 8 row blocks)
         float* dst = in_lds ? sh : scratch;
-        for (int i = tid; i < n; i += 256) {
-            const int b = i / Z, c = i - b * Z;
-            float a = 0.f;
-            for (int r0 = 0; r0 < nrb; r0 += 8) {
-                float v8[8];
+        typedef float kf4 __attribute__((ext_vector_type(4)));
+        if ((Z & 3) == 0) {
+            const int Z4 = Z >> 2;
+            for (int i = tid; i < B * Z4; i += 256) {
+                const int b = i / Z4, c4 = i - b * Z4;
+                kf4 a = kf4{0.f, 0.f, 0.f, 0.f};
+                for (int r0 = 0; r0 < nrb; r0 += 8) {
+                    kf4 v8[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int r = r0 + k < nrb ? r0 + k : nrb - 1;
-                    v8[k] = S[((size_t)b * nrb + r) * Z + c];
+                    for (int k = 0; k < 8; ++k) {
+                        const int r = r0 + k < nrb ? r0 + k : nrb - 1;
+                        v8[k] = *(const kf4*)(S + ((size_t)b * nrb + r) * Z + 4 * c4);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        if (r0 + k < nrb) a += v8[k];
                 }
-#pragma unroll
-                for (int k = 0; k < 8; ++k) a += (r0 + k < nrb) ? v8[k] : 0.f;
+                *(kf4*)(dst + (size_t)b * Z + 4 * c4) = a;
             }
-            dst[i] = a;
+        } else {
+            for (int i = tid; i < n; i += 256) {
+                const int b = i / Z, c = i - b * Z;
+                float a = 0.f;
+                for (int r = 0; r < nrb; ++r) a += S[((size_t)b * nrb + r) * Z + c];
+                dst[i] = a;
+            }
         }
         __syncthreads();
     } else if (in_lds) {

@@ -21,8 +21,11 @@
 // not a multiple of 4 (n_h = 160: tiles 8, 9) are dealt out per (tile, pixel tile) so that every wave multiplies the
 // same number of units.  Output pair: 2 n_z / 16 tiles dealt out over the 4 waves (one each at n_z = 32), every wave runs the
 // whole K range of its tiles; the results change from the MFMA layout to image rows through an exchange buffer.
-// Ring depth: a weight fragment takes ~1.2 k cycles from L2 when every CU streams, a step lasts only as long as its MFMAs
-// (~17 cycles each): phases with few MFMAs per step (8-pixel rows; the output pair) refill further ahead (fused_ring_depth).
+// Ring depth: two steps of look-ahead for the hidden layers, three for the output pair.  Round 3 measured deeper rings sized
+// by MFMAs per step (up to six steps at 8-pixel rows): the K loops gained 2 k cycles per workgroup and the bursts of preload
+// instructions in front of the epilogues cost 4.4 k -- at 8-pixel rows the K loops are bound by the CU's vector-memory
+// ISSUE rate (one 1 KiB wave-load per ~16 cycles = the 64 B/clk port: 750 wave-loads = 12 k of the second conv's 15 k cycles),
+// not by fetch latency.
 #pragma once
 #include "iaf_conv_bf3.hpp"
 #include "iaf_step_fused_types.hpp"
@@ -66,15 +69,12 @@ constexpr int fused_extra_mask(int npt, int gn, int g) {
     return m;
 }
 
-// steps of look-ahead of a phase's weight ring: enough MFMA time between the request of a fragment and its use to cover
-// the L2 round trip under load.  Measured with two steps everywhere (round 2): every phase whose steps hold fewer than ~40
-// MFMAs ran at ~600 cycles per STEP whatever its MFMA count (8x8: second conv 15 MFMAs per step at 42 cycles per MFMA, output
-// pair 512 cycles per step; 16x16 output pair 24 MFMAs per step at 27 cycles per MFMA) -- half the fetch latency each.
-constexpr int fused_ring_depth(int mfma_per_step) {
-    const int per = mfma_per_step * 17, need = 1300;
-    const int rd = (need + per - 1) / per;
-    return rd < 2 ? 2 : rd > 6 ? 6 : rd;
-}
+// Independent accumulators per (pixel tile, co tile) unit.  The six part-products of a step go to the SAME accumulator; a
+// phase whose waves hold few units (the output pair: 2 units per wave at 16-pixel rows, 1 at 8) then issues chains of
+// dependent MFMAs, which the matrix pipe does not overlap: measured 26-27 cycles per MFMA there against 19 in the hidden
+// layers (2-3 co tiles per pixel tile: the same accumulator every second or third MFMA).  Such phases spread the six products
+// over PSG accumulator groups (summed once, after the K loop), so that an accumulator is touched every third MFMA at most.
+constexpr int fused_acc_groups(int tiles_per_pixel_tile) { return tiles_per_pixel_tile >= 3 ? 1 : tiles_per_pixel_tile == 2 ? 2 : 3; }
 
 // VAR: the statement of the operator -- 0 TF, 1 Theano (image rotated by 180 degrees + border channel), 2 Theano with
 // flipmask=True (TF geometry + border channel).  Compile time: as run-time flags these cost the TF path ~1 us per launch
@@ -125,11 +125,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // ---- weight fragments: [step = pair * 5 + tap][co tile][plane][lane][8 bf16] -> ring of U step slots per phase ----
     constexpr int NPT0 = (G::rows_h(0) * W + 15) / 16;
     constexpr int NPTO = (R * W + 15) / 16;
-    // look-ahead per phase (fused_ring_depth): first hidden layer, the other hidden layers (the smallest of them decides: they
-    // share two ring arrays), output pair
-    constexpr int RD0 = fused_ring_depth(NPT0 * NHT * 6 / NW);
-    constexpr int RDH = DEPTH >= 2 ? fused_ring_depth(((G::rows_h(DEPTH - 1) * W + 15) / 16) * NHT * 6 / NW) : 2;
-    constexpr int RDO = fused_ring_depth(NPTO * NTWO * 6);
+    // look-ahead per phase: first hidden layer, the other hidden layers, output pair (see the header comment)
+    constexpr int RD0 = 2, RDH = 2, RDO = 3;
     constexpr int UA = (RD0 > RDH || DEPTH < 3 ? RD0 : RDH) + 1;     // slots of ring array A (layers 0, 2): layer 0, and layer 2 if any
     constexpr int UB = RDH + 1;                                      // ring array B (layers 1, 3)
     constexpr int UO = RDO + 1;
@@ -180,22 +177,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // context rows of this workgroup: per channel one contiguous run of CPX pixels (full-width rows) -> 16-byte loads,
     // 4 channels per wave instruction; summed with the second context here
     constexpr int CPX = G::CPX, CSTR = G::CSTR, CG = CPX / 4, NCIT = NH * CG, NCI = (NCIT + 255) / 256;
-    f32x4 cv[NCI], cv2[NCI];     // raw loads: nothing consumes them before the z rows are in LDS (a use right behind a load
-    {                            // would make every load wait for the one before)
+    f32x4 cv[NCI], cv2[NCI];     // raw loads: nothing consumes them before the z rows are in LDS.  UNCONDITIONAL loads from
+    unsigned cvalid = 0;         // clamped addresses: `x = 0; if (inside) x = load` is a select on the loaded value, i.e. a
+    {                            // vmcnt(0) behind every load -- ten serial HBM round trips in this prologue (found in the
+                                 // round-3 ISA: 7 k cycles of prologue at 16-pixel rows).  Rows past the image bottom are zeroed
+                                 // when the values are used (store_ctx), from the bit mask.  (The host never launches this
+                                 // kernel without a context: depth_ar >= 1.)
         const int vpx = (H - r0) * W < CPX ? (H - r0) * W : CPX;       // pixels of those rows that lie inside the image
 #pragma unroll
         for (int u = 0; u < NCI; ++u) {
             const int idx = tid + u * 256;
             const int ic = idx < NCIT ? idx : NCIT - 1;
             const int c = ic / CG, g4 = (ic - c * CG) * 4;
-            cv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-            cv2[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (p.ctx && g4 < vpx) {
-                const int row = g4 / W, col4 = g4 - row * W;           // 4 consecutive columns of one row
+            const int g4c = g4 < vpx ? g4 : 0;                         // a valid address either way
+            const int row = g4c / W, col4 = g4c - row * W;             // 4 consecutive columns of one row
+            const size_t gi = ((size_t)b * NH + c) * HW + gpix(r0 + row, col4 + (FLIP ? 3 : 0));
+            cv[u] = *(const f32x4*)(p.ctx + gi);           // (column order fixed up at store time)
+            cvalid |= (g4 < vpx ? 1u : 0u) << u;
+        }
+        if (p.ctx2) {                                      // (uniform branch: no select on loaded values)
+#pragma unroll
+            for (int u = 0; u < NCI; ++u) {
+                const int idx = tid + u * 256;
+                const int ic = idx < NCIT ? idx : NCIT - 1;
+                const int c = ic / CG, g4 = (ic - c * CG) * 4;
+                const int g4c = g4 < vpx ? g4 : 0;
+                const int row = g4c / W, col4 = g4c - row * W;
                 const size_t gi = ((size_t)b * NH + c) * HW + gpix(r0 + row, col4 + (FLIP ? 3 : 0));
-                cv[u] = *(const f32x4*)(p.ctx + gi);       // (column order fixed up at store time)
-                if (p.ctx2) cv2[u] = *(const f32x4*)(p.ctx2 + gi);
+                cv2[u] = *(const f32x4*)(p.ctx2 + gi);
             }
+        } else {
+#pragma unroll
+            for (int u = 0; u < NCI; ++u) cv2[u] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -228,10 +241,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
         }
     }
-    if (p.ctx2) {                // up_context + down_context (tf_train.py:58), now that both have had the z staging to arrive
-#pragma unroll
-        for (int u = 0; u < NCI; ++u) cv[u] += cv2[u];
-    }
     __syncthreads();
     IAF_FSTAMP(1);
     // the context rows go to LDS after the first conv's K loop (they had all of it to arrive), then a barrier, then its epilogue
@@ -243,8 +252,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if (idx < NCIT) {
                 const int c = idx / CG, g4 = (idx - c * CG) * 4;
                 constexpr bool fl = FLIP;                        // rotated image: the 4 columns arrived in reverse order
-                *(f32x4*)(creg + c * CSTR + g4) = f32x4{fl ? cv[u][3] : cv[u][0], fl ? cv[u][2] : cv[u][1], fl ? cv[u][1] : cv[u][2],
-                                                        fl ? cv[u][0] : cv[u][3]};
+                f32x4 v = cv[u] + cv2[u];                        // up_context + down_context (tf_train.py:58)
+                if (!((cvalid >> u) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};      // rows past the image bottom
+                *(f32x4*)(creg + c * CSTR + g4) = f32x4{fl ? v[3] : v[0], fl ? v[2] : v[1], fl ? v[1] : v[2], fl ? v[0] : v[3]};
             }
         }
     };
@@ -258,7 +268,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         constexpr int NPT = decltype(npt_c)::value, NTW = decltype(ntw_c)::value, ROWS = decltype(rows_c)::value;
         constexpr int EMASK = decltype(emask_c)::value;
         constexpr int RD = decltype(rd_c)::value, U = RD + 1;      // this phase's look-ahead; it uses slots 0 .. RD of its ring array
-        f32x4 acc[NPT][NTW];
+        constexpr int PSG = fused_acc_groups(NTW);                 // accumulator groups of a unit's six part-products
+        f32x4 acc[PSG][NPT][NTW];
         int xb[NPT];
 #pragma unroll
         for (int q = 0; q < NPT; ++q) {
@@ -267,7 +278,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int row = pix / W, col = pix - row * W;
             xb[q] = in_reg + (row * RS + col + 1) * in_s16 + kk;
 #pragma unroll
-            for (int j = 0; j < NTW; ++j) acc[q][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int g = 0; g < PSG; ++g)
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) acc[g][q][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         auto xaddr = [&](auto q_c, int s) -> int {
             const int sc = s < nstep ? s : nstep - 1;
@@ -287,29 +300,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 constexpr int NTQ = ((EMASK >> q) & 1) ? NTW : NTW - 1;      // tile slots multiplied for this pixel tile
                 // this pixel tile's share of the refill of the slot consumed RD steps from now
                 constexpr int LO = (q * NTW * 3) / NPT, HI = ((q + 1) * NTW * 3) / NPT;
-#ifndef IAF_EXP_FUSED_NOREFILL
                 ring_load(std::integral_constant<int, LO>{}, std::integral_constant<int, HI>{}, wr[(I + RD) % U], wbase, ncot, tiles, nstep,
                           s + RD);
-#endif
                 const bf16x8 xh = __builtin_bit_cast(bf16x8, xn[0]);
                 const bf16x8 xm = __builtin_bit_cast(bf16x8, xn[1]);
                 const bf16x8 xl = __builtin_bit_cast(bf16x8, xn[2]);
-#ifndef IAF_EXP_FUSED_NOLDS
                 {
                     const int a = (q + 1 < NPT) ? xaddr(std::integral_constant<int, (q + 1) % NPT>{}, s)
                                                 : xaddr(std::integral_constant<int, 0>{}, s + 1);
                     xn[0] = smem4[a]; xn[1] = smem4[a + in_c8]; xn[2] = smem4[a + 2 * in_c8];
                 }
-#endif
-#define IAF_FPROD(WP, XV)                                                                                         \
+#define IAF_FPROD(K, WP, XV)                                                                                      \
     _Pragma("unroll") for (int j = 0; j < NTQ; ++j)                                                                \
-        acc[q][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wr[I][j][WP]), XV, acc[q][j], 0, 0, 0);
-                IAF_FPROD(2, xh)
-                IAF_FPROD(0, xl)
-                IAF_FPROD(1, xm)
-                IAF_FPROD(1, xh)
-                IAF_FPROD(0, xm)
-                IAF_FPROD(0, xh)
+        acc[(K) % PSG][q][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wr[I][j][WP]), XV, acc[(K) % PSG][q][j], 0, 0, 0);
+                IAF_FPROD(0, 2, xh)
+                IAF_FPROD(1, 0, xl)
+                IAF_FPROD(2, 1, xm)
+                IAF_FPROD(3, 1, xh)
+                IAF_FPROD(4, 0, xm)
+                IAF_FPROD(5, 0, xh)
 #undef IAF_FPROD
                 sched_interleave<6 * NTQ, 3, 0, HI - LO>();
                 __builtin_amdgcn_sched_barrier(0);
@@ -326,7 +335,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int q = 0; q < NPT; ++q)
 #pragma unroll
-            for (int j = 0; j < NTW; ++j) acc_out[q][j] = acc[q][j];
+            for (int j = 0; j < NTW; ++j) {
+                f32x4 a = acc[0][q][j];
+#pragma unroll
+                for (int g = 1; g < PSG; ++g) a += acc[g][q][j];
+                acc_out[q][j] = a;
+            }
     };
 
     // hidden epilogue: bias (+ context) + ELU (layers.py:63-64,163-165) -> the three planes of the next region; rows past the
@@ -377,6 +391,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     };
 
+    // operands of the final transform (tf_train.py:56-75): requested BEFORE the last hidden layer's epilogue -- the vector
+    // memory counter retires in order, so a request issued right in front of the output pair's K loop would stall that loop's
+    // third step (the first to wait for a refill issued behind it) for a whole HBM round trip; here they have an epilogue
+    // and a barrier to arrive
+    constexpr int NEL = (NZ * R * W + 255) / 256;
+    float fz[NEL], fq[NEL][6];
+    float fb[NEL][2];
+    auto load_final_operands = [&]() {
+#pragma unroll
+        for (int e = 0; e < NEL; ++e) {
+            const int idx = tid + e * 256;
+            const int ic = idx < NZ * R * W ? idx : NZ * R * W - 1;
+            const int c = ic / (R * W), pix = ic - c * (R * W);
+            const int rr = r0 + pix / W < H ? r0 + pix / W : H - 1;
+            const size_t gi = ((size_t)b * NZ + c) * HW + gpix(rr, pix & (W - 1));
+            const int cm = (c >> 4) * 32 + (c & 15);
+            fb[e][0] = p.bias[DEPTH][cm]; fb[e][1] = p.bias[DEPTH][cm + 16];
+            fz[e] = 0.f;
+            if (p.mode == MODE_IAF || p.mode == MODE_INVERSE) fz[e] = p.zin[gi];
+            if (p.mode == MODE_POSTERIOR) {
+                fq[e][0] = p.qm[gi] + p.rm[gi]; fq[e][1] = p.ql[gi] + p.rl[gi]; fq[e][2] = p.eps[gi];
+                fq[e][3] = p.pm[gi]; fq[e][4] = p.pl[gi];
+            }
+        }
+    };
     // ---- hidden layers ---------------------------------------------------------------------------------------------
     constexpr int NSTEP_H = (NH / 32) * NTAPS;
     int otile[NTWO];
@@ -417,11 +456,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                    (NZ / 32) * NTAPS, wr0, acc0);
         IAF_FSTAMP(6);
         store_ctx();
+        if constexpr (DEPTH == 1) load_final_operands();
         preload_after(std::integral_constant<int, 0>{});
         __syncthreads();                                         // (every wave runs exactly one of the GN instantiations)
-#ifdef IAF_EXP_STAMP_MID
-        IAF_FSTAMP(7);
-#endif
         hidden_epilogue(std::integral_constant<int, NPT0>{}, std::integral_constant<int, G::rows_h(0)>{},
                         std::integral_constant<int, EM0>{}, std::integral_constant<int, 1>{}, acc0, bi0, G::HREG0, p.hsave[0], p.border[0]);
     });
@@ -448,9 +485,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             conv_phase(std::integral_constant<int, RDH>{}, std::integral_constant<int, NPTL>{}, std::integral_constant<int, NTWH>{},
                        std::integral_constant<int, G::rows_h(l)>{}, std::integral_constant<int, EML>{}, IN_REG, H16, H8, wbl, NHT, htile, 0,
                        NSTEP_H, (l & 1) ? wr1 : wr0, accl);
-#ifndef IAF_EXP_STAMP_MID
             if constexpr (l == 1) IAF_FSTAMP(7);
-#endif
+            if constexpr (l == DEPTH - 1) load_final_operands();
             preload_after(std::integral_constant<int, l>{});
             hidden_epilogue(std::integral_constant<int, NPTL>{}, std::integral_constant<int, G::rows_h(l)>{},
                             std::integral_constant<int, EML>{}, std::integral_constant<int, 0>{}, accl, bil, OUT_REG, p.hsave[l], p.border[l]);
@@ -461,25 +497,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // ---- output pair: packed tiles (m_0, s_0, m_1, s_1, ...), partial sums -> exchange buffer [K part][pixel][2 n_z] -------
     // (the operands of the final transform are fetched first: they travel while the output pair is multiplied)
-    constexpr int NEL = (NZ * R * W + 255) / 256;
-    float fz[NEL], fq[NEL][6];
-    float fb[NEL][2];
-#pragma unroll
-    for (int e = 0; e < NEL; ++e) {
-        const int idx = tid + e * 256;
-        const int ic = idx < NZ * R * W ? idx : NZ * R * W - 1;
-        const int c = ic / (R * W), pix = ic - c * (R * W);
-        const int rr = r0 + pix / W < H ? r0 + pix / W : H - 1;
-        const size_t gi = ((size_t)b * NZ + c) * HW + gpix(rr, pix & (W - 1));
-        const int cm = (c >> 4) * 32 + (c & 15);
-        fb[e][0] = p.bias[DEPTH][cm]; fb[e][1] = p.bias[DEPTH][cm + 16];
-        fz[e] = 0.f;
-        if (p.mode == MODE_IAF || p.mode == MODE_INVERSE) fz[e] = p.zin[gi];
-        if (p.mode == MODE_POSTERIOR) {
-            fq[e][0] = p.qm[gi] + p.rm[gi]; fq[e][1] = p.ql[gi] + p.rl[gi]; fq[e][2] = p.eps[gi];
-            fq[e][3] = p.pm[gi]; fq[e][4] = p.pl[gi];
-        }
-    }
     float* xbuf = (float*)(smem + (size_t)G::XB_OFF * 16);
     {
         f32x4 acco[NPTO][NTWO];

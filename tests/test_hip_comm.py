@@ -97,7 +97,8 @@ def test_overlapped_reduce_runs_through_the_c_abi_on_device_buffers():
     finally:
         if own:
             dist.destroy_process_group()
-            os.unlink(f.name)
+            if os.path.exists(f.name):
+                os.unlink(f.name)
 
 
 def _two_rank_worker(rank, idfile, out):
