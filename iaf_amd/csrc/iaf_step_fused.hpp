@@ -42,8 +42,8 @@ struct StepGeom {
     static constexpr int HREG0 = ZREG + RZ * RS * Z16;
     static constexpr int HREG1 = HREG0 + rows_h(0) * RS * H16;
     static constexpr int END = HREG1 + (DEPTH >= 2 ? rows_h(1) * RS * H16 : 0);
-    static constexpr int XB_STRIDE = 2 * NZ + 1;                                 // output exchange buffer [pixel][2 n_z] floats
-    static constexpr size_t xb_bytes() { return (size_t)R * W * XB_STRIDE * 4; }
+    static constexpr int XB_STRIDE = 2 * NZ + 1;                                 // output exchange buffer [K part][pixel][2 n_z] floats
+    static constexpr size_t xb_bytes() { return (size_t)2 * R * W * XB_STRIDE * 4; }       // (two K parts: the 8-wave variant)
     // (the last hidden layer sits in the h_odd region for an even depth: z + h_even are dead then; for an odd depth it sits in
     // h_even: the buffer goes into h_odd if it fits there, else behind everything)
     static constexpr int XB_OFF = (DEPTH % 2 == 0) ? 0 : (DEPTH >= 3 && xb_bytes() <= (size_t)(END - HREG1) * 16) ? HREG1 : END;
@@ -79,9 +79,20 @@ constexpr int fused_acc_groups(int tiles_per_pixel_tile) { return tiles_per_pixe
 // VAR: the statement of the operator -- 0 TF, 1 Theano (image rotated by 180 degrees + border channel), 2 Theano with
 // flipmask=True (TF geometry + border channel).  Compile time: as run-time flags these cost the TF path ~1 us per launch
 // (branches around the border loads split the epilogue's basic blocks).
-template <int NHT, int NZT, int DEPTH, int W, int R, int VAR = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void iaf_step_fused_kernel(StepP p) {
+// WV: waves per workgroup.  4: one wave per SIMD.  8: two per SIMD -- a second wave's MFMAs fill the issue bubbles of the first
+// (one wave alone issues a 16x16x32 MFMA every ~19 cycles, the pipe takes one every 16) and its memory / LDS latencies overlap
+// the other's arithmetic.  The two halves (waves 0-3, 4-7) keep the 4-wave tile ownership and split
+//   - the FIRST hidden layer by pixel tiles (its K is only n_z: too short to split; its small weight set is then streamed
+//     by both halves), every wave finishing its own units;
+//   - every other hidden layer by K steps, the second half's partial sums handed over through the layer's INPUT region once
+//     every wave has left the K loop (the region is dead by then), the first half running the epilogue;
+//   - the output pair by K steps as well, both partial sums meeting in the exchange buffer.
+// Weight and LDS operand traffic per workgroup stay what they are with 4 waves (+ the first layer's pack once more).
+template <int NHT, int NZT, int DEPTH, int W, int R, int VAR = 0, int WV = 4>
+__global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(WV / 4, WV / 4))) void iaf_step_fused_kernel(StepP p) {
     typedef StepGeom<NHT, NZT, DEPTH, W, R> G;
+    static_assert(WV == 4 || WV == 8, "one or two waves per SIMD");
+    constexpr int NT = 64 * WV, HV = WV / 4;                     // threads; halves
     constexpr bool FLIP = (VAR == 1), BORDER = (VAR != 0);
     static_assert(DEPTH >= 1 && DEPTH <= 4, "hidden layers ping-pong between two LDS regions (h_even, h_odd)");
     static_assert((W & (W - 1)) == 0 && W <= 16, "full-width rows of 4, 8 or 16 pixels");
@@ -90,7 +101,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     constexpr int NZ = G::NZ, NH = G::NH, RS = G::RS, Z8 = G::Z8, Z16 = G::Z16, H8 = G::H8, H16 = G::H16, RZ = G::RZ;
     constexpr int NW = 4;                                        // waves
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave8 & (NW - 1);                           // tile ownership: as with four waves
+    const int half = wave8 / NW;                                 // 0 / 1 (always 0 with four waves)
     const int pl = lane & 15, kk = lane >> 4;
     const int b = blockIdx.x / p.nrb, r0 = (blockIdx.x - b * p.nrb) * R;
     const int H = p.H, HW = p.HW;
@@ -107,7 +120,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (last_row || cl) a += *(const f32x4*)(bt + 3 * cstride + ch);
         return a;
     };
-#define IAF_FSTAMP(k) do { if (p.dbg && tid == 0) p.dbg[(size_t)blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#define IAF_FSTAMP(k) do { if (p.dbg && tid == 0) p.dbg[(size_t)blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
     IAF_FSTAMP(0);
 
     // ---- co tiles of a hidden layer per wave: NFULL rounds of 4 + (NX left-over tiles shared by groups of GN waves) ------
@@ -145,11 +158,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // ---- prologue: z rows first (the first conv cannot start without them), then the first weight steps; zero columns
     // while both travel; z -> LDS ---------------------------------------------------------------------------------------
-    constexpr int NPX = RZ * W, NIT = NPX * (NZ / 4), ZU = (NIT + 255) / 256;
+    constexpr int NPX = RZ * W, NIT = NPX * (NZ / 4), ZU = (NIT + NT - 1) / NT;
     f32x4 zv[ZU], zq[4][ZU];     // posterior input: the five tensors as raw loads, combined once all of them are on their way
 #pragma unroll
     for (int u = 0; u < ZU; ++u) {
-        const int idx = tid + u * 256;
+        const int idx = tid + u * NT;
         const int ic = idx < NIT ? idx : NIT - 1;
         const int q = ic / NPX, px = ic - q * NPX;                 // pixel fastest: coalesced along a row
         const int row = px / W, col = px - row * W;
@@ -176,7 +189,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     __builtin_amdgcn_sched_barrier(0);
     // context rows of this workgroup: per channel one contiguous run of CPX pixels (full-width rows) -> 16-byte loads,
     // 4 channels per wave instruction; summed with the second context here
-    constexpr int CPX = G::CPX, CSTR = G::CSTR, CG = CPX / 4, NCIT = NH * CG, NCI = (NCIT + 255) / 256;
+    constexpr int CPX = G::CPX, CSTR = G::CSTR, CG = CPX / 4, NCIT = NH * CG, NCI = (NCIT + NT - 1) / NT;
     f32x4 cv[NCI], cv2[NCI];     // raw loads: nothing consumes them before the z rows are in LDS.  UNCONDITIONAL loads from
     unsigned cvalid = 0;         // clamped addresses: `x = 0; if (inside) x = load` is a select on the loaded value, i.e. a
     {                            // vmcnt(0) behind every load -- ten serial HBM round trips in this prologue (found in the
@@ -186,7 +199,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int vpx = (H - r0) * W < CPX ? (H - r0) * W : CPX;       // pixels of those rows that lie inside the image
 #pragma unroll
         for (int u = 0; u < NCI; ++u) {
-            const int idx = tid + u * 256;
+            const int idx = tid + u * NT;
             const int ic = idx < NCIT ? idx : NCIT - 1;
             const int c = ic / CG, g4 = (ic - c * CG) * 4;
             const int g4c = g4 < vpx ? g4 : 0;                         // a valid address either way
@@ -198,7 +211,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (p.ctx2) {                                      // (uniform branch: no select on loaded values)
 #pragma unroll
             for (int u = 0; u < NCI; ++u) {
-                const int idx = tid + u * 256;
+                const int idx = tid + u * NT;
                 const int ic = idx < NCIT ? idx : NCIT - 1;
                 const int c = ic / CG, g4 = (ic - c * CG) * 4;
                 const int g4c = g4 < vpx ? g4 : 0;
@@ -212,13 +225,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+    IAF_FSTAMP(8);
     {
         constexpr int ZROWS = RZ, H0ROWS = G::rows_h(0), H1ROWS = 0;      // (h_1's zero columns: after the first layer)
-        for (int i = tid; i < ZROWS * 2 * Z16; i += 256) {
+        for (int i = tid; i < ZROWS * 2 * Z16; i += NT) {
             const int rs = i / Z16, u = i - rs * Z16;
             smem4[G::ZREG + ((rs >> 1) * RS + (rs & 1) * (W + 1)) * Z16 + u] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        for (int i = tid; i < (H0ROWS + H1ROWS) * 2 * H16; i += 256) {
+        for (int i = tid; i < (H0ROWS + H1ROWS) * 2 * H16; i += NT) {
             const int rs = i / H16, u = i - rs * H16;
             const int row = rs >> 1;
             const int base = row < H0ROWS ? G::HREG0 + row * RS * H16 : G::HREG1 + (row - H0ROWS) * RS * H16;
@@ -226,7 +240,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
 #pragma unroll
         for (int u = 0; u < ZU; ++u) {
-            const int idx = tid + u * 256;
+            const int idx = tid + u * NT;
             if (idx < NIT) {
                 const int q = idx / NPX, px = idx - q * NPX;
                 const int row = px / W, col = px - row * W;
@@ -241,6 +255,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
         }
     }
+    IAF_FSTAMP(9);
     __syncthreads();
     IAF_FSTAMP(1);
     // the context rows go to LDS after the first conv's K loop (they had all of it to arrive), then a barrier, then its epilogue
@@ -248,7 +263,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         float* creg = (float*)(smem + (size_t)G::CTX_OFF * 16);
 #pragma unroll
         for (int u = 0; u < NCI; ++u) {
-            const int idx = tid + u * 256;
+            const int idx = tid + u * NT;
             if (idx < NCIT) {
                 const int c = idx / CG, g4 = (idx - c * CG) * 4;
                 constexpr bool fl = FLIP;                        // rotated image: the 4 columns arrived in reverse order
@@ -262,9 +277,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // ---- one conv phase: acc[q][j] = sum over steps [s0, nstep) of W[step][tiles[j]] x X[pixel tile q, step] --------------
     // in_reg / in_s16 / in_c8: the input region (16-byte units); ROWS * W output pixels in NPT tiles.  The LAST tile slot is
     // multiplied only for the pixel tiles in EMASK (the wave's share of a left-over tile); all others for every pixel tile.
+    // q0: first pixel tile of this wave (the halves of the 8-wave variant split the first layer's pixel tiles).
     auto conv_phase = [&](auto rd_c, auto npt_c, auto ntw_c, auto rows_c, auto emask_c, int in_reg, int in_s16, int in_c8, const f32x4* wbase,
                           int ncot, const int* tiles, int s0, int nstep, f32x4 (*wr)[decltype(ntw_c)::value][3],
-                          f32x4 (*acc_out)[decltype(ntw_c)::value]) {
+                          f32x4 (*acc_out)[decltype(ntw_c)::value], int q0 = 0) {
         constexpr int NPT = decltype(npt_c)::value, NTW = decltype(ntw_c)::value, ROWS = decltype(rows_c)::value;
         constexpr int EMASK = decltype(emask_c)::value;
         constexpr int RD = decltype(rd_c)::value, U = RD + 1;      // this phase's look-ahead; it uses slots 0 .. RD of its ring array
@@ -273,7 +289,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         int xb[NPT];
 #pragma unroll
         for (int q = 0; q < NPT; ++q) {
-            int pix = q * 16 + pl;
+            int pix = (q0 + q) * 16 + pl;
             pix = pix < ROWS * W ? pix : ROWS * W - 1;             // partially filled tile: a valid address, result unused
             const int row = pix / W, col = pix - row * W;
             xb[q] = in_reg + (row * RS + col + 1) * in_s16 + kk;
@@ -350,7 +366,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int j = 0; j < NTWH; ++j) bi[j] = *(const f32x4*)(bias + (htile[j] < NHT ? htile[j] : NHT - 1) * 16 + 4 * kk);
     };
     auto hidden_epilogue = [&](auto npt_c, auto rows_c, auto emask_c, auto ctx_c, f32x4 (*acc)[NTWH], const f32x4* bias, int out_reg,
-                               float* hsave, const float* bt) {
+                               float* hsave, const float* bt, int q0 = 0) {
         constexpr int NPT = decltype(npt_c)::value, ROWS = decltype(rows_c)::value, EMASK = decltype(emask_c)::value;
         constexpr bool WITH_CTX = decltype(ctx_c)::value != 0;
         f32x4 cxv[WITH_CTX ? NPT : 1][NTWH];                     // all context reads in flight together, ahead of the arithmetic
@@ -359,7 +375,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int j = 0; j < NTWH; ++j)
 #pragma unroll
                 for (int q = 0; q < NPT; ++q) {
-                    int pix = q * 16 + pl;
+                    int pix = (q0 + q) * 16 + pl;
                     pix = pix < ROWS * W ? pix : ROWS * W - 1;
                     const int tl = htile[j] < NHT ? htile[j] : NHT - 1;
                     const float* cr = (const float*)(smem + (size_t)G::CTX_OFF * 16) + (tl * 16 + 4 * kk) * G::CSTR + pix;
@@ -374,7 +390,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int q = 0; q < NPT; ++q) {
                 if (j == NTWH - 1 && !((EMASK >> q) & 1)) continue;
-                const int pix = q * 16 + pl;
+                const int pix = (q0 + q) * 16 + pl;
                 if (pix >= ROWS * W) continue;
                 const int row = pix / W, col = pix - row * W;
                 f32x4 v = acc[q][j] + bi;
@@ -395,13 +411,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // memory counter retires in order, so a request issued right in front of the output pair's K loop would stall that loop's
     // third step (the first to wait for a refill issued behind it) for a whole HBM round trip; here they have an epilogue
     // and a barrier to arrive
-    constexpr int NEL = (NZ * R * W + 255) / 256;
+    constexpr int NEL = (NZ * R * W + NT - 1) / NT;
     float fz[NEL], fq[NEL][6];
     float fb[NEL][2];
     auto load_final_operands = [&]() {
 #pragma unroll
         for (int e = 0; e < NEL; ++e) {
-            const int idx = tid + e * 256;
+            const int idx = tid + e * NT;
             const int ic = idx < NZ * R * W ? idx : NZ * R * W - 1;
             const int c = ic / (R * W), pix = ic - c * (R * W);
             const int rr = r0 + pix / W < H ? r0 + pix / W : H - 1;
@@ -424,10 +440,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     f32x4 wr1[UB][NTWH][3];          // hidden layer l uses ring l & 1 (wr0 / wr1): the other one receives layer l + 1's first steps
     f32x4 wro[UO][NTWO][3];          // ring of the output pair
     const f32x4* wbo = (const f32x4*)p.wp3[DEPTH] + lane;
+    // K steps of this wave in a phase the halves split by K (8-wave variant; all of them with four waves)
+    const int sh0 = (half * NSTEP_H) / HV, sh1 = ((half + 1) * NSTEP_H) / HV;
     auto preload_out = [&]() {
         static_for<RDO>([&](auto i) {
             ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWO * 3>{}, wro[decltype(i)::value], wbo, 2 * NZT,
-                      otile, NSTEP_H, decltype(i)::value);
+                      otile, sh1, sh0 + decltype(i)::value);
         });
     };
     // the weights of the phase after hidden layer l -- the next hidden layer's ring, or the output pair's -- start travelling
@@ -438,7 +456,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const f32x4* wbn = (const f32x4*)p.wp3[l + 1] + lane;
             static_for<RDH>([&](auto i) {
                 ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWH * 3>{},
-                          ((l + 1) & 1) ? wr1[decltype(i)::value] : wr0[decltype(i)::value], wbn, NHT, htile, NSTEP_H, decltype(i)::value);
+                          ((l + 1) & 1) ? wr1[decltype(i)::value] : wr0[decltype(i)::value], wbn, NHT, htile, sh1, sh0 + decltype(i)::value);
             });
         } else {
             preload_out();
@@ -448,19 +466,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     static_for<GN>([&](auto g_c) {
         constexpr int GI = decltype(g_c)::value;
         if (xg != GI) return;
-        constexpr int EM0 = (NX == 0 || !XSPLIT) ? (1 << NPT0) - 1 : fused_extra_mask(NPT0, GN, GI);
-        f32x4 acc0[NPT0][NTWH], bi0[NTWH];
+        // (8 waves: each half takes NPT0 / 2 pixel tiles of this layer, all K steps)
+        static_assert(NPT0 % HV == 0, "the halves split the first layer's pixel tiles evenly");
+        constexpr int NPT0W = NPT0 / HV;
+        constexpr int EM0 = (NX == 0 || !XSPLIT) ? (1 << NPT0W) - 1 : fused_extra_mask(NPT0W, GN, GI);
+        const int q00 = half * NPT0W;
+        f32x4 acc0[NPT0W][NTWH], bi0[NTWH];
         load_bias(p.bias[0], bi0);
-        conv_phase(std::integral_constant<int, RD0>{}, std::integral_constant<int, NPT0>{}, std::integral_constant<int, NTWH>{},
+        conv_phase(std::integral_constant<int, RD0>{}, std::integral_constant<int, NPT0W>{}, std::integral_constant<int, NTWH>{},
                    std::integral_constant<int, G::rows_h(0)>{}, std::integral_constant<int, EM0>{}, G::ZREG, Z16, Z8, wb0, NHT, htile, 0,
-                   (NZ / 32) * NTAPS, wr0, acc0);
+                   (NZ / 32) * NTAPS, wr0, acc0, q00);
         IAF_FSTAMP(6);
         store_ctx();
         if constexpr (DEPTH == 1) load_final_operands();
         preload_after(std::integral_constant<int, 0>{});
+        IAF_FSTAMP(10);
         __syncthreads();                                         // (every wave runs exactly one of the GN instantiations)
-        hidden_epilogue(std::integral_constant<int, NPT0>{}, std::integral_constant<int, G::rows_h(0)>{},
-                        std::integral_constant<int, EM0>{}, std::integral_constant<int, 1>{}, acc0, bi0, G::HREG0, p.hsave[0], p.border[0]);
+        IAF_FSTAMP(11);
+        hidden_epilogue(std::integral_constant<int, NPT0W>{}, std::integral_constant<int, G::rows_h(0)>{},
+                        std::integral_constant<int, EM0>{}, std::integral_constant<int, 1>{}, acc0, bi0, G::HREG0, p.hsave[0], p.border[0], q00);
     });
     __syncthreads();
     IAF_FSTAMP(2);
@@ -469,7 +493,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         constexpr int IN_REG = ((l - 1) & 1) ? G::HREG1 : G::HREG0, OUT_REG = (l & 1) ? G::HREG1 : G::HREG0;
         if constexpr (l == 1) {   // the staged context sat in the h_odd region: its zero columns again, before the epilogue fills the rest
             constexpr int H1ROWS = G::rows_h(1);
-            for (int i = tid; i < H1ROWS * 2 * H16; i += 256) {
+            for (int i = tid; i < H1ROWS * 2 * H16; i += NT) {
                 const int rs = i / H16, u = i - rs * H16;
                 smem4[G::HREG1 + ((rs >> 1) * RS + (rs & 1) * (W + 1)) * H16 + u] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
@@ -483,13 +507,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             load_bias(p.bias[l], bil);
             const f32x4* wbl = (const f32x4*)p.wp3[l] + lane;
             conv_phase(std::integral_constant<int, RDH>{}, std::integral_constant<int, NPTL>{}, std::integral_constant<int, NTWH>{},
-                       std::integral_constant<int, G::rows_h(l)>{}, std::integral_constant<int, EML>{}, IN_REG, H16, H8, wbl, NHT, htile, 0,
-                       NSTEP_H, (l & 1) ? wr1 : wr0, accl);
+                       std::integral_constant<int, G::rows_h(l)>{}, std::integral_constant<int, EML>{}, IN_REG, H16, H8, wbl, NHT, htile, sh0,
+                       sh1, (l & 1) ? wr1 : wr0, accl);
             if constexpr (l == 1) IAF_FSTAMP(7);
             if constexpr (l == DEPTH - 1) load_final_operands();
             preload_after(std::integral_constant<int, l>{});
-            hidden_epilogue(std::integral_constant<int, NPTL>{}, std::integral_constant<int, G::rows_h(l)>{},
-                            std::integral_constant<int, EML>{}, std::integral_constant<int, 0>{}, accl, bil, OUT_REG, p.hsave[l], p.border[l]);
+            if constexpr (HV == 2) {
+                // the halves split this layer's K steps: the second half's partial sums travel through the layer's INPUT
+                // region -- dead once every wave has left the K loop (first barrier) -- [wave][unit][lane] 16-byte rows
+                static_assert(DEPTH <= 2, "the hand-over scribbles over the input region's zero columns: a third hidden layer would read them");
+                static_assert((size_t)NW * NPTL * NTWH * 1024 <= (size_t)G::rows_h(l - 1) * RS * H16 * 16, "hand-over buffer fits the input region");
+                f32x4* xr = smem4 + IN_REG + (size_t)(wave * NPTL * NTWH) * 64 + lane;
+                __syncthreads();
+                if (half == 1) {
+#pragma unroll
+                    for (int q = 0; q < NPTL; ++q)
+#pragma unroll
+                        for (int j = 0; j < NTWH; ++j) xr[(q * NTWH + j) * 64] = accl[q][j];
+                }
+                __syncthreads();
+                if (half == 0) {
+#pragma unroll
+                    for (int q = 0; q < NPTL; ++q)
+#pragma unroll
+                        for (int j = 0; j < NTWH; ++j) accl[q][j] += xr[(q * NTWH + j) * 64];
+                }
+            }
+            if (half == 0)
+                hidden_epilogue(std::integral_constant<int, NPTL>{}, std::integral_constant<int, G::rows_h(l)>{},
+                                std::integral_constant<int, EML>{}, std::integral_constant<int, 0>{}, accl, bil, OUT_REG, p.hsave[l], p.border[l]);
+            if constexpr (l == 1) IAF_FSTAMP(12);
         });
         __syncthreads();
     });
@@ -502,9 +549,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         f32x4 acco[NPTO][NTWO];
         conv_phase(std::integral_constant<int, RDO>{}, std::integral_constant<int, NPTO>{}, std::integral_constant<int, NTWO>{},
                    std::integral_constant<int, R>{}, std::integral_constant<int, (1 << NPTO) - 1>{}, ((DEPTH - 1) & 1) ? G::HREG1 : G::HREG0,
-                   H16, H8, wbo, 2 * NZT, otile, 0, NSTEP_H, wro, acco);
+                   H16, H8, wbo, 2 * NZT, otile, sh0, sh1, wro, acco);
         IAF_FSTAMP(4);
-        float* mine = xbuf;
+        float* mine = xbuf + (size_t)half * (R * W * G::XB_STRIDE);
 #pragma unroll
         for (int j = 0; j < NTWO; ++j)
 #pragma unroll
@@ -516,6 +563,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
     }
     __syncthreads();
+    IAF_FSTAMP(13);
 
     // ---- affine transform, log-det term, KL elements (tf_train.py:56-75), NCHW stores coalesced along the rows -------
     float klv[NEL];              // (0 for rows past the image bottom and surplus lanes)
@@ -523,7 +571,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int e = 0; e < NEL; ++e) klv[e] = 0.f;
 #pragma unroll
     for (int e = 0; e < NEL; ++e) {
-        const int idx = tid + e * 256;
+        const int idx = tid + e * NT;
         if (idx >= NZ * R * W) continue;
         const int c = idx / (R * W), pix = idx - c * (R * W);
         const int row = pix / W;
@@ -539,8 +587,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             m_raw += w1 * bt[cm] + w2 * bt[2 * NZ + cm] + w3 * bt[4 * NZ + cm] + w4 * bt[6 * NZ + cm];
             s_raw += w1 * bt[cm + 16] + w2 * bt[2 * NZ + cm + 16] + w3 * bt[4 * NZ + cm + 16] + w4 * bt[6 * NZ + cm + 16];
         }
-        m_raw += xbuf[pix * G::XB_STRIDE + cm];
-        s_raw += xbuf[pix * G::XB_STRIDE + cm + 16];
+#pragma unroll
+        for (int k = 0; k < HV; ++k) {                          // (the halves' K parts)
+            m_raw += xbuf[k * (R * W * G::XB_STRIDE) + pix * G::XB_STRIDE + cm];
+            s_raw += xbuf[k * (R * W * G::XB_STRIDE) + pix * G::XB_STRIDE + cm + 16];
+        }
         if (p.mode == MODE_RAW) {
             p.out0[gi] = m_raw;
             p.out1[gi] = s_raw;
@@ -580,7 +631,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             float a = klv[e];
 #pragma unroll
             for (int o = RW / 2; o > 0; o >>= 1) a += __shfl_xor(a, o);
-            const int idx = tid + e * 256;
+            const int idx = tid + e * NT;
             if (idx < NZ * RW && (idx & (RW - 1)) == 0) p.kl_part[(size_t)blockIdx.x * NZ + idx / RW] = a;
         }
     }

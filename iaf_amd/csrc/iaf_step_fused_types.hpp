@@ -19,7 +19,7 @@ struct StepP {
     // nothing else changes; border[l] = [4][packed c_out of layer l] weights of the border-indicator channel (taps 1..4), added
     // where a tap leaves the image (Theano variants only)
     const float* border[5];
-    unsigned long long* dbg;   // dev tool: per-workgroup cycle stamps [grid][8]
+    unsigned long long* dbg;   // dev tool: per-workgroup cycle stamps [grid][16]
     // Posterior mode: per-channel sums of the workgroup's KL elements, [B * nrb][n_z] -- the first step of the block's
     // reductions (tf_train.py:77: sum over H, W) leaves the launch as 1/(R*W) of the bytes of the KL tensor, and kl_elem may
     // then be NULL (no [B, n_z, H, W] KL tensor is written or re-read).  The row blocks are summed in row order, the batch
@@ -31,9 +31,10 @@ struct StepP {
 typedef void (*step_fn_t)(StepP);
 // kernel + dynamic LDS bytes for (n_h / 16, n_z / 16, depth_ar, image width, output rows per workgroup), or NULL
 // var: 0 TF statement, 1 Theano, 2 Theano with flipmask
-extern "C" step_fn_t iaf_pick_step_fused_a(int nht, int nzt, int depth, int W, int R, int var, size_t* lds);   // depth_ar <= 2 geometries
-extern "C" step_fn_t iaf_pick_step_fused_b(int nht, int nzt, int depth, int W, int R, int var, size_t* lds);   // depth_ar = 4 geometries
-static inline step_fn_t iaf_pick_step_fused(int nht, int nzt, int depth, int W, int R, int var, size_t* lds) {
-    step_fn_t f = iaf_pick_step_fused_a(nht, nzt, depth, W, R, var, lds);
-    return f ? f : iaf_pick_step_fused_b(nht, nzt, depth, W, R, var, lds);
+// wv: waves per workgroup, 4 or 8 (launch with 64 * wv threads); 8 is compiled for the geometries of the README run only
+extern "C" step_fn_t iaf_pick_step_fused_a(int nht, int nzt, int depth, int W, int R, int var, int wv, size_t* lds);   // depth_ar <= 2 geometries
+extern "C" step_fn_t iaf_pick_step_fused_b(int nht, int nzt, int depth, int W, int R, int var, int wv, size_t* lds);   // depth_ar = 4 geometries
+static inline step_fn_t iaf_pick_step_fused(int nht, int nzt, int depth, int W, int R, int var, int wv, size_t* lds) {
+    step_fn_t f = iaf_pick_step_fused_a(nht, nzt, depth, W, R, var, wv, lds);
+    return f ? f : iaf_pick_step_fused_b(nht, nzt, depth, W, R, var, wv, lds);
 }

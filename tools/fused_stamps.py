@@ -26,11 +26,11 @@ for _ in range(a.reps):
     st.iaf_step(z, ctx, out=out)
 e1.record(); torch.cuda.synchronize()
 print("iaf_step %dx%d B=%d: %.2f us per call (back to back, eager)" % (a.hw, a.hw, a.batch, e0.elapsed_time(e1) / a.reps * 1e3))
-buf = torch.zeros(8 * 65536, dtype=torch.int64, device="cuda")
+buf = torch.zeros(16 * 65536, dtype=torch.int64, device="cuda")
 _capi.check(_capi.lib().iaf_stack_set_debug(st._h, -2, ctypes.c_void_p(buf.data_ptr())))
 st.iaf_step(z, ctx, out=out); torch.cuda.synchronize()
 _capi.check(_capi.lib().iaf_stack_set_debug(st._h, -1, None))
-t = buf.cpu().numpy().reshape(-1, 8); t = t[t[:, 0] != 0]
+t = buf.cpu().numpy().reshape(-1, 16); t = t[t[:, 0] != 0]
 if len(t) == 0:
     print("the step did not run as one launch at this size"); sys.exit(0)
 names = ["start -> z staged (barrier)", "first conv + epilogue", "second conv + epilogue", "output conv", "exchange + affine + stores"]
@@ -39,6 +39,14 @@ print("%d WGs; kernel span %.0f ticks; per-WG total median %.0f; first start->la
       (len(t), t[:, 5].max() - t[:, 0].min(), np.median(t[:, 5] - t[:, 0]), t[:, 0].max() - t[:, 0].min()))
 for i, n in enumerate(names):
     print("    %-32s median %8.0f   max %8.0f ticks" % (n, np.median(d[:, i]), d[:, i].max()))
+if (t[:, 8] != 0).all():      # finer stamps (wave 0): prologue and the two epilogues
+    m = lambda a, b_: np.median(t[:, a] - t[:, b_])
+    print("    prologue: loads issued %.0f | zero fill + z arrives + z -> LDS %.0f | barrier %.0f" % (m(8, 0), m(9, 8), m(1, 9)))
+    print("    first epilogue: context -> LDS + next weights requested %.0f | barrier %.0f | bias+ctx+ELU+split -> LDS %.0f (incl. end barrier)" % (
+        m(10, 6), m(11, 10), m(2, 11)))
+    if (t[:, 12] != 0).all():
+        print("    second epilogue: %.0f + barrier %.0f; output pair: K loop %.0f, to the exchange buffer + barrier %.0f, transform + stores %.0f" % (
+            m(12, 7), m(3, 12), m(4, 3), m(13, 4), m(5, 13)))
 if (t[:, 6] != 0).all():
     print("    of which: first conv K loop %.0f, its epilogue + barrier %.0f; second conv K loop %.0f, its epilogue + barrier %.0f (wave 0)" % (
         np.median(t[:, 6] - t[:, 1]), np.median(t[:, 2] - t[:, 6]), np.median(t[:, 7] - t[:, 2]), np.median(t[:, 3] - t[:, 7])))
