@@ -51,9 +51,6 @@
 #define IAF_ABI_VERSION 3   // 2: + iaf_conv3x3_*; 3: bf16x3 default precision, THEANO_FLIPMASK, negative nt in autotune reports,
                           //    iaf_stack_set_packs, iaf_comm_* (include/iaf_hip.h)
 #define MAX_GEMM_LAYERS 10   // depth_ar <= 9 hidden + 1 output pair
-#ifndef IAF_FUSED_DEFAULT_WV
-#define IAF_FUSED_DEFAULT_WV 4   // waves per workgroup of the one-launch step where both variants are compiled (iaf_step_fused.hpp)
-#endif
 
 #include "iaf_step_fused_types.hpp"
 #include "iaf_kernels_prep.hpp"
@@ -926,9 +923,6 @@ static int run_stack_generic(iaf_stack_t* s, const ConvP& base, int first_inmode
 // everything else takes the layer-by-layer path.  All three statements of the operator (the Theano one runs on the image
 // rotated by 180 degrees, where its taps are the TF ones).  Output rows per workgroup: 2 at 16 pixels per row; at 8,
 // one row while that still leaves fewer than two workgroups per CU (less halo recompute per row otherwise).
-// waves per workgroup of the kernel fused_step_plan() returned last on this thread (every launch_fused_step follows its own
-// fused_step_plan call): 4, or 8 where the two-waves-per-SIMD variant is compiled and selected
-static thread_local int g_plan_wv = 4;
 static step_fn_t fused_step_plan(const iaf_stack_t* s, int B, int H, int W, int* R, size_t* lds) {
     static const int env = getenv("IAF_FUSE_STEP") ? atoi(getenv("IAF_FUSE_STEP")) : -1;       // dev knob: 0 / 1
     const int mode = env >= 0 ? env : s->fuse_step;
@@ -956,16 +950,7 @@ static step_fn_t fused_step_plan(const iaf_stack_t* s, int B, int H, int W, int*
         }
     }
     const int var = s->variant == IAF_VARIANT_TF ? 0 : s->variant == IAF_VARIANT_THEANO ? 1 : 2;
-    // two waves per SIMD (iaf_step_fused.hpp, WV = 8) where compiled; IAF_FUSE_STEP_WV=4 / 8: dev knob
-    static const int env_wv = getenv("IAF_FUSE_STEP_WV") ? atoi(getenv("IAF_FUSE_STEP_WV")) : 0;
-    const int want_wv = env_wv ? env_wv : IAF_FUSED_DEFAULT_WV;
-    g_plan_wv = 4;
-    step_fn_t fn = nullptr;
-    if (want_wv == 8) {
-        fn = iaf_pick_step_fused(s->n_h / 16, s->n_z / 16, s->depth_ar, W, *R, var, 8, lds);
-        if (fn && *lds <= 160 * 1024) g_plan_wv = 8; else fn = nullptr;
-    }
-    if (!fn) fn = iaf_pick_step_fused(s->n_h / 16, s->n_z / 16, s->depth_ar, W, *R, var, 4, lds);
+    step_fn_t fn = iaf_pick_step_fused(s->n_h / 16, s->n_z / 16, s->depth_ar, W, *R, var, lds);
     if (!fn || *lds > 160 * 1024) return nullptr;
     return fn;
 }
@@ -991,7 +976,7 @@ static int launch_fused_step(iaf_stack_t* s, step_fn_t fn, int R, size_t lds, co
     { int rc = raise_lds_cap((const void*)fn, lds); if (rc) return rc; }
     const bool prof = (s->prof_layer == -2 && s->prof_n < s->prof_cap);
     if (prof) HIP_TRY(hipEventRecord(s->prof_start[s->prof_n], st));
-    hipLaunchKernelGGL(fn, dim3(base.B * q.nrb), dim3(64 * g_plan_wv), lds, st, q);
+    hipLaunchKernelGGL(fn, dim3(base.B * q.nrb), dim3(256), lds, st, q);
     if (prof) { HIP_TRY(hipEventRecord(s->prof_stop[s->prof_n], st)); s->prof_n++; }
     return (int)hipGetLastError();
 }

@@ -16,6 +16,12 @@
 // v_mfma_f32_16x16x32_bf16, reading the same fragment-ordered weight packs (PrepLayer.wp3).
 // LDS: three regions (z, h_even, h_odd) of pixel slots [row][W + 2 columns][plane h/m/l][channels] -- the two extra
 // columns and the rows past the image bottom hold zeros, so tap addressing is pure arithmetic (no validity masks).
+// Two waves per SIMD do not help: round 3 built an 8-wave variant (first layer split by pixel tiles, later layers and the
+// output pair by K steps, partial sums handed over through the dead input region; bit-compatible, 233 GPU tests green) and
+// measured 29.1 vs 27.4 us at 16-pixel rows, 18.1 vs 16.0 at 8 (same box, alternating runs).  Its stamps show why: the older
+// wave of a SIMD runs its half of a K loop at the single-wave rate (18.7 ticks per MFMA = 16 shader cycles at the ~1.75 GHz the
+// chip sustains under this load: ONE wave already saturates the matrix pipe) and the younger wave runs its half AFTER it, so
+// the K loops take what they took, and issuing the prologue's loads, the barriers and the hand-over cost more.  Removed.
 // Work split: 4 waves, one per SIMD.  Hidden layers: wave w owns co tiles w, w+4, ... of every pixel tile (its weight
 // stream is disjoint from the other waves'; the activation fragments come from LDS); the tiles left over when the count is
 // not a multiple of 4 (n_h = 160: tiles 8, 9) are dealt out per (tile, pixel tile) so that every wave multiplies the
@@ -42,8 +48,8 @@ struct StepGeom {
     static constexpr int HREG0 = ZREG + RZ * RS * Z16;
     static constexpr int HREG1 = HREG0 + rows_h(0) * RS * H16;
     static constexpr int END = HREG1 + (DEPTH >= 2 ? rows_h(1) * RS * H16 : 0);
-    static constexpr int XB_STRIDE = 2 * NZ + 1;                                 // output exchange buffer [K part][pixel][2 n_z] floats
-    static constexpr size_t xb_bytes() { return (size_t)2 * R * W * XB_STRIDE * 4; }       // (two K parts: the 8-wave variant)
+    static constexpr int XB_STRIDE = 2 * NZ + 1;                                 // output exchange buffer [pixel][2 n_z] floats
+    static constexpr size_t xb_bytes() { return (size_t)R * W * XB_STRIDE * 4; }
     // (the last hidden layer sits in the h_odd region for an even depth: z + h_even are dead then; for an odd depth it sits in
     // h_even: the buffer goes into h_odd if it fits there, else behind everything)
     static constexpr int XB_OFF = (DEPTH % 2 == 0) ? 0 : (DEPTH >= 3 && xb_bytes() <= (size_t)(END - HREG1) * 16) ? HREG1 : END;
@@ -79,20 +85,9 @@ constexpr int fused_acc_groups(int tiles_per_pixel_tile) { return tiles_per_pixe
 // VAR: the statement of the operator -- 0 TF, 1 Theano (image rotated by 180 degrees + border channel), 2 Theano with
 // flipmask=True (TF geometry + border channel).  Compile time: as run-time flags these cost the TF path ~1 us per launch
 // (branches around the border loads split the epilogue's basic blocks).
-// WV: waves per workgroup.  4: one wave per SIMD.  8: two per SIMD -- a second wave's MFMAs fill the issue bubbles of the first
-// (one wave alone issues a 16x16x32 MFMA every ~19 cycles, the pipe takes one every 16) and its memory / LDS latencies overlap
-// the other's arithmetic.  The two halves (waves 0-3, 4-7) keep the 4-wave tile ownership and split
-//   - the FIRST hidden layer by pixel tiles (its K is only n_z: too short to split; its small weight set is then streamed
-//     by both halves), every wave finishing its own units;
-//   - every other hidden layer by K steps, the second half's partial sums handed over through the layer's INPUT region once
-//     every wave has left the K loop (the region is dead by then), the first half running the epilogue;
-//   - the output pair by K steps as well, both partial sums meeting in the exchange buffer.
-// Weight and LDS operand traffic per workgroup stay what they are with 4 waves (+ the first layer's pack once more).
-template <int NHT, int NZT, int DEPTH, int W, int R, int VAR = 0, int WV = 4>
-__global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(WV / 4, WV / 4))) void iaf_step_fused_kernel(StepP p) {
+template <int NHT, int NZT, int DEPTH, int W, int R, int VAR = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void iaf_step_fused_kernel(StepP p) {
     typedef StepGeom<NHT, NZT, DEPTH, W, R> G;
-    static_assert(WV == 4 || WV == 8, "one or two waves per SIMD");
-    constexpr int NT = 64 * WV, HV = WV / 4;                     // threads; halves
     constexpr bool FLIP = (VAR == 1), BORDER = (VAR != 0);
     static_assert(DEPTH >= 1 && DEPTH <= 4, "hidden layers ping-pong between two LDS regions (h_even, h_odd)");
     static_assert((W & (W - 1)) == 0 && W <= 16, "full-width rows of 4, 8 or 16 pixels");
@@ -101,15 +96,21 @@ __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(WV / 4,
     constexpr int NZ = G::NZ, NH = G::NH, RS = G::RS, Z8 = G::Z8, Z16 = G::Z16, H8 = G::H8, H16 = G::H16, RZ = G::RZ;
     constexpr int NW = 4;                                        // waves
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave = wave8 & (NW - 1);                           // tile ownership: as with four waves
-    const int half = wave8 / NW;                                 // 0 / 1 (always 0 with four waves)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pl = lane & 15, kk = lane >> 4;
     const int b = blockIdx.x / p.nrb, r0 = (blockIdx.x - b * p.nrb) * R;
     const int H = p.H, HW = p.HW;
     // pixel offset inside the image of position (image row ir, column col) of the space the kernel computes in
     // ((H-1-ir) W + (W-1-col) = HW-1 - (ir W + col))
-    auto gpix = [&](int ir, int col) -> size_t { return FLIP ? (size_t)(HW - 1 - (ir * W + col)) : (size_t)(ir * W + col); };
+    auto gpix = [&](int ir, int col) -> int { return FLIP ? (HW - 1 - (ir * W + col)) : (ir * W + col); };
+    // Global addresses = a UNIFORM base (this workgroup's image: 64-bit scalar arithmetic, once) + a 32-bit per-lane BYTE offset
+    // inside the image: the loads / stores then take the SGPR-base + VGPR-offset form.  Written with size_t element indices
+    // the same accesses cost two to four 64-bit VALU instructions each -- round 3's stamps: 4.4 k cycles to ISSUE the
+    // prologue's ~50 loads per wave, 130 v_lshl_add_u64 among ~800 prologue instructions.
+    auto ldf = [](const float* base, unsigned boff) -> float { return *(const float*)((const char*)base + boff); };
+    auto ldf4 = [](const float* base, unsigned boff) -> f32x4 { return *(const f32x4*)((const char*)base + boff); };
+    auto stf = [](float* base, unsigned boff, float v) { *(float*)((char*)base + boff) = v; };
+    const size_t img_z = (size_t)b * NZ * HW, img_h = (size_t)b * NH * HW;      // element offsets of image b (z-shaped / context-shaped tensors)
     // sum of the border-indicator weights of the taps that leave the image at (ir, col): taps (0,1) (1,-1) (1,0) (1,1)
     auto border_terms = [&](const float* bt, int cstride, int ch, int ir, int col) -> f32x4 {
         f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -144,6 +145,9 @@ __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(WV / 4,
     constexpr int UB = RDH + 1;                                      // ring array B (layers 1, 3)
     constexpr int UO = RDO + 1;
     // fragments [LO, HI) of step s (steps past s_end reload its last step; tiles past the layer's are clamped)
+    // (wbase: the layer's pack, UNIFORM; step, tile and plane are wave-uniform too: the whole fragment address is scalar
+    // arithmetic, the lane contributes its 16-byte slot as the load's 32-bit offset)
+    const unsigned lane16 = 16u * (unsigned)lane;
     auto ring_load = [&](auto lo_c, auto hi_c, f32x4 (*dst)[3], const f32x4* wbase, int ncot, const int* tiles, int s_end, int s) {
         constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
         const int sc = s < s_end ? s : s_end - 1;
@@ -152,36 +156,37 @@ __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(WV / 4,
         for (int f = LO; f < HI; ++f) {
             const int j = f / 3, pn = f - 3 * j;
             const int tc = tiles[j] < ncot ? tiles[j] : ncot - 1;
-            dst[j][pn] = q[((size_t)tc * 3 + pn) * 64];
+            dst[j][pn] = *(const f32x4*)((const char*)(q + ((size_t)tc * 3 + pn) * 64) + lane16);
         }
     };
 
     // ---- prologue: z rows first (the first conv cannot start without them), then the first weight steps; zero columns
     // while both travel; z -> LDS ---------------------------------------------------------------------------------------
-    constexpr int NPX = RZ * W, NIT = NPX * (NZ / 4), ZU = (NIT + NT - 1) / NT;
+    constexpr int NPX = RZ * W, NIT = NPX * (NZ / 4), ZU = (NIT + 255) / 256;
     f32x4 zv[ZU], zq[4][ZU];     // posterior input: the five tensors as raw loads, combined once all of them are on their way
 #pragma unroll
     for (int u = 0; u < ZU; ++u) {
-        const int idx = tid + u * NT;
+        const int idx = tid + u * 256;
         const int ic = idx < NIT ? idx : NIT - 1;
         const int q = ic / NPX, px = ic - q * NPX;                 // pixel fastest: coalesced along a row
         const int row = px / W, col = px - row * W;
         const int rr = r0 + row < H ? r0 + row : H - 1;            // rows past the image: a valid address, zeroed below
-        const size_t gb = ((size_t)b * NZ + 4 * q) * HW + gpix(rr, col);
+        const unsigned gb = 4u * (unsigned)(4 * q * HW + gpix(rr, col));        // byte offset inside image b
         if (p.z) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) zv[u][r] = p.z[gb + (size_t)r * HW];
+            for (int r = 0; r < 4; ++r) zv[u][r] = ldf(p.z + img_z, gb + 4u * (unsigned)(r * HW));
         } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const size_t i = gb + (size_t)r * HW;
-                zv[u][r] = p.qm[i]; zq[0][u][r] = p.rm[i]; zq[1][u][r] = p.ql[i]; zq[2][u][r] = p.rl[i]; zq[3][u][r] = p.eps[i];
+                const unsigned i = gb + 4u * (unsigned)(r * HW);
+                zv[u][r] = ldf(p.qm + img_z, i); zq[0][u][r] = ldf(p.rm + img_z, i); zq[1][u][r] = ldf(p.ql + img_z, i);
+                zq[2][u][r] = ldf(p.rl + img_z, i); zq[3][u][r] = ldf(p.eps + img_z, i);
             }
         }
     }
     __builtin_amdgcn_sched_barrier(0);
     f32x4 wr0[UA][NTWH][3];
-    const f32x4* wb0 = (const f32x4*)p.wp3[0] + lane;
+    const f32x4* wb0 = (const f32x4*)p.wp3[0];
     static_for<RD0>([&](auto i) {
         ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWH * 3>{}, wr0[decltype(i)::value], wb0, NHT, htile,
                   (NZ / 32) * NTAPS, decltype(i)::value);
@@ -189,7 +194,7 @@ __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(WV / 4,
     __builtin_amdgcn_sched_barrier(0);
     // context rows of this workgroup: per channel one contiguous run of CPX pixels (full-width rows) -> 16-byte loads,
     // 4 channels per wave instruction; summed with the second context here
-    constexpr int CPX = G::CPX, CSTR = G::CSTR, CG = CPX / 4, NCIT = NH * CG, NCI = (NCIT + NT - 1) / NT;
+    constexpr int CPX = G::CPX, CSTR = G::CSTR, CG = CPX / 4, NCIT = NH * CG, NCI = (NCIT + 255) / 256;
     f32x4 cv[NCI], cv2[NCI];     // raw loads: nothing consumes them before the z rows are in LDS.  UNCONDITIONAL loads from
     unsigned cvalid = 0;         // clamped addresses: `x = 0; if (inside) x = load` is a select on the loaded value, i.e. a
     {                            // vmcnt(0) behind every load -- ten serial HBM round trips in this prologue (found in the
@@ -197,42 +202,55 @@ __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(WV / 4,
                                  // when the values are used (store_ctx), from the bit mask.  (The host never launches this
                                  // kernel without a context: depth_ar >= 1.)
         const int vpx = (H - r0) * W < CPX ? (H - r0) * W : CPX;       // pixels of those rows that lie inside the image
-#pragma unroll
-        for (int u = 0; u < NCI; ++u) {
-            const int idx = tid + u * NT;
+        // item idx = tid + 256 u -> (channel c = idx / CG, pixel group g4).  Where 256 is a multiple of CG and the items
+        // fill the rounds exactly (16-pixel rows), every round reads the SAME pixel group of a channel 256 / CG further on:
+        // one address computation, then a constant stride per round (the general form costs ~22 VALU instructions per load)
+        constexpr bool REG = (256 % CG == 0) && (NCIT % 256 == 0);
+        unsigned gi0 = 0, gstep = 0;
+        bool in0 = true;
+        if constexpr (REG) {
+            const int c = tid / CG, g4 = (tid - c * CG) * 4;
+            in0 = g4 < vpx;
+            const int g4c = in0 ? g4 : 0;
+            const int row = g4c / W, col4 = g4c - row * W;
+            gi0 = 4u * (unsigned)(c * HW + gpix(r0 + row, col4 + (FLIP ? 3 : 0)));
+            gstep = 4u * (unsigned)((256 / CG) * HW);
+        }
+        auto ctx_off = [&](int u, bool& inside) -> unsigned {
+            if constexpr (REG) { inside = in0; return gi0 + (unsigned)u * gstep; }
+            const int idx = tid + u * 256;
             const int ic = idx < NCIT ? idx : NCIT - 1;
             const int c = ic / CG, g4 = (ic - c * CG) * 4;
-            const int g4c = g4 < vpx ? g4 : 0;                         // a valid address either way
+            inside = g4 < vpx;
+            const int g4c = inside ? g4 : 0;                           // a valid address either way
             const int row = g4c / W, col4 = g4c - row * W;             // 4 consecutive columns of one row
-            const size_t gi = ((size_t)b * NH + c) * HW + gpix(r0 + row, col4 + (FLIP ? 3 : 0));
-            cv[u] = *(const f32x4*)(p.ctx + gi);           // (column order fixed up at store time)
-            cvalid |= (g4 < vpx ? 1u : 0u) << u;
+            return 4u * (unsigned)(c * HW + gpix(r0 + row, col4 + (FLIP ? 3 : 0)));
+        };
+#pragma unroll
+        for (int u = 0; u < NCI; ++u) {
+            bool inside;
+            const unsigned gi = ctx_off(u, inside);
+            cv[u] = ldf4(p.ctx + img_h, gi);               // (column order fixed up at store time)
+            cvalid |= (inside ? 1u : 0u) << u;
         }
         if (p.ctx2) {                                      // (uniform branch: no select on loaded values)
 #pragma unroll
             for (int u = 0; u < NCI; ++u) {
-                const int idx = tid + u * NT;
-                const int ic = idx < NCIT ? idx : NCIT - 1;
-                const int c = ic / CG, g4 = (ic - c * CG) * 4;
-                const int g4c = g4 < vpx ? g4 : 0;
-                const int row = g4c / W, col4 = g4c - row * W;
-                const size_t gi = ((size_t)b * NH + c) * HW + gpix(r0 + row, col4 + (FLIP ? 3 : 0));
-                cv2[u] = *(const f32x4*)(p.ctx2 + gi);
+                bool inside;
+                const unsigned gi = ctx_off(u, inside);
+                cv2[u] = ldf4(p.ctx2 + img_h, gi);
             }
-        } else {
-#pragma unroll
-            for (int u = 0; u < NCI; ++u) cv2[u] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
     __builtin_amdgcn_sched_barrier(0);
     IAF_FSTAMP(8);
     {
         constexpr int ZROWS = RZ, H0ROWS = G::rows_h(0), H1ROWS = 0;      // (h_1's zero columns: after the first layer)
-        for (int i = tid; i < ZROWS * 2 * Z16; i += NT) {
+        for (int i = tid; i < ZROWS * 2 * Z16; i += 256) {
             const int rs = i / Z16, u = i - rs * Z16;
             smem4[G::ZREG + ((rs >> 1) * RS + (rs & 1) * (W + 1)) * Z16 + u] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        for (int i = tid; i < (H0ROWS + H1ROWS) * 2 * H16; i += NT) {
+        for (int i = tid; i < (H0ROWS + H1ROWS) * 2 * H16; i += 256) {
             const int rs = i / H16, u = i - rs * H16;
             const int row = rs >> 1;
             const int base = row < H0ROWS ? G::HREG0 + row * RS * H16 : G::HREG1 + (row - H0ROWS) * RS * H16;
@@ -240,7 +258,7 @@ __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(WV / 4,
         }
 #pragma unroll
         for (int u = 0; u < ZU; ++u) {
-            const int idx = tid + u * NT;
+            const int idx = tid + u * 256;
             if (idx < NIT) {
                 const int q = idx / NPX, px = idx - q * NPX;
                 const int row = px / W, col = px - row * W;
@@ -263,11 +281,12 @@ __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(WV / 4,
         float* creg = (float*)(smem + (size_t)G::CTX_OFF * 16);
 #pragma unroll
         for (int u = 0; u < NCI; ++u) {
-            const int idx = tid + u * NT;
-            if (idx < NCIT) {
+            const int idx = tid + u * 256;
+            if (NCIT % 256 == 0 || idx < NCIT) {
                 const int c = idx / CG, g4 = (idx - c * CG) * 4;
                 constexpr bool fl = FLIP;                        // rotated image: the 4 columns arrived in reverse order
-                f32x4 v = cv[u] + cv2[u];                        // up_context + down_context (tf_train.py:58)
+                f32x4 v = cv[u];
+                if (p.ctx2) v += cv2[u];                         // up_context + down_context (tf_train.py:58)
                 if (!((cvalid >> u) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};      // rows past the image bottom
                 *(f32x4*)(creg + c * CSTR + g4) = f32x4{fl ? v[3] : v[0], fl ? v[2] : v[1], fl ? v[1] : v[2], fl ? v[0] : v[3]};
             }
@@ -277,10 +296,9 @@ __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(WV / 4,
     // ---- one conv phase: acc[q][j] = sum over steps [s0, nstep) of W[step][tiles[j]] x X[pixel tile q, step] --------------
     // in_reg / in_s16 / in_c8: the input region (16-byte units); ROWS * W output pixels in NPT tiles.  The LAST tile slot is
     // multiplied only for the pixel tiles in EMASK (the wave's share of a left-over tile); all others for every pixel tile.
-    // q0: first pixel tile of this wave (the halves of the 8-wave variant split the first layer's pixel tiles).
     auto conv_phase = [&](auto rd_c, auto npt_c, auto ntw_c, auto rows_c, auto emask_c, int in_reg, int in_s16, int in_c8, const f32x4* wbase,
                           int ncot, const int* tiles, int s0, int nstep, f32x4 (*wr)[decltype(ntw_c)::value][3],
-                          f32x4 (*acc_out)[decltype(ntw_c)::value], int q0 = 0) {
+                          f32x4 (*acc_out)[decltype(ntw_c)::value]) {
         constexpr int NPT = decltype(npt_c)::value, NTW = decltype(ntw_c)::value, ROWS = decltype(rows_c)::value;
         constexpr int EMASK = decltype(emask_c)::value;
         constexpr int RD = decltype(rd_c)::value, U = RD + 1;      // this phase's look-ahead; it uses slots 0 .. RD of its ring array
@@ -289,7 +307,7 @@ __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(WV / 4,
         int xb[NPT];
 #pragma unroll
         for (int q = 0; q < NPT; ++q) {
-            int pix = (q0 + q) * 16 + pl;
+            int pix = q * 16 + pl;
             pix = pix < ROWS * W ? pix : ROWS * W - 1;             // partially filled tile: a valid address, result unused
             const int row = pix / W, col = pix - row * W;
             xb[q] = in_reg + (row * RS + col + 1) * in_s16 + kk;
@@ -366,7 +384,7 @@ __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(WV / 4,
         for (int j = 0; j < NTWH; ++j) bi[j] = *(const f32x4*)(bias + (htile[j] < NHT ? htile[j] : NHT - 1) * 16 + 4 * kk);
     };
     auto hidden_epilogue = [&](auto npt_c, auto rows_c, auto emask_c, auto ctx_c, f32x4 (*acc)[NTWH], const f32x4* bias, int out_reg,
-                               float* hsave, const float* bt, int q0 = 0) {
+                               float* hsave, const float* bt) {
         constexpr int NPT = decltype(npt_c)::value, ROWS = decltype(rows_c)::value, EMASK = decltype(emask_c)::value;
         constexpr bool WITH_CTX = decltype(ctx_c)::value != 0;
         f32x4 cxv[WITH_CTX ? NPT : 1][NTWH];                     // all context reads in flight together, ahead of the arithmetic
@@ -375,7 +393,7 @@ __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(WV / 4,
             for (int j = 0; j < NTWH; ++j)
 #pragma unroll
                 for (int q = 0; q < NPT; ++q) {
-                    int pix = (q0 + q) * 16 + pl;
+                    int pix = q * 16 + pl;
                     pix = pix < ROWS * W ? pix : ROWS * W - 1;
                     const int tl = htile[j] < NHT ? htile[j] : NHT - 1;
                     const float* cr = (const float*)(smem + (size_t)G::CTX_OFF * 16) + (tl * 16 + 4 * kk) * G::CSTR + pix;
@@ -390,7 +408,7 @@ __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(WV / 4,
 #pragma unroll
             for (int q = 0; q < NPT; ++q) {
                 if (j == NTWH - 1 && !((EMASK >> q) & 1)) continue;
-                const int pix = (q0 + q) * 16 + pl;
+                const int pix = q * 16 + pl;
                 if (pix >= ROWS * W) continue;
                 const int row = pix / W, col = pix - row * W;
                 f32x4 v = acc[q][j] + bi;
@@ -402,7 +420,7 @@ __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(WV / 4,
                 bf3_store4(smem + (size_t)out_reg * 16, row * RS + col + 1, htile[j] * 4 + kk, v, H16, H8);
                 // training: the rows this workgroup OWNS (not its halo) go to HBM for the backward pass
                 if (hsave && row < R && r0 + row < H)
-                    *(f32x4*)(hsave + ((size_t)b * HW + gpix(r0 + row, col)) * NH + htile[j] * 16 + 4 * kk) = v;
+                    *(f32x4*)(hsave + ((size_t)b * HW + (size_t)gpix(r0 + row, col)) * NH + htile[j] * 16 + 4 * kk) = v;
             }
         }
     };
@@ -411,24 +429,24 @@ __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(WV / 4,
     // memory counter retires in order, so a request issued right in front of the output pair's K loop would stall that loop's
     // third step (the first to wait for a refill issued behind it) for a whole HBM round trip; here they have an epilogue
     // and a barrier to arrive
-    constexpr int NEL = (NZ * R * W + NT - 1) / NT;
+    constexpr int NEL = (NZ * R * W + 255) / 256;
     float fz[NEL], fq[NEL][6];
     float fb[NEL][2];
     auto load_final_operands = [&]() {
 #pragma unroll
         for (int e = 0; e < NEL; ++e) {
-            const int idx = tid + e * NT;
+            const int idx = tid + e * 256;
             const int ic = idx < NZ * R * W ? idx : NZ * R * W - 1;
             const int c = ic / (R * W), pix = ic - c * (R * W);
             const int rr = r0 + pix / W < H ? r0 + pix / W : H - 1;
-            const size_t gi = ((size_t)b * NZ + c) * HW + gpix(rr, pix & (W - 1));
+            const unsigned gi = 4u * (unsigned)(c * HW + gpix(rr, pix & (W - 1)));
             const int cm = (c >> 4) * 32 + (c & 15);
             fb[e][0] = p.bias[DEPTH][cm]; fb[e][1] = p.bias[DEPTH][cm + 16];
             fz[e] = 0.f;
-            if (p.mode == MODE_IAF || p.mode == MODE_INVERSE) fz[e] = p.zin[gi];
+            if (p.mode == MODE_IAF || p.mode == MODE_INVERSE) fz[e] = ldf(p.zin + img_z, gi);
             if (p.mode == MODE_POSTERIOR) {
-                fq[e][0] = p.qm[gi] + p.rm[gi]; fq[e][1] = p.ql[gi] + p.rl[gi]; fq[e][2] = p.eps[gi];
-                fq[e][3] = p.pm[gi]; fq[e][4] = p.pl[gi];
+                fq[e][0] = ldf(p.qm + img_z, gi) + ldf(p.rm + img_z, gi); fq[e][1] = ldf(p.ql + img_z, gi) + ldf(p.rl + img_z, gi);
+                fq[e][2] = ldf(p.eps + img_z, gi); fq[e][3] = ldf(p.pm + img_z, gi); fq[e][4] = ldf(p.pl + img_z, gi);
             }
         }
     };
@@ -439,13 +457,11 @@ __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(WV / 4,
     for (int j = 0; j < NTWO; ++j) otile[j] = wave * NTWO + j;
     f32x4 wr1[UB][NTWH][3];          // hidden layer l uses ring l & 1 (wr0 / wr1): the other one receives layer l + 1's first steps
     f32x4 wro[UO][NTWO][3];          // ring of the output pair
-    const f32x4* wbo = (const f32x4*)p.wp3[DEPTH] + lane;
-    // K steps of this wave in a phase the halves split by K (8-wave variant; all of them with four waves)
-    const int sh0 = (half * NSTEP_H) / HV, sh1 = ((half + 1) * NSTEP_H) / HV;
+    const f32x4* wbo = (const f32x4*)p.wp3[DEPTH];
     auto preload_out = [&]() {
         static_for<RDO>([&](auto i) {
             ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWO * 3>{}, wro[decltype(i)::value], wbo, 2 * NZT,
-                      otile, sh1, sh0 + decltype(i)::value);
+                      otile, NSTEP_H, decltype(i)::value);
         });
     };
     // the weights of the phase after hidden layer l -- the next hidden layer's ring, or the output pair's -- start travelling
@@ -453,10 +469,10 @@ __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(WV / 4,
     auto preload_after = [&](auto l_c) {
         constexpr int l = decltype(l_c)::value;
         if constexpr (l + 1 < DEPTH) {
-            const f32x4* wbn = (const f32x4*)p.wp3[l + 1] + lane;
+            const f32x4* wbn = (const f32x4*)p.wp3[l + 1];
             static_for<RDH>([&](auto i) {
                 ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWH * 3>{},
-                          ((l + 1) & 1) ? wr1[decltype(i)::value] : wr0[decltype(i)::value], wbn, NHT, htile, sh1, sh0 + decltype(i)::value);
+                          ((l + 1) & 1) ? wr1[decltype(i)::value] : wr0[decltype(i)::value], wbn, NHT, htile, NSTEP_H, decltype(i)::value);
             });
         } else {
             preload_out();
@@ -466,16 +482,12 @@ __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(WV / 4,
     static_for<GN>([&](auto g_c) {
         constexpr int GI = decltype(g_c)::value;
         if (xg != GI) return;
-        // (8 waves: each half takes NPT0 / 2 pixel tiles of this layer, all K steps)
-        static_assert(NPT0 % HV == 0, "the halves split the first layer's pixel tiles evenly");
-        constexpr int NPT0W = NPT0 / HV;
-        constexpr int EM0 = (NX == 0 || !XSPLIT) ? (1 << NPT0W) - 1 : fused_extra_mask(NPT0W, GN, GI);
-        const int q00 = half * NPT0W;
-        f32x4 acc0[NPT0W][NTWH], bi0[NTWH];
+        constexpr int EM0 = (NX == 0 || !XSPLIT) ? (1 << NPT0) - 1 : fused_extra_mask(NPT0, GN, GI);
+        f32x4 acc0[NPT0][NTWH], bi0[NTWH];
         load_bias(p.bias[0], bi0);
-        conv_phase(std::integral_constant<int, RD0>{}, std::integral_constant<int, NPT0W>{}, std::integral_constant<int, NTWH>{},
+        conv_phase(std::integral_constant<int, RD0>{}, std::integral_constant<int, NPT0>{}, std::integral_constant<int, NTWH>{},
                    std::integral_constant<int, G::rows_h(0)>{}, std::integral_constant<int, EM0>{}, G::ZREG, Z16, Z8, wb0, NHT, htile, 0,
-                   (NZ / 32) * NTAPS, wr0, acc0, q00);
+                   (NZ / 32) * NTAPS, wr0, acc0);
         IAF_FSTAMP(6);
         store_ctx();
         if constexpr (DEPTH == 1) load_final_operands();
@@ -483,8 +495,8 @@ __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(WV / 4,
         IAF_FSTAMP(10);
         __syncthreads();                                         // (every wave runs exactly one of the GN instantiations)
         IAF_FSTAMP(11);
-        hidden_epilogue(std::integral_constant<int, NPT0W>{}, std::integral_constant<int, G::rows_h(0)>{},
-                        std::integral_constant<int, EM0>{}, std::integral_constant<int, 1>{}, acc0, bi0, G::HREG0, p.hsave[0], p.border[0], q00);
+        hidden_epilogue(std::integral_constant<int, NPT0>{}, std::integral_constant<int, G::rows_h(0)>{},
+                        std::integral_constant<int, EM0>{}, std::integral_constant<int, 1>{}, acc0, bi0, G::HREG0, p.hsave[0], p.border[0]);
     });
     __syncthreads();
     IAF_FSTAMP(2);
@@ -493,7 +505,7 @@ __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(WV / 4,
         constexpr int IN_REG = ((l - 1) & 1) ? G::HREG1 : G::HREG0, OUT_REG = (l & 1) ? G::HREG1 : G::HREG0;
         if constexpr (l == 1) {   // the staged context sat in the h_odd region: its zero columns again, before the epilogue fills the rest
             constexpr int H1ROWS = G::rows_h(1);
-            for (int i = tid; i < H1ROWS * 2 * H16; i += NT) {
+            for (int i = tid; i < H1ROWS * 2 * H16; i += 256) {
                 const int rs = i / H16, u = i - rs * H16;
                 smem4[G::HREG1 + ((rs >> 1) * RS + (rs & 1) * (W + 1)) * H16 + u] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
@@ -505,37 +517,15 @@ __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(WV / 4,
             constexpr int EML = (NX == 0 || !XSPLIT) ? (1 << NPTL) - 1 : fused_extra_mask(NPTL, GN, GI);
             f32x4 accl[NPTL][NTWH], bil[NTWH];
             load_bias(p.bias[l], bil);
-            const f32x4* wbl = (const f32x4*)p.wp3[l] + lane;
+            const f32x4* wbl = (const f32x4*)p.wp3[l];
             conv_phase(std::integral_constant<int, RDH>{}, std::integral_constant<int, NPTL>{}, std::integral_constant<int, NTWH>{},
-                       std::integral_constant<int, G::rows_h(l)>{}, std::integral_constant<int, EML>{}, IN_REG, H16, H8, wbl, NHT, htile, sh0,
-                       sh1, (l & 1) ? wr1 : wr0, accl);
+                       std::integral_constant<int, G::rows_h(l)>{}, std::integral_constant<int, EML>{}, IN_REG, H16, H8, wbl, NHT, htile, 0,
+                       NSTEP_H, (l & 1) ? wr1 : wr0, accl);
             if constexpr (l == 1) IAF_FSTAMP(7);
             if constexpr (l == DEPTH - 1) load_final_operands();
             preload_after(std::integral_constant<int, l>{});
-            if constexpr (HV == 2) {
-                // the halves split this layer's K steps: the second half's partial sums travel through the layer's INPUT
-                // region -- dead once every wave has left the K loop (first barrier) -- [wave][unit][lane] 16-byte rows
-                static_assert(DEPTH <= 2, "the hand-over scribbles over the input region's zero columns: a third hidden layer would read them");
-                static_assert((size_t)NW * NPTL * NTWH * 1024 <= (size_t)G::rows_h(l - 1) * RS * H16 * 16, "hand-over buffer fits the input region");
-                f32x4* xr = smem4 + IN_REG + (size_t)(wave * NPTL * NTWH) * 64 + lane;
-                __syncthreads();
-                if (half == 1) {
-#pragma unroll
-                    for (int q = 0; q < NPTL; ++q)
-#pragma unroll
-                        for (int j = 0; j < NTWH; ++j) xr[(q * NTWH + j) * 64] = accl[q][j];
-                }
-                __syncthreads();
-                if (half == 0) {
-#pragma unroll
-                    for (int q = 0; q < NPTL; ++q)
-#pragma unroll
-                        for (int j = 0; j < NTWH; ++j) accl[q][j] += xr[(q * NTWH + j) * 64];
-                }
-            }
-            if (half == 0)
-                hidden_epilogue(std::integral_constant<int, NPTL>{}, std::integral_constant<int, G::rows_h(l)>{},
-                                std::integral_constant<int, EML>{}, std::integral_constant<int, 0>{}, accl, bil, OUT_REG, p.hsave[l], p.border[l]);
+            hidden_epilogue(std::integral_constant<int, NPTL>{}, std::integral_constant<int, G::rows_h(l)>{},
+                            std::integral_constant<int, EML>{}, std::integral_constant<int, 0>{}, accl, bil, OUT_REG, p.hsave[l], p.border[l]);
             if constexpr (l == 1) IAF_FSTAMP(12);
         });
         __syncthreads();
@@ -549,9 +539,9 @@ __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(WV / 4,
         f32x4 acco[NPTO][NTWO];
         conv_phase(std::integral_constant<int, RDO>{}, std::integral_constant<int, NPTO>{}, std::integral_constant<int, NTWO>{},
                    std::integral_constant<int, R>{}, std::integral_constant<int, (1 << NPTO) - 1>{}, ((DEPTH - 1) & 1) ? G::HREG1 : G::HREG0,
-                   H16, H8, wbo, 2 * NZT, otile, sh0, sh1, wro, acco);
+                   H16, H8, wbo, 2 * NZT, otile, 0, NSTEP_H, wro, acco);
         IAF_FSTAMP(4);
-        float* mine = xbuf + (size_t)half * (R * W * G::XB_STRIDE);
+        float* mine = xbuf;
 #pragma unroll
         for (int j = 0; j < NTWO; ++j)
 #pragma unroll
@@ -571,12 +561,12 @@ __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(WV / 4,
     for (int e = 0; e < NEL; ++e) klv[e] = 0.f;
 #pragma unroll
     for (int e = 0; e < NEL; ++e) {
-        const int idx = tid + e * NT;
+        const int idx = tid + e * 256;
         if (idx >= NZ * R * W) continue;
         const int c = idx / (R * W), pix = idx - c * (R * W);
         const int row = pix / W;
         if (r0 + row >= H) continue;
-        const size_t gi = ((size_t)b * NZ + c) * HW + gpix(r0 + row, pix - row * W);
+        const unsigned gi = 4u * (unsigned)(c * HW + gpix(r0 + row, pix - row * W));     // byte offset inside image b
         const int cm = (c >> 4) * 32 + (c & 15);
         float m_raw = fb[e][0], s_raw = fb[e][1];
         if constexpr (BORDER) {                                  // the border channel of the output pair's own input
@@ -587,22 +577,19 @@ __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(WV / 4,
             m_raw += w1 * bt[cm] + w2 * bt[2 * NZ + cm] + w3 * bt[4 * NZ + cm] + w4 * bt[6 * NZ + cm];
             s_raw += w1 * bt[cm + 16] + w2 * bt[2 * NZ + cm + 16] + w3 * bt[4 * NZ + cm + 16] + w4 * bt[6 * NZ + cm + 16];
         }
-#pragma unroll
-        for (int k = 0; k < HV; ++k) {                          // (the halves' K parts)
-            m_raw += xbuf[k * (R * W * G::XB_STRIDE) + pix * G::XB_STRIDE + cm];
-            s_raw += xbuf[k * (R * W * G::XB_STRIDE) + pix * G::XB_STRIDE + cm + 16];
-        }
+        m_raw += xbuf[pix * G::XB_STRIDE + cm];
+        s_raw += xbuf[pix * G::XB_STRIDE + cm + 16];
         if (p.mode == MODE_RAW) {
-            p.out0[gi] = m_raw;
-            p.out1[gi] = s_raw;
+            stf(p.out0 + img_z, gi, m_raw);
+            stf(p.out1 + img_z, gi, s_raw);
         } else if (p.mode == MODE_IAF) {
             const float m = m_raw * 0.1f, s = s_raw * 0.1f;        // tf_train.py:70
-            p.out0[gi] = (fz[e] - m) / __expf(s);                  // tf_train.py:71
-            p.out1[gi] = s;                                        // tf_train.py:72
+            stf(p.out0 + img_z, gi, (fz[e] - m) / __expf(s));      // tf_train.py:71
+            stf(p.out1 + img_z, gi, s);                            // tf_train.py:72
         } else if (p.mode == MODE_INVERSE) {
             const float m = m_raw * 0.1f, s = s_raw * 0.1f;
-            p.out0[gi] = fz[e] * __expf(s) + m;
-            p.out1[gi] = s;
+            stf(p.out0 + img_z, gi, fz[e] * __expf(s) + m);
+            stf(p.out1 + img_z, gi, s);
         } else {
             const float m = m_raw * 0.1f, s = s_raw * 0.1f;
             const float mean = fq[e][0];                            // tf_train.py:57
@@ -615,10 +602,10 @@ __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(WV / 4,
             const float plv = 2.f * fq[e][4];                                                     // :56
             const float d1 = zz - fq[e][3];
             const float logps = -0.5f * (1.8378770664093453f + plv + d1 * d1 / __expf(plv));      // :73
-            p.out0[gi] = zz;
-            if (p.out1) p.out1[gi] = s;
+            stf(p.out0 + img_z, gi, zz);
+            if (p.out1) stf(p.out1 + img_z, gi, s);
             klv[e] = logqs - logps;                                                               // :75
-            if (p.kl_elem) p.kl_elem[gi] = klv[e];
+            if (p.kl_elem) stf(p.kl_elem + img_z, gi, klv[e]);
         }
     }
     // ---- the block's KL reductions start here (tf_train.py:77, sum over H, W): a channel's R*W pixels are R*W consecutive
@@ -631,7 +618,7 @@ __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(WV / 4,
             float a = klv[e];
 #pragma unroll
             for (int o = RW / 2; o > 0; o >>= 1) a += __shfl_xor(a, o);
-            const int idx = tid + e * NT;
+            const int idx = tid + e * 256;
             if (idx < NZ * RW && (idx & (RW - 1)) == 0) p.kl_part[(size_t)blockIdx.x * NZ + idx / RW] = a;
         }
     }

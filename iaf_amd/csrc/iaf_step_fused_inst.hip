@@ -4,7 +4,7 @@
 // stack of config 3 (n_z = 64, depth_ar = 4, n_h = 64 / 128 / 192) wherever its five LDS regions fit 160 KiB.  Built as its own translation unit by iaf_amd/build.py.
 #include "iaf_step_fused.hpp"
 
-template <int NHT, int NZT, int DEPTH, int W, int R, int WV = 4>
+template <int NHT, int NZT, int DEPTH, int W, int R>
 static step_fn_t inst(int var, size_t* lds) {
     typedef StepGeom<NHT, NZT, DEPTH, W, R> G;
     static_assert((G::CSTR & 15) == 4 || (G::CSTR & 15) == 12, "context rows: 4 channel groups x 16 pixels must hit 64 distinct banks");
@@ -17,9 +17,9 @@ static step_fn_t inst(int var, size_t* lds) {
     } else {
         *lds = G::lds_bytes();
         switch (var) {
-            case 0: return iaf_step_fused_kernel<NHT, NZT, DEPTH, W, R, 0, WV>;
-            case 1: return iaf_step_fused_kernel<NHT, NZT, DEPTH, W, R, 1, WV>;
-            case 2: return iaf_step_fused_kernel<NHT, NZT, DEPTH, W, R, 2, WV>;
+            case 0: return iaf_step_fused_kernel<NHT, NZT, DEPTH, W, R, 0>;
+            case 1: return iaf_step_fused_kernel<NHT, NZT, DEPTH, W, R, 1>;
+            case 2: return iaf_step_fused_kernel<NHT, NZT, DEPTH, W, R, 2>;
         }
         return nullptr;
     }
@@ -37,14 +37,8 @@ static step_fn_t inst_wr(int W, int R, int var, size_t* lds) {
 // two translation units (iaf_amd/build.py: -DIAF_FUSED_PART=0 / 1) so that the build compiles them side by side
 // (no -DIAF_FUSED_PART: both parts in one unit)
 #if !defined(IAF_FUSED_PART) || IAF_FUSED_PART == 0
-extern "C" step_fn_t iaf_pick_step_fused_a(int nht, int nzt, int depth, int W, int R, int var, int wv, size_t* lds) {
+extern "C" step_fn_t iaf_pick_step_fused_a(int nht, int nzt, int depth, int W, int R, int var, size_t* lds) {
     *lds = 0;
-    if (wv == 8) {                     // two waves per SIMD: the README run's geometries
-        if (nht == 10 && nzt == 2 && depth == 2 && W == 16 && R == 2) return inst<10, 2, 2, 16, 2, 8>(var, lds);
-        if (nht == 10 && nzt == 2 && depth == 2 && W == 8 && R == 1) return inst<10, 2, 2, 8, 1, 8>(var, lds);
-        return nullptr;
-    }
-    if (wv != 4) return nullptr;
     if (nht == 10 && nzt == 2 && depth == 2) return inst_wr<10, 2, 2>(W, R, var, lds);      // configs 1-2, 5 (README run)
     if (nht == 4 && nzt == 2 && depth == 1) return inst_wr<4, 2, 1>(W, R, var, lds);        // config 0
     return nullptr;
@@ -52,9 +46,8 @@ extern "C" step_fn_t iaf_pick_step_fused_a(int nht, int nzt, int depth, int W, i
 #endif
 #if !defined(IAF_FUSED_PART) || IAF_FUSED_PART == 1
 // config 3 (up_iaf2_nl, n_z = 64, depth_ar = 4; n_h is not fixed by the reference's scripts): the geometries that fit
-extern "C" step_fn_t iaf_pick_step_fused_b(int nht, int nzt, int depth, int W, int R, int var, int wv, size_t* lds) {
+extern "C" step_fn_t iaf_pick_step_fused_b(int nht, int nzt, int depth, int W, int R, int var, size_t* lds) {
     *lds = 0;
-    if (wv != 4) return nullptr;
     if (nht == 4 && nzt == 4 && depth == 4) return inst_wr<4, 4, 4>(W, R, var, lds);
     if (nht == 8 && nzt == 4 && depth == 4) return inst_wr<8, 4, 4>(W, R, var, lds);
     if (nht == 12 && nzt == 4 && depth == 4) return inst_wr<12, 4, 4>(W, R, var, lds);

@@ -31,10 +31,9 @@ struct StepP {
 typedef void (*step_fn_t)(StepP);
 // kernel + dynamic LDS bytes for (n_h / 16, n_z / 16, depth_ar, image width, output rows per workgroup), or NULL
 // var: 0 TF statement, 1 Theano, 2 Theano with flipmask
-// wv: waves per workgroup, 4 or 8 (launch with 64 * wv threads); 8 is compiled for the geometries of the README run only
-extern "C" step_fn_t iaf_pick_step_fused_a(int nht, int nzt, int depth, int W, int R, int var, int wv, size_t* lds);   // depth_ar <= 2 geometries
-extern "C" step_fn_t iaf_pick_step_fused_b(int nht, int nzt, int depth, int W, int R, int var, int wv, size_t* lds);   // depth_ar = 4 geometries
-static inline step_fn_t iaf_pick_step_fused(int nht, int nzt, int depth, int W, int R, int var, int wv, size_t* lds) {
-    step_fn_t f = iaf_pick_step_fused_a(nht, nzt, depth, W, R, var, wv, lds);
-    return f ? f : iaf_pick_step_fused_b(nht, nzt, depth, W, R, var, wv, lds);
+extern "C" step_fn_t iaf_pick_step_fused_a(int nht, int nzt, int depth, int W, int R, int var, size_t* lds);   // depth_ar <= 2 geometries
+extern "C" step_fn_t iaf_pick_step_fused_b(int nht, int nzt, int depth, int W, int R, int var, size_t* lds);   // depth_ar = 4 geometries
+static inline step_fn_t iaf_pick_step_fused(int nht, int nzt, int depth, int W, int R, int var, size_t* lds) {
+    step_fn_t f = iaf_pick_step_fused_a(nht, nzt, depth, W, R, var, lds);
+    return f ? f : iaf_pick_step_fused_b(nht, nzt, depth, W, R, var, lds);
 }
