@@ -32,6 +32,7 @@ struct iaf_conv3x3 {
 extern "C" int iaf_conv3x3_destroy(iaf_conv3x3_t* c) {
     if (!c) return IAF_ERR_NULL;
     if (c->L.wp) (void)hipFree(c->L.wp);
+    if (c->L.wpt3) (void)hipFree(c->L.wpt3);
     if (c->L.bias) (void)hipFree(c->L.bias);
     if (c->L.wpt) (void)hipFree(c->L.wpt);
     if (c->L.wp3) (void)hipFree(c->L.wp3);
@@ -126,6 +127,12 @@ extern "C" int iaf_conv3x3_prepare(iaf_conv3x3_t* c, const float* V, const float
         P.cin = L.cin; P.cout_each = L.cout; P.ncot = L.ncot; P.nchunk = L.nchunk; P.npair = 1; P.tile_begin = 0;
         HIP_TRY(hipMemcpyAsync(c->d_desc, c->h_desc, sizeof(PrepLayer), hipMemcpyHostToDevice, (hipStream_t)stream));
         hipLaunchKernelGGL(iaf_prep_plain_kernel, dim3(L.ncot), dim3(256), 0, (hipStream_t)stream, c->d_desc, (const int*)nullptr);
+        if (c->training) {
+            PackT3Batch tb((hipStream_t)stream);
+            int rc = tb.add(L, MAXTAPS);
+            if (!rc) rc = tb.flush();
+            if (rc) return rc;
+        }
     }
     HIP_TRY(hipGetLastError());
     c->prepared = true;
@@ -148,6 +155,12 @@ extern "C" int iaf_conv3x3_prepare_deconv(iaf_conv3x3_t* c, const float* V, cons
     hipLaunchKernelGGL(iaf_deconv_pack_kernel, dim3(blocks), dim3(256), 0, st, V, g, b, (const float*)inv_norm, L.wp, L.bias,
                        L.cin, L.cout, L.ncot, c->generic ? 1 : 0, (c->training && !c->generic) ? L.wpt : nullptr);
     HIP_TRY(hipGetLastError());
+    if (c->training && !c->generic) {           // ... and its bf16x3 form for the data gradient
+        PackT3Batch tb(st);
+        int rc = tb.add(L, MAXTAPS);
+        if (!rc) rc = tb.flush();
+        if (rc) return rc;
+    }
     c->prepared = true;
     c->deconv = true;
     return IAF_OK;
@@ -287,6 +300,13 @@ extern "C" int iaf_conv3x3_prep_batch_run(iaf_conv3x3_prep_batch_t* b, const flo
     { int rc = desc_upload(&b->tab, b->h_layers, changed, st, &d_layers); if (rc) return rc; }
     hipLaunchKernelGGL(iaf_prep_plain_kernel, dim3(b->ntiles), dim3(256), 0, st, (const PrepLayer*)d_layers, b->d_tile2layer);
     HIP_TRY(hipGetLastError());
+    {
+        PackT3Batch tb(st);
+        for (int i = 0; i < b->n; ++i)
+            if (b->convs[i]->training) { int rc = tb.add(b->convs[i]->L, MAXTAPS); if (rc) return rc; }
+        int rc = tb.flush();
+        if (rc) return rc;
+    }
     for (int i = 0; i < b->n; ++i) b->convs[i]->prepared = true;
     return IAF_OK;
 }
@@ -328,11 +348,16 @@ static bool conv3x3_bf3_shape(GemmLayer& L, int choice, long long P, int W) {
 
 static int conv3x3_launch(GemmLayer& L, ConvP& p, int epi_sel, int inmode, bool masked, bool mirror, hipStream_t st,
                           int variant = IAF_VARIANT_TF, int bf3_choice = 3) {
-    if (!masked && !mirror && epi_sel == EPI_PLAIN && inmode == IN_NCHW && conv3x3_bf3_shape(L, bf3_choice, p.P, p.W)) {
-        conv_fn_t fn = pick_bf3_plain(L.b_nt, L.b_ppw, L.b_pxt, L.b_ks, L.b_wco);
-        const int tm = 16 * L.b_ppw * L.b_pxt, W = p.W;
+    // the plain conv on the bf16 matrix cores: forward (NCHW input, EPI_PLAIN), or its data gradient (L = the transposed
+    // problem with wp3 = the transposed bf16x3 pack: dY pixel-major, mirrored taps, EPI_DGRAD)
+    const bool fwd3 = !masked && !mirror && epi_sel == EPI_PLAIN && inmode == IN_NCHW;
+    const bool bwd3 = !masked && mirror && epi_sel == EPI_DGRAD9 && inmode == IN_PIXMAJOR && variant == IAF_VARIANT_TF;
+    if ((fwd3 || bwd3) && conv3x3_bf3_shape(L, bf3_choice, p.P, p.W) &&
+        pick_bf3_plain(L.b_nt, L.b_ppw, L.b_pxt, L.b_ks, L.b_wco, bwd3 ? EPI_DGRAD : EPI_PLAIN)) {
+        conv_fn_t fn = pick_bf3_plain(L.b_nt, L.b_ppw, L.b_pxt, L.b_ks, L.b_wco, bwd3 ? EPI_DGRAD : EPI_PLAIN);
+        const int tm = 16 * L.b_ppw * L.b_pxt, W = p.W, sg = bwd3 ? -1 : 1;
         p.border = nullptr; p.wp = (const float*)L.wp3; p.bias = L.bias; p.lim = nullptr;
-        for (int t = 0; t < MAXTAPS; ++t) { p.tap_dh[t] = t / 3 - 1; p.tap_dw[t] = t % 3 - 1; }       // cross-correlation, SAME
+        for (int t = 0; t < MAXTAPS; ++t) { p.tap_dh[t] = sg * (t / 3 - 1); p.tap_dw[t] = sg * (t % 3 - 1); }   // cross-correlation, SAME (mirrored: dX)
         p.halo_before = W + 1;
         p.nslot = tm + 2 * (W + 1);
         p.cin = L.cin; p.cout = L.cout; p.nchunk = L.nchunk; p.ncot = L.ncot; p.cp = L.cin + 8;
@@ -561,10 +586,12 @@ extern "C" int iaf_conv3x3_set_training(iaf_conv3x3_t* c, int on) {
     if (!on) { c->training = false; return IAF_OK; }
     GemmLayer& L = c->L;
     if (!L.wpt) HIP_TRY(hipMalloc(&L.wpt, (size_t)L.nchunk * MAXTAPS * L.ncot * 256 * sizeof(float)));
+    // the transposed pack as bf16x3 (iaf_pack_t3_kernel): the data gradient on the bf16 matrix cores (even K tile counts)
+    if (!L.wpt3 && L.ncot % 2 == 0) HIP_TRY(hipMalloc(&L.wpt3, (size_t)(L.ncot / 2) * MAXTAPS * L.nchunk * 3 * 64 * 16));
     GemmLayer& T = c->T;
     T = GemmLayer();
     T.cin = L.cout; T.cout = L.cin; T.nchunk = L.ncot; T.ncot = L.nchunk; T.zerodiag = 0; T.npair = 1; T.full3x3 = true;
-    T.wp = L.wpt; T.nt = 1; T.pxt = 4; T.wco = 1; T.ks = 1; T.user_tuned = false;
+    T.wp = L.wpt; T.wp3 = L.wpt3; T.nt = 1; T.pxt = 4; T.wco = 1; T.ks = 1; T.user_tuned = false;
     c->training = true;
     c->prepared = false;      // the transposed pack is written by the next prepare
     return IAF_OK;
@@ -656,7 +683,9 @@ extern "C" int iaf_conv3x3_backward(iaf_conv3x3_t* c, const float* x, const floa
             p.split_end[k] = dends[k < n_dxs ? k : n_dxs - 1];
             p.split_ptr[k] = dxs[k < n_dxs ? k : n_dxs - 1];
         }
-        if ((rc = conv3x3_launch(c->T, p, EPI_DGRAD9, IN_PIXMAJOR, false, true, st))) return rc;
+        // bf16x3 unless the conv's precision is fp32 or a backward search measured the fp32 kernel faster at this size
+        const int choice3 = (c->bf3_choice == 3 || !c->T.wp3) ? 3 : (c->T.tuned_P == (long long)P && c->T.tuned_W == W && !c->T.tuned_bf3) ? 3 : 1;
+        if ((rc = conv3x3_launch(c->T, p, EPI_DGRAD9, IN_PIXMAJOR, false, true, st, IAF_VARIANT_TF, choice3))) return rc;
     }
     // (3) weight gradient: partials over pixel ranges, then reduce (+ column sums of dY for db)
     const unsigned short* tapmask = nullptr;
@@ -721,6 +750,8 @@ extern "C" int iaf_conv3x3_autotune_backward(iaf_conv3x3_t* c, const float* x, c
         return iaf_conv3x3_backward(c, x, x2, c_split, elu_input, dys, dy_channels, n_dys, dy_scale, dxs, dx_channels, n_dxs,
                                     dx_residual, V, g, dV, dg, db, B, H, W, workspace, workspace_bytes, stream);
     };
+    // (the fp32 candidates run with the bf16x3 data gradient switched off: tuned_bf3 = false for this size)
+    T.tuned_P = (long long)B * H * W; T.tuned_W = W; T.tuned_bf3 = false;
     for (int si = 0; si < 8 && rc == IAF_OK; ++si)
         for (int nt = 5; nt >= 1 && rc == IAF_OK; --nt) {
             const int pxt = k_shapes[si][0], wco = k_shapes[si][1], ks = k_shapes[si][2];
@@ -742,13 +773,32 @@ extern "C" int iaf_conv3x3_autotune_backward(iaf_conv3x3_t* c, const float* x, c
             (void)hipEventElapsedTime(&ms, e0, e1);
             if (ms < best) { best = ms; bsh[0] = nt; bsh[1] = pxt; bsh[2] = wco; bsh[3] = ks; }
         }
+    // ... and the bf16x3 data gradient in its rule shape (conv3x3_bf3_shape), if this conv has the transposed bf16x3 pack
+    bool bf3_wins = false;
+    if (rc == IAF_OK && T.wp3 && c->bf3_choice != 3) {
+        T.user_tuned = false;
+        T.tuned_bf3 = true;
+        for (int r = 0; r < 2 && rc == IAF_OK; ++r) rc = run();
+        if (rc == IAF_OK) {
+            (void)hipEventRecord(e0, st);
+            for (int r = 0; r < reps && rc == IAF_OK; ++r) rc = run();
+            (void)hipEventRecord(e1, st);
+            float ms = 0.f;
+            if (rc == IAF_OK && (rc = (int)hipEventSynchronize(e1)) == 0) {
+                (void)hipEventElapsedTime(&ms, e0, e1);
+                if (ms < best) { best = ms; bf3_wins = true; }
+            }
+        }
+    }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    T.tuned_bf3 = bf3_wins;
+    if (bf3_wins) { bsh[0] = -T.b_nt; bsh[1] = T.b_ppw; bsh[2] = T.b_wco; bsh[3] = T.b_ks; }       // reported like the forward's bf16x3 shapes
     // remember the winner for THIS problem size only (t_* hold (nt, pxt, wco, ks) here): a backward at another size goes
     // back to the automatic shape instead of inheriting a shape tuned -- and LDS-sized -- for this one
     T.user_tuned = false;
     T.tuned_P = (long long)B * H * W; T.tuned_W = W;
-    T.t_nt = bsh[0]; T.t_ppw = bsh[1]; T.t_pxt = bsh[2]; T.t_ks = bsh[3];
+    if (!bf3_wins) { T.t_nt = bsh[0]; T.t_ppw = bsh[1]; T.t_pxt = bsh[2]; T.t_ks = bsh[3]; }
     if (rc == IAF_OK) rc = run();           // leave the outputs as computed with the chosen shape
     (void)was_pending;
     if (best_shape) for (int i = 0; i < 4; ++i) best_shape[i] = bsh[i];

@@ -81,6 +81,7 @@ __global__ __launch_bounds__(64 * PXT * KS * WCO) void iaf_conv_bf3_kernel(ConvP
         asm volatile("" ::"s"(p.tap_dh[5]), "s"(p.tap_dh[6]), "s"(p.tap_dh[7]), "s"(p.tap_dh[8]), "s"(p.tap_dw[5]), "s"(p.tap_dw[6]),
                      "s"(p.tap_dw[7]), "s"(p.tap_dw[8]));
     if constexpr (EPI == EPI_PLAIN) asm volatile("" ::"s"(p.x2), "s"(p.res), "s"(p.c_split), "s"(p.in_elu), "s"(p.nsplit));
+    if constexpr (EPI == EPI_DGRAD) asm volatile("" ::"s"(p.res), "s"(p.nsplit), "s"(p.qm), "s"(p.ql));
     asm volatile("" ::"s"(p.bias), "s"(p.ctx), "s"(p.ctx2), "s"(p.y), "s"(p.zin), "s"(p.out0), "s"(p.out1), "s"(p.border));
     if constexpr (INMODE == IN_POSTERIOR || EPI == EPI_OUT)
         asm volatile("" ::"s"(p.qm), "s"(p.ql), "s"(p.rm), "s"(p.rl), "s"(p.pm), "s"(p.pl), "s"(p.eps), "s"(p.kl_elem));

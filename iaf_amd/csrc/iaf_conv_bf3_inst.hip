@@ -19,6 +19,8 @@ static conv_fn_t pick_mode_bf3(int inmode, int epi) {
         if (inmode == IN_POSTERIOR) return iaf_conv_bf3_kernel<NT, IAF_PPW, IAF_PXT, IAF_KS, IN_POSTERIOR, EPI_HIDDEN, IAF_WCO>;
         return nullptr;
     }
+    if (epi == EPI_DGRAD)     // data gradient of a masked conv: dY pixel-major, transposed bf16x3 pack, mirrored taps
+        return inmode == IN_PIXMAJOR ? iaf_conv_bf3_kernel<NT, IAF_PPW, IAF_PXT, IAF_KS, IN_PIXMAJOR, EPI_DGRAD, IAF_WCO> : nullptr;
     if (epi == EPI_OUT) {     // the output pair always reads the last hidden layer (depth_ar = 0 stays on the fp32 kernel)
         if constexpr (NT % 2 == 0) {
             if (inmode == IN_PIXMAJOR) return iaf_conv_bf3_kernel<NT, IAF_PPW, IAF_PXT, IAF_KS, IN_PIXMAJOR, EPI_OUT, IAF_WCO>;

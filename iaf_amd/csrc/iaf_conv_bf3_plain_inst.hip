@@ -13,7 +13,17 @@
 #define IAF_CAT_(a, b, c, d, e) a##b##_##c##_##d##_##e
 #define IAF_CAT(a, b, c, d, e) IAF_CAT_(a, b, c, d, e)
 
-extern "C" conv_fn_t IAF_CAT(iaf_pick_bf3p_, IAF_PPW, IAF_PXT, IAF_KS, IAF_WCO)(int nt) {
+// epi: EPI_PLAIN (forward), or EPI_DGRAD -- the data gradient of the same conv: dY pixel-major, transposed bf16x3 pack,
+// mirrored taps (iaf_conv3x3_backward)
+extern "C" conv_fn_t IAF_CAT(iaf_pick_bf3p_, IAF_PPW, IAF_PXT, IAF_KS, IAF_WCO)(int nt, int epi) {
+    if (epi == EPI_DGRAD) {
+        switch (nt) {
+            case 2: return iaf_conv_bf3_kernel<2, IAF_PPW, IAF_PXT, IAF_KS, IN_PIXMAJOR, EPI_DGRAD, IAF_WCO, MAXTAPS>;
+            case 4: return iaf_conv_bf3_kernel<4, IAF_PPW, IAF_PXT, IAF_KS, IN_PIXMAJOR, EPI_DGRAD, IAF_WCO, MAXTAPS>;
+            case 5: return iaf_conv_bf3_kernel<5, IAF_PPW, IAF_PXT, IAF_KS, IN_PIXMAJOR, EPI_DGRAD, IAF_WCO, MAXTAPS>;
+        }
+        return nullptr;
+    }
     switch (nt) {
         case 2: return iaf_conv_bf3_kernel<2, IAF_PPW, IAF_PXT, IAF_KS, IN_NCHW, EPI_PLAIN, IAF_WCO, MAXTAPS>;
         case 4: return iaf_conv_bf3_kernel<4, IAF_PPW, IAF_PXT, IAF_KS, IN_NCHW, EPI_PLAIN, IAF_WCO, MAXTAPS>;

@@ -67,6 +67,21 @@ __device__ __forceinline__ void epi_load(const ConvP& p, const EpiGeom& g, int c
                 for (int r = 0; r < 4; ++r) o.pre1[r] = p.ctx2[cb + (size_t)r * HW];
             }
         }
+    } else if (EPI == EPI_DGRAD) {  // data gradient (modes MODE_DGRAD_*, iaf_conv_kernel.hpp): no bias; operands of elu' / of the affine term
+        const int co = cot * 16 + 4 * g.kk;
+        const size_t cb = ((size_t)g.bimg * p.cout + co) * HW + g.pp;
+        if (p.mode == MODE_DGRAD_ELU) {
+            o.pre0 = *(const f32x4*)(p.zin + (size_t)g.Pl * p.cout + co);               // saved activation h, pixel-major
+        } else if (p.mode == MODE_DGRAD_PLAIN) {
+            if (p.zin) o.pre0 = *(const f32x4*)(p.zin + (size_t)g.Pl * p.cout + co);    // staged elu(x), pixel-major
+            if (p.res) {                                                                  // `input + 0.1 h`: d_out passes through
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o.pre1[r] = p.res[cb + (size_t)r * HW];
+            }
+        } else {                                                                          // MODE_DGRAD_Z: dz_new, logsd (NCHW)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { o.pre0[r] = p.qm[cb + (size_t)r * HW]; o.pre1[r] = p.ql[cb + (size_t)r * HW]; }
+        }
     } else {
         o.b0 = *(const f32x4*)(p.bias + cot * 16 + 4 * g.kk);
         o.b1 = *(const f32x4*)(p.bias + (cot + 1) * 16 + 4 * g.kk);
@@ -109,6 +124,36 @@ __device__ __forceinline__ void epi_apply(const ConvP& p, const EpiGeom& g, int 
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = elu_f(v[r]);   // layers.py:165
         *(f32x4*)(p.y + (size_t)g.Pl * p.cout + co) = v;
+    } else if (EPI == EPI_DGRAD) {      // dX = W^T dY through the transposed packs and mirrored taps (iaf_conv_kernel.hpp, same modes)
+        const int co = cot * 16 + 4 * g.kk;
+        f32x4 v = v0;
+        if (p.mode == MODE_DGRAD_ELU) {                            // d a_{l-1} = (W_l^T dY) elu'(h_{l-1}); elu'(a) = h > 0 ? 1 : h + 1
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= (o.pre0[r] > 0.f ? 1.f : o.pre0[r] + 1.f);
+            *(f32x4*)(p.y + (size_t)g.Pl * p.cout + co) = v;
+            if (p.out0) {                                          // (+ NCHW copy = d context)
+                const size_t cb = ((size_t)g.bimg * p.cout + co) * HW + g.pp;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) p.out0[cb + (size_t)r * HW] = v[r];
+            }
+        } else if (p.mode == MODE_DGRAD_PLAIN) {                   // plain conv: dx = [d_out +] act'(.) (W^T dY), NCHW through the split table
+            if (p.zin) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= (o.pre0[r] > 0.f ? 1.f : o.pre0[r] + 1.f);
+            }
+            int c0 = 0, c1 = p.split_end[0];
+            float* base = p.split_ptr[0];
+#pragma unroll
+            for (int q = 1; q < MAXSPLIT; ++q)
+                if (q < p.nsplit && co >= p.split_end[q - 1]) { c0 = p.split_end[q - 1]; c1 = p.split_end[q]; base = p.split_ptr[q]; }
+            float* dst = base + ((size_t)g.bimg * (c1 - c0) + (co - c0)) * HW + g.pp;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[(size_t)r * HW] = p.res ? o.pre1[r] + v[r] : v[r];
+        } else {                                                   // MODE_DGRAD_Z: dz = W_0^T dY + dz_new exp(-logsd) (tf_train.py:71)
+            const size_t cb = ((size_t)g.bimg * p.cout + co) * HW + g.pp;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p.out0[cb + (size_t)r * HW] = v[r] + o.pre0[r] * __expf(-o.pre1[r]);
+        }
     } else {
         const int nz = p.cout >> 1;
         const int c0 = (cot >> 1) * 16 + 4 * g.kk;       // packed tiles (cot, cot+1) = (mean, logsd) of channel group cot/2

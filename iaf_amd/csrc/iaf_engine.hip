@@ -72,6 +72,7 @@ struct GemmLayer {
     float* bias = nullptr;
     float* border = nullptr;   // Theano variant only
     float* wpt = nullptr;      // transposed pack for dgrad (allocated by iaf_stack_set_training)
+    void* wpt3 = nullptr;      // its bf16x3 form (iaf_pack_t3_kernel; even tile counts only): the data gradient on the bf16 matrix cores
     void* wp3 = nullptr;       // bf16x3 pack for iaf_conv_bf3_kernel (c_in % 32 == 0 only)
     int b_nt = 0, b_ppw = 0, b_pxt = 0, b_ks = 0, b_wco = 1;   // bf16x3 launch shape (auto or iaf_stack_set_tuning_bf3)
     bool b_user_tuned = false;
@@ -242,13 +243,13 @@ static size_t bf3_lds_bytes(int cin, int W, int nt, int ppw, int pxt, int ks, in
 // 9-tap plain convs on the bf16 matrix cores (iaf_conv_bf3_plain_inst.hip): shapes (ppw, pxt, ks, wco); keep in sync with build.py
 #define N_BF3P_SHAPES 3
 static const int k_bf3p_shapes[N_BF3P_SHAPES][4] = {{2, 1, 4, 1}, {4, 1, 4, 1}, {2, 1, 4, 2}};
-extern "C" conv_fn_t iaf_pick_bf3p_2_1_4_1(int nt);
-extern "C" conv_fn_t iaf_pick_bf3p_4_1_4_1(int nt);
-extern "C" conv_fn_t iaf_pick_bf3p_2_1_4_2(int nt);
-static conv_fn_t pick_bf3_plain(int nt, int ppw, int pxt, int ks, int wco) {
-    if (ppw == 2 && pxt == 1 && ks == 4 && wco == 1) return iaf_pick_bf3p_2_1_4_1(nt);
-    if (ppw == 4 && pxt == 1 && ks == 4 && wco == 1) return iaf_pick_bf3p_4_1_4_1(nt);
-    if (ppw == 2 && pxt == 1 && ks == 4 && wco == 2) return iaf_pick_bf3p_2_1_4_2(nt);
+extern "C" conv_fn_t iaf_pick_bf3p_2_1_4_1(int nt, int epi);
+extern "C" conv_fn_t iaf_pick_bf3p_4_1_4_1(int nt, int epi);
+extern "C" conv_fn_t iaf_pick_bf3p_2_1_4_2(int nt, int epi);
+static conv_fn_t pick_bf3_plain(int nt, int ppw, int pxt, int ks, int wco, int epi = EPI_PLAIN) {
+    if (ppw == 2 && pxt == 1 && ks == 4 && wco == 1) return iaf_pick_bf3p_2_1_4_1(nt, epi);
+    if (ppw == 4 && pxt == 1 && ks == 4 && wco == 1) return iaf_pick_bf3p_4_1_4_1(nt, epi);
+    if (ppw == 2 && pxt == 1 && ks == 4 && wco == 2) return iaf_pick_bf3p_2_1_4_2(nt, epi);
     return nullptr;
 }
 // LDS of a 9-tap bf16x3 launch: the pixel tile with a halo of W + 1 slots on BOTH sides (+ the zero slot)
@@ -444,6 +445,7 @@ extern "C" int iaf_stack_destroy(iaf_stack_t* s) {
         if (s->L[l].bias) (void)hipFree(s->L[l].bias);
         if (s->L[l].border) (void)hipFree(s->L[l].border);
         if (s->L[l].wpt) (void)hipFree(s->L[l].wpt);
+        if (s->L[l].wpt3) (void)hipFree(s->L[l].wpt3);
         if (s->L[l].wp3) (void)hipFree(s->L[l].wp3);
         if (s->L[l].lim) (void)hipFree(s->L[l].lim);
     }
@@ -499,6 +501,28 @@ extern "C" int iaf_stack_set_tuning_bf3(iaf_stack_t* s, int layer, int nt, int p
     return IAF_OK;
 }
 
+// transposed bf16x3 packs of training layers, PACKT3_MAX layers per launch (iaf_pack_t3_kernel)
+struct PackT3Batch {
+    PackT3Args a;
+    hipStream_t st;
+    explicit PackT3Batch(hipStream_t s) : st(s) { memset(&a, 0, sizeof(a)); }
+    int flush() {
+        if (!a.n) return IAF_OK;
+        hipLaunchKernelGGL(iaf_pack_t3_kernel, dim3((a.total + 255) / 256), dim3(256), 0, st, a);
+        memset(&a, 0, sizeof(a));
+        return (int)hipGetLastError();
+    }
+    // L: the FORWARD layer (wpt / wpt3 written for its transposed problem); ntp: 5 masked / 9 plain taps
+    int add(const GemmLayer& L, int ntp) {
+        if (!L.wpt || !L.wpt3) return IAF_OK;
+        if (a.n == PACKT3_MAX) { int rc = flush(); if (rc) return rc; }
+        PackT3Layer& q = a.L[a.n++];
+        q.src = L.wpt; q.dst = L.wpt3; q.ntp = ntp; q.nct = L.nchunk; q.begin = a.total;
+        a.total += (L.ncot / 2) * ntp * L.nchunk * 64;
+        return IAF_OK;
+    }
+};
+
 extern "C" int iaf_stack_prepare(iaf_stack_t* s, const float* const* V, const float* const* g, const float* const* b,
                                  void* stream) {
     if (!s || !V || !g || !b) return IAF_ERR_NULL;
@@ -541,6 +565,12 @@ extern "C" int iaf_stack_prepare(iaf_stack_t* s, const float* const* V, const fl
     }
     hipLaunchKernelGGL(iaf_prep_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
+    if (s->training) {
+        PackT3Batch tb((hipStream_t)stream);
+        for (int l = 0; l < s->nlayers; ++l) { int rc = tb.add(s->L[l], NTAPS); if (rc) return rc; }
+        int rc = tb.flush();
+        if (rc) return rc;
+    }
     s->prepared = true;
     return IAF_OK;
 }
@@ -636,6 +666,14 @@ extern "C" int iaf_prep_batch_run(iaf_prep_batch_t* b, const float* const* V, co
     { int rc = desc_upload(&b->tab, b->h_layers, changed, st, &d_layers); if (rc) return rc; }
     hipLaunchKernelGGL(iaf_prep_batch_kernel, dim3(b->ntiles), dim3(256), 0, st, (const PrepLayer*)d_layers, b->d_tile2layer);
     HIP_TRY(hipGetLastError());
+    {
+        PackT3Batch tb(st);
+        for (int i = 0; i < b->n; ++i)
+            if (b->stacks[i]->training)
+                for (int l = 0; l < b->stacks[i]->nlayers; ++l) { int rc = tb.add(b->stacks[i]->L[l], NTAPS); if (rc) return rc; }
+        int rc = tb.flush();
+        if (rc) return rc;
+    }
     for (int i = 0; i < b->n; ++i) b->stacks[i]->prepared = true;
     return IAF_OK;
 }
@@ -764,8 +802,9 @@ static bool auto_shape_bf3(GemmLayer& L, bool is_out, long long P, int W) {
 
 // will a forward launch of this layer run the bf16x3 kernel?  (also fixes L.b_* to the shape it will use)
 static bool bf3_select(const iaf_stack_t* s, GemmLayer& L, int epi, bool negate_taps, bool pix_input, long long P, int W) {
-    if (s->precision != IAF_PRECISION_BF16X3 || !L.wp3 || negate_taps) return false;
-    if (!(epi == EPI_HIDDEN || (epi == EPI_OUT && pix_input))) return false;
+    if (s->precision != IAF_PRECISION_BF16X3 || !L.wp3) return false;
+    if (negate_taps != (epi == EPI_DGRAD)) return false;           // mirrored taps: the data gradient (transposed bf16x3 pack), only
+    if (!(epi == EPI_HIDDEN || ((epi == EPI_OUT || epi == EPI_DGRAD) && pix_input))) return false;
     if (!L.b_user_tuned && L.tuned_P == P && L.tuned_W == W) {       // measured for exactly this problem size
         if (!L.tuned_bf3) return false;
         L.b_nt = L.t_nt; L.b_ppw = L.t_ppw; L.b_pxt = L.t_pxt; L.b_ks = L.t_ks; L.b_wco = L.t_wco;
@@ -1465,11 +1504,13 @@ extern "C" int iaf_stack_set_training(iaf_stack_t* s, int on) {
     for (int l = 0; l < s->nlayers; ++l) {
         GemmLayer& L = s->L[l];
         if (!L.wpt) HIP_TRY(hipMalloc(&L.wpt, (size_t)L.nchunk * NTAPS * L.ncot * 256 * sizeof(float)));
+        if (!L.wpt3 && L.ncot % 2 == 0) HIP_TRY(hipMalloc(&L.wpt3, (size_t)(L.ncot / 2) * NTAPS * L.nchunk * 3 * 64 * 16));
         GemmLayer& T = s->T[l];
         T = GemmLayer();
         T.cin = L.cout; T.cout = L.cin; T.nchunk = L.ncot; T.ncot = L.nchunk;
         T.zerodiag = L.zerodiag; T.npair = 1;
         T.wp = L.wpt; T.bias = nullptr; T.border = nullptr; T.lim = nullptr; T.wpt = nullptr;
+        T.wp3 = L.wpt3;            // the data gradient runs the bf16x3 kernel where its launch-shape rule takes it (bf3_select)
         T.nt = 1; T.pxt = 4; T.wco = 1; T.ks = 1; T.user_tuned = false;
     }
     s->training = true;

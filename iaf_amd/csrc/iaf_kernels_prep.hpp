@@ -401,3 +401,47 @@ __global__ __launch_bounds__(256) void iaf_prep_kernel(PrepArgs a) {
         if (i < a.nlayers && (int)blockIdx.x >= a.L[i].tile_begin) L = a.L[i];
     prep_dispatch(L, blockIdx.x - L.tile_begin, red, s_scale);
 }
+
+// ---------------------------------------------------------------------------------------------
+// training: the TRANSPOSED bf16x3 pack (data gradient dX = W^T dY on the bf16 matrix cores, iaf_conv_bf3.hpp with EPI_DGRAD)
+// ---------------------------------------------------------------------------------------------
+// Written from the transposed fp32 pack `wpt` the prep kernels above leave behind in training mode:
+//   wpt  [K chunk = packed c_out / 16][tap][N tile = c_in / 16][lane = kk * 16 + n][4]   = W^T[n][16 chunk + 4 kk + r]
+//   wpt3 [K pair  = packed c_out / 32][tap][N tile][plane h/m/l][lane = kk3 * 16 + n][8 bf16] = W^T[n][32 pair + 8 kk3 + e]
+// i.e. the fragment of K pair P, lane (kk3, n) is the two 16-byte rows (kk = 2 (kk3 & 1), +1) of chunk 2 P + (kk3 >> 1):
+// an elementwise re-layout + three-way split, one thread per (fragment, lane).  Up to PACKT3_MAX layers per launch.
+#define PACKT3_MAX 16
+struct PackT3Layer { const float* src; void* dst; int ntp, nct, begin; };
+struct PackT3Args { PackT3Layer L[PACKT3_MAX]; int n, total; };
+
+__global__ __launch_bounds__(256) void iaf_pack_t3_kernel(PackT3Args a) {
+    typedef float pf32x4 __attribute__((ext_vector_type(4)));
+    typedef __bf16 pb16x2 __attribute__((ext_vector_type(2)));
+    typedef float pf32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned pu32x4 __attribute__((ext_vector_type(4)));
+    const int item = blockIdx.x * 256 + threadIdx.x;
+    if (item >= a.total) return;
+    PackT3Layer L = a.L[0];
+#pragma unroll
+    for (int i = 1; i < PACKT3_MAX; ++i)
+        if (i < a.n && item >= a.L[i].begin) L = a.L[i];
+    const int local = item - L.begin, lane3 = local & 63, frag = local >> 6;
+    const int cit = frag % L.nct, pt = frag / L.nct, t = pt % L.ntp, P = pt / L.ntp;
+    const int kk3 = lane3 >> 4, n = lane3 & 15;
+    const pf32x4* src4 = (const pf32x4*)L.src + ((size_t)((2 * P + (kk3 >> 1)) * L.ntp + t) * L.nct + cit) * 64;
+    const pf32x4 a0 = src4[(2 * (kk3 & 1)) * 16 + n], a1 = src4[(2 * (kk3 & 1) + 1) * 16 + n];
+    const float w[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+    pu32x4 ph, pm, pl;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const pf32x2 x = {w[2 * k], w[2 * k + 1]};
+        const pb16x2 hb = __builtin_convertvector(x, pb16x2);
+        const pf32x2 r1 = x - __builtin_convertvector(hb, pf32x2);
+        const pb16x2 mb = __builtin_convertvector(r1, pb16x2);
+        const pf32x2 r2 = r1 - __builtin_convertvector(mb, pf32x2);
+        const pb16x2 lb = __builtin_convertvector(r2, pb16x2);
+        ph[k] = __builtin_bit_cast(unsigned, hb); pm[k] = __builtin_bit_cast(unsigned, mb); pl[k] = __builtin_bit_cast(unsigned, lb);
+    }
+    pu32x4* q = (pu32x4*)L.dst + (((size_t)(P * L.ntp + t) * L.nct + cit) * 3) * 64 + lane3;
+    q[0] = ph; q[64] = pm; q[128] = pl;
+}

@@ -322,8 +322,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int toff = tap < 2 ? tap : RS + tap - 3;          // slots: (0,0) (0,1) (1,-1) (1,0) (1,1)
             return xb[decltype(q_c)::value] + toff * in_s16 + pair * 4;
         };
+        // x operand (three planes per pixel tile): read from LDS one pixel tile ahead of its MFMAs -- or, in phases whose
+        // pixel tiles carry only 6-12 MFMAs (the output pair: less MFMA time than an LDS round trip), a whole STEP ahead:
+        // all pixel tiles of step s + 1 are requested while step s multiplies (double buffer by ring-slot parity)
+        constexpr bool XAHEAD = (NTW <= 2) && (U % 2 == 0);
         f32x4 xn[3];
-        {
+        f32x4 xs[XAHEAD ? 2 : 1][XAHEAD ? NPT : 1][3];
+        if constexpr (XAHEAD) {
+            static_for<NPT>([&](auto q_c) {
+                const int a = xaddr(q_c, s0);
+                xs[0][decltype(q_c)::value][0] = smem4[a]; xs[0][decltype(q_c)::value][1] = smem4[a + in_c8];
+                xs[0][decltype(q_c)::value][2] = smem4[a + 2 * in_c8];
+            });
+        } else {
             const int a = xaddr(std::integral_constant<int, 0>{}, s0);
             xn[0] = smem4[a]; xn[1] = smem4[a + in_c8]; xn[2] = smem4[a + 2 * in_c8];
         }
@@ -336,10 +347,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 constexpr int LO = (q * NTW * 3) / NPT, HI = ((q + 1) * NTW * 3) / NPT;
                 ring_load(std::integral_constant<int, LO>{}, std::integral_constant<int, HI>{}, wr[(I + RD) % U], wbase, ncot, tiles, nstep,
                           s + RD);
-                const bf16x8 xh = __builtin_bit_cast(bf16x8, xn[0]);
-                const bf16x8 xm = __builtin_bit_cast(bf16x8, xn[1]);
-                const bf16x8 xl = __builtin_bit_cast(bf16x8, xn[2]);
-                {
+                bf16x8 xh, xm, xl;
+                if constexpr (XAHEAD) {
+                    xh = __builtin_bit_cast(bf16x8, xs[I & 1][q][0]);
+                    xm = __builtin_bit_cast(bf16x8, xs[I & 1][q][1]);
+                    xl = __builtin_bit_cast(bf16x8, xs[I & 1][q][2]);
+                    const int a = xaddr(q_c, s + 1);
+                    xs[(I + 1) & 1][q][0] = smem4[a]; xs[(I + 1) & 1][q][1] = smem4[a + in_c8]; xs[(I + 1) & 1][q][2] = smem4[a + 2 * in_c8];
+                } else {
+                    xh = __builtin_bit_cast(bf16x8, xn[0]);
+                    xm = __builtin_bit_cast(bf16x8, xn[1]);
+                    xl = __builtin_bit_cast(bf16x8, xn[2]);
                     const int a = (q + 1 < NPT) ? xaddr(std::integral_constant<int, (q + 1) % NPT>{}, s)
                                                 : xaddr(std::integral_constant<int, 0>{}, s + 1);
                     xn[0] = smem4[a]; xn[1] = smem4[a + in_c8]; xn[2] = smem4[a + 2 * in_c8];
@@ -584,7 +602,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             stf(p.out1 + img_z, gi, s_raw);
         } else if (p.mode == MODE_IAF) {
             const float m = m_raw * 0.1f, s = s_raw * 0.1f;        // tf_train.py:70
-            stf(p.out0 + img_z, gi, (fz[e] - m) / __expf(s));      // tf_train.py:71
+            stf(p.out0 + img_z, gi, (fz[e] - m) * __expf(-s));     // tf_train.py:71: (z - m) / exp(s); x * exp(-s) instead of the
+                                                                   // 10-instruction IEEE division: <= 2 ulp from it, 1e-7 relative
             stf(p.out1 + img_z, gi, s);                            // tf_train.py:72
         } else if (p.mode == MODE_INVERSE) {
             const float m = m_raw * 0.1f, s = s_raw * 0.1f;
@@ -596,12 +615,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const float logvar = 2.f * fq[e][1];
             const float z0 = mean + __expf(0.5f * logvar) * fq[e][2];                             // :63
             const float d0 = z0 - mean;
-            float logqs = -0.5f * (1.8378770664093453f + logvar + d0 * d0 / __expf(logvar));     // :68
-            const float zz = (z0 - m) / __expf(s);                                                // :71
+            float logqs = -0.5f * (1.8378770664093453f + logvar + d0 * d0 * __expf(-logvar));    // :68 (x / exp(v) as x * exp(-v))
+            const float zz = (z0 - m) * __expf(-s);                                               // :71
             logqs += s;                                                                           // :72
             const float plv = 2.f * fq[e][4];                                                     // :56
             const float d1 = zz - fq[e][3];
-            const float logps = -0.5f * (1.8378770664093453f + plv + d1 * d1 / __expf(plv));      // :73
+            const float logps = -0.5f * (1.8378770664093453f + plv + d1 * d1 * __expf(-plv));     // :73
             stf(p.out0 + img_z, gi, zz);
             if (p.out1) stf(p.out1 + img_z, gi, s);
             klv[e] = logqs - logps;                                                               // :75

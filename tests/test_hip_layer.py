@@ -413,6 +413,47 @@ def test_wnconv2d_backward_vs_autograd_oracle(amd, shape):
     assert _relerr(host(db), pt["b"].grad.numpy()) < 1e-4
 
 
+@pytest.mark.parametrize("shape", [(16, 160, 384, 16, 16), (16, 192, 160, 16, 16), (32, 160, 160, 16, 16), (16, 160, 448, 16, 16)],
+                         ids=lambda s: "B%d_%dto%d_%dx%d" % s)
+def test_wnconv2d_data_gradient_on_the_bf16_matrix_cores(amd, shape):
+    """from 4096 pixels on the data gradient dX = W^T dY of a plain conv runs the bf16x3 kernel on the TRANSPOSED bf16x3 pack
+    (iaf_pack_t3_kernel; K = n_out up to 384 fits the LDS tile, 448 stays on the exact-fp32 kernel): against torch-fp64
+    autograd of layers.py:52-64, and against the exact-fp32 kernels on the same inputs (fp32-grade: not just inside 1e-4)"""
+    from oracle import iaf_grad_oracle as G
+    B, n_in, n_out, H, W = shape
+    rng = np.random.RandomState(72)
+    p = gi.conv_params(rng, n_in, n_out)
+    x, dy = rng.standard_normal((B, n_in, H, W)), rng.standard_normal((B, n_out, H, W))
+    V, g, b = dev(p["V"]), dev(p["g"]), dev(p["b"])
+    res = dev(rng.standard_normal(x.shape))
+    got = {}
+    for prec in ("bf16x3", "f32"):
+        conv = amd.WNConv2d(n_in, n_out)
+        conv.set_precision(prec)
+        conv.set_training(True)
+        conv.prepare(V, g, b)
+        (dx,), dV, dg, db = conv.backward(dev(x), [dev(dy)], V, g, elu_input=True, dy_scale=0.1, dx_residual=res)
+        got[prec] = [host(dx) - host(res), host(dV), host(dg), host(db)]
+    xt = G._t(f32(x), True)
+    pt = {k: G._t(f32(v), True) for k, v in p.items()}
+    chunk = 4                                        # (fp64 autograd of a 16 x 160 x 16 x 16 conv in slices: memory)
+    gx = []
+    for b0 in range(0, B, chunk):
+        xs = G._t(f32(x[b0:b0 + chunk]), True)
+        y = 0.1 * G.conv2d(torch.nn.functional.elu(xs), pt["V"], pt["g"], pt["b"])
+        (y * G._t(f32(dy[b0:b0 + chunk]))).sum().backward()
+        gx.append(xs.grad.numpy())
+    gx = np.concatenate(gx)
+    for prec in ("bf16x3", "f32"):
+        assert _relerr(got[prec][0], gx) < 1e-4
+        assert _relerr(got[prec][1], pt["V"].grad.numpy()) < 1e-4
+        assert _relerr(got[prec][2], pt["g"].grad.numpy()) < 1e-4
+        assert _relerr(got[prec][3], pt["b"].grad.numpy()) < 1e-4
+    e3, e32 = _relerr(got["bf16x3"][0], gx), _relerr(got["f32"][0], gx)
+    print("dX rel err vs fp64 autograd: bf16x3 data gradient %.3g, exact fp32 %.3g" % (e3, e32))
+    assert e3 <= 2.0 * e32 + 1e-6
+
+
 @pytest.mark.parametrize("size", [None, (8, 16, 16)], ids=["fixture_B2_8x8", "B8_16x16"])
 @pytest.mark.parametrize("kl_min", [0.25, 0.0])
 def test_iaf_layer_backward_vs_autograd_oracle(amd, kl_min, size):

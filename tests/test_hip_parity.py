@@ -265,6 +265,39 @@ def test_iaf_step_backward_vs_autograd_oracle(amd, shape):
             assert torch.count_nonzero(grads[k][torch.from_numpy(mask == 0).cuda()]).item() == 0
 
 
+@pytest.mark.parametrize("shape", [(16, 32, 64, 1, 16, 16), (32, 32, 160, 2, 16, 16), (16, 64, 128, 4, 16, 16)],
+                         ids=lambda s: "B%d_z%d_h%d_d%d_%dx%d" % s)
+def test_iaf_step_data_gradients_on_the_bf16_matrix_cores(amd, shape):
+    """from 4096 pixels on the stack's data gradients (dX = W^T dY per layer: transposed bf16x3 packs written by
+    iaf_pack_t3_kernel behind the weight prep, the bf16x3 conv kernel with mirrored taps and the EPI_DGRAD epilogue) run on
+    the bf16 matrix cores: every gradient against the exact-fp32 kernels on the same inputs (fp32 round-off apart), dz and
+    dcontext against torch-fp64 autograd on a slice of the batch"""
+    from oracle import iaf_grad_oracle as G
+    B, n_z, n_h, d, H, W = shape
+    params, z, ctx = _rand_case(1900 + n_h, *shape)
+    rng = np.random.RandomState(23)
+    dzn, dls = rng.standard_normal(z.shape), rng.standard_normal(z.shape)
+    dp = dev_params(params)
+    res = {}
+    for prec in ("bf16x3", "f32"):
+        stack = amd.ARStack(n_z, [n_h] * d)
+        stack.set_precision(prec)
+        stack.set_training(True)
+        stack.prepare(dp)
+        zd, cd = dev(z), dev(ctx)
+        z_new, logsd = stack.iaf_step_train(zd, cd)
+        dz, dctx, grads = stack.iaf_step_backward(zd, cd, z_new, logsd, dev(dzn), dev(dls), dp)
+        res[prec] = dict(dz=host(dz), dctx=host(dctx), **{k: host(v) for k, v in grads.items()})
+    for k in res["f32"]:
+        a, b_ = res["bf16x3"][k], res["f32"][k]
+        assert np.isfinite(a).all()
+        assert np.abs(a - b_).max() <= 3e-5 * max(np.abs(b_).max(), 1e-6), k       # (the forward differs by fp32 round-off too)
+    nb = 2
+    ref, _, _ = G.iaf_step_grads(f32(z[:nb]), f32(ctx[:nb]), f32_params(params), [n_h] * d, f32(dzn[:nb]), f32(dls[:nb]))
+    _rel_close(res["bf16x3"]["dz"][:nb], ref["z"], 1e-4, "dz")
+    _rel_close(res["bf16x3"]["dctx"][:nb], ref["context"], 1e-4, "dcontext")
+
+
 @pytest.mark.parametrize("kl_min", [0.0, 0.25])
 @pytest.mark.parametrize("shape", [(4, 32, 160, 2, 16, 16), (3, 32, 64, 1, 8, 8), (2, 64, 64, 4, 4, 4),
                                    (32, 32, 160, 2, 16, 16)],      # last: BASELINE configs[1] at full size
