@@ -684,7 +684,7 @@ extern "C" int iaf_conv3x3_backward(iaf_conv3x3_t* c, const float* x, const floa
             p.split_ptr[k] = dxs[k < n_dxs ? k : n_dxs - 1];
         }
         // bf16x3 unless the conv's precision is fp32 or a backward search measured the fp32 kernel faster at this size
-        const int choice3 = (c->bf3_choice == 3 || !c->T.wp3) ? 3 : (c->T.tuned_P == (long long)P && c->T.tuned_W == W && !c->T.tuned_bf3) ? 3 : 1;
+        const int choice3 = (c->precision != IAF_PRECISION_BF16X3 || c->bf3_choice == 3 || !c->T.wp3) ? 3 : (c->T.tuned_P == (long long)P && c->T.tuned_W == W && !c->T.tuned_bf3) ? 3 : 1;
         if ((rc = conv3x3_launch(c->T, p, EPI_DGRAD9, IN_PIXMAJOR, false, true, st, IAF_VARIANT_TF, choice3))) return rc;
     }
     // (3) weight gradient: partials over pixel ranges, then reduce (+ column sums of dY for db)
@@ -775,7 +775,7 @@ extern "C" int iaf_conv3x3_autotune_backward(iaf_conv3x3_t* c, const float* x, c
         }
     // ... and the bf16x3 data gradient in its rule shape (conv3x3_bf3_shape), if this conv has the transposed bf16x3 pack
     bool bf3_wins = false;
-    if (rc == IAF_OK && T.wp3 && c->bf3_choice != 3) {
+    if (rc == IAF_OK && T.wp3 && c->bf3_choice != 3 && c->precision == IAF_PRECISION_BF16X3) {
         T.user_tuned = false;
         T.tuned_bf3 = true;
         for (int r = 0; r < 2 && rc == IAF_OK; ++r) rc = run();

@@ -4,7 +4,7 @@
 # hipGraph-replayed bench.py did not finish in 400 s (round 2) -- PMC passes go over tools/run_step.py (eager, a few launches).
 set -x
 R=$GRAFT_REPO_ROOT
-RD=${ROUND:-r02}
+RD=${ROUND:-r03}
 O=$R/gpurun_out/$RD
 mkdir -p $O/pmc
 cd /tmp && export TMPDIR=/tmp
@@ -17,7 +17,7 @@ python $R/bench.py --iw-eval --steps 100 > $O/bench_iw_eval_n1.json 2> /dev/null
 IAF_BENCH_FORCE_DIST=1 python $R/bench.py --train --steps 50 > $O/bench_train_n1.json 2> /dev/null
 IAF_BENCH_FORCE_DIST=1 python $R/bench.py --train --layers --steps 20 --warmup 5 > $O/bench_train_layers_n1.json 2> /dev/null
 # kernel trace of the SAME command as the headline bench line
-timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb -o bench -- python $R/bench.py --no-cpu-baseline > $O/bench_rocprof_line.json 2>/dev/null
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb -o bench -- python $R/bench.py --no-cpu-baseline > $O/bench_rocprof_line.json 2>/dev/null
 cp /tmp/pb/*kernel_stats.csv $O/bench_kernel_stats.csv
 python - <<'PY'
 import csv, collections, glob, os
@@ -25,27 +25,26 @@ f = glob.glob('/tmp/pb/*kernel_trace.csv')[0]
 acc = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
     acc[(r['Kernel_Name'], r.get('Grid_Size_X', r.get('Grid_Size', '')), r.get('Workgroup_Size_X', r.get('Workgroup_Size', '')))].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
-out = os.environ['GRAFT_REPO_ROOT'] + '/gpurun_out/' + os.environ.get('ROUND', 'r02') + '/bench_kernel_trace_by_grid.csv'
+out = os.environ['GRAFT_REPO_ROOT'] + '/gpurun_out/' + os.environ.get('ROUND', 'r03') + '/bench_kernel_trace_by_grid.csv'
 with open(out, 'w') as o:
     o.write('kernel,grid_x,wg_x,calls,avg_ns,total_ns\n')
     for (k, g, w), v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
         o.write('"%s",%s,%s,%d,%.1f,%d\n' % (k, g, w, len(v), sum(v) / len(v), sum(v)))
 PY
-# PMC passes (one counter set per pass): the one-launch step (default path), and the layer-by-layer kernels it replaced
-# (bf16x3 with the launch shapes the autotune used to pick, and exact fp32)
+# PMC passes (one counter set per pass) over the one-launch step (the layer-by-layer kernels' counters: profiles/r02/pmc/)
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS"; do
   n=$(echo $c | tr ' ' '_')
   timeout 90 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmcs_$n -o pmc -- python $R/tools/run_step.py --hw 16 --reps 10 --precision bf16x3 > /dev/null 2>&1
   cp /tmp/pmcs_$n/*counter_collection.csv $O/pmc/step_${n}_counter_collection.csv
-  timeout 90 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$n -o pmc -- python $R/tools/run_step.py --hw 16 --reps 10 --precision bf16x3 --tune-bf3 "0:2,1,4,1;1:5,2,1,4;2:2,2,1,4" > /dev/null 2>&1
-  cp /tmp/pmc_$n/*counter_collection.csv $O/pmc/bf16x3_${n}_counter_collection.csv
-  timeout 90 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmcf_$n -o pmc -- python $R/tools/run_step.py --hw 16 --reps 10 --precision f32 > /dev/null 2>&1
-  cp /tmp/pmcf_$n/*counter_collection.csv $O/pmc/f32_${n}_counter_collection.csv
 done
 python $R/tools/pmc_summary.py $O/pmc > $O/pmc_summary.txt 2>&1
-python $R/tools/bf3_sweep.py --sweep > $O/bf3_sweep_B32.txt 2>&1
-python $R/tools/bf3_sweep.py --sweep --batch 256 --hw 16 > $O/bf3_sweep_B256.txt 2>&1
+python $R/tools/make_profile_json.py $O $RD > $O/make_profile_json.txt 2>&1
 python $R/tools/bench_configs.py > $O/bench_configs.md 2>/dev/null
-for hw in 16 8; do python $R/tools/fused_stamps.py --hw $hw; done > $O/fused_step_stamps.txt 2>&1
-(python $R/tools/soak.py --iters 60000 --fresh 1500) > $O/soak_prod_long.txt 2>&1
-tail -3 $O/pytest_gpu.txt; cut -c1-300 $O/bench_n1.json; tail -2 $O/soak_prod_long.txt
+for hw in 16 8; do python $R/tools/fused_stamps.py --hw $hw; done 2>&1 | grep -v amdgpu.ids > $O/fused_step_stamps.txt
+python $R/tools/layer_bench.py > $O/layer_bench.txt 2>&1
+python $R/tools/layer_train_bench.py > $O/layer_train_bench.txt 2>&1
+# which kernels a training step of one whole IAFLayer runs (data gradients on the bf16 matrix cores: EPI = 2 instantiations)
+timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pl -o lt -- python $R/tools/layer_train_bench.py > /dev/null 2>&1
+cp /tmp/pl/*kernel_stats.csv $O/layer_train_kernel_stats.csv
+(python $R/tools/soak.py --iters 20000 --fresh 1000) > $O/soak_prod.txt 2>&1
+tail -3 $O/pytest_gpu.txt; python $R/tools/show_bench.py $O/bench_n1.json; cat $O/make_profile_json.txt; cat $O/fused_step_stamps.txt; cat $O/layer_train_bench.txt | tail -3; head -12 $O/layer_train_kernel_stats.csv | cut -c1-160; tail -2 $O/soak_prod.txt
