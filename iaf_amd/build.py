@@ -30,7 +30,9 @@ HEADERS = [os.path.join(ROOT, "include", "iaf_hip.h")] + sorted(
 def _units():
     units = [(os.path.join(CSRC, "iaf_engine.hip"), os.path.join(OBJDIR, "iaf_engine.o"), []),
              # host-only: the RCCL gradient exchange (librccl is dlopen'ed at run time, no link dependency)
-             (os.path.join(CSRC, "iaf_comm.cpp"), os.path.join(OBJDIR, "iaf_comm.o"), ["-x", "hip"])]
+             (os.path.join(CSRC, "iaf_comm.cpp"), os.path.join(OBJDIR, "iaf_comm.o"), ["-x", "hip"]),
+             # the weight gradient on the bf16 matrix cores (transposing LDS reads)
+             (os.path.join(CSRC, "iaf_wgrad_bf3.hip"), os.path.join(OBJDIR, "iaf_wgrad_bf3.o"), [])]
     for pxt, wco, ks in SHAPES:
         units.append((os.path.join(CSRC, "iaf_conv_inst.hip"), os.path.join(OBJDIR, "iaf_conv_%d_%d_%d.o" % (pxt, wco, ks)),
                       ["-DIAF_PXT=%d" % pxt, "-DIAF_WCO=%d" % wco, "-DIAF_KS=%d" % ks]))

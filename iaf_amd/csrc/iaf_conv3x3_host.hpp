@@ -690,7 +690,7 @@ extern "C" int iaf_conv3x3_backward(iaf_conv3x3_t* c, const float* x, const floa
     // (3) weight gradient: partials over pixel ranges, then reduce (+ column sums of dY for db)
     const unsigned short* tapmask = nullptr;
     if ((rc = tapmask_for(B, H, W, st, tw.tapmask, &tapmask))) return rc;
-    if ((rc = launch_wgrad(nullptr, L, tw.xe, tw.dyc, tw.part, tapmask, B, H, W, st))) return rc;
+    if ((rc = launch_wgrad(nullptr, L, tw.xe, tw.dyc, tw.part, tapmask, B, H, W, st, 1, c->precision == IAF_PRECISION_BF16X3))) return rc;
     const int nslab = (P + 31) / 32 < 256 ? (P + 31) / 32 : 256;
     const int px_per_slab = (P + nslab - 1) / nslab;
     float* dWbuf = c->defer_wn ? c->own_dW : tw.dW;

@@ -1717,8 +1717,10 @@ static int tapmask_for(int B, int H, int W, hipStream_t st, unsigned short* ws_c
 }
 
 // tap_sign = -1: the Theano statement's taps look left / above (launch_gemm)
+// bf3: run the GEMM on the bf16 matrix cores (iaf_wgrad_bf3.hip) where its tiling covers the conv (cin % 32 == 0, an output block
+// of 4 / 10 / 12 / 14 tiles divides cout); IAF_WGRAD_BF3=0: dev knob, never
 static int launch_wgrad(const iaf_stack_t* s, const GemmLayer& L, const float* x, const float* dy, float* part,
-                        const unsigned short* tapmask, int B, int H, int W, hipStream_t st, int tap_sign = 1) {
+                        const unsigned short* tapmask, int B, int H, int W, hipStream_t st, int tap_sign = 1, bool bf3 = false) {
     WgradP p;
     memset(&p, 0, sizeof(p));
     p.x = x; p.dy = dy; p.part = part; p.tapmask = tapmask;
@@ -1733,6 +1735,19 @@ static int launch_wgrad(const iaf_stack_t* s, const GemmLayer& L, const float* x
     for (int t = 0; t < ntaps; ++t) {
         p.tap_dh[t] = L.full3x3 ? t / 3 - 1 : tap_sign * tf_dh[t];
         p.tap_dw[t] = L.full3x3 ? t % 3 - 1 : tap_sign * tf_dw[t];
+    }
+    static const bool bf3_env = !(getenv("IAF_WGRAD_BF3") && getenv("IAF_WGRAD_BF3")[0] == '0');
+    if (bf3 && bf3_env && L.cin % 32 == 0 && L.cout % 16 == 0) {
+        static const int cand[4] = {14, 12, 10, 4};
+        const int nt = L.cout / 16;
+        int ncob = 0;
+        for (int c : cand)
+            if (nt % c == 0) { ncob = c; break; }
+        if (ncob) {
+            p.gx = ntaps * (L.cin / 32);
+            p.gz = nt / ncob;
+            return iaf_launch_wgrad_bf3(&p, ncob, st);
+        }
     }
     if (w.bw) {
         switch (w.bw * 10 + w.nb) {
@@ -1853,7 +1868,7 @@ extern "C" int iaf_step_backward(iaf_stack_t* s, const float* z, const float* co
             p.out0 = (l - 1 == 0) ? dcontext : nullptr;
         }
         if ((rc = launch_gemm(s, s->T[l], EPI_DGRAD, true, -1, p, IN_PIXMAJOR, st))) return rc;
-        if ((rc = launch_wgrad(s, s->L[l], x_in, dy, tw.part[l], tapmask, B, H, W, st, tap_sign))) return rc;
+        if ((rc = launch_wgrad(s, s->L[l], x_in, dy, tw.part[l], tapmask, B, H, W, st, tap_sign, s->precision == IAF_PRECISION_BF16X3))) return rc;
         reduce_add(l, dy);
         if (l == d) {
             wn_add(d, l, s->n_z, 2, 0);       // layer_out_0 (mean tiles)

@@ -34,28 +34,7 @@ __global__ __launch_bounds__(256) void iaf_bwd_affine_kernel(const float* __rest
 //     Workgroup = (tap, pair of ci tiles, pixel range); its 4 waves split the range, reduce through LDS and write one
 //     partial [krange][tap][cin][cout]; the partials are summed by iaf_wn_bwd_kernel.  Operands are dword loads
 //     straight from L1/L2 (A: 2 per K step, B: NCOT per K step for 2*NCOT MFMAs).
-struct WgradP {
-    const float* x;      // [P][cin]
-    const float* dy;     // [P][cout]
-    float* part;         // [nrange][ntaps][cin][cout]
-    int B, H, W, HW, P, cin, cout, nrange, px_per_range;
-    int ntaps;           // 5 (masked) or 9 (plain)
-    int tap_dh[MAXTAPS], tap_dw[MAXTAPS];
-    const unsigned short* tapmask;   // [P]: bit (dh+1)*3+(dw+1) set when pixel p's neighbour (dh,dw) lies inside its image
-    int gx, gz;          // workgroups per pixel range: gx = ntaps * ceil(cin/32) operand blocks, gz output-channel blocks
-};
-
-// Workgroup -> (operand block x, pixel range, output block z), 1-D grid, the workgroups of a pixel range adjacent.
-// (Dealing whole pixel ranges to each XCD -- workgroup i runs on XCD i % 8, each XCD has its own 4 MB L2 -- so that an
-// L2 only ever sees 1/8 of the pixels was measured and changed nothing: the operand streams are not L2-capacity bound.)
-__device__ __forceinline__ void wgrad_decode(const WgradP& p, int& x, int& range, int& z) {
-    const int per_range = p.gx * p.gz;
-    const int v = blockIdx.x;
-    range = v / per_range;
-    const int rem = v - range * per_range;
-    z = rem / p.gx;
-    x = rem - z * p.gx;
-}
+#include "iaf_wgrad_types.hpp"
 
 // border table of the weight gradient: the 9 in-image bits of every pixel, computed once per backward instead of two
 // integer divisions per K step per lane (which cost as much issue time as the MFMAs of the step)
