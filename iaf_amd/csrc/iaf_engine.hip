@@ -1718,7 +1718,8 @@ static int tapmask_for(int B, int H, int W, hipStream_t st, unsigned short* ws_c
 
 // tap_sign = -1: the Theano statement's taps look left / above (launch_gemm)
 // bf3: run the GEMM on the bf16 matrix cores (iaf_wgrad_bf3.hip) where its tiling covers the conv (cin % 32 == 0, an output block
-// of 4 / 10 / 12 / 14 tiles divides cout); IAF_WGRAD_BF3=0: dev knob, never
+// of 4 / 10 / 12 / 14 tiles divides cout).  OFF by default: the first version of that kernel is slower than the fp32 MFMA one
+// (40 / 127 / 150 us against 38 / 87 / 104 us on the layer's convs, profiles/r03/experiments/ab_wgrad.txt); IAF_WGRAD_BF3=1 opts in
 static int launch_wgrad(const iaf_stack_t* s, const GemmLayer& L, const float* x, const float* dy, float* part,
                         const unsigned short* tapmask, int B, int H, int W, hipStream_t st, int tap_sign = 1, bool bf3 = false) {
     WgradP p;
@@ -1736,7 +1737,7 @@ static int launch_wgrad(const iaf_stack_t* s, const GemmLayer& L, const float* x
         p.tap_dh[t] = L.full3x3 ? t / 3 - 1 : tap_sign * tf_dh[t];
         p.tap_dw[t] = L.full3x3 ? t % 3 - 1 : tap_sign * tf_dw[t];
     }
-    static const bool bf3_env = !(getenv("IAF_WGRAD_BF3") && getenv("IAF_WGRAD_BF3")[0] == '0');
+    static const bool bf3_env = getenv("IAF_WGRAD_BF3") && getenv("IAF_WGRAD_BF3")[0] == '1';      // off unless asked for (see below)
     if (bf3 && bf3_env && L.cin % 32 == 0 && L.cout % 16 == 0) {
         static const int cand[4] = {14, 12, 10, 4};
         const int nt = L.cout / 16;

@@ -27,6 +27,17 @@ __device__ __forceinline__ wu32x2 lds_read_tr16_b64(unsigned addr) {
     return r;
 }
 
+// s_waitcnt lgkmcnt(N) that the six registers of a fragment set pass THROUGH: the compiler does not know that the outputs of
+// the load asm above are not there yet when it "returns", and nothing but a data dependency keeps a register-only consumer
+// (the MFMA) behind a bare wait statement (the first version of this kernel multiplied fragments still in flight)
+template <int N>
+__device__ __forceinline__ void lds_wait_frag(wu32x2 (&f)[3][2]) {
+    asm volatile("s_waitcnt lgkmcnt(%6)"
+                 : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[1][0]), "+v"(f[1][1]), "+v"(f[2][0]), "+v"(f[2][1])
+                 : "n"(N)
+                 : "memory");
+}
+
 template <int NCOB>
 __global__ __launch_bounds__(256) void iaf_wgrad_bf3_kernel(WgradP p) {
     static_assert(NCOB % 2 == 0, "two waves per input tile split the output tiles");
@@ -145,10 +156,11 @@ __global__ __launch_bounds__(256) void iaf_wgrad_bf3_kernel(WgradP p) {
                     bfr[(j + 1) & 1][pl][0] = lds_read_tr16_b64(ya + so + pl * YPL + 32 * (j + 1));
                     bfr[(j + 1) & 1][pl][1] = lds_read_tr16_b64(ya + so + pl * YPL + 32 * (j + 1) + 4 * YROW);
                 }
-                asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+                lds_wait_frag<6>(bfr[j & 1]);
             } else {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                lds_wait_frag<0>(bfr[j & 1]);
             }
+            if constexpr (j == 0) lds_wait_frag<(UW > 1 ? 6 : 0)>(af);      // (requested before the first output tile's: already there)
             const bf16x8 ah = IAF_WFRAG(af, 0), am = IAF_WFRAG(af, 1), al = IAF_WFRAG(af, 2);
             const bf16x8 bh = IAF_WFRAG(bfr[j & 1], 0), bm = IAF_WFRAG(bfr[j & 1], 1), bl = IAF_WFRAG(bfr[j & 1], 2);
             acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[j], 0, 0, 0);
