@@ -604,7 +604,7 @@ static size_t conv3x3_train_ws_floats(const iaf_conv3x3* c, long long P, ConvTra
     ConvTrainWs t;
     t.xe = take((size_t)P * c->n_in);
     t.dyc = take((size_t)P * c->n_out);
-    t.part = take((size_t)16 * MAXTAPS * c->n_in * c->n_out);
+    t.part = take((size_t)WGRAD_MAX_RANGES * MAXTAPS * c->n_in * c->n_out);
     t.dW = take((size_t)MAXTAPS * c->n_in * c->n_out);
     t.dbp = take((size_t)256 * c->n_out);
     t.tapmask = (unsigned short*)take(((size_t)P + 1) / 2);
@@ -700,7 +700,7 @@ extern "C" int iaf_conv3x3_backward(iaf_conv3x3_t* c, const float* x, const floa
         int nblk = (int)((n4 + 255) / 256);
         if (nblk > 1024) nblk = 1024;
         hipLaunchKernelGGL(iaf_wgrad_reduce_kernel, dim3(nblk + nslab), dim3(256), 0, st, tw.part, dWbuf,
-                           wgrad_nrange(P, L.cin, MAXTAPS, L.cout), n4, nblk, (const float*)tw.dyc, dbpbuf, P, L.cout, px_per_slab);
+                           wgrad_nrange(P, L.cin, MAXTAPS, L.cout, c->precision == IAF_PRECISION_BF16X3), n4, nblk, (const float*)tw.dyc, dbpbuf, P, L.cout, px_per_slab);
     }
     // (4) through the weight norm -- now, or in iaf_conv3x3_wn_bwd_batch_run with every other conv of the model
     if (c->deconv) {      // deconv2d's norm runs per INPUT channel over the rotated filter (layers.py:104): its own two launches

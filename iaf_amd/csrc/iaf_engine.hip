@@ -1541,15 +1541,41 @@ static bool wgrad_wide_shape(int cout, int* bw, int* nb) {
     return true;
 }
 
-struct WgradPlan { int bw, nb, ncot, gx, gz, nrange; };   // bw > 0: iaf_wgrad_wide_kernel<bw, nb>, else iaf_wgrad_kernel<ncot>
+struct WgradPlan { int bw, nb, ncot, gx, gz, nrange, bf3_ncob; };   // bf3_ncob > 0: iaf_wgrad_bf3_kernel<bf3_ncob>; bw > 0: iaf_wgrad_wide_kernel<bw, nb>; else iaf_wgrad_kernel<ncot>
+constexpr int WGRAD_MAX_RANGES = 32;             // what the partial buffers hold
 
 // Pixel ranges (the K split across workgroups; the partial buffer holds 16): a workgroup has ~5 us of fixed cost
 // (launch, first loads, the LDS reduction, its partial), equal-sized workgroups run in lockstep rounds, and two resident
 // workgroups per CU hide each other's load latency.  Measured on the layer's convs at 16x16 and 8x8 (B=32): 8 ranges
 // when an operand-block sweep already has >= 40 workgroups (the 9-tap convs), 16 otherwise (the masked stack).
-static WgradPlan wgrad_plan(long long P, int cin, int cout, int ntaps) {
+// bf16x3 weight gradient (iaf_wgrad_bf3.hip): used when the conv computes in bf16x3 and the kernel's tiling covers it;
+// IAF_WGRAD_BF3=0 keeps the fp32 MFMA kernels (dev knob for A/B runs)
+static bool wgrad_bf3_enabled() {
+    static const bool on = !(getenv("IAF_WGRAD_BF3") && getenv("IAF_WGRAD_BF3")[0] == '0');
+    return on;
+}
+
+static WgradPlan wgrad_plan(long long P, int cin, int cout, int ntaps, bool bf3 = false) {
     WgradPlan w;
     memset(&w, 0, sizeof(w));
+    if (bf3 && wgrad_bf3_enabled() && P % 8 == 0 && P >= 64 && (w.bf3_ncob = iaf_wgrad_bf3_ncob(cin, cout)) > 0) {
+        // a workgroup per (tap row, 32 input channels, output block, pixel range): enough ranges for TWO workgroups per CU (the
+        // kernel's split phase and MFMA phase overlap across co-resident workgroups, not within one), at least two K blocks
+        // of 32 pixels each
+        const int rows = ntaps == MAXTAPS ? 3 : 2;
+        w.gx = rows * (cin / 32);
+        w.gz = (cout / 16) / w.bf3_ncob;
+        static const int force = getenv("IAF_WGRAD_NRANGE") ? atoi(getenv("IAF_WGRAD_NRANGE")) : 0;               // dev knob
+        long long n = 512 / (w.gx * w.gz);                   // two full rounds of CUs, else one (320 workgroups: 29 us, 250: 27 us)
+        if (n > WGRAD_MAX_RANGES) n = 256 / (w.gx * w.gz);
+        if (force > 0) n = force;
+        if (n > WGRAD_MAX_RANGES) n = WGRAD_MAX_RANGES;
+        if (n > P / 64) n = P / 64;
+        if (n < 1) n = 1;
+        w.nrange = (int)n;
+        return w;
+    }
+    w.bf3_ncob = 0;
     w.gx = ntaps * ((cin + 31) / 32);
     const bool off32 = P * (cin > cout ? cin : cout) * 4 < (1LL << 32);      // the wide kernel's operand offsets are 32-bit
     if (off32 && cin % 16 == 0 && wgrad_wide_shape(cout, &w.bw, &w.nb)) {
@@ -1575,7 +1601,7 @@ static WgradPlan wgrad_plan(long long P, int cin, int cout, int ntaps) {
     w.nrange = (int)n;
     return w;
 }
-static int wgrad_nrange(long long P, int cin, int ntaps, int cout) { return wgrad_plan(P, cin, cout, ntaps).nrange; }
+static int wgrad_nrange(long long P, int cin, int ntaps, int cout, bool bf3) { return wgrad_plan(P, cin, cout, ntaps, bf3).nrange; }
 
 struct TrainWs {
     float* h[MAX_GEMM_LAYERS];
@@ -1602,7 +1628,7 @@ static size_t train_ws_floats(const iaf_stack_t* s, long long P, TrainWs* o, flo
     t.dy3 = take((size_t)P * 2 * s->n_z);
     t.zpm = take((size_t)P * s->n_z);
     for (int l = 0; l < s->nlayers; ++l) {
-        t.part[l] = take((size_t)16 * NTAPS * s->L[l].cin * s->L[l].cout);
+        t.part[l] = take((size_t)WGRAD_MAX_RANGES * NTAPS * s->L[l].cin * s->L[l].cout);
         t.dWeff[l] = take((size_t)NTAPS * s->L[l].cin * s->L[l].cout);
         t.dbp[l] = take((size_t)256 * s->L[l].cout);
         t.dbrd[l] = (s->variant != IAF_VARIANT_TF) ? take((size_t)256 * (NTAPS - 1) * s->L[l].cout) : nullptr;
@@ -1717,9 +1743,7 @@ static int tapmask_for(int B, int H, int W, hipStream_t st, unsigned short* ws_c
 }
 
 // tap_sign = -1: the Theano statement's taps look left / above (launch_gemm)
-// bf3: run the GEMM on the bf16 matrix cores (iaf_wgrad_bf3.hip) where its tiling covers the conv (cin % 32 == 0, an output block
-// of 4 / 10 / 12 / 14 tiles divides cout).  OFF by default: the first version of that kernel is slower than the fp32 MFMA one
-// (40 / 127 / 150 us against 38 / 87 / 104 us on the layer's convs, profiles/r03/experiments/ab_wgrad.txt); IAF_WGRAD_BF3=1 opts in
+// bf3: run the GEMM on the bf16 matrix cores (iaf_wgrad_bf3.hip) where its tiling covers the conv (wgrad_plan)
 static int launch_wgrad(const iaf_stack_t* s, const GemmLayer& L, const float* x, const float* dy, float* part,
                         const unsigned short* tapmask, int B, int H, int W, hipStream_t st, int tap_sign = 1, bool bf3 = false) {
     WgradP p;
@@ -1729,27 +1753,26 @@ static int launch_wgrad(const iaf_stack_t* s, const GemmLayer& L, const float* x
     p.cin = L.cin; p.cout = L.cout;
     const int ntaps = L.full3x3 ? MAXTAPS : NTAPS;
     p.ntaps = ntaps;
-    const WgradPlan w = wgrad_plan(p.P, L.cin, L.cout, ntaps);
+    const WgradPlan w = wgrad_plan(p.P, L.cin, L.cout, ntaps, bf3);
     p.nrange = w.nrange;
-    p.px_per_range = (int)(((long long)p.P + p.nrange - 1) / p.nrange + 15) / 16 * 16;
     static const int tf_dh[NTAPS] = {0, 0, 1, 1, 1}, tf_dw[NTAPS] = {0, 1, -1, 0, 1};
     for (int t = 0; t < ntaps; ++t) {
         p.tap_dh[t] = L.full3x3 ? t / 3 - 1 : tap_sign * tf_dh[t];
         p.tap_dw[t] = L.full3x3 ? t % 3 - 1 : tap_sign * tf_dw[t];
     }
-    static const bool bf3_env = getenv("IAF_WGRAD_BF3") && getenv("IAF_WGRAD_BF3")[0] == '1';      // off unless asked for (see below)
-    if (bf3 && bf3_env && L.cin % 32 == 0 && L.cout % 16 == 0) {
-        static const int cand[4] = {14, 12, 10, 4};
-        const int nt = L.cout / 16;
-        int ncob = 0;
-        for (int c : cand)
-            if (nt % c == 0) { ncob = c; break; }
-        if (ncob) {
-            p.gx = ntaps * (L.cin / 32);
-            p.gz = nt / ncob;
-            return iaf_launch_wgrad_bf3(&p, ncob, st);
+    if (w.bf3_ncob) {
+        p.px_per_range = (int)(((long long)p.P + p.nrange - 1) / p.nrange + 31) / 32 * 32;
+        for (int t = 0; t < ntaps; ++t) {                    // tap rows: equal dh, in order of first appearance
+            int gi = 0;
+            while (gi < p.ngroups && p.grp_dh[gi] != p.tap_dh[t]) ++gi;
+            if (gi == p.ngroups) { p.grp_dh[gi] = p.tap_dh[t]; p.grp_n[gi] = 0; ++p.ngroups; }
+            p.grp_tap[gi][p.grp_n[gi]++] = t;
         }
+        p.gx = w.gx; p.gz = w.gz;
+        (void)s;
+        return iaf_launch_wgrad_bf3(&p, w.bf3_ncob, st);
     }
+    p.px_per_range = (int)(((long long)p.P + p.nrange - 1) / p.nrange + 15) / 16 * 16;
     if (w.bw) {
         switch (w.bw * 10 + w.nb) {
             case 41: launch_wgrad_wide_t<4, 1>(p, w, st); break;
@@ -1823,7 +1846,7 @@ extern "C" int iaf_step_backward(iaf_stack_t* s, const float* z, const float* co
         const GemmLayer& L = s->L[l];
         ReduceLayer& r = ra.L[ra.n++];
         r.part = tw.part[l]; r.dW = tw.dWeff[l]; r.n4 = (size_t)NTAPS * L.cin * L.cout / 4;
-        r.nrange = wgrad_nrange(P, L.cin, NTAPS, L.cout);
+        r.nrange = wgrad_nrange(P, L.cin, NTAPS, L.cout, s->precision == IAF_PRECISION_BF16X3);
         int nblk = (int)((r.n4 + 255) / 256);
         if (nblk > 256) nblk = 256;
         r.blk_begin = ra.nblk_total;

@@ -15,6 +15,11 @@ struct WgradP {
     int tap_dh[MAXTAPS], tap_dw[MAXTAPS];
     const unsigned short* tapmask;   // [P]: bit (dh+1)*3+(dw+1) set when pixel p's neighbour (dh,dw) lies inside its image
     int gx, gz;          // workgroups per pixel range: gx = ntaps * ceil(cin/32) operand blocks, gz output-channel blocks
+    // iaf_wgrad_bf3.hip only: the taps grouped into rows of equal dh (gx = ngroups * cin/32 there)
+    int ngroups, grp_n[3], grp_dh[3], grp_tap[3][3];
+#ifdef IAF_WSTAMP
+    unsigned long long* dbg;     // [grid][4] phase ticks (tools/probe/wgrad_probe.hip)
+#endif
 };
 
 // Workgroup -> (operand block x, pixel range, output block z), 1-D grid, the workgroups of a pixel range adjacent.
@@ -30,6 +35,8 @@ __device__ __forceinline__ void wgrad_decode(const WgradP& p, int& x, int& range
 }
 
 
-// The same GEMM on the bf16 matrix cores (iaf_wgrad_bf3.hip): ncob = output tiles per workgroup (4, 10, 12 or 14; cout must be a
-// multiple of 16 * ncob, cin of 32); grid = p.gx * p.gz * p.nrange workgroups of 256 threads.  Returns a hipError_t / IAF status.
+// The same GEMM on the bf16 matrix cores (iaf_wgrad_bf3.hip): ncob = output tiles per workgroup (iaf_wgrad_bf3_ncob: 4, 10, 12 or
+// 14 dividing cout / 16, cin a multiple of 32; 0 = this conv is not covered); P % 8 == 0, px_per_range % 32 == 0, the tap rows
+// filled in; grid = p.gx * p.gz * p.nrange workgroups of 256 threads.  Returns a hipError_t / IAF status.
+extern "C" int iaf_wgrad_bf3_ncob(int cin, int cout);
 extern "C" int iaf_launch_wgrad_bf3(const WgradP* p, int ncob, hipStream_t st);
