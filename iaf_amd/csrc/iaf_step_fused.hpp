@@ -16,12 +16,15 @@
 // v_mfma_f32_16x16x32_bf16, reading the same fragment-ordered weight packs (PrepLayer.wp3).
 // LDS: three regions (z, h_even, h_odd) of pixel slots [row][W + 2 columns][plane h/m/l][channels] -- the two extra
 // columns and the rows past the image bottom hold zeros, so tap addressing is pure arithmetic (no validity masks).
-// Two waves per SIMD do not help: round 3 built an 8-wave variant (first layer split by pixel tiles, later layers and the
+// Two waves per SIMD did not help: round 3 built an 8-wave variant (first layer split by pixel tiles, later layers and the
 // output pair by K steps, partial sums handed over through the dead input region; bit-compatible, 233 GPU tests green) and
-// measured 29.1 vs 27.4 us at 16-pixel rows, 18.1 vs 16.0 at 8 (same box, alternating runs).  Its stamps show why: the older
-// wave of a SIMD runs its half of a K loop at the single-wave rate (18.7 ticks per MFMA = 16 shader cycles at the ~1.75 GHz the
-// chip sustains under this load: ONE wave already saturates the matrix pipe) and the younger wave runs its half AFTER it, so
-// the K loops take what they took, and issuing the prologue's loads, the barriers and the hand-over cost more.  Removed.
+// measured 29.1 vs 27.4 us at 16-pixel rows, 18.1 vs 16.0 at 8 (same box, alternating runs).  Its stamps showed the older wave
+// of a SIMD running its half of a K loop at the single-wave rate and the younger wave mostly after it, so the K loops took
+// what they took, and issuing the prologue's loads, the barriers and the hand-over cost more.  Removed.  (What one wave of a
+// SIMD can and cannot overlap, in wall-clock time: tools/probe/mfma_shadow.hip, profiles/r03/experiments/mfma_shadow.txt -- an
+// unrolled MFMA stream of ONE wave runs at the pipe's rate, 7.3 ns per 16x16x32 MFMA; every VALU instruction between two
+// MFMAs adds 1.1 - 1.6 ns, an LDS read 8 ns, an LDS write 13 ns; s_memtime ticks, the unit of the stamps below, change rate
+// with the number of waves per SIMD and only compare within one configuration.)
 // Work split: 4 waves, one per SIMD.  Hidden layers: wave w owns co tiles w, w+4, ... of every pixel tile (its weight
 // stream is disjoint from the other waves'; the activation fragments come from LDS); the tiles left over when the count is
 // not a multiple of 4 (n_h = 160: tiles 8, 9) are dealt out per (tile, pixel tile) so that every wave multiplies the

@@ -159,10 +159,15 @@ __device__ __forceinline__ void wgrad_bf3_row(const WgradP& p, char* wsm, int gr
     unsigned long long wst[4] = {0, 0, 0, 0}, wlast = wg_now();
 #endif
     // ---- K loop.  ONE LDS stage and a split phase / MFMA phase per block: what overlaps them is the OTHER workgroup of the CU
-    // (the stage and the registers are sized for two per CU) -- measured (tools/probe/mfma_shadow.hip): VALU work of the same
-    // wave does not hide under its own MFMAs (one wave of a SIMD gets an issue slot too rarely: 2 VALU per MFMA are free, 8
-    // cost 48 instead of 17.5 cycles), VALU of a second wave on the SIMD does, and two waves also issue MFMAs at 12 instead of
-    // 17.5 - 22 cycles apiece.  The next block's loads are issued before the MFMA phase and land under it.
+    // (the stage and the registers are sized for two per CU).  Measured in wall-clock time per MFMA of a SIMD (tools/probe/
+    // mfma_shadow.hip, profiles/r03/experiments/mfma_shadow.txt): one wave alone issues an MFMA every 9.4 ns in a rolled loop
+    // (7.3 ns = the pipe's rate, 2.3 PFLOP/s over 1024 SIMDs, unrolled); each VALU instruction it issues between two MFMAs adds
+    // 1.1 - 1.6 ns (they do not hide under its own MFMAs), a transposing LDS read 8 ns, an LDS write 13 ns.  With a second wave
+    // on the SIMD the read costs 1 ns, the write 3.6 ns, (MFMA + 2 VALU) 7 - 10 ns instead of 11.6.  A software pipeline inside
+    // one wave (the next block's split interleaved with this block's MFMAs, two LDS stages, one workgroup per CU) measured
+    // 46.4 us where the plain two-phase loop took 48.2 (160 -> 224 conv, B = 32, 16 x 16); on the 160 -> 448 conv this loop takes
+    // 87 us with one workgroup per CU and 71.5 us with two (the fp32 MFMA kernel: 104 us).
+    // The next block's loads are issued before the MFMA phase and land under it.
     if (nkb > 0) load_block(0);
     for (int kb = 0; kb < nkb; ++kb) {
         IAF_WST(3);

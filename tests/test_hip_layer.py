@@ -454,6 +454,42 @@ def test_wnconv2d_data_gradient_on_the_bf16_matrix_cores(amd, shape):
     assert e3 <= 2.0 * e32 + 1e-6
 
 
+@pytest.mark.parametrize("scale", [(1.0, 1.0), (3e4, 1e-5), (1e-6, 2e3)], ids=["unit", "x3e4_dy1e-5", "x1e-6_dy2e3"])
+@pytest.mark.parametrize("shape", [(3, 32, 64, 12, 12), (5, 64, 160, 8, 8), (2, 160, 224, 16, 16), (1, 96, 192, 24, 8)],
+                         ids=lambda s: "B%d_%dto%d_%dx%d" % s)
+def test_wnconv2d_weight_gradient_on_the_bf16_matrix_cores(amd, shape, scale):
+    """dV, dg, db of a plain conv with the weight gradient dW[tap] = X_shifted^T dY on the bf16 matrix cores (iaf_wgrad_bf3.hip:
+    tap-row workgroups, transposing LDS reads, border masks on the fragments) against torch-fp64 autograd of layers.py:52-64,
+    and against the exact-fp32 MFMA kernel on the same inputs.  Shapes: pixel counts that leave the last K block of a range
+    partial (432 = 13.5 blocks, 320 = 10, 192 = 6) and put image borders inside K blocks (12- and 24-pixel rows against
+    32-pixel blocks); scales: operands whose bf16x3 planes sit far from 1 (the split is by value, not by exponent)."""
+    from oracle import iaf_grad_oracle as G
+    B, n_in, n_out, H, W = shape
+    sx, sy = scale
+    rng = np.random.RandomState(73)
+    p = gi.conv_params(rng, n_in, n_out)
+    x, dy = sx * rng.standard_normal((B, n_in, H, W)), sy * rng.standard_normal((B, n_out, H, W))
+    V, g, b = dev(p["V"]), dev(p["g"]), dev(p["b"])
+    got = {}
+    for prec in ("bf16x3", "f32"):
+        conv = amd.WNConv2d(n_in, n_out)
+        conv.set_precision(prec)
+        conv.set_training(True)
+        conv.prepare(V, g, b)
+        (dx,), dV, dg, db = conv.backward(dev(x), [dev(dy)], V, g)
+        got[prec] = [host(dV), host(dg), host(db)]
+    xt = G._t(f32(x))
+    pt = {k: G._t(f32(v), True) for k, v in p.items()}
+    (G.conv2d(xt, pt["V"], pt["g"], pt["b"]) * G._t(f32(dy))).sum().backward()
+    want = [pt[k].grad.numpy() for k in ("V", "g", "b")]
+    for prec in ("bf16x3", "f32"):
+        for a, w_ in zip(got[prec], want):
+            assert _relerr(a, w_) < 1e-4
+    e3, e32 = _relerr(got["bf16x3"][0], want[0]), _relerr(got["f32"][0], want[0])
+    print("dV rel err vs fp64 autograd: bf16x3 weight gradient %.3g, exact fp32 %.3g" % (e3, e32))
+    assert e3 <= 2.0 * e32 + 1e-6
+
+
 @pytest.mark.parametrize("size", [None, (8, 16, 16)], ids=["fixture_B2_8x8", "B8_16x16"])
 @pytest.mark.parametrize("kl_min", [0.25, 0.0])
 def test_iaf_layer_backward_vs_autograd_oracle(amd, kl_min, size):
