@@ -862,17 +862,39 @@ def _halo_note(st, R, args):
         issued / sum(live), R)
 
 
+def _tri_skipped(nht, npair):
+    """(co tile, centre-tap step) units a channel-triangular hidden layer of the one-launch step neither loads nor multiplies
+    (iaf_step_fused.hpp, tri_live): tile slot j of wave w holds tile 4j + w (odd j: 4(j+1) - 1 - w), the left-over tiles are never
+    dead; a slot is skipped at input pair c when c > t // 2 for the tiles t of every wave of its group (waves {0,1}, {2,3} when
+    two tiles are left over, else all four)"""
+    nfull, nx = nht // 4, nht % 4
+    gn = 4 // nx if nx and 4 % nx == 0 else 1
+    skipped = 0
+    for gi in range(gn):
+        waves = range(gi * (4 // gn), (gi + 1) * (4 // gn))
+        for j in range(nfull):
+            tiles = [4 * (j + 1) - 1 - w if j & 1 else 4 * j + w for w in waves]
+            for c in range(npair):
+                if all(c > t // 2 for t in tiles):
+                    skipped += len(tiles)
+    return skipped
+
+
 def _issued_over_live(args, R, W):
     """fp32-equivalent FLOPs the one-launch step's MFMAs multiply per live FLOP: per row block, hidden layer l on
     ceil((R + depth_ar - l) * W / 16) pixel tiles, the output pair on ceil(R * W / 16), every co tile x every (32-channel,
-    tap) step of the 5 stored taps -- 16 x 16 x 32 MACs each (iaf_step_fused.hpp) -- against the mask-aware live count"""
+    tap) step of the 5 stored taps -- 16 x 16 x 32 MACs each (iaf_step_fused.hpp), less the dead centre-tap blocks the
+    triangular hidden layers skip (_tri_skipped) -- against the mask-aware live count"""
     d, nz, nh = args.depth_ar, args.n_z, args.n_h
     H = W
     nrb = (H + R - 1) // R
     units = 0
     cin = nz
     for l in range(d):
-        units += -(-((R + d - l) * W) // 16) * (nh // 16) * (cin // 32) * 5
+        per_tile = (nh // 16) * (cin // 32) * 5
+        if l >= 1 and getattr(args, "variant", "tf") == "tf":
+            per_tile -= _tri_skipped(nh // 16, cin // 32)
+        units += -(-((R + d - l) * W) // 16) * per_tile
         cin = nh
     units += -(-(R * W) // 16) * (2 * nz // 16) * (cin // 32) * 5
     issued = float(args.batch * nrb * units) * 16 * 16 * 32 * 2

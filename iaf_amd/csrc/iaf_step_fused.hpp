@@ -25,8 +25,9 @@
 // unrolled MFMA stream of ONE wave runs at the pipe's rate, 7.3 ns per 16x16x32 MFMA; every VALU instruction between two
 // MFMAs adds 1.1 - 1.6 ns, an LDS read 8 ns, an LDS write 13 ns; s_memtime ticks, the unit of the stamps below, change rate
 // with the number of waves per SIMD and only compare within one configuration.)
-// Work split: 4 waves, one per SIMD.  Hidden layers: wave w owns co tiles w, w+4, ... of every pixel tile (its weight
-// stream is disjoint from the other waves'; the activation fragments come from LDS); the tiles left over when the count is
+// Work split: 4 waves, one per SIMD.  Hidden layers: wave w owns co tiles w, 7 - w, 8 + w, ... (serpentine over rounds of 4)
+// of every pixel tile (its weight stream is disjoint from the other waves'; the activation fragments come from LDS; the
+// serpentine evens out the dead centre-tap blocks a triangular layer skips, see TRI below); the tiles left over when the count is
 // not a multiple of 4 (n_h = 160: tiles 8, 9) are dealt out per (tile, pixel tile) so that every wave multiplies the
 // same number of units.  Output pair: 2 n_z / 16 tiles dealt out over the 4 waves (one each at n_z = 32), every wave runs the
 // whole K range of its tiles; the results change from the MFMA layout to image rows through an exchange buffer.
@@ -85,6 +86,26 @@ constexpr int fused_extra_mask(int npt, int gn, int g) {
 // over PSG accumulator groups (summed once, after the K loop), so that an accumulator is touched every third MFMA at most.
 constexpr int fused_acc_groups(int tiles_per_pixel_tile) { return tiles_per_pixel_tile >= 3 ? 1 : tiles_per_pixel_tile == 2 ? 2 : 3; }
 
+constexpr int fused_popcount(int m) { int n = 0; for (; m; m &= m - 1) ++n; return n; }
+// fragments [lo, hi) (3 per tile slot) of a ring refill that belong to live slots
+constexpr int fused_live_frags(int live, int lo, int hi) {
+    int n = 0;
+    for (int f = lo; f < hi; ++f) n += (live >> (f / 3)) & 1;
+    return n;
+}
+// Tile slots of a hidden layer with a live centre-tap block at input pair c of a channel-triangular layer, for the waves of
+// group gi of gn (the waves that run one instantiation of a hidden phase): slot j < nfull holds tile 4 j + w of wave w
+// (serpentine: 4 (j + 1) - 1 - w for odd j), the left-over slot a tile >= 4 nfull; tile t is live at c iff c <= t / 2
+constexpr int tri_live(int ntw, int nfull, int nht, int c, int gn, int gi) {
+    int m = 0;
+    for (int j = 0; j < ntw; ++j)
+        for (int w = gi * (4 / gn); w < (gi + 1) * (4 / gn); ++w) {
+            const int t = j >= nfull ? nht - 1 : (j & 1) ? 4 * (j + 1) - 1 - w : 4 * j + w;
+            if (c <= t / 2) m |= 1 << j;
+        }
+    return m;
+}
+
 // VAR: the statement of the operator -- 0 TF, 1 Theano (image rotated by 180 degrees + border channel), 2 Theano with
 // flipmask=True (TF geometry + border channel).  Compile time: as run-time flags these cost the TF path ~1 us per launch
 // (branches around the border loads split the epilogue's basic blocks).
@@ -136,7 +157,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     static_assert((2 * NZT) % NW == 0, "output tiles must split evenly over the waves");
     int htile[NTWH];
 #pragma unroll
-    for (int j = 0; j < NTWH; ++j) htile[j] = (j < NFULL) ? wave + NW * j : (XSPLIT ? NW * NFULL + wave % NX : wave + NW * j);
+    for (int j = 0; j < NTWH; ++j)      // (serpentine over the rounds: the dead centre-tap blocks of a wave's tiles add up evenly, see TRI)
+        htile[j] = (j < NFULL) ? ((j & 1) ? NW * (j + 1) - 1 - wave : wave + NW * j) : (XSPLIT ? NW * NFULL + wave % NX : wave + NW * j);
     const int xg = XSPLIT ? wave / NX : 0;                       // this wave's group for the left-over tile
 
     // ---- weight fragments: [step = pair * 5 + tap][co tile][plane][lane][8 bf16] -> ring of U step slots per phase ----
@@ -151,17 +173,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // (wbase: the layer's pack, UNIFORM; step, tile and plane are wave-uniform too: the whole fragment address is scalar
     // arithmetic, the lane contributes its 16-byte slot as the load's 32-bit offset)
     const unsigned lane16 = 16u * (unsigned)lane;
-    auto ring_load = [&](auto lo_c, auto hi_c, f32x4 (*dst)[3], const f32x4* wbase, int ncot, const int* tiles, int s_end, int s) {
-        constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
-        const int sc = s < s_end ? s : s_end - 1;
+    // TRI (hidden layer l >= 1 of the TF statement): its centre tap is the channel-triangular MADE mask itself (layers.py:115-124
+    // with k = 1: input i reaches output o iff i <= o), so the block (input pair c = 32 channels, co tile t = 16 channels) of that
+    // tap is all zeros -- stored zeros in the pack -- whenever 32 c > 16 t + 15, i.e. c > t / 2: 20 of the 50 blocks at n_h = 160.
+    // Such a layer walks its steps in the order (four full taps x pairs), then (centre tap x pairs), and in a centre-tap step
+    // neither loads nor multiplies a tile SLOT whose tiles are dead at that pair for every wave that runs this instantiation of
+    // the phase (the wave groups of the left-over tiles: waves {0, 1} and {2, 3} at n_h = 160) -- known at compile time
+    // (tri_live).  With the serpentine tile order a wave of either group skips 5 of its 62.5 (tile, step) units: all 20 dead
+    // blocks, 8 % of the layer's MFMAs and weight bytes.  (Per-wave masks at RUN time -- wave-uniform branches around loads and
+    // MFMAs in the K loop -- were measured first: 57.6 k instead of 23.3 k cycles for the second conv's K loop.)
+    constexpr int NPAIR_H = NH / 32, NF_H = NPAIR_H * (NTAPS - 1);        // hidden layers: input pairs, steps of the four full taps
+    auto tri_step = [&](int sq, int& pair, int& tap) {                    // sequence index -> (input pair, tap)
+        if (sq < NF_H) { pair = sq / (NTAPS - 1); tap = 1 + sq - pair * (NTAPS - 1); }
+        else { pair = sq - NF_H; tap = 0; }
+    };
+    auto ring_load = [&](auto lo_c, auto hi_c, f32x4 (*dst)[3], const f32x4* wbase, int ncot, const int* tiles, int s_end, int s,
+                         auto tri_c, auto live_c) {
+        constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value, LIVE = decltype(live_c)::value;
+        int sc = s < s_end ? s : s_end - 1;
+        if constexpr (decltype(tri_c)::value) {
+            int pair, tap;
+            tri_step(sc, pair, tap);
+            sc = pair * NTAPS + tap;
+        }
         const f32x4* q = wbase + (size_t)sc * ncot * 3 * 64;
 #pragma unroll
         for (int f = LO; f < HI; ++f) {
             const int j = f / 3, pn = f - 3 * j;
+            if (!((LIVE >> j) & 1)) continue;                              // (compile time) a dead slot of the step being fetched
             const int tc = tiles[j] < ncot ? tiles[j] : ncot - 1;
             dst[j][pn] = *(const f32x4*)((const char*)(q + ((size_t)tc * 3 + pn) * 64) + lane16);
         }
     };
+    constexpr std::integral_constant<bool, false> NOTRI{};
+    constexpr std::integral_constant<int, -1> ALL{};                       // every slot live
 
     // ---- prologue: z rows first (the first conv cannot start without them), then the first weight steps; zero columns
     // while both travel; z -> LDS ---------------------------------------------------------------------------------------
@@ -192,7 +237,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const f32x4* wb0 = (const f32x4*)p.wp3[0];
     static_for<RD0>([&](auto i) {
         ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWH * 3>{}, wr0[decltype(i)::value], wb0, NHT, htile,
-                  (NZ / 32) * NTAPS, decltype(i)::value);
+                  (NZ / 32) * NTAPS, decltype(i)::value, NOTRI, ALL);
     });
     __builtin_amdgcn_sched_barrier(0);
     // context rows of this workgroup: per channel one contiguous run of CPX pixels (full-width rows) -> 16-byte loads,
@@ -301,8 +346,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // multiplied only for the pixel tiles in EMASK (the wave's share of a left-over tile); all others for every pixel tile.
     auto conv_phase = [&](auto rd_c, auto npt_c, auto ntw_c, auto rows_c, auto emask_c, int in_reg, int in_s16, int in_c8, const f32x4* wbase,
                           int ncot, const int* tiles, int s0, int nstep, f32x4 (*wr)[decltype(ntw_c)::value][3],
-                          f32x4 (*acc_out)[decltype(ntw_c)::value]) {
+                          f32x4 (*acc_out)[decltype(ntw_c)::value], auto tri_c, auto grp_c) {
         constexpr int NPT = decltype(npt_c)::value, NTW = decltype(ntw_c)::value, ROWS = decltype(rows_c)::value;
+        constexpr bool TRI = decltype(tri_c)::value;               // triangular centre tap: step order and dead slots, see ring_load
         constexpr int EMASK = decltype(emask_c)::value;
         constexpr int RD = decltype(rd_c)::value, U = RD + 1;      // this phase's look-ahead; it uses slots 0 .. RD of its ring array
         constexpr int PSG = fused_acc_groups(NTW);                 // accumulator groups of a unit's six part-products
@@ -321,7 +367,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         auto xaddr = [&](auto q_c, int s) -> int {
             const int sc = s < nstep ? s : nstep - 1;
-            const int pair = sc / NTAPS, tap = sc - pair * NTAPS;
+            int pair = sc / NTAPS, tap = sc - pair * NTAPS;
+            if constexpr (TRI) tri_step(sc, pair, tap);
             const int toff = tap < 2 ? tap : RS + tap - 3;          // slots: (0,0) (0,1) (1,-1) (1,0) (1,1)
             return xb[decltype(q_c)::value] + toff * in_s16 + pair * 4;
         };
@@ -341,15 +388,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int a = xaddr(std::integral_constant<int, 0>{}, s0);
             xn[0] = smem4[a]; xn[1] = smem4[a + in_c8]; xn[2] = smem4[a + 2 * in_c8];
         }
-        auto step_body = [&](auto slot_c, int s) {
-            constexpr int I = decltype(slot_c)::value;
+        // live_c: tile slots multiplied in this step; next_c: those of step s + RD, whose weights this step requests (bit masks;
+        // -1 = all, 0 = a step past the end: nothing to fetch)
+        auto step_body = [&](auto slot_c, int s, auto live_c, auto next_c) {
+            constexpr int I = decltype(slot_c)::value, LIVE = decltype(live_c)::value;
             static_for<NPT>([&](auto q_c) {
                 constexpr int q = decltype(q_c)::value;
                 constexpr int NTQ = ((EMASK >> q) & 1) ? NTW : NTW - 1;      // tile slots multiplied for this pixel tile
                 // this pixel tile's share of the refill of the slot consumed RD steps from now
                 constexpr int LO = (q * NTW * 3) / NPT, HI = ((q + 1) * NTW * 3) / NPT;
                 ring_load(std::integral_constant<int, LO>{}, std::integral_constant<int, HI>{}, wr[(I + RD) % U], wbase, ncot, tiles, nstep,
-                          s + RD);
+                          s + RD, tri_c, next_c);
                 bf16x8 xh, xm, xl;
                 if constexpr (XAHEAD) {
                     xh = __builtin_bit_cast(bf16x8, xs[I & 1][q][0]);
@@ -365,9 +414,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                                                 : xaddr(std::integral_constant<int, 0>{}, s + 1);
                     xn[0] = smem4[a]; xn[1] = smem4[a + in_c8]; xn[2] = smem4[a + 2 * in_c8];
                 }
+                constexpr int NLV = fused_popcount(LIVE & ((1 << NTQ) - 1));
 #define IAF_FPROD(K, WP, XV)                                                                                      \
-    _Pragma("unroll") for (int j = 0; j < NTQ; ++j)                                                                \
-        acc[(K) % PSG][q][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wr[I][j][WP]), XV, acc[(K) % PSG][q][j], 0, 0, 0);
+    static_for<NTQ>([&](auto j_c) {                                                                                \
+        constexpr int j = decltype(j_c)::value;                                                                    \
+        if constexpr ((LIVE >> j) & 1)                                                                             \
+            acc[(K) % PSG][q][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wr[I][j][WP]), XV, acc[(K) % PSG][q][j], 0, 0, 0); \
+    });
                 IAF_FPROD(0, 2, xh)
                 IAF_FPROD(1, 0, xl)
                 IAF_FPROD(2, 1, xm)
@@ -375,18 +428,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 IAF_FPROD(4, 0, xm)
                 IAF_FPROD(5, 0, xh)
 #undef IAF_FPROD
-                sched_interleave<6 * NTQ, 3, 0, HI - LO>();
+                constexpr int NLD = fused_live_frags(decltype(next_c)::value, LO, HI);
+                sched_interleave<6 * NLV, 3, 0, NLD>();
                 __builtin_amdgcn_sched_barrier(0);
             });
         };
         int s = s0;                                                  // ring slot of step s: (s - s0) % U
-        for (; s + U <= nstep; s += U)
-            static_for<U>([&](auto i) { step_body(i, s + decltype(i)::value); });
-        const int rem = nstep - s;
-        static_for<U>([&](auto r_c) {
-            constexpr int RR = decltype(r_c)::value;
-            if (RR > 0 && rem == RR) static_for<RR>([&](auto i) { step_body(i, s + decltype(i)::value); });
-        });
+        if constexpr (!TRI) {
+            for (; s + U <= nstep; s += U)
+                static_for<U>([&](auto i) { step_body(i, s + decltype(i)::value, ALL, ALL); });
+            const int rem = nstep - s;
+            static_for<U>([&](auto r_c) {
+                constexpr int RR = decltype(r_c)::value;
+                if (RR > 0 && rem == RR) static_for<RR>([&](auto i) { step_body(i, s + decltype(i)::value, ALL, ALL); });
+            });
+        } else {
+            // the four full taps: every slot (their look-ahead into the first centre-tap steps fetches a dead block or two: unused)
+            constexpr int MAIN = (NF_H / U) * U;
+            constexpr int TGN = XSPLIT ? GN : 1, TGI = decltype(grp_c)::value;
+            for (; s + U <= MAIN; s += U)
+                static_for<U>([&](auto i) { step_body(i, s + decltype(i)::value, ALL, ALL); });
+            static_for<NF_H - MAIN>([&](auto i) { step_body(i, MAIN + decltype(i)::value, ALL, ALL); });
+            // the centre tap: pair c multiplies the slots live at c and requests those live at c + RD
+            static_for<NPAIR_H>([&](auto c_c) {
+                constexpr int c = decltype(c_c)::value, sq = NF_H + c;
+                constexpr int live = tri_live(NTW, NFULL, NHT, c, TGN, TGI);
+                constexpr int next = (c + RD < NPAIR_H) ? tri_live(NTW, NFULL, NHT, c + RD, TGN, TGI) : 0;
+                step_body(std::integral_constant<int, sq % U>{}, sq, std::integral_constant<int, live>{}, std::integral_constant<int, next>{});
+            });
+        }
 #pragma unroll
         for (int q = 0; q < NPT; ++q)
 #pragma unroll
@@ -473,6 +543,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
     // ---- hidden layers ---------------------------------------------------------------------------------------------
     constexpr int NSTEP_H = (NH / 32) * NTAPS;
+    constexpr std::integral_constant<bool, VAR == 0> HTRI{};      // hidden layers l >= 1 of the TF statement (see ring_load)
     int otile[NTWO];
 #pragma unroll
     for (int j = 0; j < NTWO; ++j) otile[j] = wave * NTWO + j;
@@ -482,7 +553,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto preload_out = [&]() {
         static_for<RDO>([&](auto i) {
             ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWO * 3>{}, wro[decltype(i)::value], wbo, 2 * NZT,
-                      otile, NSTEP_H, decltype(i)::value);
+                      otile, NSTEP_H, decltype(i)::value, NOTRI, ALL);
         });
     };
     // the weights of the phase after hidden layer l -- the next hidden layer's ring, or the output pair's -- start travelling
@@ -493,7 +564,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const f32x4* wbn = (const f32x4*)p.wp3[l + 1];
             static_for<RDH>([&](auto i) {
                 ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWH * 3>{},
-                          ((l + 1) & 1) ? wr1[decltype(i)::value] : wr0[decltype(i)::value], wbn, NHT, htile, NSTEP_H, decltype(i)::value);
+                          ((l + 1) & 1) ? wr1[decltype(i)::value] : wr0[decltype(i)::value], wbn, NHT, htile, NSTEP_H, decltype(i)::value,
+                          HTRI, ALL);
             });
         } else {
             preload_out();
@@ -508,7 +580,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         load_bias(p.bias[0], bi0);
         conv_phase(std::integral_constant<int, RD0>{}, std::integral_constant<int, NPT0>{}, std::integral_constant<int, NTWH>{},
                    std::integral_constant<int, G::rows_h(0)>{}, std::integral_constant<int, EM0>{}, G::ZREG, Z16, Z8, wb0, NHT, htile, 0,
-                   (NZ / 32) * NTAPS, wr0, acc0);
+                   (NZ / 32) * NTAPS, wr0, acc0, NOTRI, g_c);
         IAF_FSTAMP(6);
         store_ctx();
         if constexpr (DEPTH == 1) load_final_operands();
@@ -541,7 +613,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const f32x4* wbl = (const f32x4*)p.wp3[l];
             conv_phase(std::integral_constant<int, RDH>{}, std::integral_constant<int, NPTL>{}, std::integral_constant<int, NTWH>{},
                        std::integral_constant<int, G::rows_h(l)>{}, std::integral_constant<int, EML>{}, IN_REG, H16, H8, wbl, NHT, htile, 0,
-                       NSTEP_H, (l & 1) ? wr1 : wr0, accl);
+                       NSTEP_H, (l & 1) ? wr1 : wr0, accl, HTRI, g_c);
             if constexpr (l == 1) IAF_FSTAMP(7);
             if constexpr (l == DEPTH - 1) load_final_operands();
             preload_after(std::integral_constant<int, l>{});
@@ -560,7 +632,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         f32x4 acco[NPTO][NTWO];
         conv_phase(std::integral_constant<int, RDO>{}, std::integral_constant<int, NPTO>{}, std::integral_constant<int, NTWO>{},
                    std::integral_constant<int, R>{}, std::integral_constant<int, (1 << NPTO) - 1>{}, ((DEPTH - 1) & 1) ? G::HREG1 : G::HREG0,
-                   H16, H8, wbo, 2 * NZT, otile, 0, NSTEP_H, wro, acco);
+                   H16, H8, wbo, 2 * NZT, otile, 0, NSTEP_H, wro, acco, NOTRI, std::integral_constant<int, 0>{});
         IAF_FSTAMP(4);
         float* mine = xbuf;
 #pragma unroll
