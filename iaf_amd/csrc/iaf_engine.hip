@@ -98,6 +98,12 @@ struct iaf_stack {
     bool defer_wn = false;    // backward leaves the weight-norm pass to iaf_wn_bwd_batch_run (one launch per model)
     float* pend_ws = nullptr; int pend_B = 0, pend_H = 0, pend_W = 0;   // ... which finds dWeff / dbp through these
     bool generic = false;     // channel counts outside the MFMA path: direct-conv fallback kernels
+    // one-launch step with halo exchange (iaf_step_fused.hpp, XCH): the rows the row blocks hand each other and their flags.
+    // Owned by the stack (allocated on first use outside a stream capture, flags zeroed once and left zero by every launch),
+    // so such launches of ONE stack must not overlap on different streams.
+    char* xch_buf = nullptr; size_t xch_bytes = 0;
+    unsigned* xch_flag = nullptr; size_t xch_nflag = 0;
+    std::vector<void*> xch_retired;       // outgrown buffers: a captured graph may still name them, so they live as long as the stack
     int precision = IAF_PRECISION_BF16X3;   // forward convs: bf16x3 split products on the bf16 MFMA, or the exact fp32 MFMA
     int fuse_first = 2;       // first masked conv fused into the second one's kernel: 0 never, 1 whenever possible, 2 only where
                               // iaf_stack_autotune measured it faster (on MI355X at the BASELINE sizes it is not: DESIGN.md 4.8)
@@ -449,7 +455,19 @@ extern "C" int iaf_stack_destroy(iaf_stack_t* s) {
         if (s->L[l].wp3) (void)hipFree(s->L[l].wp3);
         if (s->L[l].lim) (void)hipFree(s->L[l].lim);
     }
+    if (s->xch_buf) (void)hipFree(s->xch_buf);
+    if (s->xch_flag) (void)hipFree(s->xch_flag);
+    for (void* q : s->xch_retired) (void)hipFree(q);
     delete s;
+    return IAF_OK;
+}
+
+extern "C" int iaf_stack_exchange_errors(const iaf_stack_t* s, unsigned* errors) {
+    if (!s || !errors) return IAF_ERR_NULL;
+    *errors = 0;
+    if (!s->xch_flag) return IAF_OK;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(errors, s->xch_flag + s->xch_nflag, sizeof(unsigned), hipMemcpyDeviceToHost));
     return IAF_OK;
 }
 
@@ -1012,6 +1030,33 @@ static int launch_fused_step(iaf_stack_t* s, step_fn_t fn, int R, size_t lds, co
     if (s->variant != IAF_VARIANT_TF)                          // (the kernel variant was picked with the statement)
         for (int l = 0; l < s->nlayers; ++l) q.border[l] = s->L[l].border;
     q.dbg = (s->dbg_layer == -2) ? s->dbg : nullptr;
+    // Halo exchange instead of halo recompute (TF statement, more than one row block per image, the geometries compiled for it;
+    // IAF_FUSE_XCH=0: dev knob).  Its buffers are the stack's: allocated here on first use -- not inside a stream capture, where
+    // the recomputing kernel runs instead (warm up before capturing, as for the LDS cap below).
+    static const bool xch_env = !(getenv("IAF_FUSE_XCH") && getenv("IAF_FUSE_XCH")[0] == '0');
+    if (xch_env && s->variant == IAF_VARIANT_TF && q.nrb > 1) {
+        size_t xl = 0, xrow = 0;
+        if (step_fn_t fx = iaf_pick_step_fused_xch(s->n_h / 16, s->n_z / 16, s->depth_ar, base.W, R, &xl, &xrow)) {
+            const size_t nslot = (size_t)s->depth_ar * base.B * q.nrb, need = nslot * xrow;
+            if (need > s->xch_bytes || nslot > s->xch_nflag) {
+                hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+                (void)hipStreamIsCapturing(st, &cs);
+                if (cs == hipStreamCaptureStatusNone) {
+                    if (s->xch_buf) s->xch_retired.push_back(s->xch_buf);
+                    if (s->xch_flag) s->xch_retired.push_back(s->xch_flag);
+                    s->xch_buf = nullptr; s->xch_flag = nullptr; s->xch_bytes = 0; s->xch_nflag = 0;
+                    HIP_TRY(hipMalloc((void**)&s->xch_buf, need));
+                    HIP_TRY(hipMalloc((void**)&s->xch_flag, (nslot + 1) * sizeof(unsigned)));       // flags + error word
+                    HIP_TRY(hipMemset(s->xch_flag, 0, (nslot + 1) * sizeof(unsigned)));
+                    s->xch_bytes = need; s->xch_nflag = nslot;
+                }
+            }
+            if (need <= s->xch_bytes && nslot <= s->xch_nflag && xl <= 160 * 1024) {
+                fn = fx; lds = xl;
+                q.xh = s->xch_buf; q.xflag = s->xch_flag; q.xerr = s->xch_flag + s->xch_nflag;
+            }
+        }
+    }
     { int rc = raise_lds_cap((const void*)fn, lds); if (rc) return rc; }
     const bool prof = (s->prof_layer == -2 && s->prof_n < s->prof_cap);
     if (prof) HIP_TRY(hipEventRecord(s->prof_start[s->prof_n], st));

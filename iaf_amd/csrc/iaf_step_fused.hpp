@@ -40,18 +40,22 @@
 #include "iaf_conv_bf3.hpp"
 #include "iaf_step_fused_types.hpp"
 
-template <int NHT, int NZT, int DEPTH, int W, int R>
+// XCH = 1: neighbouring row blocks EXCHANGE their halo rows instead of recomputing them (see the kernel's header note): a
+// hidden layer computes only the R rows its workgroup owns, its region holds one more row -- the first row of the block
+// below, imported -- and z has R + 1 rows.
+template <int NHT, int NZT, int DEPTH, int W, int R, int XCH = 0>
 struct StepGeom {
     static constexpr int NZ = 16 * NZT, NH = 16 * NHT;
     static constexpr int RS = W + 2;                           // slots per row (zero column on either side)
     static constexpr int Z8 = NZ / 8, Z16 = 3 * Z8 + 2;        // z slot: planes + pad, in 16-byte units (stride = 8 * odd dwords)
     static constexpr int H8 = NH / 8, H16 = 3 * H8 + 2;
-    static constexpr int RZ = R + DEPTH + 1;
-    static constexpr int rows_h(int l) { return R + DEPTH - l; }
+    static constexpr int RZ = XCH ? R + 1 : R + DEPTH + 1;
+    static constexpr int rows_h(int l) { return XCH ? R : R + DEPTH - l; }           // rows hidden layer l computes
+    static constexpr int rows_reg(int l) { return XCH ? R + 1 : R + DEPTH - l; }     // rows its region holds
     static constexpr int ZREG = 0;                                               // region offsets in 16-byte units
     static constexpr int HREG0 = ZREG + RZ * RS * Z16;
-    static constexpr int HREG1 = HREG0 + rows_h(0) * RS * H16;
-    static constexpr int END = HREG1 + (DEPTH >= 2 ? rows_h(1) * RS * H16 : 0);
+    static constexpr int HREG1 = HREG0 + rows_reg(0) * RS * H16;
+    static constexpr int END = HREG1 + (DEPTH >= 2 ? rows_reg(1) * RS * H16 : 0);
     static constexpr int XB_STRIDE = 2 * NZ + 1;                                 // output exchange buffer [pixel][2 n_z] floats
     static constexpr size_t xb_bytes() { return (size_t)R * W * XB_STRIDE * 4; }
     // (the last hidden layer sits in the h_odd region for an even depth: z + h_even are dead then; for an odd depth it sits in
@@ -60,7 +64,7 @@ struct StepGeom {
     // context of the first epilogue, staged [channel][pixel of the h_0 rows] (row stride = 4 or 12 mod 16 floats: conflict-free for the epilogue's
     // lanes = 16 pixels x 4 channel groups): in the h_1 region, which the first conv does not touch; behind everything when
     // there is a single hidden layer
-    static constexpr int CPX = (R + DEPTH) * W, CSTR = (CPX % 16 == 0 || CPX % 16 == 8) ? CPX + 4 : CPX;
+    static constexpr int CPX = rows_h(0) * W, CSTR = (CPX % 16 == 0 || CPX % 16 == 8) ? CPX + 4 : CPX;
     static constexpr int CTX_OFF = DEPTH >= 2 ? HREG1 : END;
     static constexpr size_t ctx_bytes() { return (size_t)NH * CSTR * 4; }
     static constexpr size_t lds_bytes() {
@@ -69,6 +73,8 @@ struct StepGeom {
         a = a > b ? a : b;
         return a > c ? a : c;
     }
+    // XCH: one exported row = W pixel slots of a hidden region, as stored in LDS
+    static constexpr size_t xrow_bytes() { return (size_t)W * H16 * 16; }
 };
 
 // pixel tiles [lo, hi) of a phase with NPT tiles that group g of GN wave groups covers with its left-over co tile
@@ -85,6 +91,19 @@ constexpr int fused_extra_mask(int npt, int gn, int g) {
 // layers (2-3 co tiles per pixel tile: the same accumulator every second or third MFMA).  Such phases spread the six products
 // over PSG accumulator groups (summed once, after the K loop), so that an accumulator is touched every third MFMA at most.
 constexpr int fused_acc_groups(int tiles_per_pixel_tile) { return tiles_per_pixel_tile >= 3 ? 1 : tiles_per_pixel_tile == 2 ? 2 : 3; }
+
+// The K steps of one conv_phase call: NT taps from tap T0 on, pair-major, every tile slot live; then -- TAIL -- the centre tap x
+// pairs of a channel-triangular layer with its dead slots skipped (see TRI in the kernel).  Taps: 0 (0,0)  1 (0,+1)  2 (+1,-1)
+// 3 (+1,0)  4 (+1,+1).  A whole layer is <0, 5, 0> (or <1, 4, 1> when triangular); the halo-exchange kernels run a layer
+// that reads an imported row as two calls, <0, 2, 0> / <1, 1, 1> (the taps of the own rows) and <2, 3, 0> (the row below).
+template <int T0_, int NT_, int TAIL_, int NPAIR_>
+struct StepPart {
+    static constexpr int T0 = T0_, NT = NT_, TAIL = TAIL_, NPAIR = NPAIR_, NF = NPAIR_ * NT_, NSTEP = NF + (TAIL_ ? NPAIR_ : 0);
+    __device__ static void at(int sq, int& pair, int& tap) {              // sequence index -> (input pair, tap)
+        if (!TAIL_ || sq < NF) { pair = sq / NT_; tap = T0_ + sq - pair * NT_; }
+        else { pair = sq - NF; tap = 0; }
+    }
+};
 
 constexpr int fused_popcount(int m) { int n = 0; for (; m; m &= m - 1) ++n; return n; }
 // fragments [lo, hi) (3 per tile slot) of a ring refill that belong to live slots
@@ -109,9 +128,12 @@ constexpr int tri_live(int ntw, int nfull, int nht, int c, int gn, int gi) {
 // VAR: the statement of the operator -- 0 TF, 1 Theano (image rotated by 180 degrees + border channel), 2 Theano with
 // flipmask=True (TF geometry + border channel).  Compile time: as run-time flags these cost the TF path ~1 us per launch
 // (branches around the border loads split the epilogue's basic blocks).
-template <int NHT, int NZT, int DEPTH, int W, int R, int VAR = 0>
+template <int NHT, int NZT, int DEPTH, int W, int R, int VAR = 0, int XCH = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void iaf_step_fused_kernel(StepP p) {
-    typedef StepGeom<NHT, NZT, DEPTH, W, R> G;
+    typedef StepGeom<NHT, NZT, DEPTH, W, R, XCH> G;
+    static_assert(!XCH || VAR == 0, "the halo exchange is built for the TF statement");
+    // exchanged rows and flags: AGENT scope (sc1: coherent across the XCDs, served by the memory side)
+    constexpr int XSCOPE = __HIP_MEMORY_SCOPE_AGENT;
     constexpr bool FLIP = (VAR == 1), BORDER = (VAR != 0);
     static_assert(DEPTH >= 1 && DEPTH <= 4, "hidden layers ping-pong between two LDS regions (h_even, h_odd)");
     static_assert((W & (W - 1)) == 0 && W <= 16, "full-width rows of 4, 8 or 16 pixels");
@@ -122,7 +144,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pl = lane & 15, kk = lane >> 4;
-    const int b = blockIdx.x / p.nrb, r0 = (blockIdx.x - b * p.nrb) * R;
+    // XCH: a workgroup waits for the block BELOW it, so the blocks of an image are dealt out bottom first -- a workgroup only
+    // ever waits for one with a lower index, which the dispatcher has placed before it (any grid size)
+    const int b = blockIdx.x / p.nrb, xpos = blockIdx.x - b * p.nrb, rbk = XCH ? p.nrb - 1 - xpos : xpos, r0 = rbk * R;
     const int H = p.H, HW = p.HW;
     // pixel offset inside the image of position (image row ir, column col) of the space the kernel computes in
     // ((H-1-ir) W + (W-1-col) = HW-1 - (ir W + col))
@@ -182,21 +206,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // (tri_live).  With the serpentine tile order a wave of either group skips 5 of its 62.5 (tile, step) units: all 20 dead
     // blocks, 8 % of the layer's MFMAs and weight bytes.  (Per-wave masks at RUN time -- wave-uniform branches around loads and
     // MFMAs in the K loop -- were measured first: 57.6 k instead of 23.3 k cycles for the second conv's K loop.)
-    constexpr int NPAIR_H = NH / 32, NF_H = NPAIR_H * (NTAPS - 1);        // hidden layers: input pairs, steps of the four full taps
-    auto tri_step = [&](int sq, int& pair, int& tap) {                    // sequence index -> (input pair, tap)
-        if (sq < NF_H) { pair = sq / (NTAPS - 1); tap = 1 + sq - pair * (NTAPS - 1); }
-        else { pair = sq - NF_H; tap = 0; }
-    };
-    auto ring_load = [&](auto lo_c, auto hi_c, f32x4 (*dst)[3], const f32x4* wbase, int ncot, const int* tiles, int s_end, int s,
-                         auto tri_c, auto live_c) {
+    constexpr int NPAIR_H = NH / 32;
+    auto ring_load = [&](auto lo_c, auto hi_c, f32x4 (*dst)[3], const f32x4* wbase, int ncot, const int* tiles, auto part_c, int s,
+                         auto live_c) {
+        typedef decltype(part_c) P;
         constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value, LIVE = decltype(live_c)::value;
-        int sc = s < s_end ? s : s_end - 1;
-        if constexpr (decltype(tri_c)::value) {
-            int pair, tap;
-            tri_step(sc, pair, tap);
-            sc = pair * NTAPS + tap;
-        }
-        const f32x4* q = wbase + (size_t)sc * ncot * 3 * 64;
+        int pair, tap;
+        P::at(s < P::NSTEP ? s : P::NSTEP - 1, pair, tap);
+        const f32x4* q = wbase + (size_t)(pair * NTAPS + tap) * ncot * 3 * 64;
 #pragma unroll
         for (int f = LO; f < HI; ++f) {
             const int j = f / 3, pn = f - 3 * j;
@@ -205,7 +222,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             dst[j][pn] = *(const f32x4*)((const char*)(q + ((size_t)tc * 3 + pn) * 64) + lane16);
         }
     };
-    constexpr std::integral_constant<bool, false> NOTRI{};
+    typedef StepPart<0, NTAPS, 0, NZ / 32> PartL0;                          // the first layer (input z)
+    typedef StepPart<0, NTAPS, 0, NPAIR_H> PartFull;                        // a whole layer over n_h input channels, plain order
+    typedef StepPart<1, NTAPS - 1, 1, NPAIR_H> PartTri;                     // ... channel-triangular: full taps, then the centre tap
+    typedef StepPart<0, 2, 0, NPAIR_H> PartOwn;                             // XCH: the taps that read the workgroup's own rows
+    typedef StepPart<1, 1, 1, NPAIR_H> PartOwnTri;                          // ... of a triangular layer
+    typedef StepPart<2, 3, 0, NPAIR_H> PartBelow;                           // XCH: the taps that read the row below (the imported one)
+    typedef std::conditional_t<VAR == 0, PartTri, PartFull> PartHid;        // hidden layers l >= 1
     constexpr std::integral_constant<int, -1> ALL{};                       // every slot live
 
     // ---- prologue: z rows first (the first conv cannot start without them), then the first weight steps; zero columns
@@ -237,7 +260,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const f32x4* wb0 = (const f32x4*)p.wp3[0];
     static_for<RD0>([&](auto i) {
         ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWH * 3>{}, wr0[decltype(i)::value], wb0, NHT, htile,
-                  (NZ / 32) * NTAPS, decltype(i)::value, NOTRI, ALL);
+                  PartL0{}, decltype(i)::value, ALL);
     });
     __builtin_amdgcn_sched_barrier(0);
     // context rows of this workgroup: per channel one contiguous run of CPX pixels (full-width rows) -> 16-byte loads,
@@ -293,7 +316,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     __builtin_amdgcn_sched_barrier(0);
     IAF_FSTAMP(8);
     {
-        constexpr int ZROWS = RZ, H0ROWS = G::rows_h(0), H1ROWS = 0;      // (h_1's zero columns: after the first layer)
+        constexpr int ZROWS = RZ, H0ROWS = G::rows_reg(0), H1ROWS = 0;    // (h_1's zero columns: after the first layer)
         for (int i = tid; i < ZROWS * 2 * Z16; i += 256) {
             const int rs = i / Z16, u = i - rs * Z16;
             smem4[G::ZREG + ((rs >> 1) * RS + (rs & 1) * (W + 1)) * Z16 + u] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -341,14 +364,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     };
 
-    // ---- one conv phase: acc[q][j] = sum over steps [s0, nstep) of W[step][tiles[j]] x X[pixel tile q, step] --------------
+    // ---- one conv phase: acc[q][j] (+)= sum over the steps of `part` of W[step][tiles[j]] x X[pixel tile q, step] -------------
     // in_reg / in_s16 / in_c8: the input region (16-byte units); ROWS * W output pixels in NPT tiles.  The LAST tile slot is
     // multiplied only for the pixel tiles in EMASK (the wave's share of a left-over tile); all others for every pixel tile.
+    // The caller has requested the part's first RD steps into ring slots 0 .. RD - 1.  accum_c: add to acc_out (second part).
     auto conv_phase = [&](auto rd_c, auto npt_c, auto ntw_c, auto rows_c, auto emask_c, int in_reg, int in_s16, int in_c8, const f32x4* wbase,
-                          int ncot, const int* tiles, int s0, int nstep, f32x4 (*wr)[decltype(ntw_c)::value][3],
-                          f32x4 (*acc_out)[decltype(ntw_c)::value], auto tri_c, auto grp_c) {
+                          int ncot, const int* tiles, f32x4 (*wr)[decltype(ntw_c)::value][3],
+                          f32x4 (*acc_out)[decltype(ntw_c)::value], auto part_c, auto grp_c, auto accum_c) {
+        typedef decltype(part_c) P;
         constexpr int NPT = decltype(npt_c)::value, NTW = decltype(ntw_c)::value, ROWS = decltype(rows_c)::value;
-        constexpr bool TRI = decltype(tri_c)::value;               // triangular centre tap: step order and dead slots, see ring_load
+        constexpr bool TRI = P::TAIL != 0;                         // triangular centre tap: step order and dead slots, see StepPart
+        constexpr int nstep = P::NSTEP, s0 = 0;
         constexpr int EMASK = decltype(emask_c)::value;
         constexpr int RD = decltype(rd_c)::value, U = RD + 1;      // this phase's look-ahead; it uses slots 0 .. RD of its ring array
         constexpr int PSG = fused_acc_groups(NTW);                 // accumulator groups of a unit's six part-products
@@ -366,9 +392,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 for (int j = 0; j < NTW; ++j) acc[g][q][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         auto xaddr = [&](auto q_c, int s) -> int {
-            const int sc = s < nstep ? s : nstep - 1;
-            int pair = sc / NTAPS, tap = sc - pair * NTAPS;
-            if constexpr (TRI) tri_step(sc, pair, tap);
+            int pair, tap;
+            P::at(s < nstep ? s : nstep - 1, pair, tap);
             const int toff = tap < 2 ? tap : RS + tap - 3;          // slots: (0,0) (0,1) (1,-1) (1,0) (1,1)
             return xb[decltype(q_c)::value] + toff * in_s16 + pair * 4;
         };
@@ -397,8 +422,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 constexpr int NTQ = ((EMASK >> q) & 1) ? NTW : NTW - 1;      // tile slots multiplied for this pixel tile
                 // this pixel tile's share of the refill of the slot consumed RD steps from now
                 constexpr int LO = (q * NTW * 3) / NPT, HI = ((q + 1) * NTW * 3) / NPT;
-                ring_load(std::integral_constant<int, LO>{}, std::integral_constant<int, HI>{}, wr[(I + RD) % U], wbase, ncot, tiles, nstep,
-                          s + RD, tri_c, next_c);
+                ring_load(std::integral_constant<int, LO>{}, std::integral_constant<int, HI>{}, wr[(I + RD) % U], wbase, ncot, tiles, part_c,
+                          s + RD, next_c);
                 bf16x8 xh, xm, xl;
                 if constexpr (XAHEAD) {
                     xh = __builtin_bit_cast(bf16x8, xs[I & 1][q][0]);
@@ -433,27 +458,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 __builtin_amdgcn_sched_barrier(0);
             });
         };
-        int s = s0;                                                  // ring slot of step s: (s - s0) % U
-        if constexpr (!TRI) {
-            for (; s + U <= nstep; s += U)
-                static_for<U>([&](auto i) { step_body(i, s + decltype(i)::value, ALL, ALL); });
-            const int rem = nstep - s;
-            static_for<U>([&](auto r_c) {
-                constexpr int RR = decltype(r_c)::value;
-                if (RR > 0 && rem == RR) static_for<RR>([&](auto i) { step_body(i, s + decltype(i)::value, ALL, ALL); });
-            });
-        } else {
-            // the four full taps: every slot (their look-ahead into the first centre-tap steps fetches a dead block or two: unused)
-            constexpr int MAIN = (NF_H / U) * U;
-            constexpr int TGN = XSPLIT ? GN : 1, TGI = decltype(grp_c)::value;
-            for (; s + U <= MAIN; s += U)
-                static_for<U>([&](auto i) { step_body(i, s + decltype(i)::value, ALL, ALL); });
-            static_for<NF_H - MAIN>([&](auto i) { step_body(i, MAIN + decltype(i)::value, ALL, ALL); });
+        int s = s0;                                                  // ring slot of step s: s % U
+        // the pair-major body: every slot live (its look-ahead into the first centre-tap steps may fetch a dead block: unused)
+        constexpr int NF = P::NF, MAIN = (NF / U) * U;
+        for (; s + U <= MAIN; s += U)
+            static_for<U>([&](auto i) { step_body(i, s + decltype(i)::value, ALL, ALL); });
+        static_for<NF - MAIN>([&](auto i) { step_body(i, MAIN + decltype(i)::value, ALL, ALL); });
+        if constexpr (TRI) {
             // the centre tap: pair c multiplies the slots live at c and requests those live at c + RD
-            static_for<NPAIR_H>([&](auto c_c) {
-                constexpr int c = decltype(c_c)::value, sq = NF_H + c;
+            constexpr int TGN = XSPLIT ? GN : 1, TGI = decltype(grp_c)::value;
+            static_for<P::NPAIR>([&](auto c_c) {
+                constexpr int c = decltype(c_c)::value, sq = NF + c;
                 constexpr int live = tri_live(NTW, NFULL, NHT, c, TGN, TGI);
-                constexpr int next = (c + RD < NPAIR_H) ? tri_live(NTW, NFULL, NHT, c + RD, TGN, TGI) : 0;
+                constexpr int next = (c + RD < P::NPAIR) ? tri_live(NTW, NFULL, NHT, c + RD, TGN, TGI) : 0;
                 step_body(std::integral_constant<int, sq % U>{}, sq, std::integral_constant<int, live>{}, std::integral_constant<int, next>{});
             });
         }
@@ -464,9 +481,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 f32x4 a = acc[0][q][j];
 #pragma unroll
                 for (int g = 1; g < PSG; ++g) a += acc[g][q][j];
-                acc_out[q][j] = a;
+                if constexpr (decltype(accum_c)::value) acc_out[q][j] += a; else acc_out[q][j] = a;
             }
     };
+    constexpr std::integral_constant<bool, false> SET{};
+    constexpr std::integral_constant<bool, true> ADD{};
 
     // hidden epilogue: bias (+ context) + ELU (layers.py:63-64,163-165) -> the three planes of the next region; rows past the
     // image bottom become the zero rows the layer above pads with
@@ -474,8 +493,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int j = 0; j < NTWH; ++j) bi[j] = *(const f32x4*)(bias + (htile[j] < NHT ? htile[j] : NHT - 1) * 16 + 4 * kk);
     };
+    // bf3_store4 into the exchanged row in memory: the same three 8-byte pieces, as agent-scope stores
+    auto xch_store4 = [&](char* base, int slot, int q, f32x4 v) {
+        unsigned h0, m0, l0, h1, m1, l1;
+        bf3_split2(f32x2{v[0], v[1]}, h0, m0, l0);
+        bf3_split2(f32x2{v[2], v[3]}, h1, m1, l1);
+        unsigned long long* d = (unsigned long long*)(base + ((size_t)slot * H16 << 4) + q * 8);
+        __hip_atomic_store(d, (unsigned long long)h0 | ((unsigned long long)h1 << 32), __ATOMIC_RELAXED, XSCOPE);
+        __hip_atomic_store(d + 2 * H8, (unsigned long long)m0 | ((unsigned long long)m1 << 32), __ATOMIC_RELAXED, XSCOPE);
+        __hip_atomic_store(d + 4 * H8, (unsigned long long)l0 | ((unsigned long long)l1 << 32), __ATOMIC_RELAXED, XSCOPE);
+    };
+    // xrow (XCH): where this block's FIRST row goes for the block above (NULL: nobody above)
     auto hidden_epilogue = [&](auto npt_c, auto rows_c, auto emask_c, auto ctx_c, f32x4 (*acc)[NTWH], const f32x4* bias, int out_reg,
-                               float* hsave, const float* bt) {
+                               float* hsave, const float* bt, char* xrow) {
         constexpr int NPT = decltype(npt_c)::value, ROWS = decltype(rows_c)::value, EMASK = decltype(emask_c)::value;
         constexpr bool WITH_CTX = decltype(ctx_c)::value != 0;
         f32x4 cxv[WITH_CTX ? NPT : 1][NTWH];                     // all context reads in flight together, ahead of the arithmetic
@@ -492,12 +522,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     for (int r = 0; r < 4; ++r) cxv[q][j][r] = cr[r * G::CSTR];
                 }
         }
+        // (XCH: pixel tiles outermost -- the exported row is in the first one, its stores to memory leave first and are done
+        // when the epilogue ends)
 #pragma unroll
-        for (int j = 0; j < NTWH; ++j) {
+        for (int oi = 0; oi < NTWH * NPT; ++oi) {
+            const int j = XCH ? oi % NTWH : oi / NPT, q = XCH ? oi / NTWH : oi % NPT;
             if (htile[j] >= NHT) continue;
             const f32x4 bi = bias[j];
-#pragma unroll
-            for (int q = 0; q < NPT; ++q) {
+            {
                 if (j == NTWH - 1 && !((EMASK >> q) & 1)) continue;
                 const int pix = q * 16 + pl;
                 if (pix >= ROWS * W) continue;
@@ -509,6 +541,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 for (int r = 0; r < 4; ++r) v[r] = elu_f(v[r]);
                 if (r0 + row >= H) v = f32x4{0.f, 0.f, 0.f, 0.f};
                 bf3_store4(smem + (size_t)out_reg * 16, row * RS + col + 1, htile[j] * 4 + kk, v, H16, H8);
+                if constexpr (XCH) { if (xrow && row == 0) xch_store4(xrow, col, htile[j] * 4 + kk, v); }
                 // training: the rows this workgroup OWNS (not its halo) go to HBM for the backward pass
                 if (hsave && row < R && r0 + row < H)
                     *(f32x4*)(hsave + ((size_t)b * HW + (size_t)gpix(r0 + row, col)) * NH + htile[j] * 16 + 4 * kk) = v;
@@ -541,9 +574,61 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
         }
     };
+    // ---- XCH: halo rows through memory ---------------------------------------------------------------------------------
+    // p.xh [layer][B * nrb][W slots x H16 x 16 bytes]: row 0 of block (b, k)'s hidden layer, as it sits in LDS; p.xflag [layer]
+    // [B * nrb]: 1 = published.  The consumer (block k - 1) clears the flag after its copy, so the flags are all zero between
+    // launches; launches on one stream are ordered, and the buffers belong to the stack (not re-entrant across streams).
+    // Every access to the exchanged rows and flags is an AGENT-scope relaxed atomic (a load / store with the sc1 bit: coherent
+    // per access across the XCDs' L2s), ordered by workgroup-scope fences (plain counter waits).  Agent-scope FENCES were
+    // measured first: buffer_wbl2 / buffer_inv sc1 write back and invalidate the whole L2 -- with it the weight packs every
+    // workgroup streams -- and the launch took 78 k instead of 54 k cycles.
+    const int xslot = b * p.nrb + rbk;
+    auto xch_row = [&](int l) -> char* {
+        if constexpr (!XCH) return nullptr;
+        return rbk > 0 ? p.xh + ((size_t)l * p.B * p.nrb + xslot) * G::xrow_bytes() : nullptr;
+    };
+    auto xch_publish = [&](int l) {          // at the end of the layer's epilogue: every wave announces its own stores of the row
+        if constexpr (XCH) {
+            if (rbk > 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");             // this wave's stores are complete (issued early: no wait)
+                if (lane == 0)
+                    __hip_atomic_fetch_add(p.xflag + (size_t)l * p.B * p.nrb + xslot, 1u, __ATOMIC_RELAXED, XSCOPE);
+            }
+        }
+    };
+    auto xch_import = [&](int l, int reg) {  // row R of the region <- row 0 of the block below (zeros past the image), then a barrier
+        if constexpr (XCH) {
+            unsigned long long* dst = (unsigned long long*)(smem4 + reg + (R * RS + 1) * H16);
+            constexpr int NU = W * H16 * 2;                                          // 8-byte units
+            if (r0 + R < H) {
+                unsigned* fl = p.xflag + (size_t)l * p.B * p.nrb + xslot + 1;
+                int it = 0;                                                          // every wave polls for itself: all four waves below have published
+                while (__hip_atomic_load(fl, __ATOMIC_RELAXED, XSCOPE) < (unsigned)NW && ++it < (1 << 22)) __builtin_amdgcn_s_sleep(1);
+                if (it >= (1 << 22) && p.xerr) *p.xerr = 1u;                         // (a bounded wait: a lost neighbour must not hang the GPU)
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                const unsigned long long* src = (const unsigned long long*)(p.xh + ((size_t)l * p.B * p.nrb + xslot + 1) * G::xrow_bytes());
+                unsigned long long t[(NU + 255) / 256];
+#pragma unroll
+                for (int u = 0; u < (NU + 255) / 256; ++u) {
+                    const int i = tid + 256 * u;
+                    t[u] = __hip_atomic_load(src + (i < NU ? i : NU - 1), __ATOMIC_RELAXED, XSCOPE);
+                }
+#pragma unroll
+                for (int u = 0; u < (NU + 255) / 256; ++u) { const int i = tid + 256 * u; if (i < NU) dst[i] = t[u]; }
+                __syncthreads();
+                if (tid == 0) __hip_atomic_store(fl, 0u, __ATOMIC_RELAXED, XSCOPE);
+            } else {
+                for (int i = tid; i < NU; i += 256) dst[i] = 0ull;
+                __syncthreads();
+            }
+        }
+    };
+
     // ---- hidden layers ---------------------------------------------------------------------------------------------
-    constexpr int NSTEP_H = (NH / 32) * NTAPS;
-    constexpr std::integral_constant<bool, VAR == 0> HTRI{};      // hidden layers l >= 1 of the TF statement (see ring_load)
+    // the first (or only) part of a hidden layer l >= 1 and of the output pair; XCH: the taps of the own rows, the imported row's
+    // taps follow as a second part behind the import
+    typedef std::conditional_t<XCH != 0, PartOwnTri, PartHid> PartH1;
+    typedef std::conditional_t<XCH != 0, PartOwn, PartFull> PartO1;
     int otile[NTWO];
 #pragma unroll
     for (int j = 0; j < NTWO; ++j) otile[j] = wave * NTWO + j;
@@ -553,7 +638,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto preload_out = [&]() {
         static_for<RDO>([&](auto i) {
             ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWO * 3>{}, wro[decltype(i)::value], wbo, 2 * NZT,
-                      otile, NSTEP_H, decltype(i)::value, NOTRI, ALL);
+                      otile, PartO1{}, decltype(i)::value, ALL);
         });
     };
     // the weights of the phase after hidden layer l -- the next hidden layer's ring, or the output pair's -- start travelling
@@ -564,8 +649,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const f32x4* wbn = (const f32x4*)p.wp3[l + 1];
             static_for<RDH>([&](auto i) {
                 ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWH * 3>{},
-                          ((l + 1) & 1) ? wr1[decltype(i)::value] : wr0[decltype(i)::value], wbn, NHT, htile, NSTEP_H, decltype(i)::value,
-                          HTRI, ALL);
+                          ((l + 1) & 1) ? wr1[decltype(i)::value] : wr0[decltype(i)::value], wbn, NHT, htile, PartH1{}, decltype(i)::value,
+                          ALL);
             });
         } else {
             preload_out();
@@ -579,8 +664,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         f32x4 acc0[NPT0][NTWH], bi0[NTWH];
         load_bias(p.bias[0], bi0);
         conv_phase(std::integral_constant<int, RD0>{}, std::integral_constant<int, NPT0>{}, std::integral_constant<int, NTWH>{},
-                   std::integral_constant<int, G::rows_h(0)>{}, std::integral_constant<int, EM0>{}, G::ZREG, Z16, Z8, wb0, NHT, htile, 0,
-                   (NZ / 32) * NTAPS, wr0, acc0, NOTRI, g_c);
+                   std::integral_constant<int, G::rows_h(0)>{}, std::integral_constant<int, EM0>{}, G::ZREG, Z16, Z8, wb0, NHT, htile,
+                   wr0, acc0, PartL0{}, g_c, SET);
         IAF_FSTAMP(6);
         store_ctx();
         if constexpr (DEPTH == 1) load_final_operands();
@@ -589,15 +674,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         __syncthreads();                                         // (every wave runs exactly one of the GN instantiations)
         IAF_FSTAMP(11);
         hidden_epilogue(std::integral_constant<int, NPT0>{}, std::integral_constant<int, G::rows_h(0)>{},
-                        std::integral_constant<int, EM0>{}, std::integral_constant<int, 1>{}, acc0, bi0, G::HREG0, p.hsave[0], p.border[0]);
+                        std::integral_constant<int, EM0>{}, std::integral_constant<int, 1>{}, acc0, bi0, G::HREG0, p.hsave[0], p.border[0],
+                        xch_row(0));
     });
+    xch_publish(0);
     __syncthreads();
     IAF_FSTAMP(2);
     static_for<DEPTH - 1>([&](auto lm_c) {
         constexpr int l = decltype(lm_c)::value + 1;              // hidden layer l reads h_{l-1}, writes h_l into the other region
         constexpr int IN_REG = ((l - 1) & 1) ? G::HREG1 : G::HREG0, OUT_REG = (l & 1) ? G::HREG1 : G::HREG0;
         if constexpr (l == 1) {   // the staged context sat in the h_odd region: its zero columns again, before the epilogue fills the rest
-            constexpr int H1ROWS = G::rows_h(1);
+            constexpr int H1ROWS = G::rows_reg(1);
             for (int i = tid; i < H1ROWS * 2 * H16; i += 256) {
                 const int rs = i / H16, u = i - rs * H16;
                 smem4[G::HREG1 + ((rs >> 1) * RS + (rs & 1) * (W + 1)) * H16 + u] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -612,15 +699,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             load_bias(p.bias[l], bil);
             const f32x4* wbl = (const f32x4*)p.wp3[l];
             conv_phase(std::integral_constant<int, RDH>{}, std::integral_constant<int, NPTL>{}, std::integral_constant<int, NTWH>{},
-                       std::integral_constant<int, G::rows_h(l)>{}, std::integral_constant<int, EML>{}, IN_REG, H16, H8, wbl, NHT, htile, 0,
-                       NSTEP_H, (l & 1) ? wr1 : wr0, accl, HTRI, g_c);
+                       std::integral_constant<int, G::rows_h(l)>{}, std::integral_constant<int, EML>{}, IN_REG, H16, H8, wbl, NHT, htile,
+                       (l & 1) ? wr1 : wr0, accl, PartH1{}, g_c, SET);
+            if constexpr (XCH) {     // the row below arrives while the taps of the own rows were multiplied: its taps now
+                static_for<RDH>([&](auto i) {
+                    ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWH * 3>{},
+                              (l & 1) ? wr1[decltype(i)::value] : wr0[decltype(i)::value], wbl, NHT, htile, PartBelow{}, decltype(i)::value, ALL);
+                });
+                xch_import(l - 1, IN_REG);
+                conv_phase(std::integral_constant<int, RDH>{}, std::integral_constant<int, NPTL>{}, std::integral_constant<int, NTWH>{},
+                           std::integral_constant<int, G::rows_h(l)>{}, std::integral_constant<int, EML>{}, IN_REG, H16, H8, wbl, NHT, htile,
+                           (l & 1) ? wr1 : wr0, accl, PartBelow{}, g_c, ADD);
+            }
             if constexpr (l == 1) IAF_FSTAMP(7);
             if constexpr (l == DEPTH - 1) load_final_operands();
             preload_after(std::integral_constant<int, l>{});
             hidden_epilogue(std::integral_constant<int, NPTL>{}, std::integral_constant<int, G::rows_h(l)>{},
-                            std::integral_constant<int, EML>{}, std::integral_constant<int, 0>{}, accl, bil, OUT_REG, p.hsave[l], p.border[l]);
+                            std::integral_constant<int, EML>{}, std::integral_constant<int, 0>{}, accl, bil, OUT_REG, p.hsave[l], p.border[l],
+                            xch_row(l));
             if constexpr (l == 1) IAF_FSTAMP(12);
         });
+        xch_publish(l);
         __syncthreads();
     });
     IAF_FSTAMP(3);
@@ -630,9 +729,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     float* xbuf = (float*)(smem + (size_t)G::XB_OFF * 16);
     {
         f32x4 acco[NPTO][NTWO];
+        constexpr int LAST_REG = ((DEPTH - 1) & 1) ? G::HREG1 : G::HREG0;
         conv_phase(std::integral_constant<int, RDO>{}, std::integral_constant<int, NPTO>{}, std::integral_constant<int, NTWO>{},
-                   std::integral_constant<int, R>{}, std::integral_constant<int, (1 << NPTO) - 1>{}, ((DEPTH - 1) & 1) ? G::HREG1 : G::HREG0,
-                   H16, H8, wbo, 2 * NZT, otile, 0, NSTEP_H, wro, acco, NOTRI, std::integral_constant<int, 0>{});
+                   std::integral_constant<int, R>{}, std::integral_constant<int, (1 << NPTO) - 1>{}, LAST_REG,
+                   H16, H8, wbo, 2 * NZT, otile, wro, acco, PartO1{}, std::integral_constant<int, 0>{}, SET);
+        if constexpr (XCH) {
+            static_for<RDO>([&](auto i) {
+                ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWO * 3>{}, wro[decltype(i)::value], wbo, 2 * NZT,
+                          otile, PartBelow{}, decltype(i)::value, ALL);
+            });
+            xch_import(DEPTH - 1, LAST_REG);
+            conv_phase(std::integral_constant<int, RDO>{}, std::integral_constant<int, NPTO>{}, std::integral_constant<int, NTWO>{},
+                       std::integral_constant<int, R>{}, std::integral_constant<int, (1 << NPTO) - 1>{}, LAST_REG,
+                       H16, H8, wbo, 2 * NZT, otile, wro, acco, PartBelow{}, std::integral_constant<int, 0>{}, ADD);
+        }
         IAF_FSTAMP(4);
         float* mine = xbuf;
 #pragma unroll
@@ -713,7 +823,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int o = RW / 2; o > 0; o >>= 1) a += __shfl_xor(a, o);
             const int idx = tid + e * 256;
-            if (idx < NZ * RW && (idx & (RW - 1)) == 0) p.kl_part[(size_t)blockIdx.x * NZ + idx / RW] = a;
+            if (idx < NZ * RW && (idx & (RW - 1)) == 0) p.kl_part[((size_t)b * p.nrb + rbk) * NZ + idx / RW] = a;
         }
     }
     IAF_FSTAMP(5);

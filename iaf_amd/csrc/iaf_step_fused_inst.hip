@@ -4,9 +4,9 @@
 // stack of config 3 (n_z = 64, depth_ar = 4, n_h = 64 / 128 / 192) wherever its five LDS regions fit 160 KiB.  Built as its own translation unit by iaf_amd/build.py.
 #include "iaf_step_fused.hpp"
 
-template <int NHT, int NZT, int DEPTH, int W, int R>
-static step_fn_t inst(int var, size_t* lds) {
-    typedef StepGeom<NHT, NZT, DEPTH, W, R> G;
+template <int NHT, int NZT, int DEPTH, int W, int R, int XCH = 0>
+static step_fn_t inst(int var, size_t* lds, size_t* xrow) {
+    typedef StepGeom<NHT, NZT, DEPTH, W, R, XCH> G;
     static_assert((G::CSTR & 15) == 4 || (G::CSTR & 15) == 12, "context rows: 4 channel groups x 16 pixels must hit 64 distinct banks");
     // does the geometry fit 160 KiB, the staged context its region, the exchange buffer the regions that are dead by then?
     constexpr bool fits = G::lds_bytes() <= 160 * 1024 && (DEPTH < 2 || G::ctx_bytes() <= (size_t)(G::END - G::HREG1) * 16) &&
@@ -16,27 +16,39 @@ static step_fn_t inst(int var, size_t* lds) {
         return nullptr;
     } else {
         *lds = G::lds_bytes();
-        switch (var) {
-            case 0: return iaf_step_fused_kernel<NHT, NZT, DEPTH, W, R, 0>;
-            case 1: return iaf_step_fused_kernel<NHT, NZT, DEPTH, W, R, 1>;
-            case 2: return iaf_step_fused_kernel<NHT, NZT, DEPTH, W, R, 2>;
+        if (xrow) *xrow = G::xrow_bytes();
+        if constexpr (XCH) {
+            return var == 3 ? iaf_step_fused_kernel<NHT, NZT, DEPTH, W, R, 0, 1> : nullptr;
+        } else {
+            switch (var) {
+                case 0: return iaf_step_fused_kernel<NHT, NZT, DEPTH, W, R, 0>;
+                case 1: return iaf_step_fused_kernel<NHT, NZT, DEPTH, W, R, 1>;
+                case 2: return iaf_step_fused_kernel<NHT, NZT, DEPTH, W, R, 2>;
+            }
+            return nullptr;
         }
-        return nullptr;
     }
 }
 
 template <int NHT, int NZT, int DEPTH>
 static step_fn_t inst_wr(int W, int R, int var, size_t* lds) {
-    if (W == 16 && R == 2) return inst<NHT, NZT, DEPTH, 16, 2>(var, lds);
-    if (W == 8 && R == 1) return inst<NHT, NZT, DEPTH, 8, 1>(var, lds);
-    if (W == 8 && R == 2) return inst<NHT, NZT, DEPTH, 8, 2>(var, lds);
-    if (W == 4 && R == 4) return inst<NHT, NZT, DEPTH, 4, 4>(var, lds);
+    if (W == 16 && R == 2) return inst<NHT, NZT, DEPTH, 16, 2>(var, lds, nullptr);
+    if (W == 8 && R == 1) return inst<NHT, NZT, DEPTH, 8, 1>(var, lds, nullptr);
+    if (W == 8 && R == 2) return inst<NHT, NZT, DEPTH, 8, 2>(var, lds, nullptr);
+    if (W == 4 && R == 4) return inst<NHT, NZT, DEPTH, 4, 4>(var, lds, nullptr);
     return nullptr;
 }
 
 // two translation units (iaf_amd/build.py: -DIAF_FUSED_PART=0 / 1) so that the build compiles them side by side
 // (no -DIAF_FUSED_PART: both parts in one unit)
 #if !defined(IAF_FUSED_PART) || IAF_FUSED_PART == 0
+// the halo-exchange kernel (var 3): the BASELINE run's 16-pixel geometry (at 8-pixel rows, one row per workgroup, the exchange
+// costs more than the recompute it saves: 40.6 k against 35.6 k cycles)
+extern "C" step_fn_t iaf_pick_step_fused_xch(int nht, int nzt, int depth, int W, int R, size_t* lds, size_t* xrow) {
+    *lds = 0; *xrow = 0;
+    if (nht == 10 && nzt == 2 && depth == 2 && W == 16 && R == 2) return inst<10, 2, 2, 16, 2, 1>(3, lds, xrow);
+    return nullptr;
+}
 extern "C" step_fn_t iaf_pick_step_fused_a(int nht, int nzt, int depth, int W, int R, int var, size_t* lds) {
     *lds = 0;
     if (nht == 10 && nzt == 2 && depth == 2) return inst_wr<10, 2, 2>(W, R, var, lds);      // configs 1-2, 5 (README run)

@@ -26,13 +26,19 @@ struct StepP {
     // mean / free-bits max / channel sum applied (tf_train.py:79-85) by iaf_kl_finish_kernel: ONE small launch behind this
     // one instead of the two (row sums over the KL tensor + finish) of round 2.  NULL: no partial sums are written.
     float* kl_part;
+    // XCH kernels (halo rows exchanged between the row blocks of an image instead of recomputed): row buffer, flags, error word
+    char* xh;
+    unsigned* xflag;
+    unsigned* xerr;
 };
 
 typedef void (*step_fn_t)(StepP);
 // kernel + dynamic LDS bytes for (n_h / 16, n_z / 16, depth_ar, image width, output rows per workgroup), or NULL
-// var: 0 TF statement, 1 Theano, 2 Theano with flipmask
+// var: 0 TF statement, 1 Theano, 2 Theano with flipmask, 3 TF statement with the halo exchange (StepP::xh; *xrow = bytes of one
+// exported row)
 extern "C" step_fn_t iaf_pick_step_fused_a(int nht, int nzt, int depth, int W, int R, int var, size_t* lds);   // depth_ar <= 2 geometries
 extern "C" step_fn_t iaf_pick_step_fused_b(int nht, int nzt, int depth, int W, int R, int var, size_t* lds);   // depth_ar = 4 geometries
+extern "C" step_fn_t iaf_pick_step_fused_xch(int nht, int nzt, int depth, int W, int R, size_t* lds, size_t* xrow);     // var 3
 static inline step_fn_t iaf_pick_step_fused(int nht, int nzt, int depth, int W, int R, int var, size_t* lds) {
     step_fn_t f = iaf_pick_step_fused_a(nht, nzt, depth, W, R, var, lds);
     return f ? f : iaf_pick_step_fused_b(nht, nzt, depth, W, R, var, lds);

@@ -282,6 +282,12 @@ class ARStack(object):
         every launch runs on the bf16 matrix cores; a launch that would need it raises).  See include/iaf_hip.h."""
         _capi.check(_capi.lib().iaf_stack_set_packs(self._h, _capi.IAF_PACK_BF16X3 | (_capi.IAF_PACK_F32 if f32 else 0)))
 
+    def exchange_errors(self):
+        """bounded waits of the halo exchange between row blocks that gave up (iaf_stack_exchange_errors): 0 = never"""
+        e = ctypes.c_uint(0)
+        _capi.check(_capi.lib().iaf_stack_exchange_errors(self._h, ctypes.byref(e)))
+        return int(e.value)
+
     def step_is_fused(self, B, H, W):
         """rows per workgroup of the one-launch step at this size, 0 if the step runs layer by layer"""
         return int(_capi.lib().iaf_stack_step_is_fused(self._h, int(B), int(H), int(W)))

@@ -290,6 +290,14 @@ int iaf_stack_set_fuse_step(iaf_stack_t* s, int mode);
 #define IAF_PACK_BF16X3 2
 int iaf_stack_set_packs(iaf_stack_t* s, int packs);
 int iaf_stack_step_is_fused(const iaf_stack_t* s, int B, int H, int W);
+/* The one-launch step of the TF statement at 16-pixel rows does not recompute the rows its row blocks share: the block below
+ * hands its first hidden rows to the block above through device memory (agent-scope accesses and a counter per row; a
+ * workgroup only ever waits for one dispatched before it).  The rows and counters live in buffers the STACK owns (allocated on
+ * the first such launch outside a stream capture -- inside one, the recomputing kernel runs until they exist), so launches of
+ * one stack must not overlap on different streams.  The waits are bounded: a wait that gives up sets the stack's error word,
+ * which this call returns in *errors (0 = never; it synchronises the device).  IAF_FUSE_XCH=0 in the environment keeps the
+ * recomputing kernel. */
+int iaf_stack_exchange_errors(const iaf_stack_t* s, unsigned* errors);
 int iaf_stack_autotune(iaf_stack_t* s, const float* z, const float* context, float* z_new, float* logsd, int B, int H, int W,
                        void* workspace, size_t workspace_bytes, int reps, void* stream, int* chosen, float* us);
 /* Per-kernel timing with HIP events on the launch stream: every launch of GEMM layer `layer` is

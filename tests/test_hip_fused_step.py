@@ -200,6 +200,50 @@ def test_repeated_launches_are_deterministic(amd):
     for _ in range(200):
         z1, s1 = st.iaf_step(zd, cd)
         assert torch.equal(z1, z0) and torch.equal(s1, s0)
+    assert st.exchange_errors() == 0
+
+
+_XCH_CHILD = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests/golden")
+import golden_inputs as gi, iaf_amd
+B, H = int(sys.argv[3]), 16
+rng = np.random.RandomState(77)
+params = gi.ar_multiconv2d_params(rng, 32, [160, 160], [32, 32])
+z, ctx = rng.standard_normal((B, 32, H, H)), rng.standard_normal((B, 160, H, H))
+dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+st = iaf_amd.ARStack(32, [160, 160])
+st.prepare({k: dev(v) for k, v in params.items()})
+zd, cd = dev(z), dev(ctx)
+outs = [st.iaf_step(zd, cd) for _ in range(3)][-1]
+torch.cuda.synchronize()
+assert st.exchange_errors() == 0
+np.savez(sys.argv[2], z=outs[0].cpu().numpy(), s=outs[1].cpu().numpy())
+"""
+
+
+@pytest.mark.parametrize("B", [32, 64, 5], ids=["B32_one_round", "B64_two_rounds_of_workgroups", "B5"])
+def test_halo_exchange_agrees_with_halo_recompute(amd, B, tmp_path):
+    """16-pixel rows of the TF statement: the row blocks of an image hand each other their first hidden rows through
+    device memory instead of recomputing them (iaf_step_fused.hpp, XCH).  The imported row is bit for bit what the
+    neighbour computed for itself; the layer that reads it sums its taps in two parts (own rows, then the row below), so
+    against the recomputing kernel (IAF_FUSE_XCH=0, read once per process: a child process each) the outputs move by fp32
+    round-off and no more -- also when the grid does not fit the chip in one round (B = 64: 512 workgroups; a workgroup
+    only waits for one with a lower index) -- and no bounded wait may have given up (asserted in the child)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for mode in ("1", "0"):
+        out = str(tmp_path / ("xch%s.npz" % mode))
+        env = dict(os.environ, IAF_FUSE_XCH=mode)
+        subprocess.run([sys.executable, "-c", _XCH_CHILD, root, out, str(B)], check=True, env=env, timeout=600)
+        got[mode] = np.load(out)
+    for k in ("z", "s"):
+        a, r = got["1"][k].astype(np.float64), got["0"][k].astype(np.float64)
+        assert np.isfinite(a).all()
+        assert np.abs(a - r).max() <= 2e-6 * max(1.0, np.abs(r).max()), (k, np.abs(a - r).max())
 
 
 def _theano_params(rng, name, n_z, n_h_list):

@@ -4,5 +4,5 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r03
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-timeout 1500 python -m pytest $R/tests -q -m gpu -x 2>&1 | tail -15 > $O/pytest_gpu.txt
+timeout 1500 python -m pytest $R/tests -q -m gpu 2>&1 | tail -25 > $O/pytest_gpu.txt
 tail -5 $O/pytest_gpu.txt
