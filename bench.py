@@ -854,8 +854,12 @@ def iw_eval_bench(args, depths, dist, rank, n_gpus):
 
 def _halo_note(st, R, args):
     """how many MACs the one-launch step issues per live MAC: hidden layer l is computed on R + depth_ar - l rows per R
-    output rows (iaf_step_fused.hpp); roofline figures count the live ones only"""
+    output rows (iaf_step_fused.hpp) -- or on its R own rows where the row blocks exchange their halo rows; roofline figures
+    count the live ones only"""
     d = args.depth_ar
+    if st.step_exchanges(args.batch, 16, 16):
+        return ("the row blocks of an image exchange their halo rows through device memory (agent-scope accesses): every hidden "
+                "layer is computed on the %d rows its workgroup owns, none twice" % R)
     live = [st.layer_work(l, args.batch, 16, 16)["live_flops"] for l in range(d + 1)]
     issued = sum(live[l] * (R + d - l) / R for l in range(d)) + live[d]
     return "the launch multiplies %.2fx the live MACs (halo rows of the hidden layers recomputed per %d-row workgroup); only live MACs are counted" % (
@@ -890,16 +894,17 @@ def _issued_over_live(args, R, W):
     nrb = (H + R - 1) // R
     units = 0
     cin = nz
+    import iaf_amd
+    st = iaf_amd.ARStack(nz, [nh] * d)
+    xch = st.step_exchanges(args.batch, H, W)          # halo rows imported from the block below instead of recomputed
     for l in range(d):
         per_tile = (nh // 16) * (cin // 32) * 5
         if l >= 1 and getattr(args, "variant", "tf") == "tf":
             per_tile -= _tri_skipped(nh // 16, cin // 32)
-        units += -(-((R + d - l) * W) // 16) * per_tile
+        units += -(-((R if xch else R + d - l) * W) // 16) * per_tile
         cin = nh
     units += -(-(R * W) // 16) * (2 * nz // 16) * (cin // 32) * 5
     issued = float(args.batch * nrb * units) * 16 * 16 * 32 * 2
-    import iaf_amd
-    st = iaf_amd.ARStack(nz, [nh] * d)
     return issued / st.step_work(args.batch, H, W)["live_flops"]
 
 
@@ -1212,6 +1217,10 @@ def main():
                         "note": "the whole timed step (weight prep + every conv launch + gaps) against the same fp32-MFMA peak"}
     roofline["kernels"] = ktable
     roofline["extended_unit"] = xunit
+    # the halo exchange between the row blocks of the 16x16 step waits with a bound: a wait that gave up would have produced garbage
+    xerrs = sum(L["stack"].exchange_errors() for L in layers)
+    if xerrs:
+        raise RuntimeError("one-launch IAF step: %d halo-exchange wait(s) gave up (iaf_stack_exchange_errors)" % xerrs)
     rp = os.path.join(ROOT, "profiles", "rocprof_dominant_kernel.json")
     if os.path.exists(rp):
         try:

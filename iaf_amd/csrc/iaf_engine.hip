@@ -1012,6 +1012,22 @@ static step_fn_t fused_step_plan(const iaf_stack_t* s, int B, int H, int W, int*
     return fn;
 }
 
+// The halo-exchange form of the one-launch step (iaf_step_fused.hpp, XCH), where it applies: TF statement, more than one row
+// block per image, a geometry compiled for it (IAF_FUSE_XCH=0: dev knob)
+static step_fn_t fused_step_xch(const iaf_stack_t* s, int H, int W, int R, size_t* lds, size_t* xrow) {
+    static const bool xch_env = !(getenv("IAF_FUSE_XCH") && getenv("IAF_FUSE_XCH")[0] == '0');
+    if (!xch_env || s->variant != IAF_VARIANT_TF || R <= 0 || (H + R - 1) / R < 2) return nullptr;
+    step_fn_t f = iaf_pick_step_fused_xch(s->n_h / 16, s->n_z / 16, s->depth_ar, W, R, lds, xrow);
+    return (f && *lds <= 160 * 1024) ? f : nullptr;
+}
+
+extern "C" int iaf_stack_step_exchanges(const iaf_stack_t* s, int B, int H, int W) {
+    if (!s) return 0;
+    const int R = iaf_stack_step_is_fused(s, B, H, W);
+    size_t lds = 0, xrow = 0;
+    return (R > 0 && fused_step_xch(s, H, W, R, &lds, &xrow)) ? 1 : 0;
+}
+
 // kl_part: posterior mode only -- per-(row block, channel) sums of the KL elements, [B * nrb][n_z] (StepP::kl_part)
 static int launch_fused_step(iaf_stack_t* s, step_fn_t fn, int R, size_t lds, const ConvP& base, int first_inmode, const float* ctx,
                              const float* ctx2, hipStream_t st, float* const* hsave = nullptr, float* kl_part = nullptr) {
@@ -1033,10 +1049,9 @@ static int launch_fused_step(iaf_stack_t* s, step_fn_t fn, int R, size_t lds, co
     // Halo exchange instead of halo recompute (TF statement, more than one row block per image, the geometries compiled for it;
     // IAF_FUSE_XCH=0: dev knob).  Its buffers are the stack's: allocated here on first use -- not inside a stream capture, where
     // the recomputing kernel runs instead (warm up before capturing, as for the LDS cap below).
-    static const bool xch_env = !(getenv("IAF_FUSE_XCH") && getenv("IAF_FUSE_XCH")[0] == '0');
-    if (xch_env && s->variant == IAF_VARIANT_TF && q.nrb > 1) {
+    {
         size_t xl = 0, xrow = 0;
-        if (step_fn_t fx = iaf_pick_step_fused_xch(s->n_h / 16, s->n_z / 16, s->depth_ar, base.W, R, &xl, &xrow)) {
+        if (step_fn_t fx = fused_step_xch(s, base.H, base.W, R, &xl, &xrow)) {
             const size_t nslot = (size_t)s->depth_ar * base.B * q.nrb, need = nslot * xrow;
             if (need > s->xch_bytes || nslot > s->xch_nflag) {
                 hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -1047,7 +1062,7 @@ static int launch_fused_step(iaf_stack_t* s, step_fn_t fn, int R, size_t lds, co
                     s->xch_buf = nullptr; s->xch_flag = nullptr; s->xch_bytes = 0; s->xch_nflag = 0;
                     HIP_TRY(hipMalloc((void**)&s->xch_buf, need));
                     HIP_TRY(hipMalloc((void**)&s->xch_flag, (nslot + 1) * sizeof(unsigned)));       // flags + error word
-                    HIP_TRY(hipMemset(s->xch_flag, 0, (nslot + 1) * sizeof(unsigned)));
+                    HIP_TRY(hipMemsetAsync(s->xch_flag, 0, (nslot + 1) * sizeof(unsigned), st));      // (ordered in front of the launch)
                     s->xch_bytes = need; s->xch_nflag = nslot;
                 }
             }

@@ -288,6 +288,10 @@ class ARStack(object):
         _capi.check(_capi.lib().iaf_stack_exchange_errors(self._h, ctypes.byref(e)))
         return int(e.value)
 
+    def step_exchanges(self, B, H, W):
+        """True if the one-launch step at this size hands halo rows between its row blocks instead of recomputing them"""
+        return bool(_capi.lib().iaf_stack_step_exchanges(self._h, int(B), int(H), int(W)))
+
     def step_is_fused(self, B, H, W):
         """rows per workgroup of the one-launch step at this size, 0 if the step runs layer by layer"""
         return int(_capi.lib().iaf_stack_step_is_fused(self._h, int(B), int(H), int(W)))

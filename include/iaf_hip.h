@@ -298,6 +298,8 @@ int iaf_stack_step_is_fused(const iaf_stack_t* s, int B, int H, int W);
  * which this call returns in *errors (0 = never; it synchronises the device).  IAF_FUSE_XCH=0 in the environment keeps the
  * recomputing kernel. */
 int iaf_stack_exchange_errors(const iaf_stack_t* s, unsigned* errors);
+/* 1 if the step at this size runs as one launch in the halo-exchange form, else 0 */
+int iaf_stack_step_exchanges(const iaf_stack_t* s, int B, int H, int W);
 int iaf_stack_autotune(iaf_stack_t* s, const float* z, const float* context, float* z_new, float* logsd, int B, int H, int W,
                        void* workspace, size_t workspace_bytes, int reps, void* stream, int* chosen, float* us);
 /* Per-kernel timing with HIP events on the launch stream: every launch of GEMM layer `layer` is
