@@ -11,6 +11,12 @@
 // The halo rows are recomputed by the neighbouring workgroup (R = 2, D = 2: the first layer is computed twice, the second
 // 1.5 times); what is bought with that is one launch per step instead of three, no HBM round trip of the hidden
 // activations, no split-K exchange, and weight / context loads of the next phase in flight during the current one.
+// XCH = 1 (round 3; the TF statement at 16-pixel rows): the halo rows are EXCHANGED instead -- every hidden layer computes the R
+// rows its workgroup owns, its region holds one row more, and that row is the first row of the block below, which that block's
+// epilogue also stored to a per-stack buffer in device memory (agent-scope accesses: neighbouring workgroups sit on different
+// XCDs; a counter per row; bounded waits; a workgroup only waits for one dispatched before it).  The layer reading the imported
+// row multiplies the taps of its own rows first (StepPart), so most of the row's ~4 us of travel is covered.  See xch_* below
+// and DESIGN.md 4.9 item 7 for what was measured (also: agent-scope fences, an L2-scope variant -- both rejected).
 //
 // Arithmetic: the bf16x3 scheme of iaf_conv_bf3.hpp (three bf16 planes per operand, six products, fp32 accumulate) on
 // v_mfma_f32_16x16x32_bf16, reading the same fragment-ordered weight packs (PrepLayer.wp3).
