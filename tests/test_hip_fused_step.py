@@ -1,6 +1,7 @@
 """The one-launch IAF step (iaf_amd/csrc/iaf_step_fused.hpp: every masked conv of the stack + the affine transform /
 log-det term / KL elements in ONE kernel, a workgroup per R full-width image rows, hidden activations in LDS, halo rows
-recomputed) against the fp64 oracle and against the layer-by-layer kernels it replaces at the BASELINE sizes.
+recomputed -- or, at 16-pixel rows of the TF statement, handed from row block to row block through device memory) against the
+fp64 oracle and against the layer-by-layer kernels it replaces at the BASELINE sizes.
 
 Every other GPU parity test that builds an ARStack(32, [160, 160]) or (32, [64]) on 16- or 8-pixel-wide images already
 runs this kernel (it is the default there); this file pins down (a) WHERE it runs and where it steps aside, (b) all
