@@ -980,7 +980,44 @@ static int run_stack_generic(iaf_stack_t* s, const ConvP& base, int first_inmode
 // everything else takes the layer-by-layer path.  All three statements of the operator (the Theano one runs on the image
 // rotated by 180 degrees, where its taps are the TF ones).  Output rows per workgroup: 2 at 16 pixels per row; at 8,
 // one row while that still leaves fewer than two workgroups per CU (less halo recompute per row otherwise).
-static step_fn_t fused_step_plan(const iaf_stack_t* s, int B, int H, int W, int* R, size_t* lds) {
+// The halo-exchange form of the one-launch step (iaf_step_fused.hpp, XCH), where it applies: TF statement, more than one row
+// block per image, a geometry compiled for it (IAF_FUSE_XCH=0: dev knob)
+static step_fn_t fused_step_xch(const iaf_stack_t* s, int H, int W, int R, size_t* lds, size_t* xrow) {
+    static const bool xch_env = !(getenv("IAF_FUSE_XCH") && getenv("IAF_FUSE_XCH")[0] == '0');
+    if (!xch_env || s->variant != IAF_VARIANT_TF || R <= 0 || (H + R - 1) / R < 2) return nullptr;
+    step_fn_t f = iaf_pick_step_fused_xch(s->n_h / 16, s->n_z / 16, s->depth_ar, W, R, lds, xrow);
+    if (!f) f = iaf_pick_step_fused_xch_b(s->n_h / 16, s->n_z / 16, s->depth_ar, W, R, lds, xrow);
+    return (f && *lds <= 160 * 1024) ? f : nullptr;
+}
+
+// Its buffers are the stack's: the rows [layer][B * nrb][xrow bytes] and a counter per row (+ the error word), zero between
+// launches.  Allocated on first use -- not inside a stream capture (false then: the caller runs what it ran before; warm up
+// before capturing, as for the LDS cap).  Outgrown buffers stay alive with the stack: a captured graph may still name them.
+static bool xch_prepare(iaf_stack_t* s, int B, int nrb, size_t xrow, hipStream_t st) {
+    const size_t nslot = (size_t)s->depth_ar * B * nrb, need = nslot * xrow;
+    if (need <= s->xch_bytes && nslot <= s->xch_nflag) return true;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &cs);
+    if (cs != hipStreamCaptureStatusNone) return false;
+    char* nb = nullptr;
+    unsigned* nf = nullptr;
+    if (hipMalloc((void**)&nb, need) != hipSuccess) return false;
+    if (hipMalloc((void**)&nf, (nslot + 1) * sizeof(unsigned)) != hipSuccess ||
+        hipMemsetAsync(nf, 0, (nslot + 1) * sizeof(unsigned), st) != hipSuccess) {      // (ordered in front of the launch)
+        (void)hipFree(nb);
+        if (nf) (void)hipFree(nf);
+        return false;
+    }
+    if (s->xch_buf) s->xch_retired.push_back(s->xch_buf);
+    if (s->xch_flag) s->xch_retired.push_back(s->xch_flag);
+    s->xch_buf = nb; s->xch_flag = nf; s->xch_bytes = need; s->xch_nflag = nslot;
+    return true;
+}
+
+
+// st / launching: the stream of an imminent launch (the halo-exchange buffers may be allocated for it); a query otherwise
+static step_fn_t fused_step_plan(const iaf_stack_t* s, int B, int H, int W, int* R, size_t* lds, hipStream_t st = nullptr,
+                                 bool launching = false) {
     static const int env = getenv("IAF_FUSE_STEP") ? atoi(getenv("IAF_FUSE_STEP")) : -1;       // dev knob: 0 / 1
     const int mode = env >= 0 ? env : s->fuse_step;
     if (!mode || s->generic || s->precision != IAF_PRECISION_BF16X3) return nullptr;
@@ -1008,17 +1045,15 @@ static step_fn_t fused_step_plan(const iaf_stack_t* s, int B, int H, int W, int*
     }
     const int var = s->variant == IAF_VARIANT_TF ? 0 : s->variant == IAF_VARIANT_THEANO ? 1 : 2;
     step_fn_t fn = iaf_pick_step_fused(s->n_h / 16, s->n_z / 16, s->depth_ar, W, *R, var, lds);
-    if (!fn || *lds > 160 * 1024) return nullptr;
-    return fn;
-}
-
-// The halo-exchange form of the one-launch step (iaf_step_fused.hpp, XCH), where it applies: TF statement, more than one row
-// block per image, a geometry compiled for it (IAF_FUSE_XCH=0: dev knob)
-static step_fn_t fused_step_xch(const iaf_stack_t* s, int H, int W, int R, size_t* lds, size_t* xrow) {
-    static const bool xch_env = !(getenv("IAF_FUSE_XCH") && getenv("IAF_FUSE_XCH")[0] == '0');
-    if (!xch_env || s->variant != IAF_VARIANT_TF || R <= 0 || (H + R - 1) / R < 2) return nullptr;
-    step_fn_t f = iaf_pick_step_fused_xch(s->n_h / 16, s->n_z / 16, s->depth_ar, W, R, lds, xrow);
-    return (f && *lds <= 160 * 1024) ? f : nullptr;
+    if (fn && *lds <= 160 * 1024) return fn;               // (launch_fused_step switches to the halo-exchange form where it applies)
+    // geometries whose LDS regions only fit in the halo-exchange form (R + 1 rows per region instead of R + depth_ar): config 3's
+    // n_h = 128 / 192 at 16-pixel rows
+    size_t xl = 0, xrow = 0;
+    step_fn_t fx = fused_step_xch(s, H, W, *R, &xl, &xrow);
+    if (!fx) return nullptr;
+    if (launching && !xch_prepare(const_cast<iaf_stack_t*>(s), B, (H + *R - 1) / *R, xrow, st)) return nullptr;
+    *lds = xl;
+    return fx;
 }
 
 extern "C" int iaf_stack_step_exchanges(const iaf_stack_t* s, int B, int H, int W) {
@@ -1052,23 +1087,11 @@ static int launch_fused_step(iaf_stack_t* s, step_fn_t fn, int R, size_t lds, co
     {
         size_t xl = 0, xrow = 0;
         if (step_fn_t fx = fused_step_xch(s, base.H, base.W, R, &xl, &xrow)) {
-            const size_t nslot = (size_t)s->depth_ar * base.B * q.nrb, need = nslot * xrow;
-            if (need > s->xch_bytes || nslot > s->xch_nflag) {
-                hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-                (void)hipStreamIsCapturing(st, &cs);
-                if (cs == hipStreamCaptureStatusNone) {
-                    if (s->xch_buf) s->xch_retired.push_back(s->xch_buf);
-                    if (s->xch_flag) s->xch_retired.push_back(s->xch_flag);
-                    s->xch_buf = nullptr; s->xch_flag = nullptr; s->xch_bytes = 0; s->xch_nflag = 0;
-                    HIP_TRY(hipMalloc((void**)&s->xch_buf, need));
-                    HIP_TRY(hipMalloc((void**)&s->xch_flag, (nslot + 1) * sizeof(unsigned)));       // flags + error word
-                    HIP_TRY(hipMemsetAsync(s->xch_flag, 0, (nslot + 1) * sizeof(unsigned), st));      // (ordered in front of the launch)
-                    s->xch_bytes = need; s->xch_nflag = nslot;
-                }
-            }
-            if (need <= s->xch_bytes && nslot <= s->xch_nflag && xl <= 160 * 1024) {
+            if (xch_prepare(s, base.B, q.nrb, xrow, st)) {
                 fn = fx; lds = xl;
                 q.xh = s->xch_buf; q.xflag = s->xch_flag; q.xerr = s->xch_flag + s->xch_nflag;
+            } else if (fn == fx) {
+                return IAF_ERR_NOT_PREPARED;                 // (a geometry that only exists in this form, and no buffers: fused_step_plan refuses that)
             }
         }
     }
@@ -1104,7 +1127,7 @@ static int run_stack(iaf_stack_t* s, ConvP base, int first_inmode, const float* 
         int R = 0;
         size_t lds = 0;
         const bool aligned = (((uintptr_t)ctx | (uintptr_t)ctx2) & 15) == 0;      // it fetches the contexts 16 bytes at a time
-        if (step_fn_t fn = aligned ? fused_step_plan(s, base.B, base.H, base.W, &R, &lds) : nullptr)
+        if (step_fn_t fn = aligned ? fused_step_plan(s, base.B, base.H, base.W, &R, &lds, st, true) : nullptr)
             return launch_fused_step(s, fn, R, lds, base, first_inmode, ctx, ctx2, st);
     }
     Launch ls[MAX_GEMM_LAYERS];
@@ -1153,7 +1176,7 @@ extern "C" int iaf_step_time_layer(iaf_stack_t* s, int layer, const float* z, co
     if (layer == -2) {                // the whole step as ONE launch (iaf_step_fused.hpp), if the stack runs it that way here
         int R = 0;
         size_t lds = 0;
-        step_fn_t fn = fused_step_plan(s, B, H, W, &R, &lds);
+        step_fn_t fn = fused_step_plan(s, B, H, W, &R, &lds, st, true);
         if (!fn) return IAF_ERR_UNSUPPORTED;
         if ((rc = launch_fused_step(s, fn, R, lds, p, IN_NCHW, context, nullptr, st))) return rc;
         const int saved = s->prof_layer;
@@ -1233,7 +1256,7 @@ extern "C" int iaf_stack_autotune(iaf_stack_t* s, const float* z, const float* c
         int R = 0;
         size_t lds = 0;
         s->fs_force = 1;
-        const bool possible = fused_step_plan(s, B, H, W, &R, &lds) != nullptr;
+        const bool possible = fused_step_plan(s, B, H, W, &R, &lds, (hipStream_t)stream, true) != nullptr;
         float t[2] = {0.f, 0.f};
         // Timed as `reps` steps captured once and replayed -- the way a sampling / training loop runs them.  Issued one by one,
         // the layer-by-layer path at the small levels is bound by the host's launch rate and the comparison reads the host, not
@@ -1456,7 +1479,7 @@ extern "C" int iaf_posterior_block_forward(iaf_stack_t* s, const float* qz_mean,
         int R = 0;
         size_t lds = 0;
         const bool aligned = (((uintptr_t)up_context | (uintptr_t)down_context) & 15) == 0;
-        if (step_fn_t fn = aligned ? fused_step_plan(s, B, H, W, &R, &lds) : nullptr) {
+        if (step_fn_t fn = aligned ? fused_step_plan(s, B, H, W, &R, &lds, st, true) : nullptr) {
             const int nrb = (H + R - 1) / R;
             p.kl_elem = kl_elem;
             if ((rc = launch_fused_step(s, fn, R, lds, p, IN_POSTERIOR, up_context, down_context, st, nullptr, ws.hbuf[0]))) return rc;
@@ -1726,7 +1749,7 @@ extern "C" int iaf_step_forward_train(iaf_stack_t* s, const float* z, const floa
         int R = 0;
         size_t lds = 0;
         const bool aligned = ((uintptr_t)context & 15) == 0;
-        if (step_fn_t fn = aligned ? fused_step_plan(s, B, H, W, &R, &lds) : nullptr)
+        if (step_fn_t fn = aligned ? fused_step_plan(s, B, H, W, &R, &lds, st, true) : nullptr)
             return launch_fused_step(s, fn, R, lds, base, IN_NCHW, context, nullptr, st, tw.h);
     }
     const float* cur = z;
@@ -2107,7 +2130,7 @@ extern "C" int iaf_posterior_block_forward_train(iaf_stack_t* s, const float* qz
         int R = 0;
         size_t lds = 0;
         const bool aligned = (((uintptr_t)up_context | (uintptr_t)down_context) & 15) == 0;
-        if (step_fn_t fn = aligned ? fused_step_plan(s, B, H, W, &R, &lds) : nullptr) {
+        if (step_fn_t fn = aligned ? fused_step_plan(s, B, H, W, &R, &lds, st, true) : nullptr) {
             // (the backward never reads the KL tensor: its buffer takes the per-row-block partial sums instead)
             base.kl_elem = nullptr;
             if ((rc = launch_fused_step(s, fn, R, lds, base, IN_POSTERIOR, up_context, down_context, st, tw.h, tw.klelem))) return rc;

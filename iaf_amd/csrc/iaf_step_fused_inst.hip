@@ -58,6 +58,17 @@ extern "C" step_fn_t iaf_pick_step_fused_a(int nht, int nzt, int depth, int W, i
 #endif
 #if !defined(IAF_FUSED_PART) || IAF_FUSED_PART == 1
 // config 3 (up_iaf2_nl, n_z = 64, depth_ar = 4; n_h is not fixed by the reference's scripts): the geometries that fit
+// ... in the halo-exchange form: the regions hold R + 1 rows instead of R + depth_ar, which is what lets n_h = 128 / 192 fit
+// 160 KiB at 16-pixel rows (150 KiB at n_h = 192; the recomputing form needs 210)
+extern "C" step_fn_t iaf_pick_step_fused_xch_b(int nht, int nzt, int depth, int W, int R, size_t* lds, size_t* xrow) {
+    *lds = 0; *xrow = 0;
+    if (nzt == 4 && depth == 4 && W == 16 && R == 2) {
+        if (nht == 4) return inst<4, 4, 4, 16, 2, 1>(3, lds, xrow);
+        if (nht == 8) return inst<8, 4, 4, 16, 2, 1>(3, lds, xrow);
+        if (nht == 12) return inst<12, 4, 4, 16, 2, 1>(3, lds, xrow);
+    }
+    return nullptr;
+}
 extern "C" step_fn_t iaf_pick_step_fused_b(int nht, int nzt, int depth, int W, int R, int var, size_t* lds) {
     *lds = 0;
     if (nht == 4 && nzt == 4 && depth == 4) return inst_wr<4, 4, 4>(W, R, var, lds);

@@ -39,6 +39,7 @@ typedef void (*step_fn_t)(StepP);
 extern "C" step_fn_t iaf_pick_step_fused_a(int nht, int nzt, int depth, int W, int R, int var, size_t* lds);   // depth_ar <= 2 geometries
 extern "C" step_fn_t iaf_pick_step_fused_b(int nht, int nzt, int depth, int W, int R, int var, size_t* lds);   // depth_ar = 4 geometries
 extern "C" step_fn_t iaf_pick_step_fused_xch(int nht, int nzt, int depth, int W, int R, size_t* lds, size_t* xrow);     // var 3
+extern "C" step_fn_t iaf_pick_step_fused_xch_b(int nht, int nzt, int depth, int W, int R, size_t* lds, size_t* xrow);   // ... depth_ar = 4
 static inline step_fn_t iaf_pick_step_fused(int nht, int nzt, int depth, int W, int R, int var, size_t* lds) {
     step_fn_t f = iaf_pick_step_fused_a(nht, nzt, depth, W, R, var, lds);
     return f ? f : iaf_pick_step_fused_b(nht, nzt, depth, W, R, var, lds);

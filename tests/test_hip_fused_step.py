@@ -59,7 +59,10 @@ def test_where_the_step_runs_as_one_launch(amd):
     assert st.step_is_fused(32, 32, 32) == 0                     # no compiled geometry for 32-pixel rows
     assert amd.ARStack(32, [64]).step_is_fused(16, 16, 16) == 2   # BASELINE configs[0]
     deep = amd.ARStack(64, [192] * 4)                            # BASELINE configs[3]: five LDS regions
-    assert deep.step_is_fused(32, 16, 16) == 0 and deep.step_is_fused(32, 8, 8) == 1      # 16-pixel rows do not fit at n_h = 192
+    # 16-pixel rows at n_h = 192: five regions of R + depth_ar .. R + 1 rows do not fit 160 KiB -- in the halo-exchange form every
+    # region holds R + 1 rows and the step is one launch (150 KiB)
+    assert deep.step_is_fused(32, 16, 16) == 2 and deep.step_exchanges(32, 16, 16) and deep.step_is_fused(32, 8, 8) == 1
+    assert st.step_exchanges(32, 16, 16) and not st.step_exchanges(32, 8, 8)
     assert amd.ARStack(64, [64] * 4).step_is_fused(32, 16, 16) == 2 and amd.ARStack(64, [128] * 4).step_is_fused(32, 8, 8) == 1
     assert amd.ARStack(64, [64] * 3).step_is_fused(32, 16, 16) == 0                       # no compiled geometry
     assert amd.ARStack(32, [160, 160], variant="theano").step_is_fused(32, 16, 16) == 2           # all three statements
