@@ -104,6 +104,7 @@ struct iaf_stack {
     char* xch_buf = nullptr; size_t xch_bytes = 0;
     unsigned* xch_flag = nullptr; size_t xch_nflag = 0;
     std::vector<void*> xch_retired;       // outgrown buffers: a captured graph may still name them, so they live as long as the stack
+    bool xch_on = true;                   // iaf_stack_set_halo_exchange
     int precision = IAF_PRECISION_BF16X3;   // forward convs: bf16x3 split products on the bf16 MFMA, or the exact fp32 MFMA
     int fuse_first = 2;       // first masked conv fused into the second one's kernel: 0 never, 1 whenever possible, 2 only where
                               // iaf_stack_autotune measured it faster (on MI355X at the BASELINE sizes it is not: DESIGN.md 4.8)
@@ -459,6 +460,16 @@ extern "C" int iaf_stack_destroy(iaf_stack_t* s) {
     if (s->xch_flag) (void)hipFree(s->xch_flag);
     for (void* q : s->xch_retired) (void)hipFree(q);
     delete s;
+    return IAF_OK;
+}
+
+extern "C" int iaf_stack_set_halo_exchange(iaf_stack_t* s, int on) {
+    if (!s) return IAF_ERR_NULL;
+    s->xch_on = on != 0;
+    if (s->xch_flag) {                                       // a fresh start either way: counters and error word cleared
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemset(s->xch_flag, 0, (s->xch_nflag + 1) * sizeof(unsigned)));
+    }
     return IAF_OK;
 }
 
@@ -984,7 +995,7 @@ static int run_stack_generic(iaf_stack_t* s, const ConvP& base, int first_inmode
 // block per image, a geometry compiled for it (IAF_FUSE_XCH=0: dev knob)
 static step_fn_t fused_step_xch(const iaf_stack_t* s, int H, int W, int R, size_t* lds, size_t* xrow) {
     static const bool xch_env = !(getenv("IAF_FUSE_XCH") && getenv("IAF_FUSE_XCH")[0] == '0');
-    if (!xch_env || s->variant != IAF_VARIANT_TF || R <= 0 || (H + R - 1) / R < 2) return nullptr;
+    if (!xch_env || !s->xch_on || s->variant != IAF_VARIANT_TF || R <= 0 || (H + R - 1) / R < 2) return nullptr;
     step_fn_t f = iaf_pick_step_fused_xch(s->n_h / 16, s->n_z / 16, s->depth_ar, W, R, lds, xrow);
     if (!f) f = iaf_pick_step_fused_xch_b(s->n_h / 16, s->n_z / 16, s->depth_ar, W, R, lds, xrow);
     return (f && *lds <= 160 * 1024) ? f : nullptr;

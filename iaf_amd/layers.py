@@ -288,6 +288,10 @@ class ARStack(object):
         _capi.check(_capi.lib().iaf_stack_exchange_errors(self._h, ctypes.byref(e)))
         return int(e.value)
 
+    def set_halo_exchange(self, on=True):
+        """False: the one-launch step of this stack recomputes its halo rows instead of exchanging them (include/iaf_hip.h)"""
+        _capi.check(_capi.lib().iaf_stack_set_halo_exchange(self._h, 1 if on else 0))
+
     def step_exchanges(self, B, H, W):
         """True if the one-launch step at this size hands halo rows between its row blocks instead of recomputing them"""
         return bool(_capi.lib().iaf_stack_step_exchanges(self._h, int(B), int(H), int(W)))

@@ -298,6 +298,9 @@ int iaf_stack_step_is_fused(const iaf_stack_t* s, int B, int H, int W);
  * which this call returns in *errors (0 = never; it synchronises the device).  IAF_FUSE_XCH=0 in the environment keeps the
  * recomputing kernel. */
 int iaf_stack_exchange_errors(const iaf_stack_t* s, unsigned* errors);
+/* on = 0: this stack's one-launch step recomputes its halo rows (geometries that exist only in the exchange form run layer by
+ * layer then); on = 1 (default): exchange where it applies. */
+int iaf_stack_set_halo_exchange(iaf_stack_t* s, int on);
 /* 1 if the step at this size runs as one launch in the halo-exchange form, else 0 */
 int iaf_stack_step_exchanges(const iaf_stack_t* s, int B, int H, int W);
 int iaf_stack_autotune(iaf_stack_t* s, const float* z, const float* context, float* z_new, float* logsd, int B, int H, int W,

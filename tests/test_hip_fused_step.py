@@ -207,6 +207,31 @@ def test_repeated_launches_are_deterministic(amd):
     assert st.exchange_errors() == 0
 
 
+def test_halo_exchange_can_be_switched_off_per_stack(amd):
+    """iaf_stack_set_halo_exchange: the same stack with and without the exchange agrees to fp32 round-off (the layer that reads
+    the imported row sums its taps in two parts); a geometry that only exists in the exchange form steps aside to the
+    layer-by-layer kernels when it is off"""
+    B, n_z, n_h, d, H = 32, 32, 160, 2, 16
+    params, z, ctx = _case(41, B, n_z, n_h, d, H, H)
+    st = amd.ARStack(n_z, [n_h] * d)
+    st.prepare({k: dev(v) for k, v in params.items()})
+    zd, cd = dev(z), dev(ctx)
+    assert st.step_exchanges(B, H, H)
+    z1, s1 = st.iaf_step(zd, cd)
+    st.set_halo_exchange(False)
+    assert not st.step_exchanges(B, H, H) and st.step_is_fused(B, H, H) == 2
+    z0, s0 = st.iaf_step(zd, cd)
+    for a, r in ((z1, z0), (s1, s0)):
+        assert float((a - r).abs().max()) <= 2e-6 * max(1.0, float(r.abs().max()))
+    st.set_halo_exchange(True)
+    z2, s2 = st.iaf_step(zd, cd)
+    assert torch.equal(z2, z1) and torch.equal(s2, s1) and st.exchange_errors() == 0
+    deep = amd.ARStack(64, [192] * 4)
+    assert deep.step_is_fused(32, 16, 16) == 2
+    deep.set_halo_exchange(False)
+    assert deep.step_is_fused(32, 16, 16) == 0 and deep.step_is_fused(32, 8, 8) == 1
+
+
 _XCH_CHILD = r"""
 import sys, numpy as np, torch
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests/golden")
