@@ -48,7 +48,8 @@
 
 #include "iaf_conv_kernel.hpp"
 
-#define IAF_ABI_VERSION 3   // 2: + iaf_conv3x3_*; 3: bf16x3 default precision, THEANO_FLIPMASK, negative nt in autotune reports,
+#define IAF_ABI_VERSION 4   // 4: stack-owned halo-exchange buffers (iaf_stack_set_halo_exchange / _exchange_errors / _step_exchanges): a stack's
+                          //    one-launch steps must not overlap on different streams; 2: + iaf_conv3x3_*; 3: bf16x3 default precision, THEANO_FLIPMASK, negative nt in autotune reports,
                           //    iaf_stack_set_packs, iaf_comm_* (include/iaf_hip.h)
 #define MAX_GEMM_LAYERS 10   // depth_ar <= 9 hidden + 1 output pair
 
