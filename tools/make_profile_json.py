@@ -13,7 +13,7 @@ import os
 import sys
 
 d, rnd = sys.argv[1], sys.argv[2]
-KERNEL = "iaf_step_fused_kernel<10, 2, 2, 16, 2, 0>"
+KERNEL = "iaf_step_fused_kernel<10, 2, 2, 16, 2, 0"       # (TF statement; the halo-exchange form carries one more template argument)
 
 
 def stats_row(path, needle):
@@ -43,7 +43,7 @@ if acc:
     m = {k: sum(v) / len(v) for k, v in acc.items()}
     fetch, write = m.get("FETCH_SIZE"), m.get("WRITE_SIZE")
     alg = 4.0 * (3 * 32 + 160) * 32 * 256 + 4.0 * (9 * (32 * 160 + 160 * 160 + 2 * 160 * 32) + 2 * (160 + 160 + 64))
-    pj = {"kernel": "iaf_step_fused_kernel<NHT=10,NZT=2,DEPTH=2,W=16,R=2,VAR=0 (TF statement)> (one IAF step: masked convs "
+    pj = {"kernel": "iaf_step_fused_kernel<NHT=10,NZT=2,DEPTH=2,W=16,R=2,VAR=0 (TF statement),XCH=1 (halo rows exchanged)> (one IAF step: masked convs "
                     "32->160->160->64 + affine/log-det, B=32, 16x16)",
           "command": "rocprofv3 --kernel-trace --pmc <counter set> (separate passes) -- python tools/run_step.py --hw 16 --reps 10 "
                      "--precision bf16x3 (tools/refresh_profiles.sh; raw CSVs in profiles/%s/pmc/step_*)" % rnd,
