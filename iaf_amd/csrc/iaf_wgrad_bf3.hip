@@ -135,9 +135,14 @@ __device__ __forceinline__ void wgrad_bf3_row(const WgradP& p, char* wsm, int gr
     auto store_block = [&](int kb) {
         split_store(xs, XPL, xv);
         if (tid < 16) split_store(xs + KB * XROW, XPL, xv2);
-        const bool ok = r0 + kb * KB + row < r1;                   // rows past the range: zeros
+        if (r0 + (kb + 1) * KB <= r1) {                            // (uniform) a block inside the range: no selects
 #pragma unroll
-        for (int i = 0; i < UW; ++i) split_store(ys + 64 * i, YPL, ok ? yv[i] : f32x4{0.f, 0.f, 0.f, 0.f});
+            for (int i = 0; i < UW; ++i) split_store(ys + 64 * i, YPL, yv[i]);
+        } else {
+            const bool ok = r0 + kb * KB + row < r1;               // rows past the range: zeros
+#pragma unroll
+            for (int i = 0; i < UW; ++i) split_store(ys + 64 * i, YPL, ok ? yv[i] : f32x4{0.f, 0.f, 0.f, 0.f});
+        }
     };
 
     // ---- MFMA roles
