@@ -1263,6 +1263,8 @@ def main():
             "precision": args.precision,
             "kernels_chosen": tuned if tuned else "static rule (no autotune)",
             "repeats_ms": [1e3 * r / args.steps for r in repeats],
+            # which levels of the one-launch step hand their halo rows from row block to row block instead of recomputing them
+            "halo_exchange": sorted({"%dx%d" % (L["H"], L["H"]) for L in layers if L["stack"].step_exchanges(args.batch, L["H"], L["H"])}),
             "timing": "median of %d repeats of the timed region (%d steps each, barrier + synchronize on both sides); %d untimed "
                       "settle replays after the %d warm-up steps" % (len(repeats), args.steps, n_settle, args.warmup),
         },
