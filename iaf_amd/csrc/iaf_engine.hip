@@ -467,7 +467,7 @@ extern "C" int iaf_stack_destroy(iaf_stack_t* s) {
 extern "C" int iaf_stack_set_halo_exchange(iaf_stack_t* s, int on) {
     if (!s) return IAF_ERR_NULL;
     s->xch_on = on != 0;
-    if (s->xch_flag) {                                       // a fresh start either way: counters and error word cleared
+    if (s->xch_flag) {                                       // a fresh start either way: flags and error word cleared
         HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(hipMemset(s->xch_flag, 0, (s->xch_nflag + 1) * sizeof(unsigned)));
     }
@@ -1002,11 +1002,11 @@ static step_fn_t fused_step_xch(const iaf_stack_t* s, int H, int W, int R, size_
     return (f && *lds <= 160 * 1024) ? f : nullptr;
 }
 
-// Its buffers are the stack's: the rows [layer][B * nrb][xrow bytes] and a counter per row (+ the error word), zero between
+// Its buffers are the stack's: the rows [layer][B * nrb][xrow bytes] and four flag words per row (+ the error word), zero between
 // launches.  Allocated on first use -- not inside a stream capture (false then: the caller runs what it ran before; warm up
 // before capturing, as for the LDS cap).  Outgrown buffers stay alive with the stack: a captured graph may still name them.
 static bool xch_prepare(iaf_stack_t* s, int B, int nrb, size_t xrow, hipStream_t st) {
-    const size_t nslot = (size_t)s->depth_ar * B * nrb, need = nslot * xrow;
+    const size_t nrow = (size_t)s->depth_ar * B * nrb, need = nrow * xrow, nslot = 4 * nrow;      // four flag words per row (one per wave)
     if (need <= s->xch_bytes && nslot <= s->xch_nflag) return true;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(st, &cs);

@@ -14,7 +14,7 @@
 // XCH = 1 (round 3; the TF statement at 16-pixel rows): the halo rows are EXCHANGED instead -- every hidden layer computes the R
 // rows its workgroup owns, its region holds one row more, and that row is the first row of the block below, which that block's
 // epilogue also stored to a per-stack buffer in device memory (agent-scope accesses: neighbouring workgroups sit on different
-// XCDs; a counter per row; bounded waits; a workgroup only waits for one dispatched before it).  The layer reading the imported
+// XCDs; four flag words per row, one per publishing wave; bounded waits; a workgroup only waits for one dispatched before it).  The layer reading the imported
 // row multiplies the taps of its own rows first (StepPart), so most of the row's ~4 us of travel is covered.  See xch_* below
 // and DESIGN.md 4.9 item 7 for what was measured (also: agent-scope fences, an L2-scope variant -- both rejected).
 //
@@ -582,8 +582,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
     // ---- XCH: halo rows through memory ---------------------------------------------------------------------------------
     // p.xh [layer][B * nrb][W slots x H16 x 16 bytes]: row 0 of block (b, k)'s hidden layer, as it sits in LDS; p.xflag [layer]
-    // [B * nrb]: 1 = published.  The consumer (block k - 1) clears the flag after its copy, so the flags are all zero between
-    // launches; launches on one stream are ordered, and the buffers belong to the stack (not re-entrant across streams).
+    // [B * nrb][4]: one word per publishing wave, 1 = that wave's part of the row is in memory (four stores to four words: a shared
+    // counter -- four read-modify-writes of one word -- measured 1.7 % slower).  The consumer (block k - 1) clears the words after
+    // its copy, so they are all zero between launches; launches on one stream are ordered, and the buffers belong to the stack
+    // (not re-entrant across streams).
     // Every access to the exchanged rows and flags is an AGENT-scope relaxed atomic (a load / store with the sc1 bit: coherent
     // per access across the XCDs' L2s), ordered by workgroup-scope fences (plain counter waits).  Agent-scope FENCES were
     // measured first: buffer_wbl2 / buffer_inv sc1 write back and invalidate the whole L2 -- with it the weight packs every
@@ -598,7 +600,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if (rbk > 0) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");             // this wave's stores are complete (issued early: no wait)
                 if (lane == 0)
-                    __hip_atomic_fetch_add(p.xflag + (size_t)l * p.B * p.nrb + xslot, 1u, __ATOMIC_RELAXED, XSCOPE);
+                    __hip_atomic_store(p.xflag + 4 * ((size_t)l * p.B * p.nrb + xslot) + wave, 1u, __ATOMIC_RELAXED, XSCOPE);
             }
         }
     };
@@ -607,9 +609,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             unsigned long long* dst = (unsigned long long*)(smem4 + reg + (R * RS + 1) * H16);
             constexpr int NU = W * H16 * 2;                                          // 8-byte units
             if (r0 + R < H) {
-                unsigned* fl = p.xflag + (size_t)l * p.B * p.nrb + xslot + 1;
+                // four words per row, one per publishing wave (plain stores: four read-modify-writes of ONE word queue up at the memory side)
+                unsigned long long* fl = (unsigned long long*)(p.xflag + 4 * ((size_t)l * p.B * p.nrb + xslot + 1));
                 int it = 0;                                                          // every wave polls for itself: all four waves below have published
-                while (__hip_atomic_load(fl, __ATOMIC_RELAXED, XSCOPE) < (unsigned)NW && ++it < (1 << 22)) __builtin_amdgcn_s_sleep(1);
+                constexpr unsigned long long BOTH = 0x0000000100000001ull;
+                while ((__hip_atomic_load(fl, __ATOMIC_RELAXED, XSCOPE) != BOTH || __hip_atomic_load(fl + 1, __ATOMIC_RELAXED, XSCOPE) != BOTH) &&
+                       ++it < (1 << 22))
+                    __builtin_amdgcn_s_sleep(1);
                 if (it >= (1 << 22) && p.xerr) *p.xerr = 1u;                         // (a bounded wait: a lost neighbour must not hang the GPU)
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 const unsigned long long* src = (const unsigned long long*)(p.xh + ((size_t)l * p.B * p.nrb + xslot + 1) * G::xrow_bytes());
@@ -622,7 +628,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                 for (int u = 0; u < (NU + 255) / 256; ++u) { const int i = tid + 256 * u; if (i < NU) dst[i] = t[u]; }
                 __syncthreads();
-                if (tid == 0) __hip_atomic_store(fl, 0u, __ATOMIC_RELAXED, XSCOPE);
+                if (tid == 0) {
+                    __hip_atomic_store(fl, 0ull, __ATOMIC_RELAXED, XSCOPE);
+                    __hip_atomic_store(fl + 1, 0ull, __ATOMIC_RELAXED, XSCOPE);
+                }
             } else {
                 for (int i = tid; i < NU; i += 256) dst[i] = 0ull;
                 __syncthreads();
