@@ -52,3 +52,27 @@ def test_train_mode_executes_the_rccl_exchange_on_one_gpu():
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["rccl_ranks"] == 1 and line["exchange"]["executed"] is True
     assert line["exchange"]["buckets"] >= 2 and line["exchange"]["alone_ms"] > 0
+
+
+@pytest.mark.parametrize("nht", [4, 8, 10, 12])
+def test_skipped_blocks_of_the_issued_over_live_figure_are_dead_in_the_mask(nht):
+    """bench.py's `roofline.issued_over_live` subtracts the centre-tap blocks a channel-triangular hidden layer of the
+    one-launch step skips (`_tri_skipped`, restating iaf_step_fused.hpp's compile-time `tri_live`): every (input pair of 32
+    channels, co tile of 16) block it counts must be ALL ZERO in the reference's mask (get_linear_ar_mask, layers.py:115-124,
+    n_in = n_out), and at n_h = 160 that is every dead block there is"""
+    import importlib.util
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from iaf_amd.layers import get_linear_ar_mask
+    n = 16 * nht
+    npair = -(-n // 32)
+    mask = get_linear_ar_mask(n, n, zerodiagonal=False)              # [n_in, n_out]
+    dead = sum(1 for c in range(npair) for t in range(nht) if not mask[32 * c:32 * c + 32, 16 * t:16 * t + 16].any())
+    assert dead == sum(max(0, npair - 1 - t // 2) for t in range(nht))     # block (c, t) is dead iff c > t // 2
+    skipped = bench._tri_skipped(nht, npair)
+    assert 0 <= skipped <= dead and (skipped > 0 or nht == 4)      # (n_h = 64: both pairs are live for some tile of the only slot)
+    if nht == 10:
+        assert skipped == dead == 20
