@@ -992,13 +992,14 @@ static int run_stack_generic(iaf_stack_t* s, const ConvP& base, int first_inmode
 // everything else takes the layer-by-layer path.  All three statements of the operator (the Theano one runs on the image
 // rotated by 180 degrees, where its taps are the TF ones).  Output rows per workgroup: 2 at 16 pixels per row; at 8,
 // one row while that still leaves fewer than two workgroups per CU (less halo recompute per row otherwise).
-// The halo-exchange form of the one-launch step (iaf_step_fused.hpp, XCH), where it applies: TF statement, more than one row
-// block per image, a geometry compiled for it (IAF_FUSE_XCH=0: dev knob)
+// The halo-exchange form of the one-launch step (iaf_step_fused.hpp, XCH), where it applies: more than one row block per image, a
+// geometry compiled for it and for the stack's statement (IAF_FUSE_XCH=0: dev knob)
 static step_fn_t fused_step_xch(const iaf_stack_t* s, int H, int W, int R, size_t* lds, size_t* xrow) {
     static const bool xch_env = !(getenv("IAF_FUSE_XCH") && getenv("IAF_FUSE_XCH")[0] == '0');
-    if (!xch_env || !s->xch_on || s->variant != IAF_VARIANT_TF || R <= 0 || (H + R - 1) / R < 2) return nullptr;
-    step_fn_t f = iaf_pick_step_fused_xch(s->n_h / 16, s->n_z / 16, s->depth_ar, W, R, lds, xrow);
-    if (!f) f = iaf_pick_step_fused_xch_b(s->n_h / 16, s->n_z / 16, s->depth_ar, W, R, lds, xrow);
+    if (!xch_env || !s->xch_on || R <= 0 || (H + R - 1) / R < 2) return nullptr;
+    const int var = s->variant == IAF_VARIANT_TF ? 0 : s->variant == IAF_VARIANT_THEANO ? 1 : 2;
+    step_fn_t f = iaf_pick_step_fused_xch(s->n_h / 16, s->n_z / 16, s->depth_ar, W, R, var, lds, xrow);
+    if (!f) f = iaf_pick_step_fused_xch_b(s->n_h / 16, s->n_z / 16, s->depth_ar, W, R, var, lds, xrow);
     return (f && *lds <= 160 * 1024) ? f : nullptr;
 }
 

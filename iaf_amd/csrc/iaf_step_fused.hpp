@@ -11,7 +11,7 @@
 // The halo rows are recomputed by the neighbouring workgroup (R = 2, D = 2: the first layer is computed twice, the second
 // 1.5 times); what is bought with that is one launch per step instead of three, no HBM round trip of the hidden
 // activations, no split-K exchange, and weight / context loads of the next phase in flight during the current one.
-// XCH = 1 (round 3; the TF statement at 16-pixel rows): the halo rows are EXCHANGED instead -- every hidden layer computes the R
+// XCH = 1 (round 3; 16-pixel rows): the halo rows are EXCHANGED instead -- every hidden layer computes the R
 // rows its workgroup owns, its region holds one row more, and that row is the first row of the block below, which that block's
 // epilogue also stored to a per-stack buffer in device memory (agent-scope accesses: neighbouring workgroups sit on different
 // XCDs; four flag words per row, one per publishing wave; bounded waits; a workgroup only waits for one dispatched before it).  The layer reading the imported
@@ -137,7 +137,6 @@ constexpr int tri_live(int ntw, int nfull, int nht, int c, int gn, int gi) {
 template <int NHT, int NZT, int DEPTH, int W, int R, int VAR = 0, int XCH = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void iaf_step_fused_kernel(StepP p) {
     typedef StepGeom<NHT, NZT, DEPTH, W, R, XCH> G;
-    static_assert(!XCH || VAR == 0, "the halo exchange is built for the TF statement");
     // exchanged rows and flags: AGENT scope (sc1: coherent across the XCDs, served by the memory side)
     constexpr int XSCOPE = __HIP_MEMORY_SCOPE_AGENT;
     constexpr bool FLIP = (VAR == 1), BORDER = (VAR != 0);
@@ -642,7 +641,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // ---- hidden layers ---------------------------------------------------------------------------------------------
     // the first (or only) part of a hidden layer l >= 1 and of the output pair; XCH: the taps of the own rows, the imported row's
     // taps follow as a second part behind the import
-    typedef std::conditional_t<XCH != 0, PartOwnTri, PartHid> PartH1;
+    typedef std::conditional_t<XCH != 0, std::conditional_t<VAR == 0, PartOwnTri, PartOwn>, PartHid> PartH1;
     typedef std::conditional_t<XCH != 0, PartOwn, PartFull> PartO1;
     int otile[NTWO];
 #pragma unroll

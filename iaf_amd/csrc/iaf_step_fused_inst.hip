@@ -18,7 +18,12 @@ static step_fn_t inst(int var, size_t* lds, size_t* xrow) {
         *lds = G::lds_bytes();
         if (xrow) *xrow = G::xrow_bytes();
         if constexpr (XCH) {
-            return var == 3 ? iaf_step_fused_kernel<NHT, NZT, DEPTH, W, R, 0, 1> : nullptr;
+            switch (var) {                                    // (the statement's variant, in the exchange form)
+                case 0: return iaf_step_fused_kernel<NHT, NZT, DEPTH, W, R, 0, 1>;
+                case 1: if constexpr (DEPTH == 2) return iaf_step_fused_kernel<NHT, NZT, DEPTH, W, R, 1, 1>; else return nullptr;
+                case 2: if constexpr (DEPTH == 2) return iaf_step_fused_kernel<NHT, NZT, DEPTH, W, R, 2, 1>; else return nullptr;
+            }
+            return nullptr;
         } else {
             switch (var) {
                 case 0: return iaf_step_fused_kernel<NHT, NZT, DEPTH, W, R, 0>;
@@ -42,11 +47,11 @@ static step_fn_t inst_wr(int W, int R, int var, size_t* lds) {
 // two translation units (iaf_amd/build.py: -DIAF_FUSED_PART=0 / 1) so that the build compiles them side by side
 // (no -DIAF_FUSED_PART: both parts in one unit)
 #if !defined(IAF_FUSED_PART) || IAF_FUSED_PART == 0
-// the halo-exchange kernel (var 3): the BASELINE run's 16-pixel geometry (at 8-pixel rows, one row per workgroup, the exchange
-// costs more than the recompute it saves: 40.6 k against 35.6 k cycles)
-extern "C" step_fn_t iaf_pick_step_fused_xch(int nht, int nzt, int depth, int W, int R, size_t* lds, size_t* xrow) {
+// the halo-exchange kernels: the BASELINE run's 16-pixel geometry, all three statements (at 8-pixel rows, one row per workgroup,
+// the exchange costs more than the recompute it saves: 40.6 k against 35.6 k cycles)
+extern "C" step_fn_t iaf_pick_step_fused_xch(int nht, int nzt, int depth, int W, int R, int var, size_t* lds, size_t* xrow) {
     *lds = 0; *xrow = 0;
-    if (nht == 10 && nzt == 2 && depth == 2 && W == 16 && R == 2) return inst<10, 2, 2, 16, 2, 1>(3, lds, xrow);
+    if (nht == 10 && nzt == 2 && depth == 2 && W == 16 && R == 2) return inst<10, 2, 2, 16, 2, 1>(var, lds, xrow);
     return nullptr;
 }
 extern "C" step_fn_t iaf_pick_step_fused_a(int nht, int nzt, int depth, int W, int R, int var, size_t* lds) {
@@ -60,12 +65,12 @@ extern "C" step_fn_t iaf_pick_step_fused_a(int nht, int nzt, int depth, int W, i
 // config 3 (up_iaf2_nl, n_z = 64, depth_ar = 4; n_h is not fixed by the reference's scripts): the geometries that fit
 // ... in the halo-exchange form: the regions hold R + 1 rows instead of R + depth_ar, which is what lets n_h = 128 / 192 fit
 // 160 KiB at 16-pixel rows (150 KiB at n_h = 192; the recomputing form needs 210)
-extern "C" step_fn_t iaf_pick_step_fused_xch_b(int nht, int nzt, int depth, int W, int R, size_t* lds, size_t* xrow) {
+extern "C" step_fn_t iaf_pick_step_fused_xch_b(int nht, int nzt, int depth, int W, int R, int var, size_t* lds, size_t* xrow) {
     *lds = 0; *xrow = 0;
-    if (nzt == 4 && depth == 4 && W == 16 && R == 2) {
-        if (nht == 4) return inst<4, 4, 4, 16, 2, 1>(3, lds, xrow);
-        if (nht == 8) return inst<8, 4, 4, 16, 2, 1>(3, lds, xrow);
-        if (nht == 12) return inst<12, 4, 4, 16, 2, 1>(3, lds, xrow);
+    if (nzt == 4 && depth == 4 && W == 16 && R == 2) {      // (TF statement only: inst returns NULL for the others)
+        if (nht == 4) return inst<4, 4, 4, 16, 2, 1>(var, lds, xrow);
+        if (nht == 8) return inst<8, 4, 4, 16, 2, 1>(var, lds, xrow);
+        if (nht == 12) return inst<12, 4, 4, 16, 2, 1>(var, lds, xrow);
     }
     return nullptr;
 }

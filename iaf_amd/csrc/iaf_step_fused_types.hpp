@@ -34,12 +34,12 @@ struct StepP {
 
 typedef void (*step_fn_t)(StepP);
 // kernel + dynamic LDS bytes for (n_h / 16, n_z / 16, depth_ar, image width, output rows per workgroup), or NULL
-// var: 0 TF statement, 1 Theano, 2 Theano with flipmask, 3 TF statement with the halo exchange (StepP::xh; *xrow = bytes of one
-// exported row)
+// var: 0 TF statement, 1 Theano, 2 Theano with flipmask
 extern "C" step_fn_t iaf_pick_step_fused_a(int nht, int nzt, int depth, int W, int R, int var, size_t* lds);   // depth_ar <= 2 geometries
 extern "C" step_fn_t iaf_pick_step_fused_b(int nht, int nzt, int depth, int W, int R, int var, size_t* lds);   // depth_ar = 4 geometries
-extern "C" step_fn_t iaf_pick_step_fused_xch(int nht, int nzt, int depth, int W, int R, size_t* lds, size_t* xrow);     // var 3
-extern "C" step_fn_t iaf_pick_step_fused_xch_b(int nht, int nzt, int depth, int W, int R, size_t* lds, size_t* xrow);   // ... depth_ar = 4
+// ... in the halo-exchange form (StepP::xh; *xrow = bytes of one exported row); var as above
+extern "C" step_fn_t iaf_pick_step_fused_xch(int nht, int nzt, int depth, int W, int R, int var, size_t* lds, size_t* xrow);
+extern "C" step_fn_t iaf_pick_step_fused_xch_b(int nht, int nzt, int depth, int W, int R, int var, size_t* lds, size_t* xrow);   // depth_ar = 4
 static inline step_fn_t iaf_pick_step_fused(int nht, int nzt, int depth, int W, int R, int var, size_t* lds) {
     step_fn_t f = iaf_pick_step_fused_a(nht, nzt, depth, W, R, var, lds);
     return f ? f : iaf_pick_step_fused_b(nht, nzt, depth, W, R, var, lds);

@@ -63,6 +63,7 @@ def test_where_the_step_runs_as_one_launch(amd):
     # region holds R + 1 rows and the step is one launch (150 KiB)
     assert deep.step_is_fused(32, 16, 16) == 2 and deep.step_exchanges(32, 16, 16) and deep.step_is_fused(32, 8, 8) == 1
     assert st.step_exchanges(32, 16, 16) and not st.step_exchanges(32, 8, 8)
+    assert amd.ARStack(32, [160, 160], variant="theano").step_exchanges(32, 16, 16)            # ... in all three statements
     assert amd.ARStack(64, [64] * 4).step_is_fused(32, 16, 16) == 2 and amd.ARStack(64, [128] * 4).step_is_fused(32, 8, 8) == 1
     assert amd.ARStack(64, [64] * 3).step_is_fused(32, 16, 16) == 0                       # no compiled geometry
     assert amd.ARStack(32, [160, 160], variant="theano").step_is_fused(32, 16, 16) == 2           # all three statements
