@@ -20,8 +20,8 @@ static step_fn_t inst(int var, size_t* lds, size_t* xrow) {
         if constexpr (XCH) {
             switch (var) {                                    // (the statement's variant, in the exchange form)
                 case 0: return iaf_step_fused_kernel<NHT, NZT, DEPTH, W, R, 0, 1>;
-                case 1: if constexpr (DEPTH == 2) return iaf_step_fused_kernel<NHT, NZT, DEPTH, W, R, 1, 1>; else return nullptr;
-                case 2: if constexpr (DEPTH == 2) return iaf_step_fused_kernel<NHT, NZT, DEPTH, W, R, 2, 1>; else return nullptr;
+                case 1: return iaf_step_fused_kernel<NHT, NZT, DEPTH, W, R, 1, 1>;
+                case 2: return iaf_step_fused_kernel<NHT, NZT, DEPTH, W, R, 2, 1>;
             }
             return nullptr;
         } else {
@@ -67,7 +67,7 @@ extern "C" step_fn_t iaf_pick_step_fused_a(int nht, int nzt, int depth, int W, i
 // 160 KiB at 16-pixel rows (150 KiB at n_h = 192; the recomputing form needs 210)
 extern "C" step_fn_t iaf_pick_step_fused_xch_b(int nht, int nzt, int depth, int W, int R, int var, size_t* lds, size_t* xrow) {
     *lds = 0; *xrow = 0;
-    if (nzt == 4 && depth == 4 && W == 16 && R == 2) {      // (TF statement only: inst returns NULL for the others)
+    if (nzt == 4 && depth == 4 && W == 16 && R == 2) {
         if (nht == 4) return inst<4, 4, 4, 16, 2, 1>(var, lds, xrow);
         if (nht == 8) return inst<8, 4, 4, 16, 2, 1>(var, lds, xrow);
         if (nht == 12) return inst<12, 4, 4, 16, 2, 1>(var, lds, xrow);

@@ -290,8 +290,8 @@ int iaf_stack_set_fuse_step(iaf_stack_t* s, int mode);
 #define IAF_PACK_BF16X3 2
 int iaf_stack_set_packs(iaf_stack_t* s, int packs);
 int iaf_stack_step_is_fused(const iaf_stack_t* s, int B, int H, int W);
-/* The one-launch step at 16-pixel rows (the BASELINE geometry for all three statements of the operator; the deep stacks of
- * config 3 for the TF statement) does not recompute the rows its row blocks share: the block below
+/* The one-launch step at 16-pixel rows (the BASELINE geometry and the deep stacks of config 3, all three statements of the
+ * operator) does not recompute the rows its row blocks share: the block below
  * hands its first hidden rows to the block above through device memory (agent-scope accesses and flag words per row; a
  * workgroup only ever waits for one dispatched before it).  The rows and flags live in buffers the STACK owns (allocated on
  * the first such launch outside a stream capture -- inside one, the recomputing kernel runs until they exist), so launches of
