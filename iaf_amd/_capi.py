@@ -14,12 +14,14 @@ IAF_ERR_NOT_MULTIPLE = -3
 IAF_ERR_NOT_PREPARED = -4
 IAF_ERR_WORKSPACE = -5
 IAF_ERR_UNSUPPORTED = -6
+IAF_ERR_EXCHANGE = -7
+IAF_ERR_CAPTURE_SLOTS = -8
 IAF_PRECISION_F32 = 0
 IAF_PRECISION_BF16X3 = 1
 IAF_COMM_ID_BYTES = 128
 IAF_PACK_F32 = 1
 IAF_PACK_BF16X3 = 2
-IAF_ABI_VERSION = 4                # must equal the library's iaf_abi_version(): a stale libiaf_hip.so is rejected
+IAF_ABI_VERSION = 5                # must equal the library's iaf_abi_version(): a stale libiaf_hip.so is rejected
 IAF_VARIANT_TF = 0
 IAF_VARIANT_THEANO = 1
 IAF_VARIANT_THEANO_FLIPMASK = 2
@@ -83,6 +85,8 @@ SIGNATURES = {
     "iaf_stack_exchange_errors": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint)]),
     "iaf_stack_step_exchanges": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "iaf_stack_set_halo_exchange": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "iaf_stack_set_halo_exchange_debug": (ctypes.c_int, [_vp, ctypes.c_uint]),
+    "iaf_stack_exchange_paths": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_uint)]),
     "iaf_comm_unique_id": (ctypes.c_int, [_vp]),
     "iaf_comm_create": (ctypes.c_int, [ctypes.POINTER(_vp), _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "iaf_comm_size": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
@@ -155,6 +159,12 @@ class UnsupportedError(ValueError):
     arguments, but its own class so that callers -- and tests -- can tell "not covered" from a genuine argument error)"""
 
 
+class ExchangeError(IafHipError):
+    """IAF_ERR_EXCHANGE: a bounded wait of the halo exchange gave up in an EARLIER launch of the stack -- that launch's outputs
+    carry NaN (the caller's NaN check sees it, tf_train.py:283-285); the stack has switched to the kernels that recompute their
+    halo rows, so the call that raised this can simply be repeated.  ARStack.set_halo_exchange(True) re-arms the exchange."""
+
+
 _lib = None
 
 
@@ -191,6 +201,8 @@ def check(code):
         raise AssertionError(msg)          # tf_utils/layers.py:116
     if code == IAF_ERR_UNSUPPORTED:
         raise UnsupportedError(msg)
+    if code == IAF_ERR_EXCHANGE:
+        raise ExchangeError(msg)
     if code in (IAF_ERR_NULL, IAF_ERR_SHAPE, IAF_ERR_WORKSPACE):
         raise ValueError(msg)
     raise IafHipError(msg)

@@ -39,6 +39,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <mutex>
 #include <new>
@@ -48,7 +49,7 @@
 
 #include "iaf_conv_kernel.hpp"
 
-#define IAF_ABI_VERSION 4   // 4: stack-owned halo-exchange buffers (iaf_stack_set_halo_exchange / _exchange_errors / _step_exchanges): a stack's
+#define IAF_ABI_VERSION 5   // 5: per-stream halo-exchange sets, IAF_ERR_EXCHANGE, iaf_stack_set_halo_exchange_debug; 4: stack-owned halo-exchange buffers (iaf_stack_set_halo_exchange / _exchange_errors / _step_exchanges): a stack's
                           //    one-launch steps must not overlap on different streams; 2: + iaf_conv3x3_*; 3: bf16x3 default precision, THEANO_FLIPMASK, negative nt in autotune reports,
                           //    iaf_stack_set_packs, iaf_comm_* (include/iaf_hip.h)
 #define MAX_GEMM_LAYERS 10   // depth_ar <= 9 hidden + 1 output pair
@@ -99,13 +100,26 @@ struct iaf_stack {
     bool defer_wn = false;    // backward leaves the weight-norm pass to iaf_wn_bwd_batch_run (one launch per model)
     float* pend_ws = nullptr; int pend_B = 0, pend_H = 0, pend_W = 0;   // ... which finds dWeff / dbp through these
     bool generic = false;     // channel counts outside the MFMA path: direct-conv fallback kernels
-    // one-launch step with halo exchange (iaf_step_fused.hpp, XCH): the rows the row blocks hand each other and their flags.
-    // Owned by the stack (allocated on first use outside a stream capture, flags zeroed once and left zero by every launch),
-    // so such launches of ONE stack must not overlap on different streams.
-    char* xch_buf = nullptr; size_t xch_bytes = 0;
-    unsigned* xch_flag = nullptr; size_t xch_nflag = 0;
-    std::vector<void*> xch_retired;       // outgrown buffers: a captured graph may still name them, so they live as long as the stack
+    // one-launch step with halo exchange (iaf_step_fused.hpp, XCH): the rows the row blocks hand each other, their flag lines, the
+    // work-list heads and the announcements -- one SET per stream the stack has launched such a step on (a set is used by one
+    // launch at a time; launches of one stream are ordered), so calls on different streams do not share state (SURVEY 8b:
+    // re-entrant per stream).  Allocated on a stream's first such launch outside a capture; nothing in a set is cleared between
+    // launches (the kernel tags what it writes with a launch epoch).  Outgrown buffers live as long as the stack: a captured graph
+    // may still name them.
+    struct XchSet {
+        hipStream_t st = nullptr;
+        char* buf = nullptr; size_t bytes = 0;                 // rows
+        unsigned* flag = nullptr; size_t nrow = 0;             // flag lines (32 words per row)
+        unsigned long long* ctl = nullptr;                     // heads, arrivals, sticky error (16 words)
+        unsigned* who = nullptr; size_t nwho = 0;              // announcements
+    };
+    std::deque<XchSet> xch_sets;           // (stable addresses: a launch holds a pointer to its set outside the lock)
+    std::mutex xch_mu;
+    std::vector<void*> xch_retired;
+    unsigned* xch_err_host = nullptr;     // mapped pinned word the kernels raise when a bounded wait gives up: read at every launch,
+    unsigned* xch_err_dev = nullptr;      // ... without synchronising; its device-side alias
     bool xch_on = true;                   // iaf_stack_set_halo_exchange
+    unsigned xch_knob = 0;                // iaf_stack_set_halo_exchange_debug
     int precision = IAF_PRECISION_BF16X3;   // forward convs: bf16x3 split products on the bf16 MFMA, or the exact fp32 MFMA
     int fuse_first = 2;       // first masked conv fused into the second one's kernel: 0 never, 1 whenever possible, 2 only where
                               // iaf_stack_autotune measured it faster (on MI355X at the BASELINE sizes it is not: DESIGN.md 4.8)
@@ -178,7 +192,15 @@ static int desc_upload(DescTable* t, const void* host, bool changed, hipStream_t
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (st) (void)hipStreamIsCapturing(st, &cs);
     if (cs == hipStreamCaptureStatusActive) {
-        if (t->ncap >= PREP_CAPTURE_SLOTS) return IAF_ERR_UNSUPPORTED;       // more captured prep runs than this object carries
+        //  the caller's host copy now holds THIS run's pointers while the eager device table keeps the previous
+        // ones: the next eager run must upload even if it finds its host copy unchanged
+        if (changed) t->uploaded = false;
+        //  a capture of descriptors that an earlier capture already froze -- the usual re-capture of the same
+        // tensors -- shares that slot's table; only captures of NEW pointer sets take a slot, PREP_CAPTURE_SLOTS per object
+        // (include/iaf_hip.h: IAF_ERR_CAPTURE_SLOTS)
+        for (int i = 0; i < t->ncap; ++i)
+            if (!memcmp(t->h_ring + stride * (PREP_RING + i), host, t->bytes)) { *d_out = t->d_tabs + stride * (1 + i); return IAF_OK; }
+        if (t->ncap >= PREP_CAPTURE_SLOTS) return IAF_ERR_CAPTURE_SLOTS;
         char* snap = t->h_ring + stride * (PREP_RING + t->ncap);
         char* dtab = t->d_tabs + stride * (1 + t->ncap);
         t->ncap++;
@@ -315,6 +337,8 @@ extern "C" const char* iaf_error_string(int code) {
         case IAF_ERR_NOT_MULTIPLE: return "n_h must be a multiple of n_z or vice versa";
         case IAF_ERR_NOT_PREPARED: return "iaf_stack_prepare has not been called";
         case IAF_ERR_WORKSPACE: return "workspace too small or misaligned";
+        case IAF_ERR_EXCHANGE: return "a bounded wait of the halo exchange gave up in an earlier launch of this stack (its outputs carry NaN); the stack now recomputes its halo rows -- repeat the call";
+        case IAF_ERR_CAPTURE_SLOTS: return "this prep / weight-norm batch object has been captured into hipGraphs with more than 16 distinct sets of tensor pointers: create another batch object (include/iaf_hip.h)";
         case IAF_ERR_UNSUPPORTED: return "not covered by the gfx950 kernels (channels must be multiples of 16 and <= 256; launch shape must fit 160 KiB of LDS)";
     }
     if (code >= 10000) {                                  // 10000 + ncclResult_t (iaf_comm.cpp)
@@ -445,6 +469,18 @@ extern "C" int iaf_stack_profile_read(iaf_stack_t* s, float* ms_out, int capacit
     return IAF_OK;
 }
 
+static void xch_free_sets(iaf_stack_t* s) {
+    for (auto& x : s->xch_sets) {
+        if (x.buf) (void)hipFree(x.buf);
+        if (x.flag) (void)hipFree(x.flag);
+        if (x.ctl) (void)hipFree(x.ctl);
+        if (x.who) (void)hipFree(x.who);
+    }
+    s->xch_sets.clear();
+    for (void* q : s->xch_retired) (void)hipFree(q);
+    s->xch_retired.clear();
+}
+
 extern "C" int iaf_stack_destroy(iaf_stack_t* s) {
     if (!s) return IAF_ERR_NULL;
     prof_free(s);
@@ -457,29 +493,66 @@ extern "C" int iaf_stack_destroy(iaf_stack_t* s) {
         if (s->L[l].wp3) (void)hipFree(s->L[l].wp3);
         if (s->L[l].lim) (void)hipFree(s->L[l].lim);
     }
-    if (s->xch_buf) (void)hipFree(s->xch_buf);
-    if (s->xch_flag) (void)hipFree(s->xch_flag);
-    for (void* q : s->xch_retired) (void)hipFree(q);
+    xch_free_sets(s);
+    if (s->xch_err_host) (void)hipHostFree(s->xch_err_host);
     delete s;
+    return IAF_OK;
+}
+
+// Back to a fresh start: the device is idle after the synchronisation, so the sets can simply be zeroed (epoch 0, no flags, no
+// announcements, no sticky error) -- buffers a captured graph names stay where they are.
+static int xch_reset_sets(iaf_stack_t* s) {
+    HIP_TRY(hipDeviceSynchronize());
+    std::lock_guard<std::mutex> lk(s->xch_mu);
+    for (auto& x : s->xch_sets) {
+        HIP_TRY(hipMemset(x.flag, 0, x.nrow * 32 * sizeof(unsigned)));
+        HIP_TRY(hipMemset(x.ctl, 0, 16 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(x.who, 0, x.nwho * sizeof(unsigned)));
+    }
+    if (s->xch_err_host) *(volatile unsigned*)s->xch_err_host = 0u;
     return IAF_OK;
 }
 
 extern "C" int iaf_stack_set_halo_exchange(iaf_stack_t* s, int on) {
     if (!s) return IAF_ERR_NULL;
     s->xch_on = on != 0;
-    if (s->xch_flag) {                                       // a fresh start either way: flags and error word cleared
-        HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipMemset(s->xch_flag, 0, (s->xch_nflag + 1) * sizeof(unsigned)));
-    }
+    return xch_reset_sets(s);                                // a fresh start either way: error words cleared
+}
+
+extern "C" int iaf_stack_set_halo_exchange_debug(iaf_stack_t* s, unsigned knobs) {
+    if (!s) return IAF_ERR_NULL;
+    s->xch_knob = knobs;
     return IAF_OK;
 }
 
 extern "C" int iaf_stack_exchange_errors(const iaf_stack_t* s, unsigned* errors) {
     if (!s || !errors) return IAF_ERR_NULL;
     *errors = 0;
-    if (!s->xch_flag) return IAF_OK;
+    if (!s->xch_err_host) return IAF_OK;
+    HIP_TRY(hipDeviceSynchronize());                         // (every launch so far has had its say)
+    *errors = *(volatile unsigned*)s->xch_err_host;
+    return IAF_OK;
+}
+
+// Which way the rows of the LAST launch on every exchange set went: flag words of that launch's epoch, by path
+extern "C" int iaf_stack_exchange_paths(iaf_stack_t* s, unsigned* through_l2, unsigned* through_memory) {
+    if (!s || !through_l2 || !through_memory) return IAF_ERR_NULL;
+    *through_l2 = *through_memory = 0;
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(errors, s->xch_flag + s->xch_nflag, sizeof(unsigned), hipMemcpyDeviceToHost));
+    std::lock_guard<std::mutex> lk(s->xch_mu);
+    for (auto& x : s->xch_sets) {
+        unsigned long long head = 0;
+        HIP_TRY(hipMemcpy(&head, x.ctl, sizeof(head), hipMemcpyDeviceToHost));
+        const unsigned last = ((unsigned)(head >> 32) - 1u) & 0x3fffffffu;
+        std::vector<unsigned> f(x.nrow * 32);
+        HIP_TRY(hipMemcpy(f.data(), x.flag, f.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+        for (size_t r = 0; r < x.nrow; ++r)
+            for (int w = 0; w < 4; ++w) {
+                const unsigned v = f[r * 32 + w];
+                if ((v >> 2) != last) continue;
+                if ((v & 3u) == 2u) ++*through_l2; else if ((v & 3u) == 1u) ++*through_memory;
+            }
+    }
     return IAF_OK;
 }
 
@@ -1003,28 +1076,58 @@ static step_fn_t fused_step_xch(const iaf_stack_t* s, int H, int W, int R, size_
     return (f && *lds <= 160 * 1024) ? f : nullptr;
 }
 
-// Its buffers are the stack's: the rows [layer][B * nrb][xrow bytes] and four flag words per row (+ the error word), zero between
-// launches.  Allocated on first use -- not inside a stream capture (false then: the caller runs what it ran before; warm up
-// before capturing, as for the LDS cap).  Outgrown buffers stay alive with the stack: a captured graph may still name them.
-static bool xch_prepare(iaf_stack_t* s, int B, int nrb, size_t xrow, hipStream_t st) {
-    const size_t nrow = (size_t)s->depth_ar * B * nrb, need = nrow * xrow, nslot = 4 * nrow;      // four flag words per row (one per wave)
-    if (need <= s->xch_bytes && nslot <= s->xch_nflag) return true;
+// The exchange set of stream st, grown to [layer][B * nrb] rows of xrow bytes: created on the stream's first such launch -- not
+// inside a stream capture (NULL then: the caller runs what it ran before; warm up before capturing, as for the LDS cap).  A set
+// that grows keeps its heads (the launch epoch goes on); new flag lines and announcements start at zero, which no epoch of a
+// running set produces with a valid path / mark.  Outgrown buffers stay alive with the stack: a captured graph may still name them.
+static iaf_stack::XchSet* xch_prepare(iaf_stack_t* s, int B, int nrb, size_t xrow, hipStream_t st) {
+    std::lock_guard<std::mutex> lk(s->xch_mu);
+    iaf_stack::XchSet* x = nullptr;
+    for (auto& e : s->xch_sets) if (e.st == st) { x = &e; break; }
+    const size_t nrow = (size_t)s->depth_ar * B * nrb, need = nrow * xrow, nwho = (size_t)B * nrb;
+    if (x && need <= x->bytes && nrow <= x->nrow && nwho <= x->nwho) return x;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(st, &cs);
-    if (cs != hipStreamCaptureStatusNone) return false;
-    char* nb = nullptr;
-    unsigned* nf = nullptr;
-    if (hipMalloc((void**)&nb, need) != hipSuccess) return false;
-    if (hipMalloc((void**)&nf, (nslot + 1) * sizeof(unsigned)) != hipSuccess ||
-        hipMemsetAsync(nf, 0, (nslot + 1) * sizeof(unsigned), st) != hipSuccess) {      // (ordered in front of the launch)
-        (void)hipFree(nb);
-        if (nf) (void)hipFree(nf);
-        return false;
+    if (cs != hipStreamCaptureStatusNone) {
+        // no allocation inside a capture: a capture stream without a set of its own (torch.cuda.graph's internal stream after a
+        // warm-up elsewhere) adopts the newest set that is large enough -- the graph then must not be replayed concurrently with
+        // launches of this stack on that set's stream (include/iaf_hip.h); none: the caller runs the recomputing kernel
+        for (size_t i = s->xch_sets.size(); i-- > 0;) {
+            iaf_stack::XchSet& e = s->xch_sets[i];
+            if (need <= e.bytes && nrow <= e.nrow && nwho <= e.nwho) return &e;
+        }
+        return nullptr;
     }
-    if (s->xch_buf) s->xch_retired.push_back(s->xch_buf);
-    if (s->xch_flag) s->xch_retired.push_back(s->xch_flag);
-    s->xch_buf = nb; s->xch_flag = nf; s->xch_bytes = need; s->xch_nflag = nslot;
-    return true;
+    if (!s->xch_err_host) {
+        if (hipHostMalloc((void**)&s->xch_err_host, 64, hipHostMallocMapped) != hipSuccess) { s->xch_err_host = nullptr; return nullptr; }
+        *(volatile unsigned*)s->xch_err_host = 0u;
+        if (hipHostGetDevicePointer((void**)&s->xch_err_dev, s->xch_err_host, 0) != hipSuccess) {
+            (void)hipHostFree(s->xch_err_host); s->xch_err_host = nullptr; s->xch_err_dev = nullptr;
+            return nullptr;
+        }
+    }
+    char* nb = nullptr;
+    unsigned *nf = nullptr, *nw = nullptr;
+    unsigned long long* nc = x ? x->ctl : nullptr;
+    bool ok = hipMalloc((void**)&nb, need) == hipSuccess && hipMalloc((void**)&nf, nrow * 32 * sizeof(unsigned)) == hipSuccess &&
+              hipMalloc((void**)&nw, nwho * sizeof(unsigned)) == hipSuccess &&
+              hipMemsetAsync(nf, 0, nrow * 32 * sizeof(unsigned), st) == hipSuccess &&      // (ordered in front of the launch)
+              hipMemsetAsync(nw, 0, nwho * sizeof(unsigned), st) == hipSuccess;
+    if (ok && !nc) ok = hipMalloc((void**)&nc, 16 * sizeof(unsigned long long)) == hipSuccess &&
+                        hipMemsetAsync(nc, 0, 16 * sizeof(unsigned long long), st) == hipSuccess;
+    if (!ok) {
+        if (nb) (void)hipFree(nb);
+        if (nf) (void)hipFree(nf);
+        if (nw) (void)hipFree(nw);
+        if (nc && !(x && x->ctl == nc)) (void)hipFree(nc);
+        return nullptr;
+    }
+    if (!x) { s->xch_sets.emplace_back(); x = &s->xch_sets.back(); x->st = st; }
+    if (x->buf) s->xch_retired.push_back(x->buf);
+    if (x->flag) s->xch_retired.push_back(x->flag);
+    if (x->who) s->xch_retired.push_back(x->who);
+    x->buf = nb; x->bytes = need; x->flag = nf; x->nrow = nrow; x->who = nw; x->nwho = nwho; x->ctl = nc;
+    return x;
 }
 
 
@@ -1079,6 +1182,12 @@ extern "C" int iaf_stack_step_exchanges(const iaf_stack_t* s, int B, int H, int 
 // kl_part: posterior mode only -- per-(row block, channel) sums of the KL elements, [B * nrb][n_z] (StepP::kl_part)
 static int launch_fused_step(iaf_stack_t* s, step_fn_t fn, int R, size_t lds, const ConvP& base, int first_inmode, const float* ctx,
                              const float* ctx2, hipStream_t st, float* const* hsave = nullptr, float* kl_part = nullptr) {
+    // A bounded wait of an earlier launch of this stack gave up (its outputs carry NaN): said once, as this call's status, and
+    // the stack goes on with the kernels that recompute their halo rows until iaf_stack_set_halo_exchange re-arms the exchange.
+    if (s->xch_on && s->xch_err_host && *(volatile unsigned*)s->xch_err_host) {
+        s->xch_on = false;
+        return IAF_ERR_EXCHANGE;
+    }
     StepP q;
     memset(&q, 0, sizeof(q));
     q.kl_part = kl_part;
@@ -1091,6 +1200,9 @@ static int launch_fused_step(iaf_stack_t* s, step_fn_t fn, int R, size_t lds, co
     q.qm = base.qm; q.ql = base.ql; q.rm = base.rm; q.rl = base.rl; q.pm = base.pm; q.pl = base.pl; q.eps = base.eps;
     q.B = base.B; q.H = base.H; q.HW = base.HW; q.mode = base.mode;
     q.nrb = (base.H + R - 1) / R;
+    //  the posterior callers pass a hidden-activation buffer of the workspace ([B H W][n_h] floats) as kl_part
+    // [B * nrb][n_z]: holds for every geometry compiled today (nrb <= H, n_z <= W n_h) -- enforced here for the ones to come
+    if (kl_part && (size_t)q.nrb * s->n_z > (size_t)base.H * base.W * s->n_h) return IAF_ERR_WORKSPACE;
     if (s->variant != IAF_VARIANT_TF)                          // (the kernel variant was picked with the statement)
         for (int l = 0; l < s->nlayers; ++l) q.border[l] = s->L[l].border;
     q.dbg = (s->dbg_layer == -2) ? s->dbg : nullptr;
@@ -1100,9 +1212,9 @@ static int launch_fused_step(iaf_stack_t* s, step_fn_t fn, int R, size_t lds, co
     {
         size_t xl = 0, xrow = 0;
         if (step_fn_t fx = fused_step_xch(s, base.H, base.W, R, &xl, &xrow)) {
-            if (xch_prepare(s, base.B, q.nrb, xrow, st)) {
+            if (iaf_stack::XchSet* x = xch_prepare(s, base.B, q.nrb, xrow, st)) {
                 fn = fx; lds = xl;
-                q.xh = s->xch_buf; q.xflag = s->xch_flag; q.xerr = s->xch_flag + s->xch_nflag;
+                q.xh = x->buf; q.xflag = x->flag; q.xctl = x->ctl; q.xwho = x->who; q.xerr = s->xch_err_dev; q.xknob = s->xch_knob;
             } else if (fn == fx) {
                 return IAF_ERR_NOT_PREPARED;                 // (a geometry that only exists in this form, and no buffers: fused_step_plan refuses that)
             }

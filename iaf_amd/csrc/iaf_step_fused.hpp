@@ -149,9 +149,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pl = lane & 15, kk = lane >> 4;
-    // XCH: a workgroup waits for the block BELOW it, so the blocks of an image are dealt out bottom first -- a workgroup only
-    // ever waits for one with a lower index, which the dispatcher has placed before it (any grid size)
-    const int b = blockIdx.x / p.nrb, xpos = blockIdx.x - b * p.nrb, rbk = XCH ? p.nrb - 1 - xpos : xpos, r0 = rbk * R;
+    // Which (image b, row block rbk) this workgroup computes.  Recomputing kernels: blockIdx, statically -- no workgroup depends on
+    // another.  XCH: a workgroup waits for the rows of the block BELOW it, and HIP promises no dispatch order, so the order is one
+    // the kernel creates (xch_take_item below): a workgroup takes a TICKET from a work list whose items are dealt out bottom row
+    // block first, and therefore only ever waits for the holder of a LOWER ticket of the same list -- a workgroup that is already
+    // running and, by induction, never waits for anything not running.  Any grid size, any dispatch order, any placement.
+    int b = blockIdx.x / p.nrb, rbk = blockIdx.x - b * p.nrb, r0 = rbk * R;
     const int H = p.H, HW = p.HW;
     // pixel offset inside the image of position (image row ir, column col) of the space the kernel computes in
     // ((H-1-ir) W + (W-1-col) = HW-1 - (ir W + col))
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto ldf = [](const float* base, unsigned boff) -> float { return *(const float*)((const char*)base + boff); };
     auto ldf4 = [](const float* base, unsigned boff) -> f32x4 { return *(const f32x4*)((const char*)base + boff); };
     auto stf = [](float* base, unsigned boff, float v) { *(float*)((char*)base + boff) = v; };
-    const size_t img_z = (size_t)b * NZ * HW, img_h = (size_t)b * NH * HW;      // element offsets of image b (z-shaped / context-shaped tensors)
+    size_t img_z = (size_t)b * NZ * HW, img_h = (size_t)b * NH * HW;            // element offsets of image b (z-shaped / context-shaped tensors)
     // sum of the border-indicator weights of the taps that leave the image at (ir, col): taps (0,1) (1,-1) (1,0) (1,1)
     auto border_terms = [&](const float* bt, int cstride, int ch, int ir, int col) -> f32x4 {
         f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -237,43 +240,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     constexpr std::integral_constant<int, -1> ALL{};                       // every slot live
 
     // ---- prologue: z rows first (the first conv cannot start without them), then the first weight steps; zero columns
-    // while both travel; z -> LDS ---------------------------------------------------------------------------------------
+    // while both travel; z -> LDS.  XCH: the weight steps and the zero columns do not depend on which rows the workgroup
+    // computes -- they cover the travel time of its ticket, and the z rows follow -------------------------------------------
     constexpr int NPX = RZ * W, NIT = NPX * (NZ / 4), ZU = (NIT + 255) / 256;
     f32x4 zv[ZU], zq[4][ZU];     // posterior input: the five tensors as raw loads, combined once all of them are on their way
+    auto load_z = [&]() {
 #pragma unroll
-    for (int u = 0; u < ZU; ++u) {
-        const int idx = tid + u * 256;
-        const int ic = idx < NIT ? idx : NIT - 1;
-        const int q = ic / NPX, px = ic - q * NPX;                 // pixel fastest: coalesced along a row
-        const int row = px / W, col = px - row * W;
-        const int rr = r0 + row < H ? r0 + row : H - 1;            // rows past the image: a valid address, zeroed below
-        const unsigned gb = 4u * (unsigned)(4 * q * HW + gpix(rr, col));        // byte offset inside image b
-        if (p.z) {
+        for (int u = 0; u < ZU; ++u) {
+            const int idx = tid + u * 256;
+            const int ic = idx < NIT ? idx : NIT - 1;
+            const int q = ic / NPX, px = ic - q * NPX;                 // pixel fastest: coalesced along a row
+            const int row = px / W, col = px - row * W;
+            const int rr = r0 + row < H ? r0 + row : H - 1;            // rows past the image: a valid address, zeroed below
+            const unsigned gb = 4u * (unsigned)(4 * q * HW + gpix(rr, col));        // byte offset inside image b
+            if (p.z) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) zv[u][r] = ldf(p.z + img_z, gb + 4u * (unsigned)(r * HW));
-        } else {
+                for (int r = 0; r < 4; ++r) zv[u][r] = ldf(p.z + img_z, gb + 4u * (unsigned)(r * HW));
+            } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const unsigned i = gb + 4u * (unsigned)(r * HW);
-                zv[u][r] = ldf(p.qm + img_z, i); zq[0][u][r] = ldf(p.rm + img_z, i); zq[1][u][r] = ldf(p.ql + img_z, i);
-                zq[2][u][r] = ldf(p.rl + img_z, i); zq[3][u][r] = ldf(p.eps + img_z, i);
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned i = gb + 4u * (unsigned)(r * HW);
+                    zv[u][r] = ldf(p.qm + img_z, i); zq[0][u][r] = ldf(p.rm + img_z, i); zq[1][u][r] = ldf(p.ql + img_z, i);
+                    zq[2][u][r] = ldf(p.rl + img_z, i); zq[3][u][r] = ldf(p.eps + img_z, i);
+                }
             }
         }
-    }
-    __builtin_amdgcn_sched_barrier(0);
+    };
     f32x4 wr0[UA][NTWH][3];
     const f32x4* wb0 = (const f32x4*)p.wp3[0];
-    static_for<RD0>([&](auto i) {
-        ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWH * 3>{}, wr0[decltype(i)::value], wb0, NHT, htile,
-                  PartL0{}, decltype(i)::value, ALL);
-    });
-    __builtin_amdgcn_sched_barrier(0);
+    auto preload_w0 = [&]() {
+        static_for<RD0>([&](auto i) {
+            ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWH * 3>{}, wr0[decltype(i)::value], wb0, NHT, htile,
+                      PartL0{}, decltype(i)::value, ALL);
+        });
+    };
     // context rows of this workgroup: per channel one contiguous run of CPX pixels (full-width rows) -> 16-byte loads,
     // 4 channels per wave instruction; summed with the second context here
     constexpr int CPX = G::CPX, CSTR = G::CSTR, CG = CPX / 4, NCIT = NH * CG, NCI = (NCIT + 255) / 256;
     f32x4 cv[NCI], cv2[NCI];     // raw loads: nothing consumes them before the z rows are in LDS.  UNCONDITIONAL loads from
     unsigned cvalid = 0;         // clamped addresses: `x = 0; if (inside) x = load` is a select on the loaded value, i.e. a
-    {                            // vmcnt(0) behind every load -- ten serial HBM round trips in this prologue (found in the
+    auto load_ctx = [&]() {      // vmcnt(0) behind every load -- ten serial HBM round trips in this prologue (found in the
                                  // round-3 ISA: 7 k cycles of prologue at 16-pixel rows).  Rows past the image bottom are zeroed
                                  // when the values are used (store_ctx), from the bit mask.  (The host never launches this
                                  // kernel without a context: depth_ar >= 1.)
@@ -317,10 +323,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 cv2[u] = ldf4(p.ctx2 + img_h, gi);
             }
         }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    IAF_FSTAMP(8);
-    {
+    };
+    auto zero_cols = [&]() {
         constexpr int ZROWS = RZ, H0ROWS = G::rows_reg(0), H1ROWS = 0;    // (h_1's zero columns: after the first layer)
         for (int i = tid; i < ZROWS * 2 * Z16; i += 256) {
             const int rs = i / Z16, u = i - rs * Z16;
@@ -332,6 +336,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int base = row < H0ROWS ? G::HREG0 + row * RS * H16 : G::HREG1 + (row - H0ROWS) * RS * H16;
             smem4[base + (rs & 1) * (W + 1) * H16 + u] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+    };
+    auto stage_z = [&]() {
 #pragma unroll
         for (int u = 0; u < ZU; ++u) {
             const int idx = tid + u * 256;
@@ -348,6 +354,108 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 bf3_store4(smem + (size_t)G::ZREG * 16, row * RS + col + 1, q, v, Z16, Z8);
             }
         }
+    };
+
+    // ---- XCH: which rows this workgroup computes -- a ticket, not blockIdx -----------------------------------------------------
+    // p.xctl[0..7]: heads of eight work lists, (launch epoch << 32) | tickets taken; [8]: workgroups of this launch that are done
+    // with the heads; [9]: sticky error.  List y holds the images b = y, y + 8, y + 16, ... < B, their row blocks bottom first:
+    // ticket t of list y is (image y + 8 (t / nrb), row block nrb - 1 - t % nrb).  A workgroup asks the list of the XCD it runs on
+    // (HW_REG_XCC_ID) first -- so the row blocks of an image meet in ONE L2 wherever the dispatcher spreads workgroups evenly, and
+    // hand their rows over through it (xmode below) -- and the other lists in turn when that one is dry: grid = number of
+    // items, so every workgroup finds exactly one.  The placement decides the speed of a hand-over, never its correctness.
+    // The workgroup that arrives last at [8] (all tickets of the launch are taken by then) starts the next epoch: heads back to
+    // zero tickets, [8] to zero.  Flags and announcements carry the epoch, so nothing has to be cleared between launches and a
+    // launch that gave up leaves nothing behind that the next one could take for its own.
+    unsigned xepoch = 0, xcc = 0, xdead = 0;
+    unsigned long long xdone = 0;
+    int xslot = 0;
+    [[maybe_unused]] unsigned long long xt0 = 0;
+    [[maybe_unused]] unsigned xlist = 0;
+    unsigned* xmail = (unsigned*)(smem + (size_t)G::CTX_OFF * 16);          // (the context staging area: not written before the first conv is done)
+    auto xch_take_begin = [&]() {
+        if constexpr (XCH) {
+            if (tid == 0) {
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+                xcc &= 7u;
+                xlist = xcc;
+                if (p.xknob & 1u) xlist = (blockIdx.x * 2654435761u >> 13) & 7u;        // test knob: lists that ignore the placement
+                if (p.xknob & 2u)                                                       // test knob: tickets out of dispatch order
+                    for (unsigned i = 0, n = (blockIdx.x * 40503u >> 4) & 63u; i < n; ++i) __builtin_amdgcn_s_sleep(64);
+                xt0 = __hip_atomic_fetch_add(p.xctl + xlist, 1ull, __ATOMIC_RELAXED, XSCOPE);
+                xdead = (unsigned)__hip_atomic_load(p.xctl + 9, __ATOMIC_RELAXED, XSCOPE);
+            }
+        }
+    };
+    auto xch_take_finish = [&]() {
+        if constexpr (XCH) {
+            if (tid == 0) {
+                unsigned long long v = xt0;
+                unsigned y = xlist, t = 0;
+                bool found = false;
+                for (int k = 0; k < 8; ++k) {
+                    if (k) { y = (xlist + k) & 7u; v = __hip_atomic_fetch_add(p.xctl + y, 1ull, __ATOMIC_RELAXED, XSCOPE); }
+                    const unsigned ny = (int)y < p.B ? (unsigned)p.nrb * (unsigned)((p.B - (int)y + 7) >> 3) : 0u;
+                    t = (unsigned)v;
+                    if (t < ny) { found = true; break; }
+                }
+                const unsigned ep = (unsigned)(v >> 32);
+                // (the heads are final for this workgroup: count it -- the result is looked at after the first conv)
+                xdone = __hip_atomic_fetch_add(p.xctl + 8, 1ull, __ATOMIC_RELAXED, XSCOPE);
+                unsigned ib = 0, ir = (unsigned)p.nrb - 1;
+                if (found) { ib = y + 8u * (t / (unsigned)p.nrb); ir = (unsigned)p.nrb - 1u - t % (unsigned)p.nrb; }
+                else xdead |= 2u;                                           // (grid != B * nrb: a host bug -- loud, not a hang)
+                xmail[0] = ib; xmail[1] = ir; xmail[2] = ep; xmail[3] = xdead; xmail[4] = xcc;
+                // announce where this item's rows will be wanted: the block below chooses its hand-over path by it
+                __hip_atomic_store(p.xwho + ib * (unsigned)p.nrb + ir, (ep << 8) | 0x80u | xcc, __ATOMIC_RELAXED, XSCOPE);
+            }
+            __syncthreads();
+            b = __builtin_amdgcn_readfirstlane((int)xmail[0]);
+            rbk = __builtin_amdgcn_readfirstlane((int)xmail[1]);
+            xepoch = __builtin_amdgcn_readfirstlane(xmail[2]);
+            xdead = __builtin_amdgcn_readfirstlane(xmail[3]);
+            xcc = __builtin_amdgcn_readfirstlane(xmail[4]);
+            r0 = rbk * R;
+            img_z = (size_t)b * NZ * HW; img_h = (size_t)b * NH * HW;
+            xslot = b * p.nrb + rbk;
+            if (xdead && tid == 0) {
+                if (p.xerr) __hip_atomic_store(p.xerr, 0x100u | xdead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(p.xctl + 9, (unsigned long long)xdead, __ATOMIC_RELAXED, XSCOPE);
+            }
+        }
+    };
+    // ... and, once all of this launch's tickets are taken, the heads of the next launch
+    auto xch_next_epoch = [&]() {
+        if constexpr (XCH) {
+            if (tid == 0 && (unsigned)xdone == gridDim.x - 1u) {
+                const unsigned long long e1 = (unsigned long long)(xepoch + 1u) << 32;
+#pragma unroll
+                for (int y = 0; y < 8; ++y) __hip_atomic_store(p.xctl + y, e1, __ATOMIC_RELAXED, XSCOPE);
+                __hip_atomic_store(p.xctl + 8, 0ull, __ATOMIC_RELAXED, XSCOPE);
+            }
+        }
+    };
+
+    if constexpr (XCH) {
+        xch_take_begin();
+        preload_w0();
+        zero_cols();
+        xch_take_finish();
+        load_z();
+        __builtin_amdgcn_sched_barrier(0);
+        load_ctx();
+        __builtin_amdgcn_sched_barrier(0);
+        IAF_FSTAMP(8);
+        stage_z();
+    } else {
+        load_z();
+        __builtin_amdgcn_sched_barrier(0);
+        preload_w0();
+        __builtin_amdgcn_sched_barrier(0);
+        load_ctx();
+        __builtin_amdgcn_sched_barrier(0);
+        IAF_FSTAMP(8);
+        zero_cols();
+        stage_z();
     }
     IAF_FSTAMP(9);
     __syncthreads();
@@ -498,19 +606,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int j = 0; j < NTWH; ++j) bi[j] = *(const f32x4*)(bias + (htile[j] < NHT ? htile[j] : NHT - 1) * 16 + 4 * kk);
     };
-    // bf3_store4 into the exchanged row in memory: the same three 8-byte pieces, as agent-scope stores
-    auto xch_store4 = [&](char* base, int slot, int q, f32x4 v) {
+    // bf3_store4 into the exchanged row in memory: the same three 8-byte pieces.  THROUGH_L2 (the block above runs on this XCD,
+    // xmode): plain stores, which stay in this XCD's L2 where that block's loads find them; else agent-scope stores (sc1:
+    // written through to memory, visible to every XCD)
+    auto xch_store4 = [&](char* base, int slot, int q, f32x4 v, bool through_l2) {
         unsigned h0, m0, l0, h1, m1, l1;
         bf3_split2(f32x2{v[0], v[1]}, h0, m0, l0);
         bf3_split2(f32x2{v[2], v[3]}, h1, m1, l1);
         unsigned long long* d = (unsigned long long*)(base + ((size_t)slot * H16 << 4) + q * 8);
-        __hip_atomic_store(d, (unsigned long long)h0 | ((unsigned long long)h1 << 32), __ATOMIC_RELAXED, XSCOPE);
-        __hip_atomic_store(d + 2 * H8, (unsigned long long)m0 | ((unsigned long long)m1 << 32), __ATOMIC_RELAXED, XSCOPE);
-        __hip_atomic_store(d + 4 * H8, (unsigned long long)l0 | ((unsigned long long)l1 << 32), __ATOMIC_RELAXED, XSCOPE);
+        const unsigned long long vh = (unsigned long long)h0 | ((unsigned long long)h1 << 32), vm = (unsigned long long)m0 | ((unsigned long long)m1 << 32),
+                                 vl = (unsigned long long)l0 | ((unsigned long long)l1 << 32);
+        if (through_l2) {
+            __hip_atomic_store(d, vh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __hip_atomic_store(d + 2 * H8, vm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __hip_atomic_store(d + 4 * H8, vl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        } else {
+            __hip_atomic_store(d, vh, __ATOMIC_RELAXED, XSCOPE);
+            __hip_atomic_store(d + 2 * H8, vm, __ATOMIC_RELAXED, XSCOPE);
+            __hip_atomic_store(d + 4 * H8, vl, __ATOMIC_RELAXED, XSCOPE);
+        }
     };
     // xrow (XCH): where this block's FIRST row goes for the block above (NULL: nobody above)
     auto hidden_epilogue = [&](auto npt_c, auto rows_c, auto emask_c, auto ctx_c, f32x4 (*acc)[NTWH], const f32x4* bias, int out_reg,
-                               float* hsave, const float* bt, char* xrow) {
+                               float* hsave, const float* bt, char* xrow, bool xl2) {
         constexpr int NPT = decltype(npt_c)::value, ROWS = decltype(rows_c)::value, EMASK = decltype(emask_c)::value;
         constexpr bool WITH_CTX = decltype(ctx_c)::value != 0;
         f32x4 cxv[WITH_CTX ? NPT : 1][NTWH];                     // all context reads in flight together, ahead of the arithmetic
@@ -546,7 +664,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 for (int r = 0; r < 4; ++r) v[r] = elu_f(v[r]);
                 if (r0 + row >= H) v = f32x4{0.f, 0.f, 0.f, 0.f};
                 bf3_store4(smem + (size_t)out_reg * 16, row * RS + col + 1, htile[j] * 4 + kk, v, H16, H8);
-                if constexpr (XCH) { if (xrow && row == 0) xch_store4(xrow, col, htile[j] * 4 + kk, v); }
+                if constexpr (XCH) { if (xrow && row == 0) xch_store4(xrow, col, htile[j] * 4 + kk, v, xl2); }
                 // training: the rows this workgroup OWNS (not its halo) go to HBM for the backward pass
                 if (hsave && row < R && r0 + row < H)
                     *(f32x4*)(hsave + ((size_t)b * HW + (size_t)gpix(r0 + row, col)) * NH + htile[j] * 16 + 4 * kk) = v;
@@ -581,25 +699,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
     // ---- XCH: halo rows through memory ---------------------------------------------------------------------------------
     // p.xh [layer][B * nrb][W slots x H16 x 16 bytes]: row 0 of block (b, k)'s hidden layer, as it sits in LDS; p.xflag [layer]
-    // [B * nrb][4]: one word per publishing wave, 1 = that wave's part of the row is in memory (four stores to four words: a shared
-    // counter -- four read-modify-writes of one word -- measured 1.7 % slower).  The consumer (block k - 1) clears the words after
-    // its copy, so they are all zero between launches; launches on one stream are ordered, and the buffers belong to the stack
-    // (not re-entrant across streams).
-    // Every access to the exchanged rows and flags is an AGENT-scope relaxed atomic (a load / store with the sc1 bit: coherent
-    // per access across the XCDs' L2s), ordered by workgroup-scope fences (plain counter waits).  Agent-scope FENCES were
-    // measured first: buffer_wbl2 / buffer_inv sc1 write back and invalidate the whole L2 -- with it the weight packs every
-    // workgroup streams -- and the launch took 78 k instead of 54 k cycles.
-    const int xslot = b * p.nrb + rbk;
+    // [B * nrb][32 words = one 128-byte line]: words 0-3, one per publishing wave, = (epoch << 2) | path once that wave's part of
+    // the row is where the block above can read it (four stores to four words: a shared counter -- four read-modify-writes of one
+    // word -- measured 1.7 % slower).  Nothing is cleared: a word of another launch carries another epoch.
+    // Two hand-over paths, chosen per row by the PRODUCER from what the block above announced (p.xwho, xch_take_finish):
+    //   path 2, the block above runs on this XCD: plain row stores (they stay in this XCD's L2), a workgroup-scope flag store;
+    //   path 1, it runs elsewhere or has not announced itself yet: agent-scope stores (sc1, written through to memory).
+    // The consumer is the same for both: it polls the flag words and copies the row with agent-scope loads (sc1: they bypass its
+    // CU's L1 -- which may hold the previous launch's row -- and are served by its L2 where that holds the line dirty, by memory
+    // otherwise).  Path 2 therefore rests on a fact read from the hardware in THIS launch, not on a placement assumed.
+    // In front of a flag store every wave waits for its own row stores explicitly (s_waitcnt vmcnt(0) as inline asm: a
+    // workgroup-scope fence emits no wait on gfx950, and the compiler drops waits it believes redundant -- ADVICE r03 #1).
+    // Agent-scope FENCES were measured in round 3: buffer_wbl2 / buffer_inv sc1 write back and invalidate the whole L2 -- with it
+    // the weight packs every workgroup streams -- and the launch took 78 k instead of 54 k cycles.
+    // Giving up: every wait is bounded.  A wave whose wait ends without the flags fills its share of the imported row with NaN
+    // (which then flows through the remaining layers to this block's outputs and, where an exported row depends on it, on to the
+    // blocks above), raises the sticky word p.xctl[9] -- every later launch on these buffers then imports NaN without waiting --
+    // and the host-visible p.xerr, which the next call on the stack returns as IAF_ERR_EXCHANGE.  Wrong numbers never leave
+    // silently.
     auto xch_row = [&](int l) -> char* {
         if constexpr (!XCH) return nullptr;
         return rbk > 0 ? p.xh + ((size_t)l * p.B * p.nrb + xslot) * G::xrow_bytes() : nullptr;
     };
-    auto xch_publish = [&](int l) {          // at the end of the layer's epilogue: every wave announces its own stores of the row
+    // the announcement of the block above, requested ahead of the K loop whose epilogue exports a row
+    auto xch_peek = [&]() -> unsigned {
+        if constexpr (!XCH) return 0u;
+        return rbk > 0 ? __hip_atomic_load(p.xwho + (xslot - 1), __ATOMIC_RELAXED, XSCOPE) : 0u;
+    };
+    auto xch_l2 = [&](unsigned who) -> bool {
+        if constexpr (!XCH) return false;
+        return !(p.xknob & 4u) && who == ((xepoch << 8) | 0x80u | xcc);
+    };
+    auto xch_publish = [&](int l, bool through_l2) {   // at the end of the layer's epilogue: every wave announces its own stores of the row
         if constexpr (XCH) {
-            if (rbk > 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");             // this wave's stores are complete (issued early: no wait)
-                if (lane == 0)
-                    __hip_atomic_store(p.xflag + 4 * ((size_t)l * p.B * p.nrb + xslot) + wave, 1u, __ATOMIC_RELAXED, XSCOPE);
+            if (rbk > 0 && !((p.xknob & 8u) && b == 0 && rbk == p.nrb - 1 && l == 0)) {        // (test knob 8: one row is never published)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                              // this wave's row stores have been acknowledged
+                unsigned* f = p.xflag + 32 * ((size_t)l * p.B * p.nrb + xslot) + wave;
+                const unsigned v = (xepoch << 2) | (through_l2 ? 2u : 1u);
+                if (lane == 0) {
+                    if (through_l2) __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else __hip_atomic_store(f, v, __ATOMIC_RELAXED, XSCOPE);
+                }
             }
         }
     };
@@ -608,29 +748,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             unsigned long long* dst = (unsigned long long*)(smem4 + reg + (R * RS + 1) * H16);
             constexpr int NU = W * H16 * 2;                                          // 8-byte units
             if (r0 + R < H) {
-                // four words per row, one per publishing wave (plain stores: four read-modify-writes of ONE word queue up at the memory side)
-                unsigned long long* fl = (unsigned long long*)(p.xflag + 4 * ((size_t)l * p.B * p.nrb + xslot + 1));
-                int it = 0;                                                          // every wave polls for itself: all four waves below have published
-                constexpr unsigned long long BOTH = 0x0000000100000001ull;
-                while ((__hip_atomic_load(fl, __ATOMIC_RELAXED, XSCOPE) != BOTH || __hip_atomic_load(fl + 1, __ATOMIC_RELAXED, XSCOPE) != BOTH) &&
-                       ++it < (1 << 22))
+                const unsigned long long* fl = (const unsigned long long*)(p.xflag + 32 * ((size_t)l * p.B * p.nrb + xslot + 1));
+                // every wave polls for itself: all four waves below have published, in this launch
+                const unsigned want = xepoch & 0x3fffffffu;
+                auto ready = [&](unsigned long long w) -> bool {
+                    const unsigned lo = (unsigned)w, hi = (unsigned)(w >> 32);
+                    return (lo >> 2) == want && (hi >> 2) == want && (lo & 3u) && (hi & 3u);
+                };
+                const int tmo = (p.xknob & 8u) ? (1 << 12) : (1 << 22);              // a bounded wait: a lost neighbour must not hang the GPU
+                int it = xdead ? tmo : 0;
+                while (it < tmo && !(ready(__hip_atomic_load(fl, __ATOMIC_RELAXED, XSCOPE)) && ready(__hip_atomic_load(fl + 1, __ATOMIC_RELAXED, XSCOPE)))) {
                     __builtin_amdgcn_s_sleep(1);
-                if (it >= (1 << 22) && p.xerr) *p.xerr = 1u;                         // (a bounded wait: a lost neighbour must not hang the GPU)
+                    ++it;
+                }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 const unsigned long long* src = (const unsigned long long*)(p.xh + ((size_t)l * p.B * p.nrb + xslot + 1) * G::xrow_bytes());
                 unsigned long long t[(NU + 255) / 256];
+                if (it < tmo) {
 #pragma unroll
-                for (int u = 0; u < (NU + 255) / 256; ++u) {
-                    const int i = tid + 256 * u;
-                    t[u] = __hip_atomic_load(src + (i < NU ? i : NU - 1), __ATOMIC_RELAXED, XSCOPE);
+                    for (int u = 0; u < (NU + 255) / 256; ++u) {
+                        const int i = tid + 256 * u;
+                        t[u] = __hip_atomic_load(src + (i < NU ? i : NU - 1), __ATOMIC_RELAXED, XSCOPE);
+                    }
+                } else {                                                             // gave up (or the buffers are marked dead): NaN, loudly
+#pragma unroll
+                    for (int u = 0; u < (NU + 255) / 256; ++u) t[u] = 0x7fc07fc07fc07fc0ull;
+                    if (lane == 0 && !xdead) {
+                        if (p.xerr) __hip_atomic_store(p.xerr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        __hip_atomic_store(p.xctl + 9, 1ull, __ATOMIC_RELAXED, XSCOPE);
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < (NU + 255) / 256; ++u) { const int i = tid + 256 * u; if (i < NU) dst[i] = t[u]; }
                 __syncthreads();
-                if (tid == 0) {
-                    __hip_atomic_store(fl, 0ull, __ATOMIC_RELAXED, XSCOPE);
-                    __hip_atomic_store(fl + 1, 0ull, __ATOMIC_RELAXED, XSCOPE);
-                }
             } else {
                 for (int i = tid; i < NU; i += 256) dst[i] = 0ull;
                 __syncthreads();
@@ -671,16 +821,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     };
     // every wave group runs its own instantiation of a hidden phase (the left-over tile's pixel tiles are compile time)
+    bool xl2 = false;                                            // XCH: the hand-over path of the row the current layer exports
     static_for<GN>([&](auto g_c) {
         constexpr int GI = decltype(g_c)::value;
         if (xg != GI) return;
         constexpr int EM0 = (NX == 0 || !XSPLIT) ? (1 << NPT0) - 1 : fused_extra_mask(NPT0, GN, GI);
         f32x4 acc0[NPT0][NTWH], bi0[NTWH];
         load_bias(p.bias[0], bi0);
+        const unsigned who = xch_peek();
         conv_phase(std::integral_constant<int, RD0>{}, std::integral_constant<int, NPT0>{}, std::integral_constant<int, NTWH>{},
                    std::integral_constant<int, G::rows_h(0)>{}, std::integral_constant<int, EM0>{}, G::ZREG, Z16, Z8, wb0, NHT, htile,
                    wr0, acc0, PartL0{}, g_c, SET);
         IAF_FSTAMP(6);
+        xch_next_epoch();
+        xl2 = xch_l2(who);
         store_ctx();
         if constexpr (DEPTH == 1) load_final_operands();
         preload_after(std::integral_constant<int, 0>{});
@@ -689,9 +843,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         IAF_FSTAMP(11);
         hidden_epilogue(std::integral_constant<int, NPT0>{}, std::integral_constant<int, G::rows_h(0)>{},
                         std::integral_constant<int, EM0>{}, std::integral_constant<int, 1>{}, acc0, bi0, G::HREG0, p.hsave[0], p.border[0],
-                        xch_row(0));
+                        xch_row(0), xl2);
     });
-    xch_publish(0);
+    xch_publish(0, xl2);
     __syncthreads();
     IAF_FSTAMP(2);
     static_for<DEPTH - 1>([&](auto lm_c) {
@@ -711,6 +865,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             constexpr int EML = (NX == 0 || !XSPLIT) ? (1 << NPTL) - 1 : fused_extra_mask(NPTL, GN, GI);
             f32x4 accl[NPTL][NTWH], bil[NTWH];
             load_bias(p.bias[l], bil);
+            const unsigned who = xch_peek();
             const f32x4* wbl = (const f32x4*)p.wp3[l];
             conv_phase(std::integral_constant<int, RDH>{}, std::integral_constant<int, NPTL>{}, std::integral_constant<int, NTWH>{},
                        std::integral_constant<int, G::rows_h(l)>{}, std::integral_constant<int, EML>{}, IN_REG, H16, H8, wbl, NHT, htile,
@@ -727,13 +882,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
             if constexpr (l == 1) IAF_FSTAMP(7);
             if constexpr (l == DEPTH - 1) load_final_operands();
+            xl2 = xch_l2(who);
             preload_after(std::integral_constant<int, l>{});
             hidden_epilogue(std::integral_constant<int, NPTL>{}, std::integral_constant<int, G::rows_h(l)>{},
                             std::integral_constant<int, EML>{}, std::integral_constant<int, 0>{}, accl, bil, OUT_REG, p.hsave[l], p.border[l],
-                            xch_row(l));
+                            xch_row(l), xl2);
             if constexpr (l == 1) IAF_FSTAMP(12);
         });
-        xch_publish(l);
+        xch_publish(l, xl2);
         __syncthreads();
     });
     IAF_FSTAMP(3);

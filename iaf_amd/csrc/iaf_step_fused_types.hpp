@@ -26,10 +26,14 @@ struct StepP {
     // mean / free-bits max / channel sum applied (tf_train.py:79-85) by iaf_kl_finish_kernel: ONE small launch behind this
     // one instead of the two (row sums over the KL tensor + finish) of round 2.  NULL: no partial sums are written.
     float* kl_part;
-    // XCH kernels (halo rows exchanged between the row blocks of an image instead of recomputed): row buffer, flags, error word
-    char* xh;
-    unsigned* xflag;
-    unsigned* xerr;
+    // XCH kernels (halo rows exchanged between the row blocks of an image instead of recomputed; iaf_step_fused.hpp "XCH"):
+    char* xh;                      // rows [layer][B * nrb][xrow bytes]
+    unsigned* xflag;               // [layer][B * nrb][32 words]: words 0-3 = (epoch << 2) | path, one per publishing wave
+    unsigned long long* xctl;      // [0..7] work-list heads (epoch << 32 | tickets taken), [8] arrivals, [9] sticky error
+    unsigned* xwho;                // [B * nrb]: (epoch << 8) | 0x80 | XCD of the workgroup that holds the item
+    unsigned* xerr;                // host-visible error word (mapped pinned memory), or NULL
+    unsigned xknob;                // test knobs: 1 lists ignore the placement, 2 tickets out of dispatch order, 4 never through L2,
+                                   // 8 fault injection (image 0's bottom block never publishes its first row; short waits)
 };
 
 typedef void (*step_fn_t)(StepP);

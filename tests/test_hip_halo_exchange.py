@@ -1,0 +1,223 @@
+"""The hand-over of halo rows between the row blocks of an image inside the one-launch IAF step (iaf_amd/csrc/iaf_step_fused.hpp,
+"XCH"; the step itself is tf_train.py:69-72 over layers.py:158-166): that its results do not depend on dispatch order, timing or
+workgroup -> XCD placement (MI355X_MICROARCH.md: "placement-independent protocols only"), and that it cannot fail silently.
+
+ * order: a workgroup takes a ticket from a work list and only waits for the holder of a lower ticket.  The debug knobs
+   (include/iaf_hip.h, iaf_stack_set_halo_exchange_debug) scramble what the kernel could otherwise have relied on: 1 = the
+   list is chosen by a hash of the workgroup index (neighbouring row blocks land on arbitrary XCDs, lists run dry and
+   workgroups take from other lists), 2 = every workgroup delays its ticket by a pseudo-random time (tickets out of dispatch
+   order), 4 = no hand-over through an XCD's L2.  Every combination must give the recomputing kernel's numbers, launch
+   after launch with fresh inputs (a stale row of an earlier launch would be an O(1) error), on grids of less than one
+   and of many rounds of the chip.
+ * failure: knob 8 makes one producer skip a row; its consumer's bounded wait gives up, and then NaN must come out, the error
+   word must be set, the next call must raise ExchangeError, the stack must carry on with the recomputing kernels and the
+   exchange must come back after set_halo_exchange(True)."""
+import numpy as np
+import pytest
+import torch
+
+import golden_inputs as gi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def amd():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU")
+    import iaf_amd
+    iaf_amd._capi.lib()
+    return iaf_amd
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def _stacks(amd, n_z, n_hs, seed, variant="tf"):
+    """(exchanging stack, recomputing stack) on the same weights"""
+    rng = np.random.RandomState(seed)
+    params = {k: dev(v) for k, v in gi.ar_multiconv2d_params(rng, n_z, n_hs, [n_z, n_z]).items()}
+    xs, rc = amd.ARStack(n_z, n_hs), amd.ARStack(n_z, n_hs)
+    rc.set_halo_exchange(False)
+    xs.prepare(params)
+    rc.prepare(params)
+    return xs, rc
+
+
+def _close(a, r, what):
+    a, r = a.double(), r.double()
+    assert torch.isfinite(a).all(), what
+    err = float((a - r).abs().max())
+    assert err <= 2e-6 * max(1.0, float(r.abs().max())), (what, err)
+
+
+@pytest.mark.parametrize("knob", [0, 1, 2, 3, 4, 7], ids=lambda k: "knob%d" % k)
+@pytest.mark.parametrize("B", [32, 5, 64, 300], ids=lambda b: "B%d" % b)
+def test_results_do_not_depend_on_order_or_placement(amd, B, knob):
+    xs, rc = _stacks(amd, 32, [160, 160], 11)
+    assert xs.step_exchanges(B, 16, 16) and not rc.step_exchanges(B, 16, 16) and rc.step_is_fused(B, 16, 16) == 2
+    xs.set_halo_exchange_debug(knob)
+    g = torch.Generator(device="cuda").manual_seed(1000 + B + knob)
+    for rep in range(4 if B <= 64 else 2):
+        z = torch.randn(B, 32, 16, 16, device="cuda", generator=g)
+        ctx = torch.randn(B, 160, 16, 16, device="cuda", generator=g)
+        zx, sx = xs.iaf_step(z, ctx)
+        zr, sr = rc.iaf_step(z, ctx)
+        _close(sx, sr, "logsd rep %d" % rep)
+        _close(zx, zr, "z rep %d" % rep)
+    assert xs.exchange_errors() == 0
+
+
+@pytest.mark.parametrize("knob", [0, 3], ids=lambda k: "knob%d" % k)
+@pytest.mark.parametrize("n_h", [64, 192])
+def test_deep_stack_exchange_under_scrambled_order(amd, n_h, knob):
+    """config 3 (n_z = 64, depth_ar = 4): four exported rows per block; n_h = 192 exists ONLY in the exchange form at 16-pixel rows,
+    so its reference is the layer-by-layer path"""
+    xs, rc = _stacks(amd, 64, [n_h] * 4, 12)
+    xs.set_halo_exchange_debug(knob)
+    assert xs.step_exchanges(8, 16, 16)
+    if n_h == 192:
+        assert rc.step_is_fused(8, 16, 16) == 0
+    g = torch.Generator(device="cuda").manual_seed(77 + n_h)
+    for rep in range(3):
+        z = torch.randn(8, 64, 16, 16, device="cuda", generator=g)
+        ctx = torch.randn(8, n_h, 16, 16, device="cuda", generator=g)
+        zx, sx = xs.iaf_step(z, ctx)
+        zr, sr = rc.iaf_step(z, ctx)
+        a, r = sx.double(), sr.double()
+        assert float((a - r).abs().max()) < 5e-6 and float((zx.double() - zr.double()).abs().max()) < 1e-4
+    assert xs.exchange_errors() == 0
+
+
+def test_posterior_block_exchange_under_scrambled_order(amd):
+    """tf_train.py:56-85 in the one-launch form (sample in front, KL sums behind) through the same exchange"""
+    xs, rc = _stacks(amd, 32, [160, 160], 13)
+    xs.set_halo_exchange_debug(3)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    B = 32
+    for rep in range(3):
+        t = lambda c, s=1.0: s * torch.randn(B, c, 16, 16, device="cuda", generator=g)
+        args = dict(qz_mean=t(32), qz_logsd=t(32, .25), rz_mean=t(32), rz_logsd=t(32, .25), pz_mean=t(32), pz_logsd=t(32, .25),
+                    eps=t(32), up_context=t(160), down_context=t(160))
+        ox = xs.posterior_block(kl_min=0.25, **args)
+        orr = rc.posterior_block(kl_min=0.25, **args)
+        for k in ("z", "kl_obj", "kl_cost"):
+            a, r = ox[k].double(), orr[k].double()
+            assert torch.isfinite(a).all()
+            assert float((a - r).abs().max()) <= 3e-6 * max(1.0, float(r.abs().max())), k
+    assert xs.exchange_errors() == 0
+
+
+def test_two_streams_share_a_stack(amd):
+    """SURVEY 8b Threading: re-entrant per stream -- every stream has its own exchange set"""
+    xs, rc = _stacks(amd, 32, [160, 160], 14)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    ins = [(torch.randn(32, 32, 16, 16, device="cuda", generator=g), torch.randn(32, 160, 16, 16, device="cuda", generator=g))
+           for _ in range(2)]
+    refs = [rc.iaf_step(z, c) for z, c in ins]
+    torch.cuda.synchronize()
+    outs = [[], []]
+    for rep in range(20):
+        for i, st in enumerate((s1, s2)):
+            with torch.cuda.stream(st):
+                outs[i].append(xs.iaf_step(*ins[i]))
+    torch.cuda.synchronize()
+    for i in range(2):
+        for zx, sx in outs[i]:
+            _close(sx, refs[i][1], "stream %d logsd" % i)
+            _close(zx, refs[i][0], "stream %d z" % i)
+    assert xs.exchange_errors() == 0
+
+
+@pytest.mark.parametrize("launches", [1, 3], ids=lambda n: "graph_of_%d" % n)
+def test_replayed_graphs(amd, launches):
+    """a captured graph freezes the kernel arguments, so nothing per launch may come from the host: the launch epoch is counted
+    on the device.  Graphs of an odd and of an even number of launches, replayed with fresh inputs."""
+    xs, rc = _stacks(amd, 32, [160, 160], 15)
+    g = torch.Generator(device="cuda").manual_seed(21)
+    z = torch.randn(32, 32, 16, 16, device="cuda", generator=g)
+    ctx = torch.randn(32, 160, 16, 16, device="cuda", generator=g)
+    xs.iaf_step(z, ctx)                                         # (warm-up: the exchange set is allocated outside the capture)
+    torch.cuda.synchronize()
+    outs = [(torch.empty_like(z), torch.empty_like(z)) for _ in range(launches)]
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        cur = z
+        for o in outs:
+            xs.iaf_step(cur, ctx, out=o)
+            cur = o[0]
+    for rep in range(5):
+        z.copy_(torch.randn(32, 32, 16, 16, device="cuda", generator=g))
+        ctx.copy_(torch.randn(32, 160, 16, 16, device="cuda", generator=g))
+        graph.replay()
+        cur = z
+        for o in outs:
+            zr, sr = rc.iaf_step(cur, ctx)
+            _close(o[1], sr, "logsd")
+            _close(o[0], zr, "z")
+            cur = zr
+    assert xs.exchange_errors() == 0
+
+
+def test_a_wait_that_gives_up_is_loud_and_the_stack_recovers(amd):
+    xs, rc = _stacks(amd, 32, [160, 160], 16)
+    g = torch.Generator(device="cuda").manual_seed(33)
+    B = 8
+    z = torch.randn(B, 32, 16, 16, device="cuda", generator=g)
+    ctx = torch.randn(B, 160, 16, 16, device="cuda", generator=g)
+    zr, sr = rc.iaf_step(z, ctx)
+    zx, sx = xs.iaf_step(z, ctx)
+    _close(zx, zr, "before the fault")
+    xs.set_halo_exchange_debug(8)                                # image 0's bottom block never publishes its first hidden row
+    zf, sf = xs.iaf_step(z, ctx)
+    torch.cuda.synchronize()
+    # the block above it (rows 12, 13 of image 0) waited, gave up and says so in its numbers; every other block of the launch
+    # had what it needed (a block's exported first row never depends on an imported one at two rows per block)
+    assert torch.isnan(zf[0, :, 12:14]).all() and torch.isnan(sf[0, :, 12:14]).all()
+    assert torch.isfinite(zf[1:]).all() and torch.isfinite(zf[0, :, :12]).all() and torch.isfinite(zf[0, :, 14:]).all()
+    _close(zf[1:], zr[1:], "the other images of the faulty launch")
+    assert xs.exchange_errors() != 0
+    xs.set_halo_exchange_debug(0)
+    with pytest.raises(amd.ExchangeError):                       # said once, as the next call's status ...
+        xs.iaf_step(z, ctx)
+    assert not xs.step_exchanges(B, 16, 16) and xs.step_is_fused(B, 16, 16) == 2
+    z2, s2 = xs.iaf_step(z, ctx)                                 # ... and the stack carries on, recomputing its halo rows
+    assert torch.equal(z2, zr) and torch.equal(s2, sr)
+    assert xs.exchange_errors() != 0                             # (sticky until re-armed)
+    xs.set_halo_exchange(True)
+    assert xs.step_exchanges(B, 16, 16) and xs.exchange_errors() == 0
+    z3, s3 = xs.iaf_step(z, ctx)
+    _close(z3, zr, "re-armed")
+    _close(s3, sr, "re-armed")
+    assert xs.exchange_errors() == 0
+
+
+def test_launches_queued_behind_a_give_up_do_not_wait(amd):
+    """the sticky word: a launch that was already queued when an earlier one gave up (a graph replay, an eager launch the host
+    issued before the error word reached it) imports NaN at once instead of trusting the buffers"""
+    xs, rc = _stacks(amd, 32, [160, 160], 17)
+    g = torch.Generator(device="cuda").manual_seed(34)
+    z = torch.randn(4, 32, 16, 16, device="cuda", generator=g)
+    ctx = torch.randn(4, 160, 16, 16, device="cuda", generator=g)
+    xs.iaf_step(z, ctx)
+    torch.cuda.synchronize()
+    out = (torch.empty_like(z), torch.empty_like(z))
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        xs.iaf_step(z, ctx, out=out)
+    xs.set_halo_exchange_debug(8)
+    xs.iaf_step(z, ctx)                                          # gives up
+    graph.replay()                                               # captured without the fault knob
+    torch.cuda.synchronize()
+    assert xs.exchange_errors() != 0
+    # every image has row blocks that import: NaN in all of them; the bottom blocks import nothing
+    assert all(bool(torch.isnan(out[0][b]).any()) for b in range(4))
+    xs.set_halo_exchange_debug(0)
+    xs.set_halo_exchange(True)
+    graph.replay()
+    torch.cuda.synchronize()
+    zr, sr = rc.iaf_step(z, ctx)
+    _close(out[0], zr, "replay after re-arming")
+    assert xs.exchange_errors() == 0

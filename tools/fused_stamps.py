@@ -10,12 +10,15 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=32); ap.add_argument("--hw", type=int, default=16)
 ap.add_argument("--n-z", type=int, default=32); ap.add_argument("--n-h", type=int, default=160)
 ap.add_argument("--depth-ar", type=int, default=2); ap.add_argument("--reps", type=int, default=200)
+ap.add_argument("--knob", type=int, default=0, help="halo-exchange debug knob (include/iaf_hip.h); -1: halo rows recomputed")
 a = ap.parse_args()
 rng = np.random.RandomState(0)
 params = gi.ar_multiconv2d_params(rng, a.n_z, [a.n_h] * a.depth_ar, [a.n_z, a.n_z])
 dev = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).cuda()
 z = dev(rng.standard_normal((a.batch, a.n_z, a.hw, a.hw))); ctx = dev(rng.standard_normal((a.batch, a.n_h, a.hw, a.hw)))
 st = iaf_amd.ARStack(a.n_z, [a.n_h] * a.depth_ar); st.prepare({k: dev(v) for k, v in params.items()})
+if a.knob < 0: st.set_halo_exchange(False)
+elif a.knob: st.set_halo_exchange_debug(a.knob)
 out = (torch.empty_like(z), torch.empty_like(z))
 for _ in range(5):
     st.iaf_step(z, ctx, out=out)
@@ -25,7 +28,8 @@ e0.record()
 for _ in range(a.reps):
     st.iaf_step(z, ctx, out=out)
 e1.record(); torch.cuda.synchronize()
-print("iaf_step %dx%d B=%d: %.2f us per call (back to back, eager)" % (a.hw, a.hw, a.batch, e0.elapsed_time(e1) / a.reps * 1e3))
+print("iaf_step %dx%d B=%d knob %d: %.2f us per call (back to back, eager); rows via L2 / memory %s; errors %d" % (
+    a.hw, a.hw, a.batch, a.knob, e0.elapsed_time(e1) / a.reps * 1e3, st.exchange_paths(), st.exchange_errors()))
 buf = torch.zeros(16 * 65536, dtype=torch.int64, device="cuda")
 _capi.check(_capi.lib().iaf_stack_set_debug(st._h, -2, ctypes.c_void_p(buf.data_ptr())))
 st.iaf_step(z, ctx, out=out); torch.cuda.synchronize()
