@@ -110,7 +110,7 @@ struct iaf_stack {
         hipStream_t st = nullptr;
         char* buf = nullptr; size_t bytes = 0;                 // rows
         unsigned* flag = nullptr; size_t nrow = 0;             // flag lines (32 words per row)
-        unsigned long long* ctl = nullptr;                     // heads, arrivals, sticky error (16 words)
+        unsigned long long* ctl = nullptr;                     // heads, arrivals, sticky error (512 words: StepP::xctl)
         unsigned* who = nullptr; size_t nwho = 0;              // announcements
     };
     std::deque<XchSet> xch_sets;           // (stable addresses: a launch holds a pointer to its set outside the lock)
@@ -506,7 +506,7 @@ static int xch_reset_sets(iaf_stack_t* s) {
     std::lock_guard<std::mutex> lk(s->xch_mu);
     for (auto& x : s->xch_sets) {
         HIP_TRY(hipMemset(x.flag, 0, x.nrow * 32 * sizeof(unsigned)));
-        HIP_TRY(hipMemset(x.ctl, 0, 16 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(x.ctl, 0, 512 * sizeof(unsigned long long)));
         HIP_TRY(hipMemset(x.who, 0, x.nwho * sizeof(unsigned)));
     }
     if (s->xch_err_host) *(volatile unsigned*)s->xch_err_host = 0u;
@@ -1113,8 +1113,8 @@ static iaf_stack::XchSet* xch_prepare(iaf_stack_t* s, int B, int nrb, size_t xro
               hipMalloc((void**)&nw, nwho * sizeof(unsigned)) == hipSuccess &&
               hipMemsetAsync(nf, 0, nrow * 32 * sizeof(unsigned), st) == hipSuccess &&      // (ordered in front of the launch)
               hipMemsetAsync(nw, 0, nwho * sizeof(unsigned), st) == hipSuccess;
-    if (ok && !nc) ok = hipMalloc((void**)&nc, 16 * sizeof(unsigned long long)) == hipSuccess &&
-                        hipMemsetAsync(nc, 0, 16 * sizeof(unsigned long long), st) == hipSuccess;
+    if (ok && !nc) ok = hipMalloc((void**)&nc, 512 * sizeof(unsigned long long)) == hipSuccess &&
+                        hipMemsetAsync(nc, 0, 512 * sizeof(unsigned long long), st) == hipSuccess;
     if (!ok) {
         if (nb) (void)hipFree(nb);
         if (nf) (void)hipFree(nf);

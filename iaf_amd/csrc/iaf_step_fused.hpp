@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (last_row || cl) a += *(const f32x4*)(bt + 3 * cstride + ch);
         return a;
     };
-#define IAF_FSTAMP(k) do { if (p.dbg && tid == 0) p.dbg[(size_t)blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+#define IAF_FSTAMP(k) do { if (p.dbg && tid == 0) p.dbg[(size_t)blockIdx.x * 32 + (k)] = __builtin_readcyclecounter(); } while (0)
     IAF_FSTAMP(0);
 
     // ---- co tiles of a hidden layer per wave: NFULL rounds of 4 + (NX left-over tiles shared by groups of GN waves) ------
@@ -357,17 +357,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
 
     // ---- XCH: which rows this workgroup computes -- a ticket, not blockIdx -----------------------------------------------------
-    // p.xctl[0..7]: heads of eight work lists, (launch epoch << 32) | tickets taken; [8]: workgroups of this launch that are done
-    // with the heads; [9]: sticky error.  List y holds the images b = y, y + 8, y + 16, ... < B, their row blocks bottom first:
-    // ticket t of list y is (image y + 8 (t / nrb), row block nrb - 1 - t % nrb).  A workgroup asks the list of the XCD it runs on
-    // (HW_REG_XCC_ID) first -- so the row blocks of an image meet in ONE L2 wherever the dispatcher spreads workgroups evenly, and
-    // hand their rows over through it (xmode below) -- and the other lists in turn when that one is dry: grid = number of
-    // items, so every workgroup finds exactly one.  The placement decides the speed of a hand-over, never its correctness.
-    // The workgroup that arrives last at [8] (all tickets of the launch are taken by then) starts the next epoch: heads back to
-    // zero tickets, [8] to zero.  Flags and announcements carry the epoch, so nothing has to be cleared between launches and a
-    // launch that gave up leaves nothing behind that the next one could take for its own.
+    // p.xctl (64-bit words; every counter in a 128-byte line of its own -- 512 read-modify-writes of ONE line took 12 k cycles of
+    // this prologue when heads and arrivals shared one): [32 y] head of work list y = (launch epoch << 32) | tickets taken;
+    // [32 y + 16] holders of list y that are done with the heads; [256] lists whose holders all are; [272] sticky error.
+    // List y holds the images b = y, y + 8, y + 16, ... < B, their row blocks bottom first: ticket t of list y is (image
+    // y + 8 (t / nrb), row block nrb - 1 - t % nrb).  A workgroup asks the list of the XCD it runs on (HW_REG_XCC_ID) first -- so
+    // the row blocks of an image meet in ONE L2 wherever the dispatcher spreads workgroups evenly, and hand their rows over
+    // through it (xch_l2 below) -- and the other lists in turn when that one is dry: grid = number of items, so every workgroup
+    // finds exactly one.  The placement decides the speed of a hand-over, never its correctness.
+    // The last holder of a list to arrive counts its list at [256]; the one that completes that count (every ticket of the launch
+    // is taken by then) starts the next epoch: heads to zero tickets of epoch + 1, arrival counts to zero.  Flags and
+    // announcements carry the epoch, so nothing has to be cleared between launches and a launch that gave up leaves nothing
+    // behind that the next one could take for its own.
     unsigned xepoch = 0, xcc = 0, xdead = 0;
-    unsigned long long xdone = 0;
+    unsigned long long xdone = 0, xlists_done = 0;
+    [[maybe_unused]] unsigned xmine = 0, xmine_n = 0;                    // (thread 0: the list its ticket came from, that list's items)
     int xslot = 0;
     [[maybe_unused]] unsigned long long xt0 = 0;
     [[maybe_unused]] unsigned xlist = 0;
@@ -381,8 +385,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 if (p.xknob & 1u) xlist = (blockIdx.x * 2654435761u >> 13) & 7u;        // test knob: lists that ignore the placement
                 if (p.xknob & 2u)                                                       // test knob: tickets out of dispatch order
                     for (unsigned i = 0, n = (blockIdx.x * 40503u >> 4) & 63u; i < n; ++i) __builtin_amdgcn_s_sleep(64);
-                xt0 = __hip_atomic_fetch_add(p.xctl + xlist, 1ull, __ATOMIC_RELAXED, XSCOPE);
-                xdead = (unsigned)__hip_atomic_load(p.xctl + 9, __ATOMIC_RELAXED, XSCOPE);
+                xt0 = __hip_atomic_fetch_add(p.xctl + 32 * xlist, 1ull, __ATOMIC_RELAXED, XSCOPE);
+                xdead = (unsigned)__hip_atomic_load(p.xctl + 272, __ATOMIC_RELAXED, XSCOPE);
             }
         }
     };
@@ -390,17 +394,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if constexpr (XCH) {
             if (tid == 0) {
                 unsigned long long v = xt0;
-                unsigned y = xlist, t = 0;
+                unsigned y = xlist, t = 0, ny = 0;
                 bool found = false;
                 for (int k = 0; k < 8; ++k) {
-                    if (k) { y = (xlist + k) & 7u; v = __hip_atomic_fetch_add(p.xctl + y, 1ull, __ATOMIC_RELAXED, XSCOPE); }
-                    const unsigned ny = (int)y < p.B ? (unsigned)p.nrb * (unsigned)((p.B - (int)y + 7) >> 3) : 0u;
+                    if (k) { y = (xlist + k) & 7u; v = __hip_atomic_fetch_add(p.xctl + 32 * y, 1ull, __ATOMIC_RELAXED, XSCOPE); }
+                    ny = (int)y < p.B ? (unsigned)p.nrb * (unsigned)((p.B - (int)y + 7) >> 3) : 0u;
                     t = (unsigned)v;
                     if (t < ny) { found = true; break; }
                 }
                 const unsigned ep = (unsigned)(v >> 32);
                 // (the heads are final for this workgroup: count it -- the result is looked at after the first conv)
-                xdone = __hip_atomic_fetch_add(p.xctl + 8, 1ull, __ATOMIC_RELAXED, XSCOPE);
+                xmine = y; xmine_n = found ? ny : 0u;
+                if (found) xdone = __hip_atomic_fetch_add(p.xctl + 32 * y + 16, 1ull, __ATOMIC_RELAXED, XSCOPE);
                 unsigned ib = 0, ir = (unsigned)p.nrb - 1;
                 if (found) { ib = y + 8u * (t / (unsigned)p.nrb); ir = (unsigned)p.nrb - 1u - t % (unsigned)p.nrb; }
                 else xdead |= 2u;                                           // (grid != B * nrb: a host bug -- loud, not a hang)
@@ -419,18 +424,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             xslot = b * p.nrb + rbk;
             if (xdead && tid == 0) {
                 if (p.xerr) __hip_atomic_store(p.xerr, 0x100u | xdead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __hip_atomic_store(p.xctl + 9, (unsigned long long)xdead, __ATOMIC_RELAXED, XSCOPE);
+                __hip_atomic_store(p.xctl + 272, (unsigned long long)xdead, __ATOMIC_RELAXED, XSCOPE);
             }
         }
     };
-    // ... and, once all of this launch's tickets are taken, the heads of the next launch
-    auto xch_next_epoch = [&]() {
+    // ... and, once all of this launch's tickets are taken, the heads of the next launch: two steps, so that no wave ever waits
+    // for a counter (each result is looked at a phase after its request)
+    auto xch_next_epoch_a = [&]() {
         if constexpr (XCH) {
-            if (tid == 0 && (unsigned)xdone == gridDim.x - 1u) {
+            if (tid == 0 && xmine_n && (unsigned)xdone == xmine_n - 1u)
+                xlists_done = __hip_atomic_fetch_add(p.xctl + 256, 1ull, __ATOMIC_RELAXED, XSCOPE) + 1ull;
+        }
+    };
+    auto xch_next_epoch_b = [&]() {
+        if constexpr (XCH) {
+            if (tid == 0 && (unsigned)xlists_done == (unsigned)(p.B < 8 ? p.B : 8)) {
                 const unsigned long long e1 = (unsigned long long)(xepoch + 1u) << 32;
 #pragma unroll
-                for (int y = 0; y < 8; ++y) __hip_atomic_store(p.xctl + y, e1, __ATOMIC_RELAXED, XSCOPE);
-                __hip_atomic_store(p.xctl + 8, 0ull, __ATOMIC_RELAXED, XSCOPE);
+                for (int y = 0; y < 8; ++y) {
+                    __hip_atomic_store(p.xctl + 32 * y, e1, __ATOMIC_RELAXED, XSCOPE);
+                    __hip_atomic_store(p.xctl + 32 * y + 16, 0ull, __ATOMIC_RELAXED, XSCOPE);
+                }
+                __hip_atomic_store(p.xctl + 256, 0ull, __ATOMIC_RELAXED, XSCOPE);
             }
         }
     };
@@ -714,7 +729,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // the weight packs every workgroup streams -- and the launch took 78 k instead of 54 k cycles.
     // Giving up: every wait is bounded.  A wave whose wait ends without the flags fills its share of the imported row with NaN
     // (which then flows through the remaining layers to this block's outputs and, where an exported row depends on it, on to the
-    // blocks above), raises the sticky word p.xctl[9] -- every later launch on these buffers then imports NaN without waiting --
+    // blocks above), raises the sticky word p.xctl[272] -- every later launch on these buffers then imports NaN without waiting --
     // and the host-visible p.xerr, which the next call on the stack returns as IAF_ERR_EXCHANGE.  Wrong numbers never leave
     // silently.
     auto xch_row = [&](int l) -> char* {
@@ -733,7 +748,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto xch_publish = [&](int l, bool through_l2) {   // at the end of the layer's epilogue: every wave announces its own stores of the row
         if constexpr (XCH) {
             if (rbk > 0 && !((p.xknob & 8u) && b == 0 && rbk == p.nrb - 1 && l == 0)) {        // (test knob 8: one row is never published)
+                if (l == 0) IAF_FSTAMP(22);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                              // this wave's row stores have been acknowledged
+                if (l == 0) IAF_FSTAMP(23);
                 unsigned* f = p.xflag + 32 * ((size_t)l * p.B * p.nrb + xslot) + wave;
                 const unsigned v = (xepoch << 2) | (through_l2 ? 2u : 1u);
                 if (lane == 0) {
@@ -762,6 +779,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     ++it;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                if (l == 0) IAF_FSTAMP(16); else if (l == DEPTH - 1) IAF_FSTAMP(19);
                 const unsigned long long* src = (const unsigned long long*)(p.xh + ((size_t)l * p.B * p.nrb + xslot + 1) * G::xrow_bytes());
                 unsigned long long t[(NU + 255) / 256];
                 if (it < tmo) {
@@ -775,11 +793,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     for (int u = 0; u < (NU + 255) / 256; ++u) t[u] = 0x7fc07fc07fc07fc0ull;
                     if (lane == 0 && !xdead) {
                         if (p.xerr) __hip_atomic_store(p.xerr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        __hip_atomic_store(p.xctl + 9, 1ull, __ATOMIC_RELAXED, XSCOPE);
+                        __hip_atomic_store(p.xctl + 272, 1ull, __ATOMIC_RELAXED, XSCOPE);
                     }
                 }
 #pragma unroll
                 for (int u = 0; u < (NU + 255) / 256; ++u) { const int i = tid + 256 * u; if (i < NU) dst[i] = t[u]; }
+                if (l == 0) IAF_FSTAMP(17); else if (l == DEPTH - 1) IAF_FSTAMP(20);
                 __syncthreads();
             } else {
                 for (int i = tid; i < NU; i += 256) dst[i] = 0ull;
@@ -833,7 +852,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                    std::integral_constant<int, G::rows_h(0)>{}, std::integral_constant<int, EM0>{}, G::ZREG, Z16, Z8, wb0, NHT, htile,
                    wr0, acc0, PartL0{}, g_c, SET);
         IAF_FSTAMP(6);
-        xch_next_epoch();
+        xch_next_epoch_a();
         xl2 = xch_l2(who);
         store_ctx();
         if constexpr (DEPTH == 1) load_final_operands();
@@ -875,7 +894,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWH * 3>{},
                               (l & 1) ? wr1[decltype(i)::value] : wr0[decltype(i)::value], wbl, NHT, htile, PartBelow{}, decltype(i)::value, ALL);
                 });
+                if constexpr (l == 1) IAF_FSTAMP(14);
                 xch_import(l - 1, IN_REG);
+                if constexpr (l == 1) IAF_FSTAMP(15);
                 conv_phase(std::integral_constant<int, RDH>{}, std::integral_constant<int, NPTL>{}, std::integral_constant<int, NTWH>{},
                            std::integral_constant<int, G::rows_h(l)>{}, std::integral_constant<int, EML>{}, IN_REG, H16, H8, wbl, NHT, htile,
                            (l & 1) ? wr1 : wr0, accl, PartBelow{}, g_c, ADD);
@@ -897,6 +918,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // ---- output pair: packed tiles (m_0, s_0, m_1, s_1, ...), partial sums -> exchange buffer [K part][pixel][2 n_z] -------
     // (the operands of the final transform are fetched first: they travel while the output pair is multiplied)
     float* xbuf = (float*)(smem + (size_t)G::XB_OFF * 16);
+    xch_next_epoch_b();
     {
         f32x4 acco[NPTO][NTWO];
         constexpr int LAST_REG = ((DEPTH - 1) & 1) ? G::HREG1 : G::HREG0;
@@ -908,7 +930,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWO * 3>{}, wro[decltype(i)::value], wbo, 2 * NZT,
                           otile, PartBelow{}, decltype(i)::value, ALL);
             });
+            IAF_FSTAMP(18);
             xch_import(DEPTH - 1, LAST_REG);
+            IAF_FSTAMP(21);
             conv_phase(std::integral_constant<int, RDO>{}, std::integral_constant<int, NPTO>{}, std::integral_constant<int, NTWO>{},
                        std::integral_constant<int, R>{}, std::integral_constant<int, (1 << NPTO) - 1>{}, LAST_REG,
                        H16, H8, wbo, 2 * NZT, otile, wro, acco, PartBelow{}, std::integral_constant<int, 0>{}, ADD);

@@ -29,7 +29,8 @@ struct StepP {
     // XCH kernels (halo rows exchanged between the row blocks of an image instead of recomputed; iaf_step_fused.hpp "XCH"):
     char* xh;                      // rows [layer][B * nrb][xrow bytes]
     unsigned* xflag;               // [layer][B * nrb][32 words]: words 0-3 = (epoch << 2) | path, one per publishing wave
-    unsigned long long* xctl;      // [0..7] work-list heads (epoch << 32 | tickets taken), [8] arrivals, [9] sticky error
+    unsigned long long* xctl;      // [32 y] head of work list y (epoch << 32 | tickets taken), [32 y + 16] its arrivals, [256] lists complete,
+                                   // [272] sticky error -- a 128-byte line each (512 words in all)
     unsigned* xwho;                // [B * nrb]: (epoch << 8) | 0x80 | XCD of the workgroup that holds the item
     unsigned* xerr;                // host-visible error word (mapped pinned memory), or NULL
     unsigned xknob;                // test knobs: 1 lists ignore the placement, 2 tickets out of dispatch order, 4 never through L2,

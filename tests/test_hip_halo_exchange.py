@@ -173,10 +173,15 @@ def test_a_wait_that_gives_up_is_loud_and_the_stack_recovers(amd):
     xs.set_halo_exchange_debug(8)                                # image 0's bottom block never publishes its first hidden row
     zf, sf = xs.iaf_step(z, ctx)
     torch.cuda.synchronize()
-    # the block above it (rows 12, 13 of image 0) waited, gave up and says so in its numbers; every other block of the launch
-    # had what it needed (a block's exported first row never depends on an imported one at two rows per block)
+    # the block above it (rows 12, 13 of image 0) waited, gave up and says so in its numbers.  The blocks further up in that image
+    # may have given up as well (their rows come later the longer the chain below them waits, and every wait has the same bound)
+    # or not (a block's exported first row never depends on an imported one at two rows per block); the faulty block itself
+    # imports nothing, and no other image is touched
     assert torch.isnan(zf[0, :, 12:14]).all() and torch.isnan(sf[0, :, 12:14]).all()
-    assert torch.isfinite(zf[1:]).all() and torch.isfinite(zf[0, :, :12]).all() and torch.isfinite(zf[0, :, 14:]).all()
+    assert torch.isfinite(zf[1:]).all() and torch.isfinite(zf[0, :, 14:]).all()
+    up = zf[0, :, :12].reshape(32, 6, 2, 16)                     # a row block is NaN as a whole or right as a whole
+    for k in range(6):
+        assert torch.isnan(up[:, k]).all() or torch.allclose(up[:, k], zr[0, :, 2 * k:2 * k + 2], atol=1e-5, rtol=0)
     _close(zf[1:], zr[1:], "the other images of the faulty launch")
     assert xs.exchange_errors() != 0
     xs.set_halo_exchange_debug(0)

@@ -30,11 +30,11 @@ for _ in range(a.reps):
 e1.record(); torch.cuda.synchronize()
 print("iaf_step %dx%d B=%d knob %d: %.2f us per call (back to back, eager); rows via L2 / memory %s; errors %d" % (
     a.hw, a.hw, a.batch, a.knob, e0.elapsed_time(e1) / a.reps * 1e3, st.exchange_paths(), st.exchange_errors()))
-buf = torch.zeros(16 * 65536, dtype=torch.int64, device="cuda")
+buf = torch.zeros(32 * 65536, dtype=torch.int64, device="cuda")
 _capi.check(_capi.lib().iaf_stack_set_debug(st._h, -2, ctypes.c_void_p(buf.data_ptr())))
 st.iaf_step(z, ctx, out=out); torch.cuda.synchronize()
 _capi.check(_capi.lib().iaf_stack_set_debug(st._h, -1, None))
-t = buf.cpu().numpy().reshape(-1, 16); t = t[t[:, 0] != 0]
+t = buf.cpu().numpy().reshape(-1, 32); t = t[t[:, 0] != 0]
 if len(t) == 0:
     print("the step did not run as one launch at this size"); sys.exit(0)
 names = ["start -> z staged (barrier)", "first conv + epilogue", "second conv + epilogue", "output conv", "exchange + affine + stores"]
@@ -51,6 +51,17 @@ if (t[:, 8] != 0).all():      # finer stamps (wave 0): prologue and the two epil
     if (t[:, 12] != 0).all():
         print("    second epilogue: %.0f + barrier %.0f; output pair: K loop %.0f, to the exchange buffer + barrier %.0f, transform + stores %.0f" % (
             m(12, 7), m(3, 12), m(4, 3), m(13, 4), m(5, 13)))
+if (t[:, 14] != 0).any():
+    k = t[t[:, 14] != 0]
+    print("    second conv: own-row taps %.0f | import of the row below (wait + copy + barrier) %.0f | its taps %.0f (wave 0, %d importing WGs)" % (
+        np.median(k[:, 14] - k[:, 2]), np.median(k[:, 15] - k[:, 14]), np.median(k[:, 7] - k[:, 15]), len(k)))
+if (t[:, 16] != 0).any():
+    k = t[(t[:, 16] != 0) & (t[:, 19] != 0)]
+    md = lambda a, b_: np.median(k[:, a] - k[:, b_])
+    print("    import 1 (into the second conv): poll %.0f | loads + LDS stores %.0f | barrier %.0f;  import 2 (output pair): own taps %.0f | poll %.0f | loads + stores %.0f | barrier %.0f | taps below %.0f" % (
+        md(16, 14), md(17, 16), md(15, 17), md(18, 3), md(19, 18), md(20, 19), md(21, 20), md(4, 21)))
+    k = t[t[:, 22] != 0]
+    if len(k): print("    publish of the first row: wait for the stores' acknowledgement %.0f (wave 0, %d exporting WGs)" % (np.median(k[:, 23] - k[:, 22]), len(k)))
 if (t[:, 6] != 0).all():
     print("    of which: first conv K loop %.0f, its epilogue + barrier %.0f; second conv K loop %.0f, its epilogue + barrier %.0f (wave 0)" % (
         np.median(t[:, 6] - t[:, 1]), np.median(t[:, 2] - t[:, 6]), np.median(t[:, 7] - t[:, 2]), np.median(t[:, 3] - t[:, 7])))
