@@ -86,7 +86,6 @@ SIGNATURES = {
     "iaf_stack_step_exchanges": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "iaf_stack_set_halo_exchange": (ctypes.c_int, [_vp, ctypes.c_int]),
     "iaf_stack_set_halo_exchange_debug": (ctypes.c_int, [_vp, ctypes.c_uint]),
-    "iaf_stack_exchange_paths": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_uint)]),
     "iaf_comm_unique_id": (ctypes.c_int, [_vp]),
     "iaf_comm_create": (ctypes.c_int, [ctypes.POINTER(_vp), _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "iaf_comm_size": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),

@@ -32,6 +32,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // x = h + m + l exactly up to 2^-27|x|; each part a bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32)
 __device__ __forceinline__ void bf3_split2(f32x2 x, unsigned& h, unsigned& m, unsigned& l) {

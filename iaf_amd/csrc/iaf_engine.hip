@@ -101,21 +101,19 @@ struct iaf_stack {
     float* pend_ws = nullptr; int pend_B = 0, pend_H = 0, pend_W = 0;   // ... which finds dWeff / dbp through these
     bool generic = false;     // channel counts outside the MFMA path: direct-conv fallback kernels
     // one-launch step with halo exchange (iaf_step_fused.hpp, XCH): the rows the row blocks hand each other, their flag lines, the
-    // work-list heads and the announcements -- one SET per stream the stack has launched such a step on (a set is used by one
+    // work-list heads -- one SET per stream the stack has launched such a step on (a set is used by one
     // launch at a time; launches of one stream are ordered), so calls on different streams do not share state (SURVEY 8b:
     // re-entrant per stream).  Allocated on a stream's first such launch outside a capture; nothing in a set is cleared between
-    // launches (the kernel tags what it writes with a launch epoch).  Outgrown buffers live as long as the stack: a captured graph
+    // launches (a consumer puts the "not there yet" pattern back into what it has taken, the last arrival zeroes the counters).  Outgrown buffers live as long as the stack: a captured graph
     // may still name them.
     struct XchSet {
         hipStream_t st = nullptr;
-        char* buf = nullptr; size_t bytes = 0;                 // rows
-        unsigned* flag = nullptr; size_t nrow = 0;             // flag lines (32 words per row)
-        unsigned long long* ctl = nullptr;                     // heads, arrivals, sticky error (512 words: StepP::xctl)
-        unsigned* who = nullptr; size_t nwho = 0;              // announcements
+        char* buf = nullptr; size_t bytes = 0;                 // rows: all 0xff between launches
+        unsigned long long* ctl = nullptr;                     // heads, arrivals, sticky error (512 words: StepP::xctl): zero between launches
     };
     std::deque<XchSet> xch_sets;           // (stable addresses: a launch holds a pointer to its set outside the lock)
     std::mutex xch_mu;
-    std::vector<void*> xch_retired;
+    std::vector<std::pair<char*, size_t>> xch_retired_rows;
     unsigned* xch_err_host = nullptr;     // mapped pinned word the kernels raise when a bounded wait gives up: read at every launch,
     unsigned* xch_err_dev = nullptr;      // ... without synchronising; its device-side alias
     bool xch_on = true;                   // iaf_stack_set_halo_exchange
@@ -472,13 +470,11 @@ extern "C" int iaf_stack_profile_read(iaf_stack_t* s, float* ms_out, int capacit
 static void xch_free_sets(iaf_stack_t* s) {
     for (auto& x : s->xch_sets) {
         if (x.buf) (void)hipFree(x.buf);
-        if (x.flag) (void)hipFree(x.flag);
         if (x.ctl) (void)hipFree(x.ctl);
-        if (x.who) (void)hipFree(x.who);
     }
     s->xch_sets.clear();
-    for (void* q : s->xch_retired) (void)hipFree(q);
-    s->xch_retired.clear();
+    for (auto& r : s->xch_retired_rows) (void)hipFree(r.first);
+    s->xch_retired_rows.clear();
 }
 
 extern "C" int iaf_stack_destroy(iaf_stack_t* s) {
@@ -505,10 +501,10 @@ static int xch_reset_sets(iaf_stack_t* s) {
     HIP_TRY(hipDeviceSynchronize());
     std::lock_guard<std::mutex> lk(s->xch_mu);
     for (auto& x : s->xch_sets) {
-        HIP_TRY(hipMemset(x.flag, 0, x.nrow * 32 * sizeof(unsigned)));
+        HIP_TRY(hipMemset(x.buf, 0xff, x.bytes));
         HIP_TRY(hipMemset(x.ctl, 0, 512 * sizeof(unsigned long long)));
-        HIP_TRY(hipMemset(x.who, 0, x.nwho * sizeof(unsigned)));
     }
+    for (auto& r : s->xch_retired_rows) HIP_TRY(hipMemset(r.first, 0xff, r.second));     // (a captured graph may still name them)
     if (s->xch_err_host) *(volatile unsigned*)s->xch_err_host = 0u;
     return IAF_OK;
 }
@@ -531,28 +527,6 @@ extern "C" int iaf_stack_exchange_errors(const iaf_stack_t* s, unsigned* errors)
     if (!s->xch_err_host) return IAF_OK;
     HIP_TRY(hipDeviceSynchronize());                         // (every launch so far has had its say)
     *errors = *(volatile unsigned*)s->xch_err_host;
-    return IAF_OK;
-}
-
-// Which way the rows of the LAST launch on every exchange set went: flag words of that launch's epoch, by path
-extern "C" int iaf_stack_exchange_paths(iaf_stack_t* s, unsigned* through_l2, unsigned* through_memory) {
-    if (!s || !through_l2 || !through_memory) return IAF_ERR_NULL;
-    *through_l2 = *through_memory = 0;
-    HIP_TRY(hipDeviceSynchronize());
-    std::lock_guard<std::mutex> lk(s->xch_mu);
-    for (auto& x : s->xch_sets) {
-        unsigned long long head = 0;
-        HIP_TRY(hipMemcpy(&head, x.ctl, sizeof(head), hipMemcpyDeviceToHost));
-        const unsigned last = ((unsigned)(head >> 32) - 1u) & 0x3fffffffu;
-        std::vector<unsigned> f(x.nrow * 32);
-        HIP_TRY(hipMemcpy(f.data(), x.flag, f.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
-        for (size_t r = 0; r < x.nrow; ++r)
-            for (int w = 0; w < 4; ++w) {
-                const unsigned v = f[r * 32 + w];
-                if ((v >> 2) != last) continue;
-                if ((v & 3u) == 2u) ++*through_l2; else if ((v & 3u) == 1u) ++*through_memory;
-            }
-    }
     return IAF_OK;
 }
 
@@ -1077,25 +1051,23 @@ static step_fn_t fused_step_xch(const iaf_stack_t* s, int H, int W, int R, size_
 }
 
 // The exchange set of stream st, grown to [layer][B * nrb] rows of xrow bytes: created on the stream's first such launch -- not
-// inside a stream capture (NULL then: the caller runs what it ran before; warm up before capturing, as for the LDS cap).  A set
-// that grows keeps its heads (the launch epoch goes on); new flag lines and announcements start at zero, which no epoch of a
-// running set produces with a valid path / mark.  Outgrown buffers stay alive with the stack: a captured graph may still name them.
+// inside a stream capture (there: the stream's set, else the newest one that is large enough, else NULL and the caller runs what
+// it ran before; warm up before capturing, as for the LDS cap).  A set that grows keeps its counters; the new rows start as
+// "nothing there yet" (0xff).  Outgrown rows stay alive with the stack: a captured graph may still name them.
 static iaf_stack::XchSet* xch_prepare(iaf_stack_t* s, int B, int nrb, size_t xrow, hipStream_t st) {
     std::lock_guard<std::mutex> lk(s->xch_mu);
     iaf_stack::XchSet* x = nullptr;
     for (auto& e : s->xch_sets) if (e.st == st) { x = &e; break; }
-    const size_t nrow = (size_t)s->depth_ar * B * nrb, need = nrow * xrow, nwho = (size_t)B * nrb;
-    if (x && need <= x->bytes && nrow <= x->nrow && nwho <= x->nwho) return x;
+    const size_t need = (size_t)s->depth_ar * B * nrb * xrow;
+    if (x && need <= x->bytes) return x;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(st, &cs);
     if (cs != hipStreamCaptureStatusNone) {
         // no allocation inside a capture: a capture stream without a set of its own (torch.cuda.graph's internal stream after a
         // warm-up elsewhere) adopts the newest set that is large enough -- the graph then must not be replayed concurrently with
         // launches of this stack on that set's stream (include/iaf_hip.h); none: the caller runs the recomputing kernel
-        for (size_t i = s->xch_sets.size(); i-- > 0;) {
-            iaf_stack::XchSet& e = s->xch_sets[i];
-            if (need <= e.bytes && nrow <= e.nrow && nwho <= e.nwho) return &e;
-        }
+        for (size_t i = s->xch_sets.size(); i-- > 0;)
+            if (need <= s->xch_sets[i].bytes) return &s->xch_sets[i];
         return nullptr;
     }
     if (!s->xch_err_host) {
@@ -1107,26 +1079,18 @@ static iaf_stack::XchSet* xch_prepare(iaf_stack_t* s, int B, int nrb, size_t xro
         }
     }
     char* nb = nullptr;
-    unsigned *nf = nullptr, *nw = nullptr;
     unsigned long long* nc = x ? x->ctl : nullptr;
-    bool ok = hipMalloc((void**)&nb, need) == hipSuccess && hipMalloc((void**)&nf, nrow * 32 * sizeof(unsigned)) == hipSuccess &&
-              hipMalloc((void**)&nw, nwho * sizeof(unsigned)) == hipSuccess &&
-              hipMemsetAsync(nf, 0, nrow * 32 * sizeof(unsigned), st) == hipSuccess &&      // (ordered in front of the launch)
-              hipMemsetAsync(nw, 0, nwho * sizeof(unsigned), st) == hipSuccess;
+    bool ok = hipMalloc((void**)&nb, need) == hipSuccess && hipMemsetAsync(nb, 0xff, need, st) == hipSuccess;    // (ordered in front of the launch)
     if (ok && !nc) ok = hipMalloc((void**)&nc, 512 * sizeof(unsigned long long)) == hipSuccess &&
                         hipMemsetAsync(nc, 0, 512 * sizeof(unsigned long long), st) == hipSuccess;
     if (!ok) {
         if (nb) (void)hipFree(nb);
-        if (nf) (void)hipFree(nf);
-        if (nw) (void)hipFree(nw);
         if (nc && !(x && x->ctl == nc)) (void)hipFree(nc);
         return nullptr;
     }
     if (!x) { s->xch_sets.emplace_back(); x = &s->xch_sets.back(); x->st = st; }
-    if (x->buf) s->xch_retired.push_back(x->buf);
-    if (x->flag) s->xch_retired.push_back(x->flag);
-    if (x->who) s->xch_retired.push_back(x->who);
-    x->buf = nb; x->bytes = need; x->flag = nf; x->nrow = nrow; x->who = nw; x->nwho = nwho; x->ctl = nc;
+    if (x->buf) s->xch_retired_rows.emplace_back(x->buf, x->bytes);
+    x->buf = nb; x->bytes = need; x->ctl = nc;
     return x;
 }
 
@@ -1214,7 +1178,7 @@ static int launch_fused_step(iaf_stack_t* s, step_fn_t fn, int R, size_t lds, co
         if (step_fn_t fx = fused_step_xch(s, base.H, base.W, R, &xl, &xrow)) {
             if (iaf_stack::XchSet* x = xch_prepare(s, base.B, q.nrb, xrow, st)) {
                 fn = fx; lds = xl;
-                q.xh = x->buf; q.xflag = x->flag; q.xctl = x->ctl; q.xwho = x->who; q.xerr = s->xch_err_dev; q.xknob = s->xch_knob;
+                q.xh = x->buf; q.xctl = x->ctl; q.xerr = s->xch_err_dev; q.xknob = s->xch_knob;
             } else if (fn == fx) {
                 return IAF_ERR_NOT_PREPARED;                 // (a geometry that only exists in this form, and no buffers: fused_step_plan refuses that)
             }

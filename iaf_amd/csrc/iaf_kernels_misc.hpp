@@ -274,3 +274,4 @@ __global__ __launch_bounds__(256) void iaf_disc_logistic_kernel(const float* __r
     const float tot = block_sum_256(acc, red);
     if (threadIdx.x == 0) out[blockIdx.x] = tot;
 }
+

@@ -358,18 +358,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // ---- XCH: which rows this workgroup computes -- a ticket, not blockIdx -----------------------------------------------------
     // p.xctl (64-bit words; every counter in a 128-byte line of its own -- 512 read-modify-writes of ONE line took 12 k cycles of
-    // this prologue when heads and arrivals shared one): [32 y] head of work list y = (launch epoch << 32) | tickets taken;
-    // [32 y + 16] holders of list y that are done with the heads; [256] lists whose holders all are; [272] sticky error.
+    // this prologue when heads and arrivals shared one): [32 y] head of work list y = tickets taken; [32 y + 16] holders of list y
+    // that are done with the heads; [256] lists whose holders all are; [272] sticky error.
     // List y holds the images b = y, y + 8, y + 16, ... < B, their row blocks bottom first: ticket t of list y is (image
-    // y + 8 (t / nrb), row block nrb - 1 - t % nrb).  A workgroup asks the list of the XCD it runs on (HW_REG_XCC_ID) first -- so
-    // the row blocks of an image meet in ONE L2 wherever the dispatcher spreads workgroups evenly, and hand their rows over
-    // through it (xch_l2 below) -- and the other lists in turn when that one is dry: grid = number of items, so every workgroup
-    // finds exactly one.  The placement decides the speed of a hand-over, never its correctness.
+    // y + 8 (t / nrb), row block nrb - 1 - t % nrb).  A workgroup asks the list of the XCD it runs on (HW_REG_XCC_ID) first -- eight
+    // heads, each pulled by its own XCD's 32 CUs, answer in ~0.3 us where one head for 256 pullers takes 3 -- and the other lists
+    // in turn when that one is dry: grid = number of items, so every workgroup finds exactly one.  The placement decides which
+    // head answers, never what is computed.
     // The last holder of a list to arrive counts its list at [256]; the one that completes that count (every ticket of the launch
-    // is taken by then) starts the next epoch: heads to zero tickets of epoch + 1, arrival counts to zero.  Flags and
-    // announcements carry the epoch, so nothing has to be cleared between launches and a launch that gave up leaves nothing
-    // behind that the next one could take for its own.
-    unsigned xepoch = 0, xcc = 0, xdead = 0;
+    // is taken by then) puts heads and arrival counts back to zero for the next launch on these buffers.
+    unsigned xcc = 0, xdead = 0;
     unsigned long long xdone = 0, xlists_done = 0;
     [[maybe_unused]] unsigned xmine = 0, xmine_n = 0;                    // (thread 0: the list its ticket came from, that list's items)
     int xslot = 0;
@@ -402,23 +400,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     t = (unsigned)v;
                     if (t < ny) { found = true; break; }
                 }
-                const unsigned ep = (unsigned)(v >> 32);
                 // (the heads are final for this workgroup: count it -- the result is looked at after the first conv)
                 xmine = y; xmine_n = found ? ny : 0u;
                 if (found) xdone = __hip_atomic_fetch_add(p.xctl + 32 * y + 16, 1ull, __ATOMIC_RELAXED, XSCOPE);
                 unsigned ib = 0, ir = (unsigned)p.nrb - 1;
                 if (found) { ib = y + 8u * (t / (unsigned)p.nrb); ir = (unsigned)p.nrb - 1u - t % (unsigned)p.nrb; }
                 else xdead |= 2u;                                           // (grid != B * nrb: a host bug -- loud, not a hang)
-                xmail[0] = ib; xmail[1] = ir; xmail[2] = ep; xmail[3] = xdead; xmail[4] = xcc;
-                // announce where this item's rows will be wanted: the block below chooses its hand-over path by it
-                __hip_atomic_store(p.xwho + ib * (unsigned)p.nrb + ir, (ep << 8) | 0x80u | xcc, __ATOMIC_RELAXED, XSCOPE);
+                xmail[0] = ib; xmail[1] = ir; xmail[2] = xdead;
             }
             __syncthreads();
             b = __builtin_amdgcn_readfirstlane((int)xmail[0]);
             rbk = __builtin_amdgcn_readfirstlane((int)xmail[1]);
-            xepoch = __builtin_amdgcn_readfirstlane(xmail[2]);
-            xdead = __builtin_amdgcn_readfirstlane(xmail[3]);
-            xcc = __builtin_amdgcn_readfirstlane(xmail[4]);
+            xdead = __builtin_amdgcn_readfirstlane(xmail[2]);
             r0 = rbk * R;
             img_z = (size_t)b * NZ * HW; img_h = (size_t)b * NH * HW;
             xslot = b * p.nrb + rbk;
@@ -428,7 +421,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
         }
     };
-    // ... and, once all of this launch's tickets are taken, the heads of the next launch: two steps, so that no wave ever waits
+    // ... and, once all of this launch's tickets are taken, the counters of the next launch: two steps, so that no wave ever waits
     // for a counter (each result is looked at a phase after its request)
     auto xch_next_epoch_a = [&]() {
         if constexpr (XCH) {
@@ -439,10 +432,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto xch_next_epoch_b = [&]() {
         if constexpr (XCH) {
             if (tid == 0 && (unsigned)xlists_done == (unsigned)(p.B < 8 ? p.B : 8)) {
-                const unsigned long long e1 = (unsigned long long)(xepoch + 1u) << 32;
 #pragma unroll
                 for (int y = 0; y < 8; ++y) {
-                    __hip_atomic_store(p.xctl + 32 * y, e1, __ATOMIC_RELAXED, XSCOPE);
+                    __hip_atomic_store(p.xctl + 32 * y, 0ull, __ATOMIC_RELAXED, XSCOPE);
                     __hip_atomic_store(p.xctl + 32 * y + 16, 0ull, __ATOMIC_RELAXED, XSCOPE);
                 }
                 __hip_atomic_store(p.xctl + 256, 0ull, __ATOMIC_RELAXED, XSCOPE);
@@ -621,29 +613,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int j = 0; j < NTWH; ++j) bi[j] = *(const f32x4*)(bias + (htile[j] < NHT ? htile[j] : NHT - 1) * 16 + 4 * kk);
     };
-    // bf3_store4 into the exchanged row in memory: the same three 8-byte pieces.  THROUGH_L2 (the block above runs on this XCD,
-    // xmode): plain stores, which stay in this XCD's L2 where that block's loads find them; else agent-scope stores (sc1:
-    // written through to memory, visible to every XCD)
-    auto xch_store4 = [&](char* base, int slot, int q, f32x4 v, bool through_l2) {
-        unsigned h0, m0, l0, h1, m1, l1;
-        bf3_split2(f32x2{v[0], v[1]}, h0, m0, l0);
-        bf3_split2(f32x2{v[2], v[3]}, h1, m1, l1);
-        unsigned long long* d = (unsigned long long*)(base + ((size_t)slot * H16 << 4) + q * 8);
-        const unsigned long long vh = (unsigned long long)h0 | ((unsigned long long)h1 << 32), vm = (unsigned long long)m0 | ((unsigned long long)m1 << 32),
-                                 vl = (unsigned long long)l0 | ((unsigned long long)l1 << 32);
-        if (through_l2) {
-            __hip_atomic_store(d, vh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            __hip_atomic_store(d + 2 * H8, vm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            __hip_atomic_store(d + 4 * H8, vl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        } else {
-            __hip_atomic_store(d, vh, __ATOMIC_RELAXED, XSCOPE);
-            __hip_atomic_store(d + 2 * H8, vm, __ATOMIC_RELAXED, XSCOPE);
-            __hip_atomic_store(d + 4 * H8, vl, __ATOMIC_RELAXED, XSCOPE);
-        }
-    };
-    // xrow (XCH): where this block's FIRST row goes for the block above (NULL: nobody above)
     auto hidden_epilogue = [&](auto npt_c, auto rows_c, auto emask_c, auto ctx_c, f32x4 (*acc)[NTWH], const f32x4* bias, int out_reg,
-                               float* hsave, const float* bt, char* xrow, bool xl2) {
+                               float* hsave, const float* bt) {
         constexpr int NPT = decltype(npt_c)::value, ROWS = decltype(rows_c)::value, EMASK = decltype(emask_c)::value;
         constexpr bool WITH_CTX = decltype(ctx_c)::value != 0;
         f32x4 cxv[WITH_CTX ? NPT : 1][NTWH];                     // all context reads in flight together, ahead of the arithmetic
@@ -660,11 +631,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     for (int r = 0; r < 4; ++r) cxv[q][j][r] = cr[r * G::CSTR];
                 }
         }
-        // (XCH: pixel tiles outermost -- the exported row is in the first one, its stores to memory leave first and are done
-        // when the epilogue ends)
 #pragma unroll
         for (int oi = 0; oi < NTWH * NPT; ++oi) {
-            const int j = XCH ? oi % NTWH : oi / NPT, q = XCH ? oi / NTWH : oi % NPT;
+            const int j = oi / NPT, q = oi % NPT;
             if (htile[j] >= NHT) continue;
             const f32x4 bi = bias[j];
             {
@@ -679,7 +648,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 for (int r = 0; r < 4; ++r) v[r] = elu_f(v[r]);
                 if (r0 + row >= H) v = f32x4{0.f, 0.f, 0.f, 0.f};
                 bf3_store4(smem + (size_t)out_reg * 16, row * RS + col + 1, htile[j] * 4 + kk, v, H16, H8);
-                if constexpr (XCH) { if (xrow && row == 0) xch_store4(xrow, col, htile[j] * 4 + kk, v, xl2); }
                 // training: the rows this workgroup OWNS (not its halo) go to HBM for the backward pass
                 if (hsave && row < R && r0 + row < H)
                     *(f32x4*)(hsave + ((size_t)b * HW + (size_t)gpix(r0 + row, col)) * NH + htile[j] * 16 + 4 * kk) = v;
@@ -713,95 +681,92 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     };
     // ---- XCH: halo rows through memory ---------------------------------------------------------------------------------
-    // p.xh [layer][B * nrb][W slots x H16 x 16 bytes]: row 0 of block (b, k)'s hidden layer, as it sits in LDS; p.xflag [layer]
-    // [B * nrb][32 words = one 128-byte line]: words 0-3, one per publishing wave, = (epoch << 2) | path once that wave's part of
-    // the row is where the block above can read it (four stores to four words: a shared counter -- four read-modify-writes of one
-    // word -- measured 1.7 % slower).  Nothing is cleared: a word of another launch carries another epoch.
-    // Two hand-over paths, chosen per row by the PRODUCER from what the block above announced (p.xwho, xch_take_finish):
-    //   path 2, the block above runs on this XCD: plain row stores (they stay in this XCD's L2), a workgroup-scope flag store;
-    //   path 1, it runs elsewhere or has not announced itself yet: agent-scope stores (sc1, written through to memory).
-    // The consumer is the same for both: it polls the flag words and copies the row with agent-scope loads (sc1: they bypass its
-    // CU's L1 -- which may hold the previous launch's row -- and are served by its L2 where that holds the line dirty, by memory
-    // otherwise).  Path 2 therefore rests on a fact read from the hardware in THIS launch, not on a placement assumed.
-    // In front of a flag store every wave waits for its own row stores explicitly (s_waitcnt vmcnt(0) as inline asm: a
-    // workgroup-scope fence emits no wait on gfx950, and the compiler drops waits it believes redundant -- ADVICE r03 #1).
-    // Agent-scope FENCES were measured in round 3: buffer_wbl2 / buffer_inv sc1 write back and invalidate the whole L2 -- with it
-    // the weight packs every workgroup streams -- and the launch took 78 k instead of 54 k cycles.
-    // Giving up: every wait is bounded.  A wave whose wait ends without the flags fills its share of the imported row with NaN
+    // p.xh [layer][B * nrb][W slots x H16 x 16 bytes]: row 0 of block (b, k)'s hidden layer, as it sits in LDS.
+    // THE DATA IS THE FLAG: between launches every dword of the buffer holds XSENT (two bf16 NaNs of a payload no arithmetic
+    // produces).  The producer copies the row from LDS -- where its epilogue has just put it, behind the epilogue's barrier -- with
+    // 16-byte stores, consecutive lanes to consecutive addresses (whole 128-byte lines leave the CU; the 8-byte pieces round 3
+    // stored straight from the MFMA layout, 320 bytes apart, needed ~4 us to land) and is done: no acknowledgement to wait for,
+    // no flag to raise.  The block above loads the whole row, takes every 16-byte unit none of whose dwords is XSENT for what it
+    // is, asks again for the others, and -- the row in its registers -- puts XSENT back.  One trip to memory per hand-over instead
+    // of the three of round 3's flag words (stores acknowledged -> flag -> poll -> row loads; measured this round with flags:
+    // poll 1.6 k + row 1.2 k cycles on the consumer, 0.3 - 0.7 k on the producer, and no difference between flags in the XCD's L2
+    // and in memory -- sc1 loads are served by the memory side either way:
+    // profiles/r04/experiments/stamps_l2_vs_memory_import_breakdown.txt).
+    // Every access carries sc1 (agent scope: coherent per access across the XCDs' L2s and past this CU's L1, which may hold the
+    // previous launch's row).  Agent-scope FENCES were measured in round 3: buffer_wbl2 / buffer_inv sc1 write back and
+    // invalidate the whole L2 -- with it the weight packs every workgroup streams -- and the launch took 78 k instead of 54 k cycles.
+    // Giving up: every wait is bounded.  A wave whose wait ends with units missing fills its share of the imported row with NaN
     // (which then flows through the remaining layers to this block's outputs and, where an exported row depends on it, on to the
-    // blocks above), raises the sticky word p.xctl[272] -- every later launch on these buffers then imports NaN without waiting --
-    // and the host-visible p.xerr, which the next call on the stack returns as IAF_ERR_EXCHANGE.  Wrong numbers never leave
-    // silently.
-    auto xch_row = [&](int l) -> char* {
-        if constexpr (!XCH) return nullptr;
-        return rbk > 0 ? p.xh + ((size_t)l * p.B * p.nrb + xslot) * G::xrow_bytes() : nullptr;
+    // blocks above), raises the sticky word p.xctl[272] -- the buffer can no longer be trusted to be all XSENT, so every later
+    // launch on it imports NaN without looking -- and the host-visible p.xerr, which the next call on the stack returns as
+    // IAF_ERR_EXCHANGE; iaf_stack_set_halo_exchange re-arms the buffers.  Wrong numbers never leave silently.
+    constexpr unsigned XSENT = 0xffffffffu;
+    constexpr int XSC1 = 16;                                                         // aux bits of the buffer instructions: sc1
+    constexpr int XNU = W * H16, XNL = (XNU + 255) / 256;                            // 16-byte units of a row; per lane
+    auto xch_rsrc = [&](int l, int slot) -> __amdgpu_buffer_rsrc_t {                  // one row as a buffer: accesses past its end are dropped
+        return __builtin_amdgcn_make_buffer_rsrc(p.xh + ((size_t)l * p.B * p.nrb + slot) * G::xrow_bytes(), 0, (int)G::xrow_bytes(), 0x00020000);
     };
-    // the announcement of the block above, requested ahead of the K loop whose epilogue exports a row
-    auto xch_peek = [&]() -> unsigned {
-        if constexpr (!XCH) return 0u;
-        return rbk > 0 ? __hip_atomic_load(p.xwho + (xslot - 1), __ATOMIC_RELAXED, XSCOPE) : 0u;
-    };
-    auto xch_l2 = [&](unsigned who) -> bool {
-        if constexpr (!XCH) return false;
-        return !(p.xknob & 4u) && who == ((xepoch << 8) | 0x80u | xcc);
-    };
-    auto xch_publish = [&](int l, bool through_l2) {   // at the end of the layer's epilogue: every wave announces its own stores of the row
+    // after the barrier behind hidden layer l's epilogue: row 0 of its region -> the row buffer of this block
+    auto xch_export = [&](int l, int reg) {
         if constexpr (XCH) {
-            if (rbk > 0 && !((p.xknob & 8u) && b == 0 && rbk == p.nrb - 1 && l == 0)) {        // (test knob 8: one row is never published)
-                if (l == 0) IAF_FSTAMP(22);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                              // this wave's row stores have been acknowledged
-                if (l == 0) IAF_FSTAMP(23);
-                unsigned* f = p.xflag + 32 * ((size_t)l * p.B * p.nrb + xslot) + wave;
-                const unsigned v = (xepoch << 2) | (through_l2 ? 2u : 1u);
-                if (lane == 0) {
-                    if (through_l2) __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    else __hip_atomic_store(f, v, __ATOMIC_RELAXED, XSCOPE);
-                }
+            if (rbk > 0 && !((p.xknob & 8u) && b == 0 && rbk == p.nrb - 1 && l == 0)) {      // (test knob 8: one row is never handed over)
+                const __amdgpu_buffer_rsrc_t r = xch_rsrc(l, xslot);
+                const f32x4* src = smem4 + reg + H16;                                 // row 0, slots 1 .. W
+                f32x4 t[XNL];
+#pragma unroll
+                for (int u = 0; u < XNL; ++u) { const int i = tid + 256 * u; t[u] = src[i < XNU ? i : XNU - 1]; }
+#pragma unroll
+                for (int u = 0; u < XNL; ++u)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t[u]), r, 16 * (tid + 256 * u), 0, XSC1);
+                if (l == 0) { IAF_FSTAMP(27); if (p.dbg && tid == 0) p.dbg[(size_t)blockIdx.x * 32 + 26] = (unsigned long long)xslot + 1; }
             }
         }
     };
     auto xch_import = [&](int l, int reg) {  // row R of the region <- row 0 of the block below (zeros past the image), then a barrier
         if constexpr (XCH) {
-            unsigned long long* dst = (unsigned long long*)(smem4 + reg + (R * RS + 1) * H16);
-            constexpr int NU = W * H16 * 2;                                          // 8-byte units
+            f32x4* dst = smem4 + reg + (R * RS + 1) * H16;
             if (r0 + R < H) {
-                const unsigned long long* fl = (const unsigned long long*)(p.xflag + 32 * ((size_t)l * p.B * p.nrb + xslot + 1));
-                // every wave polls for itself: all four waves below have published, in this launch
-                const unsigned want = xepoch & 0x3fffffffu;
-                auto ready = [&](unsigned long long w) -> bool {
-                    const unsigned lo = (unsigned)w, hi = (unsigned)(w >> 32);
-                    return (lo >> 2) == want && (hi >> 2) == want && (lo & 3u) && (hi & 3u);
-                };
+                const __amdgpu_buffer_rsrc_t r = xch_rsrc(l, xslot + 1);
+                u32x4 t[XNL];
+                unsigned pad = 0;                                                    // units nobody's epilogue writes: the two 16-byte units of slot padding
+#pragma unroll
+                for (int u = 0; u < XNL; ++u) {
+                    const int i = tid + 256 * u;
+                    if (i >= XNU || (i % H16) >= 3 * H8) pad |= 1u << u;
+                }
                 const int tmo = (p.xknob & 8u) ? (1 << 12) : (1 << 22);              // a bounded wait: a lost neighbour must not hang the GPU
                 int it = xdead ? tmo : 0;
-                while (it < tmo && !(ready(__hip_atomic_load(fl, __ATOMIC_RELAXED, XSCOPE)) && ready(__hip_atomic_load(fl + 1, __ATOMIC_RELAXED, XSCOPE)))) {
-                    __builtin_amdgcn_s_sleep(1);
+                while (it < tmo) {
+                    bool ok = true;
+#pragma unroll
+                    for (int u = 0; u < XNL; ++u) t[u] = __builtin_amdgcn_raw_buffer_load_b128(r, 16 * (tid + 256 * u), 0, XSC1);
+#pragma unroll
+                    for (int u = 0; u < XNL; ++u)
+                        ok = ok && (((pad >> u) & 1u) || (t[u][0] != XSENT && t[u][1] != XSENT && t[u][2] != XSENT && t[u][3] != XSENT));
+                    if (__all(ok)) break;
+                    __builtin_amdgcn_s_sleep(2);
                     ++it;
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 if (l == 0) IAF_FSTAMP(16); else if (l == DEPTH - 1) IAF_FSTAMP(19);
-                const unsigned long long* src = (const unsigned long long*)(p.xh + ((size_t)l * p.B * p.nrb + xslot + 1) * G::xrow_bytes());
-                unsigned long long t[(NU + 255) / 256];
-                if (it < tmo) {
+                if (p.dbg && tid == 0) { p.dbg[(size_t)blockIdx.x * 32 + (l == 0 ? 24 : 25)] = (unsigned long long)it + 1; p.dbg[(size_t)blockIdx.x * 32 + 26] = (unsigned long long)xslot + 1; }
+                if (it < tmo) {                                                      // taken: the buffer is all XSENT again for the next launch
 #pragma unroll
-                    for (int u = 0; u < (NU + 255) / 256; ++u) {
-                        const int i = tid + 256 * u;
-                        t[u] = __hip_atomic_load(src + (i < NU ? i : NU - 1), __ATOMIC_RELAXED, XSCOPE);
-                    }
-                } else {                                                             // gave up (or the buffers are marked dead): NaN, loudly
+                    for (int u = 0; u < XNL; ++u)
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{XSENT, XSENT, XSENT, XSENT}, r, 16 * (tid + 256 * u), 0, XSC1);
+                } else {                                                             // gave up (or the buffer is marked dead): NaN, loudly
 #pragma unroll
-                    for (int u = 0; u < (NU + 255) / 256; ++u) t[u] = 0x7fc07fc07fc07fc0ull;
+                    for (int u = 0; u < XNL; ++u) t[u] = u32x4{0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u};
                     if (lane == 0 && !xdead) {
                         if (p.xerr) __hip_atomic_store(p.xerr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         __hip_atomic_store(p.xctl + 272, 1ull, __ATOMIC_RELAXED, XSCOPE);
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < (NU + 255) / 256; ++u) { const int i = tid + 256 * u; if (i < NU) dst[i] = t[u]; }
+                for (int u = 0; u < XNL; ++u) { const int i = tid + 256 * u; if (i < XNU) dst[i] = __builtin_bit_cast(f32x4, t[u]); }
                 if (l == 0) IAF_FSTAMP(17); else if (l == DEPTH - 1) IAF_FSTAMP(20);
                 __syncthreads();
             } else {
-                for (int i = tid; i < NU; i += 256) dst[i] = 0ull;
+                for (int i = tid; i < XNU; i += 256) dst[i] = f32x4{0.f, 0.f, 0.f, 0.f};
                 __syncthreads();
             }
         }
@@ -840,20 +805,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     };
     // every wave group runs its own instantiation of a hidden phase (the left-over tile's pixel tiles are compile time)
-    bool xl2 = false;                                            // XCH: the hand-over path of the row the current layer exports
     static_for<GN>([&](auto g_c) {
         constexpr int GI = decltype(g_c)::value;
         if (xg != GI) return;
         constexpr int EM0 = (NX == 0 || !XSPLIT) ? (1 << NPT0) - 1 : fused_extra_mask(NPT0, GN, GI);
         f32x4 acc0[NPT0][NTWH], bi0[NTWH];
         load_bias(p.bias[0], bi0);
-        const unsigned who = xch_peek();
         conv_phase(std::integral_constant<int, RD0>{}, std::integral_constant<int, NPT0>{}, std::integral_constant<int, NTWH>{},
                    std::integral_constant<int, G::rows_h(0)>{}, std::integral_constant<int, EM0>{}, G::ZREG, Z16, Z8, wb0, NHT, htile,
                    wr0, acc0, PartL0{}, g_c, SET);
         IAF_FSTAMP(6);
         xch_next_epoch_a();
-        xl2 = xch_l2(who);
         store_ctx();
         if constexpr (DEPTH == 1) load_final_operands();
         preload_after(std::integral_constant<int, 0>{});
@@ -861,12 +823,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         __syncthreads();                                         // (every wave runs exactly one of the GN instantiations)
         IAF_FSTAMP(11);
         hidden_epilogue(std::integral_constant<int, NPT0>{}, std::integral_constant<int, G::rows_h(0)>{},
-                        std::integral_constant<int, EM0>{}, std::integral_constant<int, 1>{}, acc0, bi0, G::HREG0, p.hsave[0], p.border[0],
-                        xch_row(0), xl2);
+                        std::integral_constant<int, EM0>{}, std::integral_constant<int, 1>{}, acc0, bi0, G::HREG0, p.hsave[0], p.border[0]);
     });
-    xch_publish(0, xl2);
     __syncthreads();
     IAF_FSTAMP(2);
+    xch_export(0, G::HREG0);
     static_for<DEPTH - 1>([&](auto lm_c) {
         constexpr int l = decltype(lm_c)::value + 1;              // hidden layer l reads h_{l-1}, writes h_l into the other region
         constexpr int IN_REG = ((l - 1) & 1) ? G::HREG1 : G::HREG0, OUT_REG = (l & 1) ? G::HREG1 : G::HREG0;
@@ -884,8 +845,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             constexpr int EML = (NX == 0 || !XSPLIT) ? (1 << NPTL) - 1 : fused_extra_mask(NPTL, GN, GI);
             f32x4 accl[NPTL][NTWH], bil[NTWH];
             load_bias(p.bias[l], bil);
-            const unsigned who = xch_peek();
-            const f32x4* wbl = (const f32x4*)p.wp3[l];
+                const f32x4* wbl = (const f32x4*)p.wp3[l];
             conv_phase(std::integral_constant<int, RDH>{}, std::integral_constant<int, NPTL>{}, std::integral_constant<int, NTWH>{},
                        std::integral_constant<int, G::rows_h(l)>{}, std::integral_constant<int, EML>{}, IN_REG, H16, H8, wbl, NHT, htile,
                        (l & 1) ? wr1 : wr0, accl, PartH1{}, g_c, SET);
@@ -903,15 +863,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
             if constexpr (l == 1) IAF_FSTAMP(7);
             if constexpr (l == DEPTH - 1) load_final_operands();
-            xl2 = xch_l2(who);
-            preload_after(std::integral_constant<int, l>{});
+                preload_after(std::integral_constant<int, l>{});
             hidden_epilogue(std::integral_constant<int, NPTL>{}, std::integral_constant<int, G::rows_h(l)>{},
-                            std::integral_constant<int, EML>{}, std::integral_constant<int, 0>{}, accl, bil, OUT_REG, p.hsave[l], p.border[l],
-                            xch_row(l), xl2);
+                            std::integral_constant<int, EML>{}, std::integral_constant<int, 0>{}, accl, bil, OUT_REG, p.hsave[l], p.border[l]);
             if constexpr (l == 1) IAF_FSTAMP(12);
         });
-        xch_publish(l, xl2);
         __syncthreads();
+        xch_export(l, OUT_REG);
     });
     IAF_FSTAMP(3);
 

@@ -27,14 +27,12 @@ struct StepP {
     // one instead of the two (row sums over the KL tensor + finish) of round 2.  NULL: no partial sums are written.
     float* kl_part;
     // XCH kernels (halo rows exchanged between the row blocks of an image instead of recomputed; iaf_step_fused.hpp "XCH"):
-    char* xh;                      // rows [layer][B * nrb][xrow bytes]
-    unsigned* xflag;               // [layer][B * nrb][32 words]: words 0-3 = (epoch << 2) | path, one per publishing wave
-    unsigned long long* xctl;      // [32 y] head of work list y (epoch << 32 | tickets taken), [32 y + 16] its arrivals, [256] lists complete,
-                                   // [272] sticky error -- a 128-byte line each (512 words in all)
-    unsigned* xwho;                // [B * nrb]: (epoch << 8) | 0x80 | XCD of the workgroup that holds the item
+    char* xh;                      // rows [layer][B * nrb][xrow bytes]; every 8-byte piece = 0xff..ff between launches (the data is the flag)
+    unsigned long long* xctl;      // [32 y] head of work list y (tickets taken), [32 y + 16] its arrivals, [256] lists complete,
+                                   // [272] sticky error -- a 128-byte line each (512 words in all); zero between launches
     unsigned* xerr;                // host-visible error word (mapped pinned memory), or NULL
-    unsigned xknob;                // test knobs: 1 lists ignore the placement, 2 tickets out of dispatch order, 4 never through L2,
-                                   // 8 fault injection (image 0's bottom block never publishes its first row; short waits)
+    unsigned xknob;                // test knobs: 1 lists ignore the placement, 2 tickets out of dispatch order,
+                                   // 8 fault injection (image 0's bottom block never hands over its first row; short waits)
 };
 
 typedef void (*step_fn_t)(StepP);

@@ -294,14 +294,8 @@ class ARStack(object):
 
     def set_halo_exchange_debug(self, knobs=0):
         """test knobs of the exchange (include/iaf_hip.h: 1 lists ignore the placement, 2 tickets out of dispatch order,
-        4 never through L2, 8 fault injection); 0 = production"""
+        8 fault injection); 0 = production"""
         _capi.check(_capi.lib().iaf_stack_set_halo_exchange_debug(self._h, int(knobs)))
-
-    def exchange_paths(self):
-        """(through an XCD's L2, through memory): how the rows of the most recent exchanging launch travelled (flag words)"""
-        a, b = ctypes.c_uint(0), ctypes.c_uint(0)
-        _capi.check(_capi.lib().iaf_stack_exchange_paths(self._h, ctypes.byref(a), ctypes.byref(b)))
-        return int(a.value), int(b.value)
 
     def step_exchanges(self, B, H, W):
         """True if the one-launch step at this size hands halo rows between its row blocks instead of recomputing them"""

@@ -302,36 +302,35 @@ int iaf_stack_step_is_fused(const iaf_stack_t* s, int B, int H, int W);
  * operator) does not recompute the rows its row blocks share: the block below hands its first hidden rows to the block above
  * through device memory, inside the launch.
  *   Order.  HIP promises no dispatch order, so the kernel makes its own: a workgroup takes a ticket from one of eight work lists
- *   (its XCD's first) whose items are dealt out bottom row block first, and so only ever waits for the holder of a LOWER ticket --
- *   a workgroup that is already running.  Results do not depend on dispatch order, timing or workgroup -> XCD placement; where
- *   the two blocks of a hand-over are SEEN to run on one XCD (announced by the consumer, checked by the producer, both in that
- *   launch) the row goes through that XCD's L2, otherwise through memory with agent-scope accesses.
- *   State.  Rows, flag lines, list heads and announcements live in a set of buffers the stack owns PER STREAM (allocated on a
- *   stream's first such launch outside a stream capture -- inside one, the recomputing kernel runs until they exist), tagged with
- *   a launch epoch instead of being cleared: calls on different streams are independent.  A stream capture allocates nothing: it
- *   uses its stream's set if a warm-up launch on that stream created one, else the stack's newest set that is large enough (the
- *   graph must then not be replayed concurrently with launches of this stack on the stream that set belongs to), else the
+ *   (its XCD's first: eight heads are cheap to pull, one is not) whose items are dealt out bottom row block first, and so only
+ *   ever waits for the holder of a LOWER ticket -- a workgroup that is already running.  Results do not depend on dispatch
+ *   order, timing or workgroup -> XCD placement.
+ *   Hand-over.  The data is the flag: between launches every 8-byte piece of the row buffer holds a "not there yet" pattern (a
+ *   bf16 NaN payload no arithmetic produces); the producer stores its row with agent-scope (write-through) 8-byte stores, the
+ *   consumer reads the row with agent-scope loads until no piece shows the pattern, and puts the pattern back.
+ *   State.  Rows and list heads live in a set of buffers the stack owns PER STREAM (allocated on a stream's first such launch
+ *   outside a stream capture): calls on different streams are independent.  A stream capture allocates nothing: it uses its
+ *   stream's set if a warm-up launch on that stream created one, else the stack's newest set that is large enough (the graph
+ *   must then not be replayed concurrently with launches of this stack on the stream that set belongs to), else the
  *   recomputing kernel.
  *   Failure.  Every wait is bounded (seconds).  A wait that gives up fills the rows it waited for with NaN -- the launch's
  *   outputs then carry NaN where they depend on them (numerical failure = NaN for the caller's loop, tf_train.py:283-285) --
- *   and raises the stack's error word; launches already queued on those buffers import NaN without waiting; the NEXT call on
- *   the stack returns IAF_ERR_EXCHANGE once (no synchronisation needed: the word sits in mapped host memory) and the stack goes
- *   on with the recomputing kernels until iaf_stack_set_halo_exchange(s, 1) re-arms the exchange.
+ *   and raises the stack's error word; launches already queued on those buffers import NaN without looking (the buffers can no
+ *   longer be trusted); the NEXT call on the stack returns IAF_ERR_EXCHANGE once (no synchronisation needed: the word sits in
+ *   mapped host memory) and the stack goes on with the recomputing kernels until iaf_stack_set_halo_exchange(s, 1) re-arms
+ *   the exchange.
  * iaf_stack_exchange_errors: *errors = the error word (0 = never gave up; it synchronises the device so that every launch so
  * far is accounted for).  IAF_FUSE_XCH=0 in the environment keeps the recomputing kernel. */
 int iaf_stack_exchange_errors(const iaf_stack_t* s, unsigned* errors);
 /* on = 0: this stack's one-launch step recomputes its halo rows (geometries that exist only in the exchange form run layer by
- * layer then); on = 1 (default): exchange where it applies.  Either way the exchange state starts afresh (error words cleared;
- * synchronises the device). */
+ * layer then); on = 1 (default): exchange where it applies.  Either way the exchange state starts afresh (buffers re-armed,
+ * error words cleared; synchronises the device). */
 int iaf_stack_set_halo_exchange(iaf_stack_t* s, int on);
-/* Test knobs of the exchange (OR of): 1 = work lists chosen by a hash of the workgroup index instead of its XCD (neighbours on
- * arbitrary XCDs), 2 = workgroups delay their ticket by pseudo-random amounts (tickets out of dispatch order), 4 = never through
- * L2, 8 = fault injection: the bottom row block of image 0 never publishes its first hidden row and waits are short, so the
- * block above it gives up.  0 = production. */
+/* Test knobs of the exchange (OR of): 1 = work lists chosen by a hash of the workgroup index instead of its XCD (lists run dry,
+ * workgroups take from other lists), 2 = workgroups delay their ticket by pseudo-random amounts (tickets out of dispatch
+ * order), 8 = fault injection: the bottom row block of image 0 never hands over its first hidden row and waits are short, so
+ * the block above it gives up.  0 = production. */
 int iaf_stack_set_halo_exchange_debug(iaf_stack_t* s, unsigned knobs);
-/* How the rows of the most recent launch on each of the stack's exchange sets travelled: counts of (row, publishing wave) flag
- * words by path (synchronises the device; a measurement aid -- bench.py reports the share that went through an XCD's L2). */
-int iaf_stack_exchange_paths(iaf_stack_t* s, unsigned* through_l2, unsigned* through_memory);
 /* 1 if the step at this size runs as one launch in the halo-exchange form, else 0 */
 int iaf_stack_step_exchanges(const iaf_stack_t* s, int B, int H, int W);
 int iaf_stack_autotune(iaf_stack_t* s, const float* z, const float* context, float* z_new, float* logsd, int B, int H, int W,

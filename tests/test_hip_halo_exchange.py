@@ -6,9 +6,10 @@ workgroup -> XCD placement (MI355X_MICROARCH.md: "placement-independent protocol
    (include/iaf_hip.h, iaf_stack_set_halo_exchange_debug) scramble what the kernel could otherwise have relied on: 1 = the
    list is chosen by a hash of the workgroup index (neighbouring row blocks land on arbitrary XCDs, lists run dry and
    workgroups take from other lists), 2 = every workgroup delays its ticket by a pseudo-random time (tickets out of dispatch
-   order), 4 = no hand-over through an XCD's L2.  Every combination must give the recomputing kernel's numbers, launch
-   after launch with fresh inputs (a stale row of an earlier launch would be an O(1) error), on grids of less than one
-   and of many rounds of the chip.
+   order).  Every combination must give the recomputing kernel's numbers, launch after launch with fresh inputs (a stale
+   row of an earlier launch would be an O(1) error), on grids of less than one and of many rounds of the chip.
+ * hand-over: the data is the flag -- a consumer leaves the "not there yet" pattern behind in every piece it has taken, so the
+   same tests also prove that re-arming is complete (a piece left armed with old data would be taken for new).
  * failure: knob 8 makes one producer skip a row; its consumer's bounded wait gives up, and then NaN must come out, the error
    word must be set, the next call must raise ExchangeError, the stack must carry on with the recomputing kernels and the
    exchange must come back after set_halo_exchange(True)."""
@@ -52,7 +53,7 @@ def _close(a, r, what):
     assert err <= 2e-6 * max(1.0, float(r.abs().max())), (what, err)
 
 
-@pytest.mark.parametrize("knob", [0, 1, 2, 3, 4, 7], ids=lambda k: "knob%d" % k)
+@pytest.mark.parametrize("knob", [0, 1, 2, 3], ids=lambda k: "knob%d" % k)
 @pytest.mark.parametrize("B", [32, 5, 64, 300], ids=lambda b: "B%d" % b)
 def test_results_do_not_depend_on_order_or_placement(amd, B, knob):
     xs, rc = _stacks(amd, 32, [160, 160], 11)
@@ -179,9 +180,8 @@ def test_a_wait_that_gives_up_is_loud_and_the_stack_recovers(amd):
     # imports nothing, and no other image is touched
     assert torch.isnan(zf[0, :, 12:14]).all() and torch.isnan(sf[0, :, 12:14]).all()
     assert torch.isfinite(zf[1:]).all() and torch.isfinite(zf[0, :, 14:]).all()
-    up = zf[0, :, :12].reshape(32, 6, 2, 16)                     # a row block is NaN as a whole or right as a whole
-    for k in range(6):
-        assert torch.isnan(up[:, k]).all() or torch.allclose(up[:, k], zr[0, :, 2 * k:2 * k + 2], atol=1e-5, rtol=0)
+    up, ref = zf[0, :, :12], zr[0, :, :12]                       # every number up there is NaN or right (waves give up one by one)
+    assert bool((torch.isnan(up) | ((up - ref).abs() <= 1e-5)).all())
     _close(zf[1:], zr[1:], "the other images of the faulty launch")
     assert xs.exchange_errors() != 0
     xs.set_halo_exchange_debug(0)

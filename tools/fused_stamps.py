@@ -28,8 +28,8 @@ e0.record()
 for _ in range(a.reps):
     st.iaf_step(z, ctx, out=out)
 e1.record(); torch.cuda.synchronize()
-print("iaf_step %dx%d B=%d knob %d: %.2f us per call (back to back, eager); rows via L2 / memory %s; errors %d" % (
-    a.hw, a.hw, a.batch, a.knob, e0.elapsed_time(e1) / a.reps * 1e3, st.exchange_paths(), st.exchange_errors()))
+print("iaf_step %dx%d B=%d knob %d: %.2f us per call (back to back, eager); errors %d" % (
+    a.hw, a.hw, a.batch, a.knob, e0.elapsed_time(e1) / a.reps * 1e3, st.exchange_errors()))
 buf = torch.zeros(32 * 65536, dtype=torch.int64, device="cuda")
 _capi.check(_capi.lib().iaf_stack_set_debug(st._h, -2, ctypes.c_void_p(buf.data_ptr())))
 st.iaf_step(z, ctx, out=out); torch.cuda.synchronize()
@@ -58,10 +58,22 @@ if (t[:, 14] != 0).any():
 if (t[:, 16] != 0).any():
     k = t[(t[:, 16] != 0) & (t[:, 19] != 0)]
     md = lambda a, b_: np.median(k[:, a] - k[:, b_])
-    print("    import 1 (into the second conv): poll %.0f | loads + LDS stores %.0f | barrier %.0f;  import 2 (output pair): own taps %.0f | poll %.0f | loads + stores %.0f | barrier %.0f | taps below %.0f" % (
+    print("    import 1 (into the second conv): row arrives %.0f | re-arm + LDS stores %.0f | barrier %.0f;  import 2 (output pair): own taps %.0f | row arrives %.0f | re-arm + LDS stores %.0f | barrier %.0f | taps below %.0f" % (
         md(16, 14), md(17, 16), md(15, 17), md(18, 3), md(19, 18), md(20, 19), md(21, 20), md(4, 21)))
-    k = t[t[:, 22] != 0]
-    if len(k): print("    publish of the first row: wait for the stores' acknowledgement %.0f (wave 0, %d exporting WGs)" % (np.median(k[:, 23] - k[:, 22]), len(k)))
+if (t[:, 26] != 0).any():
+    k = t[t[:, 24] != 0]
+    print("    sweeps until the row was complete: import 1 %s, import 2 %s (histogram over WGs: 1, 2, 3, more)" % (
+        [int((k[:, 24] - 1 == n).sum()) for n in (0, 1, 2)] + [int((k[:, 24] - 1 > 2).sum())],
+        [int((k[:, 25] - 1 == n).sum()) for n in (0, 1, 2)] + [int((k[:, 25] - 1 > 2).sum())]))
+    byslot = {int(r[26]) - 1: r for r in t if r[26] != 0}
+    d1, d2, d3 = [], [], []
+    for sl, r in byslot.items():
+        pr = byslot.get(sl + 1)
+        if pr is None or r[14] == 0 or pr[27] == 0: continue
+        d1.append(float(r[14]) - float(pr[27])); d2.append(float(r[16]) - float(pr[27])); d3.append(float(r[0]) - float(pr[0]))
+    if d1:
+        print("    producer's export issued -> consumer starts asking: median %.0f (min %.0f max %.0f) ticks; -> consumer has the row: median %.0f (min %.0f max %.0f); consumer's start - producer's start: median %.0f (min %.0f max %.0f)" % (
+            np.median(d1), min(d1), max(d1), np.median(d2), min(d2), max(d2), np.median(d3), min(d3), max(d3)))
 if (t[:, 6] != 0).all():
     print("    of which: first conv K loop %.0f, its epilogue + barrier %.0f; second conv K loop %.0f, its epilogue + barrier %.0f (wave 0)" % (
         np.median(t[:, 6] - t[:, 1]), np.median(t[:, 2] - t[:, 6]), np.median(t[:, 7] - t[:, 2]), np.median(t[:, 3] - t[:, 7])))
