@@ -82,6 +82,11 @@ SIGNATURES = {
     "iaf_stack_set_fuse_first": (ctypes.c_int, [_vp, ctypes.c_int]),
     "iaf_stack_set_fuse_step": (ctypes.c_int, [_vp, ctypes.c_int]),
     "iaf_stack_set_packs": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "iaf_gaussian_sample_logsd": (ctypes.c_int, [_c_float_p] * 4 + [ctypes.c_size_t, _vp]),
+    "iaf_gaussian_logps_logsd": (ctypes.c_int, [_c_float_p] * 4 + [ctypes.c_size_t, _vp]),
+    "iaf_kl_free_bits_gate": (ctypes.c_int, [_c_float_p] * 4 + [ctypes.c_int] * 3 + [ctypes.c_float, _c_float_p, _vp]),
+    "iaf_up_iaf2_backward_pre": (ctypes.c_int, [_c_float_p] * 6 + [ctypes.c_float] + [_c_float_p] * 4 + [ctypes.c_int] * 4 + [_vp]),
+    "iaf_up_iaf2_backward_post": (ctypes.c_int, [_c_float_p] * 7 + [ctypes.c_int] * 4 + [_vp]),
     "iaf_stack_exchange_errors": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint)]),
     "iaf_stack_step_exchanges": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "iaf_stack_set_halo_exchange": (ctypes.c_int, [_vp, ctypes.c_int]),

@@ -1585,16 +1585,26 @@ extern "C" int iaf_posterior_block_forward(iaf_stack_t* s, const float* qz_mean,
 
 // free bits on given KL elements (tf_train.py:77-85; models.py:455-466): kl_elem [B,C,H,W] -> kl_obj [B], kl_cost [B];
 // scratch: B*C floats
-extern "C" int iaf_kl_free_bits(const float* kl_elem, float* kl_obj, float* kl_cost, int B, int C, int HW, float kl_min,
-                                float* scratch, void* stream) {
+static int kl_free_bits_impl(const float* kl_elem, float* kl_obj, float* kl_cost, float* gate, int B, int C, int HW, float kl_min,
+                             float* scratch, void* stream) {
     if (!kl_elem || !kl_obj || !kl_cost || !scratch) return IAF_ERR_NULL;
     if (B <= 0 || C <= 0 || HW <= 0) return IAF_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     const int rows = B * C;
     hipLaunchKernelGGL(iaf_kl_rowsum_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, kl_elem, scratch, rows, HW);
-    hipLaunchKernelGGL(iaf_kl_finish_kernel, dim3(1), dim3(256), 0, st, (const float*)scratch, kl_obj, kl_cost, B, C, kl_min, (float*)nullptr,
+    hipLaunchKernelGGL(iaf_kl_finish_kernel, dim3(1), dim3(256), 0, st, (const float*)scratch, kl_obj, kl_cost, B, C, kl_min, gate,
                        0, (float*)nullptr);
     return (int)hipGetLastError();
+}
+extern "C" int iaf_kl_free_bits(const float* kl_elem, float* kl_obj, float* kl_cost, int B, int C, int HW, float kl_min,
+                                float* scratch, void* stream) {
+    return kl_free_bits_impl(kl_elem, kl_obj, kl_cost, nullptr, B, C, HW, kl_min, scratch, stream);
+}
+// ... and the per-channel gate of the free bits (1 where mean_b sum_hw kl > kl_min: where max() passes the gradient), [C]
+extern "C" int iaf_kl_free_bits_gate(const float* kl_elem, float* kl_obj, float* kl_cost, float* gate, int B, int C, int HW,
+                                     float kl_min, float* scratch, void* stream) {
+    if (!gate) return IAF_ERR_NULL;
+    return kl_free_bits_impl(kl_elem, kl_obj, kl_cost, gate, B, C, HW, kl_min, scratch, stream);
 }
 
 static dim3 ew_grid(size_t n) {
@@ -1608,7 +1618,15 @@ extern "C" int iaf_gaussian_sample(const float* mean, const float* logvar, const
                                    void* stream) {
     if (!mean || !logvar || !noise || !out) return IAF_ERR_NULL;
     if (n == 0) return IAF_OK;
-    hipLaunchKernelGGL(iaf_gauss_sample_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)stream, mean, logvar, noise, out, n);
+    hipLaunchKernelGGL(iaf_gauss_sample_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)stream, mean, logvar, noise, out, n, 1.0f);
+    return (int)hipGetLastError();
+}
+
+extern "C" int iaf_gaussian_sample_logsd(const float* mean, const float* logsd, const float* noise, float* out, size_t n,
+                                         void* stream) {
+    if (!mean || !logsd || !noise || !out) return IAF_ERR_NULL;
+    if (n == 0) return IAF_OK;
+    hipLaunchKernelGGL(iaf_gauss_sample_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)stream, mean, logsd, noise, out, n, 2.0f);
     return (int)hipGetLastError();
 }
 
@@ -1616,7 +1634,42 @@ extern "C" int iaf_gaussian_logps(const float* mean, const float* logvar, const 
                                   void* stream) {
     if (!mean || !logvar || !sample || !out) return IAF_ERR_NULL;
     if (n == 0) return IAF_OK;
-    hipLaunchKernelGGL(iaf_gauss_logps_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)stream, mean, logvar, sample, out, n);
+    hipLaunchKernelGGL(iaf_gauss_logps_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)stream, mean, logvar, sample, out, n, 1.0f);
+    return (int)hipGetLastError();
+}
+
+extern "C" int iaf_gaussian_logps_logsd(const float* mean, const float* logsd, const float* sample, float* out, size_t n,
+                                        void* stream) {
+    if (!mean || !logsd || !sample || !out) return IAF_ERR_NULL;
+    if (n == 0) return IAF_OK;
+    hipLaunchKernelGGL(iaf_gauss_logps_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)stream, mean, logsd, sample, out, n, 2.0f);
+    return (int)hipGetLastError();
+}
+
+// The elementwise halves of the backward of models.cvae_layer 'up_iaf2_nl' around iaf_step_backward (iaf_kernels_misc.hpp:
+// UpIafBwdP).  gate [n_z] non-NULL: free bits, G = gate[c] * gscale; else G = dko[b].
+extern "C" int iaf_up_iaf2_backward_pre(const float* z, const float* pz_mean, const float* pz_logsd, const float* d_h, const float* d_up,
+                                        const float* gate, float gscale, const float* dko, float* dz_tot, float* G, float* d_down_conv1,
+                                        int B, int n_h, int n_z, int HW, void* stream) {
+    if (!z || !pz_mean || !pz_logsd || !d_h || !dz_tot || !G || !d_down_conv1 || (!gate && !dko)) return IAF_ERR_NULL;
+    if (B <= 0 || n_h <= 0 || n_z <= 0 || HW <= 0) return IAF_ERR_SHAPE;
+    UpIafBwdP p;
+    memset(&p, 0, sizeof(p));
+    p.z = z; p.pz_mean = pz_mean; p.pz_logsd = pz_logsd; p.d_h = d_h; p.d_up = d_up; p.gate = gate; p.dko = dko; p.gscale = gscale;
+    p.dz_tot = dz_tot; p.Gf = G; p.d_dc1 = d_down_conv1; p.B = B; p.n_h = n_h; p.n_z = n_z; p.HW = HW;
+    hipLaunchKernelGGL(iaf_up_iaf2_bwd_pre_kernel, ew_grid((size_t)B * (n_h + 2 * n_z) * HW), dim3(256), 0, (hipStream_t)stream, p);
+    return (int)hipGetLastError();
+}
+
+extern "C" int iaf_up_iaf2_backward_post(const float* dz0, const float* z0, const float* qz_mean, const float* G, const float* dctx,
+                                         const float* d_up, float* d_up_conv1, int B, int n_h, int n_z, int HW, void* stream) {
+    if (!dz0 || !z0 || !qz_mean || !G || !dctx || !d_up_conv1) return IAF_ERR_NULL;
+    if (B <= 0 || n_h <= 0 || n_z <= 0 || HW <= 0) return IAF_ERR_SHAPE;
+    UpIafBwdP p;
+    memset(&p, 0, sizeof(p));
+    p.dz0 = dz0; p.z0 = z0; p.qz_mean = qz_mean; p.Gf = const_cast<float*>(G); p.dctx = dctx; p.d_up = d_up; p.d_uc1 = d_up_conv1;
+    p.B = B; p.n_h = n_h; p.n_z = n_z; p.HW = HW;
+    hipLaunchKernelGGL(iaf_up_iaf2_bwd_post_kernel, ew_grid((size_t)B * (2 * n_h + 2 * n_z) * HW), dim3(256), 0, (hipStream_t)stream, p);
     return (int)hipGetLastError();
 }
 

@@ -128,14 +128,70 @@ __global__ __launch_bounds__(256) void iaf_maxdiff_kernel(const float* __restric
     if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
 }
 
-__global__ void iaf_gauss_sample_kernel(const float* mean, const float* logvar, const float* noise, float* out, size_t n) {
+// lvs: 1 when the second tensor holds log-variances (distributions.py), 2 when it holds log standard deviations (the callers'
+// `2 * logsd`: tf_train.py:56-57, rand.py:81-86 -- exact in fp32, so the bits are those of a separate doubling)
+__global__ void iaf_gauss_sample_kernel(const float* mean, const float* logvar, const float* noise, float* out, size_t n, float lvs) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        out[i] = mean[i] + expf(0.5f * logvar[i]) * noise[i];
+        out[i] = mean[i] + expf(0.5f * (lvs * logvar[i])) * noise[i];
 }
-__global__ void iaf_gauss_logps_kernel(const float* mean, const float* logvar, const float* sample, float* out, size_t n) {
+__global__ void iaf_gauss_logps_kernel(const float* mean, const float* logvar, const float* sample, float* out, size_t n, float lvs) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float d = sample[i] - mean[i];
-        out[i] = -0.5f * (1.8378770664093453f + logvar[i] + d * d / expf(logvar[i]));
+        const float d = sample[i] - mean[i], lv = lvs * logvar[i];
+        out[i] = -0.5f * (1.8378770664093453f + lv + d * d / expf(lv));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward of models.cvae_layer with posterior 'up_iaf2_nl' (models.py:168-176, 201-210, 295-298, 454-466), the elementwise
+// parts on either side of iaf_step_backward.  kl = logq0 + logdet - logp(z);  G = d obj / d kl (free bits: gate[c] * gscale,
+// else dko[b]).
+//   pre:  dz_tot = dz + G (z - pz_mean) exp(-2 pz_logsd) [+ d_up_z]      (the gradient that enters the IAF step: -G dlogp/dz)
+//         Gf = G                                                           (contiguous, the step's d logdet)
+//         d_down_conv1 = [d_hdet | -G dlt e2 | G (1 - dlt^2 e2)]            (models.py:296-297 channel order)
+//   post: d_up_conv1 = [d_up_hdet | dz0 | dz0 (z0 - qz_mean) - G | dctx]    (models.py:141-143; logq0 = -(log 2pi + 2 qz_logsd + eps^2)/2)
+// d_h / d_up are [B, n_h + n_z, HW] (concat([h_det, z]) order, models.py:176,318), d_up may be NULL (zeros).
+// ---------------------------------------------------------------------------------------------
+struct UpIafBwdP {
+    const float *z, *pz_mean, *pz_logsd, *d_h, *d_up, *gate, *dko;
+    float *dz_tot, *Gf, *d_dc1;
+    const float *dz0, *z0, *qz_mean, *dctx;
+    float* d_uc1;
+    float gscale;
+    int B, n_h, n_z, HW;
+};
+__global__ __launch_bounds__(256) void iaf_up_iaf2_bwd_pre_kernel(UpIafBwdP p) {
+    const size_t nh = (size_t)p.n_h * p.HW, nz = (size_t)p.n_z * p.HW, per_in = nh + nz, per_out = nh + 2 * nz;
+    const size_t total = (size_t)p.B * per_out;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / per_out, r = i - b * per_out;
+        if (r < nh) { p.d_dc1[i] = p.d_h[b * per_in + r]; continue; }                    // d h_det passes through
+        const bool second = r >= nh + nz;
+        const size_t e = r - nh - (second ? nz : 0), zi = b * nz + e;                     // element of a [B, n_z, HW] tensor
+        const int c = (int)(e / p.HW);
+        const float G = p.gate ? p.gate[c] * p.gscale : p.dko[b];
+        const float e2 = expf(-2.0f * p.pz_logsd[zi]), dlt = p.z[zi] - p.pz_mean[zi];
+        if (!second) {
+            float t = p.d_h[b * per_in + nh + e] + G * dlt * e2;
+            if (p.d_up) t += p.d_up[b * per_in + nh + e];
+            p.dz_tot[zi] = t;
+            p.Gf[zi] = G;
+            p.d_dc1[i] = -G * dlt * e2;
+        } else {
+            p.d_dc1[i] = G * (1.0f - dlt * dlt * e2);
+        }
+    }
+}
+__global__ __launch_bounds__(256) void iaf_up_iaf2_bwd_post_kernel(UpIafBwdP p) {
+    const size_t nh = (size_t)p.n_h * p.HW, nz = (size_t)p.n_z * p.HW, per_in = nh + nz, per_out = 2 * nh + 2 * nz;
+    const size_t total = (size_t)p.B * per_out;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / per_out, r = i - b * per_out;
+        if (r < nh) p.d_uc1[i] = p.d_up ? p.d_up[b * per_in + r] : 0.f;
+        else if (r < nh + nz) p.d_uc1[i] = p.dz0[b * nz + (r - nh)];
+        else if (r < nh + 2 * nz) {
+            const size_t zi = b * nz + (r - nh - nz);
+            p.d_uc1[i] = p.dz0[zi] * (p.z0[zi] - p.qz_mean[zi]) - p.Gf[zi];
+        } else p.d_uc1[i] = p.dctx[b * nh + (r - nh - 2 * nz)];
     }
 }
 

@@ -23,6 +23,16 @@ def gaussian_diag_logps(mean, logvar, sample=None, noise=None):
     return out
 
 
+def gaussian_diag_logps_logsd(mean, logsd, sample):
+    """gaussian_diag_logps(mean, 2 * logsd, sample) (tf_train.py:56-57, rand.py:85-86) without materialising 2 * logsd"""
+    _check_act(mean, "mean")
+    _check_act(logsd, "logsd", mean.shape)
+    _check_act(sample, "sample", mean.shape)
+    out = torch.empty_like(mean)
+    _capi.check(_capi.lib().iaf_gaussian_logps_logsd(_ptr(mean), _ptr(logsd), _ptr(sample), _ptr(out), mean.numel(), _stream()))
+    return out
+
+
 class DiagonalGaussian(object):
     """distributions.py:13-25."""
 

@@ -36,8 +36,7 @@ class IAFPosterior(object):
 def gaussian_sample(mean, logsd, eps):
     """DiagonalGaussian(mean, 2*logsd).sample with the given noise (distributions.py:21-24; tf_train.py:56,61)"""
     out = torch.empty_like(mean)
-    logvar = logsd * 2.0
-    _capi.check(_capi.lib().iaf_gaussian_sample(_ptr(mean), _ptr(logvar), _ptr(eps), _ptr(out), mean.numel(), _stream()))
+    _capi.check(_capi.lib().iaf_gaussian_sample_logsd(_ptr(mean), _ptr(logsd), _ptr(eps), _ptr(out), mean.numel(), _stream()))
     return out
 
 

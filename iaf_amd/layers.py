@@ -788,13 +788,19 @@ def split(x, split_dim, split_sizes):
     return out
 
 
-def kl_free_bits(kl, kl_min):
-    """[B, C, H, W] KL elements -> (kl_cost [B], kl_obj [B]) (tf_train.py:77-85) with the engine's reduction kernels"""
+def kl_free_bits(kl, kl_min, want_gate=False):
+    """[B, C, H, W] KL elements -> (kl_cost [B], kl_obj [B]) (tf_train.py:77-85) with the engine's reduction kernels;
+    want_gate: also the per-channel gate [C] of the free bits (1 where the batch mean of the channel's KL exceeds kl_min)"""
     _check_act(kl, "kl")
     B, C, H, W = (int(v) for v in kl.shape)
     kl_obj = torch.empty(B, dtype=torch.float32, device=kl.device)
     kl_cost = torch.empty_like(kl_obj)
     scratch = torch.empty(B * C, dtype=torch.float32, device=kl.device)
+    if want_gate:
+        gate = torch.empty(C, dtype=torch.float32, device=kl.device)
+        _capi.check(_capi.lib().iaf_kl_free_bits_gate(_ptr(kl), _ptr(kl_obj), _ptr(kl_cost), _ptr(gate), B, C, H * W, float(kl_min),
+                                                      _ptr(scratch), _stream()))
+        return kl_cost, kl_obj, gate
     _capi.check(_capi.lib().iaf_kl_free_bits(_ptr(kl), _ptr(kl_obj), _ptr(kl_cost), B, C, H * W, float(kl_min), _ptr(scratch),
                                              _stream()))
     return kl_cost, kl_obj

@@ -15,9 +15,9 @@ import ctypes
 import torch
 
 from . import _capi
-from .distributions import gaussian_diag_logps
+from .distributions import gaussian_diag_logps_logsd
 from .iaf_layer import gaussian_sample
-from .layers import ARStack, split, _ptr, _stream
+from .layers import ARStack, kl_free_bits, split, _ptr, _stream
 
 
 class CVAELayerIAF(object):
@@ -54,7 +54,7 @@ class CVAELayerIAF(object):
             if eps is None:
                 raise ValueError("'up_iaf2_nl' samples the posterior in the up pass: pass eps")
             z0 = gaussian_sample(qz_mean, qz_logsd, eps)                                          # rand.py:81-83
-            logq0 = gaussian_diag_logps(qz_mean, qz_logsd * 2.0, z0)                              # rand.py:85-86
+            logq0 = gaussian_diag_logps_logsd(qz_mean, qz_logsd, z0)                              # rand.py:85-86
             z, logdet = (self.stack.iaf_step_train if self.training else self.stack.iaf_step)(z0, context)   # models.py:170-173
             st.update(z=z, logq0=logq0, logdet=logdet, z0=z0, eps=eps)
             out = torch.cat([h_det, z], dim=1)                                                    # :176
@@ -82,11 +82,15 @@ class CVAELayerIAF(object):
         else:
             h_det, pz_mean, pz_logsd = split(h, 1, [n_h, n_z, n_z])
             z = st["z"]                                                                           # :216-217
-            logp = gaussian_diag_logps(pz_mean, pz_logsd * 2.0, z)                                # :298
+            logp = gaussian_diag_logps_logsd(pz_mean, pz_logsd, z)                                # :298
             kl = torch.empty_like(z)
             _capi.check(_capi.lib().iaf_kl_combine(_ptr(st["logq0"]), _ptr(st["logdet"]), _ptr(logp), _ptr(kl), kl.numel(),
                                                    _stream()))
-            kl_sum, kl_obj = kl_reduce(kl, self.kl_min)
+            if self.training and self.kl_min > 0:        # the gate of the free bits is what backward() multiplies with
+                kl_sum, kl_obj, gate = kl_free_bits(kl, self.kl_min, want_gate=True)
+                st["gate"] = gate
+            else:
+                kl_sum, kl_obj = kl_free_bits(kl, self.kl_min)
             st.update(pz_mean=pz_mean, pz_logsd=pz_logsd, kl=kl)
         # TF: kl_obj[b] = sum_c max(mean_b sum_hw kl, kl_min) for every b (tf_train.py:79-82); Theano adds that SCALAR
         # once per layer (models.py:460-461)
@@ -121,28 +125,25 @@ class CVAELayerIAF(object):
             grads = bw["grads"]
         else:
             # kl = logq0 + logdet - logp(z): gate the per-element gradient G as the free bits prescribe, push it through
-            # logp (prior side and z), the IAF step, and the reparametrised sample z0 = qz_mean + exp(qz_logsd) eps
-            if self.kl_min > 0:
-                gate = (st["kl"].sum(dim=(2, 3)).mean(dim=0) > self.kl_min).to(torch.float32)
-                G = (gate * (dko.sum() / B)).view(1, n_z, 1, 1).expand_as(z)
-            else:
-                G = dko.view(B, 1, 1, 1).expand_as(z)
-            e2 = torch.exp(-2.0 * st["pz_logsd"])
-            dlt = z - st["pz_mean"]
-            dz_tot = dz + G * dlt * e2                                       # -G dlogp/dz
-            if d_up is not None:
-                dz_tot = dz_tot + d_up[:, n_h:]
-            dz0, dctx, grads = self.stack.iaf_step_backward(st["z0"], st["context"], z, st["logdet"], dz_tot.contiguous(),
-                                                            G.contiguous(), self._rel)
-            d_qm = dz0                                                       # logq0 = -(log 2pi + 2 qz_logsd + eps^2) / 2
-            d_ql = dz0 * (st["z0"] - st["qz_mean"]) - G
-            d_up_hdet = d_up[:, :n_h] if d_up is not None else torch.zeros_like(d_hdet)
-            d_uc1 = torch.cat([d_up_hdet, d_qm, d_ql, dctx], dim=1)
-            d_dc1 = torch.cat([d_hdet, -G * dlt * e2, G * (1.0 - dlt * dlt * e2)], dim=1)
+            # logp (prior side and z), the IAF step, and the reparametrised sample z0 = qz_mean + exp(qz_logsd) eps -- two
+            # elementwise launches around iaf_step_backward (iaf_up_iaf2_backward_pre / _post); tensors are storage only
+            H, W = int(z.shape[2]), int(z.shape[3])
+            d_h = d_h.contiguous()
+            d_up_c = d_up.contiguous() if d_up is not None else None
+            dz_tot, G = torch.empty_like(z), torch.empty_like(z)
+            d_dc1 = torch.empty(B, n_h + 2 * n_z, H, W, dtype=torch.float32, device=z.device)
+            free_bits = self.kl_min > 0
+            if free_bits and "gate" not in st:
+                raise RuntimeError("backward() with free bits follows down_q() in training mode")
+            gscale = ((1.0 if d_obj is None else float(d_obj)) / B) if free_bits else 0.0
+            _capi.check(_capi.lib().iaf_up_iaf2_backward_pre(
+                _ptr(z), _ptr(st["pz_mean"]), _ptr(st["pz_logsd"]), _ptr(d_h), _ptr(d_up_c), _ptr(st["gate"]) if free_bits else None,
+                gscale, None if free_bits else _ptr(dko), _ptr(dz_tot), _ptr(G), _ptr(d_dc1), B, n_h, n_z, H * W, _stream()))
+            dz0, dctx, grads = self.stack.iaf_step_backward(st["z0"], st["context"], z, st["logdet"], dz_tot, G, self._rel)
+            d_uc1 = torch.empty(B, 2 * n_h + 2 * n_z, H, W, dtype=torch.float32, device=z.device)
+            _capi.check(_capi.lib().iaf_up_iaf2_backward_post(
+                _ptr(dz0), _ptr(st["z0"]), _ptr(st["qz_mean"]), _ptr(G), _ptr(dctx), _ptr(d_up_c), _ptr(d_uc1), B, n_h, n_z, H * W,
+                _stream()))
         return dict(d_up_conv1=d_uc1, d_down_conv1=d_dc1, grads={pre + k: v for k, v in grads.items()})
 
 
-def kl_reduce(kl, kl_min):
-    """[B, C, H, W] KL elements -> (kl_sum [B], kl_obj [B]) with the engine's free-bits reduction kernels"""
-    from .layers import kl_free_bits
-    return kl_free_bits(kl, kl_min)

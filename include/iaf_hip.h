@@ -210,6 +210,9 @@ int iaf_posterior_block_forward(iaf_stack_t* s, const float* qz_mean, const floa
 /* DiagonalGaussian.sample (distributions.py:20-21): out = mean + exp(0.5*logvar)*noise */
 int iaf_gaussian_sample(const float* mean, const float* logvar, const float* noise, float* out, size_t n,
                         void* stream);
+/* ... with a log standard deviation where the reference writes `2 * logsd` in place (tf_train.py:56-57, rand.py:81-86) */
+int iaf_gaussian_sample_logsd(const float* mean, const float* logsd, const float* noise, float* out, size_t n, void* stream);
+int iaf_gaussian_logps_logsd(const float* mean, const float* logsd, const float* sample, float* out, size_t n, void* stream);
 /* gaussian_diag_logps (distributions.py:10) */
 int iaf_gaussian_logps(const float* mean, const float* logvar, const float* sample, float* out, size_t n,
                        void* stream);
@@ -228,6 +231,22 @@ int iaf_kl_free_bits(const float* kl_elem, float* kl_obj, float* kl_cost, int B,
                      void* stream);
 /* kl[i] = logq0[i] + logdet[i] - logp[i] (models.py:175, 298, 328), for posteriors whose three terms come from separate
  * launches ('up_iaf2_nl': IAF step in the bottom-up pass, prior density in the top-down pass) */
+/* iaf_kl_free_bits + the per-channel gate [C] of the free bits: 1 where mean_b sum_hw kl > kl_min (where max() passes the
+ * gradient, tf_train.py:79-80 / models.py:460-461), else 0 */
+int iaf_kl_free_bits_gate(const float* kl_elem, float* kl_obj, float* kl_cost, float* gate, int B, int C, int HW, float kl_min,
+                          float* scratch, void* stream);
+/* The elementwise halves of the backward of the Theano layer's 'up_iaf2_nl' posterior (models.py:168-176, 201-210, 295-298,
+ * 454-466) on either side of iaf_step_backward.  kl = logq0 + logdet - logp(z); G = d obj / d kl = gate[c] * gscale (free bits;
+ * gate from iaf_kl_free_bits_gate) or dko[b] (gate = NULL).  d_h, d_up: [B, n_h + n_z, HW] in concat([h_det, z]) order, d_up
+ * may be NULL (zeros).
+ *   pre:  dz_tot = d_h[z part] + G (z - pz_mean) exp(-2 pz_logsd) [+ d_up[z part]],  G (expanded, [B, n_z, HW]),
+ *         d_down_conv1 [B, n_h + 2 n_z, HW] = [d_h[h_det part] | -G dlt e2 | G (1 - dlt^2 e2)]
+ *   post: d_up_conv1 [B, 2 n_h + 2 n_z, HW] = [d_up[h_det part] | dz0 | dz0 (z0 - qz_mean) - G | dctx] */
+int iaf_up_iaf2_backward_pre(const float* z, const float* pz_mean, const float* pz_logsd, const float* d_h, const float* d_up,
+                             const float* gate, float gscale, const float* dko, float* dz_tot, float* G, float* d_down_conv1,
+                             int B, int n_h, int n_z, int HW, void* stream);
+int iaf_up_iaf2_backward_post(const float* dz0, const float* z0, const float* qz_mean, const float* G, const float* dctx,
+                              const float* d_up, float* d_up_conv1, int B, int n_h, int n_z, int HW, void* stream);
 int iaf_kl_combine(const float* logq0, const float* logdet, const float* logp, float* kl, size_t n, void* stream);
 /* out[j] = sum_i mat[i*n + j], i < m: the running `kl_cost += cur_cost` over a model's layers (tf_train.py:198-200) when
  * every layer wrote its [n] KL costs into one row of a [m, n] matrix */
