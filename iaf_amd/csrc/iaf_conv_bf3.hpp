@@ -8,7 +8,7 @@
 // are accumulated in the fp32 accumulator of v_mfma_f32_16x16x32_bf16: 6 MFMAs of 16 cycles per K = 32 instead of 8 of
 // 32 cycles -- 2.7x the matrix-core throughput.  Products of bf16 pairs are exact in fp32, and the accumulation is fp32
 // like the exact path's, so the result carries fp32-grade error (measured against an fp64 evaluation: not larger than the
-// fp32 MFMA chain's, tests/test_hip_bf3.py and DESIGN.md 4.7).  Masked weights are exactly zero in all three planes, so
+// fp32 MFMA chain's, tests/test_hip_bf3.py and docs/LAB_NOTEBOOK_r01-r03.md 4.7).  Masked weights are exactly zero in all three planes, so
 // the autoregressive structure stays bit-exact.
 //
 // Data flow (differs from the fp32 kernel because the operand rate per MFMA cycle is ~4x higher):

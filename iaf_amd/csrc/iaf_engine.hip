@@ -9,7 +9,7 @@
 //
 // Design (DESIGN.md has the long form).  The MADE mask is exploited as structured sparsity, not
 // as a scan: 4 of the 9 taps are dead and are never touched (the centre tap is block-triangular; its dead
-// 16x16 blocks are stored as zeros and still multiplied -- skipping them is a DESIGN.md "next" item).
+// 16x16 blocks are stored as zeros and still multiplied by the layer-by-layer kernels; the one-launch step skips them).
 // Each masked conv is an implicit GEMM on the exact-fp32 MFMA
 // (v_mfma_f32_16x16x4_f32):  D[co][pixel] += W[co][k] * X[k][pixel],  k = (tap, c_in).
 //   * X tile: pixel-major [slot][c_in (+8 pad)] in LDS, staged once per workgroup with a one-sided
@@ -120,7 +120,7 @@ struct iaf_stack {
     unsigned xch_knob = 0;                // iaf_stack_set_halo_exchange_debug
     int precision = IAF_PRECISION_BF16X3;   // forward convs: bf16x3 split products on the bf16 MFMA, or the exact fp32 MFMA
     int fuse_first = 2;       // first masked conv fused into the second one's kernel: 0 never, 1 whenever possible, 2 only where
-                              // iaf_stack_autotune measured it faster (on MI355X at the BASELINE sizes it is not: DESIGN.md 4.8)
+                              // iaf_stack_autotune measured it faster (on MI355X at the BASELINE sizes it is not: docs/LAB_NOTEBOOK_r01-r03.md 4.8)
     int fuse_step = 1;        // the whole step as ONE launch (iaf_step_fused.hpp): 0 never, 1 where a compiled geometry covers it and
                               // the size rule / autotune's measurement favours it, 2 wherever a compiled geometry covers it
     long long fs_P = -1; int fs_W = 0; bool fs_on = false;   // ... unless iaf_stack_autotune measured this size: then what it found

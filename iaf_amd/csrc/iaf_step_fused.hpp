@@ -3,7 +3,7 @@
 //
 // Why: at BASELINE batch sizes a step is depth_ar + 1 dependent launches of 6-18 us each, every one a latency chain
 // (descriptor fetch, first loads, tile staging, split-K exchange, epilogue, the gap to the next launch) that is longer
-// than its arithmetic.  The masked convs only look right and below -- taps (0,0) (0,1) (1,-1) (1,0) (1,1)
+// than its arithmetic (docs/LAB_NOTEBOOK_r01-r03.md 5).  The masked convs only look right and below -- taps (0,0) (0,1) (1,-1) (1,0) (1,1)
 // -- so a workgroup that owns R full-width output rows of one image needs, per layer down the stack, ONE more row of the
 // layer below and no columns beyond the image: it can compute all layers for its rows by itself, with the hidden
 // activations in LDS and no synchronisation with any other workgroup.  Rows needed (depth_ar = D):
@@ -16,7 +16,7 @@
 // epilogue also stored to a per-stack buffer in device memory (agent-scope accesses: neighbouring workgroups sit on different
 // XCDs; four flag words per row, one per publishing wave; bounded waits; a workgroup only waits for one dispatched before it).  The layer reading the imported
 // row multiplies the taps of its own rows first (StepPart), so most of the row's ~4 us of travel is covered.  See xch_* below
-// and DESIGN.md 4.9 item 7 for what was measured (also: agent-scope fences, an L2-scope variant -- both rejected).
+// and DESIGN.md 4.1 (round 3's measurements: docs/LAB_NOTEBOOK_r01-r03.md 4.9 item 7).
 //
 // Arithmetic: the bf16x3 scheme of iaf_conv_bf3.hpp (three bf16 planes per operand, six products, fp32 accumulate) on
 // v_mfma_f32_16x16x32_bf16, reading the same fragment-ordered weight packs (PrepLayer.wp3).

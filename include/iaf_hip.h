@@ -287,7 +287,7 @@ int iaf_stack_set_tuning_bf3(iaf_stack_t* s, int layer, int nt, int ppw, int pxt
  * output goes straight into that kernel's LDS tile (recomputed on the halo) -- one launch and one HBM round trip less per
  * IAF step.  mode 0 = never, 1 = whenever the kernels allow it, 2 (default) = only where iaf_stack_autotune measured it
  * clearly faster for the problem size (on MI355X at the BASELINE sizes the fused prologue is a latency chain that costs
- * more than the launch it saves, DESIGN.md 4.8, so the default in practice runs separate launches).  TF statement, bf16x3 precision, n_z = 32 only; results equal the unfused
+ * more than the launch it saves, docs/LAB_NOTEBOOK_r01-r03.md 4.8, so the default in practice runs separate launches).  TF statement, bf16x3 precision, n_z = 32 only; results equal the unfused
  * path's bit for bit (the same products in the same order).  In iaf_stack_autotune's report a fused pair shows as
  * chosen[0] = -1 and chosen[1] = the fused kernel's shape. */
 int iaf_stack_set_fuse_first(iaf_stack_t* s, int mode);

@@ -589,7 +589,7 @@ def test_full_size_autoregressive_property(amd, H):
     dz, ds = (z1 != z0), (s1 != s0)
     # no retry: round 1 saw ONE violation in ~700 runs of this test on a development build; the round-2 soak
     # (tools/soak.py: 2 x 20,000 steady iterations with churn + 2 x 1,500 fresh stacks, production and LDS-poisoned
-    # builds, every output compared bit for bit) did not reproduce it, and test_iaf_step_determinism_soak
+    # builds, every output compared bit for bit; docs/LAB_NOTEBOOK_r01-r03.md 2.1) did not reproduce it, and test_iaf_step_determinism_soak
     # below keeps a short version of that soak in every GPU run.
     assert int((dz & ~allowed_z).sum()) == 0
     assert int((ds & ~allowed_s).sum()) == 0
