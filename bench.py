@@ -249,6 +249,46 @@ def cpu_baseline(args, depths):
     }
 
 
+def _exchange_sweep(flat, red, dist, counts=(1, 2, 4, 8, 16), reps=3):
+    """the same flat gradient buffer all-reduced ALONE as 1, 2, 4, ... equal contiguous messages back to back (ms per whole
+    exchange): what bucket size costs on this node's links before any overlap -- read next to `exposed_ms` it says whether a
+    different --ar-buckets would help (xGMI rings are per-link bound: few large messages)"""
+    if not red.active:
+        return None
+    n = flat.grads.numel()
+    one = (lambda t: red.comm.all_reduce_sum_(t)) if red.comm is not None else (lambda t: dist.all_reduce(t))
+    out = {}
+    for c in counts:
+        cuts = [n * i // c for i in range(c + 1)]
+        views = [flat.grads[cuts[i]:cuts[i + 1]] for i in range(c) if cuts[i + 1] > cuts[i]]
+        for v in views:
+            one(v)
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            for v in views:
+                one(v)
+        b.record()
+        b.synchronize()
+        out[str(c)] = a.elapsed_time(b) / reps
+    return out
+
+
+def _exchange_expectation(n_floats, n_gpus):
+    """what the all-reduce should take on one MI355X node, so that a first multi-GPU run can be judged at once: a ring all-reduce
+    moves 2 (N-1)/N of the buffer through every GPU; xGMI is point to point, 7 links x ~153 GB/s per GPU (the task's hardware
+    notes), and RCCL lays its rings over the links it finds"""
+    if n_gpus < 2:
+        return None
+    mb = 4e-6 * n_floats
+    per_gpu_mb = 2.0 * (n_gpus - 1) / n_gpus * mb
+    return {"buffer_mb": mb, "moved_per_gpu_mb": per_gpu_mb,
+            "ms_if_one_link_carries_it": per_gpu_mb / 153.0, "ms_if_seven_links_share_it": per_gpu_mb / (7 * 153.0),
+            "note": "ring all-reduce, 153 GB/s per xGMI link and direction; anything above the one-link figure means the rings are "
+                    "not using the fabric, anything near the seven-link figure is as good as this topology gets"}
+
+
 def _chunks(lst, n):
     n = max(1, min(n, len(lst)))
     return [lst[i * len(lst) // n:(i + 1) * len(lst) // n] for i in range(n)]
@@ -330,6 +370,7 @@ def _run_segmented(args, segments, red, flat, n_gpus, dist):
         b.synchronize()
         compute_ms = a.elapsed_time(b) / reps
         exch_ms = _time_exchange(flat, red, dist)
+        sweep = _exchange_sweep(flat, red, dist)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -342,6 +383,8 @@ def _run_segmented(args, segments, red, flat, n_gpus, dist):
                 "bucket_mb": [4e-6 * (hi - lo) for lo, hi in red.bounds],
                 "alone_ms": exch_ms, "step_without_exchange_ms": compute_ms,
                 "exposed_ms": (step_ms - compute_ms) if red.active else 0.0,
+                "alone_ms_by_message_count": sweep, "expected_on_this_node": _exchange_expectation(flat.grads.numel(), n_gpus),
+                "rccl_ranks": RANK_INFO.get("rccl_ranks"),
                 "overlap": "bucket i is reduced while the backward segments i+1.. run (issued behind its segment's graph)"}
     return elapsed, graphs is not None, exchange
 
