@@ -1187,7 +1187,7 @@ static int launch_fused_step(iaf_stack_t* s, step_fn_t fn, int R, size_t lds, co
     { int rc = raise_lds_cap((const void*)fn, lds); if (rc) return rc; }
     const bool prof = (s->prof_layer == -2 && s->prof_n < s->prof_cap);
     if (prof) HIP_TRY(hipEventRecord(s->prof_start[s->prof_n], st));
-    hipLaunchKernelGGL(fn, dim3(base.B * q.nrb), dim3(256), lds, st, q);
+    hipLaunchKernelGGL(fn, dim3(base.B * q.nrb), dim3(q.xh ? 512 : 256), lds, st, q);      // (exchange form: four helper waves own the hand-overs)
     if (prof) { HIP_TRY(hipEventRecord(s->prof_stop[s->prof_n], st)); s->prof_n++; }
     return (int)hipGetLastError();
 }

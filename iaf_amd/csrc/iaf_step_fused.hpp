@@ -45,6 +45,9 @@
 #pragma once
 #include "iaf_conv_bf3.hpp"
 #include "iaf_step_fused_types.hpp"
+#ifndef IAF_HELPER_PRIO
+#define IAF_HELPER_PRIO 0
+#endif
 
 // XCH = 1: neighbouring row blocks EXCHANGE their halo rows instead of recomputing them (see the kernel's header note): a
 // hidden layer computes only the R rows its workgroup owns, its region holds one more row -- the first row of the block
@@ -135,7 +138,7 @@ constexpr int tri_live(int ntw, int nfull, int nht, int c, int gn, int gi) {
 // flipmask=True (TF geometry + border channel).  Compile time: as run-time flags these cost the TF path ~1 us per launch
 // (branches around the border loads split the epilogue's basic blocks).
 template <int NHT, int NZT, int DEPTH, int W, int R, int VAR = 0, int XCH = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void iaf_step_fused_kernel(StepP p) {
+__global__ __launch_bounds__(XCH ? 512 : 256) __attribute__((amdgpu_waves_per_eu(XCH ? 2 : 1, XCH ? 2 : 1))) void iaf_step_fused_kernel(StepP p) {
     typedef StepGeom<NHT, NZT, DEPTH, W, R, XCH> G;
     // exchanged rows and flags: AGENT scope (sc1: coherent across the XCDs, served by the memory side)
     constexpr int XSCOPE = __HIP_MEMORY_SCOPE_AGENT;
@@ -145,9 +148,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     extern __shared__ __attribute__((aligned(16))) f32x4 smem4[];
     char* smem = (char*)smem4;
     constexpr int NZ = G::NZ, NH = G::NH, RS = G::RS, Z8 = G::Z8, Z16 = G::Z16, H8 = G::H8, H16 = G::H16, RZ = G::RZ;
-    constexpr int NW = 4;                                        // waves
+    constexpr int NW = 4, NW_COMPUTE = 4;                        // (compute) waves
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // XCH: four more waves, the HELPERS, one beside every compute wave (hence 256 registers per wave: two per SIMD).  They own the
+    // workgroup's long-latency traffic -- the rows handed over between row blocks and the context rows of the first epilogue
+    // (the helper section below) -- in vector-memory queues of their own: a compute wave's queue returns in order and feeds its K
+    // loop, so a 1 us agent-scope load in it stalls its MFMAs (round 4, four waves: 8 k of 51.6 k cycles per workgroup were
+    // imports).  One helper wave for all of it was too slow (16 KiB of sc1 loads from ONE wave: 6 k cycles; from four: 2.2 k).
+    const bool is_helper = XCH && wave >= NW_COMPUTE;
+    const int htid = tid - 64 * NW_COMPUTE;                      // helpers: 0 .. 255
     const int pl = lane & 15, kk = lane >> 4;
     // Which (image b, row block rbk) this workgroup computes.  Recomputing kernels: blockIdx, statically -- no workgroup depends on
     // another.  XCH: a workgroup waits for the rows of the block BELOW it, and HIP promises no dispatch order, so the order is one
@@ -444,15 +454,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     if constexpr (XCH) {
         xch_take_begin();
-        preload_w0();
-        zero_cols();
+        if (!is_helper) {
+            preload_w0();
+            zero_cols();
+        }
         xch_take_finish();
-        load_z();
-        __builtin_amdgcn_sched_barrier(0);
-        load_ctx();
-        __builtin_amdgcn_sched_barrier(0);
-        IAF_FSTAMP(8);
-        stage_z();
+        if (!is_helper) {
+            load_z();
+            __builtin_amdgcn_sched_barrier(0);
+            IAF_FSTAMP(8);
+            stage_z();                                           // (the context rows: the helper stages them during the first conv)
+        }
     } else {
         load_z();
         __builtin_amdgcn_sched_barrier(0);
@@ -704,73 +716,140 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     constexpr int XSC1 = 16;                                                         // aux bits of the buffer instructions: sc1
     constexpr int XNU = W * H16, XNL = (XNU + 255) / 256;                            // 16-byte units of a row; per lane
     auto xch_rsrc = [&](int l, int slot) -> __amdgpu_buffer_rsrc_t {                  // one row as a buffer: accesses past its end are dropped
-        return __builtin_amdgcn_make_buffer_rsrc(p.xh + ((size_t)l * p.B * p.nrb + slot) * G::xrow_bytes(), 0, (int)G::xrow_bytes(), 0x00020000);
+        // (the base through readfirstlane: the descriptor must be SEEN to be wave-uniform, or every access is wrapped in a
+        // readfirstlane / exec-mask "waterfall" loop -- cdna_hip_programming.md T20)
+        const unsigned long long a = (unsigned long long)(p.xh + ((size_t)l * p.B * p.nrb + slot) * G::xrow_bytes());
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, (int)G::xrow_bytes(), 0x00020000);
     };
-    // after the barrier behind hidden layer l's epilogue: row 0 of its region -> the row buffer of this block
+    // Both run in the four HELPER waves (units htid + 256 u).
+    constexpr int XNLH = (XNU + 255) / 256;
+    // behind the barrier after hidden layer l's epilogue: row 0 of its region -> the row buffer of this block
     auto xch_export = [&](int l, int reg) {
         if constexpr (XCH) {
             if (rbk > 0 && !((p.xknob & 8u) && b == 0 && rbk == p.nrb - 1 && l == 0)) {      // (test knob 8: one row is never handed over)
                 const __amdgpu_buffer_rsrc_t r = xch_rsrc(l, xslot);
                 const f32x4* src = smem4 + reg + H16;                                 // row 0, slots 1 .. W
-                f32x4 t[XNL];
+                f32x4 t[XNLH];
 #pragma unroll
-                for (int u = 0; u < XNL; ++u) { const int i = tid + 256 * u; t[u] = src[i < XNU ? i : XNU - 1]; }
+                for (int u = 0; u < XNLH; ++u) { const int i = htid + 256 * u; t[u] = src[i < XNU ? i : XNU - 1]; }
 #pragma unroll
-                for (int u = 0; u < XNL; ++u)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t[u]), r, 16 * (tid + 256 * u), 0, XSC1);
-                if (l == 0) { IAF_FSTAMP(27); if (p.dbg && tid == 0) p.dbg[(size_t)blockIdx.x * 32 + 26] = (unsigned long long)xslot + 1; }
+                for (int u = 0; u < XNLH; ++u)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t[u]), r, 16 * (htid + 256 * u), 0, XSC1);
+                if (l == 0 && p.dbg && htid == 0) {
+                    p.dbg[(size_t)blockIdx.x * 32 + 27] = __builtin_readcyclecounter();
+                    p.dbg[(size_t)blockIdx.x * 32 + 26] = (unsigned long long)xslot + 1;
+                }
             }
         }
     };
-    auto xch_import = [&](int l, int reg) {  // row R of the region <- row 0 of the block below (zeros past the image), then a barrier
+    // row R of the region <- row 0 of the block below (zeros past the image); the compute waves meet it at their next barrier
+    auto xch_import = [&](int l, int reg) {
         if constexpr (XCH) {
             f32x4* dst = smem4 + reg + (R * RS + 1) * H16;
             if (r0 + R < H) {
                 const __amdgpu_buffer_rsrc_t r = xch_rsrc(l, xslot + 1);
-                u32x4 t[XNL];
+                u32x4 t[XNLH];
                 unsigned pad = 0;                                                    // units nobody's epilogue writes: the two 16-byte units of slot padding
 #pragma unroll
-                for (int u = 0; u < XNL; ++u) {
-                    const int i = tid + 256 * u;
+                for (int u = 0; u < XNLH; ++u) {
+                    const int i = htid + 256 * u;
                     if (i >= XNU || (i % H16) >= 3 * H8) pad |= 1u << u;
                 }
-                const int tmo = (p.xknob & 8u) ? (1 << 12) : (1 << 22);              // a bounded wait: a lost neighbour must not hang the GPU
+                const int tmo = (p.xknob & 8u) ? (1 << 10) : (1 << 20);              // a bounded wait: a lost neighbour must not hang the GPU
                 int it = xdead ? tmo : 0;
+                if (p.dbg && htid == 0) p.dbg[(size_t)blockIdx.x * 32 + (l == 0 ? 14 : 18)] = __builtin_readcyclecounter();
                 while (it < tmo) {
                     bool ok = true;
 #pragma unroll
-                    for (int u = 0; u < XNL; ++u) t[u] = __builtin_amdgcn_raw_buffer_load_b128(r, 16 * (tid + 256 * u), 0, XSC1);
+                    for (int u = 0; u < XNLH; ++u) t[u] = __builtin_amdgcn_raw_buffer_load_b128(r, 16 * (htid + 256 * u), 0, XSC1);
 #pragma unroll
-                    for (int u = 0; u < XNL; ++u)
+                    for (int u = 0; u < XNLH; ++u)
                         ok = ok && (((pad >> u) & 1u) || (t[u][0] != XSENT && t[u][1] != XSENT && t[u][2] != XSENT && t[u][3] != XSENT));
                     if (__all(ok)) break;
-                    __builtin_amdgcn_s_sleep(2);
+                    __builtin_amdgcn_s_sleep(8);                                     // (the row is not there yet: it is the only thing this wave waits for)
                     ++it;
                 }
-                if (l == 0) IAF_FSTAMP(16); else if (l == DEPTH - 1) IAF_FSTAMP(19);
-                if (p.dbg && tid == 0) { p.dbg[(size_t)blockIdx.x * 32 + (l == 0 ? 24 : 25)] = (unsigned long long)it + 1; p.dbg[(size_t)blockIdx.x * 32 + 26] = (unsigned long long)xslot + 1; }
+                if (p.dbg && htid == 0) {
+                    p.dbg[(size_t)blockIdx.x * 32 + (l == 0 ? 16 : 19)] = __builtin_readcyclecounter();
+                    p.dbg[(size_t)blockIdx.x * 32 + (l == 0 ? 24 : 25)] = (unsigned long long)it + 1;
+                    p.dbg[(size_t)blockIdx.x * 32 + 26] = (unsigned long long)xslot + 1;
+                }
                 if (it < tmo) {                                                      // taken: the buffer is all XSENT again for the next launch
 #pragma unroll
-                    for (int u = 0; u < XNL; ++u)
-                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{XSENT, XSENT, XSENT, XSENT}, r, 16 * (tid + 256 * u), 0, XSC1);
+                    for (int u = 0; u < XNLH; ++u)
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{XSENT, XSENT, XSENT, XSENT}, r, 16 * (htid + 256 * u), 0, XSC1);
                 } else {                                                             // gave up (or the buffer is marked dead): NaN, loudly
 #pragma unroll
-                    for (int u = 0; u < XNL; ++u) t[u] = u32x4{0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u};
+                    for (int u = 0; u < XNLH; ++u) t[u] = u32x4{0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u};
                     if (lane == 0 && !xdead) {
                         if (p.xerr) __hip_atomic_store(p.xerr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         __hip_atomic_store(p.xctl + 272, 1ull, __ATOMIC_RELAXED, XSCOPE);
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < XNL; ++u) { const int i = tid + 256 * u; if (i < XNU) dst[i] = __builtin_bit_cast(f32x4, t[u]); }
-                if (l == 0) IAF_FSTAMP(17); else if (l == DEPTH - 1) IAF_FSTAMP(20);
-                __syncthreads();
+                for (int u = 0; u < XNLH; ++u) { const int i = htid + 256 * u; if (i < XNU) dst[i] = __builtin_bit_cast(f32x4, t[u]); }
+                if (p.dbg && htid == 0) p.dbg[(size_t)blockIdx.x * 32 + (l == 0 ? 17 : 20)] = __builtin_readcyclecounter();
             } else {
-                for (int i = tid; i < XNU; i += 256) dst[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                __syncthreads();
+                for (int i = htid; i < XNU; i += 256) dst[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
     };
+    // The helper's whole life: one barrier for each of the compute waves' (same order, same count -- s_barrier counts waves),
+    // its traffic in between.  Behind the barrier that ends layer l's epilogue it sends row 0 of that layer to the block above and
+    // starts asking for the row below: the row is in LDS by the time the compute waves have multiplied the taps of their own rows
+    // and arrive at the barrier in front of the taps that read it.
+    if constexpr (XCH) {
+        if (is_helper) {
+            __builtin_amdgcn_s_setprio(IAF_HELPER_PRIO);          // (0: they take the issue slots the compute wave of their SIMD leaves)
+            {   // the context rows of the first epilogue, summed and staged [channel][pixel] (what load_ctx + store_ctx do in the
+                // recomputing kernels, where they hold 40-80 registers of every compute wave across the first conv)
+                constexpr int NCIH = (NCIT + 255) / 256;
+                float* creg = (float*)(smem + (size_t)G::CTX_OFF * 16);
+                const int vpx = (H - r0) * W < CPX ? (H - r0) * W : CPX;
+                f32x4 v[NCIH], v2[NCIH];
+                unsigned cval = 0;
+#pragma unroll
+                for (int u = 0; u < NCIH; ++u) {
+                    const int idx = htid + 256 * u, ic = idx < NCIT ? idx : NCIT - 1;
+                    const int c = ic / CG, g4 = (ic - c * CG) * 4;
+                    const bool inside = g4 < vpx;
+                    const int g4c = inside ? g4 : 0, row = g4c / W, col4 = g4c - row * W;
+                    const unsigned gi = 4u * (unsigned)(c * HW + gpix(r0 + row, col4 + (FLIP ? 3 : 0)));
+                    v[u] = ldf4(p.ctx + img_h, gi);
+                    if (p.ctx2) v2[u] = ldf4(p.ctx2 + img_h, gi);
+                    cval |= (inside ? 1u : 0u) << u;
+                }
+#pragma unroll
+                for (int u = 0; u < NCIH; ++u) {
+                    const int idx = htid + 256 * u;
+                    if (idx < NCIT) {
+                        const int c = idx / CG, g4 = (idx - c * CG) * 4;
+                        f32x4 t = v[u];
+                        if (p.ctx2) t += v2[u];                  // up_context + down_context (tf_train.py:58)
+                        if (!((cval >> u) & 1u)) t = f32x4{0.f, 0.f, 0.f, 0.f};
+                        *(f32x4*)(creg + c * CSTR + g4) = FLIP ? f32x4{t[3], t[2], t[1], t[0]} : t;
+                    }
+                }
+            }
+            __syncthreads();                                      // first conv done, context staged
+            __syncthreads();                                      // first epilogue done: h_0 complete
+            xch_export(0, G::HREG0);
+            static_for<DEPTH - 1>([&](auto lm_c) {
+                constexpr int l = decltype(lm_c)::value + 1;
+                constexpr int IN_REG = ((l - 1) & 1) ? G::HREG1 : G::HREG0, OUT_REG = (l & 1) ? G::HREG1 : G::HREG0;
+                xch_import(l - 1, IN_REG);
+                __syncthreads();                                  // row R of h_{l-1} is there
+                __syncthreads();                                  // layer l's epilogue done
+                xch_export(l, OUT_REG);
+            });
+            constexpr int LAST_REG = ((DEPTH - 1) & 1) ? G::HREG1 : G::HREG0;
+            xch_import(DEPTH - 1, LAST_REG);
+            __syncthreads();                                      // row R of the last hidden layer is there
+            __syncthreads();                                      // output pair in the exchange buffer
+            return;
+        }
+    }
 
     // ---- hidden layers ---------------------------------------------------------------------------------------------
     // the first (or only) part of a hidden layer l >= 1 and of the output pair; XCH: the taps of the own rows, the imported row's
@@ -816,7 +895,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                    wr0, acc0, PartL0{}, g_c, SET);
         IAF_FSTAMP(6);
         xch_next_epoch_a();
-        store_ctx();
+        if constexpr (!XCH) store_ctx();
         if constexpr (DEPTH == 1) load_final_operands();
         preload_after(std::integral_constant<int, 0>{});
         IAF_FSTAMP(10);
@@ -827,7 +906,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     });
     __syncthreads();
     IAF_FSTAMP(2);
-    xch_export(0, G::HREG0);
     static_for<DEPTH - 1>([&](auto lm_c) {
         constexpr int l = decltype(lm_c)::value + 1;              // hidden layer l reads h_{l-1}, writes h_l into the other region
         constexpr int IN_REG = ((l - 1) & 1) ? G::HREG1 : G::HREG0, OUT_REG = (l & 1) ? G::HREG1 : G::HREG0;
@@ -854,8 +932,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWH * 3>{},
                               (l & 1) ? wr1[decltype(i)::value] : wr0[decltype(i)::value], wbl, NHT, htile, PartBelow{}, decltype(i)::value, ALL);
                 });
-                if constexpr (l == 1) IAF_FSTAMP(14);
-                xch_import(l - 1, IN_REG);
+                if constexpr (l == 1) IAF_FSTAMP(28);
+                __syncthreads();                                  // the helper waves have put the row below into row R of IN_REG
                 if constexpr (l == 1) IAF_FSTAMP(15);
                 conv_phase(std::integral_constant<int, RDH>{}, std::integral_constant<int, NPTL>{}, std::integral_constant<int, NTWH>{},
                            std::integral_constant<int, G::rows_h(l)>{}, std::integral_constant<int, EML>{}, IN_REG, H16, H8, wbl, NHT, htile,
@@ -869,7 +947,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if constexpr (l == 1) IAF_FSTAMP(12);
         });
         __syncthreads();
-        xch_export(l, OUT_REG);
     });
     IAF_FSTAMP(3);
 
@@ -888,8 +965,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWO * 3>{}, wro[decltype(i)::value], wbo, 2 * NZT,
                           otile, PartBelow{}, decltype(i)::value, ALL);
             });
-            IAF_FSTAMP(18);
-            xch_import(DEPTH - 1, LAST_REG);
+            IAF_FSTAMP(29);
+            __syncthreads();                                      // ... and the row below of the last hidden layer
             IAF_FSTAMP(21);
             conv_phase(std::integral_constant<int, RDO>{}, std::integral_constant<int, NPTO>{}, std::integral_constant<int, NTWO>{},
                        std::integral_constant<int, R>{}, std::integral_constant<int, (1 << NPTO) - 1>{}, LAST_REG,

@@ -1,5 +1,5 @@
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r04; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-timeout 300 python $R/bench.py > $O/bench_i.json 2> $O/bench_i.err
-python $R/tools/show_bench.py $O/bench_i.json; tail -3 $O/bench_i.err; python -c "
-import json; d=json.load(open('$O/bench_i.json')); r=d['roofline']; print({k:r[k] for k in ('achieved','peak','frac','frac_of_f32_mfma_peak','avg_launch_us','avg_launch_us_relaunched_hot')}); print(r['step']); print(d['cpu_baseline'])"
+timeout 1500 python -m pytest $R/tests -q -m gpu -x 2>&1 | tail -4 > $O/pytest_gpu_b.txt
+timeout 600 python $R/tools/bench_configs.py > $O/bench_configs_helpers.md 2>/dev/null
+tail -4 $O/pytest_gpu_b.txt; cat $O/bench_configs_helpers.md

@@ -51,15 +51,14 @@ if (t[:, 8] != 0).all():      # finer stamps (wave 0): prologue and the two epil
     if (t[:, 12] != 0).all():
         print("    second epilogue: %.0f + barrier %.0f; output pair: K loop %.0f, to the exchange buffer + barrier %.0f, transform + stores %.0f" % (
             m(12, 7), m(3, 12), m(4, 3), m(13, 4), m(5, 13)))
-if (t[:, 14] != 0).any():
-    k = t[t[:, 14] != 0]
-    print("    second conv: own-row taps %.0f | import of the row below (wait + copy + barrier) %.0f | its taps %.0f (wave 0, %d importing WGs)" % (
-        np.median(k[:, 14] - k[:, 2]), np.median(k[:, 15] - k[:, 14]), np.median(k[:, 7] - k[:, 15]), len(k)))
-if (t[:, 16] != 0).any():
-    k = t[(t[:, 16] != 0) & (t[:, 19] != 0)]
-    md = lambda a, b_: np.median(k[:, a] - k[:, b_])
-    print("    import 1 (into the second conv): row arrives %.0f | re-arm + LDS stores %.0f | barrier %.0f;  import 2 (output pair): own taps %.0f | row arrives %.0f | re-arm + LDS stores %.0f | barrier %.0f | taps below %.0f" % (
-        md(16, 14), md(17, 16), md(15, 17), md(18, 3), md(19, 18), md(20, 19), md(21, 20), md(4, 21)))
+if (t[:, 28] != 0).any():
+    k = t[(t[:, 28] != 0) & (t[:, 29] != 0) & (t[:, 14] != 0) & (t[:, 18] != 0)]
+    if len(k):
+        md = lambda a, b_: np.median(k[:, a] - k[:, b_])
+        print("    compute waves (wave 0): second conv own taps %.0f | wait for the helpers' row %.0f | taps below %.0f;  output pair own taps %.0f | wait %.0f | taps below %.0f" % (
+            md(28, 2), md(15, 28), md(7, 15), md(29, 3), md(21, 29), md(4, 21)))
+        print("    helpers (first helper wave): import 1 asks %+.0f after the first epilogue's barrier, row complete +%.0f later, re-arm + LDS stores +%.0f;  import 2: asks %+.0f after the second epilogue's barrier, complete +%.0f, stores +%.0f" % (
+            md(14, 2), md(16, 14), md(17, 16), md(18, 3), md(19, 18), md(20, 19)))
 if (t[:, 26] != 0).any():
     k = t[t[:, 24] != 0]
     print("    sweeps until the row was complete: import 1 %s, import 2 %s (histogram over WGs: 1, 2, 3, more)" % (
