@@ -1143,6 +1143,20 @@ extern "C" int iaf_stack_step_exchanges(const iaf_stack_t* s, int B, int H, int 
     return (R > 0 && fused_step_xch(s, H, W, R, &lds, &xrow)) ? 1 : 0;
 }
 
+// threads per workgroup of a one-launch step kernel = its launch bound (256, or 512 with helper waves: iaf_step_fused.hpp)
+static int step_threads(step_fn_t fn) {
+    static std::mutex mu;
+    static std::map<const void*, int> cache;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find((const void*)fn);
+    if (it != cache.end()) return it->second;
+    hipFuncAttributes a;
+    int n = 256;
+    if (hipFuncGetAttributes(&a, (const void*)fn) == hipSuccess && a.maxThreadsPerBlock >= 256) n = a.maxThreadsPerBlock;
+    cache[(const void*)fn] = n;
+    return n;
+}
+
 // kl_part: posterior mode only -- per-(row block, channel) sums of the KL elements, [B * nrb][n_z] (StepP::kl_part)
 static int launch_fused_step(iaf_stack_t* s, step_fn_t fn, int R, size_t lds, const ConvP& base, int first_inmode, const float* ctx,
                              const float* ctx2, hipStream_t st, float* const* hsave = nullptr, float* kl_part = nullptr) {
@@ -1187,7 +1201,7 @@ static int launch_fused_step(iaf_stack_t* s, step_fn_t fn, int R, size_t lds, co
     { int rc = raise_lds_cap((const void*)fn, lds); if (rc) return rc; }
     const bool prof = (s->prof_layer == -2 && s->prof_n < s->prof_cap);
     if (prof) HIP_TRY(hipEventRecord(s->prof_start[s->prof_n], st));
-    hipLaunchKernelGGL(fn, dim3(base.B * q.nrb), dim3(q.xh ? 512 : 256), lds, st, q);      // (exchange form: four helper waves own the hand-overs)
+    hipLaunchKernelGGL(fn, dim3(base.B * q.nrb), dim3(step_threads(fn)), lds, st, q);       // (512 where four helper waves sit beside the compute waves)
     if (prof) { HIP_TRY(hipEventRecord(s->prof_stop[s->prof_n], st)); s->prof_n++; }
     return (int)hipGetLastError();
 }

@@ -134,11 +134,18 @@ constexpr int tri_live(int ntw, int nfull, int nht, int c, int gn, int gi) {
     return m;
 }
 
+// Which instantiations run with helper waves (512 threads, 256 registers per wave; see the kernel): every exchange-form kernel, and
+// the BASELINE run's 8-pixel geometry (n_h = 160, n_z = 32), where the helpers stage the context rows.  The launch code reads the
+// thread count off the kernel (hipFuncGetAttributes).
+constexpr bool fused_has_helpers(int nht, int nzt, int w, int xch) { return xch != 0 || (w == 8 && nht == 10 && nzt == 2); }
+
 // VAR: the statement of the operator -- 0 TF, 1 Theano (image rotated by 180 degrees + border channel), 2 Theano with
 // flipmask=True (TF geometry + border channel).  Compile time: as run-time flags these cost the TF path ~1 us per launch
 // (branches around the border loads split the epilogue's basic blocks).
 template <int NHT, int NZT, int DEPTH, int W, int R, int VAR = 0, int XCH = 0>
-__global__ __launch_bounds__(XCH ? 512 : 256) __attribute__((amdgpu_waves_per_eu(XCH ? 2 : 1, XCH ? 2 : 1))) void iaf_step_fused_kernel(StepP p) {
+__global__ __launch_bounds__(fused_has_helpers(NHT, NZT, W, XCH) ? 512 : 256)
+__attribute__((amdgpu_waves_per_eu(fused_has_helpers(NHT, NZT, W, XCH) ? 2 : 1, fused_has_helpers(NHT, NZT, W, XCH) ? 2 : 1))) void iaf_step_fused_kernel(StepP p) {
+    constexpr bool HELP = fused_has_helpers(NHT, NZT, W, XCH);
     typedef StepGeom<NHT, NZT, DEPTH, W, R, XCH> G;
     // exchanged rows and flags: AGENT scope (sc1: coherent across the XCDs, served by the memory side)
     constexpr int XSCOPE = __HIP_MEMORY_SCOPE_AGENT;
@@ -156,7 +163,7 @@ __global__ __launch_bounds__(XCH ? 512 : 256) __attribute__((amdgpu_waves_per_eu
     // (the helper section below) -- in vector-memory queues of their own: a compute wave's queue returns in order and feeds its K
     // loop, so a 1 us agent-scope load in it stalls its MFMAs (round 4, four waves: 8 k of 51.6 k cycles per workgroup were
     // imports).  One helper wave for all of it was too slow (16 KiB of sc1 loads from ONE wave: 6 k cycles; from four: 2.2 k).
-    const bool is_helper = XCH && wave >= NW_COMPUTE;
+    const bool is_helper = HELP && wave >= NW_COMPUTE;
     const int htid = tid - 64 * NW_COMPUTE;                      // helpers: 0 .. 255
     const int pl = lane & 15, kk = lane >> 4;
     // Which (image b, row block rbk) this workgroup computes.  Recomputing kernels: blockIdx, statically -- no workgroup depends on
@@ -465,12 +472,12 @@ __global__ __launch_bounds__(XCH ? 512 : 256) __attribute__((amdgpu_waves_per_eu
             IAF_FSTAMP(8);
             stage_z();                                           // (the context rows: the helper stages them during the first conv)
         }
-    } else {
+    } else if (!is_helper) {
         load_z();
         __builtin_amdgcn_sched_barrier(0);
         preload_w0();
         __builtin_amdgcn_sched_barrier(0);
-        load_ctx();
+        if constexpr (!HELP) load_ctx();                         // (HELP: the helpers stage the context rows during the first conv)
         __builtin_amdgcn_sched_barrier(0);
         IAF_FSTAMP(8);
         zero_cols();
@@ -799,7 +806,7 @@ __global__ __launch_bounds__(XCH ? 512 : 256) __attribute__((amdgpu_waves_per_eu
     // its traffic in between.  Behind the barrier that ends layer l's epilogue it sends row 0 of that layer to the block above and
     // starts asking for the row below: the row is in LDS by the time the compute waves have multiplied the taps of their own rows
     // and arrive at the barrier in front of the taps that read it.
-    if constexpr (XCH) {
+    if constexpr (HELP) {
         if (is_helper) {
             __builtin_amdgcn_s_setprio(IAF_HELPER_PRIO);          // (0: they take the issue slots the compute wave of their SIMD leaves)
             {   // the context rows of the first epilogue, summed and staged [channel][pixel] (what load_ctx + store_ctx do in the
@@ -838,14 +845,18 @@ __global__ __launch_bounds__(XCH ? 512 : 256) __attribute__((amdgpu_waves_per_eu
             static_for<DEPTH - 1>([&](auto lm_c) {
                 constexpr int l = decltype(lm_c)::value + 1;
                 constexpr int IN_REG = ((l - 1) & 1) ? G::HREG1 : G::HREG0, OUT_REG = (l & 1) ? G::HREG1 : G::HREG0;
-                xch_import(l - 1, IN_REG);
-                __syncthreads();                                  // row R of h_{l-1} is there
+                if constexpr (XCH) {
+                    xch_import(l - 1, IN_REG);
+                    __syncthreads();                              // row R of h_{l-1} is there
+                }
                 __syncthreads();                                  // layer l's epilogue done
                 xch_export(l, OUT_REG);
             });
-            constexpr int LAST_REG = ((DEPTH - 1) & 1) ? G::HREG1 : G::HREG0;
-            xch_import(DEPTH - 1, LAST_REG);
-            __syncthreads();                                      // row R of the last hidden layer is there
+            if constexpr (XCH) {
+                constexpr int LAST_REG = ((DEPTH - 1) & 1) ? G::HREG1 : G::HREG0;
+                xch_import(DEPTH - 1, LAST_REG);
+                __syncthreads();                                  // row R of the last hidden layer is there
+            }
             __syncthreads();                                      // output pair in the exchange buffer
             return;
         }
@@ -895,7 +906,7 @@ __global__ __launch_bounds__(XCH ? 512 : 256) __attribute__((amdgpu_waves_per_eu
                    wr0, acc0, PartL0{}, g_c, SET);
         IAF_FSTAMP(6);
         xch_next_epoch_a();
-        if constexpr (!XCH) store_ctx();
+        if constexpr (!HELP) store_ctx();
         if constexpr (DEPTH == 1) load_final_operands();
         preload_after(std::integral_constant<int, 0>{});
         IAF_FSTAMP(10);
