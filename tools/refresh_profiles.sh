@@ -1,10 +1,10 @@
 # Refresh the measured evidence under gpurun_out/$ROUND/ (copied to profiles/$ROUND/ afterwards):
-#   gpurun --timeout 900 -- 'ROUND=r03 timeout 880 bash tools/refresh_profiles.sh'
+#   gpurun --timeout 900 -- 'ROUND=r04 timeout 1500 bash tools/refresh_profiles.sh'
 # Every rocprofv3 pass runs under its own `timeout`: counter collection serialises the launches, and a PMC pass over the
 # hipGraph-replayed bench.py did not finish in 400 s (round 2) -- PMC passes go over tools/run_step.py (eager, a few launches).
 set -x
 R=$GRAFT_REPO_ROOT
-RD=${ROUND:-r03}
+RD=${ROUND:-r04}
 O=$R/gpurun_out/$RD
 mkdir -p $O/pmc
 cd /tmp && export TMPDIR=/tmp
