@@ -148,6 +148,33 @@ __device__ __forceinline__ void prep_tile(const PrepLayer& L, int gt, float (*re
     // same registers): slower on the whole step (0.4861 vs 0.4825 ms, 5 repeats each way) -- removed.
     constexpr int NQI = (NCH + 3) / 4;
     float v[NTP][4 * NQI];
+    // Round 4: a stack that keeps ONLY the bf16x3 pack (iaf_stack_set_packs; no fp32 pack, no transposed pack) has every weight of
+    // the tile in w3 already -- masked, one (pair, tap) unit of 8 input channels per thread and slot -- so the sum of squares comes
+    // from those registers and the second fetch of the tile (60 of the 116 strided 4-byte loads per thread at n_in = 160) is gone.
+    const bool bf3_only = BF3 && L.wp3 && !L.wp && !L.wpt;
+    if (bf3_only) {
+        if constexpr (BF3) {
+            constexpr int NUNIT = (NCH / 2) * NTP;
+            float ssb = 0.f;
+#pragma unroll
+            for (int i = 0; i < PREP_BF3_UPQ_T(NCH, NTP); ++i) {
+                if ((int)(threadIdx.x >> 6) + 4 * i >= NUNIT) continue;          // (the clamped surplus slot: loaded, not part of the tile)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ssb += w3[i][e] * w3[i][e];
+            }
+            red[cs][oo] = ssb;                                    // (cs = thread / 16, oo = thread % 16 = the lane's output channel in both mappings)
+            __syncthreads();
+            if (cs == 0) {
+                float tot = 0.f;
+                for (int i = 0; i < 16; ++i) tot += red[i][oo];
+                s_scale[oo] = expf(gval) / sqrtf(fmaxf(tot, 1e-12f));
+                L.bias[gt * 16 + oo] = bval;
+            }
+            __syncthreads();
+            prep_bf3_store<NCH, NTP>(L, gt, w3, s_scale);
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < NQI; ++i) {
         const int q = cs + 16 * i;
