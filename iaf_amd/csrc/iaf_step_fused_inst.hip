@@ -61,6 +61,21 @@ extern "C" step_fn_t iaf_pick_step_fused_a(int nht, int nzt, int depth, int W, i
     return nullptr;
 }
 #endif
+#if !defined(IAF_FUSED_PART) || IAF_FUSED_PART == 2
+// depth_ar = 3 (models.py:92 allows any depth; README.md:49 sweeps it): the n_z = 32 families of configs 0-2.  Hidden layers ping-pong
+// between the two LDS regions, so an odd depth is the same code (the output pair's exchange buffer moves: StepGeom::XB_OFF).
+extern "C" step_fn_t iaf_pick_step_fused_xch_c(int nht, int nzt, int depth, int W, int R, int var, size_t* lds, size_t* xrow) {
+    *lds = 0; *xrow = 0;
+    if (nht == 10 && nzt == 2 && depth == 3 && W == 16 && R == 2) return inst<10, 2, 3, 16, 2, 1>(var, lds, xrow);
+    return nullptr;
+}
+extern "C" step_fn_t iaf_pick_step_fused_c(int nht, int nzt, int depth, int W, int R, int var, size_t* lds) {
+    *lds = 0;
+    if (nht == 10 && nzt == 2 && depth == 3) return inst_wr<10, 2, 3>(W, R, var, lds);
+    if (nht == 4 && nzt == 2 && depth == 3) return inst_wr<4, 2, 3>(W, R, var, lds);
+    return nullptr;
+}
+#endif
 #if !defined(IAF_FUSED_PART) || IAF_FUSED_PART == 1
 // config 3 (up_iaf2_nl, n_z = 64, depth_ar = 4; n_h is not fixed by the reference's scripts): the geometries that fit
 // ... in the halo-exchange form: the regions hold R + 1 rows instead of R + depth_ar, which is what lets n_h = 128 / 192 fit

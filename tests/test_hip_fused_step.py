@@ -88,7 +88,9 @@ def test_where_the_step_runs_as_one_launch(amd):
                                  (16, 32, 64, 1, 8, 8), (4, 32, 64, 1, 3, 16), (128, 32, 64, 1, 8, 8),
                                  (16, 32, 64, 1, 4, 4), (32, 32, 160, 2, 4, 4), (5, 32, 160, 2, 3, 4), (3, 32, 64, 1, 9, 4),
                                  (32, 64, 64, 4, 16, 16), (4, 64, 64, 4, 8, 8), (3, 64, 128, 4, 8, 8), (32, 64, 192, 4, 8, 8),
-                                 (3, 64, 192, 4, 4, 4), (2, 64, 64, 4, 5, 16), (2, 64, 128, 4, 3, 4)], ids=lambda s: "B%d_z%d_h%d_d%d_%dx%d" % s)
+                                 (3, 64, 192, 4, 4, 4), (2, 64, 64, 4, 5, 16), (2, 64, 128, 4, 3, 4),
+                                 (8, 32, 160, 3, 16, 16), (5, 32, 160, 3, 8, 8), (3, 32, 160, 3, 7, 16), (4, 32, 64, 3, 8, 8),
+                                 (6, 32, 64, 3, 16, 16), (4, 32, 64, 3, 4, 4)], ids=lambda s: "B%d_z%d_h%d_d%d_%dx%d" % s)
 def test_iaf_step_and_raw_outputs_vs_oracle(amd, cfg):
     """tf_train.py:69-72 and layers.py:158-166 through the one-launch step; heights that are not a multiple of the rows
     per workgroup, single rows, one sample"""

@@ -91,6 +91,23 @@ def test_deep_stack_exchange_under_scrambled_order(amd, n_h, knob):
     assert xs.exchange_errors() == 0
 
 
+@pytest.mark.parametrize("knob", [0, 3], ids=lambda k: "knob%d" % k)
+def test_depth_3_exchanges_three_rows_per_block(amd, knob):
+    """depth_ar = 3 (models.py:92 allows any depth): an odd number of hidden layers through the same hand-over"""
+    xs, rc = _stacks(amd, 32, [160] * 3, 18)
+    xs.set_halo_exchange_debug(knob)
+    # (three hidden regions of R + 3 ... R + 1 rows do not fit the LDS at n_h = 160: without the exchange this size runs layer by layer)
+    assert xs.step_exchanges(16, 16, 16) and not rc.step_exchanges(16, 16, 16) and rc.step_is_fused(16, 16, 16) == 0
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for rep in range(3):
+        z = torch.randn(16, 32, 16, 16, device="cuda", generator=g)
+        ctx = torch.randn(16, 160, 16, 16, device="cuda", generator=g)
+        zx, sx = xs.iaf_step(z, ctx)
+        zr, sr = rc.iaf_step(z, ctx)
+        assert float((sx.double() - sr.double()).abs().max()) < 5e-6 and float((zx.double() - zr.double()).abs().max()) < 1e-4
+    assert xs.exchange_errors() == 0
+
+
 def test_posterior_block_exchange_under_scrambled_order(amd):
     """tf_train.py:56-85 in the one-launch form (sample in front, KL sums behind) through the same exchange"""
     xs, rc = _stacks(amd, 32, [160, 160], 13)
