@@ -960,3 +960,50 @@ def test_theano_single_ar_conv2d_vs_oracle(amd, zd, flip):
     y = amd.ar_conv2d_theano("q", n_in, n_out, (3, 3), zd, flip, w=w)(dev(x), w)
     e = O.theano_ar_conv2d(f32(x), f32(wv), f32(bv), f32(sv), n_in, n_out, zd, flip)
     np.testing.assert_allclose(host(y), e, atol=ATOL, rtol=0)
+
+
+def test_round4_elementwise_entry_points_vs_torch(amd):
+    """The C-ABI functions added in round 4 so that no wrapper does arithmetic in torch: the Gaussian
+    kernels on a log standard deviation (tf_train.py:56-57 / rand.py:81-86 write `2 * logsd` in place), the free-bits gate
+    (tf_train.py:79-80), and the two elementwise halves of the 'up_iaf2_nl' backward (models.py:168-176, 295-298, 454-466)
+    against the same formulas written out with torch in fp64."""
+    import ctypes
+    from iaf_amd import _capi
+    from iaf_amd.layers import _ptr, _stream, kl_free_bits
+    from iaf_amd.distributions import gaussian_diag_logps, gaussian_diag_logps_logsd
+    from iaf_amd.iaf_layer import gaussian_sample
+    g = torch.Generator(device="cuda").manual_seed(4)
+    B, n_h, n_z, H, W = 3, 16, 8, 5, 4
+    r = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    mean, logsd, x, eps = r(B, n_z, H, W), 0.3 * r(B, n_z, H, W), r(B, n_z, H, W), r(B, n_z, H, W)
+    assert torch.equal(gaussian_diag_logps_logsd(mean, logsd, x), gaussian_diag_logps(mean, logsd * 2.0, x))
+    np.testing.assert_allclose(host(gaussian_sample(mean, logsd, eps)), host(mean) + np.exp(host(logsd)) * host(eps), atol=1e-6)
+    kl = r(B, n_z, H, W) + 0.2
+    cost, obj, gate = kl_free_bits(kl, 0.25, want_gate=True)
+    mean_c = host(kl).sum(axis=(2, 3)).mean(axis=0)
+    np.testing.assert_array_equal(host(gate), (mean_c > 0.25).astype(np.float64))
+    np.testing.assert_allclose(host(obj), np.maximum(mean_c, 0.25).sum(), rtol=1e-5)
+    np.testing.assert_allclose(host(cost), host(kl).sum(axis=(1, 2, 3)), rtol=1e-5)
+    # backward halves: free bits (gate, scalar objective) and plain (per-image weights)
+    z, pm, pl = r(B, n_z, H, W), r(B, n_z, H, W), 0.3 * r(B, n_z, H, W)
+    d_h, d_up = r(B, n_h + n_z, H, W), r(B, n_h + n_z, H, W)
+    dko = r(B).abs()
+    for free_bits in (True, False):
+        for with_up in (True, False):
+            dz_tot, G = torch.empty_like(z), torch.empty_like(z)
+            d_dc1 = torch.empty(B, n_h + 2 * n_z, H, W, device="cuda")
+            _capi.check(_capi.lib().iaf_up_iaf2_backward_pre(
+                _ptr(z), _ptr(pm), _ptr(pl), _ptr(d_h), _ptr(d_up) if with_up else None, _ptr(gate) if free_bits else None, 0.7,
+                None if free_bits else _ptr(dko), _ptr(dz_tot), _ptr(G), _ptr(d_dc1), B, n_h, n_z, H * W, _stream()))
+            Gr = (host(gate) * 0.7)[None, :, None, None] * np.ones((B, 1, H, W)) if free_bits else host(dko)[:, None, None, None] * np.ones((1, n_z, H, W))
+            e2, dlt = np.exp(-2.0 * host(pl)), host(z) - host(pm)
+            want = host(d_h)[:, n_h:] + Gr * dlt * e2 + (host(d_up)[:, n_h:] if with_up else 0.0)
+            np.testing.assert_allclose(host(dz_tot), want, atol=2e-5)
+            np.testing.assert_allclose(host(G), Gr, atol=1e-6)
+            np.testing.assert_allclose(host(d_dc1), np.concatenate([host(d_h)[:, :n_h], -Gr * dlt * e2, Gr * (1.0 - dlt * dlt * e2)], axis=1), atol=2e-5)
+            dz0, z0, qm, dctx = r(B, n_z, H, W), r(B, n_z, H, W), r(B, n_z, H, W), r(B, n_h, H, W)
+            d_uc1 = torch.empty(B, 2 * n_h + 2 * n_z, H, W, device="cuda")
+            _capi.check(_capi.lib().iaf_up_iaf2_backward_post(_ptr(dz0), _ptr(z0), _ptr(qm), _ptr(G), _ptr(dctx), _ptr(d_up) if with_up else None,
+                                                              _ptr(d_uc1), B, n_h, n_z, H * W, _stream()))
+            up_h = host(d_up)[:, :n_h] if with_up else np.zeros((B, n_h, H, W))
+            np.testing.assert_allclose(host(d_uc1), np.concatenate([up_h, host(dz0), host(dz0) * (host(z0) - host(qm)) - Gr, host(dctx)], axis=1), atol=2e-5)
