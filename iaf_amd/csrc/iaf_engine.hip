@@ -109,7 +109,7 @@ struct iaf_stack {
     struct XchSet {
         hipStream_t st = nullptr;
         char* buf = nullptr; size_t bytes = 0;                 // rows: all 0xff between launches
-        unsigned long long* ctl = nullptr;                     // heads, arrivals, sticky error (512 words: StepP::xctl): zero between launches
+        unsigned long long* ctl = nullptr;                     // heads, arrivals, sticky error (StepP::xctl: words 0..511), arrivals of the in-launch KL finish (StepP::fin_ctl: words 512..): zero between launches
     };
     std::deque<XchSet> xch_sets;           // (stable addresses: a launch holds a pointer to its set outside the lock)
     std::mutex xch_mu;
@@ -502,7 +502,7 @@ static int xch_reset_sets(iaf_stack_t* s) {
     std::lock_guard<std::mutex> lk(s->xch_mu);
     for (auto& x : s->xch_sets) {
         HIP_TRY(hipMemset(x.buf, 0xff, x.bytes));
-        HIP_TRY(hipMemset(x.ctl, 0, 512 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(x.ctl, 0, 1024 * sizeof(unsigned long long)));
     }
     for (auto& r : s->xch_retired_rows) HIP_TRY(hipMemset(r.first, 0xff, r.second));     // (a captured graph may still name them)
     if (s->xch_err_host) *(volatile unsigned*)s->xch_err_host = 0u;
@@ -1059,7 +1059,7 @@ static iaf_stack::XchSet* xch_prepare(iaf_stack_t* s, int B, int nrb, size_t xro
     std::lock_guard<std::mutex> lk(s->xch_mu);
     iaf_stack::XchSet* x = nullptr;
     for (auto& e : s->xch_sets) if (e.st == st) { x = &e; break; }
-    const size_t need = (size_t)s->depth_ar * B * nrb * xrow;
+    const size_t need = (size_t)s->depth_ar * B * nrb * xrow > 256 ? (size_t)s->depth_ar * B * nrb * xrow : 256;   // (xrow = 0: only the counters are wanted)
     if (x && need <= x->bytes) return x;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(st, &cs);
@@ -1082,8 +1082,8 @@ static iaf_stack::XchSet* xch_prepare(iaf_stack_t* s, int B, int nrb, size_t xro
     char* nb = nullptr;
     unsigned long long* nc = x ? x->ctl : nullptr;
     bool ok = hipMalloc((void**)&nb, need) == hipSuccess && hipMemsetAsync(nb, 0xff, need, st) == hipSuccess;    // (ordered in front of the launch)
-    if (ok && !nc) ok = hipMalloc((void**)&nc, 512 * sizeof(unsigned long long)) == hipSuccess &&
-                        hipMemsetAsync(nc, 0, 512 * sizeof(unsigned long long), st) == hipSuccess;
+    if (ok && !nc) ok = hipMalloc((void**)&nc, 1024 * sizeof(unsigned long long)) == hipSuccess &&
+                        hipMemsetAsync(nc, 0, 1024 * sizeof(unsigned long long), st) == hipSuccess;
     if (!ok) {
         if (nb) (void)hipFree(nb);
         if (nc && !(x && x->ctl == nc)) (void)hipFree(nc);
@@ -1159,8 +1159,13 @@ static int step_threads(step_fn_t fn) {
 }
 
 // kl_part: posterior mode only -- per-(row block, channel) sums of the KL elements, [B * nrb][n_z] (StepP::kl_part)
+// fin (posterior mode, optional): where the block's free-bits results go if the launch can finish them itself (StepP::fin_*); *fin->done
+// tells the caller whether it did -- else the caller runs launch_kl_from_parts behind the launch as before
+struct StepFin { float* kl_obj; float* kl_cost; float kl_min; bool done; };
 static int launch_fused_step(iaf_stack_t* s, step_fn_t fn, int R, size_t lds, const ConvP& base, int first_inmode, const float* ctx,
-                             const float* ctx2, hipStream_t st, float* const* hsave = nullptr, float* kl_part = nullptr) {
+                             const float* ctx2, hipStream_t st, float* const* hsave = nullptr, float* kl_part = nullptr,
+                             StepFin* fin = nullptr) {
+    if (fin) fin->done = false;
     // A bounded wait of an earlier launch of this stack gave up (its outputs carry NaN): said once, as this call's status, and
     // the stack goes on with the kernels that recompute their halo rows until iaf_stack_set_halo_exchange re-arms the exchange.
     if (s->xch_on && s->xch_err_host && *(volatile unsigned*)s->xch_err_host) {
@@ -1200,6 +1205,18 @@ static int launch_fused_step(iaf_stack_t* s, step_fn_t fn, int R, size_t lds, co
         }
     }
     { int rc = raise_lds_cap((const void*)fn, lds); if (rc) return rc; }
+    // The free-bits reductions inside the launch: kernels with helper waves, a table one workgroup can walk (the bounds of the
+    // single-workgroup finish launch), n_z <= 64 channels and a set of counters for this stream (none inside a capture that was
+    // not warmed up: then the finish launch follows as before).  IAF_KL_IN_LAUNCH=0: dev knob.
+    if (fin && kl_part && base.mode == MODE_POSTERIOR && step_threads(fn) == 512 && s->n_z <= 64 &&
+        (long long)base.B * q.nrb * s->n_z <= 16384 && (long long)base.B * s->n_z <= 8192) {
+        static const bool fin_env = !(getenv("IAF_KL_IN_LAUNCH") && getenv("IAF_KL_IN_LAUNCH")[0] == '0');
+        if (fin_env)
+            if (iaf_stack::XchSet* x = xch_prepare(s, base.B, q.nrb, 0, st)) {
+                q.fin_obj = fin->kl_obj; q.fin_cost = fin->kl_cost; q.fin_kl_min = fin->kl_min; q.fin_ctl = x->ctl + 512;
+                fin->done = true;
+            }
+    }
     const bool prof = (s->prof_layer == -2 && s->prof_n < s->prof_cap);
     if (prof) HIP_TRY(hipEventRecord(s->prof_start[s->prof_n], st));
     hipLaunchKernelGGL(fn, dim3(base.B * q.nrb), dim3(step_threads(fn)), lds, st, q);       // (512 where four helper waves sit beside the compute waves)
@@ -1586,7 +1603,9 @@ extern "C" int iaf_posterior_block_forward(iaf_stack_t* s, const float* qz_mean,
         if (step_fn_t fn = aligned ? fused_step_plan(s, B, H, W, &R, &lds, st, true) : nullptr) {
             const int nrb = (H + R - 1) / R;
             p.kl_elem = kl_elem;
-            if ((rc = launch_fused_step(s, fn, R, lds, p, IN_POSTERIOR, up_context, down_context, st, nullptr, ws.hbuf[0]))) return rc;
+            StepFin fin = {kl_obj, kl_cost, kl_min, false};
+            if ((rc = launch_fused_step(s, fn, R, lds, p, IN_POSTERIOR, up_context, down_context, st, nullptr, ws.hbuf[0], &fin))) return rc;
+            if (fin.done) return IAF_OK;                       // the launch's last workgroup did the block's reductions too
             return launch_kl_from_parts(ws.hbuf[0], ws.rowsum, kl_obj, kl_cost, B, s->n_z, nrb, kl_min, nullptr, st);
         }
     }

@@ -858,6 +858,65 @@ __attribute__((amdgpu_waves_per_eu(fused_has_helpers(NHT, NZT, W, XCH) ? 2 : 1, 
                 __syncthreads();                                  // row R of the last hidden layer is there
             }
             __syncthreads();                                      // output pair in the exchange buffer
+            // ---- the block's free-bits reductions, by the helper waves of the workgroup that arrives last (StepP::fin_*) ----
+            if (p.fin_ctl && p.mode == MODE_POSTERIOR) {
+                unsigned* fmail = (unsigned*)smem;                // (every region is dead once the compute waves are through the final loop)
+                __syncthreads();                                  // every compute wave's partial sums are in memory
+                if (htid == 0) {
+                    const unsigned g = blockIdx.x & 7u, ng = (gridDim.x - g + 7u) >> 3, ngroups = gridDim.x < 8u ? gridDim.x : 8u;
+                    unsigned last = 0;
+                    if ((unsigned)__hip_atomic_fetch_add(p.fin_ctl + 32 * g, 1ull, __ATOMIC_RELAXED, XSCOPE) == ng - 1u) {
+                        __hip_atomic_store(p.fin_ctl + 32 * g, 0ull, __ATOMIC_RELAXED, XSCOPE);
+                        if ((unsigned)__hip_atomic_fetch_add(p.fin_ctl + 256, 1ull, __ATOMIC_RELAXED, XSCOPE) == ngroups - 1u) {
+                            __hip_atomic_store(p.fin_ctl + 256, 0ull, __ATOMIC_RELAXED, XSCOPE);
+                            last = 1;
+                        }
+                    }
+                    fmail[0] = last;
+                }
+                __syncthreads();
+                if (!fmail[0]) return;
+                // S[b][c] = sum over the row blocks, in row order, eight 16-byte loads in flight (as iaf_kl_finish_kernel)
+                float* S = (float*)smem + 64;                     // (behind the mail word; B * n_z <= 8192 floats: checked by the host)
+                {
+                    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)p.kl_part, 0, p.B * p.nrb * NZ * 4, 0x00020000);
+                    constexpr int Z4 = NZ / 4;
+                    for (int i = htid; i < p.B * Z4; i += 256) {
+                        const int bb = i / Z4, c4 = i - bb * Z4;
+                        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+                        for (int k0 = 0; k0 < p.nrb; k0 += 8) {
+                            u32x4 v8[8];
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) {
+                                const int rr = k0 + k < p.nrb ? k0 + k : p.nrb - 1;
+                                v8[k] = __builtin_amdgcn_raw_buffer_load_b128(r, 4 * ((bb * p.nrb + rr) * NZ + 4 * c4), 0, XSC1);
+                            }
+#pragma unroll
+                            for (int k = 0; k < 8; ++k)
+                                if (k0 + k < p.nrb) a += __builtin_bit_cast(f32x4, v8[k]);
+                        }
+                        *(f32x4*)(S + (size_t)bb * NZ + 4 * c4) = a;
+                    }
+                }
+                __syncthreads();
+                if (htid < 64) {                                  // one wave: n_z <= 64 channels, then B images in rounds of 64
+                    float a = 0.f;
+                    if (htid < NZ) {
+                        float m = 0.f;
+                        for (int bb = 0; bb < p.B; ++bb) m += S[(size_t)bb * NZ + htid];
+                        a = fmaxf(m / (float)p.B, p.fin_kl_min);  // kl_ave[c] = max(mean_b S[b,c], kl_min)          (tf_train.py:79-80)
+                    }
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);      // (the finish kernel's tree: part[t] += part[t + o])
+                    const float fb = __shfl(a, 0, 64);
+                    for (int bb = htid; bb < p.B; bb += 64) {
+                        float c = 0.f;
+                        for (int cc = 0; cc < NZ; ++cc) c += S[(size_t)bb * NZ + cc];
+                        p.fin_cost[bb] = c;                                           // tf_train.py:85
+                        p.fin_obj[bb] = p.fin_kl_min > 0.f ? fb : c;                  // tf_train.py:82 / 84
+                    }
+                }
+            }
             return;
         }
     }
@@ -1063,9 +1122,23 @@ __attribute__((amdgpu_waves_per_eu(fused_has_helpers(NHT, NZT, W, XCH) ? 2 : 1, 
 #pragma unroll
             for (int o = RW / 2; o > 0; o >>= 1) a += __shfl_xor(a, o);
             const int idx = tid + e * 256;
-            if (idx < NZ * RW && (idx & (RW - 1)) == 0) p.kl_part[((size_t)b * p.nrb + rbk) * NZ + idx / RW] = a;
+            if (idx < NZ * RW && (idx & (RW - 1)) == 0) {
+                float* q = p.kl_part + ((size_t)b * p.nrb + rbk) * NZ + idx / RW;
+                if (HELP && p.fin_ctl) __hip_atomic_store(q, a, __ATOMIC_RELAXED, XSCOPE);       // (read by another workgroup, below)
+                else *q = a;
+            }
         }
     }
     IAF_FSTAMP(5);
+    if constexpr (HELP) {
+        // the in-launch free-bits reductions (fin_helper): the compute waves only keep the barriers company
+        if (p.fin_ctl && p.mode == MODE_POSTERIOR) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // this wave's partial sums are in memory
+            __syncthreads();
+            __syncthreads();
+            if (!*(volatile unsigned*)smem) return;                                   // not the last workgroup
+            __syncthreads();
+        }
+    }
 #undef IAF_FSTAMP
 }

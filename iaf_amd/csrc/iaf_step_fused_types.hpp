@@ -26,6 +26,15 @@ struct StepP {
     // mean / free-bits max / channel sum applied (tf_train.py:79-85) by iaf_kl_finish_kernel: ONE small launch behind this
     // one instead of the two (row sums over the KL tensor + finish) of round 2.  NULL: no partial sums are written.
     float* kl_part;
+    // The block's free-bits reductions inside this launch (kernels with helper waves, posterior mode; NULL fin_ctl: the caller runs
+    // iaf_kl_finish_kernel behind the launch): the LAST workgroup to arrive -- counted in fin_ctl, 64-bit words, one 128-byte line
+    // each: [32 g] arrivals of the workgroups with blockIdx % 8 = g, [256] groups complete; zero between launches -- sums kl_part
+    // over the row blocks, takes the batch mean / max(., kl_min) / channel sum (tf_train.py:79-85) and writes fin_obj, fin_cost [B],
+    // in the summation order of iaf_kl_finish_kernel (bit-identical results).
+    float* fin_obj;
+    float* fin_cost;
+    unsigned long long* fin_ctl;
+    float fin_kl_min;
     // XCH kernels (halo rows exchanged between the row blocks of an image instead of recomputed; iaf_step_fused.hpp "XCH"):
     char* xh;                      // rows [layer][B * nrb][xrow bytes]; every 8-byte piece = 0xff..ff between launches (the data is the flag)
     unsigned long long* xctl;      // [32 y] head of work list y (tickets taken), [32 y + 16] its arrivals, [256] lists complete,

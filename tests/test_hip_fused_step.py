@@ -320,3 +320,34 @@ def test_theano_statement_through_the_one_launch_step(amd, cfg, flip):
     np.testing.assert_allclose(host(logsd), el, atol=ATOL, rtol=0)
     zb, sb = lbl.iaf_step(dev(z), dev(ctx))
     assert float((logsd - sb).abs().max()) < 2e-6 and float((z_new - zb).abs().max()) < 3e-5
+
+
+@pytest.mark.parametrize("kl_min", [0.0, 0.25])
+@pytest.mark.parametrize("cfg", [(32, 16), (5, 16), (32, 8), (3, 8), (64, 8)], ids=lambda c: "B%d_%dx%d" % (c[0], c[1], c[1]))
+def test_free_bits_reductions_inside_the_launch_equal_the_finish_launch(amd, cfg, kl_min):
+    """tf_train.py:77-85 behind the one-launch step: in the kernels with helper waves (16-pixel rows in the exchange form, the
+    BASELINE 8-pixel geometry) the LAST workgroup to arrive sums the per-row-block KL sums and applies batch mean / max(., kl_min) /
+    channel sum itself (StepP::fin_*), in iaf_kl_finish_kernel's summation order -- so kl_obj and kl_cost must be BIT-identical to
+    what the separate finish launch gives (the training forward still uses that launch: it also wants the gate)."""
+    B, HW = cfg
+    rng = np.random.RandomState(90 + B + HW)
+    params = {k: dev(v) for k, v in gi.ar_multiconv2d_params(rng, 32, [160, 160], [32, 32]).items()}
+    one, two = amd.ARStack(32, [160, 160]), amd.ARStack(32, [160, 160])
+    two.set_training(True)
+    one.prepare(params)
+    two.prepare(params)
+    assert "last workgroup" in one.posterior_block_launches(B, HW, HW) or B * (HW // (2 if HW == 16 else 1)) * 32 > 16384
+    g = torch.Generator(device="cuda").manual_seed(B)
+    for rep in range(3):
+        t = lambda c, s=1.0: s * torch.randn(B, c, HW, HW, device="cuda", generator=g)
+        args = [t(32), t(32, .25), t(32), t(32, .25), t(32), t(32, .25), t(160), t(160), t(32)]
+        a = one.posterior_block(*args, kl_min)
+        b = two.posterior_block_train(*args, kl_min)
+        assert torch.equal(a["z"], b["z"])
+        assert torch.equal(a["kl_cost"], b["kl_cost"]) and torch.equal(a["kl_obj"], b["kl_obj"])
+        want = a["kl_cost"].double()
+        if kl_min > 0:
+            assert float((a["kl_obj"] - a["kl_obj"][0]).abs().max()) == 0.0
+        else:
+            assert torch.equal(a["kl_obj"], a["kl_cost"])
+        assert torch.isfinite(want).all()
