@@ -1161,7 +1161,7 @@ static int step_threads(step_fn_t fn) {
 // kl_part: posterior mode only -- per-(row block, channel) sums of the KL elements, [B * nrb][n_z] (StepP::kl_part)
 // fin (posterior mode, optional): where the block's free-bits results go if the launch can finish them itself (StepP::fin_*); *fin->done
 // tells the caller whether it did -- else the caller runs launch_kl_from_parts behind the launch as before
-struct StepFin { float* kl_obj; float* kl_cost; float kl_min; bool done; };
+struct StepFin { float* kl_obj; float* kl_cost; float kl_min; bool done; float* gate; };
 static int launch_fused_step(iaf_stack_t* s, step_fn_t fn, int R, size_t lds, const ConvP& base, int first_inmode, const float* ctx,
                              const float* ctx2, hipStream_t st, float* const* hsave = nullptr, float* kl_part = nullptr,
                              StepFin* fin = nullptr) {
@@ -1211,9 +1211,9 @@ static int launch_fused_step(iaf_stack_t* s, step_fn_t fn, int R, size_t lds, co
     if (fin && kl_part && base.mode == MODE_POSTERIOR && step_threads(fn) == 512 && s->n_z <= 64 &&
         (long long)base.B * q.nrb * s->n_z <= 16384 && (long long)base.B * s->n_z <= 8192) {
         static const bool fin_env = !(getenv("IAF_KL_IN_LAUNCH") && getenv("IAF_KL_IN_LAUNCH")[0] == '0');
-        if (fin_env)
+        if (fin_env && !(s->xch_knob & 16u))                 // (test knob 16: the finish launch, to compare against)
             if (iaf_stack::XchSet* x = xch_prepare(s, base.B, q.nrb, 0, st)) {
-                q.fin_obj = fin->kl_obj; q.fin_cost = fin->kl_cost; q.fin_kl_min = fin->kl_min; q.fin_ctl = x->ctl + 512;
+                q.fin_obj = fin->kl_obj; q.fin_cost = fin->kl_cost; q.fin_kl_min = fin->kl_min; q.fin_ctl = x->ctl + 512; q.fin_gate = fin->gate;
                 fin->done = true;
             }
     }
@@ -1603,7 +1603,7 @@ extern "C" int iaf_posterior_block_forward(iaf_stack_t* s, const float* qz_mean,
         if (step_fn_t fn = aligned ? fused_step_plan(s, B, H, W, &R, &lds, st, true) : nullptr) {
             const int nrb = (H + R - 1) / R;
             p.kl_elem = kl_elem;
-            StepFin fin = {kl_obj, kl_cost, kl_min, false};
+            StepFin fin = {kl_obj, kl_cost, kl_min, false, nullptr};
             if ((rc = launch_fused_step(s, fn, R, lds, p, IN_POSTERIOR, up_context, down_context, st, nullptr, ws.hbuf[0], &fin))) return rc;
             if (fin.done) return IAF_OK;                       // the launch's last workgroup did the block's reductions too
             return launch_kl_from_parts(ws.hbuf[0], ws.rowsum, kl_obj, kl_cost, B, s->n_z, nrb, kl_min, nullptr, st);
@@ -2309,7 +2309,9 @@ extern "C" int iaf_posterior_block_forward_train(iaf_stack_t* s, const float* qz
         if (step_fn_t fn = aligned ? fused_step_plan(s, B, H, W, &R, &lds, st, true) : nullptr) {
             // (the backward never reads the KL tensor: its buffer takes the per-row-block partial sums instead)
             base.kl_elem = nullptr;
-            if ((rc = launch_fused_step(s, fn, R, lds, base, IN_POSTERIOR, up_context, down_context, st, tw.h, tw.klelem))) return rc;
+            StepFin fin = {kl_obj, kl_cost, kl_min, false, tw.gate};
+            if ((rc = launch_fused_step(s, fn, R, lds, base, IN_POSTERIOR, up_context, down_context, st, tw.h, tw.klelem, &fin))) return rc;
+            if (fin.done) return IAF_OK;
             return launch_kl_from_parts(tw.klelem, tw.rowsum, kl_obj, kl_cost, B, s->n_z, (H + R - 1) / R, kl_min, tw.gate, st);
         }
     }

@@ -905,6 +905,7 @@ __attribute__((amdgpu_waves_per_eu(fused_has_helpers(NHT, NZT, W, XCH) ? 2 : 1, 
                         float m = 0.f;
                         for (int bb = 0; bb < p.B; ++bb) m += S[(size_t)bb * NZ + htid];
                         a = fmaxf(m / (float)p.B, p.fin_kl_min);  // kl_ave[c] = max(mean_b S[b,c], kl_min)          (tf_train.py:79-80)
+                        if (p.fin_gate && p.fin_kl_min > 0.f) p.fin_gate[htid] = (m / (float)p.B > p.fin_kl_min) ? 1.f : 0.f;
                     }
 #pragma unroll
                     for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);      // (the finish kernel's tree: part[t] += part[t + o])

@@ -33,6 +33,7 @@ struct StepP {
     // in the summation order of iaf_kl_finish_kernel (bit-identical results).
     float* fin_obj;
     float* fin_cost;
+    float* fin_gate;               // optional [n_z]: 1 where the free-bits max() passes the gradient (training forward), else 0
     unsigned long long* fin_ctl;
     float fin_kl_min;
     // XCH kernels (halo rows exchanged between the row blocks of an image instead of recomputed; iaf_step_fused.hpp "XCH"):

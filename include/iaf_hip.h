@@ -347,7 +347,8 @@ int iaf_stack_exchange_errors(const iaf_stack_t* s, unsigned* errors);
 int iaf_stack_set_halo_exchange(iaf_stack_t* s, int on);
 /* Test knobs of the exchange (OR of): 1 = work lists chosen by a hash of the workgroup index instead of its XCD (lists run dry,
  * workgroups take from other lists), 2 = workgroups delay their ticket by pseudo-random amounts (tickets out of dispatch
- * order), 8 = fault injection: the bottom row block of image 0 never hands over its first hidden row and waits are short, so
+ * order), 16 = the posterior block's free-bits reductions by the separate finish launch instead of the step launch's
+ * last workgroup (to compare the two), 8 = fault injection: the bottom row block of image 0 never hands over its first hidden row and waits are short, so
  * the block above it gives up.  0 = production. */
 int iaf_stack_set_halo_exchange_debug(iaf_stack_t* s, unsigned knobs);
 /* 1 if the step at this size runs as one launch in the halo-exchange form, else 0 */

@@ -328,23 +328,27 @@ def test_free_bits_reductions_inside_the_launch_equal_the_finish_launch(amd, cfg
     """tf_train.py:77-85 behind the one-launch step: in the kernels with helper waves (16-pixel rows in the exchange form, the
     BASELINE 8-pixel geometry) the LAST workgroup to arrive sums the per-row-block KL sums and applies batch mean / max(., kl_min) /
     channel sum itself (StepP::fin_*), in iaf_kl_finish_kernel's summation order -- so kl_obj and kl_cost must be BIT-identical to
-    what the separate finish launch gives (the training forward still uses that launch: it also wants the gate)."""
+    what the separate finish launch gives (debug knob 16 selects it); the training forward takes the same path and also gets its
+    gate (1 where the batch mean of a channel's KL exceeds kl_min) from there."""
     B, HW = cfg
     rng = np.random.RandomState(90 + B + HW)
     params = {k: dev(v) for k, v in gi.ar_multiconv2d_params(rng, 32, [160, 160], [32, 32]).items()}
-    one, two = amd.ARStack(32, [160, 160]), amd.ARStack(32, [160, 160])
-    two.set_training(True)
-    one.prepare(params)
-    two.prepare(params)
+    one, two, three = amd.ARStack(32, [160, 160]), amd.ARStack(32, [160, 160]), amd.ARStack(32, [160, 160])
+    two.set_halo_exchange_debug(16)                               # ... by the finish launch
+    three.set_training(True)
+    for st_ in (one, two, three):
+        st_.prepare(params)
     assert "last workgroup" in one.posterior_block_launches(B, HW, HW) or B * (HW // (2 if HW == 16 else 1)) * 32 > 16384
     g = torch.Generator(device="cuda").manual_seed(B)
     for rep in range(3):
         t = lambda c, s=1.0: s * torch.randn(B, c, HW, HW, device="cuda", generator=g)
         args = [t(32), t(32, .25), t(32), t(32, .25), t(32), t(32, .25), t(160), t(160), t(32)]
         a = one.posterior_block(*args, kl_min)
-        b = two.posterior_block_train(*args, kl_min)
-        assert torch.equal(a["z"], b["z"])
-        assert torch.equal(a["kl_cost"], b["kl_cost"]) and torch.equal(a["kl_obj"], b["kl_obj"])
+        b = two.posterior_block(*args, kl_min)
+        c = three.posterior_block_train(*args, kl_min)
+        for o in (b, c):
+            assert torch.equal(a["z"], o["z"])
+            assert torch.equal(a["kl_cost"], o["kl_cost"]) and torch.equal(a["kl_obj"], o["kl_obj"])
         want = a["kl_cost"].double()
         if kl_min > 0:
             assert float((a["kl_obj"] - a["kl_obj"][0]).abs().max()) == 0.0
