@@ -1007,3 +1007,36 @@ def test_round4_elementwise_entry_points_vs_torch(amd):
                                                               _ptr(d_uc1), B, n_h, n_z, H * W, _stream()))
             up_h = host(d_up)[:, :n_h] if with_up else np.zeros((B, n_h, H, W))
             np.testing.assert_allclose(host(d_uc1), np.concatenate([up_h, host(dz0), host(dz0) * (host(z0) - host(qm)) - Gr, host(dctx)], axis=1), atol=2e-5)
+
+
+def test_prep_batch_eager_after_a_capture_with_other_tensors(amd):
+    """a captured iaf_prep_batch_run freezes its descriptors in a table of its own and leaves the caller's host copy
+    holding the CAPTURE's pointers; the next eager run with those same pointers found "nothing changed" and kept the eager device
+    table of the run BEFORE the capture -- stale V / g / b pointers.  Sequence: eager(X) -> capture(Y) -> eager(Y): the eager run
+    must now read Y.  (ADVICE r03 #3 rides along: re-capturing the same tensors shares a table, so many captures of one pointer
+    set do not run out of the 16 slots.)"""
+    B, n_z, n_h, d, H = 2, 32, 64, 1, 8
+    pX, z, ctx = _rand_case(41, B, n_z, n_h, d, H, H)
+    pY, _, _ = _rand_case(42, B, n_z, n_h, d, H, H)
+    dX, dY = dev_params(pX), dev_params(pY)
+    stack = amd.ARStack(n_z, [n_h] * d)
+    stack.prepare(dX)
+    prep = amd.PrepBatch([stack])
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        prep.run([dX])                                            # eager: the eager device table holds X
+        s.synchronize()
+        for _ in range(20):                                       # 20 captures of ONE pointer set: one slot
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                prep.run([dY])                                    # captured: the host copy now holds Y, the eager table still X
+        g.replay()
+        s.synchronize()
+        prep.run([dY])                                            # the run the finding is about: eager, with the capture's pointers -- with the
+                                                                  # stale table it re-derived the packs from X (the replay had left Y's there)
+        s.synchronize()
+        z_new, logsd = stack.iaf_step(dev(z), dev(ctx))
+    torch.cuda.synchronize()
+    ez, es = O.iaf_step(f32(z), f32(ctx), f32_params(pY), [n_h] * d)
+    np.testing.assert_allclose(host(z_new), ez, atol=ATOL, rtol=0)
+    np.testing.assert_allclose(host(logsd), es, atol=ATOL, rtol=0)
