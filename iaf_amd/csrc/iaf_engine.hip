@@ -1204,6 +1204,13 @@ static int launch_fused_step(iaf_stack_t* s, step_fn_t fn, int R, size_t lds, co
             }
         }
     }
+    // posterior block on a recomputing kernel: its form with helper waves, where one is compiled (the 8-pixel BASELINE geometry)
+    if (fin && kl_part && base.mode == MODE_POSTERIOR && !q.xh && !(s->xch_knob & 16u)) {
+        size_t hl = 0;
+        const int var = s->variant == IAF_VARIANT_TF ? 0 : s->variant == IAF_VARIANT_THEANO ? 1 : 2;
+        if (step_fn_t fh = iaf_pick_step_fused_h(s->n_h / 16, s->n_z / 16, s->depth_ar, base.W, R, var, &hl))
+            if (hl == lds) fn = fh;
+    }
     { int rc = raise_lds_cap((const void*)fn, lds); if (rc) return rc; }
     // The free-bits reductions inside the launch: kernels with helper waves, a table one workgroup can walk (the bounds of the
     // single-workgroup finish launch), n_z <= 64 channels and a set of counters for this stream (none inside a capture that was

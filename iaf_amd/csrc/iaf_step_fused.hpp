@@ -134,18 +134,19 @@ constexpr int tri_live(int ntw, int nfull, int nht, int c, int gn, int gi) {
     return m;
 }
 
-// Which instantiations run with helper waves (512 threads, 256 registers per wave; see the kernel): every exchange-form kernel, and
-// the BASELINE run's 8-pixel geometry (n_h = 160, n_z = 32), where the helpers stage the context rows.  The launch code reads the
-// thread count off the kernel (hipFuncGetAttributes).
-constexpr bool fused_has_helpers(int nht, int nzt, int w, int xch) { return xch != 0 || (w == 8 && nht == 10 && nzt == 2); }
-
+// HLP: helper waves (512 threads, 256 registers per wave; see the kernel).  Every exchange-form kernel has them (XCH implies HLP); the
+// recomputing kernels of the BASELINE run's 8-pixel geometry exist in both forms: with helpers for the posterior block (their last
+// workgroup does the block's free-bits reductions, StepP::fin_*: 24.0 -> 20.9 us), without for the bare IAF step (same-box rocprof
+// averages of the 8x8 step: 16.62 us without, 16.89 us with -- profiles/r04/experiments/ab_round3_tree_vs_head_same_box.txt).
+// The launch code reads the thread count off the kernel (hipFuncGetAttributes).
 // VAR: the statement of the operator -- 0 TF, 1 Theano (image rotated by 180 degrees + border channel), 2 Theano with
 // flipmask=True (TF geometry + border channel).  Compile time: as run-time flags these cost the TF path ~1 us per launch
 // (branches around the border loads split the epilogue's basic blocks).
-template <int NHT, int NZT, int DEPTH, int W, int R, int VAR = 0, int XCH = 0>
-__global__ __launch_bounds__(fused_has_helpers(NHT, NZT, W, XCH) ? 512 : 256)
-__attribute__((amdgpu_waves_per_eu(fused_has_helpers(NHT, NZT, W, XCH) ? 2 : 1, fused_has_helpers(NHT, NZT, W, XCH) ? 2 : 1))) void iaf_step_fused_kernel(StepP p) {
-    constexpr bool HELP = fused_has_helpers(NHT, NZT, W, XCH);
+template <int NHT, int NZT, int DEPTH, int W, int R, int VAR = 0, int XCH = 0, int HLP = XCH>
+__global__ __launch_bounds__(HLP ? 512 : 256)
+__attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fused_kernel(StepP p) {
+    static_assert(HLP || !XCH, "the exchange form runs with helper waves");
+    constexpr bool HELP = HLP != 0;
     typedef StepGeom<NHT, NZT, DEPTH, W, R, XCH> G;
     // exchanged rows and flags: AGENT scope (sc1: coherent across the XCDs, served by the memory side)
     constexpr int XSCOPE = __HIP_MEMORY_SCOPE_AGENT;

@@ -35,6 +35,26 @@ static step_fn_t inst(int var, size_t* lds, size_t* xrow) {
     }
 }
 
+// the recomputing kernel WITH helper waves (posterior block: the free-bits reductions inside the launch)
+template <int NHT, int NZT, int DEPTH, int W, int R>
+static step_fn_t inst_h(int var, size_t* lds) {
+    typedef StepGeom<NHT, NZT, DEPTH, W, R, 0> G;
+    constexpr bool fits = G::lds_bytes() <= 160 * 1024 && (DEPTH < 2 || G::ctx_bytes() <= (size_t)(G::END - G::HREG1) * 16) &&
+                          (DEPTH % 2 != 0 || G::xb_bytes() <= (size_t)G::HREG1 * 16);
+    if constexpr (!fits) {
+        (void)var;
+        return nullptr;
+    } else {
+        *lds = G::lds_bytes();
+        switch (var) {
+            case 0: return iaf_step_fused_kernel<NHT, NZT, DEPTH, W, R, 0, 0, 1>;
+            case 1: return iaf_step_fused_kernel<NHT, NZT, DEPTH, W, R, 1, 0, 1>;
+            case 2: return iaf_step_fused_kernel<NHT, NZT, DEPTH, W, R, 2, 0, 1>;
+        }
+        return nullptr;
+    }
+}
+
 template <int NHT, int NZT, int DEPTH>
 static step_fn_t inst_wr(int W, int R, int var, size_t* lds) {
     if (W == 16 && R == 2) return inst<NHT, NZT, DEPTH, 16, 2>(var, lds, nullptr);
@@ -52,6 +72,13 @@ static step_fn_t inst_wr(int W, int R, int var, size_t* lds) {
 extern "C" step_fn_t iaf_pick_step_fused_xch(int nht, int nzt, int depth, int W, int R, int var, size_t* lds, size_t* xrow) {
     *lds = 0; *xrow = 0;
     if (nht == 10 && nzt == 2 && depth == 2 && W == 16 && R == 2) return inst<10, 2, 2, 16, 2, 1>(var, lds, xrow);
+    return nullptr;
+}
+// ... with helper waves: the BASELINE run's 8-pixel geometry (same LDS layout as the plain form: call with the plain form's R)
+extern "C" step_fn_t iaf_pick_step_fused_h(int nht, int nzt, int depth, int W, int R, int var, size_t* lds) {
+    *lds = 0;
+    if (nht == 10 && nzt == 2 && depth == 2 && W == 8 && R == 1) return inst_h<10, 2, 2, 8, 1>(var, lds);
+    if (nht == 10 && nzt == 2 && depth == 2 && W == 8 && R == 2) return inst_h<10, 2, 2, 8, 2>(var, lds);
     return nullptr;
 }
 extern "C" step_fn_t iaf_pick_step_fused_a(int nht, int nzt, int depth, int W, int R, int var, size_t* lds) {

@@ -53,6 +53,7 @@ extern "C" step_fn_t iaf_pick_step_fused_b(int nht, int nzt, int depth, int W, i
 // ... in the halo-exchange form (StepP::xh; *xrow = bytes of one exported row); var as above
 extern "C" step_fn_t iaf_pick_step_fused_xch(int nht, int nzt, int depth, int W, int R, int var, size_t* lds, size_t* xrow);
 extern "C" step_fn_t iaf_pick_step_fused_xch_b(int nht, int nzt, int depth, int W, int R, int var, size_t* lds, size_t* xrow);   // depth_ar = 4
+extern "C" step_fn_t iaf_pick_step_fused_h(int nht, int nzt, int depth, int W, int R, int var, size_t* lds);   // recomputing form with helper waves
 extern "C" step_fn_t iaf_pick_step_fused_c(int nht, int nzt, int depth, int W, int R, int var, size_t* lds);   // depth_ar = 3 geometries
 extern "C" step_fn_t iaf_pick_step_fused_xch_c(int nht, int nzt, int depth, int W, int R, int var, size_t* lds, size_t* xrow);
 static inline step_fn_t iaf_pick_step_fused(int nht, int nzt, int depth, int W, int R, int var, size_t* lds) {

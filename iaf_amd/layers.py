@@ -273,7 +273,7 @@ class ARStack(object):
         R = self.step_is_fused(B, H, W)
         if R:
             nrb = -(-H // R)
-            if self.step_exchanges(B, H, W) or (W == 8 and self.n_h == 160 and self.n_z == 32):     # kernels with helper waves
+            if self.step_exchanges(B, H, W) or (W == 8 and self.n_h == 160 and self.n_z == 32 and self.depth_ar == 2):     # kernels with helper waves
                 if B * nrb * self.n_z <= 16384 and B * self.n_z <= 8192:
                     return "1 launch: the one-launch IAF step, whose last workgroup also does the block's free-bits reductions"
             return ("1 one-launch IAF step (its final loop leaves per-row-block KL sums) + %d KL reduction launch(es)"
