@@ -425,6 +425,7 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
                 if (found) { ib = y + 8u * (t / (unsigned)p.nrb); ir = (unsigned)p.nrb - 1u - t % (unsigned)p.nrb; }
                 else xdead |= 2u;                                           // (grid != B * nrb: a host bug -- loud, not a hang)
                 xmail[0] = ib; xmail[1] = ir; xmail[2] = xdead;
+                if (p.dbg) p.dbg[(size_t)blockIdx.x * 32 + 30] = 1ull + (((unsigned long long)y << 32) | t);      // (dev tool: which ticket of which list)
             }
             __syncthreads();
             b = __builtin_amdgcn_readfirstlane((int)xmail[0]);

@@ -51,6 +51,10 @@ if (t[:, 8] != 0).all():      # finer stamps (wave 0): prologue and the two epil
     if (t[:, 12] != 0).all():
         print("    second epilogue: %.0f + barrier %.0f; output pair: K loop %.0f, to the exchange buffer + barrier %.0f, transform + stores %.0f" % (
             m(12, 7), m(3, 12), m(4, 3), m(13, 4), m(5, 13)))
+if (t[:, 30] != 0).any():
+    v = t[:, 30] - 1; lst = (v >> 32).astype(np.int64); tk = (v & 0xffffffff).astype(np.int64); blk = np.arange(len(t))
+    print("    tickets: %d of %d workgroups asked the list blockIdx %% 8; %d of %d drew the ticket blockIdx // 8 (what a static assignment would have given them)" % (
+        int((lst == blk % 8).sum()), len(t), int(((lst == blk % 8) & (tk == blk // 8)).sum()), len(t)))
 if (t[:, 28] != 0).any():
     k = t[(t[:, 28] != 0) & (t[:, 29] != 0) & (t[:, 14] != 0) & (t[:, 18] != 0)]
     if len(k):
