@@ -11,12 +11,15 @@
 // The halo rows are recomputed by the neighbouring workgroup (R = 2, D = 2: the first layer is computed twice, the second
 // 1.5 times); what is bought with that is one launch per step instead of three, no HBM round trip of the hidden
 // activations, no split-K exchange, and weight / context loads of the next phase in flight during the current one.
-// XCH = 1 (round 3; 16-pixel rows): the halo rows are EXCHANGED instead -- every hidden layer computes the R
-// rows its workgroup owns, its region holds one row more, and that row is the first row of the block below, which that block's
-// epilogue also stored to a per-stack buffer in device memory (agent-scope accesses: neighbouring workgroups sit on different
-// XCDs; four flag words per row, one per publishing wave; bounded waits; a workgroup only waits for one dispatched before it).  The layer reading the imported
-// row multiplies the taps of its own rows first (StepPart), so most of the row's ~4 us of travel is covered.  See xch_* below
-// and DESIGN.md 4.1 (round 3's measurements: docs/LAB_NOTEBOOK_r01-r03.md 4.9 item 7).
+// XCH = 1 (16-pixel rows): the halo rows are EXCHANGED instead -- every hidden layer computes the R rows its workgroup owns, its
+// region holds one row more, and that row is the first row of the block below, handed over through a per-stack, per-stream buffer
+// in device memory.  Round 4's form (round 3's: docs/LAB_NOTEBOOK_r01-r03.md 4.9 item 7):
+//   order      a workgroup takes a TICKET and only waits for lower tickets -- nothing rests on dispatch order or placement (xch_take_*);
+//   hand-over  the data is the flag: rows are all-ones between launches, copied LDS -> memory -> LDS in 16-byte coalesced sc1
+//              accesses, re-armed by their consumer (xch_export / xch_import);
+//   who        four HELPER waves per workgroup (HLP), one beside each compute wave, do all of it in vector-memory queues of their
+//              own while the compute waves multiply the taps of their own rows (StepPart) -- the helper section;
+//   failure    bounded waits; a wait that gives up imports NaN and raises a sticky device word and a host-visible one.
 //
 // Arithmetic: the bf16x3 scheme of iaf_conv_bf3.hpp (three bf16 planes per operand, six products, fp32 accumulate) on
 // v_mfma_f32_16x16x32_bf16, reading the same fragment-ordered weight packs (PrepLayer.wp3).
