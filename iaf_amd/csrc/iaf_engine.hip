@@ -373,6 +373,9 @@ extern "C" int iaf_stack_create(iaf_stack_t** out, int n_z, int n_h, int depth_a
     iaf_stack* s = new (std::nothrow) iaf_stack();
     if (!s) return (int)hipErrorOutOfMemory;
     s->generic = generic;
+    // IAF_XCH_DEBUG=<bits>: every stack starts with these iaf_stack_set_halo_exchange_debug bits (1 = scrambled work lists, 2 = random
+    // delays, 16 = free-bits finish as its own launch) -- how the whole GPU suite is run under a scrambled hand-over order
+    if (const char* e = getenv("IAF_XCH_DEBUG")) s->xch_knob = (unsigned)atoi(e) & (1u | 2u | 16u);
     s->n_z = n_z; s->n_h = n_h; s->depth_ar = depth_ar; s->variant = variant;
     s->nlayers = depth_ar + 1;
     s->prepared = false;

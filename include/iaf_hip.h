@@ -349,7 +349,8 @@ int iaf_stack_set_halo_exchange(iaf_stack_t* s, int on);
  * workgroups take from other lists), 2 = workgroups delay their ticket by pseudo-random amounts (tickets out of dispatch
  * order), 16 = the posterior block's free-bits reductions by the separate finish launch instead of the step launch's
  * last workgroup (to compare the two), 8 = fault injection: the bottom row block of image 0 never hands over its first hidden row and waits are short, so
- * the block above it gives up.  0 = production. */
+ * the block above it gives up.  0 = production.  IAF_XCH_DEBUG=<bits 1|2|16> in the environment: every stack is created with
+ * these bits set (the whole GPU suite under a scrambled hand-over order: profiles/r04/pytest_gpu_scrambled.txt). */
 int iaf_stack_set_halo_exchange_debug(iaf_stack_t* s, unsigned knobs);
 /* 1 if the step at this size runs as one launch in the halo-exchange form, else 0 */
 int iaf_stack_step_exchanges(const iaf_stack_t* s, int B, int H, int W);
