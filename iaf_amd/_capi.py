@@ -128,6 +128,10 @@ SIGNATURES = {
     "iaf_conv3x3_forward": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, ctypes.POINTER(_vp),
                                            ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                            ctypes.c_int, _vp]),
+    "iaf_conv3x3_forward_stride2": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_int),
+                                                   ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
+    "iaf_conv3x3_forward_deconv": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int, ctypes.c_int,
+                                                  ctypes.c_int, _vp]),
     "iaf_conv3x3_prep_batch_create": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.c_int]),
     "iaf_conv3x3_prep_batch_run": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp]),
     "iaf_conv3x3_prep_batch_destroy": (ctypes.c_int, [_vp]),

@@ -155,6 +155,14 @@ extern "C" int iaf_conv3x3_prepare_deconv(iaf_conv3x3_t* c, const float* V, cons
     hipLaunchKernelGGL(iaf_deconv_pack_kernel, dim3(blocks), dim3(256), 0, st, V, g, b, (const float*)inv_norm, L.wp, L.bias,
                        L.cin, L.cout, L.ncot, c->generic ? 1 : 0, (c->training && !c->generic) ? L.wpt : nullptr);
     HIP_TRY(hipGetLastError());
+    if (L.wp3 && !c->generic && L.nchunk % 2 == 0) {   // the same pack as three bf16 planes (iaf_conv3x3_forward_deconv): wp has the layout
+        PackT3Args a;                                  // iaf_pack_t3_kernel reads ([K chunk][tap][N tile][lane][4])
+        memset(&a, 0, sizeof(a));
+        a.L[0].src = L.wp; a.L[0].dst = L.wp3; a.L[0].ntp = MAXTAPS; a.L[0].nct = L.ncot; a.L[0].begin = 0;
+        a.n = 1; a.total = (L.nchunk / 2) * MAXTAPS * L.ncot * 64;
+        hipLaunchKernelGGL(iaf_pack_t3_kernel, dim3((a.total + 255) / 256), dim3(256), 0, st, a);
+        HIP_TRY(hipGetLastError());
+    }
     if (c->training && !c->generic) {           // ... and its bf16x3 form for the data gradient
         PackT3Batch tb(st);
         int rc = tb.add(L, MAXTAPS);
@@ -452,6 +460,139 @@ extern "C" int iaf_conv3x3_forward(iaf_conv3x3_t* c, const float* x, const float
     }
     return conv3x3_launch(L, p, c->mask_mode ? EPI_PLAIN5 : EPI_PLAIN, IN_NCHW, c->mask_mode != 0, false, st, c->variant,
                           (c->precision == IAF_PRECISION_BF16X3 && !c->deconv) ? c->bf3_choice : 3);
+}
+
+// ---- the downsampling IAFLayer's two strided convs at their minimal work (iaf_conv_bf3.hpp, template parameter S2) ------------
+extern "C" conv_fn_t iaf_pick_bf3s_2_1_4_1(int nt, int s2);
+extern "C" conv_fn_t iaf_pick_bf3s_4_1_4_1(int nt, int s2);
+extern "C" conv_fn_t iaf_pick_bf3s_2_1_4_2(int nt, int s2);
+static conv_fn_t pick_bf3_s2(int nt, int ppw, int ks, int wco, int s2) {
+    if (ppw == 2 && ks == 4 && wco == 1) return iaf_pick_bf3s_2_1_4_1(nt, s2);
+    if (ppw == 4 && ks == 4 && wco == 1) return iaf_pick_bf3s_4_1_4_1(nt, s2);
+    if (ppw == 2 && ks == 4 && wco == 2) return iaf_pick_bf3s_2_1_4_2(nt, s2);
+    return nullptr;
+}
+// launch shape (nt, ppw, ks, wco; pxt = 1) of a strided conv: the first compiled one that divides the co tiles and fits LDS.
+// IAF_S2_SHAPE / IAF_DECONV_SHAPE="nt,ppw,ks,wco": dev override.
+static conv_fn_t s2_shape(const GemmLayer& L, int s2, int W, int* sh, size_t* lds_out) {
+    static const int cand[2][6][4] = {
+        {{4, 2, 4, 2}, {5, 2, 4, 2}, {2, 2, 4, 2}, {4, 2, 4, 1}, {5, 2, 4, 1}, {2, 2, 4, 1}},       // stride 2: 32 output pixels (4 x 32 staged)
+        {{5, 4, 4, 1}, {4, 4, 4, 1}, {2, 4, 4, 1}, {5, 2, 4, 2}, {4, 2, 4, 2}, {2, 2, 4, 2}}};      // deconv: 64 input pixels
+    int env[4] = {0, 0, 0, 0};
+    const char* e = getenv(s2 == 1 ? "IAF_S2_SHAPE" : "IAF_DECONV_SHAPE");
+    const bool has_env = e && sscanf(e, "%d,%d,%d,%d", &env[0], &env[1], &env[2], &env[3]) == 4;
+    for (int i = has_env ? -1 : 0; i < 6; ++i) {
+        const int* q = i < 0 ? env : cand[s2 - 1][i];
+        const int nt = q[0], ppw = q[1], ks = q[2], wco = q[3];
+        if (nt <= 0 || wco <= 0 || L.ncot % (nt * wco) != 0) continue;
+        conv_fn_t fn = pick_bf3_s2(nt, ppw, ks, wco, s2);
+        if (!fn) continue;
+        const int tm = 16 * ppw;
+        const size_t slots = s2 == 1 ? (size_t)4 * tm + 2 * W + 2 + 1 : (size_t)tm + W + 1 + 1;
+        const size_t tile = slots * (3 * (L.cin / 8) + 2) * 16;
+        const size_t red = (size_t)wco * ks * ppw * nt * 1024;
+        const size_t lds = tile > red ? tile : red;
+        if (lds > 160 * 1024) continue;
+        sh[0] = nt; sh[1] = ppw; sh[2] = ks; sh[3] = wco;
+        *lds_out = lds;
+        return fn;
+    }
+    return nullptr;
+}
+
+// y = conv2d(name, [elu](x), n_out, stride=[2,2]) (tf_train.py:33,36; layers.py:31-64: SAME, so window (i,j) covers input rows 2i..2i+2)
+// split into n_outs tensors like iaf_conv3x3_forward.  x [B,n_in,2H,2W]; H, W = the OUTPUT size.  Nine taps per c_in on H x W pixels --
+// a quarter of the stride-1 conv + subsampling it replaces.  IAF_ERR_UNSUPPORTED when the four staged phase tiles do not fit LDS
+// (then: iaf_conv3x3_forward at [2H,2W] + iaf_resample2 DOWN_ODD, the same numbers).
+extern "C" int iaf_conv3x3_forward_stride2(iaf_conv3x3_t* c, const float* x, int elu_input, float* const* outs, const int* out_channels,
+                                           int n_outs, int B, int H, int W, void* stream) {
+    if (!c || !x || !outs || !out_channels) return IAF_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0 || n_outs < 1 || n_outs > MAXSPLIT) return IAF_ERR_SHAPE;
+    if ((long long)B * H * W > (1LL << 30) / 64) return IAF_ERR_SHAPE;
+    if (!c->prepared) return IAF_ERR_NOT_PREPARED;
+    int tot = 0, ends[MAXSPLIT];
+    for (int k = 0; k < n_outs; ++k) {
+        if (!outs[k]) return IAF_ERR_NULL;
+        if (out_channels[k] <= 0) return IAF_ERR_SHAPE;
+        tot += out_channels[k];
+        ends[k] = tot;
+    }
+    if (tot != c->n_out) return IAF_ERR_SHAPE;
+    GemmLayer& L = c->L;
+    if (c->generic || c->mask_mode || c->deconv || !L.wp3 || c->precision != IAF_PRECISION_BF16X3) return IAF_ERR_UNSUPPORTED;
+    for (int k = 0; k < n_outs; ++k)
+        if (ends[k] & 3) return IAF_ERR_UNSUPPORTED;
+    int sh[4]; size_t lds = 0;
+    conv_fn_t fn = s2_shape(L, 1, W, sh, &lds);
+    if (!fn) return IAF_ERR_UNSUPPORTED;
+    ConvP p;
+    memset(&p, 0, sizeof(p));
+    p.B = B; p.H = H; p.W = W; p.HW = H * W; p.P = B * H * W;
+    p.x = x; p.in_elu = elu_input ? 1 : 0;
+    p.nsplit = n_outs;
+    for (int k = 0; k < MAXSPLIT; ++k) {
+        p.split_end[k] = ends[k < n_outs ? k : n_outs - 1];
+        p.split_ptr[k] = outs[k < n_outs ? k : n_outs - 1];
+    }
+    const int tm = 16 * sh[1];
+    p.wp = (const float*)L.wp3; p.bias = L.bias;
+    p.s2_pb[0] = 0; p.s2_pb[1] = tm + W + 1; p.s2_pb[2] = p.s2_pb[1] + tm + W; p.s2_pb[3] = p.s2_pb[2] + tm + 1;
+    p.nslot = p.s2_pb[3] + tm;
+    p.halo_before = 0;
+    for (int t = 0; t < MAXTAPS; ++t) {
+        const int di = t / 3, dj = t % 3;
+        p.tap_dh[t] = di >> 1; p.tap_dw[t] = dj >> 1;
+        p.tap_off[t] = p.s2_pb[(di & 1) * 2 + (dj & 1)] + (di >> 1) * W + (dj >> 1);
+    }
+    p.cin = L.cin; p.cout = L.cout; p.nchunk = L.nchunk; p.ncot = L.ncot; p.cp = L.cin + 8;
+    int rc = raise_lds_cap((const void*)fn, lds);
+    if (rc) return rc;
+    dim3 grid((p.P + tm - 1) / tm, L.ncot / (sh[0] * sh[3]));
+    p.gx = (int)grid.x;
+    p.lds_bytes = (int)lds;
+    hipLaunchKernelGGL(fn, grid, dim3(64 * sh[2] * sh[3]), lds, (hipStream_t)stream, p);
+    return (int)hipGetLastError();
+}
+
+// out = [residual upsampled +] 0.1 x deconv2d(name, [elu](concat(x[:, :c_split], x2)), n_out) (tf_train.py:87-94; layers.py:83-112) for a
+// conv prepared by iaf_conv3x3_prepare_deconv.  x (, x2) [B,.,H,W] -- H, W = the INPUT size --, out [B,n_out,2H,2W], residual
+// [B,n_out,H,W] or NULL (without it: out = the deconv itself).  Each of the four output phases (2i+a, 2j+b) is a conv of the
+// low-resolution input with the 4 / 2 / 2 / 1 filter taps that meet non-zero rows of the zero-inserted image: nine taps per input pixel
+// instead of 36.  IAF_ERR_UNSUPPORTED: run iaf_conv3x3_forward on the zero-inserted inputs (same numbers up to fp32 rounding).
+extern "C" int iaf_conv3x3_forward_deconv(iaf_conv3x3_t* c, const float* x, const float* x2, int c_split, int elu_input,
+                                          const float* residual, float* out, int B, int H, int W, void* stream) {
+    if (!c || !x || !out) return IAF_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0) return IAF_ERR_SHAPE;
+    if ((long long)B * H * W > (1LL << 30) / 256) return IAF_ERR_SHAPE;
+    if (!c->prepared) return IAF_ERR_NOT_PREPARED;
+    if (x2 && (c_split <= 0 || c_split >= c->n_in)) return IAF_ERR_SHAPE;
+    GemmLayer& L = c->L;
+    if (!c->deconv) return IAF_ERR_NOT_PREPARED;
+    if (c->generic || c->mask_mode || !L.wp3 || L.nchunk % 2 != 0 || c->precision != IAF_PRECISION_BF16X3) return IAF_ERR_UNSUPPORTED;
+    if ((x2 && (c_split & 3)) || (L.cout & 3)) return IAF_ERR_UNSUPPORTED;
+    int sh[4]; size_t lds = 0;
+    conv_fn_t fn = s2_shape(L, 2, W, sh, &lds);
+    if (!fn) return IAF_ERR_UNSUPPORTED;
+    ConvP p;
+    memset(&p, 0, sizeof(p));
+    p.B = B; p.H = H; p.W = W; p.HW = H * W; p.P = B * H * W;
+    p.x = x; p.x2 = x2; p.c_split = c_split; p.in_elu = elu_input ? 1 : 0; p.res = residual;
+    p.nsplit = 1;
+    for (int k = 0; k < MAXSPLIT; ++k) { p.split_end[k] = c->n_out; p.split_ptr[k] = out; }
+    const int tm = 16 * sh[1];
+    p.wp = (const float*)L.wp3; p.bias = L.bias;
+    // tap (di,dj) of the rotated filter on the zero-inserted image = rows i-1 (di = 0) or i (di = 1, 2) of the input
+    for (int t = 0; t < MAXTAPS; ++t) { p.tap_dh[t] = (t / 3 == 0) ? -1 : 0; p.tap_dw[t] = (t % 3 == 0) ? -1 : 0; }
+    p.halo_before = W + 1;
+    p.nslot = tm + W + 1;
+    p.cin = L.cin; p.cout = L.cout; p.nchunk = L.nchunk; p.ncot = L.ncot; p.cp = L.cin + 8;
+    int rc = raise_lds_cap((const void*)fn, lds);
+    if (rc) return rc;
+    dim3 grid((p.P + tm - 1) / tm, L.ncot / (sh[0] * sh[3]), 4);
+    p.gx = (int)grid.x;
+    p.lds_bytes = (int)lds;
+    hipLaunchKernelGGL(fn, grid, dim3(64 * sh[2] * sh[3]), lds, (hipStream_t)stream, p);
+    return (int)hipGetLastError();
 }
 
 // arithmetic of the forward conv: IAF_PRECISION_BF16X3 (default: split products on the bf16 matrix cores where a launch

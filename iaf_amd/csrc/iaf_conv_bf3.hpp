@@ -59,7 +59,15 @@ __device__ __forceinline__ void bf3_store4(char* smem, int slot, int q, f32x4 v,
 
 // NTP_: taps of the filter -- the 5 live ones of a MADE-masked conv, or all 9 of a plain conv2d (EPI_PLAIN: the convs
 // around the IAF step, tf_train.py:36,41,53,93; halo on both sides of the pixel tile)
-template <int NT, int PPW, int PXT, int KS, int INMODE, int EPI, int WCO = 1, int NTP_ = NTAPS>
+// S2: the two strided convs of the downsampling IAFLayer at their minimal work, on the 9-tap pack as it is:
+//   1  conv2d(stride 2, SAME) (tf_train.py:33,36; layers.py:31-64): out[i,j] = sum_{di,dj} x[2i+di, 2j+dj] V[di,dj].  With the four phase
+//      images x_ab[i][j] = x[2i+a][2j+b] staged side by side in LDS, tap (di,dj) is a unit-stride tap (di>>1, dj>>1) into phase
+//      (di&1, dj&1): nine steps per c_in pair as for a stride-1 conv, on a quarter of the pixels.  p.H, p.W = the OUTPUT grid.
+//   2  deconv2d(stride 2, SAME) (tf_train.py:89-91; layers.py:83-112) = the stride-1 conv of the zero-inserted input with the
+//      rotated filter (iaf_kernels_resample.hpp): output phase (a,b) = pixels (2i+a, 2j+b) only meets taps with di = a (mod 2)...
+//      precisely di in {0,2} (rows i-1, i) when a = 0, di = 1 (row i) when a = 1 -- 4, 2, 2, 1 taps for the four phases, nine in
+//      all.  blockIdx.z = the phase; the staged tile is the ordinary low-resolution one.  p.H, p.W = the INPUT grid.
+template <int NT, int PPW, int PXT, int KS, int INMODE, int EPI, int WCO = 1, int NTP_ = NTAPS, int S2 = 0>
 __global__ __launch_bounds__(64 * PXT * KS * WCO) void iaf_conv_bf3_kernel(ConvP p) {
     extern __shared__ __attribute__((aligned(16))) f32x4 smem4[];
     char* smem = (char*)smem4;
@@ -87,6 +95,19 @@ __global__ __launch_bounds__(64 * PXT * KS * WCO) void iaf_conv_bf3_kernel(ConvP
     if constexpr (INMODE == IN_POSTERIOR || EPI == EPI_OUT)
         asm volatile("" ::"s"(p.qm), "s"(p.ql), "s"(p.rm), "s"(p.rl), "s"(p.pm), "s"(p.pl), "s"(p.eps), "s"(p.kl_elem));
     const int HW = p.HW, W = p.W;
+    // S2 = 2: this workgroup's output phase and its tap list: tap k of the list = (di, dj) = (a ? 1 : 2 (k >> lgb), b ? 1 : 2 (k & nb-1))
+    const int ph_a = S2 == 2 ? (int)(blockIdx.z >> 1) : 0, ph_b = S2 == 2 ? (int)(blockIdx.z & 1) : 0;
+    const int lgb = ph_b ? 0 : 1, lgt = (ph_a ? 0 : 1) + lgb;      // log2 of the list's length
+    auto step_pair = [&](int sc) __attribute__((always_inline)) -> int { return S2 == 2 ? sc >> lgt : sc / NTP; };
+    auto step_tap = [&](int sc, int pair) __attribute__((always_inline)) -> int {                 // the tap of the 9-tap pack step sc multiplies
+        if constexpr (S2 == 2) {
+            const int k = sc & ((1 << lgt) - 1);
+            const int di = ph_a ? 1 : 2 * (k >> lgb), dj = ph_b ? 1 : 2 * (k & ((1 << lgb) - 1));
+            return di * 3 + dj;
+        } else {
+            return sc - pair * NTP;
+        }
+    };
     const int cin8 = p.cin >> 3;           // one plane of one slot, in 16-byte units
     const int s16 = 3 * cin8 + 2;          // slot stride in 16-byte units (3 planes + 32 B pad)
     const int npair = p.nchunk >> 1;       // c_in / 32
@@ -115,21 +136,23 @@ __global__ __launch_bounds__(64 * PXT * KS * WCO) void iaf_conv_bf3_kernel(ConvP
 
     // ================= prologue (2): weight ring ======================================================================
     // step s = pair * 5 + tap; wave kh owns steps [s0, s1).  One step = NT tiles x 3 planes x 1 KiB, contiguous.
-    const int S = npair * NTP;
+    const int S = S2 == 2 ? npair << lgt : npair * NTP;
     const int s0 = (kh * S) / KS, s1 = ((kh + 1) * S) / KS;
     const size_t wstep = (size_t)p.ncot * 3 * 64;                               // f32x4 per step
     const f32x4* wbase = (const f32x4*)p.wp + (size_t)cot0 * 3 * 64 + lane;    // this wave's tiles, this lane's 16 bytes
     f32x4 wr[U][NT][3];
     // fragments [lo, hi) of step s -> ring slot I (a step's refill is issued in PPW parts, one per pixel-tile group of
     // MFMAs, so that the loads sit BETWEEN the MFMAs instead of in a cluster that starves the pipe)
-    auto load_part = [&](auto slot_c, auto lo_c, auto hi_c, int s) {
+    auto load_part = [&](auto slot_c, auto lo_c, auto hi_c, int s) __attribute__((always_inline)) {
         constexpr int I = decltype(slot_c)::value, LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
         const int sc = s < s1 ? s : s1 - 1;                                     // clamped: branch-free, redundant at the tail
-        const f32x4* q = wbase + (size_t)sc * wstep;
+        int ws = sc;
+        if constexpr (S2 == 2) { const int pr = step_pair(sc); ws = pr * NTP + step_tap(sc, pr); }
+        const f32x4* q = wbase + (size_t)ws * wstep;
 #pragma unroll
         for (int f = LO; f < HI; ++f) wr[I][f / 3][f % 3] = q[f * 64];
     };
-    auto load_step = [&](auto slot_c, int s) {
+    auto load_step = [&](auto slot_c, int s) __attribute__((always_inline)) {
         load_part(slot_c, std::integral_constant<int, 0>{}, std::integral_constant<int, NT * 3>{}, s);
     };
     static_for<RD>([&](auto i) { load_step(i, s0 + decltype(i)::value); });
@@ -210,6 +233,44 @@ __global__ __launch_bounds__(64 * PXT * KS * WCO) void iaf_conv_bf3_kernel(ConvP
 #pragma unroll
             for (int u = 0; u < 4; ++u)
                 if (dsl[u] >= 0) bf3_store4(region, dsl[u], dq[u], v4[u], s16_, cin8_);
+        }
+    };
+
+    // S2 = 1: the four phase images of [elu](x), x [B,c_in,2H,2W]: slot s2_pb[2a+b] + l holds x[:, 2i+a, 2j+b] of output pixel P0 + l
+    auto stage_s2d = [&]() {
+        const int nq_ = p.cin >> 2, nsl = p.nslot, nit = nsl * nq_;
+        const int W2 = 2 * W;
+        const size_t HW4 = 4 * (size_t)HW;
+        for (int base = tid; base < nit; base += 4 * NTHREADS) {
+            int dq[4], dsl[4];
+            f32x4 v4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * NTHREADS;
+                dsl[u] = -1; dq[u] = 0;
+                v4[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (idx < nit) {
+                    const int q = idx / nsl, sl = idx - q * nsl;               // slot fastest: coalesced along pixels
+                    const int ph = (sl >= p.s2_pb[1] ? 1 : 0) + (sl >= p.s2_pb[2] ? 1 : 0) + (sl >= p.s2_pb[3] ? 1 : 0);
+                    const int pb = ph == 0 ? 0 : (ph == 1 ? p.s2_pb[1] : (ph == 2 ? p.s2_pb[2] : p.s2_pb[3]));
+                    const int Pg = P0 + (sl - pb);
+                    dsl[u] = sl; dq[u] = q;
+                    if (Pg < p.P) {
+                        const int b = Pg / HW, ppx = Pg - b * HW;
+                        const int i = ppx / W, j = ppx - i * W;
+                        const size_t gb = ((size_t)b * p.cin + 4 * q) * HW4 + (size_t)(2 * i + (ph >> 1)) * W2 + 2 * j + (ph & 1);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v4[u][r] = p.x[gb + (size_t)r * HW4];
+                        if (p.in_elu) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v4[u][r] = elu_f(v4[u][r]);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (dsl[u] >= 0) bf3_store4(smem, dsl[u], dq[u], v4[u], s16, cin8);
         }
     };
 
@@ -341,6 +402,8 @@ __global__ __launch_bounds__(64 * PXT * KS * WCO) void iaf_conv_bf3_kernel(ConvP
                 const int sl = (int)(((float)f + 0.5f) * rnq);
                 bf3_store4(smem, sl, f - sl * nq, (f >= flo && f < fhi) ? src[f] : f32x4{0.f, 0.f, 0.f, 0.f}, s16, cin8);
             }
+        } else if (S2 == 1) {
+            stage_s2d();
         } else if (INMODE == IN_NCHW || INMODE == IN_POSTERIOR) {
             stage_nchw(smem, p.nslot, p.cin, s16, cin8, p.x, INMODE == IN_POSTERIOR);
         }
@@ -357,16 +420,26 @@ __global__ __launch_bounds__(64 * PXT * KS * WCO) void iaf_conv_bf3_kernel(ConvP
         for (int t = 0; t < NT; ++t) acc[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // x operand address of (pixel tile q, step s): tap and pair are wave-uniform
-    auto xaddr = [&](auto q_c, int s) -> int {
+    auto xaddr = [&](auto q_c, int s) __attribute__((always_inline)) -> int {
         constexpr int q = decltype(q_c)::value;
         const int sc = s < s1 ? s : s1 - 1;
-        const int pair = sc / NTP, tap = sc - pair * NTP;
-        int dh = p.tap_dh[0], dw = p.tap_dw[0];                      // scalar selects on kernel arguments
-        static_for<NTP - 1>([&](auto t_c) {
-            constexpr int t = decltype(t_c)::value + 1;
-            dh = tap == t ? p.tap_dh[t] : dh; dw = tap == t ? p.tap_dw[t] : dw;
-        });
-        const int toff = (dh * W + dw) * s16;
+        const int pair = step_pair(sc), tap = step_tap(sc, pair);
+        int toff;
+        if constexpr (S2 == 1) {
+            int to = p.tap_off[0];
+            static_for<NTP - 1>([&](auto t_c) {
+                constexpr int t = decltype(t_c)::value + 1;
+                to = tap == t ? p.tap_off[t] : to;
+            });
+            toff = to * s16;
+        } else {
+            int dh = p.tap_dh[0], dw = p.tap_dw[0];                      // scalar selects on kernel arguments
+            static_for<NTP - 1>([&](auto t_c) {
+                constexpr int t = decltype(t_c)::value + 1;
+                dh = tap == t ? p.tap_dh[t] : dh; dw = tap == t ? p.tap_dw[t] : dw;
+            });
+            toff = (dh * W + dw) * s16;
+        }
         const int mask = -(int)((xvalid[q] >> tap) & 1u);              // all ones when the tap is inside the image
         return zaddr + pair * 4 + (mask & (xbase[q] + toff - zaddr));  // branch-free: a ?: here becomes control flow
     };
@@ -375,7 +448,7 @@ __global__ __launch_bounds__(64 * PXT * KS * WCO) void iaf_conv_bf3_kernel(ConvP
         const int a = xaddr(std::integral_constant<int, 0>{}, s0);
         xn[0] = smem4[a]; xn[1] = smem4[a + cin8]; xn[2] = smem4[a + 2 * cin8];
     }
-    auto step_body = [&](auto slot_c, int s) {
+    auto step_body = [&](auto slot_c, int s) __attribute__((always_inline)) {
         constexpr int I = decltype(slot_c)::value;
         static_for<PPW>([&](auto q_c) {
             constexpr int q = decltype(q_c)::value;
@@ -435,6 +508,7 @@ __global__ __launch_bounds__(64 * PXT * KS * WCO) void iaf_conv_bf3_kernel(ConvP
         const int item = kh + i * KS;
         const int q = item / NUNIT, u = item - q * NUNIT;
         g[i] = epi_geom(p, P0 + (pw * PPW + q) * 16 + pl, kk, item < NITEM);
+        if constexpr (S2 == 2) g[i].up = 4 + 2 * ph_a + ph_b;
         epi_load<EPI>(p, g[i], cot0 + u * TPU, ops[i]);
     }
     f32x4 val[NMY][TPU];

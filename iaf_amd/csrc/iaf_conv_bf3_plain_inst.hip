@@ -31,3 +31,21 @@ extern "C" conv_fn_t IAF_CAT(iaf_pick_bf3p_, IAF_PPW, IAF_PXT, IAF_KS, IAF_WCO)(
     }
     return nullptr;
 }
+
+// the downsampling layer's strided convs at their minimal work (iaf_conv_bf3.hpp, S2): s2 = 1 conv2d stride 2, 2 deconv2d by phases
+extern "C" conv_fn_t IAF_CAT(iaf_pick_bf3s_, IAF_PPW, IAF_PXT, IAF_KS, IAF_WCO)(int nt, int s2) {
+    if (s2 == 1) {
+        switch (nt) {
+            case 2: return iaf_conv_bf3_kernel<2, IAF_PPW, IAF_PXT, IAF_KS, IN_NCHW, EPI_PLAIN, IAF_WCO, MAXTAPS, 1>;
+            case 4: return iaf_conv_bf3_kernel<4, IAF_PPW, IAF_PXT, IAF_KS, IN_NCHW, EPI_PLAIN, IAF_WCO, MAXTAPS, 1>;
+            case 5: return iaf_conv_bf3_kernel<5, IAF_PPW, IAF_PXT, IAF_KS, IN_NCHW, EPI_PLAIN, IAF_WCO, MAXTAPS, 1>;
+        }
+    } else if (s2 == 2) {
+        switch (nt) {
+            case 2: return iaf_conv_bf3_kernel<2, IAF_PPW, IAF_PXT, IAF_KS, IN_NCHW, EPI_PLAIN, IAF_WCO, MAXTAPS, 2>;
+            case 4: return iaf_conv_bf3_kernel<4, IAF_PPW, IAF_PXT, IAF_KS, IN_NCHW, EPI_PLAIN, IAF_WCO, MAXTAPS, 2>;
+            case 5: return iaf_conv_bf3_kernel<5, IAF_PPW, IAF_PXT, IAF_KS, IN_NCHW, EPI_PLAIN, IAF_WCO, MAXTAPS, 2>;
+        }
+    }
+    return nullptr;
+}

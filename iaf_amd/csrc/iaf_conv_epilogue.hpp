@@ -22,6 +22,7 @@ struct EpiGeom {
     int Pl, bimg, pp, kk;
     bool pvalid;
     unsigned outside;    // bit t: tap t of this lane's pixel falls outside the image (Theano border channel)
+    int up;              // EPI_PLAIN, deconv2d by output phases (iaf_conv_bf3.hpp S2 = 2): 0, or 4 + 2a + b -> store at (2i+a, 2j+b) of a [2H,2W] map
 };
 struct EpiOps {
     f32x4 pre0, pre1, b0, b1;
@@ -35,6 +36,7 @@ __device__ __forceinline__ EpiGeom epi_geom(const ConvP& p, int Pl, int kk, bool
     fast_divmod(Pl, p.HW, 1.0f / (float)p.HW, g.bimg, g.pp);
     fast_divmod(g.pp, p.W, 1.0f / (float)p.W, h, w);
     g.outside = 0;
+    g.up = 0;
 #pragma unroll
     for (int t = 0; t < NTAPS; ++t) {
         const int dh = p.tap_dh[t], dw = p.tap_dw[t];
@@ -106,6 +108,15 @@ __device__ __forceinline__ void epi_apply(const ConvP& p, const EpiGeom& g, int 
 #pragma unroll
         for (int q = 1; q < MAXSPLIT; ++q)      // static indices only: the descriptor stays in SGPRs
             if (q < p.nsplit && co >= p.split_end[q - 1]) { c0 = p.split_end[q - 1]; c1 = p.split_end[q]; base = p.split_ptr[q]; }
+        if (g.up) {                 // one output phase of deconv2d (layers.py:83-112): pixel (i,j) of the [H,W] grid -> (2i+a, 2j+b);
+                                    // the residual is resize_nearest_neighbor(input, 2) (tf_train.py:90,94) = the low-res value
+            const int i = g.pp / p.W, j = g.pp - i * p.W;
+            float* dst = base + ((size_t)g.bimg * (c1 - c0) + (co - c0)) * (4 * (size_t)HW) + (size_t)(2 * i + ((g.up >> 1) & 1)) * (2 * p.W) +
+                         2 * j + (g.up & 1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[(size_t)r * 4 * HW] = p.res ? o.pre0[r] + 0.1f * v[r] : v[r];
+            return;
+        }
         float* dst = base + ((size_t)g.bimg * (c1 - c0) + (co - c0)) * HW + g.pp;
 #pragma unroll
         for (int r = 0; r < 4; ++r) dst[(size_t)r * HW] = p.res ? o.pre0[r] + 0.1f * v[r] : v[r];

@@ -91,6 +91,10 @@ struct ConvP {
     // IN_FUSED0: the fused first layer -- its bf16x3 pack / bias, its NCHW input z (NULL: the posterior sample from
     // qm/rm/ql/rl/eps), its c_in (32) and the context(s) added to its output (layers.py:163-164; tf_train.py:58)
     const void* f_wp; const float* f_bias; const float* f_x; int f_cin; const float* f_ctx; const float* f_ctx2;
+    // bf16x3 kernels with S2 = 1 (conv2d stride 2, tf_train.py:33,36: H, W = the OUTPUT grid, x is [B,c_in,2H,2W]): the staged tile
+    // is four phase tiles x_ab[i][j] = x[2i+a][2j+b]; s2_pb[2a+b] = first slot of phase (a,b), tap_off[t] = slot offset of tap t
+    // = s2_pb[phase of t] + (di>>1) W + (dj>>1), tap_dh / tap_dw = (di>>1, dj>>1) for the border test
+    int s2_pb[4]; int tap_off[MAXTAPS];
 };
 
 // Pin the order "MFMAs with memory instructions spread evenly between them" inside the current scheduling region:

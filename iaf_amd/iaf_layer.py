@@ -55,9 +55,10 @@ class IAFLayer(object):
     def __init__(self, z_size, h_size, depth_ar=2, kl_min=0.25, downsample=False, mode="train"):
         """downsample=True: the first layer of a coarser level (tf_train.py:196) -- up() halves the resolution (stride-2
         up_conv1, residual resize 0.5), down() doubles it (down_deconv2 instead of down_conv2, residual resize 2).
-        The strided ops run on the stride-1 conv kernel (full-resolution conv + subsample; zero-inserted input + rotated
-        filter, csrc/iaf_kernels_resample.hpp), forward and backward (the adjoint resamplings around the same backward
-        kernels; the deconv's weight norm has its own backward launches)."""
+        Forward: the strided forms of the bf16x3 conv kernel (csrc/iaf_conv_bf3.hpp, S2: nine taps per pixel of the coarser
+        grid; WNConv2d.stride2 / .deconv).  Backward: the stride-1 backward kernels between the adjoint resamplings
+        (full-resolution conv + subsample; zero-inserted input + rotated filter, csrc/iaf_kernels_resample.hpp; the deconv's
+        weight norm has its own backward launches)."""
         if mode not in ("train", "init", "sample"):
             raise ValueError("mode must be 'train', 'init' or 'sample' (tf_train.py:60-66), got %r" % (mode,))
         self.z_size, self.h_size, self.kl_min = int(z_size), int(h_size), float(kl_min)
@@ -103,11 +104,12 @@ class IAFLayer(object):
 
     def up(self, inp, autotune=False):
         zs, hs = self.z_size, self.h_size
-        parts = self.up_conv1(inp, elu_input=True, split=[zs, zs, hs, hs], autotune=autotune)             # :35-37
         if self.downsample:
-            # stride [2,2], SAME (:33,36): output (i,j) of the strided conv is output (2i+1, 2j+1) of the stride-1 conv
-            parts = [resample2(t, "down_odd") for t in parts]
+            # stride [2,2], SAME (:33,36): the strided kernel (output (i,j) = output (2i+1, 2j+1) of the stride-1 conv)
+            parts = self.up_conv1.stride2(inp, elu_input=True, split=[zs, zs, hs, hs])
             inp = resample2(inp, "down_even")                                                             # :42-43
+        else:
+            parts = self.up_conv1(inp, elu_input=True, split=[zs, zs, hs, hs], autotune=autotune)         # :35-37
         qz_mean, qz_logsd, up_context, h = parts
         self.posterior.set_up_state(qz_mean, qz_logsd, up_context)                                        # :38
         return self.up_conv3(h, elu_input=True, residual=inp, autotune=autotune)[0]                       # :40-44
@@ -137,10 +139,9 @@ class IAFLayer(object):
                                                               _ptr(rz_logsd), _ptr(eps_eq), z0.numel(), _stream()))
                 blk = po.down(pz_mean, pz_logsd, rz_mean, rz_logsd, down_context, eps_eq)
         if self.downsample:
-            # h = deconv2d(elu(concat(z, h_det))) (:87-91): elu(0) = 0, so the zero-inserted inputs go through the conv's
-            # own ELU / concat staging; input = resize_nearest_neighbor(input, 2) is the residual (:90,94)
-            out = self.down_conv2(resample2(blk["z"], "up_zero_odd"), x2=resample2(h_det, "up_zero_odd"), elu_input=True,
-                                  residual=resample2(inp, "up_nearest"), autotune=autotune)[0]
+            # h = deconv2d(elu(concat(z, h_det))) (:87-91), input = resize_nearest_neighbor(input, 2) the residual (:90,94): the
+            # four output phases as convs of the low-resolution tensors (WNConv2d.deconv)
+            out = self.down_conv2.deconv(blk["z"], x2=h_det, elu_input=True, residual=inp)
         else:
             out = self.down_conv2(blk["z"], x2=h_det, elu_input=True, residual=inp, autotune=autotune)[0]  # :87-94
         self.last_block = blk
@@ -154,11 +155,12 @@ class IAFLayer(object):
 
     def up_train(self, inp, autotune=False):
         zs, hs = self.z_size, self.h_size
-        parts = self.up_conv1(inp, elu_input=True, split=[zs, zs, hs, hs], autotune=autotune)
         res = inp
-        if self.downsample:                                       # as in up(): stride-2 conv = stride-1 conv, subsampled
-            parts = [resample2(t, "down_odd") for t in parts]
+        if self.downsample:                                       # as in up()
+            parts = self.up_conv1.stride2(inp, elu_input=True, split=[zs, zs, hs, hs])
             res = resample2(inp, "down_even")
+        else:
+            parts = self.up_conv1(inp, elu_input=True, split=[zs, zs, hs, hs], autotune=autotune)
         qz_mean, qz_logsd, up_context, h = parts
         self.posterior.set_up_state(qz_mean, qz_logsd, up_context)
         out = self.up_conv3(h, elu_input=True, residual=res, autotune=autotune)[0]
@@ -172,9 +174,9 @@ class IAFLayer(object):
         po = self.posterior
         blk = po.stack.posterior_block_train(po.qz_mean, po.qz_logsd, rz_mean, rz_logsd, pz_mean, pz_logsd, po.up_context,
                                              down_context, eps, self.kl_min)
-        if self.downsample:                                       # as in down(): deconv2d on the zero-inserted inputs
-            zu, hu = resample2(blk["z"], "up_zero_odd"), resample2(h_det, "up_zero_odd")
-            out = self.down_conv2(zu, x2=hu, elu_input=True, residual=resample2(inp, "up_nearest"), autotune=autotune)[0]
+        if self.downsample:                                       # as in down(); the backward builds the zero-inserted inputs it needs
+            zu, hu = None, None
+            out = self.down_conv2.deconv(blk["z"], x2=h_det, elu_input=True, residual=inp)
         else:
             zu, hu = blk["z"], h_det
             out = self.down_conv2(zu, x2=hu, elu_input=True, residual=inp, autotune=autotune)[0]
@@ -198,6 +200,8 @@ class IAFLayer(object):
         # dropped ("down_odd" is the adjoint of "up_zero_odd") -- and d input = the 2x2 block sums of d_out (adjoint of
         # resize_nearest_neighbor(input, 2)); the deconv's own weight norm is differentiated inside conv.backward
         cn = self.last_conv_name
+        if self.downsample:
+            sv["conv2_x"], sv["conv2_x2"] = resample2(sv["z"], "up_zero_odd"), resample2(sv["h_det"], "up_zero_odd")
         (d_z, d_h_det), _, _, _ = self.down_conv2.backward(
             sv["conv2_x"], [d_out], params[cn + "/V"], params[cn + "/g"], x2=sv["conv2_x2"], elu_input=True, dy_scale=0.1,
             grads_out=gslot(cn), autotune=autotune)

@@ -743,6 +743,52 @@ class WNConv2d(object):
         return out
 
 
+    def stride2(self, x, elu_input=False, split=None):
+        """conv2d(..., stride=[2,2]) (tf_train.py:33,36) at its minimal work: x [B,n_in,2H,2W] -> split tensors [B,.,H,W].
+        Shapes the strided kernel does not cover (UnsupportedError from the engine) run as the stride-1 conv subsampled at the
+        odd positions -- the same numbers, four times the multiplies."""
+        _check_act(x, "x")
+        B, c1, H2, W2 = (int(v) for v in x.shape)
+        if c1 != self.n_in or H2 % 2 or W2 % 2:
+            raise ValueError("stride2: x must be [B,%d,even,even], got %r" % (self.n_in, tuple(x.shape)))
+        H, W = H2 // 2, W2 // 2
+        split = [self.n_out] if split is None else [int(v) for v in split]
+        if sum(split) != self.n_out:
+            raise ValueError("split %r does not sum to %d" % (split, self.n_out))
+        out = [torch.empty((B, c, H, W), device=x.device, dtype=torch.float32) for c in split]
+        n = len(split)
+        outs = (ctypes.c_void_p * n)(*[o.data_ptr() for o in out])
+        chans = (ctypes.c_int * n)(*split)
+        rc = _capi.lib().iaf_conv3x3_forward_stride2(self._h, _ptr(x), 1 if elu_input else 0, outs, chans, n, B, H, W, _stream())
+        if rc == _capi.IAF_ERR_UNSUPPORTED:
+            return [resample2(t, "down_odd") for t in self(x, elu_input=elu_input, split=split)]
+        _capi.check(rc)
+        return out
+
+    def deconv(self, x, x2=None, elu_input=False, residual=None):
+        """[residual upsampled + 0.1 *] deconv2d(..., stride 2) (tf_train.py:87-94) of a conv prepared by prepare_deconv, at its
+        minimal work: x (, x2) [B,.,H,W] -> [B,n_out,2H,2W]; residual [B,n_out,H,W] is resize_nearest_neighbor'ed inside.
+        Shapes the phase kernel does not cover run as the stride-1 conv of the zero-inserted inputs (the same numbers)."""
+        _check_act(x, "x")
+        B, c1, H, W = (int(v) for v in x.shape)
+        c_split = 0
+        if x2 is not None:
+            _check_act(x2, "x2", (B, self.n_in - c1, H, W))
+            c_split = c1
+        elif c1 != self.n_in:
+            raise ValueError("x has %d channels, expected %d" % (c1, self.n_in))
+        if residual is not None:
+            _check_act(residual, "residual", (B, self.n_out, H, W))
+        out = torch.empty((B, self.n_out, 2 * H, 2 * W), device=x.device, dtype=torch.float32)
+        rc = _capi.lib().iaf_conv3x3_forward_deconv(self._h, _ptr(x), _ptr(x2), c_split, 1 if elu_input else 0, _ptr(residual),
+                                                    _ptr(out), B, H, W, _stream())
+        if rc == _capi.IAF_ERR_UNSUPPORTED:
+            return self(resample2(x, "up_zero_odd"), x2=None if x2 is None else resample2(x2, "up_zero_odd"), elu_input=elu_input,
+                        residual=None if residual is None else resample2(residual, "up_nearest"))[0]
+        _capi.check(rc)
+        return out
+
+
 def _conv_op(name, x, num_filters, ar_mask, init, init_scale, st):
     n_in = int(x.shape[1])
     with variable_scope(name, st):

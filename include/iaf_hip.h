@@ -511,6 +511,19 @@ int iaf_resample2(const float* src, float* dst, int B, int C, int H, int W, int 
  * conv2d_transpose(SAME, stride 2) + b.  iaf_conv3x3_backward of a conv prepared this way differentiates THIS weight
  * norm (dV in V's [3,3,n_out,n_in] layout) and, when training is on, the prepare also writes the data gradient's pack. */
 int iaf_conv3x3_prepare_deconv(iaf_conv3x3_t* c, const float* V, const float* g, const float* b, void* stream);
+/* The two strided convs at their minimal work (nine taps per pixel of the SMALLER grid; bf16x3 kernels only).
+ * iaf_conv3x3_forward_stride2: y = conv2d(name, [elu](x), n_out, stride=[2,2]) (tf_train.py:33,36; tf_utils/layers.py:31-64), split into
+ *   n_outs tensors like iaf_conv3x3_forward.  x [B,n_in,2H,2W]; H, W = the OUTPUT size; outs[k] [B,out_channels[k],H,W].
+ * iaf_conv3x3_forward_deconv: out = [residual +] 0.1 * deconv2d(name, [elu](concat(x[:, :c_split], x2)), n_out) (tf_train.py:87-94;
+ *   tf_utils/layers.py:83-112) of a conv prepared by iaf_conv3x3_prepare_deconv.  x, x2 [B,.,H,W] (H, W = the INPUT size), out
+ *   [B,n_out,2H,2W], residual [B,n_out,H,W] (added to all four pixels of its 2x2 block: resize_nearest_neighbor(input, 2),
+ *   tf_train.py:90) or NULL (then out = the deconv itself, unscaled).
+ * Both return IAF_ERR_UNSUPPORTED for shapes their tiles do not cover (fp32 precision pinned, c_in not a multiple of 32, an LDS tile
+ * over 160 KiB): the caller then uses iaf_conv3x3_forward + iaf_resample2 (DOWN_ODD / UP_ZERO_ODD), which computes the same numbers. */
+int iaf_conv3x3_forward_stride2(iaf_conv3x3_t* c, const float* x, int elu_input, float* const* outs, const int* out_channels,
+                                int n_outs, int B, int H, int W, void* stream);
+int iaf_conv3x3_forward_deconv(iaf_conv3x3_t* c, const float* x, const float* x2, int c_split, int elu_input,
+                               const float* residual, float* out, int B, int H, int W, void* stream);
 /* eps_out with (qz_mean+rz_mean) + exp(qz_logsd+rz_logsd)*eps_out == z: mode "init" of IAFLayer.down runs the posterior
  * block on a PRIOR sample (tf_train.py:60-61, 67-85) */
 int iaf_noise_from_sample(const float* z, const float* qz_mean, const float* qz_logsd, const float* rz_mean,
