@@ -10,7 +10,8 @@ from .distributions import (DiagonalGaussian, discretized_logistic, compute_lowe
 from .iaf_layer import IAFPosterior, IAFLayer  # noqa: F401
 from .iw_eval import IWEvaluator  # noqa: F401
 from .theano_layer import CVAELayerIAF  # noqa: F401
+from .model import CVAE1  # noqa: F401
 
 __all__ = ["ExchangeError", "IafHipError", "UnsupportedError", "ARStack", "PrepBatch", "VariableStore", "ar_multiconv2d", "get_conv_ar_mask", "get_linear_ar_mask", "multiconv2d", "variable_scope",
            "default_store", "DiagonalGaussian", "compute_lowerbound", "gaussian_diag_logps", "logsumexp", "repeat",
-           "StreamingLowerBound", "IAFPosterior", "IAFLayer", "IWEvaluator", "CVAELayerIAF", "WNConv2d", "ConvPrepBatch", "WnBwdBatch", "conv2d", "ar_conv2d", "discretized_logistic", "split", "resample2", "resize_nearest_neighbor", "ar_conv2d_theano"]
+           "StreamingLowerBound", "IAFPosterior", "IAFLayer", "IWEvaluator", "CVAELayerIAF", "CVAE1", "WNConv2d", "ConvPrepBatch", "WnBwdBatch", "conv2d", "ar_conv2d", "discretized_logistic", "split", "resample2", "resize_nearest_neighbor", "ar_conv2d_theano"]

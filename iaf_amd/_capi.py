@@ -128,6 +128,12 @@ SIGNATURES = {
     "iaf_conv3x3_forward": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, ctypes.POINTER(_vp),
                                            ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                            ctypes.c_int, _vp]),
+    "iaf_image_to_float": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_size_t, ctypes.c_int, _vp]),
+    "iaf_convk_weightnorm": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
+    "iaf_convk_forward": (ctypes.c_int, [_vp, _vp, _vp, _vp] + [ctypes.c_int] * 9 + [_vp]),
+    "iaf_deconvk_forward": (ctypes.c_int, [_vp, _vp, _vp, _vp] + [ctypes.c_int] * 9 + [ctypes.c_float, ctypes.c_float, _vp]),
+    "iaf_tile_channels": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
+    "iaf_sum_axpy": (ctypes.c_int, [_vp, _vp, ctypes.c_float, _vp, ctypes.c_int, _vp]),
     "iaf_conv3x3_forward_stride2": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_int),
                                                    ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
     "iaf_conv3x3_forward_deconv": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int, ctypes.c_int,

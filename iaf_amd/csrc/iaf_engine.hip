@@ -33,6 +33,7 @@
 //   iaf_kernels_resample.hpp  2x resampling and the deconv2d weight prep (downsampling IAFLayer)
 //   (this file)               stack object, launch logic, C ABI of the masked stack, forward / inverse / training
 //   iaf_conv3x3_host.hpp      C ABI of the plain and single masked 3x3 convs, init, likelihood
+//   iaf_model_edge.hpp        the two ends of the model around the layer stack (CVAE1._forward: x_enc, h_top, x_dec, obj / loss)
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -2425,3 +2426,4 @@ extern "C" int iaf_step_work(const iaf_stack_t* s, int B, int H, int W, double* 
 }
 
 #include "iaf_conv3x3_host.hpp"
+#include "iaf_model_edge.hpp"

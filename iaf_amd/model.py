@@ -1,0 +1,107 @@
+"""CVAE1 -- the caller of the hot path: the reference's whole model forward, CVAE1._forward (tf_train.py:150-218), for one tower:
+image scaling, conv2d("x_enc", 5x5, stride 2), the bottom-up pass through depth x num_blocks IAFLayers, the tiled h_top, the
+top-down pass accumulating kl_obj / kl_cost, deconv2d("x_dec", 5x5) + clip, discretized_logistic, obj and the (k-sample) loss.
+Every number is computed by HIP launches behind the C ABI (include/iaf_hip.h); torch tensors are storage.  The two edge convs
+have 3 channels on one side and run as direct convolutions (csrc/iaf_model_edge.hpp); the layers are iaf_amd.IAFLayer.
+Forward only (the trainable unit of this package is the layer stack: IAFLayer.*_backward, bench.py --train --layers)."""
+import math
+
+import torch
+
+from . import _capi
+from .distributions import compute_lowerbound, discretized_logistic
+from .iaf_layer import IAFLayer
+from .layers import _check_act, _ptr, _stream
+
+
+class CVAE1(object):
+    """Same hyper-parameters as the reference's HParams (tf_train.py:98-112) that _forward reads: z_size, h_size, kl_min, depth
+    (number of resolution levels), num_blocks (layers per level), k (importance samples), image_size.  `mode` as in the
+    reference: "train" (posterior samples), "init" (prior samples through the posterior block), "sample"."""
+
+    def __init__(self, z_size=32, h_size=160, kl_min=0.25, depth=2, num_blocks=2, k=1, image_size=32, depth_ar=2, mode="train"):
+        self.z_size, self.h_size, self.kl_min = int(z_size), int(h_size), float(kl_min)
+        self.depth, self.num_blocks, self.k, self.image_size, self.mode = int(depth), int(num_blocks), int(k), int(image_size), mode
+        if self.image_size % (2 ** self.depth):
+            raise ValueError("image_size must be divisible by 2**depth (tf_train.py:183,192)")
+        # tf_train.py:176-181: the first layer of every level but the first downsamples
+        self.layers = [[IAFLayer(z_size, h_size, depth_ar=depth_ar, kl_min=kl_min, downsample=(i > 0 and j == 0), mode=mode)
+                        for j in range(self.num_blocks)] for i in range(self.depth)]
+        self._w_enc = self._w_dec = None
+        self.params = None
+
+    def load(self, params):
+        """params: device fp32 tensors under the reference's variable names (tf_train.py:175-215): x_enc/{V [5,5,3,h],g,b},
+        IAF_<i>_<j>/<IAFLayer names>, h_top [h], x_dec/{V [5,5,3,h],g,b}, dec_log_stdv []."""
+        lib, hs = _capi.lib(), self.h_size
+        for nm, shape in (("x_enc/V", (5, 5, 3, hs)), ("x_enc/g", (hs,)), ("x_enc/b", (hs,)), ("x_dec/V", (5, 5, 3, hs)),
+                          ("x_dec/g", (3,)), ("x_dec/b", (3,)), ("h_top", (hs,))):
+            _check_act(params[nm], nm, shape)
+        self._w_enc = torch.empty_like(params["x_enc/V"])
+        self._w_dec = torch.empty_like(params["x_dec/V"])
+        _capi.check(lib.iaf_convk_weightnorm(_ptr(params["x_enc/V"]), _ptr(params["x_enc/g"]), _ptr(self._w_enc), 5, 5, 3, hs, 0,
+                                             _stream()))                                                    # layers.py:56-60
+        _capi.check(lib.iaf_convk_weightnorm(_ptr(params["x_dec/V"]), _ptr(params["x_dec/g"]), _ptr(self._w_dec), 5, 5, hs, 3, 1,
+                                             _stream()))                                                    # layers.py:104-106
+        for i, level in enumerate(self.layers):
+            for j, layer in enumerate(level):
+                pre = "IAF_%d_%d/" % (i, j)
+                layer.load({k[len(pre):]: v for k, v in params.items() if k.startswith(pre)})
+        self.params = params
+
+    def forward(self, x, noise):
+        """x: uint8 [B,3,S,S] on the device.  noise: per layer in top-down order the pair (eps_prior, eps_post) the reference's two
+        DiagonalGaussians draw (distributions.py:15-24), flattened into one list -- eps_post is used in mode "train", eps_prior in
+        "init" / "sample".  Returns (x_out [B k,3,S,S], obj [1], loss [1]) as tf_train.py:218."""
+        if self.params is None:
+            raise RuntimeError("CVAE1.load(params) first")
+        if x.dtype != torch.uint8 or not x.is_cuda or not x.is_contiguous() or x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError("x must be a contiguous uint8 [B,3,S,S] device tensor")
+        lib, p, hs, k = _capi.lib(), self.params, self.h_size, self.k
+        B, _, S, _ = (int(v) for v in x.shape)
+        if S != self.image_size or x.shape[3] != S:
+            raise ValueError("image size %r, model built for %d" % (tuple(x.shape), self.image_size))
+        n = B * k
+        if len(noise) != 2 * self.depth * self.num_blocks:
+            raise ValueError("noise: %d tensors expected (prior, posterior per layer, top-down)" % (2 * self.depth * self.num_blocks))
+        dev = x.device
+        xf = torch.empty((n, 3, S, S), dtype=torch.float32, device=dev)
+        _capi.check(lib.iaf_image_to_float(x.data_ptr(), _ptr(xf), B, 3 * S * S, k, _stream()))           # tf_train.py:153-159
+        h = torch.empty((n, hs, S // 2, S // 2), dtype=torch.float32, device=dev)
+        _capi.check(lib.iaf_convk_forward(_ptr(xf), _ptr(self._w_enc), _ptr(p["x_enc/b"]), _ptr(h), n, 3, S, S, hs, 5, 5, 2, 0,
+                                          _stream()))                                                       # :183
+        for level in self.layers:                                                                          # :184-187
+            for layer in level:
+                h = layer.up(h)
+        St = S // 2 ** self.depth
+        h = torch.empty((n, hs, St, St), dtype=torch.float32, device=dev)
+        _capi.check(lib.iaf_tile_channels(_ptr(p["h_top"]), _ptr(h), n, hs, St * St, _stream()))           # :189-192
+        nl = self.depth * self.num_blocks
+        objs = torch.empty((nl, n), dtype=torch.float32, device=dev)
+        costs = torch.empty((nl, n), dtype=torch.float32, device=dev)
+        li = 0
+        for level in reversed(self.layers):                                                                # :195-200
+            for layer in reversed(level):
+                eps_prior, eps_post = noise[2 * li], noise[2 * li + 1]
+                h, cur_obj, cur_cost = layer.down(h, eps_post, eps_prior=eps_prior)
+                objs[li].copy_(cur_obj)
+                costs[li].copy_(cur_cost)
+                li += 1
+        kl_obj = torch.empty(n, dtype=torch.float32, device=dev)
+        kl_cost = torch.empty(n, dtype=torch.float32, device=dev)
+        _capi.check(lib.iaf_colsum(_ptr(objs), _ptr(kl_obj), nl, n, _stream()))
+        _capi.check(lib.iaf_colsum(_ptr(costs), _ptr(kl_cost), nl, n, _stream()))
+        x_out = torch.empty((n, 3, S, S), dtype=torch.float32, device=dev)
+        _capi.check(lib.iaf_deconvk_forward(_ptr(h), _ptr(self._w_dec), _ptr(p["x_dec/b"]), _ptr(x_out), n, hs, S // 2, S // 2, 3, 5, 5,
+                                            2, 1, -0.5 + 1 / 512., 0.5 - 1 / 512., _stream()))             # :206-208
+        log_pxz = discretized_logistic(x_out, p["dec_log_stdv"], sample=xf)                                # :210
+        obj = torch.empty(1, dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        _capi.check(lib.iaf_sum_axpy(_ptr(kl_obj), _ptr(log_pxz), -1.0, _ptr(obj), n, _stream()))          # :211
+        lb = compute_lowerbound(log_pxz, kl_cost, k)                                                       # :218
+        _capi.check(lib.iaf_sum_axpy(_ptr(lb), None, 0.0, _ptr(loss), B, _stream()))
+        return x_out, obj, loss
+
+    def bits_per_dim(self, loss, batch_size):
+        """tf_train.py:133 for one tower: loss / (log 2 * num_pixels * batch_size)"""
+        return float(loss) / (math.log(2.) * 3 * self.image_size ** 2 * batch_size)

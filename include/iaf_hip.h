@@ -529,6 +529,32 @@ int iaf_conv3x3_forward_deconv(iaf_conv3x3_t* c, const float* x, const float* x2
 int iaf_noise_from_sample(const float* z, const float* qz_mean, const float* qz_logsd, const float* rz_mean,
                           const float* rz_logsd, float* eps_out, size_t n, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * The two ends of the model around the IAFLayer stack: CVAE1._forward (tf_train.py:150-218)
+ * ------------------------------------------------------------------------------------------ */
+/* out[(b k + s)][i] = clip((x[b][i] + 0.5) / 256, 0, 1) - 0.5, s < k: tf.to_float + clip (tf_train.py:153-154) and repeat(x, k)
+ * (:159; tf_utils/distributions.py:40-52).  x uint8 [B][n_per_image], out float [B k][n_per_image]. */
+int iaf_image_to_float(const unsigned char* x, float* out, int B, size_t n_per_image, int k, void* stream);
+/* weight norm of a kh x kw filter into w (same layout as V):
+ *   deconv = 0  conv2d (tf_utils/layers.py:56-60):    V [kh,kw,n_in,n_out],  w = exp(g[o]) V / ||V||_(kh,kw,n_in)
+ *   deconv = 1  deconv2d (tf_utils/layers.py:104-106): V [kh,kw,n_out,n_in], w = exp(g[o]) V / ||V||_(kh,kw,n_out)  (per INPUT channel) */
+int iaf_convk_weightnorm(const float* V, const float* g, float* w, int kh, int kw, int n_in, int n_out, int deconv, void* stream);
+/* y = tf.nn.conv2d([elu](x), w, [1,1,s,s], SAME, NCHW) + b (tf_utils/layers.py:63-64) for any filter size / stride -- a direct
+ * conv for the model's first layer conv2d("x_enc", x, h_size, [5,5], [2,2]) (tf_train.py:183; 3 input channels: not MFMA work).
+ * x [B,n_in,H,W], y [B,n_out,ceil(H/s),ceil(W/s)]. */
+int iaf_convk_forward(const float* x, const float* w, const float* b, float* y, int B, int n_in, int H, int W, int n_out, int kh, int kw,
+                      int stride, int elu_input, void* stream);
+/* y = clip(conv2d_transpose([elu](x), w, SAME, stride s) + b, clip_lo, clip_hi) (tf_utils/layers.py:67-80,108-111; the model's last
+ * layer deconv2d("x_dec", elu(h), 3, [5,5]) + clip_by_value, tf_train.py:206-208).  x [B,n_in,H,W], y [B,n_out,H s,W s]; no clipping
+ * when clip_lo >= clip_hi. */
+int iaf_deconvk_forward(const float* x, const float* w, const float* b, float* y, int B, int n_in, int H, int W, int n_out, int kh,
+                        int kw, int stride, int elu_input, float clip_lo, float clip_hi, void* stream);
+/* out[b,c,:] = v[c]: tf.tile(tf.reshape(h_top, [1,-1,1,1]), [data_size,1,S,S]) (tf_train.py:190-192) */
+int iaf_tile_channels(const float* v, float* out, int B, int C, int HW, void* stream);
+/* out[0] = sum_i (a[i] + sb b[i]) (b may be NULL), fixed summation order: obj = reduce_sum(kl_obj - log_pxz) (tf_train.py:211),
+ * loss = reduce_sum(compute_lowerbound(...)) (:218) */
+int iaf_sum_axpy(const float* a, const float* b, float sb, float* out, int n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

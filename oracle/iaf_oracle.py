@@ -365,6 +365,48 @@ def discretized_logistic(mean, logscale, sample, binsize=1 / 256.0):
 
 
 # --------------------------------------------------------------------------------------
+# the caller of the path: the whole model's forward pass
+# --------------------------------------------------------------------------------------
+def cvae1_forward(x_uint8, params, z_size, h_size, depth, num_blocks, kl_min, k, noise, mode="train"):
+    """tf_train.py:150-215, CVAE1._forward for ONE tower: x [B,3,S,S] uint8 -> (x_out, obj, loss).  `params` carries the TF names
+    (x_enc/{V,g,b}, IAF_i_j/..., h_top, x_dec/{V,g,b}, dec_log_stdv); `noise` the draws of the DiagonalGaussians in graph
+    order: top-down, per layer the prior's then the posterior's (distributions.py:15-24 draws at construction).
+    Pinned to the reference's own _forward executed on the TF shim: tests/golden/cvae1_forward.npz."""
+    x = np.clip((x_uint8.astype(np.float64) + 0.5) / 256.0, 0.0, 1.0) - 0.5                    # :153-154
+    x = repeat(x, k)                                                                           # :159
+    orig_x = x
+    p = _sub(params, "x_enc/")
+    h = conv2d(x, p["V"], p["g"], p["b"], stride=(2, 2))                                       # :183
+    ups = {}
+    for i in range(depth):                                                                     # :184-187
+        for j in range(num_blocks):
+            ds = i > 0 and j == 0                                                              # :180
+            h, qm, ql, uc = iaf_layer_up(h, _sub(params, "IAF_%d_%d/" % (i, j)), z_size, h_size, downsample=ds)
+            ups[(i, j)] = (qm, ql, uc)
+    n = x.shape[0]
+    hw = x.shape[2] // 2 ** depth                                                              # :192 (image_size / 2**len(layers))
+    h = np.tile(np.asarray(params["h_top"]).reshape([1, -1, 1, 1]), [n, 1, hw, hw])            # :190-192
+    kl_cost = np.zeros(n)
+    kl_obj = np.zeros(n)
+    it = iter(noise)
+    for i in reversed(range(depth)):                                                           # :195-200
+        for j in reversed(range(num_blocks)):
+            eps_prior, eps_post = next(it), next(it)
+            qm, ql, uc = ups[(i, j)]
+            h, cur_obj, cur_cost, _ = iaf_layer_down(h, _sub(params, "IAF_%d_%d/" % (i, j)), qm, ql, uc, eps_post, z_size, h_size,
+                                                     kl_min, mode=mode, downsample=(i > 0 and j == 0), eps_prior=eps_prior)
+            kl_obj = kl_obj + cur_obj
+            kl_cost = kl_cost + cur_cost
+    p = _sub(params, "x_dec/")
+    xo = deconv2d(elu(h), p["V"], p["g"], p["b"])                                              # :206-207
+    xo = np.clip(xo, -0.5 + 1 / 512., 0.5 - 1 / 512.)                                          # :208
+    log_pxz = discretized_logistic(xo, params["dec_log_stdv"], orig_x)                         # :210
+    obj = np.sum(kl_obj - log_pxz)                                                             # :211
+    loss = np.sum(compute_lowerbound(log_pxz, kl_cost, k))                                     # :218
+    return xo, obj, loss
+
+
+# --------------------------------------------------------------------------------------
 # a13  data-parallel gradient averaging + Adamax
 # --------------------------------------------------------------------------------------
 def average_grads(tower_grads):

@@ -196,3 +196,49 @@ def theano_case_inputs(cname):
     z = rng.standard_normal((B, n_z, H, W))
     ctx = rng.standard_normal((B, sizes[-1] if n_h_list else n_z, H, W))
     return w, z, ctx
+
+
+# ---------------------------------------------------------------- the whole model: CVAE1._forward (tf_train.py:150-215)
+MODEL_CASES = {
+    # name: (batch_size, k, z_size, h_size, depth, num_blocks, image_size, kl_min)
+    "model_tiny": (2, 1, 4, 8, 2, 2, 16, 0.25),
+    "model_k2":   (2, 2, 4, 8, 2, 1, 8, 0.1),
+    "model_cfg":  (2, 1, 32, 160, 2, 2, 32, 0.25),     # BASELINE geometry (z 32, h 160, 32x32 images -> 16x16 -> 8x8), shallow
+}
+
+
+def model_case_inputs(name):
+    """Variables (TF names, tf_train.py:175-215), the uint8 image batch and the noise every DiagonalGaussian draws, in the order
+    the reference's graph construction draws it: top-down, per layer the prior's noise then the posterior's."""
+    B, k, zs, hs, depth, nb, img, kl_min = MODEL_CASES[name]
+    rng = np.random.RandomState(case_seed(name))
+    p = {}
+    for kk, v in conv_params(rng, 3, hs, ksize=5).items():
+        p["x_enc/" + kk] = v
+    for kk, v in deconv_params(rng, hs, 3, k=5).items():
+        p["x_dec/" + kk] = v
+    p["h_top"] = 0.3 * rng.standard_normal(hs)
+    p["dec_log_stdv"] = np.array(-0.7 + 0.1 * rng.standard_normal())
+    for i in range(depth):
+        for j in range(nb):
+            pre = "IAF_%d_%d/" % (i, j)
+            ds = i > 0 and j == 0
+            for kk, v in conv_params(rng, hs, 2 * zs + 2 * hs).items():
+                p[pre + "up_conv1/" + kk] = v
+            for kk, v in conv_params(rng, hs, hs).items():
+                p[pre + "up_conv3/" + kk] = v
+            for kk, v in conv_params(rng, hs, 4 * zs + 2 * hs).items():
+                p[pre + "down_conv1/" + kk] = v
+            for kk, v in ar_multiconv2d_params(rng, zs, [hs, hs], [zs, zs]).items():
+                p[pre + "ar_multiconv2d/" + kk] = v
+            last = deconv_params(rng, hs + zs, hs) if ds else conv_params(rng, hs + zs, hs)
+            for kk, v in last.items():
+                p[pre + ("down_deconv2/" if ds else "down_conv2/") + kk] = v
+    x = rng.randint(0, 256, size=(B, 3, img, img)).astype(np.uint8)
+    noise = []
+    for i in reversed(range(depth)):
+        H = img // 2 // (2 ** i)
+        for j in reversed(range(nb)):
+            noise.append(rng.standard_normal((B * k, zs, H, H)))      # prior (drawn, unused in mode "train")
+            noise.append(rng.standard_normal((B * k, zs, H, H)))      # posterior
+    return dict(B=B, k=k, z_size=zs, h_size=hs, depth=depth, num_blocks=nb, image_size=img, kl_min=kl_min, params=p, x=x, noise=noise)

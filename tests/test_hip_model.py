@@ -1,0 +1,101 @@
+"""GPU parity test for the caller of the hot path: iaf_amd.CVAE1.forward -- the reference's whole model forward,
+CVAE1._forward (tf_train.py:150-218): image scaling, x_enc (5x5 stride-2 conv), the IAFLayer stack with its downsampling layers,
+h_top, x_dec (5x5 deconv) + clip, discretized_logistic, obj and the k-sample loss -- against the outputs of the reference's OWN
+_forward executed on the TF shim (tests/golden/cvae1_forward.npz, tests/golden/make_golden_model.py) and against the CPU oracle's
+restatement of it (oracle.cvae1_forward).  Also the edge entry points on their own against the oracle's leaf functions."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import golden_inputs as gi
+from oracle import iaf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def amd():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU")
+    import iaf_amd
+    iaf_amd._capi.lib()      # raises if the HIP extension is missing: no silent fallback
+    return iaf_amd
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def host(t):
+    torch.cuda.synchronize()
+    return t.detach().cpu().numpy().astype(np.float64)
+
+
+def f32(a):
+    return np.asarray(a, dtype=np.float32).astype(np.float64)
+
+
+@pytest.mark.parametrize("name", sorted(gi.MODEL_CASES))
+def test_cvae1_forward_vs_reference_golden(amd, golden_dir, name):
+    g = np.load(os.path.join(golden_dir, "cvae1_forward.npz"))
+    c = gi.model_case_inputs(name)
+    model = amd.CVAE1(z_size=c["z_size"], h_size=c["h_size"], kl_min=c["kl_min"], depth=c["depth"], num_blocks=c["num_blocks"],
+                      k=c["k"], image_size=c["image_size"])
+    model.load({k: dev(v) for k, v in c["params"].items()})
+    x = torch.from_numpy(c["x"]).cuda()
+    x_out, obj, loss = model.forward(x, [dev(e) for e in c["noise"]])
+    # the reference's outputs were computed in fp64 from fp64 variables; the GPU holds fp32 copies of the same numbers
+    np.testing.assert_allclose(host(x_out), g[name + "/x_out"], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(host(obj)[0], g[name + "/obj"], rtol=2e-5)
+    np.testing.assert_allclose(host(loss)[0], g[name + "/loss"], rtol=2e-5)
+    np.testing.assert_allclose(model.bits_per_dim(host(loss)[0], c["B"]), g[name + "/bits_per_dim"], rtol=2e-5)
+
+
+def test_edge_convs_vs_oracle(amd):
+    """conv2d 5x5 stride 2 from 3 channels, deconv2d 5x5 stride 2 to 3 channels (+ elu, clip), odd sizes and a 3x3 stride-1 case"""
+    lib, P, st = amd._capi.lib(), amd.layers._ptr, amd.layers._stream
+    rng = np.random.RandomState(3)
+    for (B, ci, co, H, W, k, s) in ((3, 3, 24, 10, 14, 5, 2), (2, 5, 7, 9, 7, 3, 1), (2, 3, 160, 32, 32, 5, 2)):
+        p = gi.conv_params(rng, ci, co, ksize=k)
+        x = rng.standard_normal((B, ci, H, W))
+        w = torch.empty((k, k, ci, co), device="cuda")
+        dV, dg, db, dx = dev(p["V"]), dev(p["g"]), dev(p["b"]), dev(x)          # (kept alive across the launches)
+        amd._capi.check(lib.iaf_convk_weightnorm(P(dV), P(dg), P(w), k, k, ci, co, 0, st()))
+        OH, OW = -(-H // s), -(-W // s)
+        y = torch.empty((B, co, OH, OW), device="cuda")
+        amd._capi.check(lib.iaf_convk_forward(P(dx), P(w), P(db), P(y), B, ci, H, W, co, k, k, s, 1, st()))
+        want = O.conv2d(O.elu(f32(x)), f32(p["V"]), f32(p["g"]), f32(p["b"]), stride=(s, s))
+        np.testing.assert_allclose(host(y), want, rtol=0, atol=1e-4)
+    for (B, ci, co, H, W, k) in ((3, 24, 3, 5, 7, 5), (2, 160, 3, 16, 16, 5), (2, 6, 4, 4, 4, 3)):
+        p = gi.deconv_params(rng, ci, co, k=k)
+        x = rng.standard_normal((B, ci, H, W))
+        w = torch.empty((k, k, co, ci), device="cuda")
+        dV, dg, db, dx = dev(p["V"]), dev(p["g"]), dev(p["b"]), dev(x)
+        amd._capi.check(lib.iaf_convk_weightnorm(P(dV), P(dg), P(w), k, k, ci, co, 1, st()))
+        y = torch.empty((B, co, 2 * H, 2 * W), device="cuda")
+        amd._capi.check(lib.iaf_deconvk_forward(P(dx), P(w), P(db), P(y), B, ci, H, W, co, k, k, 2, 1, -0.3, 0.4, st()))
+        want = np.clip(O.deconv2d(O.elu(f32(x)), f32(p["V"]), f32(p["g"]), f32(p["b"])), np.float32(-0.3), np.float32(0.4))
+        np.testing.assert_allclose(host(y), want, rtol=0, atol=1e-4)
+
+
+def test_image_scaling_tile_and_sums(amd):
+    lib, P, st = amd._capi.lib(), amd.layers._ptr, amd.layers._stream
+    rng = np.random.RandomState(4)
+    x = rng.randint(0, 256, size=(3, 3, 4, 4)).astype(np.uint8)
+    out = torch.empty((6, 3, 4, 4), device="cuda")
+    xd = torch.from_numpy(x).cuda()
+    amd._capi.check(lib.iaf_image_to_float(xd.data_ptr(), P(out), 3, 48, 2, st()))
+    want = O.repeat(np.clip((x.astype(np.float64) + 0.5) / 256.0, 0.0, 1.0) - 0.5, 2)        # tf_train.py:153-159
+    np.testing.assert_allclose(host(out), want, rtol=0, atol=1e-7)
+    v = rng.standard_normal(5)
+    t = torch.empty((2, 5, 3, 3), device="cuda")
+    vd = dev(v)
+    amd._capi.check(lib.iaf_tile_channels(P(vd), P(t), 2, 5, 9, st()))
+    np.testing.assert_array_equal(host(t), np.tile(f32(v).reshape(1, 5, 1, 1), [2, 1, 3, 3]))
+    a, b = rng.standard_normal(1000), rng.standard_normal(1000)
+    s = torch.empty(1, device="cuda")
+    ad, bd = dev(a), dev(b)
+    amd._capi.check(lib.iaf_sum_axpy(P(ad), P(bd), -1.0, P(s), 1000, st()))
+    np.testing.assert_allclose(host(s)[0], np.sum(f32(a) - f32(b)), rtol=0, atol=1e-3)

@@ -73,7 +73,8 @@ def test_stride2_conv_vs_fp64_definition_and_vs_the_subsampled_stride1_conv(amd,
     got_t = [torch.empty((B, c, H, W), device="cuda") for c in split]
     for k, t in enumerate(got_t):
         outs[k] = t.data_ptr()
-    rc = amd._capi.lib().iaf_conv3x3_forward_stride2(conv._h, amd.layers._ptr(dev(x)), 1 if elu else 0, outs,
+    xd = dev(x)
+    rc = amd._capi.lib().iaf_conv3x3_forward_stride2(conv._h, amd.layers._ptr(xd), 1 if elu else 0, outs,
                                                      (ctypes.c_int * len(split))(*split), len(split), B, H, W, amd.layers._stream())
     assert rc == 0, "the strided kernel covers this shape (rc %d)" % rc
     got = np.concatenate([host(t) for t in got_t], axis=1)
@@ -97,7 +98,8 @@ def test_stride2_conv_falls_back_where_the_phase_tiles_do_not_fit(amd):
     conv = amd.WNConv2d(ci, co)
     conv.prepare(dev(p["V"]), dev(p["g"]), dev(p["b"]))
     o = torch.empty((B, co, H, W), device="cuda")
-    rc = amd._capi.lib().iaf_conv3x3_forward_stride2(conv._h, amd.layers._ptr(dev(x)), 0, (ctypes.c_void_p * 1)(o.data_ptr()),
+    xd = dev(x)
+    rc = amd._capi.lib().iaf_conv3x3_forward_stride2(conv._h, amd.layers._ptr(xd), 0, (ctypes.c_void_p * 1)(o.data_ptr()),
                                                      (ctypes.c_int * 1)(co), 1, B, H, W, amd.layers._stream())
     assert rc == amd._capi.IAF_ERR_UNSUPPORTED
     got = host(conv.stride2(dev(x))[0])
@@ -126,8 +128,9 @@ def test_deconv_by_phases_vs_fp64_definition_and_vs_the_zero_inserted_conv(amd, 
     xa, xb = dev(x[:, :c1]), (dev(x[:, c1:]) if c2 else None)
     out = torch.empty((B, co, 2 * H, 2 * W), device="cuda")
     P = amd.layers._ptr
+    resd = dev(res) if with_res else None
     rc = amd._capi.lib().iaf_conv3x3_forward_deconv(conv._h, P(xa), P(xb), c1 if c2 else 0, 1 if elu else 0,
-                                                    P(dev(res)) if with_res else None, P(out), B, H, W, amd.layers._stream())
+                                                    P(resd), P(out), B, H, W, amd.layers._stream())
     assert rc == 0, "the phase kernel covers this shape (rc %d)" % rc
     want = ref_deconv(x, p, elu)
     if with_res:
@@ -151,6 +154,7 @@ def test_deconv_falls_back_for_channel_counts_without_a_bf16x3_pack(amd):
     conv.prepare_deconv(dev(p["V"]), dev(p["g"]), dev(p["b"]))
     out = torch.empty((B, co, 2 * H, 2 * W), device="cuda")
     P = amd.layers._ptr
-    rc = amd._capi.lib().iaf_conv3x3_forward_deconv(conv._h, P(dev(x)), None, 0, 0, None, P(out), B, H, W, amd.layers._stream())
+    xd = dev(x)
+    rc = amd._capi.lib().iaf_conv3x3_forward_deconv(conv._h, P(xd), None, 0, 0, None, P(out), B, H, W, amd.layers._stream())
     assert rc == amd._capi.IAF_ERR_UNSUPPORTED
     np.testing.assert_allclose(host(conv.deconv(dev(x))), ref_deconv(x, p, False), rtol=0, atol=ATOL)

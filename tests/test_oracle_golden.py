@@ -246,3 +246,19 @@ def test_theano_cvae_layer_vs_reference_golden(golden_dir, cname):
     obj, kl_sum = O.theano_free_bits(r["kl"], kl_min)
     np.testing.assert_allclose(kl_sum, g[cname + "/kl_sum"], rtol=1e-10)
     np.testing.assert_allclose(obj, g[cname + "/obj_kl"], rtol=1e-10)
+
+
+@pytest.mark.parametrize("name", sorted(gi.MODEL_CASES))
+def test_cvae1_forward_vs_the_references_own_forward(golden_dir, name):
+    """the whole model forward, oracle.cvae1_forward, against CVAE1._forward of the reference executed on the TF shim
+    (tests/golden/make_golden_model.py -> cvae1_forward.npz): x_enc, the layer stack with its downsampling layers, h_top,
+    x_dec + clip, discretized_logistic, obj and the k-sample loss (tf_train.py:150-218)"""
+    g = np.load(os.path.join(golden_dir, "cvae1_forward.npz"))
+    c = gi.model_case_inputs(name)
+    xo, obj, loss = O.cvae1_forward(c["x"], c["params"], c["z_size"], c["h_size"], c["depth"], c["num_blocks"], c["kl_min"], c["k"],
+                                    c["noise"])
+    np.testing.assert_allclose(xo, g[name + "/x_out"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(obj, g[name + "/obj"], rtol=1e-12)
+    np.testing.assert_allclose(loss, g[name + "/loss"], rtol=1e-12)
+    bpd = loss / (np.log(2.) * 3 * c["image_size"] ** 2 * c["B"])                    # tf_train.py:133, one tower
+    np.testing.assert_allclose(bpd, g[name + "/bits_per_dim"], rtol=1e-12)
