@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--tune", type=str, default="", help="layer:nt,pxt,wco,ks;... launch-shape override")
     ap.add_argument("--layers", action="store_true",
                     help="widened workload (SURVEY 8f-4): whole IAFLayers (plain convs + posterior block), forward")
+    ap.add_argument("--model", action="store_true",
+                    help="with --layers: the whole model forward, CVAE1._forward (tf_train.py:150-218): uint8 images -> x_enc -> the "
+                         "layer stack -> x_dec -> discretized_logistic -> obj / loss")
     ap.add_argument("--train", action="store_true",
                     help="extra mode (not the headline metric): data-parallel TRAINING step of the IAF posterior stack -- "
                          "posterior block forward + backward for every layer, one RCCL all-reduce of the flat gradient "
@@ -506,6 +509,21 @@ def layers_bench(args, depths, dist, rank, n_gpus):
             deconvs.append((lay.down_conv2, p["down_deconv2/V"], p["down_deconv2/g"], p["down_deconv2/b"]))
     prep_c = iaf_amd.ConvPrepBatch(bconvs)
     splist = [iaf_amd.IAFLayer.stack_params(L["params"]) for L in all_layers]
+    # --model: the two ends of CVAE1._forward around the stack (tf_train.py:153-159, 183, 189-192, 206-218)
+    edge = None
+    if args.model:
+        from iaf_amd.layers import _ptr, _stream
+        lib, chk = iaf_amd._capi.lib(), iaf_amd._capi.check
+        ep = {"x_enc/" + k: dev(v) for k, v in gi.conv_params(wrng, 3, hs, ksize=5).items()}
+        ep.update({"x_dec/" + k: dev(v) for k, v in gi.deconv_params(wrng, hs, 3, k=5).items()})
+        ep["h_top"] = dev(0.3 * wrng.standard_normal(hs))
+        ep["dec_log_stdv"] = dev(np.array([-0.7]))
+        nl = len(all_layers)
+        edge = dict(p=ep, w_enc=torch.empty_like(ep["x_enc/V"]), w_dec=torch.empty_like(ep["x_dec/V"]),
+                    img=torch.from_numpy(rng.randint(0, 256, size=(B, 3, 32, 32)).astype(np.uint8)).cuda(),
+                    xf=torch.empty((B, 3, 32, 32), device="cuda"), h0=torch.empty((B, hs, 16, 16), device="cuda"),
+                    x_out=torch.empty((B, 3, 32, 32), device="cuda"), kl_obj=torch.empty(B, device="cuda"), kl_cost=torch.empty(B, device="cuda"),
+                    obj=torch.empty(1, device="cuda"), loss=torch.empty(1, device="cuda"))
 
     def step(autotune=False):
         if not args.cached_weights:
@@ -515,15 +533,40 @@ def layers_bench(args, depths, dist, rank, n_gpus):
                 cv.prepare_deconv(V, g, b, force=True)
         outs = []
         h = up_in
+        if edge is not None:
+            E, ep = edge, edge["p"]
+            if not args.cached_weights:
+                chk(lib.iaf_convk_weightnorm(_ptr(ep["x_enc/V"]), _ptr(ep["x_enc/g"]), _ptr(E["w_enc"]), 5, 5, 3, hs, 0, _stream()))
+                chk(lib.iaf_convk_weightnorm(_ptr(ep["x_dec/V"]), _ptr(ep["x_dec/g"]), _ptr(E["w_dec"]), 5, 5, hs, 3, 1, _stream()))
+            chk(lib.iaf_image_to_float(E["img"].data_ptr(), _ptr(E["xf"]), B, 3 * 32 * 32, 1, _stream()))
+            chk(lib.iaf_convk_forward(_ptr(E["xf"]), _ptr(E["w_enc"]), _ptr(ep["x_enc/b"]), _ptr(E["h0"]), B, 3, 32, 32, hs, 5, 5, 2, 0,
+                                      _stream()))
+            h = E["h0"]
         for lv in levels:                         # bottom-up (tf_train.py:188-192), chained across levels
             for L in lv["layers"]:
                 h = L["layer"].up(h, autotune=autotune)
         h = down_in
+        if edge is not None:
+            chk(lib.iaf_tile_channels(_ptr(ep["h_top"]), _ptr(down_in), B, hs, Htop * Htop, _stream()))
+        li = 0
         for lv in reversed(levels):               # top-down (tf_train.py:195-200)
             for L in reversed(lv["layers"]):
                 h, kl_obj, kl_cost = L["layer"].down(h, L["eps"], autotune=autotune)
                 outs.append((kl_obj, kl_cost))
+                li += 1
         outs.append(h)
+        if edge is not None:
+            objs, costs = torch.stack([o[0] for o in outs[:li]]), torch.stack([o[1] for o in outs[:li]])
+            chk(lib.iaf_colsum(_ptr(objs), _ptr(E["kl_obj"]), li, B, _stream()))
+            chk(lib.iaf_colsum(_ptr(costs), _ptr(E["kl_cost"]), li, B, _stream()))
+            outs.append((objs, costs))
+            chk(lib.iaf_deconvk_forward(_ptr(h), _ptr(E["w_dec"]), _ptr(ep["x_dec/b"]), _ptr(E["x_out"]), B, hs, 16, 16, 3, 5, 5, 2, 1,
+                                        -0.5 + 1 / 512., 0.5 - 1 / 512., _stream()))
+            log_pxz = iaf_amd.discretized_logistic(E["x_out"], ep["dec_log_stdv"], sample=E["xf"])
+            chk(lib.iaf_sum_axpy(_ptr(E["kl_obj"]), _ptr(log_pxz), -1.0, _ptr(E["obj"]), B, _stream()))
+            lb = iaf_amd.compute_lowerbound(log_pxz, E["kl_cost"], 1)
+            chk(lib.iaf_sum_axpy(_ptr(lb), None, 0.0, _ptr(E["loss"]), B, _stream()))
+            outs.append((log_pxz, lb))
         return outs
 
     if not args.no_autotune and args.depth_ar > 0:      # masked stacks: kernel family / launch shape per layer
@@ -602,11 +645,13 @@ def layers_bench(args, depths, dist, rank, n_gpus):
     total_fl = 0.0
     for lv in levels:
         for L in lv["layers"]:
-            # useful FLOPs: a downsampling layer's strided convs are counted at their minimal cost (they run at 4x that)
+            # useful FLOPs: a downsampling layer's strided convs at their minimal cost (what the strided kernels multiply since round 4)
             total_fl += sum(c.work(B, lv["H"], lv["H"])[0] for c in L["layer"].convs())
             total_fl += L["layer"].posterior.stack.step_work(B, lv["H"], lv["H"])["live_flops"]
     emit({
-        "metric": "IAFLayer forward samples/sec (up + down of every layer: 4 plain weight-normed convs + IAF posterior block)",
+        "metric": ("CVAE1 forward samples/sec (tf_train.py:150-218: uint8 images -> x_enc -> up + down of every layer -> x_dec -> "
+                   "discretized_logistic -> obj / loss)") if edge is not None else
+                  "IAFLayer forward samples/sec (up + down of every layer: 4 plain weight-normed convs + IAF posterior block)",
         "value": n_gpus * B / (elapsed / args.steps), "unit": "samples/s", "n_gpus": n_gpus, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "f32 (forward convs: operands split into 3 bf16 parts, 6 part-products on the bf16 MFMA, fp32 accumulate: fp32-grade error; backward: exact fp32 MFMA)", "data": "synthetic",
@@ -615,6 +660,8 @@ def layers_bench(args, depths, dist, rank, n_gpus):
                                "layer of each coarser level, then the down pass back"
                                % (zs, hs, depths, args.depth_ar, B, len(all_layers), Htop, Htop),
                    "global_batch": n_gpus * B, "launch": "hipGraph replay" if graph is not None else "eager",
+                   "model_edges": None if edge is None else {"loss": float(edge["loss"].item()), "obj": float(edge["obj"].item()),
+                                                             "bits_per_dim": float(edge["loss"].item()) / (np.log(2.) * 3072 * B)},
                    "weights": "re-derived every step (2 batched launches)" if not args.cached_weights else "prepared once",
                    "live_gflop_per_step": total_fl / 1e9,
                    "model_tflops": total_fl / (elapsed / args.steps) / 1e12,

@@ -1,7 +1,8 @@
 // iaf_model_edge.hpp -- the two ends of the model around the IAFLayer stack, CVAE1._forward (tf_train.py:150-218): the image
 // scaling (:153-154, 159), conv2d("x_enc", x, h_size, [5,5], [2,2]) (:183), the tiled h_top (:189-192), deconv2d("x_dec", elu(h), 3,
 // [5,5]) + clip (:206-208) and the two scalar sums obj / loss (:211, 218).  Tiny channel counts on one side (3 image channels): not
-// MFMA work -- direct convolutions, one output element per thread, HBM/L2-bound and a few microseconds each at the BASELINE batch.
+// MFMA work -- direct convolutions (a few output channels per thread; the deconv by output phases with its input channels
+// split over 16 thread slices), latency-bound, 10-20 microseconds each at the BASELINE batch.
 // Part of the single translation unit iaf_engine.hip (included there; not a standalone header).
 #pragma once
 
@@ -50,61 +51,125 @@ struct ConvKP {
 };
 
 // y[b,o,oy,ox] = b[o] + sum_{a,c,ci} [elu](x[b,ci,oy s + a - pad_t, ox s + c - pad_l]) w[a,c,ci,o]   (tf.nn.conv2d SAME, NCHW)
+// A thread owns one output pixel and CK_NO consecutive output channels (blockIdx.y = channel chunk): every x value it loads feeds
+// CK_NO accumulators, the weights of a wave are uniform.  Out-of-image taps are multiplied by zero instead of branched around
+// (clamped address), so the (column, channel) loop is straight-line code the compiler batches the loads of.
+#define CK_NO 4
 __global__ __launch_bounds__(256) void iaf_convk_forward_kernel(ConvKP p) {
-    const size_t total = (size_t)p.B * p.n_out * p.OH * p.OW;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
-        const int ox = (int)(e % p.OW), oy = (int)((e / p.OW) % p.OH), o = (int)((e / ((size_t)p.OW * p.OH)) % p.n_out);
-        const int bimg = (int)(e / ((size_t)p.OW * p.OH * p.n_out));
-        float acc = p.b[o];
-        for (int a = 0; a < p.kh; ++a) {
-            const int iy = oy * p.stride + a - p.pad_t;
-            if (iy < 0 || iy >= p.H) continue;
-            for (int c = 0; c < p.kw; ++c) {
-                const int ix = ox * p.stride + c - p.pad_l;
-                if (ix < 0 || ix >= p.W) continue;
-                const float* xs = p.x + ((size_t)bimg * p.n_in * p.H + iy) * p.W + ix;
-                const float* ws = p.w + ((size_t)(a * p.kw + c) * p.n_in) * p.n_out + o;
+    const unsigned npx = (unsigned)p.B * p.OH * p.OW;            // < 2^30 (checked by the host): 32-bit index arithmetic
+    const unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= npx) return;
+    const unsigned erow = e / (unsigned)p.OW;
+    const int ox = (int)(e - erow * p.OW), bimg = (int)(erow / (unsigned)p.OH), oy = (int)(erow - (unsigned)bimg * p.OH);
+    const int o0 = (int)blockIdx.y * CK_NO;
+    float acc[CK_NO];
+#pragma unroll
+    for (int q = 0; q < CK_NO; ++q) acc[q] = (o0 + q < p.n_out) ? p.b[o0 + q] : 0.f;
+    const size_t HW = (size_t)p.H * p.W;
+    const int nt = p.kw * p.n_in;
+    for (int a = 0; a < p.kh; ++a) {
+        const int iy = oy * p.stride + a - p.pad_t;
+        if (iy < 0 || iy >= p.H) continue;                       // (uniform over a row of output pixels)
+        const float* xrow = p.x + ((size_t)bimg * p.n_in * p.H + iy) * p.W;
+        // the weights of this row of taps are the same for every thread: a wave-uniform base (scalar loads)
+        const float* wrow = p.w + __builtin_amdgcn_readfirstlane((a * nt) * p.n_out + o0);
+        for (int c = 0; c < p.kw; ++c) {                         // (no integer divisions in here: ~40 instructions each on this ISA)
+            const int ix = ox * p.stride + c - p.pad_l;
+            const bool in = ix >= 0 && ix < p.W;
+            const float* xs = xrow + (in ? ix : 0);
+            const float* wc = wrow + c * p.n_in * p.n_out;
+            if ((p.n_out & 3) == 0) {                             // four weights = one 16-byte load (o0 and n_out multiples of 4)
+#pragma unroll 3
                 for (int ci = 0; ci < p.n_in; ++ci) {
-                    float v = xs[(size_t)ci * p.H * p.W];
+                    float v = xs[(size_t)ci * HW];
                     if (p.elu) v = elu_f(v);
-                    acc += v * ws[(size_t)ci * p.n_out];
+                    v = in ? v : 0.f;
+                    const f32x4 w4 = *(const f32x4*)(wc + ci * p.n_out);
+#pragma unroll
+                    for (int q = 0; q < CK_NO; ++q) acc[q] += v * w4[q];
+                }
+            } else {
+#pragma unroll 3
+                for (int ci = 0; ci < p.n_in; ++ci) {
+                    float v = xs[(size_t)ci * HW];
+                    if (p.elu) v = elu_f(v);
+                    v = in ? v : 0.f;
+#pragma unroll
+                    for (int q = 0; q < CK_NO; ++q)
+                        if (o0 + q < p.n_out) acc[q] += v * wc[ci * p.n_out + q];
                 }
             }
         }
-        p.y[e] = acc;
     }
+#pragma unroll
+    for (int q = 0; q < CK_NO; ++q)
+        if (o0 + q < p.n_out) p.y[(((size_t)bimg * p.n_out + o0 + q) * p.OH + oy) * p.OW + ox] = acc[q];
 }
 
 // conv2d_transpose(SAME, stride s) + b [+ clip] (layers.py:67-80, 108-111; tf_train.py:207-208): y [B,n_out,H s,W s];
 //   y[b,o,Y,X] = b[o] + sum over taps (a,c) with (Y + pad_t - a) = s i, (X + pad_l - c) = s j inside the input of
 //                [elu](x[b,ci,i,j]) w[a,c,o,ci]          (pad_t, pad_l: the SAME padding of the forward conv it transposes)
+// By output phases: blockIdx.y = (Y mod s, X mod s), so every thread of a workgroup meets the same taps.  A workgroup owns 16
+// consecutive input-grid pixels x 16 slices of the input channels (thread = pixel + 16 slice): the partial sums of the slices are
+// added through LDS in a fixed order.  Up to DK_NO output channels per thread (blockIdx.z = channel chunk).
+#define DK_NO 4
 __global__ __launch_bounds__(256) void iaf_deconvk_forward_kernel(ConvKP p) {
-    const size_t total = (size_t)p.B * p.n_out * p.OH * p.OW;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
-        const int X = (int)(e % p.OW), Y = (int)((e / p.OW) % p.OH), o = (int)((e / ((size_t)p.OW * p.OH)) % p.n_out);
-        const int bimg = (int)(e / ((size_t)p.OW * p.OH * p.n_out));
-        float acc = p.b[o];
-        for (int a = 0; a < p.kh; ++a) {
-            const int ty = Y + p.pad_t - a;
-            if (ty < 0 || ty % p.stride != 0 || ty / p.stride >= p.H) continue;
-            const int i = ty / p.stride;
-            for (int c = 0; c < p.kw; ++c) {
-                const int tx = X + p.pad_l - c;
-                if (tx < 0 || tx % p.stride != 0 || tx / p.stride >= p.W) continue;
-                const int j = tx / p.stride;
-                const float* xs = p.x + ((size_t)bimg * p.n_in * p.H + i) * p.W + j;
-                const float* ws = p.w + ((size_t)(a * p.kw + c) * p.n_out + o) * p.n_in;
-                for (int ci = 0; ci < p.n_in; ++ci) {
-                    float v = xs[(size_t)ci * p.H * p.W];
-                    if (p.elu) v = elu_f(v);
-                    acc += v * ws[ci];
-                }
+    __shared__ float red[DK_NO][16][17];
+    extern __shared__ float wl[];                                // this phase's weights [tap of the phase][DK_NO][n_in]
+    const int s = p.stride, py = (int)blockIdx.y / s, px = (int)blockIdx.y % s;
+    const int o0 = (int)blockIdx.z * DK_NO;
+    const unsigned npx = (unsigned)p.B * p.H * p.W;              // < 2^30 (checked by the host): 32-bit index arithmetic
+    const int pl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const unsigned e = blockIdx.x * 16 + pl;
+    const bool live = e < npx;
+    const unsigned ec = live ? e : npx - 1;
+    const unsigned erow = ec / (unsigned)p.W;
+    const int j0 = (int)(ec - erow * p.W), bimg = (int)(erow / (unsigned)p.H), i0 = (int)(erow - (unsigned)bimg * p.H);
+    const int per = (p.n_in + 15) / 16, c_lo = sl * per, c_hi = (c_lo + per < p.n_in) ? c_lo + per : p.n_in;
+    // taps of this phase: a = a0, a0 + s, ... with a0 = (py + pad_t) mod s (Y + pad_t - a = s (i0 + (py + pad_t - a) / s), exact)
+    const int a0 = (py + p.pad_t) % s, c0 = (px + p.pad_l) % s;
+    const int na = (p.kh - a0 + s - 1) / s, nc = (p.kw - c0 + s - 1) / s;
+    const int wn = DK_NO * p.n_in;
+    for (int ta = 0; ta < na; ++ta)                              // (nested loops instead of index divisions)
+        for (int tc = 0; tc < nc; ++tc)
+            for (int q = 0; q < DK_NO; ++q) {
+                const float* src = p.w + ((size_t)((a0 + ta * s) * p.kw + c0 + tc * s) * p.n_out + o0 + q) * p.n_in;
+                float* dst = wl + ((ta * nc + tc) * DK_NO + q) * p.n_in;
+                for (int ci = threadIdx.x; ci < p.n_in; ci += 256) dst[ci] = (o0 + q < p.n_out) ? src[ci] : 0.f;
+            }
+    __syncthreads();
+    float acc[DK_NO];
+#pragma unroll
+    for (int q = 0; q < DK_NO; ++q) acc[q] = 0.f;
+    const size_t HW = (size_t)p.H * p.W;
+    for (int ta = 0; ta < na; ++ta) {
+        const int a = a0 + ta * s;
+        const int i = i0 + (py + p.pad_t - a) / s;
+        const bool iin = i >= 0 && i < p.H;
+        for (int tc = 0; tc < nc; ++tc) {
+            const int c = c0 + tc * s;
+            const int j = j0 + (px + p.pad_l - c) / s;
+            const bool in = iin && j >= 0 && j < p.W;
+            const float* xs = p.x + ((size_t)bimg * p.n_in * p.H + (in ? i : 0)) * p.W + (in ? j : 0);
+            const float* ws = wl + (ta * nc + tc) * wn;
+#pragma unroll 5
+            for (int ci = c_lo; ci < c_hi; ++ci) {
+                float t = xs[(size_t)ci * HW];
+                if (p.elu) t = elu_f(t);
+                t = in ? t : 0.f;
+#pragma unroll
+                for (int q = 0; q < DK_NO; ++q) acc[q] += t * ws[q * p.n_in + ci];
             }
         }
-        if (p.clip_lo < p.clip_hi) acc = fminf(fmaxf(acc, p.clip_lo), p.clip_hi);
-        p.y[e] = acc;
+    }
+#pragma unroll
+    for (int q = 0; q < DK_NO; ++q) red[q][sl][pl] = acc[q];
+    __syncthreads();
+    if (sl < DK_NO && o0 + sl < p.n_out && live) {               // thread (pixel pl, output channel sl) adds the 16 slices in order
+        float r = p.b[o0 + sl];
+        for (int k = 0; k < 16; ++k) r += red[sl][k][pl];
+        if (p.clip_lo < p.clip_hi) r = fminf(fmaxf(r, p.clip_lo), p.clip_hi);
+        p.y[(((size_t)bimg * p.n_out + o0 + sl) * p.OH + i0 * s + py) * p.OW + j0 * s + px] = r;
     }
 }
 
@@ -168,7 +233,10 @@ extern "C" int iaf_convk_forward(const float* x, const float* w, const float* b,
     p.stride = stride; p.elu = elu_input ? 1 : 0;
     same_pad(H, kh, stride, &p.OH, &p.pad_t);
     same_pad(W, kw, stride, &p.OW, &p.pad_l);
-    hipLaunchKernelGGL(iaf_convk_forward_kernel, ew_grid((size_t)B * n_out * p.OH * p.OW), dim3(256), 0, (hipStream_t)stream, p);
+    const size_t npx = (size_t)B * p.OH * p.OW;
+    if (npx > (1u << 30)) return IAF_ERR_SHAPE;
+    hipLaunchKernelGGL(iaf_convk_forward_kernel, dim3((unsigned)((npx + 255) / 256), (n_out + CK_NO - 1) / CK_NO), dim3(256), 0,
+                       (hipStream_t)stream, p);
     return (int)hipGetLastError();
 }
 
@@ -184,7 +252,13 @@ extern "C" int iaf_deconvk_forward(const float* x, const float* w, const float* 
     int o;
     same_pad(p.OH, kh, stride, &o, &p.pad_t);       // the forward conv this transposes maps [OH, OW] -> [H, W]
     same_pad(p.OW, kw, stride, &o, &p.pad_l);
-    hipLaunchKernelGGL(iaf_deconvk_forward_kernel, ew_grid((size_t)B * n_out * p.OH * p.OW), dim3(256), 0, (hipStream_t)stream, p);
+    const size_t npx = (size_t)B * H * W;
+    if (npx > (1u << 30) || stride > 8) return IAF_ERR_SHAPE;
+    // dynamic LDS: the weights of one output phase, at most ceil(kh/s) ceil(kw/s) taps x DK_NO channels x n_in
+    const size_t wl_bytes = (size_t)((kh + stride - 1) / stride) * ((kw + stride - 1) / stride) * DK_NO * n_in * sizeof(float);
+    if (wl_bytes > 60 * 1024) return IAF_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(iaf_deconvk_forward_kernel, dim3((unsigned)((npx + 15) / 16), stride * stride, (n_out + DK_NO - 1) / DK_NO),
+                       dim3(256), wl_bytes, (hipStream_t)stream, p);
     return (int)hipGetLastError();
 }
 

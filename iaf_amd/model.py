@@ -77,16 +77,16 @@ class CVAE1(object):
         h = torch.empty((n, hs, St, St), dtype=torch.float32, device=dev)
         _capi.check(lib.iaf_tile_channels(_ptr(p["h_top"]), _ptr(h), n, hs, St * St, _stream()))           # :189-192
         nl = self.depth * self.num_blocks
-        objs = torch.empty((nl, n), dtype=torch.float32, device=dev)
-        costs = torch.empty((nl, n), dtype=torch.float32, device=dev)
+        objs, costs = [], []
         li = 0
         for level in reversed(self.layers):                                                                # :195-200
             for layer in reversed(level):
                 eps_prior, eps_post = noise[2 * li], noise[2 * li + 1]
                 h, cur_obj, cur_cost = layer.down(h, eps_post, eps_prior=eps_prior)
-                objs[li].copy_(cur_obj)
-                costs[li].copy_(cur_cost)
+                objs.append(cur_obj)
+                costs.append(cur_cost)
                 li += 1
+        objs, costs = torch.stack(objs), torch.stack(costs)          # [nl, n] (one gathering copy each; the sums are iaf_colsum's)
         kl_obj = torch.empty(n, dtype=torch.float32, device=dev)
         kl_cost = torch.empty(n, dtype=torch.float32, device=dev)
         _capi.check(lib.iaf_colsum(_ptr(objs), _ptr(kl_obj), nl, n, _stream()))
