@@ -354,6 +354,10 @@ static bool conv3x3_bf3_shape(GemmLayer& L, int choice, long long P, int W) {
     return bf3_plain_lds_bytes(L.cin, W, L.b_nt, L.b_ppw, L.b_pxt, L.b_ks, L.b_wco) <= 160 * 1024;
 }
 
+// dev tool (tools/conv_stamps.py): per-workgroup cycle stamps of the bf16x3 plain-conv launches, [grid][8] u64 (NULL: off)
+static unsigned long long* g_conv_dbg = nullptr;
+extern "C" int iaf_conv3x3_set_debug(void* buf) { g_conv_dbg = (unsigned long long*)buf; return IAF_OK; }
+
 static int conv3x3_launch(GemmLayer& L, ConvP& p, int epi_sel, int inmode, bool masked, bool mirror, hipStream_t st,
                           int variant = IAF_VARIANT_TF, int bf3_choice = 3) {
     // the plain conv on the bf16 matrix cores: forward (NCHW input, EPI_PLAIN), or its data gradient (L = the transposed
@@ -375,6 +379,7 @@ static int conv3x3_launch(GemmLayer& L, ConvP& p, int epi_sel, int inmode, bool 
         dim3 grid((p.P + tm - 1) / tm, L.ncot / (L.b_nt * L.b_wco));
         p.gx = (int)grid.x;
         p.lds_bytes = (int)lds;
+        p.dbg = g_conv_dbg;
         hipLaunchKernelGGL(fn, grid, dim3(64 * L.b_pxt * L.b_ks * L.b_wco), lds, st, p);
         return (int)hipGetLastError();
     }

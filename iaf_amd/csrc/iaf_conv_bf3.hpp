@@ -188,6 +188,8 @@ __global__ __launch_bounds__(64 * PXT * KS * WCO) void iaf_conv_bf3_kernel(ConvP
     // NCHW source (z, or the posterior sample computed on the fly) -> three bf16 planes of an LDS tile of `nsl` slots
     auto stage_nchw = [&](char* region, int nsl, int cin_, int s16_, int cin8_, const float* xsrc, bool posterior) {
         const int nit = nsl * (cin_ >> 2);
+        // (index arithmetic by float reciprocal: an integer division is ~40 instructions on this ISA)
+        const float rnsl = 1.0f / (float)nsl, rHW = 1.0f / (float)HW;
         for (int base = tid; base < nit; base += 4 * NTHREADS) {
             int dq[4], dsl[4];
             f32x4 v4[4];
@@ -197,11 +199,13 @@ __global__ __launch_bounds__(64 * PXT * KS * WCO) void iaf_conv_bf3_kernel(ConvP
                 dsl[u] = -1; dq[u] = 0;
                 v4[u] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (idx < nit) {
-                    const int q = idx / nsl, sl = idx - q * nsl;               // slot fastest: coalesced along pixels
+                    int q, sl;                                                 // slot fastest: coalesced along pixels
+                    fast_divmod(idx, nsl, rnsl, q, sl);
                     const int Pg = Pbase + sl;
                     dsl[u] = sl; dq[u] = q;
                     if (Pg >= 0 && Pg < p.P) {
-                        const int b = Pg / HW, ppx = Pg - b * HW;
+                        int b, ppx;
+                        fast_divmod(Pg, HW, rHW, b, ppx);
                         const size_t gb = ((size_t)b * cin_ + 4 * q) * HW + ppx;
                         if constexpr (EPI == EPI_PLAIN) {     // input = [elu](concat(x[:, :c_split], x2))  (tf_train.py:36,52,87-88)
                             if (p.x2 && 4 * q >= p.c_split) {
@@ -241,6 +245,7 @@ __global__ __launch_bounds__(64 * PXT * KS * WCO) void iaf_conv_bf3_kernel(ConvP
         const int nq_ = p.cin >> 2, nsl = p.nslot, nit = nsl * nq_;
         const int W2 = 2 * W;
         const size_t HW4 = 4 * (size_t)HW;
+        const float rnsl = 1.0f / (float)nsl, rHW = 1.0f / (float)HW, rW = 1.0f / (float)W;
         for (int base = tid; base < nit; base += 4 * NTHREADS) {
             int dq[4], dsl[4];
             f32x4 v4[4];
@@ -250,14 +255,16 @@ __global__ __launch_bounds__(64 * PXT * KS * WCO) void iaf_conv_bf3_kernel(ConvP
                 dsl[u] = -1; dq[u] = 0;
                 v4[u] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (idx < nit) {
-                    const int q = idx / nsl, sl = idx - q * nsl;               // slot fastest: coalesced along pixels
+                    int q, sl;                                                 // slot fastest: coalesced along pixels
+                    fast_divmod(idx, nsl, rnsl, q, sl);
                     const int ph = (sl >= p.s2_pb[1] ? 1 : 0) + (sl >= p.s2_pb[2] ? 1 : 0) + (sl >= p.s2_pb[3] ? 1 : 0);
                     const int pb = ph == 0 ? 0 : (ph == 1 ? p.s2_pb[1] : (ph == 2 ? p.s2_pb[2] : p.s2_pb[3]));
                     const int Pg = P0 + (sl - pb);
                     dsl[u] = sl; dq[u] = q;
                     if (Pg < p.P) {
-                        const int b = Pg / HW, ppx = Pg - b * HW;
-                        const int i = ppx / W, j = ppx - i * W;
+                        int b, ppx, i, j;
+                        fast_divmod(Pg, HW, rHW, b, ppx);
+                        fast_divmod(ppx, W, rW, i, j);
                         const size_t gb = ((size_t)b * p.cin + 4 * q) * HW4 + (size_t)(2 * i + (ph >> 1)) * W2 + 2 * j + (ph & 1);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v4[u][r] = p.x[gb + (size_t)r * HW4];

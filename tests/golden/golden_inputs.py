@@ -204,13 +204,15 @@ MODEL_CASES = {
     "model_tiny": (2, 1, 4, 8, 2, 2, 16, 0.25),
     "model_k2":   (2, 2, 4, 8, 2, 1, 8, 0.1),
     "model_cfg":  (2, 1, 32, 160, 2, 2, 32, 0.25),     # BASELINE geometry (z 32, h 160, 32x32 images -> 16x16 -> 8x8), shallow
+    "model_sample": (3, 1, 16, 32, 2, 2, 16, 0.25, "sample"),   # mode "sample" (tf_train.py:60-66): prior samples, kl = 0
 }
 
 
 def model_case_inputs(name):
     """Variables (TF names, tf_train.py:175-215), the uint8 image batch and the noise every DiagonalGaussian draws, in the order
     the reference's graph construction draws it: top-down, per layer the prior's noise then the posterior's."""
-    B, k, zs, hs, depth, nb, img, kl_min = MODEL_CASES[name]
+    B, k, zs, hs, depth, nb, img, kl_min = MODEL_CASES[name][:8]
+    mode = MODEL_CASES[name][8] if len(MODEL_CASES[name]) > 8 else "train"
     rng = np.random.RandomState(case_seed(name))
     p = {}
     for kk, v in conv_params(rng, 3, hs, ksize=5).items():
@@ -241,4 +243,5 @@ def model_case_inputs(name):
         for j in reversed(range(nb)):
             noise.append(rng.standard_normal((B * k, zs, H, H)))      # prior (drawn, unused in mode "train")
             noise.append(rng.standard_normal((B * k, zs, H, H)))      # posterior
-    return dict(B=B, k=k, z_size=zs, h_size=hs, depth=depth, num_blocks=nb, image_size=img, kl_min=kl_min, params=p, x=x, noise=noise)
+    return dict(B=B, k=k, z_size=zs, h_size=hs, depth=depth, num_blocks=nb, image_size=img, kl_min=kl_min, params=p, x=x, noise=noise,
+                mode=mode)

@@ -23,7 +23,7 @@ def gen_model():
         MG.seed_store("", c["params"])
         STORE.noise_log[:] = []
         STORE.noise_queue[:] = list(c["noise"])
-        me = types.SimpleNamespace(hps=hps, mode="train", dec_log_stdv=tf_shim.T(np.float64(c["params"]["dec_log_stdv"])))
+        me = types.SimpleNamespace(hps=hps, mode=c["mode"], dec_log_stdv=tf_shim.T(np.float64(c["params"]["dec_log_stdv"])))
         x_out, obj, loss = TT.CVAE1._forward(me, tf_shim.T(c["x"]), 0)
         assert not STORE.noise_queue and len(STORE.noise_log) == len(c["noise"])
         num_pixels = 3 * c["image_size"] ** 2

@@ -42,7 +42,7 @@ def test_cvae1_forward_vs_reference_golden(amd, golden_dir, name):
     g = np.load(os.path.join(golden_dir, "cvae1_forward.npz"))
     c = gi.model_case_inputs(name)
     model = amd.CVAE1(z_size=c["z_size"], h_size=c["h_size"], kl_min=c["kl_min"], depth=c["depth"], num_blocks=c["num_blocks"],
-                      k=c["k"], image_size=c["image_size"])
+                      k=c["k"], image_size=c["image_size"], mode=c["mode"])
     model.load({k: dev(v) for k, v in c["params"].items()})
     x = torch.from_numpy(c["x"]).cuda()
     x_out, obj, loss = model.forward(x, [dev(e) for e in c["noise"]])

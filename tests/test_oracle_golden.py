@@ -256,7 +256,7 @@ def test_cvae1_forward_vs_the_references_own_forward(golden_dir, name):
     g = np.load(os.path.join(golden_dir, "cvae1_forward.npz"))
     c = gi.model_case_inputs(name)
     xo, obj, loss = O.cvae1_forward(c["x"], c["params"], c["z_size"], c["h_size"], c["depth"], c["num_blocks"], c["kl_min"], c["k"],
-                                    c["noise"])
+                                    c["noise"], mode=c["mode"])
     np.testing.assert_allclose(xo, g[name + "/x_out"], rtol=0, atol=1e-12)
     np.testing.assert_allclose(obj, g[name + "/obj"], rtol=1e-12)
     np.testing.assert_allclose(loss, g[name + "/loss"], rtol=1e-12)
