@@ -134,6 +134,58 @@ __global__ __launch_bounds__(64 * PXT * KS * WCO) void iaf_conv_bf3_kernel(ConvP
         }
     }
 
+    // IN_NCHW (z, or [elu](concat(x, x2)) of a plain conv).  A thread stages ONE pixel slot per pass (lane = slot: coalesced along
+    // pixels) and the channel quads q = wave, wave + NWV, ... of it: the index arithmetic (a division by reciprocal, the source
+    // select of the concat) is per slot, a quad costs one pointer add; all loads of a pass are issued before the arithmetic, and the
+    // first pass's loads are issued HERE, in front of the weight ring's (vmcnt counts in order: a wait for a staging load issued
+    // behind the ring loads would be a wait for the ring as well).  Measured (tools/conv_stamps.py,
+    // profiles/r04/experiments/plain_conv_stamps.txt): none of this moves the launch time -- two workgroups share a CU at NT = 2 and
+    // what bounds the launch is the weight stream into the CU (32 pixels per fetched fragment), not the staging.
+    constexpr int NWV = NTHREADS / 64;
+    constexpr int SQ = 10;                                         // quads in flight per thread (c_in <= 40 NWV: every c_in the packs allow at 8 waves)
+    f32x4 nb_v[SQ];
+    int nb_slot = -1, nb_q0 = 0, nb_nq = 0;
+    bool nb_ok = false;
+    // quads [qb, qb + SQ) of this thread's list, slot pass sp
+    auto nchw_issue = [&](int sp, int qb) __attribute__((always_inline)) {
+        const int sl = sp * 64 + lane;
+        const bool in = sl < p.nslot;
+        const int Pg = Pbase + sl;
+        nb_ok = in && Pg >= 0 && Pg < p.P;
+        int b, ppx;
+        fast_divmod(nb_ok ? Pg : 0, HW, 1.0f / (float)HW, b, ppx);
+        const bool two = (EPI == EPI_PLAIN) && p.x2 != nullptr;
+        const int c1 = two ? p.c_split : p.cin;                    // channels of the first source
+        const float* s1 = p.x + (size_t)b * c1 * HW + ppx;
+        const float* s2 = two ? p.x2 + (size_t)b * (p.cin - c1) * HW + ppx : s1;
+        nb_slot = in ? sl : -1; nb_q0 = wave + qb * NWV;
+#pragma unroll
+        for (int u = 0; u < SQ; ++u) {
+            const int q = nb_q0 + u * NWV;                         // this thread's u-th quad of the batch (wave-uniform)
+            if (q < nq) {                                          // (a scalar branch)
+                const bool second = two && 4 * q >= c1;
+                const float* src = (second ? s2 + (size_t)(4 * q - c1) * HW : s1 + (size_t)(4 * q) * HW);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) nb_v[u][r] = src[(size_t)r * HW];
+            }
+        }
+    };
+    auto nchw_finish = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < SQ; ++u) {
+            const int q = nb_q0 + u * NWV;
+            if (q >= nq) continue;
+            f32x4 v = nb_v[u];
+            if (EPI == EPI_PLAIN && p.in_elu) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = elu_f(v[r]);
+            }
+            if (!nb_ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (nb_slot >= 0) bf3_store4(smem, nb_slot, q, v, s16, cin8);
+        }
+    };
+    if constexpr (INMODE == IN_NCHW && S2 != 1) nchw_issue(0, 0);
+
     // ================= prologue (2): weight ring ======================================================================
     // step s = pair * 5 + tap; wave kh owns steps [s0, s1).  One step = NT tiles x 3 planes x 1 KiB, contiguous.
     const int S = S2 == 2 ? npair << lgt : npair * NTP;
@@ -186,6 +238,8 @@ __global__ __launch_bounds__(64 * PXT * KS * WCO) void iaf_conv_bf3_kernel(ConvP
     }
 
     // NCHW source (z, or the posterior sample computed on the fly) -> three bf16 planes of an LDS tile of `nsl` slots
+    // NCHW source (z, or the posterior sample computed on the fly) -> three bf16 planes of an LDS tile of `nsl` slots (the fused first
+    // layer's z tile and the posterior sample; a plain NCHW input goes through nchw_issue / nchw_finish above)
     auto stage_nchw = [&](char* region, int nsl, int cin_, int s16_, int cin8_, const float* xsrc, bool posterior) {
         const int nit = nsl * (cin_ >> 2);
         // (index arithmetic by float reciprocal: an integer division is ~40 instructions on this ISA)
@@ -411,8 +465,14 @@ __global__ __launch_bounds__(64 * PXT * KS * WCO) void iaf_conv_bf3_kernel(ConvP
             }
         } else if (S2 == 1) {
             stage_s2d();
-        } else if (INMODE == IN_NCHW || INMODE == IN_POSTERIOR) {
-            stage_nchw(smem, p.nslot, p.cin, s16, cin8, p.x, INMODE == IN_POSTERIOR);
+        } else if (INMODE == IN_NCHW) {
+            nchw_finish();                                         // (pass 0, first SQ quads: issued in prologue (1))
+            const int nqt = (nq + NWV - 1) / NWV;                  // quads per thread and slot
+            for (int qb = SQ; qb < nqt; qb += SQ) { nchw_issue(0, qb); nchw_finish(); }
+            for (int sp = 1; sp * 64 < p.nslot; ++sp)
+                for (int qb = 0; qb < nqt; qb += SQ) { nchw_issue(sp, qb); nchw_finish(); }
+        } else if (INMODE == IN_POSTERIOR) {
+            stage_nchw(smem, p.nslot, p.cin, s16, cin8, p.x, true);
         }
     }
     if constexpr (INMODE == IN_FUSED0) { IAF_BSTAMP(6); fused_layer0(); IAF_BSTAMP(7); }

@@ -46,6 +46,6 @@ for name, ci, co, split in (("up_conv1", 160, 384, [32, 32, 160, 160]), ("up_con
     st = st[st[:, 0] != 0]
     d = lambda i, j: float(np.mean(st[:, i] - st[:, j]))
     t0, t1 = st[:, 0].min(), st[:, 5].max()
-    print("%-10s shape %s: %.1f us; %d workgroups; per workgroup (100 MHz ticks): ring primed %.0f, tile staged +%.0f, K loop +%.0f, "
-          "exchange +%.0f, epilogue +%.0f = %.0f; launch span %.0f ticks" % (
-              name, sh, us, len(st), d(1, 0), d(2, 1), d(3, 2), d(4, 3), d(5, 4), d(5, 0), float(t1 - t0)), flush=True)
+    print("%-10s shape %s: %.1f us; %d workgroups; per workgroup (cycles): ring primed %.0f, tile staged +%.0f, K loop +%.0f, "
+          "exchange +%.0f, epilogue +%.0f = %.0f" % (
+              name, sh, us, len(st), d(1, 0), d(2, 1), d(3, 2), d(4, 3), d(5, 4), d(5, 0)), flush=True)
