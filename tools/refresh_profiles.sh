@@ -12,6 +12,7 @@ python -m pytest $R/tests -q -m gpu 2>&1 | tail -4 > $O/pytest_gpu.txt
 python $R/bench.py --precision f32 > $O/bench_f32_n1.json 2> /dev/null
 python $R/bench.py --no-fuse-step > $O/bench_layer_by_layer_n1.json 2> /dev/null
 python $R/bench.py --layers > $O/bench_layers_n1.json 2> /dev/null
+python $R/bench.py --layers --model > $O/bench_model_n1.json 2> /dev/null
 python $R/bench.py --iw-eval --steps 100 > $O/bench_iw_eval_n1.json 2> /dev/null
 IAF_BENCH_FORCE_DIST=1 python $R/bench.py --train --steps 50 > $O/bench_train_n1.json 2> /dev/null
 IAF_BENCH_FORCE_DIST=1 python $R/bench.py --train --layers --steps 20 --warmup 5 > $O/bench_train_layers_n1.json 2> /dev/null
@@ -49,4 +50,10 @@ python $R/tools/layer_train_bench.py > $O/layer_train_bench.txt 2>&1
 timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pl -o lt -- python $R/tools/layer_train_bench.py > /dev/null 2>&1
 cp /tmp/pl/*kernel_stats.csv $O/layer_train_kernel_stats.csv
 (python $R/tools/soak.py --iters 20000 --fresh 1000) > $O/soak_prod.txt 2>&1
+python $R/tools/ds_layer_time.py 2>&1 | grep -v amdgpu.ids > $O/ds_layer_time.txt
+python $R/tools/conv_stamps.py 2>&1 | grep -v amdgpu.ids > $O/plain_conv_stamps.txt
+IAF_XCH_DEBUG=3 python -m pytest $R/tests -q -m gpu 2>&1 | tail -4 > $O/pytest_gpu_scrambled.txt
+# one steady-state training step of the 20-layer model, kernel by kernel
+timeout 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/ptl -o tl -- python $R/bench.py --train --layers --steps 6 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+python $R/tools/step_breakdown.py $(ls /tmp/ptl/*/*kernel_trace.csv /tmp/ptl/*kernel_trace.csv 2>/dev/null | head -1) > $O/train_layers_step_breakdown.txt 2>&1
 tail -3 $O/pytest_gpu.txt; python $R/tools/show_bench.py $O/bench_n1.json; cat $O/make_profile_json.txt; cat $O/fused_step_stamps.txt; cat $O/layer_train_bench.txt | tail -3; head -12 $O/layer_train_kernel_stats.csv | cut -c1-160; tail -2 $O/soak_prod.txt
