@@ -135,6 +135,12 @@ SIGNATURES = {
     "iaf_deconvk_forward": (ctypes.c_int, [_vp, _vp, _vp, _vp] + [ctypes.c_int] * 9 + [ctypes.c_float, ctypes.c_float, _vp]),
     "iaf_tile_channels": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
     "iaf_sum_axpy": (ctypes.c_int, [_vp, _vp, ctypes.c_float, _vp, ctypes.c_int, _vp]),
+    "iaf_discretized_logistic_backward": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp, _vp,
+                                                         ctypes.c_int, ctypes.c_size_t, ctypes.c_float, _vp]),
+    "iaf_convk_wgrad": (ctypes.c_int, [_vp, _vp, _vp] + [ctypes.c_int] * 10 + [_vp]),
+    "iaf_convk_weightnorm_backward": (ctypes.c_int, [_vp] * 6 + [ctypes.c_int] * 5 + [_vp]),
+    "iaf_channel_sum": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
+    "iaf_mul_elu_grad": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t, _vp]),
     "iaf_conv3x3_forward_stride2": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_int),
                                                    ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
     "iaf_conv3x3_forward_deconv": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int, ctypes.c_int,

@@ -315,7 +315,7 @@ extern "C" int iaf_conv3x3_prep_batch_run(iaf_conv3x3_prep_batch_t* b, const flo
         int rc = tb.flush();
         if (rc) return rc;
     }
-    for (int i = 0; i < b->n; ++i) b->convs[i]->prepared = true;
+    for (int i = 0; i < b->n; ++i) { b->convs[i]->prepared = true; b->convs[i]->deconv = false; }   // (packs of a conv2d now, as iaf_conv3x3_prepare leaves them)
     return IAF_OK;
 }
 

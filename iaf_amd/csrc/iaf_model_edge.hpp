@@ -5,6 +5,7 @@
 // split over 16 thread slices), latency-bound, 10-20 microseconds each at the BASELINE batch.
 // Part of the single translation unit iaf_engine.hip (included there; not a standalone header).
 #pragma once
+#include "iaf_conv_epilogue.hpp"     // fast_divmod
 
 // out[(b k + s)][i] = clip((x[b][i] + 0.5) / 256, 0, 1) - 0.5  for s < k   (tf_train.py:153-154, repeat :159)
 __global__ __launch_bounds__(256) void iaf_image_to_float_kernel(const unsigned char* __restrict__ x, float* __restrict__ out,
@@ -274,5 +275,203 @@ extern "C" int iaf_sum_axpy(const float* a, const float* b, float sb, float* out
     if (!a || !out) return IAF_ERR_NULL;
     if (n <= 0) return IAF_ERR_SHAPE;
     hipLaunchKernelGGL(iaf_sum_axpy_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a, b, sb, out, n);
+    return (int)hipGetLastError();
+}
+
+// ==================================================================================================================================
+// Backward of the two ends: what TF autodiff derives for tf_train.py:183, 189-192, 206-211 in `opt.compute_gradients(obj)` (:128)
+// ==================================================================================================================================
+// d log_pxz / d mean and / d logscale of discretized_logistic (distributions.py:28-32), times `up` (= d obj / d log_pxz = -1,
+// tf_train.py:211), with clip_by_value's gradient folded in (:208: the gradient passes where the value was not clipped).
+//   s = (floor(x / b) b - mean) / scale,  t = s + b / scale,  P = sig(t) - sig(s) + 1e-7,  logp = log P
+//   d logp / d mean = -(sig'(t) - sig'(s)) / (scale P);   d logp / d logscale = (-t sig'(t) + s sig'(s)) / P
+// One workgroup per row; d_logscale_rows[b] = up * sum over the row (summed over rows by iaf_sum_axpy).
+__global__ __launch_bounds__(256) void iaf_discretized_logistic_bwd_kernel(const float* __restrict__ mean, const float* __restrict__ logscale,
+                                                                          const float* __restrict__ sample, float up, float clip_lo,
+                                                                          float clip_hi, float* __restrict__ d_mean,
+                                                                          float* __restrict__ d_logscale_rows, size_t n_per_row,
+                                                                          float binsize) {
+    __shared__ float red[256];
+    const float scale = __expf(logscale[0]), inv = 1.0f / scale;
+    const size_t base = (size_t)blockIdx.x * n_per_row;
+    float acc = 0.f;
+    for (size_t i = threadIdx.x; i < n_per_row; i += 256) {
+        const float m = mean[base + i];
+        const float s = (floorf(sample[base + i] / binsize) * binsize - m) * inv, t = s + binsize * inv;
+        const float ss = 1.0f / (1.0f + __expf(-s)), st = 1.0f / (1.0f + __expf(-t));
+        const float P = st - ss + 1e-7f;
+        const float ds = ss * (1.0f - ss), dt = st * (1.0f - st);
+        const bool pass = !(clip_lo < clip_hi) || (m > clip_lo && m < clip_hi);
+        d_mean[base + i] = pass ? up * (-(dt - ds) * inv / P) : 0.f;
+        acc += (-t * dt + s * ds) / P;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) d_logscale_rows[blockIdx.x] = up * red[0];
+}
+
+// dW[a][c][ci][o] = sum_{b,oy,ox} X[b,ci,oy s + a - pad_t, ox s + c - pad_l] DY[b,o,oy,ox]  -- the weight gradient of a strided SAME conv
+// with few channels (n_small) on its large-grid side: x_enc (X = the image, DY = d h) and, with the roles of data and gradient
+// exchanged, x_dec (X = d x_out, DY = elu(h): its filter [kh,kw,3,h] has the same layout).  Workgroup = (tap, ci, 16 channels o);
+// thread = (o, one of 16 pixel lanes); the lanes' partial sums are added by shuffles in a fixed order.
+struct ConvKWP {
+    const float* x; const float* dy; float* dW;
+    int B, n_small, H, W, n_big, OH, OW, kh, kw, stride, pad_t, pad_l, elu_x, elu_dy;
+};
+__global__ __launch_bounds__(256) void iaf_convk_wgrad_kernel(ConvKWP p) {
+    const int tapci = blockIdx.x, tap = tapci / p.n_small, ci = tapci - tap * p.n_small;
+    const int a = tap / p.kw, c = tap - a * p.kw;
+    const int o = blockIdx.y * 16 + (threadIdx.x >> 4), ln = threadIdx.x & 15;
+    const int OHW = p.OH * p.OW, npx = p.B * OHW;
+    const float rOHW = 1.0f / (float)OHW, rOW = 1.0f / (float)p.OW;
+    const bool olive = o < p.n_big;
+    const int oc = olive ? o : p.n_big - 1;
+    float acc = 0.f;
+    for (int px = ln; px < npx; px += 16) {
+        int b, r, oy, ox;
+        fast_divmod(px, OHW, rOHW, b, r);
+        fast_divmod(r, p.OW, rOW, oy, ox);
+        const int iy = oy * p.stride + a - p.pad_t, ix = ox * p.stride + c - p.pad_l;
+        const bool in = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        float xv = p.x[(((size_t)b * p.n_small + ci) * p.H + (in ? iy : 0)) * p.W + (in ? ix : 0)];
+        if (p.elu_x) xv = elu_f(xv);
+        xv = in ? xv : 0.f;
+        float dv = p.dy[((size_t)b * p.n_big + oc) * OHW + r];
+        if (p.elu_dy) dv = elu_f(dv);
+        acc += xv * dv;
+    }
+    acc += __shfl_xor(acc, 8, 16);
+    acc += __shfl_xor(acc, 4, 16);
+    acc += __shfl_xor(acc, 2, 16);
+    acc += __shfl_xor(acc, 1, 16);
+    if (ln == 0 && olive) p.dW[(size_t)tapci * p.n_big + o] = acc;
+}
+
+// Through the weight norm (layers.py:56-60 / 104-106), one workgroup per normalised channel `ch` (the last axis of V [taps][n_a][n_b]):
+//   conv    w = e_ch V / n_ch:      dg[ch] = e_ch (dW . V) / n;   dV = (e_ch / n) (dW - V (dW . V) / n^2)
+//   deconv  w = e_a V / n_ch (a = the n_a index): S = sum e_a dW V;  dV = e_a dW / n - V S / n^3;  dg[a] = sum_ch (partial[ch][a] = sum_taps dW w)
+__global__ __launch_bounds__(256) void iaf_convk_weightnorm_bwd_kernel(const float* __restrict__ V, const float* __restrict__ g,
+                                                                      const float* __restrict__ dW, float* __restrict__ dV,
+                                                                      float* __restrict__ dg_or_partial, int taps, int n_a, int n_b,
+                                                                      int deconv) {
+    __shared__ float red[2][256];
+    const int ch = blockIdx.x;
+    float ss = 0.f, dot = 0.f;
+    for (int e = threadIdx.x; e < taps * n_a; e += 256) {
+        const float v = V[(size_t)e * n_b + ch], d = dW[(size_t)e * n_b + ch];
+        const float gain = deconv ? __expf(g[e % n_a]) : 1.0f;
+        ss += v * v;
+        dot += d * gain * v;
+    }
+    red[0][threadIdx.x] = ss; red[1][threadIdx.x] = dot;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) { red[0][threadIdx.x] += red[0][threadIdx.x + k]; red[1][threadIdx.x] += red[1][threadIdx.x + k]; }
+        __syncthreads();
+    }
+    const float s2 = fmaxf(red[0][0], 1e-12f), n = sqrtf(s2), S = red[1][0];
+    const float e_ch = deconv ? 1.0f : __expf(g[ch]);
+    for (int e = threadIdx.x; e < taps * n_a; e += 256) {
+        const float v = V[(size_t)e * n_b + ch], d = dW[(size_t)e * n_b + ch];
+        const float gain = deconv ? __expf(g[e % n_a]) : e_ch;
+        dV[(size_t)e * n_b + ch] = deconv ? gain * d / n - v * S / (n * s2) : (gain / n) * (d - v * S / s2);
+    }
+    if (!deconv) {
+        if (threadIdx.x == 0) dg_or_partial[ch] = e_ch * S / n;
+    } else {
+        __syncthreads();
+        for (int a = 0; a < n_a; ++a) {                             // (n_a = the few output channels of x_dec)
+            float t = 0.f;
+            for (int tp = threadIdx.x; tp < taps; tp += 256) {
+                const size_t e = (size_t)tp * n_a + a;
+                t += dW[e * n_b + ch] * __expf(g[a]) * V[e * n_b + ch] / n;
+            }
+            red[0][threadIdx.x] = t;
+            __syncthreads();
+            for (int k = 128; k > 0; k >>= 1) {
+                if ((int)threadIdx.x < k) red[0][threadIdx.x] += red[0][threadIdx.x + k];
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) dg_or_partial[(size_t)ch * n_a + a] = red[0][0];
+            __syncthreads();
+        }
+    }
+}
+
+// out[c] = sum_{b,p} x[b,c,p]: a conv's bias gradient, and d h_top (the adjoint of tf.tile, tf_train.py:190-192)
+__global__ __launch_bounds__(256) void iaf_channel_sum_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int C, int HW) {
+    __shared__ float red[256];
+    const int c = blockIdx.x;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b)
+        for (int i = threadIdx.x; i < HW; i += 256) s += x[((size_t)b * C + c) * HW + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[c] = red[0];
+}
+
+// out = g * elu'(h), elu'(h) = h > 0 ? 1 : exp(h)  (the ELU in front of x_dec, tf_train.py:206)
+__global__ __launch_bounds__(256) void iaf_mul_elu_grad_kernel(const float* __restrict__ g, const float* __restrict__ h,
+                                                              float* __restrict__ out, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = g[i] * (h[i] > 0.f ? 1.0f : __expf(h[i]));
+}
+
+extern "C" int iaf_discretized_logistic_backward(const float* mean, const float* logscale, const float* sample, float up, float clip_lo,
+                                                 float clip_hi, float* d_mean, float* d_logscale_rows, int B, size_t n_per_row,
+                                                 float binsize, void* stream) {
+    if (!mean || !logscale || !sample || !d_mean || !d_logscale_rows) return IAF_ERR_NULL;
+    if (B <= 0 || n_per_row == 0 || !(binsize > 0.f)) return IAF_ERR_SHAPE;
+    hipLaunchKernelGGL(iaf_discretized_logistic_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, mean, logscale, sample, up, clip_lo,
+                       clip_hi, d_mean, d_logscale_rows, n_per_row, binsize);
+    return (int)hipGetLastError();
+}
+
+extern "C" int iaf_convk_wgrad(const float* x, const float* dy, float* dW, int B, int n_small, int H, int W, int n_big, int kh, int kw,
+                               int stride, int elu_x, int elu_dy, void* stream) {
+    if (!x || !dy || !dW) return IAF_ERR_NULL;
+    if (B <= 0 || n_small <= 0 || n_big <= 0 || H <= 0 || W <= 0 || kh <= 0 || kw <= 0 || stride <= 0) return IAF_ERR_SHAPE;
+    ConvKWP p;
+    memset(&p, 0, sizeof(p));
+    p.x = x; p.dy = dy; p.dW = dW; p.B = B; p.n_small = n_small; p.H = H; p.W = W; p.n_big = n_big; p.kh = kh; p.kw = kw;
+    p.stride = stride; p.elu_x = elu_x ? 1 : 0; p.elu_dy = elu_dy ? 1 : 0;
+    same_pad(H, kh, stride, &p.OH, &p.pad_t);
+    same_pad(W, kw, stride, &p.OW, &p.pad_l);
+    if ((long long)B * p.OH * p.OW > (1LL << 24)) return IAF_ERR_SHAPE;
+    hipLaunchKernelGGL(iaf_convk_wgrad_kernel, dim3(kh * kw * n_small, (n_big + 15) / 16), dim3(256), 0, (hipStream_t)stream, p);
+    return (int)hipGetLastError();
+}
+
+// dV (V's layout), dg [n_out]; deconv: scratch = n_in * n_out floats
+extern "C" int iaf_convk_weightnorm_backward(const float* V, const float* g, const float* dW, float* dV, float* dg, float* scratch,
+                                             int kh, int kw, int n_in, int n_out, int deconv, void* stream) {
+    if (!V || !g || !dW || !dV || !dg || (deconv && !scratch)) return IAF_ERR_NULL;
+    if (kh <= 0 || kw <= 0 || n_in <= 0 || n_out <= 0) return IAF_ERR_SHAPE;
+    hipLaunchKernelGGL(iaf_convk_weightnorm_bwd_kernel, dim3(deconv ? n_in : n_out), dim3(256), 0, (hipStream_t)stream, V, g, dW, dV,
+                       deconv ? scratch : dg, kh * kw, deconv ? n_out : n_in, deconv ? n_in : n_out, deconv ? 1 : 0);
+    HIP_TRY(hipGetLastError());
+    if (deconv) return iaf_colsum(scratch, dg, n_in, n_out, stream);
+    return IAF_OK;
+}
+
+extern "C" int iaf_channel_sum(const float* x, float* out, int B, int C, int HW, void* stream) {
+    if (!x || !out) return IAF_ERR_NULL;
+    if (B <= 0 || C <= 0 || HW <= 0) return IAF_ERR_SHAPE;
+    hipLaunchKernelGGL(iaf_channel_sum_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, out, B, C, HW);
+    return (int)hipGetLastError();
+}
+
+extern "C" int iaf_mul_elu_grad(const float* g, const float* h, float* out, size_t n, void* stream) {
+    if (!g || !h || !out) return IAF_ERR_NULL;
+    if (n == 0) return IAF_ERR_SHAPE;
+    hipLaunchKernelGGL(iaf_mul_elu_grad_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)stream, g, h, out, n);
     return (int)hipGetLastError();
 }

@@ -3,7 +3,8 @@ image scaling, conv2d("x_enc", 5x5, stride 2), the bottom-up pass through depth 
 top-down pass accumulating kl_obj / kl_cost, deconv2d("x_dec", 5x5) + clip, discretized_logistic, obj and the (k-sample) loss.
 Every number is computed by HIP launches behind the C ABI (include/iaf_hip.h); torch tensors are storage.  The two edge convs
 have 3 channels on one side and run as direct convolutions (csrc/iaf_model_edge.hpp); the layers are iaf_amd.IAFLayer.
-Forward only (the trainable unit of this package is the layer stack: IAFLayer.*_backward, bench.py --train --layers)."""
+forward() for every mode; forward_backward() = one tower's training objective and its gradient w.r.t. every variable (mode "train",
+k = 1): the layers' backward (IAFLayer.down_backward / .up_backward) chained through the model + the backward of the two ends."""
 import math
 
 import torch
@@ -43,10 +44,12 @@ class CVAE1(object):
                                              _stream()))                                                    # layers.py:56-60
         _capi.check(lib.iaf_convk_weightnorm(_ptr(params["x_dec/V"]), _ptr(params["x_dec/g"]), _ptr(self._w_dec), 5, 5, hs, 3, 1,
                                              _stream()))                                                    # layers.py:104-106
+        self._lparams = {}
         for i, level in enumerate(self.layers):
             for j, layer in enumerate(level):
                 pre = "IAF_%d_%d/" % (i, j)
-                layer.load({k[len(pre):]: v for k, v in params.items() if k.startswith(pre)})
+                self._lparams[(i, j)] = {k[len(pre):]: v for k, v in params.items() if k.startswith(pre)}
+                layer.load(self._lparams[(i, j)])
         self.params = params
 
     def forward(self, x, noise):
@@ -101,6 +104,106 @@ class CVAE1(object):
         lb = compute_lowerbound(log_pxz, kl_cost, k)                                                       # :218
         _capi.check(lib.iaf_sum_axpy(_ptr(lb), None, 0.0, _ptr(loss), B, _stream()))
         return x_out, obj, loss
+
+    # -- training: d obj / d every variable, what opt.compute_gradients(obj) hands the optimizer (tf_train.py:128, 211) -----------------
+    def set_training(self, on=True):
+        """allocate what the backward needs in every layer (transposed packs); call load(params) afterwards"""
+        for level in self.layers:
+            for layer in level:
+                layer.set_training(on)
+        self._training = bool(on)
+        self.params = None
+
+    def forward_backward(self, x, noise):
+        """One tower's forward and backward in mode "train", k = 1: returns (x_out, obj [1], grads) with grads[name] = d obj / d params[name]
+        for every variable.  The layer stack's backward is IAFLayer.down_backward / .up_backward chained through the model (the down pass
+        in up-pass order, then the up pass in reverse); the two ends -- likelihood, clip, x_dec, h_top, x_enc -- are the launches of
+        csrc/iaf_model_edge.hpp.  noise as in forward()."""
+        if not getattr(self, "_training", False) or self.params is None:
+            raise RuntimeError("CVAE1.set_training(True), then load(params), before forward_backward")
+        if self.k != 1 or self.mode != "train":
+            raise ValueError("forward_backward: mode 'train', k = 1 (the training objective, tf_train.py:211)")
+        lib, p, hs = _capi.lib(), self.params, self.h_size
+        B, _, S, _ = (int(v) for v in x.shape)
+        if x.dtype != torch.uint8 or S != self.image_size or len(noise) != 2 * self.depth * self.num_blocks:
+            raise ValueError("x: uint8 [B,3,%d,%d]; noise: %d tensors" % (self.image_size, self.image_size, 2 * self.depth * self.num_blocks))
+        n, dev, st = B, x.device, _stream
+        f32 = dict(dtype=torch.float32, device=dev)
+        # ---- forward, keeping what the backward reads
+        xf = torch.empty((n, 3, S, S), **f32)
+        _capi.check(lib.iaf_image_to_float(x.data_ptr(), _ptr(xf), B, 3 * S * S, 1, st()))
+        h = torch.empty((n, hs, S // 2, S // 2), **f32)
+        _capi.check(lib.iaf_convk_forward(_ptr(xf), _ptr(self._w_enc), _ptr(p["x_enc/b"]), _ptr(h), n, 3, S, S, hs, 5, 5, 2, 0, st()))
+        for level in self.layers:
+            for layer in level:
+                h = layer.up_train(h)
+        St = S // 2 ** self.depth
+        h = torch.empty((n, hs, St, St), **f32)
+        _capi.check(lib.iaf_tile_channels(_ptr(p["h_top"]), _ptr(h), n, hs, St * St, st()))
+        objs, li = [], 0
+        for level in reversed(self.layers):
+            for layer in reversed(level):
+                h, cur_obj, _ = layer.down_train(h, noise[2 * li + 1])
+                objs.append(cur_obj)
+                li += 1
+        h_last = h
+        objs = torch.stack(objs)
+        kl_obj = torch.empty(n, **f32)
+        _capi.check(lib.iaf_colsum(_ptr(objs), _ptr(kl_obj), li, n, st()))
+        lo, hi = -0.5 + 1 / 512., 0.5 - 1 / 512.
+        x_out = torch.empty((n, 3, S, S), **f32)
+        _capi.check(lib.iaf_deconvk_forward(_ptr(h_last), _ptr(self._w_dec), _ptr(p["x_dec/b"]), _ptr(x_out), n, hs, S // 2, S // 2, 3, 5, 5,
+                                            2, 1, lo, hi, st()))
+        log_pxz = discretized_logistic(x_out, p["dec_log_stdv"], sample=xf)
+        obj = torch.empty(1, **f32)
+        _capi.check(lib.iaf_sum_axpy(_ptr(kl_obj), _ptr(log_pxz), -1.0, _ptr(obj), n, st()))
+        # ---- backward of the top end: obj = sum(kl_obj - log_pxz)  (tf_train.py:206-211)
+        grads = {}
+        d_xout = torch.empty_like(x_out)
+        dls_rows = torch.empty(n, **f32)
+        logscale = p["dec_log_stdv"].reshape(1).contiguous()
+        _capi.check(lib.iaf_discretized_logistic_backward(_ptr(x_out), _ptr(logscale), _ptr(xf), -1.0, lo, hi, _ptr(d_xout), _ptr(dls_rows), n,
+                                                          3 * S * S, 1 / 256.0, st()))
+        dls = torch.empty(1, **f32)
+        _capi.check(lib.iaf_sum_axpy(_ptr(dls_rows), None, 0.0, _ptr(dls), n, st()))
+        grads["dec_log_stdv"] = dls.reshape(p["dec_log_stdv"].shape)
+        dW = torch.empty_like(p["x_dec/V"])
+        _capi.check(lib.iaf_convk_wgrad(_ptr(d_xout), _ptr(h_last), _ptr(dW), n, 3, S, S, hs, 5, 5, 2, 0, 1, st()))
+        grads["x_dec/V"], grads["x_dec/g"], grads["x_dec/b"] = torch.empty_like(dW), torch.empty(3, **f32), torch.empty(3, **f32)
+        scratch = torch.empty(hs * 3, **f32)
+        _capi.check(lib.iaf_convk_weightnorm_backward(_ptr(p["x_dec/V"]), _ptr(p["x_dec/g"]), _ptr(dW), _ptr(grads["x_dec/V"]),
+                                                      _ptr(grads["x_dec/g"]), _ptr(scratch), 5, 5, hs, 3, 1, st()))
+        _capi.check(lib.iaf_channel_sum(_ptr(d_xout), _ptr(grads["x_dec/b"]), n, 3, S * S, st()))
+        # d h_last = elu'(h_last) * (the strided conv of d x_out with x_dec's filter: the adjoint of the transposed conv)
+        zero_b = torch.zeros(hs, **f32)
+        t = torch.empty_like(h_last)
+        _capi.check(lib.iaf_convk_forward(_ptr(d_xout), _ptr(self._w_dec), _ptr(zero_b), _ptr(t), n, 3, S, S, hs, 5, 5, 2, 0, st()))
+        d = torch.empty_like(h_last)
+        _capi.check(lib.iaf_mul_elu_grad(_ptr(t), _ptr(h_last), _ptr(d), t.numel(), st()))
+        # ---- the layer stack: the top-down pass backwards (= in up-pass order), then the bottom-up pass backwards
+        dko = torch.ones(n, **f32)                                   # d obj / d kl_obj of every layer
+        lgrads = {}
+        for i, level in enumerate(self.layers):
+            for j, layer in enumerate(level):
+                lgrads[(i, j)] = {}
+                d = layer.down_backward(d, dko, self._lparams[(i, j)], lgrads[(i, j)])
+        grads["h_top"] = torch.empty(hs, **f32)
+        _capi.check(lib.iaf_channel_sum(_ptr(d), _ptr(grads["h_top"]), n, hs, St * St, st()))                 # adjoint of the tile (:190-192)
+        d = torch.zeros((n, hs, St, St), **f32)                      # the up pass's last output is not used (h_top replaces it)
+        for i in reversed(range(self.depth)):
+            for j in reversed(range(self.num_blocks)):
+                d = self.layers[i][j].up_backward(d, self._lparams[(i, j)], lgrads[(i, j)])
+        for (i, j), lg in lgrads.items():
+            for k, v in lg.items():
+                grads["IAF_%d_%d/%s" % (i, j, k)] = v
+        # ---- x_enc (:183)
+        dW = torch.empty_like(p["x_enc/V"])
+        _capi.check(lib.iaf_convk_wgrad(_ptr(xf), _ptr(d), _ptr(dW), n, 3, S, S, hs, 5, 5, 2, 0, 0, st()))
+        grads["x_enc/V"], grads["x_enc/g"], grads["x_enc/b"] = torch.empty_like(dW), torch.empty(hs, **f32), torch.empty(hs, **f32)
+        _capi.check(lib.iaf_convk_weightnorm_backward(_ptr(p["x_enc/V"]), _ptr(p["x_enc/g"]), _ptr(dW), _ptr(grads["x_enc/V"]),
+                                                      _ptr(grads["x_enc/g"]), None, 5, 5, 3, hs, 0, st()))
+        _capi.check(lib.iaf_channel_sum(_ptr(d), _ptr(grads["x_enc/b"]), n, hs, (S // 2) ** 2, st()))
+        return x_out, obj, grads
 
     def bits_per_dim(self, loss, batch_size):
         """tf_train.py:133 for one tower: loss / (log 2 * num_pixels * batch_size)"""

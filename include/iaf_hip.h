@@ -557,6 +557,25 @@ int iaf_tile_channels(const float* v, float* out, int B, int C, int HW, void* st
 /* out[0] = sum_i (a[i] + sb b[i]) (b may be NULL), fixed summation order: obj = reduce_sum(kl_obj - log_pxz) (tf_train.py:211),
  * loss = reduce_sum(compute_lowerbound(...)) (:218) */
 int iaf_sum_axpy(const float* a, const float* b, float sb, float* out, int n, void* stream);
+/* Backward of the two ends -- what TF autodiff derives for tf_train.py:183, 189-192, 206-211 under opt.compute_gradients(obj) (:128):
+ * iaf_discretized_logistic_backward: d_mean = up * d log_pxz / d mean with clip_by_value's gradient folded in (zero where mean sits on
+ *   clip_lo / clip_hi; no clipping when clip_lo >= clip_hi), d_logscale_rows[b] = up * sum over row b of d log p / d logscale
+ *   (tf_utils/distributions.py:28-32; up = -1 for obj = sum(kl_obj - log_pxz)).
+ * iaf_convk_wgrad: dW[a][c][ci][o] = sum_{b,oy,ox} X[b,ci,oy s + a - pad_t, ox s + c - pad_l] DY[b,o,oy,ox] (SAME padding), X [B,n_small,H,W]
+ *   on the large grid, DY [B,n_big,ceil(H/s),ceil(W/s)], optional ELU on either operand: x_enc's filter gradient (X = image, DY = d h)
+ *   and x_dec's (X = d x_out, DY = elu(h): V [kh,kw,3,h] has the same layout).
+ * iaf_convk_weightnorm_backward: dW -> dV, dg through iaf_convk_weightnorm's reparametrisation (deconv: scratch of n_in * n_out floats).
+ * iaf_channel_sum: out[c] = sum_{b,p} x[b,c,p] (bias gradients; d h_top = the adjoint of the tile).
+ * iaf_mul_elu_grad: out = g * elu'(h). */
+int iaf_discretized_logistic_backward(const float* mean, const float* logscale, const float* sample, float up, float clip_lo,
+                                      float clip_hi, float* d_mean, float* d_logscale_rows, int B, size_t n_per_row, float binsize,
+                                      void* stream);
+int iaf_convk_wgrad(const float* x, const float* dy, float* dW, int B, int n_small, int H, int W, int n_big, int kh, int kw, int stride,
+                    int elu_x, int elu_dy, void* stream);
+int iaf_convk_weightnorm_backward(const float* V, const float* g, const float* dW, float* dV, float* dg, float* scratch, int kh, int kw,
+                                  int n_in, int n_out, int deconv, void* stream);
+int iaf_channel_sum(const float* x, float* out, int B, int C, int HW, void* stream);
+int iaf_mul_elu_grad(const float* g, const float* h, float* out, size_t n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -160,6 +160,82 @@ def iaf_layer_grads(up_inp, down_inp, eps, params, z_size, h_size, kl_min, d_up_
 
 
 # --------------------------------------------------------------------------------------
+# the whole model, CVAE1._forward (tf_train.py:150-218), for `opt.compute_gradients(obj)` (tf_train.py:128)
+# --------------------------------------------------------------------------------------
+def _sub(params, prefix):
+    return {k[len(prefix):]: v for k, v in params.items() if k.startswith(prefix)}
+
+
+def _layer_up(inp, p, zs, hs, downsample):
+    """tf_train.py:29-44 (the lines of iaf_layer above, up pass only)"""
+    conv1 = conv2d_stride2 if downsample else conv2d
+    x = conv1(F.elu(inp), p["up_conv1/V"], p["up_conv1/g"], p["up_conv1/b"])
+    qz_mean, qz_logsd, up_context, h = torch.split(x, [zs, zs, hs, hs], dim=1)
+    h = conv2d(F.elu(h), p["up_conv3/V"], p["up_conv3/g"], p["up_conv3/b"])
+    return (inp[:, :, ::2, ::2] if downsample else inp) + 0.1 * h, qz_mean, qz_logsd, up_context
+
+
+def _layer_down(inp, p, qz_mean, qz_logsd, up_context, eps, zs, hs, kl_min, downsample):
+    """tf_train.py:46-95, mode train (the lines of iaf_layer above, down pass only)"""
+    x = conv2d(F.elu(inp), p["down_conv1/V"], p["down_conv1/g"], p["down_conv1/b"])
+    pz_mean, pz_logsd, rz_mean, rz_logsd, down_context, h_det = torch.split(x, [zs] * 4 + [hs] * 2, dim=1)
+    sp = _sub(p, "ar_multiconv2d/")
+    n_h = [hs] * sum(1 for k in sp if k.startswith("layer_") and not k.startswith("layer_out") and k.endswith("/g"))
+    z, kl_obj, kl_cost = posterior_block(qz_mean, qz_logsd, rz_mean, rz_logsd, pz_mean, pz_logsd, up_context, down_context, eps, sp,
+                                         n_h, kl_min)
+    hh = F.elu(torch.cat([z, h_det], dim=1))
+    if downsample:
+        h = deconv2d(hh, p["down_deconv2/V"], p["down_deconv2/g"], p["down_deconv2/b"])
+        return inp.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3) + 0.1 * h, kl_obj, kl_cost
+    return inp + 0.1 * conv2d(hh, p["down_conv2/V"], p["down_conv2/g"], p["down_conv2/b"]), kl_obj, kl_cost
+
+
+def cvae1_obj(x_uint8, params, z_size, h_size, depth, num_blocks, kl_min, noise):
+    """tf_train.py:150-211 for k = 1, mode train, on torch fp64 tensors (params: dict of tensors).  Returns (x_out, obj)."""
+    x = torch.clamp((_t(np.asarray(x_uint8, dtype=np.float64)) + 0.5) / 256.0, 0.0, 1.0) - 0.5                 # :153-154
+    V, g, b = params["x_enc/V"], params["x_enc/g"], params["x_enc/b"]
+    w = torch.exp(g).reshape(1, 1, 1, -1) * V / torch.sqrt(torch.clamp((V * V).sum(dim=(0, 1, 2), keepdim=True), min=1e-12))
+    h = F.conv2d(F.pad(x, (1, 2, 1, 2)), w.permute(3, 2, 0, 1), b, stride=2)                                    # :183 (5x5, SAME, even sizes)
+    ups = {}
+    for i in range(depth):
+        for j in range(num_blocks):
+            h, qm, ql, uc = _layer_up(h, _sub(params, "IAF_%d_%d/" % (i, j)), z_size, h_size, i > 0 and j == 0)
+            ups[(i, j)] = (qm, ql, uc)
+    n, hw = x.shape[0], x.shape[2] // 2 ** depth
+    h = params["h_top"].reshape(1, -1, 1, 1).repeat(n, 1, hw, hw)                                                # :189-192
+    kl_obj = torch.zeros(n, dtype=torch.float64)
+    it = iter(noise)
+    for i in reversed(range(depth)):
+        for j in reversed(range(num_blocks)):
+            next(it)                                                                                            # the prior's draw (unused in train mode)
+            qm, ql, uc = ups[(i, j)]
+            h, cur_obj, _ = _layer_down(h, _sub(params, "IAF_%d_%d/" % (i, j)), qm, ql, uc, _t(next(it)), z_size, h_size, kl_min,
+                                        i > 0 and j == 0)
+            kl_obj = kl_obj + cur_obj
+    V, g, b = params["x_dec/V"], params["x_dec/g"], params["x_dec/b"]
+    w = torch.exp(g).reshape(1, 1, -1, 1) * V / torch.sqrt(torch.clamp((V * V).sum(dim=(0, 1, 2), keepdim=True), min=1e-12))
+    hh = F.elu(h)
+    full = F.conv_transpose2d(hh, w.permute(3, 2, 0, 1), stride=2)                                              # [n,3,2H+3,2W+3]; SAME crops 1 in front
+    xo = full[:, :, 1:1 + 2 * hh.shape[2], 1:1 + 2 * hh.shape[3]] + b.reshape(1, -1, 1, 1)                      # :206-207
+    xo = torch.clamp(xo, -0.5 + 1 / 512., 0.5 - 1 / 512.)                                                       # :208
+    scale = torch.exp(params["dec_log_stdv"])
+    binsize = 1 / 256.0
+    s = (torch.floor(x / binsize) * binsize - xo) / scale
+    logp = torch.log(torch.sigmoid(s + binsize / scale) - torch.sigmoid(s) + 1e-7)                              # distributions.py:28-32
+    log_pxz = logp.sum(dim=(1, 2, 3))
+    return xo, (kl_obj - log_pxz).sum()                                                                         # :211
+
+
+def cvae1_grads(x_uint8, params, z_size, h_size, depth, num_blocks, kl_min, noise):
+    """d obj / d every variable (what opt.compute_gradients(obj) hands the optimizer, tf_train.py:128).  Returns (grads, x_out, obj)."""
+    pt = {k: _t(v, True) for k, v in params.items()}
+    xo, obj = cvae1_obj(x_uint8, pt, z_size, h_size, depth, num_blocks, kl_min, noise)
+    obj.backward()
+    # (a variable obj does not depend on -- the top layer's up_conv3: its output is replaced by h_top, tf_train.py:189-192 -- has gradient 0)
+    return {k: (v.grad.numpy() if v.grad is not None else np.zeros(v.shape)) for k, v in pt.items()}, xo.detach().numpy(), float(obj.detach())
+
+
+# --------------------------------------------------------------------------------------
 # the Theano statement of the same operator (graphy/nodes/ar.py, graphy/nodes/conv.py), for T.grad
 # (graphy/misc/optim.py:102) of the lines models.py:168-176 / 272-285
 # --------------------------------------------------------------------------------------

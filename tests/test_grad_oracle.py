@@ -295,3 +295,30 @@ def test_downsampling_layer_gradients_match_finite_differences():
 
             fd = (at(eps) - at(-eps)) / (2 * eps)
             assert abs(fd - got[idx]) < 2e-6 * max(1.0, abs(fd)), (name, idx, fd, got[idx])
+
+
+def test_model_gradient_oracle_forward_equals_reference_and_gradients_equal_finite_differences(golden_dir):
+    """oracle/iaf_grad_oracle.py:cvae1_grads (torch fp64 autograd of the whole model's objective, tf_train.py:150-211): its forward
+    reproduces the reference's own _forward outputs (tests/golden/cvae1_forward.npz) and its gradients equal central finite differences
+    of the NumPy oracle's obj for entries of every kind of variable (x_enc, x_dec with its per-input-channel norm, h_top, dec_log_stdv,
+    a deconv layer, a masked stack)."""
+    import os
+    import golden_inputs as gi
+    g = np.load(os.path.join(golden_dir, "cvae1_forward.npz"))
+    c = gi.model_case_inputs("model_tiny")
+    args = (c["z_size"], c["h_size"], c["depth"], c["num_blocks"], c["kl_min"])
+    grads, xo, obj = G.cvae1_grads(c["x"], c["params"], *args, c["noise"])
+    np.testing.assert_allclose(xo, g["model_tiny/x_out"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(obj, g["model_tiny/obj"], rtol=1e-12)
+    f = lambda p: O.cvae1_forward(c["x"], p, *args, 1, c["noise"])[1]
+    rng = np.random.RandomState(0)
+    for k in ("x_enc/V", "x_enc/g", "x_dec/V", "x_dec/g", "x_dec/b", "h_top", "dec_log_stdv", "IAF_1_0/down_deconv2/V", "IAF_0_1/up_conv1/g",
+              "IAF_1_1/ar_multiconv2d/layer_1/V", "IAF_0_0/down_conv1/b"):
+        v = np.array(c["params"][k], dtype=np.float64)
+        idx = tuple(rng.randint(0, s) for s in v.shape)
+        h = 1e-5
+        vp, vm = v.copy(), v.copy()
+        vp[idx] += h
+        vm[idx] -= h
+        fd = (f(dict(c["params"], **{k: vp})) - f(dict(c["params"], **{k: vm}))) / (2 * h)
+        np.testing.assert_allclose(grads[k][idx], fd, rtol=2e-5, atol=1e-6, err_msg=k)

@@ -99,3 +99,32 @@ def test_image_scaling_tile_and_sums(amd):
     ad, bd = dev(a), dev(b)
     amd._capi.check(lib.iaf_sum_axpy(P(ad), P(bd), -1.0, P(s), 1000, st()))
     np.testing.assert_allclose(host(s)[0], np.sum(f32(a) - f32(b)), rtol=0, atol=1e-3)
+
+
+def test_cvae1_forward_backward_vs_autograd_oracle(amd, golden_dir):
+    """d obj / d EVERY variable of the model (what opt.compute_gradients(obj) computes, tf_train.py:128,211) against torch-fp64 autograd
+    of the restated forward (oracle/iaf_grad_oracle.py:cvae1_grads -- its forward equals the reference's own _forward output to 1e-15
+    and its gradients equal central finite differences of the NumPy oracle, tests/test_grad_oracle.py), at the BASELINE channel counts."""
+    from oracle import iaf_grad_oracle as G
+    name = "model_cfg"
+    g = np.load(os.path.join(golden_dir, "cvae1_forward.npz"))
+    c = gi.model_case_inputs(name)
+    p32 = {k: f32(v) for k, v in c["params"].items()}
+    noise32 = [f32(e) for e in c["noise"]]
+    want, _, want_obj = G.cvae1_grads(c["x"], p32, c["z_size"], c["h_size"], c["depth"], c["num_blocks"], c["kl_min"], noise32)
+    model = amd.CVAE1(z_size=c["z_size"], h_size=c["h_size"], kl_min=c["kl_min"], depth=c["depth"], num_blocks=c["num_blocks"], k=1,
+                      image_size=c["image_size"])
+    model.set_training(True)
+    params = {k: dev(v) for k, v in c["params"].items()}
+    model.load(params)
+    x_out, obj, grads = model.forward_backward(torch.from_numpy(c["x"]).cuda(), [dev(e) for e in c["noise"]])
+    np.testing.assert_allclose(host(x_out), g[name + "/x_out"], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(host(obj)[0], want_obj, rtol=2e-5)
+    assert set(grads) == set(want), sorted(set(want) ^ set(grads))
+    worst = (0.0, None)
+    for k in sorted(want):
+        got, w = host(grads[k]), want[k]
+        err = float(np.abs(got - w).max() / (np.abs(w).max() + 1e-3))
+        worst = max(worst, (err, k))
+        assert err < 2e-3, (k, err, float(np.abs(w).max()))
+    print("worst relative gradient error %.2e (%s)" % worst)
