@@ -326,23 +326,29 @@ __global__ __launch_bounds__(256) void iaf_convk_wgrad_kernel(ConvKWP p) {
     const int tapci = blockIdx.x, tap = tapci / p.n_small, ci = tapci - tap * p.n_small;
     const int a = tap / p.kw, c = tap - a * p.kw;
     const int o = blockIdx.y * 16 + (threadIdx.x >> 4), ln = threadIdx.x & 15;
-    const int OHW = p.OH * p.OW, npx = p.B * OHW;
-    const float rOHW = 1.0f / (float)OHW, rOW = 1.0f / (float)p.OW;
+    const int OHW = p.OH * p.OW;
     const bool olive = o < p.n_big;
     const int oc = olive ? o : p.n_big - 1;
     float acc = 0.f;
-    for (int px = ln; px < npx; px += 16) {
-        int b, r, oy, ox;
-        fast_divmod(px, OHW, rOHW, b, r);
-        fast_divmod(r, p.OW, rOW, oy, ox);
-        const int iy = oy * p.stride + a - p.pad_t, ix = ox * p.stride + c - p.pad_l;
-        const bool in = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-        float xv = p.x[(((size_t)b * p.n_small + ci) * p.H + (in ? iy : 0)) * p.W + (in ? ix : 0)];
-        if (p.elu_x) xv = elu_f(xv);
-        xv = in ? xv : 0.f;
-        float dv = p.dy[((size_t)b * p.n_big + oc) * OHW + r];
-        if (p.elu_dy) dv = elu_f(dv);
-        acc += xv * dv;
+    // rows of the small grid in the outer loops, its columns over the 16 lanes: no index divisions in the loop
+    for (int b = 0; b < p.B; ++b) {
+        const float* xb = p.x + ((size_t)b * p.n_small + ci) * p.H * p.W;
+        const float* db = p.dy + ((size_t)b * p.n_big + oc) * OHW;
+        for (int ox = ln; ox < p.OW; ox += 16) {
+            const int ix = ox * p.stride + c - p.pad_l;
+            const bool cin_ = ix >= 0 && ix < p.W;
+#pragma unroll 8
+            for (int oy = 0; oy < p.OH; ++oy) {                   // branch-free: the loads of eight rows are in flight together
+                const int iy = oy * p.stride + a - p.pad_t;
+                const bool in = cin_ && iy >= 0 && iy < p.H;
+                float xv = xb[in ? (size_t)iy * p.W + ix : 0];
+                if (p.elu_x) xv = elu_f(xv);
+                xv = in ? xv : 0.f;
+                float dv = db[oy * p.OW + ox];
+                if (p.elu_dy) dv = elu_f(dv);
+                acc += xv * dv;
+            }
+        }
     }
     acc += __shfl_xor(acc, 8, 16);
     acc += __shfl_xor(acc, 4, 16);

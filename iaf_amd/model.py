@@ -12,7 +12,7 @@ import torch
 from . import _capi
 from .distributions import compute_lowerbound, discretized_logistic
 from .iaf_layer import IAFLayer
-from .layers import _check_act, _ptr, _stream
+from .layers import WnBwdBatch, _check_act, _ptr, _stream
 
 
 class CVAE1(object):
@@ -113,6 +113,15 @@ class CVAE1(object):
                 layer.set_training(on)
         self._training = bool(on)
         self.params = None
+        self._wn = None
+        if on:
+            # mask + weight-norm backward of all stacks and plain convs in ONE launch per kind at the end of the backward (a conv's own pass
+            # is 10-28 workgroups on a 256-CU chip); a downsampling layer's deconv differentiates its own norm inside its backward
+            self._wn_order = [(i, j) for i in range(self.depth) for j in range(self.num_blocks)]
+            self._wn_convs = [(ij, nm) for ij in self._wn_order
+                              for nm in ("up_conv1", "up_conv3", "down_conv1") + (() if self.layers[ij[0]][ij[1]].downsample else ("down_conv2",))]
+            self._wn = WnBwdBatch(stacks=[self.layers[i][j].posterior.stack for i, j in self._wn_order],
+                                  convs=[getattr(self.layers[ij[0]][ij[1]], nm) for ij, nm in self._wn_convs])
 
     def forward_backward(self, x, noise):
         """One tower's forward and backward in mode "train", k = 1: returns (x_out, obj [1], grads) with grads[name] = d obj / d params[name]
@@ -193,6 +202,11 @@ class CVAE1(object):
         for i in reversed(range(self.depth)):
             for j in reversed(range(self.num_blocks)):
                 d = self.layers[i][j].up_backward(d, self._lparams[(i, j)], lgrads[(i, j)])
+        tup = lambda dct, nm: (dct[nm + "/V"], dct[nm + "/g"], dct[nm + "/b"])
+        self._wn.run(stack_params=[IAFLayer.stack_params(self._lparams[ij]) for ij in self._wn_order],
+                     stack_grads=[IAFLayer.stack_params(lgrads[ij]) for ij in self._wn_order],
+                     conv_params=[tup(self._lparams[ij], nm) for ij, nm in self._wn_convs],
+                     conv_grads=[tup(lgrads[ij], nm) for ij, nm in self._wn_convs])
         for (i, j), lg in lgrads.items():
             for k, v in lg.items():
                 grads["IAF_%d_%d/%s" % (i, j, k)] = v
