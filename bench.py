@@ -60,7 +60,8 @@ def parse():
                     help="widened workload (SURVEY 8f-4): whole IAFLayers (plain convs + posterior block), forward")
     ap.add_argument("--model", action="store_true",
                     help="with --layers: the whole model forward, CVAE1._forward (tf_train.py:150-218): uint8 images -> x_enc -> the "
-                         "layer stack -> x_dec -> discretized_logistic -> obj / loss")
+                         "layer stack -> x_dec -> discretized_logistic -> obj / loss; with --train: one tower's whole training step "
+                         "from that objective (all gradients, all-reduce, Adamax/EMA)")
     ap.add_argument("--train", action="store_true",
                     help="extra mode (not the headline metric): data-parallel TRAINING step of the IAF posterior stack -- "
                          "posterior block forward + backward for every layer, one RCCL all-reduce of the flat gradient "
@@ -679,6 +680,100 @@ def layers_bench(args, depths, dist, rank, n_gpus):
                      "timing": "HIP events on the launch stream around 50 back-to-back launches per 16x16 layer"}})
 
 
+def model_train_bench(args, depths, dist, rank, n_gpus):
+    """One tower's training step of the WHOLE reference model (CVAE1, tf_train.py:114-218) from its own objective: every weight norm
+    re-derived (batched launches), forward, obj = sum(kl_obj - log_pxz), backward of everything (iaf_amd.CVAE1.forward_backward:
+    opt.compute_gradients(obj), tf_train.py:128) with the gradients written into ONE flat buffer, all-reduce(sum) of that buffer over
+    the ranks (RCCL; one message: the backward is not split into segments here), fused Adamax(1/N) + EMA on the flat parameter buffer
+    (tf_utils/adamax.py:40-56, tf_train.py:146-159).  uint8 images and noise are synthetic, weights random-init."""
+    import golden_inputs as gi
+    import iaf_amd
+    import iaf_amd.parallel as par
+    if len(set(depths)) != 1:
+        raise SystemExit("--train --model: the reference model has the same number of layers on every level (depth x num_blocks)")
+    B, zs, hs, nb = args.batch, args.n_z, args.n_h, depths[0]
+    gi.MODEL_CASES["bench"] = (B, 1, zs, hs, len(depths), nb, 32, 0.25)
+    c = gi.model_case_inputs("bench")
+    rng = np.random.RandomState(99 + rank)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+    flat = par.FlatParams({k: dev(v) for k, v in c["params"].items()})
+    model = iaf_amd.CVAE1(z_size=zs, h_size=hs, kl_min=0.25, depth=len(depths), num_blocks=nb, k=1, image_size=32, depth_ar=args.depth_ar)
+    for level in model.layers:
+        for layer in level:
+            layer.posterior.stack.set_precision(args.precision)
+            for cvx in layer.convs():
+                cvx.set_precision(args.precision)
+    model.set_training(True)
+    model.load(flat.p)
+    x = torch.from_numpy(rng.randint(0, 256, size=(B, 3, 32, 32)).astype(np.uint8)).cuda()
+    noise = [dev(rng.standard_normal(e.shape)) for e in c["noise"]]
+    comm = None
+    if dist is not None or os.environ.get("IAF_BENCH_FORCE_DIST"):
+        comm = par.RcclComm()
+    keep = {}
+
+    def step():
+        model.prepare_weights()
+        keep["out"] = model.forward_backward(x, noise, grads=flat.g)
+        if comm is not None:
+            flat.all_reduce_grads(comm=comm)
+        flat.adamax_ema_step(1e-4, world=n_gpus)
+
+    stream = torch.cuda.Stream()
+    graph = None
+    with torch.cuda.stream(stream):
+        for _ in range(2):
+            step()
+        stream.synchronize()
+        obj0 = float(keep["out"][1].item())
+        if not args.no_graph:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                step()
+        run = graph.replay if graph is not None else step
+
+        def barrier():
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        for _ in range(args.warmup):
+            run()
+        barrier()
+        repeats = []
+        for _ in range(max(1, args.repeats)):
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                run()
+            barrier()
+            repeats.append(time.perf_counter() - t0)
+        elapsed = float(np.median(repeats))
+        obj1 = float(keep["out"][1].item())
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        return
+    emit({
+        "metric": "CVAE1 TRAIN-step samples/sec (whole model from its own objective: weight norms, forward, backward of every variable, "
+                  "grad all-reduce, Adamax/EMA)",
+        "value": n_gpus * B / (elapsed / args.steps), "unit": "samples/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if args.precision == "f32" else "f32 (forward convs and most data gradients: operands split into 3 bf16 parts on the bf16 MFMA, fp32 accumulate; the rest exact fp32)",
+        "data": "synthetic",
+        "config": {"workload": "cifar10 z_size=%d h_size=%d depth=%d num_blocks=%d depth_ar=%d bs=%d per GPU, kl_min=0.25, k=1: CVAE1 "
+                               "(tf_train.py:114-218), %d trainable fp32 parameters in %d tensors, one flat gradient buffer (%.1f MB)"
+                               % (zs, hs, len(depths), nb, args.depth_ar, B, flat.params.numel(), len(flat.p), 4e-6 * flat.params.numel()),
+                   "global_batch": n_gpus * B, "launch": "hipGraph replay" if graph is not None else "eager",
+                   "obj_first_step": obj0, "obj_last_step": obj1,
+                   "bits_per_dim_last_step": obj1 / (np.log(2.) * 3072 * B),
+                   "parallelism": "dp%d (one all-reduce of the flat gradient buffer behind the backward)" % n_gpus},
+        "exchange": {"rccl": comm is not None, "messages": 1 if comm is not None else 0, "bytes": 4 * flat.params.numel()}})
+
+
 def layers_train_bench(args, depths, dist, rank, n_gpus):
     """DP training step of whole IAFLayers (SURVEY 8f-4 + 8f-1,2): weight prep, up pass, down pass, backward of both
     passes (every plain conv and the posterior block), gradients written into ONE flat buffer laid out in the order the
@@ -1014,6 +1109,11 @@ def main():
         if args.batch == 32:
             args.batch = 256              # configs[4]: bs = 256
         iw_eval_bench(args, depths, dist, rank, n_gpus)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    if args.model and args.train:
+        model_train_bench(args, depths, dist, rank, n_gpus)
         if dist is not None:
             dist.destroy_process_group()
         return

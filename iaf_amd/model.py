@@ -12,7 +12,7 @@ import torch
 from . import _capi
 from .distributions import compute_lowerbound, discretized_logistic
 from .iaf_layer import IAFLayer
-from .layers import WnBwdBatch, _check_act, _ptr, _stream
+from .layers import ConvPrepBatch, PrepBatch, WnBwdBatch, _check_act, _ptr, _stream
 
 
 class CVAE1(object):
@@ -51,6 +51,30 @@ class CVAE1(object):
                 self._lparams[(i, j)] = {k[len(pre):]: v for k, v in params.items() if k.startswith(pre)}
                 layer.load(self._lparams[(i, j)])
         self.params = params
+
+    def prepare_weights(self):
+        """Re-derive every weight norm from the loaded variables (what the reference's graph does inside every step, layers.py:56-60) in
+        batched launches: all masked stacks in one, all plain convs in one, a downsampling layer's deconv and the two ends on their own.
+        For a training loop that updates the variables in place (parallel.FlatParams): load(params) once, then prepare_weights() per step."""
+        if self.params is None:
+            raise RuntimeError("CVAE1.load(params) first")
+        lib, p, hs = _capi.lib(), self.params, self.h_size
+        if getattr(self, "_prep", None) is None:
+            order = [(i, j) for i in range(self.depth) for j in range(self.num_blocks)]
+            convs = [(ij, nm) for ij in order
+                     for nm in ("up_conv1", "up_conv3", "down_conv1") + (() if self.layers[ij[0]][ij[1]].downsample else ("down_conv2",))]
+            self._prep = dict(order=order, convs=convs, s=PrepBatch([self.layers[i][j].posterior.stack for i, j in order]),
+                              c=ConvPrepBatch([getattr(self.layers[ij[0]][ij[1]], nm) for ij, nm in convs]))
+        P = self._prep
+        P["s"].run([IAFLayer.stack_params(self._lparams[ij]) for ij in P["order"]])
+        P["c"].run([(self._lparams[ij][nm + "/V"], self._lparams[ij][nm + "/g"], self._lparams[ij][nm + "/b"]) for ij, nm in P["convs"]])
+        for i, j in P["order"]:
+            layer = self.layers[i][j]
+            if layer.downsample:
+                lp = self._lparams[(i, j)]
+                layer.down_conv2.prepare_deconv(lp["down_deconv2/V"], lp["down_deconv2/g"], lp["down_deconv2/b"], force=True)
+        _capi.check(lib.iaf_convk_weightnorm(_ptr(p["x_enc/V"]), _ptr(p["x_enc/g"]), _ptr(self._w_enc), 5, 5, 3, hs, 0, _stream()))
+        _capi.check(lib.iaf_convk_weightnorm(_ptr(p["x_dec/V"]), _ptr(p["x_dec/g"]), _ptr(self._w_dec), 5, 5, hs, 3, 1, _stream()))
 
     def forward(self, x, noise):
         """x: uint8 [B,3,S,S] on the device.  noise: per layer in top-down order the pair (eps_prior, eps_post) the reference's two
@@ -114,6 +138,7 @@ class CVAE1(object):
         self._training = bool(on)
         self.params = None
         self._wn = None
+        self._prep = None
         if on:
             # mask + weight-norm backward of all stacks and plain convs in ONE launch per kind at the end of the backward (a conv's own pass
             # is 10-28 workgroups on a 256-CU chip); a downsampling layer's deconv differentiates its own norm inside its backward
@@ -123,9 +148,9 @@ class CVAE1(object):
             self._wn = WnBwdBatch(stacks=[self.layers[i][j].posterior.stack for i, j in self._wn_order],
                                   convs=[getattr(self.layers[ij[0]][ij[1]], nm) for ij, nm in self._wn_convs])
 
-    def forward_backward(self, x, noise):
+    def forward_backward(self, x, noise, grads=None):
         """One tower's forward and backward in mode "train", k = 1: returns (x_out, obj [1], grads) with grads[name] = d obj / d params[name]
-        for every variable.  The layer stack's backward is IAFLayer.down_backward / .up_backward chained through the model (the down pass
+        for every variable (written into the tensors of `grads` where it has them -- e.g. the views of parallel.FlatParams.g).  The layer stack's backward is IAFLayer.down_backward / .up_backward chained through the model (the down pass
         in up-pass order, then the up pass in reverse); the two ends -- likelihood, clip, x_dec, h_top, x_enc -- are the launches of
         csrc/iaf_model_edge.hpp.  noise as in forward()."""
         if not getattr(self, "_training", False) or self.params is None:
@@ -167,18 +192,17 @@ class CVAE1(object):
         obj = torch.empty(1, **f32)
         _capi.check(lib.iaf_sum_axpy(_ptr(kl_obj), _ptr(log_pxz), -1.0, _ptr(obj), n, st()))
         # ---- backward of the top end: obj = sum(kl_obj - log_pxz)  (tf_train.py:206-211)
-        grads = {}
+        grads = {} if grads is None else grads
+        gs = lambda nm: grads.setdefault(nm, torch.empty_like(p[nm]))
         d_xout = torch.empty_like(x_out)
         dls_rows = torch.empty(n, **f32)
         logscale = p["dec_log_stdv"].reshape(1).contiguous()
         _capi.check(lib.iaf_discretized_logistic_backward(_ptr(x_out), _ptr(logscale), _ptr(xf), -1.0, lo, hi, _ptr(d_xout), _ptr(dls_rows), n,
                                                           3 * S * S, 1 / 256.0, st()))
-        dls = torch.empty(1, **f32)
-        _capi.check(lib.iaf_sum_axpy(_ptr(dls_rows), None, 0.0, _ptr(dls), n, st()))
-        grads["dec_log_stdv"] = dls.reshape(p["dec_log_stdv"].shape)
+        _capi.check(lib.iaf_sum_axpy(_ptr(dls_rows), None, 0.0, _ptr(gs("dec_log_stdv")), n, st()))
         dW = torch.empty_like(p["x_dec/V"])
         _capi.check(lib.iaf_convk_wgrad(_ptr(d_xout), _ptr(h_last), _ptr(dW), n, 3, S, S, hs, 5, 5, 2, 0, 1, st()))
-        grads["x_dec/V"], grads["x_dec/g"], grads["x_dec/b"] = torch.empty_like(dW), torch.empty(3, **f32), torch.empty(3, **f32)
+        gs("x_dec/V"), gs("x_dec/g"), gs("x_dec/b")
         scratch = torch.empty(hs * 3, **f32)
         _capi.check(lib.iaf_convk_weightnorm_backward(_ptr(p["x_dec/V"]), _ptr(p["x_dec/g"]), _ptr(dW), _ptr(grads["x_dec/V"]),
                                                       _ptr(grads["x_dec/g"]), _ptr(scratch), 5, 5, hs, 3, 1, st()))
@@ -194,10 +218,10 @@ class CVAE1(object):
         lgrads = {}
         for i, level in enumerate(self.layers):
             for j, layer in enumerate(level):
-                lgrads[(i, j)] = {}
+                pre = "IAF_%d_%d/" % (i, j)
+                lgrads[(i, j)] = {k[len(pre):]: v for k, v in grads.items() if k.startswith(pre)}
                 d = layer.down_backward(d, dko, self._lparams[(i, j)], lgrads[(i, j)])
-        grads["h_top"] = torch.empty(hs, **f32)
-        _capi.check(lib.iaf_channel_sum(_ptr(d), _ptr(grads["h_top"]), n, hs, St * St, st()))                 # adjoint of the tile (:190-192)
+        _capi.check(lib.iaf_channel_sum(_ptr(d), _ptr(gs("h_top")), n, hs, St * St, st()))                 # adjoint of the tile (:190-192)
         d = torch.zeros((n, hs, St, St), **f32)                      # the up pass's last output is not used (h_top replaces it)
         for i in reversed(range(self.depth)):
             for j in reversed(range(self.num_blocks)):
@@ -213,7 +237,7 @@ class CVAE1(object):
         # ---- x_enc (:183)
         dW = torch.empty_like(p["x_enc/V"])
         _capi.check(lib.iaf_convk_wgrad(_ptr(xf), _ptr(d), _ptr(dW), n, 3, S, S, hs, 5, 5, 2, 0, 0, st()))
-        grads["x_enc/V"], grads["x_enc/g"], grads["x_enc/b"] = torch.empty_like(dW), torch.empty(hs, **f32), torch.empty(hs, **f32)
+        gs("x_enc/V"), gs("x_enc/g"), gs("x_enc/b")
         _capi.check(lib.iaf_convk_weightnorm_backward(_ptr(p["x_enc/V"]), _ptr(p["x_enc/g"]), _ptr(dW), _ptr(grads["x_enc/V"]),
                                                       _ptr(grads["x_enc/g"]), None, 5, 5, 3, hs, 0, st()))
         _capi.check(lib.iaf_channel_sum(_ptr(d), _ptr(grads["x_enc/b"]), n, hs, (S // 2) ** 2, st()))

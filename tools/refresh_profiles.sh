@@ -16,6 +16,7 @@ python $R/bench.py --layers --model > $O/bench_model_n1.json 2> /dev/null
 python $R/bench.py --iw-eval --steps 100 > $O/bench_iw_eval_n1.json 2> /dev/null
 IAF_BENCH_FORCE_DIST=1 python $R/bench.py --train --steps 50 > $O/bench_train_n1.json 2> /dev/null
 IAF_BENCH_FORCE_DIST=1 python $R/bench.py --train --layers --steps 20 --warmup 5 > $O/bench_train_layers_n1.json 2> /dev/null
+IAF_BENCH_FORCE_DIST=1 python $R/bench.py --train --model --steps 20 --warmup 5 > $O/bench_train_model_n1.json 2> /dev/null
 # kernel trace of the SAME command as the headline bench line
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb -o bench -- python $R/bench.py --no-cpu-baseline > $O/bench_rocprof_line.json 2>/dev/null
 cp /tmp/pb/*kernel_stats.csv $O/bench_kernel_stats.csv
