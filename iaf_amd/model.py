@@ -135,6 +135,13 @@ class CVAE1(object):
         for level in self.layers:
             for layer in level:
                 layer.set_training(on)
+        old = getattr(self, "_wn", None)
+        if old is not None:                                          # back to per-op weight-norm backward for anyone using the layers directly
+            lib = _capi.lib()
+            for st in old.stacks:
+                _capi.check(lib.iaf_stack_set_defer_weightnorm(st._h, 0))
+            for cv in old.convs:
+                _capi.check(lib.iaf_conv3x3_set_defer_weightnorm(cv._h, 0))
         self._training = bool(on)
         self.params = None
         self._wn = None
