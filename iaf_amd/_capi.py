@@ -141,6 +141,9 @@ SIGNATURES = {
     "iaf_convk_weightnorm_backward": (ctypes.c_int, [_vp] * 6 + [ctypes.c_int] * 5 + [_vp]),
     "iaf_channel_sum": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
     "iaf_mul_elu_grad": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t, _vp]),
+    "iaf_axpby": (ctypes.c_int, [_vp, ctypes.c_float, _vp, ctypes.c_float, _vp, ctypes.c_size_t, _vp]),
+    "iaf_affine_transform": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_float, _vp, ctypes.c_size_t, _vp]),
+    "iaf_clip": (ctypes.c_int, [_vp, ctypes.c_float, ctypes.c_float, _vp, ctypes.c_size_t, _vp]),
     "iaf_conv3x3_forward_stride2": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_int),
                                                    ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
     "iaf_conv3x3_forward_deconv": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int, ctypes.c_int,

@@ -481,3 +481,38 @@ extern "C" int iaf_mul_elu_grad(const float* g, const float* h, float* out, size
     hipLaunchKernelGGL(iaf_mul_elu_grad_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)stream, g, h, out, n);
     return (int)hipGetLastError();
 }
+
+// ---- elementwise pieces of the data-dependent init pass (mode "init", tf_train.py:60-61, 70-71, 94, 208) -----------------------------
+__global__ __launch_bounds__(256) void iaf_axpby_kernel(const float* __restrict__ a, float sa, const float* __restrict__ b, float sb,
+                                                       float* __restrict__ out, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = sa * a[i] + sb * b[i];
+}
+// z' = (z - scale m) / exp(scale s): the IAF update from the raw outputs of ar_multiconv2d (tf_train.py:70-71 with scale = 0.1)
+__global__ __launch_bounds__(256) void iaf_affine_kernel(const float* __restrict__ z, const float* __restrict__ m, const float* __restrict__ s,
+                                                        float scale, float* __restrict__ out, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (z[i] - scale * m[i]) * __expf(-scale * s[i]);
+}
+__global__ __launch_bounds__(256) void iaf_clip_kernel(const float* __restrict__ x, float lo, float hi, float* __restrict__ out, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = fminf(fmaxf(x[i], lo), hi);
+}
+extern "C" int iaf_axpby(const float* a, float sa, const float* b, float sb, float* out, size_t n, void* stream) {
+    if (!a || !b || !out) return IAF_ERR_NULL;
+    if (n == 0) return IAF_ERR_SHAPE;
+    hipLaunchKernelGGL(iaf_axpby_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)stream, a, sa, b, sb, out, n);
+    return (int)hipGetLastError();
+}
+extern "C" int iaf_affine_transform(const float* z, const float* m, const float* s, float scale, float* out, size_t n, void* stream) {
+    if (!z || !m || !s || !out) return IAF_ERR_NULL;
+    if (n == 0) return IAF_ERR_SHAPE;
+    hipLaunchKernelGGL(iaf_affine_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)stream, z, m, s, scale, out, n);
+    return (int)hipGetLastError();
+}
+extern "C" int iaf_clip(const float* x, float lo, float hi, float* out, size_t n, void* stream) {
+    if (!x || !out) return IAF_ERR_NULL;
+    if (n == 0) return IAF_ERR_SHAPE;
+    hipLaunchKernelGGL(iaf_clip_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)stream, x, lo, hi, out, n);
+    return (int)hipGetLastError();
+}

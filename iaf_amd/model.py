@@ -12,7 +12,8 @@ import torch
 from . import _capi
 from .distributions import compute_lowerbound, discretized_logistic
 from .iaf_layer import IAFLayer
-from .layers import ConvPrepBatch, PrepBatch, WnBwdBatch, _check_act, _ptr, _stream
+from .layers import (ConvPrepBatch, PrepBatch, VariableStore, WnBwdBatch, ar_multiconv2d, resample2, variable_scope, _check_act, _ptr,
+                     _stream)
 
 
 class CVAE1(object):
@@ -23,6 +24,7 @@ class CVAE1(object):
     def __init__(self, z_size=32, h_size=160, kl_min=0.25, depth=2, num_blocks=2, k=1, image_size=32, depth_ar=2, mode="train"):
         self.z_size, self.h_size, self.kl_min = int(z_size), int(h_size), float(kl_min)
         self.depth, self.num_blocks, self.k, self.image_size, self.mode = int(depth), int(num_blocks), int(k), int(image_size), mode
+        self.depth_ar = int(depth_ar)
         if self.image_size % (2 ** self.depth):
             raise ValueError("image_size must be divisible by 2**depth (tf_train.py:183,192)")
         # tf_train.py:176-181: the first layer of every level but the first downsamples
@@ -75,6 +77,114 @@ class CVAE1(object):
                 layer.down_conv2.prepare_deconv(lp["down_deconv2/V"], lp["down_deconv2/g"], lp["down_deconv2/b"], force=True)
         _capi.check(lib.iaf_convk_weightnorm(_ptr(p["x_enc/V"]), _ptr(p["x_enc/g"]), _ptr(self._w_enc), 5, 5, 3, hs, 0, _stream()))
         _capi.check(lib.iaf_convk_weightnorm(_ptr(p["x_dec/V"]), _ptr(p["x_dec/g"]), _ptr(self._w_dec), 5, 5, hs, 3, 1, _stream()))
+
+    def init_pass(self, x, params, noise):
+        """The data-dependent initialisation pass: the reference builds CVAE1(hps, "init") first, i.e. _forward under
+        arg_scope([conv2d, deconv2d], init=True) (tf_train.py:175) with every IAFLayer in mode "init" (z from the prior, :60-61).  Every conv
+        -- x_enc, the plain and strided convs, the masked convs of ar_multiconv2d (conv2d is in the scope), the deconvs, x_dec -- takes its g
+        and b from the moments of its own un-gained output on this batch (layers.py:38-51, 87-100) and hands the NORMALISED output on.
+        params: the V of every conv (g / b entries are ignored), h_top, dec_log_stdv; noise as in forward() (the priors' draws are used).
+        Returns (x_out, params_out) with params_out = params + every g and b; the model is left loaded with params_out."""
+        lib, hs, zs = _capi.lib(), self.h_size, self.z_size
+        B, _, S, _ = (int(v) for v in x.shape)
+        if x.dtype != torch.uint8 or S != self.image_size or len(noise) != 2 * self.depth * self.num_blocks:
+            raise ValueError("x: uint8 [B,3,%d,%d]; noise: %d tensors" % (self.image_size, self.image_size, 2 * self.depth * self.num_blocks))
+        n, dev, st = B * self.k, x.device, _stream
+        f32 = dict(dtype=torch.float32, device=dev)
+        out = {k: v for k, v in params.items() if not (k.endswith("/g") or k.endswith("/b"))}
+
+        def norm(raw, init_scale):                        # layers.py:46-51: moments over (N,H,W), g = log(scale)/3, b = -mean scale
+            B_, C_, H_, W_ = (int(v) for v in raw.shape)
+            y, g, b = torch.empty_like(raw), torch.empty(C_, **f32), torch.empty(C_, **f32)
+            _capi.check(lib.iaf_datainit_normalize(_ptr(raw), None, _ptr(y), _ptr(g), _ptr(b), B_, C_, H_ * W_, float(init_scale), st()))
+            return y, g, b
+
+        def axpby(a, sa, b, sb):
+            o = torch.empty_like(a)
+            _capi.check(lib.iaf_axpby(_ptr(a), float(sa), _ptr(b), float(sb), _ptr(o), a.numel(), st()))
+            return o
+
+        def conv_init(conv, name, inp, kind="plain", x2=None):
+            V = params[name + "/V"]
+            z0, z1 = torch.zeros(conv.n_out, **f32), torch.zeros(conv.n_out, **f32)
+            if kind == "deconv":
+                conv.prepare_deconv(V, z0, z1, force=True)
+                raw = conv.deconv(inp, x2=x2, elu_input=True)
+            elif kind == "stride2":
+                conv.prepare(V, z0, z1, force=True)
+                raw = conv.stride2(inp, elu_input=True)[0]
+            else:
+                conv.prepare(V, z0, z1, force=True)
+                raw = conv(inp, x2=x2, elu_input=True)[0]
+            y, out[name + "/g"], out[name + "/b"] = norm(raw, 0.1)
+            return y
+
+        def pieces(t, sizes):
+            r, off = [], 0
+            for c in sizes:
+                r.append(t.narrow(1, off, c).contiguous())
+                off += c
+            return r
+
+        xf = torch.empty((n, 3, S, S), **f32)
+        _capi.check(lib.iaf_image_to_float(x.data_ptr(), _ptr(xf), B, 3 * S * S, self.k, st()))
+        w = torch.empty_like(params["x_enc/V"])
+        zg, zb = torch.zeros(hs, **f32), torch.zeros(hs, **f32)
+        _capi.check(lib.iaf_convk_weightnorm(_ptr(params["x_enc/V"]), _ptr(zg), _ptr(w), 5, 5, 3, hs, 0, st()))
+        raw = torch.empty((n, hs, S // 2, S // 2), **f32)
+        _capi.check(lib.iaf_convk_forward(_ptr(xf), _ptr(w), _ptr(zb), _ptr(raw), n, 3, S, S, hs, 5, 5, 2, 0, st()))
+        h, out["x_enc/g"], out["x_enc/b"] = norm(raw, 0.1)
+        ups = {}
+        for i in range(self.depth):                                                                        # tf_train.py:29-44
+            for j in range(self.num_blocks):
+                layer, pre = self.layers[i][j], "IAF_%d_%d/" % (i, j)
+                y1 = conv_init(layer.up_conv1, pre + "up_conv1", h, "stride2" if layer.downsample else "plain")
+                qm, ql, uc, hh = pieces(y1, [zs, zs, hs, hs])
+                y3 = conv_init(layer.up_conv3, pre + "up_conv3", hh)
+                h = axpby(resample2(h, "down_even") if layer.downsample else h, 1.0, y3, 0.1)
+                ups[(i, j)] = (qm, ql, uc)
+        St = S // 2 ** self.depth
+        h = torch.empty((n, hs, St, St), **f32)
+        _capi.check(lib.iaf_tile_channels(_ptr(params["h_top"]), _ptr(h), n, hs, St * St, st()))
+        li = 0
+        for i in reversed(range(self.depth)):                                                              # tf_train.py:46-95, mode "init"
+            for j in reversed(range(self.num_blocks)):
+                layer, pre = self.layers[i][j], "IAF_%d_%d/" % (i, j)
+                y = conv_init(layer.down_conv1, pre + "down_conv1", h)
+                pz_mean, pz_logsd, rz_mean, rz_logsd, down_context, h_det = pieces(y, [zs] * 4 + [hs] * 2)
+                z = torch.empty_like(pz_mean)
+                _capi.check(lib.iaf_gaussian_sample_logsd(_ptr(pz_mean), _ptr(pz_logsd), _ptr(noise[2 * li]), _ptr(z), z.numel(), st()))   # :60-61
+                qm, ql, uc = ups[(i, j)]
+                context = axpby(uc, 1.0, down_context, 1.0)                                                # :58
+                store = VariableStore()
+                ar = pre + "ar_multiconv2d/"
+                for k_, v in params.items():
+                    if k_.startswith(ar) and k_.endswith("/V"):
+                        store.set(k_, v)
+                with variable_scope("IAF_%d_%d" % (i, j), store):
+                    m_raw, s_raw = ar_multiconv2d("ar_multiconv2d", z, context, [hs] * self.depth_ar, [zs, zs], store=store, init=True)   # :69
+                for k_, v in store.vars.items():
+                    if k_.endswith("/g") or k_.endswith("/b"):
+                        out[k_] = v
+                z2 = torch.empty_like(z)
+                _capi.check(lib.iaf_affine_transform(_ptr(z), _ptr(m_raw), _ptr(s_raw), 0.1, _ptr(z2), z.numel(), st()))                # :70-71
+                if layer.downsample:
+                    y = conv_init(layer.down_conv2, pre + "down_deconv2", z2, "deconv", x2=h_det)
+                    h = axpby(resample2(h, "up_nearest"), 1.0, y, 0.1)
+                else:
+                    y = conv_init(layer.down_conv2, pre + "down_conv2", z2, x2=h_det)
+                    h = axpby(h, 1.0, y, 0.1)                                                              # :94
+                li += 1
+        w = torch.empty_like(params["x_dec/V"])
+        zg3, zb3 = torch.zeros(3, **f32), torch.zeros(3, **f32)
+        _capi.check(lib.iaf_convk_weightnorm(_ptr(params["x_dec/V"]), _ptr(zg3), _ptr(w), 5, 5, hs, 3, 1, st()))
+        raw = torch.empty((n, 3, S, S), **f32)
+        _capi.check(lib.iaf_deconvk_forward(_ptr(h), _ptr(w), _ptr(zb3), _ptr(raw), n, hs, S // 2, S // 2, 3, 5, 5, 2, 1, 0.0, 0.0, st()))
+        y, out["x_dec/g"], out["x_dec/b"] = norm(raw, 0.1)
+        x_out = torch.empty_like(y)
+        _capi.check(lib.iaf_clip(_ptr(y), -0.5 + 1 / 512., 0.5 - 1 / 512., _ptr(x_out), y.numel(), st()))                               # :208
+        self.load(out)
+        return x_out, out
 
     def forward(self, x, noise):
         """x: uint8 [B,3,S,S] on the device.  noise: per layer in top-down order the pair (eps_prior, eps_post) the reference's two

@@ -576,6 +576,12 @@ int iaf_convk_weightnorm_backward(const float* V, const float* g, const float* d
                                   int n_in, int n_out, int deconv, void* stream);
 int iaf_channel_sum(const float* x, float* out, int B, int C, int HW, void* stream);
 int iaf_mul_elu_grad(const float* g, const float* h, float* out, size_t n, void* stream);
+/* elementwise pieces of the model's data-dependent init pass (CVAE1 in mode "init", tf_train.py:175 arg_scope(init=True)):
+ * out = sa a + sb b (residuals `input + 0.1 h`, tf_train.py:44,94; context = up_context + down_context, :58);
+ * out = (z - scale m) / exp(scale s) (the IAF update from ar_multiconv2d's raw outputs, :70-71);  out = clip(x, lo, hi) (:208) */
+int iaf_axpby(const float* a, float sa, const float* b, float sb, float* out, size_t n, void* stream);
+int iaf_affine_transform(const float* z, const float* m, const float* s, float scale, float* out, size_t n, void* stream);
+int iaf_clip(const float* x, float lo, float hi, float* out, size_t n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -208,11 +208,18 @@ MODEL_CASES = {
 }
 
 
+# the data-dependent init pass: CVAE1(hps, "init") (tf_train.py:175: arg_scope(init=True), every layer in mode "init")
+MODEL_INIT_CASES = {
+    "model_init": (3, 1, 16, 32, 2, 2, 16, 0.25, "init"),
+}
+
+
 def model_case_inputs(name):
     """Variables (TF names, tf_train.py:175-215), the uint8 image batch and the noise every DiagonalGaussian draws, in the order
     the reference's graph construction draws it: top-down, per layer the prior's noise then the posterior's."""
-    B, k, zs, hs, depth, nb, img, kl_min = MODEL_CASES[name][:8]
-    mode = MODEL_CASES[name][8] if len(MODEL_CASES[name]) > 8 else "train"
+    case = MODEL_CASES[name] if name in MODEL_CASES else MODEL_INIT_CASES[name]
+    B, k, zs, hs, depth, nb, img, kl_min = case[:8]
+    mode = case[8] if len(case) > 8 else "train"
     rng = np.random.RandomState(case_seed(name))
     p = {}
     for kk, v in conv_params(rng, 3, hs, ksize=5).items():

@@ -35,5 +35,29 @@ def gen_model():
     MG.save("cvae1_forward", **out)
 
 
+def gen_model_init():
+    """the init pass: only the V's (and h_top, dec_log_stdv) are seeded; every g and b is created by the reference's init branches"""
+    out = {}
+    for name in gi.MODEL_INIT_CASES:
+        c = gi.model_case_inputs(name)
+        hps = TT.HParams(batch_size=P(c["B"]), k=P(c["k"]), z_size=P(c["z_size"]), h_size=P(c["h_size"]), kl_min=c["kl_min"],
+                         depth=P(c["depth"]), num_blocks=P(c["num_blocks"]), image_size=P(c["image_size"]), num_gpus=P(2))
+        MG.seed_store("", {k: v for k, v in c["params"].items() if not (k.endswith("/g") or k.endswith("/b"))})
+        STORE.noise_log[:] = []
+        STORE.noise_queue[:] = list(c["noise"])
+        me = types.SimpleNamespace(hps=hps, mode="init", dec_log_stdv=tf_shim.T(np.float64(c["params"]["dec_log_stdv"])))
+        x_out, obj, loss = TT.CVAE1._forward(me, tf_shim.T(c["x"]), 0)
+        assert not STORE.noise_queue
+        out[name + "/x_out"] = x_out
+        n = 0
+        for k, v in STORE.vars.items():
+            if k.endswith("/g") or k.endswith("/b"):
+                out[name + "/var/" + k] = v
+                n += 1
+        print(name, "initialised", n, "g / b variables; x_out range", float(np.min(x_out)), float(np.max(x_out)))
+    MG.save("cvae1_init", **out)
+
+
 if __name__ == "__main__":
     gen_model()
+    gen_model_init()

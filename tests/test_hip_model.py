@@ -128,3 +128,31 @@ def test_cvae1_forward_backward_vs_autograd_oracle(amd, golden_dir):
         worst = max(worst, (err, k))
         assert err < 2e-3, (k, err, float(np.abs(w).max()))
     print("worst relative gradient error %.2e (%s)" % worst)
+
+
+def test_cvae1_init_pass_vs_the_references_own_init_branches(amd, golden_dir):
+    """CVAE1.init_pass: the data-dependent initialisation of every conv of the model (x_enc, plain / strided / masked convs, deconvs,
+    x_dec) against the reference's own _forward executed in mode "init" on the TF shim (tests/golden/cvae1_init.npz): all 68 g / b
+    variables and the pass's output.  Moments over (N,H,W) in fp32 vs the reference's fp64."""
+    g = np.load(os.path.join(golden_dir, "cvae1_init.npz"))
+    name = "model_init"
+    c = gi.model_case_inputs(name)
+    model = amd.CVAE1(z_size=c["z_size"], h_size=c["h_size"], kl_min=c["kl_min"], depth=c["depth"], num_blocks=c["num_blocks"],
+                      k=c["k"], image_size=c["image_size"], mode="init")
+    params = {k: dev(v) for k, v in c["params"].items() if not (k.endswith("/g") or k.endswith("/b"))}
+    x_out, pout = model.init_pass(torch.from_numpy(c["x"]).cuda(), params, [dev(e) for e in c["noise"]])
+    want = {k[len(name + "/var/"):]: g[k] for k in g.files if k.startswith(name + "/var/")}
+    assert set(k for k in pout if k.endswith("/g") or k.endswith("/b")) == set(want)
+    worst = (0.0, None)
+    for k in sorted(want):
+        err = float(np.abs(host(pout[k]) - want[k]).max())
+        worst = max(worst, (err, k))
+        assert err < 2e-4, (k, err)
+    np.testing.assert_allclose(host(x_out), g[name + "/x_out"], rtol=0, atol=2e-4)
+    print("init pass: worst |g, b difference| %.2e (%s)" % worst)
+    # the model is left loaded with the initialised variables: an ordinary forward runs
+    model2 = amd.CVAE1(z_size=c["z_size"], h_size=c["h_size"], kl_min=c["kl_min"], depth=c["depth"], num_blocks=c["num_blocks"],
+                       k=c["k"], image_size=c["image_size"])
+    model2.load(pout)
+    xo, obj, loss = model2.forward(torch.from_numpy(c["x"]).cuda(), [dev(e) for e in c["noise"]])
+    assert np.isfinite(host(obj)).all() and np.isfinite(host(xo)).all()
