@@ -156,3 +156,27 @@ def test_cvae1_init_pass_vs_the_references_own_init_branches(amd, golden_dir):
     model2.load(pout)
     xo, obj, loss = model2.forward(torch.from_numpy(c["x"]).cuda(), [dev(e) for e in c["noise"]])
     assert np.isfinite(host(obj)).all() and np.isfinite(host(xo)).all()
+
+
+def test_cvae1_init_then_training_steps_lower_the_objective(amd):
+    """the reference's start of training end to end on one fixed batch: data-dependent init pass (CVAE1(hps, "init")), then steps of
+    prepare_weights -> forward_backward (gradients into the flat buffer) -> fused Adamax + EMA (tf_train.py:128,146-159): the objective falls"""
+    import iaf_amd.parallel as par
+    c = gi.model_case_inputs("model_cfg")
+    x = torch.from_numpy(c["x"]).cuda()
+    noise = [dev(e) for e in c["noise"]]
+    model = amd.CVAE1(z_size=c["z_size"], h_size=c["h_size"], kl_min=c["kl_min"], depth=c["depth"], num_blocks=c["num_blocks"], k=1,
+                      image_size=c["image_size"])
+    _, p0 = model.init_pass(x, {k: dev(v) for k, v in c["params"].items() if not (k.endswith("/g") or k.endswith("/b"))}, noise)
+    flat = par.FlatParams({k: p0[k] for k in sorted(p0)})
+    model.set_training(True)
+    model.load(flat.p)
+    objs = []
+    for _ in range(12):
+        model.prepare_weights()
+        _, obj, _ = model.forward_backward(x, noise, grads=flat.g)
+        objs.append(float(obj.item()))
+        flat.adamax_ema_step(2e-3, world=1)
+    assert all(np.isfinite(objs)), objs
+    assert objs[-1] < objs[0] - 0.02 * abs(objs[0]), objs
+    assert sum(1 for a, b in zip(objs, objs[1:]) if b < a) >= 9, objs
