@@ -712,9 +712,9 @@ def model_train_bench(args, depths, dist, rank, n_gpus):
         comm = par.RcclComm()
     keep = {}
 
-    def step():
+    def step(autotune=False):
         model.prepare_weights()
-        keep["out"] = model.forward_backward(x, noise, grads=flat.g)
+        keep["out"] = model.forward_backward(x, noise, grads=flat.g, autotune=autotune)
         if comm is not None:
             flat.all_reduce_grads(comm=comm)
         flat.adamax_ema_step(1e-4, world=n_gpus)
@@ -722,8 +722,10 @@ def model_train_bench(args, depths, dist, rank, n_gpus):
     stream = torch.cuda.Stream()
     graph = None
     with torch.cuda.stream(stream):
-        for _ in range(2):
-            step()
+        step()
+        if not args.no_autotune:
+            step(autotune=True)                   # launch-shape search of the plain convs and their data gradients (cuDNN's search)
+        step()
         stream.synchronize()
         obj0 = float(keep["out"][1].item())
         if not args.no_graph:

@@ -265,9 +265,11 @@ class CVAE1(object):
             self._wn = WnBwdBatch(stacks=[self.layers[i][j].posterior.stack for i, j in self._wn_order],
                                   convs=[getattr(self.layers[ij[0]][ij[1]], nm) for ij, nm in self._wn_convs])
 
-    def forward_backward(self, x, noise, grads=None):
+    def forward_backward(self, x, noise, grads=None, autotune=False):
         """One tower's forward and backward in mode "train", k = 1: returns (x_out, obj [1], grads) with grads[name] = d obj / d params[name]
-        for every variable (written into the tensors of `grads` where it has them -- e.g. the views of parallel.FlatParams.g).  The layer stack's backward is IAFLayer.down_backward / .up_backward chained through the model (the down pass
+        for every variable (written into the tensors of `grads` where it has them -- e.g. the views of parallel.FlatParams.g).
+        autotune=True: the first call at a new batch size searches the launch shapes of the plain convs and their data gradients (what
+        cuDNN's algorithm search does for the reference).  The layer stack's backward is IAFLayer.down_backward / .up_backward chained through the model (the down pass
         in up-pass order, then the up pass in reverse); the two ends -- likelihood, clip, x_dec, h_top, x_enc -- are the launches of
         csrc/iaf_model_edge.hpp.  noise as in forward()."""
         if not getattr(self, "_training", False) or self.params is None:
@@ -287,14 +289,14 @@ class CVAE1(object):
         _capi.check(lib.iaf_convk_forward(_ptr(xf), _ptr(self._w_enc), _ptr(p["x_enc/b"]), _ptr(h), n, 3, S, S, hs, 5, 5, 2, 0, st()))
         for level in self.layers:
             for layer in level:
-                h = layer.up_train(h)
+                h = layer.up_train(h, autotune=autotune)
         St = S // 2 ** self.depth
         h = torch.empty((n, hs, St, St), **f32)
         _capi.check(lib.iaf_tile_channels(_ptr(p["h_top"]), _ptr(h), n, hs, St * St, st()))
         objs, li = [], 0
         for level in reversed(self.layers):
             for layer in reversed(level):
-                h, cur_obj, _ = layer.down_train(h, noise[2 * li + 1])
+                h, cur_obj, _ = layer.down_train(h, noise[2 * li + 1], autotune=autotune)
                 objs.append(cur_obj)
                 li += 1
         h_last = h
@@ -337,12 +339,12 @@ class CVAE1(object):
             for j, layer in enumerate(level):
                 pre = "IAF_%d_%d/" % (i, j)
                 lgrads[(i, j)] = {k[len(pre):]: v for k, v in grads.items() if k.startswith(pre)}
-                d = layer.down_backward(d, dko, self._lparams[(i, j)], lgrads[(i, j)])
+                d = layer.down_backward(d, dko, self._lparams[(i, j)], lgrads[(i, j)], autotune=autotune)
         _capi.check(lib.iaf_channel_sum(_ptr(d), _ptr(gs("h_top")), n, hs, St * St, st()))                 # adjoint of the tile (:190-192)
         d = torch.zeros((n, hs, St, St), **f32)                      # the up pass's last output is not used (h_top replaces it)
         for i in reversed(range(self.depth)):
             for j in reversed(range(self.num_blocks)):
-                d = self.layers[i][j].up_backward(d, self._lparams[(i, j)], lgrads[(i, j)])
+                d = self.layers[i][j].up_backward(d, self._lparams[(i, j)], lgrads[(i, j)], autotune=autotune)
         tup = lambda dct, nm: (dct[nm + "/V"], dct[nm + "/g"], dct[nm + "/b"])
         self._wn.run(stack_params=[IAFLayer.stack_params(self._lparams[ij]) for ij in self._wn_order],
                      stack_grads=[IAFLayer.stack_params(lgrads[ij]) for ij in self._wn_order],
