@@ -10,7 +10,7 @@ import math
 import torch
 
 from . import _capi
-from .distributions import compute_lowerbound, discretized_logistic
+from .distributions import StreamingLowerBound, compute_lowerbound, discretized_logistic
 from .iaf_layer import IAFLayer
 from .layers import (ConvPrepBatch, PrepBatch, VariableStore, WnBwdBatch, ar_multiconv2d, resample2, variable_scope, _check_act, _ptr,
                      _stream)
@@ -186,7 +186,24 @@ class CVAE1(object):
         self.load(out)
         return x_out, out
 
-    def forward(self, x, noise):
+    def iw_eval(self, x, noise_passes):
+        """The k-sample importance-weighted bound of the whole model without materialising k samples at once (tf_train.py:168-170,218 with
+        hps.k = len(noise_passes); BASELINE config 5 evaluates k = 10^4): one forward with k = 1 per pass, the per-image terms log_pxz and
+        sum-of-KL streamed into the running log-sum-exp (StreamingLowerBound).  noise_passes: one noise list (as for forward) per sample.
+        Returns the loss [1] = sum over images of -log (1/k) sum_s exp(log_pxz_s - kl_s); bits_per_dim(loss, B) as usual."""
+        if self.k != 1:
+            raise ValueError("iw_eval streams the samples: build the model with k = 1")
+        B = int(x.shape[0])
+        acc = StreamingLowerBound(B, x.device)
+        for noise in noise_passes:
+            log_pxz, kl_cost = self.forward(x, noise, _terms=True)
+            acc.update(log_pxz.reshape(B, 1), kl_cost.reshape(B, 1))
+        lb = acc.result()
+        loss = torch.empty(1, dtype=torch.float32, device=x.device)
+        _capi.check(_capi.lib().iaf_sum_axpy(_ptr(lb), None, 0.0, _ptr(loss), B, _stream()))
+        return loss
+
+    def forward(self, x, noise, _terms=False):
         """x: uint8 [B,3,S,S] on the device.  noise: per layer in top-down order the pair (eps_prior, eps_post) the reference's two
         DiagonalGaussians draw (distributions.py:15-24), flattened into one list -- eps_post is used in mode "train", eps_prior in
         "init" / "sample".  Returns (x_out [B k,3,S,S], obj [1], loss [1]) as tf_train.py:218."""
@@ -232,6 +249,8 @@ class CVAE1(object):
         _capi.check(lib.iaf_deconvk_forward(_ptr(h), _ptr(self._w_dec), _ptr(p["x_dec/b"]), _ptr(x_out), n, hs, S // 2, S // 2, 3, 5, 5,
                                             2, 1, -0.5 + 1 / 512., 0.5 - 1 / 512., _stream()))             # :206-208
         log_pxz = discretized_logistic(x_out, p["dec_log_stdv"], sample=xf)                                # :210
+        if _terms:
+            return log_pxz, kl_cost
         obj = torch.empty(1, dtype=torch.float32, device=dev)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         _capi.check(lib.iaf_sum_axpy(_ptr(kl_obj), _ptr(log_pxz), -1.0, _ptr(obj), n, _stream()))          # :211

@@ -180,3 +180,29 @@ def test_cvae1_init_then_training_steps_lower_the_objective(amd):
     assert all(np.isfinite(objs)), objs
     assert objs[-1] < objs[0] - 0.02 * abs(objs[0]), objs
     assert sum(1 for a, b in zip(objs, objs[1:]) if b < a) >= 9, objs
+
+
+def test_cvae1_iw_eval_streamed_equals_the_k_sample_forward(amd):
+    """CVAE1.iw_eval (k passes with k = 1, per-image terms streamed into the running log-sum-exp) == the loss of ONE forward with hps.k = k
+    on the same noise (tf_train.py:159,218: images repeated k times, compute_lowerbound over the [n, k] matrix) -- BASELINE config 5's
+    evaluation at model level; and == the CPU oracle"""
+    c = gi.model_case_inputs("model_k2")
+    k = 3
+    rng = np.random.RandomState(5)
+    B = c["B"]
+    passes = [[rng.standard_normal((B,) + e.shape[1:]) for e in c["noise"]] for _ in range(k)]
+    # the k-sample forward wants [B k, ...] noise, image-major / sample-minor (repeat(x, k), distributions.py:40-52)
+    merged = [np.stack([passes[s][i] for s in range(k)], axis=1).reshape((B * k,) + passes[0][i].shape[1:]) for i in range(len(c["noise"]))]
+    kw = dict(z_size=c["z_size"], h_size=c["h_size"], kl_min=c["kl_min"], depth=c["depth"], num_blocks=c["num_blocks"], image_size=c["image_size"])
+    params = {n: dev(v) for n, v in c["params"].items()}
+    x = torch.from_numpy(c["x"]).cuda()
+    mk = amd.CVAE1(k=k, **kw)
+    mk.load(params)
+    _, _, loss_k = mk.forward(x, [dev(e) for e in merged])
+    m1 = amd.CVAE1(k=1, **kw)
+    m1.load(params)
+    loss_s = m1.iw_eval(x, [[dev(e) for e in p] for p in passes])
+    want = O.cvae1_forward(c["x"], {n: f32(v) for n, v in c["params"].items()}, c["z_size"], c["h_size"], c["depth"], c["num_blocks"],
+                           c["kl_min"], k, [f32(e) for e in merged])[2]
+    np.testing.assert_allclose(host(loss_k)[0], want, rtol=2e-5)
+    np.testing.assert_allclose(host(loss_s)[0], want, rtol=2e-5)
