@@ -113,6 +113,13 @@ def emit(out):
         sys.stdout.flush()
 
 
+def force_dist(args):
+    """The training modes run their gradient exchange through RCCL even on ONE GPU (a one-rank communicator: the call path, stream
+    ordering and graph capture of the real thing; IAF_BENCH_FORCE_DIST=0 turns that off, =1 turns it on for the other modes)."""
+    v = os.environ.get("IAF_BENCH_FORCE_DIST")
+    return (v not in ("0", "")) if v is not None else bool(args.train)
+
+
 def free_port():
     import socket
     s = socket.socket()
@@ -149,7 +156,7 @@ def init_ranks(args):
         sys.exit("bench.py: rank %d needs GPU %d but %d GPU(s) are visible" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     info = {"rccl_ranks": None, "devices": ["rank0:cuda:%d %s" % (local_rank, torch.cuda.get_device_name(local_rank))]}
-    if world == 1 and not os.environ.get("IAF_BENCH_FORCE_DIST"):     # the env switch exercises the RCCL path on one GPU
+    if world == 1 and not force_dist(args):               # (training modes: the RCCL path runs on one GPU too)
         return None, 0, 1, info
     import torch.distributed as dist
     # RCCL prints a banner (ROCm version / hostname / library path) to STDOUT whenever a communicator comes up (the first
@@ -425,7 +432,7 @@ def train_bench(args, depths, dist, rank, n_gpus):
         L["gradviews"] = {k: flat.g[L["pre"] + k] for k in L["keys"]}
     groups = _chunks(layers, args.ar_buckets)
     bounds = par.OverlappedGradReduce.bounds_from_groups(flat, [[L["pre"] + k for L in g for k in L["keys"]] for g in groups])
-    red = par.OverlappedGradReduce(flat, bounds, force=bool(os.environ.get("IAF_BENCH_FORCE_DIST")))
+    red = par.OverlappedGradReduce(flat, bounds, force=force_dist(args))
     prep = iaf_amd.PrepBatch([L["stack"] for L in layers])
     plist = [L["params"] for L in layers]
     # mask + weight-norm backward: one launch per bucket (it finishes the bucket's dV / dg)
@@ -683,8 +690,10 @@ def layers_bench(args, depths, dist, rank, n_gpus):
 def model_train_bench(args, depths, dist, rank, n_gpus):
     """One tower's training step of the WHOLE reference model (CVAE1, tf_train.py:114-218) from its own objective: every weight norm
     re-derived (batched launches), forward, obj = sum(kl_obj - log_pxz), backward of everything (iaf_amd.CVAE1.forward_backward:
-    opt.compute_gradients(obj), tf_train.py:128) with the gradients written into ONE flat buffer, all-reduce(sum) of that buffer over
-    the ranks (RCCL; one message: the backward is not split into segments here), fused Adamax(1/N) + EMA on the flat parameter buffer
+    opt.compute_gradients(obj), tf_train.py:128) with the gradients written into ONE flat buffer laid out in the order the backward
+    completes them (CVAE1.completion_order) and cut into --ar-buckets buckets (CVAE1.set_grad_buckets): each bucket's all-reduce(sum)
+    over the ranks is issued right behind the backward segment that completes it and travels while the remaining segments run
+    (tf_utils/common.py:83-86 on RCCL, parallel.OverlappedGradReduce), then the fused Adamax(1/N) + EMA on the flat parameter buffer
     (tf_utils/adamax.py:40-56, tf_train.py:146-159).  uint8 images and noise are synthetic, weights random-init."""
     import golden_inputs as gi
     import iaf_amd
@@ -696,7 +705,6 @@ def model_train_bench(args, depths, dist, rank, n_gpus):
     c = gi.model_case_inputs("bench")
     rng = np.random.RandomState(99 + rank)
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
-    flat = par.FlatParams({k: dev(v) for k, v in c["params"].items()})
     model = iaf_amd.CVAE1(z_size=zs, h_size=hs, kl_min=0.25, depth=len(depths), num_blocks=nb, k=1, image_size=32, depth_ar=args.depth_ar)
     for level in model.layers:
         for layer in level:
@@ -704,61 +712,40 @@ def model_train_bench(args, depths, dist, rank, n_gpus):
             for cvx in layer.convs():
                 cvx.set_precision(args.precision)
     model.set_training(True)
+    host = {k: dev(v) for k, v in c["params"].items()}
+    model.load(host)                                       # (names only: the flat buffer is laid out in the model's completion order)
+    flat = par.FlatParams({k: host[k] for k in model.completion_order()})
     model.load(flat.p)
+    bucket_names = model.set_grad_buckets(args.ar_buckets)
+    red = par.OverlappedGradReduce(flat, par.OverlappedGradReduce.bounds_from_groups(flat, bucket_names), force=force_dist(args))
     x = torch.from_numpy(rng.randint(0, 256, size=(B, 3, 32, 32)).astype(np.uint8)).cuda()
     noise = [dev(rng.standard_normal(e.shape)) for e in c["noise"]]
-    comm = None
-    if dist is not None or os.environ.get("IAF_BENCH_FORCE_DIST"):
-        comm = par.RcclComm()
-    keep = {}
+    keep, tune = {}, [False]
 
-    def step(autotune=False):
+    def seg0():
         model.prepare_weights()
-        keep["out"] = model.forward_backward(x, noise, grads=flat.g, autotune=autotune)
-        if comm is not None:
-            flat.all_reduce_grads(comm=comm)
-        flat.adamax_ema_step(1e-4, world=n_gpus)
+        keep["fb"] = model.fb_begin(x, noise, grads=flat.g, autotune=tune[0])
+        model.fb_segment(0)
 
-    stream = torch.cuda.Stream()
-    graph = None
-    with torch.cuda.stream(stream):
-        step()
-        if not args.no_autotune:
-            step(autotune=True)                   # launch-shape search of the plain convs and their data gradients (cuDNN's search)
-        step()
-        stream.synchronize()
-        obj0 = float(keep["out"][1].item())
-        if not args.no_graph:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=stream):
-                step()
-        run = graph.replay if graph is not None else step
-
-        def barrier():
-            torch.cuda.synchronize()
-            if dist is not None:
-                dist.barrier()
-            torch.cuda.synchronize()
-
-        for _ in range(args.warmup):
-            run()
-        barrier()
-        repeats = []
-        for _ in range(max(1, args.repeats)):
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                run()
-            barrier()
-            repeats.append(time.perf_counter() - t0)
-        elapsed = float(np.median(repeats))
-        obj1 = float(keep["out"][1].item())
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    segments = [seg0] + [(lambda i=i: model.fb_segment(i)) for i in range(1, len(bucket_names))]
+    for sgm in segments:
+        sgm()
+    if not args.no_autotune:
+        tune[0] = True                                     # launch-shape search of the plain convs and their data gradients (cuDNN's search)
+        for sgm in segments:
+            sgm()
+        tune[0] = False
+    for sgm in segments:
+        sgm()
+    torch.cuda.synchronize()
+    obj0 = float(keep["fb"]["obj"].item())
+    elapsed, graphed, exchange = _run_segmented(args, segments, red, flat, n_gpus, dist)
+    obj1 = float(keep["fb"]["obj"].item())
     if rank != 0:
         return
+    exchange["rccl"] = bool(red.comm is not None)
+    exchange["messages"] = len(bucket_names) if red.active else 0
+    exchange["bytes"] = 4 * flat.params.numel()
     emit({
         "metric": "CVAE1 TRAIN-step samples/sec (whole model from its own objective: weight norms, forward, backward of every variable, "
                   "grad all-reduce, Adamax/EMA)",
@@ -769,11 +756,12 @@ def model_train_bench(args, depths, dist, rank, n_gpus):
         "config": {"workload": "cifar10 z_size=%d h_size=%d depth=%d num_blocks=%d depth_ar=%d bs=%d per GPU, kl_min=0.25, k=1: CVAE1 "
                                "(tf_train.py:114-218), %d trainable fp32 parameters in %d tensors, one flat gradient buffer (%.1f MB)"
                                % (zs, hs, len(depths), nb, args.depth_ar, B, flat.params.numel(), len(flat.p), 4e-6 * flat.params.numel()),
-                   "global_batch": n_gpus * B, "launch": "hipGraph replay" if graph is not None else "eager",
+                   "global_batch": n_gpus * B,
+                   "launch": "hipGraph replay per gradient bucket, all-reduce behind each, then the update" if graphed else "eager",
                    "obj_first_step": obj0, "obj_last_step": obj1,
                    "bits_per_dim_last_step": obj1 / (np.log(2.) * 3072 * B),
-                   "parallelism": "dp%d (one all-reduce of the flat gradient buffer behind the backward)" % n_gpus},
-        "exchange": {"rccl": comm is not None, "messages": 1 if comm is not None else 0, "bytes": 4 * flat.params.numel()}})
+                   "parallelism": "dp%d (RCCL all-reduce of %d gradient buckets, overlapped with backward)" % (n_gpus, len(bucket_names))},
+        "exchange": exchange})
 
 
 def layers_train_bench(args, depths, dist, rank, n_gpus):
@@ -842,7 +830,7 @@ def layers_train_bench(args, depths, dist, rank, n_gpus):
         names = [[k for L in g for k in named if k.startswith(L["pre"]) and is_down(k)] for g in dgroups] + \
                 [[k for L in g for k in named if k.startswith(L["pre"]) and not is_down(k)] for g in ugroups]
     red = par.OverlappedGradReduce(flat, par.OverlappedGradReduce.bounds_from_groups(flat, names),
-                                   force=bool(os.environ.get("IAF_BENCH_FORCE_DIST")))
+                                   force=force_dist(args))
     prep_s = iaf_amd.PrepBatch([L["layer"].posterior.stack for L in all_layers])
     prep_c = iaf_amd.ConvPrepBatch([c for L in all_layers for c in L["layer"].convs()])
     splist = [iaf_amd.IAFLayer.stack_params(L["params"]) for L in all_layers]
@@ -1043,6 +1031,108 @@ def iw_eval_bench(args, depths, dist, rank, n_gpus):
                      "step": {"live_flops_per_step": step_fl, "frac_of_f32_mfma_peak": step_fl / (elapsed / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS}}})
 
 
+def iw_eval_model_bench(args, depths, dist, rank, n_gpus):
+    """BASELINE configs[4] at MODEL level: the k-sample importance-weighted bound of the whole CVAE1 (tf_train.py:168-170,218 with
+    hps.k = --iw-k), streamed: the bottom-up pass (image scaling, x_enc, every layer's up_conv1 / up_conv3) depends on x only and runs
+    ONCE per image block (CVAE1.iw_eval keeps its products across the passes); one STEP = one importance sample of every image of the
+    block = one top-down pass (h_top, every layer's down_conv1 / posterior block / down_conv2, x_dec, likelihood) + the update of the
+    running log-sum-exp.  Reported beside it: the same pass with the bottom-up pass recomputed (= k x forward, what round 4 ran)."""
+    import golden_inputs as gi
+    import iaf_amd
+    from iaf_amd.distributions import StreamingLowerBound
+    if len(set(depths)) != 1:
+        raise SystemExit("--iw-eval --model: the reference model has the same number of layers on every level")
+    B, zs, hs, nb = args.batch, args.n_z, args.n_h, depths[0]
+    gi.MODEL_CASES["bench"] = (B, 1, zs, hs, len(depths), nb, 32, 0.25)
+    c = gi.model_case_inputs("bench")
+    rng = np.random.RandomState(2468 + rank)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+    model = iaf_amd.CVAE1(z_size=zs, h_size=hs, kl_min=0.25, depth=len(depths), num_blocks=nb, k=1, image_size=32, depth_ar=args.depth_ar)
+    for level in model.layers:
+        for layer in level:
+            layer.posterior.stack.set_precision(args.precision)
+            for cvx in layer.convs():
+                cvx.set_precision(args.precision)
+    model.load({k: dev(v) for k, v in c["params"].items()})
+    x = torch.from_numpy(rng.randint(0, 256, size=(B, 3, 32, 32)).astype(np.uint8)).cuda()
+    noise = [dev(rng.standard_normal(e.shape)) for e in c["noise"]]
+    acc = StreamingLowerBound(B, x.device)
+    keep = {}
+
+    def bottom_up():
+        keep["xf"] = model._bottom_up(x, noise)
+
+    def one_pass():
+        log_pxz, kl_cost = model._top_down(keep["xf"], B, noise, terms=True)
+        acc.update(log_pxz.reshape(B, 1), kl_cost.reshape(B, 1))
+
+    def full_pass():                                       # round 4's form: the whole forward per sample
+        bottom_up()
+        one_pass()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(fn):
+        graph = None
+        fn()
+        torch.cuda.current_stream().synchronize()
+        if not args.no_graph:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=torch.cuda.current_stream()):
+                fn()
+        run = graph.replay if graph is not None else fn
+        for _ in range(args.warmup):
+            run()
+        reps = []
+        for _ in range(max(1, args.repeats)):
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                run()
+            barrier()
+            reps.append(time.perf_counter() - t0)
+        return float(np.median(reps)), graph is not None
+
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        bottom_up()
+        stream.synchronize()
+        t_up, _ = timed(bottom_up)
+        t_full, _ = timed(full_pass)
+        elapsed, graphed = timed(one_pass)
+        bound = acc.result()
+        torch.cuda.synchronize()
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        return
+    rows_per_s = n_gpus * B / (elapsed / args.steps)
+    emit({
+        "metric": "CVAE1 IW-ELBO evaluation importance-samples/sec (whole model, bottom-up pass once per image block, streaming log-sum-exp)",
+        "value": rows_per_s, "unit": "samples/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if args.precision == "f32" else "f32 (bf16x3 split-product MFMA where it wins, fp32 accumulate)",
+        "data": "synthetic",
+        "config": {"workload": "10000-sample importance-weighted ELBO eval of the whole model, inference only (BASELINE configs[4]): cifar10 "
+                               "z_size=%d h_size=%d depth=%d num_blocks=%d depth_ar=%d, %d images per block, one sample of each per pass, "
+                               "k = %d passes per estimate" % (zs, hs, len(depths), nb, args.depth_ar, B, args.iw_k),
+                   "global_batch": n_gpus * B, "k": args.iw_k, "images_per_s_at_k": rows_per_s / args.iw_k,
+                   "ms_per_pass_top_down_only": 1e3 * elapsed / args.steps,
+                   "ms_per_pass_with_the_bottom_up_pass_recomputed": 1e3 * t_full / args.steps,
+                   "ms_bottom_up_pass_once_per_block": 1e3 * t_up / args.steps,
+                   "speedup_vs_k_times_forward": t_full / elapsed,
+                   "seconds_per_estimate_of_%d_images" % B: (args.iw_k * elapsed + t_up) / args.steps,
+                   "launch": "hipGraph replay of one pass" if graphed else "eager",
+                   "finite_bound": bool(torch.isfinite(bound).all().item()),
+                   "parallelism": "dp%d (images sharded over ranks, no collective)" % n_gpus}})
+
+
 def _halo_note(st, R, args):
     """how many MACs the one-launch step issues per live MAC: hidden layer l is computed on R + depth_ar - l rows per R
     output rows (iaf_step_fused.hpp) -- or on its R own rows where the row blocks exchange their halo rows; roofline figures
@@ -1110,7 +1200,7 @@ def main():
     if args.iw_eval:
         if args.batch == 32:
             args.batch = 256              # configs[4]: bs = 256
-        iw_eval_bench(args, depths, dist, rank, n_gpus)
+        (iw_eval_model_bench if args.model else iw_eval_bench)(args, depths, dist, rank, n_gpus)
         if dist is not None:
             dist.destroy_process_group()
         return

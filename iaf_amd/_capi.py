@@ -89,6 +89,7 @@ SIGNATURES = {
     "iaf_up_iaf2_backward_post": (ctypes.c_int, [_c_float_p] * 7 + [ctypes.c_int] * 4 + [_vp]),
     "iaf_stack_exchange_errors": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint)]),
     "iaf_stack_step_exchanges": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "iaf_stack_step_pairs": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "iaf_stack_set_halo_exchange": (ctypes.c_int, [_vp, ctypes.c_int]),
     "iaf_stack_set_halo_exchange_debug": (ctypes.c_int, [_vp, ctypes.c_uint]),
     "iaf_comm_unique_id": (ctypes.c_int, [_vp]),

@@ -376,7 +376,8 @@ extern "C" int iaf_stack_create(iaf_stack_t** out, int n_z, int n_h, int depth_a
     s->generic = generic;
     // IAF_XCH_DEBUG=<bits>: every stack starts with these iaf_stack_set_halo_exchange_debug bits (1 = scrambled work lists, 2 = random
     // delays, 16 = free-bits finish as its own launch) -- how the whole GPU suite is run under a scrambled hand-over order
-    if (const char* e = getenv("IAF_XCH_DEBUG")) s->xch_knob = (unsigned)atoi(e) & (1u | 2u | 16u);
+    // (32 = the pair form at 8-pixel rows: the whole suite through it)
+    if (const char* e = getenv("IAF_XCH_DEBUG")) s->xch_knob = (unsigned)atoi(e) & (1u | 2u | 16u | 32u);
     s->n_z = n_z; s->n_h = n_h; s->depth_ar = depth_ar; s->variant = variant;
     s->nlayers = depth_ar + 1;
     s->prepared = false;
@@ -1055,7 +1056,22 @@ static step_fn_t fused_step_xch(const iaf_stack_t* s, int H, int W, int R, size_
     return (f && *lds <= 160 * 1024) ? f : nullptr;
 }
 
-// The exchange set of stream st, grown to [layer][B * nrb] rows of xrow bytes: created on the stream's first such launch -- not
+// The pair form of the one-launch step (iaf_step_fused.hpp, PAIR; 8-pixel rows): two workgroups per (image, block of R = 2 rows), each
+// streaming half of the last hidden layer's and of the output pair's weights, their halves of the last hidden region swapped through
+// the stack's exchange buffers (*prow bytes per half).  Where it is switched on it replaces the one-row-per-workgroup kernel: same number
+// of workgroups, full MFMA tiles, 0.65 instead of 1.23 MB through each CU's port.
+static step_fn_t fused_step_pair(const iaf_stack_t* s, int W, size_t* lds, size_t* prow) {
+    // OPT-IN (knob 32 of iaf_stack_set_halo_exchange_debug, or IAF_FUSE_PAIR=1): measured on MI355X at B = 32 it LOSES to the
+    // one-row kernel, 18.9 vs 17.0 us -- the K loops turned out to be bound by what ONE wave per SIMD can issue (~30 cycles per MFMA
+    // with its loads and LDS reads), not by the port, and the hand-over exposes 3.9 k cycles (profiles/r05/experiments/pair_form.txt).
+    static const bool pair_env = getenv("IAF_FUSE_PAIR") && getenv("IAF_FUSE_PAIR")[0] == '1';
+    if (!(pair_env || (s->xch_knob & 32u)) || !s->xch_on || W != 8) return nullptr;
+    const int var = s->variant == IAF_VARIANT_TF ? 0 : s->variant == IAF_VARIANT_THEANO ? 1 : 2;
+    step_fn_t f = iaf_pick_step_fused_pair(s->n_h / 16, s->n_z / 16, s->depth_ar, W, 2, var, lds, prow);
+    return (f && *lds <= 160 * 1024) ? f : nullptr;
+}
+
+// The exchange set of stream st, grown to [layer][B * nrb] rows of xrow bytes (pair form, depth_ar = 2: [B * nrb][2 halves] of xrow bytes): created on the stream's first such launch -- not
 // inside a stream capture (there: the stream's set, else the newest one that is large enough, else NULL and the caller runs what
 // it ran before; warm up before capturing, as for the LDS cap).  A set that grows keeps its counters; the new rows start as
 // "nothing there yet" (0xff).  Outgrown rows stay alive with the stack: a captured graph may still name them.
@@ -1129,6 +1145,19 @@ static step_fn_t fused_step_plan(const iaf_stack_t* s, int B, int H, int W, int*
         }
     }
     const int var = s->variant == IAF_VARIANT_TF ? 0 : s->variant == IAF_VARIANT_THEANO ? 1 : 2;
+    if (!forceR || forceR == 2) {
+        // 8-pixel rows: the pair form (R = 2 rows per PAIR of workgroups).  Without buffers for it (a capture that was not warmed up)
+        // launch_fused_step runs the recomputing kernel of the same R instead.
+        size_t pl = 0, prow = 0;
+        if (step_fn_t fp = fused_step_pair(s, W, &pl, &prow)) {
+            size_t rl = 0;
+            if (iaf_pick_step_fused(s->n_h / 16, s->n_z / 16, s->depth_ar, W, 2, var, &rl) && rl <= 160 * 1024) {
+                if (launching) (void)xch_prepare(const_cast<iaf_stack_t*>(s), B, (H + 1) / 2, prow, st);
+                *R = 2; *lds = pl;
+                return fp;
+            }
+        }
+    }
     step_fn_t fn = iaf_pick_step_fused(s->n_h / 16, s->n_z / 16, s->depth_ar, W, *R, var, lds);
     if (fn && *lds <= 160 * 1024) return fn;               // (launch_fused_step switches to the halo-exchange form where it applies)
     // geometries whose LDS regions only fit in the halo-exchange form (R + 1 rows per region instead of R + depth_ar): config 3's
@@ -1139,6 +1168,15 @@ static step_fn_t fused_step_plan(const iaf_stack_t* s, int B, int H, int W, int*
     if (launching && !xch_prepare(const_cast<iaf_stack_t*>(s), B, (H + *R - 1) / *R, xrow, st)) return nullptr;
     *lds = xl;
     return fx;
+}
+
+extern "C" int iaf_stack_step_pairs(const iaf_stack_t* s, int B, int H, int W) {
+    if (!s) return 0;
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    int R = 0;
+    size_t lds = 0, pl = 0, prow = 0;
+    step_fn_t fn = fused_step_plan(s, B, H, W, &R, &lds);
+    return (fn && fn == fused_step_pair(s, W, &pl, &prow)) ? 1 : 0;
 }
 
 extern "C" int iaf_stack_step_exchanges(const iaf_stack_t* s, int B, int H, int W) {
@@ -1197,7 +1235,22 @@ static int launch_fused_step(iaf_stack_t* s, step_fn_t fn, int R, size_t lds, co
     // Halo exchange instead of halo recompute (TF statement, more than one row block per image, the geometries compiled for it;
     // IAF_FUSE_XCH=0: dev knob).  Its buffers are the stack's: allocated here on first use -- not inside a stream capture, where
     // the recomputing kernel runs instead (warm up before capturing, as for the LDS cap below).
+    bool pair = false;
     {
+        size_t pl = 0, prow = 0;
+        step_fn_t fp = (R == 2) ? fused_step_pair(s, base.W, &pl, &prow) : nullptr;
+        if (fn == fp && fp) {
+            if (iaf_stack::XchSet* x = xch_prepare(s, base.B, q.nrb, prow, st)) {
+                pair = true; lds = pl;
+                q.xh = x->buf; q.xctl = x->ctl; q.xerr = s->xch_err_dev; q.xknob = s->xch_knob;
+            } else {                                         // no buffers (inside a capture that was not warmed up): the recomputing kernel of the same R
+                const int var = s->variant == IAF_VARIANT_TF ? 0 : s->variant == IAF_VARIANT_THEANO ? 1 : 2;
+                fn = iaf_pick_step_fused(s->n_h / 16, s->n_z / 16, s->depth_ar, base.W, R, var, &lds);
+                if (!fn) return IAF_ERR_NOT_PREPARED;
+            }
+        }
+    }
+    if (!pair) {
         size_t xl = 0, xrow = 0;
         if (step_fn_t fx = fused_step_xch(s, base.H, base.W, R, &xl, &xrow)) {
             if (iaf_stack::XchSet* x = xch_prepare(s, base.B, q.nrb, xrow, st)) {
@@ -1209,7 +1262,7 @@ static int launch_fused_step(iaf_stack_t* s, step_fn_t fn, int R, size_t lds, co
         }
     }
     // posterior block on a recomputing kernel: its form with helper waves, where one is compiled (the 8-pixel BASELINE geometry)
-    if (fin && kl_part && base.mode == MODE_POSTERIOR && !q.xh && !(s->xch_knob & 16u)) {
+    if (fin && kl_part && base.mode == MODE_POSTERIOR && !q.xh && !pair && !(s->xch_knob & 16u)) {
         size_t hl = 0;
         const int var = s->variant == IAF_VARIANT_TF ? 0 : s->variant == IAF_VARIANT_THEANO ? 1 : 2;
         if (step_fn_t fh = iaf_pick_step_fused_h(s->n_h / 16, s->n_z / 16, s->depth_ar, base.W, R, var, &hl))
@@ -1230,7 +1283,7 @@ static int launch_fused_step(iaf_stack_t* s, step_fn_t fn, int R, size_t lds, co
     }
     const bool prof = (s->prof_layer == -2 && s->prof_n < s->prof_cap);
     if (prof) HIP_TRY(hipEventRecord(s->prof_start[s->prof_n], st));
-    hipLaunchKernelGGL(fn, dim3(base.B * q.nrb), dim3(step_threads(fn)), lds, st, q);       // (512 where four helper waves sit beside the compute waves)
+    hipLaunchKernelGGL(fn, dim3(base.B * q.nrb * (pair ? 2 : 1)), dim3(step_threads(fn)), lds, st, q);       // (512 where four helper waves sit beside the compute waves)
     if (prof) { HIP_TRY(hipEventRecord(s->prof_stop[s->prof_n], st)); s->prof_n++; }
     return (int)hipGetLastError();
 }

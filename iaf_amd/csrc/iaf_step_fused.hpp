@@ -55,7 +55,9 @@
 // XCH = 1: neighbouring row blocks EXCHANGE their halo rows instead of recomputing them (see the kernel's header note): a
 // hidden layer computes only the R rows its workgroup owns, its region holds one more row -- the first row of the block
 // below, imported -- and z has R + 1 rows.
-template <int NHT, int NZT, int DEPTH, int W, int R, int XCH = 0>
+// PAIR = 1 (8-pixel rows; the header note of the kernel, "PAIR"): TWO workgroups per (image, row block), each streaming half of the last
+// hidden layer's and of the output pair's weights; the regions are those of the recomputing form.
+template <int NHT, int NZT, int DEPTH, int W, int R, int XCH = 0, int PAIR = 0>
 struct StepGeom {
     static constexpr int NZ = 16 * NZT, NH = 16 * NHT;
     static constexpr int RS = W + 2;                           // slots per row (zero column on either side)
@@ -69,7 +71,8 @@ struct StepGeom {
     static constexpr int HREG1 = HREG0 + rows_reg(0) * RS * H16;
     static constexpr int END = HREG1 + (DEPTH >= 2 ? rows_reg(1) * RS * H16 : 0);
     static constexpr int XB_STRIDE = 2 * NZ + 1;                                 // output exchange buffer [pixel][2 n_z] floats
-    static constexpr size_t xb_bytes() { return (size_t)R * W * XB_STRIDE * 4; }
+    static constexpr int XKP = PAIR ? 2 : 1;                                     // K parts of the output pair's sums (PAIR: two waves per tile)
+    static constexpr size_t xb_bytes() { return (size_t)XKP * R * W * XB_STRIDE * 4; }
     // (the last hidden layer sits in the h_odd region for an even depth: z + h_even are dead then; for an odd depth it sits in
     // h_even: the buffer goes into h_odd if it fits there, else behind everything)
     static constexpr int XB_OFF = (DEPTH % 2 == 0) ? 0 : (DEPTH >= 3 && xb_bytes() <= (size_t)(END - HREG1) * 16) ? HREG1 : END;
@@ -87,6 +90,11 @@ struct StepGeom {
     }
     // XCH: one exported row = W pixel slots of a hidden region, as stored in LDS
     static constexpr size_t xrow_bytes() { return (size_t)W * H16 * 16; }
+    // PAIR: what one workgroup hands its partner = its channel half of the last hidden layer's region: rows x W slots x 3 planes x
+    // H8 / 2 16-byte units
+    static constexpr int PUS = 3 * (H8 / 2);                                     // units per pixel slot
+    static constexpr int PUNITS = rows_reg(DEPTH - 1) * W * PUS;
+    static constexpr size_t prow_bytes() { return (size_t)PUNITS * 16; }
 };
 
 // pixel tiles [lo, hi) of a phase with NPT tiles that group g of GN wave groups covers with its left-over co tile
@@ -127,15 +135,26 @@ constexpr int fused_live_frags(int live, int lo, int hi) {
 // Tile slots of a hidden layer with a live centre-tap block at input pair c of a channel-triangular layer, for the waves of
 // group gi of gn (the waves that run one instantiation of a hidden phase): slot j < nfull holds tile 4 j + w of wave w
 // (serpentine: 4 (j + 1) - 1 - w for odd j), the left-over slot a tile >= 4 nfull; tile t is live at c iff c <= t / 2
-constexpr int tri_live(int ntw, int nfull, int nht, int c, int gn, int gi) {
+// (t0: PAIR -- the wave's tiles are tiles t0 .. t0 + nht - 1 of the layer; its left-over slot holds tile t0 + 4 nfull)
+constexpr int tri_live(int ntw, int nfull, int nht, int c, int gn, int gi, int t0 = 0) {
     int m = 0;
     for (int j = 0; j < ntw; ++j)
         for (int w = gi * (4 / gn); w < (gi + 1) * (4 / gn); ++w) {
             const int t = j >= nfull ? nht - 1 : (j & 1) ? 4 * (j + 1) - 1 - w : 4 * j + w;
-            if (c <= t / 2) m |= 1 << j;
+            if (c <= (t0 + t) / 2) m |= 1 << j;
         }
     return m;
 }
+// PAIR: the output pair's K steps of one of the two waves that share a tile -- every second step (parity PAR) of NP input pairs x 5
+// taps, pair-major; `pair` is relative to the part's first input pair (conv_phase's pair0)
+template <int NP_, int PAR_>
+struct PairPart {
+    static constexpr int T0 = 0, NT = NTAPS, TAIL = 0, NPAIR = NP_, NSTEP = (NP_ * NTAPS + 1 - PAR_) / 2, NF = NSTEP;
+    __device__ static void at(int sq, int& pair, int& tap) {
+        const int q = 2 * sq + PAR_;
+        pair = q / NTAPS; tap = q - pair * NTAPS;
+    }
+};
 
 // HLP: helper waves (512 threads, 256 registers per wave; see the kernel).  Every exchange-form kernel has them (XCH implies HLP); the
 // recomputing kernels of the BASELINE run's 8-pixel geometry exist in both forms: with helpers for the posterior block (their last
@@ -145,12 +164,23 @@ constexpr int tri_live(int ntw, int nfull, int nht, int c, int gn, int gi) {
 // VAR: the statement of the operator -- 0 TF, 1 Theano (image rotated by 180 degrees + border channel), 2 Theano with
 // flipmask=True (TF geometry + border channel).  Compile time: as run-time flags these cost the TF path ~1 us per launch
 // (branches around the border loads split the epilogue's basic blocks).
-template <int NHT, int NZT, int DEPTH, int W, int R, int VAR = 0, int XCH = 0, int HLP = XCH>
+// PAIR (8-pixel rows, R = 2; round 5): at BASELINE batch sizes an 8x8 level gives a CU 8 pixels, and the step is bound by the 1.23 MB of
+// weight fragments every workgroup pulls through its CU's 64 B/clk port (8.7 us; profiles/r04/fused_step_stamps.txt: the second
+// conv's K loop = 900 wave-loads x 16 cycles).  Here TWO workgroups share one (image, row block of R = 2 rows = 16 pixels: full MFMA
+// tiles): both compute the first hidden layer in full (its pack is 12 % of the bytes), each computes HALF of the last hidden layer's
+// output channels and half of the output pair (z channels) -- 0.65 MB per CU -- and they hand each other their half of the last hidden
+// region (R + 1 rows, 11.5 KB) through device memory with the machinery of XCH: tickets (partners hold adjacent tickets of one list, so
+// at most one workgroup per list ever waits for a partner that is not running yet), the data as the flag, helper waves.  The output
+// pair multiplies the input channels of its own half first -- they are in LDS already -- and the partner's behind the import.
+template <int NHT, int NZT, int DEPTH, int W, int R, int VAR = 0, int XCH = 0, int HLP = XCH, int PAIR = 0>
 __global__ __launch_bounds__(HLP ? 512 : 256)
 __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fused_kernel(StepP p) {
     static_assert(HLP || !XCH, "the exchange form runs with helper waves");
+    static_assert(!PAIR || (HLP && !XCH && DEPTH == 2 && NZT == 2 && NHT % 2 == 0 && (NHT / 2) % 4 == 1 && (16 * NHT / 8) % 2 == 0),
+                  "PAIR: recomputing form with helpers, two hidden layers, n_z = 32, co tiles per half = 4 k + 1");
     constexpr bool HELP = HLP != 0;
-    typedef StepGeom<NHT, NZT, DEPTH, W, R, XCH> G;
+    constexpr bool TKT = XCH != 0 || PAIR != 0;                  // the workgroup's item comes from a ticket (xch_take_*)
+    typedef StepGeom<NHT, NZT, DEPTH, W, R, XCH, PAIR> G;
     // exchanged rows and flags: AGENT scope (sc1: coherent across the XCDs, served by the memory side)
     constexpr int XSCOPE = __HIP_MEMORY_SCOPE_AGENT;
     constexpr bool FLIP = (VAR == 1), BORDER = (VAR != 0);
@@ -237,12 +267,12 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
     // MFMAs in the K loop -- were measured first: 57.6 k instead of 23.3 k cycles for the second conv's K loop.)
     constexpr int NPAIR_H = NH / 32;
     auto ring_load = [&](auto lo_c, auto hi_c, f32x4 (*dst)[3], const f32x4* wbase, int ncot, const int* tiles, auto part_c, int s,
-                         auto live_c) {
+                         auto live_c, int pair0) {
         typedef decltype(part_c) P;
         constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value, LIVE = decltype(live_c)::value;
         int pair, tap;
         P::at(s < P::NSTEP ? s : P::NSTEP - 1, pair, tap);
-        const f32x4* q = wbase + (size_t)(pair * NTAPS + tap) * ncot * 3 * 64;
+        const f32x4* q = wbase + (size_t)((pair + pair0) * NTAPS + tap) * ncot * 3 * 64;
 #pragma unroll
         for (int f = LO; f < HI; ++f) {
             const int j = f / 3, pn = f - 3 * j;
@@ -292,7 +322,7 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
     auto preload_w0 = [&]() {
         static_for<RD0>([&](auto i) {
             ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWH * 3>{}, wr0[decltype(i)::value], wb0, NHT, htile,
-                      PartL0{}, decltype(i)::value, ALL);
+                      PartL0{}, decltype(i)::value, ALL, 0);
         });
     };
     // context rows of this workgroup: per channel one contiguous run of CPX pixels (full-width rows) -> 16-byte loads,
@@ -392,11 +422,12 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
     unsigned long long xdone = 0, xlists_done = 0;
     [[maybe_unused]] unsigned xmine = 0, xmine_n = 0;                    // (thread 0: the list its ticket came from, that list's items)
     int xslot = 0;
+    int half = 0;                                                        // PAIR: which channel half this workgroup computes
     [[maybe_unused]] unsigned long long xt0 = 0;
     [[maybe_unused]] unsigned xlist = 0;
     unsigned* xmail = (unsigned*)(smem + (size_t)G::CTX_OFF * 16);          // (the context staging area: not written before the first conv is done)
     auto xch_take_begin = [&]() {
-        if constexpr (XCH) {
+        if constexpr (TKT) {
             if (tid == 0) {
                 asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
                 xcc &= 7u;
@@ -410,14 +441,15 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
         }
     };
     auto xch_take_finish = [&]() {
-        if constexpr (XCH) {
+        if constexpr (TKT) {
             if (tid == 0) {
                 unsigned long long v = xt0;
                 unsigned y = xlist, t = 0, ny = 0;
                 bool found = false;
                 for (int k = 0; k < 8; ++k) {
                     if (k) { y = (xlist + k) & 7u; v = __hip_atomic_fetch_add(p.xctl + 32 * y, 1ull, __ATOMIC_RELAXED, XSCOPE); }
-                    ny = (int)y < p.B ? (unsigned)p.nrb * (unsigned)((p.B - (int)y + 7) >> 3) : 0u;
+                    // (PAIR: two tickets per (image, row block) -- 2 k and 2 k + 1 are the two halves of item k)
+                    ny = (int)y < p.B ? (PAIR ? 2u : 1u) * (unsigned)p.nrb * (unsigned)((p.B - (int)y + 7) >> 3) : 0u;
                     t = (unsigned)v;
                     if (t < ny) { found = true; break; }
                 }
@@ -425,15 +457,17 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
                 xmine = y; xmine_n = found ? ny : 0u;
                 if (found) xdone = __hip_atomic_fetch_add(p.xctl + 32 * y + 16, 1ull, __ATOMIC_RELAXED, XSCOPE);
                 unsigned ib = 0, ir = (unsigned)p.nrb - 1;
-                if (found) { ib = y + 8u * (t / (unsigned)p.nrb); ir = (unsigned)p.nrb - 1u - t % (unsigned)p.nrb; }
+                const unsigned ti = PAIR ? t >> 1 : t;
+                if (found) { ib = y + 8u * (ti / (unsigned)p.nrb); ir = (unsigned)p.nrb - 1u - ti % (unsigned)p.nrb; }
                 else xdead |= 2u;                                           // (grid != B * nrb: a host bug -- loud, not a hang)
-                xmail[0] = ib; xmail[1] = ir; xmail[2] = xdead;
+                xmail[0] = ib; xmail[1] = ir; xmail[2] = xdead; xmail[3] = t & 1u;
                 if (p.dbg) p.dbg[(size_t)blockIdx.x * 32 + 30] = 1ull + (((unsigned long long)y << 32) | t);      // (dev tool: which ticket of which list)
             }
             __syncthreads();
             b = __builtin_amdgcn_readfirstlane((int)xmail[0]);
             rbk = __builtin_amdgcn_readfirstlane((int)xmail[1]);
             xdead = __builtin_amdgcn_readfirstlane(xmail[2]);
+            if constexpr (PAIR) half = __builtin_amdgcn_readfirstlane((int)xmail[3]);
             r0 = rbk * R;
             img_z = (size_t)b * NZ * HW; img_h = (size_t)b * NH * HW;
             xslot = b * p.nrb + rbk;
@@ -446,13 +480,13 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
     // ... and, once all of this launch's tickets are taken, the counters of the next launch: two steps, so that no wave ever waits
     // for a counter (each result is looked at a phase after its request)
     auto xch_next_epoch_a = [&]() {
-        if constexpr (XCH) {
+        if constexpr (TKT) {
             if (tid == 0 && xmine_n && (unsigned)xdone == xmine_n - 1u)
                 xlists_done = __hip_atomic_fetch_add(p.xctl + 256, 1ull, __ATOMIC_RELAXED, XSCOPE) + 1ull;
         }
     };
     auto xch_next_epoch_b = [&]() {
-        if constexpr (XCH) {
+        if constexpr (TKT) {
             if (tid == 0 && (unsigned)xlists_done == (unsigned)(p.B < 8 ? p.B : 8)) {
 #pragma unroll
                 for (int y = 0; y < 8; ++y) {
@@ -464,7 +498,7 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
         }
     };
 
-    if constexpr (XCH) {
+    if constexpr (TKT) {
         xch_take_begin();
         if (!is_helper) {
             preload_w0();
@@ -514,12 +548,18 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
     // The caller has requested the part's first RD steps into ring slots 0 .. RD - 1.  accum_c: add to acc_out (second part).
     auto conv_phase = [&](auto rd_c, auto npt_c, auto ntw_c, auto rows_c, auto emask_c, int in_reg, int in_s16, int in_c8, const f32x4* wbase,
                           int ncot, const int* tiles, f32x4 (*wr)[decltype(ntw_c)::value][3],
-                          f32x4 (*acc_out)[decltype(ntw_c)::value], auto part_c, auto grp_c, auto accum_c) {
+                          f32x4 (*acc_out)[decltype(ntw_c)::value], auto part_c, auto grp_c, auto accum_c, int pair0) {
+        // pair0: the part's first input pair (PAIR's output parts; 0 everywhere else)
         typedef decltype(part_c) P;
         constexpr int NPT = decltype(npt_c)::value, NTW = decltype(ntw_c)::value, ROWS = decltype(rows_c)::value;
         constexpr bool TRI = P::TAIL != 0;                         // triangular centre tap: step order and dead slots, see StepPart
         constexpr int nstep = P::NSTEP, s0 = 0;
         constexpr int EMASK = decltype(emask_c)::value;
+        // a wave group whose share of the left-over tile is EMPTY (fewer pixel tiles than groups: the second hidden layer at 8-pixel rows,
+        // one pixel tile for two groups) never multiplies its last slot: it does not fetch it either.  (Until round 5 it did: 150 of the
+        // 900 wave-loads of that K loop, which is bound by exactly those loads -- the CU's 64 B/clk port.)
+        constexpr int LALLV = (EMASK == 0 && NTW > 1) ? ((1 << (NTW - 1)) - 1) : -1;
+        constexpr std::integral_constant<int, LALLV> LALL{};
         constexpr int RD = decltype(rd_c)::value, U = RD + 1;      // this phase's look-ahead; it uses slots 0 .. RD of its ring array
         constexpr int PSG = fused_acc_groups(NTW);                 // accumulator groups of a unit's six part-products
         f32x4 acc[PSG][NPT][NTW];
@@ -539,7 +579,7 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
             int pair, tap;
             P::at(s < nstep ? s : nstep - 1, pair, tap);
             const int toff = tap < 2 ? tap : RS + tap - 3;          // slots: (0,0) (0,1) (1,-1) (1,0) (1,1)
-            return xb[decltype(q_c)::value] + toff * in_s16 + pair * 4;
+            return xb[decltype(q_c)::value] + toff * in_s16 + (pair + pair0) * 4;
         };
         // x operand (three planes per pixel tile): read from LDS one pixel tile ahead of its MFMAs -- or, in phases whose
         // pixel tiles carry only 6-12 MFMAs (the output pair: less MFMA time than an LDS round trip), a whole STEP ahead:
@@ -567,7 +607,7 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
                 // this pixel tile's share of the refill of the slot consumed RD steps from now
                 constexpr int LO = (q * NTW * 3) / NPT, HI = ((q + 1) * NTW * 3) / NPT;
                 ring_load(std::integral_constant<int, LO>{}, std::integral_constant<int, HI>{}, wr[(I + RD) % U], wbase, ncot, tiles, part_c,
-                          s + RD, next_c);
+                          s + RD, next_c, pair0);
                 bf16x8 xh, xm, xl;
                 if constexpr (XAHEAD) {
                     xh = __builtin_bit_cast(bf16x8, xs[I & 1][q][0]);
@@ -606,15 +646,19 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
         // the pair-major body: every slot live (its look-ahead into the first centre-tap steps may fetch a dead block: unused)
         constexpr int NF = P::NF, MAIN = (NF / U) * U;
         for (; s + U <= MAIN; s += U)
-            static_for<U>([&](auto i) { step_body(i, s + decltype(i)::value, ALL, ALL); });
-        static_for<NF - MAIN>([&](auto i) { step_body(i, MAIN + decltype(i)::value, ALL, ALL); });
+            static_for<U>([&](auto i) { step_body(i, s + decltype(i)::value, LALL, LALL); });
+        static_for<NF - MAIN>([&](auto i) { step_body(i, MAIN + decltype(i)::value, LALL, LALL); });
         if constexpr (TRI) {
             // the centre tap: pair c multiplies the slots live at c and requests those live at c + RD
-            constexpr int TGN = XSPLIT ? GN : 1, TGI = decltype(grp_c)::value;
+            // (grp_c: the wave group; PAIR's half h, whose waves own tiles h NHT/2 .. of the layer, one group per wave: 100 (1 + h) + wave)
+            constexpr int GRP = decltype(grp_c)::value;
+            constexpr bool PTRI = GRP >= 100;
+            constexpr int TGN = PTRI ? 4 : (XSPLIT ? GN : 1), TGI = GRP % 100;
+            constexpr int TNF = PTRI ? (NHT / 2) / 4 : NFULL, TNH = PTRI ? NHT / 2 : NHT, TT0 = PTRI ? (GRP / 100 - 1) * (NHT / 2) : 0;
             static_for<P::NPAIR>([&](auto c_c) {
                 constexpr int c = decltype(c_c)::value, sq = NF + c;
-                constexpr int live = tri_live(NTW, NFULL, NHT, c, TGN, TGI);
-                constexpr int next = (c + RD < P::NPAIR) ? tri_live(NTW, NFULL, NHT, c + RD, TGN, TGI) : 0;
+                constexpr int live = tri_live(NTW, TNF, TNH, c, TGN, TGI, TT0) & LALLV;
+                constexpr int next = (c + RD < P::NPAIR) ? (tri_live(NTW, TNF, TNH, c + RD, TGN, TGI, TT0) & LALLV) : 0;
                 step_body(std::integral_constant<int, sq % U>{}, sq, std::integral_constant<int, live>{}, std::integral_constant<int, next>{});
             });
         }
@@ -633,13 +677,17 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
 
     // hidden epilogue: bias (+ context) + ELU (layers.py:63-64,163-165) -> the three planes of the next region; rows past the
     // image bottom become the zero rows the layer above pads with
-    auto load_bias = [&](const float* bias, f32x4* bi) {       // issued before a phase's K loop, used by its epilogue
+    // (ntw_c slots holding tiles tl[]: NTWH / htile everywhere but in PAIR's last hidden layer)
+    auto load_bias = [&](auto ntw_c, const int* tl, const float* bias, f32x4* bi) {       // issued before a phase's K loop, used by its epilogue
 #pragma unroll
-        for (int j = 0; j < NTWH; ++j) bi[j] = *(const f32x4*)(bias + (htile[j] < NHT ? htile[j] : NHT - 1) * 16 + 4 * kk);
+        for (int j = 0; j < decltype(ntw_c)::value; ++j) bi[j] = *(const f32x4*)(bias + (tl[j] < NHT ? tl[j] : NHT - 1) * 16 + 4 * kk);
     };
-    auto hidden_epilogue = [&](auto npt_c, auto rows_c, auto emask_c, auto ctx_c, f32x4 (*acc)[NTWH], const f32x4* bias, int out_reg,
-                               float* hsave, const float* bt) {
+    // save_half: PAIR's first hidden layer, which both workgroups compute in full -- each writes the tiles of its own half to hsave
+    auto hidden_epilogue = [&](auto npt_c, auto rows_c, auto emask_c, auto ctx_c, auto ntw_c, const int* htile,
+                               f32x4 (*acc)[decltype(ntw_c)::value], const f32x4* bias, int out_reg, float* hsave, const float* bt,
+                               bool save_half) {
         constexpr int NPT = decltype(npt_c)::value, ROWS = decltype(rows_c)::value, EMASK = decltype(emask_c)::value;
+        constexpr int NTWH = decltype(ntw_c)::value;
         constexpr bool WITH_CTX = decltype(ctx_c)::value != 0;
         f32x4 cxv[WITH_CTX ? NPT : 1][NTWH];                     // all context reads in flight together, ahead of the arithmetic
         if constexpr (WITH_CTX) {
@@ -673,7 +721,7 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
                 if (r0 + row >= H) v = f32x4{0.f, 0.f, 0.f, 0.f};
                 bf3_store4(smem + (size_t)out_reg * 16, row * RS + col + 1, htile[j] * 4 + kk, v, H16, H8);
                 // training: the rows this workgroup OWNS (not its halo) go to HBM for the backward pass
-                if (hsave && row < R && r0 + row < H)
+                if (hsave && row < R && r0 + row < H && (!save_half || (htile[j] >= NHT / 2) == (half != 0)))
                     *(f32x4*)(hsave + ((size_t)b * HW + (size_t)gpix(r0 + row, col)) * NH + htile[j] * 16 + 4 * kk) = v;
             }
         }
@@ -683,15 +731,17 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
     // memory counter retires in order, so a request issued right in front of the output pair's K loop would stall that loop's
     // third step (the first to wait for a refill issued behind it) for a whole HBM round trip; here they have an epilogue
     // and a barrier to arrive
-    constexpr int NEL = (NZ * R * W + 255) / 256;
+    constexpr int NZF = PAIR ? NZ / 2 : NZ;                      // z channels this workgroup finishes (PAIR: those of its half, from fcb)
+    constexpr int NEL = (NZF * R * W + 255) / 256;
     float fz[NEL], fq[NEL][6];
     float fb[NEL][2];
     auto load_final_operands = [&]() {
+        const int fcb = PAIR ? half * NZF : 0;
 #pragma unroll
         for (int e = 0; e < NEL; ++e) {
             const int idx = tid + e * 256;
-            const int ic = idx < NZ * R * W ? idx : NZ * R * W - 1;
-            const int c = ic / (R * W), pix = ic - c * (R * W);
+            const int ic = idx < NZF * R * W ? idx : NZF * R * W - 1;
+            const int c = fcb + ic / (R * W), pix = ic % (R * W);
             const int rr = r0 + pix / W < H ? r0 + pix / W : H - 1;
             const unsigned gi = 4u * (unsigned)(c * HW + gpix(rr, pix & (W - 1)));
             const int cm = (c >> 4) * 32 + (c & 15);
@@ -745,9 +795,19 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
                 f32x4 t[XNLH];
 #pragma unroll
                 for (int u = 0; u < XNLH; ++u) { const int i = htid + 256 * u; t[u] = src[i < XNU ? i : XNU - 1]; }
+                // The pattern means "not there yet".  No arithmetic produces it, but NaNs with all-ones payloads can come in with the
+                // caller's data (uninitialised memory) and reach an activation pair unchanged: such a pair leaves as the canonical NaN
+                // pair -- NaN either way, which is the caller's signal (tf_train.py:283-285), and never an exchange that "gives up".
+                u32x4 tw[XNLH];
+#pragma unroll
+                for (int u = 0; u < XNLH; ++u) {
+                    tw[u] = __builtin_bit_cast(u32x4, t[u]);
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) tw[u][d] = tw[u][d] == XSENT ? 0x7fc07fc0u : tw[u][d];
+                }
 #pragma unroll
                 for (int u = 0; u < XNLH; ++u)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t[u]), r, 16 * (htid + 256 * u), 0, XSC1);
+                    __builtin_amdgcn_raw_buffer_store_b128(tw[u], r, 16 * (htid + 256 * u), 0, XSC1);
                 if (l == 0 && p.dbg && htid == 0) {
                     p.dbg[(size_t)blockIdx.x * 32 + 27] = __builtin_readcyclecounter();
                     p.dbg[(size_t)blockIdx.x * 32 + 26] = (unsigned long long)xslot + 1;
@@ -807,6 +867,92 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
             }
         }
     };
+    // ---- PAIR: the two workgroups of an item hand each other their channel half of the last hidden layer's region (all R + 1 rows it
+    // holds: the output pair reads every one).  p.xh [B * nrb][half][G::PUNITS x 16 bytes], unit i = ((row W + col) 3 + plane) H8/2 + u;
+    // the same hand-over as the rows above: all-ones between launches, sc1 stores by the producer's helper waves, the consumer's take
+    // every unit without an all-ones dword and put the pattern back.
+    constexpr int PNL = PAIR ? (G::PUNITS + 255) / 256 : 1;
+    constexpr int LASTH = ((DEPTH - 1) & 1) ? G::HREG1 : G::HREG0;
+    auto pair_rsrc = [&](int hf) -> __amdgpu_buffer_rsrc_t {
+        const unsigned long long a = (unsigned long long)(p.xh + ((size_t)xslot * 2 + hf) * G::prow_bytes());
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, (int)G::prow_bytes(), 0x00020000);
+    };
+    auto pair_lds = [&](int i, int hf) -> int {                  // unit i of half hf inside the last hidden region (16-byte units)
+        const int sl = i / G::PUS, rem = i - sl * G::PUS;
+        const int pn = rem / (H8 / 2), u = rem - pn * (H8 / 2);
+        const int row = sl / W, col = sl - row * W;
+        return LASTH + (row * RS + col + 1) * H16 + pn * H8 + hf * (H8 / 2) + u;
+    };
+    auto pair_export = [&]() {
+        if constexpr (PAIR) {
+            const __amdgpu_buffer_rsrc_t r = pair_rsrc(half);
+            u32x4 t[PNL];
+#pragma unroll
+            for (int u = 0; u < PNL; ++u) {
+                const int i = htid + 256 * u;
+                t[u] = __builtin_bit_cast(u32x4, smem4[pair_lds(i < G::PUNITS ? i : G::PUNITS - 1, half)]);
+                // the pattern means "not there yet": a NaN pair that happens to carry it (all-ones payloads come in with the caller's
+                // data, e.g. uninitialised memory) leaves as the canonical NaN pair -- NaN either way (tf_train.py:283-285)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) t[u][d] = t[u][d] == XSENT ? 0x7fc07fc0u : t[u][d];
+            }
+#pragma unroll
+            for (int u = 0; u < PNL; ++u)
+                __builtin_amdgcn_raw_buffer_store_b128(t[u], r, 16 * (htid + 256 * u), 0, XSC1);       // (past the end: dropped)
+            if (p.dbg && htid == 0) p.dbg[(size_t)blockIdx.x * 32 + 27] = __builtin_readcyclecounter();
+        }
+    };
+    auto pair_import = [&]() {
+        if constexpr (PAIR) {
+            const __amdgpu_buffer_rsrc_t r = pair_rsrc(half ^ 1);
+            u32x4 t[PNL];
+            unsigned pad = 0;
+#pragma unroll
+            for (int u = 0; u < PNL; ++u)
+                if (htid + 256 * u >= G::PUNITS) pad |= 1u << u;
+            const int tmo = (p.xknob & 8u) ? (1 << 10) : (1 << 20);
+            int it = xdead ? tmo : 0;
+            if (p.dbg && htid == 0) p.dbg[(size_t)blockIdx.x * 32 + 18] = __builtin_readcyclecounter();
+            while (it < tmo) {
+                bool ok = true;
+#pragma unroll
+                for (int u = 0; u < PNL; ++u) t[u] = __builtin_amdgcn_raw_buffer_load_b128(r, 16 * (htid + 256 * u), 0, XSC1);
+#pragma unroll
+                for (int u = 0; u < PNL; ++u)
+                    ok = ok && (((pad >> u) & 1u) || (t[u][0] != XSENT && t[u][1] != XSENT && t[u][2] != XSENT && t[u][3] != XSENT));
+                if (__all(ok)) break;
+                __builtin_amdgcn_s_sleep(8);
+                ++it;
+            }
+            if (p.dbg && htid == 0) {
+                p.dbg[(size_t)blockIdx.x * 32 + 19] = __builtin_readcyclecounter();
+                p.dbg[(size_t)blockIdx.x * 32 + 25] = (unsigned long long)it + 1;
+                p.dbg[(size_t)blockIdx.x * 32 + 26] = (unsigned long long)(2 * xslot + half) + 1;
+            }
+            const bool taken = it < tmo;
+            if (!taken) {
+#pragma unroll
+                for (int u = 0; u < PNL; ++u) t[u] = u32x4{0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u};
+            }
+#pragma unroll
+            for (int u = 0; u < PNL; ++u) { const int i = htid + 256 * u; if (i < G::PUNITS) smem4[pair_lds(i, half ^ 1)] = __builtin_bit_cast(f32x4, t[u]); }
+            // the compute waves are waiting for exactly this: the barrier as soon as the LDS stores are done (s_barrier counts waves: it
+            // pairs with the compute waves' __syncthreads), the re-arming -- sc1 stores whose acknowledgement a __syncthreads in front of
+            // them would wait for: 1.5 k cycles of the compute waves' wait -- behind it
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (p.dbg && htid == 0) p.dbg[(size_t)blockIdx.x * 32 + 20] = __builtin_readcyclecounter();
+            if (taken) {
+#pragma unroll
+                for (int u = 0; u < PNL; ++u)
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{XSENT, XSENT, XSENT, XSENT}, r, 16 * (htid + 256 * u), 0, XSC1);
+            } else if (lane == 0 && !xdead) {
+                if (p.xerr) __hip_atomic_store(p.xerr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(p.xctl + 272, 1ull, __ATOMIC_RELAXED, XSCOPE);
+            }
+        }
+    };
     // The helper's whole life: one barrier for each of the compute waves' (same order, same count -- s_barrier counts waves),
     // its traffic in between.  Behind the barrier that ends layer l's epilogue it sends row 0 of that layer to the block above and
     // starts asking for the row below: the row is in LDS by the time the compute waves have multiplied the taps of their own rows
@@ -861,6 +1007,10 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
                 constexpr int LAST_REG = ((DEPTH - 1) & 1) ? G::HREG1 : G::HREG0;
                 xch_import(DEPTH - 1, LAST_REG);
                 __syncthreads();                                  // row R of the last hidden layer is there
+            }
+            if constexpr (PAIR) {
+                if (!((p.xknob & 8u) && b == 0 && rbk == 0 && half == 1)) pair_export();     // (test knob 8: one half is never handed over)
+                pair_import();                                    // (ends with the barrier: the partner's half of the last hidden layer is there)
             }
             __syncthreads();                                      // output pair in the exchange buffer
             // ---- the block's free-bits reductions, by the helper waves of the workgroup that arrives last (StepP::fin_*) ----
@@ -935,25 +1085,58 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
     int otile[NTWO];
 #pragma unroll
     for (int j = 0; j < NTWO; ++j) otile[j] = wave * NTWO + j;
+    // PAIR: the tiles of this workgroup's half of the last hidden layer: tiles half NHT/2 + (0 .. NHT/2 - 1), dealt out over the waves as a
+    // layer of NHT/2 tiles would be (rounds of 4 + one left-over tile shared per pixel tile)
+    constexpr int NHTP = NHT / 2, NFULLP = NHTP / NW, NTWP = NFULLP + 1;
+    int ptile[NTWP];
+    f32x4 wrp[PAIR ? UB : 1][NTWP][3];
+    if constexpr (PAIR) {
+#pragma unroll
+        for (int j = 0; j < NTWP; ++j)
+            ptile[j] = NHTP * half + ((j < NFULLP) ? ((j & 1) ? NW * (j + 1) - 1 - wave : wave + NW * j) : NW * NFULLP);
+    }
+    // PAIR's output pair: this workgroup's NZT tiles (m and s of its z channels) over four waves = two waves per tile, which take the K
+    // steps of a part alternately (PairPart); first the part over the input channels of the own half, then -- behind the import -- the rest.
+    // Own half 0: input pairs 0 .. NPO-1 are entirely its own; half 1: the last NPO pairs.
+    const int opar = wave & 1;
+    constexpr int NPO = (NH / 2) / 32, NPR = NPAIR_H - NPO;
+    const int opair_own = half ? NPAIR_H - NPO : 0, opair_rest = half ? 0 : NPO;
+    if constexpr (PAIR) otile[0] = NZT * half + (wave >> 1);
     f32x4 wr1[UB][NTWH][3];          // hidden layer l uses ring l & 1 (wr0 / wr1): the other one receives layer l + 1's first steps
     f32x4 wro[UO][NTWO][3];          // ring of the output pair
     const f32x4* wbo = (const f32x4*)p.wp3[DEPTH];
     auto preload_out = [&]() {
+        if constexpr (PAIR) {
+            static_for<2>([&](auto par_c) {
+                if (opar != decltype(par_c)::value) return;
+                static_for<RDO>([&](auto i) {
+                    ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWO * 3>{}, wro[decltype(i)::value], wbo, 2 * NZT,
+                              otile, PairPart<NPO, decltype(par_c)::value>{}, decltype(i)::value, ALL, opair_own);
+                });
+            });
+            return;
+        }
         static_for<RDO>([&](auto i) {
             ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWO * 3>{}, wro[decltype(i)::value], wbo, 2 * NZT,
-                      otile, PartO1{}, decltype(i)::value, ALL);
+                      otile, PartO1{}, decltype(i)::value, ALL, 0);
         });
     };
     // the weights of the phase after hidden layer l -- the next hidden layer's ring, or the output pair's -- start travelling
     // while layer l's epilogue runs
     auto preload_after = [&](auto l_c) {
         constexpr int l = decltype(l_c)::value;
-        if constexpr (l + 1 < DEPTH) {
+        if constexpr (PAIR && l + 1 < DEPTH) {
+            const f32x4* wbn = (const f32x4*)p.wp3[l + 1];
+            static_for<RDH>([&](auto i) {
+                ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWP * 3>{}, wrp[decltype(i)::value], wbn, NHT, ptile,
+                          PartHid{}, decltype(i)::value, ALL, 0);
+            });
+        } else if constexpr (l + 1 < DEPTH) {
             const f32x4* wbn = (const f32x4*)p.wp3[l + 1];
             static_for<RDH>([&](auto i) {
                 ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWH * 3>{},
                           ((l + 1) & 1) ? wr1[decltype(i)::value] : wr0[decltype(i)::value], wbn, NHT, htile, PartH1{}, decltype(i)::value,
-                          ALL);
+                          ALL, 0);
             });
         } else {
             preload_out();
@@ -965,10 +1148,10 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
         if (xg != GI) return;
         constexpr int EM0 = (NX == 0 || !XSPLIT) ? (1 << NPT0) - 1 : fused_extra_mask(NPT0, GN, GI);
         f32x4 acc0[NPT0][NTWH], bi0[NTWH];
-        load_bias(p.bias[0], bi0);
+        load_bias(std::integral_constant<int, NTWH>{}, htile, p.bias[0], bi0);
         conv_phase(std::integral_constant<int, RD0>{}, std::integral_constant<int, NPT0>{}, std::integral_constant<int, NTWH>{},
                    std::integral_constant<int, G::rows_h(0)>{}, std::integral_constant<int, EM0>{}, G::ZREG, Z16, Z8, wb0, NHT, htile,
-                   wr0, acc0, PartL0{}, g_c, SET);
+                   wr0, acc0, PartL0{}, g_c, SET, 0);
         IAF_FSTAMP(6);
         xch_next_epoch_a();
         if constexpr (!HELP) store_ctx();
@@ -978,11 +1161,43 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
         __syncthreads();                                         // (every wave runs exactly one of the GN instantiations)
         IAF_FSTAMP(11);
         hidden_epilogue(std::integral_constant<int, NPT0>{}, std::integral_constant<int, G::rows_h(0)>{},
-                        std::integral_constant<int, EM0>{}, std::integral_constant<int, 1>{}, acc0, bi0, G::HREG0, p.hsave[0], p.border[0]);
+                        std::integral_constant<int, EM0>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, NTWH>{}, htile, acc0, bi0,
+                        G::HREG0, p.hsave[0], p.border[0], PAIR != 0);
     });
     __syncthreads();
     IAF_FSTAMP(2);
-    static_for<DEPTH - 1>([&](auto lm_c) {
+    if constexpr (PAIR) {
+        constexpr int l = 1, IN_REG = G::HREG0, OUT_REG = G::HREG1;
+        {   // the staged context sat in the h_odd region: its zero columns again
+            constexpr int H1ROWS = G::rows_reg(1);
+            for (int i = tid; i < H1ROWS * 2 * H16; i += 256) {
+                const int rs = i / H16, u = i - rs * H16;
+                smem4[G::HREG1 + ((rs >> 1) * RS + (rs & 1) * (W + 1)) * H16 + u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        constexpr int NPTL = (G::rows_h(l) * W + 15) / 16;
+        const f32x4* wbl = (const f32x4*)p.wp3[l];
+        // every wave is a group of its own (the left-over tile's pixel tiles); the centre tap's dead blocks depend on the half
+        static_for<2 * NW>([&](auto g_c) {
+            constexpr int GI = decltype(g_c)::value % NW, HF = decltype(g_c)::value / NW;
+            if (wave != GI || half != HF) return;
+            constexpr int EML = fused_extra_mask(NPTL, NW, GI);
+            f32x4 accl[NPTL][NTWP], bil[NTWP];
+            load_bias(std::integral_constant<int, NTWP>{}, ptile, p.bias[l], bil);
+            conv_phase(std::integral_constant<int, RDH>{}, std::integral_constant<int, NPTL>{}, std::integral_constant<int, NTWP>{},
+                       std::integral_constant<int, G::rows_h(l)>{}, std::integral_constant<int, EML>{}, IN_REG, H16, H8, wbl, NHT, ptile,
+                       wrp, accl, PartHid{}, std::integral_constant<int, 100 * (1 + HF) + GI>{}, SET, 0);
+            IAF_FSTAMP(7);
+            load_final_operands();
+            preload_out();
+            hidden_epilogue(std::integral_constant<int, NPTL>{}, std::integral_constant<int, G::rows_h(l)>{},
+                            std::integral_constant<int, EML>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, NTWP>{}, ptile, accl,
+                            bil, OUT_REG, p.hsave[l], p.border[l], false);
+            IAF_FSTAMP(12);
+        });
+        __syncthreads();
+    }
+    static_for<PAIR ? 0 : DEPTH - 1>([&](auto lm_c) {
         constexpr int l = decltype(lm_c)::value + 1;              // hidden layer l reads h_{l-1}, writes h_l into the other region
         constexpr int IN_REG = ((l - 1) & 1) ? G::HREG1 : G::HREG0, OUT_REG = (l & 1) ? G::HREG1 : G::HREG0;
         if constexpr (l == 1) {   // the staged context sat in the h_odd region: its zero columns again, before the epilogue fills the rest
@@ -998,28 +1213,29 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
             if (xg != GI) return;
             constexpr int EML = (NX == 0 || !XSPLIT) ? (1 << NPTL) - 1 : fused_extra_mask(NPTL, GN, GI);
             f32x4 accl[NPTL][NTWH], bil[NTWH];
-            load_bias(p.bias[l], bil);
+            load_bias(std::integral_constant<int, NTWH>{}, htile, p.bias[l], bil);
                 const f32x4* wbl = (const f32x4*)p.wp3[l];
             conv_phase(std::integral_constant<int, RDH>{}, std::integral_constant<int, NPTL>{}, std::integral_constant<int, NTWH>{},
                        std::integral_constant<int, G::rows_h(l)>{}, std::integral_constant<int, EML>{}, IN_REG, H16, H8, wbl, NHT, htile,
-                       (l & 1) ? wr1 : wr0, accl, PartH1{}, g_c, SET);
+                       (l & 1) ? wr1 : wr0, accl, PartH1{}, g_c, SET, 0);
             if constexpr (XCH) {     // the row below arrives while the taps of the own rows were multiplied: its taps now
                 static_for<RDH>([&](auto i) {
                     ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWH * 3>{},
-                              (l & 1) ? wr1[decltype(i)::value] : wr0[decltype(i)::value], wbl, NHT, htile, PartBelow{}, decltype(i)::value, ALL);
+                              (l & 1) ? wr1[decltype(i)::value] : wr0[decltype(i)::value], wbl, NHT, htile, PartBelow{}, decltype(i)::value, ALL, 0);
                 });
                 if constexpr (l == 1) IAF_FSTAMP(28);
                 __syncthreads();                                  // the helper waves have put the row below into row R of IN_REG
                 if constexpr (l == 1) IAF_FSTAMP(15);
                 conv_phase(std::integral_constant<int, RDH>{}, std::integral_constant<int, NPTL>{}, std::integral_constant<int, NTWH>{},
                            std::integral_constant<int, G::rows_h(l)>{}, std::integral_constant<int, EML>{}, IN_REG, H16, H8, wbl, NHT, htile,
-                           (l & 1) ? wr1 : wr0, accl, PartBelow{}, g_c, ADD);
+                           (l & 1) ? wr1 : wr0, accl, PartBelow{}, g_c, ADD, 0);
             }
             if constexpr (l == 1) IAF_FSTAMP(7);
             if constexpr (l == DEPTH - 1) load_final_operands();
                 preload_after(std::integral_constant<int, l>{});
             hidden_epilogue(std::integral_constant<int, NPTL>{}, std::integral_constant<int, G::rows_h(l)>{},
-                            std::integral_constant<int, EML>{}, std::integral_constant<int, 0>{}, accl, bil, OUT_REG, p.hsave[l], p.border[l]);
+                            std::integral_constant<int, EML>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, NTWH>{}, htile, accl,
+                            bil, OUT_REG, p.hsave[l], p.border[l], false);
             if constexpr (l == 1) IAF_FSTAMP(12);
         });
         __syncthreads();
@@ -1030,23 +1246,53 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
     // (the operands of the final transform are fetched first: they travel while the output pair is multiplied)
     float* xbuf = (float*)(smem + (size_t)G::XB_OFF * 16);
     xch_next_epoch_b();
-    {
+    if constexpr (PAIR) {
+        f32x4 acco[NPTO][NTWO];
+        constexpr int LAST_REG = ((DEPTH - 1) & 1) ? G::HREG1 : G::HREG0;
+        static_for<2>([&](auto par_c) {
+            constexpr int PAR = decltype(par_c)::value;
+            if (opar != PAR) return;
+            // the input channels of the own half (they are in LDS: this workgroup's epilogue wrote them) ...
+            conv_phase(std::integral_constant<int, RDO>{}, std::integral_constant<int, NPTO>{}, std::integral_constant<int, NTWO>{},
+                       std::integral_constant<int, R>{}, std::integral_constant<int, (1 << NPTO) - 1>{}, LAST_REG,
+                       H16, H8, wbo, 2 * NZT, otile, wro, acco, PairPart<NPO, PAR>{}, std::integral_constant<int, 0>{}, SET, opair_own);
+            static_for<RDO>([&](auto i) {
+                ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWO * 3>{}, wro[decltype(i)::value], wbo, 2 * NZT,
+                          otile, PairPart<NPR, PAR>{}, decltype(i)::value, ALL, opair_rest);
+            });
+            IAF_FSTAMP(29);
+            __syncthreads();                                      // ... then the partner's, which its helper waves sent and ours put into LDS
+            IAF_FSTAMP(21);
+            conv_phase(std::integral_constant<int, RDO>{}, std::integral_constant<int, NPTO>{}, std::integral_constant<int, NTWO>{},
+                       std::integral_constant<int, R>{}, std::integral_constant<int, (1 << NPTO) - 1>{}, LAST_REG,
+                       H16, H8, wbo, 2 * NZT, otile, wro, acco, PairPart<NPR, PAR>{}, std::integral_constant<int, 0>{}, ADD, opair_rest);
+        });
+        IAF_FSTAMP(4);
+        float* mine = xbuf + opar * (R * W * G::XB_STRIDE);       // the two waves of a tile leave their K parts side by side
+#pragma unroll
+        for (int q = 0; q < NPTO; ++q) {
+            const int pix = q * 16 + pl;
+            if (pix >= R * W) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mine[pix * G::XB_STRIDE + otile[0] * 16 + 4 * kk + r] = acco[q][0][r];
+        }
+    } else {
         f32x4 acco[NPTO][NTWO];
         constexpr int LAST_REG = ((DEPTH - 1) & 1) ? G::HREG1 : G::HREG0;
         conv_phase(std::integral_constant<int, RDO>{}, std::integral_constant<int, NPTO>{}, std::integral_constant<int, NTWO>{},
                    std::integral_constant<int, R>{}, std::integral_constant<int, (1 << NPTO) - 1>{}, LAST_REG,
-                   H16, H8, wbo, 2 * NZT, otile, wro, acco, PartO1{}, std::integral_constant<int, 0>{}, SET);
+                   H16, H8, wbo, 2 * NZT, otile, wro, acco, PartO1{}, std::integral_constant<int, 0>{}, SET, 0);
         if constexpr (XCH) {
             static_for<RDO>([&](auto i) {
                 ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWO * 3>{}, wro[decltype(i)::value], wbo, 2 * NZT,
-                          otile, PartBelow{}, decltype(i)::value, ALL);
+                          otile, PartBelow{}, decltype(i)::value, ALL, 0);
             });
             IAF_FSTAMP(29);
             __syncthreads();                                      // ... and the row below of the last hidden layer
             IAF_FSTAMP(21);
             conv_phase(std::integral_constant<int, RDO>{}, std::integral_constant<int, NPTO>{}, std::integral_constant<int, NTWO>{},
                        std::integral_constant<int, R>{}, std::integral_constant<int, (1 << NPTO) - 1>{}, LAST_REG,
-                       H16, H8, wbo, 2 * NZT, otile, wro, acco, PartBelow{}, std::integral_constant<int, 0>{}, ADD);
+                       H16, H8, wbo, 2 * NZT, otile, wro, acco, PartBelow{}, std::integral_constant<int, 0>{}, ADD, 0);
         }
         IAF_FSTAMP(4);
         float* mine = xbuf;
@@ -1067,11 +1313,12 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
     float klv[NEL];              // (0 for rows past the image bottom and surplus lanes)
 #pragma unroll
     for (int e = 0; e < NEL; ++e) klv[e] = 0.f;
+    const int fcb = PAIR ? half * NZF : 0;
 #pragma unroll
     for (int e = 0; e < NEL; ++e) {
         const int idx = tid + e * 256;
-        if (idx >= NZ * R * W) continue;
-        const int c = idx / (R * W), pix = idx - c * (R * W);
+        if (idx >= NZF * R * W) continue;
+        const int c = fcb + idx / (R * W), pix = idx % (R * W);
         const int row = pix / W;
         if (r0 + row >= H) continue;
         const unsigned gi = 4u * (unsigned)(c * HW + gpix(r0 + row, pix - row * W));     // byte offset inside image b
@@ -1087,6 +1334,10 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
         }
         m_raw += xbuf[pix * G::XB_STRIDE + cm];
         s_raw += xbuf[pix * G::XB_STRIDE + cm + 16];
+        if constexpr (PAIR) {                                    // (the other K part)
+            m_raw += xbuf[(R * W + pix) * G::XB_STRIDE + cm];
+            s_raw += xbuf[(R * W + pix) * G::XB_STRIDE + cm + 16];
+        }
         if (p.mode == MODE_RAW) {
             stf(p.out0 + img_z, gi, m_raw);
             stf(p.out1 + img_z, gi, s_raw);
@@ -1128,8 +1379,8 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
 #pragma unroll
             for (int o = RW / 2; o > 0; o >>= 1) a += __shfl_xor(a, o);
             const int idx = tid + e * 256;
-            if (idx < NZ * RW && (idx & (RW - 1)) == 0) {
-                float* q = p.kl_part + ((size_t)b * p.nrb + rbk) * NZ + idx / RW;
+            if (idx < NZF * RW && (idx & (RW - 1)) == 0) {
+                float* q = p.kl_part + ((size_t)b * p.nrb + rbk) * NZ + fcb + idx / RW;
                 if (HELP && p.fin_ctl) __hip_atomic_store(q, a, __ATOMIC_RELAXED, XSCOPE);       // (read by another workgroup, below)
                 else *q = a;
             }

@@ -55,6 +55,23 @@ static step_fn_t inst_h(int var, size_t* lds) {
     }
 }
 
+// the pair form (iaf_step_fused.hpp, PAIR): two workgroups per (image, row block), each half of the last hidden layer and of the output pair
+template <int NHT, int NZT, int DEPTH, int W, int R>
+static step_fn_t inst_p(int var, size_t* lds, size_t* prow) {
+    typedef StepGeom<NHT, NZT, DEPTH, W, R, 0, 1> G;
+    static_assert((G::CSTR & 15) == 4 || (G::CSTR & 15) == 12, "context rows: 4 channel groups x 16 pixels must hit 64 distinct banks");
+    static_assert(G::lds_bytes() <= 160 * 1024 && G::ctx_bytes() <= (size_t)(G::END - G::HREG1) * 16 && G::xb_bytes() <= (size_t)G::HREG1 * 16,
+                  "the pair form's regions");
+    *lds = G::lds_bytes();
+    *prow = G::prow_bytes();
+    switch (var) {
+        case 0: return iaf_step_fused_kernel<NHT, NZT, DEPTH, W, R, 0, 0, 1, 1>;
+        case 1: return iaf_step_fused_kernel<NHT, NZT, DEPTH, W, R, 1, 0, 1, 1>;
+        case 2: return iaf_step_fused_kernel<NHT, NZT, DEPTH, W, R, 2, 0, 1, 1>;
+    }
+    return nullptr;
+}
+
 template <int NHT, int NZT, int DEPTH>
 static step_fn_t inst_wr(int W, int R, int var, size_t* lds) {
     if (W == 16 && R == 2) return inst<NHT, NZT, DEPTH, 16, 2>(var, lds, nullptr);
@@ -121,6 +138,15 @@ extern "C" step_fn_t iaf_pick_step_fused_b(int nht, int nzt, int depth, int W, i
     if (nht == 4 && nzt == 4 && depth == 4) return inst_wr<4, 4, 4>(W, R, var, lds);
     if (nht == 8 && nzt == 4 && depth == 4) return inst_wr<8, 4, 4>(W, R, var, lds);
     if (nht == 12 && nzt == 4 && depth == 4) return inst_wr<12, 4, 4>(W, R, var, lds);
+    return nullptr;
+}
+#endif
+
+#if !defined(IAF_FUSED_PART) || IAF_FUSED_PART == 3
+// the pair form: the BASELINE run's 8-pixel geometry (R = 2: the pair's 16 pixels)
+extern "C" step_fn_t iaf_pick_step_fused_pair(int nht, int nzt, int depth, int W, int R, int var, size_t* lds, size_t* prow) {
+    *lds = 0; *prow = 0;
+    if (nht == 10 && nzt == 2 && depth == 2 && W == 8 && R == 2) return inst_p<10, 2, 2, 8, 2>(var, lds, prow);
     return nullptr;
 }
 #endif

@@ -38,6 +38,7 @@ struct StepP {
     float fin_kl_min;
     // XCH kernels (halo rows exchanged between the row blocks of an image instead of recomputed; iaf_step_fused.hpp "XCH"):
     char* xh;                      // rows [layer][B * nrb][xrow bytes]; every 8-byte piece = 0xff..ff between launches (the data is the flag)
+                                   // (PAIR kernels: [B * nrb][half][prow bytes], the halves of the last hidden region the partners swap)
     unsigned long long* xctl;      // [32 y] head of work list y (tickets taken), [32 y + 16] its arrivals, [256] lists complete,
                                    // [272] sticky error -- a 128-byte line each (512 words in all); zero between launches
     unsigned* xerr;                // host-visible error word (mapped pinned memory), or NULL
@@ -56,6 +57,8 @@ extern "C" step_fn_t iaf_pick_step_fused_xch_b(int nht, int nzt, int depth, int 
 extern "C" step_fn_t iaf_pick_step_fused_h(int nht, int nzt, int depth, int W, int R, int var, size_t* lds);   // recomputing form with helper waves
 extern "C" step_fn_t iaf_pick_step_fused_c(int nht, int nzt, int depth, int W, int R, int var, size_t* lds);   // depth_ar = 3 geometries
 extern "C" step_fn_t iaf_pick_step_fused_xch_c(int nht, int nzt, int depth, int W, int R, int var, size_t* lds, size_t* xrow);
+// the pair form (two workgroups per (image, row block), *prow = bytes one of them hands the other); R = rows per PAIR
+extern "C" step_fn_t iaf_pick_step_fused_pair(int nht, int nzt, int depth, int W, int R, int var, size_t* lds, size_t* prow);
 static inline step_fn_t iaf_pick_step_fused(int nht, int nzt, int depth, int W, int R, int var, size_t* lds) {
     step_fn_t f = iaf_pick_step_fused_a(nht, nzt, depth, W, R, var, lds);
     if (!f) f = iaf_pick_step_fused_b(nht, nzt, depth, W, R, var, lds);

@@ -273,7 +273,7 @@ class ARStack(object):
         R = self.step_is_fused(B, H, W)
         if R:
             nrb = -(-H // R)
-            if self.step_exchanges(B, H, W) or (W == 8 and self.n_h == 160 and self.n_z == 32 and self.depth_ar == 2):     # kernels with helper waves
+            if self.step_exchanges(B, H, W) or self.step_pairs(B, H, W) or (W == 8 and self.n_h == 160 and self.n_z == 32 and self.depth_ar == 2):     # kernels with helper waves
                 if B * nrb * self.n_z <= 16384 and B * self.n_z <= 8192:
                     return "1 launch: the one-launch IAF step, whose last workgroup also does the block's free-bits reductions"
             return ("1 one-launch IAF step (its final loop leaves per-row-block KL sums) + %d KL reduction launch(es)"
@@ -303,6 +303,11 @@ class ARStack(object):
     def step_exchanges(self, B, H, W):
         """True if the one-launch step at this size hands halo rows between its row blocks instead of recomputing them"""
         return bool(_capi.lib().iaf_stack_step_exchanges(self._h, int(B), int(H), int(W)))
+
+    def step_pairs(self, B, H, W):
+        """True if the one-launch step at this size runs in the pair form (8-pixel rows: two workgroups per two image rows, each half of
+        the last hidden layer's channels and of the output pair; include/iaf_hip.h)"""
+        return bool(_capi.lib().iaf_stack_step_pairs(self._h, int(B), int(H), int(W)))
 
     def step_is_fused(self, B, H, W):
         """rows per workgroup of the one-launch step at this size, 0 if the step runs layer by layer"""

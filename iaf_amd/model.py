@@ -86,10 +86,8 @@ class CVAE1(object):
         params: the V of every conv (g / b entries are ignored), h_top, dec_log_stdv; noise as in forward() (the priors' draws are used).
         Returns (x_out, params_out) with params_out = params + every g and b; the model is left loaded with params_out."""
         lib, hs, zs = _capi.lib(), self.h_size, self.z_size
-        B, _, S, _ = (int(v) for v in x.shape)
-        if x.dtype != torch.uint8 or S != self.image_size or len(noise) != 2 * self.depth * self.num_blocks:
-            raise ValueError("x: uint8 [B,3,%d,%d]; noise: %d tensors" % (self.image_size, self.image_size, 2 * self.depth * self.num_blocks))
-        n, dev, st = B * self.k, x.device, _stream
+        B, S, n = self._check_inputs(x, noise, None)
+        dev, st = x.device, _stream
         f32 = dict(dtype=torch.float32, device=dev)
         out = {k: v for k, v in params.items() if not (k.endswith("/g") or k.endswith("/b"))}
 
@@ -188,36 +186,64 @@ class CVAE1(object):
 
     def iw_eval(self, x, noise_passes):
         """The k-sample importance-weighted bound of the whole model without materialising k samples at once (tf_train.py:168-170,218 with
-        hps.k = len(noise_passes); BASELINE config 5 evaluates k = 10^4): one forward with k = 1 per pass, the per-image terms log_pxz and
-        sum-of-KL streamed into the running log-sum-exp (StreamingLowerBound).  noise_passes: one noise list (as for forward) per sample.
+        hps.k = len(noise_passes); BASELINE config 5 evaluates k = 10^4): one top-down pass with k = 1 per sample, the per-image terms
+        log_pxz and sum-of-KL streamed into the running log-sum-exp (StreamingLowerBound).  The bottom-up pass -- image scaling, x_enc,
+        every layer's up_conv1 / up_conv3 (tf_train.py:183-187) -- depends on x only: it runs ONCE and its products (qz_mean, qz_logsd,
+        up_context of every layer, tf_train.py:38) are kept across the k passes.  noise_passes: one noise list (as for forward) per sample.
         Returns the loss [1] = sum over images of -log (1/k) sum_s exp(log_pxz_s - kl_s); bits_per_dim(loss, B) as usual."""
         if self.k != 1:
             raise ValueError("iw_eval streams the samples: build the model with k = 1")
         B = int(x.shape[0])
         acc = StreamingLowerBound(B, x.device)
+        xf = None
         for noise in noise_passes:
-            log_pxz, kl_cost = self.forward(x, noise, _terms=True)
+            if xf is None:
+                xf = self._bottom_up(x, noise)
+            log_pxz, kl_cost = self._top_down(xf, B, noise, terms=True)
             acc.update(log_pxz.reshape(B, 1), kl_cost.reshape(B, 1))
         lb = acc.result()
         loss = torch.empty(1, dtype=torch.float32, device=x.device)
         _capi.check(_capi.lib().iaf_sum_axpy(_ptr(lb), None, 0.0, _ptr(loss), B, _stream()))
         return loss
 
+    def _check_inputs(self, x, noise, k):
+        """what forward(), forward_backward() and init_pass() require of (x, noise): the kernels behind them take raw pointers"""
+        if self.params is None and k is not None:
+            raise RuntimeError("CVAE1.load(params) first")
+        if not torch.is_tensor(x) or x.dtype != torch.uint8 or not x.is_cuda or not x.is_contiguous() or x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError("x must be a contiguous uint8 [B,3,S,S] device tensor")
+        B, _, S, S2 = (int(v) for v in x.shape)
+        if S != self.image_size or S2 != S:
+            raise ValueError("image size %r, model built for %d" % (tuple(x.shape), self.image_size))
+        if len(noise) != 2 * self.depth * self.num_blocks:
+            raise ValueError("noise: %d tensors expected (prior, posterior per layer, top-down)" % (2 * self.depth * self.num_blocks))
+        n = B * (self.k if k is None else k)
+        li = 0
+        for i in reversed(range(self.depth)):
+            for _ in range(self.num_blocks):
+                Sl = S // 2 ** (i + 1)
+                for e in noise[2 * li:2 * li + 2]:
+                    if e is None:
+                        continue
+                    if (not torch.is_tensor(e) or e.dtype != torch.float32 or not e.is_cuda or not e.is_contiguous()
+                            or tuple(e.shape) != (n, self.z_size, Sl, Sl)):
+                        raise ValueError("noise[%d..%d]: contiguous fp32 device tensors [%d,%d,%d,%d] (batch x k rows)"
+                                         % (2 * li, 2 * li + 1, n, self.z_size, Sl, Sl))
+                li += 1
+        return B, S, n
+
     def forward(self, x, noise, _terms=False):
         """x: uint8 [B,3,S,S] on the device.  noise: per layer in top-down order the pair (eps_prior, eps_post) the reference's two
         DiagonalGaussians draw (distributions.py:15-24), flattened into one list -- eps_post is used in mode "train", eps_prior in
         "init" / "sample".  Returns (x_out [B k,3,S,S], obj [1], loss [1]) as tf_train.py:218."""
-        if self.params is None:
-            raise RuntimeError("CVAE1.load(params) first")
-        if x.dtype != torch.uint8 or not x.is_cuda or not x.is_contiguous() or x.dim() != 4 or x.shape[1] != 3:
-            raise ValueError("x must be a contiguous uint8 [B,3,S,S] device tensor")
+        xf = self._bottom_up(x, noise)
+        return self._top_down(xf, int(x.shape[0]), noise, terms=_terms)
+
+    def _bottom_up(self, x, noise):
+        """tf_train.py:153-187: image scaling (+ repeat k), x_enc, the up pass of every layer (which leaves qz_mean, qz_logsd, up_context in
+        the layers, :38).  Returns the scaled image the likelihood compares with."""
+        B, S, n = self._check_inputs(x, noise, self.k)
         lib, p, hs, k = _capi.lib(), self.params, self.h_size, self.k
-        B, _, S, _ = (int(v) for v in x.shape)
-        if S != self.image_size or x.shape[3] != S:
-            raise ValueError("image size %r, model built for %d" % (tuple(x.shape), self.image_size))
-        n = B * k
-        if len(noise) != 2 * self.depth * self.num_blocks:
-            raise ValueError("noise: %d tensors expected (prior, posterior per layer, top-down)" % (2 * self.depth * self.num_blocks))
         dev = x.device
         xf = torch.empty((n, 3, S, S), dtype=torch.float32, device=dev)
         _capi.check(lib.iaf_image_to_float(x.data_ptr(), _ptr(xf), B, 3 * S * S, k, _stream()))           # tf_train.py:153-159
@@ -227,6 +253,12 @@ class CVAE1(object):
         for level in self.layers:                                                                          # :184-187
             for layer in level:
                 h = layer.up(h)
+        return xf
+
+    def _top_down(self, xf, B, noise, terms=False):
+        """tf_train.py:189-218 on the state _bottom_up left: h_top, the down pass, x_dec, the likelihood, obj and loss"""
+        lib, p, hs, k = _capi.lib(), self.params, self.h_size, self.k
+        n, S, dev = int(xf.shape[0]), int(xf.shape[2]), xf.device
         St = S // 2 ** self.depth
         h = torch.empty((n, hs, St, St), dtype=torch.float32, device=dev)
         _capi.check(lib.iaf_tile_channels(_ptr(p["h_top"]), _ptr(h), n, hs, St * St, _stream()))           # :189-192
@@ -249,7 +281,7 @@ class CVAE1(object):
         _capi.check(lib.iaf_deconvk_forward(_ptr(h), _ptr(self._w_dec), _ptr(p["x_dec/b"]), _ptr(x_out), n, hs, S // 2, S // 2, 3, 5, 5,
                                             2, 1, -0.5 + 1 / 512., 0.5 - 1 / 512., _stream()))             # :206-208
         log_pxz = discretized_logistic(x_out, p["dec_log_stdv"], sample=xf)                                # :210
-        if _terms:
+        if terms:
             return log_pxz, kl_cost
         obj = torch.empty(1, dtype=torch.float32, device=dev)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
@@ -264,42 +296,97 @@ class CVAE1(object):
         for level in self.layers:
             for layer in level:
                 layer.set_training(on)
-        old = getattr(self, "_wn", None)
-        if old is not None:                                          # back to per-op weight-norm backward for anyone using the layers directly
+        for sg in (getattr(self, "_segs", None) or []):              # back to per-op weight-norm backward for anyone using the layers directly
             lib = _capi.lib()
-            for st in old.stacks:
+            for st in sg["wn"].stacks:
                 _capi.check(lib.iaf_stack_set_defer_weightnorm(st._h, 0))
-            for cv in old.convs:
+            for cv in sg["wn"].convs:
                 _capi.check(lib.iaf_conv3x3_set_defer_weightnorm(cv._h, 0))
         self._training = bool(on)
         self.params = None
-        self._wn = None
         self._prep = None
-        if on:
-            # mask + weight-norm backward of all stacks and plain convs in ONE launch per kind at the end of the backward (a conv's own pass
-            # is 10-28 workgroups on a 256-CU chip); a downsampling layer's deconv differentiates its own norm inside its backward
-            self._wn_order = [(i, j) for i in range(self.depth) for j in range(self.num_blocks)]
-            self._wn_convs = [(ij, nm) for ij in self._wn_order
-                              for nm in ("up_conv1", "up_conv3", "down_conv1") + (() if self.layers[ij[0]][ij[1]].downsample else ("down_conv2",))]
-            self._wn = WnBwdBatch(stacks=[self.layers[i][j].posterior.stack for i, j in self._wn_order],
-                                  convs=[getattr(self.layers[ij[0]][ij[1]], nm) for ij, nm in self._wn_convs])
+        # mask + weight-norm backward of the stacks and plain convs of a gradient bucket in ONE launch per kind at the end of the bucket's
+        # backward segment (a conv's own pass is 10-28 workgroups on a 256-CU chip; set_grad_buckets, default: one bucket = the whole model);
+        # a downsampling layer's deconv differentiates its own norm inside its backward
+        self._segs = None
 
-    def forward_backward(self, x, noise, grads=None, autotune=False):
-        """One tower's forward and backward in mode "train", k = 1: returns (x_out, obj [1], grads) with grads[name] = d obj / d params[name]
-        for every variable (written into the tensors of `grads` where it has them -- e.g. the views of parallel.FlatParams.g).
-        autotune=True: the first call at a new batch size searches the launch shapes of the plain convs and their data gradients (what
-        cuDNN's algorithm search does for the reference).  The layer stack's backward is IAFLayer.down_backward / .up_backward chained through the model (the down pass
-        in up-pass order, then the up pass in reverse); the two ends -- likelihood, clip, x_dec, h_top, x_enc -- are the launches of
-        csrc/iaf_model_edge.hpp.  noise as in forward()."""
+    # The gradient exchange of data-parallel training (tf_train.py:124-147, tf_utils/common.py:83-86) overlaps the backward when the
+    # flat gradient buffer is laid out in the order the backward COMPLETES the gradients and cut into contiguous buckets
+    # (parallel.OverlappedGradReduce).  That order, for this model: the top end (dec_log_stdv, x_dec), then the top-down pass backwards
+    # = layer by layer in up-pass order (each layer's last conv, its ar_multiconv2d stack, down_conv1), h_top, then the bottom-up pass
+    # backwards (up_conv3, up_conv1 of every layer in reverse), x_enc.
+    _DOWN_KEYS = ("down_conv2/", "down_deconv2/", "ar_multiconv2d/", "down_conv1/")
+
+    def _layer_names(self, ij, down):
+        pre = "IAF_%d_%d/" % ij
+        src = self.params if self.params is not None else {}
+        ks = [k for k in src if k.startswith(pre) and (k[len(pre):].startswith(self._DOWN_KEYS) == down)]
+        return ks
+
+    def completion_order(self):
+        """every variable name in the order forward_backward completes its gradient (lay parallel.FlatParams out in this order)"""
+        if self.params is None:
+            raise RuntimeError("CVAE1.load(params) first")
+        order = [(i, j) for i in range(self.depth) for j in range(self.num_blocks)]
+        names = ["dec_log_stdv", "x_dec/V", "x_dec/g", "x_dec/b"]
+        for ij in order:
+            names += self._layer_names(ij, True)
+        names.append("h_top")
+        for ij in reversed(order):
+            names += self._layer_names(ij, False)
+        names += ["x_enc/V", "x_enc/g", "x_enc/b"]
+        assert sorted(names) == sorted(self.params), "completion_order must list every variable exactly once"
+        return names
+
+    def set_grad_buckets(self, n_buckets=1):
+        """Cut the backward into `n_buckets` segments, each completing one contiguous run of completion_order(): ceil(n/2) groups of layers
+        for the top-down pass's backward, floor(n/2) for the bottom-up pass's; every segment ends with the deferred mask + weight-norm
+        backward of exactly its own convs (one launch per kind).  Returns the variable names per bucket (for
+        OverlappedGradReduce.bounds_from_groups).  forward_backward(on_bucket=) then reports each bucket the moment it is complete."""
+        if not getattr(self, "_training", False) or self.params is None:
+            raise RuntimeError("CVAE1.set_training(True), then load(params), before set_grad_buckets")
+        order = [(i, j) for i in range(self.depth) for j in range(self.num_blocks)]
+        nb = max(1, min(int(n_buckets), 2 * len(order)))
+        chunks = lambda lst, n: [lst[q * len(lst) // n:(q + 1) * len(lst) // n] for q in range(n)]
+        dgroups = chunks(order, (nb + 1) // 2) if nb >= 2 else [order]
+        ugroups = chunks(list(reversed(order)), nb // 2) if nb >= 2 else []
+        L = lambda ij: self.layers[ij[0]][ij[1]]
+        dconvs = lambda ij: [(ij, "down_conv1")] + ([] if L(ij).downsample else [(ij, "down_conv2")])
+        uconvs = lambda ij: [(ij, "up_conv3"), (ij, "up_conv1")]
+        segs = []
+        for gi, g in enumerate(dgroups):
+            convs = [c for ij in g for c in dconvs(ij)]
+            up_too = nb < 2                                          # a single bucket: everything completes at the very end
+            if up_too:
+                convs += [c for ij in reversed(order) for c in uconvs(ij)]
+            names = (["dec_log_stdv", "x_dec/V", "x_dec/g", "x_dec/b"] if gi == 0 else []) + [k for ij in g for k in self._layer_names(ij, True)]
+            if up_too:
+                names += ["h_top"] + [k for ij in reversed(order) for k in self._layer_names(ij, False)] + ["x_enc/V", "x_enc/g", "x_enc/b"]
+            segs.append(dict(down=g, up=list(reversed(order)) if up_too else [], h_top=up_too, x_enc=up_too, names=names, conv_ids=convs,
+                             stack_ids=list(g),
+                             wn=WnBwdBatch(stacks=[L(ij).posterior.stack for ij in g], convs=[getattr(L(ij), nm) for ij, nm in convs])))
+        for gi, g in enumerate(ugroups):
+            convs = [c for ij in g for c in uconvs(ij)]
+            last = gi == len(ugroups) - 1
+            names = (["h_top"] if gi == 0 else []) + [k for ij in g for k in self._layer_names(ij, False)] + \
+                    (["x_enc/V", "x_enc/g", "x_enc/b"] if last else [])
+            segs.append(dict(down=[], up=g, h_top=(gi == 0), x_enc=last, names=names, conv_ids=convs, stack_ids=[],
+                             wn=WnBwdBatch(stacks=[], convs=[getattr(L(ij), nm) for ij, nm in convs])))
+        self._segs = segs
+        return [sg["names"] for sg in segs]
+
+    def fb_begin(self, x, noise, grads=None, autotune=False):
+        """forward_backward, first part: the forward pass (keeping what the backward reads) and the backward of the top end --
+        obj = sum(kl_obj - log_pxz), likelihood, clip, x_dec (tf_train.py:206-211).  Then fb_segment(0 .. n_buckets-1)."""
         if not getattr(self, "_training", False) or self.params is None:
             raise RuntimeError("CVAE1.set_training(True), then load(params), before forward_backward")
         if self.k != 1 or self.mode != "train":
             raise ValueError("forward_backward: mode 'train', k = 1 (the training objective, tf_train.py:211)")
+        if getattr(self, "_segs", None) is None:
+            self.set_grad_buckets(1)
+        B, S, n = self._check_inputs(x, noise, 1)
         lib, p, hs = _capi.lib(), self.params, self.h_size
-        B, _, S, _ = (int(v) for v in x.shape)
-        if x.dtype != torch.uint8 or S != self.image_size or len(noise) != 2 * self.depth * self.num_blocks:
-            raise ValueError("x: uint8 [B,3,%d,%d]; noise: %d tensors" % (self.image_size, self.image_size, 2 * self.depth * self.num_blocks))
-        n, dev, st = B, x.device, _stream
+        dev, st = x.device, _stream
         f32 = dict(dtype=torch.float32, device=dev)
         # ---- forward, keeping what the backward reads
         xf = torch.empty((n, 3, S, S), **f32)
@@ -351,35 +438,61 @@ class CVAE1(object):
         _capi.check(lib.iaf_convk_forward(_ptr(d_xout), _ptr(self._w_dec), _ptr(zero_b), _ptr(t), n, 3, S, S, hs, 5, 5, 2, 0, st()))
         d = torch.empty_like(h_last)
         _capi.check(lib.iaf_mul_elu_grad(_ptr(t), _ptr(h_last), _ptr(d), t.numel(), st()))
-        # ---- the layer stack: the top-down pass backwards (= in up-pass order), then the bottom-up pass backwards
-        dko = torch.ones(n, **f32)                                   # d obj / d kl_obj of every layer
         lgrads = {}
         for i, level in enumerate(self.layers):
             for j, layer in enumerate(level):
                 pre = "IAF_%d_%d/" % (i, j)
                 lgrads[(i, j)] = {k[len(pre):]: v for k, v in grads.items() if k.startswith(pre)}
-                d = layer.down_backward(d, dko, self._lparams[(i, j)], lgrads[(i, j)], autotune=autotune)
-        _capi.check(lib.iaf_channel_sum(_ptr(d), _ptr(gs("h_top")), n, hs, St * St, st()))                 # adjoint of the tile (:190-192)
-        d = torch.zeros((n, hs, St, St), **f32)                      # the up pass's last output is not used (h_top replaces it)
-        for i in reversed(range(self.depth)):
-            for j in reversed(range(self.num_blocks)):
-                d = self.layers[i][j].up_backward(d, self._lparams[(i, j)], lgrads[(i, j)], autotune=autotune)
+        self._fb = dict(x_out=x_out, obj=obj, grads=grads, lgrads=lgrads, d=d, xf=xf, n=n, S=S, St=St, autotune=autotune,
+                        dko=torch.ones(n, **f32), keep=(dW, scratch, zero_b, t, d_xout, dls_rows, logscale, log_pxz, kl_obj, objs))
+        return self._fb
+
+    def fb_segment(self, si):
+        """forward_backward, segment si (in order, after fb_begin): the backward of its layers and the deferred mask + weight-norm backward
+        of its convs -- on return every gradient of bucket si is complete (enqueued on the current stream)."""
+        lib, p, hs, F, sg = _capi.lib(), self.params, self.h_size, self._fb, self._segs[si]
+        grads, lgrads, n, S, St, autotune, st = F["grads"], F["lgrads"], F["n"], F["S"], F["St"], F["autotune"], _stream
+        gs = lambda nm: grads.setdefault(nm, torch.empty_like(p[nm]))
+        # ---- the layer stack: the top-down pass backwards (= in up-pass order), then the bottom-up pass backwards
+        for (i, j) in sg["down"]:
+            F["d"] = self.layers[i][j].down_backward(F["d"], F["dko"], self._lparams[(i, j)], lgrads[(i, j)], autotune=autotune)
+        if sg["h_top"]:
+            _capi.check(lib.iaf_channel_sum(_ptr(F["d"]), _ptr(gs("h_top")), n, hs, St * St, st()))        # adjoint of the tile (:190-192)
+            F["d"] = torch.zeros((n, hs, St, St), dtype=torch.float32, device=F["d"].device)   # the up pass's last output is not used (h_top replaces it)
+        for (i, j) in sg["up"]:
+            F["d"] = self.layers[i][j].up_backward(F["d"], self._lparams[(i, j)], lgrads[(i, j)], autotune=autotune)
         tup = lambda dct, nm: (dct[nm + "/V"], dct[nm + "/g"], dct[nm + "/b"])
-        self._wn.run(stack_params=[IAFLayer.stack_params(self._lparams[ij]) for ij in self._wn_order],
-                     stack_grads=[IAFLayer.stack_params(lgrads[ij]) for ij in self._wn_order],
-                     conv_params=[tup(self._lparams[ij], nm) for ij, nm in self._wn_convs],
-                     conv_grads=[tup(lgrads[ij], nm) for ij, nm in self._wn_convs])
-        for (i, j), lg in lgrads.items():
-            for k, v in lg.items():
+        sg["wn"].run(stack_params=[IAFLayer.stack_params(self._lparams[ij]) for ij in sg["stack_ids"]],
+                     stack_grads=[IAFLayer.stack_params(lgrads[ij]) for ij in sg["stack_ids"]],
+                     conv_params=[tup(self._lparams[ij], nm) for ij, nm in sg["conv_ids"]],
+                     conv_grads=[tup(lgrads[ij], nm) for ij, nm in sg["conv_ids"]])
+        for (i, j) in set(sg["down"]) | set(sg["up"]):
+            for k, v in lgrads[(i, j)].items():
                 grads["IAF_%d_%d/%s" % (i, j, k)] = v
-        # ---- x_enc (:183)
-        dW = torch.empty_like(p["x_enc/V"])
-        _capi.check(lib.iaf_convk_wgrad(_ptr(xf), _ptr(d), _ptr(dW), n, 3, S, S, hs, 5, 5, 2, 0, 0, st()))
-        gs("x_enc/V"), gs("x_enc/g"), gs("x_enc/b")
-        _capi.check(lib.iaf_convk_weightnorm_backward(_ptr(p["x_enc/V"]), _ptr(p["x_enc/g"]), _ptr(dW), _ptr(grads["x_enc/V"]),
-                                                      _ptr(grads["x_enc/g"]), None, 5, 5, 3, hs, 0, st()))
-        _capi.check(lib.iaf_channel_sum(_ptr(d), _ptr(grads["x_enc/b"]), n, hs, (S // 2) ** 2, st()))
-        return x_out, obj, grads
+        if sg["x_enc"]:                                                                                    # :183
+            d = F["d"]
+            dW = torch.empty_like(p["x_enc/V"])
+            _capi.check(lib.iaf_convk_wgrad(_ptr(F["xf"]), _ptr(d), _ptr(dW), n, 3, S, S, hs, 5, 5, 2, 0, 0, st()))
+            gs("x_enc/V"), gs("x_enc/g"), gs("x_enc/b")
+            _capi.check(lib.iaf_convk_weightnorm_backward(_ptr(p["x_enc/V"]), _ptr(p["x_enc/g"]), _ptr(dW), _ptr(grads["x_enc/V"]),
+                                                          _ptr(grads["x_enc/g"]), None, 5, 5, 3, hs, 0, st()))
+            _capi.check(lib.iaf_channel_sum(_ptr(d), _ptr(grads["x_enc/b"]), n, hs, (S // 2) ** 2, st()))
+            F["keep"] = F["keep"] + (dW,)
+
+    def forward_backward(self, x, noise, grads=None, autotune=False, on_bucket=None):
+        """One tower's forward and backward in mode "train", k = 1: returns (x_out, obj [1], grads) with grads[name] = d obj / d params[name]
+        for every variable (written into the tensors of `grads` where it has them -- e.g. the views of parallel.FlatParams.g).
+        autotune=True: the first call at a new batch size searches the launch shapes of the plain convs and their data gradients (what
+        cuDNN's algorithm search does for the reference).  The layer stack's backward is IAFLayer.down_backward / .up_backward chained through the model (the down pass
+        in up-pass order, then the up pass in reverse); the two ends -- likelihood, clip, x_dec, h_top, x_enc -- are the launches of
+        csrc/iaf_model_edge.hpp.  noise as in forward().  on_bucket(i): called as soon as the gradients of bucket i (set_grad_buckets) are
+        complete on the current stream -- where a data-parallel step issues that bucket's all-reduce (OverlappedGradReduce.reduce)."""
+        F = self.fb_begin(x, noise, grads, autotune)
+        for si in range(len(self._segs)):
+            self.fb_segment(si)
+            if on_bucket is not None:
+                on_bucket(si)
+        return F["x_out"], F["obj"], F["grads"]
 
     def bits_per_dim(self, loss, batch_size):
         """tf_train.py:133 for one tower: loss / (log 2 * num_pixels * batch_size)"""

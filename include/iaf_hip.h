@@ -349,11 +349,20 @@ int iaf_stack_set_halo_exchange(iaf_stack_t* s, int on);
  * workgroups take from other lists), 2 = workgroups delay their ticket by pseudo-random amounts (tickets out of dispatch
  * order), 16 = the posterior block's free-bits reductions by the separate finish launch instead of the step launch's
  * last workgroup (to compare the two), 8 = fault injection: the bottom row block of image 0 never hands over its first hidden row and waits are short, so
- * the block above it gives up.  0 = production.  IAF_XCH_DEBUG=<bits 1|2|16> in the environment: every stack is created with
+ * the block above it gives up (pair form: one half is never handed over).  32 = the PAIR form of the step at 8-pixel rows
+ * (iaf_stack_step_pairs; opt-in: on MI355X at B = 32 it is slower than the one-row kernel, profiles/r05/experiments/pair_form.txt).
+ * 0 = production.  IAF_XCH_DEBUG=<bits 1|2|16> in the environment: every stack is created with
  * these bits set (the whole GPU suite under a scrambled hand-over order: profiles/r04/pytest_gpu_scrambled.txt). */
 int iaf_stack_set_halo_exchange_debug(iaf_stack_t* s, unsigned knobs);
 /* 1 if the step at this size runs as one launch in the halo-exchange form, else 0 */
 int iaf_stack_step_exchanges(const iaf_stack_t* s, int B, int H, int W);
+/* 1 if the step at this size runs as one launch in the PAIR form (opt-in: knob 32 of iaf_stack_set_halo_exchange_debug or
+ * IAF_FUSE_PAIR=1; 8-pixel rows: two workgroups per (image, two rows), each computing
+ * half of the last hidden layer's channels and of the output pair from half of their weights, the halves of the last hidden layer
+ * swapped through the stack's exchange buffers -- same ordering, hand-over, failure behaviour (IAF_ERR_EXCHANGE) and switch
+ * (iaf_stack_set_halo_exchange) as the halo exchange; iaf_stack_step_is_fused reports 2 rows), else 0.  Replaces
+ * /root/reference/tf_utils/layers.py:158-166 + tf_train.py:69-72 at [B, n_z, 8, 8] like every other form of the step. */
+int iaf_stack_step_pairs(const iaf_stack_t* s, int B, int H, int W);
 int iaf_stack_autotune(iaf_stack_t* s, const float* z, const float* context, float* z_new, float* logsd, int B, int H, int W,
                        void* workspace, size_t workspace_bytes, int reps, void* stream, int* chosen, float* us);
 /* Per-kernel timing with HIP events on the launch stream: every launch of GEMM layer `layer` is

@@ -51,6 +51,7 @@ def _case(seed, B, n_z, n_h, d, H, W):
 def test_where_the_step_runs_as_one_launch(amd):
     st = amd.ARStack(32, [160, 160])
     assert st.step_is_fused(32, 16, 16) == 2 and st.step_is_fused(32, 8, 8) == 1 and st.step_is_fused(256, 16, 16) == 2
+    assert not st.step_pairs(32, 8, 8)                           # (the pair form at 8-pixel rows is opt-in: tests/test_hip_pair_step.py)
     assert st.step_is_fused(256, 8, 8) == 0                      # large batch of small images: layer by layer (weight stream)
     assert st.step_is_fused(3, 5, 16) == 2                       # any height, any batch
     assert st.step_is_fused(32, 4, 4) == 0                       # 4-pixel rows, one workgroup per image walking 1.2 MB of weights: no

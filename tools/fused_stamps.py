@@ -63,7 +63,24 @@ if (t[:, 28] != 0).any():
             md(28, 2), md(15, 28), md(7, 15), md(29, 3), md(21, 29), md(4, 21)))
         print("    helpers (first helper wave): import 1 asks %+.0f after the first epilogue's barrier, row complete +%.0f later, re-arm + LDS stores +%.0f;  import 2: asks %+.0f after the second epilogue's barrier, complete +%.0f, stores +%.0f" % (
             md(14, 2), md(16, 14), md(17, 16), md(18, 3), md(19, 18), md(20, 19)))
-if (t[:, 26] != 0).any():
+if (t[:, 28] == 0).all() and (t[:, 29] != 0).any() and (t[:, 19] != 0).any():
+    # the pair form (8-pixel rows): two workgroups per (image, two rows); dbg[26] = 2 * item + half + 1
+    k = t[(t[:, 29] != 0) & (t[:, 19] != 0)]
+    md = lambda a, b_: np.median(k[:, a] - k[:, b_])
+    print("    PAIR form: %d workgroups.  compute waves (wave 0): output pair, own half's channels %.0f | wait for the partner's half %.0f | the rest %.0f" % (
+        len(k), md(29, 3), md(21, 29), md(4, 21)))
+    print("    helpers (first helper wave): export issued %+.0f after the last hidden epilogue's barrier; import asks %+.0f, complete +%.0f later, re-arm + LDS stores +%.0f; sweeps %s (1, 2, 3, more)" % (
+        md(27, 3), md(18, 3), md(19, 18), md(20, 19), [int((k[:, 25] - 1 == n).sum()) for n in (0, 1, 2)] + [int((k[:, 25] - 1 > 2).sum())]))
+    byid = {int(r[26]) - 1: r for r in k if r[26] != 0}
+    d1, d2, d3 = [], [], []
+    for i, r in byid.items():
+        pr = byid.get(i ^ 1)
+        if pr is None or pr[27] == 0: continue
+        d1.append(float(r[18]) - float(pr[27])); d2.append(float(r[19]) - float(pr[27])); d3.append(float(r[0]) - float(pr[0]))
+    if d1:
+        print("    partner's export issued -> this one starts asking: median %.0f ticks; -> has the half: median %.0f (min %.0f max %.0f); start - partner's start: median |%.0f| max |%.0f|" % (
+            np.median(d1), np.median(d2), min(d2), max(d2), np.median(np.abs(d3)), max(np.abs(d3))))
+elif (t[:, 26] != 0).any():
     k = t[t[:, 24] != 0]
     print("    sweeps until the row was complete: import 1 %s, import 2 %s (histogram over WGs: 1, 2, 3, more)" % (
         [int((k[:, 24] - 1 == n).sum()) for n in (0, 1, 2)] + [int((k[:, 24] - 1 > 2).sum())],
