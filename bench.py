@@ -342,7 +342,7 @@ def _run_segmented(args, segments, red, flat, n_gpus, dist):
         torch.cuda.synchronize()
 
     stream = torch.cuda.Stream()
-    graphs = None
+    graphs, whole = None, None
     with torch.cuda.stream(stream):
         step_eager()
         stream.synchronize()
@@ -361,6 +361,26 @@ def _run_segmented(args, segments, red, flat, n_gpus, dist):
                     red.reduce(i)
                 red.wait()
                 flat.adamax_ema_step(1e-4, world=n_gpus)
+
+            # ... or the WHOLE step as one graph: the exchange stream forks off the compute stream behind every segment and joins in front of
+            # the optimiser INSIDE the capture (ncclAllReduce is capturable), so a replay has no host in its loop at all -- between
+            # per-segment graphs the host's launch + cross-stream waits cost ~0.14 ms per bucket (r04: exposed_ms 0.56 with ONE rank, whose
+            # all-reduce is a 5 us no-op).  Falls back to the per-segment graphs if the runtime refuses the capture.
+            whole = None
+            if not os.environ.get("IAF_BENCH_SEGMENT_GRAPHS"):
+                try:
+                    g1 = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g1, stream=stream, capture_error_mode="thread_local"):
+                        step_eager()
+                    g1.replay()
+                    stream.synchronize()
+                    whole = g1
+                except Exception as e:          # noqa: BLE001
+                    sys.stderr.write("bench.py: one-graph capture of the training step refused (%s): per-segment graphs\n" % (str(e).splitlines() or [""])[0])
+                    whole = None
+                    torch.cuda.synchronize()
+            if whole is not None:
+                step = whole.replay
         for _ in range(args.warmup):
             step()
         barrier()
@@ -397,6 +417,8 @@ def _run_segmented(args, segments, red, flat, n_gpus, dist):
                 "alone_ms_by_message_count": sweep, "expected_on_this_node": _exchange_expectation(flat.grads.numel(), n_gpus),
                 "rccl_ranks": RANK_INFO.get("rccl_ranks"),
                 "overlap": "bucket i is reduced while the backward segments i+1.. run (issued behind its segment's graph)"}
+    exchange["launch"] = ("one hipGraph for the whole step: segments, forked all-reduces, join, optimiser" if (graphs is not None and whole is not None)
+                          else "one hipGraph per segment, the all-reduces issued between the replays" if graphs is not None else "eager")
     return elapsed, graphs is not None, exchange
 
 

@@ -728,8 +728,12 @@ extern "C" int iaf_discretized_logistic(const float* mean, const float* logscale
 // ---------------------------------------------------------------------------------------------
 extern "C" int iaf_conv3x3_set_training(iaf_conv3x3_t* c, int on) {
     if (!c) return IAF_ERR_NULL;
-    if (c->generic || c->mask_mode) return IAF_ERR_UNSUPPORTED;
+    if (c->mask_mode) return IAF_ERR_UNSUPPORTED;
     if (!on) { c->training = false; return IAF_OK; }
+    if (c->generic) {         // channel counts outside the MFMA path: the direct backward kernels (iaf_kernels_generic.hpp), no extra packs
+        c->training = true;
+        return IAF_OK;
+    }
     GemmLayer& L = c->L;
     if (!L.wpt) HIP_TRY(hipMalloc(&L.wpt, (size_t)L.nchunk * MAXTAPS * L.ncot * 256 * sizeof(float)));
     // the transposed pack as bf16x3 (iaf_pack_t3_kernel): the data gradient on the bf16 matrix cores (even K tile counts)
@@ -809,6 +813,29 @@ extern "C" int iaf_conv3x3_backward(iaf_conv3x3_t* c, const float* x, const floa
     hipStream_t st = (hipStream_t)stream;
     GemmLayer& L = c->L;
     int rc;
+    if (c->generic) {
+        // channel counts outside the MFMA path: direct loops over the NCHW tensors as they are (iaf_kernels_generic.hpp)
+        if (c->deconv) return IAF_ERR_UNSUPPORTED;
+        GenGradP p;
+        memset(&p, 0, sizeof(p));
+        int e = 0;
+        for (int k = 0; k < n_dys; ++k) { e += dy_channels[k]; p.dy[k] = dys[k]; p.dy_end[k] = e; }
+        p.ndy = n_dys; p.dy_scale = dy_scale;
+        p.x = x; p.x2 = x2; p.c_split = c_split; p.in_elu = elu_input ? 1 : 0;
+        p.w = L.wp; p.ntaps = MAXTAPS; p.B = B; p.H = H; p.W = W; p.cin = L.cin; p.cout = L.cout;
+        for (int k = 0; k < n_dxs; ++k) { p.dx[k] = dxs[k]; p.dx_end[k] = dends[k]; }
+        p.ndx = n_dxs; p.res = dx_residual;
+        p.dW = tw.dW; p.db = tw.dbp;
+        if (n_dxs) hipLaunchKernelGGL(iaf_generic_dgrad_kernel, ew_grid((size_t)P * L.cin), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(iaf_generic_wgrad_kernel, dim3((unsigned)((size_t)MAXTAPS * L.cin * L.cout + L.cout)), dim3(256), 0, st, p);
+        GenWnBwdP wn;
+        memset(&wn, 0, sizeof(wn));
+        wn.V[0] = V; wn.g[0] = g; wn.dV[0] = dV; wn.dg[0] = dg; wn.db[0] = db;
+        wn.dW = tw.dW; wn.dbsum = tw.dbp; wn.cin = L.cin; wn.cout_each = L.cout; wn.npair = 1; wn.ntaps = MAXTAPS;
+        hipLaunchKernelGGL(iaf_generic_wn_bwd_kernel, dim3(L.cout), dim3(256), 0, st, wn);
+        c->pending = false;
+        return (int)hipGetLastError();
+    }
     // (1) operands, pixel-major
     if ((rc = pack_pixmajor(dys, dy_channels, n_dys, tw.dyc, c->n_out, HW, P, dy_scale, 0, st))) return rc;
     {

@@ -1015,8 +1015,9 @@ static int build_stack(iaf_stack_t* s, ConvP base, int first_inmode, const float
     return n;
 }
 
+// hsave: training -- every hidden activation into a buffer of its own (NCHW), where the generic backward reads it
 static int run_stack_generic(iaf_stack_t* s, const ConvP& base, int first_inmode, const float* ctx, const float* ctx2,
-                             const Ws& ws, hipStream_t st) {
+                             const Ws& ws, hipStream_t st, float* const* hsave = nullptr) {
     const float* cur = base.x;
     for (int l = 0; l <= s->depth_ar; ++l) {
         const GemmLayer& L = s->L[l];
@@ -1031,7 +1032,7 @@ static int run_stack_generic(iaf_stack_t* s, const ConvP& base, int first_inmode
             p.mode = base.mode; p.zin = base.zin; p.out0 = base.out0; p.out1 = base.out1; p.kl_elem = base.kl_elem;
         } else {
             p.ctx = (l == 0) ? ctx : nullptr; p.ctx2 = (l == 0) ? ctx2 : nullptr;
-            p.y = ws.hbuf[l & 1];
+            p.y = hsave ? hsave[l] : ws.hbuf[l & 1];
         }
         const size_t total = (size_t)p.B * (p.is_out ? p.nz : p.cout) * p.H * p.W;
         hipLaunchKernelGGL(iaf_generic_conv_kernel, ew_grid(total), dim3(256), 0, st, p);
@@ -1822,8 +1823,11 @@ extern "C" int iaf_compute_lowerbound(const float* log_pxz, const float* sum_kl,
 // ---------------------------------------------------------------------------------------------
 extern "C" int iaf_stack_set_training(iaf_stack_t* s, int on) {
     if (!s) return IAF_ERR_NULL;
-    if (s->generic) return IAF_ERR_UNSUPPORTED;
     if (!on) { s->training = false; return IAF_OK; }
+    if (s->generic) {         // channel counts outside the MFMA path: the direct backward kernels (iaf_kernels_generic.hpp) need no extra packs
+        s->training = true;
+        return IAF_OK;
+    }
     for (int l = 0; l < s->nlayers; ++l) {
         GemmLayer& L = s->L[l];
         if (!L.wpt) HIP_TRY(hipMalloc(&L.wpt, (size_t)L.nchunk * NTAPS * L.ncot * 256 * sizeof(float)));
@@ -1985,6 +1989,7 @@ extern "C" int iaf_step_forward_train(iaf_stack_t* s, const float* z, const floa
     base.B = B; base.H = H; base.W = W; base.HW = H * W; base.P = B * H * W;
     base.zin = z; base.out0 = z_new; base.out1 = logsd; base.mode = MODE_IAF;
     base.x = z;
+    if (s->generic) { Ws none; memset(&none, 0, sizeof(none)); return run_stack_generic(s, base, IN_NCHW, context, nullptr, none, st, tw.h); }
     {   // the one-launch step, writing the hidden activations of the owned rows where the backward expects them
         int R = 0;
         size_t lds = 0;
@@ -2147,6 +2152,38 @@ extern "C" int iaf_step_backward(iaf_stack_t* s, const float* z, const float* co
     TrainWs tw;
     train_ws_floats(s, P, &tw, (float*)workspace);
     hipStream_t st = (hipStream_t)stream;
+    if (s->generic) {
+        // channel counts outside the MFMA path: the same four passes as direct loops over NCHW tensors (iaf_kernels_generic.hpp)
+        const size_t nzel = (size_t)P * s->n_z;
+        hipLaunchKernelGGL(iaf_generic_bwd_affine_kernel, ew_grid(nzel), dim3(256), 0, st, z_new, logsd, dz_new, dlogsd, tw.dy3, s->n_z, H * W, nzel);
+        const float* dy = tw.dy3;
+        for (int l = d; l >= 0; --l) {
+            const GemmLayer& L = s->L[l];
+            GenGradP p;
+            memset(&p, 0, sizeof(p));
+            p.dy[0] = dy; p.dy_end[0] = L.cout; p.ndy = 1; p.dy_scale = 1.f;
+            p.x = (l == 0) ? z : tw.h[l - 1];
+            p.w = L.wp; p.ntaps = NTAPS; p.B = B; p.H = H; p.W = W; p.cin = L.cin; p.cout = L.cout;
+            p.ndx = 1; p.dx_end[0] = L.cin;
+            if (l == 0) { p.dx[0] = dz; p.dzn = dz_new; p.logsd = logsd; }
+            else { p.dx[0] = tw.da[l - 1]; p.act_out = tw.h[l - 1]; p.dx_copy = (l - 1 == 0) ? dcontext : nullptr; }
+            p.dW = tw.dWeff[l]; p.db = tw.dbp[l];
+            hipLaunchKernelGGL(iaf_generic_dgrad_kernel, ew_grid((size_t)P * L.cin), dim3(256), 0, st, p);
+            hipLaunchKernelGGL(iaf_generic_wgrad_kernel, dim3((unsigned)((size_t)NTAPS * L.cin * L.cout + L.cout)), dim3(256), 0, st, p);
+            GenWnBwdP wn;
+            memset(&wn, 0, sizeof(wn));
+            const bool pair = (l == d);
+            for (int k = 0; k < (pair ? 2 : 1); ++k) {
+                const int ci = pair ? d + k : l;
+                wn.V[k] = V[ci]; wn.g[k] = g[ci]; wn.dV[k] = dV[ci]; wn.dg[k] = dg[ci]; wn.db[k] = db[ci];
+            }
+            wn.dW = tw.dWeff[l]; wn.dbsum = tw.dbp[l];
+            wn.cin = L.cin; wn.cout_each = pair ? s->n_z : L.cout; wn.npair = pair ? 2 : 1; wn.zerodiag = L.zerodiag; wn.ntaps = NTAPS;
+            hipLaunchKernelGGL(iaf_generic_wn_bwd_kernel, dim3(L.cout), dim3(256), 0, st, wn);
+            if (l > 0) dy = tw.da[l - 1];
+        }
+        return (int)hipGetLastError();
+    }
 
     // (1) affine + log-det backward -> packed pixel-major dY of the output GEMM, pixel-major copy of z
     {
@@ -2379,19 +2416,22 @@ extern "C" int iaf_posterior_block_forward_train(iaf_stack_t* s, const float* qz
             return launch_kl_from_parts(tw.klelem, tw.rowsum, kl_obj, kl_cost, B, s->n_z, (H + R - 1) / R, kl_min, tw.gate, st);
         }
     }
-    const float* cur = nullptr;
-    int inmode = IN_POSTERIOR;
-    for (int l = 0; l < s->depth_ar; ++l) {
-        ConvP p = base;
-        p.x = cur;
-        p.ctx = (l == 0) ? up_context : nullptr;
-        p.ctx2 = (l == 0) ? down_context : nullptr;
-        p.y = tw.h[l];
-        if ((rc = launch_conv(s, l, p, inmode, st))) return rc;
-        cur = p.y;
-        inmode = IN_PIXMAJOR;
-    }
-    {
+    if (s->generic) {
+        Ws none; memset(&none, 0, sizeof(none));
+        if ((rc = run_stack_generic(s, base, IN_POSTERIOR, up_context, down_context, none, st, tw.h))) return rc;
+    } else {
+        const float* cur = nullptr;
+        int inmode = IN_POSTERIOR;
+        for (int l = 0; l < s->depth_ar; ++l) {
+            ConvP p = base;
+            p.x = cur;
+            p.ctx = (l == 0) ? up_context : nullptr;
+            p.ctx2 = (l == 0) ? down_context : nullptr;
+            p.y = tw.h[l];
+            if ((rc = launch_conv(s, l, p, inmode, st))) return rc;
+            cur = p.y;
+            inmode = IN_PIXMAJOR;
+        }
         ConvP p = base;
         p.x = cur;
         if ((rc = launch_conv(s, s->depth_ar, p, inmode, st))) return rc;

@@ -76,3 +76,23 @@ def test_skipped_blocks_of_the_issued_over_live_figure_are_dead_in_the_mask(nht)
     assert 0 <= skipped <= dead and (skipped > 0 or nht == 4)      # (n_h = 64: both pairs are live for some tile of the only slot)
     if nht == 10:
         assert skipped == dead == 20
+
+
+def test_profile_json_matches_the_csv_it_cites():
+    """`roofline.rocprof` of the bench line reads profiles/rocprof_dominant_kernel.json, which cites a rocprofv3
+    --stats CSV under profiles/rNN/ -- the average it carries must BE that CSV's row (tools/adopt_profiles.py copies both from one
+    refresh), and the per-round copy beside the CSV must be the same file."""
+    import csv
+    import re
+    top = os.path.join(ROOT, "profiles", "rocprof_dominant_kernel.json")
+    j = json.load(open(top))
+    m = re.match(r"(profiles/(r\d+)/bench_kernel_stats\.csv)", j["source"])
+    assert m, j["source"]
+    rows = [r for r in csv.DictReader(open(os.path.join(ROOT, m.group(1)))) if r["Name"] == j["kernel"]]
+    assert len(rows) == 1
+    assert int(rows[0]["Calls"]) == j["calls"]
+    assert abs(float(rows[0]["AverageNs"]) / 1e3 - j["avg_launch_us"]) < 1e-6
+    assert json.load(open(os.path.join(ROOT, "profiles", m.group(2), "rocprof_dominant_kernel.json"))) == j
+    pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_dominant_kernel.json")))
+    rp = re.search(r"profiles/(r\d+)/pmc/", pj["command"])
+    assert rp and json.load(open(os.path.join(ROOT, "profiles", rp.group(1), "pmc_dominant_kernel.json"))) == pj
