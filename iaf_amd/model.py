@@ -317,26 +317,40 @@ class CVAE1(object):
     # backwards (up_conv3, up_conv1 of every layer in reverse), x_enc.
     _DOWN_KEYS = ("down_conv2/", "down_deconv2/", "ar_multiconv2d/", "down_conv1/")
 
-    def _layer_names(self, ij, down):
+    @staticmethod
+    def _names_of_layer(all_names, ij, down):
         pre = "IAF_%d_%d/" % ij
-        src = self.params if self.params is not None else {}
-        ks = [k for k in src if k.startswith(pre) and (k[len(pre):].startswith(self._DOWN_KEYS) == down)]
-        return ks
+        return [k for k in all_names if k.startswith(pre) and (k[len(pre):].startswith(CVAE1._DOWN_KEYS) == down)]
+
+    def _layer_names(self, ij, down):
+        return CVAE1._names_of_layer(self.params if self.params is not None else {}, ij, down)
+
+    @staticmethod
+    def grad_bucket_names(all_names, depth, num_blocks, n_buckets=1):
+        """Pure bookkeeping (no device): the variable names of a depth x num_blocks model, bucket by bucket, in the order forward_backward
+        completes their gradients -- ceil(n/2) groups of layers for the top-down pass's backward (bucket 0 also holds the top end), floor(n/2)
+        for the bottom-up pass's (the first with h_top, the last with x_enc).  Concatenated = completion_order()."""
+        order = [(i, j) for i in range(depth) for j in range(num_blocks)]
+        nb = max(1, min(int(n_buckets), 2 * len(order)))
+        chunks = lambda lst, n: [lst[q * len(lst) // n:(q + 1) * len(lst) // n] for q in range(n)]
+        top, bottom = ["dec_log_stdv", "x_dec/V", "x_dec/g", "x_dec/b"], ["x_enc/V", "x_enc/g", "x_enc/b"]
+        names_of = lambda g, down: [k for ij in g for k in CVAE1._names_of_layer(all_names, ij, down)]
+        if nb < 2:
+            out = [top + names_of(order, True) + ["h_top"] + names_of(list(reversed(order)), False) + bottom]
+        else:
+            dgroups, ugroups = chunks(order, (nb + 1) // 2), chunks(list(reversed(order)), nb // 2)
+            out = [(top if gi == 0 else []) + names_of(g, True) for gi, g in enumerate(dgroups)]
+            out += [(["h_top"] if gi == 0 else []) + names_of(g, False) + (bottom if gi == len(ugroups) - 1 else []) for gi, g in enumerate(ugroups)]
+        flat = [k for b in out for k in b]
+        if sorted(flat) != sorted(all_names):
+            raise ValueError("not the variables of a %d x %d CVAE1: %s" % (depth, num_blocks, sorted(set(flat) ^ set(all_names))[:6]))
+        return out
 
     def completion_order(self):
         """every variable name in the order forward_backward completes its gradient (lay parallel.FlatParams out in this order)"""
         if self.params is None:
             raise RuntimeError("CVAE1.load(params) first")
-        order = [(i, j) for i in range(self.depth) for j in range(self.num_blocks)]
-        names = ["dec_log_stdv", "x_dec/V", "x_dec/g", "x_dec/b"]
-        for ij in order:
-            names += self._layer_names(ij, True)
-        names.append("h_top")
-        for ij in reversed(order):
-            names += self._layer_names(ij, False)
-        names += ["x_enc/V", "x_enc/g", "x_enc/b"]
-        assert sorted(names) == sorted(self.params), "completion_order must list every variable exactly once"
-        return names
+        return [k for b in CVAE1.grad_bucket_names(list(self.params), self.depth, self.num_blocks, 1) for k in b]
 
     def set_grad_buckets(self, n_buckets=1):
         """Cut the backward into `n_buckets` segments, each completing one contiguous run of completion_order(): ceil(n/2) groups of layers
@@ -372,8 +386,12 @@ class CVAE1(object):
                     (["x_enc/V", "x_enc/g", "x_enc/b"] if last else [])
             segs.append(dict(down=[], up=g, h_top=(gi == 0), x_enc=last, names=names, conv_ids=convs, stack_ids=[],
                              wn=WnBwdBatch(stacks=[], convs=[getattr(L(ij), nm) for ij, nm in convs])))
+        names = CVAE1.grad_bucket_names(list(self.params), self.depth, self.num_blocks, nb)
+        assert len(names) == len(segs) and all(sorted(sg["names"]) == sorted(nm) for sg, nm in zip(segs, names))
+        for sg, nm in zip(segs, names):
+            sg["names"] = nm
         self._segs = segs
-        return [sg["names"] for sg in segs]
+        return names
 
     def fb_begin(self, x, noise, grads=None, autotune=False):
         """forward_backward, first part: the forward pass (keeping what the backward reads) and the backward of the top end --

@@ -71,7 +71,7 @@ class FlatParams(object):
         items = list(named_tensors.items())
         device = device or items[0][1].device
         total = sum(((t.numel() + 3) // 4) * 4 for _, t in items)     # keep every view 16-byte aligned
-        self.params = torch.empty(total, dtype=torch.float32, device=device)
+        self.params = torch.zeros(total, dtype=torch.float32, device=device)     # (zeros: the alignment gaps between views stay defined)
         self.grads = torch.zeros_like(self.params)
         self.slot_m = torch.zeros_like(self.params)
         self.slot_v = torch.zeros_like(self.params)

@@ -186,3 +186,67 @@ def test_bucket_bounds_reject_misordered_or_incomplete_groups():
                 [["a", "b"], [], ["c", "d"]]):     # empty bucket
         with pytest.raises(ValueError):
             par.OverlappedGradReduce.bounds_from_groups(fp, bad)
+
+
+def _model_worker(rank, world, port, out, nb):
+    """One tower of the reference's data-parallel step on the WHOLE model (tf_train.py:124-147): this rank's images through the model's
+    objective and gradient (the fp64 autograd oracle stands in for CVAE1.forward_backward, which needs the GPU), the gradients written
+    into a flat buffer laid out by CVAE1.grad_bucket_names, every bucket all-reduced as the backward would complete it, then the fused
+    Adamax(1/N) + EMA arithmetic."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import golden_inputs as gi
+    from iaf_amd import parallel as par
+    from iaf_amd.model import CVAE1
+    from oracle import iaf_grad_oracle as G
+    c = gi.model_case_inputs("model_tiny")
+    f32 = lambda a: np.asarray(a, np.float32).astype(np.float64)
+    p32 = {k: f32(v) for k, v in c["params"].items()}
+    buckets = CVAE1.grad_bucket_names(list(p32), c["depth"], c["num_blocks"], nb)
+    order = [k for b in buckets for k in b]
+    fp = par.FlatParams({k: torch.from_numpy(np.asarray(c["params"][k], np.float32)) for k in order})
+    red = par.OverlappedGradReduce(fp, par.OverlappedGradReduce.bounds_from_groups(fp, buckets))
+    per = c["x"].shape[0] // world
+    sl = slice(rank * per, (rank + 1) * per)                              # tf.split(0, num_gpus, x)[rank]  (tf_train.py:126)
+    grads, _, obj = G.cvae1_grads(c["x"][sl], p32, c["z_size"], c["h_size"], c["depth"], c["num_blocks"], c["kl_min"], [f32(e[sl]) for e in c["noise"]])
+    for bi, names in enumerate(buckets):                                  # the backward completes bucket bi, its all-reduce is issued
+        for k in names:
+            fp.g[k].copy_(torch.from_numpy(np.asarray(grads[k], np.float32)).reshape(fp.g[k].shape))
+        red.reduce(bi)
+    red.wait()
+    fp.adamax_ema_step(0.002, world=world)
+    out[rank] = dict(params=fp.params.numpy().copy(), ema=fp.ema.numpy().copy(), grads={k: np.asarray(grads[k], np.float64) for k in order},
+                     offs={k: fp.offset_of(k) for k in order}, obj=float(obj))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_model_level_training_step_two_towers_gloo():
+    """the model-level DP step at world size 2 -- two ranks, different images, the model's gradient buckets reduced in
+    completion order: identical parameters on both ranks afterwards, equal to the reference's two-tower step (average_grads over the
+    towers' gradients, tf_utils/common.py:83-86, then adamax.py:40-56 and the EMA of tf_train.py:157-158) computed in one process"""
+    import pytest
+    world = 2
+    res = {}
+    for nb in (1, 4):
+        mgr = mp.Manager()
+        out = mgr.dict()
+        mp.spawn(_model_worker, args=(world, _free_port(), out, nb), nprocs=world, join=True)
+        np.testing.assert_array_equal(out[0]["params"], out[1]["params"])     # replicas stay bit-identical without a broadcast
+        np.testing.assert_array_equal(out[0]["ema"], out[1]["ema"])
+        assert out[0]["obj"] != out[1]["obj"]                                 # (the towers did see different images)
+        res[nb] = out[0]
+        # the reference's arithmetic, one process, fp64: per-variable mean over the towers, one Adamax step from zero slots, EMA
+        import sys
+        sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+        import golden_inputs as gi
+        c = gi.model_case_inputs("model_tiny")
+        for k, (lo, hi) in out[0]["offs"].items():
+            avg = O.average_grads([[out[r]["grads"][k]] for r in range(world)])[0]
+            var = np.asarray(c["params"][k], np.float32).astype(np.float64)
+            new, _, _ = O.adamax_step(var.copy(), avg, np.zeros_like(var), np.zeros_like(var), 0.002)
+            np.testing.assert_allclose(out[0]["params"][lo:hi].reshape(var.shape), new, rtol=2e-6, atol=1e-7, err_msg=k)
+    np.testing.assert_allclose(res[1]["params"], res[4]["params"], rtol=0, atol=0)      # bucketing does not change a bit
