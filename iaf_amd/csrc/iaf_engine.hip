@@ -110,7 +110,7 @@ struct iaf_stack {
     struct XchSet {
         hipStream_t st = nullptr;
         char* buf = nullptr; size_t bytes = 0;                 // rows: all 0xff between launches
-        unsigned long long* ctl = nullptr;                     // heads, arrivals, sticky error (StepP::xctl: words 0..511), arrivals of the in-launch KL finish (StepP::fin_ctl: words 512..): zero between launches
+        unsigned long long* ctl = nullptr;                     // heads, arrivals, sticky error (StepP::xctl), arrivals of the in-launch KL finish (StepP::fin_ctl = xctl + IAF_XCTL_FIN): zero between launches
     };
     std::deque<XchSet> xch_sets;           // (stable addresses: a launch holds a pointer to its set outside the lock)
     std::mutex xch_mu;
@@ -507,7 +507,7 @@ static int xch_reset_sets(iaf_stack_t* s) {
     std::lock_guard<std::mutex> lk(s->xch_mu);
     for (auto& x : s->xch_sets) {
         HIP_TRY(hipMemset(x.buf, 0xff, x.bytes));
-        HIP_TRY(hipMemset(x.ctl, 0, 1024 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(x.ctl, 0, IAF_XCTL_WORDS * sizeof(unsigned long long)));
     }
     for (auto& r : s->xch_retired_rows) HIP_TRY(hipMemset(r.first, 0xff, r.second));     // (a captured graph may still name them)
     if (s->xch_err_host) *(volatile unsigned*)s->xch_err_host = 0u;
@@ -1103,8 +1103,8 @@ static iaf_stack::XchSet* xch_prepare(iaf_stack_t* s, int B, int nrb, size_t xro
     char* nb = nullptr;
     unsigned long long* nc = x ? x->ctl : nullptr;
     bool ok = hipMalloc((void**)&nb, need) == hipSuccess && hipMemsetAsync(nb, 0xff, need, st) == hipSuccess;    // (ordered in front of the launch)
-    if (ok && !nc) ok = hipMalloc((void**)&nc, 1024 * sizeof(unsigned long long)) == hipSuccess &&
-                        hipMemsetAsync(nc, 0, 1024 * sizeof(unsigned long long), st) == hipSuccess;
+    if (ok && !nc) ok = hipMalloc((void**)&nc, IAF_XCTL_WORDS * sizeof(unsigned long long)) == hipSuccess &&
+                        hipMemsetAsync(nc, 0, IAF_XCTL_WORDS * sizeof(unsigned long long), st) == hipSuccess;
     if (!ok) {
         if (nb) (void)hipFree(nb);
         if (nc && !(x && x->ctl == nc)) (void)hipFree(nc);
@@ -1278,7 +1278,7 @@ static int launch_fused_step(iaf_stack_t* s, step_fn_t fn, int R, size_t lds, co
         static const bool fin_env = !(getenv("IAF_KL_IN_LAUNCH") && getenv("IAF_KL_IN_LAUNCH")[0] == '0');
         if (fin_env && !(s->xch_knob & 16u))                 // (test knob 16: the finish launch, to compare against)
             if (iaf_stack::XchSet* x = xch_prepare(s, base.B, q.nrb, 0, st)) {
-                q.fin_obj = fin->kl_obj; q.fin_cost = fin->kl_cost; q.fin_kl_min = fin->kl_min; q.fin_ctl = x->ctl + 512; q.fin_gate = fin->gate;
+                q.fin_obj = fin->kl_obj; q.fin_cost = fin->kl_cost; q.fin_kl_min = fin->kl_min; q.fin_ctl = x->ctl + IAF_XCTL_FIN; q.fin_gate = fin->gate;
                 fin->done = true;
             }
     }

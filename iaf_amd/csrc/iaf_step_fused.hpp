@@ -410,33 +410,42 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
     // ---- XCH: which rows this workgroup computes -- a ticket, not blockIdx -----------------------------------------------------
     // p.xctl (64-bit words; every counter in a 128-byte line of its own -- 512 read-modify-writes of ONE line took 12 k cycles of
     // this prologue when heads and arrivals shared one): [32 y] head of work list y = tickets taken; [32 y + 16] holders of list y
-    // that are done with the heads; [256] lists whose holders all are; [272] sticky error.
-    // List y holds the images b = y, y + 8, y + 16, ... < B, their row blocks bottom first: ticket t of list y is (image
-    // y + 8 (t / nrb), row block nrb - 1 - t % nrb).  A workgroup asks the list of the XCD it runs on (HW_REG_XCC_ID) first -- eight
-    // heads, each pulled by its own XCD's 32 CUs, answer in ~0.3 us where one head for 256 pullers takes 3 -- and the other lists
-    // in turn when that one is dry: grid = number of items, so every workgroup finds exactly one.  The placement decides which
-    // head answers, never what is computed.
-    // The last holder of a list to arrive counts its list at [256]; the one that completes that count (every ticket of the launch
-    // is taken by then) puts heads and arrival counts back to zero for the next launch on these buffers.
+    // that are done with the heads; [IAF_XCTL_DONE] lists whose holders all are; [IAF_XCTL_STICKY] sticky error.
+    // List y (y < 32) holds the images b = y, y + 32, y + 64, ... < B, their row blocks bottom first: ticket t of list y is (image
+    // y + 32 (t / nrb), row block nrb - 1 - t % nrb).  A workgroup asks one of the four lists of the XCD it runs on first (HW_REG_XCC_ID;
+    // which of the four: its CU) -- a head is a counter on the memory side that answers its pullers one after the other: eight per head
+    // at B = 32 since round 5, 32 per head with the eight lists of round 4, whose tickets took ~3 k cycles of this prologue -- and the
+    // other lists in turn when that one is dry: grid = number of items, so every workgroup finds exactly one.  The placement decides
+    // which head answers, never what is computed.
+    // The last holder of a list to arrive counts its list at [IAF_XCTL_DONE]; the one that completes that count (every ticket of the
+    // launch is taken by then) puts heads and arrival counts back to zero for the next launch on these buffers.
+    constexpr unsigned XNLST = IAF_XCTL_LISTS;
     unsigned xcc = 0, xdead = 0;
     unsigned long long xdone = 0, xlists_done = 0;
     [[maybe_unused]] unsigned xmine = 0, xmine_n = 0;                    // (thread 0: the list its ticket came from, that list's items)
     int xslot = 0;
     int half = 0;                                                        // PAIR: which channel half this workgroup computes
     [[maybe_unused]] unsigned long long xt0 = 0;
-    [[maybe_unused]] unsigned xlist = 0;
+    [[maybe_unused]] unsigned xlist = 0, xnl = 1;
     unsigned* xmail = (unsigned*)(smem + (size_t)G::CTX_OFF * 16);          // (the context staging area: not written before the first conv is done)
     auto xch_take_begin = [&]() {
         if constexpr (TKT) {
             if (tid == 0) {
+                // 32 lists, four per XCD (round 5): a head is an agent-scope counter on the memory side, its 32 pullers per launch were
+                // served one after the other -- ~3 k cycles of this prologue at eight lists (profiles/r05/experiments/ticket_lists.txt);
+                // which of its XCD's four lists a workgroup asks first is decided by the CU it runs on
+                unsigned hwid = 0;
                 asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
                 xcc &= 7u;
-                xlist = xcc;
-                if (p.xknob & 1u) xlist = (blockIdx.x * 2654435761u >> 13) & 7u;        // test knob: lists that ignore the placement
+                xlist = xcc * 4u + ((((hwid >> 8) & 15u) + ((hwid >> 13) & 7u)) & 3u);      // (CU_ID + SE_ID) & 3
+                if (p.xknob & 1u) xlist = (blockIdx.x * 2654435761u >> 13) & (XNLST - 1u);        // test knob: lists that ignore the placement
+                xnl = (unsigned)p.B < XNLST ? (unsigned)p.B : XNLST;                           // lists that hold anything: y < min(B, 32)
+                xlist %= xnl;
                 if (p.xknob & 2u)                                                       // test knob: tickets out of dispatch order
                     for (unsigned i = 0, n = (blockIdx.x * 40503u >> 4) & 63u; i < n; ++i) __builtin_amdgcn_s_sleep(64);
                 xt0 = __hip_atomic_fetch_add(p.xctl + 32 * xlist, 1ull, __ATOMIC_RELAXED, XSCOPE);
-                xdead = (unsigned)__hip_atomic_load(p.xctl + 272, __ATOMIC_RELAXED, XSCOPE);
+                xdead = (unsigned)__hip_atomic_load(p.xctl + IAF_XCTL_STICKY, __ATOMIC_RELAXED, XSCOPE);
             }
         }
     };
@@ -446,10 +455,10 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
                 unsigned long long v = xt0;
                 unsigned y = xlist, t = 0, ny = 0;
                 bool found = false;
-                for (int k = 0; k < 8; ++k) {
-                    if (k) { y = (xlist + k) & 7u; v = __hip_atomic_fetch_add(p.xctl + 32 * y, 1ull, __ATOMIC_RELAXED, XSCOPE); }
+                for (unsigned k = 0; k < xnl; ++k) {
+                    if (k) { y = (xlist + k) % xnl; v = __hip_atomic_fetch_add(p.xctl + 32 * y, 1ull, __ATOMIC_RELAXED, XSCOPE); }
                     // (PAIR: two tickets per (image, row block) -- 2 k and 2 k + 1 are the two halves of item k)
-                    ny = (int)y < p.B ? (PAIR ? 2u : 1u) * (unsigned)p.nrb * (unsigned)((p.B - (int)y + 7) >> 3) : 0u;
+                    ny = (int)y < p.B ? (PAIR ? 2u : 1u) * (unsigned)p.nrb * (unsigned)((p.B - (int)y + (int)XNLST - 1) / (int)XNLST) : 0u;
                     t = (unsigned)v;
                     if (t < ny) { found = true; break; }
                 }
@@ -458,7 +467,7 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
                 if (found) xdone = __hip_atomic_fetch_add(p.xctl + 32 * y + 16, 1ull, __ATOMIC_RELAXED, XSCOPE);
                 unsigned ib = 0, ir = (unsigned)p.nrb - 1;
                 const unsigned ti = PAIR ? t >> 1 : t;
-                if (found) { ib = y + 8u * (ti / (unsigned)p.nrb); ir = (unsigned)p.nrb - 1u - ti % (unsigned)p.nrb; }
+                if (found) { ib = y + XNLST * (ti / (unsigned)p.nrb); ir = (unsigned)p.nrb - 1u - ti % (unsigned)p.nrb; }
                 else xdead |= 2u;                                           // (grid != B * nrb: a host bug -- loud, not a hang)
                 xmail[0] = ib; xmail[1] = ir; xmail[2] = xdead; xmail[3] = t & 1u;
                 if (p.dbg) p.dbg[(size_t)blockIdx.x * 32 + 30] = 1ull + (((unsigned long long)y << 32) | t);      // (dev tool: which ticket of which list)
@@ -473,7 +482,7 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
             xslot = b * p.nrb + rbk;
             if (xdead && tid == 0) {
                 if (p.xerr) __hip_atomic_store(p.xerr, 0x100u | xdead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __hip_atomic_store(p.xctl + 272, (unsigned long long)xdead, __ATOMIC_RELAXED, XSCOPE);
+                __hip_atomic_store(p.xctl + IAF_XCTL_STICKY, (unsigned long long)xdead, __ATOMIC_RELAXED, XSCOPE);
             }
         }
     };
@@ -482,18 +491,17 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
     auto xch_next_epoch_a = [&]() {
         if constexpr (TKT) {
             if (tid == 0 && xmine_n && (unsigned)xdone == xmine_n - 1u)
-                xlists_done = __hip_atomic_fetch_add(p.xctl + 256, 1ull, __ATOMIC_RELAXED, XSCOPE) + 1ull;
+                xlists_done = __hip_atomic_fetch_add(p.xctl + IAF_XCTL_DONE, 1ull, __ATOMIC_RELAXED, XSCOPE) + 1ull;
         }
     };
     auto xch_next_epoch_b = [&]() {
         if constexpr (TKT) {
-            if (tid == 0 && (unsigned)xlists_done == (unsigned)(p.B < 8 ? p.B : 8)) {
-#pragma unroll
-                for (int y = 0; y < 8; ++y) {
+            if (tid == 0 && (unsigned)xlists_done == (unsigned)(p.B < (int)XNLST ? p.B : (int)XNLST)) {
+                for (int y = 0; y < (int)XNLST; ++y) {
                     __hip_atomic_store(p.xctl + 32 * y, 0ull, __ATOMIC_RELAXED, XSCOPE);
                     __hip_atomic_store(p.xctl + 32 * y + 16, 0ull, __ATOMIC_RELAXED, XSCOPE);
                 }
-                __hip_atomic_store(p.xctl + 256, 0ull, __ATOMIC_RELAXED, XSCOPE);
+                __hip_atomic_store(p.xctl + IAF_XCTL_DONE, 0ull, __ATOMIC_RELAXED, XSCOPE);
             }
         }
     };
@@ -771,7 +779,7 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
     // invalidate the whole L2 -- with it the weight packs every workgroup streams -- and the launch took 78 k instead of 54 k cycles.
     // Giving up: every wait is bounded.  A wave whose wait ends with units missing fills its share of the imported row with NaN
     // (which then flows through the remaining layers to this block's outputs and, where an exported row depends on it, on to the
-    // blocks above), raises the sticky word p.xctl[272] -- the buffer can no longer be trusted to be all XSENT, so every later
+    // blocks above), raises the sticky word p.xctl[IAF_XCTL_STICKY] -- the buffer can no longer be trusted to be all XSENT, so every later
     // launch on it imports NaN without looking -- and the host-visible p.xerr, which the next call on the stack returns as
     // IAF_ERR_EXCHANGE; iaf_stack_set_halo_exchange re-arms the buffers.  Wrong numbers never leave silently.
     constexpr unsigned XSENT = 0xffffffffu;
@@ -856,7 +864,7 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
                     for (int u = 0; u < XNLH; ++u) t[u] = u32x4{0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u};
                     if (lane == 0 && !xdead) {
                         if (p.xerr) __hip_atomic_store(p.xerr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        __hip_atomic_store(p.xctl + 272, 1ull, __ATOMIC_RELAXED, XSCOPE);
+                        __hip_atomic_store(p.xctl + IAF_XCTL_STICKY, 1ull, __ATOMIC_RELAXED, XSCOPE);
                     }
                 }
 #pragma unroll
@@ -949,7 +957,7 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
                     __builtin_amdgcn_raw_buffer_store_b128(u32x4{XSENT, XSENT, XSENT, XSENT}, r, 16 * (htid + 256 * u), 0, XSC1);
             } else if (lane == 0 && !xdead) {
                 if (p.xerr) __hip_atomic_store(p.xerr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __hip_atomic_store(p.xctl + 272, 1ull, __ATOMIC_RELAXED, XSCOPE);
+                __hip_atomic_store(p.xctl + IAF_XCTL_STICKY, 1ull, __ATOMIC_RELAXED, XSCOPE);
             }
         }
     };

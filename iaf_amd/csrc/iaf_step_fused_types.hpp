@@ -39,12 +39,20 @@ struct StepP {
     // XCH kernels (halo rows exchanged between the row blocks of an image instead of recomputed; iaf_step_fused.hpp "XCH"):
     char* xh;                      // rows [layer][B * nrb][xrow bytes]; every 8-byte piece = 0xff..ff between launches (the data is the flag)
                                    // (PAIR kernels: [B * nrb][half][prow bytes], the halves of the last hidden region the partners swap)
-    unsigned long long* xctl;      // [32 y] head of work list y (tickets taken), [32 y + 16] its arrivals, [256] lists complete,
-                                   // [272] sticky error -- a 128-byte line each (512 words in all); zero between launches
+    unsigned long long* xctl;      // [32 y] head of work list y (tickets taken), [32 y + 16] its arrivals, [IAF_XCTL_DONE] lists complete,
+                                   // [IAF_XCTL_STICKY] sticky error -- a 128-byte line each; zero between launches
     unsigned* xerr;                // host-visible error word (mapped pinned memory), or NULL
     unsigned xknob;                // test knobs: 1 lists ignore the placement, 2 tickets out of dispatch order,
                                    // 8 fault injection (image 0's bottom block never hands over its first row; short waits)
 };
+
+// StepP::xctl, 64-bit words, every counter in a 128-byte line of its own: [32 y] head of work list y (tickets taken), [32 y + 16] its
+// arrivals, y < IAF_XCTL_LISTS; [IAF_XCTL_DONE] lists complete; [IAF_XCTL_STICKY] sticky error; StepP::fin_ctl = xctl + IAF_XCTL_FIN
+#define IAF_XCTL_LISTS 32
+#define IAF_XCTL_DONE 1024
+#define IAF_XCTL_STICKY 1040
+#define IAF_XCTL_FIN 1536
+#define IAF_XCTL_WORDS 2048
 
 typedef void (*step_fn_t)(StepP);
 // kernel + dynamic LDS bytes for (n_h / 16, n_z / 16, depth_ar, image width, output rows per workgroup), or NULL

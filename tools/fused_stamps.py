@@ -53,8 +53,8 @@ if (t[:, 8] != 0).all():      # finer stamps (wave 0): prologue and the two epil
             m(12, 7), m(3, 12), m(4, 3), m(13, 4), m(5, 13)))
 if (t[:, 30] != 0).any():
     v = t[:, 30] - 1; lst = (v >> 32).astype(np.int64); tk = (v & 0xffffffff).astype(np.int64); blk = np.arange(len(t))
-    print("    tickets: %d of %d workgroups asked the list blockIdx %% 8; %d of %d drew the ticket blockIdx // 8 (what a static assignment would have given them)" % (
-        int((lst == blk % 8).sum()), len(t), int(((lst == blk % 8) & (tk == blk // 8)).sum()), len(t)))
+    print("    tickets: %d of %d workgroups took theirs from one of the four lists of XCD blockIdx %% 8; lists used %d; tickets per list max %d" % (
+        int((lst // 4 == blk % 8).sum()), len(t), len(set(lst.tolist())), int(np.bincount(lst).max())))
 if (t[:, 28] != 0).any():
     k = t[(t[:, 28] != 0) & (t[:, 29] != 0) & (t[:, 14] != 0) & (t[:, 18] != 0)]
     if len(k):
