@@ -118,10 +118,26 @@ constexpr int fused_acc_groups(int tiles_per_pixel_tile) { return tiles_per_pixe
 // that reads an imported row as two calls, <0, 2, 0> / <1, 1, 1> (the taps of the own rows) and <2, 3, 0> (the row below).
 template <int T0_, int NT_, int TAIL_, int NPAIR_>
 struct StepPart {
+    static constexpr int ILV = 0;
     static constexpr int T0 = T0_, NT = NT_, TAIL = TAIL_, NPAIR = NPAIR_, NF = NPAIR_ * NT_, NSTEP = NF + (TAIL_ ? NPAIR_ : 0);
     __device__ static void at(int sq, int& pair, int& tap) {              // sequence index -> (input pair, tap)
         if (!TAIL_ || sq < NF) { pair = sq / NT_; tap = T0_ + sq - pair * NT_; }
         else { pair = sq - NF; tap = 0; }
+    }
+};
+
+// The own-row taps of a channel-triangular layer in the exchange form -- tap (0,+1), every slot live, and the centre tap with its dead
+// blocks skipped -- INTERLEAVED (round 5): full step (pair 0), centre step (pair NPAIR-1: the shortest), full (1), centre (NPAIR-2), ...
+// A centre step multiplies as few as 6 MFMAs per wave; five of them in a row at the end of the part (the order until round 4) ran the
+// 2-step ring dry -- its look-ahead covers the time the two steps in between take, and two short steps are ~400 cycles against a fetch
+// latency of ~900: 37.8 cycles per MFMA in that part (profiles/r05/phase_table.md).  Between two full steps every gap is >= 36 MFMAs.
+template <int NPAIR_>
+struct StepPartIlv {
+    static constexpr int ILV = 1;
+    static constexpr int T0 = 1, NT = 1, TAIL = 1, NPAIR = NPAIR_, NF = 0, NSTEP = 2 * NPAIR_;
+    static constexpr int centre_pair(int sq) { return NPAIR_ - 1 - (sq >> 1); }
+    __device__ static void at(int sq, int& pair, int& tap) {
+        if (sq & 1) { pair = NPAIR_ - 1 - (sq >> 1); tap = 0; } else { pair = sq >> 1; tap = 1; }
     }
 };
 
@@ -149,6 +165,7 @@ constexpr int tri_live(int ntw, int nfull, int nht, int c, int gn, int gi, int t
 // taps, pair-major; `pair` is relative to the part's first input pair (conv_phase's pair0)
 template <int NP_, int PAR_>
 struct PairPart {
+    static constexpr int ILV = 0;
     static constexpr int T0 = 0, NT = NTAPS, TAIL = 0, NPAIR = NP_, NSTEP = (NP_ * NTAPS + 1 - PAR_) / 2, NF = NSTEP;
     __device__ static void at(int sq, int& pair, int& tap) {
         const int q = 2 * sq + PAR_;
@@ -248,7 +265,11 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
     constexpr int NPT0 = (G::rows_h(0) * W + 15) / 16;
     constexpr int NPTO = (R * W + 15) / 16;
     // look-ahead per phase: first hidden layer, the other hidden layers, output pair (see the header comment)
-    constexpr int RD0 = 2, RDH = 2, RDO = 3;
+#ifndef IAF_EXP_RDO_XCH
+#define IAF_EXP_RDO_XCH 3
+#endif
+    // (IAF_EXP_RDO_XCH: dev knob -- the output pair's look-ahead in the exchange-form TF kernels, which have the registers for more)
+    constexpr int RD0 = 2, RDH = 2, RDO = (XCH && VAR == 0 && NZT == 2) ? IAF_EXP_RDO_XCH : 3;
     constexpr int UA = (RD0 > RDH || DEPTH < 3 ? RD0 : RDH) + 1;     // slots of ring array A (layers 0, 2): layer 0, and layer 2 if any
     constexpr int UB = RDH + 1;                                      // ring array B (layers 1, 3)
     constexpr int UO = RDO + 1;
@@ -285,7 +306,7 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
     typedef StepPart<0, NTAPS, 0, NPAIR_H> PartFull;                        // a whole layer over n_h input channels, plain order
     typedef StepPart<1, NTAPS - 1, 1, NPAIR_H> PartTri;                     // ... channel-triangular: full taps, then the centre tap
     typedef StepPart<0, 2, 0, NPAIR_H> PartOwn;                             // XCH: the taps that read the workgroup's own rows
-    typedef StepPart<1, 1, 1, NPAIR_H> PartOwnTri;                          // ... of a triangular layer
+    typedef StepPartIlv<NPAIR_H> PartOwnTri;                                // ... of a triangular layer (full and centre steps interleaved)
     typedef StepPart<2, 3, 0, NPAIR_H> PartBelow;                           // XCH: the taps that read the row below (the imported one)
     typedef std::conditional_t<VAR == 0, PartTri, PartFull> PartHid;        // hidden layers l >= 1
     constexpr std::integral_constant<int, -1> ALL{};                       // every slot live
@@ -651,24 +672,34 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
             });
         };
         int s = s0;                                                  // ring slot of step s: s % U
+        // (grp_c: the wave group; PAIR's half h, whose waves own tiles h NHT/2 .. of the layer, one group per wave: 100 (1 + h) + wave)
+        constexpr int GRP = decltype(grp_c)::value;
+        constexpr bool PTRI = GRP >= 100;
+        constexpr int TGN = PTRI ? 4 : (XSPLIT ? GN : 1), TGI = GRP % 100;
+        constexpr int TNF = PTRI ? (NHT / 2) / 4 : NFULL, TNH = PTRI ? NHT / 2 : NHT, TT0 = PTRI ? (GRP / 100 - 1) * (NHT / 2) : 0;
         // the pair-major body: every slot live (its look-ahead into the first centre-tap steps may fetch a dead block: unused)
         constexpr int NF = P::NF, MAIN = (NF / U) * U;
+        if constexpr (P::ILV != 0) {
+            // full and centre steps interleaved (StepPartIlv): step sq multiplies the slots live in it and requests those live in sq + RD
+            static_for<P::NSTEP>([&](auto s_c) {
+                constexpr int sq = decltype(s_c)::value, sn = sq + RD;
+                constexpr int live = (sq & 1) ? (tri_live(NTW, TNF, TNH, P::centre_pair(sq), TGN, TGI, TT0) & LALLV) : LALLV;
+                constexpr int next = sn >= P::NSTEP ? 0 : (sn & 1) ? (tri_live(NTW, TNF, TNH, P::centre_pair(sn), TGN, TGI, TT0) & LALLV) : LALLV;
+                step_body(std::integral_constant<int, sq % U>{}, sq, std::integral_constant<int, live>{}, std::integral_constant<int, next>{});
+            });
+        } else {
         for (; s + U <= MAIN; s += U)
             static_for<U>([&](auto i) { step_body(i, s + decltype(i)::value, LALL, LALL); });
         static_for<NF - MAIN>([&](auto i) { step_body(i, MAIN + decltype(i)::value, LALL, LALL); });
         if constexpr (TRI) {
             // the centre tap: pair c multiplies the slots live at c and requests those live at c + RD
-            // (grp_c: the wave group; PAIR's half h, whose waves own tiles h NHT/2 .. of the layer, one group per wave: 100 (1 + h) + wave)
-            constexpr int GRP = decltype(grp_c)::value;
-            constexpr bool PTRI = GRP >= 100;
-            constexpr int TGN = PTRI ? 4 : (XSPLIT ? GN : 1), TGI = GRP % 100;
-            constexpr int TNF = PTRI ? (NHT / 2) / 4 : NFULL, TNH = PTRI ? NHT / 2 : NHT, TT0 = PTRI ? (GRP / 100 - 1) * (NHT / 2) : 0;
             static_for<P::NPAIR>([&](auto c_c) {
                 constexpr int c = decltype(c_c)::value, sq = NF + c;
                 constexpr int live = tri_live(NTW, TNF, TNH, c, TGN, TGI, TT0) & LALLV;
                 constexpr int next = (c + RD < P::NPAIR) ? (tri_live(NTW, TNF, TNH, c + RD, TGN, TGI, TT0) & LALLV) : 0;
                 step_body(std::integral_constant<int, sq % U>{}, sq, std::integral_constant<int, live>{}, std::integral_constant<int, next>{});
             });
+        }
         }
 #pragma unroll
         for (int q = 0; q < NPT; ++q)
