@@ -1263,7 +1263,8 @@ static int launch_fused_step(iaf_stack_t* s, step_fn_t fn, int R, size_t lds, co
         }
     }
     // posterior block on a recomputing kernel: its form with helper waves, where one is compiled (the 8-pixel BASELINE geometry)
-    if (fin && kl_part && base.mode == MODE_POSTERIOR && !q.xh && !pair && !(s->xch_knob & 16u)) {
+    static const int h8_env = getenv("IAF_STEP_HELPERS") ? atoi(getenv("IAF_STEP_HELPERS")) : -1;      // dev knob: 1 = also for the bare IAF step
+    if (((fin && kl_part && base.mode == MODE_POSTERIOR && !(s->xch_knob & 16u)) || h8_env == 1) && !q.xh && !pair) {
         size_t hl = 0;
         const int var = s->variant == IAF_VARIANT_TF ? 0 : s->variant == IAF_VARIANT_THEANO ? 1 : 2;
         if (step_fn_t fh = iaf_pick_step_fused_h(s->n_h / 16, s->n_z / 16, s->depth_ar, base.W, R, var, &hl))

@@ -255,6 +255,16 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
     constexpr int NTWH = NFULL + (NX ? 1 : 0);                   // tile slots per wave
     constexpr int NTWO = 2 * NZT / NW;                           // output pair: tiles per wave
     static_assert((2 * NZT) % NW == 0, "output tiles must split evenly over the waves");
+    // HLEFT (round 5): in the second hidden layer of a two-layer stack the left-over (tile, pixel tile) units -- one per compute wave: 0.5 of
+    // its 2.5 units at n_h = 160 -- are computed by the HELPER waves, one each, K loop and epilogue: a compute wave's K loops run at what one
+    // wave per SIMD can issue (~22 cycles per MFMA, profiles/r05/phase_table.md), its helper is idle from the moment the row below is in LDS,
+    // and the unit needs no partial sum from anybody (the helper runs all of the unit's taps).  The compute waves then hold NFULL slots.
+#ifndef IAF_EXP_HLEFT
+#define IAF_EXP_HLEFT 1
+#endif
+    constexpr bool HLEFT = IAF_EXP_HLEFT && HELP && !PAIR && DEPTH == 2 && XSPLIT && NX > 0 && NFULL > 0 &&
+                           (NHT - NX) / 2 >= NH / 32 - 1;     // (the left-over tiles' centre-tap blocks are all live: the helper walks the plain step order)
+    constexpr int NTW1 = HLEFT ? NFULL : NTWH;                   // slots of a compute wave in hidden layers l >= 1
     int htile[NTWH];
 #pragma unroll
     for (int j = 0; j < NTWH; ++j)      // (serpentine over the rounds: the dead centre-tap blocks of a wave's tiles add up evenly, see TRI)
@@ -575,6 +585,8 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
     // in_reg / in_s16 / in_c8: the input region (16-byte units); ROWS * W output pixels in NPT tiles.  The LAST tile slot is
     // multiplied only for the pixel tiles in EMASK (the wave's share of a left-over tile); all others for every pixel tile.
     // The caller has requested the part's first RD steps into ring slots 0 .. RD - 1.  accum_c: add to acc_out (second part).
+    // (qbase: the first pixel tile a conv_phase / hidden_epilogue call works on -- 0 everywhere but in the helper waves' left-over units, HLEFT)
+    int qbase = 0;
     auto conv_phase = [&](auto rd_c, auto npt_c, auto ntw_c, auto rows_c, auto emask_c, int in_reg, int in_s16, int in_c8, const f32x4* wbase,
                           int ncot, const int* tiles, f32x4 (*wr)[decltype(ntw_c)::value][3],
                           f32x4 (*acc_out)[decltype(ntw_c)::value], auto part_c, auto grp_c, auto accum_c, int pair0) {
@@ -590,12 +602,19 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
         constexpr int LALLV = (EMASK == 0 && NTW > 1) ? ((1 << (NTW - 1)) - 1) : -1;
         constexpr std::integral_constant<int, LALLV> LALL{};
         constexpr int RD = decltype(rd_c)::value, U = RD + 1;      // this phase's look-ahead; it uses slots 0 .. RD of its ring array
-        constexpr int PSG = fused_acc_groups(NTW);                 // accumulator groups of a unit's six part-products
+        // (grp_c: the wave group; PAIR's half h, whose waves own tiles h NHT/2 .. of the layer, one group per wave: 100 (1 + h) + wave;
+        //  300: a helper wave's left-over unit (HLEFT) -- every centre-tap block live, ONE accumulator group: the same sums in the same
+        //  order as the compute wave that holds the tile in the kernels without helpers, bit for bit)
+        constexpr int GRP = decltype(grp_c)::value;
+        //  400 + group: a compute wave of an HLEFT kernel in hidden layer 1 -- NFULL slots, but the accumulator groups of NTWH slots, so that
+        //  its sums too are those of the kernels without helpers)
+        constexpr bool TALL = GRP >= 300 && GRP < 400, PTRI = GRP >= 100 && GRP < 300, HCMP = GRP >= 400;
+        constexpr int PSG = TALL ? 1 : fused_acc_groups(HCMP ? NTWH : NTW);      // accumulator groups of a unit's six part-products
         f32x4 acc[PSG][NPT][NTW];
         int xb[NPT];
 #pragma unroll
         for (int q = 0; q < NPT; ++q) {
-            int pix = q * 16 + pl;
+            int pix = (q + qbase) * 16 + pl;
             pix = pix < ROWS * W ? pix : ROWS * W - 1;             // partially filled tile: a valid address, result unused
             const int row = pix / W, col = pix - row * W;
             xb[q] = in_reg + (row * RS + col + 1) * in_s16 + kk;
@@ -672,9 +691,6 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
             });
         };
         int s = s0;                                                  // ring slot of step s: s % U
-        // (grp_c: the wave group; PAIR's half h, whose waves own tiles h NHT/2 .. of the layer, one group per wave: 100 (1 + h) + wave)
-        constexpr int GRP = decltype(grp_c)::value;
-        constexpr bool PTRI = GRP >= 100;
         constexpr int TGN = PTRI ? 4 : (XSPLIT ? GN : 1), TGI = GRP % 100;
         constexpr int TNF = PTRI ? (NHT / 2) / 4 : NFULL, TNH = PTRI ? NHT / 2 : NHT, TT0 = PTRI ? (GRP / 100 - 1) * (NHT / 2) : 0;
         // the pair-major body: every slot live (its look-ahead into the first centre-tap steps may fetch a dead block: unused)
@@ -695,8 +711,8 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
             // the centre tap: pair c multiplies the slots live at c and requests those live at c + RD
             static_for<P::NPAIR>([&](auto c_c) {
                 constexpr int c = decltype(c_c)::value, sq = NF + c;
-                constexpr int live = tri_live(NTW, TNF, TNH, c, TGN, TGI, TT0) & LALLV;
-                constexpr int next = (c + RD < P::NPAIR) ? (tri_live(NTW, TNF, TNH, c + RD, TGN, TGI, TT0) & LALLV) : 0;
+                constexpr int live = TALL ? LALLV : (tri_live(NTW, TNF, TNH, c, TGN, TGI, TT0) & LALLV);
+                constexpr int next = (c + RD < P::NPAIR) ? (TALL ? LALLV : (tri_live(NTW, TNF, TNH, c + RD, TGN, TGI, TT0) & LALLV)) : 0;
                 step_body(std::integral_constant<int, sq % U>{}, sq, std::integral_constant<int, live>{}, std::integral_constant<int, next>{});
             });
         }
@@ -734,7 +750,7 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
             for (int j = 0; j < NTWH; ++j)
 #pragma unroll
                 for (int q = 0; q < NPT; ++q) {
-                    int pix = q * 16 + pl;
+                    int pix = (q + qbase) * 16 + pl;
                     pix = pix < ROWS * W ? pix : ROWS * W - 1;
                     const int tl = htile[j] < NHT ? htile[j] : NHT - 1;
                     const float* cr = (const float*)(smem + (size_t)G::CTX_OFF * 16) + (tl * 16 + 4 * kk) * G::CSTR + pix;
@@ -749,7 +765,7 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
             const f32x4 bi = bias[j];
             {
                 if (j == NTWH - 1 && !((EMASK >> q) & 1)) continue;
-                const int pix = q * 16 + pl;
+                const int pix = (q + qbase) * 16 + pl;
                 if (pix >= ROWS * W) continue;
                 const int row = pix / W, col = pix - row * W;
                 f32x4 v = acc[q][j] + bi;
@@ -1039,6 +1055,39 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
                     xch_import(l - 1, IN_REG);
                     __syncthreads();                              // row R of h_{l-1} is there
                 }
+                if constexpr (HLEFT) {
+                    // this helper's left-over unit of layer l: the tile its compute wave would have held in its last slot, the pixel tile of
+                    // that wave's group -- all of the layer's taps (the row below is in LDS), bias + ELU + split -> the layer's region
+                    const int hw = wave - NW_COMPUTE;
+                    constexpr int NPTL = (G::rows_h(l) * W + 15) / 16;
+                    static_for<GN>([&](auto g_c) {
+                        constexpr int GI = decltype(g_c)::value;
+                        constexpr int EM = fused_extra_mask(NPTL, GN, GI);
+                        static_assert(fused_popcount(EM) <= 1, "HLEFT: one pixel tile per left-over unit");
+                        if constexpr (EM != 0) {
+                            if (hw / NX != GI) return;
+                            int lt[1] = {NW * NFULL + hw % NX};
+                            qbase = EM == 1 ? 0 : EM == 2 ? 1 : EM == 4 ? 2 : 3;
+                            const f32x4* wbl = (const f32x4*)p.wp3[l];
+                            // (the unit is 6 MFMAs per step: a look-ahead of RDL steps = ~800 cycles of cover for its fragments; the steps in
+                            //  the order of the kernels without helpers: PartHid)
+                            constexpr int RDL = 6;
+                            f32x4 wrl[RDL + 1][1][3], accu[1][1], biu[1];
+                            static_for<RDL>([&](auto i) {
+                                ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}, wrl[decltype(i)::value], wbl, NHT, lt,
+                                          PartHid{}, decltype(i)::value, std::integral_constant<int, -1>{}, 0);
+                            });
+                            load_bias(std::integral_constant<int, 1>{}, lt, p.bias[l], biu);
+                            conv_phase(std::integral_constant<int, RDL>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{},
+                                       std::integral_constant<int, G::rows_h(l)>{}, std::integral_constant<int, 1>{}, IN_REG, H16, H8, wbl, NHT, lt,
+                                       wrl, accu, PartHid{}, std::integral_constant<int, 300>{}, std::integral_constant<bool, false>{}, 0);
+                            hidden_epilogue(std::integral_constant<int, 1>{}, std::integral_constant<int, G::rows_h(l)>{},
+                                            std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, lt,
+                                            accu, biu, OUT_REG, p.hsave[l], p.border[l], false);
+                            qbase = 0;
+                        }
+                    });
+                }
                 __syncthreads();                                  // layer l's epilogue done
                 xch_export(l, OUT_REG);
             });
@@ -1142,6 +1191,7 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
     const int opair_own = half ? NPAIR_H - NPO : 0, opair_rest = half ? 0 : NPO;
     if constexpr (PAIR) otile[0] = NZT * half + (wave >> 1);
     f32x4 wr1[UB][NTWH][3];          // hidden layer l uses ring l & 1 (wr0 / wr1): the other one receives layer l + 1's first steps
+    f32x4 wrh1[HLEFT ? UB : 1][NTW1][3];      // HLEFT: layer 1's ring of NFULL slots (wr1 is then unused)
     f32x4 wro[UO][NTWO][3];          // ring of the output pair
     const f32x4* wbo = (const f32x4*)p.wp3[DEPTH];
     auto preload_out = [&]() {
@@ -1169,6 +1219,12 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
             static_for<RDH>([&](auto i) {
                 ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWP * 3>{}, wrp[decltype(i)::value], wbn, NHT, ptile,
                           PartHid{}, decltype(i)::value, ALL, 0);
+            });
+        } else if constexpr (l + 1 < DEPTH && HLEFT) {
+            const f32x4* wbn = (const f32x4*)p.wp3[l + 1];
+            static_for<RDH>([&](auto i) {
+                ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTW1 * 3>{}, wrh1[decltype(i)::value], wbn, NHT, htile,
+                          PartH1{}, decltype(i)::value, ALL, 0);
             });
         } else if constexpr (l + 1 < DEPTH) {
             const f32x4* wbn = (const f32x4*)p.wp3[l + 1];
@@ -1236,7 +1292,49 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
         });
         __syncthreads();
     }
-    static_for<PAIR ? 0 : DEPTH - 1>([&](auto lm_c) {
+    if constexpr (HLEFT) {
+        // the second hidden layer with its left-over units in the helper waves: every compute wave multiplies NFULL whole tiles
+        constexpr int l = 1, IN_REG = G::HREG0, OUT_REG = G::HREG1;
+        {   // the staged context sat in the h_odd region: its zero columns again, before the epilogues fill the rest
+            constexpr int H1ROWS = G::rows_reg(1);
+            for (int i = tid; i < H1ROWS * 2 * H16; i += 256) {
+                const int rs = i / H16, u = i - rs * H16;
+                smem4[G::HREG1 + ((rs >> 1) * RS + (rs & 1) * (W + 1)) * H16 + u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        constexpr int NPTL = (G::rows_h(l) * W + 15) / 16, EALL = (1 << NPTL) - 1;
+        static_for<GN>([&](auto g_c) {                            // (the groups differ in the centre tap's dead blocks only)
+            constexpr int GI = decltype(g_c)::value;
+            if (xg != GI) return;
+            f32x4 accl[NPTL][NTW1], bil[NTW1];
+            load_bias(std::integral_constant<int, NTW1>{}, htile, p.bias[l], bil);
+            const f32x4* wbl = (const f32x4*)p.wp3[l];
+            conv_phase(std::integral_constant<int, RDH>{}, std::integral_constant<int, NPTL>{}, std::integral_constant<int, NTW1>{},
+                       std::integral_constant<int, G::rows_h(l)>{}, std::integral_constant<int, EALL>{}, IN_REG, H16, H8, wbl, NHT, htile,
+                       wrh1, accl, PartH1{}, std::integral_constant<int, 400 + GI>{}, SET, 0);
+            if constexpr (XCH) {
+                static_for<RDH>([&](auto i) {
+                    ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTW1 * 3>{}, wrh1[decltype(i)::value], wbl, NHT, htile,
+                              PartBelow{}, decltype(i)::value, ALL, 0);
+                });
+                IAF_FSTAMP(28);
+                __syncthreads();                                  // the helper waves have put the row below into row R of IN_REG
+                IAF_FSTAMP(15);
+                conv_phase(std::integral_constant<int, RDH>{}, std::integral_constant<int, NPTL>{}, std::integral_constant<int, NTW1>{},
+                           std::integral_constant<int, G::rows_h(l)>{}, std::integral_constant<int, EALL>{}, IN_REG, H16, H8, wbl, NHT, htile,
+                           wrh1, accl, PartBelow{}, std::integral_constant<int, 400 + GI>{}, ADD, 0);
+            }
+            IAF_FSTAMP(7);
+            load_final_operands();
+            preload_after(std::integral_constant<int, l>{});
+            hidden_epilogue(std::integral_constant<int, NPTL>{}, std::integral_constant<int, G::rows_h(l)>{},
+                            std::integral_constant<int, EALL>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, NTW1>{}, htile, accl,
+                            bil, OUT_REG, p.hsave[l], p.border[l], false);
+            IAF_FSTAMP(12);
+        });
+        __syncthreads();
+    }
+    static_for<(PAIR || HLEFT) ? 0 : DEPTH - 1>([&](auto lm_c) {
         constexpr int l = decltype(lm_c)::value + 1;              // hidden layer l reads h_{l-1}, writes h_l into the other region
         constexpr int IN_REG = ((l - 1) & 1) ? G::HREG1 : G::HREG0, OUT_REG = (l & 1) ? G::HREG1 : G::HREG0;
         if constexpr (l == 1) {   // the staged context sat in the h_odd region: its zero columns again, before the epilogue fills the rest
