@@ -52,6 +52,9 @@
 #define IAF_HELPER_PRIO 0
 #endif
 
+#ifndef IAF_EXP_HOUT
+#define IAF_EXP_HOUT 1
+#endif
 // XCH = 1: neighbouring row blocks EXCHANGE their halo rows instead of recomputing them (see the kernel's header note): a
 // hidden layer computes only the R rows its workgroup owns, its region holds one more row -- the first row of the block
 // below, imported -- and z has R + 1 rows.
@@ -71,7 +74,10 @@ struct StepGeom {
     static constexpr int HREG1 = HREG0 + rows_reg(0) * RS * H16;
     static constexpr int END = HREG1 + (DEPTH >= 2 ? rows_reg(1) * RS * H16 : 0);
     static constexpr int XB_STRIDE = 2 * NZ + 1;                                 // output exchange buffer [pixel][2 n_z] floats
-    static constexpr int XKP = PAIR ? 2 : 1;                                     // K parts of the output pair's sums (PAIR: two waves per tile)
+    // K parts of the output pair's sums: PAIR -- two waves per tile; HOUT (exchange form, n_z = 32, two hidden layers) -- the taps of the
+    // row below split between a compute wave and its helper
+    static constexpr bool HOUT = IAF_EXP_HOUT && XCH && !PAIR && NZT == 2 && DEPTH == 2;
+    static constexpr int XKP = (PAIR || HOUT) ? 2 : 1;
     static constexpr size_t xb_bytes() { return (size_t)XKP * R * W * XB_STRIDE * 4; }
     // (the last hidden layer sits in the h_odd region for an even depth: z + h_even are dead then; for an odd depth it sits in
     // h_even: the buffer goes into h_odd if it fits there, else behind everything)
@@ -161,6 +167,17 @@ constexpr int tri_live(int ntw, int nfull, int nht, int c, int gn, int gi, int t
         }
     return m;
 }
+// HOUT: the taps of the row below (2, 3, 4) x NPAIR input pairs, every second step (parity PAR): a compute wave takes the even steps of
+// its tiles, its helper wave -- idle once the row is in LDS -- the odd ones; the two sums meet in the exchange buffer
+template <int NPAIR_, int PAR_>
+struct BelowPar {
+    static constexpr int ILV = 0;
+    static constexpr int T0 = 2, NT = 3, TAIL = 0, NPAIR = NPAIR_, NSTEP = (3 * NPAIR_ + 1 - PAR_) / 2, NF = NSTEP;
+    __device__ static void at(int sq, int& pair, int& tap) {
+        const int q = 2 * sq + PAR_;
+        pair = q / 3; tap = 2 + q - 3 * pair;
+    }
+};
 // PAIR: the output pair's K steps of one of the two waves that share a tile -- every second step (parity PAR) of NP input pairs x 5
 // taps, pair-major; `pair` is relative to the part's first input pair (conv_phase's pair0)
 template <int NP_, int PAR_>
@@ -1094,7 +1111,39 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
             if constexpr (XCH) {
                 constexpr int LAST_REG = ((DEPTH - 1) & 1) ? G::HREG1 : G::HREG0;
                 xch_import(DEPTH - 1, LAST_REG);
-                __syncthreads();                                  // row R of the last hidden layer is there
+                if constexpr (G::HOUT) {
+                    // the output pair's taps of the row below, odd steps: this helper's compute wave's tiles, both pixel tiles
+                    constexpr int NPTO_ = (R * W + 15) / 16;
+                    const int hw = wave - NW_COMPUTE;
+                    int ot[NTWO];
+#pragma unroll
+                    for (int j = 0; j < NTWO; ++j) ot[j] = hw * NTWO + j;
+                    typedef BelowPar<NH / 32, 1> PartOBH;
+                    constexpr int RDOH = 3;
+                    const f32x4* wboh = (const f32x4*)p.wp3[DEPTH];
+                    f32x4 wroh[RDOH + 1][NTWO][3], accoh[NPTO_][NTWO];
+                    static_for<RDOH>([&](auto i) {
+                        ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWO * 3>{}, wroh[decltype(i)::value], wboh, 2 * NZT,
+                                  ot, PartOBH{}, decltype(i)::value, std::integral_constant<int, -1>{}, 0);
+                    });
+                    __syncthreads();                              // row R of the last hidden layer is there
+                    conv_phase(std::integral_constant<int, RDOH>{}, std::integral_constant<int, NPTO_>{}, std::integral_constant<int, NTWO>{},
+                               std::integral_constant<int, R>{}, std::integral_constant<int, (1 << NPTO_) - 1>{}, LAST_REG,
+                               H16, H8, wboh, 2 * NZT, ot, wroh, accoh, PartOBH{}, std::integral_constant<int, 0>{},
+                               std::integral_constant<bool, false>{}, 0);
+                    float* part1 = (float*)(smem + (size_t)G::XB_OFF * 16) + R * W * G::XB_STRIDE;
+#pragma unroll
+                    for (int j = 0; j < NTWO; ++j)
+#pragma unroll
+                        for (int q = 0; q < NPTO_; ++q) {
+                            const int pix = q * 16 + pl;
+                            if (pix >= R * W) continue;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) part1[pix * G::XB_STRIDE + ot[j] * 16 + 4 * kk + r] = accoh[q][j][r];
+                        }
+                } else {
+                    __syncthreads();                              // row R of the last hidden layer is there
+                }
             }
             if constexpr (PAIR) {
                 if (!((p.xknob & 8u) && b == 0 && rbk == 0 && half == 1)) pair_export();     // (test knob 8: one half is never handed over)
@@ -1420,16 +1469,17 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
                    std::integral_constant<int, R>{}, std::integral_constant<int, (1 << NPTO) - 1>{}, LAST_REG,
                    H16, H8, wbo, 2 * NZT, otile, wro, acco, PartO1{}, std::integral_constant<int, 0>{}, SET, 0);
         if constexpr (XCH) {
+            typedef std::conditional_t<G::HOUT, BelowPar<NPAIR_H, 0>, PartBelow> PartOB;      // (HOUT: the helper takes the odd steps)
             static_for<RDO>([&](auto i) {
                 ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWO * 3>{}, wro[decltype(i)::value], wbo, 2 * NZT,
-                          otile, PartBelow{}, decltype(i)::value, ALL, 0);
+                          otile, PartOB{}, decltype(i)::value, ALL, 0);
             });
             IAF_FSTAMP(29);
             __syncthreads();                                      // ... and the row below of the last hidden layer
             IAF_FSTAMP(21);
             conv_phase(std::integral_constant<int, RDO>{}, std::integral_constant<int, NPTO>{}, std::integral_constant<int, NTWO>{},
                        std::integral_constant<int, R>{}, std::integral_constant<int, (1 << NPTO) - 1>{}, LAST_REG,
-                       H16, H8, wbo, 2 * NZT, otile, wro, acco, PartBelow{}, std::integral_constant<int, 0>{}, ADD, 0);
+                       H16, H8, wbo, 2 * NZT, otile, wro, acco, PartOB{}, std::integral_constant<int, 0>{}, ADD, 0);
         }
         IAF_FSTAMP(4);
         float* mine = xbuf;
@@ -1471,7 +1521,7 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
         }
         m_raw += xbuf[pix * G::XB_STRIDE + cm];
         s_raw += xbuf[pix * G::XB_STRIDE + cm + 16];
-        if constexpr (PAIR) {                                    // (the other K part)
+        if constexpr (G::XKP == 2) {                             // (the other K part)
             m_raw += xbuf[(R * W + pix) * G::XB_STRIDE + cm];
             s_raw += xbuf[(R * W + pix) * G::XB_STRIDE + cm + 16];
         }
