@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void iaf_generic_conv3x3_kernel(GenPlainP p) {
 // GENERIC FALLBACK, BACKWARD (round 5): what TF's autodiff derives for layers.py:52-64 / 158-166 (tf_train.py:138) at channel counts
 // outside the MFMA path -- direct loops over NCHW tensors, one thread per output element or one workgroup per reduced element.
 // Slow by design (a 72-channel conv: milliseconds); it exists so that every shape the reference accepts (layers.py:116) TRAINS
-// through the same C ABI.  tests/test_hip_generic_backward.py holds it to the fp64 autograd oracle.
+// through the same C ABI (checked by tests/test_hip_generic_backward.py against fp64 autograd of the restated forward).
 //   dX  = [res +] act'(.) * (W^T dY)      (data gradient: the conv with mirrored taps)
 //   dW[t][ci][co] = sum_p a[p + shift(t)][ci] dY[p][co],  db[co] = sum_p dY[p][co]
 //   dV, dg through the mask and the weight norm (the arithmetic of wn_bwd_tile, iaf_kernels_backward.hpp)

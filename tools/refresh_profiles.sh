@@ -1,10 +1,10 @@
 # Refresh the measured evidence under gpurun_out/$ROUND/ (copied to profiles/$ROUND/ afterwards):
-#   gpurun --timeout 900 -- 'ROUND=r04 timeout 1500 bash tools/refresh_profiles.sh'
+#   gpurun --timeout 900 -- 'ROUND=r05 timeout 1500 bash tools/refresh_profiles.sh'
 # Every rocprofv3 pass runs under its own `timeout`: counter collection serialises the launches, and a PMC pass over the
 # hipGraph-replayed bench.py did not finish in 400 s (round 2) -- PMC passes go over tools/run_step.py (eager, a few launches).
 set -x
 R=$GRAFT_REPO_ROOT
-RD=${ROUND:-r04}
+RD=${ROUND:-r05}
 O=$R/gpurun_out/$RD
 mkdir -p $O/pmc
 cd /tmp && export TMPDIR=/tmp
@@ -14,9 +14,10 @@ python $R/bench.py --no-fuse-step > $O/bench_layer_by_layer_n1.json 2> /dev/null
 python $R/bench.py --layers > $O/bench_layers_n1.json 2> /dev/null
 python $R/bench.py --layers --model > $O/bench_model_n1.json 2> /dev/null
 python $R/bench.py --iw-eval --steps 100 > $O/bench_iw_eval_n1.json 2> /dev/null
-IAF_BENCH_FORCE_DIST=1 python $R/bench.py --train --steps 50 > $O/bench_train_n1.json 2> /dev/null
-IAF_BENCH_FORCE_DIST=1 python $R/bench.py --train --layers --steps 20 --warmup 5 > $O/bench_train_layers_n1.json 2> /dev/null
-IAF_BENCH_FORCE_DIST=1 python $R/bench.py --train --model --steps 20 --warmup 5 > $O/bench_train_model_n1.json 2> /dev/null
+python $R/bench.py --iw-eval --model --steps 50 --warmup 5 > $O/bench_iw_eval_model_n1.json 2> /dev/null
+python $R/bench.py --train --steps 50 > $O/bench_train_n1.json 2> /dev/null
+python $R/bench.py --train --layers --steps 20 --warmup 5 > $O/bench_train_layers_n1.json 2> /dev/null
+python $R/bench.py --train --model --steps 20 --warmup 5 > $O/bench_train_model_n1.json 2> /dev/null
 # kernel trace of the SAME command as the headline bench line
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb -o bench -- python $R/bench.py --no-cpu-baseline > $O/bench_rocprof_line.json 2>/dev/null
 cp /tmp/pb/*kernel_stats.csv $O/bench_kernel_stats.csv
@@ -29,7 +30,7 @@ f = glob.glob('/tmp/pb/*kernel_trace.csv')[0]
 acc = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
     acc[(r['Kernel_Name'], r.get('Grid_Size_X', r.get('Grid_Size', '')), r.get('Workgroup_Size_X', r.get('Workgroup_Size', '')))].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
-out = os.environ['GRAFT_REPO_ROOT'] + '/gpurun_out/' + os.environ.get('ROUND', 'r03') + '/bench_kernel_trace_by_grid.csv'
+out = os.environ['GRAFT_REPO_ROOT'] + '/gpurun_out/' + os.environ.get('ROUND', 'r05') + '/bench_kernel_trace_by_grid.csv'
 with open(out, 'w') as o:
     o.write('kernel,grid_x,wg_x,calls,avg_ns,total_ns\n')
     for (k, g, w), v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
@@ -45,6 +46,7 @@ python $R/tools/pmc_summary.py $O/pmc > $O/pmc_summary.txt 2>&1
 python $R/tools/make_profile_json.py $O $RD > $O/make_profile_json.txt 2>&1
 python $R/tools/bench_configs.py > $O/bench_configs.md 2>/dev/null
 for hw in 16 8; do python $R/tools/fused_stamps.py --hw $hw; done 2>&1 | grep -v amdgpu.ids > $O/fused_step_stamps.txt
+(IAF_STEP_HELPERS=0 python $R/tools/fused_stamps.py --hw 8; IAF_FUSE_PAIR=1 python $R/tools/fused_stamps.py --hw 8) 2>&1 | grep -v amdgpu.ids > $O/fused_step_stamps_8x8_other_forms.txt
 python $R/tools/layer_bench.py > $O/layer_bench.txt 2>&1
 python $R/tools/layer_train_bench.py > $O/layer_train_bench.txt 2>&1
 # which kernels a training step of one whole IAFLayer runs (data gradients on the bf16 matrix cores: EPI = 2 instantiations)
