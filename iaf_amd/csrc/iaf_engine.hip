@@ -109,7 +109,7 @@ struct iaf_stack {
     // may still name them.
     struct XchSet {
         hipStream_t st = nullptr;
-        char* buf = nullptr; size_t bytes = 0;                 // rows: all 0xff between launches
+        char* buf = nullptr; size_t bytes = 0;                 // rows: every dword IAF_XSENT between launches
         unsigned long long* ctl = nullptr;                     // heads, arrivals, sticky error (StepP::xctl), arrivals of the in-launch KL finish (StepP::fin_ctl = xctl + IAF_XCTL_FIN): zero between launches
     };
     std::deque<XchSet> xch_sets;           // (stable addresses: a launch holds a pointer to its set outside the lock)
@@ -506,10 +506,10 @@ static int xch_reset_sets(iaf_stack_t* s) {
     HIP_TRY(hipDeviceSynchronize());
     std::lock_guard<std::mutex> lk(s->xch_mu);
     for (auto& x : s->xch_sets) {
-        HIP_TRY(hipMemset(x.buf, 0xff, x.bytes));
+        HIP_TRY(hipMemsetD32((hipDeviceptr_t)x.buf, (int)IAF_XSENT, x.bytes / 4));
         HIP_TRY(hipMemset(x.ctl, 0, IAF_XCTL_WORDS * sizeof(unsigned long long)));
     }
-    for (auto& r : s->xch_retired_rows) HIP_TRY(hipMemset(r.first, 0xff, r.second));     // (a captured graph may still name them)
+    for (auto& r : s->xch_retired_rows) HIP_TRY(hipMemsetD32((hipDeviceptr_t)r.first, (int)IAF_XSENT, r.second / 4));     // (a captured graph may still name them)
     if (s->xch_err_host) *(volatile unsigned*)s->xch_err_host = 0u;
     return IAF_OK;
 }
@@ -1075,7 +1075,7 @@ static step_fn_t fused_step_pair(const iaf_stack_t* s, int W, size_t* lds, size_
 // The exchange set of stream st, grown to [layer][B * nrb] rows of xrow bytes (pair form, depth_ar = 2: [B * nrb][2 halves] of xrow bytes): created on the stream's first such launch -- not
 // inside a stream capture (there: the stream's set, else the newest one that is large enough, else NULL and the caller runs what
 // it ran before; warm up before capturing, as for the LDS cap).  A set that grows keeps its counters; the new rows start as
-// "nothing there yet" (0xff).  Outgrown rows stay alive with the stack: a captured graph may still name them.
+// "nothing there yet" (IAF_XSENT).  Outgrown rows stay alive with the stack: a captured graph may still name them.
 static iaf_stack::XchSet* xch_prepare(iaf_stack_t* s, int B, int nrb, size_t xrow, hipStream_t st) {
     std::lock_guard<std::mutex> lk(s->xch_mu);
     iaf_stack::XchSet* x = nullptr;
@@ -1102,7 +1102,8 @@ static iaf_stack::XchSet* xch_prepare(iaf_stack_t* s, int B, int nrb, size_t xro
     }
     char* nb = nullptr;
     unsigned long long* nc = x ? x->ctl : nullptr;
-    bool ok = hipMalloc((void**)&nb, need) == hipSuccess && hipMemsetAsync(nb, 0xff, need, st) == hipSuccess;    // (ordered in front of the launch)
+    bool ok = hipMalloc((void**)&nb, need) == hipSuccess &&
+              hipMemsetD32Async((hipDeviceptr_t)nb, (int)IAF_XSENT, need / 4, st) == hipSuccess;    // (ordered in front of the launch)
     if (ok && !nc) ok = hipMalloc((void**)&nc, IAF_XCTL_WORDS * sizeof(unsigned long long)) == hipSuccess &&
                         hipMemsetAsync(nc, 0, IAF_XCTL_WORDS * sizeof(unsigned long long), st) == hipSuccess;
     if (!ok) {

@@ -459,12 +459,14 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
     // p.xctl (64-bit words; every counter in a 128-byte line of its own -- 512 read-modify-writes of ONE line took 12 k cycles of
     // this prologue when heads and arrivals shared one): [32 y] head of work list y = tickets taken; [32 y + 16] holders of list y
     // that are done with the heads; [IAF_XCTL_DONE] lists whose holders all are; [IAF_XCTL_STICKY] sticky error.
-    // List y (y < 32) holds the images b = y, y + 32, y + 64, ... < B, their row blocks bottom first: ticket t of list y is (image
-    // y + 32 (t / nrb), row block nrb - 1 - t % nrb).  A workgroup asks one of the four lists of the XCD it runs on first (HW_REG_XCC_ID;
-    // which of the four: its CU) -- a head is a counter on the memory side that answers its pullers one after the other: eight per head
-    // at B = 32 since round 5, 32 per head with the eight lists of round 4, whose tickets took ~3 k cycles of this prologue -- and the
-    // other lists in turn when that one is dry: grid = number of items, so every workgroup finds exactly one.  The placement decides
-    // which head answers, never what is computed.
+    // List y (y < 8) holds the images b = y, y + 8, y + 16, ... < B, their row blocks bottom first: ticket t of list y is (image
+    // y + 8 (t / nrb), row block nrb - 1 - t % nrb).  A workgroup asks the list of the XCD it runs on first (HW_REG_XCC_ID) -- the
+    // dispatcher deals workgroups round robin over the XCDs, so at B = 8 k every list has exactly as many pullers as items and nobody
+    // steals -- and the other lists in turn when that one is dry (lists that hold nothing at B < 8 are never asked): grid = number of
+    // items, so every workgroup finds exactly one.  The placement decides which head answers, never what is computed.  (A ticket costs
+    // ~3.3 k cycles: the latency of one agent-scope read-modify-write with return, not contention -- four lists per XCD, picked by CU id,
+    // changed nothing in the balanced case and cost up to 30 k cycles where the surplus workgroups of an unevenly used list had to steal:
+    // profiles/r05/experiments/ticket_lists.txt.)
     // The last holder of a list to arrive counts its list at [IAF_XCTL_DONE]; the one that completes that count (every ticket of the
     // launch is taken by then) puts heads and arrival counts back to zero for the next launch on these buffers.
     constexpr unsigned XNLST = IAF_XCTL_LISTS;
@@ -479,17 +481,12 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
     auto xch_take_begin = [&]() {
         if constexpr (TKT) {
             if (tid == 0) {
-                // 32 lists, four per XCD (round 5): a head is an agent-scope counter on the memory side, its 32 pullers per launch were
-                // served one after the other -- ~3 k cycles of this prologue at eight lists (profiles/r05/experiments/ticket_lists.txt);
-                // which of its XCD's four lists a workgroup asks first is decided by the CU it runs on
-                unsigned hwid = 0;
                 asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
-                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
                 xcc &= 7u;
-                xlist = xcc * 4u + ((((hwid >> 8) & 15u) + ((hwid >> 13) & 7u)) & 3u);      // (CU_ID + SE_ID) & 3
+                xlist = xcc & (XNLST - 1u);                                               // one list per XCD
                 if (p.xknob & 1u) xlist = (blockIdx.x * 2654435761u >> 13) & (XNLST - 1u);        // test knob: lists that ignore the placement
-                xnl = (unsigned)p.B < XNLST ? (unsigned)p.B : XNLST;                           // lists that hold anything: y < min(B, 32)
-                xlist %= xnl;
+                xnl = (unsigned)p.B < XNLST ? (unsigned)p.B : XNLST;                           // lists that hold anything: y < min(B, 8)
+                if (xnl < XNLST) xlist %= xnl;
                 if (p.xknob & 2u)                                                       // test knob: tickets out of dispatch order
                     for (unsigned i = 0, n = (blockIdx.x * 40503u >> 4) & 63u; i < n; ++i) __builtin_amdgcn_s_sleep(64);
                 xt0 = __hip_atomic_fetch_add(p.xctl + 32 * xlist, 1ull, __ATOMIC_RELAXED, XSCOPE);
@@ -828,7 +825,7 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
     };
     // ---- XCH: halo rows through memory ---------------------------------------------------------------------------------
     // p.xh [layer][B * nrb][W slots x H16 x 16 bytes]: row 0 of block (b, k)'s hidden layer, as it sits in LDS.
-    // THE DATA IS THE FLAG: between launches every dword of the buffer holds XSENT (two bf16 NaNs of a payload no arithmetic
+    // THE DATA IS THE FLAG: between launches every dword of the buffer holds XSENT (two SIGNALLING bf16 NaNs: no arithmetic
     // produces).  The producer copies the row from LDS -- where its epilogue has just put it, behind the epilogue's barrier -- with
     // 16-byte stores, consecutive lanes to consecutive addresses (whole 128-byte lines leave the CU; the 8-byte pieces round 3
     // stored straight from the MFMA layout, 320 bytes apart, needed ~4 us to land) and is done: no acknowledgement to wait for,
@@ -846,7 +843,7 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
     // blocks above), raises the sticky word p.xctl[IAF_XCTL_STICKY] -- the buffer can no longer be trusted to be all XSENT, so every later
     // launch on it imports NaN without looking -- and the host-visible p.xerr, which the next call on the stack returns as
     // IAF_ERR_EXCHANGE; iaf_stack_set_halo_exchange re-arms the buffers.  Wrong numbers never leave silently.
-    constexpr unsigned XSENT = 0xffffffffu;
+    constexpr unsigned XSENT = IAF_XSENT;
     constexpr int XSC1 = 16;                                                         // aux bits of the buffer instructions: sc1
     constexpr int XNU = W * H16, XNL = (XNU + 255) / 256;                            // 16-byte units of a row; per lane
     auto xch_rsrc = [&](int l, int slot) -> __amdgpu_buffer_rsrc_t {                  // one row as a buffer: accesses past its end are dropped
@@ -867,19 +864,10 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
                 f32x4 t[XNLH];
 #pragma unroll
                 for (int u = 0; u < XNLH; ++u) { const int i = htid + 256 * u; t[u] = src[i < XNU ? i : XNU - 1]; }
-                // The pattern means "not there yet".  No arithmetic produces it, but NaNs with all-ones payloads can come in with the
-                // caller's data (uninitialised memory) and reach an activation pair unchanged: such a pair leaves as the canonical NaN
-                // pair -- NaN either way, which is the caller's signal (tf_train.py:283-285), and never an exchange that "gives up".
-                u32x4 tw[XNLH];
-#pragma unroll
-                for (int u = 0; u < XNLH; ++u) {
-                    tw[u] = __builtin_bit_cast(u32x4, t[u]);
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) tw[u][d] = tw[u][d] == XSENT ? 0x7fc07fc0u : tw[u][d];
-                }
+                // (no data dword can equal the "not there yet" pattern -- a pair of signalling bf16 NaNs, IAF_XSENT -- so the row leaves as it is)
 #pragma unroll
                 for (int u = 0; u < XNLH; ++u)
-                    __builtin_amdgcn_raw_buffer_store_b128(tw[u], r, 16 * (htid + 256 * u), 0, XSC1);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t[u]), r, 16 * (htid + 256 * u), 0, XSC1);
                 if (l == 0 && p.dbg && htid == 0) {
                     p.dbg[(size_t)blockIdx.x * 32 + 27] = __builtin_readcyclecounter();
                     p.dbg[(size_t)blockIdx.x * 32 + 26] = (unsigned long long)xslot + 1;
@@ -964,10 +952,6 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
             for (int u = 0; u < PNL; ++u) {
                 const int i = htid + 256 * u;
                 t[u] = __builtin_bit_cast(u32x4, smem4[pair_lds(i < G::PUNITS ? i : G::PUNITS - 1, half)]);
-                // the pattern means "not there yet": a NaN pair that happens to carry it (all-ones payloads come in with the caller's
-                // data, e.g. uninitialised memory) leaves as the canonical NaN pair -- NaN either way (tf_train.py:283-285)
-#pragma unroll
-                for (int d = 0; d < 4; ++d) t[u][d] = t[u][d] == XSENT ? 0x7fc07fc0u : t[u][d];
             }
 #pragma unroll
             for (int u = 0; u < PNL; ++u)
@@ -1469,7 +1453,8 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
                    std::integral_constant<int, R>{}, std::integral_constant<int, (1 << NPTO) - 1>{}, LAST_REG,
                    H16, H8, wbo, 2 * NZT, otile, wro, acco, PartO1{}, std::integral_constant<int, 0>{}, SET, 0);
         if constexpr (XCH) {
-            typedef std::conditional_t<G::HOUT, BelowPar<NPAIR_H, 0>, PartBelow> PartOB;      // (HOUT: the helper takes the odd steps)
+            // (HOUT: the helper takes the odd steps; 10 steps here and tap (+1,+1)'s 5 there was no faster: 48.8 k against 48.5 k cycles)
+            typedef std::conditional_t<G::HOUT, BelowPar<NPAIR_H, 0>, PartBelow> PartOB;
             static_for<RDO>([&](auto i) {
                 ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWO * 3>{}, wro[decltype(i)::value], wbo, 2 * NZT,
                           otile, PartOB{}, decltype(i)::value, ALL, 0);

@@ -37,7 +37,7 @@ struct StepP {
     unsigned long long* fin_ctl;
     float fin_kl_min;
     // XCH kernels (halo rows exchanged between the row blocks of an image instead of recomputed; iaf_step_fused.hpp "XCH"):
-    char* xh;                      // rows [layer][B * nrb][xrow bytes]; every 8-byte piece = 0xff..ff between launches (the data is the flag)
+    char* xh;                      // rows [layer][B * nrb][xrow bytes]; every dword = IAF_XSENT between launches (the data is the flag)
                                    // (PAIR kernels: [B * nrb][half][prow bytes], the halves of the last hidden region the partners swap)
     unsigned long long* xctl;      // [32 y] head of work list y (tickets taken), [32 y + 16] its arrivals, [IAF_XCTL_DONE] lists complete,
                                    // [IAF_XCTL_STICKY] sticky error -- a 128-byte line each; zero between launches
@@ -48,11 +48,20 @@ struct StepP {
 
 // StepP::xctl, 64-bit words, every counter in a 128-byte line of its own: [32 y] head of work list y (tickets taken), [32 y + 16] its
 // arrivals, y < IAF_XCTL_LISTS; [IAF_XCTL_DONE] lists complete; [IAF_XCTL_STICKY] sticky error; StepP::fin_ctl = xctl + IAF_XCTL_FIN
-#define IAF_XCTL_LISTS 32
+#define IAF_XCTL_LISTS 8          /* one per XCD; 32 (four per XCD, picked by CU id) was tried in round 5: where an XCD's CUs are spread unevenly
+                                     over its four lists the surplus workgroups steal, one memory-side round trip per dry list -- up to 30 k
+                                     cycles of prologue on some boxes (profiles/r05/experiments/ticket_lists.txt) */
 #define IAF_XCTL_DONE 1024
 #define IAF_XCTL_STICKY 1040
 #define IAF_XCTL_FIN 1536
 #define IAF_XCTL_WORDS 2048
+// "Not there yet" in the hand-over buffers (StepP::xh): every dword holds this pattern between launches.  A pair of SIGNALLING bf16 NaNs
+// (exponent all ones, quiet bit clear): what travels through those buffers are hidden activations -- results of arithmetic (bias + ELU,
+// then the bf16 split), and arithmetic only ever returns QUIET NaNs (IEEE mode, which HIP kernels run in), whatever payload a caller's NaN
+// carried in.  No data dword can equal it, so the consumers' "has every unit arrived" test needs no fix-up on the producers' side (round 5
+// first used 0xffffffff -- which a NaN of all ones in the inputs does reach -- plus a fix-up in the exporting helper waves: 0.7 us per
+// 16x16 launch, VALU work in waves that share their SIMD's issue with a compute wave).
+#define IAF_XSENT 0xffbfffbfu
 
 typedef void (*step_fn_t)(StepP);
 // kernel + dynamic LDS bytes for (n_h / 16, n_z / 16, depth_ar, image width, output rows per workgroup), or NULL

@@ -713,9 +713,12 @@ def test_batch_objects_reject_misuse(amd):
     masked = amd.WNConv2d(32, 32, ar_mask=True)
     with pytest.raises(ValueError):                       # batched prep is for plain convs (IAF_ERR_UNSUPPORTED)
         amd.ConvPrepBatch([masked])
-    tiny = amd.WNConv2d(6, 10)                            # fallback-path conv: no training support
+    tiny = amd.WNConv2d(6, 10)                            # fallback-path conv: trains since round 5 (tests/test_hip_generic_backward.py),
+    tiny.set_training(True)                               # but not through the batched weight-norm backward (IAF_ERR_UNSUPPORTED)
     with pytest.raises(ValueError):
-        tiny.set_training(True)
+        amd.WnBwdBatch(convs=[tiny])
+    with pytest.raises(ValueError):                       # a masked single conv still has no backward
+        masked.set_training(True)
     conv = amd.WNConv2d(32, 32)
     with pytest.raises(amd._capi.IafHipError):            # deferral needs set_training first (IAF_ERR_NOT_PREPARED)
         amd.WnBwdBatch(convs=[conv])

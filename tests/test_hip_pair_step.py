@@ -11,7 +11,8 @@ device memory.  Same protocol as the halo exchange of the 16-pixel rows (tests/t
    ExchangeError from the next call, the recomputing kernel from then on, the pair form back after set_halo_exchange(True);
  * the form is OPT-IN (knob 32): measured, it is slower than the one-row kernel at the BASELINE batch size (18.9 vs 17.0 us: the K
    loops are bound by what one wave per SIMD can issue, not by the weight port; profiles/r05/experiments/pair_form.txt);
- * NaN inputs whose bit pattern is the "not there yet" pattern are data, not an exchange failure."""
+ * NaN inputs are data, not an exchange failure, whatever their payload: "not there yet" is a pair of SIGNALLING
+   bf16 NaNs, which no arithmetic result can be; a NaN of all ones (round 4's pattern) and the pattern itself go in as inputs."""
 import numpy as np
 import pytest
 import torch
@@ -228,9 +229,10 @@ def test_a_partner_that_never_hands_over_is_loud_and_the_stack_recovers(amd):
 
 @pytest.mark.parametrize("hw", [8, 16])
 def test_nan_inputs_with_the_all_ones_pattern_are_data_not_an_exchange_failure(amd, hw):
-    """The hand-overs treat a dword of all ones as "not there yet".  A caller's NaN may carry exactly that pattern (uninitialised memory);
-    it reaches the activations of a channel pair unchanged (x + NaN keeps the payload) and must then travel as a NaN, not stall the
-    consumer until its bounded wait gives up: NaN in the outputs that depend on it, the rest untouched, no ExchangeError."""
+    """Until round 5 the hand-overs treated a dword of all ones as "not there yet"; a caller's NaN may carry exactly that pattern
+    (uninitialised memory) and reaches the activations of a channel pair unchanged (x + NaN keeps the payload): the consumer stalled until
+    its bounded wait gave up.  Now the pattern is one no arithmetic produces: NaN in the outputs that depend on the inputs' NaNs, the rest
+    untouched, no ExchangeError."""
     ps, rc, _ = _stacks(amd, 19)
     B = 8
     assert ps.step_pairs(B, hw, hw) if hw == 8 else ps.step_exchanges(B, hw, hw)
@@ -244,6 +246,12 @@ def test_nan_inputs_with_the_all_ones_pattern_are_data_not_an_exchange_failure(a
     for img, chans, row in ((0, slice(0, 2), 2), (1, slice(96, 98), 4), (2, slice(158, 160), hw - 2)):
         ctx[img, chans, row, 3] = allones                        # an adjacent channel pair = one dword of a bf16 plane
     z[3, 4:6, 2, 5] = allones
+    # ... and the pattern the buffers really hold between launches (IAF_XSENT, a pair of SIGNALLING bf16 NaNs) as an fp32 input: arithmetic
+    # quiets it on the way, so it cannot reach an exported activation either
+    snan = torch.tensor([0xffbfffbf - (1 << 32)] * 2, dtype=torch.int32, device="cuda").view(torch.float32)
+    assert torch.isnan(snan).all()
+    ctx[0, 8:10, 2, 7] = snan
+    z[3, 8:10, 2, 9 % hw] = snan
     for rep in range(2):
         zx, sx = ps.iaf_step(z, ctx)
         torch.cuda.synchronize()
