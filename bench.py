@@ -763,9 +763,11 @@ def model_train_bench(args, depths, dist, rank, n_gpus):
     obj0 = float(keep["fb"]["obj"].item())
     elapsed, graphed, exchange = _run_segmented(args, segments, red, flat, n_gpus, dist)
     obj1 = float(keep["fb"]["obj"].item())
+    xerr = model.exchange_errors()                         # (a NaN objective with a non-zero count would be the hand-over, not the numerics)
     if rank != 0:
         return
     exchange["rccl"] = bool(red.comm is not None)
+    exchange["halo_exchange_errors"] = xerr
     exchange["messages"] = len(bucket_names) if red.active else 0
     exchange["bytes"] = 4 * flat.params.numel()
     emit({

@@ -512,6 +512,12 @@ class CVAE1(object):
                 on_bucket(si)
         return F["x_out"], F["obj"], F["grads"]
 
+    def exchange_errors(self):
+        """bounded waits of the hand-overs inside the one-launch IAF steps that gave up, over all layers (0 = never; it synchronises the
+        device).  A NaN loss with a non-zero count means the exchange, not the numerics: re-arm with ARStack.set_halo_exchange(True) and,
+        if the step is replayed from a hipGraph, capture it again (include/iaf_hip.h)."""
+        return sum(layer.posterior.stack.exchange_errors() for level in self.layers for layer in level)
+
     def bits_per_dim(self, loss, batch_size):
         """tf_train.py:133 for one tower: loss / (log 2 * num_pixels * batch_size)"""
         return float(loss) / (math.log(2.) * 3 * self.image_size ** 2 * batch_size)

@@ -337,7 +337,11 @@ int iaf_stack_step_is_fused(const iaf_stack_t* s, int B, int H, int W);
  *   and raises the stack's error word; launches already queued on those buffers import NaN without looking (the buffers can no
  *   longer be trusted); the NEXT call on the stack returns IAF_ERR_EXCHANGE once (no synchronisation needed: the word sits in
  *   mapped host memory) and the stack goes on with the recomputing kernels until iaf_stack_set_halo_exchange(s, 1) re-arms
- *   the exchange.
+ *   the exchange.  A captured hipGraph holds the exchange-form launch itself: REPLAYS of it keep importing NaN (no host code runs that
+ *   could switch kernels) until the stack is re-armed AND the graph is captured again -- a training loop that replays graphs should read
+ *   iaf_stack_exchange_errors (or, from Python, CVAE1.exchange_errors()) when its loss turns NaN.
+ *   The pattern: every dword of the row buffers holds 0xffbfffbf between launches, a pair of SIGNALLING bf16 NaNs.  The rows carry hidden
+ *   activations, results of arithmetic, and arithmetic returns quiet NaNs only: a caller's NaN -- whatever its payload -- travels as data.
  * iaf_stack_exchange_errors: *errors = the error word (0 = never gave up; it synchronises the device so that every launch so
  * far is accounted for).  IAF_FUSE_XCH=0 in the environment keeps the recomputing kernel. */
 int iaf_stack_exchange_errors(const iaf_stack_t* s, unsigned* errors);
