@@ -129,7 +129,7 @@ SIGNATURES = {
     "iaf_conv3x3_forward": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, ctypes.POINTER(_vp),
                                            ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                            ctypes.c_int, _vp]),
-    "iaf_conv3x3_set_debug": (ctypes.c_int, [_vp]),
+    "iaf_conv3x3_set_debug": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t]),
     "iaf_image_to_float": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_size_t, ctypes.c_int, _vp]),
     "iaf_convk_weightnorm": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
     "iaf_convk_forward": (ctypes.c_int, [_vp, _vp, _vp, _vp] + [ctypes.c_int] * 9 + [_vp]),

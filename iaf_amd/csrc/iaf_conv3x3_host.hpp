@@ -354,9 +354,9 @@ static bool conv3x3_bf3_shape(GemmLayer& L, int choice, long long P, int W) {
     return bf3_plain_lds_bytes(L.cin, W, L.b_nt, L.b_ppw, L.b_pxt, L.b_ks, L.b_wco) <= 160 * 1024;
 }
 
-// dev tool (tools/conv_stamps.py): per-workgroup cycle stamps of the bf16x3 plain-conv launches, [grid][8] u64 (NULL: off)
-static unsigned long long* g_conv_dbg = nullptr;
-extern "C" int iaf_conv3x3_set_debug(void* buf) { g_conv_dbg = (unsigned long long*)buf; return IAF_OK; }
+// dev tool (tools/conv_stamps.py): per-workgroup cycle stamps of THIS conv's bf16x3 plain-conv launches, [grid][8] u64 in a caller
+// buffer of `bytes` bytes (NULL: off).  Per object and size-checked at every launch (it was one process-global pointer
+// that every conv's launches on every stream wrote through without a bound); declared here, defined behind the object's definition.
 
 static int conv3x3_launch(GemmLayer& L, ConvP& p, int epi_sel, int inmode, bool masked, bool mirror, hipStream_t st,
                           int variant = IAF_VARIANT_TF, int bf3_choice = 3) {
@@ -379,7 +379,7 @@ static int conv3x3_launch(GemmLayer& L, ConvP& p, int epi_sel, int inmode, bool 
         dim3 grid((p.P + tm - 1) / tm, L.ncot / (L.b_nt * L.b_wco));
         p.gx = (int)grid.x;
         p.lds_bytes = (int)lds;
-        p.dbg = g_conv_dbg;
+        p.dbg = (L.dbg && (size_t)grid.x * grid.y * 8 * sizeof(unsigned long long) <= L.dbg_bytes) ? L.dbg : nullptr;
         hipLaunchKernelGGL(fn, grid, dim3(64 * L.b_pxt * L.b_ks * L.b_wco), lds, st, p);
         return (int)hipGetLastError();
     }
@@ -726,6 +726,13 @@ extern "C" int iaf_discretized_logistic(const float* mean, const float* logscale
 // Passes: (1) pack dY and a pixel-major, (2) data gradient = the SAME conv kernel on the transposed packs with mirrored
 // taps (EPI_DGRAD, 9 taps), (3) MFMA weight gradient over pixel ranges + reduce, (4) weight-norm backward.
 // ---------------------------------------------------------------------------------------------
+extern "C" int iaf_conv3x3_set_debug(iaf_conv3x3_t* c, void* buf, size_t bytes) {
+    if (!c) return IAF_ERR_NULL;
+    c->L.dbg = (unsigned long long*)buf; c->L.dbg_bytes = buf ? bytes : 0;
+    c->T.dbg = c->L.dbg; c->T.dbg_bytes = c->L.dbg_bytes;      // (the data gradient runs the transposed problem T)
+    return IAF_OK;
+}
+
 extern "C" int iaf_conv3x3_set_training(iaf_conv3x3_t* c, int on) {
     if (!c) return IAF_ERR_NULL;
     if (c->mask_mode) return IAF_ERR_UNSUPPORTED;
@@ -742,6 +749,7 @@ extern "C" int iaf_conv3x3_set_training(iaf_conv3x3_t* c, int on) {
     T = GemmLayer();
     T.cin = L.cout; T.cout = L.cin; T.nchunk = L.ncot; T.ncot = L.nchunk; T.zerodiag = 0; T.npair = 1; T.full3x3 = true;
     T.wp = L.wpt; T.wp3 = L.wpt3; T.nt = 1; T.pxt = 4; T.wco = 1; T.ks = 1; T.user_tuned = false;
+    T.dbg = L.dbg; T.dbg_bytes = L.dbg_bytes;
     c->training = true;
     c->prepared = false;      // the transposed pack is written by the next prepare
     return IAF_OK;

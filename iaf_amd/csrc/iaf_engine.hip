@@ -89,6 +89,7 @@ struct GemmLayer {
     int nt, pxt, wco, ks;
     bool user_tuned = false;
     bool full3x3 = false;      // plain 9-tap conv (iaf_conv3x3): halo on both sides of the pixel tile
+    unsigned long long* dbg = nullptr; size_t dbg_bytes = 0;   // dev tool (iaf_conv3x3_set_debug): cycle stamps of THIS conv's bf16x3 launches
     double live_macs_per_px, dense_macs_per_px;
 };
 

@@ -468,9 +468,10 @@ int iaf_conv3x3_wn_bwd_batch_run(iaf_conv3x3_wn_bwd_batch_t* b, const float* con
 int iaf_conv3x3_wn_bwd_batch_destroy(iaf_conv3x3_wn_bwd_batch_t* b);
 /* launch shape override (nt = 0 restores the automatic choice); see iaf_stack_set_tuning */
 int iaf_conv3x3_set_tuning(iaf_conv3x3_t* c, int nt, int pxt, int wco, int ks);
-/* dev tool (tools/conv_stamps.py): buf = device array [workgroups][8] of u64 that the bf16x3 plain-conv launches fill with cycle
- * stamps (start, weight ring primed, -, tile staged, K loop done, partial sums exchanged, stores issued); NULL switches it off */
-int iaf_conv3x3_set_debug(void* buf);
+/* dev tool (tools/conv_stamps.py): buf = device array [workgroups][8] of u64, `bytes` long, that THIS conv's bf16x3 launches fill with
+ * cycle stamps (start, weight ring primed, -, tile staged, K loop done, partial sums exchanged, stores issued) -- a launch whose grid
+ * does not fit `bytes` leaves it alone; NULL switches it off */
+int iaf_conv3x3_set_debug(iaf_conv3x3_t* c, void* buf, size_t bytes);
 /* arithmetic of the forward conv, as iaf_stack_set_precision: IAF_PRECISION_BF16X3 (default; plain convs with c_in % 32 == 0
  * from 4096 pixels on, or as iaf_conv3x3_autotune measured) or IAF_PRECISION_F32 (the exact-fp32 MFMA kernel always; masked
  * single convs, deconvs and the backward kernels run it regardless).  iaf_conv3x3_runs_bf16x3: 1 if a forward call at this

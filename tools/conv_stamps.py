@@ -33,10 +33,10 @@ for name, ci, co, split in (("up_conv1", 160, 384, [32, 32, 160, 160]), ("up_con
     for _ in range(5): cv(x, elu_input=True, split=split)
     torch.cuda.synchronize()
     buf = torch.zeros(1 << 20, dtype=torch.int64, device="cuda")
-    _capi.check(_capi.lib().iaf_conv3x3_set_debug(ctypes.c_void_p(buf.data_ptr())))
+    _capi.check(_capi.lib().iaf_conv3x3_set_debug(cv._h, ctypes.c_void_p(buf.data_ptr()), buf.numel() * 8))
     cv(x, elu_input=True, split=split)
     torch.cuda.synchronize()
-    _capi.check(_capi.lib().iaf_conv3x3_set_debug(None))
+    _capi.check(_capi.lib().iaf_conv3x3_set_debug(cv._h, None, 0))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(50): cv(x, elu_input=True, split=split)
