@@ -282,6 +282,13 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
     constexpr bool HLEFT = IAF_EXP_HLEFT && HELP && !PAIR && DEPTH == 2 && XSPLIT && NX > 0 && NFULL > 0 &&
                            (NHT - NX) / 2 >= NH / 32 - 1;     // (the left-over tiles' centre-tap blocks are all live: the helper walks the plain step order)
     constexpr int NTW1 = HLEFT ? NFULL : NTWH;                   // slots of a compute wave in hidden layers l >= 1
+    // HL0: the same for the FIRST hidden layer -- a helper computes its unit between issuing the context loads and staging what they
+    // brought (5 K steps, all fragments requested at once), and runs the unit's epilogue behind the barrier that makes the context visible
+#ifndef IAF_EXP_HL0
+#define IAF_EXP_HL0 1
+#endif
+    constexpr bool HL0 = IAF_EXP_HL0 && HLEFT;
+    constexpr int NTW0 = HL0 ? NFULL : NTWH;
     int htile[NTWH];
 #pragma unroll
     for (int j = 0; j < NTWH; ++j)      // (serpentine over the rounds: the dead centre-tap blocks of a wave's tiles add up evenly, see TRI)
@@ -366,11 +373,16 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
         }
     };
     f32x4 wr0[UA][NTWH][3];
+    f32x4 wrh0[HL0 ? UA : 1][NTW0][3];       // HL0: the first layer's ring of NFULL slots (wr0 is then unused)
     const f32x4* wb0 = (const f32x4*)p.wp3[0];
     auto preload_w0 = [&]() {
         static_for<RD0>([&](auto i) {
-            ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWH * 3>{}, wr0[decltype(i)::value], wb0, NHT, htile,
-                      PartL0{}, decltype(i)::value, ALL, 0);
+            if constexpr (HL0)
+                ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTW0 * 3>{}, wrh0[decltype(i)::value], wb0, NHT, htile,
+                          PartL0{}, decltype(i)::value, ALL, 0);
+            else
+                ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWH * 3>{}, wr0[decltype(i)::value], wb0, NHT, htile,
+                          PartL0{}, decltype(i)::value, ALL, 0);
         });
     };
     // context rows of this workgroup: per channel one contiguous run of CPX pixels (full-width rows) -> 16-byte loads,
@@ -1021,6 +1033,24 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
                 constexpr int NCIH = (NCIT + 255) / 256;
                 float* creg = (float*)(smem + (size_t)G::CTX_OFF * 16);
                 const int vpx = (H - r0) * W < CPX ? (H - r0) * W : CPX;
+                // HL0: this helper's left-over unit of the first hidden layer, between issuing the context loads and staging what they brought.
+                // (Measured on one box, profiles/r05/experiments/ab_hl0_*.txt: context loads first, then the unit's fragments with a 4-step
+                //  look-ahead: 8x8 step 16.56 -> 16.10 us, 16x16 equal; the fragments FIRST -- so that the unit's first MFMA need not wait for
+                //  the context's round trip -- was slower at either ring depth: 16.5 - 16.8 us.)
+                constexpr int RDL0 = PartL0::NSTEP - 1;
+                [[maybe_unused]] f32x4 accu0[1][1], biu0[1], wrl0[HL0 ? RDL0 + 1 : 1][1][3];
+                [[maybe_unused]] int lt0[1] = {NW * NFULL + (wave - NW_COMPUTE) % (NX ? NX : 1)};
+                [[maybe_unused]] int q0 = -1;
+                if constexpr (HL0) {
+                    static_for<GN>([&](auto g_c) {
+                        constexpr int GI = decltype(g_c)::value;
+                        constexpr int EM = fused_extra_mask(NPT0, GN, GI);
+                        static_assert(fused_popcount(EM) <= 1, "HL0: one pixel tile per left-over unit");
+                        if constexpr (EM != 0) {
+                            if ((wave - NW_COMPUTE) / NX == GI) q0 = EM == 1 ? 0 : EM == 2 ? 1 : EM == 4 ? 2 : 3;
+                        }
+                    });
+                }
                 f32x4 v[NCIH], v2[NCIH];
                 unsigned cval = 0;
 #pragma unroll
@@ -1034,6 +1064,20 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
                     if (p.ctx2) v2[u] = ldf4(p.ctx2 + img_h, gi);
                     cval |= (inside ? 1u : 0u) << u;
                 }
+                if constexpr (HL0) {
+                    if (q0 >= 0) {
+                        static_for<RDL0>([&](auto i) {
+                            ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}, wrl0[decltype(i)::value], wb0, NHT, lt0,
+                                      PartL0{}, decltype(i)::value, std::integral_constant<int, -1>{}, 0);
+                        });
+                        load_bias(std::integral_constant<int, 1>{}, lt0, p.bias[0], biu0);
+                        qbase = q0;
+                        conv_phase(std::integral_constant<int, RDL0>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{},
+                                   std::integral_constant<int, G::rows_h(0)>{}, std::integral_constant<int, 1>{}, G::ZREG, Z16, Z8, wb0, NHT, lt0,
+                                   wrl0, accu0, PartL0{}, std::integral_constant<int, 300>{}, std::integral_constant<bool, false>{}, 0);
+                        qbase = 0;
+                    }
+                }
 #pragma unroll
                 for (int u = 0; u < NCIH; ++u) {
                     const int idx = htid + 256 * u;
@@ -1045,8 +1089,17 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
                         *(f32x4*)(creg + c * CSTR + g4) = FLIP ? f32x4{t[3], t[2], t[1], t[0]} : t;
                     }
                 }
+                __syncthreads();                                  // first conv done, context staged
+                if constexpr (HL0) {
+                    if (q0 >= 0) {
+                        qbase = q0;
+                        hidden_epilogue(std::integral_constant<int, 1>{}, std::integral_constant<int, G::rows_h(0)>{}, std::integral_constant<int, 1>{},
+                                        std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, lt0, accu0, biu0, G::HREG0, p.hsave[0],
+                                        p.border[0], false);
+                        qbase = 0;
+                    }
+                }
             }
-            __syncthreads();                                      // first conv done, context staged
             __syncthreads();                                      // first epilogue done: h_0 complete
             xch_export(0, G::HREG0);
             static_for<DEPTH - 1>([&](auto lm_c) {
@@ -1274,12 +1327,17 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
     static_for<GN>([&](auto g_c) {
         constexpr int GI = decltype(g_c)::value;
         if (xg != GI) return;
-        constexpr int EM0 = (NX == 0 || !XSPLIT) ? (1 << NPT0) - 1 : fused_extra_mask(NPT0, GN, GI);
-        f32x4 acc0[NPT0][NTWH], bi0[NTWH];
-        load_bias(std::integral_constant<int, NTWH>{}, htile, p.bias[0], bi0);
-        conv_phase(std::integral_constant<int, RD0>{}, std::integral_constant<int, NPT0>{}, std::integral_constant<int, NTWH>{},
-                   std::integral_constant<int, G::rows_h(0)>{}, std::integral_constant<int, EM0>{}, G::ZREG, Z16, Z8, wb0, NHT, htile,
-                   wr0, acc0, PartL0{}, g_c, SET, 0);
+        constexpr int EM0 = HL0 ? (1 << NPT0) - 1 : (NX == 0 || !XSPLIT) ? (1 << NPT0) - 1 : fused_extra_mask(NPT0, GN, GI);
+        f32x4 acc0[NPT0][NTW0], bi0[NTW0];
+        load_bias(std::integral_constant<int, NTW0>{}, htile, p.bias[0], bi0);
+        if constexpr (HL0)
+            conv_phase(std::integral_constant<int, RD0>{}, std::integral_constant<int, NPT0>{}, std::integral_constant<int, NTW0>{},
+                       std::integral_constant<int, G::rows_h(0)>{}, std::integral_constant<int, EM0>{}, G::ZREG, Z16, Z8, wb0, NHT, htile,
+                       wrh0, acc0, PartL0{}, std::integral_constant<int, 400 + GI>{}, SET, 0);
+        else
+            conv_phase(std::integral_constant<int, RD0>{}, std::integral_constant<int, NPT0>{}, std::integral_constant<int, NTW0>{},
+                       std::integral_constant<int, G::rows_h(0)>{}, std::integral_constant<int, EM0>{}, G::ZREG, Z16, Z8, wb0, NHT, htile,
+                       wr0, acc0, PartL0{}, g_c, SET, 0);
         IAF_FSTAMP(6);
         xch_next_epoch_a();
         if constexpr (!HELP) store_ctx();
@@ -1289,7 +1347,7 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
         __syncthreads();                                         // (every wave runs exactly one of the GN instantiations)
         IAF_FSTAMP(11);
         hidden_epilogue(std::integral_constant<int, NPT0>{}, std::integral_constant<int, G::rows_h(0)>{},
-                        std::integral_constant<int, EM0>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, NTWH>{}, htile, acc0, bi0,
+                        std::integral_constant<int, EM0>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, NTW0>{}, htile, acc0, bi0,
                         G::HREG0, p.hsave[0], p.border[0], PAIR != 0);
     });
     __syncthreads();
