@@ -164,6 +164,7 @@ struct DescTable {
     bool pending[PREP_RING];
     hipStream_t up;                // private stream of the capture-time uploads
     int ring_i, ncap;
+    bool cap_done[PREP_CAPTURE_SLOTS];   // the slot's device table was written OUTSIDE any graph (else: only by a copy node of the graph that took it)
     bool uploaded;                 // the eager device table holds the caller's current host copy
 };
 static size_t desc_stride(const DescTable* t) { return (t->bytes + 255) / 256 * 256; }
@@ -199,10 +200,18 @@ static int desc_upload(DescTable* t, const void* host, bool changed, hipStream_t
         // tensors -- shares that slot's table; only captures of NEW pointer sets take a slot, PREP_CAPTURE_SLOTS per object
         // (include/iaf_hip.h: IAF_ERR_CAPTURE_SLOTS)
         for (int i = 0; i < t->ncap; ++i)
-            if (!memcmp(t->h_ring + stride * (PREP_RING + i), host, t->bytes)) { *d_out = t->d_tabs + stride * (1 + i); return IAF_OK; }
+            if (!memcmp(t->h_ring + stride * (PREP_RING + i), host, t->bytes)) {
+                //  a slot whose table was only ever filled by a copy NODE of the graph that took it is unwritten if that
+                // graph was never launched (or is gone): this capture then carries the copy too
+                if (!t->cap_done[i])
+                    HIP_TRY(hipMemcpyAsync(t->d_tabs + stride * (1 + i), t->h_ring + stride * (PREP_RING + i), t->bytes, hipMemcpyHostToDevice, st));
+                *d_out = t->d_tabs + stride * (1 + i);
+                return IAF_OK;
+            }
         if (t->ncap >= PREP_CAPTURE_SLOTS) return IAF_ERR_CAPTURE_SLOTS;
         char* snap = t->h_ring + stride * (PREP_RING + t->ncap);
         char* dtab = t->d_tabs + stride * (1 + t->ncap);
+        const int slot_i = t->ncap;
         t->ncap++;
         memcpy(snap, host, t->bytes);
         hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
@@ -212,6 +221,7 @@ static int desc_upload(DescTable* t, const void* host, bool changed, hipStream_t
                    hipStreamSynchronize(t->up) == hipSuccess;
             (void)hipThreadExchangeStreamCaptureMode(&mode);
         }
+        t->cap_done[slot_i] = done;
         if (!done) {
             (void)hipGetLastError();
             HIP_TRY(hipMemcpyAsync(dtab, snap, t->bytes, hipMemcpyHostToDevice, st));      // a copy node in the graph
