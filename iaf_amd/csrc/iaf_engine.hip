@@ -1278,9 +1278,9 @@ static int launch_fused_step(iaf_stack_t* s, step_fn_t fn, int R, size_t lds, co
     // (the last workgroup's helpers do the free-bits reductions)
     // ... and since round 5 every mode of the step there: with the second hidden layer's left-over units in the helper waves (HLEFT) the
     // form with helpers is the faster one for the bare IAF step too (16.98 -> 16.50 us in situ, same box; round 4 without HLEFT: 16.62
-    // without helpers, 16.89 with).  Knob 16 (tests: the free-bits finish as its own launch) and IAF_STEP_HELPERS=0 keep the four-wave form.
+    // without helpers, 16.89 with).  IAF_STEP_HELPERS=0 keeps the four-wave form (knob 16 only moves the free-bits finish into its own launch).
     static const int h8_env = getenv("IAF_STEP_HELPERS") ? atoi(getenv("IAF_STEP_HELPERS")) : -1;
-    if (h8_env != 0 && !(s->xch_knob & 16u) && !q.xh && !pair) {
+    if (h8_env != 0 && !q.xh && !pair) {
         size_t hl = 0;
         const int var = s->variant == IAF_VARIANT_TF ? 0 : s->variant == IAF_VARIANT_THEANO ? 1 : 2;
         if (step_fn_t fh = iaf_pick_step_fused_h(s->n_h / 16, s->n_z / 16, s->depth_ar, base.W, R, var, &hl))

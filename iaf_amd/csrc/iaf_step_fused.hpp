@@ -55,6 +55,9 @@
 #ifndef IAF_EXP_HOUT
 #define IAF_EXP_HOUT 1
 #endif
+#ifndef IAF_EXP_HOUT8
+#define IAF_EXP_HOUT8 1
+#endif
 // XCH = 1: neighbouring row blocks EXCHANGE their halo rows instead of recomputing them (see the kernel's header note): a
 // hidden layer computes only the R rows its workgroup owns, its region holds one more row -- the first row of the block
 // below, imported -- and z has R + 1 rows.
@@ -77,7 +80,11 @@ struct StepGeom {
     // K parts of the output pair's sums: PAIR -- two waves per tile; HOUT (exchange form, n_z = 32, two hidden layers) -- the taps of the
     // row below split between a compute wave and its helper
     static constexpr bool HOUT = IAF_EXP_HOUT && XCH && !PAIR && NZT == 2 && DEPTH == 2;
-    static constexpr int XKP = (PAIR || HOUT) ? 2 : 1;
+    // HOUT8 (8-pixel rows, one row per workgroup, the kernels WITH helper waves): the whole output pair split the same way -- its K loop is
+    // 6 MFMAs per step behind one wave's fetch latency; two waves per tile halve each wave's chain (the four-wave kernels of this geometry
+    // size the buffer alike and use its first part only)
+    static constexpr bool HOUT8 = IAF_EXP_HOUT8 && !XCH && !PAIR && NZT == 2 && DEPTH == 2 && W == 8 && R == 1;
+    static constexpr int XKP = (PAIR || HOUT || HOUT8) ? 2 : 1;
     static constexpr size_t xb_bytes() { return (size_t)XKP * R * W * XB_STRIDE * 4; }
     // (the last hidden layer sits in the h_odd region for an even depth: z + h_even are dead then; for an odd depth it sits in
     // h_even: the buffer goes into h_odd if it fits there, else behind everything)
@@ -1102,6 +1109,14 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
             }
             __syncthreads();                                      // first epilogue done: h_0 complete
             xch_export(0, G::HREG0);
+            // HOUT8: this helper's half of the output pair (below) -- its first fragments are requested while the last hidden layer is still
+            // being multiplied (the helper is idle there, or done with its left-over unit)
+            typedef PairPart<NH / 32, 1> PartO8H;
+            constexpr int RDOH8 = 3;
+            [[maybe_unused]] f32x4 wroh8[G::HOUT8 ? RDOH8 + 1 : 1][NTWO][3];
+            [[maybe_unused]] int ot8[NTWO];
+#pragma unroll
+            for (int j = 0; j < NTWO; ++j) ot8[j] = (wave - NW_COMPUTE) * NTWO + j;
             static_for<DEPTH - 1>([&](auto lm_c) {
                 constexpr int l = decltype(lm_c)::value + 1;
                 constexpr int IN_REG = ((l - 1) & 1) ? G::HREG1 : G::HREG0, OUT_REG = (l & 1) ? G::HREG1 : G::HREG0;
@@ -1140,6 +1155,12 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
                                             accu, biu, OUT_REG, p.hsave[l], p.border[l], false);
                             qbase = 0;
                         }
+                    });
+                }
+                if constexpr (G::HOUT8 && l == DEPTH - 1) {
+                    static_for<RDOH8>([&](auto i) {
+                        ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWO * 3>{}, wroh8[decltype(i)::value],
+                                  (const f32x4*)p.wp3[DEPTH], 2 * NZT, ot8, PartO8H{}, decltype(i)::value, std::integral_constant<int, -1>{}, 0);
                     });
                 }
                 __syncthreads();                                  // layer l's epilogue done
@@ -1185,6 +1206,26 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
             if constexpr (PAIR) {
                 if (!((p.xknob & 8u) && b == 0 && rbk == 0 && half == 1)) pair_export();     // (test knob 8: one half is never handed over)
                 pair_import();                                    // (ends with the barrier: the partner's half of the last hidden layer is there)
+            }
+            if constexpr (G::HOUT8) {
+                // the output pair, odd K steps: this helper's compute wave's tiles
+                constexpr int NPTO_ = (R * W + 15) / 16, LAST_REG = ((DEPTH - 1) & 1) ? G::HREG1 : G::HREG0;
+                const f32x4* wboh = (const f32x4*)p.wp3[DEPTH];
+                f32x4 accoh[NPTO_][NTWO];
+                conv_phase(std::integral_constant<int, RDOH8>{}, std::integral_constant<int, NPTO_>{}, std::integral_constant<int, NTWO>{},
+                           std::integral_constant<int, R>{}, std::integral_constant<int, (1 << NPTO_) - 1>{}, LAST_REG,
+                           H16, H8, wboh, 2 * NZT, ot8, wroh8, accoh, PartO8H{}, std::integral_constant<int, 0>{},
+                           std::integral_constant<bool, false>{}, 0);
+                float* part1 = (float*)(smem + (size_t)G::XB_OFF * 16) + R * W * G::XB_STRIDE;
+#pragma unroll
+                for (int j = 0; j < NTWO; ++j)
+#pragma unroll
+                    for (int q = 0; q < NPTO_; ++q) {
+                        const int pix = q * 16 + pl;
+                        if (pix >= R * W) continue;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) part1[pix * G::XB_STRIDE + ot8[j] * 16 + 4 * kk + r] = accoh[q][j][r];
+                    }
             }
             __syncthreads();                                      // output pair in the exchange buffer
             // ---- the block's free-bits reductions, by the helper waves of the workgroup that arrives last (StepP::fin_*) ----
@@ -1255,7 +1296,9 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
     // the first (or only) part of a hidden layer l >= 1 and of the output pair; XCH: the taps of the own rows, the imported row's
     // taps follow as a second part behind the import
     typedef std::conditional_t<XCH != 0, std::conditional_t<VAR == 0, PartOwnTri, PartOwn>, PartHid> PartH1;
-    typedef std::conditional_t<XCH != 0, PartOwn, PartFull> PartO1;
+    constexpr bool HO8 = G::HOUT8 && HELP;                       // the output pair's K steps alternate between a compute wave and its helper
+    constexpr bool XK2 = PAIR || G::HOUT || HO8;                 // ... their sums meet in the exchange buffer's two parts
+    typedef std::conditional_t<XCH != 0, PartOwn, std::conditional_t<HO8, PairPart<NPAIR_H, 0>, PartFull>> PartO1;
     int otile[NTWO];
 #pragma unroll
     for (int j = 0; j < NTWO; ++j) otile[j] = wave * NTWO + j;
@@ -1564,7 +1607,7 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
         }
         m_raw += xbuf[pix * G::XB_STRIDE + cm];
         s_raw += xbuf[pix * G::XB_STRIDE + cm + 16];
-        if constexpr (G::XKP == 2) {                             // (the other K part)
+        if constexpr (XK2) {                                     // (the other K part)
             m_raw += xbuf[(R * W + pix) * G::XB_STRIDE + cm];
             s_raw += xbuf[(R * W + pix) * G::XB_STRIDE + cm + 16];
         }
