@@ -21,7 +21,7 @@ IAF_PRECISION_BF16X3 = 1
 IAF_COMM_ID_BYTES = 128
 IAF_PACK_F32 = 1
 IAF_PACK_BF16X3 = 2
-IAF_ABI_VERSION = 5                # must equal the library's iaf_abi_version(): a stale libiaf_hip.so is rejected
+IAF_ABI_VERSION = 6                # must equal the library's iaf_abi_version(): a stale libiaf_hip.so is rejected
 IAF_VARIANT_TF = 0
 IAF_VARIANT_THEANO = 1
 IAF_VARIANT_THEANO_FLIPMASK = 2

@@ -50,7 +50,7 @@
 
 #include "iaf_conv_kernel.hpp"
 
-#define IAF_ABI_VERSION 5   // 5: per-stream halo-exchange sets, IAF_ERR_EXCHANGE, iaf_stack_set_halo_exchange_debug; 4: stack-owned halo-exchange buffers (iaf_stack_set_halo_exchange / _exchange_errors / _step_exchanges): a stack's
+#define IAF_ABI_VERSION 6   // 6: iaf_stack_step_pairs, iaf_conv3x3_set_debug(conv, buf, bytes), generic backward behind the training entry points; 5: per-stream halo-exchange sets, IAF_ERR_EXCHANGE, iaf_stack_set_halo_exchange_debug; 4: stack-owned halo-exchange buffers (iaf_stack_set_halo_exchange / _exchange_errors / _step_exchanges): a stack's
                           //    one-launch steps must not overlap on different streams; 2: + iaf_conv3x3_*; 3: bf16x3 default precision, THEANO_FLIPMASK, negative nt in autotune reports,
                           //    iaf_stack_set_packs, iaf_comm_* (include/iaf_hip.h)
 #define MAX_GEMM_LAYERS 10   // depth_ar <= 9 hidden + 1 output pair
