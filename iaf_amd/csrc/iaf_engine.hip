@@ -1065,6 +1065,7 @@ static step_fn_t fused_step_xch(const iaf_stack_t* s, int H, int W, int R, size_
     step_fn_t f = iaf_pick_step_fused_xch(s->n_h / 16, s->n_z / 16, s->depth_ar, W, R, var, lds, xrow);
     if (!f) f = iaf_pick_step_fused_xch_b(s->n_h / 16, s->n_z / 16, s->depth_ar, W, R, var, lds, xrow);
     if (!f) f = iaf_pick_step_fused_xch_c(s->n_h / 16, s->n_z / 16, s->depth_ar, W, R, var, lds, xrow);
+    if (!f) f = iaf_pick_step_fused_xch_d(s->n_h / 16, s->n_z / 16, s->depth_ar, W, R, var, lds, xrow);
     return (f && *lds <= 160 * 1024) ? f : nullptr;
 }
 

@@ -150,3 +150,22 @@ extern "C" step_fn_t iaf_pick_step_fused_pair(int nht, int nzt, int depth, int W
     return nullptr;
 }
 #endif
+
+#if !defined(IAF_FUSED_PART) || IAF_FUSED_PART == 4
+// siblings of the README run (round 5; models.py:92 takes any n_h, README.md:49 sweeps the flow's depth): n_z = 32 with depth_ar = 2 at
+// n_h = 64 and n_h = 128 -- the 16-pixel rows in the exchange form, 8- and 4-pixel rows recomputing
+extern "C" step_fn_t iaf_pick_step_fused_xch_d(int nht, int nzt, int depth, int W, int R, int var, size_t* lds, size_t* xrow) {
+    *lds = 0; *xrow = 0;
+    if (nzt == 2 && depth == 2 && W == 16 && R == 2) {
+        if (nht == 4) return inst<4, 2, 2, 16, 2, 1>(var, lds, xrow);
+        if (nht == 8) return inst<8, 2, 2, 16, 2, 1>(var, lds, xrow);
+    }
+    return nullptr;
+}
+extern "C" step_fn_t iaf_pick_step_fused_d(int nht, int nzt, int depth, int W, int R, int var, size_t* lds) {
+    *lds = 0;
+    if (nht == 4 && nzt == 2 && depth == 2) return inst_wr<4, 2, 2>(W, R, var, lds);
+    if (nht == 8 && nzt == 2 && depth == 2) return inst_wr<8, 2, 2>(W, R, var, lds);
+    return nullptr;
+}
+#endif

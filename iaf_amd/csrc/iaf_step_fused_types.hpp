@@ -76,8 +76,11 @@ extern "C" step_fn_t iaf_pick_step_fused_c(int nht, int nzt, int depth, int W, i
 extern "C" step_fn_t iaf_pick_step_fused_xch_c(int nht, int nzt, int depth, int W, int R, int var, size_t* lds, size_t* xrow);
 // the pair form (two workgroups per (image, row block), *prow = bytes one of them hands the other); R = rows per PAIR
 extern "C" step_fn_t iaf_pick_step_fused_pair(int nht, int nzt, int depth, int W, int R, int var, size_t* lds, size_t* prow);
+extern "C" step_fn_t iaf_pick_step_fused_d(int nht, int nzt, int depth, int W, int R, int var, size_t* lds);   // n_z = 32, depth_ar = 2, n_h = 64 / 128
+extern "C" step_fn_t iaf_pick_step_fused_xch_d(int nht, int nzt, int depth, int W, int R, int var, size_t* lds, size_t* xrow);
 static inline step_fn_t iaf_pick_step_fused(int nht, int nzt, int depth, int W, int R, int var, size_t* lds) {
     step_fn_t f = iaf_pick_step_fused_a(nht, nzt, depth, W, R, var, lds);
     if (!f) f = iaf_pick_step_fused_b(nht, nzt, depth, W, R, var, lds);
-    return f ? f : iaf_pick_step_fused_c(nht, nzt, depth, W, R, var, lds);
+    if (!f) f = iaf_pick_step_fused_c(nht, nzt, depth, W, R, var, lds);
+    return f ? f : iaf_pick_step_fused_d(nht, nzt, depth, W, R, var, lds);
 }

@@ -91,7 +91,10 @@ def test_where_the_step_runs_as_one_launch(amd):
                                  (32, 64, 64, 4, 16, 16), (4, 64, 64, 4, 8, 8), (3, 64, 128, 4, 8, 8), (32, 64, 192, 4, 8, 8),
                                  (3, 64, 192, 4, 4, 4), (2, 64, 64, 4, 5, 16), (2, 64, 128, 4, 3, 4),
                                  (8, 32, 160, 3, 16, 16), (5, 32, 160, 3, 8, 8), (3, 32, 160, 3, 7, 16), (4, 32, 64, 3, 8, 8),
-                                 (6, 32, 64, 3, 16, 16), (4, 32, 64, 3, 4, 4)], ids=lambda s: "B%d_z%d_h%d_d%d_%dx%d" % s)
+                                 (6, 32, 64, 3, 16, 16), (4, 32, 64, 3, 4, 4),
+                                 (32, 32, 128, 2, 16, 16), (5, 32, 128, 2, 8, 8), (3, 32, 128, 2, 5, 4), (2, 32, 128, 2, 3, 16),
+                                 (32, 32, 64, 2, 16, 16), (5, 32, 64, 2, 8, 8), (3, 32, 64, 2, 4, 4), (2, 32, 64, 2, 7, 16)],
+                         ids=lambda s: "B%d_z%d_h%d_d%d_%dx%d" % s)
 def test_iaf_step_and_raw_outputs_vs_oracle(amd, cfg):
     """tf_train.py:69-72 and layers.py:158-166 through the one-launch step; heights that are not a multiple of the rows
     per workgroup, single rows, one sample"""
@@ -120,7 +123,7 @@ def test_iaf_step_and_raw_outputs_vs_oracle(amd, cfg):
 
 @pytest.mark.parametrize("kl_min", [0.0, 0.25])
 @pytest.mark.parametrize("cfg", [(8, 32, 160, 2, 16, 16), (5, 32, 160, 2, 8, 8), (3, 32, 160, 2, 5, 16), (4, 32, 64, 1, 8, 8),
-                                 (6, 32, 160, 2, 4, 4)],
+                                 (6, 32, 160, 2, 4, 4), (8, 32, 128, 2, 16, 16), (5, 32, 64, 2, 8, 8)],
                          ids=lambda s: "B%d_z%d_h%d_d%d_%dx%d" % s)
 def test_posterior_block_vs_oracle(amd, cfg, kl_min):
     """the extended unit (tf_train.py:56-85): posterior sample computed in the staging, two contexts, KL elements and free

@@ -300,6 +300,7 @@ def test_iaf_step_data_gradients_on_the_bf16_matrix_cores(amd, shape):
 
 @pytest.mark.parametrize("kl_min", [0.0, 0.25])
 @pytest.mark.parametrize("shape", [(4, 32, 160, 2, 16, 16), (3, 32, 64, 1, 8, 8), (2, 64, 64, 4, 4, 4),
+                                   (4, 32, 128, 2, 16, 16), (3, 32, 64, 2, 8, 8),     # round 5's one-launch families
                                    (32, 32, 160, 2, 16, 16)],      # last: BASELINE configs[1] at full size
                          ids=lambda s: "B%d_z%d_h%d_d%d_%dx%d" % s)
 def test_posterior_block_backward_vs_autograd_oracle(amd, shape, kl_min):
