@@ -521,6 +521,7 @@ static int xch_reset_sets(iaf_stack_t* s) {
         HIP_TRY(hipMemset(x.ctl, 0, IAF_XCTL_WORDS * sizeof(unsigned long long)));
     }
     for (auto& r : s->xch_retired_rows) HIP_TRY(hipMemsetD32((hipDeviceptr_t)r.first, (int)IAF_XSENT, r.second / 4));     // (a captured graph may still name them)
+    HIP_TRY(hipDeviceSynchronize());                         // (the fills ran on the null stream: a non-blocking stream's next launch is not ordered behind them)
     if (s->xch_err_host) *(volatile unsigned*)s->xch_err_host = 0u;
     return IAF_OK;
 }
@@ -1098,10 +1099,11 @@ static iaf_stack::XchSet* xch_prepare(iaf_stack_t* s, int B, int nrb, size_t xro
     (void)hipStreamIsCapturing(st, &cs);
     if (cs != hipStreamCaptureStatusNone) {
         // no allocation inside a capture: a capture stream without a set of its own (torch.cuda.graph's internal stream after a
-        // warm-up elsewhere) adopts the newest set that is large enough -- the graph then must not be replayed concurrently with
-        // launches of this stack on that set's stream (include/iaf_hip.h); none: the caller runs the recomputing kernel
+        // warm-up elsewhere) TAKES OVER the newest set that is large enough -- the set now belongs to the capture stream, so the
+        // graph's replays share no rows and no counters with later eager launches on the stream it came from (those allocate a
+        // fresh set on their next call; include/iaf_hip.h).  None large enough: the caller runs the recomputing kernel.
         for (size_t i = s->xch_sets.size(); i-- > 0;)
-            if (need <= s->xch_sets[i].bytes) return &s->xch_sets[i];
+            if (need <= s->xch_sets[i].bytes) { s->xch_sets[i].st = st; return &s->xch_sets[i]; }
         return nullptr;
     }
     if (!s->xch_err_host) {

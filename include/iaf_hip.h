@@ -329,9 +329,11 @@ int iaf_stack_step_is_fused(const iaf_stack_t* s, int B, int H, int W);
  *   consumer reads the row with agent-scope loads until no piece shows the pattern, and puts the pattern back.
  *   State.  Rows and list heads live in a set of buffers the stack owns PER STREAM (allocated on a stream's first such launch
  *   outside a stream capture): calls on different streams are independent.  A stream capture allocates nothing: it uses its
- *   stream's set if a warm-up launch on that stream created one, else the stack's newest set that is large enough (the graph
- *   must then not be replayed concurrently with launches of this stack on the stream that set belongs to), else the
- *   recomputing kernel.
+ *   stream's set if a warm-up launch on that stream created one, else it TAKES OVER the stack's newest set that is large enough
+ *   (the set changes owner: the stream it was warmed up on allocates a new one on its next eager launch, so replays of the graph
+ *   and those launches share nothing; only launches of that stream still in flight from before the capture use the old set -- a
+ *   graph is not replayed before its capture has ended, synchronise that stream before the first replay), else the recomputing
+ *   kernel.  Two graphs captured on one stream share that stream's set: replay them in stream order, not concurrently.
  *   Failure.  Every wait is bounded (seconds).  A wait that gives up fills the rows it waited for with NaN -- the launch's
  *   outputs then carry NaN where they depend on them (numerical failure = NaN for the caller's loop, tf_train.py:283-285) --
  *   and raises the stack's error word; launches already queued on those buffers import NaN without looking (the buffers can no

@@ -223,23 +223,71 @@ def test_launches_queued_behind_a_give_up_do_not_wait(amd):
     g = torch.Generator(device="cuda").manual_seed(34)
     z = torch.randn(4, 32, 16, 16, device="cuda", generator=g)
     ctx = torch.randn(4, 160, 16, 16, device="cuda", generator=g)
-    xs.iaf_step(z, ctx)
+    s1 = torch.cuda.Stream()
+    s1.wait_stream(torch.cuda.current_stream())
+    out = (torch.empty_like(z), torch.empty_like(z))
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s1):
+        xs.iaf_step(z, ctx)                                      # (warm-up on the stream of the capture: the graph and the
+        torch.cuda.synchronize()                                 #  eager launches below share s1's exchange set)
+        with torch.cuda.graph(graph, stream=s1):
+            xs.iaf_step(z, ctx, out=out)
+        xs.set_halo_exchange_debug(8)
+        xs.iaf_step(z, ctx)                                      # gives up
+        graph.replay()                                           # captured without the fault knob
+        torch.cuda.synchronize()
+        assert xs.exchange_errors() != 0
+        # every image has row blocks that import: NaN in all of them; the bottom blocks import nothing
+        assert all(bool(torch.isnan(out[0][b]).any()) for b in range(4))
+        xs.set_halo_exchange_debug(0)
+        xs.set_halo_exchange(True)
+        graph.replay()
+        torch.cuda.synchronize()
+    zr, sr = rc.iaf_step(z, ctx)
+    _close(out[0], zr, "replay after re-arming")
+    assert xs.exchange_errors() == 0
+
+
+def test_a_capture_takes_over_the_set_it_was_not_warmed_up_on(amd):
+    """a capture on a stream without an exchange set of its own (torch.cuda.graph's side stream after a warm-up on the current
+    stream) takes the warmed-up set over, counters included: later eager launches on the warm-up stream get a fresh set, so the
+    graph's replays and those launches share nothing -- run concurrently both stay right, and a give-up of an eager launch (its
+    set is dead from then on) does not reach the graph's replays (include/iaf_hip.h, State)"""
+    xs, rc = _stacks(amd, 32, [160, 160], 19)
+    g = torch.Generator(device="cuda").manual_seed(35)
+    z = torch.randn(32, 32, 16, 16, device="cuda", generator=g)
+    ctx = torch.randn(32, 160, 16, 16, device="cuda", generator=g)
+    z2 = torch.randn(32, 32, 16, 16, device="cuda", generator=g)
+    xs.iaf_step(z, ctx)                                          # warm-up on the current stream
     torch.cuda.synchronize()
     out = (torch.empty_like(z), torch.empty_like(z))
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
+    with torch.cuda.graph(graph):                                # (captures on a side stream of torch's own)
         xs.iaf_step(z, ctx, out=out)
+    zr, sr = rc.iaf_step(z, ctx)
+    zr2, sr2 = rc.iaf_step(z2, ctx)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    eager = []
+    for rep in range(30):                                        # replays on one stream, eager launches on the other, overlapping
+        with torch.cuda.stream(side):
+            graph.replay()
+        eager.append(xs.iaf_step(z2, ctx))
+    torch.cuda.synchronize()
+    _close(out[0], zr, "replayed z")
+    _close(out[1], sr, "replayed logsd")
+    for ze, se in eager:
+        _close(ze, zr2, "eager z")
+        _close(se, sr2, "eager logsd")
+    assert xs.exchange_errors() == 0
     xs.set_halo_exchange_debug(8)
-    xs.iaf_step(z, ctx)                                          # gives up
-    graph.replay()                                               # captured without the fault knob
+    xs.iaf_step(z2, ctx)                                         # gives up: the eager stream's set is dead
     torch.cuda.synchronize()
     assert xs.exchange_errors() != 0
-    # every image has row blocks that import: NaN in all of them; the bottom blocks import nothing
-    assert all(bool(torch.isnan(out[0][b]).any()) for b in range(4))
+    out[0].zero_()
+    graph.replay()                                               # the graph's set is not
+    torch.cuda.synchronize()
+    _close(out[0], zr, "replay beside a dead set")
     xs.set_halo_exchange_debug(0)
     xs.set_halo_exchange(True)
-    graph.replay()
-    torch.cuda.synchronize()
-    zr, sr = rc.iaf_step(z, ctx)
-    _close(out[0], zr, "replay after re-arming")
     assert xs.exchange_errors() == 0
