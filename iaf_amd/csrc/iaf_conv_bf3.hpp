@@ -197,7 +197,10 @@ __global__ __launch_bounds__(64 * PXT * KS * WCO) void iaf_conv_bf3_kernel(ConvP
     // MFMAs, so that the loads sit BETWEEN the MFMAs instead of in a cluster that starves the pipe)
     auto load_part = [&](auto slot_c, auto lo_c, auto hi_c, int s) __attribute__((always_inline)) {
         constexpr int I = decltype(slot_c)::value, LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
-        const int sc = s < s1 ? s : s1 - 1;                                     // clamped: branch-free, redundant at the tail
+        int sc = s < s1 ? s : s1 - 1;                                           // clamped: branch-free, redundant at the tail
+        // S2 = 2: a one-tap phase of a narrow conv has fewer steps than wave groups (c_in = 64: S = 2 < KS = 4) -- the group with the
+        // empty range [0, 0) must not clamp to step -1, one step IN FRONT of the pack (read, never used: a fault where that page is not mapped)
+        if constexpr (S2 == 2) sc = sc < 0 ? 0 : sc;
         int ws = sc;
         if constexpr (S2 == 2) { const int pr = step_pair(sc); ws = pr * NTP + step_tap(sc, pr); }
         const f32x4* q = wbase + (size_t)ws * wstep;
