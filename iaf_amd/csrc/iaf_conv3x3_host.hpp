@@ -775,14 +775,18 @@ extern "C" size_t iaf_conv3x3_train_workspace_bytes(const iaf_conv3x3_t* c, int 
     return conv3x3_train_ws_floats(c, (long long)B * H * W, nullptr, nullptr) * sizeof(float);
 }
 
-static int pack_pixmajor(const float* const* src, const int* chans, int n, float* dst, int C, int HW, int P, float scale,
-                         int elu, hipStream_t st) {
-    PackP p;
+static void pack_fill(PackP& p, const float* const* src, const int* chans, int n, float* dst, int C, int HW, int P, float scale, int elu) {
     memset(&p, 0, sizeof(p));
     int tot = 0;
     for (int k = 0; k < n; ++k) { tot += chans[k]; p.src[k] = src[k]; p.end[k] = tot; }
     p.nsrc = n; p.dst = dst; p.C = C; p.HW = HW; p.P = P; p.scale = scale; p.elu = elu;
-    hipLaunchKernelGGL(iaf_pack_pixmajor_kernel, dim3((P + 63) / 64, (C + 15) / 16), dim3(256), 0, st, p);
+}
+// the two backward operands of a conv in one launch (blockIdx.z): dY (scaled) and [elu](concat(x, x2))
+static int pack_pixmajor2(const PackP& a, const PackP& b, hipStream_t st) {
+    PackP2 pp;
+    pp.t[0] = a; pp.t[1] = b;
+    const int C = a.C > b.C ? a.C : b.C;
+    hipLaunchKernelGGL(iaf_pack_pixmajor_kernel, dim3((a.P + 63) / 64, (C + 63) / 64, 2), dim3(256), 0, st, pp);
     return (int)hipGetLastError();
 }
 
@@ -845,11 +849,13 @@ extern "C" int iaf_conv3x3_backward(iaf_conv3x3_t* c, const float* x, const floa
         return (int)hipGetLastError();
     }
     // (1) operands, pixel-major
-    if ((rc = pack_pixmajor(dys, dy_channels, n_dys, tw.dyc, c->n_out, HW, P, dy_scale, 0, st))) return rc;
     {
         const float* xs[2] = {x, x2};
         const int xc[2] = {x2 ? c_split : c->n_in, c->n_in - c_split};
-        if ((rc = pack_pixmajor(xs, xc, x2 ? 2 : 1, tw.xe, c->n_in, HW, P, 1.0f, elu_input ? 1 : 0, st))) return rc;
+        PackP pa, pb;
+        pack_fill(pa, dys, dy_channels, n_dys, tw.dyc, c->n_out, HW, P, dy_scale, 0);
+        pack_fill(pb, xs, xc, x2 ? 2 : 1, tw.xe, c->n_in, HW, P, 1.0f, elu_input ? 1 : 0);
+        if ((rc = pack_pixmajor2(pa, pb, st))) return rc;
     }
     // (2) data gradient
     if (n_dxs) {

@@ -624,29 +624,65 @@ __global__ __launch_bounds__(256) void iaf_wn_bwd_batch_kernel(const WnBwdLayer*
 }
 
 // plain convs: NCHW -> pixel-major staging of the backward operands.  dst[P][C] = scale * act(concat_k src_k)[b, c, p]
-// (act = ELU when elu is set).  Up to MAXSPLIT sources; boundaries are multiples of 4.  A thread owns 4 channels of a pixel:
-// reads are coalesced along pixels (64 lanes = 64 consecutive pixels), the write is one 16-byte store.
+// (act = ELU when elu is set).  Up to MAXSPLIT sources; boundaries are multiples of 4.  A workgroup moves a (64 pixels x 64 channels)
+// tile: the reads are coalesced along pixels (a wave = 64 consecutive pixels of one channel, 16 loads in flight per thread), the tile
+// turns in LDS, and the writes run along channels -- 16 lanes cover the 256 contiguous bytes of a pixel (round 5; before, a thread
+// wrote the 16 bytes it had read, 64 lanes = 64 pixels = 64 separate 16-byte pieces C floats apart).  blockIdx.z picks one of up to
+// two tensors: a conv's two operands (dY and [elu](x)) are packed by ONE launch.
 struct PackP {
     const float* src[MAXSPLIT]; int end[MAXSPLIT]; int nsrc;
     float* dst; int C, HW, P; float scale; int elu;
 };
-__global__ __launch_bounds__(256) void iaf_pack_pixmajor_kernel(PackP p) {
-    const int px = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int c = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 4;
-    if (px >= p.P || c >= p.C) return;
-    int k = 0;
-    while (k + 1 < p.nsrc && c >= p.end[k]) ++k;
-    const int c0 = k ? p.end[k - 1] : 0, ck = p.end[k] - c0;
-    const int b = px / p.HW, pp = px - b * p.HW;
-    const float* s = p.src[k] + ((size_t)b * ck + (c - c0)) * p.HW + pp;
-    f32x4 v;
+struct PackP2 { PackP t[2]; };
+__global__ __launch_bounds__(256) void iaf_pack_pixmajor_kernel(PackP2 pp) {
+    __shared__ float tile[64][65];
+    PackP p = pp.t[0];                                       // (a uniform select: indexing the by-value block at run time would copy it to scratch)
+    if (blockIdx.z) p = pp.t[1];
+    const int cb = blockIdx.y * 64;
+    if (cb >= p.C) return;                                   // (the other tensor of the launch has more channels)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int px0 = blockIdx.x * 64, px = px0 + lane;
+    if (px < p.P) {
+        const int b = px / p.HW, pix = px - b * p.HW;
+        float v[4][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        float t = s[(size_t)r * p.HW];
-        if (p.elu) t = elu_f(t);
-        v[r] = t * p.scale;
+        for (int u = 0; u < 4; ++u) {
+            const int c = cb + 4 * (wv + 4 * u);
+            if (c < p.C) {                                   // (wave-uniform)
+                const float* sk = p.src[0];                  // source k of the concat and its channel range [c0, c1): static indices
+                int c0 = 0, c1 = p.end[0];
+#pragma unroll
+                for (int k = 1; k < MAXSPLIT; ++k)
+                    if (k < p.nsrc && c >= p.end[k - 1]) { sk = p.src[k]; c0 = p.end[k - 1]; c1 = p.end[k]; }
+                const float* s = sk + ((size_t)b * (c1 - c0) + (c - c0)) * p.HW + pix;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[u][r] = s[(size_t)r * p.HW];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int q = wv + 4 * u;
+            if (cb + 4 * q < p.C) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float t = v[u][r];
+                    if (p.elu) t = elu_f(t);
+                    tile[lane][4 * q + r] = t * p.scale;
+                }
+            }
+        }
     }
-    *(f32x4*)(p.dst + (size_t)px * p.C + c) = v;
+    __syncthreads();
+    const int ql = threadIdx.x & 15, c = cb + 4 * ql;
+    if (c >= p.C) return;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int pl = pass * 16 + (threadIdx.x >> 4);
+        if (px0 + pl < p.P) {
+            const f32x4 o = {tile[pl][4 * ql], tile[pl][4 * ql + 1], tile[pl][4 * ql + 2], tile[pl][4 * ql + 3]};
+            *(f32x4*)(p.dst + (size_t)(px0 + pl) * p.C + c) = o;
+        }
+    }
 }
 
 // weight-norm backward of a plain (unmasked, 9-tap) conv, layers.py:60:  w = e u, u = V/n, n = ||V||_o, e = exp(g)
