@@ -848,12 +848,15 @@ extern "C" int iaf_conv3x3_backward(iaf_conv3x3_t* c, const float* x, const floa
         c->pending = false;
         return (int)hipGetLastError();
     }
-    // (1) operands, pixel-major
+    // (1) operands, pixel-major.  The column sums of dY (db's partials, one row per 64 pixels) come out of the same launch while they
+    // fit the 256 rows the buffers hold (P <= 16384); beyond that the reduce launch below sums them over larger slabs, as before.
+    const bool fold_db = (P + 63) / 64 <= 256;
     {
         const float* xs[2] = {x, x2};
         const int xc[2] = {x2 ? c_split : c->n_in, c->n_in - c_split};
         PackP pa, pb;
         pack_fill(pa, dys, dy_channels, n_dys, tw.dyc, c->n_out, HW, P, dy_scale, 0);
+        if (fold_db) pa.colsum = c->defer_wn ? c->own_dbp : tw.dbp;      // the bias gradient's partials, while the tile is in LDS
         pack_fill(pb, xs, xc, x2 ? 2 : 1, tw.xe, c->n_in, HW, P, 1.0f, elu_input ? 1 : 0);
         if ((rc = pack_pixmajor2(pa, pb, st))) return rc;
     }
@@ -878,7 +881,7 @@ extern "C" int iaf_conv3x3_backward(iaf_conv3x3_t* c, const float* x, const floa
     const unsigned short* tapmask = nullptr;
     if ((rc = tapmask_for(B, H, W, st, tw.tapmask, &tapmask))) return rc;
     if ((rc = launch_wgrad(nullptr, L, tw.xe, tw.dyc, tw.part, tapmask, B, H, W, st, 1, c->precision == IAF_PRECISION_BF16X3))) return rc;
-    const int nslab = (P + 31) / 32 < 256 ? (P + 31) / 32 : 256;
+    const int nslab = fold_db ? (P + 63) / 64 : 256;
     const int px_per_slab = (P + nslab - 1) / nslab;
     float* dWbuf = c->defer_wn ? c->own_dW : tw.dW;
     float* dbpbuf = c->defer_wn ? c->own_dbp : tw.dbp;
@@ -886,7 +889,7 @@ extern "C" int iaf_conv3x3_backward(iaf_conv3x3_t* c, const float* x, const floa
         const size_t n4 = (size_t)MAXTAPS * L.cin * L.cout / 4;
         int nblk = (int)((n4 + 255) / 256);
         if (nblk > 1024) nblk = 1024;
-        hipLaunchKernelGGL(iaf_wgrad_reduce_kernel, dim3(nblk + nslab), dim3(256), 0, st, tw.part, dWbuf,
+        hipLaunchKernelGGL(iaf_wgrad_reduce_kernel, dim3(nblk + (fold_db ? 0 : nslab)), dim3(256), 0, st, tw.part, dWbuf,
                            wgrad_nrange(P, L.cin, MAXTAPS, L.cout, c->precision == IAF_PRECISION_BF16X3), n4, nblk, (const float*)tw.dyc, dbpbuf, P, L.cout, px_per_slab);
     }
     // (4) through the weight norm -- now, or in iaf_conv3x3_wn_bwd_batch_run with every other conv of the model

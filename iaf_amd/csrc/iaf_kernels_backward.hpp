@@ -632,6 +632,7 @@ __global__ __launch_bounds__(256) void iaf_wn_bwd_batch_kernel(const WnBwdLayer*
 struct PackP {
     const float* src[MAXSPLIT]; int end[MAXSPLIT]; int nsrc;
     float* dst; int C, HW, P; float scale; int elu;
+    float* colsum;      // or NULL: [ceil(P / 64)][C] column sums of the packed tile (dY: the bias gradient's partials, one row per workgroup)
 };
 struct PackP2 { PackP t[2]; };
 __global__ __launch_bounds__(256) void iaf_pack_pixmajor_kernel(PackP2 pp) {
@@ -673,6 +674,14 @@ __global__ __launch_bounds__(256) void iaf_pack_pixmajor_kernel(PackP2 pp) {
         }
     }
     __syncthreads();
+    if (p.colsum && threadIdx.x < 64 && cb + (int)threadIdx.x < p.C) {       // (the first wave; the others go on to the stores)
+        const int n = p.P - px0 < 64 ? p.P - px0 : 64, t = threadIdx.x;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int r = 0;
+        for (; r + 4 <= n; r += 4) { a0 += tile[r][t]; a1 += tile[r + 1][t]; a2 += tile[r + 2][t]; a3 += tile[r + 3][t]; }
+        for (; r < n; ++r) a0 += tile[r][t];
+        p.colsum[(size_t)blockIdx.x * p.C + cb + t] = (a0 + a1) + (a2 + a3);
+    }
     const int ql = threadIdx.x & 15, c = cb + 4 * ql;
     if (c >= p.C) return;
 #pragma unroll
