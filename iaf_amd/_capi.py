@@ -16,12 +16,15 @@ IAF_ERR_WORKSPACE = -5
 IAF_ERR_UNSUPPORTED = -6
 IAF_ERR_EXCHANGE = -7
 IAF_ERR_CAPTURE_SLOTS = -8
+IAF_ERR_RANGE = -9
 IAF_PRECISION_F32 = 0
 IAF_PRECISION_BF16X3 = 1
+IAF_PRECISION_F16X2 = 2
 IAF_COMM_ID_BYTES = 128
 IAF_PACK_F32 = 1
 IAF_PACK_BF16X3 = 2
-IAF_ABI_VERSION = 6                # must equal the library's iaf_abi_version(): a stale libiaf_hip.so is rejected
+IAF_PACK_F16X2 = 4
+IAF_ABI_VERSION = 7                # must equal the library's iaf_abi_version(): a stale libiaf_hip.so is rejected
 IAF_VARIANT_TF = 0
 IAF_VARIANT_THEANO = 1
 IAF_VARIANT_THEANO_FLIPMASK = 2
@@ -88,6 +91,7 @@ SIGNATURES = {
     "iaf_up_iaf2_backward_pre": (ctypes.c_int, [_c_float_p] * 6 + [ctypes.c_float] + [_c_float_p] * 4 + [ctypes.c_int] * 4 + [_vp]),
     "iaf_up_iaf2_backward_post": (ctypes.c_int, [_c_float_p] * 7 + [ctypes.c_int] * 4 + [_vp]),
     "iaf_stack_exchange_errors": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint)]),
+    "iaf_stack_range_errors": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint)]),
     "iaf_stack_step_exchanges": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "iaf_stack_step_pairs": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "iaf_stack_set_halo_exchange": (ctypes.c_int, [_vp, ctypes.c_int]),
@@ -190,6 +194,13 @@ class ExchangeError(IafHipError):
     halo rows, so the call that raised this can simply be repeated.  ARStack.set_halo_exchange(True) re-arms the exchange."""
 
 
+class RangeError(IafHipError):
+    """IAF_ERR_RANGE: an operand beyond fp16's largest finite number went into the two-plane fp16 kernels ("f16x2") in an EARLIER launch
+    of the stack -- that launch's outputs carry inf / NaN (the caller's NaN check sees it, tf_train.py:283-285); the stack has gone back
+    to the bf16x3 kernels, so the call that raised this can be repeated (after another prepare where the stack kept only the fp16 pack).
+    ARStack.set_precision("f16x2") re-arms."""
+
+
 _lib = None
 
 
@@ -228,6 +239,8 @@ def check(code):
         raise UnsupportedError(msg)
     if code == IAF_ERR_EXCHANGE:
         raise ExchangeError(msg)
+    if code == IAF_ERR_RANGE:
+        raise RangeError(msg)
     if code in (IAF_ERR_NULL, IAF_ERR_SHAPE, IAF_ERR_WORKSPACE):
         raise ValueError(msg)
     raise IafHipError(msg)

@@ -57,6 +57,34 @@ __device__ __forceinline__ void bf3_store4(char* smem, int slot, int q, f32x4 v,
     *(u32x2*)(base + ((size_t)cin8 << 5)) = u32x2{l0, l1};
 }
 
+// ---- "f16x2": TWO fp16 planes per fp32 operand (round 6; iaf_step_fused.hpp F16) -------------------------------------------
+// x = h + l 2^-11 with h = fp16(x) (round to nearest even), l = fp16((x - h) 2^11): x - h is exact in fp32 and at most half an ulp of h,
+// so l sits in the binade of x or below -- in fp16's NORMAL range wherever h is (a plain fp16(x - h) would fall into the
+// subnormals from |x| < 2^-3 on and lose its bits: tests/studies/f16_split_study.py).  22 significand bits + sign handling; the
+// product of two such operands is  h h' + (h l' + l h') 2^-11  up to 2^-22 relative: THREE products on v_mfma_f32_16x16x32_f16 (each
+// exact in fp32: 11 + 11 bits), the two cross products in an accumulator of their own that is scaled once, where the sums meet.
+// Range: |x| > 65504 has no fp16 -- h = inf, the outputs carry inf / NaN, and the kernels raise a host-visible word (StepP::rng_err) on
+// which the stack returns to the bf16x3 kernels, whose planes have fp32's exponent range.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+#define IAF_F16_MAX 65504.0f
+__device__ __forceinline__ void f16s_split2(f32x2 x, unsigned& h, unsigned& l) {
+    const f16x2 hb = __builtin_convertvector(x, f16x2);
+    const f32x2 r = (x - __builtin_convertvector(hb, f32x2)) * 2048.0f;
+    const f16x2 lb = __builtin_convertvector(r, f16x2);
+    h = __builtin_bit_cast(unsigned, hb);
+    l = __builtin_bit_cast(unsigned, lb);
+}
+// 4 consecutive channels of one pixel slot -> the two planes of the LDS tile (8 bytes each)
+__device__ __forceinline__ void f16s_store4(char* smem, int slot, int q, f32x4 v, int s16, int cin8) {
+    unsigned h0, l0, h1, l1;
+    f16s_split2(f32x2{v[0], v[1]}, h0, l0);
+    f16s_split2(f32x2{v[2], v[3]}, h1, l1);
+    char* base = smem + ((size_t)slot * s16 << 4) + q * 8;
+    *(u32x2*)(base) = u32x2{h0, h1};
+    *(u32x2*)(base + ((size_t)cin8 << 4)) = u32x2{l0, l1};
+}
+
 // NTP_: taps of the filter -- the 5 live ones of a MADE-masked conv, or all 9 of a plain conv2d (EPI_PLAIN: the convs
 // around the IAF step, tf_train.py:36,41,53,93; halo on both sides of the pixel tile)
 // S2: the two strided convs of the downsampling IAFLayer at their minimal work, on the 9-tap pack as it is:

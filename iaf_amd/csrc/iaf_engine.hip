@@ -50,7 +50,7 @@
 
 #include "iaf_conv_kernel.hpp"
 
-#define IAF_ABI_VERSION 6   // 6: iaf_stack_step_pairs, iaf_conv3x3_set_debug(conv, buf, bytes), generic backward behind the training entry points; 5: per-stream halo-exchange sets, IAF_ERR_EXCHANGE, iaf_stack_set_halo_exchange_debug; 4: stack-owned halo-exchange buffers (iaf_stack_set_halo_exchange / _exchange_errors / _step_exchanges): a stack's
+#define IAF_ABI_VERSION 7   // 7: IAF_PRECISION_F16X2 / IAF_PACK_F16X2 / IAF_ERR_RANGE / iaf_stack_range_errors (the two-plane fp16 step kernels); 6: iaf_stack_step_pairs, iaf_conv3x3_set_debug(conv, buf, bytes), generic backward behind the training entry points; 5: per-stream halo-exchange sets, IAF_ERR_EXCHANGE, iaf_stack_set_halo_exchange_debug; 4: stack-owned halo-exchange buffers (iaf_stack_set_halo_exchange / _exchange_errors / _step_exchanges): a stack's
                           //    one-launch steps must not overlap on different streams; 2: + iaf_conv3x3_*; 3: bf16x3 default precision, THEANO_FLIPMASK, negative nt in autotune reports,
                           //    iaf_stack_set_packs, iaf_comm_* (include/iaf_hip.h)
 #define MAX_GEMM_LAYERS 10   // depth_ar <= 9 hidden + 1 output pair
@@ -77,6 +77,7 @@ struct GemmLayer {
     float* wpt = nullptr;      // transposed pack for dgrad (allocated by iaf_stack_set_training)
     void* wpt3 = nullptr;      // its bf16x3 form (iaf_pack_t3_kernel; even tile counts only): the data gradient on the bf16 matrix cores
     void* wp3 = nullptr;       // bf16x3 pack for iaf_conv_bf3_kernel (c_in % 32 == 0 only)
+    void* wp2 = nullptr;       // two-plane fp16 pack of the F16 step kernels (allocated by iaf_stack_set_precision(F16X2))
     int b_nt = 0, b_ppw = 0, b_pxt = 0, b_ks = 0, b_wco = 1;   // bf16x3 launch shape (auto or iaf_stack_set_tuning_bf3)
     bool b_user_tuned = false;
     // result of iaf_stack_autotune for one problem size: which kernel family and which bf16x3 shape won the timing
@@ -110,12 +111,14 @@ struct iaf_stack {
     // may still name them.
     struct XchSet {
         hipStream_t st = nullptr;
-        char* buf = nullptr; size_t bytes = 0;                 // rows: every dword IAF_XSENT between launches
+        char* buf = nullptr; size_t bytes = 0;                 // rows: every dword `pattern` between launches
+        unsigned pattern = IAF_XSENT;                          // IAF_XSENT (bf16 planes) or IAF_XSENT_F16 (fp16 planes): a set serves kernels of ONE plane type
         unsigned long long* ctl = nullptr;                     // heads, arrivals, sticky error (StepP::xctl), arrivals of the in-launch KL finish (StepP::fin_ctl = xctl + IAF_XCTL_FIN): zero between launches
     };
     std::deque<XchSet> xch_sets;           // (stable addresses: a launch holds a pointer to its set outside the lock)
     std::mutex xch_mu;
-    std::vector<std::pair<char*, size_t>> xch_retired_rows;
+    struct XchRetired { char* first; size_t second; unsigned pattern; };
+    std::vector<XchRetired> xch_retired_rows;
     unsigned* xch_err_host = nullptr;     // mapped pinned word the kernels raise when a bounded wait gives up: read at every launch,
     unsigned* xch_err_dev = nullptr;      // ... without synchronising; its device-side alias
     bool xch_on = true;                   // iaf_stack_set_halo_exchange
@@ -128,6 +131,13 @@ struct iaf_stack {
     long long fs_P = -1; int fs_W = 0; bool fs_on = false;   // ... unless iaf_stack_autotune measured this size: then what it found
     int fs_force = -1;        // (autotune's own measurements: -1 off, 0 / 1 = take this path regardless)
     bool skip_f32_pack = false;   // iaf_stack_set_packs: the prep launches write the bf16x3 packs only
+    bool skip_bf3_pack = false;   // ... the two-plane fp16 packs only (IAF_PRECISION_F16X2 stacks whose every launch is an F16 step kernel)
+    // IAF_PRECISION_F16X2: the word the F16 kernels (and the prep of their packs) raise when an operand lies beyond fp16's largest finite
+    // number -- mapped pinned memory, read without synchronising at the stack's next launch, which then returns IAF_ERR_RANGE once and
+    // the stack goes on with the bf16x3 kernels (f16_off) until iaf_stack_set_precision(F16X2) is called again
+    unsigned* rng_err_host = nullptr;
+    unsigned* rng_err_dev = nullptr;
+    bool f16_off = false;
     bool prepared;
     size_t weight_bytes;  // raw V/g/b bytes of the stack (for the algorithmic byte count)
     // optional per-launch event timing of one layer
@@ -347,6 +357,7 @@ extern "C" const char* iaf_error_string(int code) {
         case IAF_ERR_NOT_MULTIPLE: return "n_h must be a multiple of n_z or vice versa";
         case IAF_ERR_NOT_PREPARED: return "iaf_stack_prepare has not been called";
         case IAF_ERR_WORKSPACE: return "workspace too small or misaligned";
+        case IAF_ERR_RANGE: return "an operand beyond fp16's largest finite number (65504) went into the two-plane fp16 kernels in an earlier launch of this stack (its outputs carry inf / NaN); the stack now runs the bf16x3 kernels -- prepare again if asked to, and repeat the call";
         case IAF_ERR_EXCHANGE: return "a bounded wait of the halo exchange gave up in an earlier launch of this stack (its outputs carry NaN); the stack now recomputes its halo rows -- repeat the call";
         case IAF_ERR_CAPTURE_SLOTS: return "this prep / weight-norm batch object has been captured into hipGraphs with more than 16 distinct sets of tensor pointers: create another batch object (include/iaf_hip.h)";
         case IAF_ERR_UNSUPPORTED: return "not covered by the gfx950 kernels (channels must be multiples of 16 and <= 256; launch shape must fit 160 KiB of LDS)";
@@ -503,10 +514,12 @@ extern "C" int iaf_stack_destroy(iaf_stack_t* s) {
         if (s->L[l].wpt) (void)hipFree(s->L[l].wpt);
         if (s->L[l].wpt3) (void)hipFree(s->L[l].wpt3);
         if (s->L[l].wp3) (void)hipFree(s->L[l].wp3);
+        if (s->L[l].wp2) (void)hipFree(s->L[l].wp2);
         if (s->L[l].lim) (void)hipFree(s->L[l].lim);
     }
     xch_free_sets(s);
     if (s->xch_err_host) (void)hipHostFree(s->xch_err_host);
+    if (s->rng_err_host) (void)hipHostFree(s->rng_err_host);
     delete s;
     return IAF_OK;
 }
@@ -517,10 +530,10 @@ static int xch_reset_sets(iaf_stack_t* s) {
     HIP_TRY(hipDeviceSynchronize());
     std::lock_guard<std::mutex> lk(s->xch_mu);
     for (auto& x : s->xch_sets) {
-        HIP_TRY(hipMemsetD32((hipDeviceptr_t)x.buf, (int)IAF_XSENT, x.bytes / 4));
+        HIP_TRY(hipMemsetD32((hipDeviceptr_t)x.buf, (int)x.pattern, x.bytes / 4));
         HIP_TRY(hipMemset(x.ctl, 0, IAF_XCTL_WORDS * sizeof(unsigned long long)));
     }
-    for (auto& r : s->xch_retired_rows) HIP_TRY(hipMemsetD32((hipDeviceptr_t)r.first, (int)IAF_XSENT, r.second / 4));     // (a captured graph may still name them)
+    for (auto& r : s->xch_retired_rows) HIP_TRY(hipMemsetD32((hipDeviceptr_t)r.first, (int)r.pattern, r.second / 4));     // (a captured graph may still name them)
     HIP_TRY(hipDeviceSynchronize());                         // (the fills ran on the null stream: a non-blocking stream's next launch is not ordered behind them)
     if (s->xch_err_host) *(volatile unsigned*)s->xch_err_host = 0u;
     return IAF_OK;
@@ -564,11 +577,66 @@ extern "C" int iaf_stack_set_tuning(iaf_stack_t* s, int layer, int nt, int pxt, 
 
 static bool bf3_select(const iaf_stack_t* s, GemmLayer& L, int epi, bool negate_taps, bool pix_input, long long P, int W);
 
+// F32 or one of the two split arithmetics (F16X2 = BF16X3 everywhere but in the one-launch step kernels compiled with fp16 planes)
+static inline bool prec_split(const iaf_stack_t* s) { return s->precision != IAF_PRECISION_F32; }
+// the F16 step kernels are in use: the precision asks for them, every layer has the pack, no range failure has been seen
+static inline bool f16_active(const iaf_stack_t* s) {
+    if (s->precision != IAF_PRECISION_F16X2 || s->f16_off || s->generic) return false;
+    for (int l = 0; l < s->nlayers; ++l) if (!s->L[l].wp2) return false;
+    return true;
+}
+
 extern "C" int iaf_stack_set_precision(iaf_stack_t* s, int precision) {
     if (!s) return IAF_ERR_NULL;
-    if (precision != IAF_PRECISION_F32 && precision != IAF_PRECISION_BF16X3) return IAF_ERR_SHAPE;
+    if (precision != IAF_PRECISION_F32 && precision != IAF_PRECISION_BF16X3 && precision != IAF_PRECISION_F16X2) return IAF_ERR_SHAPE;
+    if (precision == IAF_PRECISION_F16X2) {
+        if (s->generic) return IAF_ERR_UNSUPPORTED;
+        for (int l = 0; l < s->nlayers; ++l) if (!s->L[l].wp3) return IAF_ERR_UNSUPPORTED;      // (c_in % 32: the same fragments, two planes)
+        if (!s->rng_err_host) {
+            if (hipHostMalloc((void**)&s->rng_err_host, 64, hipHostMallocMapped) != hipSuccess) { s->rng_err_host = nullptr; return (int)hipErrorOutOfMemory; }
+            *(volatile unsigned*)s->rng_err_host = 0u;
+            if (hipHostGetDevicePointer((void**)&s->rng_err_dev, s->rng_err_host, 0) != hipSuccess) {
+                (void)hipHostFree(s->rng_err_host); s->rng_err_host = nullptr; s->rng_err_dev = nullptr;
+                return (int)hipErrorOutOfMemory;
+            }
+        }
+        for (int l = 0; l < s->nlayers; ++l) {
+            GemmLayer& L = s->L[l];
+            if (L.wp2) continue;
+            HIP_TRY(hipMalloc(&L.wp2, (size_t)(L.cin / 32) * NTAPS * L.ncot * 2 * 1024));
+            s->prepared = false;                             // the next prepare fills it
+        }
+        if (s->f16_off || *(volatile unsigned*)s->rng_err_host) {       // re-armed after a range failure
+            HIP_TRY(hipDeviceSynchronize());
+            *(volatile unsigned*)s->rng_err_host = 0u;
+            s->f16_off = false;
+            s->prepared = false;
+        }
+    } else if (s->skip_bf3_pack) {
+        s->skip_bf3_pack = false;                            // (the bf16x3 pack is wanted again)
+        s->prepared = false;
+    }
+    if ((precision == IAF_PRECISION_F16X2) != (s->precision == IAF_PRECISION_F16X2)) s->prepared = false;   // the set of packs the prep writes changes
     s->precision = precision;
     return IAF_OK;
+}
+
+extern "C" int iaf_stack_range_errors(const iaf_stack_t* s, unsigned* errors) {
+    if (!s || !errors) return IAF_ERR_NULL;
+    *errors = 0;
+    if (!s->rng_err_host) return IAF_OK;
+    HIP_TRY(hipDeviceSynchronize());                         // (every launch so far has had its say)
+    *errors = *(volatile unsigned*)s->rng_err_host;
+    return IAF_OK;
+}
+
+// which packs a prep launch writes for layer L of stack s
+static inline void prep_pack_ptrs(const iaf_stack_t* s, const GemmLayer& L, float** wp, void** wp3, void** wp2, unsigned** rng) {
+    const bool f16 = f16_active(s);
+    *wp2 = f16 ? L.wp2 : nullptr;
+    *rng = f16 ? s->rng_err_dev : nullptr;
+    *wp3 = (f16 && s->skip_bf3_pack) ? nullptr : L.wp3;
+    *wp = (s->skip_f32_pack && L.wp3) ? nullptr : L.wp;
 }
 
 extern "C" int iaf_stack_get_precision(const iaf_stack_t* s, int layer, int B, int H, int W) {
@@ -651,8 +719,8 @@ extern "C" int iaf_stack_prepare(iaf_stack_t* s, const float* const* V, const fl
         PrepLayer& P = a.L[l];
         P.V[0] = V[l]; P.g[0] = g[l]; P.b[0] = b[l];
         if (L.npair == 2) { P.V[1] = V[l + 1]; P.g[1] = g[l + 1]; P.b[1] = b[l + 1]; }
-        P.wp = (s->skip_f32_pack && L.wp3) ? nullptr : L.wp;
-        P.bias = L.bias; P.border = L.border; P.variant = s->variant; P.wpt = L.wpt; P.wp3 = L.wp3;
+        prep_pack_ptrs(s, L, &P.wp, &P.wp3, &P.wp2, &P.rng_err);
+        P.bias = L.bias; P.border = L.border; P.variant = s->variant; P.wpt = L.wpt;
         P.cin = L.cin; P.cout_each = L.cout / L.npair; P.ncot = L.ncot; P.nchunk = L.nchunk;
         P.zerodiag = L.zerodiag; P.npair = L.npair; P.tile_begin = tiles;
         tiles += L.ncot;
@@ -719,7 +787,8 @@ extern "C" int iaf_prep_batch_create(iaf_prep_batch_t** out, iaf_stack_t* const*
         for (int l = 0; l < stacks[i]->nlayers; ++l, ++li) {
             const GemmLayer& L = stacks[i]->L[l];
             PrepLayer& P = b->h_layers[li];
-            P.wp = L.wp; P.bias = L.bias; P.border = L.border; P.variant = stacks[i]->variant; P.wpt = L.wpt; P.wp3 = L.wp3;
+            prep_pack_ptrs(stacks[i], L, &P.wp, &P.wp3, &P.wp2, &P.rng_err);
+            P.bias = L.bias; P.border = L.border; P.variant = stacks[i]->variant; P.wpt = L.wpt;
             P.cin = L.cin; P.cout_each = L.cout / L.npair; P.ncot = L.ncot; P.nchunk = L.nchunk;
             P.zerodiag = L.zerodiag; P.npair = L.npair; P.tile_begin = tile;
             for (int t = 0; t < L.ncot; ++t) t2l[tile++] = li;
@@ -748,9 +817,10 @@ extern "C" int iaf_prep_batch_run(iaf_prep_batch_t* b, const float* const* V, co
             }
             changed |= (P.wpt != s->L[l].wpt);       // training switched on/off since the last run
             P.wpt = s->L[l].wpt;
-            float* wp = (s->skip_f32_pack && s->L[l].wp3) ? nullptr : s->L[l].wp;      // iaf_stack_set_packs since the last run
-            changed |= (P.wp != wp);
-            P.wp = wp;
+            float* wp; void* wp3; void* wp2; unsigned* rng;                            // iaf_stack_set_packs / _set_precision since the last run
+            prep_pack_ptrs(s, s->L[l], &wp, &wp3, &wp2, &rng);
+            changed |= (P.wp != wp) | (P.wp3 != wp3) | (P.wp2 != wp2) | (P.rng_err != rng);
+            P.wp = wp; P.wp3 = wp3; P.wp2 = wp2; P.rng_err = rng;
         }
         ci += s->depth_ar + 2;
     }
@@ -859,7 +929,7 @@ static size_t bf3_fused_lds_bytes(int cin, int cin0, int W, int nt, int ppw, int
 }
 // can layer 0 be computed inside layer 1's bf16x3 kernel with this shape?
 static bool fuse_shape_ok(const iaf_stack_t* s, int nt, int ppw, int pxt, int ks, int wco, int W) {
-    if (s->depth_ar < 1 || s->variant != IAF_VARIANT_TF || s->generic || s->precision != IAF_PRECISION_BF16X3) return false;
+    if (s->depth_ar < 1 || s->variant != IAF_VARIANT_TF || s->generic || !prec_split(s) || s->skip_bf3_pack) return false;
     const GemmLayer& A = s->L[0];
     const GemmLayer& Bl = s->L[1];
     if (!A.wp3 || !Bl.wp3 || A.cin != 32) return false;
@@ -896,7 +966,7 @@ static bool auto_shape_bf3(GemmLayer& L, bool is_out, long long P, int W) {
 
 // will a forward launch of this layer run the bf16x3 kernel?  (also fixes L.b_* to the shape it will use)
 static bool bf3_select(const iaf_stack_t* s, GemmLayer& L, int epi, bool negate_taps, bool pix_input, long long P, int W) {
-    if (s->precision != IAF_PRECISION_BF16X3 || !L.wp3) return false;
+    if (!prec_split(s) || !L.wp3 || s->skip_bf3_pack) return false;        // (skip_bf3_pack: the bf16x3 pack is not kept up to date)
     if (negate_taps != (epi == EPI_DGRAD)) return false;           // mirrored taps: the data gradient (transposed bf16x3 pack), only
     if (!(epi == EPI_HIDDEN || ((epi == EPI_OUT || epi == EPI_DGRAD) && pix_input))) return false;
     if (!L.b_user_tuned && L.tuned_P == P && L.tuned_W == W) {       // measured for exactly this problem size
@@ -1089,10 +1159,12 @@ static step_fn_t fused_step_pair(const iaf_stack_t* s, int W, size_t* lds, size_
 // inside a stream capture (there: the stream's set, else the newest one that is large enough, else NULL and the caller runs what
 // it ran before; warm up before capturing, as for the LDS cap).  A set that grows keeps its counters; the new rows start as
 // "nothing there yet" (IAF_XSENT).  Outgrown rows stay alive with the stack: a captured graph may still name them.
-static iaf_stack::XchSet* xch_prepare(iaf_stack_t* s, int B, int nrb, size_t xrow, hipStream_t st) {
+// pattern: the "not there yet" pattern of the kernels that will use the set (IAF_XSENT: bf16 planes, IAF_XSENT_F16: fp16 planes) -- a set
+// serves one plane type; a stream that runs both has two sets.
+static iaf_stack::XchSet* xch_prepare(iaf_stack_t* s, int B, int nrb, size_t xrow, hipStream_t st, unsigned pattern = IAF_XSENT) {
     std::lock_guard<std::mutex> lk(s->xch_mu);
     iaf_stack::XchSet* x = nullptr;
-    for (auto& e : s->xch_sets) if (e.st == st) { x = &e; break; }
+    for (auto& e : s->xch_sets) if (e.st == st && e.pattern == pattern) { x = &e; break; }
     const size_t need = (size_t)s->depth_ar * B * nrb * xrow > 256 ? (size_t)s->depth_ar * B * nrb * xrow : 256;   // (xrow = 0: only the counters are wanted)
     if (x && need <= x->bytes) return x;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -1103,7 +1175,7 @@ static iaf_stack::XchSet* xch_prepare(iaf_stack_t* s, int B, int nrb, size_t xro
         // graph's replays share no rows and no counters with later eager launches on the stream it came from (those allocate a
         // fresh set on their next call; include/iaf_hip.h).  None large enough: the caller runs the recomputing kernel.
         for (size_t i = s->xch_sets.size(); i-- > 0;)
-            if (need <= s->xch_sets[i].bytes) { s->xch_sets[i].st = st; return &s->xch_sets[i]; }
+            if (need <= s->xch_sets[i].bytes && s->xch_sets[i].pattern == pattern) { s->xch_sets[i].st = st; return &s->xch_sets[i]; }
         return nullptr;
     }
     if (!s->xch_err_host) {
@@ -1117,7 +1189,7 @@ static iaf_stack::XchSet* xch_prepare(iaf_stack_t* s, int B, int nrb, size_t xro
     char* nb = nullptr;
     unsigned long long* nc = x ? x->ctl : nullptr;
     bool ok = hipMalloc((void**)&nb, need) == hipSuccess &&
-              hipMemsetD32Async((hipDeviceptr_t)nb, (int)IAF_XSENT, need / 4, st) == hipSuccess;    // (ordered in front of the launch)
+              hipMemsetD32Async((hipDeviceptr_t)nb, (int)pattern, need / 4, st) == hipSuccess;    // (ordered in front of the launch)
     if (ok && !nc) ok = hipMalloc((void**)&nc, IAF_XCTL_WORDS * sizeof(unsigned long long)) == hipSuccess &&
                         hipMemsetAsync(nc, 0, IAF_XCTL_WORDS * sizeof(unsigned long long), st) == hipSuccess;
     if (!ok) {
@@ -1125,8 +1197,8 @@ static iaf_stack::XchSet* xch_prepare(iaf_stack_t* s, int B, int nrb, size_t xro
         if (nc && !(x && x->ctl == nc)) (void)hipFree(nc);
         return nullptr;
     }
-    if (!x) { s->xch_sets.emplace_back(); x = &s->xch_sets.back(); x->st = st; }
-    if (x->buf) s->xch_retired_rows.emplace_back(x->buf, x->bytes);
+    if (!x) { s->xch_sets.emplace_back(); x = &s->xch_sets.back(); x->st = st; x->pattern = pattern; }
+    if (x->buf) s->xch_retired_rows.push_back({x->buf, x->bytes, x->pattern});
     x->buf = nb; x->bytes = need; x->ctl = nc;
     return x;
 }
@@ -1137,7 +1209,7 @@ static step_fn_t fused_step_plan(const iaf_stack_t* s, int B, int H, int W, int*
                                  bool launching = false) {
     static const int env = getenv("IAF_FUSE_STEP") ? atoi(getenv("IAF_FUSE_STEP")) : -1;       // dev knob: 0 / 1
     const int mode = env >= 0 ? env : s->fuse_step;
-    if (!mode || s->generic || s->precision != IAF_PRECISION_BF16X3) return nullptr;
+    if (!mode || s->generic || !prec_split(s)) return nullptr;
     if (s->depth_ar < 1 || s->depth_ar > 4 || (s->n_h & 15) || (s->n_z & 15)) return nullptr;
     if (s->fuse_first == 1) return nullptr;                  // the caller asked for the layer-by-layer variant with a fused first conv
     for (int l = 0; l < s->nlayers; ++l)                      // ... or pinned a per-layer launch shape: the layer-by-layer path is meant
@@ -1230,6 +1302,16 @@ static int launch_fused_step(iaf_stack_t* s, step_fn_t fn, int R, size_t lds, co
         s->xch_on = false;
         return IAF_ERR_EXCHANGE;
     }
+    // An F16 launch (or the prep of its packs) met an operand beyond fp16's range (its outputs carry inf / NaN): said once, and the stack
+    // goes on with the bf16x3 kernels -- behind another prepare where the bf16x3 pack was not being kept up to date.
+    if (s->precision == IAF_PRECISION_F16X2 && !s->f16_off && s->rng_err_host && *(volatile unsigned*)s->rng_err_host) {
+        s->f16_off = true;
+        if (s->skip_bf3_pack) { s->skip_bf3_pack = false; s->prepared = false; }
+        return IAF_ERR_RANGE;
+    }
+    const bool f16 = f16_active(s);
+    const int var_i = s->variant == IAF_VARIANT_TF ? 0 : s->variant == IAF_VARIANT_THEANO ? 1 : 2;
+    bool f16_fn = false;                                     // the launch runs an F16 kernel (on the two-plane packs)
     StepP q;
     memset(&q, 0, sizeof(q));
     q.kl_part = kl_part;
@@ -1237,7 +1319,7 @@ static int launch_fused_step(iaf_stack_t* s, step_fn_t fn, int R, size_t lds, co
         for (int l = 0; l < s->depth_ar && l < 4; ++l) q.hsave[l] = hsave[l];
     q.z = (first_inmode == IN_POSTERIOR) ? nullptr : base.x;
     q.ctx = ctx; q.ctx2 = ctx2;
-    for (int l = 0; l < s->nlayers; ++l) { q.wp3[l] = s->L[l].wp3; q.bias[l] = s->L[l].bias; }
+    for (int l = 0; l < s->nlayers; ++l) { q.wp3[l] = s->L[l].wp3; q.bias[l] = s->L[l].bias; }      // (an F16 kernel: the two-plane packs, below)
     q.zin = base.zin; q.out0 = base.out0; q.out1 = base.out1; q.kl_elem = base.kl_elem;
     q.qm = base.qm; q.ql = base.ql; q.rm = base.rm; q.rl = base.rl; q.pm = base.pm; q.pl = base.pl; q.eps = base.eps;
     q.B = base.B; q.H = base.H; q.HW = base.HW; q.mode = base.mode;
@@ -1269,7 +1351,14 @@ static int launch_fused_step(iaf_stack_t* s, step_fn_t fn, int R, size_t lds, co
     if (!pair) {
         size_t xl = 0, xrow = 0;
         if (step_fn_t fx = fused_step_xch(s, base.H, base.W, R, &xl, &xrow)) {
-            if (iaf_stack::XchSet* x = xch_prepare(s, base.B, q.nrb, xrow, st)) {
+            // the exchange form on fp16 planes, where the stack asks for it and the geometry is compiled: rows of two planes, a set of its own
+            size_t xl16 = 0, xrow16 = 0;
+            step_fn_t fx16 = f16 ? iaf_pick_step_fused_f16(s->n_h / 16, s->n_z / 16, s->depth_ar, base.W, R, var_i, 1, &xl16, &xrow16) : nullptr;
+            iaf_stack::XchSet* x16 = fx16 ? xch_prepare(s, base.B, q.nrb, xrow16, st, IAF_XSENT_F16) : nullptr;
+            if (x16) {
+                fn = fx16; lds = xl16; f16_fn = true;
+                q.xh = x16->buf; q.xctl = x16->ctl; q.xerr = s->xch_err_dev; q.xknob = s->xch_knob;
+            } else if (iaf_stack::XchSet* x = xch_prepare(s, base.B, q.nrb, xrow, st)) {
                 fn = fx; lds = xl;
                 q.xh = x->buf; q.xctl = x->ctl; q.xerr = s->xch_err_dev; q.xknob = s->xch_knob;
             } else if (fn == fx) {
@@ -1288,6 +1377,17 @@ static int launch_fused_step(iaf_stack_t* s, step_fn_t fn, int R, size_t lds, co
         const int var = s->variant == IAF_VARIANT_TF ? 0 : s->variant == IAF_VARIANT_THEANO ? 1 : 2;
         if (step_fn_t fh = iaf_pick_step_fused_h(s->n_h / 16, s->n_z / 16, s->depth_ar, base.W, R, var, &hl))
             if (hl == lds) fn = fh;
+        // ... on fp16 planes (its own LDS layout: two planes per slot)
+        size_t hl16 = 0, xr16 = 0;
+        if (step_fn_t fh16 = f16 ? iaf_pick_step_fused_f16(s->n_h / 16, s->n_z / 16, s->depth_ar, base.W, R, var, 0, &hl16, &xr16) : nullptr) {
+            fn = fh16; lds = hl16; f16_fn = true;
+        }
+    }
+    if (f16_fn) {
+        for (int l = 0; l < s->nlayers; ++l) q.wp3[l] = s->L[l].wp2;
+        q.rng_err = s->rng_err_dev;
+    } else if (s->skip_bf3_pack) {
+        return IAF_ERR_NOT_PREPARED;                         // iaf_stack_set_packs: this stack's bf16x3 pack is not kept up to date
     }
     { int rc = raise_lds_cap((const void*)fn, lds); if (rc) return rc; }
     // The free-bits reductions inside the launch: kernels with helper waves, a table one workgroup can walk (the bounds of the
@@ -1297,7 +1397,7 @@ static int launch_fused_step(iaf_stack_t* s, step_fn_t fn, int R, size_t lds, co
         (long long)base.B * q.nrb * s->n_z <= 16384 && (long long)base.B * s->n_z <= 8192) {
         static const bool fin_env = !(getenv("IAF_KL_IN_LAUNCH") && getenv("IAF_KL_IN_LAUNCH")[0] == '0');
         if (fin_env && !(s->xch_knob & 16u))                 // (test knob 16: the finish launch, to compare against)
-            if (iaf_stack::XchSet* x = xch_prepare(s, base.B, q.nrb, 0, st)) {
+            if (iaf_stack::XchSet* x = xch_prepare(s, base.B, q.nrb, 0, st, f16_fn ? IAF_XSENT_F16 : IAF_XSENT)) {
                 q.fin_obj = fin->kl_obj; q.fin_cost = fin->kl_cost; q.fin_kl_min = fin->kl_min; q.fin_ctl = x->ctl + IAF_XCTL_FIN; q.fin_gate = fin->gate;
                 fin->done = true;
             }
@@ -1430,7 +1530,7 @@ extern "C" int iaf_stack_autotune(iaf_stack_t* s, const float* z, const float* c
         if ((rc = iaf_step_time_layer(s, l, z, context, z_new, logsd, B, H, W, workspace, workspace_bytes, reps, stream, &ms))) break;
         best = ms;
         int bsel[5] = {0, 0, 0, 0, 1};
-        if (saved_prec == IAF_PRECISION_BF16X3 && L.wp3 && !(is_out && s->depth_ar == 0)) {
+        if (saved_prec != IAF_PRECISION_F32 && L.wp3 && !s->skip_bf3_pack && !(is_out && s->depth_ar == 0)) {
             s->precision = IAF_PRECISION_BF16X3;
             const bool ut = L.b_user_tuned;
             const int sv[5] = {L.b_nt, L.b_ppw, L.b_pxt, L.b_ks, L.b_wco};
@@ -1544,7 +1644,16 @@ extern "C" int iaf_stack_autotune(iaf_stack_t* s, const float* z, const float* c
 
 extern "C" int iaf_stack_set_packs(iaf_stack_t* s, int packs) {
     if (!s) return IAF_ERR_NULL;
-    if (!(packs & IAF_PACK_BF16X3) || (packs & ~(IAF_PACK_F32 | IAF_PACK_BF16X3))) return IAF_ERR_SHAPE;
+    if (packs & ~(IAF_PACK_F32 | IAF_PACK_BF16X3 | IAF_PACK_F16X2)) return IAF_ERR_SHAPE;
+    // the two-plane fp16 pack exists for IAF_PRECISION_F16X2 stacks only -- and only such a stack can do without the bf16x3 pack
+    if ((packs & IAF_PACK_F16X2) && s->precision != IAF_PRECISION_F16X2) return IAF_ERR_UNSUPPORTED;
+    if (!(packs & IAF_PACK_BF16X3) && !((packs & IAF_PACK_F16X2) && !(packs & IAF_PACK_F32) && f16_active(s))) return IAF_ERR_SHAPE;
+    if (!(packs & IAF_PACK_BF16X3) && (s->generic || s->training)) return IAF_ERR_UNSUPPORTED;
+    {
+        const bool skip3 = !(packs & IAF_PACK_BF16X3);
+        if (skip3 != s->skip_bf3_pack) s->prepared = false;
+        s->skip_bf3_pack = skip3;
+    }
     if (!(packs & IAF_PACK_F32)) {            // only a stack whose every layer has a bf16x3 pack can do without the fp32 one
         if (s->generic || s->training) return IAF_ERR_UNSUPPORTED;
         for (int l = 0; l < s->nlayers; ++l)
@@ -1862,6 +1971,7 @@ extern "C" int iaf_stack_set_training(iaf_stack_t* s, int on) {
     }
     s->training = true;
     s->skip_f32_pack = false; // (training keeps every pack: iaf_stack_set_packs refuses training stacks)
+    s->skip_bf3_pack = false;
     s->prepared = false;      // the transposed packs are written by the next prepare
     return IAF_OK;
 }
@@ -2226,7 +2336,7 @@ extern "C" int iaf_step_backward(iaf_stack_t* s, const float* z, const float* co
         const GemmLayer& L = s->L[l];
         ReduceLayer& r = ra.L[ra.n++];
         r.part = tw.part[l]; r.dW = tw.dWeff[l]; r.n4 = (size_t)NTAPS * L.cin * L.cout / 4;
-        r.nrange = wgrad_nrange(P, L.cin, NTAPS, L.cout, s->precision == IAF_PRECISION_BF16X3);
+        r.nrange = wgrad_nrange(P, L.cin, NTAPS, L.cout, prec_split(s));
         int nblk = (int)((r.n4 + 255) / 256);
         if (nblk > 256) nblk = 256;
         r.blk_begin = ra.nblk_total;
@@ -2272,7 +2382,7 @@ extern "C" int iaf_step_backward(iaf_stack_t* s, const float* z, const float* co
             p.out0 = (l - 1 == 0) ? dcontext : nullptr;
         }
         if ((rc = launch_gemm(s, s->T[l], EPI_DGRAD, true, -1, p, IN_PIXMAJOR, st))) return rc;
-        if ((rc = launch_wgrad(s, s->L[l], x_in, dy, tw.part[l], tapmask, B, H, W, st, tap_sign, s->precision == IAF_PRECISION_BF16X3))) return rc;
+        if ((rc = launch_wgrad(s, s->L[l], x_in, dy, tw.part[l], tapmask, B, H, W, st, tap_sign, prec_split(s)))) return rc;
         reduce_add(l, dy);
         if (l == d) {
             wn_add(d, l, s->n_z, 2, 0);       // layer_out_0 (mean tiles)

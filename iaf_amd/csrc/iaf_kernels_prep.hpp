@@ -33,6 +33,8 @@ struct PrepLayer {
     float* wpt;      // training: TRANSPOSED pack [chunk over packed c_out][tap][c_in tile][64][4] for dX = W^T dY (or NULL)
     void* wp3;       // bf16x3 pack (iaf_conv_bf3.hpp): [c_in pair of 32][tap][cot][plane h/m/l][lane 64][8 bf16] (or NULL)
     int cin, cout_each, ncot, nchunk, zerodiag, npair, tile_begin, variant;
+    void* wp2;       // two-plane fp16 pack ("f16x2", iaf_step_fused.hpp F16): [c_in pair of 32][tap][cot][plane hi / lo 2^11][lane 64][8 fp16] (or NULL)
+    unsigned* rng_err;   // ... host-visible word raised when a weight lies beyond fp16's largest finite number (or NULL)
 };
 struct PrepArgs {
     PrepLayer L[MAX_GEMM_LAYERS];
@@ -127,6 +129,37 @@ __device__ __forceinline__ void prep_bf3_store(const PrepLayer& L, int gt, const
     }
 }
 
+// the two-plane fp16 pack of the same tile from the same registers: x = hi + lo' 2^-11 (iaf_conv_bf3.hpp, f16s_split2)
+template <int NCH, int NTP = NTAPS>
+__device__ __forceinline__ void prep_f16_store(const PrepLayer& L, int gt, const float (*w)[8], const float* s_scale) {
+    typedef _Float16 ph16x2 __attribute__((ext_vector_type(2)));
+    typedef float pf32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned pu32x4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63, quarter = threadIdx.x >> 6;
+    const float scale = s_scale[lane & 15];
+    constexpr int NUNIT = (NCH / 2) * NTP;
+    float big = 0.f;
+#pragma unroll
+    for (int i = 0; i < PREP_BF3_UPQ_T(NCH, NTP); ++i) {
+        const int u = quarter + 4 * i;
+        if (u >= NUNIT) continue;
+        const int pair = u / NTP, t = u - pair * NTP;
+        pu32x4 ph, pl;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const pf32x2 x = {w[i][2 * k] * scale, w[i][2 * k + 1] * scale};
+            big = fmaxf(big, fmaxf(__builtin_fabsf(x[0]), __builtin_fabsf(x[1])));
+            const ph16x2 hb = __builtin_convertvector(x, ph16x2);
+            const pf32x2 r = (x - __builtin_convertvector(hb, pf32x2)) * 2048.0f;
+            const ph16x2 lb = __builtin_convertvector(r, ph16x2);
+            ph[k] = __builtin_bit_cast(unsigned, hb); pl[k] = __builtin_bit_cast(unsigned, lb);
+        }
+        pu32x4* q = (pu32x4*)L.wp2 + (((size_t)(pair * NTP + t) * L.ncot + gt) * 2) * 64 + lane;
+        q[0] = ph; q[64] = pl;
+    }
+    if (big > 65504.0f && L.rng_err) __hip_atomic_store(L.rng_err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 template <int NCH, int NTP = NTAPS>
 __device__ __forceinline__ void prep_tile(const PrepLayer& L, int gt, float (*red)[17], float* s_scale) {
     const int which = (L.npair == 2) ? (gt & 1) : 0;     // output pair: even tiles = mean, odd = logsd
@@ -139,7 +172,7 @@ __device__ __forceinline__ void prep_tile(const PrepLayer& L, int gt, float (*re
 
     constexpr bool BF3 = (NCH % 2 == 0);
     float w3[BF3 ? PREP_BF3_UPQ_T(NCH, NTP) : 1][8];
-    if constexpr (BF3) { if (L.wp3) prep_bf3_load<NCH, NTP>(L, gt, w3); }
+    if constexpr (BF3) { if (L.wp3 || L.wp2) prep_bf3_load<NCH, NTP>(L, gt, w3); }
     // pass 1: fetch + mask (layers.py:57), sum of squares over (taps, c_in) (layers.py:60).  A thread owns QUADS of four
     // consecutive input channels, quad q = cs + 16 i (ci = 4q + jj): the four channels of a quad are the four floats a lane
     // of the MFMA B fragment holds, so pass 2 writes them as ONE 16-byte store and a wave as 1 KiB contiguous (one channel
@@ -151,7 +184,7 @@ __device__ __forceinline__ void prep_tile(const PrepLayer& L, int gt, float (*re
     // Round 4: a stack that keeps ONLY the bf16x3 pack (iaf_stack_set_packs; no fp32 pack, no transposed pack) has every weight of
     // the tile in w3 already -- masked, one (pair, tap) unit of 8 input channels per thread and slot -- so the sum of squares comes
     // from those registers and the second fetch of the tile (60 of the 116 strided 4-byte loads per thread at n_in = 160) is gone.
-    const bool bf3_only = BF3 && L.wp3 && !L.wp && !L.wpt;
+    const bool bf3_only = BF3 && (L.wp3 || L.wp2) && !L.wp && !L.wpt;
     if (bf3_only) {
         if constexpr (BF3) {
             constexpr int NUNIT = (NCH / 2) * NTP;
@@ -171,7 +204,8 @@ __device__ __forceinline__ void prep_tile(const PrepLayer& L, int gt, float (*re
                 L.bias[gt * 16 + oo] = bval;
             }
             __syncthreads();
-            prep_bf3_store<NCH, NTP>(L, gt, w3, s_scale);
+            if (L.wp3) prep_bf3_store<NCH, NTP>(L, gt, w3, s_scale);
+            if (L.wp2) prep_f16_store<NCH, NTP>(L, gt, w3, s_scale);
         }
         return;
     }
@@ -237,7 +271,10 @@ __device__ __forceinline__ void prep_tile(const PrepLayer& L, int gt, float (*re
                         v[t][4 * i + jj] * scale;
         }
     }
-    if constexpr (BF3) { if (L.wp3) prep_bf3_store<NCH, NTP>(L, gt, w3, s_scale); }
+    if constexpr (BF3) {
+        if (L.wp3) prep_bf3_store<NCH, NTP>(L, gt, w3, s_scale);
+        if (L.wp2) prep_f16_store<NCH, NTP>(L, gt, w3, s_scale);
+    }
 }
 
 // Theano statement of the same weights (graphy/nodes/ar.py:243-330, l2norm=True, logscale=True, pad_channel=True):

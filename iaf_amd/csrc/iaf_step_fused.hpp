@@ -63,12 +63,16 @@
 // below, imported -- and z has R + 1 rows.
 // PAIR = 1 (8-pixel rows; the header note of the kernel, "PAIR"): TWO workgroups per (image, row block), each streaming half of the last
 // hidden layer's and of the output pair's weights; the regions are those of the recomputing form.
-template <int NHT, int NZT, int DEPTH, int W, int R, int XCH = 0, int PAIR = 0>
+// F16 = 1 (round 6): the operands as TWO fp16 planes -- x = hi + lo' 2^-11, hi = fp16(x), lo' = fp16((x - hi) 2^11) -- and THREE
+// part-products per K step on v_mfma_f32_16x16x32_f16: hi hi into the main accumulator, hi lo' + lo' hi into a cross accumulator that
+// is scaled by 2^-11 where the sums meet (the kernel's header note, "f16x2").  Two planes per pixel slot and per weight fragment.
+template <int NHT, int NZT, int DEPTH, int W, int R, int XCH = 0, int PAIR = 0, int F16 = 0>
 struct StepGeom {
     static constexpr int NZ = 16 * NZT, NH = 16 * NHT;
+    static constexpr int NPL = F16 ? 2 : 3;                    // planes per operand
     static constexpr int RS = W + 2;                           // slots per row (zero column on either side)
-    static constexpr int Z8 = NZ / 8, Z16 = 3 * Z8 + 2;        // z slot: planes + pad, in 16-byte units (stride = 8 * odd dwords)
-    static constexpr int H8 = NH / 8, H16 = 3 * H8 + 2;
+    static constexpr int Z8 = NZ / 8, Z16 = NPL * Z8 + 2;      // z slot: planes + pad, in 16-byte units (stride = 8 * odd dwords)
+    static constexpr int H8 = NH / 8, H16 = NPL * H8 + 2;
     static constexpr int RZ = XCH ? R + 1 : R + DEPTH + 1;
     static constexpr int rows_h(int l) { return XCH ? R : R + DEPTH - l; }           // rows hidden layer l computes
     static constexpr int rows_reg(int l) { return XCH ? R + 1 : R + DEPTH - l; }     // rows its region holds
@@ -156,9 +160,9 @@ struct StepPartIlv {
 
 constexpr int fused_popcount(int m) { int n = 0; for (; m; m &= m - 1) ++n; return n; }
 // fragments [lo, hi) (3 per tile slot) of a ring refill that belong to live slots
-constexpr int fused_live_frags(int live, int lo, int hi) {
+constexpr int fused_live_frags(int live, int lo, int hi, int npl = 3) {
     int n = 0;
-    for (int f = lo; f < hi; ++f) n += (live >> (f / 3)) & 1;
+    for (int f = lo; f < hi; ++f) n += (live >> (f / npl)) & 1;
     return n;
 }
 // Tile slots of a hidden layer with a live centre-tap block at input pair c of a channel-triangular layer, for the waves of
@@ -213,7 +217,7 @@ struct PairPart {
 // region (R + 1 rows, 11.5 KB) through device memory with the machinery of XCH: tickets (partners hold adjacent tickets of one list, so
 // at most one workgroup per list ever waits for a partner that is not running yet), the data as the flag, helper waves.  The output
 // pair multiplies the input channels of its own half first -- they are in LDS already -- and the partner's behind the import.
-template <int NHT, int NZT, int DEPTH, int W, int R, int VAR = 0, int XCH = 0, int HLP = XCH, int PAIR = 0>
+template <int NHT, int NZT, int DEPTH, int W, int R, int VAR = 0, int XCH = 0, int HLP = XCH, int PAIR = 0, int F16 = 0>
 __global__ __launch_bounds__(HLP ? 512 : 256)
 __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fused_kernel(StepP p) {
     static_assert(HLP || !XCH, "the exchange form runs with helper waves");
@@ -221,7 +225,9 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
                   "PAIR: recomputing form with helpers, two hidden layers, n_z = 32, co tiles per half = 4 k + 1");
     constexpr bool HELP = HLP != 0;
     constexpr bool TKT = XCH != 0 || PAIR != 0;                  // the workgroup's item comes from a ticket (xch_take_*)
-    typedef StepGeom<NHT, NZT, DEPTH, W, R, XCH, PAIR> G;
+    static_assert(!F16 || !PAIR, "the pair form exists for the bf16x3 planes only");
+    typedef StepGeom<NHT, NZT, DEPTH, W, R, XCH, PAIR, F16> G;
+    constexpr int NPL = G::NPL;                                  // planes per operand: 3 bf16 (six part-products) or 2 fp16 (three)
     // exchanged rows and flags: AGENT scope (sc1: coherent across the XCDs, served by the memory side)
     constexpr int XSCOPE = __HIP_MEMORY_SCOPE_AGENT;
     constexpr bool FLIP = (VAR == 1), BORDER = (VAR != 0);
@@ -268,6 +274,25 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
         if (last_row) a += *(const f32x4*)(bt + 2 * cstride + ch);
         if (last_row || cl) a += *(const f32x4*)(bt + 3 * cstride + ch);
         return a;
+    };
+    // one f32x4 (4 consecutive channels of a pixel slot) -> the planes of an LDS region; F16: the largest magnitude this lane has split
+    // (NaNs pass fmaxf by: a NaN in the inputs is the caller's, not a range failure)
+    [[maybe_unused]] float rngmax = 0.f;
+    auto split_store4 = [&](char* region, int slot, int q, f32x4 v, int s16, int c8) {
+        if constexpr (F16) {
+            rngmax = fmaxf(fmaxf(rngmax, fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1]))), fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3])));
+            f16s_store4(region, slot, q, v, s16, c8);
+        } else {
+            bf3_store4(region, slot, q, v, s16, c8);
+        }
+    };
+    // F16: an operand beyond fp16's largest finite number went into the planes (this launch's outputs carry inf / NaN): say so where the
+    // host reads it at its next call on the stack (StepP::rng_err), which then goes back to the bf16x3 kernels
+    auto raise_range = [&]() {
+        if constexpr (F16) {
+            if (__any(rngmax > IAF_F16_MAX) && lane == 0 && p.rng_err)
+                __hip_atomic_store(p.rng_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     };
 #define IAF_FSTAMP(k) do { if (p.dbg && tid == 0) p.dbg[(size_t)blockIdx.x * 32 + (k)] = __builtin_readcyclecounter(); } while (0)
     IAF_FSTAMP(0);
@@ -334,13 +359,13 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
         constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value, LIVE = decltype(live_c)::value;
         int pair, tap;
         P::at(s < P::NSTEP ? s : P::NSTEP - 1, pair, tap);
-        const f32x4* q = wbase + (size_t)((pair + pair0) * NTAPS + tap) * ncot * 3 * 64;
+        const f32x4* q = wbase + (size_t)((pair + pair0) * NTAPS + tap) * ncot * NPL * 64;
 #pragma unroll
         for (int f = LO; f < HI; ++f) {
-            const int j = f / 3, pn = f - 3 * j;
+            const int j = f / NPL, pn = f - NPL * j;
             if (!((LIVE >> j) & 1)) continue;                              // (compile time) a dead slot of the step being fetched
             const int tc = tiles[j] < ncot ? tiles[j] : ncot - 1;
-            dst[j][pn] = *(const f32x4*)((const char*)(q + ((size_t)tc * 3 + pn) * 64) + lane16);
+            dst[j][pn] = *(const f32x4*)((const char*)(q + ((size_t)tc * NPL + pn) * 64) + lane16);
         }
     };
     typedef StepPart<0, NTAPS, 0, NZ / 32> PartL0;                          // the first layer (input z)
@@ -385,10 +410,10 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
     auto preload_w0 = [&]() {
         static_for<RD0>([&](auto i) {
             if constexpr (HL0)
-                ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTW0 * 3>{}, wrh0[decltype(i)::value], wb0, NHT, htile,
+                ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTW0 * NPL>{}, wrh0[decltype(i)::value], wb0, NHT, htile,
                           PartL0{}, decltype(i)::value, ALL, 0);
             else
-                ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWH * 3>{}, wr0[decltype(i)::value], wb0, NHT, htile,
+                ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWH * NPL>{}, wr0[decltype(i)::value], wb0, NHT, htile,
                           PartL0{}, decltype(i)::value, ALL, 0);
         });
     };
@@ -469,7 +494,7 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
                         v[r] = (zv[u][r] + zq[0][u][r]) + __expf(0.5f * (2.f * (zq[1][u][r] + zq[2][u][r]))) * zq[3][u][r];
                 }
                 if (r0 + row >= H) v = f32x4{0.f, 0.f, 0.f, 0.f};
-                bf3_store4(smem + (size_t)G::ZREG * 16, row * RS + col + 1, q, v, Z16, Z8);
+                split_store4(smem + (size_t)G::ZREG * 16, row * RS + col + 1, q, v, Z16, Z8);
             }
         }
     };
@@ -642,7 +667,9 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
         //  400 + group: a compute wave of an HLEFT kernel in hidden layer 1 -- NFULL slots, but the accumulator groups of NTWH slots, so that
         //  its sums too are those of the kernels without helpers)
         constexpr bool TALL = GRP >= 300 && GRP < 400, PTRI = GRP >= 100 && GRP < 300, HCMP = GRP >= 400;
-        constexpr int PSG = TALL ? 1 : fused_acc_groups(HCMP ? NTWH : NTW);      // accumulator groups of a unit's six part-products
+        // F16: group 0 = the main products (hi hi), groups 1 .. = the cross products (hi lo' + lo' hi; two groups where a wave holds a single
+        // tile per pixel tile, so that no MFMA waits for the one in front of it), scaled by 2^-11 where the sums meet
+        constexpr int PSG = F16 ? (NTW >= 2 ? 2 : 3) : TALL ? 1 : fused_acc_groups(HCMP ? NTWH : NTW);   // accumulator groups of a unit's part-products
         f32x4 acc[PSG][NPT][NTW];
         int xb[NPT];
 #pragma unroll
@@ -672,11 +699,12 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
             static_for<NPT>([&](auto q_c) {
                 const int a = xaddr(q_c, s0);
                 xs[0][decltype(q_c)::value][0] = smem4[a]; xs[0][decltype(q_c)::value][1] = smem4[a + in_c8];
-                xs[0][decltype(q_c)::value][2] = smem4[a + 2 * in_c8];
+                if constexpr (NPL == 3) xs[0][decltype(q_c)::value][2] = smem4[a + 2 * in_c8];
             });
         } else {
             const int a = xaddr(std::integral_constant<int, 0>{}, s0);
-            xn[0] = smem4[a]; xn[1] = smem4[a + in_c8]; xn[2] = smem4[a + 2 * in_c8];
+            xn[0] = smem4[a]; xn[1] = smem4[a + in_c8];
+            if constexpr (NPL == 3) xn[2] = smem4[a + 2 * in_c8];
         }
         // live_c: tile slots multiplied in this step; next_c: those of step s + RD, whose weights this step requests (bit masks;
         // -1 = all, 0 = a step past the end: nothing to fetch)
@@ -686,40 +714,53 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
                 constexpr int q = decltype(q_c)::value;
                 constexpr int NTQ = ((EMASK >> q) & 1) ? NTW : NTW - 1;      // tile slots multiplied for this pixel tile
                 // this pixel tile's share of the refill of the slot consumed RD steps from now
-                constexpr int LO = (q * NTW * 3) / NPT, HI = ((q + 1) * NTW * 3) / NPT;
+                constexpr int LO = (q * NTW * NPL) / NPT, HI = ((q + 1) * NTW * NPL) / NPT;
                 ring_load(std::integral_constant<int, LO>{}, std::integral_constant<int, HI>{}, wr[(I + RD) % U], wbase, ncot, tiles, part_c,
                           s + RD, next_c, pair0);
-                bf16x8 xh, xm, xl;
+                f32x4 xr[3];                                      // the pixel tile's x planes (raw 16 bytes per lane)
                 if constexpr (XAHEAD) {
-                    xh = __builtin_bit_cast(bf16x8, xs[I & 1][q][0]);
-                    xm = __builtin_bit_cast(bf16x8, xs[I & 1][q][1]);
-                    xl = __builtin_bit_cast(bf16x8, xs[I & 1][q][2]);
+                    xr[0] = xs[I & 1][q][0]; xr[1] = xs[I & 1][q][1];
+                    if constexpr (NPL == 3) xr[2] = xs[I & 1][q][2];
                     const int a = xaddr(q_c, s + 1);
-                    xs[(I + 1) & 1][q][0] = smem4[a]; xs[(I + 1) & 1][q][1] = smem4[a + in_c8]; xs[(I + 1) & 1][q][2] = smem4[a + 2 * in_c8];
+                    xs[(I + 1) & 1][q][0] = smem4[a]; xs[(I + 1) & 1][q][1] = smem4[a + in_c8];
+                    if constexpr (NPL == 3) xs[(I + 1) & 1][q][2] = smem4[a + 2 * in_c8];
                 } else {
-                    xh = __builtin_bit_cast(bf16x8, xn[0]);
-                    xm = __builtin_bit_cast(bf16x8, xn[1]);
-                    xl = __builtin_bit_cast(bf16x8, xn[2]);
+                    xr[0] = xn[0]; xr[1] = xn[1];
+                    if constexpr (NPL == 3) xr[2] = xn[2];
                     const int a = (q + 1 < NPT) ? xaddr(std::integral_constant<int, (q + 1) % NPT>{}, s)
                                                 : xaddr(std::integral_constant<int, 0>{}, s + 1);
-                    xn[0] = smem4[a]; xn[1] = smem4[a + in_c8]; xn[2] = smem4[a + 2 * in_c8];
+                    xn[0] = smem4[a]; xn[1] = smem4[a + in_c8];
+                    if constexpr (NPL == 3) xn[2] = smem4[a + 2 * in_c8];
                 }
                 constexpr int NLV = fused_popcount(LIVE & ((1 << NTQ) - 1));
-#define IAF_FPROD(K, WP, XV)                                                                                      \
+                // part-product K of the step: weight plane WP x x plane XP into accumulator group G
+#define IAF_FPROD(G, WP, XP)                                                                                       \
     static_for<NTQ>([&](auto j_c) {                                                                                \
         constexpr int j = decltype(j_c)::value;                                                                    \
-        if constexpr ((LIVE >> j) & 1)                                                                             \
-            acc[(K) % PSG][q][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wr[I][j][WP]), XV, acc[(K) % PSG][q][j], 0, 0, 0); \
+        if constexpr ((LIVE >> j) & 1) {                                                                           \
+            if constexpr (F16)                                                                                     \
+                acc[(G)][q][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wr[I][j][WP]),   \
+                                                                        __builtin_bit_cast(f16x8, xr[XP]), acc[(G)][q][j], 0, 0, 0); \
+            else                                                                                                   \
+                acc[(G)][q][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wr[I][j][WP]), \
+                                                                         __builtin_bit_cast(bf16x8, xr[XP]), acc[(G)][q][j], 0, 0, 0); \
+        }                                                                                                          \
     });
-                IAF_FPROD(0, 2, xh)
-                IAF_FPROD(1, 0, xl)
-                IAF_FPROD(2, 1, xm)
-                IAF_FPROD(3, 1, xh)
-                IAF_FPROD(4, 0, xm)
-                IAF_FPROD(5, 0, xh)
+                if constexpr (F16) {
+                    IAF_FPROD(1, 0, 1)                            // hi x lo'
+                    IAF_FPROD(0, 0, 0)                            // hi x hi   (between the two cross products: an accumulator every third MFMA at most)
+                    IAF_FPROD(PSG - 1, 1, 0)                      // lo' x hi
+                } else {
+                    IAF_FPROD(0 % PSG, 2, 0)
+                    IAF_FPROD(1 % PSG, 0, 2)
+                    IAF_FPROD(2 % PSG, 1, 1)
+                    IAF_FPROD(3 % PSG, 1, 0)
+                    IAF_FPROD(4 % PSG, 0, 1)
+                    IAF_FPROD(5 % PSG, 0, 0)
+                }
 #undef IAF_FPROD
-                constexpr int NLD = fused_live_frags(decltype(next_c)::value, LO, HI);
-                sched_interleave<6 * NLV, 3, 0, NLD>();
+                constexpr int NLD = fused_live_frags(decltype(next_c)::value, LO, HI, NPL);
+                sched_interleave<(F16 ? 3 : 6) * NLV, NPL, 0, NLD>();
                 __builtin_amdgcn_sched_barrier(0);
             });
         };
@@ -755,8 +796,14 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
                 f32x4 a = acc[0][q][j];
+                if constexpr (F16) {
+                    f32x4 c = acc[1][q][j];
+                    if constexpr (PSG == 3) c += acc[2][q][j];
+                    a += c * (1.0f / 2048.0f);                    // the cross products carry lo' = lo 2^11
+                } else {
 #pragma unroll
-                for (int g = 1; g < PSG; ++g) a += acc[g][q][j];
+                    for (int g = 1; g < PSG; ++g) a += acc[g][q][j];
+                }
                 if constexpr (decltype(accum_c)::value) acc_out[q][j] += a; else acc_out[q][j] = a;
             }
     };
@@ -807,7 +854,7 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = elu_f(v[r]);
                 if (r0 + row >= H) v = f32x4{0.f, 0.f, 0.f, 0.f};
-                bf3_store4(smem + (size_t)out_reg * 16, row * RS + col + 1, htile[j] * 4 + kk, v, H16, H8);
+                split_store4(smem + (size_t)out_reg * 16, row * RS + col + 1, htile[j] * 4 + kk, v, H16, H8);
                 // training: the rows this workgroup OWNS (not its halo) go to HBM for the backward pass
                 if (hsave && row < R && r0 + row < H && (!save_half || (htile[j] >= NHT / 2) == (half != 0)))
                     *(f32x4*)(hsave + ((size_t)b * HW + (size_t)gpix(r0 + row, col)) * NH + htile[j] * 16 + 4 * kk) = v;
@@ -862,7 +909,8 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
     // blocks above), raises the sticky word p.xctl[IAF_XCTL_STICKY] -- the buffer can no longer be trusted to be all XSENT, so every later
     // launch on it imports NaN without looking -- and the host-visible p.xerr, which the next call on the stack returns as
     // IAF_ERR_EXCHANGE; iaf_stack_set_halo_exchange re-arms the buffers.  Wrong numbers never leave silently.
-    constexpr unsigned XSENT = IAF_XSENT;
+    constexpr unsigned XSENT = F16 ? IAF_XSENT_F16 : IAF_XSENT;
+    constexpr unsigned XNAN = F16 ? 0x7e007e00u : 0x7fc07fc0u;                       // a pair of quiet NaNs of the planes' type
     constexpr int XSC1 = 16;                                                         // aux bits of the buffer instructions: sc1
     constexpr int XNU = W * H16, XNL = (XNU + 255) / 256;                            // 16-byte units of a row; per lane
     auto xch_rsrc = [&](int l, int slot) -> __amdgpu_buffer_rsrc_t {                  // one row as a buffer: accesses past its end are dropped
@@ -905,7 +953,7 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
 #pragma unroll
                 for (int u = 0; u < XNLH; ++u) {
                     const int i = htid + 256 * u;
-                    if (i >= XNU || (i % H16) >= 3 * H8) pad |= 1u << u;
+                    if (i >= XNU || (i % H16) >= NPL * H8) pad |= 1u << u;
                 }
                 const int tmo = (p.xknob & 8u) ? (1 << 10) : (1 << 20);              // a bounded wait: a lost neighbour must not hang the GPU
                 int it = xdead ? tmo : 0;
@@ -932,7 +980,7 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
                         __builtin_amdgcn_raw_buffer_store_b128(u32x4{XSENT, XSENT, XSENT, XSENT}, r, 16 * (htid + 256 * u), 0, XSC1);
                 } else {                                                             // gave up (or the buffer is marked dead): NaN, loudly
 #pragma unroll
-                    for (int u = 0; u < XNLH; ++u) t[u] = u32x4{0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u};
+                    for (int u = 0; u < XNLH; ++u) t[u] = u32x4{XNAN, XNAN, XNAN, XNAN};
                     if (lane == 0 && !xdead) {
                         if (p.xerr) __hip_atomic_store(p.xerr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         __hip_atomic_store(p.xctl + IAF_XCTL_STICKY, 1ull, __ATOMIC_RELAXED, XSCOPE);
@@ -1008,7 +1056,7 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
             const bool taken = it < tmo;
             if (!taken) {
 #pragma unroll
-                for (int u = 0; u < PNL; ++u) t[u] = u32x4{0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u};
+                for (int u = 0; u < PNL; ++u) t[u] = u32x4{XNAN, XNAN, XNAN, XNAN};
             }
 #pragma unroll
             for (int u = 0; u < PNL; ++u) { const int i = htid + 256 * u; if (i < G::PUNITS) smem4[pair_lds(i, half ^ 1)] = __builtin_bit_cast(f32x4, t[u]); }
@@ -1074,7 +1122,7 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
                 if constexpr (HL0) {
                     if (q0 >= 0) {
                         static_for<RDL0>([&](auto i) {
-                            ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}, wrl0[decltype(i)::value], wb0, NHT, lt0,
+                            ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NPL>{}, wrl0[decltype(i)::value], wb0, NHT, lt0,
                                       PartL0{}, decltype(i)::value, std::integral_constant<int, -1>{}, 0);
                         });
                         load_bias(std::integral_constant<int, 1>{}, lt0, p.bias[0], biu0);
@@ -1143,7 +1191,7 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
                             constexpr int RDL = 6;
                             f32x4 wrl[RDL + 1][1][3], accu[1][1], biu[1];
                             static_for<RDL>([&](auto i) {
-                                ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}, wrl[decltype(i)::value], wbl, NHT, lt,
+                                ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NPL>{}, wrl[decltype(i)::value], wbl, NHT, lt,
                                           PartHid{}, decltype(i)::value, std::integral_constant<int, -1>{}, 0);
                             });
                             load_bias(std::integral_constant<int, 1>{}, lt, p.bias[l], biu);
@@ -1159,7 +1207,7 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
                 }
                 if constexpr (G::HOUT8 && l == DEPTH - 1) {
                     static_for<RDOH8>([&](auto i) {
-                        ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWO * 3>{}, wroh8[decltype(i)::value],
+                        ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWO * NPL>{}, wroh8[decltype(i)::value],
                                   (const f32x4*)p.wp3[DEPTH], 2 * NZT, ot8, PartO8H{}, decltype(i)::value, std::integral_constant<int, -1>{}, 0);
                     });
                 }
@@ -1181,7 +1229,7 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
                     const f32x4* wboh = (const f32x4*)p.wp3[DEPTH];
                     f32x4 wroh[RDOH + 1][NTWO][3], accoh[NPTO_][NTWO];
                     static_for<RDOH>([&](auto i) {
-                        ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWO * 3>{}, wroh[decltype(i)::value], wboh, 2 * NZT,
+                        ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWO * NPL>{}, wroh[decltype(i)::value], wboh, 2 * NZT,
                                   ot, PartOBH{}, decltype(i)::value, std::integral_constant<int, -1>{}, 0);
                     });
                     __syncthreads();                              // row R of the last hidden layer is there
@@ -1227,6 +1275,7 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
                         for (int r = 0; r < 4; ++r) part1[pix * G::XB_STRIDE + ot8[j] * 16 + 4 * kk + r] = accoh[q][j][r];
                     }
             }
+            raise_range();                                        // (the helpers' own units went through the split too)
             __syncthreads();                                      // output pair in the exchange buffer
             // ---- the block's free-bits reductions, by the helper waves of the workgroup that arrives last (StepP::fin_*) ----
             if (p.fin_ctl && p.mode == MODE_POSTERIOR) {
@@ -1328,14 +1377,14 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
             static_for<2>([&](auto par_c) {
                 if (opar != decltype(par_c)::value) return;
                 static_for<RDO>([&](auto i) {
-                    ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWO * 3>{}, wro[decltype(i)::value], wbo, 2 * NZT,
+                    ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWO * NPL>{}, wro[decltype(i)::value], wbo, 2 * NZT,
                               otile, PairPart<NPO, decltype(par_c)::value>{}, decltype(i)::value, ALL, opair_own);
                 });
             });
             return;
         }
         static_for<RDO>([&](auto i) {
-            ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWO * 3>{}, wro[decltype(i)::value], wbo, 2 * NZT,
+            ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWO * NPL>{}, wro[decltype(i)::value], wbo, 2 * NZT,
                       otile, PartO1{}, decltype(i)::value, ALL, 0);
         });
     };
@@ -1346,19 +1395,19 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
         if constexpr (PAIR && l + 1 < DEPTH) {
             const f32x4* wbn = (const f32x4*)p.wp3[l + 1];
             static_for<RDH>([&](auto i) {
-                ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWP * 3>{}, wrp[decltype(i)::value], wbn, NHT, ptile,
+                ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWP * NPL>{}, wrp[decltype(i)::value], wbn, NHT, ptile,
                           PartHid{}, decltype(i)::value, ALL, 0);
             });
         } else if constexpr (l + 1 < DEPTH && HLEFT) {
             const f32x4* wbn = (const f32x4*)p.wp3[l + 1];
             static_for<RDH>([&](auto i) {
-                ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTW1 * 3>{}, wrh1[decltype(i)::value], wbn, NHT, htile,
+                ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTW1 * NPL>{}, wrh1[decltype(i)::value], wbn, NHT, htile,
                           PartH1{}, decltype(i)::value, ALL, 0);
             });
         } else if constexpr (l + 1 < DEPTH) {
             const f32x4* wbn = (const f32x4*)p.wp3[l + 1];
             static_for<RDH>([&](auto i) {
-                ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWH * 3>{},
+                ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWH * NPL>{},
                           ((l + 1) & 1) ? wr1[decltype(i)::value] : wr0[decltype(i)::value], wbn, NHT, htile, PartH1{}, decltype(i)::value,
                           ALL, 0);
             });
@@ -1448,7 +1497,7 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
                        wrh1, accl, PartH1{}, std::integral_constant<int, 400 + GI>{}, SET, 0);
             if constexpr (XCH) {
                 static_for<RDH>([&](auto i) {
-                    ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTW1 * 3>{}, wrh1[decltype(i)::value], wbl, NHT, htile,
+                    ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTW1 * NPL>{}, wrh1[decltype(i)::value], wbl, NHT, htile,
                               PartBelow{}, decltype(i)::value, ALL, 0);
                 });
                 IAF_FSTAMP(28);
@@ -1491,7 +1540,7 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
                        (l & 1) ? wr1 : wr0, accl, PartH1{}, g_c, SET, 0);
             if constexpr (XCH) {     // the row below arrives while the taps of the own rows were multiplied: its taps now
                 static_for<RDH>([&](auto i) {
-                    ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWH * 3>{},
+                    ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWH * NPL>{},
                               (l & 1) ? wr1[decltype(i)::value] : wr0[decltype(i)::value], wbl, NHT, htile, PartBelow{}, decltype(i)::value, ALL, 0);
                 });
                 if constexpr (l == 1) IAF_FSTAMP(28);
@@ -1512,6 +1561,7 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
         __syncthreads();
     });
     IAF_FSTAMP(3);
+    raise_range();
 
     // ---- output pair: packed tiles (m_0, s_0, m_1, s_1, ...), partial sums -> exchange buffer [K part][pixel][2 n_z] -------
     // (the operands of the final transform are fetched first: they travel while the output pair is multiplied)
@@ -1528,7 +1578,7 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
                        std::integral_constant<int, R>{}, std::integral_constant<int, (1 << NPTO) - 1>{}, LAST_REG,
                        H16, H8, wbo, 2 * NZT, otile, wro, acco, PairPart<NPO, PAR>{}, std::integral_constant<int, 0>{}, SET, opair_own);
             static_for<RDO>([&](auto i) {
-                ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWO * 3>{}, wro[decltype(i)::value], wbo, 2 * NZT,
+                ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWO * NPL>{}, wro[decltype(i)::value], wbo, 2 * NZT,
                           otile, PairPart<NPR, PAR>{}, decltype(i)::value, ALL, opair_rest);
             });
             IAF_FSTAMP(29);
@@ -1557,7 +1607,7 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
             // (HOUT: the helper takes the odd steps; 10 steps here and tap (+1,+1)'s 5 there was no faster: 48.8 k against 48.5 k cycles)
             typedef std::conditional_t<G::HOUT, BelowPar<NPAIR_H, 0>, PartBelow> PartOB;
             static_for<RDO>([&](auto i) {
-                ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWO * 3>{}, wro[decltype(i)::value], wbo, 2 * NZT,
+                ring_load(std::integral_constant<int, 0>{}, std::integral_constant<int, NTWO * NPL>{}, wro[decltype(i)::value], wbo, 2 * NZT,
                           otile, PartOB{}, decltype(i)::value, ALL, 0);
             });
             IAF_FSTAMP(29);

@@ -169,3 +169,26 @@ extern "C" step_fn_t iaf_pick_step_fused_d(int nht, int nzt, int depth, int W, i
     return nullptr;
 }
 #endif
+
+#if !defined(IAF_FUSED_PART) || IAF_FUSED_PART == 5
+// the two-plane fp16 kernels (round 6, "f16x2": three part-products per K step instead of six): the BASELINE run's two geometries, TF
+// statement -- 16-pixel rows in the exchange form (form 1), 8-pixel rows recomputing with helper waves (form 0)
+template <int NHT, int NZT, int DEPTH, int W, int R, int XCH>
+static step_fn_t inst_f16(size_t* lds, size_t* xrow) {
+    typedef StepGeom<NHT, NZT, DEPTH, W, R, XCH, 0, 1> G;
+    static_assert((G::CSTR & 15) == 4 || (G::CSTR & 15) == 12, "context rows: 4 channel groups x 16 pixels must hit 64 distinct banks");
+    // (the staged context may reach past the h_odd region's end here -- two-plane regions are smaller than the fp32 context rows --;
+    //  StepGeom::lds_bytes() covers it, and nothing else lives behind that region)
+    static_assert(G::lds_bytes() <= 160 * 1024 && (DEPTH % 2 != 0 || G::xb_bytes() <= (size_t)G::HREG1 * 16), "the two-plane regions");
+    *lds = G::lds_bytes();
+    if (xrow) *xrow = XCH ? G::xrow_bytes() : 0;
+    return iaf_step_fused_kernel<NHT, NZT, DEPTH, W, R, 0, XCH, 1, 0, 1>;
+}
+extern "C" step_fn_t iaf_pick_step_fused_f16(int nht, int nzt, int depth, int W, int R, int var, int form, size_t* lds, size_t* xrow) {
+    *lds = 0; *xrow = 0;
+    if (var != 0 || nht != 10 || nzt != 2 || depth != 2) return nullptr;
+    if (form == 1 && W == 16 && R == 2) return inst_f16<10, 2, 2, 16, 2, 1>(lds, xrow);
+    if (form == 0 && W == 8 && R == 1) return inst_f16<10, 2, 2, 8, 1, 0>(lds, xrow);
+    return nullptr;
+}
+#endif

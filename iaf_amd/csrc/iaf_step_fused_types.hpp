@@ -42,6 +42,8 @@ struct StepP {
     unsigned long long* xctl;      // [32 y] head of work list y (tickets taken), [32 y + 16] its arrivals, [IAF_XCTL_DONE] lists complete,
                                    // [IAF_XCTL_STICKY] sticky error -- a 128-byte line each; zero between launches
     unsigned* xerr;                // host-visible error word (mapped pinned memory), or NULL
+    unsigned* rng_err;             // F16 kernels: host-visible word (mapped pinned memory) raised when an operand beyond fp16's largest finite
+                                   // number went into the planes (the launch's outputs then carry inf / NaN); or NULL
     unsigned xknob;                // test knobs: 1 lists ignore the placement, 2 tickets out of dispatch order,
                                    // 8 fault injection (image 0's bottom block never hands over its first row; short waits)
 };
@@ -62,6 +64,9 @@ struct StepP {
 // first used 0xffffffff -- which a NaN of all ones in the inputs does reach -- plus a fix-up in the exporting helper waves: 0.7 us per
 // 16x16 launch, VALU work in waves that share their SIMD's issue with a compute wave).
 #define IAF_XSENT 0xffbfffbfu
+// ... of the F16 kernels, whose rows hold fp16 planes: a pair of SIGNALLING fp16 NaNs (exponent all ones, quiet bit 9 clear) -- 0xffbf read as
+// fp16 is a QUIET NaN, which a conversion of a caller's NaN can return
+#define IAF_XSENT_F16 0xfdfffdffu
 
 typedef void (*step_fn_t)(StepP);
 // kernel + dynamic LDS bytes for (n_h / 16, n_z / 16, depth_ar, image width, output rows per workgroup), or NULL
@@ -78,6 +83,8 @@ extern "C" step_fn_t iaf_pick_step_fused_xch_c(int nht, int nzt, int depth, int 
 extern "C" step_fn_t iaf_pick_step_fused_pair(int nht, int nzt, int depth, int W, int R, int var, size_t* lds, size_t* prow);
 extern "C" step_fn_t iaf_pick_step_fused_d(int nht, int nzt, int depth, int W, int R, int var, size_t* lds);   // n_z = 32, depth_ar = 2, n_h = 64 / 128
 extern "C" step_fn_t iaf_pick_step_fused_xch_d(int nht, int nzt, int depth, int W, int R, int var, size_t* lds, size_t* xrow);
+// the two-plane fp16 kernels ("f16x2"): form = 0 recomputing with helper waves, 1 halo exchange; *xrow as above (0 for form 0)
+extern "C" step_fn_t iaf_pick_step_fused_f16(int nht, int nzt, int depth, int W, int R, int var, int form, size_t* lds, size_t* xrow);
 static inline step_fn_t iaf_pick_step_fused(int nht, int nzt, int depth, int W, int R, int var, size_t* lds) {
     step_fn_t f = iaf_pick_step_fused_a(nht, nzt, depth, W, R, var, lds);
     if (!f) f = iaf_pick_step_fused_b(nht, nzt, depth, W, R, var, lds);

@@ -221,9 +221,13 @@ class ARStack(object):
 
     def set_precision(self, precision):
         """"bf16x3" (default): forward masked convs on the bf16 matrix cores as six split products, fp32-grade;
-        "f32": the exact-fp32 MFMA (bit-equal to an fmaf chain).  See include/iaf_hip.h."""
-        code = {"f32": _capi.IAF_PRECISION_F32, "bf16x3": _capi.IAF_PRECISION_BF16X3}.get(precision, precision)
+        "f32": the exact-fp32 MFMA (bit-equal to an fmaf chain); "f16x2": as bf16x3, with the one-launch step kernels of the
+        BASELINE geometries on TWO fp16 planes and three products (operands up to 65504; beyond: RangeError at the next call and
+        bf16x3 from then on).  See include/iaf_hip.h."""
+        code = {"f32": _capi.IAF_PRECISION_F32, "bf16x3": _capi.IAF_PRECISION_BF16X3,
+                "f16x2": _capi.IAF_PRECISION_F16X2}.get(precision, precision)
         _capi.check(_capi.lib().iaf_stack_set_precision(self._h, int(code)))
+        self._prep_key = None                        # (the set of packs the next prepare writes may have changed)
 
     def layer_precision(self, layer, B, H, W):
         """what a forward launch of GEMM layer `layer` at this size will run: "bf16x3" or "f32" (layers the bf16x3 kernels
@@ -280,10 +284,19 @@ class ARStack(object):
                     % (1 if B * nrb * self.n_z <= 16384 else 2))
         return "%d masked convs + 2 KL reductions" % (self.depth_ar + 1)
 
-    def set_packs(self, f32=True):
+    def set_packs(self, f32=True, bf16x3=True, f16x2=False):
         """which weight packs the prep launches keep up to date: f32=False drops the fp32 fragment pack (a stack whose
-        every launch runs on the bf16 matrix cores; a launch that would need it raises).  See include/iaf_hip.h."""
-        _capi.check(_capi.lib().iaf_stack_set_packs(self._h, _capi.IAF_PACK_BF16X3 | (_capi.IAF_PACK_F32 if f32 else 0)))
+        every launch runs on the bf16 matrix cores; a launch that would need it raises); f16x2=True with the other two False keeps
+        only the two-plane fp16 pack ("f16x2" stacks whose every launch is an F16 step kernel).  See include/iaf_hip.h."""
+        _capi.check(_capi.lib().iaf_stack_set_packs(self._h, (_capi.IAF_PACK_BF16X3 if bf16x3 else 0) | (_capi.IAF_PACK_F32 if f32 else 0) |
+                                                    (_capi.IAF_PACK_F16X2 if f16x2 else 0)))
+        self._prep_key = None
+
+    def range_errors(self):
+        """the range word of an "f16x2" stack (iaf_stack_range_errors): 0 = no operand beyond fp16's range so far"""
+        e = ctypes.c_uint(0)
+        _capi.check(_capi.lib().iaf_stack_range_errors(self._h, ctypes.byref(e)))
+        return int(e.value)
 
     def exchange_errors(self):
         """bounded waits of the halo exchange between row blocks that gave up (iaf_stack_exchange_errors): 0 = never"""

@@ -38,6 +38,10 @@ extern "C" {
                                     * tensor pointers it has been captured with into hipGraphs (a captured launch cannot be fed
                                     * a table that changes under it); 16 per object, for the object's life.  Re-capturing the
                                     * same tensors shares a table.  Beyond that: create another batch object. */
+#define IAF_ERR_RANGE (-9)         /* IAF_PRECISION_F16X2: an operand beyond fp16's largest finite number (65504) went into the two-plane fp16
+                                    * kernels in an EARLIER launch of this stack (see iaf_stack_range_errors): that launch's outputs carry
+                                    * inf / NaN; the stack has gone back to the bf16x3 kernels (whose planes have fp32's exponent range) --
+                                    * prepare again if the next call says IAF_ERR_NOT_PREPARED, then repeat the call */
 #define IAF_ERR_EXCHANGE (-7)      /* a bounded wait of the halo exchange gave up in an EARLIER launch of this stack (see
                                     * iaf_stack_exchange_errors): that launch's outputs carry NaN; the stack has switched to the
                                     * kernels that recompute their halo rows, and the call can simply be repeated */
@@ -270,9 +274,22 @@ int iaf_stack_set_tuning(iaf_stack_t* s, int layer, int nt, int pxt, int wco, in
  * gradients, the plain 9-tap convs) or do not speed up (fewer than ~4096 pixels per launch, unless autotuned or a shape
  * is pinned) run the fp32 kernel in either mode; iaf_stack_get_precision reports what GEMM layer `layer` will run at a
  * given problem size.  Outputs of the two modes differ by fp32 round-off only; each is deterministic. */
+/*   IAF_PRECISION_F16X2 (round 6)   as BF16X3, except that the one-launch step kernels compiled for it (TF statement, n_z = 32,
+ *       n_h = 160, depth_ar = 2, images 16 and 8 pixels wide: the BASELINE run) split every operand into TWO fp16 planes, x = hi +
+ *       lo' 2^-11 with hi = fp16(x), lo' = fp16((x - hi) 2^11), and accumulate THREE part-products per K step on
+ *       v_mfma_f32_16x16x32_f16 -- hi hi' in one fp32 accumulator, hi lo' + lo' hi' in a second one that is scaled by 2^-11 where
+ *       the sums meet: half the matrix-core instructions and two thirds of the pack and LDS bytes of bf16x3, 22 significand bits
+ *       per operand, error against an fp64 evaluation within the bound tests/test_hip_dynamic_range.py holds bf16x3 to.  What fp16
+ *       does not have is fp32's exponent range: an operand (weight or activation) beyond 65504 makes the launch's outputs inf / NaN
+ *       and raises a word in mapped host memory; the stack's NEXT call returns IAF_ERR_RANGE once and the stack runs the bf16x3
+ *       kernels from then on (iaf_stack_range_errors reads the word; iaf_stack_set_precision(s, F16X2) re-arms).  Every other
+ *       launch of such a stack (other geometries, layer-by-layer kernels, backward) is the BF16X3 one. */
 #define IAF_PRECISION_F32 0
 #define IAF_PRECISION_BF16X3 1
+#define IAF_PRECISION_F16X2 2
 int iaf_stack_set_precision(iaf_stack_t* s, int precision);
+/* *errors = the range word of an IAF_PRECISION_F16X2 stack (0: none; bit 0: an activation, bit 1: a weight); synchronises the device */
+int iaf_stack_range_errors(const iaf_stack_t* s, unsigned* errors);
 int iaf_stack_get_precision(const iaf_stack_t* s, int layer, int B, int H, int W);
 /* launch shape of the bf16x3 kernel for GEMM layer `layer`: co tiles per wave, pixel tiles per wave, waves along
  * pixels, K-slice waves, co groups sharing one staged activation tile (nt = 0 restores the automatic choice) */
@@ -313,8 +330,11 @@ int iaf_stack_set_fuse_step(iaf_stack_t* s, int mode);
  * stacks and stacks with a layer outside the bf16x3 kernels (c_in not a multiple of 32) refuse with IAF_ERR_UNSUPPORTED.
  * The reference re-derives w = exp(g) * mask*V / ||mask*V|| every step (layers.py:56-60); which layout it is left in is
  * this engine's business. */
+/* IAF_PRECISION_F16X2 stacks also write IAF_PACK_F16X2, the two-plane fp16 pack (4 B per weight); one whose every launch is an F16
+ * step kernel can keep ONLY that: packs = IAF_PACK_F16X2. */
 #define IAF_PACK_F32 1
 #define IAF_PACK_BF16X3 2
+#define IAF_PACK_F16X2 4
 int iaf_stack_set_packs(iaf_stack_t* s, int packs);
 int iaf_stack_step_is_fused(const iaf_stack_t* s, int B, int H, int W);
 /* The one-launch step at 16-pixel rows (the BASELINE geometry and the deep stacks of config 3, all three statements of the
