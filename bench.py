@@ -66,10 +66,11 @@ def parse():
                     help="extra mode (not the headline metric): data-parallel TRAINING step of the IAF posterior stack -- "
                          "posterior block forward + backward for every layer, one RCCL all-reduce of the flat gradient "
                          "buffer, fused Adamax + EMA")
-    ap.add_argument("--precision", type=str, default="bf16x3", choices=["bf16x3", "f32"],
-                    help="arithmetic of the forward masked convs: bf16x3 = fp32 operands split into three bf16 parts, six "
-                         "part-products accumulated in fp32 on the bf16 matrix cores (fp32-grade; the engine's default); "
-                         "f32 = the exact-fp32 MFMA everywhere")
+    ap.add_argument("--precision", type=str, default="f16x2", choices=["f16x2", "bf16x3", "f32"],
+                    help="arithmetic of the forward masked convs: f16x2 (the engine's default since round 6) = the one-launch step "
+                         "kernels of the BASELINE geometries split every fp32 operand into two fp16 planes (hi, lo 2^11) and accumulate "
+                         "three part-products in two fp32 accumulators on the fp16 matrix cores, everything else as bf16x3; bf16x3 = "
+                         "three bf16 parts, six part-products (fp32-grade; round 5's default); f32 = the exact-fp32 MFMA everywhere")
     ap.add_argument("--no-fuse", action="store_true",
                     help="never run the first masked conv inside the second one's kernel (iaf_stack_set_fuse_first)")
     ap.add_argument("--no-fuse-step", action="store_true",
@@ -1277,10 +1278,13 @@ def main():
 
     # every IAF step of this workload runs as ONE bf16x3 launch: the prep launch need not keep the fp32 fragment pack up to
     # date (iaf_stack_set_packs; a launch that needed it would fail loudly, not read stale weights)
-    bf3_only = (not args.keep_f32_pack) and args.precision == "bf16x3" and all(L["one"] for L in layers)
+    bf3_only = (not args.keep_f32_pack) and args.precision in ("bf16x3", "f16x2") and all(L["one"] for L in layers)
+    # ... and where every one of them is a two-plane fp16 kernel, not the bf16x3 pack either (4 B per weight instead of 6 + 4)
+    f16_all = args.precision == "f16x2" and all(L["stack"].step_is_f16(args.batch, L["H"], L["H"]) for L in layers)
+    f16_only = bf3_only and f16_all
     if bf3_only:
         for L in layers:
-            L["stack"].set_packs(f32=False)
+            L["stack"].set_packs(f32=False, bf16x3=not f16_only, f16x2=f16_only)
             L["stack"].prepare(L["params"])
     prep = iaf_amd.PrepBatch([L["stack"] for L in layers])
     plist = [L["params"] for L in layers]
@@ -1421,7 +1425,8 @@ def main():
                 tf_ = w["live_flops"] / (ms * 1e-3) / 1e12
                 ktable.append({"layer": "IAF step: masked convs %d->%d%s->%d (mean,logsd pair) + affine/log-det, ONE launch, %d rows per workgroup"
                                         % (args.n_z, args.n_h, "->%d" % args.n_h if args.depth_ar > 1 else "", 2 * args.n_z, L["one"]),
-                               "latent": "%dx%d" % (H, H), "kernel": "bf16x3", "us": 1e3 * ms, "live_gflop": w["live_flops"] / 1e9,
+                               "latent": "%dx%d" % (H, H), "kernel": "f16x2" if st.step_is_f16(args.batch, H, H) else "bf16x3",
+                               "us": 1e3 * ms, "live_gflop": w["live_flops"] / 1e9,
                                "live_tflops": tf_, "frac": tf_ / PEAK_BF16X3_TFLOPS, "frac_of_f32_mfma_peak": tf_ / PEAK_F32_MFMA_TFLOPS,
                                "us_method": ("in situ: the level's %d launches (every layer its own packs and inputs) replayed as a graph "
                                              "between one event pair, %d launches, gaps included" % (len([x for x in layers if x["H"] == H]), insitu_n[H]))
@@ -1489,7 +1494,7 @@ def main():
                 sw = st.step_work(args.batch, H, H)
                 xunit.append({"latent": "%dx%d" % (H, H), "us": us, "samples_per_s": args.batch / (us * 1e-6),
                               "live_tflops": sw["live_flops"] / (us * 1e-6) / 1e12,
-                              "frac": sw["live_flops"] / (us * 1e-6) / 1e12 / (PEAK_BF16X3_TFLOPS if args.precision == "bf16x3" else PEAK_F32_MFMA_TFLOPS),
+                              "frac": sw["live_flops"] / (us * 1e-6) / 1e12 / (PEAK_BF16X3_TFLOPS if args.precision != "f32" else PEAK_F32_MFMA_TFLOPS),
                               "frac_of_f32_mfma_peak": sw["live_flops"] / (us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                               "repeats_us": xs,
                               "launches": st.posterior_block_launches(args.batch, H, H),
@@ -1528,8 +1533,9 @@ def main():
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    dom_kernel = "bf16x3" if one16 else st0.layer_precision(dom_layer, args.batch, 16, 16)
-    pipe_peak = PEAK_BF16X3_TFLOPS if dom_kernel == "bf16x3" else PEAK_F32_MFMA_TFLOPS
+    dom_f16 = one16 and st0.step_is_f16(args.batch, 16, 16)
+    dom_kernel = ("f16x2" if dom_f16 else "bf16x3") if one16 else st0.layer_precision(dom_layer, args.batch, 16, 16)
+    pipe_peak = PEAK_BF16X3_TFLOPS if dom_kernel in ("bf16x3", "f16x2") else PEAK_F32_MFMA_TFLOPS
     roofline = {
         # yardstick = the pipe the kernel's instruction stream runs on (VERDICT r03 "next" #5).  bf16x3 kernels issue
         # v_mfma_f32_16x16x32_bf16: dense bf16 peak 2500 TF / 6 part-products per fp32 product = 416.7 TF of fp32-grade live FLOPs.
@@ -1537,10 +1543,14 @@ def main():
         # kept next to it (frac_of_f32_mfma_peak): config 3's n_h = 192 already exceeds it, so it can no longer rank kernels.
         "bound": "mfma", "achieved": achieved, "peak": pipe_peak, "unit": "TFLOP/s",
         "frac": achieved / pipe_peak, "traffic": traffic,
-        "peak_note": ("dense bf16 MFMA peak 2500 TF / 6 bf16 part-products per fp32 product" if dom_kernel == "bf16x3"
-                      else "dense fp32 MFMA peak (v_mfma_f32_16x16x4_f32)"),
+        "peak_note": ("dense bf16 MFMA peak 2500 TF / 6 bf16 part-products per fp32 product" if dom_kernel == "bf16x3" else
+                      "416.7 TF = dense 16-bit MFMA peak 2500 TF / 6: the bf16x3 yardstick of rounds 4-5, KEPT as the denominator (VERDICT r05 "
+                      "'next' #1) although this kernel issues 3 fp16 part-products per fp32 product -- against its own pipe "
+                      "(2500 / 3 = 833.3 TF) see frac_of_own_pipe" if dom_kernel == "f16x2" else
+                      "dense fp32 MFMA peak (v_mfma_f32_16x16x4_f32)"),
         "frac_of_f32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS, "peak_f32_mfma": PEAK_F32_MFMA_TFLOPS,
         "dominant_kernel_family": dom_kernel,
+        "frac_of_own_pipe": achieved / (PEAK_BF16_MFMA_TFLOPS / 3.0) if dom_kernel == "f16x2" else achieved / pipe_peak,
         # how many MACs the launch ISSUES per live MAC (halo rows of the hidden layers recomputed per row block where they are
         # not exchanged, partially filled pixel tiles, dead centre-tap blocks multiplied as stored zeros)
         "issued_over_live": _issued_over_live(args, prof[0]["one"], 16) if one16 else 1.0,
@@ -1573,6 +1583,9 @@ def main():
     xerrs = sum(L["stack"].exchange_errors() for L in layers)
     if xerrs:
         raise RuntimeError("one-launch IAF step: %d halo-exchange wait(s) gave up (iaf_stack_exchange_errors)" % xerrs)
+    # ... and an operand beyond fp16's range in a two-plane fp16 kernel would have produced inf / NaN
+    if any(L["stack"].range_errors() for L in layers):
+        raise RuntimeError("one-launch IAF step (f16x2): an operand beyond fp16's range (iaf_stack_range_errors)")
     rp = os.path.join(ROOT, "profiles", "rocprof_dominant_kernel.json")
     if os.path.exists(rp):
         try:
@@ -1586,7 +1599,10 @@ def main():
         "metric": "IAF-step samples/sec (down_iaf2_nl posterior stack, forward + log-det)",
         "value": value, "unit": "samples/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.precision == "f32" else "f32 (operands split into 3 bf16 parts, 6 part-products on the bf16 MFMA, fp32 accumulate: fp32-grade error)",
+        "dtype": "f32" if args.precision == "f32" else
+                 "f32 (operands split into 2 fp16 planes hi + lo 2^-11, 3 part-products on the fp16 MFMA in two fp32 accumulators: fp32-grade error, "
+                 "operands up to 65504)" if f16_all else
+                 "f32 (operands split into 3 bf16 parts, 6 part-products on the bf16 MFMA, fp32 accumulate: fp32-grade error)",
         "data": "synthetic",
         "config": {
             "workload": "cifar10 n_z=%d n_h=%d depths=%s depth_ar=%d down_iaf2_nl bs=%d per GPU (BASELINE configs[1]); "
@@ -1596,6 +1612,7 @@ def main():
             "global_batch": n_gpus * args.batch, "iaf_steps_per_step": n_iaf,
             "iaf_step_samples_per_s": value * n_iaf,
             "weights": ("re-derived every step (mask, l2-norm, exp(g)) for all layers in one batched launch" + (
+                            "; two-plane fp16 packs only (no launch of this workload reads another)" if f16_only else
                             "; bf16x3 packs only (no launch of this workload reads the fp32 pack)" if bf3_only else "")) if not args.cached_weights else "prepared once",
             "launch": "hipGraph replay" if graph is not None else "eager",
             "parallelism": "dp%d (batch-sharded replicas, no forward collective)" % n_gpus,
@@ -1607,6 +1624,7 @@ def main():
             "halo_exchange": sorted({"%dx%d" % (L["H"], L["H"]) for L in layers if L["stack"].step_exchanges(args.batch, L["H"], L["H"])}),
             "timing": "median of %d repeats of the timed region (%d steps each, barrier + synchronize on both sides); %d untimed "
                       "settle replays after the %d warm-up steps" % (len(repeats), args.steps, n_settle, args.warmup),
+            "settle_replays": n_settle,
         },
         "roofline": roofline,
     }

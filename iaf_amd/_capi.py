@@ -92,6 +92,7 @@ SIGNATURES = {
     "iaf_up_iaf2_backward_post": (ctypes.c_int, [_c_float_p] * 7 + [ctypes.c_int] * 4 + [_vp]),
     "iaf_stack_exchange_errors": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint)]),
     "iaf_stack_range_errors": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint)]),
+    "iaf_stack_step_is_f16": (ctypes.c_int, [_vp] + [ctypes.c_int] * 3),
     "iaf_stack_step_exchanges": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "iaf_stack_step_pairs": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "iaf_stack_set_halo_exchange": (ctypes.c_int, [_vp, ctypes.c_int]),

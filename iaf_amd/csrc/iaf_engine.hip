@@ -445,6 +445,18 @@ extern "C" int iaf_stack_create(iaf_stack_t** out, int n_z, int n_h, int depth_a
         }
         cin = each;
     }
+    // Default arithmetic (round 6): where the two-plane fp16 step kernels are compiled for the stack -- TF statement, (n_z, n_h, depth_ar) =
+    // (32, 160, 2): the BASELINE run -- a new stack asks for them (IAF_PRECISION_F16X2: bf16x3 everywhere else, and after a range
+    // failure); IAF_DEFAULT_PRECISION=bf16x3 keeps round 5's default.
+    if (!generic && variant == IAF_VARIANT_TF) {
+        static const bool f16_default = !(getenv("IAF_DEFAULT_PRECISION") && !strcmp(getenv("IAF_DEFAULT_PRECISION"), "bf16x3"));
+        size_t l16 = 0, x16 = 0;
+        if (f16_default && (iaf_pick_step_fused_f16(n_h / 16, n_z / 16, depth_ar, 16, 2, 0, 1, &l16, &x16) ||
+                            iaf_pick_step_fused_f16(n_h / 16, n_z / 16, depth_ar, 8, 1, 0, 0, &l16, &x16))) {
+            int rc = iaf_stack_set_precision(s, IAF_PRECISION_F16X2);
+            if (rc != IAF_OK && rc != IAF_ERR_UNSUPPORTED) { iaf_stack_destroy(s); return rc; }
+        }
+    }
     *out = s;
     return IAF_OK;
 }
@@ -1265,6 +1277,18 @@ extern "C" int iaf_stack_step_pairs(const iaf_stack_t* s, int B, int H, int W) {
     size_t lds = 0, pl = 0, prow = 0;
     step_fn_t fn = fused_step_plan(s, B, H, W, &R, &lds);
     return (fn && fn == fused_step_pair(s, W, &pl, &prow)) ? 1 : 0;
+}
+
+// 1: the one-launch step at this size runs a two-plane fp16 kernel (IAF_PRECISION_F16X2, a compiled geometry, no range failure so far)
+extern "C" int iaf_stack_step_is_f16(const iaf_stack_t* s, int B, int H, int W) {
+    if (!s || B <= 0 || H <= 0 || W <= 0 || !f16_active(s)) return 0;
+    const int R = iaf_stack_step_is_fused(s, B, H, W);
+    if (R <= 0 || iaf_stack_step_pairs(s, B, H, W)) return 0;
+    const int var = s->variant == IAF_VARIANT_TF ? 0 : s->variant == IAF_VARIANT_THEANO ? 1 : 2;
+    size_t l = 0, x = 0, xl = 0, xr = 0;
+    if (fused_step_xch(s, H, W, R, &xl, &xr)) return iaf_pick_step_fused_f16(s->n_h / 16, s->n_z / 16, s->depth_ar, W, R, var, 1, &l, &x) ? 1 : 0;
+    static const int h8_env = getenv("IAF_STEP_HELPERS") ? atoi(getenv("IAF_STEP_HELPERS")) : -1;
+    return (h8_env != 0 && iaf_pick_step_fused_f16(s->n_h / 16, s->n_z / 16, s->depth_ar, W, R, var, 0, &l, &x)) ? 1 : 0;
 }
 
 extern "C" int iaf_stack_step_exchanges(const iaf_stack_t* s, int B, int H, int W) {

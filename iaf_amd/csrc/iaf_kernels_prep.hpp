@@ -157,7 +157,7 @@ __device__ __forceinline__ void prep_f16_store(const PrepLayer& L, int gt, const
         pu32x4* q = (pu32x4*)L.wp2 + (((size_t)(pair * NTP + t) * L.ncot + gt) * 2) * 64 + lane;
         q[0] = ph; q[64] = pl;
     }
-    if (big > 65504.0f && L.rng_err) __hip_atomic_store(L.rng_err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (big > 65504.0f && L.rng_err) __hip_atomic_fetch_or(L.rng_err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 template <int NCH, int NTP = NTAPS>

@@ -291,7 +291,7 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
     auto raise_range = [&]() {
         if constexpr (F16) {
             if (__any(rngmax > IAF_F16_MAX) && lane == 0 && p.rng_err)
-                __hip_atomic_store(p.rng_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_fetch_or(p.rng_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     };
 #define IAF_FSTAMP(k) do { if (p.dbg && tid == 0) p.dbg[(size_t)blockIdx.x * 32 + (k)] = __builtin_readcyclecounter(); } while (0)

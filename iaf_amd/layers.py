@@ -292,6 +292,10 @@ class ARStack(object):
                                                     (_capi.IAF_PACK_F16X2 if f16x2 else 0)))
         self._prep_key = None
 
+    def step_is_f16(self, B, H, W):
+        """True if the one-launch step at this size runs a two-plane fp16 kernel ("f16x2" precision, a compiled geometry)"""
+        return bool(_capi.lib().iaf_stack_step_is_f16(self._h, int(B), int(H), int(W)))
+
     def range_errors(self):
         """the range word of an "f16x2" stack (iaf_stack_range_errors): 0 = no operand beyond fp16's range so far"""
         e = ctypes.c_uint(0)
@@ -634,7 +638,8 @@ class WNConv2d(object):
     def set_precision(self, precision):
         """"bf16x3" (default: the forward conv on the bf16 matrix cores with split products, fp32-grade, where a launch shape
         covers it) or "f32" (the exact-fp32 MFMA kernel always)"""
-        code = {"f32": _capi.IAF_PRECISION_F32, "bf16x3": _capi.IAF_PRECISION_BF16X3}.get(precision, precision)
+        # ("f16x2" is an arithmetic of the one-launch step kernels only: a plain conv runs bf16x3 under it)
+        code = {"f32": _capi.IAF_PRECISION_F32, "bf16x3": _capi.IAF_PRECISION_BF16X3, "f16x2": _capi.IAF_PRECISION_BF16X3}.get(precision, precision)
         _capi.check(_capi.lib().iaf_conv3x3_set_precision(self._h, int(code)))
 
     def runs_bf16x3(self, B, H, W):

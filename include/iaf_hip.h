@@ -290,6 +290,8 @@ int iaf_stack_set_tuning(iaf_stack_t* s, int layer, int nt, int pxt, int wco, in
 int iaf_stack_set_precision(iaf_stack_t* s, int precision);
 /* *errors = the range word of an IAF_PRECISION_F16X2 stack (0: none; bit 0: an activation, bit 1: a weight); synchronises the device */
 int iaf_stack_range_errors(const iaf_stack_t* s, unsigned* errors);
+/* 1 if the one-launch step of the stack at this size would run a two-plane fp16 kernel now, else 0 */
+int iaf_stack_step_is_f16(const iaf_stack_t* s, int B, int H, int W);
 int iaf_stack_get_precision(const iaf_stack_t* s, int layer, int B, int H, int W);
 /* launch shape of the bf16x3 kernel for GEMM layer `layer`: co tiles per wave, pixel tiles per wave, waves along
  * pixels, K-slice waves, co groups sharing one staged activation tile (nt = 0 restores the automatic choice) */
