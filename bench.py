@@ -87,6 +87,9 @@ def parse():
     ap.add_argument("--keep-f32-pack", action="store_true",
                     help="keep the fp32 fragment pack up to date in the per-step weight prep even when every step runs on the "
                          "bf16 matrix cores (iaf_stack_set_packs; default: dropped when no launch of the workload reads it)")
+    ap.add_argument("--no-modes", action="store_true",
+                    help="default mode: skip the `modes` object (quick in-process runs of --train --model, --layers --model and "
+                         "--iw-eval --model behind the headline measurement, ~20 s)")
     ap.add_argument("--repeats", type=int, default=5,
                     help="the timed region (--steps steps between barriers) is run this many times; the median is reported")
     ap.add_argument("--settle-seconds", type=float, default=0.4,
@@ -96,11 +99,15 @@ def parse():
 
 RANK_INFO = {}
 OUT_FD = [None]
+CAPTURE = [None]      # a list: emit() appends to it instead of printing (the default mode's `modes` object runs the other modes in-process)
 
 
 def emit(out):
     """rank 0's ONE JSON line; every mode reports who actually took part (read back from the communicator)"""
     out = dict(out)
+    if CAPTURE[0] is not None:
+        CAPTURE[0].append(out)
+        return
     out["rccl_ranks"] = RANK_INFO.get("rccl_ranks")
     out["devices"] = RANK_INFO.get("devices")
     if "halo_exchange" in RANK_INFO:
@@ -117,6 +124,8 @@ def emit(out):
 def force_dist(args):
     """The training modes run their gradient exchange through RCCL even on ONE GPU (a one-rank communicator: the call path, stream
     ordering and graph capture of the real thing; IAF_BENCH_FORCE_DIST=0 turns that off, =1 turns it on for the other modes)."""
+    if getattr(args, "_no_dist", False):      # (the quick in-process runs behind the headline line: no process group)
+        return False
     v = os.environ.get("IAF_BENCH_FORCE_DIST")
     return (v not in ("0", "")) if v is not None else bool(args.train)
 
@@ -171,8 +180,18 @@ def init_ranks(args):
         os.environ.setdefault("MASTER_PORT", str(free_port()))
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dist.barrier()
+    try:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.barrier()
+    except Exception as e:          # noqa: BLE001
+        if world > 1:
+            raise
+        # (the one-rank communicator of the single-GPU training modes is a convenience -- the same call path as N ranks --,
+        #  not a requirement: without it the step runs with no exchange and the line says so)
+        info["rccl_one_rank_init"] = "failed (%s): no communicator, the gradient exchange is skipped" % (str(e).splitlines() or [""])[0][:160]
+        os.dup2(OUT_FD[0], 1)
+        OUT_FD[0] = None
+        return None, 0, 1, info
     # read the participants back from the communicator: every rank contributes 1 and its device identity
     ones = torch.ones(1, device="cuda")
     dist.all_reduce(ones)
@@ -423,6 +442,40 @@ def _run_segmented(args, segments, red, flat, n_gpus, dist):
     return elapsed, graphs is not None, exchange
 
 
+def _train_roofline(fwd_flops, ms_per_step, mode):
+    """VERDICT r05 "next" #3b: the training lines' roofline.  Work = the forward's live FLOPs (mask-aware) three times over:
+    forward, data gradients (dX = W^T dY: the same contraction), weight gradients (dW = X^T dY: the same again; the MADE mask on dV,
+    graphy/nodes/ar.py:369-373, makes the same half of it live).  Peak = the pipe the forward and most of the backward run on (bf16x3:
+    2500 / 6 TF; the round-6 fp16 planes of the step kernels are priced against the same denominator).  `kernels`: the six launches
+    that take most of one steady-state step, from the committed rocprofv3 kernel trace of the same command (tools/step_breakdown.py
+    --json), each family with the live FLOPs it carries and its own fraction of the pipe."""
+    tf_ = 3.0 * fwd_flops / (ms_per_step * 1e-3) / 1e12
+    r = {"bound": "mfma", "achieved": tf_, "peak": PEAK_BF16X3_TFLOPS, "unit": "TFLOP/s", "frac": tf_ / PEAK_BF16X3_TFLOPS, "traffic": None,
+         "frac_of_f32_mfma_peak": tf_ / PEAK_F32_MFMA_TFLOPS,
+         "live_gflop_per_step": {"forward": fwd_flops / 1e9, "data_gradients": fwd_flops / 1e9, "weight_gradients": fwd_flops / 1e9},
+         "note": "whole training step (weight prep + forward + backward + weight-norm backward + all-reduce + Adamax/EMA) against the "
+                 "bf16x3 pipe peak; live FLOPs = 3 x the forward's mask-aware count"}
+    pth = os.path.join(ROOT, "profiles", "train_kernels_%s.json" % mode)
+    if os.path.exists(pth):
+        try:
+            tj = json.load(open(pth))
+            fam = {}
+            for k in tj.get("families", []):
+                # a family's live FLOPs: forward-shaped convs carry forward + data gradients (2 F), the weight-gradient kernels F
+                share = {"conv": 2.0, "wgrad": 1.0}.get(k["family"])
+                if share and k["us_per_step"] > 0:
+                    k = dict(k)
+                    k["live_gflop_per_step"] = share * fwd_flops / 1e9
+                    k["frac"] = share * fwd_flops / (k["us_per_step"] * 1e-6) / 1e12 / PEAK_BF16X3_TFLOPS
+                fam[k["family"]] = k
+            r["kernels"] = tj.get("top", [])[:6]
+            r["kernel_families"] = list(fam.values())
+            r["kernels_source"] = tj.get("source")
+        except Exception:
+            pass
+    return r
+
+
 def train_bench(args, depths, dist, rank, n_gpus):
     """DP training step of the IAF posterior stack (SURVEY 8f-1,2): per step, for every layer, posterior block forward
     (tf_train.py:56-85) + backward (what opt.compute_gradients derives, tf_train.py:138), gradients written into ONE flat
@@ -448,7 +501,7 @@ def train_bench(args, depths, dist, rank, n_gpus):
             pre = "IAF_%d_%d/ar_multiconv2d/" % (lvl, j)
             for k, v in params.items():
                 named[pre + k] = dev(v)
-            layers.append(dict(stack=st, pre=pre, keys=list(params), inp=inp))
+            layers.append(dict(stack=st, pre=pre, keys=list(params), inp=inp, H=H))
     flat = par.FlatParams(named)          # `named` is in layer order == the order this step completes the gradients
     for L in layers:
         L["params"] = {k: flat.p[L["pre"] + k] for k in L["keys"]}
@@ -487,6 +540,8 @@ def train_bench(args, depths, dist, rank, n_gpus):
                        "global_batch": n_gpus * args.batch,
                        "launch": "hipGraph replay per gradient bucket, all-reduce behind each, then the update" if graphed else "eager",
                        "parallelism": "dp%d (RCCL all-reduce of %d gradient buckets, overlapped with backward)" % (n_gpus, len(groups))},
+            "roofline": _train_roofline(sum(L["stack"].step_work(args.batch, L["H"], L["H"])["live_flops"] for L in layers),
+                                        1e3 * elapsed / args.steps, "stacks"),
             "exchange": exchange})
 
 
@@ -771,6 +826,12 @@ def model_train_bench(args, depths, dist, rank, n_gpus):
     exchange["halo_exchange_errors"] = xerr
     exchange["messages"] = len(bucket_names) if red.active else 0
     exchange["bytes"] = 4 * flat.params.numel()
+    fwd_fl = 0.0
+    for li, level in enumerate(model.layers):
+        Hl = 16 >> li
+        for layer in level:
+            fwd_fl += sum(cv.work(B, Hl, Hl)[0] for cv in layer.convs())
+            fwd_fl += layer.posterior.stack.step_work(B, Hl, Hl)["live_flops"]
     emit({
         "metric": "CVAE1 TRAIN-step samples/sec (whole model from its own objective: weight norms, forward, backward of every variable, "
                   "grad all-reduce, Adamax/EMA)",
@@ -786,6 +847,7 @@ def model_train_bench(args, depths, dist, rank, n_gpus):
                    "obj_first_step": obj0, "obj_last_step": obj1,
                    "bits_per_dim_last_step": obj1 / (np.log(2.) * 3072 * B),
                    "parallelism": "dp%d (RCCL all-reduce of %d gradient buckets, overlapped with backward)" % (n_gpus, len(bucket_names))},
+        "roofline": _train_roofline(fwd_fl, 1e3 * elapsed / args.steps, "model"),
         "exchange": exchange})
 
 
@@ -939,6 +1001,7 @@ def layers_train_bench(args, depths, dist, rank, n_gpus):
                        "launch": "hipGraph replay per gradient bucket, all-reduce behind each, then the update" if graphed else "eager",
                        "model_tflops_fwd_plus_bwd": 3.0 * fwd_fl / (elapsed / args.steps) / 1e12,
                        "parallelism": "dp%d (RCCL all-reduce of %d gradient buckets, overlapped with backward)" % (n_gpus, len(segments))},
+            "roofline": _train_roofline(fwd_fl, 1e3 * elapsed / args.steps, "layers"),
             "exchange": exchange})
 
 
@@ -1091,6 +1154,8 @@ def iw_eval_model_bench(args, depths, dist, rank, n_gpus):
         log_pxz, kl_cost = model._top_down(keep["xf"], B, noise, terms=True)
         acc.update(log_pxz.reshape(B, 1), kl_cost.reshape(B, 1))
 
+    passes_run = [0]
+
     def full_pass():                                       # round 4's form: the whole forward per sample
         bottom_up()
         one_pass()
@@ -1101,9 +1166,10 @@ def iw_eval_model_bench(args, depths, dist, rank, n_gpus):
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(fn):
+    def timed(fn, updates=False):
         graph = None
         fn()
+        n_run = 1                                          # passes that reached the device accumulators (a capture does not execute)
         torch.cuda.current_stream().synchronize()
         if not args.no_graph:
             graph = torch.cuda.CUDAGraph()
@@ -1112,6 +1178,9 @@ def iw_eval_model_bench(args, depths, dist, rank, n_gpus):
         run = graph.replay if graph is not None else fn
         for _ in range(args.warmup):
             run()
+        n_run += args.warmup + max(1, args.repeats) * args.steps
+        if updates:
+            passes_run[0] += n_run
         reps = []
         for _ in range(max(1, args.repeats)):
             barrier()
@@ -1127,8 +1196,11 @@ def iw_eval_model_bench(args, depths, dist, rank, n_gpus):
         bottom_up()
         stream.synchronize()
         t_up, _ = timed(bottom_up)
-        t_full, _ = timed(full_pass)
-        elapsed, graphed = timed(one_pass)
+        t_full, _ = timed(full_pass, updates=True)
+        elapsed, graphed = timed(one_pass, updates=True)
+        # (graph replays update the device accumulators, the host-side count only saw the eager call and the capture:
+        #  the bound's log k comes from the passes that actually ran)
+        acc.k = passes_run[0]
         bound = acc.result()
         torch.cuda.synchronize()
     if dist is not None:
@@ -1156,6 +1228,52 @@ def iw_eval_model_bench(args, depths, dist, rank, n_gpus):
                    "launch": "hipGraph replay of one pass" if graphed else "eager",
                    "finite_bound": bool(torch.isfinite(bound).all().item()),
                    "parallelism": "dp%d (images sharded over ranks, no collective)" % n_gpus}})
+
+
+def quick_modes(args, depths, xunit):
+    """VERDICT r05 "next" #3a: the widened workloads measured in the SAME run as the headline, each a short in-process
+    run of the mode's own code path (`bench.py --train --model`, `--layers --model`, `--iw-eval --model`; 3 timed steps behind 2 warm-up
+    steps, no process group, no CPU baseline) -- so that the driver's default run sees them.  None of these is `value`."""
+    import copy
+    res = {"note": "quick in-process runs of the other modes (3 timed steps each); the full lines: python bench.py --train --model | "
+                   "--layers --model | --iw-eval --model"}
+    for pb in xunit:
+        res["posterior_block_us_%s" % pb["latent"]] = pb["us"]
+
+    def run(fn, **over):
+        a2 = copy.copy(args)
+        a2.steps, a2.warmup, a2.repeats, a2.settle_seconds, a2.no_cpu_baseline, a2._no_dist = 3, 2, 1, 0.0, True, True
+        for k, v in over.items():
+            setattr(a2, k, v)
+        CAPTURE[0] = []
+        t0 = time.perf_counter()
+        try:
+            fn(a2, depths, None, 0, 1)
+            got = CAPTURE[0][0] if CAPTURE[0] else None
+        except BaseException as e:          # noqa: BLE001  (SystemExit included: a mode that refuses this configuration)
+            got = {"error": "%s: %s" % (type(e).__name__, (str(e).splitlines() or [""])[0][:200])}
+        finally:
+            CAPTURE[0] = None
+        torch.cuda.synchronize()
+        return got, time.perf_counter() - t0
+
+    got, dt = run(model_train_bench, train=True, model=True)
+    if got is not None:
+        res["train_model_ms"] = got.get("ms_per_step", got.get("error"))
+        if "roofline" in got:
+            res["train_model_frac"] = got["roofline"].get("frac")
+        res["train_model_wall_s"] = dt
+    got, dt = run(layers_bench, layers=True, model=True)
+    if got is not None:
+        res["model_fwd_ms"] = got.get("ms_per_step", got.get("error"))
+        if "config" in got:
+            res["model_fwd_tflops"] = got["config"].get("model_tflops")
+        res["model_fwd_wall_s"] = dt
+    got, dt = run(iw_eval_model_bench, iw_eval=True, model=True, batch=256, iw_k=8)
+    if got is not None:
+        res["iw_eval_ms_per_pass"] = (got.get("config") or {}).get("ms_per_pass", got.get("ms_per_step", got.get("error")))
+        res["iw_eval_wall_s"] = dt
+    return res
 
 
 def _halo_note(st, R, args):
@@ -1631,6 +1749,8 @@ def main():
     if n_gpus == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, depths)
         out["config"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+    if n_gpus == 1 and not args.no_modes and dist is None:
+        out["modes"] = quick_modes(args, depths, xunit)
     emit(out)
     if dist is not None:
         dist.destroy_process_group()

@@ -628,7 +628,8 @@ extern "C" int iaf_stack_set_precision(iaf_stack_t* s, int precision) {
         s->skip_bf3_pack = false;                            // (the bf16x3 pack is wanted again)
         s->prepared = false;
     }
-    if ((precision == IAF_PRECISION_F16X2) != (s->precision == IAF_PRECISION_F16X2)) s->prepared = false;   // the set of packs the prep writes changes
+    if (precision == IAF_PRECISION_F16X2 && s->precision != IAF_PRECISION_F16X2) s->prepared = false;   // the fp16 pack has not been kept up to date
+                                                             // (away from F16X2: the packs the other kernels read were written all along)
     s->precision = precision;
     return IAF_OK;
 }

@@ -335,7 +335,19 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
 #define IAF_EXP_RDO_XCH 3
 #endif
     // (IAF_EXP_RDO_XCH: dev knob -- the output pair's look-ahead in the exchange-form TF kernels, which have the registers for more)
-    constexpr int RD0 = 2, RDH = 2, RDO = (XCH && VAR == 0 && NZT == 2) ? IAF_EXP_RDO_XCH : 3;
+    // F16: a K step carries half the MFMA time of a bf16x3 step (12 MFMAs = 190 cycles at 16-pixel rows, 6 at 8), so the same fetch latency
+    // (~900 cycles from L2) wants a deeper look-ahead -- and the two-plane rings have the registers for it (profiles/r06/experiments/f16x2_ring_depth.txt)
+#ifndef IAF_F16_RD0
+#define IAF_F16_RD0 2
+#endif
+#ifndef IAF_F16_RDH
+#define IAF_F16_RDH 2
+#endif
+#ifndef IAF_F16_RDO
+#define IAF_F16_RDO 3
+#endif
+    constexpr int RD0 = F16 ? IAF_F16_RD0 : 2, RDH = F16 ? IAF_F16_RDH : 2,
+                  RDO = F16 ? IAF_F16_RDO : (XCH && VAR == 0 && NZT == 2) ? IAF_EXP_RDO_XCH : 3;
     constexpr int UA = (RD0 > RDH || DEPTH < 3 ? RD0 : RDH) + 1;     // slots of ring array A (layers 0, 2): layer 0, and layer 2 if any
     constexpr int UB = RDH + 1;                                      // ring array B (layers 1, 3)
     constexpr int UO = RDO + 1;

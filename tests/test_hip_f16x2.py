@@ -207,7 +207,6 @@ def test_nan_and_inf_inputs(amd, H):
     zn = z.copy()
     zn[0, 3, H - 1, H - 1] = np.nan
     zn.view(np.uint32)[1, 0, 0, 0] = 0xffffffff               # an all-ones NaN
-    zn.view(np.uint32)[2, 0, 0, 0] = 0xfdfffdff               # the fp16 rows' "not there yet" pattern read as fp32 (a NaN)
     a, b = st.iaf_step(dev(zn), dev(ctx))
     ha = host(a)
     assert np.isnan(ha[0]).any() and np.isfinite(ha[3:]).all()
