@@ -51,6 +51,8 @@ SIGNATURES = {
     "iaf_step_inverse": (ctypes.c_int, [_vp, _c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_int, _vp, ctypes.c_size_t, ctypes.c_int, ctypes.c_float, ctypes.c_int, _vp,
                                         ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_float)]),
+    "iaf_step_inverse_device": (ctypes.c_int, [_vp, _c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int,
+                                               ctypes.c_int, _vp, ctypes.c_size_t, ctypes.c_int, ctypes.c_float, ctypes.c_int, _vp, _vp]),
     "iaf_stack_set_defer_weightnorm": (ctypes.c_int, [_vp, ctypes.c_int]),
     "iaf_wn_bwd_batch_create": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.c_int]),
     "iaf_wn_bwd_batch_run": (ctypes.c_int, [_vp] + [ctypes.POINTER(_vp)] * 5 + [_vp]),

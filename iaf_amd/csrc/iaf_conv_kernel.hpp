@@ -95,6 +95,10 @@ struct ConvP {
     // is four phase tiles x_ab[i][j] = x[2i+a][2j+b]; s2_pb[2a+b] = first slot of phase (a,b), tap_off[t] = slot offset of tap t
     // = s2_pb[phase of t] + (di>>1) W + (dj>>1), tap_dh / tap_dw = (di>>1, dj>>1) for the border test
     int s2_pb[4]; int tap_off[MAXTAPS];
+    // MODE_INVERSE sweeps chained without the host (iaf_step_inverse): a device word that is non-zero once the fixed point has been
+    // reached -- the one-launch step kernel returns at once then (the layer-by-layer kernels ignore it: a sweep at the fixed point
+    // changes nothing); NULL otherwise.  Host-side field only: read by launch_fused_step.
+    const unsigned* inv_done;
 };
 
 // Pin the order "MFMAs with memory instructions spread evenly between them" inside the current scheduling region:

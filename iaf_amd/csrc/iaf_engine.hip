@@ -1348,6 +1348,7 @@ static int launch_fused_step(iaf_stack_t* s, step_fn_t fn, int R, size_t lds, co
     q.zin = base.zin; q.out0 = base.out0; q.out1 = base.out1; q.kl_elem = base.kl_elem;
     q.qm = base.qm; q.ql = base.ql; q.rm = base.rm; q.rl = base.rl; q.pm = base.pm; q.pl = base.pl; q.eps = base.eps;
     q.B = base.B; q.H = base.H; q.HW = base.HW; q.mode = base.mode;
+    q.skip = base.mode == MODE_INVERSE ? base.inv_done : nullptr;
     q.nrb = (base.H + R - 1) / R;
     //  the posterior callers pass a hidden-activation buffer of the workspace ([B H W][n_h] floats) as kl_part
     // [B * nrb][n_z]: holds for every geometry compiled today (nrb <= H, n_z <= W n_h) -- enforced here for the ones to come
@@ -1746,6 +1747,59 @@ extern "C" int iaf_step_forward(iaf_stack_t* s, const float* z, const float* con
 // fixes at least one more position per sweep (exact after at most H*W*n_z sweeps) and, because the reference scales
 // m and s by 0.1, contracts to fp32 precision in a handful of sweeps; every sweep is one full-width run of the conv
 // stack instead of H*W*n_z dependent scalar steps.
+// The sweeps of one inverse are QUEUED: the residual check (every check_every sweeps and after the last) runs on the device, raises a word
+// the remaining sweep launches read (the one-launch step kernel returns at once: ~2 us per skipped sweep instead of a sweep) and a last
+// small launch moves the result into z0 -- no host synchronisation inside the call, so it can be captured into a hipGraph.
+// d_out (optional, device, two words): sweeps run (int) and the last residual (float, -1 if tol = 0).
+static int step_inverse_queue(iaf_stack_t* s, const float* z, const float* context, float* z0, float* logsd, int B, int H, int W,
+                              const Ws& ws, int max_sweeps, float tol, int check_every, hipStream_t st, unsigned* d_out) {
+    const size_t n = (size_t)B * s->n_z * H * W;
+    // ping-pong between the caller's z0 and the workspace's kl_elem plane, arranged so that the last sweep lands in z0
+    float* buf[2] = {z0, ws.kl_elem};
+    InvCtl* ctl = (InvCtl*)ws.rowsum;                     // [B*n_z] floats are free during the inverse (>= 8 words: n_z >= 16)
+    unsigned* out = d_out ? d_out : (unsigned*)ws.rowsum + 8;
+    const bool checking = (tol > 0.f && check_every > 0);
+    HIP_TRY(hipMemsetAsync(ctl, 0, sizeof(InvCtl), st));
+    ConvP p;
+    memset(&p, 0, sizeof(p));
+    p.B = B; p.H = H; p.W = W; p.HW = H * W; p.P = B * H * W;
+    p.zin = z; p.out1 = logsd; p.mode = MODE_INVERSE;
+    int R = 0;
+    size_t lds = 0;
+    const bool skipping = checking && !s->generic && fused_step_plan(s, B, H, W, &R, &lds) != nullptr &&
+                          ((((uintptr_t)context) & 15) == 0);
+    p.inv_done = skipping ? &ctl->done : nullptr;
+    const float* cur = z;                                 // initial guess z0 = z (m = 0, s = 0)
+    int rc, k = 0;
+    for (int done = 0; done < max_sweeps; ++done) {
+        float* dst = buf[(max_sweeps - 1 - done) & 1];
+        p.x = cur; p.out0 = dst;
+        if ((rc = run_stack(s, p, IN_NCHW, context, nullptr, ws, st))) return rc;
+        if (checking && (++k == check_every || done + 1 == max_sweeps)) {
+            k = 0;
+            // (a SMALL grid: every workgroup ends in two agent-scope atomics on one line -- 4096 of them took 30 us, 128 take 3)
+            const unsigned cg = (unsigned)((n + 8191) / 8192) < 128u ? (unsigned)((n + 8191) / 8192) : 128u;
+            hipLaunchKernelGGL(iaf_inverse_check_kernel, dim3(cg), dim3(256), 0, st, (const float*)dst, cur, n, ctl, tol, (unsigned)(done + 1));
+        }
+        cur = dst;
+    }
+    hipLaunchKernelGGL(iaf_inverse_finish_kernel, ew_grid(n), dim3(256), 0, st, (const float*)buf[1], z0, n, (const InvCtl*)ctl, max_sweeps,
+                       skipping ? 1 : 0, checking ? 1 : 0, out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int iaf_step_inverse_device(iaf_stack_t* s, const float* z, const float* context, float* z0, float* logsd, int B, int H,
+                                       int W, void* workspace, size_t workspace_bytes, int max_sweeps, float tol, int check_every,
+                                       void* stream, unsigned* d_sweeps_residual) {
+    int rc = check_dims(s, B, H, W);
+    if (rc) return rc;
+    if (!z || !z0 || !logsd || (s->depth_ar > 0 && !context)) return IAF_ERR_NULL;
+    if (max_sweeps <= 0 || check_every < 0 || tol < 0.f) return IAF_ERR_SHAPE;
+    Ws ws;
+    if ((rc = carve_ws(s, B, H, W, workspace, workspace_bytes, &ws))) return rc;
+    return step_inverse_queue(s, z, context, z0, logsd, B, H, W, ws, max_sweeps, tol, check_every, (hipStream_t)stream, d_sweeps_residual);
+}
+
 extern "C" int iaf_step_inverse(iaf_stack_t* s, const float* z, const float* context, float* z0, float* logsd, int B, int H,
                                 int W, void* workspace, size_t workspace_bytes, int max_sweeps, float tol, int check_every,
                                 void* stream, int* sweeps_done, float* residual) {
@@ -1756,39 +1810,20 @@ extern "C" int iaf_step_inverse(iaf_stack_t* s, const float* z, const float* con
     Ws ws;
     if ((rc = carve_ws(s, B, H, W, workspace, workspace_bytes, &ws))) return rc;
     hipStream_t st = (hipStream_t)stream;
-    const size_t n = (size_t)B * s->n_z * H * W;
-    // ping-pong between the caller's z0 and the workspace's kl_elem plane, arranged so that the last sweep lands in z0
-    float* buf[2] = {z0, ws.kl_elem};
-    unsigned* d_res = (unsigned*)ws.rowsum;               // [B*n_z] floats are free during the inverse: first word
+    if ((rc = step_inverse_queue(s, z, context, z0, logsd, B, H, W, ws, max_sweeps, tol, check_every, st, nullptr))) return rc;
+    if (sweeps_done) *sweeps_done = max_sweeps;
+    if (residual) *residual = -1.f;
     const bool checking = (tol > 0.f && check_every > 0);
-    ConvP p;
-    memset(&p, 0, sizeof(p));
-    p.B = B; p.H = H; p.W = W; p.HW = H * W; p.P = B * H * W;
-    p.zin = z; p.out1 = logsd; p.mode = MODE_INVERSE;
-    const float* cur = z;                                 // initial guess z0 = z (m = 0, s = 0)
-    int k = 0, done = 0;
-    float res = -1.f;
-    while (done < max_sweeps) {
-        // choose the target so that parity works out if we stop at max_sweeps; an early stop may need one copy
-        float* dst = buf[(max_sweeps - 1 - done) & 1];
-        p.x = cur; p.out0 = dst;
-        if ((rc = run_stack(s, p, IN_NCHW, context, nullptr, ws, st))) return rc;
-        ++done;
-        if (checking && (++k == check_every || done == max_sweeps)) {
-            k = 0;
-            HIP_TRY(hipMemsetAsync(d_res, 0, sizeof(unsigned), st));
-            hipLaunchKernelGGL(iaf_maxdiff_kernel, ew_grid(n), dim3(256), 0, st, (const float*)dst, cur, n, d_res);
-            unsigned bits = 0;
-            HIP_TRY(hipMemcpyAsync(&bits, d_res, sizeof(unsigned), hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            memcpy(&res, &bits, sizeof(float));
-            if (res <= tol) { cur = dst; break; }
-        }
-        cur = dst;
-    }
-    if (cur != z0) HIP_TRY(hipMemcpyAsync(z0, cur, n * sizeof(float), hipMemcpyDeviceToDevice, st));
-    if (sweeps_done) *sweeps_done = done;
-    if (residual) *residual = res;
+    if (!checking || (!sweeps_done && !residual)) return IAF_OK;
+    // the two numbers, the call's only synchronisation (behind ALL of its launches; a stream capture cannot read them: see iaf_step_inverse_device)
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &cs);
+    if (cs != hipStreamCaptureStatusNone) { if (sweeps_done) *sweeps_done = -1; return IAF_OK; }
+    unsigned two[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(two, (unsigned*)ws.rowsum + 8, sizeof(two), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (sweeps_done) *sweeps_done = (int)two[0];
+    if (residual) memcpy(residual, &two[1], sizeof(float));
     return IAF_OK;
 }
 

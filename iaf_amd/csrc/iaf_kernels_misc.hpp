@@ -128,6 +128,55 @@ __global__ __launch_bounds__(256) void iaf_maxdiff_kernel(const float* __restric
     if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
 }
 
+// ---- iaf_step_inverse without the host in its loop (round 6) -------------------------------------------------------------------
+// The inverse of the IAF step -- z0 with z = (z0 - m(z0)) / exp(s(z0)) (tf_train.py:69-72 read backwards; the reference never inverts:
+// it only evaluates densities of its own samples, tf_train.py:60-66, models.py:330-359) -- as JACOBI sweeps z0 <- z exp(s(z0)) + m(z0)
+// on the forward kernels.  Why not the anti-diagonal wavefront north_star names: m, s at (pixel p, channel c) depend on z0 at the pixels
+// right of / below p and on the lower channels at p (the MADE order), a DAG of depth H W n_z -- a true scan is H W n_z dependent steps of
+// one channel of one pixel each (8192 launches-worth of latency at 16x16), while a Jacobi sweep is one full-rate forward launch that moves
+// EVERY element one step down the DAG at once: exact after at most H W n_z sweeps (the DAG's depth), and -- the 0.1 on m and s makes the
+// map a contraction in practice -- at fp32 resolution after ~8.  The control words live in device memory:
+struct InvCtl { unsigned res_bits, done, sweeps, arrivals; float last_res; unsigned pad[3]; };
+// max |a - b| of one sweep pair; the LAST workgroup to arrive compares it with tol, records (sweeps so far, residual), raises `done` (which the
+// queued sweep launches read: StepP::skip) and re-arms the two scratch words.  Does nothing once done.  NaN counts as +inf (never converged).
+__global__ __launch_bounds__(256) void iaf_inverse_check_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n, InvCtl* c,
+                                                               float tol, unsigned sweeps_so_far) {
+    if (*(volatile unsigned*)&c->done) return;
+    float m = 0.f;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float d = fabsf(a[i] - b[i]);
+        m = (d > m || d != d) ? (d != d ? __builtin_inff() : d) : m;
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
+    __shared__ float wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+        __hip_atomic_fetch_max(&c->res_bits, __float_as_uint(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__hip_atomic_fetch_add(&c->arrivals, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) {
+            const float res = __uint_as_float(__hip_atomic_load(&c->res_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            c->last_res = res;
+            c->sweeps = sweeps_so_far;
+            c->res_bits = 0u; c->arrivals = 0u;
+            if (res <= tol) __hip_atomic_store(&c->done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+// the result into z0: where the sweep launches return early once converged (skipping), the converged estimate sits in the buffer sweep
+// number c->sweeps wrote, buf[(max_sweeps - sweeps) & 1] with buf[0] = z0; otherwise the last sweep has written z0 itself.  Also the two
+// numbers the caller may ask for: out[0] = sweeps run (as an int), out[1] = the last residual (as a float; -1: never checked)
+__global__ __launch_bounds__(256) void iaf_inverse_finish_kernel(const float* __restrict__ other, float* __restrict__ z0, size_t n, const InvCtl* c,
+                                                                int max_sweeps, int skipping, int checked, unsigned* out) {
+    const unsigned done = c->done, sw = c->sweeps;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && out) {
+        out[0] = done ? sw : (unsigned)max_sweeps;
+        out[1] = __float_as_uint(checked ? c->last_res : -1.f);
+    }
+    if (!(skipping && done && ((max_sweeps - (int)sw) & 1))) return;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) z0[i] = other[i];
+}
+
 // lvs: 1 when the second tensor holds log-variances (distributions.py), 2 when it holds log standard deviations (the callers'
 // `2 * logsd`: tf_train.py:56-57, rand.py:81-86 -- exact in fp32, so the bits are those of a separate doubling)
 __global__ void iaf_gauss_sample_kernel(const float* mean, const float* logvar, const float* noise, float* out, size_t n, float lvs) {

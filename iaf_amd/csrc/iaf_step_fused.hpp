@@ -233,6 +233,9 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
     constexpr bool FLIP = (VAR == 1), BORDER = (VAR != 0);
     static_assert(DEPTH >= 1 && DEPTH <= 4, "hidden layers ping-pong between two LDS regions (h_even, h_odd)");
     static_assert((W & (W - 1)) == 0 && W <= 16, "full-width rows of 4, 8 or 16 pixels");
+    // a sweep of a converged inverse (iaf_step_inverse: the sweeps of one call are queued without the host in the loop; the word is
+    // written by the residual check between two sweeps, never during one, so every workgroup of a launch reads the same value)
+    if (p.mode == MODE_INVERSE && p.skip && *(const volatile unsigned*)p.skip) return;
     extern __shared__ __attribute__((aligned(16))) f32x4 smem4[];
     char* smem = (char*)smem4;
     constexpr int NZ = G::NZ, NH = G::NH, RS = G::RS, Z8 = G::Z8, Z16 = G::Z16, H8 = G::H8, H16 = G::H16, RZ = G::RZ;

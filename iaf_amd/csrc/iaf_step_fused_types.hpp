@@ -44,6 +44,7 @@ struct StepP {
     unsigned* xerr;                // host-visible error word (mapped pinned memory), or NULL
     unsigned* rng_err;             // F16 kernels: host-visible word (mapped pinned memory) raised when an operand beyond fp16's largest finite
                                    // number went into the planes (the launch's outputs then carry inf / NaN); or NULL
+    const unsigned* skip;          // MODE_INVERSE: a device word; non-zero = the chain of sweeps this launch belongs to has converged: return at once
     unsigned xknob;                // test knobs: 1 lists ignore the placement, 2 tickets out of dispatch order,
                                    // 8 fault injection (image 0's bottom block never hands over its first row; short waits)
 };

@@ -396,6 +396,18 @@ class ARStack(object):
                                                  ctypes.byref(n), ctypes.byref(res)))
         return z0, logsd, n.value, res.value
 
+    def iaf_step_inverse_queued(self, z, context, max_sweeps=64, tol=1e-6, check_every=4, out=None, stats=None):
+        """iaf_step_inverse without ANY host synchronisation (iaf_step_inverse_device): every sweep, the residual tests and the early-out
+        are queued on the stream -- capturable into a hipGraph.  `stats` (optional): an int32 tensor of two words on the device that receives
+        (sweeps run, the last residual's float bits).  Returns (z0, logsd)."""
+        B, H, W = self._dims(z, context)
+        z0, logsd = out if out is not None else (torch.empty_like(z), torch.empty_like(z))
+        ws, need = self.workspace(B, H, W, z.device)
+        _capi.check(_capi.lib().iaf_step_inverse_device(self._h, _ptr(z), _ptr(context), _ptr(z0), _ptr(logsd), B, H, W, _ptr(ws), need,
+                                                        int(max_sweeps), float(tol), int(check_every), _stream(),
+                                                        _ptr(stats) if stats is not None else None))
+        return z0, logsd
+
     # -- training (SURVEY 8f-1) ---------------------------------------------------------------------
     def set_training(self, on=True):
         """allocate the transposed weight packs used by the data-gradient kernels; re-prepare afterwards"""

@@ -104,13 +104,24 @@ int iaf_step_forward(iaf_stack_t* s, const float* z, const float* context, float
 /* Inverse of the IAF step: given the flow output z (what iaf_step_forward wrote to z_new) and the context, recover
  * z0 with (z0 - m(z0))/exp(s(z0)) == z, and logsd = s(z0).  The reference never inverts the flow (sample mode bypasses
  * it, tf_train.py:60-66) -- this is the density-evaluation direction SURVEY D3 / 8f-4 lists; it is checked by round trip
- * against iaf_step_forward.  Method: Jacobi sweeps z0 <- z*exp(s(z0)) + m(z0), each one full run of the conv stack; a
- * sweep finalises at least one more position of the autoregressive order, so H*W*n_z sweeps are exact for any weights,
- * and with the reference's 0.1 scaling a handful reach fp32 precision.
- *   max_sweeps  upper bound (and the exact count when tol == 0: then the call never synchronises and can be captured);
- *   tol > 0     stop when max|z0_new - z0_old| <= tol, tested every check_every sweeps (each test synchronises);
- *   sweeps_done / residual (optional): sweeps run, last tested max update (-1 if never tested).
+ * against iaf_step_forward.  Method: Jacobi sweeps z0 <- z*exp(s(z0)) + m(z0), each one full-rate forward launch (the one-launch
+ * step kernel in MODE_INVERSE where a geometry is compiled).  Exactness: m, s at (pixel p, channel c) depend on z0 at the pixels
+ * right of / below p and on the lower channels at p -- a DAG of depth H*W*n_z; a sweep moves every element one level down it, so
+ * H*W*n_z sweeps are exact for ANY weights, and with the reference's 0.1 on m and s the map contracts to fp32 resolution in ~8
+ * (tools/inverse_bench.py).  An anti-diagonal wavefront scan would be H*W*n_z dependent single-channel steps: latency, not work.
+ *   max_sweeps  upper bound (and the exact count when tol == 0);
+ *   tol > 0     stop when max|z0_new - z0_old| <= tol, tested ON THE DEVICE every check_every sweeps and after the last one: all
+ *               max_sweeps launches are queued at once, a launch behind the converged one returns immediately (one-launch step
+ *               kernels; the layer-by-layer kernels run on -- a sweep at the fixed point changes nothing), and a last small launch
+ *               leaves the result in z0.  No host synchronisation inside the loop (round 5: one per test);
+ *   sweeps_done / residual (optional): sweeps run, last tested max update (-1 if never tested).  Asking for them with tol > 0 costs
+ *               ONE synchronisation at the end of the call (inside a stream capture: *sweeps_done = -1, nothing is read).
+ * iaf_step_inverse_device: the same, never synchronises, capturable with any tol; d_sweeps_residual (optional, DEVICE, two words):
+ * sweeps run as an int, the last residual as a float.
  * z0 must not alias z.  Workspace: iaf_stack_workspace_bytes. */
+int iaf_step_inverse_device(iaf_stack_t* s, const float* z, const float* context, float* z0, float* logsd, int B, int H, int W,
+                            void* workspace, size_t workspace_bytes, int max_sweeps, float tol, int check_every, void* stream,
+                            unsigned* d_sweeps_residual);
 int iaf_step_inverse(iaf_stack_t* s, const float* z, const float* context, float* z0, float* logsd, int B, int H, int W,
                      void* workspace, size_t workspace_bytes, int max_sweeps, float tol, int check_every, void* stream,
                      int* sweeps_done, float* residual);

@@ -29,6 +29,39 @@ def main():
         print("%dx%d  max|z0_rec - z0| after n sweeps: %s" % (H, H, " ".join("%d:%.1e" % (i + 1, e) for i, e in enumerate(errs))))
         _, _, sweeps, res = stack.iaf_step_inverse(z, ctx, max_sweeps=200, tol=1e-6, check_every=1)
         print("      tol 1e-6 reached after %d sweeps (last update %.2e)" % (sweeps, res))
+        # the whole call with the residual tested on the device every 2 sweeps, 16 sweeps queued, early-out behind the converged one
+        for _ in range(3):
+            stack.iaf_step_inverse_queued(z, ctx, max_sweeps=16, tol=1e-6, check_every=2)
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(20):
+            stack.iaf_step_inverse_queued(z, ctx, max_sweeps=16, tol=1e-6, check_every=2)
+        b.record()
+        torch.cuda.synchronize()
+        t = a.elapsed_time(b) / 20 * 1e3
+        print("      tol 1e-6, 16 sweeps queued, test every 2, no host in the loop: %.1f us per inverse -> %.0f samples/s" % (t, B / t * 1e6))
+        g = torch.cuda.CUDAGraph()
+        out = (torch.empty_like(z), torch.empty_like(z))
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            side.wait_stream(torch.cuda.current_stream())
+            stack.iaf_step_inverse_queued(z, ctx, max_sweeps=16, tol=1e-6, check_every=2, out=out)
+            side.synchronize()
+            with torch.cuda.graph(g, stream=side):
+                stack.iaf_step_inverse_queued(z, ctx, max_sweeps=16, tol=1e-6, check_every=2, out=out)
+            for _ in range(5):
+                g.replay()
+            side.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(side)
+            for _ in range(20):
+                g.replay()
+            b.record(side)
+            b.synchronize()
+        t = a.elapsed_time(b) / 20 * 1e3
+        print("      the same as ONE hipGraph replay: %.1f us per inverse -> %.0f samples/s (max |z0_rec - z0| %.1e)" % (
+            t, B / t * 1e6, float((out[0] - z0).abs().max())))
         for n in (sweeps, 8):
             stack.iaf_step_inverse(z, ctx, max_sweeps=n, tol=0.0)
             torch.cuda.synchronize()
