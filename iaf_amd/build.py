@@ -44,7 +44,7 @@ def _units():
                       ["-DIAF_PPW=%d" % ppw, "-DIAF_PXT=%d" % pxt, "-DIAF_KS=%d" % ks, "-DIAF_WCO=%d" % wco]))
     # accumulators in architectural VGPRs: left to itself the register allocator puts them in AGPRs and rotates them through
     # VGPR copies inside the K loop (48 v_accvgpr moves per 162 MFMAs)
-    for part in (0, 1, 2, 3, 4, 5):
+    for part in (0, 1, 2, 3, 4, 5, 6):
         units.append((os.path.join(CSRC, "iaf_step_fused_inst.hip"), os.path.join(OBJDIR, "iaf_step_fused_%d.o" % part),
                       ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-DIAF_FUSED_PART=%d" % part]))
     return units

@@ -14,7 +14,11 @@ template <int NT>
 static conv_fn_t pick_mode_bf3(int inmode, int epi) {
     if (epi == EPI_HIDDEN) {
         if (inmode == IN_PIXMAJOR) return iaf_conv_bf3_kernel<NT, IAF_PPW, IAF_PXT, IAF_KS, IN_PIXMAJOR, EPI_HIDDEN, IAF_WCO>;
-        if (inmode == IN_FUSED0) return iaf_conv_bf3_kernel<NT, IAF_PPW, IAF_PXT, IAF_KS, IN_FUSED0, EPI_HIDDEN, IAF_WCO>;
+        // (the first layer fused into this one's prologue, iaf_stack_set_fuse_first: not with two co groups per workgroup -- those three
+        //  instantiations spilled 10-68 VGPRs, and the form has lost to separate launches at every size measured on MI355X anyway)
+        if constexpr (IAF_WCO == 1) {
+            if (inmode == IN_FUSED0) return iaf_conv_bf3_kernel<NT, IAF_PPW, IAF_PXT, IAF_KS, IN_FUSED0, EPI_HIDDEN, IAF_WCO>;
+        }
         if (inmode == IN_NCHW) return iaf_conv_bf3_kernel<NT, IAF_PPW, IAF_PXT, IAF_KS, IN_NCHW, EPI_HIDDEN, IAF_WCO>;
         if (inmode == IN_POSTERIOR) return iaf_conv_bf3_kernel<NT, IAF_PPW, IAF_PXT, IAF_KS, IN_POSTERIOR, EPI_HIDDEN, IAF_WCO>;
         return nullptr;
@@ -24,7 +28,9 @@ static conv_fn_t pick_mode_bf3(int inmode, int epi) {
     if (epi == EPI_OUT) {     // the output pair always reads the last hidden layer (depth_ar = 0 stays on the fp32 kernel)
         if constexpr (NT % 2 == 0) {
             if (inmode == IN_PIXMAJOR) return iaf_conv_bf3_kernel<NT, IAF_PPW, IAF_PXT, IAF_KS, IN_PIXMAJOR, EPI_OUT, IAF_WCO>;
-            if (inmode == IN_FUSED0) return iaf_conv_bf3_kernel<NT, IAF_PPW, IAF_PXT, IAF_KS, IN_FUSED0, EPI_OUT, IAF_WCO>;
+            if constexpr (IAF_WCO == 1) {
+                if (inmode == IN_FUSED0) return iaf_conv_bf3_kernel<NT, IAF_PPW, IAF_PXT, IAF_KS, IN_FUSED0, EPI_OUT, IAF_WCO>;
+            }
         }
         return nullptr;
     }

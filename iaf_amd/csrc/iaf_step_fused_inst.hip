@@ -170,11 +170,10 @@ extern "C" step_fn_t iaf_pick_step_fused_d(int nht, int nzt, int depth, int W, i
 }
 #endif
 
-#if !defined(IAF_FUSED_PART) || IAF_FUSED_PART == 5
-// the two-plane fp16 kernels (round 6, "f16x2": three part-products per K step instead of six): the BASELINE run's two geometries, TF
-// statement -- 16-pixel rows in the exchange form (form 1), 8-pixel rows recomputing with helper waves (form 0)
+// the two-plane fp16 kernels (round 6, "f16x2": three part-products per K step instead of six): the BASELINE run's geometries, TF
+// statement -- 16-pixel rows in the exchange form (form 1), 8-pixel rows recomputing with helper waves (form 0) -- and config 3's
 template <int NHT, int NZT, int DEPTH, int W, int R, int XCH>
-static step_fn_t inst_f16(size_t* lds, size_t* xrow) {
+static step_fn_t inst_f16(int var, size_t* lds, size_t* xrow) {
     typedef StepGeom<NHT, NZT, DEPTH, W, R, XCH, 0, 1> G;
     static_assert((G::CSTR & 15) == 4 || (G::CSTR & 15) == 12, "context rows: 4 channel groups x 16 pixels must hit 64 distinct banks");
     // (the staged context may reach past the h_odd region's end here -- two-plane regions are smaller than the fp32 context rows --;
@@ -182,13 +181,40 @@ static step_fn_t inst_f16(size_t* lds, size_t* xrow) {
     static_assert(G::lds_bytes() <= 160 * 1024 && (DEPTH % 2 != 0 || G::xb_bytes() <= (size_t)G::HREG1 * 16), "the two-plane regions");
     *lds = G::lds_bytes();
     if (xrow) *xrow = XCH ? G::xrow_bytes() : 0;
+    switch (var) {
+        case 0: return iaf_step_fused_kernel<NHT, NZT, DEPTH, W, R, 0, XCH, 1, 0, 1>;
+        case 1: return iaf_step_fused_kernel<NHT, NZT, DEPTH, W, R, 1, XCH, 1, 0, 1>;
+        case 2: return iaf_step_fused_kernel<NHT, NZT, DEPTH, W, R, 2, XCH, 1, 0, 1>;
+    }
+    return nullptr;
+}
+// TF statement only
+template <int NHT, int NZT, int DEPTH, int W, int R, int XCH>
+static step_fn_t inst_f16_tf(int var, size_t* lds, size_t* xrow) {
+    typedef StepGeom<NHT, NZT, DEPTH, W, R, XCH, 0, 1> G;
+    static_assert(G::lds_bytes() <= 160 * 1024 && (DEPTH % 2 != 0 || G::xb_bytes() <= (size_t)G::HREG1 * 16), "the two-plane regions");
+    if (var != 0) return nullptr;
+    *lds = G::lds_bytes();
+    if (xrow) *xrow = XCH ? G::xrow_bytes() : 0;
     return iaf_step_fused_kernel<NHT, NZT, DEPTH, W, R, 0, XCH, 1, 0, 1>;
 }
-extern "C" step_fn_t iaf_pick_step_fused_f16(int nht, int nzt, int depth, int W, int R, int var, int form, size_t* lds, size_t* xrow) {
+#if !defined(IAF_FUSED_PART) || IAF_FUSED_PART == 5
+extern "C" step_fn_t iaf_pick_step_fused_f16_a(int nht, int nzt, int depth, int W, int R, int var, int form, size_t* lds, size_t* xrow) {
     *lds = 0; *xrow = 0;
-    if (var != 0 || nht != 10 || nzt != 2 || depth != 2) return nullptr;
-    if (form == 1 && W == 16 && R == 2) return inst_f16<10, 2, 2, 16, 2, 1>(lds, xrow);
-    if (form == 0 && W == 8 && R == 1) return inst_f16<10, 2, 2, 8, 1, 0>(lds, xrow);
+    if (nht != 10 || nzt != 2 || depth != 2) return nullptr;
+    if (form == 1 && W == 16 && R == 2) return inst_f16_tf<10, 2, 2, 16, 2, 1>(var, lds, xrow);
+    if (form == 0 && W == 8 && R == 1) return inst_f16_tf<10, 2, 2, 8, 1, 0>(var, lds, xrow);
+    if (form == 0 && W == 8 && R == 2) return inst_f16_tf<10, 2, 2, 8, 2, 0>(var, lds, xrow);
     return nullptr;
+}
+#endif
+#if !defined(IAF_FUSED_PART) || IAF_FUSED_PART == 6
+// config 3 (n_z = 64, depth_ar = 4; n_h = 64 / 128) in the exchange form on fp16 planes, all three statements
+extern "C" step_fn_t iaf_pick_step_fused_f16_b(int nht, int nzt, int depth, int W, int R, int var, int form, size_t* lds, size_t* xrow) {
+    *lds = 0; *xrow = 0;
+    if (nzt != 4 || depth != 4 || form != 1 || W != 16 || R != 2) return nullptr;
+    if (nht == 4) return inst_f16<4, 4, 4, 16, 2, 1>(var, lds, xrow);
+    if (nht == 8) return inst_f16_tf<8, 4, 4, 16, 2, 1>(var, lds, xrow);      // (its Theano variants spill 28 VGPRs: bf16x3 for those)
+    return nullptr;            // (n_h = 192: the second accumulator set of three tiles per pixel tile does not fit 256 registers -- bf16x3 there)
 }
 #endif

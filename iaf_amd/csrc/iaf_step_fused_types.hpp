@@ -85,7 +85,12 @@ extern "C" step_fn_t iaf_pick_step_fused_pair(int nht, int nzt, int depth, int W
 extern "C" step_fn_t iaf_pick_step_fused_d(int nht, int nzt, int depth, int W, int R, int var, size_t* lds);   // n_z = 32, depth_ar = 2, n_h = 64 / 128
 extern "C" step_fn_t iaf_pick_step_fused_xch_d(int nht, int nzt, int depth, int W, int R, int var, size_t* lds, size_t* xrow);
 // the two-plane fp16 kernels ("f16x2"): form = 0 recomputing with helper waves, 1 halo exchange; *xrow as above (0 for form 0)
-extern "C" step_fn_t iaf_pick_step_fused_f16(int nht, int nzt, int depth, int W, int R, int var, int form, size_t* lds, size_t* xrow);
+extern "C" step_fn_t iaf_pick_step_fused_f16_a(int nht, int nzt, int depth, int W, int R, int var, int form, size_t* lds, size_t* xrow);
+extern "C" step_fn_t iaf_pick_step_fused_f16_b(int nht, int nzt, int depth, int W, int R, int var, int form, size_t* lds, size_t* xrow);
+static inline step_fn_t iaf_pick_step_fused_f16(int nht, int nzt, int depth, int W, int R, int var, int form, size_t* lds, size_t* xrow) {
+    step_fn_t f = iaf_pick_step_fused_f16_a(nht, nzt, depth, W, R, var, form, lds, xrow);
+    return f ? f : iaf_pick_step_fused_f16_b(nht, nzt, depth, W, R, var, form, lds, xrow);
+}
 static inline step_fn_t iaf_pick_step_fused(int nht, int nzt, int depth, int W, int R, int var, size_t* lds) {
     step_fn_t f = iaf_pick_step_fused_a(nht, nzt, depth, W, R, var, lds);
     if (!f) f = iaf_pick_step_fused_b(nht, nzt, depth, W, R, var, lds);

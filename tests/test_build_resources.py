@@ -18,3 +18,20 @@ def test_plain_and_strided_bf16x3_conv_kernels_use_no_scratch():
     assert len(rows) >= 12, "forward, data-gradient and the two strided forms at NT = 2, 4, 5"
     bad = [(r["name"], r.get("scratch"), r.get("vspill")) for r in rows if r.get("scratch", 0) or r.get("vspill", 0)]
     assert not bad, bad
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
+def test_no_one_launch_step_kernel_and_no_bf16x3_conv_kernel_uses_scratch():
+    """all nine depth-4 exchange-form instantiations of the one-launch step ran with 13-27 spilled VGPRs inside their
+    MFMA regions, unseen because this file looked at one translation unit.  Now: EVERY iaf_step_fused_* and iaf_bf3* unit of the build
+    (~140 + ~250 kernels, a few minutes of device-only compiles, eight at a time) -- no scratch, no spilled VGPR."""
+    import kernel_resources as kr
+    rows = kr.all_resources(["iaf_step_fused_", "iaf_bf3"])
+    fused = [r for r in rows if "iaf_step_fused_kernel" in r["name"]]
+    assert len(fused) >= 130 and len(rows) >= 250, (len(fused), len(rows))
+    # (the stride-2 deconv forms, template argument S2 = 2, index a kernel-argument array of tap offsets at run time: the compiler keeps a
+    #  20-byte copy of it in scratch -- no register is spilled)
+    deconv = lambda r: r["name"].endswith("ELi2EEv5ConvP")
+    bad = [(r["unit"], r["name"], r.get("scratch"), r.get("vspill")) for r in rows
+           if r.get("vspill", 0) or (r.get("scratch", 0) > (32 if deconv(r) else 0))]
+    assert not bad, bad
