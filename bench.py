@@ -740,7 +740,7 @@ def layers_bench(args, depths, dist, rank, n_gpus):
                   "IAFLayer forward samples/sec (up + down of every layer: 4 plain weight-normed convs + IAF posterior block)",
         "value": n_gpus * B / (elapsed / args.steps), "unit": "samples/s", "n_gpus": n_gpus, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "f32 (forward convs: operands split into 3 bf16 parts, 6 part-products on the bf16 MFMA, fp32 accumulate: fp32-grade error; backward: exact fp32 MFMA)", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "f32 (forward convs: operands split into 2 fp16 planes, 3 part-products on the fp16 MFMA in two fp32 accumulators: fp32-grade error, operands up to 65504)" if cv.runs_f16x2(B, 16, 16) else "f32 (forward convs: operands split into 3 bf16 parts, 6 part-products on the bf16 MFMA, fp32 accumulate: fp32-grade error; backward: exact fp32 MFMA)", "data": "synthetic",
         "config": {"workload": "cifar10 z_size=%d h_size=%d depths=%s depth_ar=%d bs=%d per GPU, kl_min=0.25: %d IAFLayers "
                                "(tf_train.py:23-95) as one connected model -- up pass 16x16 -> %dx%d through the downsampling "
                                "layer of each coarser level, then the down pass back"
@@ -759,7 +759,8 @@ def layers_bench(args, depths, dist, rank, n_gpus):
                      "frac_of_f32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS,
                      "kernel": "%s<.., EPI_PLAIN, 9 taps> (down_conv1 %d->%d, B=%d 16x16)" % (
                          "iaf_conv_bf3_kernel" if cv.runs_bf16x3(B, 16, 16) else "iaf_conv_kernel", cv.n_in, cv.n_out, B),
-                     "dominant_kernel_family": "bf16x3" if cv.runs_bf16x3(B, 16, 16) else "f32",
+                     "dominant_kernel_family": "f16x2" if cv.runs_f16x2(B, 16, 16) else "bf16x3" if cv.runs_bf16x3(B, 16, 16) else "f32",
+                     "peak_note": "416.7 TF = 2500 / 6 (the bf16x3 yardstick) kept as the denominator for the two-plane fp16 launch too (3 part-products per fp32 product: own pipe 833.3 TF)",
                      "avg_launch_us": 1e3 * k_ms, "launches_timed": 50 * len(kt), "flops_per_launch": fl,
                      "bytes_per_launch": by, "hbm_frac_at_this_rate": (by / (k_ms * 1e-3) / 1e9) / PEAK_HBM_GBS,
                      "timing": "HIP events on the launch stream around 50 back-to-back launches per 16x16 layer"}})

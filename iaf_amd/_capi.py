@@ -172,7 +172,9 @@ SIGNATURES = {
                                                      ctypes.c_size_t, ctypes.c_int, _vp, ctypes.POINTER(ctypes.c_int),
                                                      ctypes.POINTER(ctypes.c_float)]),
     "iaf_conv3x3_set_precision": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "iaf_conv3x3_range_errors": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint)]),
     "iaf_conv3x3_runs_bf16x3": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "iaf_conv3x3_runs_f16x2": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "iaf_conv3x3_autotune": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, ctypes.POINTER(_vp),
                                             ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                             ctypes.c_int, ctypes.c_int, _vp, ctypes.POINTER(ctypes.c_int),

@@ -19,7 +19,13 @@ struct iaf_conv3x3 {
     bool training = false;
     bool deconv = false;           // weights prepared by iaf_conv3x3_prepare_deconv (deconv2d's norm + rotated filter)
     // forward on the bf16 matrix cores (bf16x3 split products, iaf_conv_bf3.hpp with 9 taps): plain convs with c_in % 32 == 0
+    // IAF_PRECISION_F16X2 (round 6): as BF16X3, the stride-1 forward launches on TWO fp16 planes (iaf_conv_bf3.hpp F16) from the pack L.wp2;
+    // an operand beyond 65504 raises rng_err (mapped host memory): the next forward returns IAF_ERR_RANGE once and the conv runs bf16x3
+    // from then on (f16_off) until iaf_conv3x3_set_precision(F16X2) re-arms
     int precision = IAF_PRECISION_BF16X3;
+    unsigned* rng_err_host = nullptr;
+    unsigned* rng_err_dev = nullptr;
+    bool f16_off = false;
     int bf3_choice = 1;            // 1 size rule, 2 the shape in L.b_* (pinned by iaf_conv3x3_autotune), 3 fp32 kernel (measured faster)
     GemmLayer T;                   // transposed problem dX = W^T dY (valid when training)
     // deferred weight-norm backward (iaf_conv3x3_wn_bwd_batch_run): the reduced dW / db partials live here, not in the
@@ -36,6 +42,8 @@ extern "C" int iaf_conv3x3_destroy(iaf_conv3x3_t* c) {
     if (c->L.bias) (void)hipFree(c->L.bias);
     if (c->L.wpt) (void)hipFree(c->L.wpt);
     if (c->L.wp3) (void)hipFree(c->L.wp3);
+    if (c->L.wp2) (void)hipFree(c->L.wp2);
+    if (c->rng_err_host) (void)hipHostFree(c->rng_err_host);
     if (c->L.border) (void)hipFree(c->L.border);
     if (c->own_dW) (void)hipFree(c->own_dW);
     if (c->own_dbp) (void)hipFree(c->own_dbp);
@@ -45,6 +53,11 @@ extern "C" int iaf_conv3x3_destroy(iaf_conv3x3_t* c) {
     return IAF_OK;
 }
 
+static inline bool conv_split(const iaf_conv3x3* c) { return c->precision != IAF_PRECISION_F32; }
+// the forward launches of this conv run the two-plane fp16 kernels now
+static inline bool conv_f16_active(const iaf_conv3x3* c) {
+    return c->precision == IAF_PRECISION_F16X2 && !c->f16_off && c->L.wp2 && !c->generic && !c->mask_mode;
+}
 static int conv3x3_create(iaf_conv3x3_t** out, int n_in, int n_out, int mask_mode);
 extern "C" int iaf_conv3x3_create(iaf_conv3x3_t** out, int n_in, int n_out) { return conv3x3_create(out, n_in, n_out, 0); }
 extern "C" int iaf_conv3x3_create_masked(iaf_conv3x3_t** out, int n_in, int n_out, int zerodiagonal) {
@@ -93,6 +106,14 @@ static int conv3x3_create(iaf_conv3x3_t** out, int n_in, int n_out, int mask_mod
         iaf_conv3x3_destroy(c);
         return rc;
     }
+    // default arithmetic of a plain conv with a split pack: the two-plane fp16 forward (IAF_DEFAULT_PRECISION=bf16x3: round 5's)
+    if (L.wp3) {
+        static const bool f16_default = !(getenv("IAF_DEFAULT_PRECISION") && !strcmp(getenv("IAF_DEFAULT_PRECISION"), "bf16x3"));
+        if (f16_default) {
+            rc = iaf_conv3x3_set_precision(c, IAF_PRECISION_F16X2);
+            if (rc != IAF_OK && rc != IAF_ERR_UNSUPPORTED) { iaf_conv3x3_destroy(c); return rc; }
+        }
+    }
     *out = c;
     return IAF_OK;
 }
@@ -124,6 +145,7 @@ extern "C" int iaf_conv3x3_prepare(iaf_conv3x3_t* c, const float* V, const float
         P.V[0] = V; P.g[0] = g; P.b[0] = b; P.wp = L.wp; P.bias = L.bias; P.variant = PREP_PLAIN9;
         P.wpt = c->training ? L.wpt : nullptr;
         P.wp3 = L.wp3;
+        P.wp2 = conv_f16_active(c) ? L.wp2 : nullptr; P.rng_err = P.wp2 ? c->rng_err_dev : nullptr;
         P.cin = L.cin; P.cout_each = L.cout; P.ncot = L.ncot; P.nchunk = L.nchunk; P.npair = 1; P.tile_begin = 0;
         HIP_TRY(hipMemcpyAsync(c->d_desc, c->h_desc, sizeof(PrepLayer), hipMemcpyHostToDevice, (hipStream_t)stream));
         hipLaunchKernelGGL(iaf_prep_plain_kernel, dim3(L.ncot), dim3(256), 0, (hipStream_t)stream, c->d_desc, (const int*)nullptr);
@@ -282,6 +304,7 @@ extern "C" int iaf_conv3x3_prep_batch_create(iaf_conv3x3_prep_batch_t** out, iaf
         const GemmLayer& L = convs[i]->L;
         PrepLayer& P = b->h_layers[i];
         P.wp = L.wp; P.bias = L.bias; P.variant = PREP_PLAIN9; P.wp3 = L.wp3;
+        P.wp2 = conv_f16_active(convs[i]) ? L.wp2 : nullptr; P.rng_err = P.wp2 ? convs[i]->rng_err_dev : nullptr;
         P.cin = L.cin; P.cout_each = L.cout; P.ncot = L.ncot; P.nchunk = L.nchunk; P.npair = 1; P.tile_begin = tile;
         for (int t = 0; t < L.ncot; ++t) t2l[tile++] = i;
     }
@@ -300,8 +323,10 @@ extern "C" int iaf_conv3x3_prep_batch_run(iaf_conv3x3_prep_batch_t* b, const flo
         if (!V[i] || !g[i] || !bias[i]) return IAF_ERR_NULL;
         PrepLayer& P = b->h_layers[i];
         float* wpt = b->convs[i]->training ? b->convs[i]->L.wpt : nullptr;
-        changed |= (P.V[0] != V[i]) | (P.g[0] != g[i]) | (P.b[0] != bias[i]) | (P.wpt != wpt);
-        P.V[0] = V[i]; P.g[0] = g[i]; P.b[0] = bias[i]; P.wpt = wpt;
+        void* wp2 = conv_f16_active(b->convs[i]) ? b->convs[i]->L.wp2 : nullptr;      // iaf_conv3x3_set_precision / a range failure since the last run
+        unsigned* rng = wp2 ? b->convs[i]->rng_err_dev : nullptr;
+        changed |= (P.V[0] != V[i]) | (P.g[0] != g[i]) | (P.b[0] != bias[i]) | (P.wpt != wpt) | (P.wp2 != wp2) | (P.rng_err != rng);
+        P.V[0] = V[i]; P.g[0] = g[i]; P.b[0] = bias[i]; P.wpt = wpt; P.wp2 = wp2; P.rng_err = rng;
     }
     hipStream_t st = (hipStream_t)stream;
     const void* d_layers = nullptr;     // see iaf_prep_batch_run
@@ -359,7 +384,7 @@ static bool conv3x3_bf3_shape(GemmLayer& L, int choice, long long P, int W) {
 // that every conv's launches on every stream wrote through without a bound); declared here, defined behind the object's definition.
 
 static int conv3x3_launch(GemmLayer& L, ConvP& p, int epi_sel, int inmode, bool masked, bool mirror, hipStream_t st,
-                          int variant = IAF_VARIANT_TF, int bf3_choice = 3) {
+                          int variant = IAF_VARIANT_TF, int bf3_choice = 3, unsigned* f16_rng = nullptr) {
     // the plain conv on the bf16 matrix cores: forward (NCHW input, EPI_PLAIN), or its data gradient (L = the transposed
     // problem with wp3 = the transposed bf16x3 pack: dY pixel-major, mirrored taps, EPI_DGRAD)
     const bool fwd3 = !masked && !mirror && epi_sel == EPI_PLAIN && inmode == IN_NCHW;
@@ -369,6 +394,10 @@ static int conv3x3_launch(GemmLayer& L, ConvP& p, int epi_sel, int inmode, bool 
         conv_fn_t fn = pick_bf3_plain(L.b_nt, L.b_ppw, L.b_pxt, L.b_ks, L.b_wco, bwd3 ? EPI_DGRAD : EPI_PLAIN);
         const int tm = 16 * L.b_ppw * L.b_pxt, W = p.W, sg = bwd3 ? -1 : 1;
         p.border = nullptr; p.wp = (const float*)L.wp3; p.bias = L.bias; p.lim = nullptr;
+        // f16_rng (the caller's conv runs IAF_PRECISION_F16X2): the forward on two fp16 planes, the same launch shape and LDS bound
+        if (conv_fn_t fn16 = (fwd3 && f16_rng && L.wp2) ? pick_bf3_plain_f16(L.b_nt, L.b_ppw, L.b_pxt, L.b_ks, L.b_wco) : nullptr) {
+            fn = fn16; p.wp = (const float*)L.wp2; p.rng_err = f16_rng;
+        }
         for (int t = 0; t < MAXTAPS; ++t) { p.tap_dh[t] = sg * (t / 3 - 1); p.tap_dw[t] = sg * (t % 3 - 1); }   // cross-correlation, SAME (mirrored: dX)
         p.halo_before = W + 1;
         p.nslot = tm + 2 * (W + 1);
@@ -463,8 +492,13 @@ extern "C" int iaf_conv3x3_forward(iaf_conv3x3_t* c, const float* x, const float
         p.split_end[k] = ends[k < n_outs ? k : n_outs - 1];
         p.split_ptr[k] = outs[k < n_outs ? k : n_outs - 1];
     }
+    // an F16 launch of this conv (or the prep of its pack) met an operand beyond fp16's range: said once; bf16x3 from here on
+    if (c->precision == IAF_PRECISION_F16X2 && !c->f16_off && c->rng_err_host && *(volatile unsigned*)c->rng_err_host) {
+        c->f16_off = true;
+        return IAF_ERR_RANGE;
+    }
     return conv3x3_launch(L, p, c->mask_mode ? EPI_PLAIN5 : EPI_PLAIN, IN_NCHW, c->mask_mode != 0, false, st, c->variant,
-                          (c->precision == IAF_PRECISION_BF16X3 && !c->deconv) ? c->bf3_choice : 3);
+                          (conv_split(c) && !c->deconv) ? c->bf3_choice : 3, conv_f16_active(c) ? c->rng_err_dev : nullptr);
 }
 
 // ---- the downsampling IAFLayer's two strided convs at their minimal work (iaf_conv_bf3.hpp, template parameter S2) ------------
@@ -524,7 +558,7 @@ extern "C" int iaf_conv3x3_forward_stride2(iaf_conv3x3_t* c, const float* x, int
     }
     if (tot != c->n_out) return IAF_ERR_SHAPE;
     GemmLayer& L = c->L;
-    if (c->generic || c->mask_mode || c->deconv || !L.wp3 || c->precision != IAF_PRECISION_BF16X3) return IAF_ERR_UNSUPPORTED;
+    if (c->generic || c->mask_mode || c->deconv || !L.wp3 || !conv_split(c)) return IAF_ERR_UNSUPPORTED;
     for (int k = 0; k < n_outs; ++k)
         if (ends[k] & 3) return IAF_ERR_UNSUPPORTED;
     int sh[4]; size_t lds = 0;
@@ -573,7 +607,7 @@ extern "C" int iaf_conv3x3_forward_deconv(iaf_conv3x3_t* c, const float* x, cons
     if (x2 && (c_split <= 0 || c_split >= c->n_in)) return IAF_ERR_SHAPE;
     GemmLayer& L = c->L;
     if (!c->deconv) return IAF_ERR_NOT_PREPARED;
-    if (c->generic || c->mask_mode || !L.wp3 || L.nchunk % 2 != 0 || c->precision != IAF_PRECISION_BF16X3) return IAF_ERR_UNSUPPORTED;
+    if (c->generic || c->mask_mode || !L.wp3 || L.nchunk % 2 != 0 || !conv_split(c)) return IAF_ERR_UNSUPPORTED;
     if ((x2 && (c_split & 3)) || (L.cout & 3)) return IAF_ERR_UNSUPPORTED;
     int sh[4]; size_t lds = 0;
     conv_fn_t fn = s2_shape(L, 2, W, sh, &lds);
@@ -604,15 +638,53 @@ extern "C" int iaf_conv3x3_forward_deconv(iaf_conv3x3_t* c, const float* x, cons
 // shape covers the problem, fp32-grade) or IAF_PRECISION_F32 (the exact-fp32 MFMA kernel always)
 extern "C" int iaf_conv3x3_set_precision(iaf_conv3x3_t* c, int precision) {
     if (!c) return IAF_ERR_NULL;
-    if (precision != IAF_PRECISION_F32 && precision != IAF_PRECISION_BF16X3) return IAF_ERR_SHAPE;
+    if (precision != IAF_PRECISION_F32 && precision != IAF_PRECISION_BF16X3 && precision != IAF_PRECISION_F16X2) return IAF_ERR_SHAPE;
+    if (precision == IAF_PRECISION_F16X2) {
+        GemmLayer& L = c->L;
+        if (c->generic || c->mask_mode || !L.wp3) return IAF_ERR_UNSUPPORTED;       // (plain convs with c_in % 32 == 0: the same fragments, two planes)
+        if (!c->rng_err_host) {
+            if (hipHostMalloc((void**)&c->rng_err_host, 64, hipHostMallocMapped) != hipSuccess) { c->rng_err_host = nullptr; return (int)hipErrorOutOfMemory; }
+            *(volatile unsigned*)c->rng_err_host = 0u;
+            if (hipHostGetDevicePointer((void**)&c->rng_err_dev, c->rng_err_host, 0) != hipSuccess) {
+                (void)hipHostFree(c->rng_err_host); c->rng_err_host = nullptr; c->rng_err_dev = nullptr;
+                return (int)hipErrorOutOfMemory;
+            }
+        }
+        if (!L.wp2) {
+            HIP_TRY(hipMalloc(&L.wp2, (size_t)(L.cin / 32) * MAXTAPS * L.ncot * 2 * 1024));
+            c->prepared = false;                             // the next prepare fills it
+        }
+        if (c->f16_off || *(volatile unsigned*)c->rng_err_host) {        // re-armed after a range failure
+            HIP_TRY(hipDeviceSynchronize());
+            *(volatile unsigned*)c->rng_err_host = 0u;
+            c->f16_off = false;
+            c->prepared = false;
+        }
+        if (c->precision != IAF_PRECISION_F16X2) c->prepared = false;     // the fp16 pack has not been kept up to date
+    }
     c->precision = precision;
+    return IAF_OK;
+}
+extern "C" int iaf_conv3x3_range_errors(const iaf_conv3x3_t* c, unsigned* errors) {
+    if (!c || !errors) return IAF_ERR_NULL;
+    *errors = 0;
+    if (!c->rng_err_host) return IAF_OK;
+    HIP_TRY(hipDeviceSynchronize());
+    *errors = *(volatile unsigned*)c->rng_err_host;
     return IAF_OK;
 }
 // 1 if a forward call at this size would run the bf16x3 kernel
 extern "C" int iaf_conv3x3_runs_bf16x3(iaf_conv3x3_t* c, int B, int H, int W) {
-    if (!c || c->generic || c->mask_mode || c->deconv || c->precision != IAF_PRECISION_BF16X3) return 0;
+    if (!c || c->generic || c->mask_mode || c->deconv || !conv_split(c)) return 0;
     GemmLayer t = c->L;
     return conv3x3_bf3_shape(t, c->bf3_choice, (long long)B * H * W, W) ? 1 : 0;
+}
+// ... and on two fp16 planes (the split-product launch of this size is an F16 instantiation)
+extern "C" int iaf_conv3x3_runs_f16x2(iaf_conv3x3_t* c, int B, int H, int W) {
+    if (!iaf_conv3x3_runs_bf16x3(c, B, H, W) || !conv_f16_active(c)) return 0;
+    GemmLayer t = c->L;
+    if (!conv3x3_bf3_shape(t, c->bf3_choice, (long long)B * H * W, W)) return 0;
+    return pick_bf3_plain_f16(t.b_nt, t.b_ppw, t.b_pxt, t.b_ks, t.b_wco) ? 1 : 0;
 }
 
 extern "C" int iaf_conv3x3_autotune(iaf_conv3x3_t* c, const float* x, const float* x2, int c_split, int elu_input,
@@ -655,7 +727,7 @@ extern "C" int iaf_conv3x3_autotune(iaf_conv3x3_t* c, const float* x, const floa
     L.nt = bsh[0]; L.pxt = bsh[1]; L.wco = bsh[2]; L.ks = bsh[3]; L.user_tuned = true;
     // ... and the same conv on the bf16 matrix cores, every compiled 9-tap shape
     int bz[5] = {0, 0, 0, 0, 1};
-    if (rc == IAF_OK && L.wp3 && c->precision == IAF_PRECISION_BF16X3 && !c->mask_mode && !c->deconv) {
+    if (rc == IAF_OK && L.wp3 && conv_split(c) && !c->mask_mode && !c->deconv) {
         static const int nts[3] = {5, 4, 2};
         for (int si = 0; si < N_BF3P_SHAPES && rc == IAF_OK; ++si)
             for (int nt : nts) {
@@ -874,13 +946,13 @@ extern "C" int iaf_conv3x3_backward(iaf_conv3x3_t* c, const float* x, const floa
             p.split_ptr[k] = dxs[k < n_dxs ? k : n_dxs - 1];
         }
         // bf16x3 unless the conv's precision is fp32 or a backward search measured the fp32 kernel faster at this size
-        const int choice3 = (c->precision != IAF_PRECISION_BF16X3 || c->bf3_choice == 3 || !c->T.wp3) ? 3 : (c->T.tuned_P == (long long)P && c->T.tuned_W == W && !c->T.tuned_bf3) ? 3 : 1;
+        const int choice3 = (!conv_split(c) || c->bf3_choice == 3 || !c->T.wp3) ? 3 : (c->T.tuned_P == (long long)P && c->T.tuned_W == W && !c->T.tuned_bf3) ? 3 : 1;
         if ((rc = conv3x3_launch(c->T, p, EPI_DGRAD9, IN_PIXMAJOR, false, true, st, IAF_VARIANT_TF, choice3))) return rc;
     }
     // (3) weight gradient: partials over pixel ranges, then reduce (+ column sums of dY for db)
     const unsigned short* tapmask = nullptr;
     if ((rc = tapmask_for(B, H, W, st, tw.tapmask, &tapmask))) return rc;
-    if ((rc = launch_wgrad(nullptr, L, tw.xe, tw.dyc, tw.part, tapmask, B, H, W, st, 1, c->precision == IAF_PRECISION_BF16X3))) return rc;
+    if ((rc = launch_wgrad(nullptr, L, tw.xe, tw.dyc, tw.part, tapmask, B, H, W, st, 1, conv_split(c)))) return rc;
     const int nslab = fold_db ? (P + 63) / 64 : 256;
     const int px_per_slab = (P + nslab - 1) / nslab;
     float* dWbuf = c->defer_wn ? c->own_dW : tw.dW;
@@ -890,7 +962,7 @@ extern "C" int iaf_conv3x3_backward(iaf_conv3x3_t* c, const float* x, const floa
         int nblk = (int)((n4 + 255) / 256);
         if (nblk > 1024) nblk = 1024;
         hipLaunchKernelGGL(iaf_wgrad_reduce_kernel, dim3(nblk + (fold_db ? 0 : nslab)), dim3(256), 0, st, tw.part, dWbuf,
-                           wgrad_nrange(P, L.cin, MAXTAPS, L.cout, c->precision == IAF_PRECISION_BF16X3), n4, nblk, (const float*)tw.dyc, dbpbuf, P, L.cout, px_per_slab);
+                           wgrad_nrange(P, L.cin, MAXTAPS, L.cout, conv_split(c)), n4, nblk, (const float*)tw.dyc, dbpbuf, P, L.cout, px_per_slab);
     }
     // (4) through the weight norm -- now, or in iaf_conv3x3_wn_bwd_batch_run with every other conv of the model
     if (c->deconv) {      // deconv2d's norm runs per INPUT channel over the rotated filter (layers.py:104): its own two launches
@@ -965,7 +1037,7 @@ extern "C" int iaf_conv3x3_autotune_backward(iaf_conv3x3_t* c, const float* x, c
         }
     // ... and the bf16x3 data gradient in its rule shape (conv3x3_bf3_shape), if this conv has the transposed bf16x3 pack
     bool bf3_wins = false;
-    if (rc == IAF_OK && T.wp3 && c->bf3_choice != 3 && c->precision == IAF_PRECISION_BF16X3) {
+    if (rc == IAF_OK && T.wp3 && c->bf3_choice != 3 && conv_split(c)) {
         T.user_tuned = false;
         T.tuned_bf3 = true;
         for (int r = 0; r < 2 && rc == IAF_OK; ++r) rc = run();

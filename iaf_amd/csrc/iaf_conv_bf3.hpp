@@ -95,11 +95,16 @@ __device__ __forceinline__ void f16s_store4(char* smem, int slot, int q, f32x4 v
 //      rotated filter (iaf_kernels_resample.hpp): output phase (a,b) = pixels (2i+a, 2j+b) only meets taps with di = a (mod 2)...
 //      precisely di in {0,2} (rows i-1, i) when a = 0, di = 1 (row i) when a = 1 -- 4, 2, 2, 1 taps for the four phases, nine in
 //      all.  blockIdx.z = the phase; the staged tile is the ordinary low-resolution one.  p.H, p.W = the INPUT grid.
-template <int NT, int PPW, int PXT, int KS, int INMODE, int EPI, int WCO = 1, int NTP_ = NTAPS, int S2 = 0>
+// F16 = 1 (round 6): the operands as TWO fp16 planes and three part-products per step ("f16x2", see f16s_split2 above and
+// iaf_step_fused.hpp) -- the forward plain convs (EPI_PLAIN, NCHW input: activations O(1), weight-normed filters); the data gradients keep
+// the bf16 planes (a gradient tensor's magnitudes have no business with fp16's exponent range).  p.wp = the two-plane pack.
+template <int NT, int PPW, int PXT, int KS, int INMODE, int EPI, int WCO = 1, int NTP_ = NTAPS, int S2 = 0, int F16 = 0>
 __global__ __launch_bounds__(64 * PXT * KS * WCO) void iaf_conv_bf3_kernel(ConvP p) {
+    static_assert(!F16 || INMODE != IN_FUSED0, "the fused first layer exists on bf16 planes only");
     extern __shared__ __attribute__((aligned(16))) f32x4 smem4[];
     char* smem = (char*)smem4;
     constexpr int NTP = NTP_;
+    constexpr int NPL = F16 ? 2 : 3;                             // planes per operand
     constexpr int TM = 16 * PPW * PXT;
     constexpr int NTHREADS = 64 * PXT * KS * WCO;   // WCO co groups share ONE staged activation tile
     constexpr int RD = (PPW >= 2) ? 1 : 2;   // ring look-ahead in steps (a step is PPW*NT*6 MFMAs of 16 cycles)
@@ -137,7 +142,17 @@ __global__ __launch_bounds__(64 * PXT * KS * WCO) void iaf_conv_bf3_kernel(ConvP
         }
     };
     const int cin8 = p.cin >> 3;           // one plane of one slot, in 16-byte units
-    const int s16 = 3 * cin8 + 2;          // slot stride in 16-byte units (3 planes + 32 B pad)
+    const int s16 = NPL * cin8 + 2;        // slot stride in 16-byte units (the planes + 32 B pad)
+    // 4 channels of a pixel slot -> the planes of an LDS tile; F16: the largest magnitude this lane has split (NaNs pass fmaxf by)
+    [[maybe_unused]] float rngmax = 0.f;
+    auto split4 = [&](char* region, int slot, int q, f32x4 v, int s16_, int c8_) __attribute__((always_inline)) {
+        if constexpr (F16) {
+            rngmax = fmaxf(fmaxf(rngmax, fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1]))), fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3])));
+            f16s_store4(region, slot, q, v, s16_, c8_);
+        } else {
+            bf3_store4(region, slot, q, v, s16_, c8_);
+        }
+    };
     const int npair = p.nchunk >> 1;       // c_in / 32
 #define IAF_BSTAMP(k) do { if (p.dbg && tid == 0) p.dbg[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
     IAF_BSTAMP(0);
@@ -209,7 +224,7 @@ __global__ __launch_bounds__(64 * PXT * KS * WCO) void iaf_conv_bf3_kernel(ConvP
                 for (int r = 0; r < 4; ++r) v[r] = elu_f(v[r]);
             }
             if (!nb_ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (nb_slot >= 0) bf3_store4(smem, nb_slot, q, v, s16, cin8);
+            if (nb_slot >= 0) split4(smem, nb_slot, q, v, s16, cin8);
         }
     };
     if constexpr (INMODE == IN_NCHW && S2 != 1) nchw_issue(0, 0);
@@ -218,8 +233,8 @@ __global__ __launch_bounds__(64 * PXT * KS * WCO) void iaf_conv_bf3_kernel(ConvP
     // step s = pair * 5 + tap; wave kh owns steps [s0, s1).  One step = NT tiles x 3 planes x 1 KiB, contiguous.
     const int S = S2 == 2 ? npair << lgt : npair * NTP;
     const int s0 = (kh * S) / KS, s1 = ((kh + 1) * S) / KS;
-    const size_t wstep = (size_t)p.ncot * 3 * 64;                               // f32x4 per step
-    const f32x4* wbase = (const f32x4*)p.wp + (size_t)cot0 * 3 * 64 + lane;    // this wave's tiles, this lane's 16 bytes
+    const size_t wstep = (size_t)p.ncot * NPL * 64;                             // f32x4 per step
+    const f32x4* wbase = (const f32x4*)p.wp + (size_t)cot0 * NPL * 64 + lane;  // this wave's tiles, this lane's 16 bytes
     f32x4 wr[U][NT][3];
     // fragments [lo, hi) of step s -> ring slot I (a step's refill is issued in PPW parts, one per pixel-tile group of
     // MFMAs, so that the loads sit BETWEEN the MFMAs instead of in a cluster that starves the pipe)
@@ -233,10 +248,10 @@ __global__ __launch_bounds__(64 * PXT * KS * WCO) void iaf_conv_bf3_kernel(ConvP
         if constexpr (S2 == 2) { const int pr = step_pair(sc); ws = pr * NTP + step_tap(sc, pr); }
         const f32x4* q = wbase + (size_t)ws * wstep;
 #pragma unroll
-        for (int f = LO; f < HI; ++f) wr[I][f / 3][f % 3] = q[f * 64];
+        for (int f = LO; f < HI; ++f) wr[I][f / NPL][f % NPL] = q[f * 64];
     };
     auto load_step = [&](auto slot_c, int s) __attribute__((always_inline)) {
-        load_part(slot_c, std::integral_constant<int, 0>{}, std::integral_constant<int, NT * 3>{}, s);
+        load_part(slot_c, std::integral_constant<int, 0>{}, std::integral_constant<int, NT * NPL>{}, s);
     };
     static_for<RD>([&](auto i) { load_step(i, s0 + decltype(i)::value); });
     IAF_BSTAMP(1);
@@ -321,7 +336,7 @@ __global__ __launch_bounds__(64 * PXT * KS * WCO) void iaf_conv_bf3_kernel(ConvP
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                if (dsl[u] >= 0) bf3_store4(region, dsl[u], dq[u], v4[u], s16_, cin8_);
+                if (dsl[u] >= 0) split4(region, dsl[u], dq[u], v4[u], s16_, cin8_);
         }
     };
 
@@ -362,7 +377,7 @@ __global__ __launch_bounds__(64 * PXT * KS * WCO) void iaf_conv_bf3_kernel(ConvP
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                if (dsl[u] >= 0) bf3_store4(smem, dsl[u], dq[u], v4[u], s16, cin8);
+                if (dsl[u] >= 0) split4(smem, dsl[u], dq[u], v4[u], s16, cin8);
         }
     };
 
@@ -469,7 +484,7 @@ __global__ __launch_bounds__(64 * PXT * KS * WCO) void iaf_conv_bf3_kernel(ConvP
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = elu_f(v[r]);
                     }
-                    bf3_store4(smem, sl, tile_of[j] * 4 + kk, v, s16, cin8);
+                    split4(smem, sl, tile_of[j] * 4 + kk, v, s16, cin8);
                 }
             }
         }
@@ -486,13 +501,13 @@ __global__ __launch_bounds__(64 * PXT * KS * WCO) void iaf_conv_bf3_kernel(ConvP
                 const int f = tid + u * NTHREADS;
                 if (f < nitems) {
                     const int sl = (int)(((float)f + 0.5f) * rnq);
-                    bf3_store4(smem, sl, f - sl * nq, sv[u], s16, cin8);
+                    split4(smem, sl, f - sl * nq, sv[u], s16, cin8);
                 }
             }
             const f32x4* src = (const f32x4*)p.x + (long long)Pbase * nq;
             for (int f = tid + SU * NTHREADS; f < nitems; f += NTHREADS) {
                 const int sl = (int)(((float)f + 0.5f) * rnq);
-                bf3_store4(smem, sl, f - sl * nq, (f >= flo && f < fhi) ? src[f] : f32x4{0.f, 0.f, 0.f, 0.f}, s16, cin8);
+                split4(smem, sl, f - sl * nq, (f >= flo && f < fhi) ? src[f] : f32x4{0.f, 0.f, 0.f, 0.f}, s16, cin8);
             }
         } else if (S2 == 1) {
             stage_s2d();
@@ -512,10 +527,18 @@ __global__ __launch_bounds__(64 * PXT * KS * WCO) void iaf_conv_bf3_kernel(ConvP
 
     // ================= K loop =========================================================================================
     f32x4 acc[PPW][NT];
+    [[maybe_unused]] f32x4 accx[F16 ? PPW : 1][F16 ? NT : 1];   // F16: the cross products (hi lo' + lo' hi), scaled by 2^-11 behind the K loop
 #pragma unroll
     for (int q = 0; q < PPW; ++q)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < NT; ++t) {
+            acc[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (F16) accx[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    if constexpr (F16) {        // an operand beyond fp16's largest finite number went into the planes: the host reads this word at its next call
+        if (__any(rngmax > IAF_F16_MAX) && lane == 0 && p.rng_err)
+            __hip_atomic_fetch_or(p.rng_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 
     // x operand address of (pixel tile q, step s): tap and pair are wave-uniform
     auto xaddr = [&](auto q_c, int s) __attribute__((always_inline)) -> int {
@@ -544,7 +567,8 @@ __global__ __launch_bounds__(64 * PXT * KS * WCO) void iaf_conv_bf3_kernel(ConvP
     f32x4 xn[3];      // the NEXT (step, pixel tile)'s three planes, in flight while the current one is multiplied
     {
         const int a = xaddr(std::integral_constant<int, 0>{}, s0);
-        xn[0] = smem4[a]; xn[1] = smem4[a + cin8]; xn[2] = smem4[a + 2 * cin8];
+        xn[0] = smem4[a]; xn[1] = smem4[a + cin8];
+        if constexpr (NPL == 3) xn[2] = smem4[a + 2 * cin8];
     }
     auto step_body = [&](auto slot_c, int s) __attribute__((always_inline)) {
         constexpr int I = decltype(slot_c)::value;
@@ -553,17 +577,31 @@ __global__ __launch_bounds__(64 * PXT * KS * WCO) void iaf_conv_bf3_kernel(ConvP
             // refill (this group's share) of the slot consumed RD steps from now; the last group of a multi-group step issues
             // none, so that every fragment has at least one group of MFMAs (~500 cycles) to arrive
             constexpr int NG = PPW > 1 ? PPW - 1 : 1;
-            constexpr int LO = q < NG ? (q * NT * 3) / NG : NT * 3, HI = q < NG ? ((q + 1) * NT * 3) / NG : NT * 3;
+            constexpr int LO = q < NG ? (q * NT * NPL) / NG : NT * NPL, HI = q < NG ? ((q + 1) * NT * NPL) / NG : NT * NPL;
             load_part(std::integral_constant<int, (I + RD) % U>{}, std::integral_constant<int, LO>{},
                       std::integral_constant<int, HI>{}, s + RD);
-            const bf16x8 xh = __builtin_bit_cast(bf16x8, xn[0]);
-            const bf16x8 xm = __builtin_bit_cast(bf16x8, xn[1]);
-            const bf16x8 xl = __builtin_bit_cast(bf16x8, xn[2]);
+            f32x4 xr[3];
+            xr[0] = xn[0]; xr[1] = xn[1];
+            if constexpr (NPL == 3) xr[2] = xn[2];
             {   // prefetch the next pixel tile of this step, or tile 0 of the next step
                 const int a = (q + 1 < PPW) ? xaddr(std::integral_constant<int, (q + 1) % PPW>{}, s)
                                             : xaddr(std::integral_constant<int, 0>{}, s + 1);
-                xn[0] = smem4[a]; xn[1] = smem4[a + cin8]; xn[2] = smem4[a + 2 * cin8];
+                xn[0] = smem4[a]; xn[1] = smem4[a + cin8];
+                if constexpr (NPL == 3) xn[2] = smem4[a + 2 * cin8];
             }
+            if constexpr (F16) {
+                // three products per co tile: hi x lo' and lo' x hi into the cross accumulator, hi x hi into the main one (between them)
+#define IAF_F16_PROD(ACC, WP, XP)                                                                                  \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                                 \
+        ACC[q][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wr[I][t][WP]), __builtin_bit_cast(f16x8, xr[XP]), ACC[q][t], 0, 0, 0);
+                IAF_F16_PROD(accx, 0, 1)
+                IAF_F16_PROD(acc, 0, 0)
+                IAF_F16_PROD(accx, 1, 0)
+#undef IAF_F16_PROD
+            } else {
+            const bf16x8 xh = __builtin_bit_cast(bf16x8, xr[0]);
+            const bf16x8 xm = __builtin_bit_cast(bf16x8, xr[1]);
+            const bf16x8 xl = __builtin_bit_cast(bf16x8, xr[2]);
             // six products per co tile, interleaved over the tiles so that consecutive MFMAs hit different accumulators;
             // the small terms first
 #define IAF_BF3_PROD(WP, XV)                                                                                      \
@@ -576,7 +614,8 @@ __global__ __launch_bounds__(64 * PXT * KS * WCO) void iaf_conv_bf3_kernel(ConvP
             IAF_BF3_PROD(0, xm)   // w_h x_m
             IAF_BF3_PROD(0, xh)   // w_h x_h
 #undef IAF_BF3_PROD
-            sched_interleave<6 * NT, 3, 0, HI - LO>();
+            }
+            sched_interleave<(F16 ? 3 : 6) * NT, NPL, 0, HI - LO>();
             __builtin_amdgcn_sched_barrier(0);
         });
     };
@@ -591,6 +630,12 @@ __global__ __launch_bounds__(64 * PXT * KS * WCO) void iaf_conv_bf3_kernel(ConvP
         });
     }
 
+    if constexpr (F16) {
+#pragma unroll
+        for (int q = 0; q < PPW; ++q)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[q][t] += accx[q][t] * (1.0f / 2048.0f);      // the cross products carry lo' = lo 2^11
+    }
     IAF_BSTAMP(3);
     // ================= split-K exchange through LDS + epilogue ========================================================
     // item = (pixel tile q of this wave group, epilogue unit u); the KS waves of a group share the items round-robin

@@ -49,3 +49,13 @@ extern "C" conv_fn_t IAF_CAT(iaf_pick_bf3s_, IAF_PPW, IAF_PXT, IAF_KS, IAF_WCO)(
     }
     return nullptr;
 }
+
+// the forward plain conv on two fp16 planes (iaf_conv_bf3.hpp F16; IAF_PRECISION_F16X2): p.wp = the two-plane pack
+extern "C" conv_fn_t IAF_CAT(iaf_pick_bf3p16_, IAF_PPW, IAF_PXT, IAF_KS, IAF_WCO)(int nt) {
+    switch (nt) {
+        case 2: return iaf_conv_bf3_kernel<2, IAF_PPW, IAF_PXT, IAF_KS, IN_NCHW, EPI_PLAIN, IAF_WCO, MAXTAPS, 0, 1>;
+        case 4: return iaf_conv_bf3_kernel<4, IAF_PPW, IAF_PXT, IAF_KS, IN_NCHW, EPI_PLAIN, IAF_WCO, MAXTAPS, 0, 1>;
+        case 5: return iaf_conv_bf3_kernel<5, IAF_PPW, IAF_PXT, IAF_KS, IN_NCHW, EPI_PLAIN, IAF_WCO, MAXTAPS, 0, 1>;
+    }
+    return nullptr;
+}

@@ -99,6 +99,8 @@ struct ConvP {
     // reached -- the one-launch step kernel returns at once then (the layer-by-layer kernels ignore it: a sweep at the fixed point
     // changes nothing); NULL otherwise.  Host-side field only: read by launch_fused_step.
     const unsigned* inv_done;
+    // two-plane fp16 kernels (iaf_conv_bf3.hpp F16): host-visible word raised when an operand beyond fp16's largest finite number was staged
+    unsigned* rng_err;
 };
 
 // Pin the order "MFMAs with memory instructions spread evenly between them" inside the current scheduling region:

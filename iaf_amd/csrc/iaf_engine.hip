@@ -113,6 +113,7 @@ struct iaf_stack {
         hipStream_t st = nullptr;
         char* buf = nullptr; size_t bytes = 0;                 // rows: every dword `pattern` between launches
         unsigned pattern = IAF_XSENT;                          // IAF_XSENT (bf16 planes) or IAF_XSENT_F16 (fp16 planes): a set serves kernels of ONE plane type
+        bool captured = false;                                 // a hipGraph names this set's rows and counters: no OTHER capture stream may take it over
         unsigned long long* ctl = nullptr;                     // heads, arrivals, sticky error (StepP::xctl), arrivals of the in-launch KL finish (StepP::fin_ctl = xctl + IAF_XCTL_FIN): zero between launches
     };
     std::deque<XchSet> xch_sets;           // (stable addresses: a launch holds a pointer to its set outside the lock)
@@ -300,6 +301,15 @@ static conv_fn_t pick_bf3_plain(int nt, int ppw, int pxt, int ks, int wco, int e
     if (ppw == 2 && pxt == 1 && ks == 4 && wco == 1) return iaf_pick_bf3p_2_1_4_1(nt, epi);
     if (ppw == 4 && pxt == 1 && ks == 4 && wco == 1) return iaf_pick_bf3p_4_1_4_1(nt, epi);
     if (ppw == 2 && pxt == 1 && ks == 4 && wco == 2) return iaf_pick_bf3p_2_1_4_2(nt, epi);
+    return nullptr;
+}
+extern "C" conv_fn_t iaf_pick_bf3p16_2_1_4_1(int nt);
+extern "C" conv_fn_t iaf_pick_bf3p16_4_1_4_1(int nt);
+extern "C" conv_fn_t iaf_pick_bf3p16_2_1_4_2(int nt);
+static conv_fn_t pick_bf3_plain_f16(int nt, int ppw, int pxt, int ks, int wco) {
+    if (ppw == 2 && pxt == 1 && ks == 4 && wco == 1) return iaf_pick_bf3p16_2_1_4_1(nt);
+    if (ppw == 4 && pxt == 1 && ks == 4 && wco == 1) return iaf_pick_bf3p16_4_1_4_1(nt);
+    if (ppw == 2 && pxt == 1 && ks == 4 && wco == 2) return iaf_pick_bf3p16_2_1_4_2(nt);
     return nullptr;
 }
 // LDS of a 9-tap bf16x3 launch: the pixel tile with a halo of W + 1 slots on BOTH sides (+ the zero slot)
@@ -1179,16 +1189,23 @@ static iaf_stack::XchSet* xch_prepare(iaf_stack_t* s, int B, int nrb, size_t xro
     iaf_stack::XchSet* x = nullptr;
     for (auto& e : s->xch_sets) if (e.st == st && e.pattern == pattern) { x = &e; break; }
     const size_t need = (size_t)s->depth_ar * B * nrb * xrow > 256 ? (size_t)s->depth_ar * B * nrb * xrow : 256;   // (xrow = 0: only the counters are wanted)
-    if (x && need <= x->bytes) return x;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(st, &cs);
+    if (x && need <= x->bytes) {
+        if (cs != hipStreamCaptureStatusNone) x->captured = true;
+        return x;
+    }
     if (cs != hipStreamCaptureStatusNone) {
         // no allocation inside a capture: a capture stream without a set of its own (torch.cuda.graph's internal stream after a
         // warm-up elsewhere) TAKES OVER the newest set that is large enough -- the set now belongs to the capture stream, so the
         // graph's replays share no rows and no counters with later eager launches on the stream it came from (those allocate a
         // fresh set on their next call; include/iaf_hip.h).  None large enough: the caller runs the recomputing kernel.
-        for (size_t i = s->xch_sets.size(); i-- > 0;)
-            if (need <= s->xch_sets[i].bytes && s->xch_sets[i].pattern == pattern) { s->xch_sets[i].st = st; return &s->xch_sets[i]; }
+        // A set that a graph captured on ANOTHER stream already names is not taken (two graphs on two streams would share
+        // its rows and counters, and concurrent replays race into bounded waits and NaN): the caller then runs the recomputing kernel.
+        for (size_t i = s->xch_sets.size(); i-- > 0;) {
+            iaf_stack::XchSet& e = s->xch_sets[i];
+            if (need <= e.bytes && e.pattern == pattern && !e.captured) { e.st = st; e.captured = true; return &e; }
+        }
         return nullptr;
     }
     if (!s->xch_err_host) {

@@ -159,8 +159,13 @@ __global__ __launch_bounds__(256) void iaf_generic_conv3x3_kernel(GenPlainP p) {
 // ---------------------------------------------------------------------------------------------
 // GENERIC FALLBACK, BACKWARD (round 5): what TF's autodiff derives for layers.py:52-64 / 158-166 (tf_train.py:138) at channel counts
 // outside the MFMA path -- direct loops over NCHW tensors, one thread per output element or one workgroup per reduced element.
-// Slow by design (a 72-channel conv: milliseconds); it exists so that every shape the reference accepts (layers.py:116) TRAINS
-// through the same C ABI (checked by tests/test_hip_generic_backward.py against fp64 autograd of the restated forward).
+// Slow by design (a 72-channel conv: milliseconds); it exists so that the per-op and per-layer training entry points (iaf_step_backward,
+// iaf_posterior_block_backward, iaf_conv3x3_backward, a whole IAFLayer) accept the channel counts the reference accepts (layers.py:116;
+// checked by tests/test_hip_generic_backward.py against fp64 autograd of the restated forward).  What it does NOT cover: channel
+// splits / concat pieces that are not multiples of 4 (iaf_conv3x3_backward returns IAF_ERR_SHAPE for those before it gets here), and the
+// BATCHED prep / weight-norm-backward objects (iaf_prep_batch_*, iaf_wn_bwd_batch_*: IAF_ERR_UNSUPPORTED for generic members) that
+// CVAE1.prepare_weights / set_grad_buckets always build -- a MODEL with such channel counts trains layer by layer, not through
+// CVAE1.forward_backward.
 //   dX  = [res +] act'(.) * (W^T dY)      (data gradient: the conv with mirrored taps)
 //   dW[t][ci][co] = sum_p a[p + shift(t)][ci] dY[p][co],  db[co] = sum_p dY[p][co]
 //   dV, dg through the mask and the weight norm (the arithmetic of wn_bwd_tile, iaf_kernels_backward.hpp)

@@ -650,12 +650,24 @@ class WNConv2d(object):
     def set_precision(self, precision):
         """"bf16x3" (default: the forward conv on the bf16 matrix cores with split products, fp32-grade, where a launch shape
         covers it) or "f32" (the exact-fp32 MFMA kernel always)"""
-        # ("f16x2" is an arithmetic of the one-launch step kernels only: a plain conv runs bf16x3 under it)
-        code = {"f32": _capi.IAF_PRECISION_F32, "bf16x3": _capi.IAF_PRECISION_BF16X3, "f16x2": _capi.IAF_PRECISION_BF16X3}.get(precision, precision)
-        _capi.check(_capi.lib().iaf_conv3x3_set_precision(self._h, int(code)))
+        code = {"f32": _capi.IAF_PRECISION_F32, "bf16x3": _capi.IAF_PRECISION_BF16X3, "f16x2": _capi.IAF_PRECISION_F16X2}.get(precision, precision)
+        rc = _capi.lib().iaf_conv3x3_set_precision(self._h, int(code))
+        if rc == _capi.IAF_ERR_UNSUPPORTED and code == _capi.IAF_PRECISION_F16X2:      # (no split pack for this conv: bf16x3 semantics)
+            rc = _capi.lib().iaf_conv3x3_set_precision(self._h, _capi.IAF_PRECISION_BF16X3)
+        _capi.check(rc)
+        self._prep_key = None
+
+    def range_errors(self):
+        """the range word of an "f16x2" conv (iaf_conv3x3_range_errors): 0 = no operand beyond fp16's range so far"""
+        e = ctypes.c_uint(0)
+        _capi.check(_capi.lib().iaf_conv3x3_range_errors(self._h, ctypes.byref(e)))
+        return int(e.value)
 
     def runs_bf16x3(self, B, H, W):
         return bool(_capi.lib().iaf_conv3x3_runs_bf16x3(self._h, int(B), int(H), int(W)))
+
+    def runs_f16x2(self, B, H, W):
+        return bool(_capi.lib().iaf_conv3x3_runs_f16x2(self._h, int(B), int(H), int(W)))
 
     # -- training --------------------------------------------------------------------------------
     _shared_ws = {}     # device -> one scratch buffer shared by all plain convs (they run one after another)

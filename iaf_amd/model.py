@@ -197,6 +197,7 @@ class CVAE1(object):
         acc = StreamingLowerBound(B, x.device)
         xf = None
         for noise in noise_passes:
+            self._check_inputs(x, noise, self.k)      # every pass's noise list (host-only checks: the kernels take raw pointers)
             if xf is None:
                 xf = self._bottom_up(x, noise)
             log_pxz, kl_cost = self._top_down(xf, B, noise, terms=True)

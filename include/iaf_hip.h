@@ -363,6 +363,8 @@ int iaf_stack_step_is_fused(const iaf_stack_t* s, int B, int H, int W);
  *   State.  Rows and list heads live in a set of buffers the stack owns PER STREAM (allocated on a stream's first such launch
  *   outside a stream capture): calls on different streams are independent.  A stream capture allocates nothing: it uses its
  *   stream's set if a warm-up launch on that stream created one, else it TAKES OVER the stack's newest set that is large enough
+ *   AND that no graph captured on another stream already names (such a set stays with its graph: two graphs on two streams never
+ *   share rows or counters; a capture that finds none runs the recomputing kernel)
  *   (the set changes owner: the stream it was warmed up on allocates a new one on its next eager launch, so replays of the graph
  *   and those launches share nothing; only launches of that stream still in flight from before the capture use the old set -- a
  *   graph is not replayed before its capture has ended, synchronise that stream before the first replay), else the recomputing
@@ -375,6 +377,7 @@ int iaf_stack_step_is_fused(const iaf_stack_t* s, int B, int H, int W);
  *   the exchange.  A captured hipGraph holds the exchange-form launch itself: REPLAYS of it keep importing NaN (no host code runs that
  *   could switch kernels) until the stack is re-armed AND the graph is captured again -- a training loop that replays graphs should read
  *   iaf_stack_exchange_errors (or, from Python, CVAE1.exchange_errors()) when its loss turns NaN.
+ *   (The two-plane fp16 kernels of IAF_PRECISION_F16X2 keep sets of their own, with the pattern 0xfdfffdff: a pair of SIGNALLING fp16 NaNs.)
  *   The pattern: every dword of the row buffers holds 0xffbfffbf between launches, a pair of SIGNALLING bf16 NaNs.  The rows carry hidden
  *   activations, results of arithmetic, and arithmetic returns quiet NaNs only: a caller's NaN -- whatever its payload -- travels as data.
  * iaf_stack_exchange_errors: *errors = the error word (0 = never gave up; it synchronises the device so that every launch so
@@ -512,7 +515,14 @@ int iaf_conv3x3_set_debug(iaf_conv3x3_t* c, void* buf, size_t bytes);
  * single convs, deconvs and the backward kernels run it regardless).  iaf_conv3x3_runs_bf16x3: 1 if a forward call at this
  * size would run the bf16x3 kernel. */
 int iaf_conv3x3_set_precision(iaf_conv3x3_t* c, int precision);
+/* IAF_PRECISION_F16X2 for a plain conv (the default where c_in % 32 == 0): its stride-1 forward launches split the operands into two fp16
+ * planes as the one-launch step does (iaf_stack_set_precision); the strided forms, the data and weight gradients stay on bf16 planes.
+ * The same range protocol: an operand beyond 65504 -> inf / NaN outputs, the NEXT iaf_conv3x3_forward returns IAF_ERR_RANGE once and the
+ * conv runs bf16x3 from then on; *errors = its range word (synchronises). */
+int iaf_conv3x3_range_errors(const iaf_conv3x3_t* c, unsigned* errors);
 int iaf_conv3x3_runs_bf16x3(iaf_conv3x3_t* c, int B, int H, int W);
+/* 1 if that launch would be the two-plane fp16 one */
+int iaf_conv3x3_runs_f16x2(iaf_conv3x3_t* c, int B, int H, int W);
 /* times every compiled launch shape with `reps` back-to-back forwards on the caller's buffers (same arguments as
  * iaf_conv3x3_forward; outputs end up holding the forward result), pins the fastest as if by set_tuning, and reports it
  * (best_shape[4] = nt,pxt,wco,ks; best_us per call; both optional).  With IAF_PRECISION_BF16X3 (the default) a plain conv

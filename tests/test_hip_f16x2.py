@@ -284,3 +284,97 @@ def test_training_forward_on_fp16_planes_feeds_the_same_backward(amd):
     close(host(dctx), ref["context"], 1e-4, "dcontext")
     for k in sorted(params):
         close(host(grads[k]), ref[k], 2e-4, k)
+
+
+# ---------------------------------------------------------------- the plain 9-tap conv on two fp16 planes (iaf_conv_bf3.hpp F16)
+PLAIN = [(32, 160, 160, 16, 16), (32, 160, 448, 16, 16), (32, 192, 160, 16, 16), (64, 160, 384, 8, 8), (5, 160, 320, 30, 30)]
+
+
+def _conv(amd, p, n_in, n_out, precision=None):
+    conv = amd.WNConv2d(n_in, n_out)
+    if precision:
+        conv.set_precision(precision)
+    conv.prepare(dev(p["V"]), dev(p["g"]), dev(p["b"]))
+    return conv
+
+
+def test_a_plain_conv_runs_the_fp16_planes_by_default_where_the_split_kernels_cover_it(amd):
+    rng = np.random.RandomState(2)
+    conv = _conv(amd, gi.conv_params(rng, 160, 160), 160, 160)
+    assert conv.runs_bf16x3(32, 16, 16) and conv.runs_f16x2(32, 16, 16)
+    assert not conv.runs_f16x2(2, 8, 8)                       # below the size rule: the exact-fp32 kernel
+    conv.set_precision("bf16x3")
+    assert conv.runs_bf16x3(32, 16, 16) and not conv.runs_f16x2(32, 16, 16)
+    conv.set_precision("f32")
+    assert not conv.runs_bf16x3(32, 16, 16) and not conv.runs_f16x2(32, 16, 16)
+    odd = _conv(amd, gi.conv_params(rng, 48, 64), 48, 64)     # c_in % 32 != 0: no split pack at all
+    assert not odd.runs_f16x2(32, 16, 16)
+    odd.set_precision("f16x2")                                # (bf16x3 semantics: accepted, nothing to run it on)
+    assert not odd.runs_f16x2(32, 16, 16)
+
+
+@pytest.mark.parametrize("case", PLAIN, ids=lambda s: "B%d_%dto%d_%dx%d" % s)
+def test_plain_conv_error_vs_fp64_is_within_1p5x_of_the_exact_fp32_kernel(amd, case):
+    """the gate of the step kernels, held for the plain convs of IAFLayer.up / .down (tf_train.py:33-36,87-94) too:
+    ELU'd concat input, residual -- max |f16x2 - fp64| <= 1.5 x max |exact fp32 - fp64|"""
+    B, n_in, n_out, H, W = case
+    rng = np.random.RandomState(500 + n_in + n_out + H)
+    p = gi.conv_params(rng, n_in, n_out)
+    x, res = rng.standard_normal((B, n_in, H, W)), rng.standard_normal((B, n_out, H, W))
+    nb = min(B, 4)                                            # the oracle's share of the batch (the first and the last images)
+    sel = np.r_[0:nb // 2, B - (nb - nb // 2):B]
+    e = f32(res[sel]) + 0.1 * O.conv2d(O.elu(f32(x[sel])), f32(p["V"]), f32(p["g"]), f32(p["b"]))
+    errs = {}
+    for prec in ("f32", "bf16x3", "f16x2"):
+        conv = _conv(amd, p, n_in, n_out, prec)
+        assert conv.runs_f16x2(B, H, W) == (prec == "f16x2")
+        y = conv(dev(x), elu_input=True, residual=dev(res))[0]
+        errs[prec] = np.abs(host(y)[sel] - e).max()
+        if prec == "f16x2":
+            assert conv.range_errors() == 0
+    print("%s: max |. - fp64 oracle|: %s" % (case, ", ".join("%s %.3g" % kv for kv in errs.items())))
+    assert errs["f16x2"] <= 1.5 * errs["f32"], errs
+    assert errs["f16x2"] < 2e-5
+
+
+def test_plain_conv_operand_beyond_fp16_is_loud_and_the_conv_goes_back_to_bf16x3(amd):
+    B, n_in, n_out, H = 16, 160, 160, 16
+    rng = np.random.RandomState(61)
+    p = gi.conv_params(rng, n_in, n_out)
+    conv = _conv(amd, p, n_in, n_out, "f16x2")
+    x = 1e5 * rng.standard_normal((B, n_in, H, H))
+    y = conv(dev(x))[0]
+    assert not np.isfinite(host(y)).all()
+    assert conv.range_errors() & 1
+    with pytest.raises(amd._capi.RangeError):
+        conv(dev(x))
+    assert not conv.runs_f16x2(B, H, H) and conv.runs_bf16x3(B, H, H)
+    y = conv(dev(x))[0]                                       # bf16x3 now: fp32's exponent range
+    e = O.conv2d(f32(x[:2]), f32(p["V"]), f32(p["g"]), f32(p["b"]))
+    assert np.abs(host(y)[:2] - e).max() < 1e-5 * np.abs(e).max()
+    conv.set_precision("f16x2")                               # re-armed
+    conv.prepare(dev(p["V"]), dev(p["g"]), dev(p["b"]))
+    assert conv.runs_f16x2(B, H, H) and conv.range_errors() == 0
+    x1 = rng.standard_normal((B, n_in, H, H))
+    y = conv(dev(x1))[0]
+    e = O.conv2d(f32(x1[:2]), f32(p["V"]), f32(p["g"]), f32(p["b"]))
+    assert np.abs(host(y)[:2] - e).max() < 2e-5 and conv.range_errors() == 0
+    # a caller's NaN is data, not a range failure
+    xn = x1.astype(np.float32).copy()
+    xn[3, 5, 7, 7] = np.nan
+    y = host(conv(dev(xn))[0])
+    assert np.isnan(y[3]).any() and np.isfinite(y[:3]).all() and conv.range_errors() == 0
+
+
+def test_plain_conv_weight_beyond_fp16_is_found_by_its_prep(amd):
+    rng = np.random.RandomState(62)
+    p = gi.conv_params(rng, 160, 160)
+    p["g"] = p["g"] + 15.0
+    conv = _conv(amd, p, 160, 160, "f16x2")
+    assert conv.range_errors() & 2
+    x = rng.standard_normal((16, 160, 16, 16))
+    with pytest.raises(amd._capi.RangeError):
+        conv(dev(x))
+    y = conv(dev(x))[0]
+    e = O.conv2d(f32(x[:1]), f32(p["V"]), f32(p["g"]), f32(p["b"]))
+    assert np.abs(host(y)[:1] - e).max() < 1e-5 * np.abs(e).max()

@@ -130,6 +130,49 @@ def test_cvae1_forward_backward_vs_autograd_oracle(amd, golden_dir):
     print("worst relative gradient error %.2e (%s)" % worst)
 
 
+@pytest.mark.parametrize("n_buckets", [2, 3, 8])
+def test_cvae1_gradient_buckets_are_complete_at_their_segment_end_and_equal_one_bucket(amd, n_buckets):
+    """bench.py --train --model runs the backward in 4 gradient buckets and issues each bucket's all-reduce the moment
+    on_bucket(i) fires -- so (a) every variable of bucket i must already hold its FINAL gradient at that moment and (b) the bucketed
+    backward must compute what the single-bucket one does (tf_train.py:128: one compute_gradients).  n_buckets = 2 * layers = 8: one
+    bucket per layer and pass."""
+    import iaf_amd.parallel as par
+    c = gi.model_case_inputs("model_cfg")
+    x = torch.from_numpy(c["x"]).cuda()
+    noise = [dev(e) for e in c["noise"]]
+
+    def run(nb):
+        model = amd.CVAE1(z_size=c["z_size"], h_size=c["h_size"], kl_min=c["kl_min"], depth=c["depth"], num_blocks=c["num_blocks"], k=1,
+                          image_size=c["image_size"])
+        model.set_training(True)
+        host_p = {k: dev(v) for k, v in c["params"].items()}
+        model.load(host_p)
+        flat = par.FlatParams({k: host_p[k] for k in model.completion_order()})
+        model.load(flat.p)
+        names = model.set_grad_buckets(nb)
+        flat.grads.fill_(float("nan"))                          # whatever is read before it is written shows
+        snaps = []
+
+        def on_bucket(i):
+            torch.cuda.synchronize()
+            snaps.append({k: flat.g[k].clone() for k in names[i]})
+        _, obj, _ = model.forward_backward(x, noise, grads=flat.g, on_bucket=on_bucket)
+        torch.cuda.synchronize()
+        assert len(snaps) == len(names)
+        for i, snap in enumerate(snaps):                        # (a) complete when reported
+            for k, v in snap.items():
+                assert torch.isfinite(v).all(), (nb, i, k)
+                assert torch.equal(v, flat.g[k]), (nb, i, k)
+        assert sorted(k for g in names for k in g) == sorted(flat.g)       # every variable in exactly one bucket
+        return {k: flat.g[k].clone() for k in flat.g}, float(obj.item())
+
+    one, obj1 = run(1)
+    many, objn = run(n_buckets)
+    assert obj1 == objn
+    for k in one:                                               # (b) the same numbers (same kernels, same order inside a layer)
+        assert torch.equal(one[k], many[k]), k
+
+
 def test_cvae1_init_pass_vs_the_references_own_init_branches(amd, golden_dir):
     """CVAE1.init_pass: the data-dependent initialisation of every conv of the model (x_enc, plain / strided / masked convs, deconvs,
     x_dec) against the reference's own _forward executed in mode "init" on the TF shim (tests/golden/cvae1_init.npz): all 68 g / b
