@@ -66,6 +66,8 @@ def parse():
                     help="extra mode (not the headline metric): data-parallel TRAINING step of the IAF posterior stack -- "
                          "posterior block forward + backward for every layer, one RCCL all-reduce of the flat gradient "
                          "buffer, fused Adamax + EMA")
+    ap.add_argument("--all-packs", action="store_true",
+                    help="--layers (inference): keep every weight pack of every conv up to date instead of the one its launch reads")
     ap.add_argument("--precision", type=str, default="f16x2", choices=["f16x2", "bf16x3", "f32"],
                     help="arithmetic of the forward masked convs: f16x2 (the engine's default since round 6) = the one-launch step "
                          "kernels of the BASELINE geometries split every fp32 operand into two fp16 planes (hi, lo 2^11) and accumulate "
@@ -667,6 +669,18 @@ def layers_bench(args, depths, dist, rank, n_gpus):
         step()
         step(autotune=True)                       # launch-shape search of the plain convs (cuDNN's algorithm search)
         stream.synchronize()
+        packs_kept = None
+        if not args.all_packs:
+            # inference at one size: every conv / stack keeps only the weight pack its launch reads (IAFLayer.trim_packs: the prep launches
+            # then write 4-6 instead of 14 bytes per weight; a launch that needed another pack would fail loudly, not read stale weights)
+            packs_kept = {}
+            for lvl, lv in enumerate(levels):
+                for L in lv["layers"]:
+                    Hin = 2 * lv["H"] if L["layer"].downsample else lv["H"]
+                    for nm, pk in L["layer"].trim_packs(B, Hin, Hin).items():
+                        packs_kept[pk] = packs_kept.get(pk, 0) + 1
+            step()
+            stream.synchronize()
         if not args.no_graph:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=stream):
@@ -749,6 +763,7 @@ def layers_bench(args, depths, dist, rank, n_gpus):
                    "model_edges": None if edge is None else {"loss": float(edge["loss"].item()), "obj": float(edge["obj"].item()),
                                                              "bits_per_dim": float(edge["loss"].item()) / (np.log(2.) * 3072 * B)},
                    "weights": "re-derived every step (2 batched launches)" if not args.cached_weights else "prepared once",
+                   "weight_packs_kept": packs_kept if packs_kept is not None else "all (--all-packs)",
                    "live_gflop_per_step": total_fl / 1e9,
                    "model_tflops": total_fl / (elapsed / args.steps) / 1e12,
                    "parallelism": "dp%d (batch-sharded replicas, no forward collective)" % n_gpus},

@@ -24,7 +24,7 @@ IAF_COMM_ID_BYTES = 128
 IAF_PACK_F32 = 1
 IAF_PACK_BF16X3 = 2
 IAF_PACK_F16X2 = 4
-IAF_ABI_VERSION = 7                # must equal the library's iaf_abi_version(): a stale libiaf_hip.so is rejected
+IAF_ABI_VERSION = 8                # must equal the library's iaf_abi_version(): a stale libiaf_hip.so is rejected
 IAF_VARIANT_TF = 0
 IAF_VARIANT_THEANO = 1
 IAF_VARIANT_THEANO_FLIPMASK = 2
@@ -173,6 +173,7 @@ SIGNATURES = {
                                                      ctypes.POINTER(ctypes.c_float)]),
     "iaf_conv3x3_set_precision": (ctypes.c_int, [_vp, ctypes.c_int]),
     "iaf_conv3x3_range_errors": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint)]),
+    "iaf_conv3x3_set_packs": (ctypes.c_int, [_vp, ctypes.c_int]),
     "iaf_conv3x3_runs_bf16x3": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "iaf_conv3x3_runs_f16x2": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "iaf_conv3x3_autotune": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, ctypes.POINTER(_vp),

@@ -26,6 +26,7 @@ struct iaf_conv3x3 {
     unsigned* rng_err_host = nullptr;
     unsigned* rng_err_dev = nullptr;
     bool f16_off = false;
+    int packs = IAF_PACK_F32 | IAF_PACK_BF16X3 | IAF_PACK_F16X2;   // iaf_conv3x3_set_packs: which packs the prep launches keep up to date
     int bf3_choice = 1;            // 1 size rule, 2 the shape in L.b_* (pinned by iaf_conv3x3_autotune), 3 fp32 kernel (measured faster)
     GemmLayer T;                   // transposed problem dX = W^T dY (valid when training)
     // deferred weight-norm backward (iaf_conv3x3_wn_bwd_batch_run): the reduced dW / db partials live here, not in the
@@ -57,6 +58,15 @@ static inline bool conv_split(const iaf_conv3x3* c) { return c->precision != IAF
 // the forward launches of this conv run the two-plane fp16 kernels now
 static inline bool conv_f16_active(const iaf_conv3x3* c) {
     return c->precision == IAF_PRECISION_F16X2 && !c->f16_off && c->L.wp2 && !c->generic && !c->mask_mode;
+}
+// which packs a prep launch writes for a plain conv (iaf_conv3x3_set_packs; training keeps all of them)
+static inline void conv_prep_packs(const iaf_conv3x3* c, PrepLayer& P) {
+    const GemmLayer& L = c->L;
+    P.wp = (c->packs & IAF_PACK_F32) ? L.wp : nullptr;
+    P.wp3 = (c->packs & IAF_PACK_BF16X3) ? L.wp3 : nullptr;
+    P.wp2 = ((c->packs & IAF_PACK_F16X2) && conv_f16_active(c)) ? L.wp2 : nullptr;
+    P.rng_err = P.wp2 ? c->rng_err_dev : nullptr;
+    P.wpt = c->training ? L.wpt : nullptr;
 }
 static int conv3x3_create(iaf_conv3x3_t** out, int n_in, int n_out, int mask_mode);
 extern "C" int iaf_conv3x3_create(iaf_conv3x3_t** out, int n_in, int n_out) { return conv3x3_create(out, n_in, n_out, 0); }
@@ -138,14 +148,12 @@ extern "C" int iaf_conv3x3_prepare(iaf_conv3x3_t* c, const float* V, const float
         PrepLayer& P = a.L[0];
         P.V[0] = V; P.g[0] = g; P.b[0] = b; P.wp = L.wp; P.bias = L.bias; P.variant = c->variant; P.border = L.border;
         P.cin = L.cin; P.cout_each = L.cout; P.ncot = L.ncot; P.nchunk = L.nchunk; P.zerodiag = L.zerodiag; P.npair = 1;
-        hipLaunchKernelGGL(iaf_prep_kernel, dim3(L.ncot), dim3(256), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(iaf_prep_kernel, dim3(L.ncot), dim3(256), 0, (hipStream_t)stream, a, 0u);
     } else {
         PrepLayer& P = *c->h_desc;
         memset(&P, 0, sizeof(P));
-        P.V[0] = V; P.g[0] = g; P.b[0] = b; P.wp = L.wp; P.bias = L.bias; P.variant = PREP_PLAIN9;
-        P.wpt = c->training ? L.wpt : nullptr;
-        P.wp3 = L.wp3;
-        P.wp2 = conv_f16_active(c) ? L.wp2 : nullptr; P.rng_err = P.wp2 ? c->rng_err_dev : nullptr;
+        P.V[0] = V; P.g[0] = g; P.b[0] = b; P.bias = L.bias; P.variant = PREP_PLAIN9;
+        conv_prep_packs(c, P);
         P.cin = L.cin; P.cout_each = L.cout; P.ncot = L.ncot; P.nchunk = L.nchunk; P.npair = 1; P.tile_begin = 0;
         HIP_TRY(hipMemcpyAsync(c->d_desc, c->h_desc, sizeof(PrepLayer), hipMemcpyHostToDevice, (hipStream_t)stream));
         hipLaunchKernelGGL(iaf_prep_plain_kernel, dim3(L.ncot), dim3(256), 0, (hipStream_t)stream, c->d_desc, (const int*)nullptr);
@@ -167,6 +175,7 @@ extern "C" int iaf_conv3x3_prepare(iaf_conv3x3_t* c, const float* V, const float
 extern "C" int iaf_conv3x3_prepare_deconv(iaf_conv3x3_t* c, const float* V, const float* g, const float* b, void* stream) {
     if (!c || !V || !g || !b) return IAF_ERR_NULL;
     if (c->mask_mode) return IAF_ERR_UNSUPPORTED;
+    if (c->packs != (IAF_PACK_F32 | IAF_PACK_BF16X3 | IAF_PACK_F16X2)) return IAF_ERR_UNSUPPORTED;    // (the deconv packs derive from the fp32 one)
     GemmLayer& L = c->L;
     hipStream_t st = (hipStream_t)stream;
     float* inv_norm = L.bias + (size_t)L.ncot * 16;    // n_in floats behind the packed bias (conv3x3_create)
@@ -303,8 +312,8 @@ extern "C" int iaf_conv3x3_prep_batch_create(iaf_conv3x3_prep_batch_t** out, iaf
     for (int i = 0; i < n; ++i) {
         const GemmLayer& L = convs[i]->L;
         PrepLayer& P = b->h_layers[i];
-        P.wp = L.wp; P.bias = L.bias; P.variant = PREP_PLAIN9; P.wp3 = L.wp3;
-        P.wp2 = conv_f16_active(convs[i]) ? L.wp2 : nullptr; P.rng_err = P.wp2 ? convs[i]->rng_err_dev : nullptr;
+        P.bias = L.bias; P.variant = PREP_PLAIN9;
+        conv_prep_packs(convs[i], P);
         P.cin = L.cin; P.cout_each = L.cout; P.ncot = L.ncot; P.nchunk = L.nchunk; P.npair = 1; P.tile_begin = tile;
         for (int t = 0; t < L.ncot; ++t) t2l[tile++] = i;
     }
@@ -322,11 +331,12 @@ extern "C" int iaf_conv3x3_prep_batch_run(iaf_conv3x3_prep_batch_t* b, const flo
     for (int i = 0; i < b->n; ++i) {
         if (!V[i] || !g[i] || !bias[i]) return IAF_ERR_NULL;
         PrepLayer& P = b->h_layers[i];
-        float* wpt = b->convs[i]->training ? b->convs[i]->L.wpt : nullptr;
-        void* wp2 = conv_f16_active(b->convs[i]) ? b->convs[i]->L.wp2 : nullptr;      // iaf_conv3x3_set_precision / a range failure since the last run
-        unsigned* rng = wp2 ? b->convs[i]->rng_err_dev : nullptr;
-        changed |= (P.V[0] != V[i]) | (P.g[0] != g[i]) | (P.b[0] != bias[i]) | (P.wpt != wpt) | (P.wp2 != wp2) | (P.rng_err != rng);
-        P.V[0] = V[i]; P.g[0] = g[i]; P.b[0] = bias[i]; P.wpt = wpt; P.wp2 = wp2; P.rng_err = rng;
+        PrepLayer N = P;                             // iaf_conv3x3_set_precision / _set_packs / _set_training / a range failure since the last run
+        conv_prep_packs(b->convs[i], N);
+        changed |= (P.V[0] != V[i]) | (P.g[0] != g[i]) | (P.b[0] != bias[i]) | (P.wpt != N.wpt) | (P.wp2 != N.wp2) | (P.rng_err != N.rng_err) |
+                   (P.wp != N.wp) | (P.wp3 != N.wp3);
+        P = N;
+        P.V[0] = V[i]; P.g[0] = g[i]; P.b[0] = bias[i];
     }
     hipStream_t st = (hipStream_t)stream;
     const void* d_layers = nullptr;     // see iaf_prep_batch_run
@@ -495,7 +505,19 @@ extern "C" int iaf_conv3x3_forward(iaf_conv3x3_t* c, const float* x, const float
     // an F16 launch of this conv (or the prep of its pack) met an operand beyond fp16's range: said once; bf16x3 from here on
     if (c->precision == IAF_PRECISION_F16X2 && !c->f16_off && c->rng_err_host && *(volatile unsigned*)c->rng_err_host) {
         c->f16_off = true;
+        if (!(c->packs & IAF_PACK_BF16X3)) {           // (iaf_conv3x3_set_packs: the bf16x3 pack was not kept up to date -- every pack from the next prepare on)
+            c->packs = IAF_PACK_F32 | IAF_PACK_BF16X3 | IAF_PACK_F16X2;
+            c->prepared = false;
+        }
         return IAF_ERR_RANGE;
+    }
+    if (!c->mask_mode && c->packs != (IAF_PACK_F32 | IAF_PACK_BF16X3 | IAF_PACK_F16X2)) {
+        // iaf_conv3x3_set_packs: the pack this launch reads must be one the prep launches write
+        GemmLayer t = L;
+        const bool split = conv_split(c) && !c->deconv && conv3x3_bf3_shape(t, c->bf3_choice, p.P, W);
+        const bool f16 = split && conv_f16_active(c) && pick_bf3_plain_f16(t.b_nt, t.b_ppw, t.b_pxt, t.b_ks, t.b_wco);
+        const int need = f16 ? IAF_PACK_F16X2 : split ? IAF_PACK_BF16X3 : IAF_PACK_F32;
+        if (!(c->packs & need)) return IAF_ERR_NOT_PREPARED;
     }
     return conv3x3_launch(L, p, c->mask_mode ? EPI_PLAIN5 : EPI_PLAIN, IN_NCHW, c->mask_mode != 0, false, st, c->variant,
                           (conv_split(c) && !c->deconv) ? c->bf3_choice : 3, conv_f16_active(c) ? c->rng_err_dev : nullptr);
@@ -559,6 +581,7 @@ extern "C" int iaf_conv3x3_forward_stride2(iaf_conv3x3_t* c, const float* x, int
     if (tot != c->n_out) return IAF_ERR_SHAPE;
     GemmLayer& L = c->L;
     if (c->generic || c->mask_mode || c->deconv || !L.wp3 || !conv_split(c)) return IAF_ERR_UNSUPPORTED;
+    if (!(c->packs & IAF_PACK_BF16X3)) return IAF_ERR_NOT_PREPARED;     // (iaf_conv3x3_set_packs: the strided form reads the bf16 planes)
     for (int k = 0; k < n_outs; ++k)
         if (ends[k] & 3) return IAF_ERR_UNSUPPORTED;
     int sh[4]; size_t lds = 0;
@@ -636,6 +659,19 @@ extern "C" int iaf_conv3x3_forward_deconv(iaf_conv3x3_t* c, const float* x, cons
 
 // arithmetic of the forward conv: IAF_PRECISION_BF16X3 (default: split products on the bf16 matrix cores where a launch
 // shape covers the problem, fp32-grade) or IAF_PRECISION_F32 (the exact-fp32 MFMA kernel always)
+// which packs the prep launches of a plain conv keep up to date (as iaf_stack_set_packs): a conv that runs at ONE size needs one
+extern "C" int iaf_conv3x3_set_packs(iaf_conv3x3_t* c, int packs) {
+    if (!c) return IAF_ERR_NULL;
+    if (packs & ~(IAF_PACK_F32 | IAF_PACK_BF16X3 | IAF_PACK_F16X2)) return IAF_ERR_SHAPE;
+    if (!packs) return IAF_ERR_SHAPE;
+    const int all = IAF_PACK_F32 | IAF_PACK_BF16X3 | IAF_PACK_F16X2;
+    if (packs != all && (c->generic || c->mask_mode || c->training || c->deconv)) return IAF_ERR_UNSUPPORTED;
+    if ((packs & IAF_PACK_BF16X3) && !(packs & IAF_PACK_F32) && !c->L.wp3) return IAF_ERR_UNSUPPORTED;      // (no split pack for this conv)
+    if ((packs & IAF_PACK_F16X2) && !(packs & (IAF_PACK_F32 | IAF_PACK_BF16X3)) && !conv_f16_active(c)) return IAF_ERR_UNSUPPORTED;
+    if (packs & ~c->packs) c->prepared = false;              // a pack that was not kept up to date comes back: the next prepare fills it
+    c->packs = packs;
+    return IAF_OK;
+}
 extern "C" int iaf_conv3x3_set_precision(iaf_conv3x3_t* c, int precision) {
     if (!c) return IAF_ERR_NULL;
     if (precision != IAF_PRECISION_F32 && precision != IAF_PRECISION_BF16X3 && precision != IAF_PRECISION_F16X2) return IAF_ERR_SHAPE;
@@ -823,6 +859,7 @@ extern "C" int iaf_conv3x3_set_training(iaf_conv3x3_t* c, int on) {
     T.wp = L.wpt; T.wp3 = L.wpt3; T.nt = 1; T.pxt = 4; T.wco = 1; T.ks = 1; T.user_tuned = false;
     T.dbg = L.dbg; T.dbg_bytes = L.dbg_bytes;
     c->training = true;
+    c->packs = IAF_PACK_F32 | IAF_PACK_BF16X3 | IAF_PACK_F16X2;     // (training keeps every pack)
     c->prepared = false;      // the transposed pack is written by the next prepare
     return IAF_OK;
 }

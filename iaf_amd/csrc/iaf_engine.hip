@@ -50,7 +50,7 @@
 
 #include "iaf_conv_kernel.hpp"
 
-#define IAF_ABI_VERSION 7   // 7: IAF_PRECISION_F16X2 / IAF_PACK_F16X2 / IAF_ERR_RANGE / iaf_stack_range_errors (the two-plane fp16 step kernels); 6: iaf_stack_step_pairs, iaf_conv3x3_set_debug(conv, buf, bytes), generic backward behind the training entry points; 5: per-stream halo-exchange sets, IAF_ERR_EXCHANGE, iaf_stack_set_halo_exchange_debug; 4: stack-owned halo-exchange buffers (iaf_stack_set_halo_exchange / _exchange_errors / _step_exchanges): a stack's
+#define IAF_ABI_VERSION 8   // 8: the plain convs on two fp16 planes (iaf_conv3x3_range_errors, iaf_conv3x3_runs_f16x2); 7: IAF_PRECISION_F16X2 / IAF_PACK_F16X2 / IAF_ERR_RANGE / iaf_stack_range_errors (the two-plane fp16 step kernels); 6: iaf_stack_step_pairs, iaf_conv3x3_set_debug(conv, buf, bytes), generic backward behind the training entry points; 5: per-stream halo-exchange sets, IAF_ERR_EXCHANGE, iaf_stack_set_halo_exchange_debug; 4: stack-owned halo-exchange buffers (iaf_stack_set_halo_exchange / _exchange_errors / _step_exchanges): a stack's
                           //    one-launch steps must not overlap on different streams; 2: + iaf_conv3x3_*; 3: bf16x3 default precision, THEANO_FLIPMASK, negative nt in autotune reports,
                           //    iaf_stack_set_packs, iaf_comm_* (include/iaf_hip.h)
 #define MAX_GEMM_LAYERS 10   // depth_ar <= 9 hidden + 1 output pair
@@ -708,6 +708,26 @@ struct PackT3Batch {
     }
 };
 
+// dynamic LDS of a masked-stack prep launch (prep_tile_fast, iaf_kernels_prep.hpp): the largest tile [5 taps x c_in rows + 1 pad row per 8][16]
+// among the TF-statement layers that keep split packs only; 0 = no such layer (IAF_PREP_DBG bit 1: never).  Up to 160 KiB are allowed once.
+static unsigned prep_fast_floats(const PrepLayer* P, int n) {
+    static const bool off = getenv("IAF_PREP_DBG") && (atoi(getenv("IAF_PREP_DBG")) & 2);
+    if (off) return 0;
+    unsigned m = 0;
+    for (int i = 0; i < n; ++i) {
+        const bool tf = P[i].variant == IAF_VARIANT_TF, split_only = (P[i].wp3 || P[i].wp2) && !P[i].wp && !P[i].wpt;
+        const unsigned f = (unsigned)NTAPS * (unsigned)P[i].cin * 18u;
+        if (tf && split_only && P[i].nchunk % 2 == 0 && f * 4u <= 96u * 1024u && f > m) m = f;
+    }
+    static bool once = false;
+    if (m && !once) {
+        if (hipFuncSetAttribute((const void*)iaf_prep_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)iaf_prep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) { (void)hipGetLastError(); return 0; }
+        once = true;
+    }
+    return m;
+}
+
 extern "C" int iaf_stack_prepare(iaf_stack_t* s, const float* const* V, const float* const* g, const float* const* b,
                                  void* stream) {
     if (!s || !V || !g || !b) return IAF_ERR_NULL;
@@ -748,7 +768,8 @@ extern "C" int iaf_stack_prepare(iaf_stack_t* s, const float* const* V, const fl
         P.zerodiag = L.zerodiag; P.npair = L.npair; P.tile_begin = tiles;
         tiles += L.ncot;
     }
-    hipLaunchKernelGGL(iaf_prep_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, a);
+    const unsigned ff = prep_fast_floats(a.L, a.nlayers);
+    hipLaunchKernelGGL(iaf_prep_kernel, dim3(tiles), dim3(256), (size_t)ff * 4, (hipStream_t)stream, a, ff);
     HIP_TRY(hipGetLastError());
     if (s->training) {
         PackT3Batch tb((hipStream_t)stream);
@@ -851,7 +872,13 @@ extern "C" int iaf_prep_batch_run(iaf_prep_batch_t* b, const float* const* V, co
     // the descriptor table only travels when a pointer in it changed (a training loop passes the same buffers every step)
     const void* d_layers = nullptr;
     { int rc = desc_upload(&b->tab, b->h_layers, changed, st, &d_layers); if (rc) return rc; }
-    hipLaunchKernelGGL(iaf_prep_batch_kernel, dim3(b->ntiles), dim3(256), 0, st, (const PrepLayer*)d_layers, b->d_tile2layer);
+    // (IAF_PREP_DBG, dev knob: bit 0 = tiles in blockIdx order instead of paired per XCD, bit 1 = round 5's tile function; same box, 20 stacks,
+    //  fp16 packs: 13.4 us with both bits, 12.1 us with neither -- gpurun_out/r06/prep_time_ab.txt)
+    static const int prep_dbg = getenv("IAF_PREP_DBG") ? atoi(getenv("IAF_PREP_DBG")) : 0;
+    const int xcdpair = (prep_dbg & 1) ? 0 : 1;
+    const unsigned ff = prep_fast_floats(b->h_layers, b->nlayers_total);
+    hipLaunchKernelGGL(iaf_prep_batch_kernel, dim3(xcdpair ? (b->ntiles + 15) / 16 * 16 : b->ntiles), dim3(256), (size_t)ff * 4, st, (const PrepLayer*)d_layers,
+                       b->d_tile2layer, b->ntiles, xcdpair, ff);
     HIP_TRY(hipGetLastError());
     {
         PackT3Batch tb(st);

@@ -160,8 +160,90 @@ __device__ __forceinline__ void prep_f16_store(const PrepLayer& L, int gt, const
     if (big > 65504.0f && L.rng_err) __hip_atomic_fetch_or(L.rng_err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// Round 6 (the batched prep at 15.5 us against a ~5 us HBM floor).  A TF-statement layer that keeps ONLY split packs
+// (bf16x3 and / or two-plane fp16: every stack of the headline run) and whose tile fits the launch's dynamic LDS: the 16 output channels of
+// a tile are 64 contiguous bytes of every V row [kh][kw][c_in][n_out] -- four lanes x 16 bytes -- so a wave instruction fetches 16 whole
+// rows (1 KiB, against 4 x 64 B of 4-byte items in the fragment's own thread mapping: 15 loads per thread at n_in = 160 instead of 56),
+// the tile goes through LDS once, unscaled, [row = tap n_in + c_in][16 o] with one pad row per 8 (the fragment's lanes (kk, oo) then read
+// 8 rows 16-byte-strided from four different bank groups: conflict-free), and the sum of squares is taken on the way (wave shuffles +
+// 4 x 16 partials).  The fragment registers come back in prep_bf3_load's mapping, so the split + store code is the same.
+template <int NCH>
+__device__ __forceinline__ void prep_tile_fast(const PrepLayer& L, int gt, float (*red)[17], float* s_scale, float* tile) {
+    typedef float pf32x4 __attribute__((ext_vector_type(4)));
+    constexpr int NIN = 16 * NCH, NP = (NIN + 63) / 64;
+    const int which = (L.npair == 2) ? (gt & 1) : 0;
+    const int src_tile = (L.npair == 2) ? (gt >> 1) : gt;
+    const float* __restrict__ V = PREP_PICK(L.V, which);
+    const int tid = threadIdx.x, c4 = tid & 3, r = tid >> 2;
+    const int n_out = L.cout_each, n_in = L.cin;
+    const int o4 = src_tile * 16 + 4 * c4;
+    pf32x4 v[NTAPS][NP];
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int ci = r + 64 * j;
+            const int cic = (NIN % 64 == 0 || ci < NIN) ? ci : 0;
+            v[t][j] = *(const pf32x4*)(V + ((size_t)(tap_kh<NTAPS>(t) * 3 + tap_kw<NTAPS>(t)) * n_in + cic) * n_out + o4);
+        }
+    float ss[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int ci = r + 64 * j;
+            if (NIN % 64 != 0 && ci >= NIN) continue;
+            pf32x4 x = v[t][j];
+            if (t == 0) {                                           // centre tap: channel MADE mask (layers.py:57)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (!made_live(ci, o4 + e, n_in, n_out, L.zerodiag)) x[e] = 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ss[e] += x[e] * x[e];
+            const int row = t * NIN + ci;
+            *(pf32x4*)(tile + (size_t)(row + (row >> 3)) * 16 + 4 * c4) = x;
+        }
+    // lanes of a wave with the same c4 (lane bits 2..5) hold partial sums of the same four output channels
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float a = ss[e];
+        a += __shfl_xor(a, 4); a += __shfl_xor(a, 8); a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
+        ss[e] = a;
+    }
+    if ((tid & 63) < 4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[tid >> 6][4 * c4 + e] = ss[e];
+    }
+    __syncthreads();
+    if (tid < 16) {
+        const int o = src_tile * 16 + tid;
+        const float tot = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+        s_scale[tid] = expf(PREP_PICK(L.g, which)[o]) / sqrtf(fmaxf(tot, 1e-12f));      // w = exp(g) * v / sqrt(max(sum v^2, 1e-12))
+        L.bias[gt * 16 + tid] = PREP_PICK(L.b, which)[o];
+    }
+    float w3[PREP_BF3_UPQ(NCH)][8];
+    {
+        const int lane = tid & 63, quarter = tid >> 6, oo = lane & 15, kk = lane >> 4;
+        constexpr int NUNIT = (NCH / 2) * NTAPS;
+#pragma unroll
+        for (int i = 0; i < PREP_BF3_UPQ(NCH); ++i) {
+            const int uu = quarter + 4 * i;
+            const int u = uu < NUNIT ? uu : NUNIT - 1;              // (the surplus slot: read, never stored)
+            const int pair = u / NTAPS, t = u - pair * NTAPS;
+            const int row0 = t * NIN + pair * 32 + 8 * kk;          // a multiple of 8: its 8 rows share one pad offset
+            const float* src = tile + (size_t)(row0 + (row0 >> 3)) * 16 + oo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) w3[i][e] = src[16 * e];
+        }
+    }
+    __syncthreads();
+    if (L.wp3) prep_bf3_store<NCH, NTAPS>(L, gt, w3, s_scale);
+    if (L.wp2) prep_f16_store<NCH, NTAPS>(L, gt, w3, s_scale);
+}
+
 template <int NCH, int NTP = NTAPS>
-__device__ __forceinline__ void prep_tile(const PrepLayer& L, int gt, float (*red)[17], float* s_scale) {
+__device__ __forceinline__ void prep_tile(const PrepLayer& L, int gt, float (*red)[17], float* s_scale, float* fast_tile = nullptr) {
     const int which = (L.npair == 2) ? (gt & 1) : 0;     // output pair: even tiles = mean, odd = logsd
     const int src_tile = (L.npair == 2) ? (gt >> 1) : gt;
     const float* __restrict__ V = PREP_PICK(L.V, which);
@@ -171,6 +253,10 @@ __device__ __forceinline__ void prep_tile(const PrepLayer& L, int gt, float (*re
     const float gval = PREP_PICK(L.g, which)[o], bval = PREP_PICK(L.b, which)[o];
 
     constexpr bool BF3 = (NCH % 2 == 0);
+    if constexpr (BF3 && NTP == NTAPS) {
+        // split packs only, TF statement, the tile fits the launch's LDS: whole-row loads through LDS (prep_tile_fast)
+        if (fast_tile && (L.wp3 || L.wp2) && !L.wp && !L.wpt) { prep_tile_fast<NCH>(L, gt, red, s_scale, fast_tile); return; }
+    }
     float w3[BF3 ? PREP_BF3_UPQ_T(NCH, NTP) : 1][8];
     if constexpr (BF3) { if (L.wp3 || L.wp2) prep_bf3_load<NCH, NTP>(L, gt, w3); }
     // pass 1: fetch + mask (layers.py:57), sum of squares over (taps, c_in) (layers.py:60).  A thread owns QUADS of four
@@ -376,8 +462,11 @@ __device__ __forceinline__ void prep_tile_theano(const PrepLayer& L, int gt, flo
 
 #define PREP_MAXI 16   // n_in <= 256
 #define PREP_PLAIN9 100   // PrepLayer.variant of a plain (unmasked, 9-tap) TF conv2d
+// fast_tile / fast_floats: the launch's dynamic LDS (prep_tile_fast) and its size in floats (0: none)
 template <int DUMMY = 0>
-__device__ __forceinline__ void prep_dispatch(const PrepLayer& L, int gt, float (*red)[17], float* s_scale) {
+__device__ __forceinline__ void prep_dispatch(const PrepLayer& L, int gt, float (*red)[17], float* s_scale, float* fast_tile = nullptr,
+                                              unsigned fast_floats = 0) {
+    if ((size_t)NTAPS * L.cin * 18 > fast_floats) fast_tile = nullptr;
     if (L.variant == IAF_VARIANT_THEANO || L.variant == IAF_VARIANT_THEANO_FLIPMASK) {
         switch (L.nchunk) {
             case 1: prep_tile_theano<1>(L, gt, red, s_scale); break;
@@ -400,32 +489,44 @@ __device__ __forceinline__ void prep_dispatch(const PrepLayer& L, int gt, float 
         return;
     }
     switch (L.nchunk) {
-        case 1: prep_tile<1>(L, gt, red, s_scale); break;
-        case 2: prep_tile<2>(L, gt, red, s_scale); break;
-        case 3: prep_tile<3>(L, gt, red, s_scale); break;
-        case 4: prep_tile<4>(L, gt, red, s_scale); break;
-        case 5: prep_tile<5>(L, gt, red, s_scale); break;
-        case 6: prep_tile<6>(L, gt, red, s_scale); break;
-        case 7: prep_tile<7>(L, gt, red, s_scale); break;
-        case 8: prep_tile<8>(L, gt, red, s_scale); break;
-        case 9: prep_tile<9>(L, gt, red, s_scale); break;
-        case 10: prep_tile<10>(L, gt, red, s_scale); break;
-        case 11: prep_tile<11>(L, gt, red, s_scale); break;
-        case 12: prep_tile<12>(L, gt, red, s_scale); break;
-        case 13: prep_tile<13>(L, gt, red, s_scale); break;
-        case 14: prep_tile<14>(L, gt, red, s_scale); break;
-        case 15: prep_tile<15>(L, gt, red, s_scale); break;
-        case 16: prep_tile<16>(L, gt, red, s_scale); break;
+        case 1: prep_tile<1>(L, gt, red, s_scale, fast_tile); break;
+        case 2: prep_tile<2>(L, gt, red, s_scale, fast_tile); break;
+        case 3: prep_tile<3>(L, gt, red, s_scale, fast_tile); break;
+        case 4: prep_tile<4>(L, gt, red, s_scale, fast_tile); break;
+        case 5: prep_tile<5>(L, gt, red, s_scale, fast_tile); break;
+        case 6: prep_tile<6>(L, gt, red, s_scale, fast_tile); break;
+        case 7: prep_tile<7>(L, gt, red, s_scale, fast_tile); break;
+        case 8: prep_tile<8>(L, gt, red, s_scale, fast_tile); break;
+        case 9: prep_tile<9>(L, gt, red, s_scale, fast_tile); break;
+        case 10: prep_tile<10>(L, gt, red, s_scale, fast_tile); break;
+        case 11: prep_tile<11>(L, gt, red, s_scale, fast_tile); break;
+        case 12: prep_tile<12>(L, gt, red, s_scale, fast_tile); break;
+        case 13: prep_tile<13>(L, gt, red, s_scale, fast_tile); break;
+        case 14: prep_tile<14>(L, gt, red, s_scale, fast_tile); break;
+        case 15: prep_tile<15>(L, gt, red, s_scale, fast_tile); break;
+        case 16: prep_tile<16>(L, gt, red, s_scale, fast_tile); break;
     }
 }
 
 // many stacks in one launch: descriptors live in device memory; tile2layer maps a workgroup to its GEMM layer
+// xcdpair != 0 (grid padded to a multiple of 16): tiles 2 m and 2 m + 1 -- the two 64-byte halves of the 128-byte lines of V rows
+// [c_in][n_out] -- go to workgroups blockIdx and blockIdx + 8, which the dispatcher places on ONE XCD (round robin over 8): the line is
+// fetched into one L2 once instead of into two
+__device__ __forceinline__ int prep_virtual_tile(int xcdpair) {
+    const int b = blockIdx.x;
+    if (!xcdpair) return b;
+    const int xcd = b & 7, slot = b >> 3;
+    return ((((slot >> 1) << 3) + xcd) << 1) + (slot & 1);
+}
 __global__ __launch_bounds__(256) void iaf_prep_batch_kernel(const PrepLayer* __restrict__ layers,
-                                                            const int* __restrict__ tile2layer) {
+                                                            const int* __restrict__ tile2layer, int ntiles, int xcdpair, unsigned fast_floats) {
     __shared__ float red[16][17];
     __shared__ float s_scale[16];
-    const PrepLayer& L = layers[__builtin_amdgcn_readfirstlane(tile2layer[blockIdx.x])];
-    prep_dispatch(L, blockIdx.x - L.tile_begin, red, s_scale);
+    extern __shared__ __attribute__((aligned(16))) float prep_dyn_lds[];
+    const int v = prep_virtual_tile(xcdpair);
+    if (v >= ntiles) return;
+    const PrepLayer& L = layers[__builtin_amdgcn_readfirstlane(tile2layer[v])];
+    prep_dispatch(L, v - L.tile_begin, red, s_scale, prep_dyn_lds, fast_floats);
 }
 
 // plain (unmasked, 9-tap) convs: their own kernel so that the 9-tap register footprint does not tax the masked prep.
@@ -456,14 +557,15 @@ __global__ __launch_bounds__(256) void iaf_prep_plain_kernel(const PrepLayer* __
     }
 }
 
-__global__ __launch_bounds__(256) void iaf_prep_kernel(PrepArgs a) {
+__global__ __launch_bounds__(256) void iaf_prep_kernel(PrepArgs a, unsigned fast_floats) {
     __shared__ float red[16][17];
     __shared__ float s_scale[16];
+    extern __shared__ __attribute__((aligned(16))) float prep_dyn_lds[];
     PrepLayer L = a.L[0];          // (selected with uniform compares: indexing the by-value block at run time copies it to scratch)
 #pragma unroll
     for (int i = 1; i < MAX_GEMM_LAYERS; ++i)
         if (i < a.nlayers && (int)blockIdx.x >= a.L[i].tile_begin) L = a.L[i];
-    prep_dispatch(L, blockIdx.x - L.tile_begin, red, s_scale);
+    prep_dispatch(L, blockIdx.x - L.tile_begin, red, s_scale, prep_dyn_lds, fast_floats);
 }
 
 // ---------------------------------------------------------------------------------------------

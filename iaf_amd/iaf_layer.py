@@ -92,6 +92,24 @@ class IAFLayer(object):
     def convs(self):
         return [getattr(self, nm) for nm in self.CONVS]
 
+    def trim_packs(self, B, H, W):
+        """inference at ONE size ((B, H, W) = this layer's input; a downsampling layer's convs at H/2 x W/2): every plain conv keeps only the
+        weight pack its launch reads (WNConv2d.trim_packs: 4-6 instead of 14 bytes written per weight by every prep launch) and the stack
+        only split packs.  Not for training layers (they keep every pack); returns {conv name: pack}."""
+        h, w = (H // 2, W // 2) if self.downsample else (H, W)
+        kept = {"up_conv1": self.up_conv1.trim_packs(B, H, W, strided=self.downsample),
+                "up_conv3": self.up_conv3.trim_packs(B, h, w), "down_conv1": self.down_conv1.trim_packs(B, h, w)}
+        if not self.downsample:                     # (the deconv's packs derive from its fp32 pack: all kept)
+            kept["down_conv2"] = self.down_conv2.trim_packs(B, h, w)
+        st = self.posterior.stack
+        if st.step_is_f16(B, h, w):                 # the one-launch step on two fp16 planes reads nothing else
+            st.set_packs(f32=False, bf16x3=False, f16x2=True)
+            kept["ar_multiconv2d"] = "f16x2"
+        elif st.step_is_fused(B, h, w):
+            st.set_packs(f32=False, bf16x3=True, f16x2=False)
+            kept["ar_multiconv2d"] = "bf16x3"
+        return kept
+
     @staticmethod
     def conv_params(params):
         """the (V, g, b) tuples of one layer's plain convs in `convs()` order (for ConvPrepBatch.run)"""

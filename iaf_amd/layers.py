@@ -669,6 +669,25 @@ class WNConv2d(object):
     def runs_f16x2(self, B, H, W):
         return bool(_capi.lib().iaf_conv3x3_runs_f16x2(self._h, int(B), int(H), int(W)))
 
+    def set_packs(self, f32=True, bf16x3=True, f16x2=True):
+        """which weight packs the prep launches of this plain conv keep up to date (iaf_conv3x3_set_packs; default: all three, 14 bytes
+        written per weight).  A launch whose pack is not kept raises IafHipError (IAF_ERR_NOT_PREPARED); training convs keep every pack."""
+        _capi.check(_capi.lib().iaf_conv3x3_set_packs(self._h, (_capi.IAF_PACK_F32 if f32 else 0) | (_capi.IAF_PACK_BF16X3 if bf16x3 else 0) |
+                                                      (_capi.IAF_PACK_F16X2 if f16x2 else 0)))
+        self._prep_key = None
+
+    def trim_packs(self, B, H, W, strided=False):
+        """keep only the pack the forward launch at this size reads: the two-plane fp16 one, else the bf16x3 one (also what the stride-2
+        form reads: strided=True), else the fp32 one.  Call it again after autotune / set_precision / set_tuning; returns the pack kept."""
+        if strided or (self.runs_bf16x3(B, H, W) and not self.runs_f16x2(B, H, W)):
+            self.set_packs(f32=False, bf16x3=True, f16x2=False)
+            return "bf16x3"
+        if self.runs_f16x2(B, H, W):
+            self.set_packs(f32=False, bf16x3=False, f16x2=True)
+            return "f16x2"
+        self.set_packs(f32=True, bf16x3=False, f16x2=False)
+        return "f32"
+
     # -- training --------------------------------------------------------------------------------
     _shared_ws = {}     # device -> one scratch buffer shared by all plain convs (they run one after another)
 

@@ -54,6 +54,19 @@ class CVAE1(object):
                 layer.load(self._lparams[(i, j)])
         self.params = params
 
+    def trim_packs(self, B):
+        """inference with batch B: every plain conv of every layer keeps only the weight pack its launch reads (IAFLayer.trim_packs); the
+        prep launches of prepare_weights() then write 4-6 instead of 14 bytes per weight.  After load(); not for training."""
+        kept = {}
+        for i, level in enumerate(self.layers):
+            for j, layer in enumerate(level):
+                # input resolution of layer (i, j): level i runs at image_size / 2^(i+1); its first layer (downsample) is fed the finer level
+                H = self.image_size // (2 ** (i + 1))
+                Hin = 2 * H if layer.downsample else H
+                kept[(i, j)] = layer.trim_packs(B, Hin, Hin)
+        self.prepare_weights()
+        return kept
+
     def prepare_weights(self):
         """Re-derive every weight norm from the loaded variables (what the reference's graph does inside every step, layers.py:56-60) in
         batched launches: all masked stacks in one, all plain convs in one, a downsampling layer's deconv and the two ends on their own.

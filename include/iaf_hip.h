@@ -520,6 +520,13 @@ int iaf_conv3x3_set_precision(iaf_conv3x3_t* c, int precision);
  * The same range protocol: an operand beyond 65504 -> inf / NaN outputs, the NEXT iaf_conv3x3_forward returns IAF_ERR_RANGE once and the
  * conv runs bf16x3 from then on; *errors = its range word (synchronises). */
 int iaf_conv3x3_range_errors(const iaf_conv3x3_t* c, unsigned* errors);
+/* Which packs the prep launches of a PLAIN conv keep up to date (IAF_PACK_* as iaf_stack_set_packs; default: all three, 14 bytes written
+ * per weight).  A conv of a model runs at one size, i.e. reads one pack: the two-plane fp16 one (iaf_conv3x3_runs_f16x2), else the
+ * bf16x3 one (iaf_conv3x3_runs_bf16x3; also what iaf_conv3x3_forward_stride2 reads), else the fp32 one.  A forward launch whose pack is
+ * not kept returns IAF_ERR_NOT_PREPARED; after a range failure of an fp16-only conv every pack is kept again from the next prepare on
+ * (IAF_ERR_RANGE once, then IAF_ERR_NOT_PREPARED until that prepare).  Training convs, masked convs, deconvs (iaf_conv3x3_prepare_deconv)
+ * and generic channel counts keep every pack: IAF_ERR_UNSUPPORTED for anything else. */
+int iaf_conv3x3_set_packs(iaf_conv3x3_t* c, int packs);
 int iaf_conv3x3_runs_bf16x3(iaf_conv3x3_t* c, int B, int H, int W);
 /* 1 if that launch would be the two-plane fp16 one */
 int iaf_conv3x3_runs_f16x2(iaf_conv3x3_t* c, int B, int H, int W);

@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol(capi):
 
 def test_abi_version_and_error_strings(capi):
     lib = capi.lib()
-    assert lib.iaf_abi_version() == 7 == capi.IAF_ABI_VERSION
+    assert lib.iaf_abi_version() == 8 == capi.IAF_ABI_VERSION
     assert b"halo exchange" in lib.iaf_error_string(capi.IAF_ERR_EXCHANGE)
     with pytest.raises(capi.ExchangeError):
         capi.check(capi.IAF_ERR_EXCHANGE)

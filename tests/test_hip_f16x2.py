@@ -378,3 +378,103 @@ def test_plain_conv_weight_beyond_fp16_is_found_by_its_prep(amd):
     y = conv(dev(x))[0]
     e = O.conv2d(f32(x[:1]), f32(p["V"]), f32(p["g"]), f32(p["b"]))
     assert np.abs(host(y)[:1] - e).max() < 1e-5 * np.abs(e).max()
+
+
+# ---------------------------------------------------------------- one pack per conv (iaf_conv3x3_set_packs) and the whole-row prep of split-pack-only stacks
+def test_plain_conv_keeps_only_the_pack_its_launch_reads(amd):
+    """WNConv2d.trim_packs: 4 (fp16 planes) / 6 (bf16 planes) / 4 (fp32) instead of 14 bytes written per weight by every prep launch; same
+    results; a launch that needs a pack that is not kept fails loudly (IAF_ERR_NOT_PREPARED) instead of reading stale weights"""
+    rng = np.random.RandomState(71)
+    n_in, n_out = 160, 160
+    p = gi.conv_params(rng, n_in, n_out)
+    x_big, x_small = rng.standard_normal((32, n_in, 16, 16)), rng.standard_normal((2, n_in, 8, 8))
+    full = _conv(amd, p, n_in, n_out)
+    want_big, want_small = full(dev(x_big))[0], full(dev(x_small))[0]
+    dp = [dev(p[k]) for k in ("V", "g", "b")]
+    for (B, H), kept, other in (((32, 16), "f16x2", x_small), ((2, 8), "f32", x_big)):
+        conv = _conv(amd, p, n_in, n_out)
+        assert conv.trim_packs(B, H, H) == kept
+        # new weights: only the kept pack follows them
+        p2 = gi.conv_params(rng, n_in, n_out)
+        conv.prepare(*[dev(p2[k]) for k in ("V", "g", "b")])
+        conv.prepare(*dp)
+        x = x_big if kept == "f16x2" else x_small
+        got, want = conv(dev(x))[0], want_big if kept == "f16x2" else want_small
+        # (equal up to the last bit of the weight norm: a prep launch that writes only split packs sums the squares in another order)
+        assert (got - want).abs().max().item() < 4e-6 * max(1.0, float(want.abs().max()))
+        with pytest.raises(amd._capi.IafHipError):            # the other size reads another pack: not kept
+            conv(dev(other))
+        conv.set_packs()                                      # every pack again: the next prepare fills them
+        with pytest.raises(amd._capi.IafHipError):
+            conv(dev(other))
+        conv.prepare(*dp, force=True)
+        want = want_small if kept == "f16x2" else want_big
+        assert (conv(dev(other))[0] - want).abs().max().item() < 4e-6 * max(1.0, float(want.abs().max()))
+    bf = _conv(amd, p, n_in, n_out, "bf16x3")
+    assert bf.trim_packs(32, 16, 16) == "bf16x3" and bf.trim_packs(32, 16, 16, strided=True) == "bf16x3"
+    bf.prepare(*dp, force=True)
+    assert (bf(dev(x_big))[0] - want_big).abs().max().item() < 2e-5
+    tr = _conv(amd, p, n_in, n_out)
+    tr.set_training(True)
+    with pytest.raises(amd.UnsupportedError):
+        tr.set_packs(f32=False)
+
+
+def test_fp16_only_plain_conv_after_a_range_failure_asks_for_a_prepare(amd):
+    rng = np.random.RandomState(72)
+    p = gi.conv_params(rng, 160, 160)
+    dp = [dev(p[k]) for k in ("V", "g", "b")]
+    conv = _conv(amd, p, 160, 160)
+    assert conv.trim_packs(32, 16, 16) == "f16x2"
+    conv.prepare(*dp, force=True)
+    x = rng.standard_normal((32, 160, 16, 16))
+    conv(dev(1e6 * x))
+    torch.cuda.synchronize()
+    with pytest.raises(amd._capi.RangeError):
+        conv(dev(x))
+    with pytest.raises(amd._capi.IafHipError):                # IAF_ERR_NOT_PREPARED: its bf16x3 pack was never written
+        conv(dev(x))
+    conv.prepare(*dp, force=True)
+    y = conv(dev(x))[0]
+    e = O.conv2d(f32(x[:2]), f32(p["V"]), f32(p["g"]), f32(p["b"]))
+    assert np.abs(host(y)[:2] - e).max() < 2e-5 and not conv.runs_f16x2(32, 16, 16)
+
+
+@pytest.mark.parametrize("geom", [(32, 160, 2), (32, 64, 1), (64, 64, 4), (64, 128, 4), (64, 192, 4), (32, 128, 2), (32, 160, 3)],
+                         ids=lambda g: "nz%d_nh%d_d%d" % g)
+@pytest.mark.parametrize("packs", ["bf16x3", "f16x2"])
+def test_split_packs_only_stacks_prep_through_whole_rows_equals_the_default_prep(amd, geom, packs):
+    """a stack that keeps only split packs re-derives them in prep_tile_fast (iaf_kernels_prep.hpp: 16-byte row loads, tile through LDS, tiles
+    paired per XCD): the same weights as the default prep up to the order of the l2 norm's sum -- every n_in of the compiled geometries, through
+    the batched launch (odd tile counts: the padded grid) and the per-stack one"""
+    n_z, n_h, d = geom
+    B = 4
+    rng = np.random.RandomState(400 + n_h + d)
+    params = gi.ar_multiconv2d_params(rng, n_z, [n_h] * d, [n_z, n_z])
+    dp = {k: dev(v) for k, v in params.items()}
+    ref = amd.ARStack(n_z, [n_h] * d)
+    ref.set_precision(packs)
+    ref.prepare(dp)
+    H = 8
+    if packs == "f16x2":                                      # a size whose step runs on the fp16 planes (the only pack kept)
+        sizes = [h for h in (16, 8, 4) if ref.step_is_f16(B, h, h)]
+        if not sizes:
+            pytest.skip("no two-plane fp16 step kernel for this geometry")
+        H = sizes[0]
+    z, ctx = dev(rng.standard_normal((B, n_z, H, H))), dev(rng.standard_normal((B, n_h, H, H)))
+    only = [amd.ARStack(n_z, [n_h] * d) for _ in range(3)]
+    for st in only:
+        st.set_precision(packs)
+        st.prepare(dp)
+        try:
+            st.set_packs(f32=False, bf16x3=packs == "bf16x3", f16x2=packs == "f16x2")
+        except (amd.UnsupportedError, ValueError) as e:       # (no step kernel of this arithmetic for the geometry: nothing to compare)
+            pytest.skip(str(e))
+    only[0].prepare(dp, force=True)
+    amd.PrepBatch(only[1:]).run([dp, dp])
+    wm, ws = ref.ar_multiconv2d(z, ctx)
+    scale = max(1.0, float(wm.abs().max()), float(ws.abs().max()))
+    for st in only:
+        m, s = st.ar_multiconv2d(z, ctx)
+        assert (m - wm).abs().max().item() < 4e-6 * scale and (s - ws).abs().max().item() < 4e-6 * scale
+        assert st.range_errors() == 0

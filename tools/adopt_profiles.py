@@ -17,7 +17,7 @@ for dp, dn, fn in os.walk(src):
     os.makedirs(os.path.join(dst, rel), exist_ok=True)
     for f in fn:
         shutil.copy2(os.path.join(dp, f), os.path.join(dst, rel, f))
-for f in ("rocprof_dominant_kernel.json", "pmc_dominant_kernel.json"):
+for f in ("rocprof_dominant_kernel.json", "pmc_dominant_kernel.json", "train_kernels_model.json", "train_kernels_layers.json"):
     if os.path.exists(os.path.join(dst, f)):
         shutil.copy2(os.path.join(dst, f), os.path.join(ROOT, "profiles", f))
         print("profiles/%s <- profiles/%s/%s" % (f, rnd, f))

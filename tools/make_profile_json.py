@@ -13,6 +13,7 @@ import os
 import sys
 
 d, rnd = sys.argv[1], sys.argv[2]
+prec = os.environ.get("PMC_PREC", "f16x2")
 KERNEL = "iaf_step_fused_kernel<10, 2, 2, 16, 2, 0"       # (TF statement; the halo-exchange form carries one more template argument)
 
 
@@ -46,7 +47,7 @@ if acc:
     pj = {"kernel": "iaf_step_fused_kernel<NHT=10,NZT=2,DEPTH=2,W=16,R=2,VAR=0 (TF statement),XCH=1 (halo rows exchanged)> (one IAF step: masked convs "
                     "32->160->160->64 + affine/log-det, B=32, 16x16)",
           "command": "rocprofv3 --kernel-trace --pmc <counter set> (separate passes) -- python tools/run_step.py --hw 16 --reps 10 "
-                     "--precision bf16x3 (tools/refresh_profiles.sh; raw CSVs in profiles/%s/pmc/step_*)" % rnd,
+                     "--precision %s (tools/refresh_profiles.sh; raw CSVs in profiles/%s/pmc/step_*)" % (prec, rnd),
           "FETCH_SIZE_KiB_raw": fetch, "WRITE_SIZE_KiB_raw": write,
           "correction": "FETCH_SIZE doubled (gfx950 reports 1/2 of the bytes of wide coalesced reads: MI355X_MICROARCH.md, HBM "
                         "section); WRITE_SIZE as reported",
