@@ -115,12 +115,37 @@ class IAFLayer(object):
         """the (V, g, b) tuples of one layer's plain convs in `convs()` order (for ConvPrepBatch.run)"""
         return [(params[nm + "/V"], params[nm + "/g"], params[nm + "/b"]) for nm in IAFLayer.CONVS]
 
+    # The public forward methods.  A launch on two fp16 planes (the default arithmetic of the step and of the plain convs, round 6) that met an
+    # operand beyond 65504 wrote inf / NaN -- the caller's NaN check sees that step (tf_train.py:283-285) -- and the NEXT call on that stack /
+    # conv says so once (_capi.RangeError) while the object goes back to bf16 planes.  At layer level the call is simply repeated (the
+    # object now computes in fp32's exponent range) behind a RuntimeWarning; the C ABI and the per-object Python classes raise.
+    def _range_retry(self, fn, *a):
+        import warnings
+        for _ in range(len(self.CONVS) + 1):                  # (every conv and the stack say it once, each for itself)
+            try:
+                return fn(*a)
+            except _capi.RangeError as e:
+                warnings.warn("IAFLayer: %s -- the call is repeated on bf16 planes" % (e,), RuntimeWarning, stacklevel=3)
+        return fn(*a)
+
+    def up(self, inp, autotune=False):
+        return self._range_retry(self._up, inp, autotune)
+
+    def down(self, inp, eps, autotune=False, eps_prior=None):
+        return self._range_retry(self._down, inp, eps, autotune, eps_prior)
+
+    def up_train(self, inp, autotune=False):
+        return self._range_retry(self._up_train, inp, autotune)
+
+    def down_train(self, inp, eps, autotune=False):
+        return self._range_retry(self._down_train, inp, eps, autotune)
+
     @staticmethod
     def stack_params(params):
         pre = "ar_multiconv2d/"
         return {k[len(pre):]: v for k, v in params.items() if k.startswith(pre)}
 
-    def up(self, inp, autotune=False):
+    def _up(self, inp, autotune=False):
         zs, hs = self.z_size, self.h_size
         if self.downsample:
             # stride [2,2], SAME (:33,36): the strided kernel (output (i,j) = output (2i+1, 2j+1) of the stride-1 conv)
@@ -132,7 +157,7 @@ class IAFLayer(object):
         self.posterior.set_up_state(qz_mean, qz_logsd, up_context)                                        # :38
         return self.up_conv3(h, elu_input=True, residual=inp, autotune=autotune)[0]                       # :40-44
 
-    def down(self, inp, eps, autotune=False, eps_prior=None):
+    def _down(self, inp, eps, autotune=False, eps_prior=None):
         """Returns (output, kl_obj, kl_cost) like tf_train.py:95.  `eps` is the posterior noise (mode "train"),
         `eps_prior` the prior noise modes "init" / "sample" draw instead (tf_train.py:60-61).  autotune=True: the first
         call at a new (B,H,W) searches the launch shapes of the plain convs (cuDNN's algorithm search in the reference)."""
@@ -171,7 +196,7 @@ class IAFLayer(object):
             c.set_training(on)
         self.posterior.stack.set_training(on)
 
-    def up_train(self, inp, autotune=False):
+    def _up_train(self, inp, autotune=False):
         zs, hs = self.z_size, self.h_size
         res = inp
         if self.downsample:                                       # as in up()
@@ -185,7 +210,7 @@ class IAFLayer(object):
         self._up_saved = dict(inp=inp, h=h)
         return out
 
-    def down_train(self, inp, eps, autotune=False):
+    def _down_train(self, inp, eps, autotune=False):
         zs, hs = self.z_size, self.h_size
         pz_mean, pz_logsd, rz_mean, rz_logsd, down_context, h_det = self.down_conv1(
             inp, elu_input=True, split=[zs] * 4 + [hs] * 2, autotune=autotune)

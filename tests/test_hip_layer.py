@@ -222,13 +222,13 @@ def test_full_size_layer_properties(amd):
     layer.up(dev(up_in))
     out, kl_obj, kl_cost = layer.down(dev(down_in), dev(eps))
     # With these weights |z| behind the IAF step reaches 1e7: beyond fp16's range, which down_conv2's default arithmetic (two fp16
-    # planes, round 6) says out loud -- its outputs are not finite, its range word is up, the next call raises RangeError ONCE and the
-    # conv computes on bf16 planes (fp32's exponent range) from then on (include/iaf_hip.h, iaf_conv3x3_range_errors)
+    # planes, round 6) says out loud -- its outputs are not finite, its range word is up, the conv's next call raises RangeError ONCE and
+    # it computes on bf16 planes (fp32's exponent range) from then on (include/iaf_hip.h, iaf_conv3x3_range_errors); the LAYER repeats
+    # that call behind a RuntimeWarning
     assert float(layer.last_block["z"].abs().max()) > 65504.0
     assert layer.down_conv2.range_errors() & 1 and not torch.isfinite(out).all()
-    with pytest.raises(amd._capi.RangeError):
-        layer.down(dev(down_in), dev(eps))
-    out, kl_obj, kl_cost = layer.down(dev(down_in), dev(eps))
+    with pytest.warns(RuntimeWarning, match="repeated on bf16 planes"):
+        out, kl_obj, kl_cost = layer.down(dev(down_in), dev(eps))
     assert torch.isfinite(out).all() and not layer.down_conv2.runs_f16x2(B, H, W)
     # batch independence: the first 4 entries alone give the same values
     layer.up(dev(up_in[:4]))
