@@ -107,7 +107,11 @@ __global__ __launch_bounds__(64 * PXT * KS * WCO) void iaf_conv_bf3_kernel(ConvP
     constexpr int NPL = F16 ? 2 : 3;                             // planes per operand
     constexpr int TM = 16 * PPW * PXT;
     constexpr int NTHREADS = 64 * PXT * KS * WCO;   // WCO co groups share ONE staged activation tile
-    constexpr int RD = (PPW >= 2) ? 1 : 2;   // ring look-ahead in steps (a step is PPW*NT*6 MFMAs of 16 cycles)
+#ifndef IAF_F16_PLAIN_RD
+#define IAF_F16_PLAIN_RD 1
+#endif
+    // ring look-ahead in steps (a step is PPW*NT*6 MFMAs of 16 cycles; on the fp16 planes PPW*NT*3: IAF_F16_PLAIN_RD, dev knob)
+    constexpr int RD = F16 ? IAF_F16_PLAIN_RD : (PPW >= 2) ? 1 : 2;
     constexpr int U = RD + 1;                                   // ring slots
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -227,7 +231,46 @@ __global__ __launch_bounds__(64 * PXT * KS * WCO) void iaf_conv_bf3_kernel(ConvP
             if (nb_slot >= 0) split4(smem, nb_slot, q, v, s16, cin8);
         }
     };
-    if constexpr (INMODE == IN_NCHW && S2 != 1) nchw_issue(0, 0);
+    // The slots past the first 64 (16-pixel rows at 32 pixels per workgroup: 66 slots) used to be a second slot pass with TWO live lanes and a
+    // whole load round trip of its own; where they are few -- (nslot - 64) nq items <= one per thread -- they travel with the first pass
+    // instead, one (slot, quad) item per thread (round 6; profiles/r06/plain_conv_stamps.txt: staging is 10-18 k of a workgroup's 35 k cycles)
+    f32x4 tl_v = f32x4{0.f, 0.f, 0.f, 0.f};
+    int tl_slot = -1, tl_q = 0;
+    bool tl_ok = false;
+    const int ntail = p.nslot > 64 ? p.nslot - 64 : 0;
+#ifndef IAF_EXP_TAILFOLD
+#define IAF_EXP_TAILFOLD 1
+#endif
+    const bool tail_fold = IAF_EXP_TAILFOLD && (INMODE == IN_NCHW && S2 != 1) && ntail > 0 && ntail * nq <= NTHREADS;
+    auto tail_issue = [&]() __attribute__((always_inline)) {
+        const bool valid = tid < ntail * nq;
+        int q, t;
+        fast_divmod(valid ? tid : 0, ntail, 1.0f / (float)ntail, q, t);
+        const int sl = 64 + t, Pg = Pbase + sl;
+        tl_ok = valid && Pg >= 0 && Pg < p.P;
+        int b, ppx;
+        fast_divmod(tl_ok ? Pg : 0, HW, 1.0f / (float)HW, b, ppx);
+        const bool two = (EPI == EPI_PLAIN) && p.x2 != nullptr;
+        const int c1 = two ? p.c_split : p.cin;
+        const bool second = two && 4 * q >= c1;
+        const float* src = second ? p.x2 + ((size_t)b * (p.cin - c1) + (4 * q - c1)) * HW + ppx : p.x + ((size_t)b * c1 + 4 * q) * HW + ppx;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tl_v[r] = src[(size_t)r * HW];
+        tl_slot = valid ? sl : -1; tl_q = q;
+    };
+    auto tail_finish = [&]() __attribute__((always_inline)) {
+        f32x4 v = tl_v;
+        if (EPI == EPI_PLAIN && p.in_elu) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = elu_f(v[r]);
+        }
+        if (!tl_ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (tl_slot >= 0) split4(smem, tl_slot, tl_q, v, s16, cin8);
+    };
+    if constexpr (INMODE == IN_NCHW && S2 != 1) {
+        nchw_issue(0, 0);
+        if (tail_fold) tail_issue();
+    }
 
     // ================= prologue (2): weight ring ======================================================================
     // step s = pair * 5 + tap; wave kh owns steps [s0, s1).  One step = NT tiles x 3 planes x 1 KiB, contiguous.
@@ -235,7 +278,7 @@ __global__ __launch_bounds__(64 * PXT * KS * WCO) void iaf_conv_bf3_kernel(ConvP
     const int s0 = (kh * S) / KS, s1 = ((kh + 1) * S) / KS;
     const size_t wstep = (size_t)p.ncot * NPL * 64;                             // f32x4 per step
     const f32x4* wbase = (const f32x4*)p.wp + (size_t)cot0 * NPL * 64 + lane;  // this wave's tiles, this lane's 16 bytes
-    f32x4 wr[U][NT][3];
+    f32x4 wr[U][NT][NPL];
     // fragments [lo, hi) of step s -> ring slot I (a step's refill is issued in PPW parts, one per pixel-tile group of
     // MFMAs, so that the loads sit BETWEEN the MFMAs instead of in a cluster that starves the pipe)
     auto load_part = [&](auto slot_c, auto lo_c, auto hi_c, int s) __attribute__((always_inline)) {
@@ -513,10 +556,12 @@ __global__ __launch_bounds__(64 * PXT * KS * WCO) void iaf_conv_bf3_kernel(ConvP
             stage_s2d();
         } else if (INMODE == IN_NCHW) {
             nchw_finish();                                         // (pass 0, first SQ quads: issued in prologue (1))
+            if (tail_fold) tail_finish();                          // (... and the slots past 64 with them)
             const int nqt = (nq + NWV - 1) / NWV;                  // quads per thread and slot
             for (int qb = SQ; qb < nqt; qb += SQ) { nchw_issue(0, qb); nchw_finish(); }
-            for (int sp = 1; sp * 64 < p.nslot; ++sp)
-                for (int qb = 0; qb < nqt; qb += SQ) { nchw_issue(sp, qb); nchw_finish(); }
+            if (!tail_fold)
+                for (int sp = 1; sp * 64 < p.nslot; ++sp)
+                    for (int qb = 0; qb < nqt; qb += SQ) { nchw_issue(sp, qb); nchw_finish(); }
         } else if (INMODE == IN_POSTERIOR) {
             stage_nchw(smem, p.nslot, p.cin, s16, cin8, p.x, true);
         }
