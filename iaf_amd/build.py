@@ -19,7 +19,7 @@ LIBDIR = os.path.join(HERE, "_lib" + ("_" + _TAG if _TAG else ""))
 OBJDIR = os.path.join(LIBDIR, "obj")
 OUT = os.path.join(LIBDIR, "libiaf_hip.so")
 SHAPES = [(4, 1, 1), (4, 1, 2), (2, 2, 1), (2, 2, 2), (2, 1, 2), (2, 1, 4), (1, 1, 4), (1, 2, 2)]   # keep in sync with pick_kernel()
-BF3_PLAIN_SHAPES = [(2, 1, 4, 1), (4, 1, 4, 1), (2, 1, 4, 2)]   # 9-tap plain convs: keep in sync with pick_bf3_plain()
+BF3_PLAIN_SHAPES = [(2, 1, 4, 1), (4, 1, 4, 1), (2, 1, 4, 2), (2, 1, 4, 3)]   # 9-tap plain convs: keep in sync with pick_bf3_plain()
 BF3_SHAPES = [(4, 1, 4, 1), (2, 1, 4, 1), (1, 1, 4, 1), (1, 4, 1, 1), (2, 1, 4, 2), (1, 1, 4, 2)]   # (ppw, pxt, ks, wco): keep in sync with pick_bf3()
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 CFLAGS += os.environ.get("IAF_EXTRA_CFLAGS", "").split()       # dev experiments only (e.g. -DIAF_EXP_NOREFILL)

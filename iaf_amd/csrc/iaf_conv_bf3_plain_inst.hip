@@ -13,6 +13,7 @@
 #define IAF_CAT_(a, b, c, d, e) a##b##_##c##_##d##_##e
 #define IAF_CAT(a, b, c, d, e) IAF_CAT_(a, b, c, d, e)
 
+// (WCO = 3: 768 threads, three waves per SIMD, 170 registers -- NT = 5 does not fit and is not instantiated)
 // epi: EPI_PLAIN (forward), or EPI_DGRAD -- the data gradient of the same conv: dY pixel-major, transposed bf16x3 pack,
 // mirrored taps (iaf_conv3x3_backward)
 extern "C" conv_fn_t IAF_CAT(iaf_pick_bf3p_, IAF_PPW, IAF_PXT, IAF_KS, IAF_WCO)(int nt, int epi) {
@@ -20,14 +21,18 @@ extern "C" conv_fn_t IAF_CAT(iaf_pick_bf3p_, IAF_PPW, IAF_PXT, IAF_KS, IAF_WCO)(
         switch (nt) {
             case 2: return iaf_conv_bf3_kernel<2, IAF_PPW, IAF_PXT, IAF_KS, IN_PIXMAJOR, EPI_DGRAD, IAF_WCO, MAXTAPS>;
             case 4: return iaf_conv_bf3_kernel<4, IAF_PPW, IAF_PXT, IAF_KS, IN_PIXMAJOR, EPI_DGRAD, IAF_WCO, MAXTAPS>;
+#if IAF_WCO < 3
             case 5: return iaf_conv_bf3_kernel<5, IAF_PPW, IAF_PXT, IAF_KS, IN_PIXMAJOR, EPI_DGRAD, IAF_WCO, MAXTAPS>;
+#endif
         }
         return nullptr;
     }
     switch (nt) {
         case 2: return iaf_conv_bf3_kernel<2, IAF_PPW, IAF_PXT, IAF_KS, IN_NCHW, EPI_PLAIN, IAF_WCO, MAXTAPS>;
         case 4: return iaf_conv_bf3_kernel<4, IAF_PPW, IAF_PXT, IAF_KS, IN_NCHW, EPI_PLAIN, IAF_WCO, MAXTAPS>;
+#if IAF_WCO < 3
         case 5: return iaf_conv_bf3_kernel<5, IAF_PPW, IAF_PXT, IAF_KS, IN_NCHW, EPI_PLAIN, IAF_WCO, MAXTAPS>;
+#endif
     }
     return nullptr;
 }
@@ -38,13 +43,17 @@ extern "C" conv_fn_t IAF_CAT(iaf_pick_bf3s_, IAF_PPW, IAF_PXT, IAF_KS, IAF_WCO)(
         switch (nt) {
             case 2: return iaf_conv_bf3_kernel<2, IAF_PPW, IAF_PXT, IAF_KS, IN_NCHW, EPI_PLAIN, IAF_WCO, MAXTAPS, 1>;
             case 4: return iaf_conv_bf3_kernel<4, IAF_PPW, IAF_PXT, IAF_KS, IN_NCHW, EPI_PLAIN, IAF_WCO, MAXTAPS, 1>;
+#if IAF_WCO < 3
             case 5: return iaf_conv_bf3_kernel<5, IAF_PPW, IAF_PXT, IAF_KS, IN_NCHW, EPI_PLAIN, IAF_WCO, MAXTAPS, 1>;
+#endif
         }
     } else if (s2 == 2) {
         switch (nt) {
             case 2: return iaf_conv_bf3_kernel<2, IAF_PPW, IAF_PXT, IAF_KS, IN_NCHW, EPI_PLAIN, IAF_WCO, MAXTAPS, 2>;
             case 4: return iaf_conv_bf3_kernel<4, IAF_PPW, IAF_PXT, IAF_KS, IN_NCHW, EPI_PLAIN, IAF_WCO, MAXTAPS, 2>;
+#if IAF_WCO < 3
             case 5: return iaf_conv_bf3_kernel<5, IAF_PPW, IAF_PXT, IAF_KS, IN_NCHW, EPI_PLAIN, IAF_WCO, MAXTAPS, 2>;
+#endif
         }
     }
     return nullptr;
@@ -55,7 +64,9 @@ extern "C" conv_fn_t IAF_CAT(iaf_pick_bf3p16_, IAF_PPW, IAF_PXT, IAF_KS, IAF_WCO
     switch (nt) {
         case 2: return iaf_conv_bf3_kernel<2, IAF_PPW, IAF_PXT, IAF_KS, IN_NCHW, EPI_PLAIN, IAF_WCO, MAXTAPS, 0, 1>;
         case 4: return iaf_conv_bf3_kernel<4, IAF_PPW, IAF_PXT, IAF_KS, IN_NCHW, EPI_PLAIN, IAF_WCO, MAXTAPS, 0, 1>;
+#if IAF_WCO < 3
         case 5: return iaf_conv_bf3_kernel<5, IAF_PPW, IAF_PXT, IAF_KS, IN_NCHW, EPI_PLAIN, IAF_WCO, MAXTAPS, 0, 1>;
+#endif
     }
     return nullptr;
 }

@@ -292,24 +292,30 @@ static size_t bf3_lds_bytes(int cin, int W, int nt, int ppw, int pxt, int ks, in
 }
 
 // 9-tap plain convs on the bf16 matrix cores (iaf_conv_bf3_plain_inst.hip): shapes (ppw, pxt, ks, wco); keep in sync with build.py
-#define N_BF3P_SHAPES 3
-static const int k_bf3p_shapes[N_BF3P_SHAPES][4] = {{2, 1, 4, 1}, {4, 1, 4, 1}, {2, 1, 4, 2}};
+// (2, 1, 4, 3), round 6: THREE co groups of NT tiles on one staged tile (768 threads, three waves per SIMD: NT = 2 / 4 only) -- the 24 output
+// tiles of up_conv1 (160 -> 384) in two workgroups per pixel block instead of three
+#define N_BF3P_SHAPES 4
+static const int k_bf3p_shapes[N_BF3P_SHAPES][4] = {{2, 1, 4, 1}, {4, 1, 4, 1}, {2, 1, 4, 2}, {2, 1, 4, 3}};
 extern "C" conv_fn_t iaf_pick_bf3p_2_1_4_1(int nt, int epi);
 extern "C" conv_fn_t iaf_pick_bf3p_4_1_4_1(int nt, int epi);
 extern "C" conv_fn_t iaf_pick_bf3p_2_1_4_2(int nt, int epi);
+extern "C" conv_fn_t iaf_pick_bf3p_2_1_4_3(int nt, int epi);
 static conv_fn_t pick_bf3_plain(int nt, int ppw, int pxt, int ks, int wco, int epi = EPI_PLAIN) {
     if (ppw == 2 && pxt == 1 && ks == 4 && wco == 1) return iaf_pick_bf3p_2_1_4_1(nt, epi);
     if (ppw == 4 && pxt == 1 && ks == 4 && wco == 1) return iaf_pick_bf3p_4_1_4_1(nt, epi);
     if (ppw == 2 && pxt == 1 && ks == 4 && wco == 2) return iaf_pick_bf3p_2_1_4_2(nt, epi);
+    if (ppw == 2 && pxt == 1 && ks == 4 && wco == 3) return iaf_pick_bf3p_2_1_4_3(nt, epi);
     return nullptr;
 }
 extern "C" conv_fn_t iaf_pick_bf3p16_2_1_4_1(int nt);
 extern "C" conv_fn_t iaf_pick_bf3p16_4_1_4_1(int nt);
 extern "C" conv_fn_t iaf_pick_bf3p16_2_1_4_2(int nt);
+extern "C" conv_fn_t iaf_pick_bf3p16_2_1_4_3(int nt);
 static conv_fn_t pick_bf3_plain_f16(int nt, int ppw, int pxt, int ks, int wco) {
     if (ppw == 2 && pxt == 1 && ks == 4 && wco == 1) return iaf_pick_bf3p16_2_1_4_1(nt);
     if (ppw == 4 && pxt == 1 && ks == 4 && wco == 1) return iaf_pick_bf3p16_4_1_4_1(nt);
     if (ppw == 2 && pxt == 1 && ks == 4 && wco == 2) return iaf_pick_bf3p16_2_1_4_2(nt);
+    if (ppw == 2 && pxt == 1 && ks == 4 && wco == 3) return iaf_pick_bf3p16_2_1_4_3(nt);
     return nullptr;
 }
 // LDS of a 9-tap bf16x3 launch: the pixel tile with a halo of W + 1 slots on BOTH sides (+ the zero slot)

@@ -129,11 +129,11 @@ def test_wnconv2d_every_launch_shape(amd, tune):
     np.testing.assert_allclose(host(y), e, atol=ATOL, rtol=0)
 
 
-BF3P = [(nt, ppw, wco, 4) for (ppw, wco) in ((2, 1), (4, 1), (2, 2)) for nt in (5, 4, 2)]
+BF3P = [(nt, ppw, wco, 4) for (ppw, wco) in ((2, 1), (4, 1), (2, 2)) for nt in (5, 4, 2)] + [(4, 2, 3, 4), (2, 2, 3, 4)]
 
 
 @pytest.mark.parametrize("shp", BF3P, ids=lambda t: "nt%d_ppw%d_wco%d_ks%d" % t)
-@pytest.mark.parametrize("case", [(3, 160, 320, 8, 8), (32, 160, 160, 16, 16), (2, 32, 40 * 16, 5, 7)], ids=lambda s: "B%d_%dto%d_%dx%d" % s)
+@pytest.mark.parametrize("case", [(3, 160, 320, 8, 8), (32, 160, 160, 16, 16), (2, 32, 40 * 16, 5, 7), (8, 160, 384, 16, 16)], ids=lambda s: "B%d_%dto%d_%dx%d" % s)
 def test_plain_conv_on_the_bf16_matrix_cores_every_shape(amd, shp, case):
     """the 9-tap plain conv as bf16x3 split products (iaf_conv_bf3.hpp, NTP = 9, halo on both sides of the pixel tile): every
     compiled launch shape, with the fused ELU / residual, against the oracle -- and fp32-grade, not just inside the tolerance"""
