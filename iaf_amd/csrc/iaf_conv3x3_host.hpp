@@ -354,12 +354,19 @@ extern "C" int iaf_conv3x3_prep_batch_run(iaf_conv3x3_prep_batch_t* b, const flo
     return IAF_OK;
 }
 
+// co tiles per workgroup (NT x WCO) of a 9-tap split-product launch need not divide the layer's tile count: the last workgroup's surplus
+// tiles are computed on clamped fragments and dropped (iaf_conv_bf3.hpp, toff) -- accepted up to a quarter of the layer's tiles
+static inline bool bf3_ragged_ok(int ncot, int per_wg) {
+    if (per_wg <= 0) return false;
+    const int covered = (ncot + per_wg - 1) / per_wg * per_wg;
+    return (covered - ncot) * 4 <= ncot;
+}
 extern "C" int iaf_conv3x3_set_tuning(iaf_conv3x3_t* c, int nt, int pxt, int wco, int ks) {
     if (!c) return IAF_ERR_NULL;
     GemmLayer& L = c->L;
     if (nt == 0) { L.user_tuned = false; c->bf3_choice = 1; return IAF_OK; }     // back to the automatic choice
     if (nt < 0) {           // a bf16x3 launch shape, as iaf_conv3x3_autotune reports it: (-nt, ppw, wco, ks), pxt = 1
-        if (c->generic || c->mask_mode || !L.wp3 || L.ncot % (-nt * wco) != 0 || !pick_bf3_plain(-nt, pxt, 1, ks, wco)) return IAF_ERR_UNSUPPORTED;
+        if (c->generic || c->mask_mode || !L.wp3 || !bf3_ragged_ok(L.ncot, -nt * wco) || !pick_bf3_plain(-nt, pxt, 1, ks, wco)) return IAF_ERR_UNSUPPORTED;
         L.b_nt = -nt; L.b_ppw = pxt; L.b_pxt = 1; L.b_ks = ks; L.b_wco = wco;
         c->bf3_choice = 2;
         return IAF_OK;
@@ -385,7 +392,7 @@ static bool conv3x3_bf3_shape(GemmLayer& L, int choice, long long P, int W) {
         if (!L.b_nt) return false;
         L.b_ppw = 2; L.b_pxt = 1; L.b_ks = 4; L.b_wco = 1;
     }
-    if (L.ncot % (L.b_nt * L.b_wco) != 0 || !pick_bf3_plain(L.b_nt, L.b_ppw, L.b_pxt, L.b_ks, L.b_wco)) return false;
+    if (!bf3_ragged_ok(L.ncot, L.b_nt * L.b_wco) || !pick_bf3_plain(L.b_nt, L.b_ppw, L.b_pxt, L.b_ks, L.b_wco)) return false;
     return bf3_plain_lds_bytes(L.cin, W, L.b_nt, L.b_ppw, L.b_pxt, L.b_ks, L.b_wco) <= 160 * 1024;
 }
 
@@ -415,7 +422,7 @@ static int conv3x3_launch(GemmLayer& L, ConvP& p, int epi_sel, int inmode, bool 
         const size_t lds = bf3_plain_lds_bytes(L.cin, W, L.b_nt, L.b_ppw, L.b_pxt, L.b_ks, L.b_wco);
         int rc = raise_lds_cap((const void*)fn, lds);
         if (rc) return rc;
-        dim3 grid((p.P + tm - 1) / tm, L.ncot / (L.b_nt * L.b_wco));
+        dim3 grid((p.P + tm - 1) / tm, (L.ncot + L.b_nt * L.b_wco - 1) / (L.b_nt * L.b_wco));
         p.gx = (int)grid.x;
         p.lds_bytes = (int)lds;
         p.dbg = (L.dbg && (size_t)grid.x * grid.y * 8 * sizeof(unsigned long long) <= L.dbg_bytes) ? L.dbg : nullptr;
@@ -768,7 +775,7 @@ extern "C" int iaf_conv3x3_autotune(iaf_conv3x3_t* c, const float* x, const floa
         for (int si = 0; si < N_BF3P_SHAPES && rc == IAF_OK; ++si)
             for (int nt : nts) {
                 const int* sh = k_bf3p_shapes[si];
-                if (L.ncot % (nt * sh[3]) != 0) continue;
+                if (!bf3_ragged_ok(L.ncot, nt * sh[3])) continue;
                 L.b_nt = nt; L.b_ppw = sh[0]; L.b_pxt = sh[1]; L.b_ks = sh[2]; L.b_wco = sh[3];
                 c->bf3_choice = 2;
                 GemmLayer t = L;

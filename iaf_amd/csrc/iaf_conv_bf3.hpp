@@ -278,6 +278,15 @@ __global__ __launch_bounds__(64 * PXT * KS * WCO) void iaf_conv_bf3_kernel(ConvP
     const int s0 = (kh * S) / KS, s1 = ((kh + 1) * S) / KS;
     const size_t wstep = (size_t)p.ncot * NPL * 64;                             // f32x4 per step
     const f32x4* wbase = (const f32x4*)p.wp + (size_t)cot0 * NPL * 64 + lane;  // this wave's tiles, this lane's 16 bytes
+    // ragged co groups (round 6: c_out / 16 need not be a multiple of NT x WCO -- down_conv1's 28 tiles in three workgroups of 2 x 5 per
+    // pixel block instead of seven of 2 x 2): a tile past the layer's last one reads the last one's fragments (a valid address; its
+    // sums are computed and dropped -- the epilogue's items of such tiles are inactive)
+    int toff[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int ta = cot0 + t < p.ncot ? cot0 + t : p.ncot - 1;
+        toff[t] = (ta - cot0) * NPL * 64;
+    }
     f32x4 wr[U][NT][NPL];
     // fragments [lo, hi) of step s -> ring slot I (a step's refill is issued in PPW parts, one per pixel-tile group of
     // MFMAs, so that the loads sit BETWEEN the MFMAs instead of in a cluster that starves the pipe)
@@ -291,7 +300,7 @@ __global__ __launch_bounds__(64 * PXT * KS * WCO) void iaf_conv_bf3_kernel(ConvP
         if constexpr (S2 == 2) { const int pr = step_pair(sc); ws = pr * NTP + step_tap(sc, pr); }
         const f32x4* q = wbase + (size_t)ws * wstep;
 #pragma unroll
-        for (int f = LO; f < HI; ++f) wr[I][f / NPL][f % NPL] = q[f * 64];
+        for (int f = LO; f < HI; ++f) wr[I][f / NPL][f % NPL] = q[toff[f / NPL] + (f % NPL) * 64];
     };
     auto load_step = [&](auto slot_c, int s) __attribute__((always_inline)) {
         load_part(slot_c, std::integral_constant<int, 0>{}, std::integral_constant<int, NT * NPL>{}, s);
@@ -695,7 +704,7 @@ __global__ __launch_bounds__(64 * PXT * KS * WCO) void iaf_conv_bf3_kernel(ConvP
     for (int i = 0; i < NMY; ++i) {
         const int item = kh + i * KS;
         const int q = item / NUNIT, u = item - q * NUNIT;
-        g[i] = epi_geom(p, P0 + (pw * PPW + q) * 16 + pl, kk, item < NITEM);
+        g[i] = epi_geom(p, P0 + (pw * PPW + q) * 16 + pl, kk, item < NITEM && cot0 + u * TPU < p.ncot);
         if constexpr (S2 == 2) g[i].up = 4 + 2 * ph_a + ph_b;
         epi_load<EPI>(p, g[i], cot0 + u * TPU, ops[i]);
     }

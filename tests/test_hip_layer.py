@@ -133,14 +133,16 @@ BF3P = [(nt, ppw, wco, 4) for (ppw, wco) in ((2, 1), (4, 1), (2, 2)) for nt in (
 
 
 @pytest.mark.parametrize("shp", BF3P, ids=lambda t: "nt%d_ppw%d_wco%d_ks%d" % t)
-@pytest.mark.parametrize("case", [(3, 160, 320, 8, 8), (32, 160, 160, 16, 16), (2, 32, 40 * 16, 5, 7), (8, 160, 384, 16, 16)], ids=lambda s: "B%d_%dto%d_%dx%d" % s)
+@pytest.mark.parametrize("case", [(3, 160, 320, 8, 8), (32, 160, 160, 16, 16), (2, 32, 40 * 16, 5, 7), (8, 160, 384, 16, 16), (8, 160, 448, 16, 16)], ids=lambda s: "B%d_%dto%d_%dx%d" % s)
 def test_plain_conv_on_the_bf16_matrix_cores_every_shape(amd, shp, case):
     """the 9-tap plain conv as bf16x3 split products (iaf_conv_bf3.hpp, NTP = 9, halo on both sides of the pixel tile): every
     compiled launch shape, with the fused ELU / residual, against the oracle -- and fp32-grade, not just inside the tolerance"""
     B, n_in, n_out, H, W = case
     nt, ppw, wco, ks = shp
-    if (n_out // 16) % (nt * wco):
-        pytest.skip("this co tiling does not divide %d output tiles" % (n_out // 16))
+    tiles, per_wg = n_out // 16, nt * wco
+    covered = -(-tiles // per_wg) * per_wg
+    if (covered - tiles) * 4 > tiles:          # (ragged co groups, round 6: the last workgroup's surplus tiles are computed and dropped -- up to a quarter)
+        pytest.skip("this co tiling wastes more than a quarter of %d output tiles" % tiles)
     rng = np.random.RandomState(31 + nt + ppw)
     p = gi.conv_params(rng, n_in, n_out)
     x, res = rng.standard_normal((B, n_in, H, W)), rng.standard_normal((B, n_out, H, W))
