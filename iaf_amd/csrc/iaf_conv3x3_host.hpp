@@ -381,16 +381,29 @@ extern "C" int iaf_conv3x3_set_tuning(iaf_conv3x3_t* c, int nt, int pxt, int wco
 // launch of the conv kernel for a plain / single masked conv descriptor (forward, or its transposed problem with the
 // taps mirrored for the data gradient)
 // the plain conv on the bf16 matrix cores: which shape, if any, for this size (choice: see iaf_conv3x3.bf3_choice)
-static bool conv3x3_bf3_shape(GemmLayer& L, int choice, long long P, int W) {
+static bool conv3x3_bf3_shape(GemmLayer& L, int choice, long long P, int W, bool f16 = false) {
     if (!L.wp3 || choice == 3) return false;
-    if (choice != 2) {                                            // size rule: worth it from ~4096 pixels on (as for the masked stack)
-        if (P < 4096) return false;
-        static const int nts[3] = {5, 4, 2};
-        L.b_nt = 0;
-        for (int nt : nts)
-            if (L.ncot % nt == 0) { L.b_nt = nt; break; }
-        if (!L.b_nt) return false;
-        L.b_ppw = 2; L.b_pxt = 1; L.b_ks = 4; L.b_wco = 1;
+    if (choice != 2) {
+        // size rule: worth it from ~4096 pixels on (as for the masked stack); on the fp16 planes (half the MFMAs) from 2048
+        if (P < (f16 ? 2048 : 4096)) return false;
+        // (nt, wco) at ppw 2, ks 4 -- what iaf_conv3x3_autotune finds at the BASELINE sizes (round 6): every workgroup of a 32-pixel block
+        // stages the block's tile again, so the FEWEST workgroups per block that still give the chip a workgroup per CU, at most an
+        // eighth of the co tiles wasted on a ragged last group; else whatever gives the most workgroups
+        static const int cand[8][2] = {{4, 3}, {5, 2}, {4, 2}, {2, 3}, {5, 1}, {4, 1}, {2, 2}, {2, 1}};
+        const long long nblk = (P + 31) / 32;
+        int best = -1;
+        long long best_wgs = 0;
+        for (int i = 0; i < 8; ++i) {
+            const int nt = cand[i][0], wco = cand[i][1], per = nt * wco;
+            const int covered = (L.ncot + per - 1) / per * per;
+            if ((covered - L.ncot) * 8 > L.ncot || !pick_bf3_plain(nt, 2, 1, 4, wco)) continue;
+            if (bf3_plain_lds_bytes(L.cin, W, nt, 2, 1, 4, wco) > 160 * 1024) continue;
+            const long long wgs = nblk * (covered / per);
+            if (wgs >= 256) { best = i; break; }
+            if (wgs > best_wgs) { best_wgs = wgs; best = i; }
+        }
+        if (best < 0) return false;
+        L.b_nt = cand[best][0]; L.b_ppw = 2; L.b_pxt = 1; L.b_ks = 4; L.b_wco = cand[best][1];
     }
     if (!bf3_ragged_ok(L.ncot, L.b_nt * L.b_wco) || !pick_bf3_plain(L.b_nt, L.b_ppw, L.b_pxt, L.b_ks, L.b_wco)) return false;
     return bf3_plain_lds_bytes(L.cin, W, L.b_nt, L.b_ppw, L.b_pxt, L.b_ks, L.b_wco) <= 160 * 1024;
@@ -406,7 +419,7 @@ static int conv3x3_launch(GemmLayer& L, ConvP& p, int epi_sel, int inmode, bool 
     // problem with wp3 = the transposed bf16x3 pack: dY pixel-major, mirrored taps, EPI_DGRAD)
     const bool fwd3 = !masked && !mirror && epi_sel == EPI_PLAIN && inmode == IN_NCHW;
     const bool bwd3 = !masked && mirror && epi_sel == EPI_DGRAD9 && inmode == IN_PIXMAJOR && variant == IAF_VARIANT_TF;
-    if ((fwd3 || bwd3) && conv3x3_bf3_shape(L, bf3_choice, p.P, p.W) &&
+    if ((fwd3 || bwd3) && conv3x3_bf3_shape(L, bf3_choice, p.P, p.W, fwd3 && f16_rng != nullptr) &&
         pick_bf3_plain(L.b_nt, L.b_ppw, L.b_pxt, L.b_ks, L.b_wco, bwd3 ? EPI_DGRAD : EPI_PLAIN)) {
         conv_fn_t fn = pick_bf3_plain(L.b_nt, L.b_ppw, L.b_pxt, L.b_ks, L.b_wco, bwd3 ? EPI_DGRAD : EPI_PLAIN);
         const int tm = 16 * L.b_ppw * L.b_pxt, W = p.W, sg = bwd3 ? -1 : 1;
@@ -521,7 +534,7 @@ extern "C" int iaf_conv3x3_forward(iaf_conv3x3_t* c, const float* x, const float
     if (!c->mask_mode && c->packs != (IAF_PACK_F32 | IAF_PACK_BF16X3 | IAF_PACK_F16X2)) {
         // iaf_conv3x3_set_packs: the pack this launch reads must be one the prep launches write
         GemmLayer t = L;
-        const bool split = conv_split(c) && !c->deconv && conv3x3_bf3_shape(t, c->bf3_choice, p.P, W);
+        const bool split = conv_split(c) && !c->deconv && conv3x3_bf3_shape(t, c->bf3_choice, p.P, W, conv_f16_active(c));
         const bool f16 = split && conv_f16_active(c) && pick_bf3_plain_f16(t.b_nt, t.b_ppw, t.b_pxt, t.b_ks, t.b_wco);
         const int need = f16 ? IAF_PACK_F16X2 : split ? IAF_PACK_BF16X3 : IAF_PACK_F32;
         if (!(c->packs & need)) return IAF_ERR_NOT_PREPARED;
@@ -720,13 +733,13 @@ extern "C" int iaf_conv3x3_range_errors(const iaf_conv3x3_t* c, unsigned* errors
 extern "C" int iaf_conv3x3_runs_bf16x3(iaf_conv3x3_t* c, int B, int H, int W) {
     if (!c || c->generic || c->mask_mode || c->deconv || !conv_split(c)) return 0;
     GemmLayer t = c->L;
-    return conv3x3_bf3_shape(t, c->bf3_choice, (long long)B * H * W, W) ? 1 : 0;
+    return conv3x3_bf3_shape(t, c->bf3_choice, (long long)B * H * W, W, conv_f16_active(c)) ? 1 : 0;
 }
 // ... and on two fp16 planes (the split-product launch of this size is an F16 instantiation)
 extern "C" int iaf_conv3x3_runs_f16x2(iaf_conv3x3_t* c, int B, int H, int W) {
     if (!iaf_conv3x3_runs_bf16x3(c, B, H, W) || !conv_f16_active(c)) return 0;
     GemmLayer t = c->L;
-    if (!conv3x3_bf3_shape(t, c->bf3_choice, (long long)B * H * W, W)) return 0;
+    if (!conv3x3_bf3_shape(t, c->bf3_choice, (long long)B * H * W, W, true)) return 0;
     return pick_bf3_plain_f16(t.b_nt, t.b_ppw, t.b_pxt, t.b_ks, t.b_wco) ? 1 : 0;
 }
 
