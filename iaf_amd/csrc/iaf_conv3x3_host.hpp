@@ -44,6 +44,7 @@ extern "C" int iaf_conv3x3_destroy(iaf_conv3x3_t* c) {
     if (c->L.wpt) (void)hipFree(c->L.wpt);
     if (c->L.wp3) (void)hipFree(c->L.wp3);
     if (c->L.wp2) (void)hipFree(c->L.wp2);
+    if (c->L.wpt2) (void)hipFree(c->L.wpt2);
     if (c->rng_err_host) (void)hipHostFree(c->rng_err_host);
     if (c->L.border) (void)hipFree(c->L.border);
     if (c->own_dW) (void)hipFree(c->own_dW);
@@ -397,7 +398,7 @@ static bool conv3x3_bf3_shape(GemmLayer& L, int choice, long long P, int W, bool
             const int nt = cand[i][0], wco = cand[i][1], per = nt * wco;
             const int covered = (L.ncot + per - 1) / per * per;
             if ((covered - L.ncot) * 8 > L.ncot || !pick_bf3_plain(nt, 2, 1, 4, wco)) continue;
-            if (bf3_plain_lds_bytes(L.cin, W, nt, 2, 1, 4, wco) > 160 * 1024) continue;
+            if (bf3_plain_lds_bytes(L.cin, W, nt, 2, 1, 4, wco, f16 ? 2 : 3) > 160 * 1024) continue;
             const long long wgs = nblk * (covered / per);
             if (wgs >= 256) { best = i; break; }
             if (wgs > best_wgs) { best_wgs = wgs; best = i; }
@@ -406,33 +407,40 @@ static bool conv3x3_bf3_shape(GemmLayer& L, int choice, long long P, int W, bool
         L.b_nt = cand[best][0]; L.b_ppw = 2; L.b_pxt = 1; L.b_ks = 4; L.b_wco = cand[best][1];
     }
     if (!bf3_ragged_ok(L.ncot, L.b_nt * L.b_wco) || !pick_bf3_plain(L.b_nt, L.b_ppw, L.b_pxt, L.b_ks, L.b_wco)) return false;
-    return bf3_plain_lds_bytes(L.cin, W, L.b_nt, L.b_ppw, L.b_pxt, L.b_ks, L.b_wco) <= 160 * 1024;
+    return bf3_plain_lds_bytes(L.cin, W, L.b_nt, L.b_ppw, L.b_pxt, L.b_ks, L.b_wco, f16 ? 2 : 3) <= 160 * 1024;
 }
 
 // dev tool (tools/conv_stamps.py): per-workgroup cycle stamps of THIS conv's bf16x3 plain-conv launches, [grid][8] u64 in a caller
 // buffer of `bytes` bytes (NULL: off).  Per object and size-checked at every launch (it was one process-global pointer
 // that every conv's launches on every stream wrote through without a bound); declared here, defined behind the object's definition.
 
+// dgrad16: the data gradient (bwd3) of a conv whose arithmetic is IAF_PRECISION_F16X2 -- two fp16 planes with a tile-local scale
 static int conv3x3_launch(GemmLayer& L, ConvP& p, int epi_sel, int inmode, bool masked, bool mirror, hipStream_t st,
-                          int variant = IAF_VARIANT_TF, int bf3_choice = 3, unsigned* f16_rng = nullptr) {
+                          int variant = IAF_VARIANT_TF, int bf3_choice = 3, unsigned* f16_rng = nullptr, bool dgrad16 = false) {
     // the plain conv on the bf16 matrix cores: forward (NCHW input, EPI_PLAIN), or its data gradient (L = the transposed
     // problem with wp3 = the transposed bf16x3 pack: dY pixel-major, mirrored taps, EPI_DGRAD)
     const bool fwd3 = !masked && !mirror && epi_sel == EPI_PLAIN && inmode == IN_NCHW;
     const bool bwd3 = !masked && mirror && epi_sel == EPI_DGRAD9 && inmode == IN_PIXMAJOR && variant == IAF_VARIANT_TF;
-    if ((fwd3 || bwd3) && conv3x3_bf3_shape(L, bf3_choice, p.P, p.W, fwd3 && f16_rng != nullptr) &&
+    const bool f16l = (fwd3 && f16_rng != nullptr) || (bwd3 && dgrad16 && L.wp2 != nullptr);
+    if ((fwd3 || bwd3) && conv3x3_bf3_shape(L, bf3_choice, p.P, p.W, f16l) &&
         pick_bf3_plain(L.b_nt, L.b_ppw, L.b_pxt, L.b_ks, L.b_wco, bwd3 ? EPI_DGRAD : EPI_PLAIN)) {
         conv_fn_t fn = pick_bf3_plain(L.b_nt, L.b_ppw, L.b_pxt, L.b_ks, L.b_wco, bwd3 ? EPI_DGRAD : EPI_PLAIN);
         const int tm = 16 * L.b_ppw * L.b_pxt, W = p.W, sg = bwd3 ? -1 : 1;
         p.border = nullptr; p.wp = (const float*)L.wp3; p.bias = L.bias; p.lim = nullptr;
         // f16_rng (the caller's conv runs IAF_PRECISION_F16X2): the forward on two fp16 planes, the same launch shape and LDS bound
+        bool npl2 = false;
         if (conv_fn_t fn16 = (fwd3 && f16_rng && L.wp2) ? pick_bf3_plain_f16(L.b_nt, L.b_ppw, L.b_pxt, L.b_ks, L.b_wco) : nullptr) {
-            fn = fn16; p.wp = (const float*)L.wp2; p.rng_err = f16_rng;
+            fn = fn16; p.wp = (const float*)L.wp2; p.rng_err = f16_rng; npl2 = true;
+        } else if (conv_fn_t fd16 = (bwd3 && dgrad16 && L.wp2) ? pick_bf3_plain_f16d(L.b_nt, L.b_ppw, L.b_pxt, L.b_ks, L.b_wco) : nullptr) {
+            fn = fd16; p.wp = (const float*)L.wp2; p.rng_err = nullptr; npl2 = true;
+        } else if (f16l) {
+            return IAF_ERR_UNSUPPORTED;         // (the shape was sized for two planes and no two-plane kernel exists for it: not reached by the compiled shape lists)
         }
         for (int t = 0; t < MAXTAPS; ++t) { p.tap_dh[t] = sg * (t / 3 - 1); p.tap_dw[t] = sg * (t % 3 - 1); }   // cross-correlation, SAME (mirrored: dX)
         p.halo_before = W + 1;
         p.nslot = tm + 2 * (W + 1);
         p.cin = L.cin; p.cout = L.cout; p.nchunk = L.nchunk; p.ncot = L.ncot; p.cp = L.cin + 8;
-        const size_t lds = bf3_plain_lds_bytes(L.cin, W, L.b_nt, L.b_ppw, L.b_pxt, L.b_ks, L.b_wco);
+        const size_t lds = bf3_plain_lds_bytes(L.cin, W, L.b_nt, L.b_ppw, L.b_pxt, L.b_ks, L.b_wco, npl2 ? 2 : 3);
         int rc = raise_lds_cap((const void*)fn, lds);
         if (rc) return rc;
         dim3 grid((p.P + tm - 1) / tm, (L.ncot + L.b_nt * L.b_wco - 1) / (L.b_nt * L.b_wco));
@@ -873,10 +881,13 @@ extern "C" int iaf_conv3x3_set_training(iaf_conv3x3_t* c, int on) {
     if (!L.wpt) HIP_TRY(hipMalloc(&L.wpt, (size_t)L.nchunk * MAXTAPS * L.ncot * 256 * sizeof(float)));
     // the transposed pack as bf16x3 (iaf_pack_t3_kernel): the data gradient on the bf16 matrix cores (even K tile counts)
     if (!L.wpt3 && L.ncot % 2 == 0) HIP_TRY(hipMalloc(&L.wpt3, (size_t)(L.ncot / 2) * MAXTAPS * L.nchunk * 3 * 64 * 16));
+    // ... and as two fp16 planes: the data gradient of a conv whose arithmetic is IAF_PRECISION_F16X2 (iaf_conv_bf3.hpp DG16; IAF_DGRAD_F16=0: dev knob)
+    static const bool dg16_env = !(getenv("IAF_DGRAD_F16") && getenv("IAF_DGRAD_F16")[0] == '0');
+    if (dg16_env && L.wpt3 && !L.wpt2) HIP_TRY(hipMalloc(&L.wpt2, (size_t)(L.ncot / 2) * MAXTAPS * L.nchunk * 2 * 64 * 16));
     GemmLayer& T = c->T;
     T = GemmLayer();
     T.cin = L.cout; T.cout = L.cin; T.nchunk = L.ncot; T.ncot = L.nchunk; T.zerodiag = 0; T.npair = 1; T.full3x3 = true;
-    T.wp = L.wpt; T.wp3 = L.wpt3; T.nt = 1; T.pxt = 4; T.wco = 1; T.ks = 1; T.user_tuned = false;
+    T.wp = L.wpt; T.wp3 = L.wpt3; T.wp2 = L.wpt2; T.nt = 1; T.pxt = 4; T.wco = 1; T.ks = 1; T.user_tuned = false;
     T.dbg = L.dbg; T.dbg_bytes = L.dbg_bytes;
     c->training = true;
     c->packs = IAF_PACK_F32 | IAF_PACK_BF16X3 | IAF_PACK_F16X2;     // (training keeps every pack)
@@ -1004,7 +1015,8 @@ extern "C" int iaf_conv3x3_backward(iaf_conv3x3_t* c, const float* x, const floa
         }
         // bf16x3 unless the conv's precision is fp32 or a backward search measured the fp32 kernel faster at this size
         const int choice3 = (!conv_split(c) || c->bf3_choice == 3 || !c->T.wp3) ? 3 : (c->T.tuned_P == (long long)P && c->T.tuned_W == W && !c->T.tuned_bf3) ? 3 : 1;
-        if ((rc = conv3x3_launch(c->T, p, EPI_DGRAD9, IN_PIXMAJOR, false, true, st, IAF_VARIANT_TF, choice3))) return rc;
+        const bool dgrad16 = c->precision == IAF_PRECISION_F16X2 && !c->f16_off && c->T.wp2 != nullptr && !c->deconv;
+        if ((rc = conv3x3_launch(c->T, p, EPI_DGRAD9, IN_PIXMAJOR, false, true, st, IAF_VARIANT_TF, choice3, nullptr, dgrad16))) return rc;
     }
     // (3) weight gradient: partials over pixel ranges, then reduce (+ column sums of dY for db)
     const unsigned short* tapmask = nullptr;

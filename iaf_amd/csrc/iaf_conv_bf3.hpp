@@ -101,6 +101,13 @@ __device__ __forceinline__ void f16s_store4(char* smem, int slot, int q, f32x4 v
 template <int NT, int PPW, int PXT, int KS, int INMODE, int EPI, int WCO = 1, int NTP_ = NTAPS, int S2 = 0, int F16 = 0>
 __global__ __launch_bounds__(64 * PXT * KS * WCO) void iaf_conv_bf3_kernel(ConvP p) {
     static_assert(!F16 || INMODE != IN_FUSED0, "the fused first layer exists on bf16 planes only");
+    // F16 with a pixel-major input = the DATA GRADIENT on two fp16 planes (round 6): a gradient tensor has no business with fp16's exponent
+    // range, so the workgroup scales the tile it stages by a power of two of its own -- the largest magnitude of the tile lands in
+    // [2^13, 2^14) -- and its sums by the inverse behind the K loop: nothing can leave fp16's range (no range word), an element's error is
+    // 2^-22 of itself down to 2^-14 of the tile's largest and 2^-36 of that largest below (fp16's subnormals), which is what the gradient
+    // tests hold (errors relative to the tensor's largest element).
+    constexpr bool DG16 = F16 && INMODE == IN_PIXMAJOR;
+    [[maybe_unused]] float dg_scale = 1.0f, dg_inv = 1.0f;
     extern __shared__ __attribute__((aligned(16))) f32x4 smem4[];
     char* smem = (char*)smem4;
     constexpr int NTP = NTP_;
@@ -548,18 +555,44 @@ __global__ __launch_bounds__(64 * PXT * KS * WCO) void iaf_conv_bf3_kernel(ConvP
         for (int i = tid; i < s16; i += NTHREADS) zslot[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (INMODE == IN_PIXMAJOR) {
             const float rnq = 1.0f / (float)nq;
+            const f32x4* src = (const f32x4*)p.x + (long long)Pbase * nq;
+            if constexpr (DG16) {
+                // the tile's largest magnitude: the items in registers, then one pass of loads over the rest (they are loaded again below: L2)
+                float m = 0.f;
+                auto amax4 = [&](f32x4 v) __attribute__((always_inline)) {
+                    m = fmaxf(fmaxf(m, fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1]))), fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3])));
+                };
+#pragma unroll
+                for (int u = 0; u < SU; ++u) amax4(sv[u]);
+                for (int f = tid + SU * NTHREADS; f < nitems; f += NTHREADS)
+                    if (f >= flo && f < fhi) amax4(src[f]);
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+                __shared__ float dg_wmax[NTHREADS / 64];
+                if (lane == 0) dg_wmax[wave] = m;
+                __syncthreads();
+                m = dg_wmax[0];
+#pragma unroll
+                for (int w = 1; w < NTHREADS / 64; ++w) m = fmaxf(m, dg_wmax[w]);
+                // scale = 2^k, k = 13 - e, e = the largest magnitude's exponent
+                const int eb = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 0xffu);            // 0 (zero / subnormal) .. 255 (inf / NaN)
+                int k = 13 - (eb - 127);
+                k = k < -100 ? -100 : (k > 100 ? 100 : k);                                       // (both factors normal, exact inverses of each other)
+                dg_scale = __builtin_bit_cast(float, (unsigned)(127 + k) << 23);
+                dg_inv = __builtin_bit_cast(float, (unsigned)(127 - k) << 23);
+            }
 #pragma unroll
             for (int u = 0; u < SU; ++u) {
                 const int f = tid + u * NTHREADS;
                 if (f < nitems) {
                     const int sl = (int)(((float)f + 0.5f) * rnq);
-                    split4(smem, sl, f - sl * nq, sv[u], s16, cin8);
+                    split4(smem, sl, f - sl * nq, DG16 ? sv[u] * dg_scale : sv[u], s16, cin8);
                 }
             }
-            const f32x4* src = (const f32x4*)p.x + (long long)Pbase * nq;
             for (int f = tid + SU * NTHREADS; f < nitems; f += NTHREADS) {
                 const int sl = (int)(((float)f + 0.5f) * rnq);
-                split4(smem, sl, f - sl * nq, (f >= flo && f < fhi) ? src[f] : f32x4{0.f, 0.f, 0.f, 0.f}, s16, cin8);
+                const f32x4 v = (f >= flo && f < fhi) ? src[f] : f32x4{0.f, 0.f, 0.f, 0.f};
+                split4(smem, sl, f - sl * nq, DG16 ? v * dg_scale : v, s16, cin8);
             }
         } else if (S2 == 1) {
             stage_s2d();
@@ -688,7 +721,10 @@ __global__ __launch_bounds__(64 * PXT * KS * WCO) void iaf_conv_bf3_kernel(ConvP
 #pragma unroll
         for (int q = 0; q < PPW; ++q)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[q][t] += accx[q][t] * (1.0f / 2048.0f);      // the cross products carry lo' = lo 2^11
+            for (int t = 0; t < NT; ++t) {
+                acc[q][t] += accx[q][t] * (1.0f / 2048.0f);                              // the cross products carry lo' = lo 2^11
+                if constexpr (DG16) acc[q][t] *= dg_inv;                                // (the staged tile was scaled by 2^k)
+            }
     }
     IAF_BSTAMP(3);
     // ================= split-K exchange through LDS + epilogue ========================================================

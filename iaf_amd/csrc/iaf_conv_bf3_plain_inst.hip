@@ -70,3 +70,15 @@ extern "C" conv_fn_t IAF_CAT(iaf_pick_bf3p16_, IAF_PPW, IAF_PXT, IAF_KS, IAF_WCO
     }
     return nullptr;
 }
+
+// ... and its data gradient on two fp16 planes with a tile-local scale (iaf_conv_bf3.hpp DG16): dY pixel-major, the transposed two-plane pack
+extern "C" conv_fn_t IAF_CAT(iaf_pick_bf3p16d_, IAF_PPW, IAF_PXT, IAF_KS, IAF_WCO)(int nt) {
+    switch (nt) {
+        case 2: return iaf_conv_bf3_kernel<2, IAF_PPW, IAF_PXT, IAF_KS, IN_PIXMAJOR, EPI_DGRAD, IAF_WCO, MAXTAPS, 0, 1>;
+        case 4: return iaf_conv_bf3_kernel<4, IAF_PPW, IAF_PXT, IAF_KS, IN_PIXMAJOR, EPI_DGRAD, IAF_WCO, MAXTAPS, 0, 1>;
+#if IAF_WCO < 3
+        case 5: return iaf_conv_bf3_kernel<5, IAF_PPW, IAF_PXT, IAF_KS, IN_PIXMAJOR, EPI_DGRAD, IAF_WCO, MAXTAPS, 0, 1>;
+#endif
+    }
+    return nullptr;
+}

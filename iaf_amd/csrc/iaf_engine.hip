@@ -78,6 +78,7 @@ struct GemmLayer {
     void* wpt3 = nullptr;      // its bf16x3 form (iaf_pack_t3_kernel; even tile counts only): the data gradient on the bf16 matrix cores
     void* wp3 = nullptr;       // bf16x3 pack for iaf_conv_bf3_kernel (c_in % 32 == 0 only)
     void* wp2 = nullptr;       // two-plane fp16 pack of the F16 step kernels (allocated by iaf_stack_set_precision(F16X2))
+    void* wpt2 = nullptr;      // ... of the TRANSPOSED problem (plain convs in training: the data gradient on two fp16 planes, iaf_conv_bf3.hpp DG16)
     int b_nt = 0, b_ppw = 0, b_pxt = 0, b_ks = 0, b_wco = 1;   // bf16x3 launch shape (auto or iaf_stack_set_tuning_bf3)
     bool b_user_tuned = false;
     // result of iaf_stack_autotune for one problem size: which kernel family and which bf16x3 shape won the timing
@@ -311,6 +312,18 @@ extern "C" conv_fn_t iaf_pick_bf3p16_2_1_4_1(int nt);
 extern "C" conv_fn_t iaf_pick_bf3p16_4_1_4_1(int nt);
 extern "C" conv_fn_t iaf_pick_bf3p16_2_1_4_2(int nt);
 extern "C" conv_fn_t iaf_pick_bf3p16_2_1_4_3(int nt);
+extern "C" conv_fn_t iaf_pick_bf3p16d_2_1_4_1(int nt);
+extern "C" conv_fn_t iaf_pick_bf3p16d_4_1_4_1(int nt);
+extern "C" conv_fn_t iaf_pick_bf3p16d_2_1_4_2(int nt);
+extern "C" conv_fn_t iaf_pick_bf3p16d_2_1_4_3(int nt);
+// ... the data gradient on two fp16 planes (iaf_conv_bf3.hpp DG16)
+static conv_fn_t pick_bf3_plain_f16d(int nt, int ppw, int pxt, int ks, int wco) {
+    if (ppw == 2 && pxt == 1 && ks == 4 && wco == 1) return iaf_pick_bf3p16d_2_1_4_1(nt);
+    if (ppw == 4 && pxt == 1 && ks == 4 && wco == 1) return iaf_pick_bf3p16d_4_1_4_1(nt);
+    if (ppw == 2 && pxt == 1 && ks == 4 && wco == 2) return iaf_pick_bf3p16d_2_1_4_2(nt);
+    if (ppw == 2 && pxt == 1 && ks == 4 && wco == 3) return iaf_pick_bf3p16d_2_1_4_3(nt);
+    return nullptr;
+}
 static conv_fn_t pick_bf3_plain_f16(int nt, int ppw, int pxt, int ks, int wco) {
     if (ppw == 2 && pxt == 1 && ks == 4 && wco == 1) return iaf_pick_bf3p16_2_1_4_1(nt);
     if (ppw == 4 && pxt == 1 && ks == 4 && wco == 1) return iaf_pick_bf3p16_4_1_4_1(nt);
@@ -319,8 +332,8 @@ static conv_fn_t pick_bf3_plain_f16(int nt, int ppw, int pxt, int ks, int wco) {
     return nullptr;
 }
 // LDS of a 9-tap bf16x3 launch: the pixel tile with a halo of W + 1 slots on BOTH sides (+ the zero slot)
-static size_t bf3_plain_lds_bytes(int cin, int W, int nt, int ppw, int pxt, int ks, int wco) {
-    const size_t tile = (size_t)(16 * ppw * pxt + 2 * (W + 1) + 1) * (3 * (cin / 8) + 2) * 16;
+static size_t bf3_plain_lds_bytes(int cin, int W, int nt, int ppw, int pxt, int ks, int wco, int npl = 3) {
+    const size_t tile = (size_t)(16 * ppw * pxt + 2 * (W + 1) + 1) * (npl * (cin / 8) + 2) * 16;
     const size_t red = ks > 1 ? (size_t)pxt * wco * ks * ppw * nt * 1024 : 0;
     return tile > red ? tile : red;
 }
@@ -708,7 +721,7 @@ struct PackT3Batch {
         if (!L.wpt || !L.wpt3) return IAF_OK;
         if (a.n == PACKT3_MAX) { int rc = flush(); if (rc) return rc; }
         PackT3Layer& q = a.L[a.n++];
-        q.src = L.wpt; q.dst = L.wpt3; q.ntp = ntp; q.nct = L.nchunk; q.begin = a.total;
+        q.src = L.wpt; q.dst = L.wpt3; q.dst2 = L.wpt2; q.ntp = ntp; q.nct = L.nchunk; q.begin = a.total;
         a.total += (L.ncot / 2) * ntp * L.nchunk * 64;
         return IAF_OK;
     }
@@ -970,7 +983,10 @@ static int raise_lds_cap(const void* fn, size_t lds) {
     static std::unordered_set<const void*> done;
     std::lock_guard<std::mutex> lk(mu);
     if (!done.count(fn)) {
-        HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        // (a kernel with static LDS of its own -- the fp16-plane data gradient's 32 bytes -- may ask for 160 KiB less that much)
+        hipFuncAttributes fa;
+        HIP_TRY(hipFuncGetAttributes(&fa, fn));
+        HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)fa.sharedSizeBytes));
         done.insert(fn);
     }
     return 0;

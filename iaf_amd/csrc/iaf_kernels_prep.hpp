@@ -577,7 +577,7 @@ __global__ __launch_bounds__(256) void iaf_prep_kernel(PrepArgs a, unsigned fast
 // i.e. the fragment of K pair P, lane (kk3, n) is the two 16-byte rows (kk = 2 (kk3 & 1), +1) of chunk 2 P + (kk3 >> 1):
 // an elementwise re-layout + three-way split, one thread per (fragment, lane).  Up to PACKT3_MAX layers per launch.
 #define PACKT3_MAX 16
-struct PackT3Layer { const float* src; void* dst; int ntp, nct, begin; };
+struct PackT3Layer { const float* src; void* dst; int ntp, nct, begin; void* dst2; };   // dst2 (or NULL): the same fragments as two fp16 planes (hi, lo 2^11)
 struct PackT3Args { PackT3Layer L[PACKT3_MAX]; int n, total; };
 
 __global__ __launch_bounds__(256) void iaf_pack_t3_kernel(PackT3Args a) {
@@ -610,4 +610,18 @@ __global__ __launch_bounds__(256) void iaf_pack_t3_kernel(PackT3Args a) {
     }
     pu32x4* q = (pu32x4*)L.dst + (((size_t)(P * L.ntp + t) * L.nct + cit) * 3) * 64 + lane3;
     q[0] = ph; q[64] = pm; q[128] = pl;
+    if (L.dst2) {       // the data gradient on two fp16 planes (iaf_conv_bf3.hpp DG16): weights' magnitudes were checked by the forward pack's prep
+        typedef _Float16 ph16x2 __attribute__((ext_vector_type(2)));
+        pu32x4 fh, fl;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const pf32x2 x = {w[2 * k], w[2 * k + 1]};
+            const ph16x2 hb = __builtin_convertvector(x, ph16x2);
+            const pf32x2 r = (x - __builtin_convertvector(hb, pf32x2)) * 2048.0f;
+            const ph16x2 lb = __builtin_convertvector(r, ph16x2);
+            fh[k] = __builtin_bit_cast(unsigned, hb); fl[k] = __builtin_bit_cast(unsigned, lb);
+        }
+        pu32x4* q2 = (pu32x4*)L.dst2 + (((size_t)(P * L.ntp + t) * L.nct + cit) * 2) * 64 + lane3;
+        q2[0] = fh; q2[64] = fl;
+    }
 }

@@ -438,7 +438,7 @@ def test_wnconv2d_data_gradient_on_the_bf16_matrix_cores(amd, shape):
     V, g, b = dev(p["V"]), dev(p["g"]), dev(p["b"])
     res = dev(rng.standard_normal(x.shape))
     got = {}
-    for prec in ("bf16x3", "f32"):
+    for prec in ("bf16x3", "f32", "f16x2"):
         conv = amd.WNConv2d(n_in, n_out)
         conv.set_precision(prec)
         conv.set_training(True)
@@ -455,7 +455,7 @@ def test_wnconv2d_data_gradient_on_the_bf16_matrix_cores(amd, shape):
         (y * G._t(f32(dy[b0:b0 + chunk]))).sum().backward()
         gx.append(xs.grad.numpy())
     gx = np.concatenate(gx)
-    for prec in ("bf16x3", "f32"):
+    for prec in ("bf16x3", "f32", "f16x2"):
         assert _relerr(got[prec][0], gx) < 1e-4
         assert _relerr(got[prec][1], pt["V"].grad.numpy()) < 1e-4
         assert _relerr(got[prec][2], pt["g"].grad.numpy()) < 1e-4
@@ -463,6 +463,48 @@ def test_wnconv2d_data_gradient_on_the_bf16_matrix_cores(amd, shape):
     e3, e32 = _relerr(got["bf16x3"][0], gx), _relerr(got["f32"][0], gx)
     print("dX rel err vs fp64 autograd: bf16x3 data gradient %.3g, exact fp32 %.3g" % (e3, e32))
     assert e3 <= 2.0 * e32 + 1e-6
+    # round 6: under "f16x2" the data gradient runs on two fp16 planes with a power-of-two scale per staged tile (iaf_conv_bf3.hpp DG16) --
+    # also for K = n_out = 448, whose two-plane tile fits the LDS
+    e16 = _relerr(got["f16x2"][0], gx)
+    print("   two fp16 planes: %.3g" % e16)
+    assert e16 <= 2.0 * e32 + 1e-6
+
+
+@pytest.mark.parametrize("dy_scale", [1e-12, 1.0, 1e10, "mixed"], ids=lambda v: "dy_x%s" % v)
+def test_fp16_plane_data_gradient_has_no_exponent_range_of_its_own(amd, dy_scale):
+    """a gradient tensor's magnitudes have nothing to do with fp16's range: the workgroup scales the tile it stages by a power of two taken
+    from the tile's own largest element and its sums back -- gradients of 1e-12 and of 1e10 come out with the relative error of the unit case, a batch whose
+    images differ by up to 1e6 within 3e-5 of each IMAGE's largest gradient, and nothing raises a range word"""
+    from oracle import iaf_grad_oracle as G
+    B, n_in, n_out, H, W = 16, 160, 160, 16, 16
+    rng = np.random.RandomState(75)
+    p = gi.conv_params(rng, n_in, n_out)
+    x, dy = rng.standard_normal((B, n_in, H, W)), rng.standard_normal((B, n_out, H, W))
+    if dy_scale == "mixed":
+        dy *= (10.0 ** rng.randint(-3, 4, size=(B, 1, 1, 1)))
+    else:
+        dy *= dy_scale
+    V, g, b = dev(p["V"]), dev(p["g"]), dev(p["b"])
+    conv = amd.WNConv2d(n_in, n_out)
+    conv.set_precision("f16x2")
+    conv.set_training(True)
+    conv.prepare(V, g, b)
+    (dx,), dV, dg, db = conv.backward(dev(x), [dev(dy)], V, g, elu_input=True)
+    pt = {k: G._t(f32(v), True) for k, v in p.items()}
+    worst = 0.0
+    for b0 in range(0, B, 4):
+        xs = G._t(f32(x[b0:b0 + 4]), True)
+        y = G.conv2d(torch.nn.functional.elu(xs), pt["V"], pt["g"], pt["b"])
+        (y * G._t(f32(dy[b0:b0 + 4]))).sum().backward()
+        gx = xs.grad.numpy()
+        for i in range(4):
+            worst = max(worst, _relerr(host(dx)[b0 + i], gx[i]))
+    print("dX rel err per image vs fp64 autograd: %.3g" % worst)
+    # (a tile's halo reaches 17 pixels into the neighbouring image: where that image's gradients are 1e6 larger they set the tile's scale)
+    assert worst < (3e-5 if dy_scale == "mixed" else 3e-6)
+    assert conv.range_errors() == 0
+
+
 
 
 @pytest.mark.parametrize("scale", [(1.0, 1.0), (3e4, 1e-5), (1e-6, 2e3)], ids=["unit", "x3e4_dy1e-5", "x1e-6_dy2e3"])

@@ -9,6 +9,9 @@ print("%.4f ms/step  %.0f %s  dominant %.2f us frac %.3f  step frac %s" % (d["ms
                                                                           r.get("step", {}).get("frac")))
 print(d["config"].get("kernels_chosen"))
 for k in r.get("kernels", []):
-    print("  ", k["latent"], k["layer"][:70], k["kernel"], "%.2f us %.1f TF" % (k["us"], k["live_tflops"]))
+    if "latent" in k:
+        print("  ", k["latent"], k["layer"][:70], k["kernel"], "%.2f us %.1f TF" % (k["us"], k["live_tflops"]))
+    else:               # (training lines: the top launches of the committed kernel trace)
+        print("  ", k.get("kernel", "")[:90], "x%s" % k.get("launches_per_step"), "%.1f us" % k.get("avg_us", 0))
 for x in r.get("extended_unit", []):
     print("   posterior block", x["latent"], "%.1f us" % x["us"])
