@@ -192,9 +192,10 @@ __global__ __launch_bounds__(64 * PXT * KS * WCO) void iaf_conv_bf3_kernel(ConvP
     // pixels) and the channel quads q = wave, wave + NWV, ... of it: the index arithmetic (a division by reciprocal, the source
     // select of the concat) is per slot, a quad costs one pointer add; all loads of a pass are issued before the arithmetic, and the
     // first pass's loads are issued HERE, in front of the weight ring's (vmcnt counts in order: a wait for a staging load issued
-    // behind the ring loads would be a wait for the ring as well).  Measured (tools/conv_stamps.py,
-    // profiles/r04/experiments/plain_conv_stamps.txt): none of this moves the launch time -- two workgroups share a CU at NT = 2 and
-    // what bounds the launch is the weight stream into the CU (32 pixels per fetched fragment), not the staging.
+    // behind the ring loads would be a wait for the ring as well).  Round 4 measured (tools/conv_stamps.py,
+    // profiles/r04/experiments/plain_conv_stamps.txt) that none of this moved the launch time of the bf16x3 kernels -- two workgroups shared a
+    // CU at NT = 2 and the weight stream bound the launch; on the fp16 planes the searched shapes are 512-thread workgroups, one per CU, and the
+    // staging is exposed (round 6: tail_fold below, profiles/r06/experiments/ab_plain_conv_tail_slots_same_box.txt).
     constexpr int NWV = NTHREADS / 64;
     constexpr int SQ = 10;                                         // quads in flight per thread (c_in <= 40 NWV: every c_in the packs allow at 8 waves)
     f32x4 nb_v[SQ];

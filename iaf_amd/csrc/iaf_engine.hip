@@ -892,7 +892,7 @@ extern "C" int iaf_prep_batch_run(iaf_prep_batch_t* b, const float* const* V, co
     const void* d_layers = nullptr;
     { int rc = desc_upload(&b->tab, b->h_layers, changed, st, &d_layers); if (rc) return rc; }
     // (IAF_PREP_DBG, dev knob: bit 0 = tiles in blockIdx order instead of paired per XCD, bit 1 = round 5's tile function; same box, 20 stacks,
-    //  fp16 packs: 13.4 us with both bits, 12.1 us with neither -- gpurun_out/r06/prep_time_ab.txt)
+    //  fp16 packs: 13.4 us with both bits, 12.1 us with neither -- profiles/r06/experiments/prep_time_ab_same_box.txt)
     static const int prep_dbg = getenv("IAF_PREP_DBG") ? atoi(getenv("IAF_PREP_DBG")) : 0;
     const int xcdpair = (prep_dbg & 1) ? 0 : 1;
     const unsigned ff = prep_fast_floats(b->h_layers, b->nlayers_total);

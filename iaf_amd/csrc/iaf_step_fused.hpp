@@ -323,7 +323,7 @@ __attribute__((amdgpu_waves_per_eu(HLP ? 2 : 1, HLP ? 2 : 1))) void iaf_step_fus
 #define IAF_EXP_HL0 1
 #endif
     // (not on the fp16 planes: there the compute waves' first K loop is half as long and the helper's unit sits on the critical path to
-    //  the first epilogue's barrier -- 8x8 step 13.25 -> 12.87 us without it, 16x16 equal, gpurun_out/r06/ab_helper_knobs.txt)
+    //  the first epilogue's barrier -- 8x8 step 13.25 -> 12.87 us without it, 16x16 equal, profiles/r06/experiments/ab_helper_knobs_f16_same_box.txt)
     constexpr bool HL0 = IAF_EXP_HL0 && HLEFT && !F16;
     constexpr int NTW0 = HL0 ? NFULL : NTWH;
     int htile[NTWH];
