@@ -510,15 +510,18 @@ int iaf_conv3x3_set_tuning(iaf_conv3x3_t* c, int nt, int pxt, int wco, int ks);
  * cycle stamps (start, weight ring primed, -, tile staged, K loop done, partial sums exchanged, stores issued) -- a launch whose grid
  * does not fit `bytes` leaves it alone; NULL switches it off */
 int iaf_conv3x3_set_debug(iaf_conv3x3_t* c, void* buf, size_t bytes);
-/* arithmetic of the forward conv, as iaf_stack_set_precision: IAF_PRECISION_BF16X3 (default; plain convs with c_in % 32 == 0
- * from 4096 pixels on, or as iaf_conv3x3_autotune measured) or IAF_PRECISION_F32 (the exact-fp32 MFMA kernel always; masked
- * single convs, deconvs and the backward kernels run it regardless).  iaf_conv3x3_runs_bf16x3: 1 if a forward call at this
- * size would run the bf16x3 kernel. */
+/* arithmetic of the conv, as iaf_stack_set_precision: IAF_PRECISION_BF16X3 (plain convs with c_in % 32 == 0 from 4096 pixels on, or as
+ * iaf_conv3x3_autotune measured, run the split-product kernels on three bf16 planes) or IAF_PRECISION_F32 (the exact-fp32 MFMA kernel
+ * always; masked single convs run it regardless).  iaf_conv3x3_runs_bf16x3: 1 if a forward call at this size would run a split-product
+ * kernel (bf16 or fp16 planes). */
 int iaf_conv3x3_set_precision(iaf_conv3x3_t* c, int precision);
-/* IAF_PRECISION_F16X2 for a plain conv (the default where c_in % 32 == 0): its stride-1 forward launches split the operands into two fp16
- * planes as the one-launch step does (iaf_stack_set_precision); the strided forms, the data and weight gradients stay on bf16 planes.
- * The same range protocol: an operand beyond 65504 -> inf / NaN outputs, the NEXT iaf_conv3x3_forward returns IAF_ERR_RANGE once and the
- * conv runs bf16x3 from then on; *errors = its range word (synchronises). */
+/* IAF_PRECISION_F16X2 for a plain conv (THE DEFAULT where c_in % 32 == 0; from 2048 pixels on): its stride-1 forward launches split the
+ * operands into two fp16 planes as the one-launch step does (iaf_stack_set_precision); the strided forms and the weight gradient stay on
+ * bf16 planes.  Range protocol of the forward: an operand beyond 65504 -> inf / NaN outputs, the NEXT iaf_conv3x3_forward returns
+ * IAF_ERR_RANGE once and the conv runs bf16x3 from then on; *errors = its range word (synchronises).
+ * The DATA gradient of such a conv (iaf_conv3x3_backward) runs on two fp16 planes as well, with no range of its own: every workgroup
+ * scales the dY tile it stages by the power of two that puts the tile's largest magnitude into [2^13, 2^14) and its sums by the inverse
+ * -- gradients of any fp32 magnitude, errors relative to the tile's largest element (IAF_DGRAD_F16=0 in the environment: bf16 planes). */
 int iaf_conv3x3_range_errors(const iaf_conv3x3_t* c, unsigned* errors);
 /* Which packs the prep launches of a PLAIN conv keep up to date (IAF_PACK_* as iaf_stack_set_packs; default: all three, 14 bytes written
  * per weight).  A conv of a model runs at one size, i.e. reads one pack: the two-plane fp16 one (iaf_conv3x3_runs_f16x2), else the

@@ -4,9 +4,11 @@ VERDICT r05 "next" #1 set the gate under which this arithmetic may carry the hea
 unmodified (it builds its "one-launch" stack with the DEFAULT precision, which is f16x2 where the kernels are compiled -- asserted
 here) AND, at every case of tests/test_hip_baseline_configs.py the kernels cover, the largest error against the fp64 oracle is at most
 1.5x that of the exact-fp32 MFMA kernels (`--precision f32`).  This file holds the second half, and the behaviour at the edge fp16 has
-and fp32 does not: operands beyond 65504.
+and fp32 does not: operands beyond 65504.  Further down: the same arithmetic in the plain convs around the step (forward: the same gate and
+range protocol; one weight pack per conv) and the whole-row prep of stacks that keep only split packs.  (The plain convs' data gradient on
+two fp16 planes, which has no exponent range of its own: tests/test_hip_layer.py.)
 
-Reference operator: tf_utils/layers.py:56-64,158-166; tf_train.py:56-85."""
+Reference operator: tf_utils/layers.py:31-64,158-166; tf_train.py:29-95."""
 import numpy as np
 import pytest
 import torch
