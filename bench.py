@@ -1565,7 +1565,9 @@ def main():
                                "us_method": ("in situ: the level's %d launches (every layer its own packs and inputs) replayed as a graph "
                                              "between one event pair, %d launches, gaps included" % (len([x for x in layers if x["H"] == H]), insitu_n[H]))
                                             if H in insitu_ms else "relaunched layer",
-                               "us_relaunched_hot": 1e3 * hot_ms})
+                               "us_relaunched_hot": 1e3 * hot_ms,
+                               # MFMA work issued per live FLOP (half-filled 16-pixel tiles and recomputed halo rows at 8-pixel rows)
+                               "issued_over_live": _issued_over_live(args, L["one"], H)})
             for gl in range(args.depth_ar + 1) if not L["one"] else ():
                 cout = args.n_h if gl < args.depth_ar else 2 * args.n_z
                 name = "masked conv %d->%d%s" % (cin, cout, " (mean,logsd pair + affine/log-det epilogue)" if gl == args.depth_ar else "")
